@@ -1,0 +1,239 @@
+/*
+ * h2r.h -- C ABI of the MI355X-native halo2-rsa witness engine (libh2r.so).
+ *
+ * Drop-in boundary for ONE path of SoraSuegami/halo2-rsa: the witness ("assign_*") values of
+ *   RSAChip::modpow_public_key            reference src/chip.rs:99-114
+ *     -> BigIntChip::pow_mod_fixed_exp    reference src/big_integer/chip.rs:710-742
+ *     -> BigIntChip::pow_mod              reference src/big_integer/chip.rs:664-696
+ *     -> BigIntChip::mul_mod / square_mod reference src/big_integer/chip.rs:542-629 / 642-649
+ *        (mul :386-419, is_equal_muled :822-895, div_mod_main_gate :1323-1349)
+ *   plus the RangeChip sub-limb decomposition of every range-checked value on that path
+ *   (call sites big_integer/chip.rs:74, 590, 598, 880-885) and its lookup multiplicities.
+ *
+ * The reference has no FFI; it is a Rust crate whose API is the two traits
+ * BigIntInstructions<F> (src/big_integer/instructions.rs:7-260) and RSAInstructions<F>
+ * (src/instructions.rs:8-39).  Each export below is the batch form of one trait method: a Rust
+ * `impl BigIntInstructions<F> for GpuBigIntChip<F>` calls the export, then walks the returned
+ * trace with h2r_trace_flatten()/the h2r_layout offsets and assigns the values to cells
+ * (INTEGRATION.md shows the `extern "C"` block).
+ *
+ * Conventions
+ *  - Integers are little-endian limb vectors, limb 0 least significant (big_integer/mod.rs:348-359),
+ *    `num_limbs` limbs of `limb_width` bits: uint64_t limbs for limb_width 64, uint32_t for 32.
+ *    Batches are element-major: element e occupies limbs [e*num_limbs, (e+1)*num_limbs).
+ *  - Every data pointer is a DEVICE (HBM) pointer valid on the ctx's device.  `stream` is a
+ *    hipStream_t (NULL = the null stream).  Calls only enqueue work; they never synchronise the
+ *    device.  Calls on distinct streams may run concurrently; a ctx is immutable after creation.
+ *  - The library owns nothing but the ctx.  `workspace` is caller-provided scratch of at least
+ *    h2r_workspace_bytes(); pass NULL to let the call use stream-ordered hipMallocAsync/hipFreeAsync.
+ *  - Every call returns an int32_t status and never throws or aborts.  Where the reference panics
+ *    on a per-value condition (division by a zero modulus big_integer/chip.rs:566; quotient not
+ *    fitting num_limbs limbs :583-584) the element's byte in `status` is set instead and that
+ *    element's trace is unspecified; other elements are unaffected.
+ */
+#ifndef H2R_H
+#define H2R_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define H2R_VERSION 1
+
+/* ---- status codes (function return values and per-element status bytes) ---------------------- */
+enum {
+    H2R_OK = 0,
+    H2R_E_SHAPE = 1,           /* reference asserts big_integer/chip.rs:555, 1175, 1266 */
+    H2R_E_ZERO_MODULUS = 2,    /* reference divides by zero, big_integer/chip.rs:566 */
+    H2R_E_NOT_REDUCED = 3,     /* a*b/n does not fit num_limbs limbs, big_integer/chip.rs:583-584 */
+    H2R_E_FIELD_TOO_SMALL = 4, /* reference assert big_integer/chip.rs:1178 */
+    H2R_E_HIP = 5,             /* a HIP runtime call failed (h2r_last_hip_error) */
+    H2R_E_UNSUPPORTED = 6,     /* (limb_width, num_limbs) has no compiled kernel */
+    H2R_E_NULL = 7,            /* required pointer is NULL */
+    H2R_E_NOT_IN_FIELD = 8     /* x >= n: assert_in_field fails, src/chip.rs:106 */
+};
+
+/* ---- fields (only F::NUM_BITS and the encoding of negative a_b depend on it) ------------------ */
+enum {
+    H2R_FIELD_BN254_FR = 0, /* halo2curves bn256::Fr (examples/rsa_example.rs:148, benches/bench.rs:35) */
+    H2R_FIELD_BN254_FQ = 1, /* bn256::Fq   (tests: big_integer/chip.rs:1461) */
+    H2R_FIELD_PASTA_FP = 2, /* pasta::Fp   (big_integer/chip.rs:1462) */
+    H2R_FIELD_PASTA_FQ = 3  /* pasta::Fq   (big_integer/chip.rs:1463) */
+};
+
+/* flags for the batch calls */
+#define H2R_F_SHARED_MODULUS 1u /* `n` holds ONE modulus used by every element */
+
+typedef struct h2r_ctx h2r_ctx;
+typedef void *h2r_stream_t; /* hipStream_t */
+
+/* BigIntChip::new(config, limb_width, bits_len) -- big_integer/chip.rs:1174-1185 */
+typedef struct h2r_params {
+    uint32_t limb_width; /* 64 (RSAChip::LIMB_WIDTH, src/chip.rs:203) or 32 */
+    uint32_t bits_len;   /* bits_len % limb_width == 0; num_limbs = bits_len / limb_width */
+    uint32_t field;      /* H2R_FIELD_* */
+    int32_t device;      /* HIP device ordinal */
+} h2r_params;
+
+/* ---- trace layout ------------------------------------------------------------------------------
+ * One mul_mod produces one RECORD: a struct of planes.  Plane p starts at byte plane_off[p] of the
+ * record, has plane_count[p] entries of plane_elem[p] bytes (0 = plane absent for this config).
+ * Values wider than 16 bytes are split into a 16-byte LO plane and an 8-byte HI plane.
+ * C = 2*num_limbs-1 is the number of un-carried product columns.  Index maps:
+ *   H2R_PL_Q, _R           [k]            quotient / remainder limb k          (chip.rs:570-582)
+ *   H2R_PL_Q_SUB, _R_SUB   [k][t]         sub-limb t of limb k, one byte each  (chip.rs:590, 598)
+ *   H2R_PL_AB_*, _QN_*     [j][i % L]     accumulator of column i=j+k right after adding
+ *                                         a[j]*b[k] (resp. q[j]*n[k]); the reference's order is
+ *                                         i ascending, then j ascending        (chip.rs:400-412)
+ *   H2R_PL_EQB_*           [i], i < L     qn[i] + r[i]                         (chip.rs:617)
+ *   per-column planes      [i], i < C     is_equal_muled step i                (chip.rs:857-893)
+ *   H2R_PL_CARRY_DUP/_SUB  [i], i < C-1   the range-assigned carry and its sub-limbs (:879-885)
+ *   H2R_PL_FLAGS           [i][4]         cs_acc_eq, eq_bit, range_eq|final_carry_eq, eq_bit
+ */
+enum {
+    H2R_PL_Q = 0, H2R_PL_R, H2R_PL_Q_SUB, H2R_PL_R_SUB,
+    H2R_PL_AB_LO, H2R_PL_AB_HI, H2R_PL_QN_LO, H2R_PL_QN_HI,
+    H2R_PL_EQB_LO, H2R_PL_EQB_HI,
+    H2R_PL_AMB_LO, H2R_PL_AMB_HI,   /* a_b = a[i]-b[i], two's complement (chip.rs:859) */
+    H2R_PL_SUM_LO, H2R_PL_SUM_HI,   /* a_b + carry[i] + word_max (chip.rs:860-861) */
+    H2R_PL_CARRY,                   /* carry[i+1] (div_mod q, chip.rs:864) */
+    H2R_PL_CMOD,                    /* c = sum mod 2^w (div_mod r) */
+    H2R_PL_NQ1_LO, H2R_PL_NQ1_HI,   /* 2^w * carry[i+1] (chip.rs:1345) */
+    H2R_PL_AMNQ1,                   /* sum - nq (chip.rs:1346) */
+    H2R_PL_ACCX_LO, H2R_PL_ACCX_HI, /* accumulated_extra + word_max (chip.rs:869-870) */
+    H2R_PL_QACC, H2R_PL_MODACC,     /* div_mod of it (chip.rs:871) */
+    H2R_PL_NQ2_LO, H2R_PL_NQ2_HI, H2R_PL_AMNQ2,
+    H2R_PL_FLAGS, H2R_PL_CARRY_DUP, H2R_PL_CARRY_SUB,
+    H2R_PL_COUNT
+};
+
+typedef struct h2r_layout {
+    uint32_t limb_width, num_limbs, num_cols;
+    uint32_t limb_bytes, wide_bytes, carry_bytes; /* flat-stream widths: LIMB, WIDE, CARRY */
+    uint32_t limb_sub_bits, limb_nsub;            /* RangeChip::assign(v, limb_width/8, limb_width) */
+    uint32_t carry_bits, carry_sub_bits, carry_nsub, carry_sub_stride;
+    uint32_t word_max_bits;
+    uint32_t reserved0;
+    uint64_t record_stride;  /* bytes from one mul_mod record to the next */
+    uint64_t stream_bytes;   /* flat-stream (algorithmic) bytes of one mul_mod */
+    uint64_t plane_off[H2R_PL_COUNT];
+    uint32_t plane_elem[H2R_PL_COUNT];
+    uint32_t plane_count[H2R_PL_COUNT];
+} h2r_layout;
+
+/* Layout of one element's pow trace: `num_mul_mods` records back to back, then extras.
+ *   fixed exponent (pow_mod_fixed_exp): record order = the reference's call order: for each
+ *     exponent bit (LSB first) square_mod, then mul_mod if the bit is set (chip.rs:731-740).
+ *   variable exponent (pow_mod): per exponent bit mul_mod(acc, squared) then square_mod
+ *     (chip.rs:684-694); e_bits[] (one byte per bit) and selected[bit][limb] are the extra planes. */
+typedef struct h2r_pow_layout {
+    uint32_t num_mul_mods;
+    uint32_t num_exp_bits;
+    uint64_t elem_stride;     /* bytes from one element's trace to the next */
+    uint64_t off_records;     /* record t at off_records + t*record_stride */
+    uint64_t off_result;      /* num_limbs limbs: x^e mod n */
+    uint64_t off_e_bits;      /* variable exponent only, else UINT64_MAX */
+    uint64_t off_selected;    /* variable exponent only: [bit][limb] */
+    uint64_t selected_stride; /* bytes between consecutive bits' selected[] */
+    uint64_t stream_bytes;    /* flat-stream bytes of one element */
+} h2r_pow_layout;
+
+/* ---- context ---------------------------------------------------------------------------------- */
+
+/* BigIntChip::new (big_integer/chip.rs:1174-1185).  Returns H2R_E_SHAPE where the reference
+ * asserts bits_len % limb_width == 0 (:1175), H2R_E_FIELD_TOO_SMALL for (:1178), and
+ * H2R_E_UNSUPPORTED when no kernel is compiled for the shape. */
+int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out);
+void h2r_ctx_destroy(h2r_ctx *ctx);
+
+/* BigIntChip::compute_range_lens (big_integer/chip.rs:1220-1249).  Host-only, no ctx needed. */
+int32_t h2r_compute_range_lens(uint32_t limb_width, uint32_t num_limbs,
+                               uint32_t composition_bit_lens[3], uint32_t overflow_bit_lens[3]);
+/* RSAChip::compute_range_lens (src/chip.rs:249-254): appends 32/8 to the composition lens. */
+int32_t h2r_rsa_compute_range_lens(uint32_t num_limbs, uint32_t composition_bit_lens[4],
+                                   uint32_t overflow_bit_lens[3]);
+
+int32_t h2r_trace_layout(const h2r_ctx *ctx, h2r_layout *out);
+int32_t h2r_pow_fixed_layout(const h2r_ctx *ctx, const uint8_t *e_le_bytes, size_t e_len,
+                             h2r_pow_layout *out);
+int32_t h2r_pow_var_layout(const h2r_ctx *ctx, uint32_t e_num_limbs, uint32_t exp_limb_bits,
+                           h2r_pow_layout *out);
+
+/* Scratch needed by one batch call that runs `num_mul_mods` mul_mods per element. */
+uint64_t h2r_workspace_bytes(const h2r_ctx *ctx, uint64_t batch, uint32_t num_mul_mods);
+
+/* ---- the hot path ------------------------------------------------------------------------------ */
+
+/* BigIntInstructions::mul_mod (big_integer/chip.rs:542-629).  trace: batch records
+ * (record_stride apart).  r_out (nullable): batch*num_limbs limbs of a*b mod n. */
+int32_t h2r_mul_mod_batch(const h2r_ctx *ctx, const void *a, const void *b, const void *n,
+                          uint64_t batch, uint32_t flags, void *trace, void *r_out,
+                          uint8_t *status, void *workspace, h2r_stream_t stream);
+
+/* BigIntInstructions::square_mod (big_integer/chip.rs:642-649) = mul_mod(a, a, n). */
+int32_t h2r_square_mod_batch(const h2r_ctx *ctx, const void *a, const void *n, uint64_t batch,
+                             uint32_t flags, void *trace, void *r_out, uint8_t *status,
+                             void *workspace, h2r_stream_t stream);
+
+/* BigIntInstructions::pow_mod_fixed_exp (big_integer/chip.rs:710-742).  `e` is a HOST buffer:
+ * e.to_bytes_le() (chip.rs:719-720), the same exponent for every element (RSAPubE::Fix).
+ * trace: batch elements laid out per h2r_pow_fixed_layout().  out (nullable): x^e mod n. */
+int32_t h2r_pow_mod_fixed_exp_batch(const h2r_ctx *ctx, const void *x, const void *n,
+                                    const uint8_t *e_le_bytes, size_t e_len, uint64_t batch,
+                                    uint32_t flags, void *trace, void *out, uint8_t *status,
+                                    void *workspace, h2r_stream_t stream);
+
+/* BigIntInstructions::pow_mod (big_integer/chip.rs:664-696): per-element variable exponent given
+ * as e_num_limbs limbs (same limb type as x) of which the low exp_limb_bits bits are used
+ * (main_gate.to_bits, chip.rs:677). */
+int32_t h2r_pow_mod_batch(const h2r_ctx *ctx, const void *x, const void *e_limbs,
+                          uint32_t e_num_limbs, uint32_t exp_limb_bits, const void *n,
+                          uint64_t batch, uint32_t flags, void *trace, void *out, uint8_t *status,
+                          void *workspace, h2r_stream_t stream);
+
+/* RSAInstructions::modpow_public_key with RSAPubE::Fix (src/chip.rs:99-114): per element sets
+ * H2R_E_NOT_IN_FIELD where bigint_chip.assert_in_field(x, n) (:106) fails, otherwise runs
+ * pow_mod_fixed_exp.  Same trace layout as h2r_pow_mod_fixed_exp_batch. */
+int32_t h2r_modpow_public_key_batch(const h2r_ctx *ctx, const void *x, const void *n,
+                                    const uint8_t *e_le_bytes, size_t e_len, uint64_t batch,
+                                    uint32_t flags, void *trace, void *out, uint8_t *status,
+                                    void *workspace, h2r_stream_t stream);
+
+/* ---- the lookup range-check batch --------------------------------------------------------------
+ * RangeChip::assign(value, sublimb_bits, bit_len) decomposition of `count` values of `value_bytes`
+ * bytes each (8 or 16) into ceil(bit_len/sublimb_bits) one-byte sub-limbs (stride sub_stride),
+ * plus (hist nullable) the multiplicity of every (tag, value) lookup-table row:
+ * hist[0 .. 2^sublimb_bits) for the composition table, then 2^(bit_len % sublimb_bits) entries
+ * for the overflow table if any (uint32 counters, ADDED to). */
+int32_t h2r_range_decompose_batch(const h2r_ctx *ctx, const void *values, uint32_t value_bytes,
+                                  uint64_t count, uint32_t bit_len, uint32_t sublimb_bits,
+                                  uint8_t *sublimbs_out, uint32_t sub_stride, uint32_t *hist,
+                                  h2r_stream_t stream);
+
+/* Multiplicities of every lookup-table row touched by the range checks of `num_records` mul_mod
+ * records (q, r limbs and carries): hist_out[elem][h2r_hist_len()] uint32, where `records_per_elem`
+ * consecutive records belong to one element (= one circuit).  Row order: the composition table of
+ * limb_sub_bits, then of carry_sub_bits if different, then the carry overflow table if any. */
+uint32_t h2r_hist_len(const h2r_ctx *ctx);
+int32_t h2r_trace_lookup_hist(const h2r_ctx *ctx, const void *trace, uint64_t first_record_off,
+                              uint64_t elem_stride, uint64_t num_elems, uint32_t records_per_elem,
+                              uint32_t *hist_out, h2r_stream_t stream);
+
+/* ---- host-side helpers (no device work) --------------------------------------------------------
+ * h2r_trace_flatten: walk ONE record (host copy, record_stride bytes) in the reference's assignment
+ * order and write its flat op-trace stream (layout.stream_bytes bytes; widths in h2r_layout).
+ * This is the order in which a layouter shim assigns the values to cells. */
+int32_t h2r_trace_flatten(const h2r_ctx *ctx, const void *record_host, void *stream_out);
+int32_t h2r_pow_trace_flatten(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *elem_host,
+                              void *stream_out);
+
+const char *h2r_status_str(int32_t status);
+const char *h2r_last_hip_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* H2R_H */

@@ -1,0 +1,539 @@
+"""TEST INFRASTRUCTURE ONLY -- independent big-int restatement of the halo2-rsa hot path.
+
+This file is the *second*, independent checker beside ``oracle/h2r_oracle.c``: it
+restates the reference's control flow with Python's arbitrary-precision ints so
+that the C oracle (schoolbook + Knuth-D on 64-bit limbs) can be cross-checked
+against something that shares no arithmetic code with it.  It is used by
+``tests/`` and by ``tests/golden/make_golden.py`` to mint the committed fixtures.
+Nothing in the product path (``halo2_rsa_amd/``) may import it.
+
+Every function cites the reference file:line it follows (paths relative to
+``/root/reference``; that tree is NOT read at run time).
+
+Op-trace stream ("flat stream")
+-------------------------------
+The oracle emits, in the exact order in which the reference issues its
+``assign``/``main_gate`` calls, every *witness value* of the path as a
+little-endian fixed-width integer (constants bound by ``assign_constant`` are
+not emitted).  Widths (bytes) depend only on ``(limb_width w, num_limbs L)``:
+
+=========  ==========================================  (w=64,L=32)  (w=32,L=128)
+LIMB       w/8                                          8            4
+WIDE       8*ceil((bits(word_max)+2)/64)                24           16
+CARRY      8*ceil(carry_bits/64)                        16           8
+sub-limb   1                                            1            1
+flag/bit   1                                            1            1
+=========  ==========================================
+
+``a_b = a[i]-b[i]`` (big_integer/chip.rs:859) is a *field* subtraction in the
+reference; the stream stores it as a WIDE two's-complement signed integer (the
+canonical field element is ``v mod p``).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Sequence, Tuple
+
+NUM_LOOKUP_LIMBS = 8  # big_integer/chip.rs:1163
+
+
+def bits_size(v: int) -> int:
+    """big_integer/chip.rs:1352-1354 (BigUint::bits)."""
+    return v.bit_length()
+
+
+def sublimb_bit_len(bit_len_limb: int) -> int:
+    """big_integer/chip.rs:1357-1365."""
+    val = bit_len_limb // NUM_LOOKUP_LIMBS
+    return 1 if val == 0 else val
+
+
+def compute_mul_word_max(limb_width: int, min_n: int) -> int:
+    """big_integer/chip.rs:1368-1372."""
+    out_base = 1 << limb_width
+    return min_n * (out_base - 1) * (out_base - 1) + (out_base - 1)
+
+
+def compute_range_lens(limb_width: int, num_limbs: int) -> Tuple[List[int], List[int]]:
+    """big_integer/chip.rs:1220-1249."""
+    out_comp_bit_len = limb_width // NUM_LOOKUP_LIMBS
+    out_overflow_bit_len = limb_width % out_comp_bit_len
+    out_base = 1 << limb_width
+    fresh_word_max_width = (2 * out_base).bit_length()
+    fresh_carry_bits = fresh_word_max_width - limb_width
+    fresh_carry_comp_bit_len = sublimb_bit_len(fresh_carry_bits)
+    fresh_carry_overflow_bit_len = fresh_carry_bits % fresh_carry_comp_bit_len
+    mul_word_max = num_limbs * (out_base - 1) * (out_base - 1) + (out_base - 1)
+    mul_word_max_width = (mul_word_max * 2).bit_length()
+    mul_carry_bits = mul_word_max_width - limb_width
+    mul_carry_comp_bit_len = sublimb_bit_len(mul_carry_bits)
+    mul_carry_overflow_bit_len = mul_carry_bits % mul_carry_comp_bit_len
+    return (
+        [out_comp_bit_len, fresh_carry_comp_bit_len, mul_carry_comp_bit_len],
+        [out_overflow_bit_len, fresh_carry_overflow_bit_len, mul_carry_overflow_bit_len],
+    )
+
+
+def rsa_compute_range_lens(num_limbs: int) -> Tuple[List[int], List[int]]:
+    """src/chip.rs:249-254 (LIMB_WIDTH = 64, src/chip.rs:203)."""
+    comp, over = compute_range_lens(64, num_limbs)
+    comp.append(32 // NUM_LOOKUP_LIMBS)
+    return comp, over
+
+
+def refresh_aux_increased_limbs(limb_width: int, num_limbs_l: int, num_limbs_r: int) -> List[int]:
+    """big_integer/mod.rs:428-482 (RefreshAux::new) -> increased_limbs_vec."""
+    max_limb = (1 << limb_width) - 1
+    d = num_limbs_l + num_limbs_r - 1
+    muled = []
+    for i in range(d):
+        j = 0 if num_limbs_r >= i + 1 else i + 1 - num_limbs_r
+        acc = 0
+        while j < num_limbs_l and j <= i:
+            acc += max_limb * max_limb
+            j += 1
+        muled.append(acc)
+    out = []
+    cur_d = 0
+    max_d = d
+    while cur_d <= max_d:
+        if cur_d >= len(muled):
+            muled.append(0)
+        nb = muled[cur_d].bit_length()
+        num_chunks = nb // limb_width if nb % limb_width == 0 else nb // limb_width + 1
+        out.append(num_chunks - 1)
+        chunks = []
+        for _ in range(num_chunks):
+            chunks.append(muled[cur_d] & max_limb)
+            muled[cur_d] >>= limb_width
+        assert muled[cur_d] == 0
+        for j in range(num_chunks):
+            if len(muled) <= cur_d + j:
+                muled.append(0)
+            muled[cur_d + j] += chunks[j]
+        cur_d += 1
+    return out
+
+
+@dataclass(frozen=True)
+class Params:
+    """Derived constants of BigIntChip::new(config, limb_width, bits_len) (chip.rs:1174-1185)."""
+
+    w: int
+    L: int
+
+    def __post_init__(self):
+        assert self.w % 8 == 0 and self.L >= 1
+
+    @property
+    def B(self) -> int:
+        return 1 << self.w
+
+    @property
+    def word_max(self) -> int:
+        return compute_mul_word_max(self.w, self.L)
+
+    @property
+    def carry_bits(self) -> int:
+        # big_integer/chip.rs:841-842
+        return bits_size(self.word_max * 2) - self.w
+
+    @property
+    def LB(self) -> int:
+        return self.w // 8
+
+    @property
+    def WB(self) -> int:
+        return 8 * ((bits_size(self.word_max) + 2 + 63) // 64)
+
+    @property
+    def CB(self) -> int:
+        return 8 * ((self.carry_bits + 63) // 64)
+
+    @property
+    def limb_sub_bits(self) -> int:
+        return sublimb_bit_len(self.w)
+
+    @property
+    def carry_sub_bits(self) -> int:
+        return sublimb_bit_len(self.carry_bits)
+
+    def n_sublimbs(self, bit_len: int) -> int:
+        s = sublimb_bit_len(bit_len)
+        return bit_len // s + (1 if bit_len % s else 0)
+
+    @property
+    def mul_mod_stream_bytes(self) -> int:
+        L, C = self.L, 2 * self.L - 1
+        nl, nc = self.n_sublimbs(self.w), self.n_sublimbs(self.carry_bits)
+        per_col = 5 * self.WB + 2 * self.CB + 4 * self.LB + 4
+        return (2 * L * (self.LB + nl) + 2 * L * L * self.WB + L * self.WB
+                + C * per_col + (C - 1) * (self.CB + nc))
+
+
+class Stream:
+    """Little-endian fixed-width value stream (see module docstring)."""
+
+    def __init__(self):
+        self.buf = bytearray()
+
+    def put(self, v: int, nbytes: int, signed: bool = False):
+        self.buf += int(v).to_bytes(nbytes, "little", signed=signed)
+
+    def bytes(self) -> bytes:
+        return bytes(self.buf)
+
+
+def to_limbs(v: int, L: int, w: int) -> List[int]:
+    """maingate decompose_big [3P]: little-endian split (cf. mod.rs:348-359 for the inverse)."""
+    m = (1 << w) - 1
+    out = [(v >> (w * i)) & m for i in range(L)]
+    assert v >> (w * L) == 0, "value does not fit"
+    return out
+
+
+def from_limbs(limbs: Sequence[int], w: int) -> int:
+    """big_integer/mod.rs:348-359 (to_big_uint)."""
+    return sum(int(l) << (w * i) for i, l in enumerate(limbs))
+
+
+def range_sublimbs(v: int, sub_bits: int, bit_len: int) -> List[int]:
+    """RangeChip::assign [3P maingate]: bit_len/sub_bits composition sub-limbs (+1 overflow)."""
+    n = bit_len // sub_bits + (1 if bit_len % sub_bits else 0)
+    m = (1 << sub_bits) - 1
+    return [(v >> (sub_bits * t)) & m for t in range(n)]
+
+
+def emit_range_assign(st: Stream, v: int, sub_bits: int, bit_len: int, nbytes: int):
+    """One RangeChip::assign call: the value, then its sub-limbs (LSB first)."""
+    st.put(v, nbytes)
+    for s in range_sublimbs(v, sub_bits, bit_len):
+        st.put(s, 1)
+
+
+def mul_columns(a: Sequence[int], b: Sequence[int], st: Stream | None, WB: int) -> List[int]:
+    """BigIntChip::mul, big_integer/chip.rs:386-419: un-carried column sums, every partial emitted."""
+    d0, d1 = len(a), len(b)
+    d = d0 + d1 - 1
+    cols = []
+    for i in range(d):
+        acc = 0  # assign_constant(0), chip.rs:402 (not emitted)
+        j = 0 if d1 >= i + 1 else i + 1 - d1
+        while j < d0 and j <= i:
+            acc = a[j] * b[i - j] + acc  # main_gate.mul_add, chip.rs:408
+            if st is not None:
+                st.put(acc, WB)
+            j += 1
+        cols.append(acc)
+    return cols
+
+
+def is_equal_muled(p: Params, a: Sequence[int], b: Sequence[int], st: Stream) -> int:
+    """BigIntChip::is_equal_muled, big_integer/chip.rs:822-895 (num_limbs_l = num_limbs_r = L)."""
+    w, B, W = p.w, p.B, p.word_max
+    num_limbs = len(a)
+    assert num_limbs == len(b) == 2 * p.L - 1
+    carry_bits = p.carry_bits
+    acc_extra = 0
+    carry = [0]
+    eq_bit = 1
+    for i in range(num_limbs):
+        a_b = a[i] - b[i]                      # :859 (field sub; signed here)
+        st.put(a_b, p.WB, signed=True)
+        s = a_b + carry[i] + W                  # :860-861
+        assert s >= 0
+        st.put(s, p.WB)
+        new_carry, c = divmod(s, B)             # :864 -> div_mod_main_gate :1323-1349
+        st.put(new_carry, p.CB)
+        st.put(c, p.LB)
+        nq = B * new_carry
+        st.put(nq, p.WB)
+        st.put(s - nq, p.LB)
+        carry.append(new_carry)
+        acc_extra = acc_extra + W               # :869-870
+        st.put(acc_extra, p.WB)
+        q_acc, mod_acc = divmod(acc_extra, B)   # :871
+        st.put(q_acc, p.CB)
+        st.put(mod_acc, p.LB)
+        nq2 = B * q_acc
+        st.put(nq2, p.WB)
+        st.put(acc_extra - nq2, p.LB)
+        cs_acc_eq = 1 if c == mod_acc else 0    # :873
+        st.put(cs_acc_eq, 1)
+        eq_bit &= cs_acc_eq                     # :874
+        st.put(eq_bit, 1)
+        acc_extra = q_acc                       # :875
+        if i < num_limbs - 1:
+            # :879-887 -- range-assign the carry, compare, AND
+            emit_range_assign(st, new_carry, p.carry_sub_bits, carry_bits, p.CB)
+            range_eq = 1
+            st.put(range_eq, 1)
+            eq_bit &= range_eq
+            st.put(eq_bit, 1)
+        else:
+            final_carry_eq = 1 if new_carry == acc_extra else 0   # :890
+            st.put(final_carry_eq, 1)
+            eq_bit &= final_carry_eq
+            st.put(eq_bit, 1)
+    return eq_bit
+
+
+def mul_mod(p: Params, a: Sequence[int], b: Sequence[int], n: Sequence[int], st: Stream) -> List[int]:
+    """BigIntChip::mul_mod, big_integer/chip.rs:542-629.  Returns the r limbs."""
+    w, L = p.w, p.L
+    assert len(a) == len(n) == L and len(b) == L    # :555
+    a_big, b_big, n_big = from_limbs(a, w), from_limbs(b, w), from_limbs(n, w)
+    if n_big == 0:
+        raise ZeroDivisionError("modulus is zero (chip.rs:566)")
+    full = a_big * b_big                               # :562
+    q_big, r_big = divmod(full, n_big)                 # :564-567
+    if q_big >> (w * L):
+        raise OverflowError("quotient does not fit num_limbs limbs (chip.rs:584)")
+    q = to_limbs(q_big, L, w)                           # :570-584
+    r = to_limbs(r_big, L, w)
+    for v in q:                                         # :588-591
+        emit_range_assign(st, v, p.limb_sub_bits, w, p.LB)
+    for v in r:                                         # :596-599
+        emit_range_assign(st, v, p.limb_sub_bits, w, p.LB)
+    ab = mul_columns(a, b, st, p.WB)                    # :608
+    qn = mul_columns(q, n, st, p.WB)                    # :609
+    eq_b = []
+    for i in range(2 * L - 1):                          # :614-623
+        if i < L:
+            v = qn[i] + r[i]
+            st.put(v, p.WB)
+            eq_b.append(v)
+        else:
+            eq_b.append(qn[i])
+    ok = is_equal_muled(p, ab, eq_b, st)               # :626
+    assert ok == 1                                      # assert_equal_muled :1062
+    return r
+
+
+def fixed_exp_bits(e: int) -> List[int]:
+    """big_integer/chip.rs:717-728: LSB-first bits of e, exactly e.bits() of them."""
+    return [(e >> i) & 1 for i in range(e.bit_length())]
+
+
+def pow_mod_fixed_exp(p: Params, x: Sequence[int], e: int, n: Sequence[int], st: Stream) -> List[int]:
+    """BigIntChip::pow_mod_fixed_exp, big_integer/chip.rs:710-742."""
+    acc = to_limbs(1, p.L, p.w)          # :729 assign_constant(1, a.num_limbs())
+    squared = list(x)
+    for bit in fixed_exp_bits(e):
+        cur_sq = squared
+        squared = mul_mod(p, cur_sq, cur_sq, n, st)   # :734 square_mod -> :642-649
+        if not bit:
+            continue
+        acc = mul_mod(p, acc, cur_sq, n, st)          # :739
+    for v in acc:
+        st.put(v, p.LB)
+    return acc
+
+
+def pow_mod_var(p: Params, x: Sequence[int], e_limbs: Sequence[int], n: Sequence[int],
+                exp_limb_bits: int, st: Stream) -> List[int]:
+    """BigIntChip::pow_mod, big_integer/chip.rs:664-696."""
+    e_bits = []
+    for limb in e_limbs:                                # :674-681 main_gate.to_bits LSB first
+        for t in range(exp_limb_bits):
+            e_bits.append((limb >> t) & 1)
+    for b in e_bits:
+        st.put(b, 1)
+    acc = to_limbs(1, p.L, p.w)                         # :682
+    squared = list(x)
+    for bit in e_bits:
+        muled = mul_mod(p, acc, squared, n, st)         # :686
+        acc = [muled[j] if bit else acc[j] for j in range(p.L)]   # :688-691 select
+        for v in acc:
+            st.put(v, p.LB)
+        squared = mul_mod(p, squared, squared, n, st)   # :693
+    for v in acc:
+        st.put(v, p.LB)
+    return acc
+
+
+def big_pow_mod(a: int, b: int, n: int) -> int:
+    """big_integer/utils.rs:2-17 (recursive square-and-multiply; b == 0 returns 1 un-reduced)."""
+    if b == 0:
+        return 1
+    is_odd = b % 2 == 1
+    bb = b - 1 if is_odd else b
+    x = big_pow_mod(a, bb // 2, n)
+    x2 = (x * x) % n
+    return (a * x2) % n if is_odd else x2
+
+
+# ----------------------------------------------------------------------------------------------
+# "next" rows of SURVEY 8(f): assert_in_field (#1) and the pkcs1v15 encoded-message check (#2)
+# ----------------------------------------------------------------------------------------------
+
+def add_fresh(p: Params, a: Sequence[int], b: Sequence[int], st: Stream) -> List[int]:
+    """BigIntChip::add, big_integer/chip.rs:245-297."""
+    w, B = p.w, p.B
+    max_n = max(len(a), len(b))
+    a = list(a) + [0] * (max_n - len(a))
+    b = list(b) + [0] * (max_n - len(b))
+    c_vals, carrys = [], [0]
+    SB = p.LB + 8  # a_b / sum / c+carry*B : up to w+2 bits
+    for i in range(max_n):
+        a_b = a[i] + b[i]                                # :272
+        st.put(a_b, SB)
+        s = a_b + carrys[i]                              # :273
+        st.put(s, SB)
+        c, carry = s % B, s >> w                         # :276-277
+        emit_range_assign(st, c, p.limb_sub_bits, w, p.LB)       # :279-280
+        emit_range_assign(st, carry, p.limb_sub_bits, w, p.LB)   # :281-282
+        st.put(carry * B + c, SB)                        # :283 mul_add
+        c_vals.append(c)
+        carrys.append(carry)
+    c_vals.append(carrys[max_n])                         # :290
+    return c_vals
+
+
+def is_equal_fresh(p: Params, a: Sequence[int], b: Sequence[int], st: Stream) -> int:
+    """BigIntChip::is_equal_fresh, big_integer/chip.rs:780-805."""
+    n1, n2 = len(a), len(b)
+    is_a_larger = n1 > n2
+    max_n = n1 if is_a_larger else n2
+    eq_bit = 1
+    for i in range(max_n):
+        if is_a_larger and i >= n2:
+            flag = 1 if a[i] == 0 else 0
+        elif (not is_a_larger) and i >= n1:
+            flag = 1 if b[i] == 0 else 0
+        else:
+            flag = 1 if a[i] == b[i] else 0
+        st.put(flag, 1)
+        eq_bit &= flag
+        st.put(eq_bit, 1)
+    return eq_bit
+
+
+def sub_unchecked(p: Params, a: Sequence[int], b: Sequence[int], st: Stream) -> List[int]:
+    """BigIntChip::sub_unchecked, big_integer/chip.rs:1286-1318."""
+    w = p.w
+    assert len(a) >= len(b)                              # :1294
+    max_n = len(a)
+    c_big = from_limbs(a, w) - from_limbs(b, w)          # :1300 (panics on underflow)
+    if c_big < 0:
+        raise OverflowError("a < b in sub_unchecked (chip.rs:1300)")
+    c = []
+    for _ in range(max_n):                               # :1304-1311
+        v = c_big % p.B
+        emit_range_assign(st, v, p.limb_sub_bits, w, p.LB)
+        c.append(v)
+        c_big >>= w
+    added = add_fresh(p, b, c, st)                       # :1315
+    ok = is_equal_fresh(p, a, added, st)                 # :1316
+    assert ok == 1
+    return c
+
+
+def sub_fresh(p: Params, a: Sequence[int], b: Sequence[int], st: Stream) -> Tuple[List[int], int]:
+    """BigIntChip::sub, big_integer/chip.rs:310-373.  Returns (|a-b| limbs, is_overflowed)."""
+    n2 = len(b)
+    max_int = [p.B - 1] * n2                             # :319 max_value :138-154 (constants)
+    inflated_a = add_fresh(p, a, max_int, st)            # :321
+    inflated_subed = sub_unchecked(p, inflated_a, b, st)  # :323
+    is_not_overflowed = 1 if inflated_subed[n2] == 1 else 0   # :330
+    st.put(is_not_overflowed, 1)
+    is_overflowed = 1 - is_not_overflowed                # :331
+    st.put(is_overflowed, 1)
+    num_limbs_l = len(inflated_subed)
+    num_limbs_r = max(len(a), n2)
+    sel_l, sel_r = [], []
+    for i in range(num_limbs_l):                         # :345-357
+        if i >= n2:
+            v = inflated_subed[i] if is_not_overflowed else 0
+        else:
+            v = inflated_subed[i] if is_not_overflowed else b[i]
+        st.put(v, p.LB)
+        sel_l.append(v)
+    for i in range(num_limbs_r):                         # :358-367
+        if i >= len(a):
+            v = max_int[i] if is_not_overflowed else 0
+        elif i >= n2:
+            v = 0 if is_not_overflowed else a[i]
+        else:
+            v = max_int[i] if is_not_overflowed else a[i]
+        st.put(v, p.LB)
+        sel_r.append(v)
+    real_subed = sub_unchecked(p, sel_l, sel_r, st)      # :371
+    return real_subed, is_overflowed
+
+
+def is_less_than(p: Params, a: Sequence[int], b: Sequence[int], st: Stream) -> int:
+    """BigIntChip::is_less_than, big_integer/chip.rs:908-919 (+ :932-941)."""
+    _, is_overflowed = sub_fresh(p, a, b, st)            # :939
+    is_eq = is_equal_fresh(p, a, b, st)                  # :916
+    is_not_eq = 1 - is_eq                                # :917
+    st.put(is_not_eq, 1)
+    out = is_overflowed & is_not_eq                      # :918
+    st.put(out, 1)
+    return out
+
+
+def assert_in_field(p: Params, a: Sequence[int], n: Sequence[int], st: Stream) -> int:
+    """BigIntChip::assert_in_field, big_integer/chip.rs:1150-1158 -> is_in_field :998-1006."""
+    return is_less_than(p, a, n, st)
+
+
+PKCS1_PREFIX_64_1 = 217300885422736416   # src/chip.rs:150
+PKCS1_PREFIX_64_2 = 938447882527703397   # src/chip.rs:152
+PKCS1_PREFIX_32 = 3158320                # src/chip.rs:175
+PKCS1_FF_32 = 4294967295                 # src/chip.rs:180
+PKCS1_FF_64 = 18446744073709551615       # src/chip.rs:184
+PKCS1_LAST_EM = 562949953421311          # src/chip.rs:191
+
+
+def pkcs1v15_em_check(powed: Sequence[int], hashed: Sequence[int], bits_len: int, st: Stream) -> int:
+    """RSAChip::verify_pkcs1v15_signature after the modpow, src/chip.rs:136-198 (LIMB_WIDTH = 64)."""
+    is_eq = 1
+    hash_len = 4
+    for i in range(hash_len):                            # :141-144
+        f = 1 if powed[i] == hashed[i] else 0
+        st.put(f, 1)
+        is_eq &= f
+        st.put(is_eq, 1)
+    f1 = 1 if powed[hash_len] == PKCS1_PREFIX_64_1 else 0          # :153
+    f2 = 1 if powed[hash_len + 1] == PKCS1_PREFIX_64_2 else 0      # :154
+    st.put(f1, 1)
+    st.put(f2, 1)
+    is_eq &= f1
+    st.put(is_eq, 1)
+    is_eq &= f2
+    st.put(is_eq, 1)
+    v = powed[hash_len + 2]
+    low, high = v % (1 << 32), v >> 32                    # :159-168
+    emit_range_assign(st, low, 4, 32, 4)                  # :170
+    emit_range_assign(st, high, 4, 32, 4)                 # :171
+    st.put(high * (1 << 32) + low, 8)                     # :173 mul_add
+    f = 1 if low == PKCS1_PREFIX_32 else 0                # :176
+    st.put(f, 1)
+    is_eq &= f
+    st.put(is_eq, 1)
+    f = 1 if high == PKCS1_FF_32 else 0                   # :181
+    st.put(f, 1)
+    is_eq &= f
+    st.put(is_eq, 1)
+    nl = bits_len // 64
+    for i in range(hash_len + 3, nl - 1):                 # :185-188
+        f = 1 if powed[i] == PKCS1_FF_64 else 0
+        st.put(f, 1)
+        is_eq &= f
+        st.put(is_eq, 1)
+    f = 1 if powed[nl - 1] == PKCS1_LAST_EM else 0        # :192-196
+    st.put(f, 1)
+    is_eq &= f
+    st.put(is_eq, 1)
+    return is_eq
+
+
+def modpow_public_key_fixed(p: Params, x: Sequence[int], e: int, n: Sequence[int], st: Stream,
+                            with_in_field: bool = True) -> List[int]:
+    """RSAChip::modpow_public_key with RSAPubE::Fix, src/chip.rs:99-114."""
+    if with_in_field:
+        ok = assert_in_field(p, x, n, st)                 # :106
+        if ok != 1:
+            raise ValueError("x >= n (src/chip.rs:106 assert_in_field)")
+    return pow_mod_fixed_exp(p, x, e, n, st)              # :111

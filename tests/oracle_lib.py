@@ -1,0 +1,144 @@
+"""ctypes binding of oracle/libh2r_oracle.so -- TEST INFRASTRUCTURE (the checker), never the product.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_SO = os.path.join(ORACLE_DIR, "libh2r_oracle.so")
+
+
+class OracleParams(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_uint32), ("L", ctypes.c_uint32), ("LB", ctypes.c_uint32),
+                ("WB", ctypes.c_uint32), ("CB", ctypes.c_uint32), ("word_max_bits", ctypes.c_uint32),
+                ("carry_bits", ctypes.c_uint32), ("limb_sub_bits", ctypes.c_uint32),
+                ("limb_nsub", ctypes.c_uint32), ("carry_sub_bits", ctypes.c_uint32),
+                ("carry_nsub", ctypes.c_uint32), ("word_max", ctypes.c_uint64 * 4),
+                ("mul_mod_stream_bytes", ctypes.c_uint64)]
+
+
+def build():
+    """Compile the C restatement with gcc (building the checker is not using it)."""
+    src = os.path.join(ORACLE_DIR, "h2r_oracle.c")
+    if (not os.path.exists(_SO)) or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(ORACLE_DIR, "h2r_oracle.h"))):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(build())
+        for name in ("h2ro_pow_fixed_stream_bytes", "h2ro_pow_var_stream_bytes", "h2ro_in_field_stream_bytes",
+                     "h2ro_pkcs1v15_stream_bytes"):
+            getattr(_lib, name).restype = ctypes.c_uint64
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+class Oracle:
+    """Thin object wrapper: numpy in, numpy out.  Limbs are uint64 (w=64) / uint32 (w=32) arrays."""
+
+    def __init__(self, w, L):
+        self.p = OracleParams()
+        rc = lib().h2ro_params_init(ctypes.byref(self.p), w, L)
+        if rc:
+            raise ValueError("h2ro_params_init failed: %d" % rc)
+        self.w, self.L = w, L
+        self.dtype = np.uint64 if w == 64 else np.uint32
+
+    @property
+    def mul_mod_stream_bytes(self):
+        return int(self.p.mul_mod_stream_bytes)
+
+    def limbs(self, v, L=None):
+        L = self.L if L is None else L
+        m = (1 << self.w) - 1
+        assert v >> (self.w * L) == 0
+        return np.array([(v >> (self.w * i)) & m for i in range(L)], dtype=self.dtype)
+
+    def to_int(self, a):
+        return sum(int(x) << (self.w * i) for i, x in enumerate(a))
+
+    def mul_mod(self, a, b, n, want_stream=True):
+        st = np.zeros(self.mul_mod_stream_bytes, dtype=np.uint8) if want_stream else None
+        r = np.zeros(self.L, dtype=self.dtype)
+        rc = lib().h2ro_mul_mod(ctypes.byref(self.p), _ptr(np.ascontiguousarray(a, self.dtype)), _ptr(np.ascontiguousarray(b, self.dtype)),
+                                _ptr(np.ascontiguousarray(n, self.dtype)), _ptr(st), _ptr(r))
+        return rc, r, st
+
+    def mul_columns(self, a, b):
+        cols = np.zeros((2 * self.L - 1, 4), dtype=np.uint64)
+        lib().h2ro_mul_columns(ctypes.byref(self.p), _ptr(np.ascontiguousarray(a, self.dtype)), _ptr(np.ascontiguousarray(b, self.dtype)), None, _ptr(cols))
+        return [sum(int(cols[i, k]) << (64 * k) for k in range(4)) for i in range(2 * self.L - 1)]
+
+    def pow_fixed_stream_bytes(self, e):
+        eb = e_bytes(e)
+        return int(lib().h2ro_pow_fixed_stream_bytes(ctypes.byref(self.p), eb, len(eb)))
+
+    def pow_mod_fixed_exp(self, x, n, e, want_stream=True):
+        eb = e_bytes(e)
+        st = np.zeros(self.pow_fixed_stream_bytes(e), dtype=np.uint8) if want_stream else None
+        out = np.zeros(self.L, dtype=self.dtype)
+        rc = lib().h2ro_pow_mod_fixed_exp(ctypes.byref(self.p), _ptr(np.ascontiguousarray(x, self.dtype)), _ptr(np.ascontiguousarray(n, self.dtype)),
+                                          eb, len(eb), _ptr(st), _ptr(out))
+        return rc, out, st
+
+    def pow_var_stream_bytes(self, e_num_limbs, exp_limb_bits):
+        return int(lib().h2ro_pow_var_stream_bytes(ctypes.byref(self.p), e_num_limbs, exp_limb_bits))
+
+    def pow_mod(self, x, e_limbs, exp_limb_bits, n, want_stream=True):
+        e_limbs = np.ascontiguousarray(e_limbs, self.dtype)
+        st = np.zeros(self.pow_var_stream_bytes(len(e_limbs), exp_limb_bits), dtype=np.uint8) if want_stream else None
+        out = np.zeros(self.L, dtype=self.dtype)
+        rc = lib().h2ro_pow_mod(ctypes.byref(self.p), _ptr(np.ascontiguousarray(x, self.dtype)), _ptr(e_limbs), len(e_limbs), exp_limb_bits,
+                                _ptr(np.ascontiguousarray(n, self.dtype)), _ptr(st), _ptr(out))
+        return rc, out, st
+
+    def big_pow_mod(self, a, e, n):
+        eb = e_bytes(e)
+        out = np.zeros(self.L, dtype=self.dtype)
+        rc = lib().h2ro_big_pow_mod(ctypes.byref(self.p), _ptr(np.ascontiguousarray(a, self.dtype)), eb, len(eb), _ptr(np.ascontiguousarray(n, self.dtype)), _ptr(out))
+        return rc, out
+
+    def assert_in_field(self, a, n):
+        nb = int(lib().h2ro_in_field_stream_bytes(ctypes.byref(self.p)))
+        st = np.zeros(nb, dtype=np.uint8)
+        lt = ctypes.c_int(-1)
+        rc = lib().h2ro_assert_in_field(ctypes.byref(self.p), _ptr(np.ascontiguousarray(a, self.dtype)), _ptr(np.ascontiguousarray(n, self.dtype)), _ptr(st), ctypes.byref(lt))
+        return rc, lt.value, st
+
+    def pkcs1v15_em_check(self, powed, hashed4):
+        nb = int(lib().h2ro_pkcs1v15_stream_bytes(ctypes.byref(self.p)))
+        st = np.zeros(nb, dtype=np.uint8)
+        ok = ctypes.c_int(-1)
+        h = np.ascontiguousarray(hashed4, np.uint64)
+        rc = lib().h2ro_pkcs1v15_em_check(ctypes.byref(self.p), _ptr(np.ascontiguousarray(powed, np.uint64)), _ptr(h), _ptr(st), ctypes.byref(ok))
+        return rc, ok.value, st
+
+    def pow_mod_fixed_exp_batch(self, x, n, e, nthreads=1, want_stream=False):
+        eb = e_bytes(e)
+        batch = x.shape[0]
+        sb = self.pow_fixed_stream_bytes(e)
+        st = np.zeros((batch, sb), dtype=np.uint8) if want_stream else None
+        out = np.zeros((batch, self.L), dtype=self.dtype)
+        status = np.zeros(batch, dtype=np.uint8)
+        lib().h2ro_pow_mod_fixed_exp_batch(ctypes.byref(self.p), _ptr(np.ascontiguousarray(x, self.dtype)), _ptr(np.ascontiguousarray(n, self.dtype)),
+                                           eb, len(eb), ctypes.c_uint64(batch), _ptr(st), _ptr(out), _ptr(status), nthreads)
+        return out, status, st
+
+
+def e_bytes(e):
+    """e.to_bytes_le() (reference big_integer/chip.rs:719-720); BigUint zero is one zero byte."""
+    return int(e).to_bytes(max(1, (int(e).bit_length() + 7) // 8), "little")
