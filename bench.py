@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- RSA-2048 pkcs1v15 witness assignments / second on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path (RSAChip::modpow_public_key witness generation: chain kernel +
+trace kernel through the C ABI) over one batch of synthetic signatures that is already resident in
+HBM.  At N GPUs every rank processes its own shard of `--batch` signatures (weak scaling, no
+data-path collective: signatures are independent); the only collectives are the configuration
+broadcast before and the result gather after the timed region, plus the barrier / MAX-reduce that
+brackets the timing.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (trace_kernel, HBM-write bound): algorithmic bytes per launch
+                  / average launch duration measured with HIP events on the launch stream during
+                  the timed steps.
+  cpu_baseline -- the CPU oracle ("port" of the reference's path, oracle/h2r_oracle.c) timed on this
+                  host's cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import halo2_rsa_amd as H  # noqa: E402
+from halo2_rsa_amd import _lib  # noqa: E402
+from halo2_rsa_amd.dist import DistEnv  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (limb_width, bits_len, exponent)
+    "rsa2048_e65537": (64, 2048, 65537),   # BASELINE configs[1] (batch 1024) / configs[2] shards
+    "rsa4096_w32_e65537": (32, 4096, 65537),  # configs[3]
+    "rsa1024_e65537": (64, 1024, 65537),
+}
+
+
+def synth_inputs(w, bits, batch, seed, golden_first=True):
+    """Seeded synthetic batch: odd moduli with the top bit set, x uniform mod n; the
+    reference's two valid and one invalid RSA-2048 signatures occupy elements 0-2."""
+    rng = random.Random(seed)
+    L = bits // w
+    ns, xs = [], []
+    if golden_first and (w, bits) == (64, 2048):
+        with open(os.path.join(ROOT, "tests", "golden", "halo2_rsa_golden.json")) as f:
+            for k in json.load(f)["rsa_kats"]:
+                ns.append(int(k["n"])); xs.append(int(k["sig"]))
+    while len(ns) < batch:
+        n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+        ns.append(n); xs.append(rng.randrange(n))
+    ns, xs = ns[:batch], xs[:batch]
+    un = H.UnassignedInteger.from_ints(ns, L, w)
+    ux = H.UnassignedInteger.from_ints(xs, L, w)
+    return ns, xs, un, ux
+
+
+def cpu_baseline(w, bits, e, un, ux, max_seconds=20.0):
+    """Time the CPU oracle (checker used as the reported baseline) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle
+    o = Oracle(w, bits // w)
+    cores = os.cpu_count() or 1
+    sample = min(un.limbs.shape[0], 64 * cores)
+    x, n = ux.limbs[:sample], un.limbs[:sample]
+    o.pow_mod_fixed_exp_batch(x[:cores], n[:cores], e, nthreads=cores, want_stream=True)  # warm-up
+    best, spent, runs = 0.0, 0.0, 0
+    while spent < max_seconds and runs < 4:
+        t0 = time.perf_counter()
+        out, status, st = o.pow_mod_fixed_exp_batch(x, n, e, nthreads=cores, want_stream=True)
+        dt = time.perf_counter() - t0
+        spent += dt; runs += 1
+        best = max(best, sample / dt)
+    return {"value": round(best, 1), "unit": "assigns/s", "cores": cores, "kind": "port",
+            "sample": "%d signatures of the same synthetic batch, full op-trace stream written, best of %d runs, %d threads"
+                      % (sample, runs, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="signatures per GPU per step")
+    ap.add_argument("--workload", default="rsa2048_e65537", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    env = DistEnv.from_environment(args.gpus)
+    w, bits, e = WORKLOADS[args.workload]
+    torch.cuda.set_device(env.local_rank)
+    env.init("nccl")
+    # configuration broadcast (rank 0 decides e / batch): the only pre-run collective
+    cfg = env.broadcast_ints([e, args.batch, args.steps, args.warmup])
+    e, batch, steps, warmup = cfg
+
+    chip = H.BigIntChip(w, bits, device=env.local_rank)
+    ns, xs, un, ux = synth_inputs(w, bits, batch, 0x68327273 + 2 + 1000 * env.rank)
+    n_dev, x_dev = chip.assign_integer(un), chip.assign_integer(ux)
+    pl = chip.pow_fixed_layout(e)
+    dev = "cuda:%d" % env.local_rank
+    trace_buf = torch.empty(batch * pl.elem_stride, dtype=torch.uint8, device=dev)
+    workspace = torch.empty(chip.workspace_bytes(batch, pl.num_mul_mods), dtype=torch.uint8, device=dev)
+    out = torch.empty((batch, chip.num_limbs), dtype=chip.torch_dtype, device=dev)
+    status = torch.zeros(batch, dtype=torch.uint8, device=dev)
+
+    def step():
+        return chip.pow_mod_fixed_exp(x_dev, e, n_dev, want_trace=True, trace_buf=trace_buf, check_in_field=True,
+                                      workspace=workspace, out=out, status=status)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    _lib.profile_enable(2 * steps + 8)
+    env.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    torch.cuda.synchronize()
+    env.barrier()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
+    trace_ms = _lib.profile_read(_lib.KERNEL_TRACE)
+    chain_ms = _lib.profile_read(_lib.KERNEL_CHAIN)
+    _lib.profile_enable(0)
+
+    # post-run: correctness of what was timed + the result gather (rank 0 receives every shard's x^e mod n)
+    assert int(status.max().item()) == 0 or (w, bits) != (64, 2048), "unexpected per-element status"
+    got = res.value.to_big_uint()
+    for i in (0, 1, 2, batch - 1):
+        if i < batch:
+            assert got[i] == pow(xs[i], e, ns[i]), "GPU result differs from pow(x, e, n)"
+    gathered = env.gather_to_rank0(out)
+    if env.rank == 0:
+        assert gathered.shape[0] == env.world * batch
+
+    if env.rank == 0:
+        algo_bytes_per_assign = pl.stream_bytes + 2 * chip.num_limbs * chip.layout.limb_bytes  # written + inputs read
+        trace_bytes_per_launch = batch * (pl.num_mul_mods * chip.layout.stream_bytes)         # trace_kernel's algorithmic output
+        avg_trace_s = (sum(trace_ms) / len(trace_ms)) / 1e3 if trace_ms else float("nan")
+        achieved = trace_bytes_per_launch / avg_trace_s / 1e9 if trace_ms else None
+        line = {
+            "metric": "RSA-2048 pkcs1v15 witness assigns/sec" if bits == 2048 else "RSA-%d witness assigns/sec" % bits,
+            "value": round(env.world * batch * steps / dt, 1),
+            "unit": "assigns/s",
+            "n_gpus": env.world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * dt / steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u%d" % w, "data": "synthetic",
+            "config": {"workload": "%s batch=%d per GPU, %d-bit limbs, full op-trace (%d B/assign)" %
+                       (args.workload, batch, w, algo_bytes_per_assign),
+                       "per_gpu_batch": batch, "global_batch": env.world * batch,
+                       "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                         "traffic": None, "kernel": "trace_kernel<%d,%d>" % (w, chip.num_limbs),
+                         "avg_launch_ms": round(1e3 * avg_trace_s, 4) if trace_ms else None,
+                         "algorithmic_bytes_per_launch": trace_bytes_per_launch,
+                         "chain_kernel_avg_ms": round(sum(chain_ms) / len(chain_ms), 4) if chain_ms else None},
+            "whole_path_hbm_frac": round(env.world * batch * steps / dt * algo_bytes_per_assign / (env.world * HBM_PEAK_GBS * 1e9), 4),
+        }
+        if env.world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w, bits, e, un, ux)
+        print(json.dumps(line))
+    env.finalize()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,41 @@
+"""Builds halo2_rsa_amd/lib/libh2r.so (hand-written HIP for gfx950) in-tree with hipcc."""
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+SRC = os.path.join(PKG, "csrc", "h2r_api.hip")
+DEPS = [SRC, os.path.join(PKG, "csrc", "h2r_kernels.hpp"), os.path.join(PKG, "csrc", "h2r_layout.hpp"),
+        os.path.join(ROOT, "include", "h2r.h")]
+LIB = os.path.join(PKG, "lib", "libh2r.so")
+
+
+def hipcc_path():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libh2r.so cannot be built")
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build_lib(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), "-o", LIB, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force=True, verbose=True))

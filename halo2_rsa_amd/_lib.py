@@ -1,0 +1,133 @@
+"""ctypes binding of libh2r.so (the C ABI declared in include/h2r.h).
+
+The product path has NO CPU fallback: if the HIP library is missing this module raises.
+"""
+import ctypes
+import os
+
+from . import _build
+
+H2R_PL_COUNT = 29
+PLANES = ["Q", "R", "Q_SUB", "R_SUB", "AB_LO", "AB_HI", "QN_LO", "QN_HI", "EQB_LO", "EQB_HI", "AMB_LO", "AMB_HI",
+          "SUM_LO", "SUM_HI", "CARRY", "CMOD", "NQ1_LO", "NQ1_HI", "AMNQ1", "ACCX_LO", "ACCX_HI", "QACC", "MODACC",
+          "NQ2_LO", "NQ2_HI", "AMNQ2", "FLAGS", "CARRY_DUP", "CARRY_SUB"]
+assert len(PLANES) == H2R_PL_COUNT
+
+H2R_OK, H2R_E_SHAPE, H2R_E_ZERO_MODULUS, H2R_E_NOT_REDUCED, H2R_E_FIELD_TOO_SMALL, H2R_E_HIP, H2R_E_UNSUPPORTED, \
+    H2R_E_NULL, H2R_E_NOT_IN_FIELD = range(9)
+FIELDS = {"bn254_fr": 0, "bn254_fq": 1, "pasta_fp": 2, "pasta_fq": 3}
+H2R_F_SHARED_MODULUS = 1
+
+
+class H2RParams(ctypes.Structure):
+    _fields_ = [("limb_width", ctypes.c_uint32), ("bits_len", ctypes.c_uint32), ("field", ctypes.c_uint32),
+                ("device", ctypes.c_int32)]
+
+
+class H2RLayout(ctypes.Structure):
+    _fields_ = [("limb_width", ctypes.c_uint32), ("num_limbs", ctypes.c_uint32), ("num_cols", ctypes.c_uint32),
+                ("limb_bytes", ctypes.c_uint32), ("wide_bytes", ctypes.c_uint32), ("carry_bytes", ctypes.c_uint32),
+                ("limb_sub_bits", ctypes.c_uint32), ("limb_nsub", ctypes.c_uint32),
+                ("carry_bits", ctypes.c_uint32), ("carry_sub_bits", ctypes.c_uint32), ("carry_nsub", ctypes.c_uint32),
+                ("carry_sub_stride", ctypes.c_uint32), ("word_max_bits", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
+                ("record_stride", ctypes.c_uint64), ("stream_bytes", ctypes.c_uint64),
+                ("plane_off", ctypes.c_uint64 * H2R_PL_COUNT), ("plane_elem", ctypes.c_uint32 * H2R_PL_COUNT),
+                ("plane_count", ctypes.c_uint32 * H2R_PL_COUNT)]
+
+
+class H2RPowLayout(ctypes.Structure):
+    _fields_ = [("num_mul_mods", ctypes.c_uint32), ("num_exp_bits", ctypes.c_uint32),
+                ("elem_stride", ctypes.c_uint64), ("off_records", ctypes.c_uint64), ("off_result", ctypes.c_uint64),
+                ("off_e_bits", ctypes.c_uint64), ("off_selected", ctypes.c_uint64), ("selected_stride", ctypes.c_uint64),
+                ("stream_bytes", ctypes.c_uint64)]
+
+
+class H2RError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib().h2r_status_str(code).decode()
+        if code == H2R_E_HIP:
+            msg += " (" + lib().h2r_last_hip_error().decode() + ")"
+        super().__init__("%s: h2r status %d: %s" % (where, code, msg))
+
+
+_lib = None
+EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_rsa_compute_range_lens",
+           "h2r_trace_layout", "h2r_pow_fixed_layout", "h2r_pow_var_layout", "h2r_workspace_bytes",
+           "h2r_mul_mod_batch", "h2r_square_mod_batch", "h2r_pow_mod_fixed_exp_batch", "h2r_pow_mod_batch",
+           "h2r_modpow_public_key_batch", "h2r_range_decompose_batch", "h2r_hist_len", "h2r_trace_lookup_hist",
+           "h2r_trace_flatten", "h2r_pow_trace_flatten", "h2r_profile_enable", "h2r_profile_read", "h2r_status_str",
+           "h2r_last_hip_error"]
+KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST = 0, 1, 2
+
+
+def lib_path():
+    return _build.LIB
+
+
+def lib():
+    """Load libh2r.so.  `import torch` must happen first so that the HIP runtime torch ships
+    (same SONAME libamdhip64.so.7) is the one both share."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError("libh2r.so is not built (%s). Run `python -m halo2_rsa_amd._build`; there is no CPU fallback." % path)
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64 first)
+    except Exception:  # pragma: no cover - torch-less use links /opt/rocm's runtime
+        pass
+    L = ctypes.CDLL(path)
+    vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32
+    L.h2r_ctx_create.argtypes = [ctypes.POINTER(H2RParams), ctypes.POINTER(vp)]
+    L.h2r_ctx_destroy.argtypes = [vp]
+    L.h2r_ctx_destroy.restype = None
+    L.h2r_compute_range_lens.argtypes = [u32, u32, ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    L.h2r_rsa_compute_range_lens.argtypes = [u32, ctypes.POINTER(u32), ctypes.POINTER(u32)]
+    L.h2r_trace_layout.argtypes = [vp, ctypes.POINTER(H2RLayout)]
+    L.h2r_pow_fixed_layout.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(H2RPowLayout)]
+    L.h2r_pow_var_layout.argtypes = [vp, u32, u32, ctypes.POINTER(H2RPowLayout)]
+    L.h2r_workspace_bytes.argtypes = [vp, u64, u32]
+    L.h2r_workspace_bytes.restype = u64
+    L.h2r_mul_mod_batch.argtypes = [vp, vp, vp, vp, u64, u32, vp, vp, vp, vp, vp]
+    L.h2r_square_mod_batch.argtypes = [vp, vp, vp, u64, u32, vp, vp, vp, vp, vp]
+    L.h2r_pow_mod_fixed_exp_batch.argtypes = [vp, vp, vp, ctypes.c_char_p, ctypes.c_size_t, u64, u32, vp, vp, vp, vp, vp]
+    L.h2r_modpow_public_key_batch.argtypes = L.h2r_pow_mod_fixed_exp_batch.argtypes
+    L.h2r_pow_mod_batch.argtypes = [vp, vp, vp, u32, u32, vp, u64, u32, vp, vp, vp, vp, vp]
+    L.h2r_range_decompose_batch.argtypes = [vp, vp, u32, u64, u32, u32, vp, u32, vp, vp]
+    L.h2r_hist_len.argtypes = [vp]
+    L.h2r_hist_len.restype = u32
+    L.h2r_trace_lookup_hist.argtypes = [vp, vp, u64, u64, u64, u32, vp, vp]
+    L.h2r_trace_flatten.argtypes = [vp, vp, vp]
+    L.h2r_pow_trace_flatten.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, vp]
+    L.h2r_profile_enable.argtypes = [u32]
+    L.h2r_profile_read.argtypes = [u32, ctypes.POINTER(ctypes.c_float), u32, ctypes.POINTER(u32)]
+    L.h2r_status_str.argtypes = [i32]
+    L.h2r_status_str.restype = ctypes.c_char_p
+    L.h2r_last_hip_error.restype = ctypes.c_char_p
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if fn.restype is ctypes.c_int:
+            fn.restype = i32
+    _lib = L
+    return _lib
+
+
+def check(code, where):
+    if code != H2R_OK:
+        raise H2RError(code, where)
+
+
+def profile_enable(capacity):
+    check(lib().h2r_profile_enable(capacity), "h2r_profile_enable")
+
+
+def profile_read(kernel, max_count=1 << 16):
+    """Durations (ms) of the recorded launches of one kernel class, in launch order."""
+    n = ctypes.c_uint32(0)
+    check(lib().h2r_profile_read(kernel, None, 0, ctypes.byref(n)), "h2r_profile_read")
+    k = min(n.value, max_count)
+    buf = (ctypes.c_float * max(k, 1))()
+    check(lib().h2r_profile_read(kernel, buf, k, ctypes.byref(n)), "h2r_profile_read")
+    return [float(buf[i]) for i in range(k)]

@@ -1,0 +1,247 @@
+"""Host-side mirror of the reference's `big_integer` module for the accelerated path.
+
+Same names and argument meaning as `BigIntInstructions<F>` (reference src/big_integer/instructions.rs:7-260)
+for the methods on the hot path -- `assign_integer`, `mul_mod`, `square_mod`, `pow_mod`,
+`pow_mod_fixed_exp` -- in batch form: every integer argument is a batch of integers (one per
+independent circuit), resident in HBM.  All arithmetic happens in libh2r.so (hand-written HIP);
+this module only moves pointers.  There is no CPU fallback.
+"""
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import H2RLayout, H2RParams, H2RPowLayout, check, lib
+
+
+def _e_bytes(e: int) -> bytes:
+    """BigUint::to_bytes_le (reference big_integer/chip.rs:719-720)."""
+    return int(e).to_bytes(max(1, (int(e).bit_length() + 7) // 8), "little")
+
+
+@dataclass
+class UnassignedInteger:
+    """reference big_integer/mod.rs:270-302: limb values about to be assigned (host side)."""
+    limbs: np.ndarray  # [batch, num_limbs]
+
+    @property
+    def num_limbs(self):
+        return self.limbs.shape[1]
+
+    @staticmethod
+    def from_ints(values: Sequence[int], num_limbs: int, limb_width: int) -> "UnassignedInteger":
+        """maingate::decompose_big (call sites examples/rsa_example.rs:177,182): little-endian split."""
+        dt = np.uint64 if limb_width == 64 else np.uint32
+        m = (1 << limb_width) - 1
+        out = np.zeros((len(values), num_limbs), dtype=dt)
+        for r, v in enumerate(values):
+            v = int(v)
+            if v >> (limb_width * num_limbs):
+                raise ValueError("value does not fit %d limbs of %d bits" % (num_limbs, limb_width))
+            for i in range(num_limbs):
+                out[r, i] = (v >> (limb_width * i)) & m
+        return UnassignedInteger(out)
+
+
+class AssignedInteger:
+    """reference big_integer/mod.rs:306-382 (Fresh range type): a batch of limb vectors in HBM."""
+
+    def __init__(self, limbs: torch.Tensor, limb_width: int):
+        assert limbs.is_cuda and limbs.dim() == 2 and limbs.is_contiguous()
+        self.limbs_dev = limbs
+        self.limb_width = limb_width
+
+    def num_limbs(self):
+        return self.limbs_dev.shape[1]
+
+    @property
+    def batch(self):
+        return self.limbs_dev.shape[0]
+
+    def limbs_host(self) -> np.ndarray:
+        dt = np.uint64 if self.limb_width == 64 else np.uint32
+        return self.limbs_dev.cpu().numpy().view(dt)
+
+    def to_big_uint(self) -> List[int]:
+        """reference big_integer/mod.rs:348-359."""
+        h = self.limbs_host()
+        return [sum(int(x) << (self.limb_width * i) for i, x in enumerate(row)) for row in h]
+
+    def data_ptr(self):
+        return self.limbs_dev.data_ptr()
+
+
+class Trace:
+    """Witness records of a batch call, resident in HBM, plus the layout needed to walk them."""
+
+    def __init__(self, chip: "BigIntChip", buf: torch.Tensor, batch: int, pow_layout: Optional[H2RPowLayout]):
+        self.chip, self.buf, self.batch, self.pow_layout = chip, buf, batch, pow_layout
+        self.layout = chip.layout
+        self.elem_stride = pow_layout.elem_stride if pow_layout is not None else chip.layout.record_stride
+        self.num_mul_mods = pow_layout.num_mul_mods if pow_layout is not None else 1
+
+    @property
+    def stream_bytes(self):
+        return self.pow_layout.stream_bytes if self.pow_layout is not None else self.layout.stream_bytes
+
+    def elem_host(self, elem: int) -> np.ndarray:
+        s = self.elem_stride
+        return self.buf[elem * s:(elem + 1) * s].cpu().numpy()
+
+    def flatten(self, elem: int) -> np.ndarray:
+        """The element's op-trace in the reference's assignment order (h2r_trace_flatten)."""
+        host = np.ascontiguousarray(self.elem_host(elem))
+        out = np.zeros(self.stream_bytes, dtype=np.uint8)
+        if self.pow_layout is None:
+            check(lib().h2r_trace_flatten(self.chip._ctx, host.ctypes.data, out.ctypes.data), "h2r_trace_flatten")
+        else:
+            check(lib().h2r_pow_trace_flatten(self.chip._ctx, ctypes.byref(self.pow_layout), host.ctypes.data, out.ctypes.data),
+                  "h2r_pow_trace_flatten")
+        return out
+
+    def plane(self, elem: int, t: int, name: str) -> np.ndarray:
+        """Raw bytes [count, elem_bytes] of one plane of mul_mod record t of element elem."""
+        p = _lib.PLANES.index(name)
+        lo = self.layout
+        off0 = (self.pow_layout.off_records if self.pow_layout is not None else 0) + t * lo.record_stride
+        start = elem * self.elem_stride + off0 + lo.plane_off[p]
+        n = lo.plane_elem[p] * lo.plane_count[p]
+        return self.buf[start:start + n].cpu().numpy().reshape(lo.plane_count[p], lo.plane_elem[p])
+
+    def lookup_hist(self) -> torch.Tensor:
+        """Multiplicity of every lookup-table row hit by this trace's range checks, per element."""
+        hl = lib().h2r_hist_len(self.chip._ctx)
+        hist = torch.zeros((self.batch, hl), dtype=torch.int32, device=self.buf.device)
+        off = self.pow_layout.off_records if self.pow_layout is not None else 0
+        check(lib().h2r_trace_lookup_hist(self.chip._ctx, self.buf.data_ptr(), off, self.elem_stride, self.batch,
+                                          self.num_mul_mods, hist.data_ptr(), self.chip._stream()), "h2r_trace_lookup_hist")
+        return hist
+
+
+@dataclass
+class BatchResult:
+    value: AssignedInteger      # a*b mod n  /  a^e mod n
+    trace: Optional[Trace]
+    status: torch.Tensor        # uint8 [batch], H2R_* per element
+
+
+class BigIntChip:
+    """reference big_integer/chip.rs:42-51, 1161-1249."""
+
+    NUM_LOOKUP_LIMBS = 8  # big_integer/chip.rs:1163
+
+    def __init__(self, limb_width: int, bits_len: int, field: str = "bn254_fr", device: int = 0):
+        """BigIntChip::new (big_integer/chip.rs:1174-1185); raises where the reference asserts."""
+        self.limb_width, self.bits_len, self.device = limb_width, bits_len, device
+        self._ctx = ctypes.c_void_p()
+        p = H2RParams(limb_width, bits_len, _lib.FIELDS[field], device)
+        check(lib().h2r_ctx_create(ctypes.byref(p), ctypes.byref(self._ctx)), "BigIntChip::new")
+        self.num_limbs = bits_len // limb_width
+        self.layout = H2RLayout()
+        check(lib().h2r_trace_layout(self._ctx, ctypes.byref(self.layout)), "h2r_trace_layout")
+        self.torch_dtype = torch.int64 if limb_width == 64 else torch.int32
+        self.np_dtype = np.uint64 if limb_width == 64 else np.uint32
+
+    def __del__(self):
+        try:
+            if self._ctx:
+                lib().h2r_ctx_destroy(self._ctx)
+                self._ctx = ctypes.c_void_p()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def compute_range_lens(limb_width: int, num_limbs: int):
+        """big_integer/chip.rs:1220-1249 -> (composition_bit_lens, overflow_bit_lens)."""
+        comp, over = (ctypes.c_uint32 * 3)(), (ctypes.c_uint32 * 3)()
+        check(lib().h2r_compute_range_lens(limb_width, num_limbs, comp, over), "compute_range_lens")
+        return list(comp), list(over)
+
+    # ---- assignment ---------------------------------------------------------------------------------
+    def assign_integer(self, integer) -> AssignedInteger:
+        """big_integer/chip.rs:62-82: here = move the limbs into HBM (the range-check sub-limbs of
+        assigned inputs are the limbs' own bytes)."""
+        if isinstance(integer, AssignedInteger):
+            return integer
+        if isinstance(integer, UnassignedInteger):
+            arr = integer.limbs
+        else:
+            arr = UnassignedInteger.from_ints(list(integer), self.num_limbs, self.limb_width).limbs
+        t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int64 if self.limb_width == 64 else np.int32))
+        return AssignedInteger(t.to("cuda:%d" % self.device).contiguous(), self.limb_width)
+
+    def _new_limbs(self, batch):
+        return torch.empty((batch, self.num_limbs), dtype=self.torch_dtype, device="cuda:%d" % self.device)
+
+    def _flags(self, n: AssignedInteger, batch: int):
+        if n.batch == 1 and batch != 1:
+            return _lib.H2R_F_SHARED_MODULUS
+        assert n.batch == batch
+        return 0
+
+    # ---- the hot path ---------------------------------------------------------------------------------
+    def mul_mod(self, a: AssignedInteger, b: AssignedInteger, n: AssignedInteger, want_trace: bool = True) -> BatchResult:
+        """big_integer/chip.rs:542-629."""
+        assert a.num_limbs() == n.num_limbs() == self.num_limbs  # :555
+        batch = a.batch
+        dev = "cuda:%d" % self.device
+        trace = torch.empty(batch * self.layout.record_stride, dtype=torch.uint8, device=dev) if want_trace else None
+        r = self._new_limbs(batch)
+        status = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        check(lib().h2r_mul_mod_batch(self._ctx, a.data_ptr(), b.data_ptr(), n.data_ptr(), batch, self._flags(n, batch),
+                                      trace.data_ptr() if want_trace else None, r.data_ptr(), status.data_ptr(), None,
+                                      self._stream()), "mul_mod")
+        return BatchResult(AssignedInteger(r, self.limb_width), Trace(self, trace, batch, None) if want_trace else None, status)
+
+    def square_mod(self, a: AssignedInteger, n: AssignedInteger, want_trace: bool = True) -> BatchResult:
+        """big_integer/chip.rs:642-649."""
+        return self.mul_mod(a, a, n, want_trace)
+
+    def pow_fixed_layout(self, e: int) -> H2RPowLayout:
+        pl = H2RPowLayout()
+        eb = _e_bytes(e)
+        check(lib().h2r_pow_fixed_layout(self._ctx, eb, len(eb), ctypes.byref(pl)), "h2r_pow_fixed_layout")
+        return pl
+
+    def pow_mod_fixed_exp(self, a: AssignedInteger, e: int, n: AssignedInteger, want_trace: bool = True,
+                          trace_buf: Optional[torch.Tensor] = None, check_in_field: bool = False,
+                          workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                          status: Optional[torch.Tensor] = None) -> BatchResult:
+        """big_integer/chip.rs:710-742 (check_in_field=True: RSAChip::modpow_public_key, src/chip.rs:99-114)."""
+        batch = a.batch
+        dev = "cuda:%d" % self.device
+        pl = self.pow_fixed_layout(e)
+        eb = _e_bytes(e)
+        if want_trace and trace_buf is None:
+            trace_buf = torch.empty(batch * pl.elem_stride, dtype=torch.uint8, device=dev)
+        out = self._new_limbs(batch) if out is None else out
+        status = torch.zeros(batch, dtype=torch.uint8, device=dev) if status is None else status
+        fn = lib().h2r_modpow_public_key_batch if check_in_field else lib().h2r_pow_mod_fixed_exp_batch
+        check(fn(self._ctx, a.data_ptr(), n.data_ptr(), eb, len(eb), batch, self._flags(n, batch),
+                 trace_buf.data_ptr() if want_trace else None, out.data_ptr(), status.data_ptr(),
+                 workspace.data_ptr() if workspace is not None else None, self._stream()), "pow_mod_fixed_exp")
+        return BatchResult(AssignedInteger(out, self.limb_width), Trace(self, trace_buf, batch, pl) if want_trace else None, status)
+
+    def pow_mod(self, a: AssignedInteger, e: AssignedInteger, n: AssignedInteger, exp_limb_bits: int,
+                want_trace: bool = True) -> BatchResult:
+        """big_integer/chip.rs:664-696: variable exponent, `exp_limb_bits` bits used per e-limb."""
+        batch = a.batch
+        dev = "cuda:%d" % self.device
+        pl = H2RPowLayout()
+        check(lib().h2r_pow_var_layout(self._ctx, e.num_limbs(), exp_limb_bits, ctypes.byref(pl)), "h2r_pow_var_layout")
+        trace = torch.empty(batch * pl.elem_stride, dtype=torch.uint8, device=dev) if want_trace else None
+        out = self._new_limbs(batch)
+        status = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        check(lib().h2r_pow_mod_batch(self._ctx, a.data_ptr(), e.data_ptr(), e.num_limbs(), exp_limb_bits, n.data_ptr(), batch,
+                                      self._flags(n, batch), trace.data_ptr() if want_trace else None, out.data_ptr(),
+                                      status.data_ptr(), None, self._stream()), "pow_mod")
+        return BatchResult(AssignedInteger(out, self.limb_width), Trace(self, trace, batch, pl) if want_trace else None, status)
+
+    def workspace_bytes(self, batch: int, num_mul_mods: int) -> int:
+        return int(lib().h2r_workspace_bytes(self._ctx, batch, num_mul_mods))

@@ -1,0 +1,568 @@
+// C ABI of libh2r (see include/h2r.h).  Host side: context, layouts, kernel launches, flatten.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "h2r.h"
+#include "h2r_kernels.hpp"
+#include "h2r_layout.hpp"
+
+using namespace h2r;
+
+namespace {
+
+thread_local char g_hip_err[256] = "";
+
+bool hip_ok(hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    std::snprintf(g_hip_err, sizeof g_hip_err, "%s: %s", what, hipGetErrorString(e));
+    return false;
+}
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        if (!hip_ok((expr), #expr)) return H2R_E_HIP;   \
+    } while (0)
+
+// ---- optional per-kernel event timing --------------------------------------------------------------
+struct ProfRec { u32 kernel; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+u32 g_prof_cap = 0;
+struct ProfScope {  // records start/stop events around one launch when profiling is armed
+    hipStream_t st; hipEvent_t a = nullptr, b = nullptr; u32 kernel; bool on = false;
+    ProfScope(u32 k, hipStream_t s) : st(s), kernel(k) {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (g_prof_cap && g_prof.size() < g_prof_cap && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) {
+            on = true; (void)hipEventRecord(a, st);
+        }
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(b, st);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(ProfRec{kernel, a, b});
+    }
+};
+
+struct Workspace {  // carve-up of the scratch of one batch call
+    u64 opA, opB, opQ, opR, total;
+};
+Workspace workspace_plan(u32 limb_bytes, u32 L, u64 batch, u32 T) {
+    Workspace w;
+    const u64 arr = round_up(batch * T * (u64)L * limb_bytes, 256);
+    w.opA = 0; w.opB = arr; w.opQ = 2 * arr; w.opR = 3 * arr; w.total = 4 * arr + 256;
+    return w;
+}
+
+}  // namespace
+
+struct h2r_ctx {
+    h2r_params params;
+    h2r_layout layout;
+    u32 L, K;           // limbs, 32-bit digits
+    U256 word_max;
+    u8 *const_rec_dev;  // device copy of the constant record
+    std::vector<u8> const_rec_host;
+    // lookup-table row offsets for the multiplicity histogram
+    u32 tab0_len, tab1_off, tab1_len, tab2_off, tab2_len, hist_len;
+};
+
+namespace {
+
+bool shape_supported(u32 w, u32 L) {
+    if (w == 64) return L == 4 || L == 8 || L == 16 || L == 32 || L == 64;
+    if (w == 32) return L == 8 || L == 32 || L == 64 || L == 128;
+    return false;
+}
+
+void put_le(u8 *dst, const U256 &v, u32 nbytes) { std::memcpy(dst, v.v, nbytes); }
+
+// Fill the input-independent planes of is_equal_muled (accumulated_extra chain, chip.rs:869-875).
+void build_const_record(h2r_ctx *c) {
+    const h2r_layout &lo = c->layout;
+    c->const_rec_host.assign(lo.record_stride, 0);
+    u8 *r = c->const_rec_host.data();
+    const u32 w = lo.limb_width, C = lo.num_cols;
+    U256 acc_extra;
+    for (u32 i = 0; i < C; ++i) {
+        acc_extra = acc_extra + c->word_max;                 // :869-870
+        U256 q_acc = acc_extra.shr(w);                       // :871
+        u64 mod_acc = acc_extra.low(w);
+        U256 nq = q_acc.shl(w);
+        put_le(r + lo.plane_off[H2R_PL_ACCX_LO] + (u64)i * 16, acc_extra, 16);
+        put_le(r + lo.plane_off[H2R_PL_NQ2_LO] + (u64)i * 16, nq, 16);
+        if (lo.plane_elem[H2R_PL_ACCX_HI]) {
+            std::memcpy(r + lo.plane_off[H2R_PL_ACCX_HI] + (u64)i * 8, &acc_extra.v[2], 8);
+            std::memcpy(r + lo.plane_off[H2R_PL_NQ2_HI] + (u64)i * 8, &nq.v[2], 8);
+        }
+        put_le(r + lo.plane_off[H2R_PL_QACC] + (u64)i * lo.carry_bytes, q_acc, lo.carry_bytes);
+        std::memcpy(r + lo.plane_off[H2R_PL_MODACC] + (u64)i * lo.limb_bytes, &mod_acc, lo.limb_bytes);
+        u64 amnq = (acc_extra - nq).low(w);
+        std::memcpy(r + lo.plane_off[H2R_PL_AMNQ2] + (u64)i * lo.limb_bytes, &amnq, lo.limb_bytes);
+        acc_extra = q_acc;                                   // :875
+    }
+}
+
+template <int LW, int L>
+hipError_t launch_trace_t(const TraceArgs &ta, hipStream_t st) {
+    constexpr int TPI = 2 * L;
+    constexpr int IPB = TPI >= 256 ? 1 : 256 / TPI;
+    const u64 blocks = (ta.n_items + IPB - 1) / IPB;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL((trace_kernel<LW, L>), dim3((unsigned)blocks), dim3(256), 0, st, ta);
+    return hipGetLastError();
+}
+hipError_t launch_trace(u32 w, u32 L, const TraceArgs &ta, hipStream_t st) {
+#define H2R_CASE(W_, L_) if (w == W_ && L == L_) return launch_trace_t<W_, L_>(ta, st)
+    H2R_CASE(64, 4); H2R_CASE(64, 8); H2R_CASE(64, 16); H2R_CASE(64, 32); H2R_CASE(64, 64);
+    H2R_CASE(32, 8); H2R_CASE(32, 32); H2R_CASE(32, 64); H2R_CASE(32, 128);
+#undef H2R_CASE
+    return hipErrorInvalidValue;
+}
+template <int K>
+hipError_t launch_chain_t(const ChainArgs &ca, hipStream_t st) {
+    if (ca.batch == 0) return hipSuccess;
+    hipLaunchKernelGGL((chain_kernel<K>), dim3((unsigned)ca.batch), dim3(64), 0, st, ca);
+    return hipGetLastError();
+}
+hipError_t launch_chain(u32 K, const ChainArgs &ca, hipStream_t st) {
+    switch (K) {
+        case 8: return launch_chain_t<8>(ca, st);
+        case 16: return launch_chain_t<16>(ca, st);
+        case 32: return launch_chain_t<32>(ca, st);
+        case 64: return launch_chain_t<64>(ca, st);
+        case 128: return launch_chain_t<128>(ca, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+struct ScratchGuard {  // stream-ordered scratch when the caller passes workspace == NULL
+    void *p = nullptr; hipStream_t st = nullptr; bool owned = false;
+    ~ScratchGuard() { if (owned && p) (void)hipFreeAsync(p, st); }
+};
+
+void fill_trace_args(const h2r_ctx *c, TraceArgs &ta) {
+    std::memset(&ta, 0, sizeof ta);
+    const h2r_layout &lo = c->layout;
+    for (int p = 0; p < H2R_PL_COUNT; ++p) ta.off[p] = lo.plane_off[p];
+    ta.wm[0] = c->word_max.v[0]; ta.wm[1] = c->word_max.v[1]; ta.wm[2] = c->word_max.v[2];
+    ta.carry_bits = lo.carry_bits; ta.carry_sub_bits = lo.carry_sub_bits;
+    ta.carry_nsub = lo.carry_nsub; ta.carry_sub_stride = lo.carry_sub_stride;
+    ta.record_stride = lo.record_stride;
+    ta.const_rec = c->const_rec_dev;
+}
+
+// Common driver: chain kernel (q, r of every mul_mod) then trace kernel (the witness records).
+int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const void *n, const void *e_limbs,
+                 u32 e_num_limbs, u32 exp_limb_bits, const ExpBits *eb, u32 check_in_field, u64 batch, u32 flags,
+                 u32 T, void *trace, u64 elem_stride, u64 off_records, const h2r_pow_layout *pl, void *out,
+                 uint8_t *status, void *workspace, hipStream_t st) {
+    if (!c || !n || !a || !status) return H2R_E_NULL;
+    if (batch == 0) return H2R_OK;
+    if (T == 0) {  // e == 0: no mul_mod at all; result is the constant 1 (chip.rs:729)
+        // handled by the chain kernel (loop of zero bits); still need a dummy ops buffer
+    }
+    HIP_TRY(hipSetDevice(c->params.device));
+    const h2r_layout &lo = c->layout;
+    const Workspace wp = workspace_plan(lo.limb_bytes, c->L, batch, T ? T : 1);
+    ScratchGuard sg; sg.st = st;
+    u8 *ws = static_cast<u8 *>(workspace);
+    if (!ws) {
+        HIP_TRY(hipMallocAsync(&sg.p, wp.total, st));
+        sg.owned = true; ws = static_cast<u8 *>(sg.p);
+    }
+    ws = reinterpret_cast<u8 *>(round_up(reinterpret_cast<u64>(ws), 256));
+    ChainArgs ca;
+    std::memset(&ca, 0, sizeof ca);
+    ca.a = static_cast<const u32 *>(a); ca.b = static_cast<const u32 *>(b); ca.n = static_cast<const u32 *>(n);
+    ca.e_limbs = static_cast<const u32 *>(e_limbs);
+    ca.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : c->K;
+    ca.batch = batch; ca.mode = mode; ca.T = T ? T : 1;
+    ca.e_num_limbs = e_num_limbs; ca.exp_limb_bits = exp_limb_bits; ca.digits_per_limb = lo.limb_width / 32;
+    ca.check_in_field = check_in_field;
+    ca.opA = reinterpret_cast<u32 *>(ws + wp.opA); ca.opB = reinterpret_cast<u32 *>(ws + wp.opB);
+    ca.opQ = reinterpret_cast<u32 *>(ws + wp.opQ); ca.opR = reinterpret_cast<u32 *>(ws + wp.opR);
+    ca.out = static_cast<u32 *>(out); ca.status = status;
+    if (pl && trace) {
+        ca.trace = static_cast<u8 *>(trace); ca.elem_stride = pl->elem_stride;
+        ca.off_e_bits = pl->off_e_bits; ca.off_selected = pl->off_selected; ca.selected_stride = pl->selected_stride;
+        ca.off_result = pl->off_result; ca.write_result_to_trace = 1;
+        if (mode != CHAIN_POW_VAR) { ca.off_e_bits = 0; ca.off_selected = 0; }
+    }
+    if (eb) ca.e = *eb;
+    {
+        ProfScope ps(H2R_KERNEL_CHAIN, st);
+        HIP_TRY(launch_chain(c->K, ca, st));
+    }
+    if (trace && T) {
+        TraceArgs ta;
+        fill_trace_args(c, ta);
+        ta.opA = ca.opA; ta.opB = ca.opB; ta.opQ = ca.opQ; ta.opR = ca.opR;
+        ta.n = n; ta.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : c->L;
+        ta.status = status; ta.n_items = batch * T; ta.T = T;
+        ta.trace = static_cast<u8 *>(trace); ta.elem_stride = elem_stride; ta.off_records = off_records;
+        ProfScope ps(H2R_KERNEL_TRACE, st);
+        HIP_TRY(launch_trace(lo.limb_width, c->L, ta, st));
+    }
+    return H2R_OK;
+}
+
+int32_t exp_to_bits(const uint8_t *e_le, size_t e_len, ExpBits *eb, u32 *T) {
+    if (!e_le && e_len) return H2R_E_NULL;
+    std::memset(eb, 0, sizeof *eb);
+    eb->nbits = exp_num_bits(e_le, e_len);
+    if (eb->nbits > 8 * sizeof eb->bytes) return H2R_E_UNSUPPORTED;
+    std::memcpy(eb->bytes, e_le, (eb->nbits + 7) / 8);
+    u32 t = 0;
+    for (u32 i = 0; i < eb->nbits; ++i) t += 1 + exp_bit(e_le, i);  // one square per bit, one mul per set bit
+    *T = t;
+    return H2R_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
+    if (!params || !out) return H2R_E_NULL;
+    *out = nullptr;
+    const u32 w = params->limb_width;
+    if (w == 0 || params->bits_len == 0 || params->bits_len % w != 0) return H2R_E_SHAPE;  // chip.rs:1175
+    const u32 L = params->bits_len / w;
+    if (w != 32 && w != 64) return H2R_E_UNSUPPORTED;
+    const u32 fbits = field_num_bits(params->field);
+    if (!fbits) return H2R_E_SHAPE;
+    if (L > 4096) return H2R_E_UNSUPPORTED;
+    U256 wm = compute_mul_word_max(w, L);
+    if (wm.bits() > fbits) return H2R_E_FIELD_TOO_SMALL;  // chip.rs:1178
+    if (!shape_supported(w, L)) return H2R_E_UNSUPPORTED;
+    h2r_ctx *c = new (std::nothrow) h2r_ctx();
+    if (!c) return H2R_E_HIP;
+    c->params = *params; c->L = L; c->K = params->bits_len / 32; c->word_max = wm; c->const_rec_dev = nullptr;
+    layout_compute(w, L, &c->layout);
+    build_const_record(c);
+    // histogram rows: composition table of the limb sub-limbs, then of the carry sub-limbs when its width
+    // differs, then the carry overflow table
+    const h2r_layout &lo = c->layout;
+    c->tab0_len = 1u << lo.limb_sub_bits;
+    if (lo.carry_sub_bits == lo.limb_sub_bits) { c->tab1_off = 0; c->tab1_len = 0; }
+    else { c->tab1_off = c->tab0_len; c->tab1_len = 1u << lo.carry_sub_bits; }
+    const u32 ovb = lo.carry_bits % lo.carry_sub_bits;
+    c->tab2_off = c->tab0_len + c->tab1_len; c->tab2_len = ovb ? (1u << ovb) : 0;
+    c->hist_len = c->tab2_off + c->tab2_len;
+    if (!hip_ok(hipSetDevice(params->device), "hipSetDevice") ||
+        !hip_ok(hipMalloc(reinterpret_cast<void **>(&c->const_rec_dev), lo.record_stride), "hipMalloc(const record)") ||
+        !hip_ok(hipMemcpy(c->const_rec_dev, c->const_rec_host.data(), lo.record_stride, hipMemcpyHostToDevice), "hipMemcpy(const record)")) {
+        if (c->const_rec_dev) (void)hipFree(c->const_rec_dev);
+        delete c;
+        return H2R_E_HIP;
+    }
+    *out = c;
+    return H2R_OK;
+}
+
+void h2r_ctx_destroy(h2r_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->const_rec_dev) { (void)hipSetDevice(ctx->params.device); (void)hipFree(ctx->const_rec_dev); }
+    delete ctx;
+}
+
+int32_t h2r_compute_range_lens(uint32_t limb_width, uint32_t num_limbs, uint32_t comp[3], uint32_t over[3]) {
+    if (!comp || !over) return H2R_E_NULL;
+    if (limb_width < kNumLookupLimbs || limb_width > 64 || num_limbs == 0) return H2R_E_SHAPE;
+    compute_range_lens(limb_width, num_limbs, comp, over);
+    return H2R_OK;
+}
+int32_t h2r_rsa_compute_range_lens(uint32_t num_limbs, uint32_t comp[4], uint32_t over[3]) {
+    if (!comp || !over) return H2R_E_NULL;
+    if (num_limbs == 0) return H2R_E_SHAPE;
+    compute_range_lens(64, num_limbs, comp, over);  // src/chip.rs:250-251, LIMB_WIDTH = 64
+    comp[3] = 32 / kNumLookupLimbs;                 // src/chip.rs:252
+    return H2R_OK;
+}
+
+int32_t h2r_trace_layout(const h2r_ctx *ctx, h2r_layout *out) {
+    if (!ctx || !out) return H2R_E_NULL;
+    *out = ctx->layout;
+    return H2R_OK;
+}
+
+int32_t h2r_pow_fixed_layout(const h2r_ctx *ctx, const uint8_t *e_le, size_t e_len, h2r_pow_layout *out) {
+    if (!ctx || !out) return H2R_E_NULL;
+    ExpBits eb; u32 T;
+    int32_t rc = exp_to_bits(e_le, e_len, &eb, &T);
+    if (rc) return rc;
+    const h2r_layout &lo = ctx->layout;
+    std::memset(out, 0, sizeof *out);
+    out->num_mul_mods = T; out->num_exp_bits = eb.nbits;
+    out->off_records = 0;
+    out->off_result = (u64)T * lo.record_stride;
+    out->off_e_bits = UINT64_MAX; out->off_selected = UINT64_MAX; out->selected_stride = 0;
+    out->elem_stride = out->off_result + round_up((u64)lo.num_limbs * lo.limb_bytes, 256);
+    out->stream_bytes = (u64)T * lo.stream_bytes + (u64)lo.num_limbs * lo.limb_bytes;
+    return H2R_OK;
+}
+
+int32_t h2r_pow_var_layout(const h2r_ctx *ctx, uint32_t e_num_limbs, uint32_t exp_limb_bits, h2r_pow_layout *out) {
+    if (!ctx || !out) return H2R_E_NULL;
+    const h2r_layout &lo = ctx->layout;
+    if (e_num_limbs == 0 || exp_limb_bits == 0 || exp_limb_bits > lo.limb_width) return H2R_E_SHAPE;
+    const u64 nbits = (u64)e_num_limbs * exp_limb_bits;
+    if (nbits > (1u << 20)) return H2R_E_UNSUPPORTED;
+    std::memset(out, 0, sizeof *out);
+    out->num_mul_mods = (u32)(2 * nbits); out->num_exp_bits = (u32)nbits;
+    out->off_records = 0;
+    const u64 limbs_bytes = round_up((u64)lo.num_limbs * lo.limb_bytes, 256);
+    out->off_selected = 2 * nbits * lo.record_stride;
+    out->selected_stride = limbs_bytes;
+    out->off_result = out->off_selected + nbits * limbs_bytes;
+    out->off_e_bits = out->off_result + limbs_bytes;
+    out->elem_stride = out->off_e_bits + round_up(nbits, 256);
+    out->stream_bytes = nbits + nbits * (2 * lo.stream_bytes + (u64)lo.num_limbs * lo.limb_bytes) + (u64)lo.num_limbs * lo.limb_bytes;
+    return H2R_OK;
+}
+
+uint64_t h2r_workspace_bytes(const h2r_ctx *ctx, uint64_t batch, uint32_t num_mul_mods) {
+    if (!ctx) return 0;
+    return workspace_plan(ctx->layout.limb_bytes, ctx->L, batch, num_mul_mods ? num_mul_mods : 1).total;
+}
+
+int32_t h2r_mul_mod_batch(const h2r_ctx *ctx, const void *a, const void *b, const void *n, uint64_t batch,
+                          uint32_t flags, void *trace, void *r_out, uint8_t *status, void *workspace,
+                          h2r_stream_t stream) {
+    if (!ctx || !b) return H2R_E_NULL;
+    return run_path(ctx, CHAIN_MULMOD, a, b, n, nullptr, 0, 0, nullptr, 0, batch, flags, 1, trace,
+                    ctx->layout.record_stride, 0, nullptr, r_out, status, workspace, static_cast<hipStream_t>(stream));
+}
+
+int32_t h2r_square_mod_batch(const h2r_ctx *ctx, const void *a, const void *n, uint64_t batch, uint32_t flags,
+                             void *trace, void *r_out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+    return h2r_mul_mod_batch(ctx, a, a, n, batch, flags, trace, r_out, status, workspace, stream);  // chip.rs:648
+}
+
+static int32_t pow_fixed_impl(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le, size_t e_len,
+                              uint64_t batch, uint32_t flags, void *trace, void *out, uint8_t *status,
+                              void *workspace, h2r_stream_t stream, u32 check_in_field) {
+    if (!ctx) return H2R_E_NULL;
+    ExpBits eb; u32 T;
+    int32_t rc = exp_to_bits(e_le, e_len, &eb, &T);
+    if (rc) return rc;
+    h2r_pow_layout pl;
+    rc = h2r_pow_fixed_layout(ctx, e_le, e_len, &pl);
+    if (rc) return rc;
+    return run_path(ctx, CHAIN_POW_FIXED, x, nullptr, n, nullptr, 0, 0, &eb, check_in_field, batch, flags, T, trace,
+                    pl.elem_stride, pl.off_records, &pl, out, status, workspace, static_cast<hipStream_t>(stream));
+}
+
+int32_t h2r_pow_mod_fixed_exp_batch(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le,
+                                    size_t e_len, uint64_t batch, uint32_t flags, void *trace, void *out,
+                                    uint8_t *status, void *workspace, h2r_stream_t stream) {
+    return pow_fixed_impl(ctx, x, n, e_le, e_len, batch, flags, trace, out, status, workspace, stream, 0);
+}
+
+int32_t h2r_modpow_public_key_batch(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le,
+                                    size_t e_len, uint64_t batch, uint32_t flags, void *trace, void *out,
+                                    uint8_t *status, void *workspace, h2r_stream_t stream) {
+    return pow_fixed_impl(ctx, x, n, e_le, e_len, batch, flags, trace, out, status, workspace, stream, 1);
+}
+
+int32_t h2r_pow_mod_batch(const h2r_ctx *ctx, const void *x, const void *e_limbs, uint32_t e_num_limbs,
+                          uint32_t exp_limb_bits, const void *n, uint64_t batch, uint32_t flags, void *trace,
+                          void *out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+    if (!ctx || !e_limbs) return H2R_E_NULL;
+    h2r_pow_layout pl;
+    int32_t rc = h2r_pow_var_layout(ctx, e_num_limbs, exp_limb_bits, &pl);
+    if (rc) return rc;
+    return run_path(ctx, CHAIN_POW_VAR, x, nullptr, n, e_limbs, e_num_limbs, exp_limb_bits, nullptr, 0, batch, flags,
+                    pl.num_mul_mods, trace, pl.elem_stride, pl.off_records, &pl, out, status, workspace,
+                    static_cast<hipStream_t>(stream));
+}
+
+int32_t h2r_range_decompose_batch(const h2r_ctx *ctx, const void *values, uint32_t value_bytes, uint64_t count,
+                                  uint32_t bit_len, uint32_t sublimb_bits, uint8_t *sublimbs_out,
+                                  uint32_t sub_stride, uint32_t *hist, h2r_stream_t stream) {
+    if (!ctx || !values) return H2R_E_NULL;
+    if ((value_bytes != 8 && value_bytes != 16) || bit_len == 0 || bit_len > 8 * value_bytes || sublimb_bits == 0 ||
+        sublimb_bits > 8)
+        return H2R_E_SHAPE;
+    DecompArgs da;
+    std::memset(&da, 0, sizeof da);
+    da.values = static_cast<const u8 *>(values); da.value_bytes = value_bytes; da.count = count;
+    da.bit_len = bit_len; da.sub_bits = sublimb_bits;
+    da.has_ov = bit_len % sublimb_bits ? 1 : 0; da.nsub = bit_len / sublimb_bits + da.has_ov;
+    if (sublimbs_out && sub_stride < da.nsub) return H2R_E_SHAPE;
+    da.sub_out = sublimbs_out; da.sub_stride = sub_stride; da.hist = hist; da.comp_len = 1u << sublimb_bits;
+    if (count == 0) return H2R_OK;
+    HIP_TRY(hipSetDevice(ctx->params.device));
+    u64 blocks = (count + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const u32 shmem = (da.comp_len + 256) * sizeof(u32);
+    hipLaunchKernelGGL(decompose_kernel, dim3((unsigned)blocks), dim3(256), shmem, static_cast<hipStream_t>(stream), da);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
+
+uint32_t h2r_hist_len(const h2r_ctx *ctx) { return ctx ? ctx->hist_len : 0; }
+
+int32_t h2r_trace_lookup_hist(const h2r_ctx *ctx, const void *trace, uint64_t first_record_off, uint64_t elem_stride,
+                              uint64_t num_elems, uint32_t records_per_elem, uint32_t *hist_out, h2r_stream_t stream) {
+    if (!ctx || !trace || !hist_out) return H2R_E_NULL;
+    if (num_elems == 0) return H2R_OK;
+    const h2r_layout &lo = ctx->layout;
+    HistArgs ha;
+    std::memset(&ha, 0, sizeof ha);
+    ha.trace = static_cast<const u8 *>(trace); ha.first_record_off = first_record_off; ha.elem_stride = elem_stride;
+    ha.record_stride = lo.record_stride; ha.num_elems = num_elems; ha.records_per_elem = records_per_elem;
+    ha.off_q_sub = lo.plane_off[H2R_PL_Q_SUB]; ha.off_r_sub = lo.plane_off[H2R_PL_R_SUB];
+    ha.off_carry_sub = lo.plane_off[H2R_PL_CARRY_SUB];
+    ha.L = lo.num_limbs; ha.C = lo.num_cols; ha.carry_nsub = lo.carry_nsub; ha.carry_sub_stride = lo.carry_sub_stride;
+    ha.carry_has_ov = (lo.carry_bits % lo.carry_sub_bits) ? 1 : 0;
+    ha.tab0_len = ctx->tab0_len; ha.tab1_off = ctx->tab1_off; ha.tab1_len = ctx->tab1_len;
+    ha.tab2_off = ctx->tab2_off; ha.tab2_len = ctx->tab2_len; ha.hist_len = ctx->hist_len;
+    ha.hist = hist_out;
+    HIP_TRY(hipSetDevice(ctx->params.device));
+    ProfScope ps(H2R_KERNEL_HIST, static_cast<hipStream_t>(stream));
+    hipLaunchKernelGGL(hist_kernel, dim3((unsigned)num_elems), dim3(256), ctx->hist_len * sizeof(u32),
+                       static_cast<hipStream_t>(stream), ha);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
+
+// ---- host-side flatten: planes -> the reference's assignment order -----------------------------------
+namespace {
+struct Out { u8 *p; };
+inline void emit(Out &o, const u8 *src, u32 n) { std::memcpy(o.p, src, n); o.p += n; }
+// WIDE value = 16-byte LO entry followed by the (wide_bytes-16)-byte HI entry
+inline void emit_wide(Out &o, const h2r_layout &lo, const u8 *rec, int pl_lo, u64 idx) {
+    emit(o, rec + lo.plane_off[pl_lo] + idx * 16, lo.wide_bytes < 16 ? lo.wide_bytes : 16);
+    if (lo.wide_bytes > 16) emit(o, rec + lo.plane_off[pl_lo + 1] + idx * 8, lo.wide_bytes - 16);
+}
+inline void emit_plane(Out &o, const h2r_layout &lo, const u8 *rec, int pl, u64 idx, u32 n) {
+    emit(o, rec + lo.plane_off[pl] + idx * lo.plane_elem[pl], n);
+}
+}  // namespace
+
+int32_t h2r_trace_flatten(const h2r_ctx *ctx, const void *record_host, void *stream_out) {
+    if (!ctx || !record_host || !stream_out) return H2R_E_NULL;
+    const h2r_layout &lo = ctx->layout;
+    const u8 *rec = static_cast<const u8 *>(record_host);
+    const u32 L = lo.num_limbs, C = lo.num_cols;
+    Out o{static_cast<u8 *>(stream_out)};
+    // T1/T2: q then r, each limb followed by its sub-limbs (chip.rs:588-599)
+    for (int which = 0; which < 2; ++which)
+        for (u32 k = 0; k < L; ++k) {
+            emit_plane(o, lo, rec, which ? H2R_PL_R : H2R_PL_Q, k, lo.limb_bytes);
+            emit_plane(o, lo, rec, which ? H2R_PL_R_SUB : H2R_PL_Q_SUB, k, lo.limb_nsub);
+        }
+    // T3/T4: mul(a,b) then mul(q,n): column i ascending, j ascending (chip.rs:400-412)
+    for (int which = 0; which < 2; ++which)
+        for (u32 i = 0; i < C; ++i) {
+            u32 j = (L >= i + 1) ? 0 : i + 1 - L;
+            for (; j < L && j <= i; ++j) emit_wide(o, lo, rec, which ? H2R_PL_QN_LO : H2R_PL_AB_LO, (u64)j * L + (i % L));
+        }
+    // T5: eq_b[i] = qn[i] + r[i], i < L (chip.rs:617)
+    for (u32 i = 0; i < L; ++i) emit_wide(o, lo, rec, H2R_PL_EQB_LO, i);
+    // T6: is_equal_muled steps (chip.rs:857-893)
+    for (u32 i = 0; i < C; ++i) {
+        emit_wide(o, lo, rec, H2R_PL_AMB_LO, i);
+        emit_wide(o, lo, rec, H2R_PL_SUM_LO, i);
+        emit_plane(o, lo, rec, H2R_PL_CARRY, i, lo.carry_bytes);
+        emit_plane(o, lo, rec, H2R_PL_CMOD, i, lo.limb_bytes);
+        emit_wide(o, lo, rec, H2R_PL_NQ1_LO, i);
+        emit_plane(o, lo, rec, H2R_PL_AMNQ1, i, lo.limb_bytes);
+        emit_wide(o, lo, rec, H2R_PL_ACCX_LO, i);
+        emit_plane(o, lo, rec, H2R_PL_QACC, i, lo.carry_bytes);
+        emit_plane(o, lo, rec, H2R_PL_MODACC, i, lo.limb_bytes);
+        emit_wide(o, lo, rec, H2R_PL_NQ2_LO, i);
+        emit_plane(o, lo, rec, H2R_PL_AMNQ2, i, lo.limb_bytes);
+        const u8 *fl = rec + lo.plane_off[H2R_PL_FLAGS] + (u64)i * 4;
+        emit(o, fl, 2);
+        if (i < C - 1) {
+            emit_plane(o, lo, rec, H2R_PL_CARRY_DUP, i, lo.carry_bytes);
+            emit_plane(o, lo, rec, H2R_PL_CARRY_SUB, i, lo.carry_nsub);
+        }
+        emit(o, fl + 2, 2);
+    }
+    if ((u64)(o.p - static_cast<u8 *>(stream_out)) != lo.stream_bytes) return H2R_E_SHAPE;
+    return H2R_OK;
+}
+
+int32_t h2r_pow_trace_flatten(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *elem_host, void *stream_out) {
+    if (!ctx || !pl || !elem_host || !stream_out) return H2R_E_NULL;
+    const h2r_layout &lo = ctx->layout;
+    const u8 *e = static_cast<const u8 *>(elem_host);
+    u8 *o = static_cast<u8 *>(stream_out);
+    const u32 limbs_bytes = lo.num_limbs * lo.limb_bytes;
+    const bool var = pl->off_e_bits != UINT64_MAX;
+    if (var) {
+        std::memcpy(o, e + pl->off_e_bits, pl->num_exp_bits); o += pl->num_exp_bits;
+        for (u32 b = 0; b < pl->num_exp_bits; ++b) {
+            int32_t rc = h2r_trace_flatten(ctx, e + pl->off_records + (u64)(2 * b) * lo.record_stride, o);
+            if (rc) return rc;
+            o += lo.stream_bytes;
+            std::memcpy(o, e + pl->off_selected + (u64)b * pl->selected_stride, limbs_bytes); o += limbs_bytes;
+            rc = h2r_trace_flatten(ctx, e + pl->off_records + (u64)(2 * b + 1) * lo.record_stride, o);
+            if (rc) return rc;
+            o += lo.stream_bytes;
+        }
+    } else {
+        for (u32 t = 0; t < pl->num_mul_mods; ++t) {
+            int32_t rc = h2r_trace_flatten(ctx, e + pl->off_records + (u64)t * lo.record_stride, o);
+            if (rc) return rc;
+            o += lo.stream_bytes;
+        }
+    }
+    std::memcpy(o, e + pl->off_result, limbs_bytes); o += limbs_bytes;
+    if ((u64)(o - static_cast<u8 *>(stream_out)) != pl->stream_bytes) return H2R_E_SHAPE;
+    return H2R_OK;
+}
+
+int32_t h2r_profile_enable(uint32_t capacity) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+    g_prof_cap = capacity;
+    if (capacity) g_prof.reserve(capacity);
+    return H2R_OK;
+}
+
+int32_t h2r_profile_read(uint32_t kernel, float *ms_out, uint32_t max_count, uint32_t *count) {
+    if (!count) return H2R_E_NULL;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    u32 n = 0;
+    for (auto &r : g_prof) {
+        if (r.kernel != kernel) continue;
+        if (ms_out && n < max_count) {
+            HIP_TRY(hipEventSynchronize(r.b));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+            ms_out[n] = ms;
+        }
+        ++n;
+    }
+    *count = n;
+    return H2R_OK;
+}
+
+const char *h2r_status_str(int32_t s) {
+    switch (s) {
+        case H2R_OK: return "ok";
+        case H2R_E_SHAPE: return "shape";
+        case H2R_E_ZERO_MODULUS: return "zero modulus";
+        case H2R_E_NOT_REDUCED: return "quotient does not fit num_limbs limbs";
+        case H2R_E_FIELD_TOO_SMALL: return "field too small for the un-carried column bound";
+        case H2R_E_HIP: return "HIP runtime error";
+        case H2R_E_UNSUPPORTED: return "unsupported shape";
+        case H2R_E_NULL: return "null pointer";
+        case H2R_E_NOT_IN_FIELD: return "x >= n";
+        default: return "unknown";
+    }
+}
+const char *h2r_last_hip_error(void) { return g_hip_err; }
+
+}  // extern "C"

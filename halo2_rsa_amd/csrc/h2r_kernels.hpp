@@ -1,0 +1,904 @@
+// gfx950 (MI355X, CDNA4, wave64) kernels of libh2r.  Hand-written HIP; no CUDA paths.
+//
+//   chain_kernel<K>   K2/K3/K5: one wave64 per element.  Runs the element's dependent chain of
+//                     modular multiplications on 32-bit digits spread one per lane (K = bits/32),
+//                     producing for every mul_mod t the operands and the TRUE quotient/remainder
+//                     (q_t, r_t) of BigIntChip::mul_mod (reference big_integer/chip.rs:562-584).
+//                     Barrett with a per-modulus reciprocal computed in-kernel (wave-parallel
+//                     Knuth D); carries are resolved with wavefront ballots.
+//   trace_kernel<W,L> K1: 2L threads per mul_mod, 256-thread workgroups.  Emits the whole witness
+//                     record of one mul_mod (mul :386-419 twice, eq_b :614-623, is_equal_muled
+//                     :822-895 incl. div_mod_main_gate :1323-1349 and the range-check sub-limbs)
+//                     as planes whose entries are written by consecutive lanes (coalesced).
+//                     Bound: HBM writes (64,338 algorithmic bytes per RSA-2048 mul_mod).
+//   hist_kernel       K4: lookup-table multiplicities of the range-check sub-limbs (LDS atomics).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "h2r.h"
+
+namespace h2r {
+
+using u8 = uint8_t;
+using u32 = uint32_t;
+using u64 = uint64_t;
+using i32 = int32_t;
+using i64 = int64_t;
+using u128 = unsigned __int128;
+
+// ------------------------------------------------------------------------------------------------
+// wavefront carry resolution
+//   Position i (lane i of a 64-lane group) generates a carry (g) or propagates an incoming one (p);
+//   g and p are mutually exclusive.  carry-in(i) = ((G << 1 | cin) + P) ^ P, one 64-bit scalar add.
+// ------------------------------------------------------------------------------------------------
+struct CarryGroup {
+    u64 cin_mask;  // bit i = carry into position i
+    bool cout;     // carry out of position width-1
+};
+__device__ __forceinline__ CarryGroup carry_group(u64 G, u64 P, bool cin, int width) {
+    u64 g1 = (G << 1) | (u64)cin;
+    u64 S = g1 + P;
+    CarryGroup r;
+    r.cin_mask = S ^ P;
+    if (width >= 64) r.cout = ((G >> 63) != 0) || (S < g1);
+    else r.cout = ((r.cin_mask >> width) & 1) != 0;
+    return r;
+}
+
+// ================================================================================================
+// K2: chain kernel
+// ================================================================================================
+enum { CHAIN_MULMOD = 0, CHAIN_POW_FIXED = 1, CHAIN_POW_VAR = 2 };
+
+struct ExpBits {
+    u32 nbits;
+    u8 bytes[512];  // e.to_bytes_le(), up to 4096 bits
+};
+
+struct ChainArgs {
+    const u32 *a;        // MULMOD: a operands; POW: x       [elem][K]
+    const u32 *b;        // MULMOD: b operands
+    const u32 *n;        // moduli [elem][K] (stride 0 when shared)
+    const u32 *e_limbs;  // POW_VAR: [elem][e_num_limbs * (limb_width/32)] digits
+    u64 n_stride;        // digits between consecutive moduli (0 = shared)
+    u64 batch;
+    u32 mode, T;         // T = mul_mods per element
+    u32 e_num_limbs, exp_limb_bits, digits_per_limb;
+    u32 check_in_field;  // modpow_public_key: status NOT_IN_FIELD when x >= n (src/chip.rs:106)
+    u32 *opA, *opB, *opQ, *opR;  // [elem*T + t][K]
+    u32 *out;            // nullable: result [elem][K]
+    u8 *status;          // [elem]
+    // POW_VAR extras written straight into the element traces
+    u8 *trace; u64 elem_stride, off_e_bits, off_selected, selected_stride, off_result;
+    u32 write_result_to_trace;
+    ExpBits e;
+};
+
+template <int K>
+struct ChainLds {
+    u32 nn[K];           // normalised modulus n' = n << s
+    u32 mu[K];           // mu' = floor((2^(64K) - 1) / n') - 2^(32K)
+    u32 acc[K], cur[K];  // chain values
+    u32 opa[K], opb[K];  // multiplication operands
+    u32 x0[2 * K], x1[2 * K], x2[2 * K], y[2 * K + 2];
+};
+
+template <int K>
+struct WaveNum {
+    static constexpr int V = (K + 63) / 64;  // digits per lane
+    static constexpr int GW = K < 64 ? K : 64;
+};
+
+// 2K-digit product of two K-digit numbers held in LDS, one wave.  Lane `lane` ends up with the
+// normalised digits of columns v = lane + 64m (plo[m]) and v + K (phi[m]).
+template <int K>
+__device__ __forceinline__ void wave_mul(const u32 *A, const u32 *B, ChainLds<K> &s, int lane,
+                                         u32 (&plo)[WaveNum<K>::V], u32 (&phi)[WaveNum<K>::V]) {
+    constexpr int V = WaveNum<K>::V;
+    constexpr int GW = WaveNum<K>::GW;
+    u64 acc[V], flo[V];
+    u32 ov[V], flo_ov[V];
+#pragma unroll
+    for (int m = 0; m < V; ++m) { acc[m] = 0; ov[m] = 0; flo[m] = 0; flo_ov[m] = 0; }
+#pragma unroll 4
+    for (int st = 0; st < K; ++st) {
+        const u32 as = A[st];  // LDS broadcast
+#pragma unroll
+        for (int m = 0; m < V; ++m) {
+            const int v = lane + 64 * m;
+            const u32 bv = B[(v - st) & (K - 1)];
+            const u64 p = (u64)as * bv;
+            const u64 t = acc[m] + p;
+            ov[m] += (t < p) ? 1u : 0u;
+            acc[m] = t;
+            if (st == v) { flo[m] = acc[m]; flo_ov[m] = ov[m]; acc[m] = 0; ov[m] = 0; }
+        }
+    }
+    __syncthreads();  // previous readers of x0..y are done
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+        const int v = lane + 64 * m;
+        if (v < K) {
+            s.x0[v] = (u32)flo[m]; s.x1[v] = (u32)(flo[m] >> 32); s.x2[v] = flo_ov[m];
+            s.x0[v + K] = (u32)acc[m]; s.x1[v + K] = (u32)(acc[m] >> 32); s.x2[v + K] = ov[m];
+        }
+    }
+    __syncthreads();
+    u32 tlo[2 * V];
+#pragma unroll
+    for (int g = 0; g < 2 * V; ++g) {
+        const int c = lane + 64 * (g % V) + (g >= V ? K : 0);
+        u64 t = 0;
+        if (lane + 64 * (g % V) < K) {
+            t = (u64)s.x0[c];
+            if (c >= 1) t += s.x1[c - 1];
+            if (c >= 2) t += s.x2[c - 2];
+            s.y[c + 1] = (u32)(t >> 32);
+        }
+        tlo[g] = (u32)t;
+    }
+    if (lane == 0) s.y[0] = 0;
+    __syncthreads();
+    bool cin = false;
+#pragma unroll
+    for (int g = 0; g < 2 * V; ++g) {
+        const int vv = lane + 64 * (g % V);
+        const int c = vv + (g >= V ? K : 0);
+        u64 d = 0;
+        bool gen = false, prop = false;
+        if (vv < K) {
+            d = (u64)tlo[g] + s.y[c];
+            gen = (d >> 32) != 0;
+            prop = ((u32)d == 0xffffffffu);
+        }
+        const CarryGroup cg = carry_group(__ballot(gen), __ballot(prop), cin, GW);
+        cin = cg.cout;
+        const u32 digit = (u32)d + (u32)((cg.cin_mask >> lane) & 1);
+        if (g < V) plo[g] = digit; else phi[g - V] = digit;
+    }
+}
+
+// K-digit a + b (+cin): returns carry out.
+template <int K>
+__device__ __forceinline__ bool wave_add(u32 (&r)[WaveNum<K>::V], const u32 (&a)[WaveNum<K>::V],
+                                         const u32 (&b)[WaveNum<K>::V], int lane) {
+    constexpr int V = WaveNum<K>::V;
+    constexpr int GW = WaveNum<K>::GW;
+    bool cin = false;
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+        const bool act = lane + 64 * m < K;
+        const u64 d = act ? (u64)a[m] + b[m] : 0;
+        const CarryGroup cg = carry_group(__ballot((d >> 32) != 0), __ballot(act && (u32)d == 0xffffffffu), cin, GW);
+        cin = cg.cout;
+        r[m] = (u32)d + (u32)((cg.cin_mask >> lane) & 1);
+    }
+    return cin;
+}
+// K-digit a - b: returns borrow out.
+template <int K>
+__device__ __forceinline__ bool wave_sub(u32 (&r)[WaveNum<K>::V], const u32 (&a)[WaveNum<K>::V],
+                                         const u32 (&b)[WaveNum<K>::V], int lane, bool bin = false) {
+    constexpr int V = WaveNum<K>::V;
+    constexpr int GW = WaveNum<K>::GW;
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+        const bool act = lane + 64 * m < K;
+        const CarryGroup cg = carry_group(__ballot(act && a[m] < b[m]), __ballot(act && a[m] == b[m]), bin, GW);
+        bin = cg.cout;
+        r[m] = a[m] - b[m] - (u32)((cg.cin_mask >> lane) & 1);
+    }
+    return bin;
+}
+// a >= b over K digits.
+template <int K>
+__device__ __forceinline__ bool wave_ge(const u32 (&a)[WaveNum<K>::V], const u32 (&b)[WaveNum<K>::V], int lane) {
+    constexpr int V = WaveNum<K>::V;
+#pragma unroll
+    for (int m = V - 1; m >= 0; --m) {
+        const bool act = lane + 64 * m < K;
+        const u64 ne = __ballot(act && a[m] != b[m]);
+        if (ne) {
+            const u64 gt = __ballot(act && a[m] > b[m]);
+            const int top = 63 - __builtin_clzll(ne);
+            return ((gt >> top) & 1) != 0;
+        }
+    }
+    return true;
+}
+// a += 1: returns carry out.
+template <int K>
+__device__ __forceinline__ bool wave_inc(u32 (&a)[WaveNum<K>::V], int lane) {
+    constexpr int V = WaveNum<K>::V;
+    constexpr int GW = WaveNum<K>::GW;
+    bool cin = true;
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+        const bool act = lane + 64 * m < K;
+        const CarryGroup cg = carry_group(0, __ballot(act && a[m] == 0xffffffffu), cin, GW);
+        cin = cg.cout;
+        a[m] += (u32)((cg.cin_mask >> lane) & 1);
+    }
+    return cin;
+}
+
+template <int K>
+__device__ __forceinline__ void lds_store(u32 *dst, const u32 (&r)[WaveNum<K>::V], int lane) {
+#pragma unroll
+    for (int m = 0; m < WaveNum<K>::V; ++m) if (lane + 64 * m < K) dst[lane + 64 * m] = r[m];
+}
+template <int K>
+__device__ __forceinline__ void lds_load(u32 (&r)[WaveNum<K>::V], const u32 *src, int lane) {
+#pragma unroll
+    for (int m = 0; m < WaveNum<K>::V; ++m) r[m] = (lane + 64 * m < K) ? src[lane + 64 * m] : 0;
+}
+template <int K>
+__device__ __forceinline__ void glb_store(u32 *dst, const u32 (&r)[WaveNum<K>::V], int lane) {
+#pragma unroll
+    for (int m = 0; m < WaveNum<K>::V; ++m) if (lane + 64 * m < K) dst[lane + 64 * m] = r[m];
+}
+
+// mu' = floor(((~n') * 2^(32K) + 2^(32K) - 1) / n')  by wave-parallel Knuth algorithm D
+// (n' normalised: top bit set).  Result left in s.mu.
+template <int K>
+__device__ __forceinline__ void wave_reciprocal(ChainLds<K> &s, int lane) {
+    constexpr int V = WaveNum<K>::V;
+    constexpr int GW = WaveNum<K>::GW;
+    u32 nn[V], rem[V];
+    lds_load<K>(nn, s.nn, lane);
+#pragma unroll
+    for (int m = 0; m < V; ++m) rem[m] = ~nn[m];
+    const u32 ntop = s.nn[K - 1];
+    for (int j = K - 1; j >= 0; --j) {
+        __syncthreads();
+        lds_store<K>(s.x0, rem, lane);
+        __syncthreads();
+        const u32 top = s.x0[K - 1], second = (K >= 2) ? s.x0[K - 2] : 0xffffffffu;
+        // 2-by-1 estimate of the quotient digit
+        u64 qd;
+        if (top >= ntop) qd = 0xffffffffull;
+        else {
+            const u64 num = ((u64)top << 32) | second;
+            qd = (u64)((double)num / (double)ntop);
+            if (qd > 0xffffffffull) qd = 0xffffffffull;
+            // exact fix-up (|error| <= 1 before clamping)
+            u128 prod = (u128)qd * ntop;
+            if (prod > num) { qd -= 1; prod -= ntop; }
+            if ((u128)num - prod >= ntop && qd < 0xffffffffull) { qd += 1; }
+        }
+        // e = qd * n' as K+1 normalised digits
+        u32 plo[V], phi_prev[V], remsh[V];
+#pragma unroll
+        for (int m = 0; m < V; ++m) {
+            const int v = lane + 64 * m;
+            const u64 p = (u64)(u32)qd * nn[m];
+            plo[m] = (u32)p;
+            if (v < K) s.x1[v] = (u32)(p >> 32);
+        }
+        __syncthreads();
+        bool cin = false;
+        u32 e[V];
+#pragma unroll
+        for (int m = 0; m < V; ++m) {
+            const int v = lane + 64 * m;
+            const bool act = v < K;
+            phi_prev[m] = (act && v >= 1) ? s.x1[v - 1] : 0;
+            remsh[m] = act ? (v >= 1 ? s.x0[v - 1] : 0xffffffffu) : 0;
+            const u64 d = act ? (u64)plo[m] + phi_prev[m] : 0;
+            const CarryGroup cg = carry_group(__ballot((d >> 32) != 0), __ballot(act && (u32)d == 0xffffffffu), cin, GW);
+            cin = cg.cout;
+            e[m] = (u32)d + (u32)((cg.cin_mask >> lane) & 1);
+        }
+        const u32 etop = s.x1[K - 1] + (cin ? 1u : 0u);
+        // rem'' = rem' - e
+        u32 diff[V];
+        const bool bout = wave_sub<K>(diff, remsh, e, lane);
+        i64 dtop = (i64)top - (i64)etop - (bout ? 1 : 0);
+        while (dtop < 0) {  // qd was too large (at most twice): add n' back
+            u32 t2[V];
+            const bool c = wave_add<K>(t2, diff, nn, lane);
+#pragma unroll
+            for (int m = 0; m < V; ++m) diff[m] = t2[m];
+            dtop += c ? 1 : 0;
+            qd -= 1;
+        }
+#pragma unroll
+        for (int m = 0; m < V; ++m) rem[m] = diff[m];
+        if (lane == 0) s.mu[j] = (u32)qd;
+    }
+    __syncthreads();
+}
+
+// Shift a 2K-digit number (s.x0[0..2K)) left by sh bits into (lo, hi); returns true when bits are lost.
+template <int K>
+__device__ __forceinline__ bool wave_shl2k(ChainLds<K> &s, u32 sh, int lane, u32 (&lo)[WaveNum<K>::V], u32 (&hi)[WaveNum<K>::V]) {
+    constexpr int V = WaveNum<K>::V;
+    const int ws = (int)(sh >> 5), bs = (int)(sh & 31);
+    bool lost = false;
+#pragma unroll
+    for (int g = 0; g < 2 * V; ++g) {
+        const int vv = lane + 64 * (g % V);
+        const int c = vv + (g >= V ? K : 0);
+        u32 d = 0;
+        if (vv < K) {
+            const int i0 = c - ws, i1 = c - ws - 1;
+            const u32 a0 = (i0 >= 0) ? s.x0[i0] : 0, a1 = (i1 >= 0) ? s.x0[i1] : 0;
+            d = bs ? ((a0 << bs) | (a1 >> (32 - bs))) : a0;
+            // digits shifted out of the top: source index i with i + ws >= 2K, or the top bits of index 2K-1-ws
+            const int src = c;  // this lane also inspects source digit c
+            bool l = false;
+            if (src + ws >= 2 * K) l = s.x0[src] != 0;
+            else if (src + ws == 2 * K - 1 && bs) l = (s.x0[src] >> (32 - bs)) != 0;
+            lost = lost || l;
+        }
+        if (g < V) lo[g] = d; else hi[g - V] = d;
+    }
+    return __ballot(lost) != 0;
+}
+// K-digit right shift by sh bits of (s.x0[0..K) plus the extra top digit s.x0[K]).
+template <int K>
+__device__ __forceinline__ void wave_shr(ChainLds<K> &s, u32 sh, int lane, u32 (&r)[WaveNum<K>::V]) {
+    constexpr int V = WaveNum<K>::V;
+    const int ws = (int)(sh >> 5), bs = (int)(sh & 31);
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+        const int v = lane + 64 * m;
+        u32 d = 0;
+        if (v < K) {
+            const int i0 = v + ws, i1 = v + ws + 1;
+            const u32 a0 = (i0 <= K) ? s.x0[i0] : 0, a1 = (i1 <= K) ? s.x0[i1] : 0;
+            d = bs ? ((a0 >> bs) | (a1 << (32 - bs))) : a0;
+        }
+        r[m] = d;
+    }
+}
+
+// One BigIntChip::mul_mod's off-circuit arithmetic (reference big_integer/chip.rs:562-584):
+// (q, r) = divmod(opa * opb, n).  Operands in s.opa / s.opb; returns status.
+template <int K>
+__device__ __forceinline__ int wave_mulmod(ChainLds<K> &s, u32 shift, int lane, u32 (&q)[WaveNum<K>::V], u32 (&r)[WaveNum<K>::V]) {
+    constexpr int V = WaveNum<K>::V;
+    u32 xlo[V], xhi[V];
+    wave_mul<K>(s.opa, s.opb, s, lane, xlo, xhi);
+    if (shift) {  // x' = x << s  (n' = n << s); wave-uniform branch
+        __syncthreads();
+        lds_store<K>(s.x0, xlo, lane); lds_store<K>(s.x0 + K, xhi, lane);
+        __syncthreads();
+        if (wave_shl2k<K>(s, shift, lane, xlo, xhi)) return H2R_E_NOT_REDUCED;
+    }
+    // q^ = x1 + floor(x1 * mu' / 2^(32K)),  x1 = floor(x' / 2^(32K))
+    __syncthreads();
+    lds_store<K>(s.opa, xhi, lane);
+    __syncthreads();
+    u32 ylo[V], yhi[V];
+    wave_mul<K>(s.opa, s.mu, s, lane, ylo, yhi);
+    if (wave_add<K>(q, xhi, yhi, lane)) return H2R_E_NOT_REDUCED;
+    // R = x' - q^ * n'   (0 <= R < 5 n')
+    __syncthreads();
+    lds_store<K>(s.opa, q, lane);
+    __syncthreads();
+    u32 zlo[V], zhi[V];
+    wave_mul<K>(s.opa, s.nn, s, lane, zlo, zhi);
+    u32 rl[V], nn[V];
+    const bool b0 = wave_sub<K>(rl, xlo, zlo, lane);
+    u32 rtop = __shfl(xhi[0] - zhi[0] - (b0 ? 1u : 0u), 0);
+    lds_load<K>(nn, s.nn, lane);
+    for (int it = 0; it < 8; ++it) {
+        if (rtop == 0 && !wave_ge<K>(rl, nn, lane)) break;
+        u32 t[V];
+        const bool bo = wave_sub<K>(t, rl, nn, lane);
+#pragma unroll
+        for (int m = 0; m < V; ++m) rl[m] = t[m];
+        rtop -= bo ? 1u : 0u;
+        if (wave_inc<K>(q, lane)) return H2R_E_NOT_REDUCED;
+    }
+    if (shift) {  // r = R >> s
+        __syncthreads();
+        lds_store<K>(s.x0, rl, lane);
+        if (lane == 0) s.x0[K] = 0;
+        __syncthreads();
+        wave_shr<K>(s, shift, lane, r);
+    } else {
+#pragma unroll
+        for (int m = 0; m < V; ++m) r[m] = rl[m];
+    }
+    return H2R_OK;
+}
+
+template <int K>
+__global__ __launch_bounds__(64) void chain_kernel(ChainArgs args) {
+    constexpr int V = WaveNum<K>::V;
+    __shared__ ChainLds<K> s;
+    const int lane = threadIdx.x;
+    const u64 elem = blockIdx.x;
+    if (elem >= args.batch) return;
+    const u32 *n_g = args.n + elem * args.n_stride;
+    u32 nraw[V];
+#pragma unroll
+    for (int m = 0; m < V; ++m) nraw[m] = (lane + 64 * m < K) ? n_g[lane + 64 * m] : 0;
+    // normalisation shift: leading zero bits of n within 32K bits
+    int top_digit = -1;
+#pragma unroll
+    for (int m = V - 1; m >= 0; --m) {
+        const u64 nz = __ballot(nraw[m] != 0);
+        if (nz && top_digit < 0) top_digit = 64 * m + (63 - __builtin_clzll(nz));
+    }
+    int status = H2R_OK;
+    if (top_digit < 0) status = H2R_E_ZERO_MODULUS;  // reference divides by zero, chip.rs:566
+    u32 shift = 0;
+    if (status == H2R_OK) {
+        lds_store<K>(s.x0, nraw, lane);
+        for (int i = lane; i < K; i += 64) s.x0[K + i] = 0;
+        __syncthreads();
+        const u32 topv = s.x0[top_digit];
+        shift = 32u * (u32)(K - 1 - top_digit) + (u32)__builtin_clz(topv);
+        u32 nlo[V], nhi[V];
+        if (shift) { wave_shl2k<K>(s, shift, lane, nlo, nhi); }
+        else {
+#pragma unroll
+            for (int m = 0; m < V; ++m) nlo[m] = nraw[m];
+        }
+        __syncthreads();
+        lds_store<K>(s.nn, nlo, lane);
+        __syncthreads();
+        wave_reciprocal<K>(s, lane);
+    }
+    u32 q[V], r[V];
+    const u64 item0 = elem * args.T;
+    if (status == H2R_OK && args.mode == CHAIN_MULMOD) {
+        u32 a[V], b[V];
+#pragma unroll
+        for (int m = 0; m < V; ++m) {
+            const int v = lane + 64 * m;
+            a[m] = v < K ? args.a[elem * K + v] : 0;
+            b[m] = v < K ? args.b[elem * K + v] : 0;
+        }
+        __syncthreads();
+        lds_store<K>(s.opa, a, lane); lds_store<K>(s.opb, b, lane);
+        __syncthreads();
+        status = wave_mulmod<K>(s, shift, lane, q, r);
+        if (status == H2R_OK) {
+            glb_store<K>(args.opA + item0 * K, a, lane); glb_store<K>(args.opB + item0 * K, b, lane);
+            glb_store<K>(args.opQ + item0 * K, q, lane); glb_store<K>(args.opR + item0 * K, r, lane);
+            if (args.out) glb_store<K>(args.out + elem * K, r, lane);
+        }
+    } else if (status == H2R_OK) {
+        // pow_mod_fixed_exp (chip.rs:710-742) / pow_mod (chip.rs:664-696)
+        u32 x[V], one[V];
+#pragma unroll
+        for (int m = 0; m < V; ++m) {
+            const int v = lane + 64 * m;
+            x[m] = v < K ? args.a[elem * K + v] : 0;
+            one[m] = (v == 0) ? 1u : 0u;  // acc = const 1 padded to num_limbs (:729 / :682)
+        }
+        if (args.check_in_field && wave_ge<K>(x, nraw, lane)) status = H2R_E_NOT_IN_FIELD;  // src/chip.rs:106
+        __syncthreads();
+        lds_store<K>(s.cur, x, lane); lds_store<K>(s.acc, one, lane);
+        __syncthreads();
+        u32 t = 0;
+        const bool var = args.mode == CHAIN_POW_VAR;
+        const u32 nbits = var ? args.e_num_limbs * args.exp_limb_bits : args.e.nbits;
+        u8 *etrace = args.trace ? args.trace + elem * args.elem_stride : nullptr;
+        for (u32 bi = 0; bi < nbits && status == H2R_OK; ++bi) {
+            u32 bit;
+            if (var) {  // main_gate.to_bits per e-limb, LSB first (chip.rs:674-681)
+                const u32 limb = bi / args.exp_limb_bits, pos = bi % args.exp_limb_bits;
+                const u32 *eg = args.e_limbs + (elem * args.e_num_limbs + limb) * args.digits_per_limb;
+                bit = (eg[pos >> 5] >> (pos & 31)) & 1u;
+                if (etrace && lane == 0) etrace[args.off_e_bits + bi] = (u8)bit;
+            } else {
+                bit = (args.e.bytes[bi >> 3] >> (bi & 7)) & 1u;
+            }
+            u32 cur[V], acc[V];
+            lds_load<K>(cur, s.cur, lane); lds_load<K>(acc, s.acc, lane);
+            if (var) {
+                // muled = mul_mod(acc, squared) ALWAYS (:686); acc[j] = select(muled[j], acc[j], bit) (:688-691)
+                __syncthreads();
+                lds_store<K>(s.opa, acc, lane); lds_store<K>(s.opb, cur, lane);
+                __syncthreads();
+                status = wave_mulmod<K>(s, shift, lane, q, r);
+                if (status != H2R_OK) break;
+                const u64 it = item0 + t;
+                glb_store<K>(args.opA + it * K, acc, lane); glb_store<K>(args.opB + it * K, cur, lane);
+                glb_store<K>(args.opQ + it * K, q, lane); glb_store<K>(args.opR + it * K, r, lane);
+                ++t;
+#pragma unroll
+                for (int m = 0; m < V; ++m) acc[m] = bit ? r[m] : acc[m];
+                if (etrace) glb_store<K>((u32 *)(etrace + args.off_selected + (u64)bi * args.selected_stride), acc, lane);
+                __syncthreads();
+                lds_store<K>(s.acc, acc, lane);
+            }
+            // squared = square_mod(cur) (:734 resp. :693)
+            __syncthreads();
+            lds_store<K>(s.opa, cur, lane); lds_store<K>(s.opb, cur, lane);
+            __syncthreads();
+            status = wave_mulmod<K>(s, shift, lane, q, r);
+            if (status != H2R_OK) break;
+            {
+                const u64 it = item0 + t;
+                glb_store<K>(args.opA + it * K, cur, lane); glb_store<K>(args.opB + it * K, cur, lane);
+                glb_store<K>(args.opQ + it * K, q, lane); glb_store<K>(args.opR + it * K, r, lane);
+                ++t;
+            }
+            __syncthreads();
+            lds_store<K>(s.cur, r, lane);
+            if (!var && bit) {  // acc = mul_mod(acc, cur_sq) with the value BEFORE this squaring (:732-739)
+                __syncthreads();
+                lds_store<K>(s.opa, acc, lane); lds_store<K>(s.opb, cur, lane);
+                __syncthreads();
+                status = wave_mulmod<K>(s, shift, lane, q, r);
+                if (status != H2R_OK) break;
+                const u64 it = item0 + t;
+                glb_store<K>(args.opA + it * K, acc, lane); glb_store<K>(args.opB + it * K, cur, lane);
+                glb_store<K>(args.opQ + it * K, q, lane); glb_store<K>(args.opR + it * K, r, lane);
+                ++t;
+                __syncthreads();
+                lds_store<K>(s.acc, r, lane);
+            }
+            __syncthreads();
+        }
+        if (status == H2R_OK) {
+            u32 acc[V];
+            __syncthreads();
+            lds_load<K>(acc, s.acc, lane);
+            if (args.out) glb_store<K>(args.out + elem * K, acc, lane);
+            if (etrace && args.write_result_to_trace) glb_store<K>((u32 *)(etrace + args.off_result), acc, lane);
+        }
+    }
+    if (lane == 0) args.status[elem] = (u8)status;
+}
+
+// ================================================================================================
+// K1: trace kernel
+// ================================================================================================
+template <int LW> struct LimbT;
+template <> struct LimbT<64> { using type = u64; };
+template <> struct LimbT<32> { using type = u32; };
+
+// Wide values: up to 160 bits for 64-bit limbs (u128 + u32), 128 bits for 32-bit limbs.
+template <int LW> struct Wide;
+template <> struct Wide<64> {
+    u128 lo; u32 hi;
+    __device__ __forceinline__ static Wide zero() { return Wide{0, 0}; }
+    __device__ __forceinline__ static Wide from(u128 x) { return Wide{x, 0}; }
+    __device__ __forceinline__ Wide operator+(const Wide &o) const { Wide r; r.lo = lo + o.lo; r.hi = hi + o.hi + (r.lo < lo ? 1u : 0u); return r; }
+    __device__ __forceinline__ Wide operator-(const Wide &o) const { Wide r; r.lo = lo - o.lo; r.hi = hi - o.hi - (lo < o.lo ? 1u : 0u); return r; }
+    __device__ __forceinline__ u64 low_limb() const { return (u64)lo; }
+    __device__ __forceinline__ Wide shr_limb() const { Wide r; r.lo = (lo >> 64) | ((u128)hi << 64); r.hi = 0; return r; }
+    __device__ __forceinline__ Wide shl_limb() const { Wide r; r.lo = lo << 64; r.hi = (u32)(lo >> 64); return r; }
+    __device__ __forceinline__ u64 hi_word() const { return (u64)(i64)(i32)hi; }  // sign-extended third word
+};
+template <> struct Wide<32> {
+    u128 lo;
+    __device__ __forceinline__ static Wide zero() { return Wide{0}; }
+    __device__ __forceinline__ static Wide from(u128 x) { return Wide{x}; }
+    __device__ __forceinline__ Wide operator+(const Wide &o) const { return Wide{lo + o.lo}; }
+    __device__ __forceinline__ Wide operator-(const Wide &o) const { return Wide{lo - o.lo}; }
+    __device__ __forceinline__ u64 low_limb() const { return (u64)(u32)lo; }
+    __device__ __forceinline__ Wide shr_limb() const { return Wide{lo >> 32}; }
+    __device__ __forceinline__ Wide shl_limb() const { return Wide{lo << 32}; }
+    __device__ __forceinline__ u64 hi_word() const { return 0; }
+};
+
+struct TraceArgs {
+    const void *opA, *opB, *opQ, *opR;  // [item][L] limbs
+    const void *n;                      // [elem][L] limbs
+    u64 n_stride;                       // limbs between moduli (0 = shared)
+    const u8 *status;                   // [elem]; nonzero => skip the element's items
+    u64 n_items; u32 T;                 // item = elem*T + t
+    u8 *trace; u64 elem_stride, off_records, record_stride;
+    const u8 *const_rec;                // a record whose ACCX/QACC/MODACC/NQ2/AMNQ2 planes hold the (w,L) constants
+    u64 off[H2R_PL_COUNT];
+    u64 wm[3];                          // word_max (chip.rs:838)
+    u32 carry_bits, carry_sub_bits, carry_nsub, carry_sub_stride;
+};
+
+template <int LW, int L>
+struct TraceLds {
+    using limb_t = typename LimbT<LW>::type;
+    limb_t A[2][L];  // [0] = a, [1] = q
+    limb_t B[2][L];  // [0] = b, [1] = n
+    limb_t r[L];
+    u64 c0[2][2 * L], c1[2][2 * L];  // final columns: [0] ab, [1] eq_b   (words 0, 1)
+    u32 c2[2][2 * L];                //                                    (word 2)
+    u64 dhi0[2 * L]; u32 dhi1[2 * L]; u32 shi[2 * L];
+};
+
+__device__ __forceinline__ void st16(u8 *p, u64 a, u64 b) {
+    *reinterpret_cast<ulonglong2 *>(p) = make_ulonglong2(a, b);
+}
+__device__ __forceinline__ void st8(u8 *p, u64 a) { *reinterpret_cast<u64 *>(p) = a; }
+__device__ __forceinline__ void st4(u8 *p, u32 a) { *reinterpret_cast<u32 *>(p) = a; }
+
+template <int LW>
+__device__ __forceinline__ void store_wide(u8 *rec, const u64 *off, int pl_lo, u64 idx, const Wide<LW> &v) {
+    st16(rec + off[pl_lo] + idx * 16, (u64)v.lo, (u64)(v.lo >> 64));
+    if constexpr (LW == 64) st8(rec + off[pl_lo + 1] + idx * 8, v.hi_word());
+}
+template <int LW>
+__device__ __forceinline__ void store_limb(u8 *rec, const u64 *off, int pl, u64 idx, u64 v) {
+    if constexpr (LW == 64) st8(rec + off[pl] + idx * 8, v); else st4(rec + off[pl] + idx * 4, (u32)v);
+}
+// CARRY-class value (carry_bits bits): 16 bytes for 64-bit limbs, 8 for 32-bit limbs.
+template <int LW>
+__device__ __forceinline__ void store_carry(u8 *rec, const u64 *off, int pl, u64 idx, const Wide<LW> &v) {
+    if constexpr (LW == 64) st16(rec + off[pl] + idx * 16, (u64)v.lo, (u64)(v.lo >> 64)); else st8(rec + off[pl] + idx * 8, (u64)v.lo);
+}
+// one byte per sub-limb (RangeChip::assign decomposition of a limb: limb_width/8 bits each, 8 of them)
+template <int LW>
+__device__ __forceinline__ u64 limb_sub_bytes(u64 v) {
+    if constexpr (LW == 64) return v;  // 8-bit sub-limbs: the bytes themselves
+    else {                             // 4-bit sub-limbs -> one byte each
+        u64 x = v & 0xffffffffull;
+        x = (x | (x << 16)) & 0x0000ffff0000ffffull;
+        x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
+        x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+        return x;
+    }
+}
+
+template <int LW, int L>
+__global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
+    using limb_t = typename LimbT<LW>::type;
+    using W = Wide<LW>;
+    constexpr int TPI = 2 * L;                   // threads per item
+    constexpr int IPB = TPI >= 256 ? 1 : 256 / TPI;  // items per block
+    constexpr int C = 2 * L - 1;
+    constexpr int WPI = TPI / 64 > 0 ? TPI / 64 : 1;  // waves per item (when TPI >= 64)
+    static_assert(TPI <= 256, "num_limbs > 128 not supported");
+    __shared__ TraceLds<LW, L> lds_all[IPB];
+    __shared__ u64 xg[4], xp[4], xbad[4];  // per-wave carry masks for multi-wave items
+
+    const int tid = threadIdx.x;
+    const int slot = tid / TPI, t = tid % TPI;
+    const int h = t / L, i = t % L;
+    const int lane = tid & 63, wave = tid >> 6;
+    TraceLds<LW, L> &s = lds_all[slot];
+    const u64 item = (u64)blockIdx.x * IPB + slot;
+    const bool in_range = item < args.n_items;
+    const u64 elem = in_range ? item / args.T : 0;
+    const u32 tt = in_range ? (u32)(item % args.T) : 0;
+    const bool live = in_range && (args.status == nullptr || args.status[elem] == 0);
+    u8 *rec = args.trace + elem * args.elem_stride + args.off_records + (u64)tt * args.record_stride;
+    const u64 *off = args.off;
+
+    // ---- stage operands in LDS; emit q, r and their sub-limbs (chip.rs:588-599) -------------------
+    if (live) {
+        const limb_t *gA = reinterpret_cast<const limb_t *>(h == 0 ? args.opA : args.opQ) + item * L;
+        const limb_t *gB = h == 0 ? reinterpret_cast<const limb_t *>(args.opB) + item * L
+                                  : reinterpret_cast<const limb_t *>(args.n) + elem * args.n_stride;
+        const limb_t av = gA[i], bv = gB[i];
+        s.A[h][i] = av; s.B[h][i] = bv;
+        if (h == 1) {
+            const limb_t rv = reinterpret_cast<const limb_t *>(args.opR)[item * L + i];
+            s.r[i] = rv;
+            store_limb<LW>(rec, off, H2R_PL_Q, i, av);
+            store_limb<LW>(rec, off, H2R_PL_R, i, rv);
+            st8(rec + off[H2R_PL_Q_SUB] + (u64)i * 8, limb_sub_bytes<LW>(av));
+            st8(rec + off[H2R_PL_R_SUB] + (u64)i * 8, limb_sub_bytes<LW>(rv));
+        }
+    }
+    __syncthreads();
+
+    // ---- BigIntChip::mul twice (chip.rs:386-419): lanes [0,L) a*b, lanes [L,2L) q*n ---------------
+    // Lane i owns column i (steps s <= i) and then column i+L (steps s > i); step s multiplies
+    // A[s] * B[(i-s) mod L], so every product a[j]*b[k] is visited once, in ascending j per column.
+    W acc = W::zero(), first = W::zero();
+    if (live) {
+        u8 *plo = rec + off[h == 0 ? H2R_PL_AB_LO : H2R_PL_QN_LO];
+        u8 *phi = rec + off[h == 0 ? H2R_PL_AB_HI : H2R_PL_QN_HI];
+#pragma unroll 4
+        for (int st = 0; st < L; ++st) {
+            const limb_t x = s.A[h][st];
+            const limb_t y = s.B[h][(i - st) & (L - 1)];
+            W p;
+            if constexpr (LW == 64) p = W::from((u128)x * y); else p = W::from((u128)((u64)x * y));
+            acc = (st == i + 1) ? p : acc + p;
+            const u64 idx = (u64)st * L + i;
+            st16(plo + idx * 16, (u64)acc.lo, (u64)(acc.lo >> 64));
+            if constexpr (LW == 64) st8(phi + idx * 8, acc.hi_word());
+            if (st == i) first = acc;
+        }
+        // final columns -> LDS; eq_b[i] = qn[i] + r[i] for i < L (chip.rs:614-623)
+        if (h == 1) {
+            first = first + W::from((u128)s.r[i]);
+            store_wide<LW>(rec, off, H2R_PL_EQB_LO, i, first);
+        }
+        s.c0[h][i] = (u64)first.lo; s.c1[h][i] = (u64)(first.lo >> 64);
+        if constexpr (LW == 64) s.c2[h][i] = first.hi;
+        if (i < L - 1) {
+            s.c0[h][i + L] = (u64)acc.lo; s.c1[h][i + L] = (u64)(acc.lo >> 64);
+            if constexpr (LW == 64) s.c2[h][i + L] = acc.hi;
+        }
+    }
+    __syncthreads();
+
+    // ---- BigIntChip::is_equal_muled (chip.rs:822-895): thread t = column c -------------------------
+    const int c = t;
+    const bool col = live && c < C;
+    W wm; wm.lo = ((u128)args.wm[1] << 64) | args.wm[0];
+    if constexpr (LW == 64) wm.hi = (u32)args.wm[2];
+    W a_b = W::zero(), D = W::zero();
+    u64 dlo = 0; W dhi = W::zero();
+    if (col) {
+        W A, Bq;
+        A.lo = ((u128)s.c1[0][c] << 64) | s.c0[0][c];
+        Bq.lo = ((u128)s.c1[1][c] << 64) | s.c0[1][c];
+        if constexpr (LW == 64) { A.hi = s.c2[0][c]; Bq.hi = s.c2[1][c]; }
+        a_b = A - Bq;              // :859 (two's complement)
+        D = a_b + wm;              // >= 0
+        dlo = D.low_limb();
+        dhi = D.shr_limb();
+        s.dhi0[c] = (u64)dhi.lo; s.dhi1[c] = (u32)(dhi.lo >> 64);
+    }
+    __syncthreads();
+    W dhi_prev = W::zero();
+    u64 slo = 0; u32 shi = 0;
+    if (col) {
+        if (c > 0) dhi_prev.lo = ((u128)s.dhi1[c - 1] << 64) | s.dhi0[c - 1];
+        const W S = W::from((u128)dlo) + dhi_prev;
+        slo = S.low_limb();
+        shi = (u32)S.shr_limb().lo;
+        s.shi[c] = shi;
+    }
+    __syncthreads();
+    u32 shi_prev = 0; bool gen = false, prop = false;
+    if (col) {
+        shi_prev = c > 0 ? s.shi[c - 1] : 0;
+        const u128 U = (u128)slo + shi_prev;
+        constexpr u64 mask = LW == 64 ? ~0ull : 0xffffffffull;
+        gen = (U >> LW) != 0;
+        prop = ((u64)U & mask) == mask;
+    }
+    // carry-in bit f[c]: within-wave ballots, chained across the waves of a multi-wave item
+    const u64 G = __ballot(gen), P = __ballot(prop);
+    bool f;
+    if constexpr (TPI <= 64) {
+        const CarryGroup cg = carry_group(G, P, false, 64);
+        f = ((cg.cin_mask >> lane) & 1) != 0;
+    } else {
+        if (lane == 0) { xg[wave] = G; xp[wave] = P; }
+        __syncthreads();
+        const int w0 = (wave / WPI) * WPI;  // first wave of this item
+        bool cin = false;
+        for (int k = w0; k < wave; ++k) cin = carry_group(xg[k], xp[k], cin, 64).cout;
+        const CarryGroup cg = carry_group(G, P, cin, 64);
+        f = ((cg.cin_mask >> lane) & 1) != 0;
+    }
+    bool f1 = true, f2 = true;
+    W carry_out = W::zero();
+    u64 cmod = 0;
+    if (col) {
+        const W carry_in = dhi_prev + W::from((u128)shi_prev + (f ? 1u : 0u));
+        const W sum = D + carry_in;                       // :860-861
+        cmod = sum.low_limb();                            // :864 div_mod r
+        carry_out = sum.shr_limb();                       //            q
+        const W nq = carry_out.shl_limb();                // :1345
+        store_wide<LW>(rec, off, H2R_PL_AMB_LO, c, a_b);
+        store_wide<LW>(rec, off, H2R_PL_SUM_LO, c, sum);
+        store_carry<LW>(rec, off, H2R_PL_CARRY, c, carry_out);
+        store_limb<LW>(rec, off, H2R_PL_CMOD, c, cmod);
+        store_wide<LW>(rec, off, H2R_PL_NQ1_LO, c, nq);
+        store_limb<LW>(rec, off, H2R_PL_AMNQ1, c, (sum - nq).low_limb());   // :1346
+        // input-independent part of the step (acc_extra chain, :869-871): copy from the constant record
+        const u8 *cr = args.const_rec;
+        const ulonglong2 ax = *reinterpret_cast<const ulonglong2 *>(cr + off[H2R_PL_ACCX_LO] + (u64)c * 16);
+        const ulonglong2 n2 = *reinterpret_cast<const ulonglong2 *>(cr + off[H2R_PL_NQ2_LO] + (u64)c * 16);
+        st16(rec + off[H2R_PL_ACCX_LO] + (u64)c * 16, ax.x, ax.y);
+        st16(rec + off[H2R_PL_NQ2_LO] + (u64)c * 16, n2.x, n2.y);
+        u64 modacc; W qacc = W::zero();
+        if constexpr (LW == 64) {
+            st8(rec + off[H2R_PL_ACCX_HI] + (u64)c * 8, *reinterpret_cast<const u64 *>(cr + off[H2R_PL_ACCX_HI] + (u64)c * 8));
+            st8(rec + off[H2R_PL_NQ2_HI] + (u64)c * 8, *reinterpret_cast<const u64 *>(cr + off[H2R_PL_NQ2_HI] + (u64)c * 8));
+            const ulonglong2 qa = *reinterpret_cast<const ulonglong2 *>(cr + off[H2R_PL_QACC] + (u64)c * 16);
+            qacc.lo = ((u128)qa.y << 64) | qa.x;
+            modacc = *reinterpret_cast<const u64 *>(cr + off[H2R_PL_MODACC] + (u64)c * 8);
+            st8(rec + off[H2R_PL_AMNQ2] + (u64)c * 8, *reinterpret_cast<const u64 *>(cr + off[H2R_PL_AMNQ2] + (u64)c * 8));
+        } else {
+            qacc.lo = *reinterpret_cast<const u64 *>(cr + off[H2R_PL_QACC] + (u64)c * 8);
+            modacc = *reinterpret_cast<const u32 *>(cr + off[H2R_PL_MODACC] + (u64)c * 4);
+            st4(rec + off[H2R_PL_AMNQ2] + (u64)c * 4, *reinterpret_cast<const u32 *>(cr + off[H2R_PL_AMNQ2] + (u64)c * 4));
+        }
+        store_carry<LW>(rec, off, H2R_PL_QACC, c, qacc);
+        store_limb<LW>(rec, off, H2R_PL_MODACC, c, modacc);
+        f1 = cmod == modacc;                               // cs_acc_eq, :873
+        if (c < C - 1) {
+            // range-assign the carry (:879-885): duplicate value + sub-limbs; range_eq == 1 (:886)
+            store_carry<LW>(rec, off, H2R_PL_CARRY_DUP, c, carry_out);
+            const u32 sb = args.carry_sub_bits, ns = args.carry_nsub;
+            u32 wds[4] = {0, 0, 0, 0};
+            u128 v = carry_out.lo;
+            const u32 m = (1u << sb) - 1;
+            for (u32 k = 0; k < ns; ++k) { wds[k >> 2] |= ((u32)v & m) << (8 * (k & 3)); v >>= sb; }
+            u8 *sp = rec + off[H2R_PL_CARRY_SUB] + (u64)c * args.carry_sub_stride;
+            for (u32 k = 0; k < args.carry_sub_stride / 4; ++k) st4(sp + 4 * k, wds[k]);
+            f2 = true;
+        } else {
+            f2 = carry_out.lo == qacc.lo;                  // final_carry_eq, :890 (acc_extra == q_acc)
+        }
+    }
+    // eq_bit is the running AND over (cs_acc_eq, range_eq | final_carry_eq) in column order (:874, :887, :891)
+    const u64 bad = __ballot(col && !(f1 && f2));
+    bool prev_ok;
+    if constexpr (TPI <= 64) {
+        const u64 seg = (TPI == 64) ? ~0ull : (((1ull << TPI) - 1) << (lane - t));
+        prev_ok = (bad & seg & ((1ull << lane) - 1)) == 0;
+    } else {
+        if (lane == 0) xbad[wave] = bad;
+        __syncthreads();
+        const int w0 = (wave / WPI) * WPI;
+        prev_ok = (bad & ((1ull << lane) - 1)) == 0;
+        for (int k = w0; k < wave; ++k) prev_ok = prev_ok && xbad[k] == 0;
+    }
+    if (col) {
+        const u32 e1 = (prev_ok && f1) ? 1u : 0u, e2 = (e1 && f2) ? 1u : 0u;
+        st4(rec + off[H2R_PL_FLAGS] + (u64)c * 4, (f1 ? 1u : 0u) | (e1 << 8) | ((f2 ? 1u : 0u) << 16) | (e2 << 24));
+    }
+}
+
+// ================================================================================================
+// K4: lookup multiplicities of the range-check sub-limbs of a set of records
+// ================================================================================================
+struct HistArgs {
+    const u8 *trace; u64 first_record_off, elem_stride, record_stride, num_elems; u32 records_per_elem;
+    u64 off_q_sub, off_r_sub, off_carry_sub;
+    u32 L, C, carry_nsub, carry_sub_stride, carry_has_ov;
+    u32 tab0_len, tab1_off, tab1_len, tab2_off, tab2_len, hist_len;  // table row offsets in the histogram
+    u32 *hist;  // [elem][hist_len]
+};
+
+__global__ __launch_bounds__(256) void hist_kernel(HistArgs a) {
+    extern __shared__ u32 h[];
+    const u64 elem = blockIdx.x;
+    for (u32 k = threadIdx.x; k < a.hist_len; k += blockDim.x) h[k] = 0;
+    __syncthreads();
+    const u8 *base = a.trace + elem * a.elem_stride + a.first_record_off;
+    const u32 limb_bytes_per_rec = 2 * a.L * 8;
+    const u32 ncomp = a.carry_nsub - a.carry_has_ov;
+    for (u32 rcd = 0; rcd < a.records_per_elem; ++rcd) {
+        const u8 *rec = base + (u64)rcd * a.record_stride;
+        // limb sub-limbs: Q_SUB and R_SUB are adjacent planes of L*8 bytes each
+        for (u32 k = threadIdx.x * 4; k < limb_bytes_per_rec; k += blockDim.x * 4) {
+            const u8 *p = (k < a.L * 8) ? rec + a.off_q_sub + k : rec + a.off_r_sub + (k - a.L * 8);
+            const u32 wv = *reinterpret_cast<const u32 *>(p);
+            atomicAdd(&h[wv & 0xff], 1u); atomicAdd(&h[(wv >> 8) & 0xff], 1u);
+            atomicAdd(&h[(wv >> 16) & 0xff], 1u); atomicAdd(&h[wv >> 24], 1u);
+        }
+        for (u32 k = threadIdx.x; k < (a.C - 1) * a.carry_nsub; k += blockDim.x) {
+            const u32 cc = k / a.carry_nsub, j = k % a.carry_nsub;
+            const u32 v = rec[a.off_carry_sub + (u64)cc * a.carry_sub_stride + j];
+            if (j < ncomp) atomicAdd(&h[a.tab1_off + v], 1u); else atomicAdd(&h[a.tab2_off + v], 1u);
+        }
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < a.hist_len; k += blockDim.x) a.hist[elem * a.hist_len + k] = h[k];
+}
+
+// stand-alone RangeChip::assign decomposition of a value array (8- or 16-byte values)
+struct DecompArgs {
+    const u8 *values; u32 value_bytes; u64 count; u32 bit_len, sub_bits, nsub, has_ov;
+    u8 *sub_out; u32 sub_stride; u32 *hist; u32 comp_len;
+};
+__global__ __launch_bounds__(256) void decompose_kernel(DecompArgs a) {
+    extern __shared__ u32 h[];
+    const u32 hl = a.hist ? a.comp_len + (a.has_ov ? (1u << (a.bit_len % a.sub_bits)) : 0) : 0;
+    for (u32 k = threadIdx.x; k < hl; k += blockDim.x) h[k] = 0;
+    __syncthreads();
+    const u32 m = (1u << a.sub_bits) - 1;
+    for (u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x; idx < a.count; idx += (u64)gridDim.x * blockDim.x) {
+        u128 v = *reinterpret_cast<const u64 *>(a.values + idx * a.value_bytes);
+        if (a.value_bytes == 16) v |= (u128)(*reinterpret_cast<const u64 *>(a.values + idx * 16 + 8)) << 64;
+        for (u32 k = 0; k < a.nsub; ++k) {
+            const u32 sv = (u32)v & m; v >>= a.sub_bits;
+            if (a.sub_out) a.sub_out[idx * a.sub_stride + k] = (u8)sv;
+            if (a.hist) atomicAdd(&h[(a.has_ov && k == a.nsub - 1) ? a.comp_len + sv : sv], 1u);
+        }
+    }
+    __syncthreads();
+    for (u32 k = threadIdx.x; k < hl; k += blockDim.x) if (h[k]) atomicAdd(&a.hist[k], h[k]);
+}
+
+}  // namespace h2r

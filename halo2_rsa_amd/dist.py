@@ -1,0 +1,94 @@
+"""Multi-GPU plumbing: one process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).
+
+Signatures are independent, so the hot path shards with NO data-path collective: each
+rank owns a contiguous slice of the batch and keeps its traces resident on its own GPU.  Collectives
+are only: the configuration broadcast, the timing barrier / MAX-reduce, and the gather of the small
+per-signature results (num_limbs limbs + status) to rank 0.
+"""
+import os
+from dataclasses import dataclass
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous batch shards: rank g gets [g*total/world, (g+1)*total/world) (remainder spread low)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+@dataclass
+class DistEnv:
+    rank: int
+    local_rank: int
+    world: int
+    initialised: bool = False
+    backend: str = ""
+
+    @staticmethod
+    def from_environment(expected_world: int = 1) -> "DistEnv":
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", str(rank)))
+        if world != expected_world and world != 1:
+            raise RuntimeError("--gpus %d but WORLD_SIZE=%d" % (expected_world, world))
+        if expected_world > 1 and world == 1:
+            raise RuntimeError("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
+                               "--nproc-per-node %d" % (expected_world, expected_world))
+        return DistEnv(rank, local, world)
+
+    def init(self, backend: str):
+        self.backend = backend
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            kw = {}
+            if backend == "nccl":
+                kw["device_id"] = torch.device("cuda", self.local_rank)
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world, **kw)
+            self.initialised = True
+
+    def _dev(self):
+        return torch.device("cuda", self.local_rank) if self.backend == "nccl" else torch.device("cpu")
+
+    def barrier(self):
+        if self.initialised:
+            if self.backend == "nccl":
+                dist.barrier(device_ids=[self.local_rank])
+            else:
+                dist.barrier()
+
+    def max_over_ranks(self, value: float) -> float:
+        if not self.initialised:
+            return value
+        t = torch.tensor([value], dtype=torch.float64, device=self._dev())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def broadcast_ints(self, values: List[int]) -> List[int]:
+        if not self.initialised:
+            return list(values)
+        t = torch.tensor(values, dtype=torch.int64, device=self._dev())
+        dist.broadcast(t, src=0)
+        return [int(v) for v in t.tolist()]
+
+    def gather_to_rank0(self, shard: torch.Tensor):
+        """Gather equally sized per-rank result tensors; rank 0 returns the concatenation, others None."""
+        if not self.initialised:
+            return shard
+        if self.backend == "nccl":
+            outs = [torch.empty_like(shard) for _ in range(self.world)]
+            dist.all_gather(outs, shard)  # RCCL all-gather over xGMI; results are tiny (num_limbs limbs each)
+            return torch.cat(outs, 0) if self.rank == 0 else None
+        outs = [torch.empty_like(shard) for _ in range(self.world)] if self.rank == 0 else None
+        dist.gather(shard, outs, dst=0)
+        return torch.cat(outs, 0) if self.rank == 0 else None
+
+    def finalize(self):
+        if self.initialised:
+            dist.barrier() if self.backend != "nccl" else dist.barrier(device_ids=[self.local_rank])
+            dist.destroy_process_group()
+            self.initialised = False

@@ -1,0 +1,78 @@
+"""Host-side mirror of the reference's RSAChip for the accelerated path (reference src/chip.rs:38-255,
+src/lib.rs:25-140): RSAPublicKey / RSAPubE / RSASignature containers and
+RSAInstructions::{assign_public_key, assign_signature, modpow_public_key} in batch form."""
+from dataclasses import dataclass
+from typing import Union
+
+import ctypes
+
+from ._lib import check, lib
+from .big_integer import AssignedInteger, BatchResult, BigIntChip, UnassignedInteger
+
+
+@dataclass
+class Fix:
+    """RSAPubE::Fix(BigUint) (src/lib.rs): the same fixed exponent for every element."""
+    e: int
+
+
+@dataclass
+class Var:
+    """RSAPubE::Var(UnassignedInteger): per-element exponent limbs."""
+    e: Union[UnassignedInteger, AssignedInteger]
+
+
+@dataclass
+class RSAPublicKey:
+    n: Union[UnassignedInteger, AssignedInteger]
+    e: Union[Fix, Var]
+
+
+@dataclass
+class RSASignature:
+    c: Union[UnassignedInteger, AssignedInteger]
+
+
+class RSAChip:
+    LIMB_WIDTH = 64  # src/chip.rs:203
+
+    def __init__(self, bits_len: int, exp_limb_bits: int, field: str = "bn254_fr", device: int = 0):
+        """RSAChip::new (src/chip.rs:214-221)."""
+        self.bits_len, self.exp_limb_bits = bits_len, exp_limb_bits
+        self._bigint = BigIntChip(self.LIMB_WIDTH, bits_len, field, device)
+
+    def bigint_chip(self) -> BigIntChip:
+        """src/chip.rs:224-230."""
+        return self._bigint
+
+    @staticmethod
+    def compute_range_lens(num_limbs: int):
+        """src/chip.rs:249-254."""
+        comp, over = (ctypes.c_uint32 * 4)(), (ctypes.c_uint32 * 3)()
+        check(lib().h2r_rsa_compute_range_lens(num_limbs, comp, over), "RSAChip::compute_range_lens")
+        return list(comp), list(over)
+
+    def assign_public_key(self, public_key: RSAPublicKey) -> RSAPublicKey:
+        """src/chip.rs:58-70."""
+        n = self._bigint.assign_integer(public_key.n)
+        e = public_key.e
+        if isinstance(e, Var):
+            ev = e.e
+            if isinstance(ev, UnassignedInteger):
+                import numpy as np
+                import torch
+                t = torch.from_numpy(np.ascontiguousarray(ev.limbs).view(np.int64)).to(n.limbs_dev.device)
+                ev = AssignedInteger(t.contiguous(), self.LIMB_WIDTH)
+            e = Var(ev)
+        return RSAPublicKey(n, e)
+
+    def assign_signature(self, signature: RSASignature) -> RSASignature:
+        """src/chip.rs:80-88."""
+        return RSASignature(self._bigint.assign_integer(signature.c))
+
+    def modpow_public_key(self, x: AssignedInteger, public_key: RSAPublicKey, want_trace: bool = True) -> BatchResult:
+        """src/chip.rs:99-114: assert x < n (:106; per-element status H2R_E_NOT_IN_FIELD), then
+        Fix -> pow_mod_fixed_exp, Var -> pow_mod."""
+        if isinstance(public_key.e, Fix):
+            return self._bigint.pow_mod_fixed_exp(x, public_key.e.e, public_key.n, want_trace, check_in_field=True)
+        return self._bigint.pow_mod(x, public_key.e.e, public_key.n, self.exp_limb_bits, want_trace)

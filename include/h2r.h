@@ -230,6 +230,14 @@ int32_t h2r_trace_flatten(const h2r_ctx *ctx, const void *record_host, void *str
 int32_t h2r_pow_trace_flatten(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *elem_host,
                               void *stream_out);
 
+/* ---- per-kernel timing (HIP events recorded on the launch stream around each kernel) -----------
+ * h2r_profile_enable(capacity) arms process-wide recording of up to `capacity` launches (0 disarms
+ * and frees the events).  h2r_profile_read() synchronises the recorded events of one kernel class
+ * and returns their durations in milliseconds, in launch order. */
+enum { H2R_KERNEL_CHAIN = 0, H2R_KERNEL_TRACE = 1, H2R_KERNEL_HIST = 2, H2R_KERNEL_COUNT = 3 };
+int32_t h2r_profile_enable(uint32_t capacity);
+int32_t h2r_profile_read(uint32_t kernel, float *ms_out, uint32_t max_count, uint32_t *count);
+
 const char *h2r_status_str(int32_t status);
 const char *h2r_last_hip_error(void);
 

@@ -1,0 +1,50 @@
+"""N > 1 harness on CPU: world_size-2 gloo run of the sharding / barrier / MAX-reduce / broadcast /
+gather plumbing that bench.py uses around the (GPU-only) hot path."""
+import os
+import subprocess
+import sys
+import textwrap
+
+from halo2_rsa_amd.dist import shard_range
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_the_batch():
+    for total in (0, 1, 7, 1024, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_range(65536, 3, 8) == (3 * 8192, 4 * 8192)   # BASELINE config 3: 8,192 per GPU
+
+
+def test_gloo_world2_harness(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent('''
+        import sys, torch
+        sys.path.insert(0, %r)
+        from halo2_rsa_amd.dist import DistEnv, shard_range
+        env = DistEnv.from_environment(2)
+        env.init("gloo")
+        cfg = env.broadcast_ints([65537, 1024, 5, 1] if env.rank == 0 else [0, 0, 0, 0])
+        assert cfg == [65537, 1024, 5, 1]
+        lo, hi = shard_range(10, env.rank, env.world)
+        shard = torch.arange(lo, hi, dtype=torch.int64).reshape(-1, 1).repeat(1, 4)
+        env.barrier()
+        t = env.max_over_ranks(1.0 + env.rank)
+        assert t == 2.0
+        g = env.gather_to_rank0(shard)
+        if env.rank == 0:
+            assert g.shape == (10, 4) and g[:, 0].tolist() == list(range(10))
+            print("GLOO_OK")
+        env.finalize()
+    ''' % ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29577", str(script)],
+                         capture_output=True, text=True, timeout=240, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "GLOO_OK" in out.stdout

@@ -1,0 +1,318 @@
+"""GPU parity: libh2r.so (hand-written HIP, through the C ABI) vs the CPU oracle, bit-exact.
+
+Every test here needs a real MI355X (`-m gpu`).  The op-trace of each element is walked with
+h2r_trace_flatten (the order a layouter shim assigns cells in) and compared byte for byte with the
+oracle's stream for the same inputs.  Nothing here reads /root/reference.
+"""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle_lib import Oracle  # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(bytes(a)).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def H():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU is visible")
+    import halo2_rsa_amd
+    return halo2_rsa_amd
+
+
+def rand_modulus(rng, bits, odd=True):
+    n = rng.getrandbits(bits) | (1 << (bits - 1))
+    return n | 1 if odd else n
+
+
+def test_rsa_kats_modpow_public_key(H, golden):
+    """reference src/chip.rs:683-816 through RSAChip::modpow_public_key (Fix e = 65537)."""
+    rsa = H.RSAChip(2048, 5)
+    chip = rsa.bigint_chip()
+    kats = golden["rsa_kats"]
+    ns = [int(k["n"]) for k in kats]
+    sigs = [int(k["sig"]) for k in kats]
+    pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Fix(65537)))
+    sig = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64)))
+    res = rsa.modpow_public_key(sig.c, pk)
+    torch.cuda.synchronize()
+    assert res.status.cpu().tolist() == [0, 0, 0]
+    powed = res.value.to_big_uint()
+    o = Oracle(64, 32)
+    for i, k in enumerate(kats):
+        assert powed[i] == pow(sigs[i], 65537, ns[i])
+        assert ["%x" % int(v) for v in res.value.limbs_host()[i]] == k["powed_limbs"]
+        st = res.trace.flatten(i)
+        assert len(st) == k["pow_stream_bytes"] == 19 * 64338 + 256
+        assert sha(st) == k["pow_stream_sha256"], k["name"]
+        rc, out, ost = o.pow_mod_fixed_exp(o.limbs(sigs[i]), o.limbs(ns[i]), 65537)
+        assert rc == 0 and np.array_equal(ost, st)
+        # EM check of the pkcs1v15 verifier on the GPU result (expected is_valid = 1, 1, 0)
+        rc, ok, _ = o.pkcs1v15_em_check(res.value.limbs_host()[i], o.limbs(int(k["hashed"]), 4))
+        assert ok == k["is_valid"]
+
+
+@pytest.mark.parametrize("w,L,batch", [(64, 32, 48), (64, 16, 24), (32, 128, 6), (64, 64, 6), (32, 64, 8), (64, 4, 40), (32, 8, 40)])
+def test_mul_mod_random_parity(H, w, L, batch):
+    """mul_mod (reference big_integer/chip.rs:542-629) incl. the reference's own edge identities
+    (:3123-3246), even and small moduli (the reference's random n is not forced odd, :1439-1442)."""
+    chip = H.BigIntChip(w, w * L)
+    o = Oracle(w, L)
+    rng = random.Random(7 * w + L)
+    bits = w * L
+    A, B, N = [], [], []
+    for i in range(batch):
+        kind = i % 8
+        n = rand_modulus(rng, bits, odd=(kind != 1))
+        if kind == 2:
+            n = rng.getrandbits(bits // 2 + 5) | 1          # small modulus: leading zero limbs
+        if kind == 3:
+            n = rng.getrandbits(bits - 7) | (1 << (bits - 8))  # top bit clear: normalisation shift
+        a, b = rng.randrange(n), rng.randrange(n)
+        if kind == 4:
+            a, b = 0, rng.randrange(n)                       # 0 * b = 0
+        if kind == 5:
+            a, b = n - 1, n - 1                               # (n-1)^2 = 1
+        if kind == 6:
+            a, b = n - 1, max(n - 2, 0)                       # (n-1)(n-2) = 2
+        if kind == 7:
+            a, b = n, 1                                       # n * 1 = 0 (a == n still has q fitting)
+        A.append(a); B.append(b); N.append(n)
+    res = chip.mul_mod(chip.assign_integer(A), chip.assign_integer(B), chip.assign_integer(N))
+    torch.cuda.synchronize()
+    assert not res.status.cpu().numpy().any()
+    r = res.value.to_big_uint()
+    for i in range(batch):
+        assert r[i] == (A[i] * B[i]) % N[i], (i, i % 8)
+        rc, rr, ost = o.mul_mod(o.limbs(A[i]), o.limbs(B[i]), o.limbs(N[i]))
+        assert rc == 0
+        st = res.trace.flatten(i)
+        if not np.array_equal(ost, st):
+            bad = int(np.nonzero(ost != st)[0][0])
+            pytest.fail("w=%d L=%d elem %d kind %d: first stream mismatch at byte %d of %d" % (w, L, i, i % 8, bad, len(st)))
+
+
+def test_mul_mod_golden_identities(H, golden):
+    chip = H.BigIntChip(64, 2048)
+    ids = golden["mul_mod_identities"]
+    res = chip.mul_mod(chip.assign_integer([int(c["a"]) for c in ids]), chip.assign_integer([int(c["b"]) for c in ids]),
+                       chip.assign_integer([int(c["n"]) for c in ids]))
+    torch.cuda.synchronize()
+    for i, c in enumerate(ids):
+        assert res.value.to_big_uint()[i] == int(c["r"])
+        assert sha(res.trace.flatten(i)) == c["stream_sha256"], c["name"]
+
+
+def test_error_statuses(H):
+    """n = 0 (reference divides by zero, chip.rs:566); quotient overflow (:583-584); x >= n (src/chip.rs:106)."""
+    chip = H.BigIntChip(64, 2048)
+    big = (1 << 2048) - 1
+    n_ok = (1 << 2047) | 12345
+    res = chip.mul_mod(chip.assign_integer([3, big, 5, big]), chip.assign_integer([4, big, 6, 2]),
+                       chip.assign_integer([0, 5, n_ok, (1 << 2047) + 1]))
+    torch.cuda.synchronize()
+    st = res.status.cpu().tolist()
+    assert st[0] == H.H2R_E_ZERO_MODULUS and st[1] == H.H2R_E_NOT_REDUCED and st[2] == 0
+    # big*2 / (2^2047+1) = 3 with a remainder: fits -> ok
+    assert st[3] == 0 and res.value.to_big_uint()[3] == (big * 2) % ((1 << 2047) + 1)
+    rsa = H.RSAChip(2048, 5)
+    pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints([n_ok, n_ok, n_ok], 32, 64), H.Fix(65537)))
+    x = rsa.bigint_chip().assign_integer([n_ok - 1, n_ok, n_ok + 1])
+    res = rsa.modpow_public_key(x, pk, want_trace=False)
+    torch.cuda.synchronize()
+    assert res.status.cpu().tolist() == [0, H.H2R_E_NOT_IN_FIELD, H.H2R_E_NOT_IN_FIELD]
+    assert res.value.to_big_uint()[0] == pow(n_ok - 1, 65537, n_ok)
+
+
+@pytest.mark.parametrize("w,L,batch,e", [(64, 32, 12, 65537), (64, 16, 8, 65537), (32, 128, 3, 65537), (64, 32, 4, 0b1011011), (64, 32, 3, 1), (64, 64, 2, 17)])
+def test_pow_mod_fixed_exp_parity(H, w, L, batch, e):
+    """pow_mod_fixed_exp (reference big_integer/chip.rs:710-742; tests :2314-2353 use a 7-bit e)."""
+    chip = H.BigIntChip(w, w * L)
+    o = Oracle(w, L)
+    rng = random.Random(w * 1000 + L + e)
+    N = [rand_modulus(rng, w * L, odd=(i % 3 != 2)) for i in range(batch)]
+    X = [rng.randrange(n) for n in N]
+    res = chip.pow_mod_fixed_exp(chip.assign_integer(X), e, chip.assign_integer(N))
+    torch.cuda.synchronize()
+    assert not res.status.cpu().numpy().any()
+    out = res.value.to_big_uint()
+    for i in range(batch):
+        assert out[i] == pow(X[i], e, N[i])
+        rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(X[i]), o.limbs(N[i]), e)
+        assert rc == 0 and np.array_equal(ost, res.trace.flatten(i)), (w, L, i)
+
+
+def test_rsa4096_w32_golden(H, golden):
+    """BASELINE config 4 shape (128 x 32-bit limbs): golden stream digest."""
+    c = golden["rsa4096_w32"]
+    chip = H.BigIntChip(32, 4096)
+    res = chip.pow_mod_fixed_exp(chip.assign_integer([int(c["x"])]), c["e"], chip.assign_integer([int(c["n"])]))
+    torch.cuda.synchronize()
+    assert res.value.to_big_uint()[0] == int(c["result"])
+    st = res.trace.flatten(0)
+    assert len(st) == c["stream_bytes"] and sha(st) == c["stream_sha256"]
+
+
+def test_pow_mod_var_parity(H, golden):
+    """pow_mod with a 5-bit variable exponent (reference big_integer/chip.rs:664-696; src/chip.rs:283, 327)."""
+    rsa = H.RSAChip(2048, 5)
+    chip = rsa.bigint_chip()
+    o = Oracle(64, 32)
+    k = golden["rsa_kats"][0]
+    es = [c["e"] for c in golden["pow_var_kat1"]] + [7, 24]
+    rng = random.Random(99)
+    N = [int(k["n"])] * 4 + [rand_modulus(rng, 2048), rand_modulus(rng, 2048, odd=False)]
+    X = [int(k["sig"])] * 4 + [rng.randrange(N[4]), rng.randrange(N[5])]
+    pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(N, 32, 64), H.Var(H.UnassignedInteger.from_ints(es, 1, 64))))
+    res = rsa.modpow_public_key(chip.assign_integer(X), pk)
+    torch.cuda.synchronize()
+    assert not res.status.cpu().numpy().any()
+    for i in range(len(es)):
+        assert res.value.to_big_uint()[i] == pow(X[i], es[i], N[i])
+        rc, oo, ost = o.pow_mod(o.limbs(X[i]), np.array([es[i]], np.uint64), 5, o.limbs(N[i]))
+        st = res.trace.flatten(i)
+        assert rc == 0 and np.array_equal(ost, st)
+        if i < 4:
+            assert sha(st) == golden["pow_var_kat1"][i]["stream_sha256"]
+
+
+def test_shared_modulus(H):
+    """One key, many signatures (H2R_F_SHARED_MODULUS)."""
+    chip = H.BigIntChip(64, 2048)
+    rng = random.Random(3)
+    n = rand_modulus(rng, 2048)
+    X = [rng.randrange(n) for _ in range(5)]
+    res = chip.pow_mod_fixed_exp(chip.assign_integer(X), 65537, chip.assign_integer([n]))
+    res2 = chip.pow_mod_fixed_exp(chip.assign_integer(X), 65537, chip.assign_integer([n] * 5))
+    torch.cuda.synchronize()
+    assert res.value.to_big_uint() == [pow(x, 65537, n) for x in X]
+    assert torch.equal(res.trace.buf, res2.trace.buf) or all(np.array_equal(res.trace.flatten(i), res2.trace.flatten(i)) for i in range(5))
+
+
+def expected_hist(o, streams):
+    """Count the sub-limb lookups of oracle mul_mod streams: rows = 2^limb_sub_bits composition,
+    [2^carry_sub_bits composition if different], 2^overflow_bits overflow."""
+    p = o.p
+    L, C = p.L, 2 * p.L - 1
+    t0 = 1 << p.limb_sub_bits
+    same = p.carry_sub_bits == p.limb_sub_bits
+    t1_off = 0 if same else t0
+    t1_len = 0 if same else (1 << p.carry_sub_bits)
+    ovb = p.carry_bits % p.carry_sub_bits
+    t2_off = t0 + t1_len
+    hist = np.zeros(t2_off + ((1 << ovb) if ovb else 0), dtype=np.int64)
+    per_col = 5 * p.WB + 2 * p.CB + 4 * p.LB + 2
+    for st in streams:
+        pos = 0
+        for _ in range(2 * L):
+            pos += p.LB
+            for _ in range(p.limb_nsub):
+                hist[int(st[pos])] += 1
+                pos += 1
+        pos += 2 * L * L * p.WB + L * p.WB
+        for i in range(C):
+            pos += per_col
+            if i < C - 1:
+                pos += p.CB
+                for j in range(p.carry_nsub):
+                    if ovb and j == p.carry_nsub - 1:
+                        hist[t2_off + int(st[pos])] += 1
+                    else:
+                        hist[t1_off + int(st[pos])] += 1
+                    pos += 1
+            pos += 2
+        assert pos == len(st)
+    return hist
+
+
+@pytest.mark.parametrize("w,L", [(64, 32), (32, 128)])
+def test_lookup_multiplicities(H, w, L):
+    """The range-check lookup batch: per-circuit multiplicity of every (tag, value) table row
+    (RangeChip call sites big_integer/chip.rs:590, 598, 880-885)."""
+    chip = H.BigIntChip(w, w * L)
+    o = Oracle(w, L)
+    rng = random.Random(11)
+    N = [rand_modulus(rng, w * L) for _ in range(3)]
+    X = [rng.randrange(n) for n in N]
+    res = chip.pow_mod_fixed_exp(chip.assign_integer(X), 65537, chip.assign_integer(N))
+    hist = res.trace.lookup_hist().cpu().numpy()
+    msb = o.mul_mod_stream_bytes
+    for i in range(3):
+        rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(X[i]), o.limbs(N[i]), 65537)
+        streams = [ost[t * msb:(t + 1) * msb] for t in range(19)]
+        want = expected_hist(o, streams)
+        assert np.array_equal(hist[i], want)
+        if (w, L) == (64, 32):
+            assert int(hist[i].sum()) == 20330   # sub-limb lookups per RSA-2048 e=65537 pow path
+
+
+def test_range_decompose_batch(H):
+    import ctypes
+    from halo2_rsa_amd._lib import check, lib
+    chip = H.BigIntChip(64, 2048)
+    rng = np.random.default_rng(5)
+    vals = rng.integers(0, 1 << 63, size=(1000, 2), dtype=np.uint64)
+    vals[:, 1] &= np.uint64(0x3f)            # 70-bit values
+    dv = torch.from_numpy(vals.view(np.int64)).cuda()
+    sub = torch.zeros((1000, 12), dtype=torch.uint8, device="cuda")
+    hist = torch.zeros(256 + 64, dtype=torch.int32, device="cuda")
+    check(lib().h2r_range_decompose_batch(chip._ctx, dv.data_ptr(), 16, 1000, 70, 8, sub.data_ptr(), 12, hist.data_ptr(), None), "decompose")
+    torch.cuda.synchronize()
+    s = sub.cpu().numpy()
+    want = np.zeros((1000, 9), dtype=np.uint8)
+    for i in range(1000):
+        v = int(vals[i, 0]) | (int(vals[i, 1]) << 64)
+        want[i] = [(v >> (8 * k)) & 0xff for k in range(9)]
+    assert np.array_equal(s[:, :9], want)
+    h = hist.cpu().numpy()
+    assert np.array_equal(h[:256], np.bincount(want[:, :8].ravel(), minlength=256))
+    assert np.array_equal(h[256:], np.bincount(want[:, 8], minlength=64))
+
+
+def test_config2_full_batch_properties(H, golden):
+    """BASELINE config 2 at full size (batch 1024, RSA-2048, e = 65537, KAT1/KAT2/BAD as elements 0-2):
+    every result equals pow(x, e, n); sampled elements are byte-exact vs the oracle; every record's
+    q/r planes satisfy a*b = q*n + r."""
+    chip = H.BigIntChip(64, 2048)
+    o = Oracle(64, 32)
+    rng = random.Random(0x68327273 + 2)
+    kats = golden["rsa_kats"]
+    N = [int(k["n"]) for k in kats] + [rand_modulus(rng, 2048) for _ in range(1021)]
+    X = [int(k["sig"]) for k in kats] + [rng.randrange(n) for n in N[3:]]
+    res = chip.pow_mod_fixed_exp(chip.assign_integer(X), 65537, chip.assign_integer(N))
+    torch.cuda.synchronize()
+    assert not res.status.cpu().numpy().any()
+    out = res.value.to_big_uint()
+    assert all(out[i] == pow(X[i], 65537, N[i]) for i in range(1024))
+    for i in [0, 1, 2] + rng.sample(range(3, 1024), 13):
+        rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(X[i]), o.limbs(N[i]), 65537)
+        assert np.array_equal(ost, res.trace.flatten(i)), i
+    # chain identity on the q/r planes of every record of 64 more elements
+    for i in rng.sample(range(1024), 64):
+        acc, cur, t = 1, X[i], 0
+
+        def qr(t):
+            q = int.from_bytes(res.trace.plane(i, t, "Q").tobytes(), "little")
+            r = int.from_bytes(res.trace.plane(i, t, "R").tobytes(), "little")
+            return q, r
+        for k in range(17):
+            q, r = qr(t)
+            assert cur * cur == q * N[i] + r and r < N[i]
+            nxt = r
+            t += 1
+            if (65537 >> k) & 1:
+                q, r = qr(t)
+                assert acc * cur == q * N[i] + r and r < N[i]
+                acc = r
+                t += 1
+            cur = nxt
+        assert t == 19 and acc == out[i]
