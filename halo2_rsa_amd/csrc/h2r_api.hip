@@ -124,19 +124,19 @@ hipError_t launch_trace(u32 w, u32 L, const TraceArgs &ta, hipStream_t st) {
 #undef H2R_CASE
     return hipErrorInvalidValue;
 }
-template <int K>
+template <int K, int NW>
 hipError_t launch_chain_t(const ChainArgs &ca, hipStream_t st) {
     if (ca.batch == 0) return hipSuccess;
-    hipLaunchKernelGGL((chain_kernel<K>), dim3((unsigned)ca.batch), dim3(64), 0, st, ca);
+    hipLaunchKernelGGL((chain_kernel<K, NW>), dim3((unsigned)ca.batch), dim3(64 * NW), 0, st, ca);
     return hipGetLastError();
 }
 hipError_t launch_chain(u32 K, const ChainArgs &ca, hipStream_t st) {
-    switch (K) {
-        case 8: return launch_chain_t<8>(ca, st);
-        case 16: return launch_chain_t<16>(ca, st);
-        case 32: return launch_chain_t<32>(ca, st);
-        case 64: return launch_chain_t<64>(ca, st);
-        case 128: return launch_chain_t<128>(ca, st);
+    switch (K) {  // NW = waves per element (multiple of the number of 64-column groups of the product)
+        case 8: return launch_chain_t<8, 1>(ca, st);
+        case 16: return launch_chain_t<16, 1>(ca, st);
+        case 32: return launch_chain_t<32, 4>(ca, st);
+        case 64: return launch_chain_t<64, 8>(ca, st);
+        case 128: return launch_chain_t<128, 8>(ca, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -1,11 +1,12 @@
 // gfx950 (MI355X, CDNA4, wave64) kernels of libh2r.  Hand-written HIP; no CUDA paths.
 //
-//   chain_kernel<K>   K2/K3/K5: one wave64 per element.  Runs the element's dependent chain of
-//                     modular multiplications on 32-bit digits spread one per lane (K = bits/32),
-//                     producing for every mul_mod t the operands and the TRUE quotient/remainder
-//                     (q_t, r_t) of BigIntChip::mul_mod (reference big_integer/chip.rs:562-584).
-//                     Barrett with a per-modulus reciprocal computed in-kernel (wave-parallel
-//                     Knuth D); carries are resolved with wavefront ballots.
+//   chain_kernel<K,NW> K2/K3/K5: one workgroup of NW waves per element.  Runs the element's dependent
+//                     chain of modular multiplications on 32-bit digits (K = bits/32), producing for
+//                     every mul_mod t the operands and the TRUE quotient/remainder (q_t, r_t) of
+//                     BigIntChip::mul_mod (reference big_integer/chip.rs:562-584).  Wave 0 holds the
+//                     numbers one digit per lane and owns the serial logic (Barrett with a
+//                     per-modulus reciprocal computed in-kernel by wave-parallel Knuth D; carries
+//                     resolved with wavefront ballots); all NW waves share the partial products.
 //   trace_kernel<W,L> K1: 2L threads per mul_mod, 256-thread workgroups.  Emits the whole witness
 //                     record of one mul_mod (mul :386-419 twice, eq_b :614-623, is_equal_muled
 //                     :822-895 incl. div_mod_main_gate :1323-1349 and the range-check sub-limbs)
@@ -77,71 +78,75 @@ struct ChainArgs {
     ExpBits e;
 };
 
-template <int K>
+// Block geometry of the chain kernel: NW waves (64*NW threads) per element.
+//   The 2K product columns are split into CG = ceil(2K/64) groups of 64 columns (one column per
+//   lane) and the K inner-product steps into SS = NW/CG slices, so wave w accumulates the slice
+//   ss = w / CG of column group cg = w % CG.  The B operand is zero-padded on both sides so the
+//   inner loop has no bounds logic:  col[c] = sum_j A[j] * Bpad[K + c - j].
+template <int K, int NW>
+struct Geo {
+    static constexpr int V = (K + 63) / 64;       // digits per lane (every wave holds whole numbers)
+    static constexpr int GW = K < 64 ? K : 64;    // positions per ballot group
+    static constexpr int CG = (2 * K + 63) / 64;  // column groups
+    static constexpr int SS = NW / CG;            // step slices
+    static constexpr int SL = K / SS;             // steps per slice
+    static_assert(NW % CG == 0 && SS >= 1 && K % SS == 0, "bad chain geometry");
+};
+
+template <int K, int NW>
 struct ChainLds {
-    u32 nn[K];           // normalised modulus n' = n << s
-    u32 mu[K];           // mu' = floor((2^(64K) - 1) / n') - 2^(32K)
-    u32 acc[K], cur[K];  // chain values
-    u32 opa[K], opb[K];  // multiplication operands
-    u32 x0[2 * K], x1[2 * K], x2[2 * K], y[2 * K + 2];
+    u32 opa[K];                  // A operand of the running multiplication
+    u32 bpad[3 * K];             // B operand, data at [K, 2K), zeros elsewhere
+    u32 nnpad[3 * K];            // normalised modulus n' = n << s, padded like bpad
+    u32 mupad[3 * K];            // mu' = floor((2^(64K) - 1) / n') - 2^(32K), padded
+    u32 part[Geo<K, NW>::SS][3][2 * K];  // per-slice column partial sums (3 words)
+    u32 x0[2 * K + 4], x1[2 * K + 4], x2[2 * K + 4];  // reduced columns; also shift scratch
+    u32 rx0[K + 1], rx1[K + 1];          // wave-0 scratch of the reciprocal
 };
 
-template <int K>
-struct WaveNum {
-    static constexpr int V = (K + 63) / 64;  // digits per lane
-    static constexpr int GW = K < 64 ? K : 64;
-};
+// intra-wave ordering of LDS traffic (ds ops of one wave execute in order; stop compiler motion)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 
-// 2K-digit product of two K-digit numbers held in LDS, one wave.  Lane `lane` ends up with the
-// normalised digits of columns v = lane + 64m (plo[m]) and v + K (phi[m]).
-template <int K>
-__device__ __forceinline__ void wave_mul(const u32 *A, const u32 *B, ChainLds<K> &s, int lane,
-                                         u32 (&plo)[WaveNum<K>::V], u32 (&phi)[WaveNum<K>::V]) {
-    constexpr int V = WaveNum<K>::V;
-    constexpr int GW = WaveNum<K>::GW;
-    u64 acc[V], flo[V];
-    u32 ov[V], flo_ov[V];
-#pragma unroll
-    for (int m = 0; m < V; ++m) { acc[m] = 0; ov[m] = 0; flo[m] = 0; flo_ov[m] = 0; }
-#pragma unroll 4
-    for (int st = 0; st < K; ++st) {
-        const u32 as = A[st];  // LDS broadcast
-#pragma unroll
-        for (int m = 0; m < V; ++m) {
-            const int v = lane + 64 * m;
-            const u32 bv = B[(v - st) & (K - 1)];
-            const u64 p = (u64)as * bv;
-            const u64 t = acc[m] + p;
-            ov[m] += (t < p) ? 1u : 0u;
-            acc[m] = t;
-            if (st == v) { flo[m] = acc[m]; flo_ov[m] = ov[m]; acc[m] = 0; ov[m] = 0; }
+// 2K-digit product A (K digits at `A`) x B (padded at `Bpad`) computed by the whole block.  All waves
+// accumulate column partial sums; WAVE 0 alone receives the normalised digits (lane holds columns
+// v = lane + 64m in plo[m] and v + K in phi[m]) -- it owns the serial carry/decision logic while the
+// other waves only help with the products.  Three block barriers; wave 0 publishes A/Bpad before.
+template <int K, int NW>
+__device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLds<K, NW> &s, int lane, int wave,
+                                          u32 (&plo)[Geo<K, NW>::V], u32 (&phi)[Geo<K, NW>::V]) {
+    using G = Geo<K, NW>;
+    constexpr int V = G::V;
+    __syncthreads();  // operands published; previous readers of part/x* are done
+    {
+        const int cg = wave % G::CG, ss = wave / G::CG;
+        const int c = 64 * cg + lane;
+        const int j0 = ss * G::SL;
+        u64 acc = 0;
+        u32 ov = 0;
+        const u32 *bp = Bpad + K + c - j0;
+#pragma unroll 8
+        for (int j = 0; j < G::SL; ++j) {
+            const u64 p = (u64)A[j0 + j] * bp[-j];
+            acc += p;
+            ov += (acc < p) ? 1u : 0u;
         }
-    }
-    __syncthreads();  // previous readers of x0..y are done
-#pragma unroll
-    for (int m = 0; m < V; ++m) {
-        const int v = lane + 64 * m;
-        if (v < K) {
-            s.x0[v] = (u32)flo[m]; s.x1[v] = (u32)(flo[m] >> 32); s.x2[v] = flo_ov[m];
-            s.x0[v + K] = (u32)acc[m]; s.x1[v + K] = (u32)(acc[m] >> 32); s.x2[v + K] = ov[m];
-        }
+        if (c < 2 * K) { s.part[ss][0][c] = (u32)acc; s.part[ss][1][c] = (u32)(acc >> 32); s.part[ss][2][c] = ov; }
     }
     __syncthreads();
-    u32 tlo[2 * V];
+    for (int c = threadIdx.x; c < 2 * K; c += 64 * NW) {  // reduce the SS slices of column c
+        u64 s0 = 0, s1 = 0; u32 s2 = 0;
 #pragma unroll
-    for (int g = 0; g < 2 * V; ++g) {
-        const int c = lane + 64 * (g % V) + (g >= V ? K : 0);
-        u64 t = 0;
-        if (lane + 64 * (g % V) < K) {
-            t = (u64)s.x0[c];
-            if (c >= 1) t += s.x1[c - 1];
-            if (c >= 2) t += s.x2[c - 2];
-            s.y[c + 1] = (u32)(t >> 32);
-        }
-        tlo[g] = (u32)t;
+        for (int k = 0; k < G::SS; ++k) { s0 += s.part[k][0][c]; s1 += s.part[k][1][c]; s2 += s.part[k][2][c]; }
+        const u64 t1 = s1 + (s0 >> 32);
+        s.x0[c + 3] = (u32)s0; s.x1[c + 3] = (u32)t1; s.x2[c + 3] = s2 + (u32)(t1 >> 32);
     }
-    if (lane == 0) s.y[0] = 0;
+    if (threadIdx.x < 3) { s.x0[threadIdx.x] = 0; s.x1[threadIdx.x] = 0; s.x2[threadIdx.x] = 0; }
     __syncthreads();
+    if (wave != 0) return;
+    // digits: t(c) = x0[c] + x1[c-1] + x2[c-2]; d(c) = lo(t(c)) + hi(t(c-1)); 1-bit carries by ballot
     bool cin = false;
 #pragma unroll
     for (int g = 0; g < 2 * V; ++g) {
@@ -150,23 +155,25 @@ __device__ __forceinline__ void wave_mul(const u32 *A, const u32 *B, ChainLds<K>
         u64 d = 0;
         bool gen = false, prop = false;
         if (vv < K) {
-            d = (u64)tlo[g] + s.y[c];
+            const u64 t = (u64)s.x0[c + 3] + s.x1[c + 2] + s.x2[c + 1];
+            const u64 tp = (u64)s.x0[c + 2] + s.x1[c + 1] + s.x2[c];
+            d = (u64)(u32)t + (tp >> 32);
             gen = (d >> 32) != 0;
             prop = ((u32)d == 0xffffffffu);
         }
-        const CarryGroup cg = carry_group(__ballot(gen), __ballot(prop), cin, GW);
-        cin = cg.cout;
-        const u32 digit = (u32)d + (u32)((cg.cin_mask >> lane) & 1);
+        const CarryGroup cgp = carry_group(__ballot(gen), __ballot(prop), cin, G::GW);
+        cin = cgp.cout;
+        const u32 digit = (u32)d + (u32)((cgp.cin_mask >> lane) & 1);
         if (g < V) plo[g] = digit; else phi[g - V] = digit;
     }
 }
 
-// K-digit a + b (+cin): returns carry out.
+// K-digit a + b: returns carry out.
 template <int K>
-__device__ __forceinline__ bool wave_add(u32 (&r)[WaveNum<K>::V], const u32 (&a)[WaveNum<K>::V],
-                                         const u32 (&b)[WaveNum<K>::V], int lane) {
-    constexpr int V = WaveNum<K>::V;
-    constexpr int GW = WaveNum<K>::GW;
+__device__ __forceinline__ bool wave_add(u32 (&r)[(K + 63) / 64], const u32 (&a)[(K + 63) / 64],
+                                         const u32 (&b)[(K + 63) / 64], int lane) {
+    constexpr int V = (K + 63) / 64;
+    constexpr int GW = K < 64 ? K : 64;
     bool cin = false;
 #pragma unroll
     for (int m = 0; m < V; ++m) {
@@ -180,10 +187,10 @@ __device__ __forceinline__ bool wave_add(u32 (&r)[WaveNum<K>::V], const u32 (&a)
 }
 // K-digit a - b: returns borrow out.
 template <int K>
-__device__ __forceinline__ bool wave_sub(u32 (&r)[WaveNum<K>::V], const u32 (&a)[WaveNum<K>::V],
-                                         const u32 (&b)[WaveNum<K>::V], int lane, bool bin = false) {
-    constexpr int V = WaveNum<K>::V;
-    constexpr int GW = WaveNum<K>::GW;
+__device__ __forceinline__ bool wave_sub(u32 (&r)[(K + 63) / 64], const u32 (&a)[(K + 63) / 64],
+                                         const u32 (&b)[(K + 63) / 64], int lane, bool bin = false) {
+    constexpr int V = (K + 63) / 64;
+    constexpr int GW = K < 64 ? K : 64;
 #pragma unroll
     for (int m = 0; m < V; ++m) {
         const bool act = lane + 64 * m < K;
@@ -195,8 +202,8 @@ __device__ __forceinline__ bool wave_sub(u32 (&r)[WaveNum<K>::V], const u32 (&a)
 }
 // a >= b over K digits.
 template <int K>
-__device__ __forceinline__ bool wave_ge(const u32 (&a)[WaveNum<K>::V], const u32 (&b)[WaveNum<K>::V], int lane) {
-    constexpr int V = WaveNum<K>::V;
+__device__ __forceinline__ bool wave_ge(const u32 (&a)[(K + 63) / 64], const u32 (&b)[(K + 63) / 64], int lane) {
+    constexpr int V = (K + 63) / 64;
 #pragma unroll
     for (int m = V - 1; m >= 0; --m) {
         const bool act = lane + 64 * m < K;
@@ -211,9 +218,9 @@ __device__ __forceinline__ bool wave_ge(const u32 (&a)[WaveNum<K>::V], const u32
 }
 // a += 1: returns carry out.
 template <int K>
-__device__ __forceinline__ bool wave_inc(u32 (&a)[WaveNum<K>::V], int lane) {
-    constexpr int V = WaveNum<K>::V;
-    constexpr int GW = WaveNum<K>::GW;
+__device__ __forceinline__ bool wave_inc(u32 (&a)[(K + 63) / 64], int lane) {
+    constexpr int V = (K + 63) / 64;
+    constexpr int GW = K < 64 ? K : 64;
     bool cin = true;
 #pragma unroll
     for (int m = 0; m < V; ++m) {
@@ -226,78 +233,76 @@ __device__ __forceinline__ bool wave_inc(u32 (&a)[WaveNum<K>::V], int lane) {
 }
 
 template <int K>
-__device__ __forceinline__ void lds_store(u32 *dst, const u32 (&r)[WaveNum<K>::V], int lane) {
+__device__ __forceinline__ void lds_store(u32 *dst, const u32 (&r)[(K + 63) / 64], int lane) {
 #pragma unroll
-    for (int m = 0; m < WaveNum<K>::V; ++m) if (lane + 64 * m < K) dst[lane + 64 * m] = r[m];
+    for (int m = 0; m < (K + 63) / 64; ++m) if (lane + 64 * m < K) dst[lane + 64 * m] = r[m];
 }
 template <int K>
-__device__ __forceinline__ void lds_load(u32 (&r)[WaveNum<K>::V], const u32 *src, int lane) {
+__device__ __forceinline__ void lds_load(u32 (&r)[(K + 63) / 64], const u32 *src, int lane) {
 #pragma unroll
-    for (int m = 0; m < WaveNum<K>::V; ++m) r[m] = (lane + 64 * m < K) ? src[lane + 64 * m] : 0;
+    for (int m = 0; m < (K + 63) / 64; ++m) r[m] = (lane + 64 * m < K) ? src[lane + 64 * m] : 0;
 }
 template <int K>
-__device__ __forceinline__ void glb_store(u32 *dst, const u32 (&r)[WaveNum<K>::V], int lane) {
+__device__ __forceinline__ void glb_store(u32 *dst, const u32 (&r)[(K + 63) / 64], int lane) {
 #pragma unroll
-    for (int m = 0; m < WaveNum<K>::V; ++m) if (lane + 64 * m < K) dst[lane + 64 * m] = r[m];
+    for (int m = 0; m < (K + 63) / 64; ++m) if (lane + 64 * m < K) dst[lane + 64 * m] = r[m];
 }
 
-// mu' = floor(((~n') * 2^(32K) + 2^(32K) - 1) / n')  by wave-parallel Knuth algorithm D
-// (n' normalised: top bit set).  Result left in s.mu.
-template <int K>
-__device__ __forceinline__ void wave_reciprocal(ChainLds<K> &s, int lane) {
-    constexpr int V = WaveNum<K>::V;
-    constexpr int GW = WaveNum<K>::GW;
-    u32 nn[V], rem[V];
-    lds_load<K>(nn, s.nn, lane);
+// mu' = floor(((~n') * 2^(32K) + 2^(32K) - 1) / n') by wave-parallel Knuth algorithm D (n'
+// normalised).  Run by wave 0 only (wave-local LDS exchanges, no block barriers); returns the K
+// quotient digits distributed one per lane.
+template <int K, int NW>
+__device__ __forceinline__ void wave_reciprocal(ChainLds<K, NW> &s, const u32 (&nn)[Geo<K, NW>::V], int lane, int wave,
+                                                u32 (&mu)[Geo<K, NW>::V]) {
+    using G = Geo<K, NW>;
+    constexpr int V = G::V;
+    u32 rem[V];
+    u32 *x0 = s.rx0, *x1 = s.rx1;
+    (void)wave;
 #pragma unroll
-    for (int m = 0; m < V; ++m) rem[m] = ~nn[m];
-    const u32 ntop = s.nn[K - 1];
+    for (int m = 0; m < V; ++m) { rem[m] = ~nn[m]; mu[m] = 0; }
+    const u32 ntop = s.nnpad[K + K - 1];
     for (int j = K - 1; j >= 0; --j) {
-        __syncthreads();
-        lds_store<K>(s.x0, rem, lane);
-        __syncthreads();
-        const u32 top = s.x0[K - 1], second = (K >= 2) ? s.x0[K - 2] : 0xffffffffu;
-        // 2-by-1 estimate of the quotient digit
-        u64 qd;
+        wave_sync();
+        lds_store<K>(x0, rem, lane);
+        wave_sync();
+        const u32 top = x0[K - 1], second = (K >= 2) ? x0[K - 2] : 0xffffffffu;
+        u64 qd;  // 2-by-1 estimate of the quotient digit (exact for the two leading digits)
         if (top >= ntop) qd = 0xffffffffull;
         else {
             const u64 num = ((u64)top << 32) | second;
             qd = (u64)((double)num / (double)ntop);
             if (qd > 0xffffffffull) qd = 0xffffffffull;
-            // exact fix-up (|error| <= 1 before clamping)
             u128 prod = (u128)qd * ntop;
             if (prod > num) { qd -= 1; prod -= ntop; }
             if ((u128)num - prod >= ntop && qd < 0xffffffffull) { qd += 1; }
         }
-        // e = qd * n' as K+1 normalised digits
-        u32 plo[V], phi_prev[V], remsh[V];
+        u32 plo[V], remsh[V], e[V];
 #pragma unroll
         for (int m = 0; m < V; ++m) {
             const int v = lane + 64 * m;
             const u64 p = (u64)(u32)qd * nn[m];
             plo[m] = (u32)p;
-            if (v < K) s.x1[v] = (u32)(p >> 32);
+            if (v < K) x1[v] = (u32)(p >> 32);
         }
-        __syncthreads();
+        wave_sync();
         bool cin = false;
-        u32 e[V];
 #pragma unroll
         for (int m = 0; m < V; ++m) {
             const int v = lane + 64 * m;
             const bool act = v < K;
-            phi_prev[m] = (act && v >= 1) ? s.x1[v - 1] : 0;
-            remsh[m] = act ? (v >= 1 ? s.x0[v - 1] : 0xffffffffu) : 0;
-            const u64 d = act ? (u64)plo[m] + phi_prev[m] : 0;
-            const CarryGroup cg = carry_group(__ballot((d >> 32) != 0), __ballot(act && (u32)d == 0xffffffffu), cin, GW);
+            const u32 phi_prev = (act && v >= 1) ? x1[v - 1] : 0;
+            remsh[m] = act ? (v >= 1 ? x0[v - 1] : 0xffffffffu) : 0;
+            const u64 d = act ? (u64)plo[m] + phi_prev : 0;
+            const CarryGroup cg = carry_group(__ballot((d >> 32) != 0), __ballot(act && (u32)d == 0xffffffffu), cin, G::GW);
             cin = cg.cout;
             e[m] = (u32)d + (u32)((cg.cin_mask >> lane) & 1);
         }
-        const u32 etop = s.x1[K - 1] + (cin ? 1u : 0u);
-        // rem'' = rem' - e
+        const u32 etop = x1[K - 1] + (cin ? 1u : 0u);
         u32 diff[V];
         const bool bout = wave_sub<K>(diff, remsh, e, lane);
         i64 dtop = (i64)top - (i64)etop - (bout ? 1 : 0);
-        while (dtop < 0) {  // qd was too large (at most twice): add n' back
+        for (int it = 0; it < 3 && dtop < 0; ++it) {  // qd too large (at most twice): add n' back
             u32 t2[V];
             const bool c = wave_add<K>(t2, diff, nn, lane);
 #pragma unroll
@@ -306,16 +311,23 @@ __device__ __forceinline__ void wave_reciprocal(ChainLds<K> &s, int lane) {
             qd -= 1;
         }
 #pragma unroll
-        for (int m = 0; m < V; ++m) rem[m] = diff[m];
-        if (lane == 0) s.mu[j] = (u32)qd;
+        for (int m = 0; m < V; ++m) {
+            rem[m] = diff[m];
+            if (lane + 64 * m == j) mu[m] = (u32)qd;
+        }
     }
-    __syncthreads();
 }
 
-// Shift a 2K-digit number (s.x0[0..2K)) left by sh bits into (lo, hi); returns true when bits are lost.
-template <int K>
-__device__ __forceinline__ bool wave_shl2k(ChainLds<K> &s, u32 sh, int lane, u32 (&lo)[WaveNum<K>::V], u32 (&hi)[WaveNum<K>::V]) {
-    constexpr int V = WaveNum<K>::V;
+// (lo, hi) = (2K-digit number held as digits lo/hi) << sh.  Uses s.x0 as block-shared scratch.
+// Returns true when non-zero bits are shifted out.
+template <int K, int NW>
+__device__ __forceinline__ bool block_shl2k(ChainLds<K, NW> &s, u32 sh, int lane, int wave,
+                                            u32 (&lo)[Geo<K, NW>::V], u32 (&hi)[Geo<K, NW>::V]) {
+    constexpr int V = Geo<K, NW>::V;
+    __syncthreads();
+    if (wave == 0) { lds_store<K>(s.x0, lo, lane); lds_store<K>(s.x0 + K, hi, lane); }
+    __syncthreads();
+    if (wave != 0) return false;
     const int ws = (int)(sh >> 5), bs = (int)(sh & 31);
     bool lost = false;
 #pragma unroll
@@ -327,21 +339,24 @@ __device__ __forceinline__ bool wave_shl2k(ChainLds<K> &s, u32 sh, int lane, u32
             const int i0 = c - ws, i1 = c - ws - 1;
             const u32 a0 = (i0 >= 0) ? s.x0[i0] : 0, a1 = (i1 >= 0) ? s.x0[i1] : 0;
             d = bs ? ((a0 << bs) | (a1 >> (32 - bs))) : a0;
-            // digits shifted out of the top: source index i with i + ws >= 2K, or the top bits of index 2K-1-ws
-            const int src = c;  // this lane also inspects source digit c
-            bool l = false;
-            if (src + ws >= 2 * K) l = s.x0[src] != 0;
-            else if (src + ws == 2 * K - 1 && bs) l = (s.x0[src] >> (32 - bs)) != 0;
+            bool l = false;  // this lane also checks whether source digit c loses bits
+            if (c + ws >= 2 * K) l = s.x0[c] != 0;
+            else if (c + ws == 2 * K - 1 && bs) l = (s.x0[c] >> (32 - bs)) != 0;
             lost = lost || l;
         }
         if (g < V) lo[g] = d; else hi[g - V] = d;
     }
     return __ballot(lost) != 0;
 }
-// K-digit right shift by sh bits of (s.x0[0..K) plus the extra top digit s.x0[K]).
-template <int K>
-__device__ __forceinline__ void wave_shr(ChainLds<K> &s, u32 sh, int lane, u32 (&r)[WaveNum<K>::V]) {
-    constexpr int V = WaveNum<K>::V;
+// r = (K-digit number in `a`) >> sh.
+template <int K, int NW>
+__device__ __forceinline__ void block_shr(ChainLds<K, NW> &s, u32 sh, int lane, int wave,
+                                          const u32 (&a)[Geo<K, NW>::V], u32 (&r)[Geo<K, NW>::V]) {
+    constexpr int V = Geo<K, NW>::V;
+    __syncthreads();
+    if (wave == 0) { lds_store<K>(s.x0, a, lane); if (lane == 0) s.x0[K] = 0; }
+    __syncthreads();
+    if (wave != 0) return;
     const int ws = (int)(sh >> 5), bs = (int)(sh & 31);
 #pragma unroll
     for (int m = 0; m < V; ++m) {
@@ -357,198 +372,181 @@ __device__ __forceinline__ void wave_shr(ChainLds<K> &s, u32 sh, int lane, u32 (
 }
 
 // One BigIntChip::mul_mod's off-circuit arithmetic (reference big_integer/chip.rs:562-584):
-// (q, r) = divmod(opa * opb, n).  Operands in s.opa / s.opb; returns status.
-template <int K>
-__device__ __forceinline__ int wave_mulmod(ChainLds<K> &s, u32 shift, int lane, u32 (&q)[WaveNum<K>::V], u32 (&r)[WaveNum<K>::V]) {
-    constexpr int V = WaveNum<K>::V;
+// (q, r) = divmod(a * b, n) by Barrett reduction with the per-modulus mu'.  a, b, nn, q, r and the
+// returned status are meaningful in WAVE 0 only; every wave must call it (block barriers inside, and
+// the control flow never depends on the data).
+template <int K, int NW>
+__device__ __forceinline__ int block_mulmod(ChainLds<K, NW> &s, u32 shift, int lane, int wave,
+                                            const u32 (&a)[Geo<K, NW>::V], const u32 (&b)[Geo<K, NW>::V],
+                                            const u32 (&nn)[Geo<K, NW>::V],
+                                            u32 (&q)[Geo<K, NW>::V], u32 (&r)[Geo<K, NW>::V]) {
+    constexpr int V = Geo<K, NW>::V;
+    const bool w0 = wave == 0;
+    int status = H2R_OK;
     u32 xlo[V], xhi[V];
-    wave_mul<K>(s.opa, s.opb, s, lane, xlo, xhi);
-    if (shift) {  // x' = x << s  (n' = n << s); wave-uniform branch
-        __syncthreads();
-        lds_store<K>(s.x0, xlo, lane); lds_store<K>(s.x0 + K, xhi, lane);
-        __syncthreads();
-        if (wave_shl2k<K>(s, shift, lane, xlo, xhi)) return H2R_E_NOT_REDUCED;
+    __syncthreads();
+    if (w0) { lds_store<K>(s.opa, a, lane); lds_store<K>(s.bpad + K, b, lane); }
+    block_mul<K, NW>(s.opa, s.bpad, s, lane, wave, xlo, xhi);
+    if (shift) {  // x' = x << s  (n' = n << s); block-uniform branch
+        if (block_shl2k<K, NW>(s, shift, lane, wave, xlo, xhi)) status = H2R_E_NOT_REDUCED;
     }
     // q^ = x1 + floor(x1 * mu' / 2^(32K)),  x1 = floor(x' / 2^(32K))
     __syncthreads();
-    lds_store<K>(s.opa, xhi, lane);
-    __syncthreads();
+    if (w0) lds_store<K>(s.opa, xhi, lane);
     u32 ylo[V], yhi[V];
-    wave_mul<K>(s.opa, s.mu, s, lane, ylo, yhi);
-    if (wave_add<K>(q, xhi, yhi, lane)) return H2R_E_NOT_REDUCED;
+    block_mul<K, NW>(s.opa, s.mupad, s, lane, wave, ylo, yhi);
+    if (w0 && wave_add<K>(q, xhi, yhi, lane)) status = H2R_E_NOT_REDUCED;
     // R = x' - q^ * n'   (0 <= R < 5 n')
     __syncthreads();
-    lds_store<K>(s.opa, q, lane);
-    __syncthreads();
+    if (w0) lds_store<K>(s.opa, q, lane);
     u32 zlo[V], zhi[V];
-    wave_mul<K>(s.opa, s.nn, s, lane, zlo, zhi);
-    u32 rl[V], nn[V];
-    const bool b0 = wave_sub<K>(rl, xlo, zlo, lane);
-    u32 rtop = __shfl(xhi[0] - zhi[0] - (b0 ? 1u : 0u), 0);
-    lds_load<K>(nn, s.nn, lane);
-    for (int it = 0; it < 8; ++it) {
-        if (rtop == 0 && !wave_ge<K>(rl, nn, lane)) break;
-        u32 t[V];
-        const bool bo = wave_sub<K>(t, rl, nn, lane);
+    block_mul<K, NW>(s.opa, s.nnpad, s, lane, wave, zlo, zhi);
+    u32 rl[V];
 #pragma unroll
-        for (int m = 0; m < V; ++m) rl[m] = t[m];
-        rtop -= bo ? 1u : 0u;
-        if (wave_inc<K>(q, lane)) return H2R_E_NOT_REDUCED;
+    for (int m = 0; m < V; ++m) rl[m] = 0;
+    if (w0) {
+        const bool b0 = wave_sub<K>(rl, xlo, zlo, lane);
+        u32 rtop = __shfl(xhi[0] - zhi[0] - (b0 ? 1u : 0u), 0);
+        for (int it = 0; it < 8; ++it) {
+            if (rtop == 0 && !wave_ge<K>(rl, nn, lane)) break;
+            u32 t[V];
+            const bool bo = wave_sub<K>(t, rl, nn, lane);
+#pragma unroll
+            for (int m = 0; m < V; ++m) rl[m] = t[m];
+            rtop -= bo ? 1u : 0u;
+            if (wave_inc<K>(q, lane)) status = H2R_E_NOT_REDUCED;
+        }
     }
-    if (shift) {  // r = R >> s
-        __syncthreads();
-        lds_store<K>(s.x0, rl, lane);
-        if (lane == 0) s.x0[K] = 0;
-        __syncthreads();
-        wave_shr<K>(s, shift, lane, r);
-    } else {
+    if (shift) block_shr<K, NW>(s, shift, lane, wave, rl, r);  // r = R >> s
+    else {
 #pragma unroll
         for (int m = 0; m < V; ++m) r[m] = rl[m];
     }
-    return H2R_OK;
+    return status;
 }
 
-template <int K>
-__global__ __launch_bounds__(64) void chain_kernel(ChainArgs args) {
-    constexpr int V = WaveNum<K>::V;
-    __shared__ ChainLds<K> s;
-    const int lane = threadIdx.x;
+template <int K, int NW>
+__global__ __launch_bounds__(64 * NW, (K <= 64 ? 8 : 4)) void chain_kernel(ChainArgs args) {
+    using G = Geo<K, NW>;
+    constexpr int V = G::V;
+    __shared__ ChainLds<K, NW> s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool w0 = wave == 0;
     const u64 elem = blockIdx.x;
-    if (elem >= args.batch) return;
     const u32 *n_g = args.n + elem * args.n_stride;
     u32 nraw[V];
 #pragma unroll
     for (int m = 0; m < V; ++m) nraw[m] = (lane + 64 * m < K) ? n_g[lane + 64 * m] : 0;
-    // normalisation shift: leading zero bits of n within 32K bits
+    for (int i = threadIdx.x; i < 3 * K; i += 64 * NW) { s.bpad[i] = 0; s.nnpad[i] = 0; s.mupad[i] = 0; }
+    // normalisation shift: leading zero bits of n within 32K bits (every wave computes it: block-uniform)
     int top_digit = -1;
 #pragma unroll
     for (int m = V - 1; m >= 0; --m) {
         const u64 nz = __ballot(nraw[m] != 0);
         if (nz && top_digit < 0) top_digit = 64 * m + (63 - __builtin_clzll(nz));
     }
-    int status = H2R_OK;
-    if (top_digit < 0) status = H2R_E_ZERO_MODULUS;  // reference divides by zero, chip.rs:566
-    u32 shift = 0;
-    if (status == H2R_OK) {
-        lds_store<K>(s.x0, nraw, lane);
-        for (int i = lane; i < K; i += 64) s.x0[K + i] = 0;
-        __syncthreads();
-        const u32 topv = s.x0[top_digit];
-        shift = 32u * (u32)(K - 1 - top_digit) + (u32)__builtin_clz(topv);
-        u32 nlo[V], nhi[V];
-        if (shift) { wave_shl2k<K>(s, shift, lane, nlo, nhi); }
-        else {
+    int status = top_digit < 0 ? H2R_E_ZERO_MODULUS : H2R_OK;  // reference divides by zero, chip.rs:566
+    // operands of the first step (all waves load x so that the in-field predicate is block-uniform)
+    u32 cur[V], acc[V], bop[V];
 #pragma unroll
-            for (int m = 0; m < V; ++m) nlo[m] = nraw[m];
+    for (int m = 0; m < V; ++m) {
+        const int v = lane + 64 * m;
+        cur[m] = v < K ? args.a[elem * K + v] : 0;
+        bop[m] = (args.mode == CHAIN_MULMOD && v < K) ? args.b[elem * K + v] : 0;
+        acc[m] = (v == 0) ? 1u : 0u;  // acc = const 1 padded to num_limbs (:729 / :682)
+    }
+    if (status == H2R_OK && args.mode != CHAIN_MULMOD && args.check_in_field && wave_ge<K>(cur, nraw, lane))
+        status = H2R_E_NOT_IN_FIELD;  // src/chip.rs:106
+    if (status != H2R_OK) {  // block-uniform early exit
+        if (threadIdx.x == 0) args.status[elem] = (u8)status;
+        return;
+    }
+    u32 shift;
+    u32 nn[V];
+#pragma unroll
+    for (int m = 0; m < V; ++m) nn[m] = nraw[m];
+    {
+        const u32 topv = __shfl(top_digit >= 64 ? nraw[V - 1] : nraw[0], top_digit & 63);
+        shift = 32u * (u32)(K - 1 - top_digit) + (u32)__builtin_clz(topv);
+        if (shift) {
+            u32 zero[V];
+#pragma unroll
+            for (int m = 0; m < V; ++m) zero[m] = 0;
+            block_shl2k<K, NW>(s, shift, lane, wave, nn, zero);
         }
         __syncthreads();
-        lds_store<K>(s.nn, nlo, lane);
+        if (w0) {
+            lds_store<K>(s.nnpad + K, nn, lane);
+            wave_sync();
+            u32 mu[V];
+            wave_reciprocal<K, NW>(s, nn, lane, wave, mu);
+            lds_store<K>(s.mupad + K, mu, lane);
+        }
         __syncthreads();
-        wave_reciprocal<K>(s, lane);
     }
     u32 q[V], r[V];
     const u64 item0 = elem * args.T;
-    if (status == H2R_OK && args.mode == CHAIN_MULMOD) {
-        u32 a[V], b[V];
-#pragma unroll
-        for (int m = 0; m < V; ++m) {
-            const int v = lane + 64 * m;
-            a[m] = v < K ? args.a[elem * K + v] : 0;
-            b[m] = v < K ? args.b[elem * K + v] : 0;
+    auto emit = [&](u32 t, const u32 (&oa)[V], const u32 (&ob)[V]) {
+        if (w0 && status == H2R_OK) {
+            const u64 it = item0 + t;
+            glb_store<K>(args.opA + it * K, oa, lane); glb_store<K>(args.opB + it * K, ob, lane);
+            glb_store<K>(args.opQ + it * K, q, lane); glb_store<K>(args.opR + it * K, r, lane);
         }
-        __syncthreads();
-        lds_store<K>(s.opa, a, lane); lds_store<K>(s.opb, b, lane);
-        __syncthreads();
-        status = wave_mulmod<K>(s, shift, lane, q, r);
-        if (status == H2R_OK) {
-            glb_store<K>(args.opA + item0 * K, a, lane); glb_store<K>(args.opB + item0 * K, b, lane);
-            glb_store<K>(args.opQ + item0 * K, q, lane); glb_store<K>(args.opR + item0 * K, r, lane);
-            if (args.out) glb_store<K>(args.out + elem * K, r, lane);
-        }
-    } else if (status == H2R_OK) {
+    };
+    auto fold = [&](int st) { if (st != H2R_OK && status == H2R_OK) status = st; };
+    if (args.mode == CHAIN_MULMOD) {
+        fold(block_mulmod<K, NW>(s, shift, lane, wave, cur, bop, nn, q, r));
+        emit(0, cur, bop);
+        if (w0 && status == H2R_OK && args.out) glb_store<K>(args.out + elem * K, r, lane);
+    } else {
         // pow_mod_fixed_exp (chip.rs:710-742) / pow_mod (chip.rs:664-696)
-        u32 x[V], one[V];
-#pragma unroll
-        for (int m = 0; m < V; ++m) {
-            const int v = lane + 64 * m;
-            x[m] = v < K ? args.a[elem * K + v] : 0;
-            one[m] = (v == 0) ? 1u : 0u;  // acc = const 1 padded to num_limbs (:729 / :682)
-        }
-        if (args.check_in_field && wave_ge<K>(x, nraw, lane)) status = H2R_E_NOT_IN_FIELD;  // src/chip.rs:106
-        __syncthreads();
-        lds_store<K>(s.cur, x, lane); lds_store<K>(s.acc, one, lane);
-        __syncthreads();
         u32 t = 0;
         const bool var = args.mode == CHAIN_POW_VAR;
         const u32 nbits = var ? args.e_num_limbs * args.exp_limb_bits : args.e.nbits;
         u8 *etrace = args.trace ? args.trace + elem * args.elem_stride : nullptr;
-        for (u32 bi = 0; bi < nbits && status == H2R_OK; ++bi) {
+        for (u32 bi = 0; bi < nbits; ++bi) {
             u32 bit;
             if (var) {  // main_gate.to_bits per e-limb, LSB first (chip.rs:674-681)
                 const u32 limb = bi / args.exp_limb_bits, pos = bi % args.exp_limb_bits;
                 const u32 *eg = args.e_limbs + (elem * args.e_num_limbs + limb) * args.digits_per_limb;
                 bit = (eg[pos >> 5] >> (pos & 31)) & 1u;
-                if (etrace && lane == 0) etrace[args.off_e_bits + bi] = (u8)bit;
+                if (etrace && threadIdx.x == 0) etrace[args.off_e_bits + bi] = (u8)bit;
             } else {
                 bit = (args.e.bytes[bi >> 3] >> (bi & 7)) & 1u;
             }
-            u32 cur[V], acc[V];
-            lds_load<K>(cur, s.cur, lane); lds_load<K>(acc, s.acc, lane);
             if (var) {
                 // muled = mul_mod(acc, squared) ALWAYS (:686); acc[j] = select(muled[j], acc[j], bit) (:688-691)
-                __syncthreads();
-                lds_store<K>(s.opa, acc, lane); lds_store<K>(s.opb, cur, lane);
-                __syncthreads();
-                status = wave_mulmod<K>(s, shift, lane, q, r);
-                if (status != H2R_OK) break;
-                const u64 it = item0 + t;
-                glb_store<K>(args.opA + it * K, acc, lane); glb_store<K>(args.opB + it * K, cur, lane);
-                glb_store<K>(args.opQ + it * K, q, lane); glb_store<K>(args.opR + it * K, r, lane);
+                fold(block_mulmod<K, NW>(s, shift, lane, wave, acc, cur, nn, q, r));
+                emit(t, acc, cur);
                 ++t;
 #pragma unroll
                 for (int m = 0; m < V; ++m) acc[m] = bit ? r[m] : acc[m];
-                if (etrace) glb_store<K>((u32 *)(etrace + args.off_selected + (u64)bi * args.selected_stride), acc, lane);
-                __syncthreads();
-                lds_store<K>(s.acc, acc, lane);
+                if (etrace && w0 && status == H2R_OK)
+                    glb_store<K>((u32 *)(etrace + args.off_selected + (u64)bi * args.selected_stride), acc, lane);
             }
             // squared = square_mod(cur) (:734 resp. :693)
-            __syncthreads();
-            lds_store<K>(s.opa, cur, lane); lds_store<K>(s.opb, cur, lane);
-            __syncthreads();
-            status = wave_mulmod<K>(s, shift, lane, q, r);
-            if (status != H2R_OK) break;
-            {
-                const u64 it = item0 + t;
-                glb_store<K>(args.opA + it * K, cur, lane); glb_store<K>(args.opB + it * K, cur, lane);
-                glb_store<K>(args.opQ + it * K, q, lane); glb_store<K>(args.opR + it * K, r, lane);
-                ++t;
-            }
-            __syncthreads();
-            lds_store<K>(s.cur, r, lane);
+            fold(block_mulmod<K, NW>(s, shift, lane, wave, cur, cur, nn, q, r));
+            emit(t, cur, cur);
+            ++t;
+            u32 sq[V];
+#pragma unroll
+            for (int m = 0; m < V; ++m) sq[m] = r[m];
             if (!var && bit) {  // acc = mul_mod(acc, cur_sq) with the value BEFORE this squaring (:732-739)
-                __syncthreads();
-                lds_store<K>(s.opa, acc, lane); lds_store<K>(s.opb, cur, lane);
-                __syncthreads();
-                status = wave_mulmod<K>(s, shift, lane, q, r);
-                if (status != H2R_OK) break;
-                const u64 it = item0 + t;
-                glb_store<K>(args.opA + it * K, acc, lane); glb_store<K>(args.opB + it * K, cur, lane);
-                glb_store<K>(args.opQ + it * K, q, lane); glb_store<K>(args.opR + it * K, r, lane);
+                fold(block_mulmod<K, NW>(s, shift, lane, wave, acc, cur, nn, q, r));
+                emit(t, acc, cur);
                 ++t;
-                __syncthreads();
-                lds_store<K>(s.acc, r, lane);
+#pragma unroll
+                for (int m = 0; m < V; ++m) acc[m] = r[m];
             }
-            __syncthreads();
+#pragma unroll
+            for (int m = 0; m < V; ++m) cur[m] = sq[m];
         }
-        if (status == H2R_OK) {
-            u32 acc[V];
-            __syncthreads();
-            lds_load<K>(acc, s.acc, lane);
+        if (status == H2R_OK && w0) {
             if (args.out) glb_store<K>(args.out + elem * K, acc, lane);
             if (etrace && args.write_result_to_trace) glb_store<K>((u32 *)(etrace + args.off_result), acc, lane);
         }
     }
-    if (lane == 0) args.status[elem] = (u8)status;
+    if (threadIdx.x == 0) args.status[elem] = (u8)status;
 }
 
 // ================================================================================================
