@@ -164,6 +164,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
                  uint8_t *status, void *workspace, hipStream_t st) {
     if (!c || !n || !a || !status) return H2R_E_NULL;
     if (batch == 0) return H2R_OK;
+    if (batch * (u64)(T ? T : 1) >= (1ull << 32)) return H2R_E_UNSUPPORTED;  // item index is 32-bit in the kernels
     if (T == 0) {  // e == 0: no mul_mod at all; result is the constant 1 (chip.rs:729)
         // handled by the chain kernel (loop of zero bits); still need a dummy ops buffer
     }
@@ -442,6 +443,12 @@ inline void emit_wide(Out &o, const h2r_layout &lo, const u8 *rec, int pl_lo, u6
     emit(o, rec + lo.plane_off[pl_lo] + idx * 16, lo.wide_bytes < 16 ? lo.wide_bytes : 16);
     if (lo.wide_bytes > 16) emit(o, rec + lo.plane_off[pl_lo + 1] + idx * 8, lo.wide_bytes - 16);
 }
+// accumulator of (j, i % L): LO entry j*L + i%L; the HI words of rows (2p, 2p+1) share 16-byte slots
+inline void emit_acc(Out &o, const h2r_layout &lo, const u8 *rec, int pl_lo, u32 j, u32 im) {
+    const u32 L = lo.num_limbs;
+    emit(o, rec + lo.plane_off[pl_lo] + ((u64)j * L + im) * 16, lo.wide_bytes < 16 ? lo.wide_bytes : 16);
+    if (lo.wide_bytes > 16) emit(o, rec + lo.plane_off[pl_lo + 1] + (((u64)(j >> 1) * L + im) * 2 + (j & 1)) * 8, lo.wide_bytes - 16);
+}
 inline void emit_plane(Out &o, const h2r_layout &lo, const u8 *rec, int pl, u64 idx, u32 n) {
     emit(o, rec + lo.plane_off[pl] + idx * lo.plane_elem[pl], n);
 }
@@ -463,7 +470,7 @@ int32_t h2r_trace_flatten(const h2r_ctx *ctx, const void *record_host, void *str
     for (int which = 0; which < 2; ++which)
         for (u32 i = 0; i < C; ++i) {
             u32 j = (L >= i + 1) ? 0 : i + 1 - L;
-            for (; j < L && j <= i; ++j) emit_wide(o, lo, rec, which ? H2R_PL_QN_LO : H2R_PL_AB_LO, (u64)j * L + (i % L));
+            for (; j < L && j <= i; ++j) emit_acc(o, lo, rec, which ? H2R_PL_QN_LO : H2R_PL_AB_LO, j, i % L);
         }
     // T5: eq_b[i] = qn[i] + r[i], i < L (chip.rs:617)
     for (u32 i = 0; i < L; ++i) emit_wide(o, lo, rec, H2R_PL_EQB_LO, i);

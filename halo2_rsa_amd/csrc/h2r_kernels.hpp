@@ -638,6 +638,50 @@ __device__ __forceinline__ u64 limb_sub_bytes(u64 v) {
     }
 }
 
+// Running accumulator of a product column: 160 bits (5 words) for 64-bit limbs, 96 bits (3 words) for
+// 32-bit limbs, with explicit carry chains (v_add_co / v_addc_co) and branch-free reset / capture.
+template <int LW> struct ColAcc;
+template <> struct ColAcc<64> {
+    u32 w[5];
+    __device__ __forceinline__ void clear() { w[0] = w[1] = w[2] = w[3] = w[4] = 0; }
+    __device__ __forceinline__ void keep_if(bool k) { const u32 m = k ? ~0u : 0u; w[0] &= m; w[1] &= m; w[2] &= m; w[3] &= m; w[4] &= m; }
+    __device__ __forceinline__ void add_product(u64 x, u64 y) {  // += x * y (64 x 64 -> 128)
+        const u32 x0 = (u32)x, x1 = (u32)(x >> 32), y0 = (u32)y, y1 = (u32)(y >> 32);
+        const u64 t0 = (u64)x0 * y0;
+        const u64 t1 = (u64)x1 * y0 + (t0 >> 32);
+        const u64 t2 = (u64)x0 * y1 + (u32)t1;
+        const u64 hi = (u64)x1 * y1 + (t1 >> 32) + (t2 >> 32);
+        u32 c;
+        w[0] = __builtin_addc(w[0], (u32)t0, 0u, &c);
+        w[1] = __builtin_addc(w[1], (u32)t2, c, &c);
+        w[2] = __builtin_addc(w[2], (u32)hi, c, &c);
+        w[3] = __builtin_addc(w[3], (u32)(hi >> 32), c, &c);
+        w[4] += c;
+    }
+    __device__ __forceinline__ void take_if(bool t, const ColAcc &o) { for (int k = 0; k < 5; ++k) w[k] = t ? o.w[k] : w[k]; }
+    __device__ __forceinline__ u64 lo0() const { return ((u64)w[1] << 32) | w[0]; }
+    __device__ __forceinline__ u64 lo1() const { return ((u64)w[3] << 32) | w[2]; }
+    __device__ __forceinline__ u64 hi64() const { return (u64)w[4]; }
+    __device__ __forceinline__ Wide<64> wide() const { Wide<64> r; r.lo = ((u128)lo1() << 64) | lo0(); r.hi = w[4]; return r; }
+};
+template <> struct ColAcc<32> {
+    u32 w[3];
+    __device__ __forceinline__ void clear() { w[0] = w[1] = w[2] = 0; }
+    __device__ __forceinline__ void keep_if(bool k) { const u32 m = k ? ~0u : 0u; w[0] &= m; w[1] &= m; w[2] &= m; }
+    __device__ __forceinline__ void add_product(u64 x, u64 y) {  // += x * y (32 x 32 -> 64)
+        const u64 t = (u64)(u32)x * (u32)y;
+        u32 c;
+        w[0] = __builtin_addc(w[0], (u32)t, 0u, &c);
+        w[1] = __builtin_addc(w[1], (u32)(t >> 32), c, &c);
+        w[2] += c;
+    }
+    __device__ __forceinline__ void take_if(bool t, const ColAcc &o) { for (int k = 0; k < 3; ++k) w[k] = t ? o.w[k] : w[k]; }
+    __device__ __forceinline__ u64 lo0() const { return ((u64)w[1] << 32) | w[0]; }
+    __device__ __forceinline__ u64 lo1() const { return (u64)w[2]; }
+    __device__ __forceinline__ u64 hi64() const { return 0; }
+    __device__ __forceinline__ Wide<32> wide() const { Wide<32> r; r.lo = ((u128)lo1() << 64) | lo0(); return r; }
+};
+
 template <int LW, int L>
 __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
     using limb_t = typename LimbT<LW>::type;
@@ -655,66 +699,76 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
     const int h = t / L, i = t % L;
     const int lane = tid & 63, wave = tid >> 6;
     TraceLds<LW, L> &s = lds_all[slot];
-    const u64 item = (u64)blockIdx.x * IPB + slot;
+    const u32 item = blockIdx.x * IPB + slot;  // n_items < 2^32 (checked by the host)
     const bool in_range = item < args.n_items;
-    const u64 elem = in_range ? item / args.T : 0;
-    const u32 tt = in_range ? (u32)(item % args.T) : 0;
+    const u32 elem32 = in_range ? item / args.T : 0;
+    const u32 tt = in_range ? item - elem32 * args.T : 0;
+    const u64 elem = elem32;
     const bool live = in_range && (args.status == nullptr || args.status[elem] == 0);
     u8 *rec = args.trace + elem * args.elem_stride + args.off_records + (u64)tt * args.record_stride;
     const u64 *off = args.off;
+    // An item that fits one wave (2L <= 64) never needs a workgroup barrier: its LDS traffic is
+    // wave-local, so waves of a block run independently.
+    auto item_sync = [&]() { if constexpr (TPI <= 64) wave_sync(); else __syncthreads(); };
 
     // ---- stage operands in LDS; emit q, r and their sub-limbs (chip.rs:588-599) -------------------
     if (live) {
-        const limb_t *gA = reinterpret_cast<const limb_t *>(h == 0 ? args.opA : args.opQ) + item * L;
-        const limb_t *gB = h == 0 ? reinterpret_cast<const limb_t *>(args.opB) + item * L
+        const limb_t *gQ = reinterpret_cast<const limb_t *>(args.opQ) + (u64)item * L;
+        const limb_t *gA = h == 0 ? reinterpret_cast<const limb_t *>(args.opA) + (u64)item * L : gQ;
+        const limb_t *gB = h == 0 ? reinterpret_cast<const limb_t *>(args.opB) + (u64)item * L
                                   : reinterpret_cast<const limb_t *>(args.n) + elem * args.n_stride;
         const limb_t av = gA[i], bv = gB[i];
+        // half 0 emits q and its sub-limbs, half 1 emits r (each store instruction covers both planes)
+        const limb_t ov = h == 0 ? gQ[i] : reinterpret_cast<const limb_t *>(args.opR)[(u64)item * L + i];
         s.A[h][i] = av; s.B[h][i] = bv;
-        if (h == 1) {
-            const limb_t rv = reinterpret_cast<const limb_t *>(args.opR)[item * L + i];
-            s.r[i] = rv;
-            store_limb<LW>(rec, off, H2R_PL_Q, i, av);
-            store_limb<LW>(rec, off, H2R_PL_R, i, rv);
-            st8(rec + off[H2R_PL_Q_SUB] + (u64)i * 8, limb_sub_bytes<LW>(av));
-            st8(rec + off[H2R_PL_R_SUB] + (u64)i * 8, limb_sub_bytes<LW>(rv));
-        }
+        if (h == 1) s.r[i] = ov;
+        store_limb<LW>(rec, off, h == 0 ? H2R_PL_Q : H2R_PL_R, i, ov);
+        st8(rec + off[h == 0 ? H2R_PL_Q_SUB : H2R_PL_R_SUB] + (u64)i * 8, limb_sub_bytes<LW>(ov));
     }
-    __syncthreads();
+    item_sync();
 
     // ---- BigIntChip::mul twice (chip.rs:386-419): lanes [0,L) a*b, lanes [L,2L) q*n ---------------
     // Lane i owns column i (steps s <= i) and then column i+L (steps s > i); step s multiplies
     // A[s] * B[(i-s) mod L], so every product a[j]*b[k] is visited once, in ascending j per column.
-    W acc = W::zero(), first = W::zero();
+    ColAcc<LW> acc, first;
+    acc.clear(); first.clear();
     if (live) {
-        u8 *plo = rec + off[h == 0 ? H2R_PL_AB_LO : H2R_PL_QN_LO];
-        u8 *phi = rec + off[h == 0 ? H2R_PL_AB_HI : H2R_PL_QN_HI];
+        u8 *plo = rec + off[h == 0 ? H2R_PL_AB_LO : H2R_PL_QN_LO] + (u64)i * 16;
+        u8 *phi = rec + off[h == 0 ? H2R_PL_AB_HI : H2R_PL_QN_HI] + (u64)i * 16;
+        const limb_t *Ah = s.A[h], *Bh = s.B[h];
+        limb_t x = Ah[0], y = Bh[i];
+        u64 hi_even = 0;
 #pragma unroll 4
         for (int st = 0; st < L; ++st) {
-            const limb_t x = s.A[h][st];
-            const limb_t y = s.B[h][(i - st) & (L - 1)];
-            W p;
-            if constexpr (LW == 64) p = W::from((u128)x * y); else p = W::from((u128)((u64)x * y));
-            acc = (st == i + 1) ? p : acc + p;
-            const u64 idx = (u64)st * L + i;
-            st16(plo + idx * 16, (u64)acc.lo, (u64)(acc.lo >> 64));
-            if constexpr (LW == 64) st8(phi + idx * 8, acc.hi_word());
-            if (st == i) first = acc;
+            const limb_t xn = Ah[(st + 1) & (L - 1)], yn = Bh[(i - st - 1) & (L - 1)];  // prefetch next step
+            acc.keep_if(st != i + 1);       // column i is complete: start column i+L from zero
+            acc.add_product(x, y);
+            st16(plo + (u64)st * (L * 16), acc.lo0(), acc.lo1());
+            if constexpr (LW == 64) {       // third words of steps (2p, 2p+1) share one 16-byte slot
+                if (st & 1) st16(phi + (u64)(st >> 1) * (L * 16), hi_even, acc.hi64());
+                else hi_even = acc.hi64();
+            }
+            first.take_if(st == i, acc);
+            x = xn; y = yn;
         }
         // final columns -> LDS; eq_b[i] = qn[i] + r[i] for i < L (chip.rs:614-623)
+        W fw = first.wide();
         if (h == 1) {
-            first = first + W::from((u128)s.r[i]);
-            store_wide<LW>(rec, off, H2R_PL_EQB_LO, i, first);
+            fw = fw + W::from((u128)s.r[i]);
+            store_wide<LW>(rec, off, H2R_PL_EQB_LO, i, fw);
         }
-        s.c0[h][i] = (u64)first.lo; s.c1[h][i] = (u64)(first.lo >> 64);
-        if constexpr (LW == 64) s.c2[h][i] = first.hi;
+        s.c0[h][i] = (u64)fw.lo; s.c1[h][i] = (u64)(fw.lo >> 64);
+        if constexpr (LW == 64) s.c2[h][i] = fw.hi;
         if (i < L - 1) {
-            s.c0[h][i + L] = (u64)acc.lo; s.c1[h][i + L] = (u64)(acc.lo >> 64);
-            if constexpr (LW == 64) s.c2[h][i + L] = acc.hi;
+            s.c0[h][i + L] = acc.lo0(); s.c1[h][i + L] = acc.lo1();
+            if constexpr (LW == 64) s.c2[h][i + L] = acc.w[4];
         }
     }
-    __syncthreads();
+    item_sync();
 
     // ---- BigIntChip::is_equal_muled (chip.rs:822-895): thread t = column c -------------------------
+    // Thread 2L-1 has no column; it still stores (zeros) so that every store instruction of this
+    // phase covers whole 128-byte lines (the planes reserve 2L entries).
     const int c = t;
     const bool col = live && c < C;
     W wm; wm.lo = ((u128)args.wm[1] << 64) | args.wm[0];
@@ -732,7 +786,7 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
         dhi = D.shr_limb();
         s.dhi0[c] = (u64)dhi.lo; s.dhi1[c] = (u32)(dhi.lo >> 64);
     }
-    __syncthreads();
+    item_sync();
     W dhi_prev = W::zero();
     u64 slo = 0; u32 shi = 0;
     if (col) {
@@ -742,7 +796,7 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
         shi = (u32)S.shr_limb().lo;
         s.shi[c] = shi;
     }
-    __syncthreads();
+    item_sync();
     u32 shi_prev = 0; bool gen = false, prop = false;
     if (col) {
         shi_prev = c > 0 ? s.shi[c - 1] : 0;
@@ -767,14 +821,16 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
         f = ((cg.cin_mask >> lane) & 1) != 0;
     }
     bool f1 = true, f2 = true;
-    W carry_out = W::zero();
-    u64 cmod = 0;
+    W carry_out = W::zero(), sum = W::zero(), nq = W::zero(), qacc = W::zero();
+    u64 cmod = 0, modacc = 0;
     if (col) {
         const W carry_in = dhi_prev + W::from((u128)shi_prev + (f ? 1u : 0u));
-        const W sum = D + carry_in;                       // :860-861
+        sum = D + carry_in;                               // :860-861
         cmod = sum.low_limb();                            // :864 div_mod r
         carry_out = sum.shr_limb();                       //            q
-        const W nq = carry_out.shl_limb();                // :1345
+        nq = carry_out.shl_limb();                        // :1345
+    }
+    if (live) {
         store_wide<LW>(rec, off, H2R_PL_AMB_LO, c, a_b);
         store_wide<LW>(rec, off, H2R_PL_SUM_LO, c, sum);
         store_carry<LW>(rec, off, H2R_PL_CARRY, c, carry_out);
@@ -782,12 +838,12 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
         store_wide<LW>(rec, off, H2R_PL_NQ1_LO, c, nq);
         store_limb<LW>(rec, off, H2R_PL_AMNQ1, c, (sum - nq).low_limb());   // :1346
         // input-independent part of the step (acc_extra chain, :869-871): copy from the constant record
+        // (whose entry 2L-1 is zero)
         const u8 *cr = args.const_rec;
         const ulonglong2 ax = *reinterpret_cast<const ulonglong2 *>(cr + off[H2R_PL_ACCX_LO] + (u64)c * 16);
         const ulonglong2 n2 = *reinterpret_cast<const ulonglong2 *>(cr + off[H2R_PL_NQ2_LO] + (u64)c * 16);
         st16(rec + off[H2R_PL_ACCX_LO] + (u64)c * 16, ax.x, ax.y);
         st16(rec + off[H2R_PL_NQ2_LO] + (u64)c * 16, n2.x, n2.y);
-        u64 modacc; W qacc = W::zero();
         if constexpr (LW == 64) {
             st8(rec + off[H2R_PL_ACCX_HI] + (u64)c * 8, *reinterpret_cast<const u64 *>(cr + off[H2R_PL_ACCX_HI] + (u64)c * 8));
             st8(rec + off[H2R_PL_NQ2_HI] + (u64)c * 8, *reinterpret_cast<const u64 *>(cr + off[H2R_PL_NQ2_HI] + (u64)c * 8));
@@ -803,20 +859,21 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
         store_carry<LW>(rec, off, H2R_PL_QACC, c, qacc);
         store_limb<LW>(rec, off, H2R_PL_MODACC, c, modacc);
         f1 = cmod == modacc;                               // cs_acc_eq, :873
+        // range-assign the carry (:879-885): duplicate value + sub-limbs; range_eq == 1 (:886).
+        // Columns C-1 (no range check, :888-892) and 2L-1 (no column) store zeros.
+        W dup = W::zero();
+        u32 wds[4] = {0, 0, 0, 0};
         if (c < C - 1) {
-            // range-assign the carry (:879-885): duplicate value + sub-limbs; range_eq == 1 (:886)
-            store_carry<LW>(rec, off, H2R_PL_CARRY_DUP, c, carry_out);
+            dup = carry_out;
             const u32 sb = args.carry_sub_bits, ns = args.carry_nsub;
-            u32 wds[4] = {0, 0, 0, 0};
             u128 v = carry_out.lo;
             const u32 m = (1u << sb) - 1;
             for (u32 k = 0; k < ns; ++k) { wds[k >> 2] |= ((u32)v & m) << (8 * (k & 3)); v >>= sb; }
-            u8 *sp = rec + off[H2R_PL_CARRY_SUB] + (u64)c * args.carry_sub_stride;
-            for (u32 k = 0; k < args.carry_sub_stride / 4; ++k) st4(sp + 4 * k, wds[k]);
-            f2 = true;
-        } else {
+        } else if (c == C - 1) {
             f2 = carry_out.lo == qacc.lo;                  // final_carry_eq, :890 (acc_extra == q_acc)
         }
+        store_carry<LW>(rec, off, H2R_PL_CARRY_DUP, c, dup);
+        st16(rec + off[H2R_PL_CARRY_SUB] + (u64)c * 16, ((u64)wds[1] << 32) | wds[0], ((u64)wds[3] << 32) | wds[2]);
     }
     // eq_bit is the running AND over (cs_acc_eq, range_eq | final_carry_eq) in column order (:874, :887, :891)
     const u64 bad = __ballot(col && !(f1 && f2));
@@ -831,9 +888,10 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
         prev_ok = (bad & ((1ull << lane) - 1)) == 0;
         for (int k = w0; k < wave; ++k) prev_ok = prev_ok && xbad[k] == 0;
     }
-    if (col) {
+    if (live) {
         const u32 e1 = (prev_ok && f1) ? 1u : 0u, e2 = (e1 && f2) ? 1u : 0u;
-        st4(rec + off[H2R_PL_FLAGS] + (u64)c * 4, (f1 ? 1u : 0u) | (e1 << 8) | ((f2 ? 1u : 0u) << 16) | (e2 << 24));
+        const u32 fl = (f1 ? 1u : 0u) | (e1 << 8) | ((f2 ? 1u : 0u) << 16) | (e2 << 24);
+        st4(rec + off[H2R_PL_FLAGS] + (u64)c * 4, col ? fl : 0u);
     }
 }
 

@@ -112,7 +112,7 @@ inline void layout_compute(u32 w, u32 L, h2r_layout *o) {
     o->limb_nsub = n_sublimbs(w);
     o->carry_sub_bits = sublimb_bit_len(o->carry_bits);
     o->carry_nsub = n_sublimbs(o->carry_bits);
-    o->carry_sub_stride = (u32)round_up(o->carry_nsub, 4);
+    o->carry_sub_stride = 16;  // one 16-byte store per column (carry_nsub <= 16)
     const u32 LB = o->limb_bytes, WB = o->wide_bytes, CB = o->carry_bytes;
     const u32 HI = WB > 16 ? WB - 16 : 0;
     auto set = [&](int p, u32 elem, u32 count) { o->plane_elem[p] = elem; o->plane_count[p] = elem ? count : 0; };

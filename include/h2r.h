@@ -87,10 +87,15 @@ typedef struct h2r_params {
  *   H2R_PL_Q_SUB, _R_SUB   [k][t]         sub-limb t of limb k, one byte each  (chip.rs:590, 598)
  *   H2R_PL_AB_*, _QN_*     [j][i % L]     accumulator of column i=j+k right after adding
  *                                         a[j]*b[k] (resp. q[j]*n[k]); the reference's order is
- *                                         i ascending, then j ascending        (chip.rs:400-412)
+ *                                         i ascending, then j ascending        (chip.rs:400-412).
+ *                                         LO entry index j*L + i%L; the 8-byte HI words of rows
+ *                                         (2p, 2p+1) share 16-byte slots: HI entry index
+ *                                         ((j/2)*L + i%L)*2 + j%2
  *   H2R_PL_EQB_*           [i], i < L     qn[i] + r[i]                         (chip.rs:617)
  *   per-column planes      [i], i < C     is_equal_muled step i                (chip.rs:857-893)
- *   H2R_PL_CARRY_DUP/_SUB  [i], i < C-1   the range-assigned carry and its sub-limbs (:879-885)
+ *   H2R_PL_CARRY_DUP/_SUB  [i], i < C-1   the range-assigned carry and its sub-limbs (:879-885);
+ *                                         one byte per sub-limb in a 16-byte slot per column
+ * Per-column planes reserve 2L entries; entries past the plane's count are written as zeros.
  *   H2R_PL_FLAGS           [i][4]         cs_acc_eq, eq_bit, range_eq|final_carry_eq, eq_bit
  */
 enum {
