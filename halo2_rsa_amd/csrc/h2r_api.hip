@@ -163,6 +163,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
                  u32 T, void *trace, u64 elem_stride, u64 off_records, const h2r_pow_layout *pl, void *out,
                  uint8_t *status, void *workspace, hipStream_t st) {
     if (!c || !n || !a || !status) return H2R_E_NULL;
+    if (c->params.device < 0) return H2R_E_UNSUPPORTED;  // host-only context
     if (batch == 0) return H2R_OK;
     if (batch * (u64)(T ? T : 1) >= (1ull << 32)) return H2R_E_UNSUPPORTED;  // item index is 32-bit in the kernels
     if (T == 0) {  // e == 0: no mul_mod at all; result is the constant 1 (chip.rs:729)
@@ -256,6 +257,10 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
     const u32 ovb = lo.carry_bits % lo.carry_sub_bits;
     c->tab2_off = c->tab0_len + c->tab1_len; c->tab2_len = ovb ? (1u << ovb) : 0;
     c->hist_len = c->tab2_off + c->tab2_len;
+    if (params->device < 0) {  // host-only context: layouts, flatten and parameter queries; no device work
+        *out = c;
+        return H2R_OK;
+    }
     if (!hip_ok(hipSetDevice(params->device), "hipSetDevice") ||
         !hip_ok(hipMalloc(reinterpret_cast<void **>(&c->const_rec_dev), lo.record_stride), "hipMalloc(const record)") ||
         !hip_ok(hipMemcpy(c->const_rec_dev, c->const_rec_host.data(), lo.record_stride, hipMemcpyHostToDevice), "hipMemcpy(const record)")) {
@@ -398,6 +403,7 @@ int32_t h2r_range_decompose_batch(const h2r_ctx *ctx, const void *values, uint32
     da.has_ov = bit_len % sublimb_bits ? 1 : 0; da.nsub = bit_len / sublimb_bits + da.has_ov;
     if (sublimbs_out && sub_stride < da.nsub) return H2R_E_SHAPE;
     da.sub_out = sublimbs_out; da.sub_stride = sub_stride; da.hist = hist; da.comp_len = 1u << sublimb_bits;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (count == 0) return H2R_OK;
     HIP_TRY(hipSetDevice(ctx->params.device));
     u64 blocks = (count + 255) / 256;
@@ -413,6 +419,7 @@ uint32_t h2r_hist_len(const h2r_ctx *ctx) { return ctx ? ctx->hist_len : 0; }
 int32_t h2r_trace_lookup_hist(const h2r_ctx *ctx, const void *trace, uint64_t first_record_off, uint64_t elem_stride,
                               uint64_t num_elems, uint32_t records_per_elem, uint32_t *hist_out, h2r_stream_t stream) {
     if (!ctx || !trace || !hist_out) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (num_elems == 0) return H2R_OK;
     const h2r_layout &lo = ctx->layout;
     HistArgs ha;

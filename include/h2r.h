@@ -75,7 +75,7 @@ typedef struct h2r_params {
     uint32_t limb_width; /* 64 (RSAChip::LIMB_WIDTH, src/chip.rs:203) or 32 */
     uint32_t bits_len;   /* bits_len % limb_width == 0; num_limbs = bits_len / limb_width */
     uint32_t field;      /* H2R_FIELD_* */
-    int32_t device;      /* HIP device ordinal */
+    int32_t device;      /* HIP device ordinal; < 0 = host-only ctx (layouts + flatten, no device work) */
 } h2r_params;
 
 /* ---- trace layout ------------------------------------------------------------------------------

@@ -1,0 +1,106 @@
+"""CPU-side checks of the C ABI: every symbol include/h2r.h declares is exported, parameter and
+layout queries match the goldens, and h2r_trace_flatten agrees with an independent Python placement
+of the oracle's stream (pins the documented plane index maps).  No device work, no compute calls."""
+import ctypes
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+from halo2_rsa_amd import _lib
+from halo2_rsa_amd._lib import H2RLayout, H2RParams, H2RPowLayout, lib
+from layout_ref import unflatten_record
+from oracle_lib import Oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHAPES = [(64, 4), (64, 8), (64, 16), (64, 32), (64, 64), (32, 8), (32, 32), (32, 64), (32, 128)]
+
+
+def host_ctx(w, L):
+    ctx = ctypes.c_void_p()
+    p = H2RParams(w, w * L, 0, -1)
+    rc = lib().h2r_ctx_create(ctypes.byref(p), ctypes.byref(ctx))
+    assert rc == 0, rc
+    return ctx
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "h2r.h")).read()
+    declared = sorted(set(re.findall(r"\b(h2r_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 20
+    L = ctypes.CDLL(_lib.lib_path())
+    missing = [n for n in declared if not hasattr(L, n)]
+    assert not missing, missing
+    assert sorted(_lib.EXPORTS) == declared
+
+
+def test_ctx_create_status_codes():
+    ctx = ctypes.c_void_p()
+    for (w, bits, field, want) in [(64, 2048 + 32, 0, _lib.H2R_E_SHAPE),      # bits_len % limb_width (chip.rs:1175)
+                                   (0, 2048, 0, _lib.H2R_E_SHAPE), (16, 2048, 0, _lib.H2R_E_UNSUPPORTED),
+                                   (64, 64 * 3, 0, _lib.H2R_E_UNSUPPORTED), (64, 2048, 9, _lib.H2R_E_SHAPE)]:
+        p = H2RParams(w, bits, field, -1)
+        assert lib().h2r_ctx_create(ctypes.byref(p), ctypes.byref(ctx)) == want
+    assert lib().h2r_ctx_create(None, ctypes.byref(ctx)) == _lib.H2R_E_NULL
+    assert lib().h2r_status_str(_lib.H2R_E_NOT_REDUCED).decode().startswith("quotient")
+    c = host_ctx(64, 32)   # host-only ctx refuses device work
+    st = (ctypes.c_uint8 * 1)()
+    buf = (ctypes.c_uint64 * 32)()
+    assert lib().h2r_mul_mod_batch(c, buf, buf, buf, 1, 0, None, None, st, None, None) == _lib.H2R_E_UNSUPPORTED
+    lib().h2r_ctx_destroy(c)
+
+
+def test_range_lens_and_layout_match_goldens(golden):
+    for row in golden["params"]:
+        comp, over = (ctypes.c_uint32 * 3)(), (ctypes.c_uint32 * 3)()
+        assert lib().h2r_compute_range_lens(row["w"], row["L"], comp, over) == 0
+        assert list(comp) == row["comp"] and list(over) == row["over"]
+        if (row["w"], row["L"]) in SHAPES:
+            c = host_ctx(row["w"], row["L"])
+            lo = H2RLayout()
+            assert lib().h2r_trace_layout(c, ctypes.byref(lo)) == 0
+            assert (lo.limb_bytes, lo.wide_bytes, lo.carry_bytes, lo.carry_bits, lo.word_max_bits, lo.stream_bytes) == \
+                (row["LB"], row["WB"], row["CB"], row["carry_bits"], row["word_max_bits"], row["mul_mod_stream_bytes"])
+            offs = list(lo.plane_off)
+            assert offs == sorted(offs) and all(o % 256 == 0 for o in offs) and lo.record_stride % 256 == 0
+            assert lo.record_stride >= lo.stream_bytes
+            lib().h2r_ctx_destroy(c)
+    comp4, over3 = (ctypes.c_uint32 * 4)(), (ctypes.c_uint32 * 3)()
+    assert lib().h2r_rsa_compute_range_lens(32, comp4, over3) == 0
+    assert [list(comp4), list(over3)] == golden["rsa_range_lens_2048"]
+
+
+def test_pow_layouts():
+    c = host_ctx(64, 32)
+    o = Oracle(64, 32)
+    pl = H2RPowLayout()
+    for e in (65537, 1, 0b1011011, (1 << 2047) | 12345, 0):
+        eb = int(e).to_bytes(max(1, (e.bit_length() + 7) // 8), "little")
+        assert lib().h2r_pow_fixed_layout(c, eb, len(eb), ctypes.byref(pl)) == 0
+        assert pl.num_mul_mods == e.bit_length() + bin(e).count("1") and pl.num_exp_bits == e.bit_length()
+        assert pl.stream_bytes == o.pow_fixed_stream_bytes(e)
+    assert lib().h2r_pow_var_layout(c, 1, 5, ctypes.byref(pl)) == 0
+    assert pl.num_mul_mods == 10 and pl.stream_bytes == o.pow_var_stream_bytes(1, 5)
+    assert lib().h2r_pow_var_layout(c, 1, 65, ctypes.byref(pl)) == _lib.H2R_E_SHAPE
+    lib().h2r_ctx_destroy(c)
+
+
+@pytest.mark.parametrize("w,L", SHAPES)
+def test_flatten_inverts_documented_layout(w, L):
+    """oracle stream -> (python placement per include/h2r.h) -> h2r_trace_flatten == oracle stream."""
+    c = host_ctx(w, L)
+    lo = H2RLayout()
+    lib().h2r_trace_layout(c, ctypes.byref(lo))
+    o = Oracle(w, L)
+    rng = random.Random(w + L)
+    n = rng.getrandbits(w * L) | (1 << (w * L - 1))
+    a, b = rng.randrange(n), rng.randrange(n)
+    rc, r, st = o.mul_mod(o.limbs(a), o.limbs(b), o.limbs(n))
+    assert rc == 0
+    rec = unflatten_record(st, lo, _lib.PLANES)
+    out = np.zeros(lo.stream_bytes, dtype=np.uint8)
+    assert lib().h2r_trace_flatten(c, rec.ctypes.data, out.ctypes.data) == 0
+    assert np.array_equal(out, st)
+    lib().h2r_ctx_destroy(c)
