@@ -155,6 +155,7 @@ void fill_trace_args(const h2r_ctx *c, TraceArgs &ta) {
     ta.carry_nsub = lo.carry_nsub; ta.carry_sub_stride = lo.carry_sub_stride;
     ta.record_stride = lo.record_stride;
     ta.const_rec = c->const_rec_dev;
+    if (const char *ab = std::getenv("H2R_ABLATE")) ta.ablate = (u32)std::atoi(ab);
 }
 
 // Common driver: chain kernel (q, r of every mul_mod) then trace kernel (the witness records).

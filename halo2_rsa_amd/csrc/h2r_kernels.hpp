@@ -592,6 +592,7 @@ struct TraceArgs {
     u64 off[H2R_PL_COUNT];
     u64 wm[3];                          // word_max (chip.rs:838)
     u32 carry_bits, carry_sub_bits, carry_nsub, carry_sub_stride;
+    u32 ablate;                         // timing experiments only (H2R_ABLATE); 0 in production
 };
 
 template <int LW, int L>
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
     // A[s] * B[(i-s) mod L], so every product a[j]*b[k] is visited once, in ascending j per column.
     ColAcc<LW> acc, first;
     acc.clear(); first.clear();
-    if (live) {
+    if (live && !(args.ablate & 2)) {
         u8 *plo = rec + off[h == 0 ? H2R_PL_AB_LO : H2R_PL_QN_LO] + (u64)i * 16;
         u8 *phi = rec + off[h == 0 ? H2R_PL_AB_HI : H2R_PL_QN_HI] + (u64)i * 16;
         const limb_t *Ah = s.A[h], *Bh = s.B[h];
@@ -740,9 +741,12 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
         u64 hi_even = 0;
 #pragma unroll 4
         for (int st = 0; st < L; ++st) {
-            const limb_t xn = Ah[(st + 1) & (L - 1)], yn = Bh[(i - st - 1) & (L - 1)];  // prefetch next step
+            limb_t xn, yn;
+            if (args.ablate & 4) { xn = x + 3; yn = y ^ (limb_t)st; }
+            else { xn = Ah[(st + 1) & (L - 1)]; yn = Bh[(i - st - 1) & (L - 1)]; }  // prefetch next step
             acc.keep_if(st != i + 1);       // column i is complete: start column i+L from zero
-            acc.add_product(x, y);
+            if (args.ablate & 8) { acc.w[0] += (u32)x; acc.w[1] ^= (u32)y; }
+            else acc.add_product(x, y);
             st16(plo + (u64)st * (L * 16), acc.lo0(), acc.lo1());
             if constexpr (LW == 64) {       // third words of steps (2p, 2p+1) share one 16-byte slot
                 if (st & 1) st16(phi + (u64)(st >> 1) * (L * 16), hi_even, acc.hi64());
@@ -765,6 +769,7 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
         }
     }
     item_sync();
+    if (args.ablate & 1) return;
 
     // ---- BigIntChip::is_equal_muled (chip.rs:822-895): thread t = column c -------------------------
     // Thread 2L-1 has no column; it still stores (zeros) so that every store instruction of this
