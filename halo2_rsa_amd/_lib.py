@@ -42,6 +42,12 @@ class H2RPowLayout(ctypes.Structure):
                 ("stream_bytes", ctypes.c_uint64)]
 
 
+class H2RVerifyLayout(ctypes.Structure):
+    _fields_ = [("pow", H2RPowLayout), ("off_in_field", ctypes.c_uint64), ("in_field_stream_bytes", ctypes.c_uint64),
+                ("off_em", ctypes.c_uint64), ("em_stream_bytes", ctypes.c_uint64), ("elem_stride", ctypes.c_uint64),
+                ("stream_bytes", ctypes.c_uint64)]
+
+
 class H2RError(RuntimeError):
     def __init__(self, code, where):
         self.code = code
@@ -55,10 +61,11 @@ _lib = None
 EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_rsa_compute_range_lens",
            "h2r_trace_layout", "h2r_pow_fixed_layout", "h2r_pow_var_layout", "h2r_workspace_bytes",
            "h2r_mul_mod_batch", "h2r_square_mod_batch", "h2r_pow_mod_fixed_exp_batch", "h2r_pow_mod_batch",
-           "h2r_modpow_public_key_batch", "h2r_range_decompose_batch", "h2r_hist_len", "h2r_trace_lookup_hist",
+           "h2r_modpow_public_key_batch", "h2r_verify_layout_fixed", "h2r_verify_pkcs1v15_batch",
+           "h2r_verify_trace_flatten", "h2r_range_decompose_batch", "h2r_hist_len", "h2r_trace_lookup_hist",
            "h2r_trace_flatten", "h2r_pow_trace_flatten", "h2r_profile_enable", "h2r_profile_read", "h2r_status_str",
            "h2r_last_hip_error"]
-KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST = 0, 1, 2
+KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST, KERNEL_AUX = 0, 1, 2, 3
 
 
 def lib_path():
@@ -95,6 +102,9 @@ def lib():
     L.h2r_pow_mod_fixed_exp_batch.argtypes = [vp, vp, vp, ctypes.c_char_p, ctypes.c_size_t, u64, u32, vp, vp, vp, vp, vp]
     L.h2r_modpow_public_key_batch.argtypes = L.h2r_pow_mod_fixed_exp_batch.argtypes
     L.h2r_pow_mod_batch.argtypes = [vp, vp, vp, u32, u32, vp, u64, u32, vp, vp, vp, vp, vp]
+    L.h2r_verify_layout_fixed.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(H2RVerifyLayout)]
+    L.h2r_verify_pkcs1v15_batch.argtypes = [vp, vp, vp, ctypes.c_char_p, ctypes.c_size_t, vp, u64, u32, vp, vp, vp, vp, vp, vp]
+    L.h2r_verify_trace_flatten.argtypes = [vp, ctypes.POINTER(H2RVerifyLayout), vp, vp]
     L.h2r_range_decompose_batch.argtypes = [vp, vp, u32, u64, u32, u32, vp, u32, vp, vp]
     L.h2r_hist_len.argtypes = [vp]
     L.h2r_hist_len.restype = u32

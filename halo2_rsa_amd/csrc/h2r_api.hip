@@ -192,7 +192,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
     ca.opQ = reinterpret_cast<u32 *>(ws + wp.opQ); ca.opR = reinterpret_cast<u32 *>(ws + wp.opR);
     ca.out = static_cast<u32 *>(out); ca.status = status;
     if (pl && trace) {
-        ca.trace = static_cast<u8 *>(trace); ca.elem_stride = pl->elem_stride;
+        ca.trace = static_cast<u8 *>(trace); ca.elem_stride = elem_stride;
         ca.off_e_bits = pl->off_e_bits; ca.off_selected = pl->off_selected; ca.selected_stride = pl->selected_stride;
         ca.off_result = pl->off_result; ca.write_result_to_trace = 1;
         if (mode != CHAIN_POW_VAR) { ca.off_e_bits = 0; ca.off_selected = 0; }
@@ -225,6 +225,23 @@ int32_t exp_to_bits(const uint8_t *e_le, size_t e_len, ExpBits *eb, u32 *T) {
     for (u32 i = 0; i < eb->nbits; ++i) t += 1 + exp_bit(e_le, i);  // one square per bit, one mul per set bit
     *T = t;
     return H2R_OK;
+}
+
+// walk the in-field region (AuxGeom sections) in stream order
+template <typename F>
+void in_field_sections(const AuxGeom &g, F &&emit) {
+    u64 off = 0;
+    auto add = [&](u32 n) { emit(off, (u64)n * g.STEP); off += g.add_sz(n); };
+    auto eq = [&](u32 n) { emit(off, 2ull * n); off += g.eq_sz(n); };
+    auto subu = [&](u32 n1) { emit(off, (u64)n1 * g.RA); off += g.cl_sz(n1); add(n1); eq(n1 + 1); };
+    const u32 L = g.L;
+    add(L); subu(L + 1);
+    emit(off, 2); off += 16;
+    emit(off, (u64)(L + 1) * g.LB); off += AuxGeom::a16((u64)(L + 1) * g.LB);
+    emit(off, (u64)L * g.LB); off += AuxGeom::a16((u64)L * g.LB);
+    subu(L + 1);
+    eq(L);
+    emit(off, 2); off += 16;
 }
 
 }  // namespace
@@ -388,6 +405,64 @@ int32_t h2r_pow_mod_batch(const h2r_ctx *ctx, const void *x, const void *e_limbs
     return run_path(ctx, CHAIN_POW_VAR, x, nullptr, n, e_limbs, e_num_limbs, exp_limb_bits, nullptr, 0, batch, flags,
                     pl.num_mul_mods, trace, pl.elem_stride, pl.off_records, &pl, out, status, workspace,
                     static_cast<hipStream_t>(stream));
+}
+
+int32_t h2r_verify_layout_fixed(const h2r_ctx *ctx, const uint8_t *e_le, size_t e_len, h2r_verify_layout *out) {
+    if (!ctx || !out) return H2R_E_NULL;
+    if (ctx->layout.limb_width != 64 || ctx->L < 9) return H2R_E_SHAPE;  // RSAChip::LIMB_WIDTH, src/chip.rs:203
+    std::memset(out, 0, sizeof *out);
+    int32_t rc = h2r_pow_fixed_layout(ctx, e_le, e_len, &out->pow);
+    if (rc) return rc;
+    const AuxGeom g(ctx->L, 64);
+    out->off_in_field = out->pow.elem_stride;
+    u64 sb = 0;
+    in_field_sections(g, [&](u64, u64 len) { sb += len; });
+    out->in_field_stream_bytes = sb;
+    out->off_em = out->off_in_field + round_up(g.in_field_sz(), 256);
+    out->em_stream_bytes = 2ull * ctx->L + 34;
+    out->elem_stride = out->off_em + round_up(g.em_sz(), 256);
+    out->stream_bytes = out->in_field_stream_bytes + out->pow.stream_bytes + out->em_stream_bytes;
+    return H2R_OK;
+}
+
+int32_t h2r_verify_pkcs1v15_batch(const h2r_ctx *ctx, const void *sig, const void *n, const uint8_t *e_le, size_t e_len,
+                                  const uint64_t *hashed, uint64_t batch, uint32_t flags, void *trace, void *powed_out,
+                                  uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+    if (!ctx || !sig || !n || !hashed || !trace || !powed_out || !status) return H2R_E_NULL;
+    h2r_verify_layout vl;
+    int32_t rc = h2r_verify_layout_fixed(ctx, e_le, e_len, &vl);
+    if (rc) return rc;
+    ExpBits eb; u32 T;
+    rc = exp_to_bits(e_le, e_len, &eb, &T);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = run_path(ctx, CHAIN_POW_FIXED, sig, nullptr, n, nullptr, 0, 0, &eb, 1, batch, flags, T, trace, vl.elem_stride,
+                  vl.pow.off_records, &vl.pow, powed_out, status, workspace, st);
+    if (rc || batch == 0) return rc;
+    AuxArgs aa;
+    std::memset(&aa, 0, sizeof aa);
+    aa.x = sig; aa.n = n; aa.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
+    aa.hashed = hashed; aa.powed = powed_out; aa.batch = batch; aa.L = ctx->L;
+    aa.trace = static_cast<u8 *>(trace); aa.elem_stride = vl.elem_stride; aa.off_in_field = vl.off_in_field; aa.off_em = vl.off_em;
+    aa.is_valid = is_valid_out; aa.status = status;
+    ProfScope ps(H2R_KERNEL_AUX, st);
+    hipLaunchKernelGGL((aux_kernel<64>), dim3((unsigned)batch), dim3(64), 0, st, aa);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
+
+int32_t h2r_verify_trace_flatten(const h2r_ctx *ctx, const h2r_verify_layout *vl, const void *elem_host, void *stream_out) {
+    if (!ctx || !vl || !elem_host || !stream_out) return H2R_E_NULL;
+    const u8 *e = static_cast<const u8 *>(elem_host);
+    u8 *o = static_cast<u8 *>(stream_out);
+    const AuxGeom g(ctx->L, ctx->layout.limb_width);
+    in_field_sections(g, [&](u64 off, u64 len) { std::memcpy(o, e + vl->off_in_field + off, len); o += len; });
+    int32_t rc = h2r_pow_trace_flatten(ctx, &vl->pow, e, o);
+    if (rc) return rc;
+    o += vl->pow.stream_bytes;
+    std::memcpy(o, e + vl->off_em, vl->em_stream_bytes); o += vl->em_stream_bytes;
+    if ((u64)(o - static_cast<u8 *>(stream_out)) != vl->stream_bytes) return H2R_E_SHAPE;
+    return H2R_OK;
 }
 
 int32_t h2r_range_decompose_batch(const h2r_ctx *ctx, const void *values, uint32_t value_bytes, uint64_t count,

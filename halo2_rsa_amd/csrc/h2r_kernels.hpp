@@ -901,6 +901,203 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
 }
 
 // ================================================================================================
+// K6: auxiliary witness of RSAChip::verify_pkcs1v15_signature around the pow path
+//   (a) BigIntChip::assert_in_field(x, n)  src/chip.rs:106 -> big_integer/chip.rs:1150 -> 998 -> 908-919:
+//       is_less_than = sub (:310-373: add :245-297, sub_unchecked :1286-1318 twice, selects) and
+//       is_equal_fresh (:780-805).
+//   (b) the encoded-message check after the modpow, src/chip.rs:136-198.
+// One wave per element; limb positions are spread over the lanes and every carry / borrow / running
+// AND is resolved with ballots.  The output is the flat stream itself, section by section, each
+// section starting on a 16-byte boundary of the device buffer (AuxGeom); ~10 KB per element.
+// ================================================================================================
+struct AuxGeom {
+    u32 L, LB, SB, RA, STEP;  // limbs, LIMB bytes, LIMB+8 bytes (a_b/sum/c+carry*B), range-assigned limb (LB+8), add step
+    __host__ __device__ static u64 a16(u64 x) { return (x + 15) & ~15ull; }
+    __host__ __device__ AuxGeom(u32 L_, u32 lw) : L(L_), LB(lw / 8), SB(lw / 8 + 8), RA(lw / 8 + 8), STEP(3 * (lw / 8 + 8) + 2 * (lw / 8 + 8)) {}
+    __host__ __device__ u64 add_sz(u32 n) const { return a16((u64)n * STEP); }
+    __host__ __device__ u64 eq_sz(u32 n) const { return a16(2ull * n); }
+    __host__ __device__ u64 cl_sz(u32 n) const { return a16((u64)n * RA); }
+    __host__ __device__ u64 subu_sz(u32 n1) const { return cl_sz(n1) + add_sz(n1) + eq_sz(n1 + 1); }
+    __host__ __device__ u64 sub_sz() const { return add_sz(L) + subu_sz(L + 1) + 16 + a16((u64)(L + 1) * LB) + a16((u64)L * LB) + subu_sz(L + 1); }
+    __host__ __device__ u64 in_field_sz() const { return sub_sz() + eq_sz(L) + 16; }
+    __host__ __device__ u64 em_sz() const { return a16(2ull * L + 34); }
+};
+
+struct AuxArgs {
+    const void *x, *n; u64 n_stride;   // limbs
+    const u64 *hashed;                 // [elem][4] 64-bit limbs of the SHA-256 digest (nullable: no EM check)
+    const void *powed;                 // [elem][L] result of the pow path
+    u64 batch; u32 L;
+    u8 *trace; u64 elem_stride, off_in_field, off_em;
+    u8 *is_valid;                      // [elem] (nullable)
+    const u8 *status;                  // [elem]: EM check skipped (is_valid = 0) when nonzero
+};
+
+constexpr int AUX_V = 3;  // positions per lane: L + 2 <= 192
+
+template <int LW>
+struct AuxW {
+    static constexpr u64 MASK = LW == 64 ? ~0ull : 0xffffffffull;
+    static constexpr int LB = LW / 8;
+    // store a (LW+1)-bit value (lo, hi bit) in LB+8 bytes / a limb in LB bytes (4-byte granular)
+    __device__ static void put_sb(u8 *p, u64 lo, u32 hi) {
+        if constexpr (LW == 64) { st8(p, lo); st8(p + 8, hi); }
+        else { st4(p, (u32)lo); st4(p + 4, (u32)(lo >> 32) | (hi << 0)); st4(p + 8, 0); }
+    }
+    __device__ static void put_limb(u8 *p, u64 v) { if constexpr (LW == 64) st8(p, v); else st4(p, (u32)v); }
+    __device__ static void put_ra(u8 *p, u64 v) {  // RangeChip::assign(limb): value + its 8 sub-limb bytes
+        put_limb(p, v);
+        const u64 sb = limb_sub_bytes<LW>(v);
+        if constexpr (LW == 64) st8(p + 8, sb); else { st4(p + 4, (u32)sb); st4(p + 8, (u32)(sb >> 32)); }
+    }
+};
+
+// BigIntChip::add (chip.rs:245-297) of A (nA limbs) and B (nB limbs); OUT gets max_n + 1 limbs.
+template <int LW>
+__device__ __forceinline__ void aux_add(u8 *sec, const AuxGeom &g, const u64 (&A)[AUX_V], u32 nA, const u64 (&B)[AUX_V], u32 nB,
+                                        u64 (&OUT)[AUX_V], int lane) {
+    using X = AuxW<LW>;
+    const u32 max_n = nA > nB ? nA : nB;
+    bool cin = false;
+#pragma unroll
+    for (int m = 0; m < AUX_V; ++m) {
+        const u32 p = lane + 64 * m;
+        const u64 ai = p < nA ? A[m] : 0, bi = p < nB ? B[m] : 0;   // :258-263 zero padding
+        const u64 ab_lo = (ai + bi) & X::MASK;
+        const bool ab_hi = LW == 64 ? (ab_lo < ai) : (((ai + bi) >> 32) != 0);
+        const bool act = p < max_n;
+        const CarryGroup cg = carry_group(__ballot(act && ab_hi), __ballot(act && !ab_hi && ab_lo == X::MASK), cin, 64);
+        cin = cg.cout;
+        const u32 ci = (u32)((cg.cin_mask >> lane) & 1);
+        const u64 c = (ab_lo + ci) & X::MASK;                          // :276
+        const bool sum_hi = ab_hi || (ci && ab_lo == X::MASK);         // carry out of this limb, :277
+        if (act) {
+            u8 *q = sec + (u64)p * g.STEP;
+            X::put_sb(q, ab_lo, ab_hi ? 1u : 0u);                       // a_b  :272
+            X::put_sb(q + g.SB, c, sum_hi ? 1u : 0u);                   // sum  :273
+            X::put_ra(q + 2 * g.SB, c);                                 // c    :279-280
+            X::put_ra(q + 2 * g.SB + g.RA, sum_hi ? 1u : 0u);           // carry :281-282
+            X::put_sb(q + 2 * g.SB + 2 * g.RA, c, sum_hi ? 1u : 0u);    // c + carry * 2^w  :283
+        }
+        OUT[m] = act ? c : (p == max_n ? (u64)ci : 0);                  // :286, :290
+    }
+}
+
+// BigIntChip::is_equal_fresh (chip.rs:780-805); returns the final eq_bit.
+template <int LW>
+__device__ __forceinline__ bool aux_eq(u8 *sec, const u64 (&A)[AUX_V], u32 n1, const u64 (&B)[AUX_V], u32 n2, int lane) {
+    const bool a_larger = n1 > n2;
+    const u32 max_n = a_larger ? n1 : n2;
+    bool all_prev = true;
+#pragma unroll
+    for (int m = 0; m < AUX_V; ++m) {
+        const u32 p = lane + 64 * m;
+        const bool act = p < max_n;
+        bool flag;
+        if (a_larger && p >= n2) flag = A[m] == 0;
+        else if (!a_larger && p >= n1) flag = B[m] == 0;
+        else flag = A[m] == B[m];
+        const u64 bad = __ballot(act && !flag);
+        const bool eq = all_prev && (bad & ((2ull << lane) - 1)) == 0;   // AND over positions <= p
+        if (act) *reinterpret_cast<uint16_t *>(sec + 2ull * p) = (uint16_t)((flag ? 1u : 0u) | ((eq ? 1u : 0u) << 8));
+        all_prev = all_prev && bad == 0;
+    }
+    return all_prev;
+}
+
+// BigIntChip::sub_unchecked (chip.rs:1286-1318): C = A - B (A >= B), then add(B, C) and is_equal_fresh(A, added).
+template <int LW>
+__device__ __forceinline__ void aux_subu(u8 *sec, const AuxGeom &g, const u64 (&A)[AUX_V], u32 n1, const u64 (&B)[AUX_V], u32 n2,
+                                         u64 (&C)[AUX_V], int lane) {
+    using X = AuxW<LW>;
+    bool bin = false;
+#pragma unroll
+    for (int m = 0; m < AUX_V; ++m) {
+        const u32 p = lane + 64 * m;
+        const bool act = p < n1;
+        const u64 ai = act ? A[m] : 0, bi = p < n2 ? B[m] : 0;
+        const CarryGroup cg = carry_group(__ballot(act && ai < bi), __ballot(act && ai == bi), bin, 64);
+        bin = cg.cout;
+        C[m] = act ? ((ai - bi - ((cg.cin_mask >> lane) & 1)) & X::MASK) : 0;   // :1300, :1304-1311
+        if (act) X::put_ra(sec + (u64)p * g.RA, C[m]);                           // :1307-1308
+    }
+    u64 added[AUX_V];
+    aux_add<LW>(sec + g.cl_sz(n1), g, B, n2, C, n1, added, lane);                // :1315
+    aux_eq<LW>(sec + g.cl_sz(n1) + g.add_sz(n1), A, n1, added, n1 + 1, lane);    // :1316
+}
+
+template <int LW>
+__global__ __launch_bounds__(64) void aux_kernel(AuxArgs a) {
+    using X = AuxW<LW>;
+    using limb_t = typename LimbT<LW>::type;
+    const int lane = threadIdx.x;
+    const u64 elem = blockIdx.x;
+    const u32 L = a.L;
+    const AuxGeom g(L, LW);
+    u64 Xv[AUX_V], Nv[AUX_V], MAXI[AUX_V];
+#pragma unroll
+    for (int m = 0; m < AUX_V; ++m) {
+        const u32 p = lane + 64 * m;
+        Xv[m] = p < L ? (u64) reinterpret_cast<const limb_t *>(a.x)[elem * L + p] : 0;
+        Nv[m] = p < L ? (u64) reinterpret_cast<const limb_t *>(a.n)[elem * a.n_stride + p] : 0;
+        MAXI[m] = p < L ? X::MASK : 0;                                    // max_value, chip.rs:138-154
+    }
+    u8 *et = a.trace + elem * a.elem_stride;
+    u8 *sec = et + a.off_in_field;
+    // ---- is_less_than(x, n) = sub(x, n).overflow & !is_equal_fresh(x, n)   (chip.rs:908-919) ----------
+    u64 IA[AUX_V], IS[AUX_V], SL[AUX_V], SR[AUX_V], REAL[AUX_V];
+    aux_add<LW>(sec, g, Xv, L, MAXI, L, IA, lane);                         // inflated_a, :321
+    sec += g.add_sz(L);
+    aux_subu<LW>(sec, g, IA, L + 1, Nv, L, IS, lane);                      // inflated_subed, :323
+    sec += g.subu_sz(L + 1);
+    const u64 top = __shfl(L >= 128 ? IS[2] : (L >= 64 ? IS[1] : IS[0]), (int)(L & 63));   // limb n2 = L of inflated_subed
+    const bool not_ov = top == 1;                                          // :330
+    if (lane == 0) *reinterpret_cast<uint16_t *>(sec) = (uint16_t)((not_ov ? 1u : 0u) | ((not_ov ? 0u : 1u) << 8));   // :330-331
+    sec += 16;
+#pragma unroll
+    for (int m = 0; m < AUX_V; ++m) {                                      // selects, :345-367
+        const u32 p = lane + 64 * m;
+        SL[m] = p < L + 1 ? (p >= L ? (not_ov ? IS[m] : 0) : (not_ov ? IS[m] : Nv[m])) : 0;
+        SR[m] = p < L ? (not_ov ? MAXI[m] : Xv[m]) : 0;
+        if (p < L + 1) X::put_limb(sec + (u64)p * g.LB, SL[m]);
+        if (p < L) X::put_limb(sec + AuxGeom::a16((u64)(L + 1) * g.LB) + (u64)p * g.LB, SR[m]);
+    }
+    sec += AuxGeom::a16((u64)(L + 1) * g.LB) + AuxGeom::a16((u64)L * g.LB);
+    aux_subu<LW>(sec, g, SL, L + 1, SR, L, REAL, lane);                    // real_subed, :371
+    sec += g.subu_sz(L + 1);
+    const bool is_eq = aux_eq<LW>(sec, Xv, L, Nv, L, lane);                // :916
+    sec += g.eq_sz(L);
+    const bool lt = !not_ov && !is_eq;                                     // :917-918
+    if (lane == 0) *reinterpret_cast<uint16_t *>(sec) = (uint16_t)((is_eq ? 0u : 1u) | ((lt ? 1u : 0u) << 8));
+    (void)lt;
+    // ---- encoded-message check (src/chip.rs:136-198; LIMB_WIDTH = 64 only) ----------------------------
+    if constexpr (LW == 64) {
+        if (a.hashed != nullptr && lane == 0) {
+            u8 *e = et + a.off_em;
+            const bool ok_status = a.status == nullptr || a.status[elem] == 0;
+            const u64 *pw = reinterpret_cast<const u64 *>(a.powed) + elem * L;
+            const u64 *hm = a.hashed + elem * 4;
+            u32 is_eqv = 1;
+            auto pair = [&](u8 *q, bool f) { is_eqv &= f ? 1u : 0u; *reinterpret_cast<uint16_t *>(q) = (uint16_t)((f ? 1u : 0u) | (is_eqv << 8)); };
+            if (ok_status) {
+                for (int i = 0; i < 4; ++i) pair(e + 2 * i, pw[i] == hm[i]);                      // :141-144
+                const bool f1 = pw[4] == 217300885422736416ull, f2 = pw[5] == 938447882527703397ull;   // :150-154
+                e[8] = f1; e[9] = f2; is_eqv &= f1; e[10] = (u8)is_eqv; is_eqv &= f2; e[11] = (u8)is_eqv;   // :155-156
+                const u32 low = (u32)pw[6], high = (u32)(pw[6] >> 32);                              // :159-168
+                auto ra32 = [&](u8 *q, u32 v) { st4(q, v); const u64 sb = limb_sub_bytes<32>(v); st4(q + 4, (u32)sb); st4(q + 8, (u32)(sb >> 32)); };
+                ra32(e + 12, low); ra32(e + 24, high);                                              // :170-171
+                st4(e + 36, low); st4(e + 40, high);                                                // :173
+                pair(e + 44, low == 3158320u);                                                      // :175-177
+                pair(e + 46, high == 4294967295u);                                                  // :180-182
+                for (u32 i = 7; i < L - 1; ++i) pair(e + 48 + 2 * (i - 7), pw[i] == 18446744073709551615ull);   // :185-188
+                pair(e + 48 + 2 * (L - 8), pw[L - 1] == 562949953421311ull);                        // :191-197
+            } else is_eqv = 0;
+            if (a.is_valid) a.is_valid[elem] = (u8)is_eqv;
+        }
+    }
+}
+
+// ================================================================================================
 // K4: lookup multiplicities of the range-check sub-limbs of a set of records
 // ================================================================================================
 struct HistArgs {

@@ -6,8 +6,11 @@ from typing import Union
 
 import ctypes
 
-from ._lib import check, lib
-from .big_integer import AssignedInteger, BatchResult, BigIntChip, UnassignedInteger
+import numpy as np
+import torch
+
+from ._lib import H2RVerifyLayout, check, lib
+from .big_integer import AssignedInteger, BatchResult, BigIntChip, UnassignedInteger, _e_bytes
 
 
 @dataclass
@@ -76,3 +79,46 @@ class RSAChip:
         if isinstance(public_key.e, Fix):
             return self._bigint.pow_mod_fixed_exp(x, public_key.e.e, public_key.n, want_trace, check_in_field=True)
         return self._bigint.pow_mod(x, public_key.e.e, public_key.n, self.exp_limb_bits, want_trace)
+
+
+    def verify_pkcs1v15_signature(self, public_key: RSAPublicKey, hashed_msg, signature: RSASignature) -> "VerifyResult":
+        """src/chip.rs:128-199 (after the SHA step): assert_in_field + modpow_public_key + encoded-message check.
+        hashed_msg: per element the SHA-256 digest as an integer / 4 little-endian 64-bit limbs (src/chip.rs:141-144)."""
+        if not isinstance(public_key.e, Fix):
+            raise NotImplementedError("verify_pkcs1v15_signature batch path takes RSAPubE::Fix")
+        chip, e = self._bigint, public_key.e.e
+        n, sig = chip.assign_integer(public_key.n), chip.assign_integer(signature.c)
+        batch, dev = sig.batch, sig.limbs_dev.device
+        if isinstance(hashed_msg, AssignedInteger):
+            hashed = hashed_msg.limbs_dev
+        else:
+            hashed = torch.from_numpy(UnassignedInteger.from_ints(list(hashed_msg), 4, 64).limbs.view(np.int64)).to(dev)
+        vl = H2RVerifyLayout()
+        eb = _e_bytes(e)
+        check(lib().h2r_verify_layout_fixed(chip._ctx, eb, len(eb), ctypes.byref(vl)), "h2r_verify_layout_fixed")
+        trace = torch.empty(batch * vl.elem_stride, dtype=torch.uint8, device=dev)
+        powed = torch.empty((batch, chip.num_limbs), dtype=torch.int64, device=dev)
+        is_valid = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        status = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        check(lib().h2r_verify_pkcs1v15_batch(chip._ctx, sig.data_ptr(), n.data_ptr(), eb, len(eb), hashed.data_ptr(), batch,
+                                              chip._flags(n, batch), trace.data_ptr(), powed.data_ptr(), is_valid.data_ptr(),
+                                              status.data_ptr(), None, chip._stream()), "verify_pkcs1v15_signature")
+        return VerifyResult(is_valid, AssignedInteger(powed, 64), status, trace, vl, chip)
+
+
+@dataclass
+class VerifyResult:
+    is_valid: "torch.Tensor"     # uint8 [batch]
+    powed: AssignedInteger
+    status: "torch.Tensor"
+    trace: "torch.Tensor"
+    layout: H2RVerifyLayout
+    chip: BigIntChip
+
+    def flatten(self, elem: int) -> "np.ndarray":
+        s = self.layout.elem_stride
+        host = np.ascontiguousarray(self.trace[elem * s:(elem + 1) * s].cpu().numpy())
+        out = np.zeros(self.layout.stream_bytes, dtype=np.uint8)
+        check(lib().h2r_verify_trace_flatten(self.chip._ctx, ctypes.byref(self.layout), host.ctypes.data, out.ctypes.data),
+              "h2r_verify_trace_flatten")
+        return out

@@ -207,6 +207,32 @@ int32_t h2r_modpow_public_key_batch(const h2r_ctx *ctx, const void *x, const voi
                                     uint32_t flags, void *trace, void *out, uint8_t *status,
                                     void *workspace, h2r_stream_t stream);
 
+/* ---- RSAInstructions::verify_pkcs1v15_signature after the SHA step (src/chip.rs:128-199) ------
+ * For every element: the assert_in_field(sig, n) witness (src/chip.rs:106 ->
+ * big_integer/chip.rs:1150-1158, 908-919, 310-373, 245-297, 1286-1318, 780-805), the
+ * pow_mod_fixed_exp trace, the encoded-message check against `hashed` (4 little-endian 64-bit limbs
+ * of the SHA-256 digest per element, src/chip.rs:141-144) and is_valid (one byte per element).
+ * limb_width must be 64 (RSAChip::LIMB_WIDTH).  Element layout: the pow trace at offset 0, then the
+ * in-field region and the encoded-message region; the two latter hold their flat streams directly,
+ * section by section, each section starting on a 16-byte boundary (h2r_verify_trace_flatten packs
+ * them).  status: H2R_E_NOT_IN_FIELD elements get is_valid = 0 and no pow / EM trace. */
+typedef struct h2r_verify_layout {
+    h2r_pow_layout pow;
+    uint64_t off_in_field, in_field_stream_bytes;
+    uint64_t off_em, em_stream_bytes;
+    uint64_t elem_stride;
+    uint64_t stream_bytes; /* in-field + pow + EM flat streams, in the reference's order */
+} h2r_verify_layout;
+int32_t h2r_verify_layout_fixed(const h2r_ctx *ctx, const uint8_t *e_le_bytes, size_t e_len,
+                                h2r_verify_layout *out);
+int32_t h2r_verify_pkcs1v15_batch(const h2r_ctx *ctx, const void *sig, const void *n,
+                                  const uint8_t *e_le_bytes, size_t e_len, const uint64_t *hashed,
+                                  uint64_t batch, uint32_t flags, void *trace, void *powed_out,
+                                  uint8_t *is_valid_out, uint8_t *status, void *workspace,
+                                  h2r_stream_t stream);
+int32_t h2r_verify_trace_flatten(const h2r_ctx *ctx, const h2r_verify_layout *vl,
+                                 const void *elem_host, void *stream_out);
+
 /* ---- the lookup range-check batch --------------------------------------------------------------
  * RangeChip::assign(value, sublimb_bits, bit_len) decomposition of `count` values of `value_bytes`
  * bytes each (8 or 16) into ceil(bit_len/sublimb_bits) one-byte sub-limbs (stride sub_stride),
@@ -239,7 +265,7 @@ int32_t h2r_pow_trace_flatten(const h2r_ctx *ctx, const h2r_pow_layout *pl, cons
  * h2r_profile_enable(capacity) arms process-wide recording of up to `capacity` launches (0 disarms
  * and frees the events).  h2r_profile_read() synchronises the recorded events of one kernel class
  * and returns their durations in milliseconds, in launch order. */
-enum { H2R_KERNEL_CHAIN = 0, H2R_KERNEL_TRACE = 1, H2R_KERNEL_HIST = 2, H2R_KERNEL_COUNT = 3 };
+enum { H2R_KERNEL_CHAIN = 0, H2R_KERNEL_TRACE = 1, H2R_KERNEL_HIST = 2, H2R_KERNEL_AUX = 3, H2R_KERNEL_COUNT = 4 };
 int32_t h2r_profile_enable(uint32_t capacity);
 int32_t h2r_profile_read(uint32_t kernel, float *ms_out, uint32_t max_count, uint32_t *count);
 

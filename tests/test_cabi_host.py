@@ -104,3 +104,24 @@ def test_flatten_inverts_documented_layout(w, L):
     assert lib().h2r_trace_flatten(c, rec.ctypes.data, out.ctypes.data) == 0
     assert np.array_equal(out, st)
     lib().h2r_ctx_destroy(c)
+
+
+def test_verify_layout_sizes(golden):
+    """in-field / EM stream sizes of h2r_verify_layout_fixed equal the oracle's (SURVEY 8f next #1, #2)."""
+    from halo2_rsa_amd._lib import H2RVerifyLayout
+    from oracle_lib import lib as olib
+    for L in (16, 32, 64):
+        c = host_ctx(64, L)
+        o = Oracle(64, L)
+        vl = H2RVerifyLayout()
+        eb = (65537).to_bytes(3, "little")
+        assert lib().h2r_verify_layout_fixed(c, eb, 3, ctypes.byref(vl)) == 0
+        assert vl.in_field_stream_bytes == int(olib().h2ro_in_field_stream_bytes(ctypes.byref(o.p)))
+        assert vl.em_stream_bytes == int(olib().h2ro_pkcs1v15_stream_bytes(ctypes.byref(o.p))) == 2 * L + 34
+        assert vl.stream_bytes == vl.in_field_stream_bytes + o.pow_fixed_stream_bytes(65537) + vl.em_stream_bytes
+        assert vl.off_in_field % 256 == 0 and vl.off_em % 256 == 0 and vl.elem_stride % 256 == 0
+        lib().h2r_ctx_destroy(c)
+    assert golden["rsa_kats"][0]["in_field_stream_bytes"] == 9620
+    c = host_ctx(32, 128)
+    assert lib().h2r_verify_layout_fixed(c, (65537).to_bytes(3, "little"), 3, ctypes.byref(H2RVerifyLayout())) == _lib.H2R_E_SHAPE
+    lib().h2r_ctx_destroy(c)
