@@ -62,7 +62,8 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_trace_layout", "h2r_pow_fixed_layout", "h2r_pow_var_layout", "h2r_workspace_bytes",
            "h2r_mul_mod_batch", "h2r_square_mod_batch", "h2r_pow_mod_fixed_exp_batch", "h2r_pow_mod_batch",
            "h2r_modpow_public_key_batch", "h2r_verify_layout_fixed", "h2r_verify_pkcs1v15_batch",
-           "h2r_verify_trace_flatten", "h2r_range_decompose_batch", "h2r_hist_len", "h2r_trace_lookup_hist",
+           "h2r_verify_trace_flatten", "h2r_range_decompose_batch", "h2r_hist_len", "h2r_trace_lookup_hist", "h2r_lookups_per_record",
+           "h2r_trace_lookup_permutation",
            "h2r_trace_flatten", "h2r_pow_trace_flatten", "h2r_profile_enable", "h2r_profile_read", "h2r_status_str",
            "h2r_last_hip_error"]
 KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST, KERNEL_AUX = 0, 1, 2, 3
@@ -109,6 +110,9 @@ def lib():
     L.h2r_hist_len.argtypes = [vp]
     L.h2r_hist_len.restype = u32
     L.h2r_trace_lookup_hist.argtypes = [vp, vp, u64, u64, u64, u32, vp, vp]
+    L.h2r_lookups_per_record.argtypes = [vp]
+    L.h2r_lookups_per_record.restype = u32
+    L.h2r_trace_lookup_permutation.argtypes = [vp, vp, u64, u64, u64, u32, vp, vp, vp]
     L.h2r_trace_flatten.argtypes = [vp, vp, vp]
     L.h2r_pow_trace_flatten.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, vp]
     L.h2r_profile_enable.argtypes = [u32]

@@ -121,6 +121,18 @@ class Trace:
         return hist
 
 
+    def lookup_permutation(self):
+        """(perm, rows): stable grouping of every element's lookup cells by table row (h2r_trace_lookup_permutation)."""
+        n = lib().h2r_lookups_per_record(self.chip._ctx) * self.num_mul_mods
+        perm = torch.empty((self.batch, n), dtype=torch.int32, device=self.buf.device)
+        rows = torch.empty((self.batch, n), dtype=torch.int16, device=self.buf.device)
+        off = self.pow_layout.off_records if self.pow_layout is not None else 0
+        check(lib().h2r_trace_lookup_permutation(self.chip._ctx, self.buf.data_ptr(), off, self.elem_stride, self.batch,
+                                                 self.num_mul_mods, perm.data_ptr(), rows.data_ptr(), self.chip._stream()),
+              "h2r_trace_lookup_permutation")
+        return perm, rows
+
+
 @dataclass
 class BatchResult:
     value: AssignedInteger      # a*b mod n  /  a^e mod n

@@ -517,6 +517,41 @@ int32_t h2r_trace_lookup_hist(const h2r_ctx *ctx, const void *trace, uint64_t fi
     return H2R_OK;
 }
 
+uint32_t h2r_lookups_per_record(const h2r_ctx *ctx) {
+    if (!ctx) return 0;
+    const h2r_layout &lo = ctx->layout;
+    return 2 * lo.num_limbs * lo.limb_nsub + (lo.num_cols - 1) * lo.carry_nsub;
+}
+
+int32_t h2r_trace_lookup_permutation(const h2r_ctx *ctx, const void *trace, uint64_t first_record_off, uint64_t elem_stride,
+                                     uint64_t num_elems, uint32_t records_per_elem, uint32_t *perm_out, uint16_t *rows_out,
+                                     h2r_stream_t stream) {
+    if (!ctx || !trace || !perm_out) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    if (num_elems == 0 || records_per_elem == 0) return H2R_OK;
+    const h2r_layout &lo = ctx->layout;
+    if (ctx->hist_len > (u32)PERM_MAX_ROWS || lo.limb_nsub != 8) return H2R_E_UNSUPPORTED;
+    PermArgs pa;
+    std::memset(&pa, 0, sizeof pa);
+    HistArgs &ha = pa.h;
+    ha.trace = static_cast<const u8 *>(trace); ha.first_record_off = first_record_off; ha.elem_stride = elem_stride;
+    ha.record_stride = lo.record_stride; ha.num_elems = num_elems; ha.records_per_elem = records_per_elem;
+    ha.off_q_sub = lo.plane_off[H2R_PL_Q_SUB]; ha.off_r_sub = lo.plane_off[H2R_PL_R_SUB];
+    ha.off_carry_sub = lo.plane_off[H2R_PL_CARRY_SUB];
+    ha.L = lo.num_limbs; ha.C = lo.num_cols; ha.carry_nsub = lo.carry_nsub; ha.carry_sub_stride = lo.carry_sub_stride;
+    ha.carry_has_ov = (lo.carry_bits % lo.carry_sub_bits) ? 1 : 0;
+    ha.tab0_len = ctx->tab0_len; ha.tab1_off = ctx->tab1_off; ha.tab1_len = ctx->tab1_len;
+    ha.tab2_off = ctx->tab2_off; ha.tab2_len = ctx->tab2_len; ha.hist_len = ctx->hist_len;
+    pa.cells_per_record = h2r_lookups_per_record(ctx);
+    const u64 n_cells = (u64)pa.cells_per_record * records_per_elem;
+    if (n_cells >= (1ull << 31)) return H2R_E_UNSUPPORTED;
+    pa.n_cells = (u32)n_cells; pa.perm = perm_out; pa.rows = rows_out;
+    HIP_TRY(hipSetDevice(ctx->params.device));
+    hipLaunchKernelGGL(perm_kernel, dim3((unsigned)num_elems), dim3(256), 0, static_cast<hipStream_t>(stream), pa);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
+
 // ---- host-side flatten: planes -> the reference's assignment order -----------------------------------
 namespace {
 struct Out { u8 *p; };

@@ -1135,6 +1135,76 @@ __global__ __launch_bounds__(256) void hist_kernel(HistArgs a) {
     for (u32 k = threadIdx.x; k < a.hist_len; k += blockDim.x) a.hist[elem * a.hist_len + k] = h[k];
 }
 
+// Grouped ("sorted") arrangement of an element's lookup inputs: a stable counting sort of its sub-limb
+// cells by lookup-table row.  Cell ids follow the flat stream: record t contributes, in order, the q
+// sub-limbs, the r sub-limbs and the carry sub-limbs (cells_per_record = 16 L + (C-1) carry_nsub).
+// perm[k] = id of the cell at sorted position k; rows[k] = its table row (the halo2 lookup argument's
+// permuted input column A' is the row values in this order; the theta-compression is [3P]).
+struct PermArgs {
+    HistArgs h;
+    u32 cells_per_record, n_cells;
+    u32 *perm;     // [elem][n_cells]
+    uint16_t *rows;  // nullable [elem][n_cells]
+};
+constexpr int PERM_MAX_ROWS = 1024;
+
+__device__ __forceinline__ u32 perm_cell_key(const HistArgs &a, const u8 *base, u32 cell, u32 cells_per_record) {
+    const u32 rcd = cell / cells_per_record, li = cell - rcd * cells_per_record;
+    const u8 *rec = base + (u64)rcd * a.record_stride;
+    const u32 nl = a.L * 8;
+    if (li < nl) return rec[a.off_q_sub + li];
+    if (li < 2 * nl) return rec[a.off_r_sub + (li - nl)];
+    const u32 cj = li - 2 * nl, cc = cj / a.carry_nsub, j = cj - cc * a.carry_nsub;
+    const u32 v = rec[a.off_carry_sub + (u64)cc * a.carry_sub_stride + j];
+    return (j < a.carry_nsub - a.carry_has_ov) ? a.tab1_off + v : a.tab2_off + v;
+}
+
+__global__ __launch_bounds__(256) void perm_kernel(PermArgs p) {
+    __shared__ u32 cnt[4][PERM_MAX_ROWS];   // per-wave row counts, then per-wave running bases
+    __shared__ u32 start[PERM_MAX_ROWS];
+    const HistArgs &a = p.h;
+    const u64 elem = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u32 R = a.hist_len;
+    for (u32 k = threadIdx.x; k < 4 * PERM_MAX_ROWS; k += 256) (&cnt[0][0])[k] = 0;
+    __syncthreads();
+    const u8 *base = a.trace + elem * a.elem_stride + a.first_record_off;
+    const u32 Q = (p.n_cells + 3) / 4, c0 = wave * Q, c1 = min(p.n_cells, c0 + Q);
+    for (u32 c = c0 + lane; c < c1; c += 64) atomicAdd(&cnt[wave][perm_cell_key(a, base, c, p.cells_per_record)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {  // exclusive scan over the (few hundred) table rows
+        u32 run = 0;
+        for (u32 r = 0; r < R; ++r) { start[r] = run; run += cnt[0][r] + cnt[1][r] + cnt[2][r] + cnt[3][r]; }
+    }
+    __syncthreads();
+    for (u32 r = threadIdx.x; r < R; r += 256) {  // per-wave bases keep the sort stable across the 4 slices
+        u32 b = start[r];
+        for (int w = 0; w < 4; ++w) { const u32 t = cnt[w][r]; cnt[w][r] = b; b += t; }
+    }
+    __syncthreads();
+    u32 *perm = p.perm + elem * (u64)p.n_cells;
+    uint16_t *rows = p.rows ? p.rows + elem * (u64)p.n_cells : nullptr;
+    for (u32 cb = c0; cb < c1; cb += 64) {  // wave-level multi-split, 64 cells at a time, in cell order
+        const u32 c = cb + lane;
+        const bool valid = c < c1;
+        const u32 key = valid ? perm_cell_key(a, base, c, p.cells_per_record) : 0xffffffffu;
+        u64 remaining = __ballot(valid);
+        u32 pos = 0;
+        while (remaining) {
+            const int leader = __builtin_ctzll(remaining);
+            const u32 k = __shfl(key, leader);
+            const u64 mask = __ballot(valid && key == k);
+            const u32 b = cnt[wave][k];
+            if (valid && key == k) pos = b + (u32)__builtin_popcountll(mask & ((1ull << lane) - 1));
+            wave_sync();
+            if (lane == leader) cnt[wave][k] = b + (u32)__builtin_popcountll(mask);
+            wave_sync();
+            remaining &= ~mask;
+        }
+        if (valid) { perm[pos] = c; if (rows) rows[pos] = (uint16_t)key; }
+    }
+}
+
 // stand-alone RangeChip::assign decomposition of a value array (8- or 16-byte values)
 struct DecompArgs {
     const u8 *values; u32 value_bytes; u64 count; u32 bit_len, sub_bits, nsub, has_ov;

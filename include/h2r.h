@@ -253,6 +253,16 @@ int32_t h2r_trace_lookup_hist(const h2r_ctx *ctx, const void *trace, uint64_t fi
                               uint64_t elem_stride, uint64_t num_elems, uint32_t records_per_elem,
                               uint32_t *hist_out, h2r_stream_t stream);
 
+/* Grouped arrangement of each element's lookup inputs (stable counting sort by table row; the
+ * theta-independent core of the halo2 lookup permutation, which itself is third-party and unpinned).
+ * Cell ids follow the flat stream: record t contributes q sub-limbs, r sub-limbs, carry sub-limbs
+ * (h2r_lookups_per_record() cells).  perm_out[elem][k] = id of the cell at sorted position k;
+ * rows_out (nullable) [elem][k] = its table row in h2r_trace_lookup_hist order. */
+uint32_t h2r_lookups_per_record(const h2r_ctx *ctx);
+int32_t h2r_trace_lookup_permutation(const h2r_ctx *ctx, const void *trace, uint64_t first_record_off,
+                                     uint64_t elem_stride, uint64_t num_elems, uint32_t records_per_elem,
+                                     uint32_t *perm_out, uint16_t *rows_out, h2r_stream_t stream);
+
 /* ---- host-side helpers (no device work) --------------------------------------------------------
  * h2r_trace_flatten: walk ONE record (host copy, record_stride bytes) in the reference's assignment
  * order and write its flat op-trace stream (layout.stream_bytes bytes; widths in h2r_layout).

@@ -402,3 +402,44 @@ def test_verify_pkcs1v15_1024(H):
         rc, ok, s_em = o.pkcs1v15_em_check(out, o.limbs(hashes[i], 4))
         assert ok == [1, 0, 0][i]
         assert np.array_equal(res.flatten(i), np.concatenate([s_if, s_pow, s_em])), i
+
+
+def test_lookup_permutation(H):
+    """Grouped arrangement of the lookup inputs: a stable counting sort of every element's
+    sub-limb cells by table row, checked against numpy's stable argsort of the oracle's sub-limb sequence."""
+    chip = H.BigIntChip(64, 2048)
+    o = Oracle(64, 32)
+    rng = random.Random(17)
+    N = [rand_modulus(rng, 2048) for _ in range(3)]
+    X = [rng.randrange(n) for n in N]
+    res = chip.pow_mod_fixed_exp(chip.assign_integer(X), 65537, chip.assign_integer(N))
+    perm, rows = res.trace.lookup_permutation()
+    hist = res.trace.lookup_hist().cpu().numpy()
+    perm, rows = perm.cpu().numpy(), rows.cpu().numpy()
+    p = o.p
+    L, C = p.L, 2 * p.L - 1
+    msb = o.mul_mod_stream_bytes
+    per_col = 5 * p.WB + 2 * p.CB + 4 * p.LB + 2
+    for i in range(3):
+        rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(X[i]), o.limbs(N[i]), 65537)
+        keys = []
+        for t in range(19):
+            st = ost[t * msb:(t + 1) * msb]
+            pos = 0
+            for _ in range(2 * L):
+                pos += p.LB
+                keys.extend(int(v) for v in st[pos:pos + 8]); pos += 8
+            pos += 2 * L * L * p.WB + L * p.WB
+            for c in range(C):
+                pos += per_col
+                if c < C - 1:
+                    pos += p.CB
+                    for j in range(p.carry_nsub):
+                        keys.append((256 if j == p.carry_nsub - 1 else 0) + int(st[pos])); pos += 1
+                pos += 2
+        keys = np.array(keys)
+        assert len(keys) == 20330 == perm.shape[1]
+        want = np.argsort(keys, kind="stable")
+        assert np.array_equal(perm[i], want)
+        assert np.array_equal(rows[i], keys[want])
+        assert np.array_equal(np.bincount(keys, minlength=320), hist[i])
