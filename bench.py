@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="signatures per GPU per step")
     ap.add_argument("--workload", default="rsa2048_e65537", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="fully stream-ordered calls (chain then trace per step) instead of the two-stream pipeline")
     args = ap.parse_args()
 
     env = DistEnv.from_environment(args.gpus)
@@ -105,24 +107,38 @@ def main():
     n_dev, x_dev = chip.assign_integer(un), chip.assign_integer(ux)
     pl = chip.pow_fixed_layout(e)
     dev = "cuda:%d" % env.local_rank
-    trace_buf = torch.empty(batch * pl.elem_stride, dtype=torch.uint8, device=dev)
-    workspace = torch.empty(chip.workspace_bytes(batch, pl.num_mul_mods), dtype=torch.uint8, device=dev)
-    out = torch.empty((batch, chip.num_limbs), dtype=chip.torch_dtype, device=dev)
-    status = torch.zeros(batch, dtype=torch.uint8, device=dev)
+    # two buffer sets: in pipeline mode step k+1's chain kernel overlaps step k's trace kernel
+    nbuf = 1 if args.no_pipeline else 2
+    trace_bufs = [torch.empty(batch * pl.elem_stride, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    workspaces = [torch.empty(chip.workspace_bytes(batch, pl.num_mul_mods), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    outs = [torch.empty((batch, chip.num_limbs), dtype=chip.torch_dtype, device=dev) for _ in range(nbuf)]
+    statuses = [torch.zeros(batch, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    pipe = None if args.no_pipeline else chip.pipeline()
+    counter = [0]
 
     def step():
-        return chip.pow_mod_fixed_exp(x_dev, e, n_dev, want_trace=True, trace_buf=trace_buf, check_in_field=True,
-                                      workspace=workspace, out=out, status=status)
+        b = counter[0] % nbuf
+        counter[0] += 1
+        if pipe is None:
+            chip.pow_mod_fixed_exp(x_dev, e, n_dev, want_trace=True, trace_buf=trace_bufs[b], check_in_field=True,
+                                   workspace=workspaces[b], out=outs[b], status=statuses[b])
+        else:
+            pipe.modpow_public_key(x_dev, e, n_dev, trace_bufs[b], workspaces[b], outs[b], statuses[b])
+        return b
 
     for _ in range(warmup):
         step()
+    if pipe is not None:
+        pipe.join()
     torch.cuda.synchronize()
     _lib.profile_enable(2 * steps + 8)
     env.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        res = step()
+        last = step()
+    if pipe is not None:
+        pipe.join()   # every step's trace is complete before the clock stops
     torch.cuda.synchronize()
     env.barrier()
     dt = env.max_over_ranks(time.perf_counter() - t0)
@@ -131,8 +147,14 @@ def main():
     _lib.profile_enable(0)
 
     # post-run: correctness of what was timed + the result gather (rank 0 receives every shard's x^e mod n)
+    out, status = outs[last], statuses[last]
     assert int(status.max().item()) == 0 or (w, bits) != (64, 2048), "unexpected per-element status"
-    got = res.value.to_big_uint()
+    got = H.AssignedInteger(out, w).to_big_uint()
+    # the trace that was timed is the real thing: element 0 of the last step, byte-exact vs pow() through q*n+r
+    tr = H.Trace(chip, trace_bufs[last], batch, pl)
+    q0 = int.from_bytes(tr.plane(0, 0, "Q").tobytes(), "little")
+    r0 = int.from_bytes(tr.plane(0, 0, "R").tobytes(), "little")
+    assert xs[0] * xs[0] == q0 * ns[0] + r0, "first mul_mod record of the timed trace is wrong"
     for i in (0, 1, 2, batch - 1):
         if i < batch:
             assert got[i] == pow(xs[i], e, ns[i]), "GPU result differs from pow(x, e, n)"
@@ -156,7 +178,8 @@ def main():
             "config": {"workload": "%s batch=%d per GPU, %d-bit limbs, full op-trace (%d B/assign)" %
                        (args.workload, batch, w, algo_bytes_per_assign),
                        "per_gpu_batch": batch, "global_batch": env.world * batch,
-                       "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world},
+                       "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world,
+                       "pipeline": "two-stream (chain k+1 || trace k)" if pipe is not None else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": None, "kernel": "trace_kernel<%d,%d>" % (w, chip.num_limbs),

@@ -255,5 +255,40 @@ class BigIntChip:
                                       status.data_ptr(), None, self._stream()), "pow_mod")
         return BatchResult(AssignedInteger(out, self.limb_width), Trace(self, trace, batch, pl) if want_trace else None, status)
 
+    def pipeline(self) -> "Pipeline":
+        """Opt-in two-stream pipeline (h2r_pipeline_*): consecutive modpow batches overlap chain and trace."""
+        return Pipeline(self)
+
     def workspace_bytes(self, batch: int, num_mul_mods: int) -> int:
         return int(lib().h2r_workspace_bytes(self._ctx, batch, num_mul_mods))
+
+
+class Pipeline:
+    """h2r_pipeline: batch k+1's off-circuit chain overlaps batch k's record emission (two HIP streams).
+    Callers alternate between (at least) two buffer sets and call join() before reading the last trace."""
+
+    def __init__(self, chip: BigIntChip):
+        self.chip = chip
+        self._p = ctypes.c_void_p()
+        check(lib().h2r_pipeline_create(chip._ctx, ctypes.byref(self._p)), "h2r_pipeline_create")
+
+    def modpow_public_key(self, x: AssignedInteger, e: int, n: AssignedInteger, trace_buf, workspace, out, status):
+        eb = _e_bytes(e)
+        check(lib().h2r_pipeline_modpow_public_key(self._p, x.data_ptr(), n.data_ptr(), eb, len(eb), x.batch,
+                                                   self.chip._flags(n, x.batch), trace_buf.data_ptr(), out.data_ptr(),
+                                                   status.data_ptr(), workspace.data_ptr(), self.chip._stream()),
+              "h2r_pipeline_modpow_public_key")
+
+    def join(self):
+        check(lib().h2r_pipeline_join(self._p, self.chip._stream()), "h2r_pipeline_join")
+
+    def close(self):
+        if self._p:
+            lib().h2r_pipeline_destroy(self._p)
+            self._p = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

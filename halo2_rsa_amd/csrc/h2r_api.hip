@@ -114,7 +114,8 @@ hipError_t launch_trace_t(const TraceArgs &ta, hipStream_t st) {
     constexpr int IPB = TPI >= 256 ? 1 : 256 / TPI;
     const u64 blocks = (ta.n_items + IPB - 1) / IPB;
     if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL((trace_kernel<LW, L>), dim3((unsigned)blocks), dim3(256), 0, st, ta);
+    // dyn_lds > 0 caps the blocks resident per CU (leaves wave slots for a co-running chain kernel)
+    hipLaunchKernelGGL((trace_kernel<LW, L>), dim3((unsigned)blocks), dim3(256), ta.dyn_lds, st, ta);
     return hipGetLastError();
 }
 hipError_t launch_trace(u32 w, u32 L, const TraceArgs &ta, hipStream_t st) {
@@ -156,14 +157,19 @@ void fill_trace_args(const h2r_ctx *c, TraceArgs &ta) {
     ta.record_stride = lo.record_stride;
     ta.const_rec = c->const_rec_dev;
     if (const char *ab = std::getenv("H2R_ABLATE")) ta.ablate = (u32)std::atoi(ab);
+    if (const char *dl = std::getenv("H2R_TRACE_DYN_LDS")) ta.dyn_lds = (u32)std::atoi(dl);
+    if (const char *pr = std::getenv("H2R_TRACE_PRIO")) ta.prio = (u32)std::atoi(pr);
 }
 
 // Common driver: chain kernel (q, r of every mul_mod) then trace kernel (the witness records).
 int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const void *n, const void *e_limbs,
                  u32 e_num_limbs, u32 exp_limb_bits, const ExpBits *eb, u32 check_in_field, u64 batch, u32 flags,
                  u32 T, void *trace, u64 elem_stride, u64 off_records, const h2r_pow_layout *pl, void *out,
-                 uint8_t *status, void *workspace, hipStream_t st) {
+                 uint8_t *status, void *workspace, hipStream_t st, hipStream_t trace_st = nullptr,
+                 hipEvent_t chain_done = nullptr) {
+    // trace_st != nullptr (pipeline mode): the record-writing kernel runs on trace_st after `chain_done`
     if (!c || !n || !a || !status) return H2R_E_NULL;
+    if (trace_st && !workspace) return H2R_E_NULL;
     if (c->params.device < 0) return H2R_E_UNSUPPORTED;  // host-only context
     if (batch == 0) return H2R_OK;
     if (batch * (u64)(T ? T : 1) >= (1ull << 32)) return H2R_E_UNSUPPORTED;  // item index is 32-bit in the kernels
@@ -209,8 +215,14 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         ta.n = n; ta.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : c->L;
         ta.status = status; ta.n_items = batch * T; ta.T = T;
         ta.trace = static_cast<u8 *>(trace); ta.elem_stride = elem_stride; ta.off_records = off_records;
-        ProfScope ps(H2R_KERNEL_TRACE, st);
-        HIP_TRY(launch_trace(lo.limb_width, c->L, ta, st));
+        hipStream_t ts = st;
+        if (trace_st) {
+            HIP_TRY(hipEventRecord(chain_done, st));
+            HIP_TRY(hipStreamWaitEvent(trace_st, chain_done, 0));
+            ts = trace_st;
+        }
+        ProfScope ps(H2R_KERNEL_TRACE, ts);
+        HIP_TRY(launch_trace(lo.limb_width, c->L, ta, ts));
     }
     return H2R_OK;
 }
@@ -462,6 +474,73 @@ int32_t h2r_verify_trace_flatten(const h2r_ctx *ctx, const h2r_verify_layout *vl
     o += vl->pow.stream_bytes;
     std::memcpy(o, e + vl->off_em, vl->em_stream_bytes); o += vl->em_stream_bytes;
     if ((u64)(o - static_cast<u8 *>(stream_out)) != vl->stream_bytes) return H2R_E_SHAPE;
+    return H2R_OK;
+}
+
+struct h2r_pipeline {
+    const h2r_ctx *ctx;
+    hipStream_t aux;
+    hipEvent_t chain_done[2], trace_done[2];
+    u32 k;            // calls issued
+    bool pending;     // trace_done[(k-1)&1] not yet joined into a user stream
+};
+
+int32_t h2r_pipeline_create(const h2r_ctx *ctx, h2r_pipeline **out) {
+    if (!ctx || !out) return H2R_E_NULL;
+    *out = nullptr;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    HIP_TRY(hipSetDevice(ctx->params.device));
+    h2r_pipeline *p = new (std::nothrow) h2r_pipeline();
+    if (!p) return H2R_E_HIP;
+    p->ctx = ctx; p->k = 0; p->pending = false;
+    if (!hip_ok(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking), "hipStreamCreate")) { delete p; return H2R_E_HIP; }
+    for (int i = 0; i < 2; ++i) {
+        if (!hip_ok(hipEventCreateWithFlags(&p->chain_done[i], hipEventDisableTiming), "hipEventCreate") ||
+            !hip_ok(hipEventCreateWithFlags(&p->trace_done[i], hipEventDisableTiming), "hipEventCreate")) { delete p; return H2R_E_HIP; }
+    }
+    *out = p;
+    return H2R_OK;
+}
+
+void h2r_pipeline_destroy(h2r_pipeline *p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->params.device);
+    (void)hipStreamSynchronize(p->aux);
+    for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(p->chain_done[i]); (void)hipEventDestroy(p->trace_done[i]); }
+    (void)hipStreamDestroy(p->aux);
+    delete p;
+}
+
+int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream) {
+    if (!p) return H2R_E_NULL;
+    if (p->pending) {
+        HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->trace_done[(p->k - 1) & 1], 0));
+        p->pending = false;
+    }
+    return H2R_OK;
+}
+
+int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len,
+                                       uint64_t batch, uint32_t flags, void *trace, void *out, uint8_t *status,
+                                       void *workspace, h2r_stream_t stream) {
+    if (!p || !trace || !workspace) return H2R_E_NULL;
+    const h2r_ctx *ctx = p->ctx;
+    ExpBits eb; u32 T;
+    int32_t rc = exp_to_bits(e_le, e_len, &eb, &T);
+    if (rc) return rc;
+    h2r_pow_layout pl;
+    rc = h2r_pow_fixed_layout(ctx, e_le, e_len, &pl);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const u32 slot = p->k & 1;
+    rc = run_path(ctx, CHAIN_POW_FIXED, x, nullptr, n, nullptr, 0, 0, &eb, 1, batch, flags, T, trace, pl.elem_stride,
+                  pl.off_records, &pl, out, status, workspace, st, p->aux, p->chain_done[slot]);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(p->trace_done[slot], p->aux));
+    // lazily join the PREVIOUS call's trace kernel: enqueued behind this call's chain kernel, so the two overlap
+    if (p->pending) HIP_TRY(hipStreamWaitEvent(st, p->trace_done[slot ^ 1], 0));
+    p->pending = true;
+    p->k += 1;
     return H2R_OK;
 }
 

@@ -95,7 +95,7 @@ struct Geo {
 
 template <int K, int NW>
 struct ChainLds {
-    u32 opa[K];                  // A operand of the running multiplication
+    alignas(16) u32 opa[K];      // A operand of the running multiplication
     u32 bpad[3 * K];             // B operand, data at [K, 2K), zeros elsewhere
     u32 nnpad[3 * K];            // normalised modulus n' = n << s, padded like bpad
     u32 mupad[3 * K];            // mu' = floor((2^(64K) - 1) / n') - 2^(32K), padded
@@ -127,11 +127,24 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
         u64 acc = 0;
         u32 ov = 0;
         const u32 *bp = Bpad + K + c - j0;
-#pragma unroll 8
-        for (int j = 0; j < G::SL; ++j) {
-            const u64 p = (u64)A[j0 + j] * bp[-j];
-            acc += p;
-            ov += (acc < p) ? 1u : 0u;
+        const u32 *ap = A + j0;
+        // acc(64) += a*b with the multiplier's own carry-out feeding the overflow word: 2 VALU per product
+        // (v_mad_u64_u32 writes the carry to an SGPR pair; gfx950 needs 2 wait states before a VALU reads it).
+        auto mac = [&](u32 av, u32 bv) {
+            u64 carry;
+            asm volatile("v_mad_u64_u32 %0, %2, %3, %4, %0\n\ts_nop 1\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2"
+                         : "+v"(acc), "+v"(ov), "=&s"(carry) : "v"(av), "v"(bv));
+        };
+        if constexpr (G::SL % 4 == 0) {
+#pragma unroll 2
+            for (int j = 0; j < G::SL; j += 4) {
+                const uint4 a4 = *reinterpret_cast<const uint4 *>(ap + j);  // broadcast 16-byte read
+                const u32 b0 = bp[-j], b1 = bp[-j - 1], b2 = bp[-j - 2], b3 = bp[-j - 3];
+                mac(a4.x, b0); mac(a4.y, b1); mac(a4.z, b2); mac(a4.w, b3);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < G::SL; ++j) mac(ap[j], bp[-j]);
         }
         if (c < 2 * K) { s.part[ss][0][c] = (u32)acc; s.part[ss][1][c] = (u32)(acc >> 32); s.part[ss][2][c] = ov; }
     }
@@ -593,6 +606,8 @@ struct TraceArgs {
     u64 wm[3];                          // word_max (chip.rs:838)
     u32 carry_bits, carry_sub_bits, carry_nsub, carry_sub_stride;
     u32 ablate;                         // timing experiments only (H2R_ABLATE); 0 in production
+    u32 dyn_lds;                        // extra dynamic LDS per block: caps residency (pipeline co-scheduling)
+    u32 prio;                           // raise wave priority (pipeline co-scheduling)
 };
 
 template <int LW, int L>
@@ -695,6 +710,7 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
     __shared__ TraceLds<LW, L> lds_all[IPB];
     __shared__ u64 xg[4], xp[4], xbad[4];  // per-wave carry masks for multi-wave items
 
+    if (args.prio) __builtin_amdgcn_s_setprio(3);  // co-scheduled with chain_kernel: keep the store stream fed
     const int tid = threadIdx.x;
     const int slot = tid / TPI, t = tid % TPI;
     const int h = t / L, i = t % L;

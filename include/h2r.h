@@ -207,6 +207,22 @@ int32_t h2r_modpow_public_key_batch(const h2r_ctx *ctx, const void *x, const voi
                                     uint32_t flags, void *trace, void *out, uint8_t *status,
                                     void *workspace, h2r_stream_t stream);
 
+/* ---- pipelined form (opt-in): overlap batch k+1's off-circuit chain with batch k's witness emission
+ * A pipeline owns a second HIP stream.  h2r_pipeline_modpow_public_key() is h2r_modpow_public_key_batch
+ * except that its record-writing kernel runs on the pipeline's stream and `stream` joins it only at
+ * the NEXT pipelined call (after that call's chain kernel has been enqueued) or at h2r_pipeline_join().
+ * Until then the call's trace must not be read.  Consecutive calls must use distinct trace / out /
+ * status / workspace buffers (workspace is mandatory here).  Not thread-safe: one pipeline per
+ * producer thread.  The chain's results (`out`, `status`) are stream-ordered on `stream` as usual. */
+typedef struct h2r_pipeline h2r_pipeline;
+int32_t h2r_pipeline_create(const h2r_ctx *ctx, h2r_pipeline **out);
+void h2r_pipeline_destroy(h2r_pipeline *p);
+int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const void *n,
+                                       const uint8_t *e_le_bytes, size_t e_len, uint64_t batch,
+                                       uint32_t flags, void *trace, void *out, uint8_t *status,
+                                       void *workspace, h2r_stream_t stream);
+int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream);
+
 /* ---- RSAInstructions::verify_pkcs1v15_signature after the SHA step (src/chip.rs:128-199) ------
  * For every element: the assert_in_field(sig, n) witness (src/chip.rs:106 ->
  * big_integer/chip.rs:1150-1158, 908-919, 310-373, 245-297, 1286-1318, 780-805), the

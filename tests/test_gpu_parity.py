@@ -443,3 +443,44 @@ def test_lookup_permutation(H):
         assert np.array_equal(perm[i], want)
         assert np.array_equal(rows[i], keys[want])
         assert np.array_equal(np.bincount(keys, minlength=320), hist[i])
+
+
+def test_pipelined_calls_match_oracle(H):
+    """h2r_pipeline_*: four back-to-back pipelined modpow batches (chain k+1 overlapping trace k) produce the
+    same bytes as the oracle for every batch."""
+    chip = H.BigIntChip(64, 2048)
+    o = Oracle(64, 32)
+    pipe = chip.pipeline()
+    pl = chip.pow_fixed_layout(65537)
+    rng = random.Random(31)
+    B = 96
+    sets = []
+    for k in range(4):
+        N = [rand_modulus(rng, 2048) for _ in range(B)]
+        X = [rng.randrange(n) for n in N]
+        if k == 2:
+            X[5] = N[5] + 1      # not in field -> status, other elements unaffected
+        bufs = dict(N=N, X=X, n=chip.assign_integer(N), x=chip.assign_integer(X),
+                    trace=torch.empty(B * pl.elem_stride, dtype=torch.uint8, device="cuda"),
+                    ws=torch.empty(chip.workspace_bytes(B, pl.num_mul_mods), dtype=torch.uint8, device="cuda"),
+                    out=torch.empty((B, 32), dtype=torch.int64, device="cuda"),
+                    status=torch.zeros(B, dtype=torch.uint8, device="cuda"))
+        sets.append(bufs)
+    for s in sets:
+        pipe.modpow_public_key(s["x"], 65537, s["n"], s["trace"], s["ws"], s["out"], s["status"])
+    pipe.join()
+    torch.cuda.synchronize()
+    for k, s in enumerate(sets):
+        st = s["status"].cpu().tolist()
+        assert all(v == 0 for i, v in enumerate(st) if not (k == 2 and i == 5))
+        if k == 2:
+            assert st[5] == H.H2R_E_NOT_IN_FIELD
+        out = H.AssignedInteger(s["out"], 64).to_big_uint()
+        tr = H.Trace(chip, s["trace"], B, pl)
+        for i in (0, 5, 41, B - 1):
+            if k == 2 and i == 5:
+                continue
+            assert out[i] == pow(s["X"][i], 65537, s["N"][i])
+            rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(s["X"][i]), o.limbs(s["N"][i]), 65537)
+            assert np.array_equal(ost, tr.flatten(i)), (k, i)
+    pipe.close()
