@@ -136,7 +136,10 @@ hipError_t launch_chain(u32 K, const ChainArgs &ca, hipStream_t st) {
         case 8: return launch_chain_t<8, 1>(ca, st);
         case 16: return launch_chain_t<16, 1>(ca, st);
         case 32: return launch_chain_t<32, 4>(ca, st);
-        case 64: return launch_chain_t<64, 8>(ca, st);
+        case 64: { static const int nw = std::getenv("H2R_CHAIN_NW") ? std::atoi(std::getenv("H2R_CHAIN_NW")) : 4;  // 4 measured best (profiles/r01_notes)
+                   if (nw == 8) return launch_chain_t<64, 8>(ca, st);
+                   if (nw == 2) return launch_chain_t<64, 2>(ca, st);
+                   return launch_chain_t<64, 4>(ca, st); }
         case 128: return launch_chain_t<128, 8>(ca, st);
         default: return hipErrorInvalidValue;
     }
@@ -217,6 +220,10 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         ta.trace = static_cast<u8 *>(trace); ta.elem_stride = elem_stride; ta.off_records = off_records;
         hipStream_t ts = st;
         if (trace_st) {
+            // co-scheduled with the next batch's chain kernel: cap the trace kernel's residency (its store
+            // stream does not need full occupancy) 
+            // (measured sweep: profiles/r01_pipeline_sweep.txt -- 32000 B extra LDS = 3 blocks/CU, normal priority)
+            if (!std::getenv("H2R_TRACE_DYN_LDS")) ta.dyn_lds = 32000;
             HIP_TRY(hipEventRecord(chain_done, st));
             HIP_TRY(hipStreamWaitEvent(trace_st, chain_done, 0));
             ts = trace_st;

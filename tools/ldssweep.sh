@@ -1,6 +1,6 @@
 #!/bin/bash
-for pr in 0 1; do
-for a in 32000 60000 100000 140000; do
+for pr in 1 0; do
+for a in 0 20000 32000 45000 60000 100000; do
   H2R_TRACE_PRIO=$pr H2R_TRACE_DYN_LDS=$a timeout 100 python bench.py --steps 40 --warmup 4 --no-cpu-baseline 2>/dev/null | tail -1 > /tmp/ab.json
   python - <<PY
 import json
