@@ -137,8 +137,6 @@ inline void layout_compute(u32 w, u32 L, h2r_layout *o) {
         u64 cnt = o->plane_count[p];
         if (cnt == C || cnt == C - 1) cnt = 2 * L;
         off += round_up((u64)o->plane_elem[p] * cnt, 256);
-        if (p >= H2R_PL_AB_LO && p <= H2R_PL_QN_HI)
-            if (const char *pp = std::getenv("H2R_PLANE_PAD")) off += 256ull * (u64)std::atoi(pp);  // experiment knob
     }
     o->record_stride = off;
     // HBM channel interleaving: record strides of 253*256 / 257*256 bytes alias (measured -10 % on the

@@ -484,3 +484,55 @@ def test_pipelined_calls_match_oracle(H):
             rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(s["X"][i]), o.limbs(s["N"][i]), 65537)
             assert np.array_equal(ost, tr.flatten(i)), (k, i)
     pipe.close()
+
+
+def _check_pow_batch(H, chip, o, X, N, e, res, sample, rng):
+    torch.cuda.synchronize()
+    assert not res.status.cpu().numpy().any()
+    out = res.value.to_big_uint()
+    assert all(out[i] == pow(X[i], e, N[i]) for i in range(len(X)))
+    for i in sample:
+        rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(X[i]), o.limbs(N[i]), e)
+        assert rc == 0 and np.array_equal(ost, res.trace.flatten(i)), i
+
+
+def test_config3_shard_size_properties(H):
+    """BASELINE config 3: one GPU's shard (8,192 signatures of the 65,536) -- every result equals pow(x, e, n),
+    sampled elements byte-exact, and the per-element lookup multiplicities always sum to 20,330."""
+    chip = H.BigIntChip(64, 2048)
+    o = Oracle(64, 32)
+    rng = random.Random(0x68327273 + 3)
+    B = 8192
+    N = [rand_modulus(rng, 2048) for _ in range(B)]
+    X = [rng.randrange(n) for n in N]
+    res = chip.pow_mod_fixed_exp(chip.assign_integer(X), 65537, chip.assign_integer(N))
+    _check_pow_batch(H, chip, o, X, N, 65537, res, [0, 1, B // 2, B - 1] + rng.sample(range(B), 4), rng)
+    hist = res.trace.lookup_hist()
+    assert int(hist.sum(dim=1).min().item()) == int(hist.sum(dim=1).max().item()) == 20330
+
+
+def test_config4_rsa4096_w32_full_batch(H):
+    """BASELINE config 4: RSA-4096 as 128 x 32-bit limbs, batch 4096 (44 GB of trace)."""
+    chip = H.BigIntChip(32, 4096)
+    o = Oracle(32, 128)
+    rng = random.Random(0x68327273 + 4)
+    B = 4096
+    N = [rand_modulus(rng, 4096) for _ in range(B)]
+    X = [rng.randrange(n) for n in N]
+    res = chip.pow_mod_fixed_exp(chip.assign_integer(X), 65537, chip.assign_integer(N))
+    _check_pow_batch(H, chip, o, X, N, 65537, res, [0, B - 1] + rng.sample(range(B), 2), rng)
+
+
+def test_config5_large_exponent(H):
+    """BASELINE config 5: RSA-2048 with a 2048-bit exponent (2048 squarings + popcount(e) multiplies, one
+    dependent chain per signature), batch 256 (about 50 GB of trace)."""
+    chip = H.BigIntChip(64, 2048)
+    o = Oracle(64, 32)
+    rng = random.Random(0x68327273 + 5)
+    B = 256
+    e = rng.getrandbits(2048) | (1 << 2047)
+    N = [rand_modulus(rng, 2048) for _ in range(B)]
+    X = [rng.randrange(n) for n in N]
+    res = chip.pow_mod_fixed_exp(chip.assign_integer(X), e, chip.assign_integer(N))
+    assert res.trace.num_mul_mods == 2048 + bin(e).count("1")
+    _check_pow_batch(H, chip, o, X, N, e, res, [0, B - 1], rng)
