@@ -34,6 +34,22 @@ from halo2_rsa_amd.dist import DistEnv  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
+
+def pmc_traffic(kernel_name, batch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json: WRITE_SIZE + 2*FETCH_SIZE, KB units, collected in separate --pmc
+    passes as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read from inside this process,
+    so the number is the measured one for the same kernel/batch, else None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            d = json.load(f)
+        ent = d.get(kernel_name)
+        if ent and ent.get("batch") == batch:
+            return int(ent["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
 WORKLOADS = {
     # name: (limb_width, bits_len, exponent)
     "rsa2048_e65537": (64, 2048, 65537),   # BASELINE configs[1] (batch 1024) / configs[2] shards
@@ -94,7 +110,7 @@ def main():
                     help="fully stream-ordered calls (chain then trace per step) instead of the two-stream pipeline")
     args = ap.parse_args()
 
-    env = DistEnv.from_environment(args.gpus)
+    env = DistEnv.from_environment(args.gpus, force=bool(os.environ.get("H2R_FORCE_DIST")))
     w, bits, e = WORKLOADS[args.workload]
     torch.cuda.set_device(env.local_rank)
     env.init("nccl")
@@ -182,7 +198,8 @@ def main():
                        "pipeline": "two-stream (chain k+1 || trace k)" if pipe is not None else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                         "traffic": None, "kernel": "trace_kernel<%d,%d>" % (w, chip.num_limbs),
+                         "traffic": pmc_traffic("trace_kernel<%d,%d>" % (w, chip.num_limbs), batch),
+                         "kernel": "trace_kernel<%d,%d>" % (w, chip.num_limbs),
                          "avg_launch_ms": round(1e3 * avg_trace_s, 4) if trace_ms else None,
                          "algorithmic_bytes_per_launch": trace_bytes_per_launch,
                          "chain_kernel_avg_ms": round(sum(chain_ms) / len(chain_ms), 4) if chain_ms else None},

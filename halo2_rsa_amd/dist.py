@@ -27,9 +27,10 @@ class DistEnv:
     world: int
     initialised: bool = False
     backend: str = ""
+    force: bool = False   # initialise the process group even for world == 1 (exercises the RCCL path)
 
     @staticmethod
-    def from_environment(expected_world: int = 1) -> "DistEnv":
+    def from_environment(expected_world: int = 1, force: bool = False) -> "DistEnv":
         world = int(os.environ.get("WORLD_SIZE", "1"))
         rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", str(rank)))
@@ -38,11 +39,11 @@ class DistEnv:
         if expected_world > 1 and world == 1:
             raise RuntimeError("--gpus %d needs one process per GPU: launch with python -m torch.distributed.run "
                                "--nproc-per-node %d" % (expected_world, expected_world))
-        return DistEnv(rank, local, world)
+        return DistEnv(rank, local, world, force=force)
 
     def init(self, backend: str):
         self.backend = backend
-        if self.world > 1:
+        if self.world > 1 or self.force:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
             kw = {}
