@@ -1,0 +1,266 @@
+// h2r_chips.hpp -- header-only C++17 host mirror of the reference's chip API over the C ABI (h2r.h).
+//
+// The reference is a Rust crate; its API for the accelerated path is
+//   BigIntChip / BigIntInstructions<F>   reference src/big_integer/chip.rs:42-51, instructions.rs:7-260
+//   RSAChip / RSAInstructions<F>         reference src/chip.rs:38-255, src/instructions.rs:8-39
+//   RSAPublicKey / RSAPubE / RSASignature  reference src/lib.rs:25-140
+// This header keeps those names, argument order and error behaviour (a C++ exception where the
+// reference panics or returns plonk::Error at construction; a per-element status byte where it would
+// panic on a value) in BATCH form: every integer is a batch of integers, one per independent circuit,
+// resident in HBM.  All arithmetic happens in libh2r.so; there is no CPU fallback here.
+//
+// Build: g++ -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude ... -lh2r -lamdhip64
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#include "h2r.h"
+
+namespace h2r_host {
+
+struct Error : std::runtime_error {
+    int32_t code;
+    Error(int32_t c, const std::string &where)
+        : std::runtime_error(where + ": " + h2r_status_str(c) + (c == H2R_E_HIP ? std::string(" (") + h2r_last_hip_error() + ")" : "")), code(c) {}
+};
+inline void check(int32_t rc, const char *where) { if (rc != H2R_OK) throw Error(rc, where); }
+inline void hip_check(hipError_t e, const char *where) { if (e != hipSuccess) throw std::runtime_error(std::string(where) + ": " + hipGetErrorString(e)); }
+
+// RAII device allocation
+class DeviceBuffer {
+  public:
+    DeviceBuffer() = default;
+    explicit DeviceBuffer(size_t bytes) : n_(bytes) { if (bytes) hip_check(hipMalloc(&p_, bytes), "hipMalloc"); }
+    DeviceBuffer(DeviceBuffer &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    DeviceBuffer &operator=(DeviceBuffer &&o) noexcept { if (this != &o) { release(); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; } return *this; }
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    ~DeviceBuffer() { release(); }
+    void *get() const { return p_; }
+    size_t size() const { return n_; }
+    void upload(const void *src, size_t bytes) { hip_check(hipMemcpy(p_, src, bytes, hipMemcpyHostToDevice), "hipMemcpy H2D"); }
+    void download(void *dst, size_t bytes, size_t offset = 0) const { hip_check(hipMemcpy(dst, static_cast<const uint8_t *>(p_) + offset, bytes, hipMemcpyDeviceToHost), "hipMemcpy D2H"); }
+  private:
+    void release() { if (p_) (void)hipFree(p_); p_ = nullptr; }
+    void *p_ = nullptr; size_t n_ = 0;
+};
+
+// reference src/big_integer/mod.rs:270-302 -- limb values about to be assigned (host side, 64-bit limbs)
+struct UnassignedInteger {
+    std::vector<uint64_t> limbs;  // [batch][num_limbs], limb 0 least significant (decompose_big)
+    size_t batch = 0, num_limbs = 0;
+    static UnassignedInteger from(std::vector<uint64_t> l, size_t batch, size_t num_limbs) {
+        if (l.size() != batch * num_limbs) throw std::invalid_argument("UnassignedInteger: shape");
+        return UnassignedInteger{std::move(l), batch, num_limbs};
+    }
+};
+
+// reference src/big_integer/mod.rs:306-382 (range type Fresh): a batch of limb vectors in HBM
+class AssignedInteger {
+  public:
+    AssignedInteger(DeviceBuffer d, size_t batch, size_t num_limbs) : dev_(std::move(d)), batch_(batch), num_limbs_(num_limbs) {}
+    size_t num_limbs() const { return num_limbs_; }
+    size_t batch() const { return batch_; }
+    const void *data() const { return dev_.get(); }
+    std::vector<uint64_t> limbs() const { std::vector<uint64_t> h(batch_ * num_limbs_); dev_.download(h.data(), h.size() * 8); return h; }
+  private:
+    DeviceBuffer dev_; size_t batch_, num_limbs_;
+};
+
+class BigIntChip;
+
+// witness records of one batch call + what is needed to walk them in the reference's order
+class Trace {
+  public:
+    Trace(const BigIntChip *chip, DeviceBuffer buf, size_t batch, bool is_pow, h2r_pow_layout pl, uint64_t elem_stride, uint64_t stream_bytes)
+        : chip_(chip), buf_(std::move(buf)), batch_(batch), is_pow_(is_pow), pl_(pl), elem_stride_(elem_stride), stream_bytes_(stream_bytes) {}
+    uint64_t stream_bytes() const { return stream_bytes_; }
+    const void *data() const { return buf_.get(); }
+    std::vector<uint8_t> flatten(size_t elem) const;  // the element's op-trace in assignment order
+  private:
+    const BigIntChip *chip_; DeviceBuffer buf_; size_t batch_; bool is_pow_; h2r_pow_layout pl_; uint64_t elem_stride_, stream_bytes_;
+};
+
+struct BatchResult {
+    AssignedInteger value;        // a*b mod n  /  a^e mod n
+    Trace trace;
+    std::vector<uint8_t> status;  // H2R_* per element
+};
+
+// reference src/big_integer/chip.rs:42-51, 1161-1249
+class BigIntChip {
+  public:
+    static constexpr unsigned NUM_LOOKUP_LIMBS = 8;  // big_integer/chip.rs:1163
+    // BigIntChip::new(config, limb_width, bits_len), big_integer/chip.rs:1174-1185
+    BigIntChip(uint32_t limb_width, uint32_t bits_len, uint32_t field = H2R_FIELD_BN254_FR, int device = 0)
+        : limb_width_(limb_width), num_limbs_(limb_width ? bits_len / limb_width : 0) {
+        h2r_params p{limb_width, bits_len, field, device};
+        check(h2r_ctx_create(&p, &ctx_), "BigIntChip::new");
+        check(h2r_trace_layout(ctx_, &layout_), "h2r_trace_layout");
+    }
+    ~BigIntChip() { h2r_ctx_destroy(ctx_); }
+    BigIntChip(const BigIntChip &) = delete;
+    BigIntChip &operator=(const BigIntChip &) = delete;
+
+    // big_integer/chip.rs:1220-1249
+    static std::pair<std::vector<uint32_t>, std::vector<uint32_t>> compute_range_lens(uint32_t limb_width, uint32_t num_limbs) {
+        std::vector<uint32_t> c(3), o(3);
+        check(h2r_compute_range_lens(limb_width, num_limbs, c.data(), o.data()), "compute_range_lens");
+        return {c, o};
+    }
+    uint32_t num_limbs() const { return num_limbs_; }
+    const h2r_ctx *ctx() const { return ctx_; }
+    const h2r_layout &layout() const { return layout_; }
+
+    // big_integer/chip.rs:62-82
+    AssignedInteger assign_integer(const UnassignedInteger &integer) const {
+        DeviceBuffer d(integer.limbs.size() * 8);
+        d.upload(integer.limbs.data(), integer.limbs.size() * 8);
+        return AssignedInteger(std::move(d), integer.batch, integer.num_limbs);
+    }
+    // big_integer/chip.rs:542-629
+    BatchResult mul_mod(const AssignedInteger &a, const AssignedInteger &b, const AssignedInteger &n) const {
+        if (a.num_limbs() != n.num_limbs() || a.num_limbs() != num_limbs_) throw Error(H2R_E_SHAPE, "mul_mod");  // :555
+        const size_t batch = a.batch();
+        DeviceBuffer trace(batch * layout_.record_stride), r(batch * num_limbs_ * 8), st(batch);
+        check(h2r_mul_mod_batch(ctx_, a.data(), b.data(), n.data(), batch, flags(n, batch), trace.get(), r.get(),
+                                static_cast<uint8_t *>(st.get()), nullptr, nullptr), "mul_mod");
+        return finish(std::move(trace), std::move(r), st, batch, false, h2r_pow_layout{}, layout_.record_stride, layout_.stream_bytes);
+    }
+    // big_integer/chip.rs:642-649
+    BatchResult square_mod(const AssignedInteger &a, const AssignedInteger &n) const { return mul_mod(a, a, n); }
+    // big_integer/chip.rs:710-742; e = BigUint::to_bytes_le()
+    BatchResult pow_mod_fixed_exp(const AssignedInteger &a, const std::vector<uint8_t> &e_le, const AssignedInteger &n,
+                                  bool check_in_field = false) const {
+        h2r_pow_layout pl;
+        check(h2r_pow_fixed_layout(ctx_, e_le.data(), e_le.size(), &pl), "h2r_pow_fixed_layout");
+        const size_t batch = a.batch();
+        DeviceBuffer trace(batch * pl.elem_stride), out(batch * num_limbs_ * 8), st(batch);
+        auto fn = check_in_field ? h2r_modpow_public_key_batch : h2r_pow_mod_fixed_exp_batch;
+        check(fn(ctx_, a.data(), n.data(), e_le.data(), e_le.size(), batch, flags(n, batch), trace.get(), out.get(),
+                 static_cast<uint8_t *>(st.get()), nullptr, nullptr), "pow_mod_fixed_exp");
+        return finish(std::move(trace), std::move(out), st, batch, true, pl, pl.elem_stride, pl.stream_bytes);
+    }
+    // big_integer/chip.rs:664-696
+    BatchResult pow_mod(const AssignedInteger &a, const AssignedInteger &e, const AssignedInteger &n, uint32_t exp_limb_bits) const {
+        h2r_pow_layout pl;
+        check(h2r_pow_var_layout(ctx_, (uint32_t)e.num_limbs(), exp_limb_bits, &pl), "h2r_pow_var_layout");
+        const size_t batch = a.batch();
+        DeviceBuffer trace(batch * pl.elem_stride), out(batch * num_limbs_ * 8), st(batch);
+        check(h2r_pow_mod_batch(ctx_, a.data(), e.data(), (uint32_t)e.num_limbs(), exp_limb_bits, n.data(), batch, flags(n, batch),
+                                trace.get(), out.get(), static_cast<uint8_t *>(st.get()), nullptr, nullptr), "pow_mod");
+        return finish(std::move(trace), std::move(out), st, batch, true, pl, pl.elem_stride, pl.stream_bytes);
+    }
+
+  private:
+    static uint32_t flags(const AssignedInteger &n, size_t batch) { return (n.batch() == 1 && batch != 1) ? H2R_F_SHARED_MODULUS : 0u; }
+    BatchResult finish(DeviceBuffer trace, DeviceBuffer value, const DeviceBuffer &st, size_t batch, bool is_pow, h2r_pow_layout pl,
+                       uint64_t elem_stride, uint64_t stream_bytes) const {
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        std::vector<uint8_t> status(batch);
+        st.download(status.data(), batch);
+        return BatchResult{AssignedInteger(std::move(value), batch, num_limbs_), Trace(this, std::move(trace), batch, is_pow, pl, elem_stride, stream_bytes),
+                           std::move(status)};
+    }
+    uint32_t limb_width_, num_limbs_;
+    h2r_ctx *ctx_ = nullptr;
+    h2r_layout layout_{};
+    friend class Trace;
+    friend class RSAChip;
+};
+
+inline std::vector<uint8_t> Trace::flatten(size_t elem) const {
+    std::vector<uint8_t> host(elem_stride_), out(stream_bytes_);
+    buf_.download(host.data(), elem_stride_, elem * elem_stride_);
+    if (is_pow_) check(h2r_pow_trace_flatten(chip_->ctx(), &pl_, host.data(), out.data()), "h2r_pow_trace_flatten");
+    else check(h2r_trace_flatten(chip_->ctx(), host.data(), out.data()), "h2r_trace_flatten");
+    return out;
+}
+
+// reference src/lib.rs:25-140
+struct RSAPubE {
+    struct Fix { std::vector<uint8_t> e_le; };        // RSAPubE::Fix(BigUint)
+    struct Var { UnassignedInteger e; };               // RSAPubE::Var(UnassignedInteger)
+    std::variant<Fix, Var> v;
+    static RSAPubE fix(uint64_t e) { std::vector<uint8_t> b; do { b.push_back((uint8_t)e); e >>= 8; } while (e); return RSAPubE{Fix{b}}; }
+};
+struct RSAPublicKey { UnassignedInteger n; RSAPubE e; };
+struct RSASignature { UnassignedInteger c; };
+struct AssignedRSAPublicKey { AssignedInteger n; std::variant<RSAPubE::Fix, AssignedInteger> e; };
+struct AssignedRSASignature { AssignedInteger c; };
+
+struct VerifyResult {
+    std::vector<uint8_t> is_valid;   // one byte per signature
+    std::vector<uint8_t> status;
+    AssignedInteger powed;
+    DeviceBuffer trace; h2r_verify_layout layout;
+};
+
+// reference src/chip.rs:38-255
+class RSAChip {
+  public:
+    static constexpr uint32_t LIMB_WIDTH = 64;  // src/chip.rs:203
+    // RSAChip::new(config, bits_len, exp_limb_bits), src/chip.rs:214-221
+    RSAChip(uint32_t bits_len, uint32_t exp_limb_bits, uint32_t field = H2R_FIELD_BN254_FR, int device = 0)
+        : bits_len_(bits_len), exp_limb_bits_(exp_limb_bits), bigint_(LIMB_WIDTH, bits_len, field, device) {}
+    const BigIntChip &bigint_chip() const { return bigint_; }  // src/chip.rs:224-230
+    // src/chip.rs:249-254
+    static std::pair<std::vector<uint32_t>, std::vector<uint32_t>> compute_range_lens(uint32_t num_limbs) {
+        std::vector<uint32_t> c(4), o(3);
+        check(h2r_rsa_compute_range_lens(num_limbs, c.data(), o.data()), "RSAChip::compute_range_lens");
+        return {c, o};
+    }
+    // src/chip.rs:58-70
+    AssignedRSAPublicKey assign_public_key(const RSAPublicKey &pk) const {
+        AssignedInteger n = bigint_.assign_integer(pk.n);
+        if (auto *f = std::get_if<RSAPubE::Fix>(&pk.e.v)) return AssignedRSAPublicKey{std::move(n), *f};
+        return AssignedRSAPublicKey{std::move(n), bigint_.assign_integer(std::get<RSAPubE::Var>(pk.e.v).e)};
+    }
+    // src/chip.rs:80-88
+    AssignedRSASignature assign_signature(const RSASignature &s) const { return AssignedRSASignature{bigint_.assign_integer(s.c)}; }
+    // src/chip.rs:99-114: assert x < n (:106, status H2R_E_NOT_IN_FIELD), then Fix -> pow_mod_fixed_exp, Var -> pow_mod
+    BatchResult modpow_public_key(const AssignedInteger &x, const AssignedRSAPublicKey &pk) const {
+        if (auto *f = std::get_if<RSAPubE::Fix>(&pk.e)) return bigint_.pow_mod_fixed_exp(x, f->e_le, pk.n, /*check_in_field=*/true);
+        return bigint_.pow_mod(x, std::get<AssignedInteger>(pk.e), pk.n, exp_limb_bits_);
+    }
+    // src/chip.rs:128-199 (hashed_msg = 4 little-endian 64-bit limbs of the SHA-256 digest per signature, :141-144)
+    VerifyResult verify_pkcs1v15_signature(const AssignedRSAPublicKey &pk, const AssignedInteger &hashed_msg,
+                                           const AssignedRSASignature &sig) const {
+        auto *f = std::get_if<RSAPubE::Fix>(&pk.e);
+        if (!f) throw Error(H2R_E_UNSUPPORTED, "verify_pkcs1v15_signature (batch path takes RSAPubE::Fix)");
+        h2r_verify_layout vl;
+        check(h2r_verify_layout_fixed(bigint_.ctx(), f->e_le.data(), f->e_le.size(), &vl), "h2r_verify_layout_fixed");
+        const size_t batch = sig.c.batch();
+        DeviceBuffer trace(batch * vl.elem_stride), powed(batch * bigint_.num_limbs() * 8), valid(batch), st(batch);
+        check(h2r_verify_pkcs1v15_batch(bigint_.ctx(), sig.c.data(), pk.n.data(), f->e_le.data(), f->e_le.size(),
+                                        static_cast<const uint64_t *>(hashed_msg.data()), batch, BigIntChip::flags(pk.n, batch), trace.get(),
+                                        powed.get(), static_cast<uint8_t *>(valid.get()), static_cast<uint8_t *>(st.get()), nullptr, nullptr),
+              "verify_pkcs1v15_signature");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        VerifyResult r{std::vector<uint8_t>(batch), std::vector<uint8_t>(batch), AssignedInteger(std::move(powed), batch, bigint_.num_limbs()),
+                       std::move(trace), vl};
+        valid.download(r.is_valid.data(), batch);
+        st.download(r.status.data(), batch);
+        return r;
+    }
+    std::vector<uint8_t> flatten(const VerifyResult &r, size_t elem) const {
+        std::vector<uint8_t> host(r.layout.elem_stride), out(r.layout.stream_bytes);
+        r.trace.download(host.data(), host.size(), elem * r.layout.elem_stride);
+        check(h2r_verify_trace_flatten(bigint_.ctx(), &r.layout, host.data(), out.data()), "h2r_verify_trace_flatten");
+        return out;
+    }
+
+  private:
+    uint32_t bits_len_, exp_limb_bits_;
+    BigIntChip bigint_;
+};
+
+}  // namespace h2r_host

@@ -1,0 +1,94 @@
+// C++ host-mirror test: reads like the reference's RSA tests (src/chip.rs:683-816) but runs the
+// batch path on the GPU through include/h2r_chips.hpp and checks every byte against the CPU oracle.
+//   test_rsa_signature_circuit1 / circuit2 : valid pkcs1v15 signatures  -> is_valid == 1
+//   test_bad_rsa_signature_circuit2        : one digit off              -> is_valid == 0
+// TEST CODE: links the oracle (checker).  Build: see tests/test_cpp_host.py.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "h2r_chips.hpp"
+#include "../../oracle/h2r_oracle.h"
+
+using namespace h2r_host;
+
+#define REQUIRE(cond)                                                                  \
+    do {                                                                               \
+        if (!(cond)) { std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } \
+    } while (0)
+
+struct Kat { std::string name; int is_valid; std::vector<uint64_t> n, sig, hashed; };
+
+static std::vector<Kat> load(const char *path) {
+    std::vector<Kat> out; std::ifstream f(path); std::string line;
+    while (std::getline(f, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream is(line); Kat k; is >> k.name >> k.is_valid;
+        auto rd = [&](std::vector<uint64_t> &v, int n) { for (int i = 0; i < n; ++i) { std::string h; is >> h; v.push_back(std::stoull(h, nullptr, 16)); } };
+        rd(k.n, 32); rd(k.sig, 32); rd(k.hashed, 4);
+        out.push_back(k);
+    }
+    return out;
+}
+
+int main(int argc, char **argv) {
+    REQUIRE(argc == 2);
+    std::vector<Kat> kats = load(argv[1]);
+    REQUIRE(kats.size() == 3);
+    const size_t B = kats.size();
+    // configure(): RSAChip::compute_range_lens(BITS_LEN / LIMB_WIDTH)  (src/chip.rs:639-642)
+    auto lens = RSAChip::compute_range_lens(2048 / RSAChip::LIMB_WIDTH);
+    REQUIRE((lens.first == std::vector<uint32_t>{8, 1, 8, 4}) && (lens.second == std::vector<uint32_t>{0, 0, 6}));
+
+    RSAChip rsa_chip(2048, 5);                       // RSAChip::new(config, BITS_LEN, EXP_LIMB_BITS)
+    const BigIntChip &bigint_chip = rsa_chip.bigint_chip();
+    std::vector<uint64_t> n_limbs, sign_limbs, hashed_limbs;
+    for (auto &k : kats) { n_limbs.insert(n_limbs.end(), k.n.begin(), k.n.end()); sign_limbs.insert(sign_limbs.end(), k.sig.begin(), k.sig.end());
+                           hashed_limbs.insert(hashed_limbs.end(), k.hashed.begin(), k.hashed.end()); }
+    RSAPublicKey public_key{UnassignedInteger::from(n_limbs, B, 32), RSAPubE::fix(65537)};       // e_fix = 65537
+    AssignedRSAPublicKey pk = rsa_chip.assign_public_key(public_key);
+    AssignedRSASignature sign = rsa_chip.assign_signature(RSASignature{UnassignedInteger::from(sign_limbs, B, 32)});
+    AssignedInteger hashed_msg_assigned = bigint_chip.assign_integer(UnassignedInteger::from(hashed_limbs, B, 4));
+    VerifyResult res = rsa_chip.verify_pkcs1v15_signature(pk, hashed_msg_assigned, sign);
+
+    h2ro_params op;
+    REQUIRE(h2ro_params_init(&op, 64, 32) == 0);
+    const uint8_t e_le[3] = {0x01, 0x00, 0x01};
+    for (size_t i = 0; i < B; ++i) {
+        REQUIRE(res.status[i] == H2R_OK);
+        REQUIRE(res.is_valid[i] == kats[i].is_valid);                     // main_gate.assert_one(is_valid) / the Bad twin
+        // oracle: in-field + pow + EM streams
+        std::vector<uint8_t> s_if(h2ro_in_field_stream_bytes(&op)), s_pow(h2ro_pow_fixed_stream_bytes(&op, e_le, 3)), s_em(h2ro_pkcs1v15_stream_bytes(&op));
+        int lt = -1, ok = -1; std::vector<uint64_t> powed(32);
+        REQUIRE(h2ro_assert_in_field(&op, kats[i].sig.data(), kats[i].n.data(), s_if.data(), &lt) == 0 && lt == 1);
+        REQUIRE(h2ro_pow_mod_fixed_exp(&op, kats[i].sig.data(), kats[i].n.data(), e_le, 3, s_pow.data(), powed.data()) == 0);
+        REQUIRE(h2ro_pkcs1v15_em_check(&op, powed.data(), kats[i].hashed.data(), s_em.data(), &ok) == 0 && ok == kats[i].is_valid);
+        std::vector<uint8_t> want(s_if); want.insert(want.end(), s_pow.begin(), s_pow.end()); want.insert(want.end(), s_em.begin(), s_em.end());
+        std::vector<uint8_t> got = rsa_chip.flatten(res, i);
+        REQUIRE(got == want);
+        std::vector<uint64_t> gp = res.powed.limbs();
+        REQUIRE(std::vector<uint64_t>(gp.begin() + 32 * i, gp.begin() + 32 * (i + 1)) == powed);
+    }
+    // BigIntInstructions::mul_mod identity (n - 1) * (n - 1) mod n = 1   (big_integer/chip.rs:3204)
+    {
+        std::vector<uint64_t> n(kats[0].n), a(n); a[0] -= 1;   // n is odd -> no borrow
+        AssignedInteger an = bigint_chip.assign_integer(UnassignedInteger::from(n, 1, 32));
+        AssignedInteger aa = bigint_chip.assign_integer(UnassignedInteger::from(a, 1, 32));
+        BatchResult r = bigint_chip.mul_mod(aa, aa, an);
+        REQUIRE(r.status[0] == H2R_OK);
+        std::vector<uint64_t> one(32, 0); one[0] = 1;
+        REQUIRE(r.value.limbs() == one);
+        std::vector<uint8_t> st(op.mul_mod_stream_bytes); std::vector<uint64_t> rr(32);
+        REQUIRE(h2ro_mul_mod(&op, a.data(), a.data(), n.data(), st.data(), rr.data()) == 0);
+        REQUIRE(r.trace.flatten(0) == st);
+    }
+    // BigIntChip::new asserts bits_len % limb_width == 0 (big_integer/chip.rs:1175) -> exception
+    bool threw = false;
+    try { BigIntChip bad(64, 2048 + 8); } catch (const Error &e) { threw = e.code == H2R_E_SHAPE; }
+    REQUIRE(threw);
+    std::printf("CPP_HOST_MIRROR_OK %zu signatures\n", B);
+    return 0;
+}

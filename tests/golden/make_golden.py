@@ -175,6 +175,13 @@ def main():
     out["rsa4096_w32"] = {"n": str(n4), "x": str(x4), "e": E_FIX, "result": str(R.from_limbs(res, 32)),
                           "stream_bytes": len(st.buf), "stream_sha256": sha(st.bytes())}
 
+    # plain-text limb fixture for the C++ host-mirror test (tests/cpp/test_rsa_chip.cpp)
+    with open(os.path.join(HERE, "rsa_kats_limbs.txt"), "w") as f:
+        f.write("# name is_valid | 32 n limbs | 32 sig limbs | 4 hashed limbs   (hex, little-endian 64-bit limbs)\n")
+        for k in kats:
+            nl = R.to_limbs(int(k["n"]), 32, 64); sl = R.to_limbs(int(k["sig"]), 32, 64); hl = R.to_limbs(int(k["hashed"]), 4, 64)
+            f.write("%s %d %s %s %s\n" % (k["name"], k["is_valid"], " ".join("%x" % v for v in nl), " ".join("%x" % v for v in sl),
+                                          " ".join("%x" % v for v in hl)))
     path = os.path.join(HERE, "halo2_rsa_golden.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
