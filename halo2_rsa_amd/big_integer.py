@@ -188,6 +188,18 @@ class BigIntChip:
         t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int64 if self.limb_width == 64 else np.int32))
         return AssignedInteger(t.to("cuda:%d" % self.device).contiguous(), self.limb_width)
 
+    def range_check_sublimbs(self, integer: AssignedInteger) -> torch.Tensor:
+        """The RangeChip::assign(limb, limb_width/8, limb_width) decomposition that assign_integer performs for
+        every limb of an input integer (big_integer/chip.rs:71-76): uint8 [batch, num_limbs, 8] sub-limbs."""
+        sub = torch.empty((integer.batch, integer.num_limbs(), 8), dtype=torch.uint8, device=integer.limbs_dev.device)
+        values = integer.limbs_dev
+        if self.limb_width == 32:   # h2r_range_decompose_batch takes 8- or 16-byte values
+            values = (values.to(torch.int64) & 0xffffffff).contiguous()
+        check(lib().h2r_range_decompose_batch(self._ctx, values.data_ptr(), 8, values.numel(), self.limb_width,
+                                              self.limb_width // 8, sub.data_ptr(), 8, None, self._stream()),
+              "range_check_sublimbs")
+        return sub
+
     def _new_limbs(self, batch):
         return torch.empty((batch, self.num_limbs), dtype=self.torch_dtype, device="cuda:%d" % self.device)
 

@@ -536,3 +536,18 @@ def test_config5_large_exponent(H):
     res = chip.pow_mod_fixed_exp(chip.assign_integer(X), e, chip.assign_integer(N))
     assert res.trace.num_mul_mods == 2048 + bin(e).count("1")
     _check_pow_batch(H, chip, o, X, N, e, res, [0, B - 1], rng)
+
+
+@pytest.mark.parametrize("w,L", [(64, 32), (32, 128)])
+def test_assign_integer_range_check_sublimbs(H, w, L):
+    """assign_integer range-checks every input limb (big_integer/chip.rs:71-76): 8 sub-limbs of w/8 bits."""
+    chip = H.BigIntChip(w, w * L)
+    rng = random.Random(w)
+    vals = [rng.getrandbits(w * L) for _ in range(5)]
+    a = chip.assign_integer(vals)
+    sub = chip.range_check_sublimbs(a).cpu().numpy()
+    sb = w // 8
+    for i, v in enumerate(vals):
+        for k in range(L):
+            limb = (v >> (w * k)) & ((1 << w) - 1)
+            assert [int(x) for x in sub[i, k]] == [(limb >> (sb * t)) & ((1 << sb) - 1) for t in range(8)]
