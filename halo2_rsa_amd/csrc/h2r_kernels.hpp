@@ -90,6 +90,7 @@ struct Geo {
     static constexpr int CG = (2 * K + 63) / 64;  // column groups
     static constexpr int SS = NW / CG;            // step slices
     static constexpr int SL = K / SS;             // steps per slice
+    static constexpr int SSMAX = (K >= 64) ? NW / (K / 64) : SS;   // slices of the half products (K columns)
     static_assert(NW % CG == 0 && SS >= 1 && K % SS == 0, "bad chain geometry");
 };
 
@@ -99,7 +100,7 @@ struct ChainLds {
     u32 bpad[3 * K];             // B operand, data at [K, 2K), zeros elsewhere
     u32 nnpad[3 * K];            // normalised modulus n' = n << s, padded like bpad
     u32 mupad[3 * K];            // mu' = floor((2^(64K) - 1) / n') - 2^(32K), padded
-    u32 part[Geo<K, NW>::SS][3][2 * K];  // per-slice column partial sums (3 words)
+    u32 part[Geo<K, NW>::SSMAX][3][2 * K];  // per-slice column partial sums (3 words)
     u32 x0[2 * K + 4], x1[2 * K + 4], x2[2 * K + 4];  // reduced columns; also shift scratch
     u32 rx0[K + 1], rx1[K + 1];          // wave-0 scratch of the reciprocal
 };
@@ -110,20 +111,35 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// 2K-digit product A (K digits at `A`) x B (padded at `Bpad`) computed by the whole block.  All waves
-// accumulate column partial sums; WAVE 0 alone receives the normalised digits (lane holds columns
-// v = lane + 64m in plo[m] and v + K in phi[m]) -- it owns the serial carry/decision logic while the
-// other waves only help with the products.  Three block barriers; wave 0 publishes A/Bpad before.
-template <int K, int NW>
+// K x K digit product A (K digits at `A`) x B (padded at `Bpad`) computed by the whole block.  All
+// waves accumulate column partial sums; WAVE 0 alone receives the normalised digits (lane holds
+// columns v = lane + 64m in plo[m] and v + K in phi[m]) -- it owns the serial carry/decision logic
+// while the other waves only help with the products.  Three block barriers; wave 0 publishes
+// A/Bpad before the call.
+//   MUL_FULL  all 2K digits.
+//   MUL_HIGH  only phi, computed from the columns >= K-2 (never larger than the true high half and at
+//             most 1 ulp smaller): Barrett's  floor(x1 * mu' / 2^(32K))  needs no more.
+//   MUL_LOW   only plo and digit K (returned in dk): Barrett's  R = x' - q^ * n'  is < 2^(32(K+1)).
+// The half forms run K columns instead of 2K (half the multiply-accumulates); they fall back to the
+// full product when K < 64 (a single 64-column group already covers everything).
+enum { MUL_FULL = 0, MUL_HIGH = 1, MUL_LOW = 2 };
+
+template <int K, int NW, int MODE>
 __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLds<K, NW> &s, int lane, int wave,
-                                          u32 (&plo)[Geo<K, NW>::V], u32 (&phi)[Geo<K, NW>::V]) {
+                                          u32 (&plo)[Geo<K, NW>::V], u32 (&phi)[Geo<K, NW>::V], u32 &dk) {
     using G = Geo<K, NW>;
     constexpr int V = G::V;
+    constexpr bool HALF = (MODE != MUL_FULL) && (K >= 64);
+    constexpr int CGA = HALF ? K / 64 : G::CG;           // active 64-column groups
+    constexpr int SSA = NW / CGA;                         // step slices
+    constexpr int SLA = K / SSA;                          // steps per slice
+    constexpr int CB = (HALF && MODE == MUL_HIGH) ? K - 2 : 0;   // first column of the window
+    static_assert(NW % CGA == 0 && K % SSA == 0 && SSA <= Geo<K, NW>::SSMAX, "bad half-product geometry");
     __syncthreads();  // operands published; previous readers of part/x* are done
     {
-        const int cg = wave % G::CG, ss = wave / G::CG;
-        const int c = 64 * cg + lane;
-        const int j0 = ss * G::SL;
+        const int cg = wave % CGA, ss = wave / CGA;
+        const int c = CB + 64 * cg + lane;
+        const int j0 = ss * SLA;
         u64 acc = 0;
         u32 ov = 0;
         const u32 *bp = Bpad + K + c - j0;
@@ -135,34 +151,57 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
             asm volatile("v_mad_u64_u32 %0, %2, %3, %4, %0\n\ts_nop 1\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2"
                          : "+v"(acc), "+v"(ov), "=&s"(carry) : "v"(av), "v"(bv));
         };
-        if constexpr (G::SL % 4 == 0) {
+        if constexpr (SLA % 4 == 0) {
 #pragma unroll 2
-            for (int j = 0; j < G::SL; j += 4) {
+            for (int j = 0; j < SLA; j += 4) {
                 const uint4 a4 = *reinterpret_cast<const uint4 *>(ap + j);  // broadcast 16-byte read
                 const u32 b0 = bp[-j], b1 = bp[-j - 1], b2 = bp[-j - 2], b3 = bp[-j - 3];
                 mac(a4.x, b0); mac(a4.y, b1); mac(a4.z, b2); mac(a4.w, b3);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < G::SL; ++j) mac(ap[j], bp[-j]);
+            for (int j = 0; j < SLA; ++j) mac(ap[j], bp[-j]);
         }
         if (c < 2 * K) { s.part[ss][0][c] = (u32)acc; s.part[ss][1][c] = (u32)(acc >> 32); s.part[ss][2][c] = ov; }
+        if constexpr (HALF && MODE == MUL_HIGH) {
+            // column 2K-2 lies one past the window: its single product A[K-1]*B[K-1]
+            if (lane == 0) {
+                const u64 p = (wave == 0) ? (u64)A[K - 1] * Bpad[K + K - 1] : 0;
+                if (wave < SSA) { s.part[wave][0][2 * K - 2] = (u32)p; s.part[wave][1][2 * K - 2] = (u32)(p >> 32); s.part[wave][2][2 * K - 2] = 0; }
+            }
+        }
+        if constexpr (HALF && MODE == MUL_LOW) {
+            // digit K needs column K only modulo 2^32: sum_j lo32(A[j] * B[K-j]), j = 1..K-1 (wave 0, butterfly add)
+            if (wave == 0) {
+                u32 t = 0;
+#pragma unroll
+                for (int m = 0; m < V; ++m) { const int j = lane + 64 * m; if (j >= 1 && j < K) t += A[j] * Bpad[K + K - j]; }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
+                if (lane == 0) s.x0[K + 3] = t;   // x0 of column K (published by the barrier below; the reduce skips c = K)
+            }
+        }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * K; c += 64 * NW) {  // reduce the SS slices of column c
+    constexpr int C0 = CB, C1 = HALF ? (MODE == MUL_HIGH ? 2 * K - 1 : K) : 2 * K;   // columns reduced: [C0, C1)
+    for (int c = C0 + (int)threadIdx.x; c < C1; c += 64 * NW) {  // reduce the slices of column c
         u64 s0 = 0, s1 = 0; u32 s2 = 0;
 #pragma unroll
-        for (int k = 0; k < G::SS; ++k) { s0 += s.part[k][0][c]; s1 += s.part[k][1][c]; s2 += s.part[k][2][c]; }
+        for (int k = 0; k < SSA; ++k) { s0 += s.part[k][0][c]; s1 += s.part[k][1][c]; s2 += s.part[k][2][c]; }
         const u64 t1 = s1 + (s0 >> 32);
         s.x0[c + 3] = (u32)s0; s.x1[c + 3] = (u32)t1; s.x2[c + 3] = s2 + (u32)(t1 >> 32);
     }
-    if (threadIdx.x < 3) { s.x0[threadIdx.x] = 0; s.x1[threadIdx.x] = 0; s.x2[threadIdx.x] = 0; }
+    // three zero columns below the window (c = C0-3 .. C0-1) and, for MUL_HIGH, the always-zero column 2K-1
+    if (threadIdx.x < 3) { s.x0[C0 + threadIdx.x] = 0; s.x1[C0 + threadIdx.x] = 0; s.x2[C0 + threadIdx.x] = 0; }
+    if (HALF && MODE == MUL_HIGH && threadIdx.x == 3) { s.x0[2 * K + 2] = 0; s.x1[2 * K + 2] = 0; s.x2[2 * K + 2] = 0; }
     __syncthreads();
     if (wave != 0) return;
     // digits: t(c) = x0[c] + x1[c-1] + x2[c-2]; d(c) = lo(t(c)) + hi(t(c-1)); 1-bit carries by ballot
     bool cin = false;
 #pragma unroll
     for (int g = 0; g < 2 * V; ++g) {
+        if (HALF && MODE == MUL_HIGH && g < V) continue;   // low half not needed
+        if (HALF && MODE == MUL_LOW && g >= V) continue;   // high half not needed (digit K below)
         const int vv = lane + 64 * (g % V);
         const int c = vv + (g >= V ? K : 0);
         u64 d = 0;
@@ -178,6 +217,13 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
         cin = cgp.cout;
         const u32 digit = (u32)d + (u32)((cgp.cin_mask >> lane) & 1);
         if (g < V) plo[g] = digit; else phi[g - V] = digit;
+    }
+    if constexpr (HALF && MODE == MUL_LOW) {
+        // digit K = lo32( x0[K] + x1[K-1] + x2[K-2] + hi(t(K-1)) + carry out of digit K-1 )
+        const u64 tp = (u64)s.x0[K + 2] + s.x1[K + 1] + s.x2[K];
+        dk = s.x0[K + 3] + s.x1[K + 2] + s.x2[K + 1] + (u32)(tp >> 32) + (cin ? 1u : 0u);
+    } else {
+        dk = 0;
     }
 }
 
@@ -397,29 +443,30 @@ __device__ __forceinline__ int block_mulmod(ChainLds<K, NW> &s, u32 shift, int l
     const bool w0 = wave == 0;
     int status = H2R_OK;
     u32 xlo[V], xhi[V];
-    __syncthreads();
+    // (no barrier needed before re-publishing opa/bpad: every wave has passed the two barriers that follow the
+    //  product loop of the previous block_mul, so nobody still reads them; block_mul's first barrier publishes)
     if (w0) { lds_store<K>(s.opa, a, lane); lds_store<K>(s.bpad + K, b, lane); }
-    block_mul<K, NW>(s.opa, s.bpad, s, lane, wave, xlo, xhi);
+    u32 dk;
+    block_mul<K, NW, MUL_FULL>(s.opa, s.bpad, s, lane, wave, xlo, xhi, dk);
     if (shift) {  // x' = x << s  (n' = n << s); block-uniform branch
         if (block_shl2k<K, NW>(s, shift, lane, wave, xlo, xhi)) status = H2R_E_NOT_REDUCED;
     }
     // q^ = x1 + floor(x1 * mu' / 2^(32K)),  x1 = floor(x' / 2^(32K))
-    __syncthreads();
     if (w0) lds_store<K>(s.opa, xhi, lane);
     u32 ylo[V], yhi[V];
-    block_mul<K, NW>(s.opa, s.mupad, s, lane, wave, ylo, yhi);
+    block_mul<K, NW, MUL_HIGH>(s.opa, s.mupad, s, lane, wave, ylo, yhi, dk);
     if (w0 && wave_add<K>(q, xhi, yhi, lane)) status = H2R_E_NOT_REDUCED;
-    // R = x' - q^ * n'   (0 <= R < 5 n')
-    __syncthreads();
+    // R = x' - q^ * n'   (0 <= R < 7 n': q^ may be up to 6 short of the true quotient)
     if (w0) lds_store<K>(s.opa, q, lane);
     u32 zlo[V], zhi[V];
-    block_mul<K, NW>(s.opa, s.nnpad, s, lane, wave, zlo, zhi);
+    block_mul<K, NW, MUL_LOW>(s.opa, s.nnpad, s, lane, wave, zlo, zhi, dk);
+    if (K < 64) dk = __shfl(zhi[0], 0);   // full product was computed: digit K is its first high digit
     u32 rl[V];
 #pragma unroll
     for (int m = 0; m < V; ++m) rl[m] = 0;
     if (w0) {
         const bool b0 = wave_sub<K>(rl, xlo, zlo, lane);
-        u32 rtop = __shfl(xhi[0] - zhi[0] - (b0 ? 1u : 0u), 0);
+        u32 rtop = __shfl(xhi[0], 0) - dk - (b0 ? 1u : 0u);
         for (int it = 0; it < 8; ++it) {
             if (rtop == 0 && !wave_ge<K>(rl, nn, lane)) break;
             u32 t[V];
