@@ -63,11 +63,14 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_mul_mod_batch", "h2r_square_mod_batch", "h2r_pow_mod_fixed_exp_batch", "h2r_pow_mod_batch",
            "h2r_modpow_public_key_batch", "h2r_pipeline_create", "h2r_pipeline_destroy",
            "h2r_pipeline_modpow_public_key", "h2r_pipeline_join", "h2r_verify_layout_fixed", "h2r_verify_pkcs1v15_batch",
-           "h2r_verify_trace_flatten", "h2r_range_decompose_batch", "h2r_hist_len", "h2r_trace_lookup_hist", "h2r_lookups_per_record",
+           "h2r_verify_trace_flatten", "h2r_fresh_op_layout", "h2r_fresh_op_batch", "h2r_fresh_op_flatten",
+           "h2r_range_decompose_batch", "h2r_hist_len", "h2r_trace_lookup_hist", "h2r_lookups_per_record",
            "h2r_trace_lookup_permutation",
            "h2r_trace_flatten", "h2r_pow_trace_flatten", "h2r_profile_enable", "h2r_profile_read", "h2r_status_str",
            "h2r_last_hip_error"]
 KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST, KERNEL_AUX = 0, 1, 2, 3
+FRESH_OPS = ["add", "sub", "add_mod", "sub_mod", "is_zero", "is_equal_fresh", "is_less_than", "is_less_than_or_equal",
+             "is_greater_than", "is_greater_than_or_equal", "is_in_field"]
 
 
 def lib_path():
@@ -112,6 +115,9 @@ def lib():
     L.h2r_verify_layout_fixed.argtypes = [vp, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(H2RVerifyLayout)]
     L.h2r_verify_pkcs1v15_batch.argtypes = [vp, vp, vp, ctypes.c_char_p, ctypes.c_size_t, vp, u64, u32, vp, vp, vp, vp, vp, vp]
     L.h2r_verify_trace_flatten.argtypes = [vp, ctypes.POINTER(H2RVerifyLayout), vp, vp]
+    L.h2r_fresh_op_layout.argtypes = [vp, u32, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u32)]
+    L.h2r_fresh_op_batch.argtypes = [vp, u32, vp, vp, vp, u64, u32, vp, vp, vp, vp, vp]
+    L.h2r_fresh_op_flatten.argtypes = [vp, u32, vp, vp]
     L.h2r_range_decompose_batch.argtypes = [vp, vp, u32, u64, u32, u32, vp, u32, vp, vp]
     L.h2r_hist_len.argtypes = [vp]
     L.h2r_hist_len.restype = u32

@@ -267,6 +267,68 @@ class BigIntChip:
                                       status.data_ptr(), None, self._stream()), "pow_mod")
         return BatchResult(AssignedInteger(out, self.limb_width), Trace(self, trace, batch, pl) if want_trace else None, status)
 
+    # ---- the Fresh-integer family (add / sub / add_mod / sub_mod / comparisons) -----------------------
+    def _fresh_op(self, name: str, a: AssignedInteger, b: Optional[AssignedInteger], n: Optional[AssignedInteger]) -> "FreshResult":
+        op = _lib.FRESH_OPS.index(name)
+        es, sb, vl = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint32()
+        check(lib().h2r_fresh_op_layout(self._ctx, op, ctypes.byref(es), ctypes.byref(sb), ctypes.byref(vl)), name)
+        batch, dev = a.batch, a.limbs_dev.device
+        trace = torch.zeros(batch * es.value, dtype=torch.uint8, device=dev)
+        value = torch.zeros((batch, vl.value), dtype=self.torch_dtype, device=dev) if vl.value else None
+        flag = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        status = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        flags = self._flags(n, batch) if n is not None else 0
+        check(lib().h2r_fresh_op_batch(self._ctx, op, a.data_ptr(), b.data_ptr() if b is not None else None,
+                                       n.data_ptr() if n is not None else None, batch, flags, trace.data_ptr(),
+                                       value.data_ptr() if value is not None else None, flag.data_ptr(), status.data_ptr(),
+                                       self._stream()), name)
+        return FreshResult(AssignedInteger(value, self.limb_width) if value is not None else None, flag, status, trace,
+                           es.value, sb.value, op, self)
+
+    def add(self, a, b):
+        """big_integer/chip.rs:245-297 -> num_limbs + 1 limbs."""
+        return self._fresh_op("add", a, b, None)
+
+    def sub(self, a, b):
+        """big_integer/chip.rs:310-373 -> (|a - b|, flag = is_overflowed)."""
+        return self._fresh_op("sub", a, b, None)
+
+    def add_mod(self, a, b, n):
+        """big_integer/chip.rs:452-481."""
+        return self._fresh_op("add_mod", a, b, n)
+
+    def sub_mod(self, a, b, n):
+        """big_integer/chip.rs:495-528."""
+        return self._fresh_op("sub_mod", a, b, n)
+
+    def is_zero(self, a):
+        """big_integer/chip.rs:754-767."""
+        return self._fresh_op("is_zero", a, None, None)
+
+    def is_equal_fresh(self, a, b):
+        """big_integer/chip.rs:780-805."""
+        return self._fresh_op("is_equal_fresh", a, b, None)
+
+    def is_less_than(self, a, b):
+        """big_integer/chip.rs:908-919."""
+        return self._fresh_op("is_less_than", a, b, None)
+
+    def is_less_than_or_equal(self, a, b):
+        """big_integer/chip.rs:932-941."""
+        return self._fresh_op("is_less_than_or_equal", a, b, None)
+
+    def is_greater_than(self, a, b):
+        """big_integer/chip.rs:954-963."""
+        return self._fresh_op("is_greater_than", a, b, None)
+
+    def is_greater_than_or_equal(self, a, b):
+        """big_integer/chip.rs:976-985."""
+        return self._fresh_op("is_greater_than_or_equal", a, b, None)
+
+    def is_in_field(self, a, n):
+        """big_integer/chip.rs:998-1006."""
+        return self._fresh_op("is_in_field", a, n, None)
+
     def pipeline(self) -> "Pipeline":
         """Opt-in two-stream pipeline (h2r_pipeline_*): consecutive modpow batches overlap chain and trace."""
         return Pipeline(self)
@@ -304,3 +366,21 @@ class Pipeline:
             self.close()
         except Exception:
             pass
+
+
+@dataclass
+class FreshResult:
+    value: Optional[AssignedInteger]
+    flag: torch.Tensor      # predicate / overflow bit per element
+    status: torch.Tensor
+    trace: torch.Tensor
+    elem_stride: int
+    stream_bytes: int
+    op: int
+    chip: BigIntChip
+
+    def flatten(self, elem: int) -> np.ndarray:
+        host = np.ascontiguousarray(self.trace[elem * self.elem_stride:(elem + 1) * self.elem_stride].cpu().numpy())
+        out = np.zeros(self.stream_bytes, dtype=np.uint8)
+        check(lib().h2r_fresh_op_flatten(self.chip._ctx, self.op, host.ctypes.data, out.ctypes.data), "h2r_fresh_op_flatten")
+        return out

@@ -246,22 +246,38 @@ int32_t exp_to_bits(const uint8_t *e_le, size_t e_len, ExpBits *eb, u32 *T) {
     return H2R_OK;
 }
 
-// walk the in-field region (AuxGeom sections) in stream order
+// Walk the sections of a Fresh-op region (AuxGeom) in stream order: emit(device_offset, length).
+// Sections start on 16-byte boundaries in the device buffer; the flat stream is their concatenation.
 template <typename F>
-void in_field_sections(const AuxGeom &g, F &&emit) {
+void fresh_sections(const AuxGeom &g, u32 op, F &&emit) {
     u64 off = 0;
+    const u32 L = g.L;
     auto add = [&](u32 n) { emit(off, (u64)n * g.STEP); off += g.add_sz(n); };
     auto eq = [&](u32 n) { emit(off, 2ull * n); off += g.eq_sz(n); };
     auto subu = [&](u32 n1) { emit(off, (u64)n1 * g.RA); off += g.cl_sz(n1); add(n1); eq(n1 + 1); };
-    const u32 L = g.L;
-    add(L); subu(L + 1);
-    emit(off, 2); off += 16;
-    emit(off, (u64)(L + 1) * g.LB); off += AuxGeom::a16((u64)(L + 1) * g.LB);
-    emit(off, (u64)L * g.LB); off += AuxGeom::a16((u64)L * g.LB);
-    subu(L + 1);
-    eq(L);
-    emit(off, 2); off += 16;
+    auto sub = [&](u32 nA, u32 nB) {
+        const u32 m = nA > nB ? nA : nB, n1 = m + 1;
+        add(m); subu(n1);
+        emit(off, 2); off += 16;
+        emit(off, (u64)n1 * g.LB); off += AuxGeom::a16((u64)n1 * g.LB);
+        emit(off, (u64)m * g.LB); off += AuxGeom::a16((u64)m * g.LB);
+        subu(n1);
+    };
+    auto lt = [&]() { sub(L, L); eq(L); emit(off, 2); off += 16; };
+    switch (op) {
+        case FRESH_ADD: add(L); break;
+        case FRESH_SUB: case FRESH_IS_LESS_THAN_OR_EQUAL: sub(L, L); break;
+        case FRESH_ADD_MOD: add(L); sub(L + 1, L); emit(off, (u64)(L + 2) * g.LB); break;
+        case FRESH_SUB_MOD: sub(L, L); sub(L, L + 1); emit(off, (u64)(L + 2) * g.LB); break;
+        case FRESH_IS_ZERO: case FRESH_IS_EQUAL_FRESH: eq(L); break;
+        case FRESH_IS_LESS_THAN: case FRESH_IS_IN_FIELD: lt(); break;
+        case FRESH_IS_GREATER_THAN: sub(L, L); emit(off, 1); break;
+        case FRESH_IS_GREATER_THAN_OR_EQUAL: lt(); emit(off, 1); break;
+        default: break;
+    }
 }
+template <typename F>
+void in_field_sections(const AuxGeom &g, F &&emit) { fresh_sections(g, FRESH_IS_IN_FIELD, emit); }
 
 }  // namespace
 
@@ -548,6 +564,53 @@ int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const voi
     if (p->pending) HIP_TRY(hipStreamWaitEvent(st, p->trace_done[slot ^ 1], 0));
     p->pending = true;
     p->k += 1;
+    return H2R_OK;
+}
+
+int32_t h2r_fresh_op_layout(const h2r_ctx *ctx, uint32_t op, uint64_t *elem_stride, uint64_t *stream_bytes, uint32_t *value_limbs) {
+    if (!ctx) return H2R_E_NULL;
+    if (op >= FRESH_OP_COUNT) return H2R_E_UNSUPPORTED;
+    if (ctx->L + 3 > 64 * AUX_V) return H2R_E_UNSUPPORTED;
+    const AuxGeom g(ctx->L, ctx->layout.limb_width);
+    u64 dev = 0, sb = 0;
+    fresh_sections(g, op, [&](u64 off, u64 len) { sb += len; dev = off + len; });
+    if (elem_stride) *elem_stride = round_up(dev, 256);
+    if (stream_bytes) *stream_bytes = sb;
+    if (value_limbs) *value_limbs = (op == FRESH_ADD || op == FRESH_SUB) ? ctx->L + 1 : ((op == FRESH_ADD_MOD || op == FRESH_SUB_MOD) ? ctx->L : 0);
+    return H2R_OK;
+}
+
+int32_t h2r_fresh_op_batch(const h2r_ctx *ctx, uint32_t op, const void *a, const void *b, const void *n, uint64_t batch,
+                           uint32_t flags, void *trace, void *value_out, uint8_t *flag_out, uint8_t *status, h2r_stream_t stream) {
+    if (!ctx || !a || !trace || !status) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    u64 es; u32 vl;
+    int32_t rc = h2r_fresh_op_layout(ctx, op, &es, nullptr, &vl);
+    if (rc) return rc;
+    const bool needs_b = op != FRESH_IS_ZERO, needs_n = op == FRESH_ADD_MOD || op == FRESH_SUB_MOD;
+    if ((needs_b && !b) || (needs_n && !n)) return H2R_E_NULL;
+    if (batch == 0) return H2R_OK;
+    FreshArgs fa;
+    std::memset(&fa, 0, sizeof fa);
+    fa.a = a; fa.b = b; fa.n = n; fa.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
+    fa.batch = batch; fa.L = ctx->L; fa.op = op; fa.trace = static_cast<u8 *>(trace); fa.elem_stride = es;
+    fa.value_out = value_out; fa.value_limbs = vl; fa.flag_out = flag_out; fa.status = status;
+    HIP_TRY(hipSetDevice(ctx->params.device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope ps(H2R_KERNEL_AUX, st);
+    if (ctx->layout.limb_width == 64) hipLaunchKernelGGL((fresh_kernel<64>), dim3((unsigned)batch), dim3(64), 0, st, fa);
+    else hipLaunchKernelGGL((fresh_kernel<32>), dim3((unsigned)batch), dim3(64), 0, st, fa);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
+
+int32_t h2r_fresh_op_flatten(const h2r_ctx *ctx, uint32_t op, const void *elem_host, void *stream_out) {
+    if (!ctx || !elem_host || !stream_out) return H2R_E_NULL;
+    if (op >= FRESH_OP_COUNT) return H2R_E_UNSUPPORTED;
+    const u8 *e = static_cast<const u8 *>(elem_host);
+    u8 *o = static_cast<u8 *>(stream_out);
+    const AuxGeom g(ctx->L, ctx->layout.limb_width);
+    fresh_sections(g, op, [&](u64 off, u64 len) { std::memcpy(o, e + off, len); o += len; });
     return H2R_OK;
 }
 

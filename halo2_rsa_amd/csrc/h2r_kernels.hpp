@@ -981,8 +981,14 @@ struct AuxGeom {
     __host__ __device__ u64 eq_sz(u32 n) const { return a16(2ull * n); }
     __host__ __device__ u64 cl_sz(u32 n) const { return a16((u64)n * RA); }
     __host__ __device__ u64 subu_sz(u32 n1) const { return cl_sz(n1) + add_sz(n1) + eq_sz(n1 + 1); }
-    __host__ __device__ u64 sub_sz() const { return add_sz(L) + subu_sz(L + 1) + 16 + a16((u64)(L + 1) * LB) + a16((u64)L * LB) + subu_sz(L + 1); }
+    __host__ __device__ u64 sub_sz(u32 nA, u32 nB) const {
+        const u32 m = nA > nB ? nA : nB, n1 = m + 1;
+        return add_sz(m) + subu_sz(n1) + 16 + a16((u64)n1 * LB) + a16((u64)m * LB) + subu_sz(n1);
+    }
+    __host__ __device__ u64 sub_sz() const { return sub_sz(L, L); }
     __host__ __device__ u64 in_field_sz() const { return sub_sz() + eq_sz(L) + 16; }
+    // largest Fresh-op region: sub_mod = sub(L, L) + sub(L, L+1) + (L+2) limbs
+    __host__ __device__ u64 fresh_max_sz() const { return sub_sz(L, L) + sub_sz(L, L + 1) + add_sz(L) + a16((u64)(L + 2) * LB) + eq_sz(L) + 64; }
     __host__ __device__ u64 em_sz() const { return a16(2ull * L + 34); }
 };
 
@@ -1089,6 +1095,62 @@ __device__ __forceinline__ void aux_subu(u8 *sec, const AuxGeom &g, const u64 (&
     aux_eq<LW>(sec + g.cl_sz(n1) + g.add_sz(n1), A, n1, added, n1 + 1, lane);    // :1316
 }
 
+// limb `idx` of a distributed integer, broadcast to the wave
+__device__ __forceinline__ u64 aux_limb(const u64 (&X)[AUX_V], u32 idx) {
+    const u32 m = idx >> 6;
+    return __shfl(m == 0 ? X[0] : (m == 1 ? X[1] : X[2]), (int)(idx & 63));
+}
+
+// BigIntChip::sub (chip.rs:310-373): REAL = |A - B| (max(nA,nB)+1 limbs), returns is_overflowed (1 iff A <= B).
+// Advances `sec` past its sections.
+template <int LW>
+__device__ __forceinline__ bool aux_sub(u8 *&sec, const AuxGeom &g, const u64 (&A)[AUX_V], u32 nA, const u64 (&B)[AUX_V], u32 nB,
+                                        u64 (&REAL)[AUX_V], int lane) {
+    using X = AuxW<LW>;
+    const u32 m = nA > nB ? nA : nB, n1 = m + 1;
+    u64 MAXI[AUX_V], IA[AUX_V], IS[AUX_V], SL[AUX_V], SR[AUX_V];
+#pragma unroll
+    for (int k = 0; k < AUX_V; ++k) MAXI[k] = (u32)(lane + 64 * k) < nB ? X::MASK : 0;   // max_value(n2), :319 -> :138-154
+    aux_add<LW>(sec, g, A, nA, MAXI, nB, IA, lane);                          // inflated_a, :321
+    sec += g.add_sz(m);
+    aux_subu<LW>(sec, g, IA, n1, B, nB, IS, lane);                           // inflated_subed, :323
+    sec += g.subu_sz(n1);
+    const bool not_ov = aux_limb(IS, nB) == 1;                               // :330
+    if (lane == 0) *reinterpret_cast<uint16_t *>(sec) = (uint16_t)((not_ov ? 1u : 0u) | ((not_ov ? 0u : 1u) << 8));   // :330-331
+    sec += 16;
+#pragma unroll
+    for (int k = 0; k < AUX_V; ++k) {                                        // selects, :345-367
+        const u32 p = lane + 64 * k;
+        SL[k] = p < n1 ? (p >= nB ? (not_ov ? IS[k] : 0) : (not_ov ? IS[k] : B[k])) : 0;
+        u64 r = 0;
+        if (p < m) {
+            if (p >= nA) r = not_ov ? MAXI[k] : 0;
+            else if (p >= nB) r = not_ov ? 0 : A[k];
+            else r = not_ov ? MAXI[k] : A[k];
+        }
+        SR[k] = r;
+        if (p < n1) X::put_limb(sec + (u64)p * g.LB, SL[k]);
+        if (p < m) X::put_limb(sec + AuxGeom::a16((u64)n1 * g.LB) + (u64)p * g.LB, SR[k]);
+    }
+    sec += AuxGeom::a16((u64)n1 * g.LB) + AuxGeom::a16((u64)m * g.LB);
+    aux_subu<LW>(sec, g, SL, n1, SR, m, REAL, lane);                         // real_subed, :371
+    sec += g.subu_sz(n1);
+    return !not_ov;
+}
+
+// BigIntChip::is_less_than (chip.rs:908-919)
+template <int LW>
+__device__ __forceinline__ bool aux_less_than(u8 *&sec, const AuxGeom &g, const u64 (&A)[AUX_V], const u64 (&B)[AUX_V], int lane) {
+    u64 REAL[AUX_V];
+    const bool ov = aux_sub<LW>(sec, g, A, g.L, B, g.L, REAL, lane);         // is_less_than_or_equal, :915 -> :939
+    const bool is_eq = aux_eq<LW>(sec, A, g.L, B, g.L, lane);                // :916
+    sec += g.eq_sz(g.L);
+    const bool lt = ov && !is_eq;                                            // :917-918
+    if (lane == 0) *reinterpret_cast<uint16_t *>(sec) = (uint16_t)((is_eq ? 0u : 1u) | ((lt ? 1u : 0u) << 8));
+    sec += 16;
+    return lt;
+}
+
 template <int LW>
 __global__ __launch_bounds__(64) void aux_kernel(AuxArgs a) {
     using X = AuxW<LW>;
@@ -1097,42 +1159,17 @@ __global__ __launch_bounds__(64) void aux_kernel(AuxArgs a) {
     const u64 elem = blockIdx.x;
     const u32 L = a.L;
     const AuxGeom g(L, LW);
-    u64 Xv[AUX_V], Nv[AUX_V], MAXI[AUX_V];
+    u64 Xv[AUX_V], Nv[AUX_V];
 #pragma unroll
     for (int m = 0; m < AUX_V; ++m) {
         const u32 p = lane + 64 * m;
         Xv[m] = p < L ? (u64) reinterpret_cast<const limb_t *>(a.x)[elem * L + p] : 0;
         Nv[m] = p < L ? (u64) reinterpret_cast<const limb_t *>(a.n)[elem * a.n_stride + p] : 0;
-        MAXI[m] = p < L ? X::MASK : 0;                                    // max_value, chip.rs:138-154
     }
     u8 *et = a.trace + elem * a.elem_stride;
     u8 *sec = et + a.off_in_field;
-    // ---- is_less_than(x, n) = sub(x, n).overflow & !is_equal_fresh(x, n)   (chip.rs:908-919) ----------
-    u64 IA[AUX_V], IS[AUX_V], SL[AUX_V], SR[AUX_V], REAL[AUX_V];
-    aux_add<LW>(sec, g, Xv, L, MAXI, L, IA, lane);                         // inflated_a, :321
-    sec += g.add_sz(L);
-    aux_subu<LW>(sec, g, IA, L + 1, Nv, L, IS, lane);                      // inflated_subed, :323
-    sec += g.subu_sz(L + 1);
-    const u64 top = __shfl(L >= 128 ? IS[2] : (L >= 64 ? IS[1] : IS[0]), (int)(L & 63));   // limb n2 = L of inflated_subed
-    const bool not_ov = top == 1;                                          // :330
-    if (lane == 0) *reinterpret_cast<uint16_t *>(sec) = (uint16_t)((not_ov ? 1u : 0u) | ((not_ov ? 0u : 1u) << 8));   // :330-331
-    sec += 16;
-#pragma unroll
-    for (int m = 0; m < AUX_V; ++m) {                                      // selects, :345-367
-        const u32 p = lane + 64 * m;
-        SL[m] = p < L + 1 ? (p >= L ? (not_ov ? IS[m] : 0) : (not_ov ? IS[m] : Nv[m])) : 0;
-        SR[m] = p < L ? (not_ov ? MAXI[m] : Xv[m]) : 0;
-        if (p < L + 1) X::put_limb(sec + (u64)p * g.LB, SL[m]);
-        if (p < L) X::put_limb(sec + AuxGeom::a16((u64)(L + 1) * g.LB) + (u64)p * g.LB, SR[m]);
-    }
-    sec += AuxGeom::a16((u64)(L + 1) * g.LB) + AuxGeom::a16((u64)L * g.LB);
-    aux_subu<LW>(sec, g, SL, L + 1, SR, L, REAL, lane);                    // real_subed, :371
-    sec += g.subu_sz(L + 1);
-    const bool is_eq = aux_eq<LW>(sec, Xv, L, Nv, L, lane);                // :916
-    sec += g.eq_sz(L);
-    const bool lt = !not_ov && !is_eq;                                     // :917-918
-    if (lane == 0) *reinterpret_cast<uint16_t *>(sec) = (uint16_t)((is_eq ? 0u : 1u) | ((lt ? 1u : 0u) << 8));
-    (void)lt;
+    (void)aux_less_than<LW>(sec, g, Xv, Nv, lane);   // assert_in_field = is_less_than(x, n), chip.rs:998-1006
+    (void)sizeof(X);
     // ---- encoded-message check (src/chip.rs:136-198; LIMB_WIDTH = 64 only) ----------------------------
     if constexpr (LW == 64) {
         if (a.hashed != nullptr && lane == 0) {
@@ -1158,6 +1195,105 @@ __global__ __launch_bounds__(64) void aux_kernel(AuxArgs a) {
             if (a.is_valid) a.is_valid[elem] = (u8)is_eqv;
         }
     }
+}
+
+// The Fresh-integer family of BigIntInstructions as one batch op: one wave per element,
+// flat stream written section by section like aux_kernel.
+enum { FRESH_ADD = 0, FRESH_SUB, FRESH_ADD_MOD, FRESH_SUB_MOD, FRESH_IS_ZERO, FRESH_IS_EQUAL_FRESH, FRESH_IS_LESS_THAN,
+       FRESH_IS_LESS_THAN_OR_EQUAL, FRESH_IS_GREATER_THAN, FRESH_IS_GREATER_THAN_OR_EQUAL, FRESH_IS_IN_FIELD, FRESH_OP_COUNT };
+
+struct FreshArgs {
+    const void *a, *b, *n; u64 n_stride;
+    u64 batch; u32 L, op;
+    u8 *trace; u64 elem_stride;
+    void *value_out; u32 value_limbs;   // [elem][value_limbs] (nullable)
+    u8 *flag_out;                       // [elem] (nullable)
+    u8 *status;                         // [elem]
+};
+
+template <int LW>
+__global__ __launch_bounds__(64) void fresh_kernel(FreshArgs f) {
+    using X = AuxW<LW>;
+    using limb_t = typename LimbT<LW>::type;
+    const int lane = threadIdx.x;
+    const u64 elem = blockIdx.x;
+    const u32 L = f.L;
+    const AuxGeom g(L, LW);
+    u64 A[AUX_V], B[AUX_V], N[AUX_V], R1[AUX_V], R2[AUX_V], OUT[AUX_V];
+#pragma unroll
+    for (int m = 0; m < AUX_V; ++m) {
+        const u32 p = lane + 64 * m;
+        A[m] = p < L ? (u64) reinterpret_cast<const limb_t *>(f.a)[elem * L + p] : 0;
+        B[m] = (f.b && p < L) ? (u64) reinterpret_cast<const limb_t *>(f.b)[elem * L + p] : 0;
+        N[m] = (f.n && p < L) ? (u64) reinterpret_cast<const limb_t *>(f.n)[elem * f.n_stride + p] : 0;
+        OUT[m] = 0;
+    }
+    u8 *sec = f.trace + elem * f.elem_stride;
+    int status = H2R_OK;
+    int flag = 0;
+    u32 nv = 0;
+    switch (f.op) {  // block-uniform
+        case FRESH_ADD: aux_add<LW>(sec, g, A, L, B, L, OUT, lane); nv = L + 1; break;                     // chip.rs:245-297
+        case FRESH_SUB: flag = aux_sub<LW>(sec, g, A, L, B, L, OUT, lane); nv = L + 1; break;              // chip.rs:310-373
+        case FRESH_ADD_MOD: {                                                                              // chip.rs:452-481
+            aux_add<LW>(sec, g, A, L, B, L, R1, lane); sec += g.add_sz(L);                                 // added, :462
+            const bool ov = aux_sub<LW>(sec, g, R1, L + 1, N, L, R2, lane);                                // :464
+            bool bad = false;
+#pragma unroll
+            for (int m = 0; m < AUX_V; ++m) {                                                              // select(added, subed, ov), :469-474
+                const u32 p = lane + 64 * m;
+                const u64 v = p < L + 2 ? (ov ? (p < L + 1 ? R1[m] : 0) : R2[m]) : 0;
+                if (p < L + 2) X::put_limb(sec + (u64)p * g.LB, v);
+                OUT[m] = p < L ? v : 0;
+                bad = bad || (p >= L && v != 0);                                                           // assert_zero, :475-478
+            }
+            if (__ballot(bad)) status = H2R_E_NOT_REDUCED;
+            nv = L; break;
+        }
+        case FRESH_SUB_MOD: {                                                                              // chip.rs:495-528
+            const bool ov1 = aux_sub<LW>(sec, g, A, L, B, L, R1, lane);                                    // subed1 (L+1 limbs), :506
+            const bool ov2 = aux_sub<LW>(sec, g, N, L, R1, L + 1, R2, lane);                               // subed2 (L+2 limbs), :509
+            if (ov2) status = H2R_E_NOT_IN_FIELD;                                                          // assert_zero(is_overflowed2), :510
+            bool bad = false;
+#pragma unroll
+            for (int m = 0; m < AUX_V; ++m) {                                                              // select(subed2, subed1, ov1), :516-521
+                const u32 p = lane + 64 * m;
+                const u64 v = p < L + 2 ? (ov1 ? R2[m] : (p < L + 1 ? R1[m] : 0)) : 0;
+                if (p < L + 2) X::put_limb(sec + (u64)p * g.LB, v);
+                OUT[m] = p < L ? v : 0;
+                bad = bad || (p >= L && v != 0);
+            }
+            if (status == H2R_OK && __ballot(bad)) status = H2R_E_NOT_REDUCED;
+            nv = L; break;
+        }
+        case FRESH_IS_ZERO: {                                                                              // chip.rs:754-767
+            u64 Z[AUX_V];
+#pragma unroll
+            for (int m = 0; m < AUX_V; ++m) Z[m] = 0;
+            flag = aux_eq<LW>(sec, A, L, Z, L, lane);   // same (flag, running AND) pair sequence as is_equal against zero
+            break;
+        }
+        case FRESH_IS_EQUAL_FRESH: flag = aux_eq<LW>(sec, A, L, B, L, lane); break;                        // chip.rs:780-805
+        case FRESH_IS_LESS_THAN: case FRESH_IS_IN_FIELD: flag = aux_less_than<LW>(sec, g, A, B, lane); break;
+        case FRESH_IS_LESS_THAN_OR_EQUAL: flag = aux_sub<LW>(sec, g, A, L, B, L, R1, lane); break;         // chip.rs:932-941
+        case FRESH_IS_GREATER_THAN:                                                                        // chip.rs:954-963
+            flag = !aux_sub<LW>(sec, g, A, L, B, L, R1, lane);
+            if (lane == 0) sec[0] = (u8)flag;
+            break;
+        case FRESH_IS_GREATER_THAN_OR_EQUAL:                                                               // chip.rs:976-985
+            flag = !aux_less_than<LW>(sec, g, A, B, lane);
+            if (lane == 0) sec[0] = (u8)flag;
+            break;
+        default: status = H2R_E_UNSUPPORTED; break;
+    }
+    if (f.value_out && nv) {
+#pragma unroll
+        for (int m = 0; m < AUX_V; ++m) {
+            const u32 p = lane + 64 * m;
+            if (p < nv && p < f.value_limbs) reinterpret_cast<limb_t *>(f.value_out)[elem * f.value_limbs + p] = (limb_t)OUT[m];
+        }
+    }
+    if (lane == 0) { if (f.flag_out) f.flag_out[elem] = (u8)flag; f.status[elem] = (u8)status; }
 }
 
 // ================================================================================================

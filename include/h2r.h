@@ -249,6 +249,27 @@ int32_t h2r_verify_pkcs1v15_batch(const h2r_ctx *ctx, const void *sig, const voi
 int32_t h2r_verify_trace_flatten(const h2r_ctx *ctx, const h2r_verify_layout *vl,
                                  const void *elem_host, void *stream_out);
 
+/* ---- the Fresh-integer family of BigIntInstructions ---------------------------
+ * add (big_integer/chip.rs:245-297), sub (:310-373; flag = is_overflowed, value = |a-b|), add_mod (:452-481),
+ * sub_mod (:495-528), is_zero (:754-767), is_equal_fresh (:780-805), is_less_than (:908-919),
+ * is_less_than_or_equal (:932-941), is_greater_than (:954-963), is_greater_than_or_equal (:976-985),
+ * is_in_field (:998-1006), all on num_limbs-limb operands.  The element trace holds the op's flat stream
+ * section by section (16-byte aligned sections; h2r_fresh_op_flatten packs them).  value_out
+ * (nullable): value_limbs limbs per element (num_limbs+1 for add/sub, num_limbs for add_mod/sub_mod);
+ * flag_out (nullable): the predicate / overflow bit.  As in the reference, sub's overflow bit is 1 iff
+ * a <= b, so add_mod returns a+b un-reduced when a+b == n and sub_mod(a, a, n) returns n.
+ * status: H2R_E_NOT_IN_FIELD where sub_mod's assert_zero(is_overflowed2) (:510) fails, H2R_E_NOT_REDUCED
+ * where the high limbs of an add_mod/sub_mod result are non-zero (:475-478, :522-525). */
+enum { H2R_OP_ADD = 0, H2R_OP_SUB, H2R_OP_ADD_MOD, H2R_OP_SUB_MOD, H2R_OP_IS_ZERO, H2R_OP_IS_EQUAL_FRESH,
+       H2R_OP_IS_LESS_THAN, H2R_OP_IS_LESS_THAN_OR_EQUAL, H2R_OP_IS_GREATER_THAN,
+       H2R_OP_IS_GREATER_THAN_OR_EQUAL, H2R_OP_IS_IN_FIELD, H2R_OP_COUNT };
+int32_t h2r_fresh_op_layout(const h2r_ctx *ctx, uint32_t op, uint64_t *elem_stride, uint64_t *stream_bytes,
+                            uint32_t *value_limbs);
+int32_t h2r_fresh_op_batch(const h2r_ctx *ctx, uint32_t op, const void *a, const void *b, const void *n,
+                           uint64_t batch, uint32_t flags, void *trace, void *value_out, uint8_t *flag_out,
+                           uint8_t *status, h2r_stream_t stream);
+int32_t h2r_fresh_op_flatten(const h2r_ctx *ctx, uint32_t op, const void *elem_host, void *stream_out);
+
 /* ---- the lookup range-check batch --------------------------------------------------------------
  * RangeChip::assign(value, sublimb_bits, bit_len) decomposition of `count` values of `value_bytes`
  * bytes each (8 or 16) into ceil(bit_len/sublimb_bits) one-byte sub-limbs (stride sub_stride),

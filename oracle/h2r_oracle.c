@@ -498,14 +498,14 @@ static int sub_unchecked(const h2ro_params *p, const uint64_t *a, unsigned n1, c
     }
     if (borrow) return -1;                                              /* :1300 underflow panics */
     for (unsigned i = 0; i < n1; ++i) emit_range_assign(s, u256_from64(c[i]), p->limb_sub_bits, w, p->LB); /* :1307-1308 */
-    uint64_t added[MAXL + 2];
+    uint64_t added[MAXL + 4];
     unsigned na = add_fresh(p, b, n2, c, n1, s, added);                 /* :1315 */
     if (!is_equal_fresh(a, n1, added, na, s)) return -1;                /* :1316 */
     return 0;
 }
 /* BigIntChip::sub, big_integer/chip.rs:310-373 */
-static int sub_fresh(const h2ro_params *p, const uint64_t *a, unsigned n1, const uint64_t *b, unsigned n2, wr *s, int *is_overflowed) {
-    uint64_t max_int[MAXL + 2], inflated_a[MAXL + 2], inflated_subed[MAXL + 2], sel_l[MAXL + 2], sel_r[MAXL + 2], real[MAXL + 2];
+static int sub_fresh(const h2ro_params *p, const uint64_t *a, unsigned n1, const uint64_t *b, unsigned n2, wr *s, int *is_overflowed, uint64_t *real) {
+    uint64_t max_int[MAXL + 4], inflated_a[MAXL + 4], inflated_subed[MAXL + 4], sel_l[MAXL + 4], sel_r[MAXL + 4];
     uint64_t mask = p->w == 64 ? ~0ull : ((1ull << p->w) - 1);
     for (unsigned i = 0; i < n2; ++i) max_int[i] = mask;               /* :319 max_value :138-154 */
     unsigned nia = add_fresh(p, a, n1, max_int, n2, s, inflated_a);     /* :321 */
@@ -539,7 +539,8 @@ int h2ro_assert_in_field(const h2ro_params *p, const void *a, const void *n, uin
     uint64_t A[MAXL], N[MAXL]; load_limbs(A, a, p->L, p->w); load_limbs(N, n, p->L, p->w);
     wr s = {stream};
     int is_overflowed = 0;
-    if (sub_fresh(p, A, p->L, N, p->L, &s, &is_overflowed)) return H2RO_E_SHAPE; /* :939 */
+    uint64_t real[MAXL + 4];
+    if (sub_fresh(p, A, p->L, N, p->L, &s, &is_overflowed, real)) return H2RO_E_SHAPE; /* :939 */
     int is_eq = is_equal_fresh(A, p->L, N, p->L, &s);                   /* :916 */
     int is_not_eq = !is_eq;                                             /* :917 */
     put64(&s, (uint64_t)is_not_eq, 1);
@@ -547,6 +548,100 @@ int h2ro_assert_in_field(const h2ro_params *p, const void *a, const void *n, uin
     put64(&s, (uint64_t)lt, 1);
     if (is_less) *is_less = lt;
     return lt ? H2RO_OK : H2RO_E_NOT_IN_FIELD;                          /* assert_one, :1157 */
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * the Fresh-integer family of BigIntInstructions
+ *   add :245-297, sub :310-373, add_mod :452-481, sub_mod :495-528, is_zero :754-767,
+ *   is_equal_fresh :780-805, is_less_than :908-919, is_less_than_or_equal :932-941,
+ *   is_greater_than :954-963, is_greater_than_or_equal :976-985, is_in_field :998-1006
+ * ---------------------------------------------------------------------------------------------- */
+static uint64_t add_bytes(const h2ro_params *p, uint64_t n) { return n * (3ull * (p->LB + 8) + 2ull * (p->LB + p->limb_nsub)); }
+static uint64_t subu_bytes(const h2ro_params *p, uint64_t n1) { return n1 * (p->LB + p->limb_nsub) + add_bytes(p, n1) + 2 * (n1 + 1); }
+static uint64_t sub_bytes(const h2ro_params *p, uint64_t nA, uint64_t nB) {
+    uint64_t m = nA > nB ? nA : nB, n1 = m + 1;
+    return add_bytes(p, m) + subu_bytes(p, n1) + 2 + n1 * p->LB + m * p->LB + subu_bytes(p, n1);
+}
+uint64_t h2ro_fresh_op_stream_bytes(const h2ro_params *p, int op) {
+    uint64_t L = p->L;
+    switch (op) {
+        case H2RO_OP_ADD: return add_bytes(p, L);
+        case H2RO_OP_SUB: return sub_bytes(p, L, L);
+        case H2RO_OP_ADD_MOD: return add_bytes(p, L) + sub_bytes(p, L + 1, L) + (L + 2) * p->LB;
+        case H2RO_OP_SUB_MOD: return sub_bytes(p, L, L) + sub_bytes(p, L, L + 1) + (L + 2) * p->LB;
+        case H2RO_OP_IS_ZERO: return 2 * L;
+        case H2RO_OP_IS_EQUAL_FRESH: return 2 * L;
+        case H2RO_OP_IS_LESS_THAN: case H2RO_OP_IS_IN_FIELD: return sub_bytes(p, L, L) + 2 * L + 2;
+        case H2RO_OP_IS_LESS_THAN_OR_EQUAL: return sub_bytes(p, L, L);
+        case H2RO_OP_IS_GREATER_THAN: return sub_bytes(p, L, L) + 1;
+        case H2RO_OP_IS_GREATER_THAN_OR_EQUAL: return sub_bytes(p, L, L) + 2 * L + 2 + 1;
+        default: return 0;
+    }
+}
+static int is_less_than(const h2ro_params *p, const uint64_t *A, const uint64_t *B, wr *s, int *lt) {
+    int ov = 0; uint64_t real[MAXL + 4];
+    if (sub_fresh(p, A, p->L, B, p->L, s, &ov, real)) return -1;       /* :915 -> :939 */
+    int is_eq = is_equal_fresh(A, p->L, B, p->L, s);                    /* :916 */
+    put64(s, (uint64_t)!is_eq, 1);                                      /* :917 */
+    *lt = ov & !is_eq; put64(s, (uint64_t)*lt, 1);                      /* :918 */
+    return 0;
+}
+/* value_out receives *nvalue limbs (may be NULL for predicate ops); flag_out the predicate / overflow bit. */
+int h2ro_fresh_op(const h2ro_params *p, int op, const void *a, const void *b, const void *n, uint8_t *stream,
+                  void *value_out, uint32_t *nvalue, int *flag_out) {
+    unsigned L = p->L, w = p->w;
+    uint64_t A[MAXL], B[MAXL], N[MAXL], v1[MAXL + 4], v2[MAXL + 4], res[MAXL + 4];
+    load_limbs(A, a, L, w);
+    if (b) load_limbs(B, b, L, w); else memset(B, 0, sizeof B);
+    if (n) load_limbs(N, n, L, w); else memset(N, 0, sizeof N);
+    wr s = {stream};
+    unsigned nv = 0; int flag = -1, ov = 0, ov2 = 0;
+    switch (op) {
+        case H2RO_OP_ADD: nv = add_fresh(p, A, L, B, L, &s, res); break;
+        case H2RO_OP_SUB: if (sub_fresh(p, A, L, B, L, &s, &ov, res)) return H2RO_E_SHAPE; nv = L + 1; flag = ov; break;
+        case H2RO_OP_ADD_MOD: {                                            /* chip.rs:452-481 */
+            unsigned na = add_fresh(p, A, L, B, L, &s, v1);                 /* :462 */
+            if (sub_fresh(p, v1, na, N, L, &s, &ov, v2)) return H2RO_E_SHAPE; /* :464 */
+            unsigned num = na + 1;                                          /* subed.num_limbs() */
+            for (unsigned i = 0; i < num; ++i) {                            /* :469-474 */
+                uint64_t ad = i < na ? v1[i] : 0;
+                res[i] = ov ? ad : v2[i]; put64(&s, res[i], p->LB);
+            }
+            for (unsigned i = L; i < num; ++i) if (res[i]) return H2RO_E_SHAPE;   /* :475-478 assert_zero */
+            nv = L; break;
+        }
+        case H2RO_OP_SUB_MOD: {                                            /* chip.rs:495-528 */
+            if (sub_fresh(p, A, L, B, L, &s, &ov, v1)) return H2RO_E_SHAPE;       /* :506, L+1 limbs */
+            if (sub_fresh(p, N, L, v1, L + 1, &s, &ov2, v2)) return H2RO_E_SHAPE; /* :509, L+2 limbs */
+            if (ov2) return H2RO_E_NOT_IN_FIELD;                            /* :510 assert_zero(is_overflowed2) */
+            unsigned num = L + 2;
+            for (unsigned i = 0; i < num; ++i) {                            /* :516-521 */
+                uint64_t s1 = i < L + 1 ? v1[i] : 0;
+                res[i] = ov ? v2[i] : s1; put64(&s, res[i], p->LB);
+            }
+            for (unsigned i = L; i < num; ++i) if (res[i]) return H2RO_E_SHAPE;
+            nv = L; break;
+        }
+        case H2RO_OP_IS_ZERO: {                                            /* chip.rs:754-767 */
+            int bit = 1;
+            for (unsigned i = 0; i < L; ++i) { int z = A[i] == 0; put64(&s, (uint64_t)z, 1); bit &= z; put64(&s, (uint64_t)bit, 1); }
+            flag = bit; break;
+        }
+        case H2RO_OP_IS_EQUAL_FRESH: flag = is_equal_fresh(A, L, B, L, &s); break;
+        case H2RO_OP_IS_LESS_THAN: case H2RO_OP_IS_IN_FIELD: if (is_less_than(p, A, B, &s, &flag)) return H2RO_E_SHAPE; break;
+        case H2RO_OP_IS_LESS_THAN_OR_EQUAL: if (sub_fresh(p, A, L, B, L, &s, &ov, res)) return H2RO_E_SHAPE; flag = ov; break;
+        case H2RO_OP_IS_GREATER_THAN:                                      /* chip.rs:954-963 */
+            if (sub_fresh(p, A, L, B, L, &s, &ov, res)) return H2RO_E_SHAPE;
+            flag = !ov; put64(&s, (uint64_t)flag, 1); break;
+        case H2RO_OP_IS_GREATER_THAN_OR_EQUAL:                             /* chip.rs:976-985 */
+            if (is_less_than(p, A, B, &s, &flag)) return H2RO_E_SHAPE;
+            flag = !flag; put64(&s, (uint64_t)flag, 1); break;
+        default: return H2RO_E_SHAPE;
+    }
+    if (nvalue) *nvalue = nv;
+    if (value_out && nv) store_limbs(value_out, res, nv, w);
+    if (flag_out) *flag_out = flag;
+    return H2RO_OK;
 }
 
 /* ------------------------------------------------------------------------------------------------

@@ -47,6 +47,14 @@ int h2ro_assert_in_field(const h2ro_params *p, const void *a, const void *n, uin
 uint64_t h2ro_pkcs1v15_stream_bytes(const h2ro_params *p);
 int h2ro_pkcs1v15_em_check(const h2ro_params *p, const void *powed, const uint64_t hashed[4], uint8_t *stream, int *is_valid);
 
+/* Fresh-integer family (add, sub, add_mod, sub_mod, comparisons) */
+enum { H2RO_OP_ADD = 0, H2RO_OP_SUB, H2RO_OP_ADD_MOD, H2RO_OP_SUB_MOD, H2RO_OP_IS_ZERO, H2RO_OP_IS_EQUAL_FRESH,
+       H2RO_OP_IS_LESS_THAN, H2RO_OP_IS_LESS_THAN_OR_EQUAL, H2RO_OP_IS_GREATER_THAN, H2RO_OP_IS_GREATER_THAN_OR_EQUAL,
+       H2RO_OP_IS_IN_FIELD, H2RO_OP_COUNT };
+uint64_t h2ro_fresh_op_stream_bytes(const h2ro_params *p, int op);
+int h2ro_fresh_op(const h2ro_params *p, int op, const void *a, const void *b, const void *n, uint8_t *stream,
+                  void *value_out, uint32_t *nvalue, int *flag_out);
+
 /* Batch drivers used by the CPU-baseline timing leg: element-major inputs, `nthreads` pthreads,
  * one element per task.  stream (nullable) holds batch*stream_bytes bytes. */
 int h2ro_pow_mod_fixed_exp_batch(const h2ro_params *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len,

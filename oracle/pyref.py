@@ -478,6 +478,100 @@ def assert_in_field(p: Params, a: Sequence[int], n: Sequence[int], st: Stream) -
     return is_less_than(p, a, n, st)
 
 
+def is_zero(p: Params, a: Sequence[int], st: Stream) -> int:
+    """BigIntChip::is_zero, big_integer/chip.rs:754-767."""
+    bit = 1
+    for v in a:
+        z = 1 if v == 0 else 0
+        st.put(z, 1)
+        bit &= z
+        st.put(bit, 1)
+    return bit
+
+
+def add_mod(p: Params, a: Sequence[int], b: Sequence[int], n: Sequence[int], st: Stream) -> List[int]:
+    """BigIntChip::add_mod, big_integer/chip.rs:452-481.  NOTE: sub's overflow bit is 1 iff added <= n, so the
+    result is `added` (un-reduced) when a + b == n -- restated as written."""
+    added = add_fresh(p, a, b, st)                        # :462
+    subed, is_overflowed = sub_fresh(p, added, n, st)    # :464
+    num_limbs = len(subed)
+    added = list(added) + [0] * (num_limbs - len(added))  # :467
+    res = []
+    for i in range(num_limbs):                            # :469-474 select(added, subed, is_overflowed)
+        v = added[i] if is_overflowed else subed[i]
+        st.put(v, p.LB)
+        res.append(v)
+    assert all(v == 0 for v in res[len(n):])              # :475-478 assert_zero
+    return res[:len(n)]
+
+
+def sub_mod(p: Params, a: Sequence[int], b: Sequence[int], n: Sequence[int], st: Stream) -> List[int]:
+    """BigIntChip::sub_mod, big_integer/chip.rs:495-528."""
+    subed1, is_overflowed1 = sub_fresh(p, a, b, st)       # :506
+    subed2, is_overflowed2 = sub_fresh(p, n, subed1, st)  # :509
+    if is_overflowed2 != 0:                                 # :510 assert_zero (fails e.g. when a == b: n - 0 <= ... see tests)
+        raise ValueError("sub_mod: n <= |a - b| (chip.rs:510)")
+    num_limbs = len(subed2)
+    subed1 = list(subed1) + [0] * (num_limbs - len(subed1))
+    res = []
+    for i in range(num_limbs):                            # :516-521 select(subed2, subed1, is_overflowed1)
+        v = subed2[i] if is_overflowed1 else subed1[i]
+        st.put(v, p.LB)
+        res.append(v)
+    assert all(v == 0 for v in res[len(n):])
+    return res[:len(n)]
+
+
+def is_less_than_or_equal(p, a, b, st):
+    """big_integer/chip.rs:932-941."""
+    _, ov = sub_fresh(p, a, b, st)
+    return ov
+
+
+def is_greater_than(p, a, b, st):
+    """big_integer/chip.rs:954-963."""
+    le = is_less_than_or_equal(p, a, b, st)
+    st.put(1 - le, 1)
+    return 1 - le
+
+
+def is_greater_than_or_equal(p, a, b, st):
+    """big_integer/chip.rs:976-985."""
+    lt = is_less_than(p, a, b, st)
+    st.put(1 - lt, 1)
+    return 1 - lt
+
+
+FRESH_OPS = ("add", "sub", "add_mod", "sub_mod", "is_zero", "is_equal_fresh", "is_less_than", "is_less_than_or_equal",
+             "is_greater_than", "is_greater_than_or_equal", "is_in_field")
+
+
+def fresh_op(p: Params, op: str, a, b, n, st: Stream):
+    """Dispatch used by the tests: returns (value limbs or None, flag or None)."""
+    if op == "add":
+        return add_fresh(p, a, b, st), None
+    if op == "sub":
+        v, ov = sub_fresh(p, a, b, st)
+        return v, ov
+    if op == "add_mod":
+        return add_mod(p, a, b, n, st), None
+    if op == "sub_mod":
+        return sub_mod(p, a, b, n, st), None
+    if op == "is_zero":
+        return None, is_zero(p, a, st)
+    if op == "is_equal_fresh":
+        return None, is_equal_fresh(p, a, b, st)
+    if op in ("is_less_than", "is_in_field"):
+        return None, is_less_than(p, a, b, st)
+    if op == "is_less_than_or_equal":
+        return None, is_less_than_or_equal(p, a, b, st)
+    if op == "is_greater_than":
+        return None, is_greater_than(p, a, b, st)
+    if op == "is_greater_than_or_equal":
+        return None, is_greater_than_or_equal(p, a, b, st)
+    raise ValueError(op)
+
+
 PKCS1_PREFIX_64_1 = 217300885422736416   # src/chip.rs:150
 PKCS1_PREFIX_64_2 = 938447882527703397   # src/chip.rs:152
 PKCS1_PREFIX_32 = 3158320                # src/chip.rs:175

@@ -142,3 +142,22 @@ class Oracle:
 def e_bytes(e):
     """e.to_bytes_le() (reference big_integer/chip.rs:719-720); BigUint zero is one zero byte."""
     return int(e).to_bytes(max(1, (int(e).bit_length() + 7) // 8), "little")
+
+
+FRESH_OPS = ["add", "sub", "add_mod", "sub_mod", "is_zero", "is_equal_fresh", "is_less_than", "is_less_than_or_equal",
+             "is_greater_than", "is_greater_than_or_equal", "is_in_field"]
+
+
+def fresh_op(o, name, a, b, n):
+    """Oracle for the Fresh-integer family: returns (rc, value limbs, flag, stream)."""
+    lib().h2ro_fresh_op_stream_bytes.restype = ctypes.c_uint64
+    k = FRESH_OPS.index(name)
+    nb = int(lib().h2ro_fresh_op_stream_bytes(ctypes.byref(o.p), k))
+    st = np.zeros(nb, dtype=np.uint8)
+    vout = np.zeros(o.L + 4, dtype=o.dtype)
+    nv, fl = ctypes.c_uint32(0), ctypes.c_int(-1)
+    rc = lib().h2ro_fresh_op(ctypes.byref(o.p), k, _ptr(np.ascontiguousarray(a, o.dtype)),
+                             _ptr(np.ascontiguousarray(b, o.dtype)) if b is not None else None,
+                             _ptr(np.ascontiguousarray(n, o.dtype)) if n is not None else None, _ptr(st), _ptr(vout),
+                             ctypes.byref(nv), ctypes.byref(fl))
+    return rc, vout[:nv.value].copy(), fl.value, st

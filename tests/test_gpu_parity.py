@@ -551,3 +551,55 @@ def test_assign_integer_range_check_sublimbs(H, w, L):
         for k in range(L):
             limb = (v >> (w * k)) & ((1 << w) - 1)
             assert [int(x) for x in sub[i, k]] == [(limb >> (sb * t)) & ((1 << sb) - 1) for t in range(8)]
+
+
+@pytest.mark.parametrize("w,L", [(64, 32), (32, 128), (64, 16)])
+def test_fresh_integer_family(H, w, L):
+    """BigIntInstructions add / sub / add_mod / sub_mod / is_zero / is_equal_fresh / comparisons / is_in_field
+    (reference big_integer/chip.rs:245-373, 452-528, 754-805, 908-1006; tests :1470-1660, 2395-2800):
+    values, predicate bits and the whole op-trace vs the oracle, incl. the a+b == n and a == b corner cases."""
+    from oracle_lib import FRESH_OPS, fresh_op
+    chip = H.BigIntChip(w, w * L)
+    o = Oracle(w, L)
+    rng = random.Random(5 * w + L)
+    bits = w * L
+    n = rand_modulus(rng, bits)
+    A = [rng.randrange(n) for _ in range(10)]
+    B = [rng.randrange(n) for _ in range(10)]
+    B[0] = n - A[0]          # a + b == n
+    B[1] = A[1]              # a == b
+    A[2] = 0                 # zero
+    A[3], B[3] = n - 1, n - 1
+    A[4], B[4] = 1, 0
+    a_dev, b_dev, n_dev = chip.assign_integer(A), chip.assign_integer(B), chip.assign_integer([n])
+    for name in FRESH_OPS:
+        fn = getattr(chip, name)
+        if name in ("add_mod", "sub_mod"):
+            res = fn(a_dev, b_dev, n_dev)
+        elif name == "is_zero":
+            res = fn(a_dev)
+        else:
+            res = fn(a_dev, b_dev)
+        torch.cuda.synchronize()
+        st = res.status.cpu().tolist()
+        fl = res.flag.cpu().tolist()
+        vals = res.value.to_big_uint() if res.value is not None else None
+        for i in range(10):
+            rc, ov, of, ost = fresh_op(o, name, o.limbs(A[i]), o.limbs(B[i]), o.limbs(n))
+            if rc != 0:
+                assert st[i] != 0, (name, i)
+                continue
+            assert st[i] == 0, (name, i, st[i])
+            assert np.array_equal(res.flatten(i), ost), (name, i)
+            if vals is not None:
+                assert vals[i] == o.to_int(ov), (name, i)
+            if of >= 0:
+                assert fl[i] == of, (name, i)
+        if name == "add_mod":
+            assert vals[5] == (A[5] + B[5]) % n and vals[0] == n          # un-reduced when a + b == n (as in the reference)
+        if name == "sub_mod":
+            assert vals[5] == (A[5] - B[5]) % n and vals[1] == n          # sub_mod(a, a, n) == n (as in the reference)
+        if name == "is_less_than":
+            assert fl == [int(A[i] < B[i]) for i in range(10)]
+        if name == "is_greater_than_or_equal":
+            assert fl == [int(A[i] >= B[i]) for i in range(10)]

@@ -166,3 +166,34 @@ def test_batch_driver_matches_single():
         rc, o1, s1 = o.pow_mod_fixed_exp(x[i], n[i], 65537)
         assert np.array_equal(o1, out[i]) and np.array_equal(s1, st[i])
         assert o.to_int(out[i]) == pow(xs[i], 65537, ns[i])
+
+
+@pytest.mark.parametrize("w,L", [(64, 4), (64, 32), (32, 8), (32, 128)])
+def test_fresh_family_c_oracle_equals_python(w, L):
+    """add / sub / add_mod / sub_mod / comparisons -- C restatement == Python restatement,
+    and the predicates / values agree with plain integer arithmetic (incl. the reference's a+b == n quirk)."""
+    from oracle_lib import FRESH_OPS, fresh_op
+    assert list(R.FRESH_OPS) == FRESH_OPS
+    o, p = Oracle(w, L), R.Params(w, L)
+    rng = random.Random(77 * w + L)
+    bits = w * L
+    n = rng.getrandbits(bits) | (1 << (bits - 1))
+    for t in range(8):
+        a, b = rng.randrange(n), rng.randrange(n)
+        if t == 0:
+            b = n - a
+        if t == 1:
+            b = a
+        if t == 2:
+            a = 0
+        for name in FRESH_OPS:
+            st = R.Stream()
+            val, fl = R.fresh_op(p, name, R.to_limbs(a, L, w), R.to_limbs(b, L, w), R.to_limbs(n, L, w), st)
+            rc, ov, of, ost = fresh_op(o, name, o.limbs(a), o.limbs(b), o.limbs(n))
+            assert rc == 0 and bytes(ost) == st.bytes(), (name, t)
+            if val is not None:
+                assert [int(x) for x in ov] == val
+            if fl is not None:
+                assert of == fl
+        assert R.from_limbs(R.fresh_op(p, "add", R.to_limbs(a, L, w), R.to_limbs(b, L, w), None, R.Stream())[0], w) == a + b
+        assert R.fresh_op(p, "is_less_than", R.to_limbs(a, L, w), R.to_limbs(b, L, w), None, R.Stream())[1] == int(a < b)
