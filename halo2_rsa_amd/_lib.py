@@ -64,6 +64,8 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_modpow_public_key_batch", "h2r_pipeline_create", "h2r_pipeline_destroy",
            "h2r_pipeline_modpow_public_key", "h2r_pipeline_join", "h2r_verify_layout_fixed", "h2r_verify_pkcs1v15_batch",
            "h2r_verify_trace_flatten", "h2r_fresh_op_layout", "h2r_fresh_op_batch", "h2r_fresh_op_flatten",
+           "h2r_mul_stream_bytes", "h2r_is_equal_muled_stream_bytes", "h2r_refresh_stream_bytes", "h2r_mul_batch",
+           "h2r_mul_trace_flatten", "h2r_is_equal_muled_batch", "h2r_is_equal_muled_flatten", "h2r_refresh_batch",
            "h2r_range_decompose_batch", "h2r_hist_len", "h2r_trace_lookup_hist", "h2r_lookups_per_record",
            "h2r_trace_lookup_permutation",
            "h2r_trace_flatten", "h2r_pow_trace_flatten", "h2r_profile_enable", "h2r_profile_read", "h2r_status_str",
@@ -118,6 +120,14 @@ def lib():
     L.h2r_fresh_op_layout.argtypes = [vp, u32, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u32)]
     L.h2r_fresh_op_batch.argtypes = [vp, u32, vp, vp, vp, u64, u32, vp, vp, vp, vp, vp]
     L.h2r_fresh_op_flatten.argtypes = [vp, u32, vp, vp]
+    for nm in ("h2r_mul_stream_bytes", "h2r_is_equal_muled_stream_bytes", "h2r_refresh_stream_bytes"):
+        getattr(L, nm).argtypes = [vp]
+        getattr(L, nm).restype = u64
+    L.h2r_mul_batch.argtypes = [vp, vp, vp, u64, vp, vp, vp]
+    L.h2r_mul_trace_flatten.argtypes = [vp, vp, vp]
+    L.h2r_is_equal_muled_batch.argtypes = [vp, vp, vp, u64, vp, vp, vp]
+    L.h2r_is_equal_muled_flatten.argtypes = [vp, vp, vp]
+    L.h2r_refresh_batch.argtypes = [vp, vp, u64, vp, vp, vp, vp]
     L.h2r_range_decompose_batch.argtypes = [vp, vp, u32, u64, u32, u32, vp, u32, vp, vp]
     L.h2r_hist_len.argtypes = [vp]
     L.h2r_hist_len.restype = u32

@@ -329,6 +329,47 @@ class BigIntChip:
         """big_integer/chip.rs:998-1006."""
         return self._fresh_op("is_in_field", a, n, None)
 
+    # ---- Muled integers: mul / square / is_equal_muled / refresh ----------------------------------------
+    def mul(self, a: AssignedInteger, b: AssignedInteger) -> "MuledResult":
+        """big_integer/chip.rs:386-419 -> AssignedInteger<Muled> (2L-1 un-carried columns) + the accumulator trace."""
+        batch, dev = a.batch, a.limbs_dev.device
+        trace = torch.empty(batch * self.layout.record_stride, dtype=torch.uint8, device=dev)
+        cols = torch.zeros((batch, 2 * self.num_limbs, 4), dtype=torch.int64, device=dev)
+        check(lib().h2r_mul_batch(self._ctx, a.data_ptr(), b.data_ptr(), batch, trace.data_ptr(), cols.data_ptr(), self._stream()), "mul")
+        return MuledResult(cols, trace, self)
+
+    def square(self, a: AssignedInteger) -> "MuledResult":
+        """big_integer/chip.rs:431-437."""
+        return self.mul(a, a)
+
+    def is_equal_muled(self, a: "MuledResult", b: "MuledResult"):
+        """big_integer/chip.rs:822-895 (num_limbs_l = num_limbs_r = num_limbs) -> (eq bits uint8[batch], trace tensor)."""
+        batch, dev = a.cols.shape[0], a.cols.device
+        trace = torch.empty(batch * self.layout.record_stride, dtype=torch.uint8, device=dev)
+        eq = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        check(lib().h2r_is_equal_muled_batch(self._ctx, a.cols.data_ptr(), b.cols.data_ptr(), batch, trace.data_ptr(), eq.data_ptr(),
+                                             self._stream()), "is_equal_muled")
+        return eq, trace
+
+    def flatten_is_equal_muled(self, trace: torch.Tensor, elem: int) -> np.ndarray:
+        rs = self.layout.record_stride
+        host = np.ascontiguousarray(trace[elem * rs:(elem + 1) * rs].cpu().numpy())
+        out = np.zeros(int(lib().h2r_is_equal_muled_stream_bytes(self._ctx)), dtype=np.uint8)
+        check(lib().h2r_is_equal_muled_flatten(self._ctx, host.ctypes.data, out.ctypes.data), "h2r_is_equal_muled_flatten")
+        return out
+
+    def refresh(self, a: "MuledResult"):
+        """big_integer/chip.rs:168-233 with RefreshAux::new(limb_width, L, L) -> (Fresh 2L limbs, stream tensor, status)."""
+        batch, dev = a.cols.shape[0], a.cols.device
+        sb = int(lib().h2r_refresh_stream_bytes(self._ctx))
+        stride = (sb + 255) // 256 * 256
+        trace = torch.zeros(batch * stride, dtype=torch.uint8, device=dev)
+        fresh = torch.zeros((batch, 2 * self.num_limbs), dtype=self.torch_dtype, device=dev)
+        status = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        check(lib().h2r_refresh_batch(self._ctx, a.cols.data_ptr(), batch, trace.data_ptr(), fresh.data_ptr(), status.data_ptr(),
+                                      self._stream()), "refresh")
+        return AssignedInteger(fresh, self.limb_width), trace.view(batch, stride)[:, :sb], status
+
     def pipeline(self) -> "Pipeline":
         """Opt-in two-stream pipeline (h2r_pipeline_*): consecutive modpow batches overlap chain and trace."""
         return Pipeline(self)
@@ -383,4 +424,23 @@ class FreshResult:
         host = np.ascontiguousarray(self.trace[elem * self.elem_stride:(elem + 1) * self.elem_stride].cpu().numpy())
         out = np.zeros(self.stream_bytes, dtype=np.uint8)
         check(lib().h2r_fresh_op_flatten(self.chip._ctx, self.op, host.ctypes.data, out.ctypes.data), "h2r_fresh_op_flatten")
+        return out
+
+
+@dataclass
+class MuledResult:
+    """AssignedInteger<Muled>: [batch, 2L, 4] int64 (256-bit little-endian un-carried columns) + the mul trace."""
+    cols: torch.Tensor
+    trace: torch.Tensor
+    chip: BigIntChip
+
+    def columns(self, elem: int) -> List[int]:
+        h = self.cols[elem].cpu().numpy().view(np.uint64)
+        return [sum(int(h[c, k]) << (64 * k) for k in range(4)) for c in range(2 * self.chip.num_limbs - 1)]
+
+    def flatten(self, elem: int) -> np.ndarray:
+        rs = self.chip.layout.record_stride
+        host = np.ascontiguousarray(self.trace[elem * rs:(elem + 1) * rs].cpu().numpy())
+        out = np.zeros(int(lib().h2r_mul_stream_bytes(self.chip._ctx)), dtype=np.uint8)
+        check(lib().h2r_mul_trace_flatten(self.chip._ctx, host.ctypes.data, out.ctypes.data), "h2r_mul_trace_flatten")
         return out

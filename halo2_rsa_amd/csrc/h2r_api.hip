@@ -70,6 +70,8 @@ struct h2r_ctx {
     std::vector<u8> const_rec_host;
     // lookup-table row offsets for the multiplicity histogram
     u32 tab0_len, tab1_off, tab1_len, tab2_off, tab2_len, hist_len;
+    // RefreshAux::new(w, L, L).increased_limbs_vec (host copy and device copy)
+    u8 refresh_inc[2 * 128 + 8]; u32 refresh_nf; u8 *refresh_inc_dev;
 };
 
 namespace {
@@ -299,6 +301,9 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
     h2r_ctx *c = new (std::nothrow) h2r_ctx();
     if (!c) return H2R_E_HIP;
     c->params = *params; c->L = L; c->K = params->bits_len / 32; c->word_max = wm; c->const_rec_dev = nullptr;
+    c->refresh_inc_dev = nullptr;
+    std::memset(c->refresh_inc, 0, sizeof c->refresh_inc);
+    c->refresh_nf = (L <= 128) ? refresh_aux_increased_limbs(w, L, c->refresh_inc) : 0;
     layout_compute(w, L, &c->layout);
     build_const_record(c);
     // histogram rows: composition table of the limb sub-limbs, then of the carry sub-limbs when its width
@@ -316,8 +321,11 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
     }
     if (!hip_ok(hipSetDevice(params->device), "hipSetDevice") ||
         !hip_ok(hipMalloc(reinterpret_cast<void **>(&c->const_rec_dev), lo.record_stride), "hipMalloc(const record)") ||
-        !hip_ok(hipMemcpy(c->const_rec_dev, c->const_rec_host.data(), lo.record_stride, hipMemcpyHostToDevice), "hipMemcpy(const record)")) {
+        !hip_ok(hipMemcpy(c->const_rec_dev, c->const_rec_host.data(), lo.record_stride, hipMemcpyHostToDevice), "hipMemcpy(const record)") ||
+        !hip_ok(hipMalloc(reinterpret_cast<void **>(&c->refresh_inc_dev), sizeof c->refresh_inc), "hipMalloc(refresh aux)") ||
+        !hip_ok(hipMemcpy(c->refresh_inc_dev, c->refresh_inc, sizeof c->refresh_inc, hipMemcpyHostToDevice), "hipMemcpy(refresh aux)")) {
         if (c->const_rec_dev) (void)hipFree(c->const_rec_dev);
+        if (c->refresh_inc_dev) (void)hipFree(c->refresh_inc_dev);
         delete c;
         return H2R_E_HIP;
     }
@@ -328,6 +336,7 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
 void h2r_ctx_destroy(h2r_ctx *ctx) {
     if (!ctx) return;
     if (ctx->const_rec_dev) { (void)hipSetDevice(ctx->params.device); (void)hipFree(ctx->const_rec_dev); }
+    if (ctx->refresh_inc_dev) (void)hipFree(ctx->refresh_inc_dev);
     delete ctx;
 }
 
@@ -721,48 +730,136 @@ inline void emit_plane(Out &o, const h2r_layout &lo, const u8 *rec, int pl, u64 
 }
 }  // namespace
 
-int32_t h2r_trace_flatten(const h2r_ctx *ctx, const void *record_host, void *stream_out) {
-    if (!ctx || !record_host || !stream_out) return H2R_E_NULL;
-    const h2r_layout &lo = ctx->layout;
-    const u8 *rec = static_cast<const u8 *>(record_host);
+// parts: 1 = q/r limbs + sub-limbs (T1, T2), 2 = mul(a,b) accumulators (T3), 4 = mul(q,n) accumulators (T4),
+//        8 = eq_b (T5), 16 = is_equal_muled steps (T6)
+static u8 *flatten_parts(const h2r_layout &lo, const u8 *rec, u8 *outp, u32 parts) {
     const u32 L = lo.num_limbs, C = lo.num_cols;
-    Out o{static_cast<u8 *>(stream_out)};
-    // T1/T2: q then r, each limb followed by its sub-limbs (chip.rs:588-599)
-    for (int which = 0; which < 2; ++which)
-        for (u32 k = 0; k < L; ++k) {
-            emit_plane(o, lo, rec, which ? H2R_PL_R : H2R_PL_Q, k, lo.limb_bytes);
-            emit_plane(o, lo, rec, which ? H2R_PL_R_SUB : H2R_PL_Q_SUB, k, lo.limb_nsub);
-        }
+    Out o{outp};
+    if (parts & 1)   // T1/T2: q then r, each limb followed by its sub-limbs (chip.rs:588-599)
+        for (int which = 0; which < 2; ++which)
+            for (u32 k = 0; k < L; ++k) {
+                emit_plane(o, lo, rec, which ? H2R_PL_R : H2R_PL_Q, k, lo.limb_bytes);
+                emit_plane(o, lo, rec, which ? H2R_PL_R_SUB : H2R_PL_Q_SUB, k, lo.limb_nsub);
+            }
     // T3/T4: mul(a,b) then mul(q,n): column i ascending, j ascending (chip.rs:400-412)
-    for (int which = 0; which < 2; ++which)
+    for (int which = 0; which < 2; ++which) {
+        if (!(parts & (which ? 4u : 2u))) continue;
         for (u32 i = 0; i < C; ++i) {
             u32 j = (L >= i + 1) ? 0 : i + 1 - L;
             for (; j < L && j <= i; ++j) emit_acc(o, lo, rec, which ? H2R_PL_QN_LO : H2R_PL_AB_LO, j, i % L);
         }
-    // T5: eq_b[i] = qn[i] + r[i], i < L (chip.rs:617)
-    for (u32 i = 0; i < L; ++i) emit_wide(o, lo, rec, H2R_PL_EQB_LO, i);
-    // T6: is_equal_muled steps (chip.rs:857-893)
-    for (u32 i = 0; i < C; ++i) {
-        emit_wide(o, lo, rec, H2R_PL_AMB_LO, i);
-        emit_wide(o, lo, rec, H2R_PL_SUM_LO, i);
-        emit_plane(o, lo, rec, H2R_PL_CARRY, i, lo.carry_bytes);
-        emit_plane(o, lo, rec, H2R_PL_CMOD, i, lo.limb_bytes);
-        emit_wide(o, lo, rec, H2R_PL_NQ1_LO, i);
-        emit_plane(o, lo, rec, H2R_PL_AMNQ1, i, lo.limb_bytes);
-        emit_wide(o, lo, rec, H2R_PL_ACCX_LO, i);
-        emit_plane(o, lo, rec, H2R_PL_QACC, i, lo.carry_bytes);
-        emit_plane(o, lo, rec, H2R_PL_MODACC, i, lo.limb_bytes);
-        emit_wide(o, lo, rec, H2R_PL_NQ2_LO, i);
-        emit_plane(o, lo, rec, H2R_PL_AMNQ2, i, lo.limb_bytes);
-        const u8 *fl = rec + lo.plane_off[H2R_PL_FLAGS] + (u64)i * 4;
-        emit(o, fl, 2);
-        if (i < C - 1) {
-            emit_plane(o, lo, rec, H2R_PL_CARRY_DUP, i, lo.carry_bytes);
-            emit_plane(o, lo, rec, H2R_PL_CARRY_SUB, i, lo.carry_nsub);
-        }
-        emit(o, fl + 2, 2);
     }
-    if ((u64)(o.p - static_cast<u8 *>(stream_out)) != lo.stream_bytes) return H2R_E_SHAPE;
+    if (parts & 8)   // T5: eq_b[i] = qn[i] + r[i], i < L (chip.rs:617)
+        for (u32 i = 0; i < L; ++i) emit_wide(o, lo, rec, H2R_PL_EQB_LO, i);
+    if (parts & 16)  // T6: is_equal_muled steps (chip.rs:857-893)
+        for (u32 i = 0; i < C; ++i) {
+            emit_wide(o, lo, rec, H2R_PL_AMB_LO, i);
+            emit_wide(o, lo, rec, H2R_PL_SUM_LO, i);
+            emit_plane(o, lo, rec, H2R_PL_CARRY, i, lo.carry_bytes);
+            emit_plane(o, lo, rec, H2R_PL_CMOD, i, lo.limb_bytes);
+            emit_wide(o, lo, rec, H2R_PL_NQ1_LO, i);
+            emit_plane(o, lo, rec, H2R_PL_AMNQ1, i, lo.limb_bytes);
+            emit_wide(o, lo, rec, H2R_PL_ACCX_LO, i);
+            emit_plane(o, lo, rec, H2R_PL_QACC, i, lo.carry_bytes);
+            emit_plane(o, lo, rec, H2R_PL_MODACC, i, lo.limb_bytes);
+            emit_wide(o, lo, rec, H2R_PL_NQ2_LO, i);
+            emit_plane(o, lo, rec, H2R_PL_AMNQ2, i, lo.limb_bytes);
+            const u8 *fl = rec + lo.plane_off[H2R_PL_FLAGS] + (u64)i * 4;
+            emit(o, fl, 2);
+            if (i < C - 1) {
+                emit_plane(o, lo, rec, H2R_PL_CARRY_DUP, i, lo.carry_bytes);
+                emit_plane(o, lo, rec, H2R_PL_CARRY_SUB, i, lo.carry_nsub);
+            }
+            emit(o, fl + 2, 2);
+        }
+    return o.p;
+}
+
+int32_t h2r_trace_flatten(const h2r_ctx *ctx, const void *record_host, void *stream_out) {
+    if (!ctx || !record_host || !stream_out) return H2R_E_NULL;
+    const h2r_layout &lo = ctx->layout;
+    u8 *end = flatten_parts(lo, static_cast<const u8 *>(record_host), static_cast<u8 *>(stream_out), 31);
+    if ((u64)(end - static_cast<u8 *>(stream_out)) != lo.stream_bytes) return H2R_E_SHAPE;
+    return H2R_OK;
+}
+
+// ---- BigIntInstructions::mul / square, is_equal_muled, refresh -----------------
+uint64_t h2r_mul_stream_bytes(const h2r_ctx *ctx) { return ctx ? (u64)ctx->L * ctx->L * ctx->layout.wide_bytes : 0; }
+uint64_t h2r_is_equal_muled_stream_bytes(const h2r_ctx *ctx) {
+    if (!ctx) return 0;
+    const h2r_layout &lo = ctx->layout;
+    return (u64)lo.num_cols * (5ull * lo.wide_bytes + 2ull * lo.carry_bytes + 4ull * lo.limb_bytes + 4) +
+           (u64)(lo.num_cols - 1) * (lo.carry_bytes + lo.carry_nsub);
+}
+uint64_t h2r_refresh_stream_bytes(const h2r_ctx *ctx) {
+    if (!ctx) return 0;
+    const h2r_layout &lo = ctx->layout;
+    u64 b = 0;
+    for (u32 i = 0; i < ctx->refresh_nf; ++i)
+        b += (u64)(ctx->refresh_inc[i] + 1) * (lo.carry_bytes + lo.limb_bytes + lo.wide_bytes + lo.limb_bytes) + (u64)ctx->refresh_inc[i] * lo.wide_bytes;
+    return b + (u64)ctx->refresh_nf * (lo.limb_bytes + lo.limb_nsub);
+}
+
+int32_t h2r_mul_batch(const h2r_ctx *ctx, const void *a, const void *b, uint64_t batch, void *trace, uint64_t *muled_out,
+                      h2r_stream_t stream) {
+    if (!ctx || !a || !b || !trace || !muled_out) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    if (batch == 0) return H2R_OK;
+    if (batch >= (1ull << 32)) return H2R_E_UNSUPPORTED;
+    TraceArgs ta;
+    fill_trace_args(ctx, ta);
+    ta.mode = TRACE_MUL; ta.opA = a; ta.opB = b; ta.n_items = batch; ta.T = 1;
+    ta.trace = static_cast<u8 *>(trace); ta.elem_stride = ctx->layout.record_stride; ta.off_records = 0;
+    ta.muled_out = muled_out;
+    HIP_TRY(hipSetDevice(ctx->params.device));
+    ProfScope ps(H2R_KERNEL_TRACE, static_cast<hipStream_t>(stream));
+    HIP_TRY(launch_trace(ctx->layout.limb_width, ctx->L, ta, static_cast<hipStream_t>(stream)));
+    return H2R_OK;
+}
+int32_t h2r_mul_trace_flatten(const h2r_ctx *ctx, const void *record_host, void *stream_out) {
+    if (!ctx || !record_host || !stream_out) return H2R_E_NULL;
+    flatten_parts(ctx->layout, static_cast<const u8 *>(record_host), static_cast<u8 *>(stream_out), 2);
+    return H2R_OK;
+}
+
+int32_t h2r_is_equal_muled_batch(const h2r_ctx *ctx, const uint64_t *muled_a, const uint64_t *muled_b, uint64_t batch,
+                                 void *trace, uint8_t *eq_out, h2r_stream_t stream) {
+    if (!ctx || !muled_a || !muled_b || !trace) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    if (batch == 0) return H2R_OK;
+    if (batch >= (1ull << 32)) return H2R_E_UNSUPPORTED;
+    TraceArgs ta;
+    fill_trace_args(ctx, ta);
+    ta.mode = TRACE_EQ; ta.n_items = batch; ta.T = 1;
+    ta.trace = static_cast<u8 *>(trace); ta.elem_stride = ctx->layout.record_stride; ta.off_records = 0;
+    ta.muled_a = muled_a; ta.muled_b = muled_b; ta.eq_out = eq_out;
+    HIP_TRY(hipSetDevice(ctx->params.device));
+    ProfScope ps(H2R_KERNEL_TRACE, static_cast<hipStream_t>(stream));
+    HIP_TRY(launch_trace(ctx->layout.limb_width, ctx->L, ta, static_cast<hipStream_t>(stream)));
+    return H2R_OK;
+}
+int32_t h2r_is_equal_muled_flatten(const h2r_ctx *ctx, const void *record_host, void *stream_out) {
+    if (!ctx || !record_host || !stream_out) return H2R_E_NULL;
+    flatten_parts(ctx->layout, static_cast<const u8 *>(record_host), static_cast<u8 *>(stream_out), 16);
+    return H2R_OK;
+}
+
+int32_t h2r_refresh_batch(const h2r_ctx *ctx, const uint64_t *muled, uint64_t batch, void *trace, void *fresh_out,
+                          uint8_t *status, h2r_stream_t stream) {
+    if (!ctx || !muled || !trace || !status) return H2R_E_NULL;
+    if (ctx->params.device < 0 || ctx->refresh_nf == 0) return H2R_E_UNSUPPORTED;
+    if (batch == 0) return H2R_OK;
+    RefreshArgs ra;
+    std::memset(&ra, 0, sizeof ra);
+    ra.muled = muled; ra.batch = batch; ra.L = ctx->L; ra.nf = ctx->refresh_nf; ra.inc = ctx->refresh_inc_dev;
+    ra.trace = static_cast<u8 *>(trace); ra.elem_stride = round_up(h2r_refresh_stream_bytes(ctx), 256);
+    ra.fresh_out = fresh_out; ra.status = status; ra.WB = ctx->layout.wide_bytes; ra.CB = ctx->layout.carry_bytes;
+    HIP_TRY(hipSetDevice(ctx->params.device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope ps(H2R_KERNEL_AUX, st);
+    if (ctx->layout.limb_width == 64) hipLaunchKernelGGL((refresh_kernel<64>), dim3((unsigned)batch), dim3(64), 0, st, ra);
+    else hipLaunchKernelGGL((refresh_kernel<32>), dim3((unsigned)batch), dim3(64), 0, st, ra);
+    HIP_TRY(hipGetLastError());
     return H2R_OK;
 }
 

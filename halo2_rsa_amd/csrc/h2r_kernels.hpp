@@ -641,6 +641,8 @@ template <> struct Wide<32> {
     __device__ __forceinline__ u64 hi_word() const { return 0; }
 };
 
+enum { TRACE_FULL = 0, TRACE_MUL = 1, TRACE_EQ = 2 };
+
 struct TraceArgs {
     const void *opA, *opB, *opQ, *opR;  // [item][L] limbs
     const void *n;                      // [elem][L] limbs
@@ -655,6 +657,10 @@ struct TraceArgs {
     u32 ablate;                         // timing experiments only (H2R_ABLATE); 0 in production
     u32 dyn_lds;                        // extra dynamic LDS per block: caps residency (pipeline co-scheduling)
     u32 prio;                           // raise wave priority (pipeline co-scheduling)
+    u32 mode;                           // TRACE_FULL (mul_mod), TRACE_MUL (BigIntChip::mul only), TRACE_EQ (is_equal_muled only)
+    const u64 *muled_a, *muled_b;       // TRACE_EQ inputs: [item][2L] x 4 u64 (256-bit columns)
+    u64 *muled_out;                     // TRACE_MUL output, same format
+    u8 *eq_out;                         // TRACE_EQ: final eq_bit per item
 };
 
 template <int LW, int L>
@@ -775,8 +781,14 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
     // wave-local, so waves of a block run independently.
     auto item_sync = [&]() { if constexpr (TPI <= 64) wave_sync(); else __syncthreads(); };
 
+    const u32 mode = args.mode;
+    const bool prod = live && mode != TRACE_EQ && (mode == TRACE_FULL || h == 0);   // this thread runs a product column
     // ---- stage operands in LDS; emit q, r and their sub-limbs (chip.rs:588-599) -------------------
-    if (live) {
+    if (live && mode == TRACE_MUL && h == 0) {   // BigIntChip::mul(a, b) alone: only the a*b half is active
+        s.A[0][i] = reinterpret_cast<const limb_t *>(args.opA)[(u64)item * L + i];
+        s.B[0][i] = reinterpret_cast<const limb_t *>(args.opB)[(u64)item * L + i];
+    }
+    if (live && mode == TRACE_FULL) {
         const limb_t *gQ = reinterpret_cast<const limb_t *>(args.opQ) + (u64)item * L;
         const limb_t *gA = h == 0 ? reinterpret_cast<const limb_t *>(args.opA) + (u64)item * L : gQ;
         const limb_t *gB = h == 0 ? reinterpret_cast<const limb_t *>(args.opB) + (u64)item * L
@@ -796,7 +808,7 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
     // A[s] * B[(i-s) mod L], so every product a[j]*b[k] is visited once, in ascending j per column.
     ColAcc<LW> acc, first;
     acc.clear(); first.clear();
-    if (live && !(args.ablate & 2)) {
+    if (prod && !(args.ablate & 2)) {
         u8 *plo = rec + off[h == 0 ? H2R_PL_AB_LO : H2R_PL_QN_LO] + (u64)i * 16;
         u8 *phi = rec + off[h == 0 ? H2R_PL_AB_HI : H2R_PL_QN_HI] + (u64)i * 16;
         const limb_t *Ah = s.A[h], *Bh = s.B[h];
@@ -820,6 +832,13 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
         }
         // final columns -> LDS; eq_b[i] = qn[i] + r[i] for i < L (chip.rs:614-623)
         W fw = first.wide();
+        if (mode == TRACE_MUL) {   // hand the un-carried columns to the caller (AssignedInteger<Muled>)
+            u64 *mo = args.muled_out + (u64)item * (2 * L) * 4;
+            mo[4 * i] = first.lo0(); mo[4 * i + 1] = first.lo1(); mo[4 * i + 2] = first.hi64(); mo[4 * i + 3] = 0;
+            const bool has2 = i < L - 1;
+            mo[4 * (i + L)] = has2 ? acc.lo0() : 0; mo[4 * (i + L) + 1] = has2 ? acc.lo1() : 0;
+            mo[4 * (i + L) + 2] = has2 ? acc.hi64() : 0; mo[4 * (i + L) + 3] = 0;
+        }
         if (h == 1) {
             fw = fw + W::from((u128)s.r[i]);
             store_wide<LW>(rec, off, H2R_PL_EQB_LO, i, fw);
@@ -832,7 +851,7 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
         }
     }
     item_sync();
-    if (args.ablate & 1) return;
+    if ((args.ablate & 1) || mode == TRACE_MUL) return;
 
     // ---- BigIntChip::is_equal_muled (chip.rs:822-895): thread t = column c -------------------------
     // Thread 2L-1 has no column; it still stores (zeros) so that every store instruction of this
@@ -845,9 +864,15 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
     u64 dlo = 0; W dhi = W::zero();
     if (col) {
         W A, Bq;
-        A.lo = ((u128)s.c1[0][c] << 64) | s.c0[0][c];
-        Bq.lo = ((u128)s.c1[1][c] << 64) | s.c0[1][c];
-        if constexpr (LW == 64) { A.hi = s.c2[0][c]; Bq.hi = s.c2[1][c]; }
+        if (mode == TRACE_EQ) {   // stand-alone is_equal_muled: the two Muled integers come from the caller
+            const u64 *pa = args.muled_a + ((u64)item * (2 * L) + c) * 4, *pb = args.muled_b + ((u64)item * (2 * L) + c) * 4;
+            A.lo = ((u128)pa[1] << 64) | pa[0]; Bq.lo = ((u128)pb[1] << 64) | pb[0];
+            if constexpr (LW == 64) { A.hi = (u32)pa[2]; Bq.hi = (u32)pb[2]; }
+        } else {
+            A.lo = ((u128)s.c1[0][c] << 64) | s.c0[0][c];
+            Bq.lo = ((u128)s.c1[1][c] << 64) | s.c0[1][c];
+            if constexpr (LW == 64) { A.hi = s.c2[0][c]; Bq.hi = s.c2[1][c]; }
+        }
         a_b = A - Bq;              // :859 (two's complement)
         D = a_b + wm;              // >= 0
         dlo = D.low_limb();
@@ -960,6 +985,7 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
         const u32 e1 = (prev_ok && f1) ? 1u : 0u, e2 = (e1 && f2) ? 1u : 0u;
         const u32 fl = (f1 ? 1u : 0u) | (e1 << 8) | ((f2 ? 1u : 0u) << 16) | (e2 << 24);
         st4(rec + off[H2R_PL_FLAGS] + (u64)c * 4, col ? fl : 0u);
+        if (mode == TRACE_EQ && c == C - 1 && args.eq_out) args.eq_out[item] = (u8)e2;   // is_equal_muled's result bit
     }
 }
 
@@ -1294,6 +1320,75 @@ __global__ __launch_bounds__(64) void fresh_kernel(FreshArgs f) {
         }
     }
     if (lane == 0) { if (f.flag_out) f.flag_out[elem] = (u8)flag; f.status[elem] = (u8)status; }
+}
+
+// BigIntChip::refresh (chip.rs:168-233) with aux = RefreshAux::new(w, L, L): Muled (2L-1 columns) -> Fresh (2L limbs).
+// Off the RSA path: one wave per element, lane 0 walks the second-order carry recurrence and
+// writes the flat stream directly (every field is 4/8-byte aligned, so no section padding is needed).
+struct RefreshArgs {
+    const u64 *muled;     // [elem][2L] x 4 u64
+    u64 batch; u32 L, nf;
+    const u8 *inc;        // increased_limbs_vec (device), nf entries
+    u8 *trace; u64 elem_stride;
+    void *fresh_out;      // [elem][2L] limbs (nullable)
+    u8 *status;
+    u32 WB, CB;
+};
+
+template <int LW>
+__global__ __launch_bounds__(64) void refresh_kernel(RefreshArgs a) {
+    using limb_t = typename LimbT<LW>::type;
+    constexpr u32 LB = LW / 8;
+    __shared__ u64 r0[2 * 128 + 8], r1[2 * 128 + 8]; __shared__ u32 r2[2 * 128 + 8];   // running limbs (3 words)
+    const int lane = threadIdx.x;
+    const u64 elem = blockIdx.x;
+    const u32 C = 2 * a.L - 1, nf = a.nf;
+    for (u32 p = lane; p < nf + 4; p += 64) {
+        const u64 *m = a.muled + (elem * (2 * a.L) + p) * 4;
+        const bool in = p < C;
+        r0[p] = in ? m[0] : 0; r1[p] = in ? m[1] : 0; r2[p] = in ? (u32)m[2] : 0;
+    }
+    wave_sync();
+    int status = H2R_OK;
+    if (lane == 0) {
+        u8 *o = a.trace + elem * a.elem_stride;
+        auto put = [&](u64 w0, u64 w1, u64 w2, u32 nbytes) {   // little-endian value of nbytes (4, 8, 16 or 24)
+            if (nbytes == 4) { st4(o, (u32)w0); } else { st8(o, w0); if (nbytes >= 16) st8(o + 8, w1); if (nbytes >= 24) st8(o + 16, w2); }
+            o += nbytes;
+        };
+        for (u32 i = 0; i < nf; ++i) {
+            u64 l0 = r0[i], l1 = r1[i]; u32 l2 = r2[i];                  // limb = refreshed_limbs[i]  (:197)
+            const u32 reps = (u32)a.inc[i] + 1;
+            for (u32 j = 0; j < reps; ++j) {                             // :198
+                // (q, n) = divmod(limb, 2^w)  (:201 -> :1323-1349)
+                u64 q0, q1, n; u32 q2 = 0;
+                if constexpr (LW == 64) { n = l0; q0 = l1; q1 = l2; }
+                else { n = l0 & 0xffffffffull; q0 = (l0 >> 32) | (l1 << 32); q1 = (l1 >> 32) | ((u64)l2 << 32); }
+                put(q0, q1, 0, a.CB); put(n, 0, 0, LB);
+                // nq = 2^w * q, a - nq = n
+                if constexpr (LW == 64) put(0, q0, q1, a.WB); else put(l0 & ~0xffffffffull, l1, 0, a.WB);
+                put(n, 0, 0, LB);
+                if (j == 0) { r0[i] = n; r1[i] = 0; r2[i] = 0; }          // :204
+                else {                                                   // refreshed_limbs[i+j] += n  (:207)
+                    const u64 t0 = r0[i + j] + n; const u64 c0 = t0 < n ? 1 : 0;
+                    const u64 t1 = r1[i + j] + c0; const u32 c1 = t1 < c0 ? 1u : 0u;
+                    r0[i + j] = t0; r1[i + j] = t1; r2[i + j] += c1;
+                    put(t0, t1, r2[i + j], a.WB);
+                }
+                l0 = q0; l1 = q1; l2 = q2;                               // limb = q
+            }
+            if (l0 | l1 | l2) status = H2R_E_NOT_REDUCED;                // assert_zero(limb), :213
+        }
+        for (u32 i = 0; i < nf; ++i) {                                   // range-assign every refreshed limb, :217-226
+            const u64 v = r0[i];
+            put(v, 0, 0, LB);
+            const u64 sb = limb_sub_bytes<LW>(v);
+            if constexpr (LW == 64) { st8(o, sb); } else { st4(o, (u32)sb); st4(o + 4, (u32)(sb >> 32)); }
+            o += 8;
+            if (a.fresh_out) reinterpret_cast<limb_t *>(a.fresh_out)[elem * nf + i] = (limb_t)v;
+        }
+        a.status[elem] = (u8)status;
+    }
 }
 
 // ================================================================================================

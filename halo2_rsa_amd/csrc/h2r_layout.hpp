@@ -148,6 +148,33 @@ inline void layout_compute(u32 w, u32 L, h2r_layout *o) {
                       (u64)(C - 1) * (CB + o->carry_nsub);
 }
 
+// RefreshAux::new(limb_width, L, L).increased_limbs_vec (big_integer/mod.rs:428-482): how many extra limbs the
+// i-th Muled limb spills into when it is cut into limb_width-bit chunks.  Returns the vector length (2L).
+inline u32 refresh_aux_increased_limbs(u32 w, u32 L, u8 *inc /* >= 2L + 2 entries */) {
+    const u32 d = 2 * L - 1;
+    U256 muled[2 * 128 + 8];
+    u32 len = d;
+    const u64 bm1 = w == 64 ? ~0ull : ((1ull << w) - 1);
+    const u128 sq = (u128)bm1 * bm1;
+    U256 sqv; sqv.v[0] = (u64)sq; sqv.v[1] = (u64)(sq >> 64);
+    for (u32 i = 0; i < d; ++i) {
+        const u32 cnt = (i < L) ? i + 1 : 2 * L - 1 - i;
+        for (u32 k = 0; k < cnt; ++k) muled[i] = muled[i] + sqv;
+    }
+    u32 n = 0;
+    for (u32 cur = 0; cur <= d; ++cur) {
+        if (cur >= len) muled[len++] = U256();
+        const u32 nb = muled[cur].bits();
+        const u32 chunks = nb % w == 0 ? nb / w : nb / w + 1;
+        inc[n++] = (u8)(chunks - 1);
+        U256 t = muled[cur]; u64 ch[8];
+        for (u32 j = 0; j < chunks; ++j) { ch[j] = t.low(w); t = t.shr(w); }
+        muled[cur] = U256();
+        for (u32 j = 0; j < chunks; ++j) { while (len <= cur + j) muled[len++] = U256(); muled[cur + j] = muled[cur + j] + U256::from64(ch[j]); }
+    }
+    return n;
+}
+
 // Exponent helpers: e.to_bytes_le() + Self::bits_size(e) (big_integer/chip.rs:717-728).
 inline u32 exp_num_bits(const u8 *e_le, size_t e_len) {
     while (e_len > 0 && e_le[e_len - 1] == 0) --e_len;

@@ -270,6 +270,29 @@ int32_t h2r_fresh_op_batch(const h2r_ctx *ctx, uint32_t op, const void *a, const
                            uint8_t *status, h2r_stream_t stream);
 int32_t h2r_fresh_op_flatten(const h2r_ctx *ctx, uint32_t op, const void *elem_host, void *stream_out);
 
+/* ---- Muled integers: BigIntInstructions::mul / square, is_equal_muled, refresh ----
+ * A Muled integer (the un-carried product columns, big_integer/mod.rs:216-232) is passed as 2*num_limbs
+ * columns of 4 x uint64_t (256-bit little-endian) per element; column 2*num_limbs-1 is zero.
+ *  h2r_mul_batch            BigIntChip::mul (chip.rs:386-419; square = mul(a, a)): trace = one record per
+ *                           element with only the AB planes written; stream = its L*L accumulators.
+ *  h2r_is_equal_muled_batch BigIntChip::is_equal_muled (chip.rs:822-895, num_limbs_l = num_limbs_r =
+ *                           num_limbs): trace = one record per element with only the per-column planes
+ *                           written; eq_out[elem] = the returned bit (assert_equal_muled = bit must be 1).
+ *  h2r_refresh_batch        BigIntChip::refresh (chip.rs:168-233) with RefreshAux::new(limb_width, L, L)
+ *                           (mod.rs:428-482): 2*num_limbs Fresh limbs; the element trace (stride
+ *                           h2r_refresh_stream_bytes rounded up to 256) IS the flat stream. */
+uint64_t h2r_mul_stream_bytes(const h2r_ctx *ctx);
+uint64_t h2r_is_equal_muled_stream_bytes(const h2r_ctx *ctx);
+uint64_t h2r_refresh_stream_bytes(const h2r_ctx *ctx);
+int32_t h2r_mul_batch(const h2r_ctx *ctx, const void *a, const void *b, uint64_t batch, void *trace,
+                      uint64_t *muled_out, h2r_stream_t stream);
+int32_t h2r_mul_trace_flatten(const h2r_ctx *ctx, const void *record_host, void *stream_out);
+int32_t h2r_is_equal_muled_batch(const h2r_ctx *ctx, const uint64_t *muled_a, const uint64_t *muled_b,
+                                 uint64_t batch, void *trace, uint8_t *eq_out, h2r_stream_t stream);
+int32_t h2r_is_equal_muled_flatten(const h2r_ctx *ctx, const void *record_host, void *stream_out);
+int32_t h2r_refresh_batch(const h2r_ctx *ctx, const uint64_t *muled, uint64_t batch, void *trace,
+                          void *fresh_out, uint8_t *status, h2r_stream_t stream);
+
 /* ---- the lookup range-check batch --------------------------------------------------------------
  * RangeChip::assign(value, sublimb_bits, bit_len) decomposition of `count` values of `value_bytes`
  * bytes each (8 or 16) into ceil(bit_len/sublimb_bits) one-byte sub-limbs (stride sub_stride),

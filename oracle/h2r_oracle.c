@@ -645,6 +645,82 @@ int h2ro_fresh_op(const h2ro_params *p, int op, const void *a, const void *b, co
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * refresh (big_integer/chip.rs:168-233) with RefreshAux::new(w, L, L)
+ * (big_integer/mod.rs:428-482), and stand-alone is_equal_muled (chip.rs:822-895).
+ * Muled integers are passed as 2L-1 values of 4 x u64 (256-bit little-endian).
+ * ---------------------------------------------------------------------------------------------- */
+static unsigned refresh_aux(unsigned w, unsigned L, unsigned *inc) { /* mod.rs:428-482, num_limbs_l = num_limbs_r = L */
+    static __thread u256 muled[2 * MAXL + 4];
+    unsigned d = 2 * L - 1, len = d;
+    uint64_t bm1 = w == 64 ? ~0ull : ((1ull << w) - 1);
+    u256 sq = u256_mul64(bm1, bm1);
+    for (unsigned i = 0; i < d; ++i) {
+        unsigned cnt = (i < L) ? i + 1 : 2 * L - 1 - i;
+        muled[i] = u256_zero();
+        for (unsigned k = 0; k < cnt; ++k) muled[i] = u256_add(muled[i], sq);
+    }
+    unsigned n = 0;
+    for (unsigned cur = 0; cur <= d; ++cur) {                          /* while cur_d <= max_d */
+        if (cur >= len) { muled[len++] = u256_zero(); }
+        unsigned nb = u256_bits(muled[cur]);
+        unsigned chunks = nb % w == 0 ? nb / w : nb / w + 1;
+        inc[n++] = chunks - 1;
+        u256 t = muled[cur]; uint64_t ch[8];
+        for (unsigned j = 0; j < chunks; ++j) { ch[j] = u256_low(t, w); t = u256_shr(t, w); }
+        muled[cur] = u256_zero();
+        for (unsigned j = 0; j < chunks; ++j) {
+            while (len <= cur + j) muled[len++] = u256_zero();
+            muled[cur + j] = u256_add(muled[cur + j], u256_from64(ch[j]));
+        }
+    }
+    return n;
+}
+uint64_t h2ro_refresh_stream_bytes(const h2ro_params *p) {
+    unsigned inc[2 * MAXL + 4]; unsigned n = refresh_aux(p->w, p->L, inc);
+    uint64_t b = 0;
+    for (unsigned i = 0; i < n; ++i) b += (uint64_t)(inc[i] + 1) * (p->CB + p->LB + p->WB + p->LB) + (uint64_t)inc[i] * p->WB;
+    return b + (uint64_t)n * (p->LB + p->limb_nsub);
+}
+int h2ro_refresh(const h2ro_params *p, const uint64_t *muled /* (2L-1) x 4 u64 */, uint8_t *stream, void *fresh_out /* 2L limbs */) {
+    unsigned w = p->w, L = p->L;
+    unsigned inc[2 * MAXL + 4]; unsigned nf = refresh_aux(w, L, inc);
+    static __thread u256 r[2 * MAXL + 8];
+    wr s = {stream};
+    for (unsigned i = 0; i < nf + 4; ++i) r[i] = u256_zero();
+    for (unsigned i = 0; i < 2 * L - 1; ++i) memcpy(&r[i], muled + 4 * i, sizeof(u256));   /* :186-192 */
+    for (unsigned i = 0; i < nf; ++i) {                                  /* :195 */
+        u256 limb = r[i];
+        for (unsigned j = 0; j < inc[i] + 1; ++j) {                      /* :198 */
+            u256 q = u256_shr(limb, w); uint64_t n = u256_low(limb, w);  /* :201 */
+            put256(&s, q, p->CB); put64(&s, n, p->LB);
+            u256 nq = u256_shl(q, w);
+            put256(&s, nq, p->WB); put256(&s, u256_sub(limb, nq), p->LB);
+            if (j == 0) r[i] = u256_from64(n);                           /* :204 */
+            else { r[i + j] = u256_add(r[i + j], u256_from64(n)); put256(&s, r[i + j], p->WB); }   /* :207 */
+            limb = q;
+        }
+        if (u256_bits(limb)) return H2RO_E_NOT_REDUCED;                  /* :213 assert_zero */
+    }
+    for (unsigned i = 0; i < nf; ++i) {                                  /* :217-226 */
+        emit_range_assign(&s, r[i], p->limb_sub_bits, w, p->LB);
+        if (fresh_out) set_limb(fresh_out, i, w, r[i].v[0]);
+    }
+    return H2RO_OK;
+}
+uint64_t h2ro_is_equal_muled_stream_bytes(const h2ro_params *p) {
+    uint64_t C = 2ull * p->L - 1;
+    return C * (5ull * p->WB + 2ull * p->CB + 4ull * p->LB + 4) + (C - 1) * (p->CB + p->carry_nsub);
+}
+int h2ro_is_equal_muled(const h2ro_params *p, const uint64_t *a, const uint64_t *b, uint8_t *stream, int *eq_bit) {
+    static __thread u256 A[2 * MAXL], B[2 * MAXL];
+    for (unsigned i = 0; i < 2 * p->L - 1; ++i) { memcpy(&A[i], a + 4 * i, sizeof(u256)); memcpy(&B[i], b + 4 * i, sizeof(u256)); }
+    wr s = {stream};
+    int e = is_equal_muled(p, A, B, &s);
+    if (eq_bit) *eq_bit = e;
+    return H2RO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * the encoded-message check of RSAChip::verify_pkcs1v15_signature,
  * src/chip.rs:136-198 (LIMB_WIDTH = 64 only, src/chip.rs:203)
  * ---------------------------------------------------------------------------------------------- */

@@ -55,6 +55,11 @@ uint64_t h2ro_fresh_op_stream_bytes(const h2ro_params *p, int op);
 int h2ro_fresh_op(const h2ro_params *p, int op, const void *a, const void *b, const void *n, uint8_t *stream,
                   void *value_out, uint32_t *nvalue, int *flag_out);
 
+uint64_t h2ro_refresh_stream_bytes(const h2ro_params *p);
+int h2ro_refresh(const h2ro_params *p, const uint64_t *muled, uint8_t *stream, void *fresh_out);
+uint64_t h2ro_is_equal_muled_stream_bytes(const h2ro_params *p);
+int h2ro_is_equal_muled(const h2ro_params *p, const uint64_t *a, const uint64_t *b, uint8_t *stream, int *eq_bit);
+
 /* Batch drivers used by the CPU-baseline timing leg: element-major inputs, `nthreads` pthreads,
  * one element per task.  stream (nullable) holds batch*stream_bytes bytes. */
 int h2ro_pow_mod_fixed_exp_batch(const h2ro_params *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len,

@@ -478,6 +478,35 @@ def assert_in_field(p: Params, a: Sequence[int], n: Sequence[int], st: Stream) -
     return is_less_than(p, a, n, st)
 
 
+def refresh(p: Params, a: Sequence[int], st: Stream) -> List[int]:
+    """BigIntChip::refresh, big_integer/chip.rs:168-233, with aux = RefreshAux::new(w, L, L) (mod.rs:428-482).
+    `a` holds the 2L-1 Muled limbs; returns the 2L Fresh limbs."""
+    w, B, L = p.w, p.B, p.L
+    inc = refresh_aux_increased_limbs(w, L, L)
+    assert len(a) == 2 * L - 1                       # :181
+    num_limbs_fresh = len(inc)
+    r = list(a) + [0] * (num_limbs_fresh - len(a))   # :186-192
+    for i in range(num_limbs_fresh):                 # :195
+        limb = r[i]
+        for j in range(inc[i] + 1):                  # :198
+            q, n = divmod(limb, B)                   # :201 div_mod_main_gate :1323-1349
+            st.put(q, p.CB)
+            st.put(n, p.LB)
+            st.put(B * q, p.WB)
+            st.put(limb - B * q, p.LB)
+            if j == 0:
+                r[i] = n                             # :204
+            else:
+                r[i + j] = r[i + j] + n              # :207 main_gate.add
+                st.put(r[i + j], p.WB)
+            limb = q
+        if limb != 0:                                # :213 assert_zero
+            raise OverflowError("refresh: limb does not fit increased_limbs_vec (chip.rs:213)")
+    for i in range(num_limbs_fresh):                 # :217-226
+        emit_range_assign(st, r[i], p.limb_sub_bits, w, p.LB)
+    return r
+
+
 def is_zero(p: Params, a: Sequence[int], st: Stream) -> int:
     """BigIntChip::is_zero, big_integer/chip.rs:754-767."""
     bit = 1

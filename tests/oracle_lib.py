@@ -161,3 +161,34 @@ def fresh_op(o, name, a, b, n):
                              _ptr(np.ascontiguousarray(n, o.dtype)) if n is not None else None, _ptr(st), _ptr(vout),
                              ctypes.byref(nv), ctypes.byref(fl))
     return rc, vout[:nv.value].copy(), fl.value, st
+
+
+def _u256(vals):
+    return np.array([[(int(v) >> (64 * k)) & (2 ** 64 - 1) for k in range(4)] for v in vals], dtype=np.uint64)
+
+
+def refresh(o, cols):
+    """Oracle BigIntChip::refresh of 2L-1 Muled columns -> (rc, 2L fresh limbs, stream)."""
+    lib().h2ro_refresh_stream_bytes.restype = ctypes.c_uint64
+    nb = int(lib().h2ro_refresh_stream_bytes(ctypes.byref(o.p)))
+    st = np.zeros(nb, dtype=np.uint8)
+    out = np.zeros(2 * o.L, dtype=o.dtype)
+    rc = lib().h2ro_refresh(ctypes.byref(o.p), _ptr(_u256(cols)), _ptr(st), _ptr(out))
+    return rc, out, st
+
+
+def is_equal_muled(o, a_cols, b_cols):
+    lib().h2ro_is_equal_muled_stream_bytes.restype = ctypes.c_uint64
+    nb = int(lib().h2ro_is_equal_muled_stream_bytes(ctypes.byref(o.p)))
+    st = np.zeros(nb, dtype=np.uint8)
+    eq = ctypes.c_int(-1)
+    lib().h2ro_is_equal_muled(ctypes.byref(o.p), _ptr(_u256(a_cols)), _ptr(_u256(b_cols)), _ptr(st), ctypes.byref(eq))
+    return eq.value, st
+
+
+def mul_stream(o, a, b):
+    """Oracle BigIntChip::mul: (columns, stream of the L*L partial accumulators)."""
+    st = np.zeros(o.L * o.L * o.p.WB, dtype=np.uint8)
+    cols = np.zeros((2 * o.L - 1, 4), dtype=np.uint64)
+    lib().h2ro_mul_columns(ctypes.byref(o.p), _ptr(np.ascontiguousarray(a, o.dtype)), _ptr(np.ascontiguousarray(b, o.dtype)), _ptr(st), _ptr(cols))
+    return [sum(int(cols[i, k]) << (64 * k) for k in range(4)) for i in range(2 * o.L - 1)], st

@@ -603,3 +603,61 @@ def test_fresh_integer_family(H, w, L):
             assert fl == [int(A[i] < B[i]) for i in range(10)]
         if name == "is_greater_than_or_equal":
             assert fl == [int(A[i] >= B[i]) for i in range(10)]
+
+
+def test_mul_reference_cases_on_gpu(H, golden):
+    """BigIntChip::mul known answers of the reference (big_integer/chip.rs:2797-3107, incl. the 16-limb squaring
+    with all 31 un-carried columns) through h2r_mul_batch."""
+    from oracle_lib import mul_stream
+    chip = H.BigIntChip(64, 2048)
+    o = Oracle(64, 32)
+    cases = golden["mul_cases"]
+    A = [sum(int(x, 16) << (64 * i) for i, x in enumerate(c["a"])) for c in cases]
+    B = [sum(int(x, 16) << (64 * i) for i, x in enumerate(c["b"])) for c in cases]
+    res = chip.mul(chip.assign_integer(A), chip.assign_integer(B))
+    torch.cuda.synchronize()
+    for i, c in enumerate(cases):
+        cols = res.columns(i)
+        want = [int(x) for x in c["cols"]]
+        assert cols[:len(want)] == want and all(v == 0 for v in cols[len(want):]), c["name"]
+        ocols, ost = mul_stream(o, o.limbs(A[i]), o.limbs(B[i]))
+        assert ocols == cols and np.array_equal(res.flatten(i), ost), c["name"]
+
+
+@pytest.mark.parametrize("w,L", [(64, 32), (32, 128), (64, 16)])
+def test_mul_is_equal_muled_refresh(H, w, L):
+    """The reference's Muled-integer tests: ab == ba (test_muled_equal_circuit :1699), a bad twin (:1742), and
+    refresh(ab) == refresh(ba) == a*b as Fresh limbs (test_refresh_circuit :1863-1890)."""
+    from oracle_lib import is_equal_muled, mul_stream, refresh
+    chip = H.BigIntChip(w, w * L)
+    o = Oracle(w, L)
+    rng = random.Random(9 * w + L)
+    bits = w * L
+    A = [rng.getrandbits(bits) for _ in range(6)]
+    B = [rng.getrandbits(bits) for _ in range(6)]
+    A[0] = B[0] = (1 << bits) - 1      # maximal limbs: every column at word_max
+    A[1] = 0
+    a_dev, b_dev = chip.assign_integer(A), chip.assign_integer(B)
+    ab, ba = chip.mul(a_dev, b_dev), chip.mul(b_dev, a_dev)
+    aa = chip.square(a_dev)
+    eq, tr = chip.is_equal_muled(ab, ba)
+    neq, trn = chip.is_equal_muled(ab, aa)           # a*b vs a*a: unequal unless a == b
+    fresh, rstream, rstatus = chip.refresh(ab)
+    torch.cuda.synchronize()
+    assert eq.cpu().tolist() == [1] * 6
+    assert neq.cpu().tolist() == [1 if A[i] * B[i] == A[i] * A[i] else 0 for i in range(6)]
+    assert not rstatus.cpu().numpy().any()
+    fr = fresh.to_big_uint()
+    for i in range(6):
+        assert fr[i] == A[i] * B[i]
+        cols_ab, st_ab = mul_stream(o, o.limbs(A[i]), o.limbs(B[i]))
+        cols_ba, _ = mul_stream(o, o.limbs(B[i]), o.limbs(A[i]))
+        cols_aa, st_aa = mul_stream(o, o.limbs(A[i]), o.limbs(A[i]))
+        assert ab.columns(i) == cols_ab and np.array_equal(ab.flatten(i), st_ab)
+        assert np.array_equal(aa.flatten(i), st_aa)
+        e, est = is_equal_muled(o, cols_ab, cols_ba)
+        assert e == 1 and np.array_equal(chip.flatten_is_equal_muled(tr, i), est), i
+        e, est = is_equal_muled(o, cols_ab, cols_aa)
+        assert e == int(neq[i].item()) and np.array_equal(chip.flatten_is_equal_muled(trn, i), est), i
+        rc, rl, rst = refresh(o, cols_ab)
+        assert rc == 0 and np.array_equal(rstream[i].cpu().numpy(), rst), i

@@ -197,3 +197,30 @@ def test_fresh_family_c_oracle_equals_python(w, L):
                 assert of == fl
         assert R.from_limbs(R.fresh_op(p, "add", R.to_limbs(a, L, w), R.to_limbs(b, L, w), None, R.Stream())[0], w) == a + b
         assert R.fresh_op(p, "is_less_than", R.to_limbs(a, L, w), R.to_limbs(b, L, w), None, R.Stream())[1] == int(a < b)
+
+
+@pytest.mark.parametrize("w,L", [(64, 4), (64, 32), (32, 128)])
+def test_refresh_and_is_equal_muled_c_oracle_equals_python(w, L):
+    """SURVEY 8(f) next #4: refresh (chip.rs:168-233, RefreshAux mod.rs:428-482) and stand-alone is_equal_muled."""
+    from oracle_lib import is_equal_muled, mul_stream, refresh
+    o, p = Oracle(w, L), R.Params(w, L)
+    rng = random.Random(w * L + 1)
+    for t in range(3):
+        a = [rng.getrandbits(w) for _ in range(L)]
+        b = [rng.getrandbits(w) for _ in range(L)]
+        if t == 0:
+            a = b = [(1 << w) - 1] * L
+        cols = R.mul_columns(a, b, None, p.WB)
+        ocols, _ = mul_stream(o, np.array(a, o.dtype), np.array(b, o.dtype))
+        assert ocols == cols
+        st = R.Stream()
+        r = R.refresh(p, cols, st)
+        rc, rl, rst = refresh(o, cols)
+        assert rc == 0 and bytes(rst) == st.bytes() and [int(x) for x in rl] == r
+        assert R.from_limbs(r, w) == R.from_limbs(a, w) * R.from_limbs(b, w)
+        other = [c + (1 if i == 1 else 0) for i, c in enumerate(cols)]
+        for x, want in ((R.mul_columns(b, a, None, p.WB), 1), (other, 0)):
+            st = R.Stream()
+            assert R.is_equal_muled(p, cols, x, st) == want
+            e, est = is_equal_muled(o, cols, x)
+            assert e == want and bytes(est) == st.bytes()
