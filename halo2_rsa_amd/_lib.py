@@ -32,7 +32,9 @@ class H2RLayout(ctypes.Structure):
                 ("carry_sub_stride", ctypes.c_uint32), ("word_max_bits", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
                 ("record_stride", ctypes.c_uint64), ("stream_bytes", ctypes.c_uint64),
                 ("plane_off", ctypes.c_uint64 * H2R_PL_COUNT), ("plane_elem", ctypes.c_uint32 * H2R_PL_COUNT),
-                ("plane_count", ctypes.c_uint32 * H2R_PL_COUNT)]
+                ("plane_count", ctypes.c_uint32 * H2R_PL_COUNT),
+                ("acc_steps_per_group", ctypes.c_uint32), ("acc_lo_row_bytes", ctypes.c_uint32),
+                ("acc_lo_group_bytes", ctypes.c_uint64), ("acc_hi_group_bytes", ctypes.c_uint64)]
 
 
 class H2RPowLayout(ctypes.Structure):

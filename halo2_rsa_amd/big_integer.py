@@ -105,6 +105,8 @@ class Trace:
     def plane(self, elem: int, t: int, name: str) -> np.ndarray:
         """Raw bytes [count, elem_bytes] of one plane of mul_mod record t of element elem."""
         p = _lib.PLANES.index(name)
+        if name in ("AB_LO", "AB_HI", "QN_LO", "QN_HI"):
+            raise ValueError("the accumulator planes are interleaved (see include/h2r.h); use flatten()")
         lo = self.layout
         off0 = (self.pow_layout.off_records if self.pow_layout is not None else 0) + t * lo.record_stride
         start = elem * self.elem_stride + off0 + lo.plane_off[p]

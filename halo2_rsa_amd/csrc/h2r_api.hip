@@ -160,6 +160,7 @@ void fill_trace_args(const h2r_ctx *c, TraceArgs &ta) {
     ta.carry_bits = lo.carry_bits; ta.carry_sub_bits = lo.carry_sub_bits;
     ta.carry_nsub = lo.carry_nsub; ta.carry_sub_stride = lo.carry_sub_stride;
     ta.record_stride = lo.record_stride;
+    ta.acc_spg = lo.acc_steps_per_group; ta.acc_lo_row = lo.acc_lo_row_bytes; ta.acc_lo_group = lo.acc_lo_group_bytes; ta.acc_hi_group = lo.acc_hi_group_bytes;
     ta.const_rec = c->const_rec_dev;
     if (const char *ab = std::getenv("H2R_ABLATE")) ta.ablate = (u32)std::atoi(ab);
     if (const char *dl = std::getenv("H2R_TRACE_DYN_LDS")) ta.dyn_lds = (u32)std::atoi(dl);
@@ -719,11 +720,11 @@ inline void emit_wide(Out &o, const h2r_layout &lo, const u8 *rec, int pl_lo, u6
     emit(o, rec + lo.plane_off[pl_lo] + idx * 16, lo.wide_bytes < 16 ? lo.wide_bytes : 16);
     if (lo.wide_bytes > 16) emit(o, rec + lo.plane_off[pl_lo + 1] + idx * 8, lo.wide_bytes - 16);
 }
-// accumulator of (j, i % L): LO entry j*L + i%L; the HI words of rows (2p, 2p+1) share 16-byte slots
+// accumulator of (j, i % L) in the interleaved AB/QN region (see h2r.h)
 inline void emit_acc(Out &o, const h2r_layout &lo, const u8 *rec, int pl_lo, u32 j, u32 im) {
-    const u32 L = lo.num_limbs;
-    emit(o, rec + lo.plane_off[pl_lo] + ((u64)j * L + im) * 16, lo.wide_bytes < 16 ? lo.wide_bytes : 16);
-    if (lo.wide_bytes > 16) emit(o, rec + lo.plane_off[pl_lo + 1] + (((u64)(j >> 1) * L + im) * 2 + (j & 1)) * 8, lo.wide_bytes - 16);
+    const u64 g = j / lo.acc_steps_per_group, st = j % lo.acc_steps_per_group;
+    emit(o, rec + lo.plane_off[pl_lo] + g * lo.acc_lo_group_bytes + st * lo.acc_lo_row_bytes + (u64)im * 16, lo.wide_bytes < 16 ? lo.wide_bytes : 16);
+    if (lo.wide_bytes > 16) emit(o, rec + lo.plane_off[pl_lo + 1] + (u64)(j >> 1) * lo.acc_hi_group_bytes + (u64)im * 16 + (j & 1) * 8, lo.wide_bytes - 16);
 }
 inline void emit_plane(Out &o, const h2r_layout &lo, const u8 *rec, int pl, u64 idx, u32 n) {
     emit(o, rec + lo.plane_off[pl] + idx * lo.plane_elem[pl], n);

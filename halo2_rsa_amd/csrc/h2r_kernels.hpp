@@ -657,6 +657,7 @@ struct TraceArgs {
     u32 ablate;                         // timing experiments only (H2R_ABLATE); 0 in production
     u32 dyn_lds;                        // extra dynamic LDS per block: caps residency (pipeline co-scheduling)
     u32 prio;                           // raise wave priority (pipeline co-scheduling)
+    u32 acc_spg, acc_lo_row; u64 acc_lo_group, acc_hi_group;   // accumulator-plane addressing (h2r_layout)
     u32 mode;                           // TRACE_FULL (mul_mod), TRACE_MUL (BigIntChip::mul only), TRACE_EQ (is_equal_muled only)
     const u64 *muled_a, *muled_b;       // TRACE_EQ inputs: [item][2L] x 4 u64 (256-bit columns)
     u64 *muled_out;                     // TRACE_MUL output, same format
@@ -809,6 +810,9 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
     ColAcc<LW> acc, first;
     acc.clear(); first.clear();
     if (prod && !(args.ablate & 2)) {
+        // accumulator addressing (h2r.h): planar rows, or interleaved [ab half | qn half] rows with a shared HI row
+        const u64 lo_group = args.acc_lo_group, hi_group = args.acc_hi_group, lo_row = args.acc_lo_row;
+        const bool two = args.acc_spg == 2;
         u8 *plo = rec + off[h == 0 ? H2R_PL_AB_LO : H2R_PL_QN_LO] + (u64)i * 16;
         u8 *phi = rec + off[h == 0 ? H2R_PL_AB_HI : H2R_PL_QN_HI] + (u64)i * 16;
         const limb_t *Ah = s.A[h], *Bh = s.B[h];
@@ -822,9 +826,10 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
             acc.keep_if(st != i + 1);       // column i is complete: start column i+L from zero
             if (args.ablate & 8) { acc.w[0] += (u32)x; acc.w[1] ^= (u32)y; }
             else acc.add_product(x, y);
-            st16(plo + (u64)st * (L * 16), acc.lo0(), acc.lo1());
+            const u64 lo_off = two ? (u64)(st >> 1) * lo_group + (u64)(st & 1) * lo_row : (u64)st * lo_group;
+            st16(plo + lo_off, acc.lo0(), acc.lo1());
             if constexpr (LW == 64) {       // third words of steps (2p, 2p+1) share one 16-byte slot
-                if (st & 1) st16(phi + (u64)(st >> 1) * (L * 16), hi_even, acc.hi64());
+                if (st & 1) st16(phi + (u64)(st >> 1) * hi_group, hi_even, acc.hi64());
                 else hi_even = acc.hi64();
             }
             first.take_if(st == i, acc);

@@ -130,13 +130,37 @@ inline void layout_compute(u32 w, u32 L, h2r_layout *o) {
     set(H2R_PL_QACC, CB, C); set(H2R_PL_MODACC, LB, C);
     set(H2R_PL_NQ2_LO, 16, C); set(H2R_PL_NQ2_HI, HI, C); set(H2R_PL_AMNQ2, LB, C);
     set(H2R_PL_FLAGS, 4, C); set(H2R_PL_CARRY_DUP, CB, C - 1); set(H2R_PL_CARRY_SUB, o->carry_sub_stride, C - 1);
+    // Accumulator planes: planar (four separate regions, rows of L entries) or interleaved row by row -- group g of
+    // acc_steps_per_group steps holds the LO rows [ab half | qn half] of its steps and then one HI row [ab | qn]
+    // (limb_width 64: the third words of two steps share 16-byte slots), so that one step of one mul_mod writes ONE
+    // contiguous run and its product phase is one sequential stream.  Measured choice per shape below.
+    // (same-box A/B, profiles/r01_layout_ab.txt: interleaved +0.5..1.3 % for 64-bit limbs, no difference for 32-bit)
+    const bool interleaved = (w == 64);
     u64 off = 0;
     for (int p = 0; p < H2R_PL_COUNT; ++p) {
+        if (interleaved && p == H2R_PL_AB_LO) {
+            const u64 acc = off;
+            o->acc_steps_per_group = HI ? 2 : 1;
+            o->acc_lo_row_bytes = 2 * L * 16;
+            o->acc_lo_group_bytes = (u64)o->acc_steps_per_group * o->acc_lo_row_bytes + (HI ? 2ull * L * 16 : 0);
+            o->acc_hi_group_bytes = o->acc_lo_group_bytes;
+            o->plane_off[H2R_PL_AB_LO] = acc;
+            o->plane_off[H2R_PL_QN_LO] = acc + (u64)L * 16;
+            o->plane_off[H2R_PL_AB_HI] = acc + (u64)o->acc_steps_per_group * o->acc_lo_row_bytes;
+            o->plane_off[H2R_PL_QN_HI] = o->plane_off[H2R_PL_AB_HI] + (u64)L * 16;
+            off += round_up((u64)(L / o->acc_steps_per_group) * o->acc_lo_group_bytes, 256);
+            continue;
+        }
+        if (interleaved && (p == H2R_PL_AB_HI || p == H2R_PL_QN_LO || p == H2R_PL_QN_HI)) continue;
         o->plane_off[p] = off;
         // per-column planes reserve C+1 entries so that a full 2L-thread group may address them
         u64 cnt = o->plane_count[p];
         if (cnt == C || cnt == C - 1) cnt = 2 * L;
         off += round_up((u64)o->plane_elem[p] * cnt, 256);
+    }
+    if (!interleaved) {
+        o->acc_steps_per_group = 1; o->acc_lo_row_bytes = 0;
+        o->acc_lo_group_bytes = (u64)L * 16; o->acc_hi_group_bytes = (u64)L * 16;
     }
     o->record_stride = off;
     // HBM channel interleaving: record strides of 253*256 / 257*256 bytes alias (measured -10 % on the

@@ -88,9 +88,16 @@ typedef struct h2r_params {
  *   H2R_PL_AB_*, _QN_*     [j][i % L]     accumulator of column i=j+k right after adding
  *                                         a[j]*b[k] (resp. q[j]*n[k]); the reference's order is
  *                                         i ascending, then j ascending        (chip.rs:400-412).
- *                                         LO entry index j*L + i%L; the 8-byte HI words of rows
- *                                         (2p, 2p+1) share 16-byte slots: HI entry index
- *                                         ((j/2)*L + i%L)*2 + j%2
+ *                                         Addressing (strides in h2r_layout), with
+ *                                         g = j / acc_steps_per_group, s = j % acc_steps_per_group:
+ *                                           LO(j, i%L) at plane_off[P_LO] + g*acc_lo_group_bytes
+ *                                                         + s*acc_lo_row_bytes + (i%L)*16
+ *                                           HI(j, i%L) at plane_off[P_HI] + (j/2)*acc_hi_group_bytes
+ *                                                         + (i%L)*16 + (j%2)*8      (limb_width 64 only)
+ *                                         The four planes may be separate regions (planar) or
+ *                                         interleaved row by row ([ab | qn] LO rows of a group of
+ *                                         steps, then one shared [ab | qn] HI row) so that a step
+ *                                         writes one contiguous run; the strides say which.
  *   H2R_PL_EQB_*           [i], i < L     qn[i] + r[i]                         (chip.rs:617)
  *   per-column planes      [i], i < C     is_equal_muled step i                (chip.rs:857-893)
  *   H2R_PL_CARRY_DUP/_SUB  [i], i < C-1   the range-assigned carry and its sub-limbs (:879-885);
@@ -127,6 +134,11 @@ typedef struct h2r_layout {
     uint64_t plane_off[H2R_PL_COUNT];
     uint32_t plane_elem[H2R_PL_COUNT];
     uint32_t plane_count[H2R_PL_COUNT];
+    /* interleaving of the AB/QN accumulator planes (see above) */
+    uint32_t acc_steps_per_group; /* LO rows per group */
+    uint32_t acc_lo_row_bytes;    /* bytes between the LO rows of one group */
+    uint64_t acc_lo_group_bytes;  /* bytes from one group's LO rows to the next group's */
+    uint64_t acc_hi_group_bytes;  /* bytes from one HI row (two steps) to the next */
 } h2r_layout;
 
 /* Layout of one element's pow trace: `num_mul_mods` records back to back, then extras.

@@ -38,9 +38,10 @@ def unflatten_record(stream, lo, planes):
             while j < L and j <= i:
                 v = take(WB)
                 im = i % L
-                put(which + "_LO", (j * L + im) * 16, v[:16])
+                g, stp = divmod(j, lo.acc_steps_per_group)
+                put(which + "_LO", g * lo.acc_lo_group_bytes + stp * lo.acc_lo_row_bytes + im * 16, v[:16])
                 if WB > 16:
-                    put(which + "_HI", (((j >> 1) * L + im) * 2 + (j & 1)) * 8, v[16:])
+                    put(which + "_HI", (j >> 1) * lo.acc_hi_group_bytes + im * 16 + (j & 1) * 8, v[16:])
                 j += 1
     for i in range(L):
         put_wide("EQB_LO", i, take(WB))

@@ -63,9 +63,11 @@ def test_range_lens_and_layout_match_goldens(golden):
             assert lib().h2r_trace_layout(c, ctypes.byref(lo)) == 0
             assert (lo.limb_bytes, lo.wide_bytes, lo.carry_bytes, lo.carry_bits, lo.word_max_bits, lo.stream_bytes) == \
                 (row["LB"], row["WB"], row["CB"], row["carry_bits"], row["word_max_bits"], row["mul_mod_stream_bytes"])
-            offs = list(lo.plane_off)
+            acc = {_lib.PLANES.index(n) for n in ("AB_LO", "AB_HI", "QN_LO", "QN_HI")}
+            offs = [o for k, o in enumerate(lo.plane_off) if k not in acc or k == _lib.PLANES.index("AB_LO")]
             assert offs == sorted(offs) and all(o % 256 == 0 for o in offs) and lo.record_stride % 256 == 0
-            assert lo.record_stride >= lo.stream_bytes
+            assert all(lo.plane_off[k] % 16 == 0 and lo.plane_off[k] < lo.record_stride for k in acc)
+            assert lo.acc_steps_per_group in (1, 2) and lo.acc_lo_group_bytes % 16 == 0
             lib().h2r_ctx_destroy(c)
     comp4, over3 = (ctypes.c_uint32 * 4)(), (ctypes.c_uint32 * 3)()
     assert lib().h2r_rsa_compute_range_lens(32, comp4, over3) == 0
