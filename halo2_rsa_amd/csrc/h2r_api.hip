@@ -525,12 +525,13 @@ int32_t h2r_pipeline_create(const h2r_ctx *ctx, h2r_pipeline **out) {
     HIP_TRY(hipSetDevice(ctx->params.device));
     h2r_pipeline *p = new (std::nothrow) h2r_pipeline();
     if (!p) return H2R_E_HIP;
-    p->ctx = ctx; p->k = 0; p->pending = false;
-    if (!hip_ok(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking), "hipStreamCreate")) { delete p; return H2R_E_HIP; }
-    for (int i = 0; i < 2; ++i) {
-        if (!hip_ok(hipEventCreateWithFlags(&p->chain_done[i], hipEventDisableTiming), "hipEventCreate") ||
-            !hip_ok(hipEventCreateWithFlags(&p->trace_done[i], hipEventDisableTiming), "hipEventCreate")) { delete p; return H2R_E_HIP; }
-    }
+    p->ctx = ctx; p->k = 0; p->pending = false; p->aux = nullptr;
+    for (int i = 0; i < 2; ++i) { p->chain_done[i] = nullptr; p->trace_done[i] = nullptr; }
+    bool ok = hip_ok(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking), "hipStreamCreate");
+    for (int i = 0; ok && i < 2; ++i)
+        ok = hip_ok(hipEventCreateWithFlags(&p->chain_done[i], hipEventDisableTiming), "hipEventCreate") &&
+             hip_ok(hipEventCreateWithFlags(&p->trace_done[i], hipEventDisableTiming), "hipEventCreate");
+    if (!ok) { h2r_pipeline_destroy(p); return H2R_E_HIP; }
     *out = p;
     return H2R_OK;
 }
@@ -538,9 +539,12 @@ int32_t h2r_pipeline_create(const h2r_ctx *ctx, h2r_pipeline **out) {
 void h2r_pipeline_destroy(h2r_pipeline *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->params.device);
-    (void)hipStreamSynchronize(p->aux);
-    for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(p->chain_done[i]); (void)hipEventDestroy(p->trace_done[i]); }
-    (void)hipStreamDestroy(p->aux);
+    if (p->aux) (void)hipStreamSynchronize(p->aux);
+    for (int i = 0; i < 2; ++i) {
+        if (p->chain_done[i]) (void)hipEventDestroy(p->chain_done[i]);
+        if (p->trace_done[i]) (void)hipEventDestroy(p->trace_done[i]);
+    }
+    if (p->aux) (void)hipStreamDestroy(p->aux);
     delete p;
 }
 
