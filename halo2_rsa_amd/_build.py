@@ -25,17 +25,26 @@ def stale():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
-def build_lib(force=False, verbose=False):
-    if not force and not stale():
+def build_lib(force=False, verbose=False, out=None, defines=()):
+    """`out`/`defines` build a developer variant (tools/*: same-box A/B runs via H2R_LIB)."""
+    if out is None and not force and not stale():
         return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    out = out or LIB
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), "-o", LIB, SRC]
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), "-o", out, SRC]
+    cmd += ["-D" + d for d in defines]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":
-    print(build_lib(force=True, verbose=True))
+    import sys
+    # python -m halo2_rsa_amd._build [variant-name -DFOO=1 ...]  -> lib/variants/<name>.so
+    if len(sys.argv) > 1:
+        print(build_lib(out=os.path.join(PKG, "lib", "variants", sys.argv[1] + ".so"),
+                        defines=[a[2:] if a.startswith("-D") else a for a in sys.argv[2:]], verbose=True))
+    else:
+        print(build_lib(force=True, verbose=True))

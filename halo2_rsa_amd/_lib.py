@@ -78,7 +78,8 @@ FRESH_OPS = ["add", "sub", "add_mod", "sub_mod", "is_zero", "is_equal_fresh", "i
 
 
 def lib_path():
-    return _build.LIB
+    # H2R_LIB: developer override used by tools/ for same-box A/B runs of build variants
+    return os.environ.get("H2R_LIB") or _build.LIB
 
 
 def lib():

@@ -210,10 +210,25 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         if (mode != CHAIN_POW_VAR) { ca.off_e_bits = 0; ca.off_selected = 0; }
     }
     if (eb) ca.e = *eb;
+#ifdef H2R_CHAIN_TIMING   // developer build (tools/chain_timing.py): dump block 0's s_memtime stamps
+    static u64 *dbg_buf = nullptr;
+    if (std::getenv("H2R_CHAIN_TIMING")) { if (!dbg_buf) (void)hipMalloc(&dbg_buf, 4096 * 8); (void)hipMemsetAsync(dbg_buf, 0, 4096 * 8, st); ca.dbg_time = dbg_buf; }
     {
         ProfScope ps(H2R_KERNEL_CHAIN, st);
         HIP_TRY(launch_chain(c->K, ca, st));
     }
+    if (ca.dbg_time) {
+        static u64 host[4096];
+        (void)hipStreamSynchronize(st); (void)hipMemcpy(host, ca.dbg_time, sizeof host, hipMemcpyDeviceToHost);
+        FILE *f = std::fopen("/tmp/h2r_chain_timing.txt", "w");
+        if (f) { for (int i = 0; i < 4000 && host[i]; ++i) std::fprintf(f, "%llu\n", (unsigned long long)host[i]); std::fclose(f); }
+    }
+#else
+    {
+        ProfScope ps(H2R_KERNEL_CHAIN, st);
+        HIP_TRY(launch_chain(c->K, ca, st));
+    }
+#endif
     if (trace && T) {
         TraceArgs ta;
         fill_trace_args(c, ta);

@@ -75,6 +75,7 @@ struct ChainArgs {
     // POW_VAR extras written straight into the element traces
     u8 *trace; u64 elem_stride, off_e_bits, off_selected, selected_stride, off_result;
     u32 write_result_to_trace;
+    u64 *dbg_time;       // debug: s_memtime stamps of block 0 / wave 0 (nullable)
     ExpBits e;
 };
 
@@ -103,6 +104,7 @@ struct ChainLds {
     u32 part[Geo<K, NW>::SSMAX][3][2 * K];  // per-slice column partial sums (3 words)
     u32 x0[2 * K + 4], x1[2 * K + 4], x2[2 * K + 4];  // reduced columns; also shift scratch
     u32 rx0[K + 1], rx1[K + 1];          // wave-0 scratch of the reciprocal
+    u64 *dbg; u32 dbg_n;                 // debug timing (nullable)
 };
 
 // intra-wave ordering of LDS traffic (ds ops of one wave execute in order; stop compiler motion)
@@ -124,6 +126,16 @@ __device__ __forceinline__ void wave_sync() {
 // full product when K < 64 (a single 64-column group already covers everything).
 enum { MUL_FULL = 0, MUL_HIGH = 1, MUL_LOW = 2 };
 
+// Developer build only (-DH2R_CHAIN_TIMING, tools/chain_timing.py): s_memtime stamps of block 0 / thread 0.
+#ifdef H2R_CHAIN_TIMING
+#define H2R_STAMP(s_) do { if ((s_).dbg && threadIdx.x == 0 && (s_).dbg_n < 4000) (s_).dbg[(s_).dbg_n++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define H2R_STAMP(s_) do { } while (0)
+#endif
+#ifndef H2R_CHAIN_MINB
+#define H2R_CHAIN_MINB 8   // blocks per CU the register budget is sized for (K <= 64); 4 and 8 measure alike
+#endif
+
 template <int K, int NW, int MODE>
 __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLds<K, NW> &s, int lane, int wave,
                                           u32 (&plo)[Geo<K, NW>::V], u32 (&phi)[Geo<K, NW>::V], u32 &dk) {
@@ -135,7 +147,9 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
     constexpr int SLA = K / SSA;                          // steps per slice
     constexpr int CB = (HALF && MODE == MUL_HIGH) ? K - 2 : 0;   // first column of the window
     static_assert(NW % CGA == 0 && K % SSA == 0 && SSA <= Geo<K, NW>::SSMAX, "bad half-product geometry");
+    H2R_STAMP(s);
     __syncthreads();  // operands published; previous readers of part/x* are done
+    H2R_STAMP(s);
     {
         const int cg = wave % CGA, ss = wave / CGA;
         const int c = CB + 64 * cg + lane;
@@ -146,6 +160,9 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
         const u32 *ap = A + j0;
         // acc(64) += a*b with the multiplier's own carry-out feeding the overflow word: 2 VALU per product
         // (v_mad_u64_u32 writes the carry to an SGPR pair; gfx950 needs 2 wait states before a VALU reads it).
+        // Tried and measured slower on the same box (tools/ab_chain.sh): four independent accumulators with
+        // operands preloaded 16 products ahead (4 x mad then 4 x addc, no s_nop) -- 0.117 vs 0.110 ms alone and
+        // 0.339 vs 0.279 ms pipelined, because it needs 128 VGPRs and halves the waves that hide LDS latency.
         auto mac = [&](u32 av, u32 bv) {
             u64 carry;
             asm volatile("v_mad_u64_u32 %0, %2, %3, %4, %0\n\ts_nop 1\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2"
@@ -182,7 +199,9 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
             }
         }
     }
+    H2R_STAMP(s);
     __syncthreads();
+    H2R_STAMP(s);
     constexpr int C0 = CB, C1 = HALF ? (MODE == MUL_HIGH ? 2 * K - 1 : K) : 2 * K;   // columns reduced: [C0, C1)
     for (int c = C0 + (int)threadIdx.x; c < C1; c += 64 * NW) {  // reduce the slices of column c
         u64 s0 = 0, s1 = 0; u32 s2 = 0;
@@ -194,7 +213,9 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
     // three zero columns below the window (c = C0-3 .. C0-1) and, for MUL_HIGH, the always-zero column 2K-1
     if (threadIdx.x < 3) { s.x0[C0 + threadIdx.x] = 0; s.x1[C0 + threadIdx.x] = 0; s.x2[C0 + threadIdx.x] = 0; }
     if (HALF && MODE == MUL_HIGH && threadIdx.x == 3) { s.x0[2 * K + 2] = 0; s.x1[2 * K + 2] = 0; s.x2[2 * K + 2] = 0; }
+    H2R_STAMP(s);
     __syncthreads();
+    H2R_STAMP(s);
     if (wave != 0) return;
     // digits: t(c) = x0[c] + x1[c-1] + x2[c-2]; d(c) = lo(t(c)) + hi(t(c-1)); 1-bit carries by ballot
     bool cin = false;
@@ -225,6 +246,7 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
     } else {
         dk = 0;
     }
+    H2R_STAMP(s);
 }
 
 // K-digit a + b: returns carry out.
@@ -486,7 +508,7 @@ __device__ __forceinline__ int block_mulmod(ChainLds<K, NW> &s, u32 shift, int l
 }
 
 template <int K, int NW>
-__global__ __launch_bounds__(64 * NW, (K <= 64 ? 8 : 4)) void chain_kernel(ChainArgs args) {
+__global__ __launch_bounds__(64 * NW, (K <= 64 ? H2R_CHAIN_MINB : H2R_CHAIN_MINB / 2)) void chain_kernel(ChainArgs args) {
     using G = Geo<K, NW>;
     constexpr int V = G::V;
     __shared__ ChainLds<K, NW> s;
@@ -498,6 +520,7 @@ __global__ __launch_bounds__(64 * NW, (K <= 64 ? 8 : 4)) void chain_kernel(Chain
 #pragma unroll
     for (int m = 0; m < V; ++m) nraw[m] = (lane + 64 * m < K) ? n_g[lane + 64 * m] : 0;
     for (int i = threadIdx.x; i < 3 * K; i += 64 * NW) { s.bpad[i] = 0; s.nnpad[i] = 0; s.mupad[i] = 0; }
+    if (threadIdx.x == 0) { s.dbg = (blockIdx.x == 0) ? args.dbg_time : nullptr; s.dbg_n = 0; }
     // normalisation shift: leading zero bits of n within 32K bits (every wave computes it: block-uniform)
     int top_digit = -1;
 #pragma unroll
