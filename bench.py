@@ -108,6 +108,12 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="signatures per GPU per step")
     ap.add_argument("--workload", default="rsa2048_e65537", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline-depth", type=int, default=2, help="buffer sets the pipelined calls rotate through (2..4)")
+    ap.add_argument("--side-streams", type=int, default=1,
+                    help="streams the record kernels alternate between; 2 lets consecutive record kernels overlap "
+                         "(higher throughput, but each launch's duration then includes the overlap)")
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="developer: do not arm the C ABI's per-kernel event timing (roofline fields become null)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="fully stream-ordered calls (chain then trace per step) instead of the two-stream pipeline")
     args = ap.parse_args()
@@ -126,12 +132,12 @@ def main():
     pl = chip.pow_fixed_layout(e)
     dev = "cuda:%d" % env.local_rank
     # two buffer sets: in pipeline mode step k+1's chain kernel overlaps step k's trace kernel
-    nbuf = 1 if args.no_pipeline else 2
+    nbuf = 1 if args.no_pipeline else args.pipeline_depth
     trace_bufs = [torch.empty(batch * pl.elem_stride, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     workspaces = [torch.empty(chip.workspace_bytes(batch, pl.num_mul_mods), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     outs = [torch.empty((batch, chip.num_limbs), dtype=chip.torch_dtype, device=dev) for _ in range(nbuf)]
     statuses = [torch.zeros(batch, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    pipe = None if args.no_pipeline else chip.pipeline()
+    pipe = None if args.no_pipeline else H.Pipeline(chip, depth=args.pipeline_depth, side_streams=args.side_streams)
     counter = [0]
 
     def step():
@@ -149,7 +155,7 @@ def main():
     if pipe is not None:
         pipe.join()
     torch.cuda.synchronize()
-    _lib.profile_enable(2 * steps + 8)
+    _lib.profile_enable(0 if args.no_kernel_timing else 2 * steps + 8)
     env.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -197,7 +203,8 @@ def main():
                        (args.workload, batch, w, algo_bytes_per_assign),
                        "per_gpu_batch": batch, "global_batch": env.world * batch,
                        "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world,
-                       "pipeline": "two-stream (chain k+1 || trace k)" if pipe is not None else "none"},
+                       "pipeline": ("chain k+1 || trace k, %d buffer sets, %d record stream(s)" % (args.pipeline_depth, args.side_streams))
+                                   if pipe is not None else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": pmc_traffic("trace_kernel<%d,%d>" % (w, chip.num_limbs), batch),

@@ -3,7 +3,7 @@
 `halo2_rsa_amd/csrc` holds the hand-written HIP kernels and the C ABI (include/h2r.h);
 `big_integer` / `rsa` mirror the reference's chip API for that path.  No CPU fallback exists.
 """
-from ._lib import (H2R_E_NOT_IN_FIELD, H2R_E_NOT_REDUCED, H2R_E_ZERO_MODULUS, H2R_OK, H2RError,  # noqa: F401
+from ._lib import (H2R_E_NOT_IN_FIELD, H2R_E_NOT_REDUCED, H2R_E_SHAPE, H2R_E_ZERO_MODULUS, H2R_OK, H2RError,  # noqa: F401
                    lib, lib_path)
-from .big_integer import AssignedInteger, BatchResult, BigIntChip, Trace, UnassignedInteger  # noqa: F401
+from .big_integer import AssignedInteger, BatchResult, BigIntChip, Pipeline, Trace, UnassignedInteger  # noqa: F401
 from .rsa import Fix, RSAChip, RSAPublicKey, RSASignature, Var  # noqa: F401

@@ -381,13 +381,14 @@ class BigIntChip:
 
 
 class Pipeline:
-    """h2r_pipeline: batch k+1's off-circuit chain overlaps batch k's record emission (two HIP streams).
-    Callers alternate between (at least) two buffer sets and call join() before reading the last trace."""
+    """h2r_pipeline: batch k+1's off-circuit chain overlaps batch k's record emission (side HIP streams).
+    Callers rotate through `depth` buffer sets and call join() before reading the last traces."""
 
-    def __init__(self, chip: BigIntChip):
+    def __init__(self, chip: BigIntChip, depth: int = 2, side_streams: int = 1):
         self.chip = chip
+        self.depth = depth
         self._p = ctypes.c_void_p()
-        check(lib().h2r_pipeline_create(chip._ctx, ctypes.byref(self._p)), "h2r_pipeline_create")
+        check(lib().h2r_pipeline_create_ex(chip._ctx, depth, side_streams, ctypes.byref(self._p)), "h2r_pipeline_create_ex")
 
     def modpow_public_key(self, x: AssignedInteger, e: int, n: AssignedInteger, trace_buf, workspace, out, status):
         eb = _e_bytes(e)

@@ -1,5 +1,6 @@
 // C ABI of libh2r (see include/h2r.h).  Host side: context, layouts, kernel launches, flatten.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -33,17 +34,22 @@ struct ProfRec { u32 kernel; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
 u32 g_prof_cap = 0;
-struct ProfScope {  // records start/stop events around one launch when profiling is armed
-    hipStream_t st; hipEvent_t a = nullptr, b = nullptr; u32 kernel; bool on = false;
-    ProfScope(u32 k, hipStream_t s) : st(s), kernel(k) {
+struct ProfScope {  // start/stop events of one launch when profiling is armed
+    // ext == false: the events are recorded around the launch (two marker packets on the stream).
+    // ext == true:  the caller hands a/b to hipExtLaunchKernelGGL, which stamps them from the dispatch packet's own
+    //               completion signal -- no extra packets (each marker costs ~5 us of queue time between kernels).
+    hipStream_t st; hipEvent_t a = nullptr, b = nullptr; u32 kernel; bool on = false, ext;
+    ProfScope(u32 k, hipStream_t s, bool ext_ = false) : st(s), kernel(k), ext(ext_) {
         std::lock_guard<std::mutex> lk(g_prof_mu);
-        if (g_prof_cap && g_prof.size() < g_prof_cap && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) {
-            on = true; (void)hipEventRecord(a, st);
+        if (g_prof_cap && g_prof.size() < g_prof_cap && hipEventCreate(&a) == hipSuccess) {
+            if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); a = nullptr; return; }
+            on = true;
+            if (!ext) (void)hipEventRecord(a, st);
         }
     }
     ~ProfScope() {
         if (!on) return;
-        (void)hipEventRecord(b, st);
+        if (!ext) (void)hipEventRecord(b, st);
         std::lock_guard<std::mutex> lk(g_prof_mu);
         g_prof.push_back(ProfRec{kernel, a, b});
     }
@@ -111,38 +117,39 @@ void build_const_record(h2r_ctx *c) {
 }
 
 template <int LW, int L>
-hipError_t launch_trace_t(const TraceArgs &ta, hipStream_t st) {
+hipError_t launch_trace_t(const TraceArgs &ta, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
     constexpr int TPI = 2 * L;
     constexpr int IPB = TPI >= 256 ? 1 : 256 / TPI;
     const u64 blocks = (ta.n_items + IPB - 1) / IPB;
     if (blocks == 0) return hipSuccess;
     // dyn_lds > 0 caps the blocks resident per CU (leaves wave slots for a co-running chain kernel)
-    hipLaunchKernelGGL((trace_kernel<LW, L>), dim3((unsigned)blocks), dim3(256), ta.dyn_lds, st, ta);
+    // ea/eb (nullable): start/stop events stamped by the dispatch itself
+    hipExtLaunchKernelGGL((trace_kernel<LW, L>), dim3((unsigned)blocks), dim3(256), ta.dyn_lds, st, ea, eb, 0, ta);
     return hipGetLastError();
 }
-hipError_t launch_trace(u32 w, u32 L, const TraceArgs &ta, hipStream_t st) {
-#define H2R_CASE(W_, L_) if (w == W_ && L == L_) return launch_trace_t<W_, L_>(ta, st)
+hipError_t launch_trace(u32 w, u32 L, const TraceArgs &ta, hipStream_t st, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr) {
+#define H2R_CASE(W_, L_) if (w == W_ && L == L_) return launch_trace_t<W_, L_>(ta, st, ea, eb)
     H2R_CASE(64, 4); H2R_CASE(64, 8); H2R_CASE(64, 16); H2R_CASE(64, 32); H2R_CASE(64, 64);
     H2R_CASE(32, 8); H2R_CASE(32, 32); H2R_CASE(32, 64); H2R_CASE(32, 128);
 #undef H2R_CASE
     return hipErrorInvalidValue;
 }
 template <int K, int NW>
-hipError_t launch_chain_t(const ChainArgs &ca, hipStream_t st) {
+hipError_t launch_chain_t(const ChainArgs &ca, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
     if (ca.batch == 0) return hipSuccess;
-    hipLaunchKernelGGL((chain_kernel<K, NW>), dim3((unsigned)ca.batch), dim3(64 * NW), 0, st, ca);
+    hipExtLaunchKernelGGL((chain_kernel<K, NW>), dim3((unsigned)ca.batch), dim3(64 * NW), 0, st, ea, eb, 0, ca);
     return hipGetLastError();
 }
-hipError_t launch_chain(u32 K, const ChainArgs &ca, hipStream_t st) {
+hipError_t launch_chain(u32 K, const ChainArgs &ca, hipStream_t st, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr) {
     switch (K) {  // NW = waves per element (multiple of the number of 64-column groups of the product)
-        case 8: return launch_chain_t<8, 1>(ca, st);
-        case 16: return launch_chain_t<16, 1>(ca, st);
-        case 32: return launch_chain_t<32, 4>(ca, st);
+        case 8: return launch_chain_t<8, 1>(ca, st, ea, eb);
+        case 16: return launch_chain_t<16, 1>(ca, st, ea, eb);
+        case 32: return launch_chain_t<32, 4>(ca, st, ea, eb);
         case 64: { static const int nw = std::getenv("H2R_CHAIN_NW") ? std::atoi(std::getenv("H2R_CHAIN_NW")) : 4;  // 4 measured best (profiles/r01_notes)
-                   if (nw == 8) return launch_chain_t<64, 8>(ca, st);
-                   if (nw == 2) return launch_chain_t<64, 2>(ca, st);
-                   return launch_chain_t<64, 4>(ca, st); }
-        case 128: return launch_chain_t<128, 8>(ca, st);
+                   if (nw == 8) return launch_chain_t<64, 8>(ca, st, ea, eb);
+                   if (nw == 2) return launch_chain_t<64, 2>(ca, st, ea, eb);
+                   return launch_chain_t<64, 4>(ca, st, ea, eb); }
+        case 128: return launch_chain_t<128, 8>(ca, st, ea, eb);
         default: return hipErrorInvalidValue;
     }
 }
@@ -172,7 +179,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
                  u32 e_num_limbs, u32 exp_limb_bits, const ExpBits *eb, u32 check_in_field, u64 batch, u32 flags,
                  u32 T, void *trace, u64 elem_stride, u64 off_records, const h2r_pow_layout *pl, void *out,
                  uint8_t *status, void *workspace, hipStream_t st, hipStream_t trace_st = nullptr,
-                 hipEvent_t chain_done = nullptr) {
+                 hipEvent_t chain_done = nullptr, hipEvent_t trace_done = nullptr) {
     // trace_st != nullptr (pipeline mode): the record-writing kernel runs on trace_st after `chain_done`
     if (!c || !n || !a || !status) return H2R_E_NULL;
     if (trace_st && !workspace) return H2R_E_NULL;
@@ -210,12 +217,17 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         if (mode != CHAIN_POW_VAR) { ca.off_e_bits = 0; ca.off_selected = 0; }
     }
     if (eb) ca.e = *eb;
+    if (const char *pr = std::getenv("H2R_CHAIN_PRIO")) ca.prio = (u32)std::atoi(pr);
+    bool chain_done_folded = false;
 #ifdef H2R_CHAIN_TIMING   // developer build (tools/chain_timing.py): dump block 0's s_memtime stamps
     static u64 *dbg_buf = nullptr;
     if (std::getenv("H2R_CHAIN_TIMING")) { if (!dbg_buf) (void)hipMalloc(&dbg_buf, 4096 * 8); (void)hipMemsetAsync(dbg_buf, 0, 4096 * 8, st); ca.dbg_time = dbg_buf; }
     {
-        ProfScope ps(H2R_KERNEL_CHAIN, st);
-        HIP_TRY(launch_chain(c->K, ca, st));
+        // stop event of the dispatch: the profiler's when armed, else (pipeline mode) chain_done itself
+        ProfScope ps(H2R_KERNEL_CHAIN, st, true);
+        const bool fold = !ps.on && trace_st && trace && T;
+        HIP_TRY(launch_chain(c->K, ca, st, ps.a, ps.on ? ps.b : (fold ? chain_done : nullptr)));
+        chain_done_folded = fold;
     }
     if (ca.dbg_time) {
         static u64 host[4096];
@@ -225,8 +237,11 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
     }
 #else
     {
-        ProfScope ps(H2R_KERNEL_CHAIN, st);
-        HIP_TRY(launch_chain(c->K, ca, st));
+        // stop event of the dispatch: the profiler's when armed, else (pipeline mode) chain_done itself
+        ProfScope ps(H2R_KERNEL_CHAIN, st, true);
+        const bool fold = !ps.on && trace_st && trace && T;
+        HIP_TRY(launch_chain(c->K, ca, st, ps.a, ps.on ? ps.b : (fold ? chain_done : nullptr)));
+        chain_done_folded = fold;
     }
 #endif
     if (trace && T) {
@@ -242,12 +257,14 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
             // stream does not need full occupancy) 
             // (measured sweep: profiles/r01_pipeline_sweep.txt -- 32000 B extra LDS = 3 blocks/CU, normal priority)
             if (!std::getenv("H2R_TRACE_DYN_LDS")) ta.dyn_lds = 32000;
-            HIP_TRY(hipEventRecord(chain_done, st));
+            if (!chain_done_folded) HIP_TRY(hipEventRecord(chain_done, st));
             HIP_TRY(hipStreamWaitEvent(trace_st, chain_done, 0));
             ts = trace_st;
         }
-        ProfScope ps(H2R_KERNEL_TRACE, ts);
-        HIP_TRY(launch_trace(lo.limb_width, c->L, ta, ts));
+        ProfScope ps(H2R_KERNEL_TRACE, ts, true);
+        const bool fold = !ps.on && trace_done;
+        HIP_TRY(launch_trace(lo.limb_width, c->L, ta, ts, ps.a, ps.on ? ps.b : (fold ? trace_done : nullptr)));
+        if (trace_done && !fold) HIP_TRY(hipEventRecord(trace_done, ts));
     }
     return H2R_OK;
 }
@@ -527,25 +544,37 @@ int32_t h2r_verify_trace_flatten(const h2r_ctx *ctx, const h2r_verify_layout *vl
 
 struct h2r_pipeline {
     const h2r_ctx *ctx;
-    hipStream_t aux;
-    hipEvent_t chain_done[2], trace_done[2];
+    // Record kernels alternate between two side streams: call k+1's may start as soon as its own chain kernel is
+    // done, so it fills the CUs while call k's drains (a single side stream leaves a ~20 us barrier + dispatch gap
+    // between consecutive record kernels, measured with rocprofv3 --kernel-trace).
+    hipStream_t aux[2];
+    enum { MAX_DEPTH = 4 };
+    u32 depth;        // buffer sets the caller rotates through: call k may reuse call k-depth's buffers
+    hipEvent_t chain_done[MAX_DEPTH], trace_done[MAX_DEPTH];
     u32 k;            // calls issued
-    bool pending;     // trace_done[(k-1)&1] not yet joined into a user stream
+    u32 joined;       // calls whose record kernel the user stream has been ordered after
 };
 
-int32_t h2r_pipeline_create(const h2r_ctx *ctx, h2r_pipeline **out) {
+int32_t h2r_pipeline_create(const h2r_ctx *ctx, h2r_pipeline **out) { return h2r_pipeline_create_ex(ctx, 2, 1, out); }
+
+int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side_streams, h2r_pipeline **out) {
     if (!ctx || !out) return H2R_E_NULL;
     *out = nullptr;
+    if (depth < 2 || depth > h2r_pipeline::MAX_DEPTH || side_streams < 1 || side_streams > 2) return H2R_E_SHAPE;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     HIP_TRY(hipSetDevice(ctx->params.device));
     h2r_pipeline *p = new (std::nothrow) h2r_pipeline();
     if (!p) return H2R_E_HIP;
-    p->ctx = ctx; p->k = 0; p->pending = false; p->aux = nullptr;
-    for (int i = 0; i < 2; ++i) { p->chain_done[i] = nullptr; p->trace_done[i] = nullptr; }
-    bool ok = hip_ok(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking), "hipStreamCreate");
-    for (int i = 0; ok && i < 2; ++i)
-        ok = hip_ok(hipEventCreateWithFlags(&p->chain_done[i], hipEventDisableTiming), "hipEventCreate") &&
-             hip_ok(hipEventCreateWithFlags(&p->trace_done[i], hipEventDisableTiming), "hipEventCreate");
+    p->ctx = ctx; p->k = 0; p->joined = 0; p->depth = depth;
+    const int n_aux = (int)side_streams;
+    for (int i = 0; i < 2; ++i) p->aux[i] = nullptr;
+    for (int i = 0; i < h2r_pipeline::MAX_DEPTH; ++i) { p->chain_done[i] = nullptr; p->trace_done[i] = nullptr; }
+    bool ok = true;
+    for (int i = 0; ok && i < n_aux; ++i) ok = hip_ok(hipStreamCreateWithFlags(&p->aux[i], hipStreamNonBlocking), "hipStreamCreate");
+    if (ok && n_aux == 1) p->aux[1] = p->aux[0];
+    for (u32 i = 0; ok && i < p->depth; ++i)
+        ok = hip_ok(hipEventCreate(&p->chain_done[i]), "hipEventCreate") &&
+             hip_ok(hipEventCreate(&p->trace_done[i]), "hipEventCreate");
     if (!ok) { h2r_pipeline_destroy(p); return H2R_E_HIP; }
     *out = p;
     return H2R_OK;
@@ -554,21 +583,20 @@ int32_t h2r_pipeline_create(const h2r_ctx *ctx, h2r_pipeline **out) {
 void h2r_pipeline_destroy(h2r_pipeline *p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->params.device);
-    if (p->aux) (void)hipStreamSynchronize(p->aux);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i) if (p->aux[i]) (void)hipStreamSynchronize(p->aux[i]);
+    for (int i = 0; i < h2r_pipeline::MAX_DEPTH; ++i) {
         if (p->chain_done[i]) (void)hipEventDestroy(p->chain_done[i]);
         if (p->trace_done[i]) (void)hipEventDestroy(p->trace_done[i]);
     }
-    if (p->aux) (void)hipStreamDestroy(p->aux);
+    if (p->aux[1] && p->aux[1] != p->aux[0]) (void)hipStreamDestroy(p->aux[1]);
+    if (p->aux[0]) (void)hipStreamDestroy(p->aux[0]);
     delete p;
 }
 
 int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream) {
     if (!p) return H2R_E_NULL;
-    if (p->pending) {
-        HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->trace_done[(p->k - 1) & 1], 0));
-        p->pending = false;
-    }
+    for (; p->joined < p->k; ++p->joined)
+        HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->trace_done[p->joined % p->depth], 0));
     return H2R_OK;
 }
 
@@ -584,15 +612,15 @@ int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const voi
     rc = h2r_pow_fixed_layout(ctx, e_le, e_len, &pl);
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const u32 slot = p->k & 1;
+    const u32 slot = p->k % p->depth;
     rc = run_path(ctx, CHAIN_POW_FIXED, x, nullptr, n, nullptr, 0, 0, &eb, 1, batch, flags, T, trace, pl.elem_stride,
-                  pl.off_records, &pl, out, status, workspace, st, p->aux, p->chain_done[slot]);
+                  pl.off_records, &pl, out, status, workspace, st, p->aux[p->k & 1], p->chain_done[slot], p->trace_done[slot]);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(p->trace_done[slot], p->aux));
-    // lazily join the PREVIOUS call's trace kernel: enqueued behind this call's chain kernel, so the two overlap
-    if (p->pending) HIP_TRY(hipStreamWaitEvent(st, p->trace_done[slot ^ 1], 0));
-    p->pending = true;
     p->k += 1;
+    // lazy join: the NEXT call reuses the buffers of call k - depth, so order the user stream after that call's
+    // record kernel now -- behind this call's chain kernel, which therefore overlaps the record kernels in flight
+    for (; p->joined + p->depth <= p->k; ++p->joined)
+        HIP_TRY(hipStreamWaitEvent(st, p->trace_done[p->joined % p->depth], 0));
     return H2R_OK;
 }
 

@@ -56,7 +56,10 @@ enum { CHAIN_MULMOD = 0, CHAIN_POW_FIXED = 1, CHAIN_POW_VAR = 2 };
 
 struct ExpBits {
     u32 nbits;
-    u8 bytes[512];  // e.to_bytes_le(), up to 4096 bits
+    union {           // e.to_bytes_le(), up to 4096 bits; the kernel reads whole 32-bit words (little-endian host)
+        u8 bytes[512];
+        u32 words[128];
+    };
 };
 
 struct ChainArgs {
@@ -75,6 +78,7 @@ struct ChainArgs {
     // POW_VAR extras written straight into the element traces
     u8 *trace; u64 elem_stride, off_e_bits, off_selected, selected_stride, off_result;
     u32 write_result_to_trace;
+    u32 prio;            // s_setprio level of the chain's waves (pipeline mode: they share CUs with record kernels)
     u64 *dbg_time;       // debug: s_memtime stamps of block 0 / wave 0 (nullable)
     ExpBits e;
 };
@@ -133,7 +137,7 @@ enum { MUL_FULL = 0, MUL_HIGH = 1, MUL_LOW = 2 };
 #define H2R_STAMP(s_) do { } while (0)
 #endif
 #ifndef H2R_CHAIN_MINB
-#define H2R_CHAIN_MINB 8   // blocks per CU the register budget is sized for (K <= 64); 4 and 8 measure alike
+#define H2R_CHAIN_MINB 6   // blocks per CU the register budget is sized for (K <= 64): 79 VGPRs, no scratch (8 => 64 VGPRs + spills whose reloads wait on vmcnt(0))
 #endif
 
 template <int K, int NW, int MODE>
@@ -512,6 +516,7 @@ __global__ __launch_bounds__(64 * NW, (K <= 64 ? H2R_CHAIN_MINB : H2R_CHAIN_MINB
     using G = Geo<K, NW>;
     constexpr int V = G::V;
     __shared__ ChainLds<K, NW> s;
+    if (args.prio) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool w0 = wave == 0;
     const u64 elem = blockIdx.x;
@@ -587,15 +592,20 @@ __global__ __launch_bounds__(64 * NW, (K <= 64 ? H2R_CHAIN_MINB : H2R_CHAIN_MINB
         const bool var = args.mode == CHAIN_POW_VAR;
         const u32 nbits = var ? args.e_num_limbs * args.exp_limb_bits : args.e.nbits;
         u8 *etrace = args.trace ? args.trace + elem * args.elem_stride : nullptr;
+        // Exponent bits are fetched one 32-bit word at a time: a per-bit load would put an s_waitcnt vmcnt(0) into
+        // every iteration, which also waits for the previous mul_mod's operand stores (slow while a record kernel
+        // saturates HBM next to this one).
+        u32 eword = 0;
         for (u32 bi = 0; bi < nbits; ++bi) {
             u32 bit;
             if (var) {  // main_gate.to_bits per e-limb, LSB first (chip.rs:674-681)
                 const u32 limb = bi / args.exp_limb_bits, pos = bi % args.exp_limb_bits;
-                const u32 *eg = args.e_limbs + (elem * args.e_num_limbs + limb) * args.digits_per_limb;
-                bit = (eg[pos >> 5] >> (pos & 31)) & 1u;
+                if ((pos & 31) == 0) eword = (args.e_limbs + (elem * args.e_num_limbs + limb) * args.digits_per_limb)[pos >> 5];
+                bit = (eword >> (pos & 31)) & 1u;
                 if (etrace && threadIdx.x == 0) etrace[args.off_e_bits + bi] = (u8)bit;
             } else {
-                bit = (args.e.bytes[bi >> 3] >> (bi & 7)) & 1u;
+                if ((bi & 31) == 0) eword = args.e.words[bi >> 5];
+                bit = (eword >> (bi & 31)) & 1u;
             }
             if (var) {
                 // muled = mul_mod(acc, squared) ALWAYS (:686); acc[j] = select(muled[j], acc[j], bit) (:688-691)

@@ -225,9 +225,16 @@ int32_t h2r_modpow_public_key_batch(const h2r_ctx *ctx, const void *x, const voi
  * the NEXT pipelined call (after that call's chain kernel has been enqueued) or at h2r_pipeline_join().
  * Until then the call's trace must not be read.  Consecutive calls must use distinct trace / out /
  * status / workspace buffers (workspace is mandatory here).  Not thread-safe: one pipeline per
- * producer thread.  The chain's results (`out`, `status`) are stream-ordered on `stream` as usual. */
+ * producer thread.  The chain's results (`out`, `status`) are stream-ordered on `stream` as usual.
+ *
+ * h2r_pipeline_create_ex: `depth` (2..4) = buffer sets the caller rotates through -- call k may reuse
+ * the buffers of call k - depth, and `stream` is ordered after call k - depth + 1's records when call k
+ * returns; `side_streams` (1 or 2) = streams the record kernels alternate between (with 2, call k+1's
+ * record kernel may start while call k's still drains).  h2r_pipeline_create == (depth 2, 1 stream). */
 typedef struct h2r_pipeline h2r_pipeline;
 int32_t h2r_pipeline_create(const h2r_ctx *ctx, h2r_pipeline **out);
+int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side_streams,
+                               h2r_pipeline **out);
 void h2r_pipeline_destroy(h2r_pipeline *p);
 int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const void *n,
                                        const uint8_t *e_le_bytes, size_t e_len, uint64_t batch,

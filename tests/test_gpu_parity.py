@@ -4,6 +4,7 @@ Every test here needs a real MI355X (`-m gpu`).  The op-trace of each element is
 h2r_trace_flatten (the order a layouter shim assigns cells in) and compared byte for byte with the
 oracle's stream for the same inputs.  Nothing here reads /root/reference.
 """
+import ctypes
 import hashlib
 import random
 
@@ -484,6 +485,52 @@ def test_pipelined_calls_match_oracle(H):
             rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(s["X"][i]), o.limbs(s["N"][i]), 65537)
             assert np.array_equal(ost, tr.flatten(i)), (k, i)
     pipe.close()
+
+
+@pytest.mark.parametrize("depth,side_streams", [(2, 1), (2, 2), (3, 2), (4, 1)])
+def test_pipeline_buffer_rotation(H, depth, side_streams):
+    """h2r_pipeline_create_ex: seven calls rotating through `depth` buffer sets.  The contract under test: when call
+    k returns, the caller's stream is ordered after the records of call k - depth + 1, so the set about to be reused
+    can be copied out (stream-ordered) right before the next call overwrites it.  Every copy must equal the oracle."""
+    chip = H.BigIntChip(64, 2048)
+    o = Oracle(64, 32)
+    pipe = H.Pipeline(chip, depth=depth, side_streams=side_streams)
+    pl = chip.pow_fixed_layout(65537)
+    rng = random.Random(77 + depth)
+    B, CALLS = 64, 7
+    sets = [dict(trace=torch.empty(B * pl.elem_stride, dtype=torch.uint8, device="cuda"),
+                 ws=torch.empty(chip.workspace_bytes(B, pl.num_mul_mods), dtype=torch.uint8, device="cuda"),
+                 out=torch.empty((B, 32), dtype=torch.int64, device="cuda"),
+                 status=torch.zeros(B, dtype=torch.uint8, device="cuda")) for _ in range(depth)]
+    inputs, snaps = [], {}
+    for k in range(CALLS):
+        N = [rand_modulus(rng, 2048) for _ in range(B)]
+        X = [rng.randrange(n) for n in N]
+        inputs.append((N, X, chip.assign_integer(N), chip.assign_integer(X)))
+        s = sets[k % depth]
+        if k >= depth:   # copy call k-depth's results out before its buffers are reused
+            snaps[k - depth] = (s["trace"].clone(), s["out"].clone(), s["status"].clone())
+        pipe.modpow_public_key(inputs[k][3], 65537, inputs[k][2], s["trace"], s["ws"], s["out"], s["status"])
+    pipe.join()
+    for k in range(CALLS - depth, CALLS):
+        s = sets[k % depth]
+        snaps[k] = (s["trace"].clone(), s["out"].clone(), s["status"].clone())
+    torch.cuda.synchronize()
+    for k in range(CALLS):
+        N, X = inputs[k][0], inputs[k][1]
+        trace, out, status = snaps[k]
+        assert not status.cpu().numpy().any()
+        got = H.AssignedInteger(out, 64).to_big_uint()
+        assert all(got[i] == pow(X[i], 65537, N[i]) for i in range(B)), k
+        tr = H.Trace(chip, trace, B, pl)
+        for i in (0, 17, B - 1):
+            rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(X[i]), o.limbs(N[i]), 65537)
+            assert np.array_equal(ost, tr.flatten(i)), (k, i)
+    pipe.close()
+    # shape errors where the C ABI defines them
+    bad = ctypes.c_void_p()
+    assert H.lib().h2r_pipeline_create_ex(chip._ctx, 1, 1, ctypes.byref(bad)) == H.H2R_E_SHAPE
+    assert H.lib().h2r_pipeline_create_ex(chip._ctx, 2, 3, ctypes.byref(bad)) == H.H2R_E_SHAPE
 
 
 def _check_pow_batch(H, chip, o, X, N, e, res, sample, rng):

@@ -9,6 +9,6 @@ for v in vals:
     try:
         d = json.loads(out.stdout.strip().splitlines()[-1])
         r = d["roofline"]
-        print("%s=%-8s step_ms %.4f value %.0f trace_ms %s (%s GB/s) chain_ms %s" % (var, v, d["ms_per_step"], d["value"], r["avg_launch_ms"], r["achieved"], r["chain_kernel_avg_ms"]), flush=True)
+        print("%s=%-8s step_ms %.4f value %.0f trace_ms %s (%s GB/s) chain_ms %s %s" % (var, v, d["ms_per_step"], d["value"], r["avg_launch_ms"], r["achieved"], r["chain_kernel_avg_ms"], " ".join(rest)), flush=True)
     except Exception as e:
         print(var, v, "FAILED", out.stderr[-300:])
