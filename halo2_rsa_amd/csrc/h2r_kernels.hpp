@@ -785,6 +785,13 @@ template <> struct ColAcc<32> {
     __device__ __forceinline__ Wide<32> wide() const { Wide<32> r; r.lo = ((u128)lo1() << 64) | lo0(); return r; }
 };
 
+// Timing experiments (tools/ablate.sh, developer build -DH2R_ABLATION): skip parts of the kernel at run time.
+#ifdef H2R_ABLATION
+#define H2R_ABLATE(bit_) ((args.ablate & (bit_)) != 0)
+#else
+#define H2R_ABLATE(bit_) false
+#endif
+
 template <int LW, int L>
 __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
     using limb_t = typename LimbT<LW>::type;
@@ -842,10 +849,10 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
     // A[s] * B[(i-s) mod L], so every product a[j]*b[k] is visited once, in ascending j per column.
     ColAcc<LW> acc, first;
     acc.clear(); first.clear();
-    if (prod && !(args.ablate & 2)) {
+    if (prod && !H2R_ABLATE(2)) {
         // accumulator addressing (h2r.h): planar rows, or interleaved [ab half | qn half] rows with a shared HI row
         const u64 lo_group = args.acc_lo_group, hi_group = args.acc_hi_group, lo_row = args.acc_lo_row;
-        const bool two = args.acc_spg == 2;
+        constexpr bool two = LW == 64;   // layout_compute: interleaved rows, two steps per group, iff the HI word exists
         u8 *plo = rec + off[h == 0 ? H2R_PL_AB_LO : H2R_PL_QN_LO] + (u64)i * 16;
         u8 *phi = rec + off[h == 0 ? H2R_PL_AB_HI : H2R_PL_QN_HI] + (u64)i * 16;
         const limb_t *Ah = s.A[h], *Bh = s.B[h];
@@ -854,10 +861,10 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
 #pragma unroll 4
         for (int st = 0; st < L; ++st) {
             limb_t xn, yn;
-            if (args.ablate & 4) { xn = x + 3; yn = y ^ (limb_t)st; }
+            if (H2R_ABLATE(4)) { xn = x + 3; yn = y ^ (limb_t)st; }
             else { xn = Ah[(st + 1) & (L - 1)]; yn = Bh[(i - st - 1) & (L - 1)]; }  // prefetch next step
             acc.keep_if(st != i + 1);       // column i is complete: start column i+L from zero
-            if (args.ablate & 8) { acc.w[0] += (u32)x; acc.w[1] ^= (u32)y; }
+            if (H2R_ABLATE(8)) { acc.w[0] += (u32)x; acc.w[1] ^= (u32)y; }
             else acc.add_product(x, y);
             const u64 lo_off = two ? (u64)(st >> 1) * lo_group + (u64)(st & 1) * lo_row : (u64)st * lo_group;
             st16(plo + lo_off, acc.lo0(), acc.lo1());
@@ -889,7 +896,7 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
         }
     }
     item_sync();
-    if ((args.ablate & 1) || mode == TRACE_MUL) return;
+    if (H2R_ABLATE(1) || mode == TRACE_MUL) return;
 
     // ---- BigIntChip::is_equal_muled (chip.rs:822-895): thread t = column c -------------------------
     // Thread 2L-1 has no column; it still stores (zeros) so that every store instruction of this
