@@ -34,6 +34,7 @@ struct ProfRec { u32 kernel; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;
 u32 g_prof_cap = 0;
+u32 g_prof_gen = 0;   // bumped whenever the recorded events are destroyed (h2r_profile_enable)
 struct ProfScope {  // start/stop events of one launch when profiling is armed
     // ext == false: the events are recorded around the launch (two marker packets on the stream).
     // ext == true:  the caller hands a/b to hipExtLaunchKernelGGL, which stamps them from the dispatch packet's own
@@ -54,6 +55,10 @@ struct ProfScope {  // start/stop events of one launch when profiling is armed
         g_prof.push_back(ProfRec{kernel, a, b});
     }
 };
+
+// The event a pipeline waits on for one call's record kernel.  With the profiler armed it is the profiler's own
+// stop event (borrowed; alive while g_prof_gen == gen), so that no extra marker packet sits between kernels.
+struct DoneRef { hipEvent_t ev = nullptr; u32 gen = 0; bool borrowed = false; };
 
 struct Workspace {  // carve-up of the scratch of one batch call
     u64 opA, opB, opQ, opR, total;
@@ -179,7 +184,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
                  u32 e_num_limbs, u32 exp_limb_bits, const ExpBits *eb, u32 check_in_field, u64 batch, u32 flags,
                  u32 T, void *trace, u64 elem_stride, u64 off_records, const h2r_pow_layout *pl, void *out,
                  uint8_t *status, void *workspace, hipStream_t st, hipStream_t trace_st = nullptr,
-                 hipEvent_t chain_done = nullptr, hipEvent_t trace_done = nullptr) {
+                 hipEvent_t chain_done = nullptr, hipEvent_t trace_done = nullptr, DoneRef *done_ref = nullptr) {
     // trace_st != nullptr (pipeline mode): the record-writing kernel runs on trace_st after `chain_done`
     if (!c || !n || !a || !status) return H2R_E_NULL;
     if (trace_st && !workspace) return H2R_E_NULL;
@@ -218,30 +223,25 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
     }
     if (eb) ca.e = *eb;
     if (const char *pr = std::getenv("H2R_CHAIN_PRIO")) ca.prio = (u32)std::atoi(pr);
-    bool chain_done_folded = false;
+    // Pipeline mode: the record stream must wait for this chain kernel.  The event it waits on is the dispatch's own
+    // stop event (the profiler's when armed, else chain_done) -- no separate marker packet.
+    hipEvent_t chain_wait = nullptr;
 #ifdef H2R_CHAIN_TIMING   // developer build (tools/chain_timing.py): dump block 0's s_memtime stamps
     static u64 *dbg_buf = nullptr;
     if (std::getenv("H2R_CHAIN_TIMING")) { if (!dbg_buf) (void)hipMalloc(&dbg_buf, 4096 * 8); (void)hipMemsetAsync(dbg_buf, 0, 4096 * 8, st); ca.dbg_time = dbg_buf; }
+#endif
     {
-        // stop event of the dispatch: the profiler's when armed, else (pipeline mode) chain_done itself
         ProfScope ps(H2R_KERNEL_CHAIN, st, true);
-        const bool fold = !ps.on && trace_st && trace && T;
-        HIP_TRY(launch_chain(c->K, ca, st, ps.a, ps.on ? ps.b : (fold ? chain_done : nullptr)));
-        chain_done_folded = fold;
+        const bool piped = trace_st && trace && T;
+        chain_wait = ps.on ? ps.b : (piped ? chain_done : nullptr);
+        HIP_TRY(launch_chain(c->K, ca, st, ps.a, chain_wait));
     }
+#ifdef H2R_CHAIN_TIMING
     if (ca.dbg_time) {
         static u64 host[4096];
         (void)hipStreamSynchronize(st); (void)hipMemcpy(host, ca.dbg_time, sizeof host, hipMemcpyDeviceToHost);
         FILE *f = std::fopen("/tmp/h2r_chain_timing.txt", "w");
         if (f) { for (int i = 0; i < 4000 && host[i]; ++i) std::fprintf(f, "%llu\n", (unsigned long long)host[i]); std::fclose(f); }
-    }
-#else
-    {
-        // stop event of the dispatch: the profiler's when armed, else (pipeline mode) chain_done itself
-        ProfScope ps(H2R_KERNEL_CHAIN, st, true);
-        const bool fold = !ps.on && trace_st && trace && T;
-        HIP_TRY(launch_chain(c->K, ca, st, ps.a, ps.on ? ps.b : (fold ? chain_done : nullptr)));
-        chain_done_folded = fold;
     }
 #endif
     if (trace && T) {
@@ -257,14 +257,17 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
             // stream does not need full occupancy) 
             // (measured sweep: profiles/r01_pipeline_sweep.txt -- 32000 B extra LDS = 3 blocks/CU, normal priority)
             if (!std::getenv("H2R_TRACE_DYN_LDS")) ta.dyn_lds = 32000;
-            if (!chain_done_folded) HIP_TRY(hipEventRecord(chain_done, st));
-            HIP_TRY(hipStreamWaitEvent(trace_st, chain_done, 0));
+            HIP_TRY(hipStreamWaitEvent(trace_st, chain_wait, 0));
             ts = trace_st;
         }
         ProfScope ps(H2R_KERNEL_TRACE, ts, true);
-        const bool fold = !ps.on && trace_done;
-        HIP_TRY(launch_trace(lo.limb_width, c->L, ta, ts, ps.a, ps.on ? ps.b : (fold ? trace_done : nullptr)));
-        if (trace_done && !fold) HIP_TRY(hipEventRecord(trace_done, ts));
+        HIP_TRY(launch_trace(lo.limb_width, c->L, ta, ts, ps.a, ps.on ? ps.b : trace_done));
+        if (done_ref) {
+            if (ps.on) { std::lock_guard<std::mutex> lk(g_prof_mu); *done_ref = DoneRef{ps.b, g_prof_gen, true}; }
+            else *done_ref = DoneRef{trace_done, 0, false};
+        }
+    } else if (done_ref) {
+        *done_ref = DoneRef{};
     }
     return H2R_OK;
 }
@@ -551,6 +554,8 @@ struct h2r_pipeline {
     enum { MAX_DEPTH = 4 };
     u32 depth;        // buffer sets the caller rotates through: call k may reuse call k-depth's buffers
     hipEvent_t chain_done[MAX_DEPTH], trace_done[MAX_DEPTH];
+    DoneRef done[MAX_DEPTH];   // what marks the end of the record kernel of the call in each slot
+    hipStream_t done_stream[MAX_DEPTH];
     u32 k;            // calls issued
     u32 joined;       // calls whose record kernel the user stream has been ordered after
 };
@@ -593,10 +598,30 @@ void h2r_pipeline_destroy(h2r_pipeline *p) {
     delete p;
 }
 
+namespace {
+// Order `st` after the record kernel of the call in `slot`.
+int32_t pipeline_wait_slot(h2r_pipeline *p, u32 slot, hipStream_t st) {
+    DoneRef &d = p->done[slot];
+    if (!d.ev) return H2R_OK;   // that call launched no record kernel
+    bool alive = true;
+    if (d.borrowed) { std::lock_guard<std::mutex> lk(g_prof_mu); alive = d.gen == g_prof_gen; }
+    if (!alive) {
+        // the profiler's events were released in between: fall back to the tail of that record stream, which is
+        // behind the kernel in question (over-synchronises, never under-synchronises)
+        HIP_TRY(hipEventRecord(p->trace_done[slot], p->done_stream[slot]));
+        d = DoneRef{p->trace_done[slot], 0, false};
+    }
+    HIP_TRY(hipStreamWaitEvent(st, d.ev, 0));
+    return H2R_OK;
+}
+}  // namespace
+
 int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream) {
     if (!p) return H2R_E_NULL;
-    for (; p->joined < p->k; ++p->joined)
-        HIP_TRY(hipStreamWaitEvent(static_cast<hipStream_t>(stream), p->trace_done[p->joined % p->depth], 0));
+    for (; p->joined < p->k; ++p->joined) {
+        const int32_t rc = pipeline_wait_slot(p, p->joined % p->depth, static_cast<hipStream_t>(stream));
+        if (rc) return rc;
+    }
     return H2R_OK;
 }
 
@@ -613,14 +638,18 @@ int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const voi
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const u32 slot = p->k % p->depth;
+    p->done[slot] = DoneRef{};
     rc = run_path(ctx, CHAIN_POW_FIXED, x, nullptr, n, nullptr, 0, 0, &eb, 1, batch, flags, T, trace, pl.elem_stride,
-                  pl.off_records, &pl, out, status, workspace, st, p->aux[p->k & 1], p->chain_done[slot], p->trace_done[slot]);
+                  pl.off_records, &pl, out, status, workspace, st, p->aux[p->k & 1], p->chain_done[slot], p->trace_done[slot], &p->done[slot]);
     if (rc) return rc;
+    p->done_stream[slot] = p->aux[p->k & 1];
     p->k += 1;
     // lazy join: the NEXT call reuses the buffers of call k - depth, so order the user stream after that call's
     // record kernel now -- behind this call's chain kernel, which therefore overlaps the record kernels in flight
-    for (; p->joined + p->depth <= p->k; ++p->joined)
-        HIP_TRY(hipStreamWaitEvent(st, p->trace_done[p->joined % p->depth], 0));
+    for (; p->joined + p->depth <= p->k; ++p->joined) {
+        rc = pipeline_wait_slot(p, p->joined % p->depth, st);
+        if (rc) return rc;
+    }
     return H2R_OK;
 }
 
@@ -945,6 +974,7 @@ int32_t h2r_profile_enable(uint32_t capacity) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
+    ++g_prof_gen;
     g_prof_cap = capacity;
     if (capacity) g_prof.reserve(capacity);
     return H2R_OK;

@@ -487,11 +487,15 @@ def test_pipelined_calls_match_oracle(H):
     pipe.close()
 
 
-@pytest.mark.parametrize("depth,side_streams", [(2, 1), (2, 2), (3, 2), (4, 1)])
-def test_pipeline_buffer_rotation(H, depth, side_streams):
+@pytest.mark.parametrize("depth,side_streams,toggle_profiler", [(2, 1, False), (2, 2, False), (3, 2, False), (4, 1, False),
+                                                              (2, 1, True), (3, 2, True)])
+def test_pipeline_buffer_rotation(H, depth, side_streams, toggle_profiler):
     """h2r_pipeline_create_ex: seven calls rotating through `depth` buffer sets.  The contract under test: when call
     k returns, the caller's stream is ordered after the records of call k - depth + 1, so the set about to be reused
-    can be copied out (stream-ordered) right before the next call overwrites it.  Every copy must equal the oracle."""
+    can be copied out (stream-ordered) right before the next call overwrites it.  Every copy must equal the oracle.
+    toggle_profiler: the per-kernel event profiler is armed, released and exhausted between calls -- the pipeline
+    borrows the profiler's stop events while it is armed and must survive their release."""
+    from halo2_rsa_amd import _lib
     chip = H.BigIntChip(64, 2048)
     o = Oracle(64, 32)
     pipe = H.Pipeline(chip, depth=depth, side_streams=side_streams)
@@ -510,7 +514,16 @@ def test_pipeline_buffer_rotation(H, depth, side_streams):
         s = sets[k % depth]
         if k >= depth:   # copy call k-depth's results out before its buffers are reused
             snaps[k - depth] = (s["trace"].clone(), s["out"].clone(), s["status"].clone())
+        if toggle_profiler:
+            if k == 1:
+                _lib.profile_enable(64)
+            if k == 3:
+                _lib.profile_enable(0)      # releases the events calls 1 and 2 lent to the pipeline
+            if k == 4:
+                _lib.profile_enable(3)      # runs out of capacity in the middle of call 5
         pipe.modpow_public_key(inputs[k][3], 65537, inputs[k][2], s["trace"], s["ws"], s["out"], s["status"])
+    if toggle_profiler:
+        _lib.profile_enable(0)
     pipe.join()
     for k in range(CALLS - depth, CALLS):
         s = sets[k % depth]
