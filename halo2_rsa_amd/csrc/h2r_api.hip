@@ -61,12 +61,12 @@ struct ProfScope {  // start/stop events of one launch when profiling is armed
 struct DoneRef { hipEvent_t ev = nullptr; u32 gen = 0; bool borrowed = false; };
 
 struct Workspace {  // carve-up of the scratch of one batch call
-    u64 opA, opB, opQ, opR, total;
+    u64 total;   // one [batch * T][4][L] limb array: a, b, q, r of every mul_mod
 };
 Workspace workspace_plan(u32 limb_bytes, u32 L, u64 batch, u32 T) {
     Workspace w;
     const u64 arr = round_up(batch * T * (u64)L * limb_bytes, 256);
-    w.opA = 0; w.opB = arr; w.opQ = 2 * arr; w.opR = 3 * arr; w.total = 4 * arr + 256;
+    w.total = 4 * arr + 256;
     return w;
 }
 
@@ -212,8 +212,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
     ca.batch = batch; ca.mode = mode; ca.T = T ? T : 1;
     ca.e_num_limbs = e_num_limbs; ca.exp_limb_bits = exp_limb_bits; ca.digits_per_limb = lo.limb_width / 32;
     ca.check_in_field = check_in_field;
-    ca.opA = reinterpret_cast<u32 *>(ws + wp.opA); ca.opB = reinterpret_cast<u32 *>(ws + wp.opB);
-    ca.opQ = reinterpret_cast<u32 *>(ws + wp.opQ); ca.opR = reinterpret_cast<u32 *>(ws + wp.opR);
+    ca.ops = reinterpret_cast<u32 *>(ws);
     ca.out = static_cast<u32 *>(out); ca.status = status;
     if (pl && trace) {
         ca.trace = static_cast<u8 *>(trace); ca.elem_stride = elem_stride;
@@ -247,7 +246,8 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
     if (trace && T) {
         TraceArgs ta;
         fill_trace_args(c, ta);
-        ta.opA = ca.opA; ta.opB = ca.opB; ta.opQ = ca.opQ; ta.opR = ca.opR;
+        const u64 lb = lo.limb_width / 8;   // the four values of an item are L limbs apart
+        ta.opA = ws; ta.opB = ws + c->L * lb; ta.opQ = ws + 2 * c->L * lb; ta.opR = ws + 3 * c->L * lb; ta.op_stride = 4ull * c->L;
         ta.n = n; ta.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : c->L;
         ta.status = status; ta.n_items = batch * T; ta.T = T;
         ta.trace = static_cast<u8 *>(trace); ta.elem_stride = elem_stride; ta.off_records = off_records;
@@ -885,7 +885,7 @@ int32_t h2r_mul_batch(const h2r_ctx *ctx, const void *a, const void *b, uint64_t
     if (batch >= (1ull << 32)) return H2R_E_UNSUPPORTED;
     TraceArgs ta;
     fill_trace_args(ctx, ta);
-    ta.mode = TRACE_MUL; ta.opA = a; ta.opB = b; ta.n_items = batch; ta.T = 1;
+    ta.mode = TRACE_MUL; ta.opA = a; ta.opB = b; ta.op_stride = ctx->L; ta.n_items = batch; ta.T = 1;
     ta.trace = static_cast<u8 *>(trace); ta.elem_stride = ctx->layout.record_stride; ta.off_records = 0;
     ta.muled_out = muled_out;
     HIP_TRY(hipSetDevice(ctx->params.device));

@@ -72,7 +72,7 @@ struct ChainArgs {
     u32 mode, T;         // T = mul_mods per element
     u32 e_num_limbs, exp_limb_bits, digits_per_limb;
     u32 check_in_field;  // modpow_public_key: status NOT_IN_FIELD when x >= n (src/chip.rs:106)
-    u32 *opA, *opB, *opQ, *opR;  // [elem*T + t][K]
+    u32 *ops;            // [elem*T + t][4][K]: a, b, q, r of every mul_mod (one contiguous 16K-byte run per item)
     u32 *out;            // nullable: result [elem][K]
     u8 *status;          // [elem]
     // POW_VAR extras written straight into the element traces
@@ -108,6 +108,7 @@ struct ChainLds {
     u32 part[Geo<K, NW>::SSMAX][3][2 * K];  // per-slice column partial sums (3 words)
     u32 x0[2 * K + 4], x1[2 * K + 4], x2[2 * K + 4];  // reduced columns; also shift scratch
     u32 rx0[K + 1], rx1[K + 1];          // wave-0 scratch of the reciprocal
+    alignas(16) u32 stage[4 * K];        // a, b, q, r of one mul_mod on their way to the ops buffer
     u64 *dbg; u32 dbg_n;                 // debug timing (nullable)
 };
 
@@ -577,8 +578,14 @@ __global__ __launch_bounds__(64 * NW, (K <= 64 ? H2R_CHAIN_MINB : H2R_CHAIN_MINB
     auto emit = [&](u32 t, const u32 (&oa)[V], const u32 (&ob)[V]) {
         if (w0 && status == H2R_OK) {
             const u64 it = item0 + t;
-            glb_store<K>(args.opA + it * K, oa, lane); glb_store<K>(args.opB + it * K, ob, lane);
-            glb_store<K>(args.opQ + it * K, q, lane); glb_store<K>(args.opR + it * K, r, lane);
+            // staged through LDS so that the four K-digit values leave as 16-byte stores (one instruction for K = 64):
+            // a store instruction of this wave queues behind the co-running record kernel's stores, so fewer is faster
+            wave_sync();
+            lds_store<K>(s.stage, oa, lane); lds_store<K>(s.stage + K, ob, lane);
+            lds_store<K>(s.stage + 2 * K, q, lane); lds_store<K>(s.stage + 3 * K, r, lane);
+            wave_sync();
+            uint4 *dst = reinterpret_cast<uint4 *>(args.ops + it * (4 * K));
+            for (int v = lane; v < K; v += 64) dst[v] = reinterpret_cast<const uint4 *>(s.stage)[v];
         }
     };
     auto fold = [&](int st) { if (st != H2R_OK && status == H2R_OK) status = st; };
@@ -677,7 +684,8 @@ template <> struct Wide<32> {
 enum { TRACE_FULL = 0, TRACE_MUL = 1, TRACE_EQ = 2 };
 
 struct TraceArgs {
-    const void *opA, *opB, *opQ, *opR;  // [item][L] limbs
+    const void *opA, *opB, *opQ, *opR;  // limbs of item k at [k * op_stride, k * op_stride + L)
+    u64 op_stride;                      // L for caller-owned arrays, 4L inside the chain kernel's ops buffer
     const void *n;                      // [elem][L] limbs
     u64 n_stride;                       // limbs between moduli (0 = shared)
     const u8 *status;                   // [elem]; nonzero => skip the element's items
@@ -826,17 +834,18 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
     const bool prod = live && mode != TRACE_EQ && (mode == TRACE_FULL || h == 0);   // this thread runs a product column
     // ---- stage operands in LDS; emit q, r and their sub-limbs (chip.rs:588-599) -------------------
     if (live && mode == TRACE_MUL && h == 0) {   // BigIntChip::mul(a, b) alone: only the a*b half is active
-        s.A[0][i] = reinterpret_cast<const limb_t *>(args.opA)[(u64)item * L + i];
-        s.B[0][i] = reinterpret_cast<const limb_t *>(args.opB)[(u64)item * L + i];
+        s.A[0][i] = reinterpret_cast<const limb_t *>(args.opA)[(u64)item * args.op_stride + i];
+        s.B[0][i] = reinterpret_cast<const limb_t *>(args.opB)[(u64)item * args.op_stride + i];
     }
     if (live && mode == TRACE_FULL) {
-        const limb_t *gQ = reinterpret_cast<const limb_t *>(args.opQ) + (u64)item * L;
-        const limb_t *gA = h == 0 ? reinterpret_cast<const limb_t *>(args.opA) + (u64)item * L : gQ;
-        const limb_t *gB = h == 0 ? reinterpret_cast<const limb_t *>(args.opB) + (u64)item * L
+        const u64 ib = (u64)item * args.op_stride;
+        const limb_t *gQ = reinterpret_cast<const limb_t *>(args.opQ) + ib;
+        const limb_t *gA = h == 0 ? reinterpret_cast<const limb_t *>(args.opA) + ib : gQ;
+        const limb_t *gB = h == 0 ? reinterpret_cast<const limb_t *>(args.opB) + ib
                                   : reinterpret_cast<const limb_t *>(args.n) + elem * args.n_stride;
         const limb_t av = gA[i], bv = gB[i];
         // half 0 emits q and its sub-limbs, half 1 emits r (each store instruction covers both planes)
-        const limb_t ov = h == 0 ? gQ[i] : reinterpret_cast<const limb_t *>(args.opR)[(u64)item * L + i];
+        const limb_t ov = h == 0 ? gQ[i] : reinterpret_cast<const limb_t *>(args.opR)[ib + i];
         s.A[h][i] = av; s.B[h][i] = bv;
         if (h == 1) s.r[i] = ov;
         store_limb<LW>(rec, off, h == 0 ? H2R_PL_Q : H2R_PL_R, i, ov);
