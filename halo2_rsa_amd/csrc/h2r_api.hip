@@ -139,22 +139,31 @@ hipError_t launch_trace(u32 w, u32 L, const TraceArgs &ta, hipStream_t st, hipEv
 #undef H2R_CASE
     return hipErrorInvalidValue;
 }
-template <int K, int NW>
+template <int K, int NW, bool DEEP>
 hipError_t launch_chain_t(const ChainArgs &ca, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
     if (ca.batch == 0) return hipSuccess;
-    hipExtLaunchKernelGGL((chain_kernel<K, NW>), dim3((unsigned)ca.batch), dim3(64 * NW), 0, st, ea, eb, 0, ca);
+    hipExtLaunchKernelGGL((chain_kernel<K, NW, DEEP>), dim3((unsigned)ca.batch), dim3(64 * NW), 0, st, ea, eb, 0, ca);
     return hipGetLastError();
 }
 hipError_t launch_chain(u32 K, const ChainArgs &ca, hipStream_t st, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr) {
     switch (K) {  // NW = waves per element (multiple of the number of 64-column groups of the product)
-        case 8: return launch_chain_t<8, 1>(ca, st, ea, eb);
-        case 16: return launch_chain_t<16, 1>(ca, st, ea, eb);
-        case 32: return launch_chain_t<32, 4>(ca, st, ea, eb);
-        case 64: { static const int nw = std::getenv("H2R_CHAIN_NW") ? std::atoi(std::getenv("H2R_CHAIN_NW")) : 4;  // 4 measured best (profiles/r01_notes)
-                   if (nw == 8) return launch_chain_t<64, 8>(ca, st, ea, eb);
-                   if (nw == 2) return launch_chain_t<64, 2>(ca, st, ea, eb);
-                   return launch_chain_t<64, 4>(ca, st, ea, eb); }
-        case 128: return launch_chain_t<128, 8>(ca, st, ea, eb);
+        case 8: return launch_chain_t<8, 1, false>(ca, st, ea, eb);
+        case 16: return launch_chain_t<16, 1, false>(ca, st, ea, eb);
+        case 32: return launch_chain_t<32, 4, false>(ca, st, ea, eb);
+        case 64: {
+            // Throughput build (6 blocks per CU) when the batch fills the chip; latency build (deep operand prefetch,
+            // 139 VGPRs) when there are at most two elements per CU and each chain's own latency is what the call
+            // waits for (BASELINE config 5: 256 elements x 3,072 dependent mul_mods: 9.4 -> 7.8 ms, tools/c5_sweep.sh).
+            static const int nw_env = std::getenv("H2R_CHAIN_NW") ? std::atoi(std::getenv("H2R_CHAIN_NW")) : 0;
+            static const int deep_env = std::getenv("H2R_CHAIN_DEEP") ? std::atoi(std::getenv("H2R_CHAIN_DEEP")) : -1;
+            const bool small = ca.batch <= 512;
+            const int nw = nw_env ? nw_env : 4;
+            const bool deep = deep_env >= 0 ? deep_env != 0 : small;
+            if (nw == 8) return deep ? launch_chain_t<64, 8, true>(ca, st, ea, eb) : launch_chain_t<64, 8, false>(ca, st, ea, eb);
+            if (nw == 2) return launch_chain_t<64, 2, false>(ca, st, ea, eb);
+            return deep ? launch_chain_t<64, 4, true>(ca, st, ea, eb) : launch_chain_t<64, 4, false>(ca, st, ea, eb);
+        }
+        case 128: return launch_chain_t<128, 8, false>(ca, st, ea, eb);
         default: return hipErrorInvalidValue;
     }
 }

@@ -141,7 +141,7 @@ enum { MUL_FULL = 0, MUL_HIGH = 1, MUL_LOW = 2 };
 #define H2R_CHAIN_MINB 6   // blocks per CU the register budget is sized for (K <= 64): 79 VGPRs, no scratch (8 => 64 VGPRs + spills whose reloads wait on vmcnt(0))
 #endif
 
-template <int K, int NW, int MODE>
+template <int K, int NW, int MODE, bool DEEP>
 __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLds<K, NW> &s, int lane, int wave,
                                           u32 (&plo)[Geo<K, NW>::V], u32 (&phi)[Geo<K, NW>::V], u32 &dk) {
     using G = Geo<K, NW>;
@@ -163,26 +163,77 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
         u32 ov = 0;
         const u32 *bp = Bpad + K + c - j0;
         const u32 *ap = A + j0;
-        // acc(64) += a*b with the multiplier's own carry-out feeding the overflow word: 2 VALU per product
-        // (v_mad_u64_u32 writes the carry to an SGPR pair; gfx950 needs 2 wait states before a VALU reads it).
-        // Tried and measured slower on the same box (tools/ab_chain.sh): four independent accumulators with
-        // operands preloaded 16 products ahead (4 x mad then 4 x addc, no s_nop) -- 0.117 vs 0.110 ms alone and
-        // 0.339 vs 0.279 ms pipelined, because it needs 128 VGPRs and halves the waves that hide LDS latency.
-        auto mac = [&](u32 av, u32 bv) {
-            u64 carry;
-            asm volatile("v_mad_u64_u32 %0, %2, %3, %4, %0\n\ts_nop 1\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2"
-                         : "+v"(acc), "+v"(ov), "=&s"(carry) : "v"(av), "v"(bv));
-        };
-        if constexpr (SLA % 4 == 0) {
-#pragma unroll 2
-            for (int j = 0; j < SLA; j += 4) {
-                const uint4 a4 = *reinterpret_cast<const uint4 *>(ap + j);  // broadcast 16-byte read
-                const u32 b0 = bp[-j], b1 = bp[-j - 1], b2 = bp[-j - 2], b3 = bp[-j - 3];
-                mac(a4.x, b0); mac(a4.y, b1); mac(a4.z, b2); mac(a4.w, b3);
-            }
-        } else {
+        if constexpr (DEEP && SLA % 4 == 0) {
+            // Latency build: one wave per SIMD, so nothing hides the LDS round trip but this wave's own instructions.
+            // Operands are preloaded CH products ahead (double buffered) and four independent accumulators advance by
+            // 4 x v_mad_u64_u32 followed by their 4 x v_addc (which also covers the VALU-writes-SGPR hazard).
+            u64 acc4[4] = {0, 0, 0, 0};
+            u32 ov4[4] = {0, 0, 0, 0};
+            auto mac4 = [&](const uint4 &av, u32 b0, u32 b1, u32 b2, u32 b3) {
+                u64 c0, c1, c2, c3;
+                asm volatile(
+                    "v_mad_u64_u32 %0, %8, %12, %16, %0\n\t"
+                    "v_mad_u64_u32 %1, %9, %13, %17, %1\n\t"
+                    "v_mad_u64_u32 %2, %10, %14, %18, %2\n\t"
+                    "v_mad_u64_u32 %3, %11, %15, %19, %3\n\t"
+                    "v_addc_co_u32_e64 %4, %8, 0, %4, %8\n\t"
+                    "v_addc_co_u32_e64 %5, %9, 0, %5, %9\n\t"
+                    "v_addc_co_u32_e64 %6, %10, 0, %6, %10\n\t"
+                    "v_addc_co_u32_e64 %7, %11, 0, %7, %11"
+                    : "+v"(acc4[0]), "+v"(acc4[1]), "+v"(acc4[2]), "+v"(acc4[3]), "+v"(ov4[0]), "+v"(ov4[1]), "+v"(ov4[2]), "+v"(ov4[3]),
+                      "=&s"(c0), "=&s"(c1), "=&s"(c2), "=&s"(c3)
+                    : "v"(av.x), "v"(av.y), "v"(av.z), "v"(av.w), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+            };
+            constexpr int CH = SLA < 16 ? SLA : 16;   // products per preloaded chunk
+            uint4 ac[CH / 4]; u32 bc[CH];
 #pragma unroll
-            for (int j = 0; j < SLA; ++j) mac(ap[j], bp[-j]);
+            for (int q = 0; q < CH / 4; ++q) ac[q] = *reinterpret_cast<const uint4 *>(ap + 4 * q);   // broadcast 16-byte reads
+#pragma unroll
+            for (int q = 0; q < CH; ++q) bc[q] = bp[-q];
+#pragma unroll
+            for (int ch = 0; ch < SLA / CH; ++ch) {
+                uint4 an[CH / 4]; u32 bn[CH];
+                if (ch + 1 < SLA / CH) {   // prefetch the next chunk before consuming this one
+#pragma unroll
+                    for (int q = 0; q < CH / 4; ++q) an[q] = *reinterpret_cast<const uint4 *>(ap + (ch + 1) * CH + 4 * q);
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) bn[q] = bp[-(ch + 1) * CH - q];
+                }
+#pragma unroll
+                for (int q = 0; q < CH / 4; ++q) mac4(ac[q], bc[4 * q], bc[4 * q + 1], bc[4 * q + 2], bc[4 * q + 3]);
+                if (ch + 1 < SLA / CH) {
+#pragma unroll
+                    for (int q = 0; q < CH / 4; ++q) ac[q] = an[q];
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) bc[q] = bn[q];
+                }
+            }
+            acc = acc4[0];
+            ov = ov4[0] + ov4[1] + ov4[2] + ov4[3];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) { acc += acc4[k]; ov += (acc < acc4[k]) ? 1u : 0u; }
+        } else {
+            // acc(64) += a*b with the multiplier's own carry-out feeding the overflow word: 2 VALU per product
+            // (v_mad_u64_u32 writes the carry to an SGPR pair; gfx950 needs 2 wait states before a VALU reads it).
+            // Tried and measured slower on the same box (tools/ab_chain.sh): four independent accumulators with
+            // operands preloaded 16 products ahead (4 x mad then 4 x addc, no s_nop) -- 0.117 vs 0.110 ms alone and
+            // 0.339 vs 0.279 ms pipelined, because it needs 128 VGPRs and halves the waves that hide LDS latency.
+            auto mac = [&](u32 av, u32 bv) {
+                u64 carry;
+                asm volatile("v_mad_u64_u32 %0, %2, %3, %4, %0\n\ts_nop 1\n\tv_addc_co_u32_e64 %1, %2, 0, %1, %2"
+                             : "+v"(acc), "+v"(ov), "=&s"(carry) : "v"(av), "v"(bv));
+            };
+            if constexpr (SLA % 4 == 0) {
+#pragma unroll 2
+                for (int j = 0; j < SLA; j += 4) {
+                    const uint4 a4 = *reinterpret_cast<const uint4 *>(ap + j);  // broadcast 16-byte read
+                    const u32 b0 = bp[-j], b1 = bp[-j - 1], b2 = bp[-j - 2], b3 = bp[-j - 3];
+                    mac(a4.x, b0); mac(a4.y, b1); mac(a4.z, b2); mac(a4.w, b3);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < SLA; ++j) mac(ap[j], bp[-j]);
+            }
         }
         if (c < 2 * K) { s.part[ss][0][c] = (u32)acc; s.part[ss][1][c] = (u32)(acc >> 32); s.part[ss][2][c] = ov; }
         if constexpr (HALF && MODE == MUL_HIGH) {
@@ -461,7 +512,7 @@ __device__ __forceinline__ void block_shr(ChainLds<K, NW> &s, u32 sh, int lane, 
 // (q, r) = divmod(a * b, n) by Barrett reduction with the per-modulus mu'.  a, b, nn, q, r and the
 // returned status are meaningful in WAVE 0 only; every wave must call it (block barriers inside, and
 // the control flow never depends on the data).
-template <int K, int NW>
+template <int K, int NW, bool DEEP>
 __device__ __forceinline__ int block_mulmod(ChainLds<K, NW> &s, u32 shift, int lane, int wave,
                                             const u32 (&a)[Geo<K, NW>::V], const u32 (&b)[Geo<K, NW>::V],
                                             const u32 (&nn)[Geo<K, NW>::V],
@@ -474,19 +525,19 @@ __device__ __forceinline__ int block_mulmod(ChainLds<K, NW> &s, u32 shift, int l
     //  product loop of the previous block_mul, so nobody still reads them; block_mul's first barrier publishes)
     if (w0) { lds_store<K>(s.opa, a, lane); lds_store<K>(s.bpad + K, b, lane); }
     u32 dk;
-    block_mul<K, NW, MUL_FULL>(s.opa, s.bpad, s, lane, wave, xlo, xhi, dk);
+    block_mul<K, NW, MUL_FULL, DEEP>(s.opa, s.bpad, s, lane, wave, xlo, xhi, dk);
     if (shift) {  // x' = x << s  (n' = n << s); block-uniform branch
         if (block_shl2k<K, NW>(s, shift, lane, wave, xlo, xhi)) status = H2R_E_NOT_REDUCED;
     }
     // q^ = x1 + floor(x1 * mu' / 2^(32K)),  x1 = floor(x' / 2^(32K))
     if (w0) lds_store<K>(s.opa, xhi, lane);
     u32 ylo[V], yhi[V];
-    block_mul<K, NW, MUL_HIGH>(s.opa, s.mupad, s, lane, wave, ylo, yhi, dk);
+    block_mul<K, NW, MUL_HIGH, DEEP>(s.opa, s.mupad, s, lane, wave, ylo, yhi, dk);
     if (w0 && wave_add<K>(q, xhi, yhi, lane)) status = H2R_E_NOT_REDUCED;
     // R = x' - q^ * n'   (0 <= R < 7 n': q^ may be up to 6 short of the true quotient)
     if (w0) lds_store<K>(s.opa, q, lane);
     u32 zlo[V], zhi[V];
-    block_mul<K, NW, MUL_LOW>(s.opa, s.nnpad, s, lane, wave, zlo, zhi, dk);
+    block_mul<K, NW, MUL_LOW, DEEP>(s.opa, s.nnpad, s, lane, wave, zlo, zhi, dk);
     if (K < 64) dk = __shfl(zhi[0], 0);   // full product was computed: digit K is its first high digit
     u32 rl[V];
 #pragma unroll
@@ -512,8 +563,10 @@ __device__ __forceinline__ int block_mulmod(ChainLds<K, NW> &s, u32 shift, int l
     return status;
 }
 
-template <int K, int NW>
-__global__ __launch_bounds__(64 * NW, (K <= 64 ? H2R_CHAIN_MINB : H2R_CHAIN_MINB / 2)) void chain_kernel(ChainArgs args) {
+// DEEP: the latency build for small batches (about one block per CU, nothing else to hide LDS latency behind): the
+// product loop preloads its operands 16 products ahead and runs four accumulators; it needs twice the registers.
+template <int K, int NW, bool DEEP>
+__global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R_CHAIN_MINB / 2)) void chain_kernel(ChainArgs args) {
     using G = Geo<K, NW>;
     constexpr int V = G::V;
     __shared__ ChainLds<K, NW> s;
@@ -590,7 +643,7 @@ __global__ __launch_bounds__(64 * NW, (K <= 64 ? H2R_CHAIN_MINB : H2R_CHAIN_MINB
     };
     auto fold = [&](int st) { if (st != H2R_OK && status == H2R_OK) status = st; };
     if (args.mode == CHAIN_MULMOD) {
-        fold(block_mulmod<K, NW>(s, shift, lane, wave, cur, bop, nn, q, r));
+        fold(block_mulmod<K, NW, DEEP>(s, shift, lane, wave, cur, bop, nn, q, r));
         emit(0, cur, bop);
         if (w0 && status == H2R_OK && args.out) glb_store<K>(args.out + elem * K, r, lane);
     } else {
@@ -616,7 +669,7 @@ __global__ __launch_bounds__(64 * NW, (K <= 64 ? H2R_CHAIN_MINB : H2R_CHAIN_MINB
             }
             if (var) {
                 // muled = mul_mod(acc, squared) ALWAYS (:686); acc[j] = select(muled[j], acc[j], bit) (:688-691)
-                fold(block_mulmod<K, NW>(s, shift, lane, wave, acc, cur, nn, q, r));
+                fold(block_mulmod<K, NW, DEEP>(s, shift, lane, wave, acc, cur, nn, q, r));
                 emit(t, acc, cur);
                 ++t;
 #pragma unroll
@@ -625,14 +678,14 @@ __global__ __launch_bounds__(64 * NW, (K <= 64 ? H2R_CHAIN_MINB : H2R_CHAIN_MINB
                     glb_store<K>((u32 *)(etrace + args.off_selected + (u64)bi * args.selected_stride), acc, lane);
             }
             // squared = square_mod(cur) (:734 resp. :693)
-            fold(block_mulmod<K, NW>(s, shift, lane, wave, cur, cur, nn, q, r));
+            fold(block_mulmod<K, NW, DEEP>(s, shift, lane, wave, cur, cur, nn, q, r));
             emit(t, cur, cur);
             ++t;
             u32 sq[V];
 #pragma unroll
             for (int m = 0; m < V; ++m) sq[m] = r[m];
             if (!var && bit) {  // acc = mul_mod(acc, cur_sq) with the value BEFORE this squaring (:732-739)
-                fold(block_mulmod<K, NW>(s, shift, lane, wave, acc, cur, nn, q, r));
+                fold(block_mulmod<K, NW, DEEP>(s, shift, lane, wave, acc, cur, nn, q, r));
                 emit(t, acc, cur);
                 ++t;
 #pragma unroll
