@@ -584,7 +584,17 @@ int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side
     for (int i = 0; i < 2; ++i) p->aux[i] = nullptr;
     for (int i = 0; i < h2r_pipeline::MAX_DEPTH; ++i) { p->chain_done[i] = nullptr; p->trace_done[i] = nullptr; }
     bool ok = true;
-    for (int i = 0; ok && i < n_aux; ++i) ok = hip_ok(hipStreamCreateWithFlags(&p->aux[i], hipStreamNonBlocking), "hipStreamCreate");
+    // The side streams are created at the LOWEST stream priority: HIP multiplexes streams of one priority onto a
+    // few hardware queues (GPU_MAX_HW_QUEUES, default 4), and two streams that share a queue never overlap -- under
+    // torchrun, RCCL's own streams pushed the side stream onto the caller's queue and the pipeline ran serially
+    // (0.362 vs 0.257 ms/step).  Another priority level means another queue; low rather than high because the
+    // record kernel should fill what the chain kernel leaves, not the other way round (measured: tools/dist_ab.sh).
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    int prio = prio_least;
+    if (const char *pe = std::getenv("H2R_PIPE_STREAM_PRIO")) prio = !std::strcmp(pe, "high") ? prio_greatest : (!std::strcmp(pe, "low") ? prio_least : 0);
+    for (int i = 0; ok && i < n_aux; ++i)
+        ok = hip_ok(hipStreamCreateWithPriority(&p->aux[i], hipStreamNonBlocking, prio), "hipStreamCreate");
     if (ok && n_aux == 1) p->aux[1] = p->aux[0];
     for (u32 i = 0; ok && i < p->depth; ++i)
         ok = hip_ok(hipEventCreate(&p->chain_done[i]), "hipEventCreate") &&

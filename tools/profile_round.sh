@@ -1,13 +1,26 @@
 #!/bin/bash
 # Collect the per-round profile set on the GPU box into gpurun_out/prof_final (copied to profiles/ afterwards).
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_final; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_final; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 ARGS="--steps 20 --warmup 3 --no-cpu-baseline"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o r -- python $R/bench.py $ARGS > $O/kt.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_serial -o r -- python $R/bench.py $ARGS --no-pipeline > $O/kt_serial.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o r -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pipeline > $O/pmc_w.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_r -o r -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pipeline > $O/pmc_r.log 2>&1
 cd $R
+python tools/pmc_to_json.py $O 1024 > $O/pmc_traffic.json
+python tools/timeline.py $O/kt > $O/timeline_pipeline.txt
 timeout 300 python bench.py --steps 40 --warmup 4 > $O/bench_pipeline.json 2> $O/bench_pipeline.err
 timeout 300 python bench.py --steps 40 --warmup 4 --no-pipeline --no-cpu-baseline > $O/bench_serial.json 2>/dev/null
+timeout 300 python bench.py --steps 40 --warmup 4 --pipeline-depth 3 --side-streams 2 --no-cpu-baseline > $O/bench_pipeline_d3s2.json 2>/dev/null
 H2R_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err
-tail -1 $O/bench_pipeline.json | cut -c1-400; tail -1 $O/bench_serial.json | cut -c1-200; tail -1 $O/bench_torchrun1.json | cut -c1-200; tail -3 $O/bench_torchrun1.err
+{
+  echo "# other BASELINE configs, same box (tools/sweep.py lines: step, value = assigns/s, record kernel, chain kernel)"
+  python tools/sweep.py CONFIG C3-shard-8192 --batch 8192 --steps 6 --warmup 2
+  python tools/sweep.py CONFIG C3-shard-8192-serial --batch 8192 --steps 6 --warmup 2 --no-pipeline
+  python tools/sweep.py CONFIG C4-rsa4096-w32-4096 --workload rsa4096_w32_e65537 --batch 4096 --steps 4 --warmup 1
+  python tools/sweep.py CONFIG C4-rsa4096-w32-4096-serial --workload rsa4096_w32_e65537 --batch 4096 --steps 4 --warmup 1 --no-pipeline
+  python tools/sweep.py CONFIG C5-e2048bit-256 --workload rsa2048_e2048bit --batch 256 --steps 8 --warmup 2
+  python tools/sweep.py CONFIG C5-e2048bit-256-serial --workload rsa2048_e2048bit --batch 256 --steps 4 --warmup 1 --no-pipeline
+  python tools/sweep.py CONFIG rsa1024 --workload rsa1024_e65537 --steps 40 --warmup 4
+} > $O/other_configs.txt 2>&1
+tail -1 $O/bench_pipeline.json | cut -c1-600; tail -1 $O/bench_serial.json | cut -c1-200; tail -1 $O/bench_pipeline_d3s2.json | cut -c1-200; tail -1 $O/bench_torchrun1.json | cut -c1-200; tail -3 $O/bench_torchrun1.err; cat $O/other_configs.txt; cat $O/pmc_traffic.json | head -30
