@@ -220,7 +220,8 @@ int32_t h2r_modpow_public_key_batch(const h2r_ctx *ctx, const void *x, const voi
                                     void *workspace, h2r_stream_t stream);
 
 /* ---- pipelined form (opt-in): overlap batch k+1's off-circuit chain with batch k's witness emission
- * A pipeline owns a second HIP stream.  h2r_pipeline_modpow_public_key() is h2r_modpow_public_key_batch
+ * A pipeline owns its side HIP stream(s), created at the lowest stream priority so that they get a hardware
+ * queue of their own.  h2r_pipeline_modpow_public_key() is h2r_modpow_public_key_batch
  * except that its record-writing kernel runs on the pipeline's stream and `stream` joins it only at
  * the NEXT pipelined call (after that call's chain kernel has been enqueued) or at h2r_pipeline_join().
  * Until then the call's trace must not be read.  Consecutive calls must use distinct trace / out /
