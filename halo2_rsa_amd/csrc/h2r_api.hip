@@ -784,7 +784,8 @@ int32_t h2r_trace_lookup_permutation(const h2r_ctx *ctx, const void *trace, uint
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (num_elems == 0 || records_per_elem == 0) return H2R_OK;
     const h2r_layout &lo = ctx->layout;
-    if (ctx->hist_len > (u32)PERM_MAX_ROWS || lo.limb_nsub != 8) return H2R_E_UNSUPPORTED;
+    if (ctx->hist_len > (u32)PERM_MAX_ROWS || lo.limb_nsub != 8 || lo.carry_sub_stride % 16) return H2R_E_UNSUPPORTED;
+    if ((2ull * lo.num_limbs * 8 + (u64)(lo.num_cols - 1) * lo.carry_sub_stride) / 16 > (u64)PERM_STAGE_U4) return H2R_E_UNSUPPORTED;
     PermArgs pa;
     std::memset(&pa, 0, sizeof pa);
     HistArgs &ha = pa.h;
@@ -801,7 +802,13 @@ int32_t h2r_trace_lookup_permutation(const h2r_ctx *ctx, const void *trace, uint
     if (n_cells >= (1ull << 31)) return H2R_E_UNSUPPORTED;
     pa.n_cells = (u32)n_cells; pa.perm = perm_out; pa.rows = rows_out;
     HIP_TRY(hipSetDevice(ctx->params.device));
-    hipLaunchKernelGGL(perm_kernel, dim3((unsigned)num_elems), dim3(256), 0, static_cast<hipStream_t>(stream), pa);
+    const u64 stage_bytes = 4ull * ((2ull * lo.num_limbs * 8 + (u64)(lo.num_cols - 1) * lo.carry_sub_stride) / 16) * 16;
+    const u64 staged_bytes = stage_bytes + 2ull * n_cells;
+    // staged form: 16-bit cell ids in LDS (two workgroups per CU still fit next to the 27 KB of static tables)
+    if (n_cells < 65536 && staged_bytes <= 52 * 1024)
+        hipLaunchKernelGGL(perm_kernel<true>, dim3((unsigned)num_elems), dim3(256), (unsigned)staged_bytes, static_cast<hipStream_t>(stream), pa);
+    else
+        hipLaunchKernelGGL(perm_kernel<false>, dim3((unsigned)num_elems), dim3(256), (unsigned)stage_bytes, static_cast<hipStream_t>(stream), pa);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
 }

@@ -1547,62 +1547,124 @@ struct PermArgs {
     u32 *perm;     // [elem][n_cells]
     uint16_t *rows;  // nullable [elem][n_cells]
 };
-constexpr int PERM_MAX_ROWS = 1024;
+constexpr int PERM_MAX_ROWS = 512;   // table rows: at most 256 (8-bit) + 128 (7-bit overflow) on this path
 
-__device__ __forceinline__ u32 perm_cell_key(const HistArgs &a, const u8 *base, u32 cell, u32 cells_per_record) {
-    const u32 rcd = cell / cells_per_record, li = cell - rcd * cells_per_record;
-    const u8 *rec = base + (u64)rcd * a.record_stride;
-    const u32 nl = a.L * 8;
-    if (li < nl) return rec[a.off_q_sub + li];
-    if (li < 2 * nl) return rec[a.off_r_sub + (li - nl)];
-    const u32 cj = li - 2 * nl, cc = cj / a.carry_nsub, j = cj - cc * a.carry_nsub;
-    const u32 v = rec[a.off_carry_sub + (u64)cc * a.carry_sub_stride + j];
-    return (j < a.carry_nsub - a.carry_has_ov) ? a.tab1_off + v : a.tab2_off + v;
-}
+constexpr int PERM_STAGE_U4 = 384;   // 16-byte units of lookup bytes per record (L = 128: 2 * 1024 + 254 * 16 bytes)
+constexpr int PERM_STAGE_NR = PERM_STAGE_U4 / 64;
 
+// One workgroup per element, four waves; wave w owns a contiguous range of the element's records, so a stable
+// sort only needs per-wave row counts.  A record's lookup bytes (q / r sub-limb planes, carry sub-limb slots) are
+// staged in the wave's LDS buffer with 16-byte loads -- the next record's loads are in flight while the current
+// one is processed -- because byte-granular reads straight from HBM made the kernel latency bound
+// (0.73 ms per 1024 RSA-2048 traces; tools/lookup_timing.py).
+// STAGED (an element's cells fit 16-bit ids and LDS): positions are scattered into an LDS copy of the permutation and
+// written out as full lines, rows[] is rebuilt from the row starts -- the scattered 4- and 2-byte global stores of
+// the direct form (64 partial lines per store instruction) were the next bound after the key reads.
+template <bool STAGED>
 __global__ __launch_bounds__(256) void perm_kernel(PermArgs p) {
     __shared__ u32 cnt[4][PERM_MAX_ROWS];   // per-wave row counts, then per-wave running bases
-    __shared__ u32 start[PERM_MAX_ROWS];
+    __shared__ u32 start[PERM_MAX_ROWS + 1];
+    __shared__ u64 same[4][PERM_MAX_ROWS];  // per wave: lanes of the current 64-cell group that hit each row
+    extern __shared__ uint4 dyn_lds[];      // [4][stage_u4] record staging, then (STAGED) u16 perm_s[n_cells]
+    uint4 *const stage_all = dyn_lds;
     const HistArgs &a = p.h;
     const u64 elem = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u32 R = a.hist_len;
-    for (u32 k = threadIdx.x; k < 4 * PERM_MAX_ROWS; k += 256) (&cnt[0][0])[k] = 0;
+    for (u32 k = threadIdx.x; k < 4 * PERM_MAX_ROWS; k += 256) { (&cnt[0][0])[k] = 0; (&same[0][0])[k] = 0; }
     __syncthreads();
     const u8 *base = a.trace + elem * a.elem_stride + a.first_record_off;
-    const u32 Q = (p.n_cells + 3) / 4, c0 = wave * Q, c1 = min(p.n_cells, c0 + Q);
-    for (u32 c = c0 + lane; c < c1; c += 64) atomicAdd(&cnt[wave][perm_cell_key(a, base, c, p.cells_per_record)], 1u);
-    __syncthreads();
-    if (threadIdx.x == 0) {  // exclusive scan over the (few hundred) table rows
-        u32 run = 0;
-        for (u32 r = 0; r < R; ++r) { start[r] = run; run += cnt[0][r] + cnt[1][r] + cnt[2][r] + cnt[3][r]; }
-    }
-    __syncthreads();
-    for (u32 r = threadIdx.x; r < R; r += 256) {  // per-wave bases keep the sort stable across the 4 slices
-        u32 b = start[r];
-        for (int w = 0; w < 4; ++w) { const u32 t = cnt[w][r]; cnt[w][r] = b; b += t; }
-    }
-    __syncthreads();
+    const u32 T = a.records_per_elem, per = (T + 3) / 4;
+    const u32 r0 = min(T, wave * per), r1 = min(T, r0 + per);
+    const u32 nl = a.L * 8, nl4 = nl / 16, nc4 = (a.C - 1) * a.carry_sub_stride / 16, n_u4 = 2 * nl4 + nc4;
+    const u32 cpr = p.cells_per_record, ncomp = a.carry_nsub - a.carry_has_ov;
+    uint4 *const stage_w = stage_all + (u64)wave * n_u4;
+    uint16_t *const perm_s = reinterpret_cast<uint16_t *>(stage_all + 4ull * n_u4);
+    uint4 regs[PERM_STAGE_NR];
+    auto fetch = [&](u32 rcd) {   // 16-byte loads of record rcd's lookup bytes into registers
+        const u8 *rec = base + (u64)rcd * a.record_stride;
+#pragma unroll
+        for (int k = 0; k < PERM_STAGE_NR; ++k) {
+            const u32 idx = lane + 64 * k;
+            if (idx < n_u4) {
+                const u8 *src = idx < nl4 ? rec + a.off_q_sub + 16ull * idx
+                              : idx < 2 * nl4 ? rec + a.off_r_sub + 16ull * (idx - nl4) : rec + a.off_carry_sub + 16ull * (idx - 2 * nl4);
+                regs[k] = *reinterpret_cast<const uint4 *>(src);
+            }
+        }
+    };
+    auto publish = [&]() {
+#pragma unroll
+        for (int k = 0; k < PERM_STAGE_NR; ++k) { const u32 idx = lane + 64 * k; if (idx < n_u4) stage_w[idx] = regs[k]; }
+    };
+    const u8 *sb = reinterpret_cast<const u8 *>(stage_w);
+    // table row of cell li of the staged record (cells in stream order: q sub-limbs, r sub-limbs, carry sub-limbs)
+    auto key_of = [&](u32 li) -> u32 {
+        if (li < 2 * nl) return sb[li];
+        const u32 cj = li - 2 * nl, cc = cj / a.carry_nsub, j = cj - cc * a.carry_nsub;
+        const u32 v = sb[2 * nl + cc * a.carry_sub_stride + j];
+        return (j < ncomp) ? a.tab1_off + v : a.tab2_off + v;
+    };
     u32 *perm = p.perm + elem * (u64)p.n_cells;
     uint16_t *rows = p.rows ? p.rows + elem * (u64)p.n_cells : nullptr;
-    for (u32 cb = c0; cb < c1; cb += 64) {  // wave-level multi-split, 64 cells at a time, in cell order
-        const u32 c = cb + lane;
-        const bool valid = c < c1;
-        const u32 key = valid ? perm_cell_key(a, base, c, p.cells_per_record) : 0xffffffffu;
-        u64 remaining = __ballot(valid);
-        u32 pos = 0;
-        while (remaining) {
-            const int leader = __builtin_ctzll(remaining);
-            const u32 k = __shfl(key, leader);
-            const u64 mask = __ballot(valid && key == k);
-            const u32 b = cnt[wave][k];
-            if (valid && key == k) pos = b + (u32)__builtin_popcountll(mask & ((1ull << lane) - 1));
+    const u64 lane_bit = 1ull << lane, below = lane_bit - 1;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (r0 < r1) fetch(r0);
+        for (u32 rcd = r0; rcd < r1; ++rcd) {
+            publish();
             wave_sync();
-            if (lane == leader) cnt[wave][k] = b + (u32)__builtin_popcountll(mask);
-            wave_sync();
-            remaining &= ~mask;
+            if (rcd + 1 < r1) fetch(rcd + 1);
+            for (u32 lb = 0; lb < cpr; lb += 64) {
+                const u32 li = lb + lane;
+                const bool valid = li < cpr;
+                const u32 key = valid ? key_of(li) : 0;
+                if (pass == 0) {
+                    if (valid) atomicAdd(&cnt[wave][key], 1u);
+                } else {
+                    // Multi-split of 64 cells in cell order.  "Which lanes hold my row" is one LDS atomic OR of the
+                    // lane bit into same[wave][row] -- a match-any in O(1) instead of one ballot per distinct row
+                    // (with ~300 rows nearly every lane holds a different one); the rank is a popcount below the lane.
+                    if (valid) atomicOr(reinterpret_cast<unsigned long long *>(&same[wave][key]), (unsigned long long)lane_bit);
+                    wave_sync();
+                    u64 mask = 0; u32 b = 0;
+                    if (valid) { mask = same[wave][key]; b = cnt[wave][key]; }
+                    wave_sync();
+                    if (valid) {
+                        const u32 pos = b + (u32)__builtin_popcountll(mask & below);
+                        if ((mask & below) == 0) { cnt[wave][key] = b + (u32)__builtin_popcountll(mask); same[wave][key] = 0; }  // lowest lane of the row
+                        if constexpr (STAGED) perm_s[pos] = (uint16_t)(rcd * cpr + li);
+                        else { perm[pos] = rcd * cpr + li; if (rows) rows[pos] = (uint16_t)key; }
+                    }
+                    wave_sync();
+                }
+            }
+            wave_sync();   // everyone is done with the staged record before the next publish
         }
-        if (valid) { perm[pos] = c; if (rows) rows[pos] = (uint16_t)key; }
+        if (pass == 0) {
+            __syncthreads();
+            if (threadIdx.x == 0) {  // exclusive scan over the (few hundred) table rows
+                u32 run = 0;
+                for (u32 r = 0; r < R; ++r) { start[r] = run; run += cnt[0][r] + cnt[1][r] + cnt[2][r] + cnt[3][r]; }
+                start[R] = run;
+            }
+            __syncthreads();
+            for (u32 r = threadIdx.x; r < R; r += 256) {  // per-wave bases keep the sort stable across the 4 record ranges
+                u32 bb = start[r];
+                for (int w = 0; w < 4; ++w) { const u32 t = cnt[w][r]; cnt[w][r] = bb; bb += t; }
+            }
+            __syncthreads();
+        }
+    }
+    if constexpr (STAGED) {
+        __syncthreads();
+        for (u32 k = threadIdx.x; k < p.n_cells; k += 256) {
+            perm[k] = perm_s[k];
+            if (rows) {   // the row whose [start[r], start[r+1]) holds k
+                u32 lo = 0, hi = R;
+                while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (start[mid] <= k) lo = mid; else hi = mid; }
+                rows[k] = (uint16_t)lo;
+            }
+        }
     }
 }
 

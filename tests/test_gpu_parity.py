@@ -405,45 +405,71 @@ def test_verify_pkcs1v15_1024(H):
         assert np.array_equal(res.flatten(i), np.concatenate([s_if, s_pow, s_em])), i
 
 
-def test_lookup_permutation(H):
-    """Grouped arrangement of the lookup inputs (SURVEY row a10): a stable counting sort of every element's
-    sub-limb cells by table row, checked against numpy's stable argsort of the oracle's sub-limb sequence."""
-    chip = H.BigIntChip(64, 2048)
-    o = Oracle(64, 32)
-    rng = random.Random(17)
-    N = [rand_modulus(rng, 2048) for _ in range(3)]
-    X = [rng.randrange(n) for n in N]
-    res = chip.pow_mod_fixed_exp(chip.assign_integer(X), 65537, chip.assign_integer(N))
-    perm, rows = res.trace.lookup_permutation()
-    hist = res.trace.lookup_hist().cpu().numpy()
-    perm, rows = perm.cpu().numpy(), rows.cpu().numpy()
+def _oracle_lookup_keys(o, ost, T, hist_tab1_off, hist_tab2_off):
+    """Table rows of every range-check sub-limb of a pow stream, in stream order (q, r sub-limbs then carries)."""
     p = o.p
     L, C = p.L, 2 * p.L - 1
     msb = o.mul_mod_stream_bytes
     per_col = 5 * p.WB + 2 * p.CB + 4 * p.LB + 2
+    has_ov = p.carry_bits % p.carry_sub_bits != 0
+    keys = []
+    for t in range(T):
+        st = ost[t * msb:(t + 1) * msb]
+        pos = 0
+        for _ in range(2 * L):
+            pos += p.LB
+            keys.extend(int(v) for v in st[pos:pos + 8]); pos += 8
+        pos += 2 * L * L * p.WB + L * p.WB
+        for c in range(C):
+            pos += per_col
+            if c < C - 1:
+                pos += p.CB
+                for j in range(p.carry_nsub):
+                    ov = has_ov and j == p.carry_nsub - 1
+                    keys.append((hist_tab2_off if ov else hist_tab1_off) + int(st[pos])); pos += 1
+            pos += 2
+    return np.array(keys)
+
+
+@pytest.mark.parametrize("w,bits,e", [
+    (64, 2048, 65537),                 # 20,330 cells: LDS-staged form
+    (64, 2048, (1 << 33) - 1),         # 66 records, 70,620 cells: direct form
+    (32, 1024, 65537),                 # 32-bit limbs: 4-bit limb sub-limbs, 5-bit carry sub-limbs (+ overflow)
+])
+def test_lookup_permutation(H, w, bits, e):
+    """Grouped arrangement of the lookup inputs (SURVEY row a10): a stable counting sort of every element's
+    sub-limb cells by table row, checked against numpy's stable argsort of the oracle's sub-limb sequence."""
+    chip = H.BigIntChip(w, bits)
+    o = Oracle(w, bits // w)
+    rng = random.Random(17)
+    N = [rand_modulus(rng, bits) for _ in range(3)]
+    X = [rng.randrange(n) for n in N]
+    res = chip.pow_mod_fixed_exp(chip.assign_integer(X), e, chip.assign_integer(N))
+    perm, rows = res.trace.lookup_permutation()
+    hist = res.trace.lookup_hist().cpu().numpy()
+    perm, rows = perm.cpu().numpy(), rows.cpu().numpy()
+    T = e.bit_length() + bin(e).count("1")
+    # table row offsets as h2r_ctx_create lays them out: limb table, carry table (if its width differs), overflow table
+    q = o.p
+    tab0 = 1 << q.limb_sub_bits
+    same = q.carry_sub_bits == q.limb_sub_bits
+    tab1 = 0 if same else tab0
+    tab2 = tab0 + (0 if same else 1 << q.carry_sub_bits)
+    ovb = q.carry_bits % q.carry_sub_bits
+    hist_len = tab2 + ((1 << ovb) if ovb else 0)
+    assert hist.shape[1] == hist_len
+    if w == 64:
+        assert (tab1, tab2, hist_len) == (0, 256, 320)
     for i in range(3):
-        rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(X[i]), o.limbs(N[i]), 65537)
-        keys = []
-        for t in range(19):
-            st = ost[t * msb:(t + 1) * msb]
-            pos = 0
-            for _ in range(2 * L):
-                pos += p.LB
-                keys.extend(int(v) for v in st[pos:pos + 8]); pos += 8
-            pos += 2 * L * L * p.WB + L * p.WB
-            for c in range(C):
-                pos += per_col
-                if c < C - 1:
-                    pos += p.CB
-                    for j in range(p.carry_nsub):
-                        keys.append((256 if j == p.carry_nsub - 1 else 0) + int(st[pos])); pos += 1
-                pos += 2
-        keys = np.array(keys)
-        assert len(keys) == 20330 == perm.shape[1]
+        rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(X[i]), o.limbs(N[i]), e)
+        keys = _oracle_lookup_keys(o, ost, T, tab1, tab2)
+        assert len(keys) == perm.shape[1]
+        if (w, e) == (64, 65537):
+            assert len(keys) == 20330
         want = np.argsort(keys, kind="stable")
         assert np.array_equal(perm[i], want)
         assert np.array_equal(rows[i], keys[want])
-        assert np.array_equal(np.bincount(keys, minlength=320), hist[i])
+        assert np.array_equal(np.bincount(keys, minlength=hist_len), hist[i])
 
 
 def test_pipelined_calls_match_oracle(H):
