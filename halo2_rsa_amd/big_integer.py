@@ -397,6 +397,15 @@ class Pipeline:
                                                    status.data_ptr(), workspace.data_ptr(), self.chip._stream()),
               "h2r_pipeline_modpow_public_key")
 
+    def verify_pkcs1v15(self, sig: AssignedInteger, e: int, n: AssignedInteger, hashed, trace_buf, workspace, powed, is_valid, status):
+        """Pipelined RSAInstructions::verify_pkcs1v15_signature (after the SHA step); `hashed`: int64 [batch, 4] on the
+        device, `trace_buf` sized batch * h2r_verify_layout.elem_stride."""
+        eb = _e_bytes(e)
+        check(lib().h2r_pipeline_verify_pkcs1v15(self._p, sig.data_ptr(), n.data_ptr(), eb, len(eb), hashed.data_ptr(), sig.batch,
+                                                 self.chip._flags(n, sig.batch), trace_buf.data_ptr(), powed.data_ptr(),
+                                                 is_valid.data_ptr(), status.data_ptr(), workspace.data_ptr(), self.chip._stream()),
+              "h2r_pipeline_verify_pkcs1v15")
+
     def join(self):
         check(lib().h2r_pipeline_join(self._p, self.chip._stream()), "h2r_pipeline_join")
 

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -514,6 +515,11 @@ int32_t h2r_verify_layout_fixed(const h2r_ctx *ctx, const uint8_t *e_le, size_t 
     return H2R_OK;
 }
 
+namespace {
+int32_t launch_verify_aux(const h2r_ctx *ctx, const void *sig, const void *n, const uint64_t *hashed, uint64_t batch, uint32_t flags,
+                          void *trace, const h2r_verify_layout &vl, void *powed_out, uint8_t *is_valid_out, uint8_t *status, hipStream_t st);
+}
+
 int32_t h2r_verify_pkcs1v15_batch(const h2r_ctx *ctx, const void *sig, const void *n, const uint8_t *e_le, size_t e_len,
                                   const uint64_t *hashed, uint64_t batch, uint32_t flags, void *trace, void *powed_out,
                                   uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) {
@@ -528,16 +534,7 @@ int32_t h2r_verify_pkcs1v15_batch(const h2r_ctx *ctx, const void *sig, const voi
     rc = run_path(ctx, CHAIN_POW_FIXED, sig, nullptr, n, nullptr, 0, 0, &eb, 1, batch, flags, T, trace, vl.elem_stride,
                   vl.pow.off_records, &vl.pow, powed_out, status, workspace, st);
     if (rc || batch == 0) return rc;
-    AuxArgs aa;
-    std::memset(&aa, 0, sizeof aa);
-    aa.x = sig; aa.n = n; aa.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
-    aa.hashed = hashed; aa.powed = powed_out; aa.batch = batch; aa.L = ctx->L;
-    aa.trace = static_cast<u8 *>(trace); aa.elem_stride = vl.elem_stride; aa.off_in_field = vl.off_in_field; aa.off_em = vl.off_em;
-    aa.is_valid = is_valid_out; aa.status = status;
-    ProfScope ps(H2R_KERNEL_AUX, st);
-    hipLaunchKernelGGL((aux_kernel<64>), dim3((unsigned)batch), dim3(64), 0, st, aa);
-    HIP_TRY(hipGetLastError());
-    return H2R_OK;
+    return launch_verify_aux(ctx, sig, n, hashed, batch, flags, trace, vl, powed_out, is_valid_out, status, st);
 }
 
 int32_t h2r_verify_trace_flatten(const h2r_ctx *ctx, const h2r_verify_layout *vl, const void *elem_host, void *stream_out) {
@@ -644,25 +641,25 @@ int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream) {
     return H2R_OK;
 }
 
-int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len,
-                                       uint64_t batch, uint32_t flags, void *trace, void *out, uint8_t *status,
-                                       void *workspace, h2r_stream_t stream) {
-    if (!p || !trace || !workspace) return H2R_E_NULL;
+namespace {
+// One pipelined call: chain kernel (+ `after_chain`, e.g. the verifier's aux kernel) on the caller's stream, the
+// record kernel on a side stream, then the lazy join of the call whose buffers the next call may reuse.
+int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch,
+                       uint32_t flags, void *trace, const h2r_pow_layout &pl, uint64_t elem_stride, void *out,
+                       uint8_t *status, void *workspace, hipStream_t st, const std::function<int32_t()> &after_chain) {
     const h2r_ctx *ctx = p->ctx;
     ExpBits eb; u32 T;
     int32_t rc = exp_to_bits(e_le, e_len, &eb, &T);
     if (rc) return rc;
-    h2r_pow_layout pl;
-    rc = h2r_pow_fixed_layout(ctx, e_le, e_len, &pl);
-    if (rc) return rc;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     const u32 slot = p->k % p->depth;
     p->done[slot] = DoneRef{};
-    rc = run_path(ctx, CHAIN_POW_FIXED, x, nullptr, n, nullptr, 0, 0, &eb, 1, batch, flags, T, trace, pl.elem_stride,
+    rc = run_path(ctx, CHAIN_POW_FIXED, x, nullptr, n, nullptr, 0, 0, &eb, 1, batch, flags, T, trace, elem_stride,
                   pl.off_records, &pl, out, status, workspace, st, p->aux[p->k & 1], p->chain_done[slot], p->trace_done[slot], &p->done[slot]);
     if (rc) return rc;
     p->done_stream[slot] = p->aux[p->k & 1];
     p->k += 1;
+    rc = after_chain();
+    if (rc) return rc;
     // lazy join: the NEXT call reuses the buffers of call k - depth, so order the user stream after that call's
     // record kernel now -- behind this call's chain kernel, which therefore overlaps the record kernels in flight
     for (; p->joined + p->depth <= p->k; ++p->joined) {
@@ -670,6 +667,49 @@ int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const voi
         if (rc) return rc;
     }
     return H2R_OK;
+}
+
+int32_t launch_verify_aux(const h2r_ctx *ctx, const void *sig, const void *n, const uint64_t *hashed, uint64_t batch, uint32_t flags,
+                          void *trace, const h2r_verify_layout &vl, void *powed_out, uint8_t *is_valid_out, uint8_t *status, hipStream_t st) {
+    AuxArgs aa;
+    std::memset(&aa, 0, sizeof aa);
+    aa.x = sig; aa.n = n; aa.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
+    aa.hashed = hashed; aa.powed = powed_out; aa.batch = batch; aa.L = ctx->L;
+    aa.trace = static_cast<u8 *>(trace); aa.elem_stride = vl.elem_stride; aa.off_in_field = vl.off_in_field; aa.off_em = vl.off_em;
+    aa.is_valid = is_valid_out; aa.status = status;
+    ProfScope ps(H2R_KERNEL_AUX, st);
+    hipLaunchKernelGGL((aux_kernel<64>), dim3((unsigned)batch), dim3(64), 0, st, aa);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
+}  // namespace
+
+int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len,
+                                       uint64_t batch, uint32_t flags, void *trace, void *out, uint8_t *status,
+                                       void *workspace, h2r_stream_t stream) {
+    if (!p || !trace || !workspace) return H2R_E_NULL;
+    h2r_pow_layout pl;
+    const int32_t rc = h2r_pow_fixed_layout(p->ctx, e_le, e_len, &pl);
+    if (rc) return rc;
+    return pipeline_issue(p, x, n, e_le, e_len, batch, flags, trace, pl, pl.elem_stride, out, status, workspace,
+                          static_cast<hipStream_t>(stream), []() -> int32_t { return H2R_OK; });
+}
+
+int32_t h2r_pipeline_verify_pkcs1v15(h2r_pipeline *p, const void *sig, const void *n, const uint8_t *e_le, size_t e_len,
+                                     const uint64_t *hashed, uint64_t batch, uint32_t flags, void *trace, void *powed_out,
+                                     uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+    if (!p || !sig || !n || !hashed || !trace || !powed_out || !status || !workspace) return H2R_E_NULL;
+    h2r_verify_layout vl;
+    const int32_t rc = h2r_verify_layout_fixed(p->ctx, e_le, e_len, &vl);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the in-field / encoded-message kernel needs only the chain's result: it runs on the caller's stream right
+    // behind the chain kernel and writes the element's in-field and EM regions (disjoint from the records)
+    return pipeline_issue(p, sig, n, e_le, e_len, batch, flags, trace, vl.pow, vl.elem_stride, powed_out, status, workspace, st,
+                          [&]() -> int32_t {
+                              if (batch == 0) return H2R_OK;
+                              return launch_verify_aux(p->ctx, sig, n, hashed, batch, flags, trace, vl, powed_out, is_valid_out, status, st);
+                          });
 }
 
 int32_t h2r_fresh_op_layout(const h2r_ctx *ctx, uint32_t op, uint64_t *elem_stride, uint64_t *stream_bytes, uint32_t *value_limbs) {

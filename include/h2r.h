@@ -268,6 +268,14 @@ int32_t h2r_verify_pkcs1v15_batch(const h2r_ctx *ctx, const void *sig, const voi
                                   h2r_stream_t stream);
 int32_t h2r_verify_trace_flatten(const h2r_ctx *ctx, const h2r_verify_layout *vl,
                                  const void *elem_host, void *stream_out);
+/* Pipelined form of h2r_verify_pkcs1v15_batch (see h2r_pipeline_create): the in-field / encoded-message
+ * kernel runs on `stream` right behind the chain kernel; powed_out / is_valid_out / status are
+ * stream-ordered on `stream`, the trace follows the pipeline's join rule. */
+int32_t h2r_pipeline_verify_pkcs1v15(h2r_pipeline *p, const void *sig, const void *n,
+                                     const uint8_t *e_le_bytes, size_t e_len, const uint64_t *hashed,
+                                     uint64_t batch, uint32_t flags, void *trace, void *powed_out,
+                                     uint8_t *is_valid_out, uint8_t *status, void *workspace,
+                                     h2r_stream_t stream);
 
 /* ---- the Fresh-integer family of BigIntInstructions ---------------------------
  * add (big_integer/chip.rs:245-297), sub (:310-373; flag = is_overflowed, value = |a-b|), add_mod (:452-481),

@@ -357,6 +357,67 @@ def test_verify_pkcs1v15_signature_kats(H, golden):
             assert sha(got[len(s_if):len(s_if) + len(s_pow)]) == k["pow_stream_sha256"]
 
 
+def test_pipelined_verify_matches_batch_call(H, golden):
+    """h2r_pipeline_verify_pkcs1v15: three pipelined verifier batches over two buffer sets produce, element for
+    element, the bytes and verdicts of h2r_verify_pkcs1v15_batch (itself checked against the oracle above) and the
+    oracle's stream for sampled elements."""
+    rsa = H.RSAChip(2048, 5)
+    chip = rsa.bigint_chip()
+    o = Oracle(64, 32)
+    kats = golden["rsa_kats"]
+    rng = random.Random(23)
+    B = 48
+    pipe = H.Pipeline(chip, depth=2, side_streams=1)
+    sets, calls, snaps = [], [], []
+    for k in range(3):
+        ns = [int(q["n"]) for q in kats] + [rand_modulus(rng, 2048) for _ in range(B - 3)]
+        sigs = [int(q["sig"]) for q in kats] + [rng.randrange(n) for n in ns[3:]]
+        hashed = [int(q["hashed"]) for q in kats] + [rng.getrandbits(256) for _ in range(B - 3)]
+        if k == 1:
+            sigs[7] = ns[7] + 1
+        pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Fix(65537)))
+        sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64)))
+        ref = rsa.verify_pkcs1v15_signature(pk, hashed, sg)
+        hd = torch.from_numpy(H.UnassignedInteger.from_ints(hashed, 4, 64).limbs.view(np.int64)).cuda()
+        calls.append(dict(ns=ns, sigs=sigs, hashed=hashed, ref=ref, n=chip.assign_integer(pk.n), s=chip.assign_integer(sg.c), h=hd))
+    vl = calls[0]["ref"].layout
+    for _ in range(2):
+        sets.append(dict(trace=torch.empty(B * vl.elem_stride, dtype=torch.uint8, device="cuda"),
+                         ws=torch.empty(chip.workspace_bytes(B, vl.pow.num_mul_mods), dtype=torch.uint8, device="cuda"),
+                         powed=torch.empty((B, 32), dtype=torch.int64, device="cuda"),
+                         valid=torch.zeros(B, dtype=torch.uint8, device="cuda"),
+                         status=torch.zeros(B, dtype=torch.uint8, device="cuda")))
+    for k, c in enumerate(calls):
+        s = sets[k % 2]
+        if k >= 2:
+            snaps.append(tuple(t.clone() for t in (s["trace"], s["powed"], s["valid"], s["status"])))
+        pipe.verify_pkcs1v15(c["s"], 65537, c["n"], c["h"], s["trace"], s["ws"], s["powed"], s["valid"], s["status"])
+    pipe.join()
+    for k in (1, 2):
+        s = sets[k % 2]
+        snaps.append(tuple(t.clone() for t in (s["trace"], s["powed"], s["valid"], s["status"])))
+    torch.cuda.synchronize()
+    for k, c in enumerate(calls):
+        trace, powed, valid, status = snaps[k]
+        ref = c["ref"]
+        assert torch.equal(valid, ref.is_valid) and torch.equal(status, ref.status)
+        assert valid.cpu().tolist()[:3] == [1, 1, 0]
+        ok_rows = (status == 0).nonzero().flatten()
+        assert torch.equal(powed[ok_rows], ref.powed.limbs_dev[ok_rows])
+        es = vl.elem_stride
+        got = H.rsa.VerifyResult(valid, H.AssignedInteger(powed, 64), status, trace, vl, chip)
+        for i in (0, 1, 2, 7, B - 1):
+            if int(status[i]) != 0:
+                continue
+            assert np.array_equal(got.flatten(i), ref.flatten(i)), (k, i)
+        i = 5
+        rc_if, lt, s_if = o.assert_in_field(o.limbs(c["sigs"][i]), o.limbs(c["ns"][i]))
+        rc, out, s_pow = o.pow_mod_fixed_exp(o.limbs(c["sigs"][i]), o.limbs(c["ns"][i]), 65537)
+        rc, ok, s_em = o.pkcs1v15_em_check(out, o.limbs(c["hashed"][i], 4))
+        assert np.array_equal(got.flatten(i), np.concatenate([s_if, s_pow, s_em])), k
+    pipe.close()
+
+
 def test_verify_pkcs1v15_1024(H):
     """RSA-1024 (the reference bench's key size, benches/bench.rs:393-407): a genuinely valid signature built
     with a known factorisation, plus tampered variants."""
