@@ -263,4 +263,53 @@ class RSAChip {
     BigIntChip bigint_;
 };
 
+// h2r_pipeline_*: consecutive verifier batches overlap the off-circuit chain of batch k+1 with the record emission
+// of batch k.  The caller rotates through `depth` buffer sets; join() orders `stream` after every record kernel.
+class Pipeline {
+  public:
+    struct Buffers {   // one buffer set (sized for `batch` signatures and public exponent `e_le`)
+        DeviceBuffer trace, workspace, powed, is_valid, status;
+        h2r_verify_layout layout{};
+    };
+    explicit Pipeline(const RSAChip &chip, uint32_t depth = 2, uint32_t side_streams = 1) : chip_(chip) {
+        check(h2r_pipeline_create_ex(chip.bigint_chip().ctx(), depth, side_streams, &p_), "h2r_pipeline_create_ex");
+    }
+    ~Pipeline() { h2r_pipeline_destroy(p_); }
+    Pipeline(const Pipeline &) = delete;
+    Pipeline &operator=(const Pipeline &) = delete;
+    Buffers make_buffers(size_t batch, const std::vector<uint8_t> &e_le) const {
+        Buffers b;
+        const BigIntChip &bc = chip_.bigint_chip();
+        check(h2r_verify_layout_fixed(bc.ctx(), e_le.data(), e_le.size(), &b.layout), "h2r_verify_layout_fixed");
+        const uint64_t ws = h2r_workspace_bytes(bc.ctx(), batch, b.layout.pow.num_mul_mods);
+        b.trace = DeviceBuffer(batch * b.layout.elem_stride); b.workspace = DeviceBuffer(ws);
+        b.powed = DeviceBuffer(batch * bc.num_limbs() * 8); b.is_valid = DeviceBuffer(batch); b.status = DeviceBuffer(batch);
+        return b;
+    }
+    // RSAInstructions::verify_pkcs1v15_signature (src/chip.rs:128-199), asynchronous on `stream`
+    void verify_pkcs1v15_signature(const AssignedRSAPublicKey &pk, const AssignedInteger &hashed_msg, const AssignedRSASignature &sig,
+                                   Buffers &b, hipStream_t stream = nullptr) {
+        auto *f = std::get_if<RSAPubE::Fix>(&pk.e);
+        if (!f) throw Error(H2R_E_UNSUPPORTED, "Pipeline::verify_pkcs1v15_signature (takes RSAPubE::Fix)");
+        const size_t batch = sig.c.batch();
+        check(h2r_pipeline_verify_pkcs1v15(p_, sig.c.data(), pk.n.data(), f->e_le.data(), f->e_le.size(),
+                                           static_cast<const uint64_t *>(hashed_msg.data()), batch,
+                                           (pk.n.batch() == 1 && batch != 1) ? H2R_F_SHARED_MODULUS : 0u, b.trace.get(), b.powed.get(),
+                                           static_cast<uint8_t *>(b.is_valid.get()), static_cast<uint8_t *>(b.status.get()),
+                                           b.workspace.get(), stream), "h2r_pipeline_verify_pkcs1v15");
+    }
+    void join(hipStream_t stream = nullptr) { check(h2r_pipeline_join(p_, stream), "h2r_pipeline_join"); }
+    // an element's whole verify witness in the reference's order (after join() + synchronisation)
+    std::vector<uint8_t> flatten(const Buffers &b, size_t elem) const {
+        std::vector<uint8_t> host(b.layout.elem_stride), out(b.layout.stream_bytes);
+        b.trace.download(host.data(), host.size(), elem * b.layout.elem_stride);
+        check(h2r_verify_trace_flatten(chip_.bigint_chip().ctx(), &b.layout, host.data(), out.data()), "h2r_verify_trace_flatten");
+        return out;
+    }
+
+  private:
+    const RSAChip &chip_;
+    h2r_pipeline *p_ = nullptr;
+};
+
 }  // namespace h2r_host

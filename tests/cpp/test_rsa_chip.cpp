@@ -85,6 +85,23 @@ int main(int argc, char **argv) {
         REQUIRE(h2ro_mul_mod(&op, a.data(), a.data(), n.data(), st.data(), rr.data()) == 0);
         REQUIRE(r.trace.flatten(0) == st);
     }
+    // pipelined verifier: three back-to-back batches over two buffer sets give the same witnesses as the batch call
+    {
+        Pipeline pipe(rsa_chip, 2, 1);
+        const std::vector<uint8_t> e65537 = {0x01, 0x00, 0x01};
+        Pipeline::Buffers bufs[2] = {pipe.make_buffers(B, e65537), pipe.make_buffers(B, e65537)};
+        for (int k = 0; k < 3; ++k) pipe.verify_pkcs1v15_signature(pk, hashed_msg_assigned, sign, bufs[k & 1]);
+        pipe.join();
+        REQUIRE(hipDeviceSynchronize() == hipSuccess);
+        for (int s = 0; s < 2; ++s) {
+            std::vector<uint8_t> valid(B);
+            bufs[s].is_valid.download(valid.data(), B);
+            for (size_t i = 0; i < B; ++i) {
+                REQUIRE(valid[i] == kats[i].is_valid);
+                REQUIRE(pipe.flatten(bufs[s], i) == rsa_chip.flatten(res, i));
+            }
+        }
+    }
     // BigIntChip::new asserts bits_len % limb_width == 0 (big_integer/chip.rs:1175) -> exception
     bool threw = false;
     try { BigIntChip bad(64, 2048 + 8); } catch (const Error &e) { threw = e.code == H2R_E_SHAPE; }
