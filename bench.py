@@ -100,7 +100,25 @@ def cpu_baseline(w, bits, e, un, ux, max_seconds=20.0):
                       % (sample, runs, cores)}
 
 
+def ensure_built():
+    """The bench needs the prebuilt libh2r.so (it ships with the tree).  If it is missing, local rank 0 builds it with
+    hipcc and the other ranks wait for it -- never eight concurrent compiles into one file."""
+    from halo2_rsa_amd import _build
+    if os.path.exists(_build.LIB):
+        return
+    if int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        tmp = _build.build_lib(out=_build.LIB + ".tmp%d" % os.getpid())
+        os.replace(tmp, _build.LIB)
+    else:
+        deadline = time.time() + 600
+        while not os.path.exists(_build.LIB):
+            if time.time() > deadline:
+                raise RuntimeError("libh2r.so did not appear (local rank 0 builds it)")
+            time.sleep(0.5)
+
+
 def main():
+    ensure_built()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
