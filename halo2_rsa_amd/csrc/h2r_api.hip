@@ -128,6 +128,9 @@ hipError_t launch_trace_t(const TraceArgs &ta, hipStream_t st, hipEvent_t ea, hi
     constexpr int IPB = TPI >= 256 ? 1 : 256 / TPI;
     const u64 blocks = (ta.n_items + IPB - 1) / IPB;
     if (blocks == 0) return hipSuccess;
+    // the kernel hard-codes the accumulator row strides layout_compute derives for (LW, L)
+    if (ta.acc_lo_group != (LW == 64 ? 3ull * (2 * L * 16) : (u64)L * 16) || ta.acc_hi_group != ta.acc_lo_group ||
+        ta.acc_lo_row != (LW == 64 ? 2u * L * 16 : 0u) || ta.acc_spg != (LW == 64 ? 2u : 1u)) return hipErrorInvalidValue;
     // dyn_lds > 0 caps the blocks resident per CU (leaves wave slots for a co-running chain kernel)
     // ea/eb (nullable): start/stop events stamped by the dispatch itself
     hipExtLaunchKernelGGL((trace_kernel<LW, L>), dim3((unsigned)blocks), dim3(256), ta.dyn_lds, st, ea, eb, 0, ta);

@@ -913,7 +913,8 @@ __global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
     acc.clear(); first.clear();
     if (prod && !H2R_ABLATE(2)) {
         // accumulator addressing (h2r.h): planar rows, or interleaved [ab half | qn half] rows with a shared HI row
-        const u64 lo_group = args.acc_lo_group, hi_group = args.acc_hi_group, lo_row = args.acc_lo_row;
+        // row strides as layout_compute derives them from (limb_width, L): compile-time, so the stores use immediate offsets
+        constexpr u64 lo_row = LW == 64 ? 2ull * L * 16 : 0, lo_group = LW == 64 ? 3ull * (2 * L * 16) : (u64)L * 16, hi_group = lo_group;
         constexpr bool two = LW == 64;   // layout_compute: interleaved rows, two steps per group, iff the HI word exists
         u8 *plo = rec + off[h == 0 ? H2R_PL_AB_LO : H2R_PL_QN_LO] + (u64)i * 16;
         u8 *phi = rec + off[h == 0 ? H2R_PL_AB_HI : H2R_PL_QN_HI] + (u64)i * 16;
