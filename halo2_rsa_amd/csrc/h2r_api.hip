@@ -122,19 +122,23 @@ void build_const_record(h2r_ctx *c) {
     }
 }
 
-template <int LW, int L>
-hipError_t launch_trace_t(const TraceArgs &ta, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
+template <int LW, int L, int BT>
+hipError_t launch_trace_bt(const TraceArgs &ta, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
     constexpr int TPI = 2 * L;
-    constexpr int IPB = TPI >= 256 ? 1 : 256 / TPI;
+    constexpr int IPB = TPI >= BT ? 1 : BT / TPI;
     const u64 blocks = (ta.n_items + IPB - 1) / IPB;
     if (blocks == 0) return hipSuccess;
+    // dyn_lds > 0 caps the blocks resident per CU; ea/eb (nullable): start/stop events stamped by the dispatch itself
+    hipExtLaunchKernelGGL((trace_kernel<LW, L, BT>), dim3((unsigned)blocks), dim3(BT), ta.dyn_lds, st, ea, eb, 0, ta);
+    return hipGetLastError();
+}
+template <int LW, int L>
+hipError_t launch_trace_t(const TraceArgs &ta, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
     // the kernel hard-codes the accumulator row strides layout_compute derives for (LW, L)
     if (ta.acc_lo_group != (LW == 64 ? 3ull * (2 * L * 16) : (u64)L * 16) || ta.acc_hi_group != ta.acc_lo_group ||
         ta.acc_lo_row != (LW == 64 ? 2u * L * 16 : 0u) || ta.acc_spg != (LW == 64 ? 2u : 1u)) return hipErrorInvalidValue;
-    // dyn_lds > 0 caps the blocks resident per CU (leaves wave slots for a co-running chain kernel)
-    // ea/eb (nullable): start/stop events stamped by the dispatch itself
-    hipExtLaunchKernelGGL((trace_kernel<LW, L>), dim3((unsigned)blocks), dim3(256), ta.dyn_lds, st, ea, eb, 0, ta);
-    return hipGetLastError();
+    // (measured for the RSA-2048 shape: 128- and 64-thread workgroups are no better at any residency)
+    return launch_trace_bt<LW, L, 256>(ta, st, ea, eb);
 }
 hipError_t launch_trace(u32 w, u32 L, const TraceArgs &ta, hipStream_t st, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr) {
 #define H2R_CASE(W_, L_) if (w == W_ && L == L_) return launch_trace_t<W_, L_>(ta, st, ea, eb)
@@ -265,6 +269,10 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         ta.status = status; ta.n_items = batch * T; ta.T = T;
         ta.trace = static_cast<u8 *>(trace); ta.elem_stride = elem_stride; ta.off_records = off_records;
         hipStream_t ts = st;
+        // Residency of the record kernel (a dynamic-LDS request that is never touched caps the workgroups per CU).
+        // With non-temporal stores the RSA-2048 shape writes fastest with FEW concurrent store streams: alone, one
+        // workgroup (4 records in flight) per CU -- 0.227 -> 0.213 ms, 5.87 TB/s; next to a chain kernel, three.
+        if (!std::getenv("H2R_TRACE_DYN_LDS") && lo.limb_width == 64 && c->L == 32) ta.dyn_lds = 90000;
         if (trace_st) {
             // co-scheduled with the next batch's chain kernel: cap the trace kernel's residency (its store
             // stream does not need full occupancy) 

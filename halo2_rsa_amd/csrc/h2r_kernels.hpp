@@ -867,12 +867,14 @@ template <> struct ColAcc<32> {
 #define H2R_ABLATE(bit_) false
 #endif
 
-template <int LW, int L>
-__global__ __launch_bounds__(256) void trace_kernel(TraceArgs args) {
+// BT = threads per workgroup (a multiple of the 2L threads of an item, at most 256)
+template <int LW, int L, int BT = 256>
+__global__ __launch_bounds__(BT) void trace_kernel(TraceArgs args) {
     using limb_t = typename LimbT<LW>::type;
     using W = Wide<LW>;
     constexpr int TPI = 2 * L;                   // threads per item
-    constexpr int IPB = TPI >= 256 ? 1 : 256 / TPI;  // items per block
+    constexpr int IPB = TPI >= BT ? 1 : BT / TPI;  // items per block
+    static_assert(BT % 64 == 0 && (TPI >= BT ? TPI == BT || BT == 256 : BT % TPI == 0), "block shape");
     constexpr int C = 2 * L - 1;
     constexpr int WPI = TPI / 64 > 0 ? TPI / 64 : 1;  // waves per item (when TPI >= 64)
     static_assert(TPI <= 256, "num_limbs > 128 not supported");
