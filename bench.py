@@ -44,6 +44,8 @@ def pmc_traffic(kernel_name, batch):
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             d = json.load(f)
         ent = d.get(kernel_name)
+        if ent is None:   # template arguments after the shape (workgroup size) are part of the profiler's name
+            ent = next((v for k, v in d.items() if k.startswith(kernel_name[:-1] + ",")), None)
         if ent and ent.get("batch") == batch:
             return int(ent["hbm_bytes_per_launch"])
     except Exception:
