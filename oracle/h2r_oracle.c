@@ -326,7 +326,7 @@ static int mul_mod_limbs(const h2ro_params *p, const uint64_t *a, const uint64_t
     unsigned w = p->w, L = p->L;
     static __thread uint32_t ad[MAXD], bd[MAXD], nd[MAXD], full[2 * MAXD], qd[2 * MAXD + 1], rd[MAXD];
     static __thread u256 ab[2 * MAXL], qn[2 * MAXL], eq_b[2 * MAXL];
-    uint64_t q[MAXL], r[MAXL];
+    uint64_t q[MAXL] = {0}, r[MAXL] = {0};
     int D = (w == 64) ? (int)(2 * L) : (int)L;
     for (unsigned i = 0; i < L; ++i) {
         if (w == 64) { ad[2 * i] = (uint32_t)a[i]; ad[2 * i + 1] = (uint32_t)(a[i] >> 32); bd[2 * i] = (uint32_t)b[i]; bd[2 * i + 1] = (uint32_t)(b[i] >> 32); nd[2 * i] = (uint32_t)n[i]; nd[2 * i + 1] = (uint32_t)(n[i] >> 32); }
