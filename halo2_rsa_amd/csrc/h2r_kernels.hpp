@@ -106,7 +106,7 @@ struct ChainLds {
     u32 nnpad[3 * K];            // normalised modulus n' = n << s, padded like bpad
     u32 mupad[3 * K];            // mu' = floor((2^(64K) - 1) / n') - 2^(32K), padded
     u32 part[Geo<K, NW>::SSMAX][3][2 * K];  // per-slice column partial sums (3 words)
-    u32 x0[2 * K + 4], x1[2 * K + 4], x2[2 * K + 4];  // reduced columns; also shift scratch
+    u32 x0[2 * K + 4];                   // shift scratch; x0[K+3] = low word of column K for the low half product
     u32 rx0[K + 1], rx1[K + 1];          // wave-0 scratch of the reciprocal
     alignas(16) u32 stage[4 * K];        // a, b, q, r of one mul_mod on their way to the ops buffer
     u64 *dbg; u32 dbg_n;                 // debug timing (nullable)
@@ -121,8 +121,8 @@ __device__ __forceinline__ void wave_sync() {
 // K x K digit product A (K digits at `A`) x B (padded at `Bpad`) computed by the whole block.  All
 // waves accumulate column partial sums; WAVE 0 alone receives the normalised digits (lane holds
 // columns v = lane + 64m in plo[m] and v + K in phi[m]) -- it owns the serial carry/decision logic
-// while the other waves only help with the products.  Three block barriers; wave 0 publishes
-// A/Bpad before the call.
+// while the other waves only help with the products.  Two block barriers (operands published / partial
+// sums published); wave 0 publishes A/Bpad before the call.
 //   MUL_FULL  all 2K digits.
 //   MUL_HIGH  only phi, computed from the columns >= K-2 (never larger than the true high half and at
 //             most 1 ulp smaller): Barrett's  floor(x1 * mu' / 2^(32K))  needs no more.
@@ -258,22 +258,39 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
     H2R_STAMP(s);
     __syncthreads();
     H2R_STAMP(s);
-    constexpr int C0 = CB, C1 = HALF ? (MODE == MUL_HIGH ? 2 * K - 1 : K) : 2 * K;   // columns reduced: [C0, C1)
-    for (int c = C0 + (int)threadIdx.x; c < C1; c += 64 * NW) {  // reduce the slices of column c
+    // Wave 0 alone finishes the product: it sums the slices of its own columns straight from `part`, gets the
+    // neighbouring columns' words with wavefront DPP shifts (no second LDS round trip, no third barrier) and resolves
+    // the carries by ballot.  The other waves are done; they wait at the next block_mul's first barrier, which is also
+    // what keeps `part` intact until wave 0 has read it.
+    //   x0|x1|x2 (c) = the 96-bit sum of column c as 32-bit words;  t(c) = x0(c) + x1(c-1) + x2(c-2);
+    //   digit d(c) = lo32 t(c) + hi32 t(c-1) + carry.
+    if (wave != 0) return;
+    constexpr int GWL = K < 64 ? K : 64;        // lanes of a column group
+    u32 prev_x1 = 0, prev_x2 = 0, prev_r1 = 0, prev_thi = 0;   // previous group's words, for the seam lanes
+    auto shr1 = [&](u32 cur, u32 prev) -> u32 {   // value of lane-1; lane 0 takes the previous group's last lane
+        const u32 up = __builtin_amdgcn_readlane(prev, GWL - 1);
+        return (u32)__builtin_amdgcn_update_dpp((int)up, (int)cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    };
+    auto group = [&](int c, bool active) -> u64 {   // returns lo32 t(c) + hi32 t(c-1)
+        // unconditional reads at a clamped column (inactive lanes are zeroed afterwards): lets the loads of all
+        // groups issue back to back instead of one exec-masked LDS round trip per group
+        const int cc = c < 0 ? 0 : (c > 2 * K - 1 ? 2 * K - 1 : c);
         u64 s0 = 0, s1 = 0; u32 s2 = 0;
 #pragma unroll
-        for (int k = 0; k < SSA; ++k) { s0 += s.part[k][0][c]; s1 += s.part[k][1][c]; s2 += s.part[k][2][c]; }
+        for (int k = 0; k < SSA; ++k) { s0 += s.part[k][0][cc]; s1 += s.part[k][1][cc]; s2 += s.part[k][2][cc]; }
+        if (!active) { s0 = 0; s1 = 0; s2 = 0; }
         const u64 t1 = s1 + (s0 >> 32);
-        s.x0[c + 3] = (u32)s0; s.x1[c + 3] = (u32)t1; s.x2[c + 3] = s2 + (u32)(t1 >> 32);
-    }
-    // three zero columns below the window (c = C0-3 .. C0-1) and, for MUL_HIGH, the always-zero column 2K-1
-    if (threadIdx.x < 3) { s.x0[C0 + threadIdx.x] = 0; s.x1[C0 + threadIdx.x] = 0; s.x2[C0 + threadIdx.x] = 0; }
-    if (HALF && MODE == MUL_HIGH && threadIdx.x == 3) { s.x0[2 * K + 2] = 0; s.x1[2 * K + 2] = 0; s.x2[2 * K + 2] = 0; }
-    H2R_STAMP(s);
-    __syncthreads();
-    H2R_STAMP(s);
-    if (wave != 0) return;
-    // digits: t(c) = x0[c] + x1[c-1] + x2[c-2]; d(c) = lo(t(c)) + hi(t(c-1)); 1-bit carries by ballot
+        const u32 x0 = (u32)s0, x1 = (u32)t1, x2 = s2 + (u32)(t1 >> 32);
+        const u32 a1 = shr1(x1, prev_x1);       // x1(c-1)
+        const u32 r1 = shr1(x2, prev_x2);       // x2(c-1)
+        const u32 b2 = shr1(r1, prev_r1);       // x2(c-2)
+        const u64 t = (u64)x0 + a1 + b2;
+        const u32 thi = (u32)(t >> 32);
+        const u32 tph = shr1(thi, prev_thi);    // hi32 t(c-1)
+        prev_x1 = x1; prev_x2 = x2; prev_r1 = r1; prev_thi = thi;
+        return (u64)(u32)t + tph;
+    };
+    if constexpr (HALF && MODE == MUL_HIGH) (void)group(K - 64 + lane, lane >= 62);   // columns K-2, K-1 feed digit K
     bool cin = false;
 #pragma unroll
     for (int g = 0; g < 2 * V; ++g) {
@@ -281,24 +298,19 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
         if (HALF && MODE == MUL_LOW && g >= V) continue;   // high half not needed (digit K below)
         const int vv = lane + 64 * (g % V);
         const int c = vv + (g >= V ? K : 0);
-        u64 d = 0;
-        bool gen = false, prop = false;
-        if (vv < K) {
-            const u64 t = (u64)s.x0[c + 3] + s.x1[c + 2] + s.x2[c + 1];
-            const u64 tp = (u64)s.x0[c + 2] + s.x1[c + 1] + s.x2[c];
-            d = (u64)(u32)t + (tp >> 32);
-            gen = (d >> 32) != 0;
-            prop = ((u32)d == 0xffffffffu);
-        }
+        const bool in_col = vv < K;
+        const u64 d = group(c, in_col && !(HALF && MODE == MUL_HIGH && c >= 2 * K - 1));   // column 2K-1 of the window is zero
+        const bool gen = in_col && (d >> 32) != 0;
+        const bool prop = in_col && ((u32)d == 0xffffffffu);
         const CarryGroup cgp = carry_group(__ballot(gen), __ballot(prop), cin, G::GW);
         cin = cgp.cout;
-        const u32 digit = (u32)d + (u32)((cgp.cin_mask >> lane) & 1);
+        const u32 digit = in_col ? (u32)d + (u32)((cgp.cin_mask >> lane) & 1) : 0u;
         if (g < V) plo[g] = digit; else phi[g - V] = digit;
     }
     if constexpr (HALF && MODE == MUL_LOW) {
-        // digit K = lo32( x0[K] + x1[K-1] + x2[K-2] + hi(t(K-1)) + carry out of digit K-1 )
-        const u64 tp = (u64)s.x0[K + 2] + s.x1[K + 1] + s.x2[K];
-        dk = s.x0[K + 3] + s.x1[K + 2] + s.x2[K + 1] + (u32)(tp >> 32) + (cin ? 1u : 0u);
+        // digit K = lo32( x0(K) + x1(K-1) + x2(K-2) + hi32 t(K-1) + carry out of digit K-1 ); x0(K) was left in x0[K+3]
+        dk = s.x0[K + 3] + __builtin_amdgcn_readlane(prev_x1, 63) + __builtin_amdgcn_readlane(prev_r1, 63) +
+             __builtin_amdgcn_readlane(prev_thi, 63) + (cin ? 1u : 0u);
     } else {
         dk = 0;
     }

@@ -16,15 +16,17 @@ for _ in range(2):
 torch.cuda.synchronize()
 t = [int(l) for l in open("/tmp/h2r_chain_timing.txt")]
 d = [b - a for a, b in zip(t, t[1:])]
-# 7 stamps per block_mul: [pre-B1, post-B1, pre-B2(after products), post-B2, pre-B3(after reduce), post-B3, end(phase C)]
-names = ["B1 wait", "products", "B2 wait", "reduce", "B3 wait", "phaseC", "glue->next"]
-n = len(t) // 7
-print("stamps", len(t), "block_muls", n, "total cycles", t[-1] - t[0], "(s_memtime ticks; 100 MHz counter => x ~21 for shader cycles at 2.1 GHz?)")
+# 5 stamps per block_mul: [pre-B1, post-B1, pre-B2(after products), post-B2, end(reduce + carries by wave 0)]
+# (each stamp itself costs ~265 cycles: subtract that from every interval)
+names = ["B1 wait", "products", "B2 wait", "reduce+carries", "glue->next"]
+NS = len(names)
+n = len(t) // NS
+print("stamps", len(t), "block_muls", n, "total cycles", t[-1] - t[0], "(s_memtime ticks ~ shader cycles)")
 import collections
 acc = collections.defaultdict(list)
 for k in range(n):
-    for j in range(7):
-        idx = 7 * k + j
+    for j in range(NS):
+        idx = NS * k + j
         if idx < len(d):
             acc[(k % 3, names[j])].append(d[idx])
 for mode, mn in enumerate(["FULL", "HIGH", "LOW"]):
