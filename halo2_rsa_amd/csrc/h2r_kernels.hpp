@@ -118,6 +118,18 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// Sum of a 32-bit value over the 64 lanes (all active), result valid in lane 63: an inclusive DPP scan
+// (row_shr 1/2/4/8, row_bcast 15/31) -- six VALU instructions instead of six LDS-routed butterfly shuffles.
+__device__ __forceinline__ u32 wave_sum_u32(u32 v) {
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // K x K digit product A (K digits at `A`) x B (padded at `Bpad`) computed by the whole block.  All
 // waves accumulate column partial sums; WAVE 0 alone receives the normalised digits (lane holds
 // columns v = lane + 64m in plo[m] and v + K in phi[m]) -- it owns the serial carry/decision logic
@@ -249,9 +261,8 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
                 u32 t = 0;
 #pragma unroll
                 for (int m = 0; m < V; ++m) { const int j = lane + 64 * m; if (j >= 1 && j < K) t += A[j] * Bpad[K + K - j]; }
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
-                if (lane == 0) s.x0[K + 3] = t;   // x0 of column K (published by the barrier below; the reduce skips c = K)
+                t = wave_sum_u32(t);   // DPP scan: the total sits in lane 63
+                if (lane == 63) s.x0[K + 3] = t;   // x0 of column K (published by the barrier below; the reduce skips c = K)
             }
         }
     }
@@ -550,13 +561,13 @@ __device__ __forceinline__ int block_mulmod(ChainLds<K, NW> &s, u32 shift, int l
     if (w0) lds_store<K>(s.opa, q, lane);
     u32 zlo[V], zhi[V];
     block_mul<K, NW, MUL_LOW, DEEP>(s.opa, s.nnpad, s, lane, wave, zlo, zhi, dk);
-    if (K < 64) dk = __shfl(zhi[0], 0);   // full product was computed: digit K is its first high digit
+    if (K < 64) dk = __builtin_amdgcn_readfirstlane(zhi[0]);   // full product was computed: digit K is its first high digit
     u32 rl[V];
 #pragma unroll
     for (int m = 0; m < V; ++m) rl[m] = 0;
     if (w0) {
         const bool b0 = wave_sub<K>(rl, xlo, zlo, lane);
-        u32 rtop = __shfl(xhi[0], 0) - dk - (b0 ? 1u : 0u);
+        u32 rtop = __builtin_amdgcn_readfirstlane(xhi[0]) - dk - (b0 ? 1u : 0u);
         for (int it = 0; it < 8; ++it) {
             if (rtop == 0 && !wave_ge<K>(rl, nn, lane)) break;
             u32 t[V];
@@ -1108,7 +1119,7 @@ __global__ __launch_bounds__(BT) void trace_kernel(TraceArgs args) {
     const u64 bad = __ballot(col && !(f1 && f2));
     bool prev_ok;
     if constexpr (TPI <= 64) {
-        const u64 seg = (TPI == 64) ? ~0ull : (((1ull << TPI) - 1) << (lane - t));
+        const u64 seg = (TPI == 64) ? ~0ull : (((1ull << (TPI & 63)) - 1) << (lane - t));
         prev_ok = (bad & seg & ((1ull << lane) - 1)) == 0;
     } else {
         if (lane == 0) xbad[wave] = bad;
