@@ -277,7 +277,8 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
             // co-scheduled with the next batch's chain kernel: cap the trace kernel's residency (its store
             // stream does not need full occupancy) 
             // (measured sweep: profiles/r01_pipeline_sweep.txt -- 32000 B extra LDS = 3 blocks/CU, normal priority)
-            if (!std::getenv("H2R_TRACE_DYN_LDS")) ta.dyn_lds = 32000;
+            // (a latency-build chain kernel -- at most two 4-wave workgroups per CU -- leaves room for the sparser setting)
+            if (!std::getenv("H2R_TRACE_DYN_LDS")) ta.dyn_lds = batch <= 512 ? 45000 : 32000;
             // a chain kernel with more than ~8 workgroups per CU queued keeps every CU full of its waves: the record
             // kernel's waves then need the raised wave priority to keep their stores issuing (batch 8192: 2.11 -> 2.05 ms)
             if (!std::getenv("H2R_TRACE_PRIO") && batch > 2048) ta.prio = 1;
