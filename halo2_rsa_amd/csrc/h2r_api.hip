@@ -129,6 +129,11 @@ hipError_t launch_trace_bt(const TraceArgs &ta, hipStream_t st, hipEvent_t ea, h
     const u64 blocks = (ta.n_items + IPB - 1) / IPB;
     if (blocks == 0) return hipSuccess;
     // dyn_lds > 0 caps the blocks resident per CU; ea/eb (nullable): start/stop events stamped by the dispatch itself
+    if (ta.dyn_lds > 48 * 1024) {   // large requests must be announced (once per device; harmless to repeat)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&trace_kernel<LW, L, BT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)ta.dyn_lds);
+        (void)hipGetLastError();
+    }
     hipExtLaunchKernelGGL((trace_kernel<LW, L, BT>), dim3((unsigned)blocks), dim3(BT), ta.dyn_lds, st, ea, eb, 0, ta);
     return hipGetLastError();
 }
