@@ -57,6 +57,25 @@ struct ProfScope {  // start/stop events of one launch when profiling is armed
     }
 };
 
+// Developer knobs (environment, read once): they only override the measured defaults for the sweeps under tools/.
+struct Knobs {
+    int chain_nw = 0, chain_deep = -1;          // H2R_CHAIN_NW, H2R_CHAIN_DEEP
+    long trace_dyn_lds = -1, trace_prio = -1;    // H2R_TRACE_DYN_LDS, H2R_TRACE_PRIO
+    long chain_prio = -1, ablate = 0;            // H2R_CHAIN_PRIO, H2R_ABLATE (needs the -DH2R_ABLATION build)
+    int pipe_stream_prio = 0;                    // H2R_PIPE_STREAM_PRIO = low (default) | normal | high  -> -1 | 0 | +1
+    bool chain_timing = false;                   // H2R_CHAIN_TIMING (needs the -DH2R_CHAIN_TIMING build)
+    Knobs() {
+        auto num = [](const char *name, long dflt) { const char *v = std::getenv(name); return v ? std::atol(v) : dflt; };
+        chain_nw = (int)num("H2R_CHAIN_NW", 0); chain_deep = (int)num("H2R_CHAIN_DEEP", -1);
+        trace_dyn_lds = num("H2R_TRACE_DYN_LDS", -1); trace_prio = num("H2R_TRACE_PRIO", -1);
+        chain_prio = num("H2R_CHAIN_PRIO", -1); ablate = num("H2R_ABLATE", 0);
+        const char *pe = std::getenv("H2R_PIPE_STREAM_PRIO");
+        pipe_stream_prio = !pe ? -1 : (!std::strcmp(pe, "high") ? 1 : (!std::strcmp(pe, "low") ? -1 : 0));
+        chain_timing = std::getenv("H2R_CHAIN_TIMING") != nullptr;
+    }
+};
+const Knobs &knobs() { static const Knobs k; return k; }
+
 // The event a pipeline waits on for one call's record kernel.  With the profiler armed it is the profiler's own
 // stop event (borrowed; alive while g_prof_gen == gen), so that no extra marker packet sits between kernels.
 struct DoneRef { hipEvent_t ev = nullptr; u32 gen = 0; bool borrowed = false; };
@@ -167,8 +186,7 @@ hipError_t launch_chain(u32 K, const ChainArgs &ca, hipStream_t st, hipEvent_t e
             // Throughput build (6 blocks per CU) when the batch fills the chip; latency build (deep operand prefetch,
             // 139 VGPRs) when there are at most two elements per CU and each chain's own latency is what the call
             // waits for (BASELINE config 5: 256 elements x 3,072 dependent mul_mods: 9.4 -> 7.8 ms, tools/c5_sweep.sh).
-            static const int nw_env = std::getenv("H2R_CHAIN_NW") ? std::atoi(std::getenv("H2R_CHAIN_NW")) : 0;
-            static const int deep_env = std::getenv("H2R_CHAIN_DEEP") ? std::atoi(std::getenv("H2R_CHAIN_DEEP")) : -1;
+            const int nw_env = knobs().chain_nw, deep_env = knobs().chain_deep;
             const bool small = ca.batch <= 512;
             const int nw = nw_env ? nw_env : 4;
             const bool deep = deep_env >= 0 ? deep_env != 0 : small;
@@ -196,9 +214,9 @@ void fill_trace_args(const h2r_ctx *c, TraceArgs &ta) {
     ta.record_stride = lo.record_stride;
     ta.acc_spg = lo.acc_steps_per_group; ta.acc_lo_row = lo.acc_lo_row_bytes; ta.acc_lo_group = lo.acc_lo_group_bytes; ta.acc_hi_group = lo.acc_hi_group_bytes;
     ta.const_rec = c->const_rec_dev;
-    if (const char *ab = std::getenv("H2R_ABLATE")) ta.ablate = (u32)std::atoi(ab);
-    if (const char *dl = std::getenv("H2R_TRACE_DYN_LDS")) ta.dyn_lds = (u32)std::atoi(dl);
-    if (const char *pr = std::getenv("H2R_TRACE_PRIO")) ta.prio = (u32)std::atoi(pr);
+    ta.ablate = (u32)knobs().ablate;
+    if (knobs().trace_dyn_lds >= 0) ta.dyn_lds = (u32)knobs().trace_dyn_lds;
+    if (knobs().trace_prio >= 0) ta.prio = (u32)knobs().trace_prio;
 }
 
 // Common driver: chain kernel (q, r of every mul_mod) then trace kernel (the witness records).
@@ -243,13 +261,13 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         if (mode != CHAIN_POW_VAR) { ca.off_e_bits = 0; ca.off_selected = 0; }
     }
     if (eb) ca.e = *eb;
-    if (const char *pr = std::getenv("H2R_CHAIN_PRIO")) ca.prio = (u32)std::atoi(pr);
+    if (knobs().chain_prio >= 0) ca.prio = (u32)knobs().chain_prio;
     // Pipeline mode: the record stream must wait for this chain kernel.  The event it waits on is the dispatch's own
     // stop event (the profiler's when armed, else chain_done) -- no separate marker packet.
     hipEvent_t chain_wait = nullptr;
 #ifdef H2R_CHAIN_TIMING   // developer build (tools/chain_timing.py): dump block 0's s_memtime stamps
     static u64 *dbg_buf = nullptr;
-    if (std::getenv("H2R_CHAIN_TIMING")) { if (!dbg_buf) (void)hipMalloc(&dbg_buf, 4096 * 8); (void)hipMemsetAsync(dbg_buf, 0, 4096 * 8, st); ca.dbg_time = dbg_buf; }
+    if (knobs().chain_timing) { if (!dbg_buf) (void)hipMalloc(&dbg_buf, 4096 * 8); (void)hipMemsetAsync(dbg_buf, 0, 4096 * 8, st); ca.dbg_time = dbg_buf; }
 #endif
     {
         ProfScope ps(H2R_KERNEL_CHAIN, st, true);
@@ -277,16 +295,17 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         // Residency of the record kernel (a dynamic-LDS request that is never touched caps the workgroups per CU).
         // With non-temporal stores the RSA-2048 shape writes fastest with FEW concurrent store streams: alone, one
         // workgroup (4 records in flight) per CU -- 0.227 -> 0.213 ms, 5.87 TB/s; next to a chain kernel, three.
-        if (!std::getenv("H2R_TRACE_DYN_LDS") && lo.limb_width == 64 && c->L == 32) ta.dyn_lds = 90000;
+        const bool tune_lds = knobs().trace_dyn_lds < 0;
+        if (tune_lds && lo.limb_width == 64 && c->L == 32) ta.dyn_lds = 90000;
         if (trace_st) {
             // co-scheduled with the next batch's chain kernel: cap the trace kernel's residency (its store
             // stream does not need full occupancy) 
             // (measured sweep: profiles/r01_pipeline_sweep.txt -- 32000 B extra LDS = 3 blocks/CU, normal priority)
             // (a latency-build chain kernel -- at most two 4-wave workgroups per CU -- leaves room for the sparser setting)
-            if (!std::getenv("H2R_TRACE_DYN_LDS")) ta.dyn_lds = batch <= 512 ? 45000 : 32000;
+            if (tune_lds) ta.dyn_lds = batch <= 512 ? 45000 : 32000;
             // a chain kernel with more than ~8 workgroups per CU queued keeps every CU full of its waves: the record
             // kernel's waves then need the raised wave priority to keep their stores issuing (batch 8192: 2.11 -> 2.05 ms)
-            if (!std::getenv("H2R_TRACE_PRIO") && batch > 2048) ta.prio = 1;
+            if (knobs().trace_prio < 0 && batch > 2048) ta.prio = 1;
             HIP_TRY(hipStreamWaitEvent(trace_st, chain_wait, 0));
             ts = trace_st;
         }
@@ -608,8 +627,7 @@ int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side
     // record kernel should fill what the chain kernel leaves, not the other way round (measured: tools/dist_ab.sh).
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    int prio = prio_least;
-    if (const char *pe = std::getenv("H2R_PIPE_STREAM_PRIO")) prio = !std::strcmp(pe, "high") ? prio_greatest : (!std::strcmp(pe, "low") ? prio_least : 0);
+    const int prio = knobs().pipe_stream_prio < 0 ? prio_least : (knobs().pipe_stream_prio > 0 ? prio_greatest : 0);
     for (int i = 0; ok && i < n_aux; ++i)
         ok = hip_ok(hipStreamCreateWithPriority(&p->aux[i], hipStreamNonBlocking, prio), "hipStreamCreate");
     if (ok && n_aux == 1) p->aux[1] = p->aux[0];

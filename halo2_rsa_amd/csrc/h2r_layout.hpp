@@ -166,7 +166,6 @@ inline void layout_compute(u32 w, u32 L, h2r_layout *o) {
     // HBM channel interleaving: record strides of 253*256 / 257*256 bytes alias (measured -10 % on the
     // trace kernel, profiles/r01_stride_sweep.txt); 255*256 does not.
     if (w == 64 && L == 32) o->record_stride += 512;
-    if (const char *pad = std::getenv("H2R_RECORD_PAD")) o->record_stride += 256ull * (u64)std::atoi(pad);  // experiment knob
     const u64 per_col = 5ull * WB + 2ull * CB + 4ull * LB + 4;
     o->stream_bytes = 2ull * L * (LB + o->limb_nsub) + 2ull * L * L * WB + (u64)L * WB + (u64)C * per_col +
                       (u64)(C - 1) * (CB + o->carry_nsub);
