@@ -107,7 +107,6 @@ struct ChainLds {
     u32 mupad[3 * K];            // mu' = floor((2^(64K) - 1) / n') - 2^(32K), padded
     u32 part[Geo<K, NW>::SSMAX][3][2 * K];  // per-slice column partial sums (3 words)
     u32 x0[2 * K + 4];                   // shift scratch; x0[K+3] = low word of column K for the low half product
-    u32 rx0[K + 1], rx1[K + 1];          // wave-0 scratch of the reciprocal
     alignas(16) u32 stage[4 * K];        // a, b, q, r of one mul_mod on their way to the ops buffer
     u64 *dbg; u32 dbg_n;                 // debug timing (nullable)
 };
@@ -417,48 +416,58 @@ __device__ __forceinline__ void wave_reciprocal(ChainLds<K, NW> &s, const u32 (&
     using G = Geo<K, NW>;
     constexpr int V = G::V;
     u32 rem[V];
-    u32 *x0 = s.rx0, *x1 = s.rx1;
-    (void)wave;
+    (void)wave; (void)s;
 #pragma unroll
     for (int m = 0; m < V; ++m) { rem[m] = ~nn[m]; mu[m] = 0; }
-    const u32 ntop = s.nnpad[K + K - 1];
+    // digit K-1 / K-2 of a lane-distributed number, and the number shifted up by one digit (digit v-1 in lane v):
+    // register traffic only (readlane, DPP wave_shr) -- the LDS round trips of an earlier version cost 40 % of the loop
+    constexpr int MT = (K - 1) / 64, LT = (K - 1) % 64, MS = K >= 2 ? (K - 2) / 64 : 0, LS = K >= 2 ? (K - 2) % 64 : 0;
+    auto shift_up = [&](u32 (&out)[V], const u32 (&in)[V], u32 fill) {
+        u32 up = fill;
+#pragma unroll
+        for (int m = 0; m < V; ++m) {
+            out[m] = (u32)__builtin_amdgcn_update_dpp((int)up, (int)in[m], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+            up = __builtin_amdgcn_readlane(in[m], 63);
+        }
+    };
+    const u32 ntop = __builtin_amdgcn_readlane(nn[MT], LT);
+    // vrec = floor((2^64 - 1) / ntop) - 2^32: the 2-by-1 division reciprocal of the normalised top digit
+    const u32 vrec = ntop ? (u32)(0xffffffffffffffffull / ntop - 0x100000000ull) : 0u;
     for (int j = K - 1; j >= 0; --j) {
-        wave_sync();
-        lds_store<K>(x0, rem, lane);
-        wave_sync();
-        const u32 top = x0[K - 1], second = (K >= 2) ? x0[K - 2] : 0xffffffffu;
+        const u32 top = __builtin_amdgcn_readlane(rem[MT], LT);
+        const u32 second = (K >= 2) ? __builtin_amdgcn_readlane(rem[MS], LS) : 0xffffffffu;
         u64 qd;  // 2-by-1 estimate of the quotient digit (exact for the two leading digits)
         if (top >= ntop) qd = 0xffffffffull;
         else {
-            const u64 num = ((u64)top << 32) | second;
-            qd = (u64)((double)num / (double)ntop);
-            if (qd > 0xffffffffull) qd = 0xffffffffull;
-            u128 prod = (u128)qd * ntop;
-            if (prod > num) { qd -= 1; prod -= ntop; }
-            if ((u128)num - prod >= ntop && qd < 0xffffffffull) { qd += 1; }
+            // floor((top * 2^32 + second) / ntop) with the precomputed reciprocal (Moeller-Granlund, exact for top < ntop)
+            const u64 qq = (u64)vrec * top + (((u64)top << 32) | second);
+            u32 q1 = (u32)(qq >> 32) + 1u;
+            const u32 q0 = (u32)qq;
+            u32 rr = second - q1 * ntop;
+            if (rr > q0) { q1 -= 1u; rr += ntop; }
+            if (rr >= ntop) { q1 += 1u; }
+            qd = q1;
         }
-        u32 plo[V], remsh[V], e[V];
+        u32 plo[V], phi[V], phi_prev[V], remsh[V], e[V];
 #pragma unroll
         for (int m = 0; m < V; ++m) {
-            const int v = lane + 64 * m;
             const u64 p = (u64)(u32)qd * nn[m];
-            plo[m] = (u32)p;
-            if (v < K) x1[v] = (u32)(p >> 32);
+            plo[m] = (u32)p; phi[m] = (lane + 64 * m < K) ? (u32)(p >> 32) : 0u;
         }
-        wave_sync();
+        shift_up(phi_prev, phi, 0u);
+        shift_up(remsh, rem, 0xffffffffu);
         bool cin = false;
 #pragma unroll
         for (int m = 0; m < V; ++m) {
             const int v = lane + 64 * m;
             const bool act = v < K;
-            const u32 phi_prev = (act && v >= 1) ? x1[v - 1] : 0;
-            remsh[m] = act ? (v >= 1 ? x0[v - 1] : 0xffffffffu) : 0;
-            const u64 d = act ? (u64)plo[m] + phi_prev : 0;
+            if (!act) remsh[m] = 0;
+            const u64 d = act ? (u64)plo[m] + phi_prev[m] : 0;
             const CarryGroup cg = carry_group(__ballot((d >> 32) != 0), __ballot(act && (u32)d == 0xffffffffu), cin, G::GW);
             cin = cg.cout;
             e[m] = (u32)d + (u32)((cg.cin_mask >> lane) & 1);
         }
-        const u32 etop = x1[K - 1] + (cin ? 1u : 0u);
+        const u32 etop = __builtin_amdgcn_readlane(phi[MT], LT) + (cin ? 1u : 0u);
         u32 diff[V];
         const bool bout = wave_sub<K>(diff, remsh, e, lane);
         i64 dtop = (i64)top - (i64)etop - (bout ? 1 : 0);
