@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--side-streams", type=int, default=1,
                     help="streams the record kernels alternate between; 2 lets consecutive record kernels overlap "
                          "(higher throughput, but each launch's duration then includes the overlap)")
+    ap.add_argument("--verify", action="store_true",
+                    help="time the whole verify_pkcs1v15_signature witness (in-field + modpow + encoded-message check) "
+                         "instead of modpow_public_key alone (RSA-2048 workloads, pipelined mode)")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="developer: do not arm the C ABI's per-kernel event timing (roofline fields become null)")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -159,7 +162,17 @@ def main():
     dev = "cuda:%d" % env.local_rank
     # two buffer sets: in pipeline mode step k+1's chain kernel overlaps step k's trace kernel
     nbuf = 1 if args.no_pipeline else args.pipeline_depth
-    trace_bufs = [torch.empty(batch * pl.elem_stride, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    elem_stride = pl.elem_stride
+    verify = args.verify and not args.no_pipeline and (w, bits) == (64, 2048)
+    if verify:   # whole verifier witness: the element also holds the in-field and encoded-message regions
+        import ctypes
+        vl = _lib.H2RVerifyLayout()
+        eb = e.to_bytes((e.bit_length() + 7) // 8, "little")
+        _lib.check(_lib.lib().h2r_verify_layout_fixed(chip._ctx, eb, len(eb), ctypes.byref(vl)), "h2r_verify_layout_fixed")
+        elem_stride = vl.elem_stride
+        hashed_dev = torch.randint(-2**62, 2**62, (batch, 4), dtype=torch.int64, device=dev)
+        valids = [torch.zeros(batch, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    trace_bufs = [torch.empty(batch * elem_stride, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     workspaces = [torch.empty(chip.workspace_bytes(batch, pl.num_mul_mods), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     outs = [torch.empty((batch, chip.num_limbs), dtype=chip.torch_dtype, device=dev) for _ in range(nbuf)]
     statuses = [torch.zeros(batch, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
@@ -172,6 +185,8 @@ def main():
         if pipe is None:
             chip.pow_mod_fixed_exp(x_dev, e, n_dev, want_trace=True, trace_buf=trace_bufs[b], check_in_field=True,
                                    workspace=workspaces[b], out=outs[b], status=statuses[b])
+        elif verify:
+            pipe.verify_pkcs1v15(x_dev, e, n_dev, hashed_dev, trace_bufs[b], workspaces[b], outs[b], valids[b], statuses[b])
         else:
             pipe.modpow_public_key(x_dev, e, n_dev, trace_bufs[b], workspaces[b], outs[b], statuses[b])
         return b
@@ -228,6 +243,7 @@ def main():
             "config": {"workload": "%s batch=%d per GPU, %d-bit limbs, full op-trace (%d B/assign)" %
                        (args.workload, batch, w, algo_bytes_per_assign),
                        "per_gpu_batch": batch, "global_batch": env.world * batch,
+                       "path": "verify_pkcs1v15_signature (in-field + modpow + EM check)" if verify else "modpow_public_key",
                        "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world,
                        "pipeline": ("chain k+1 || trace k, %d buffer sets, %d record stream(s)" % (args.pipeline_depth, args.side_streams))
                                    if pipe is not None else "none"},

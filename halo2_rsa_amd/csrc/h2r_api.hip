@@ -76,6 +76,19 @@ struct Knobs {
 };
 const Knobs &knobs() { static const Knobs k; return k; }
 
+// Element strides, in units of 256 bytes.  The record kernel's store rate depends on how consecutive elements' records
+// fall on the HBM channel interleave (sweep of the stride at batch 1024, profiles/r01_elem_stride_sweep.txt): the
+// compact pow element (19 * 255 + 20 = 4865 units) is the best, strides whose residue modulo 256 units lies around
+// 40..50 lose up to 10 % (that is where the verify element, 4904 units, landed), most others lose ~2 %.  Rule: odd
+// multiple of 256 bytes, and residues 24..62 are bumped to 65.
+inline u64 odd_stride_256(u64 bytes) {
+    u64 u = round_up(bytes, 256) / 256;
+    u |= 1;
+    const u64 r = u % 256;
+    if (r >= 24 && r <= 62) u += 65 - r;
+    return u * 256;
+}
+
 // The event a pipeline waits on for one call's record kernel.  With the profiler armed it is the profiler's own
 // stop event (borrowed; alive while g_prof_gen == gen), so that no extra marker packet sits between kernels.
 struct DoneRef { hipEvent_t ev = nullptr; u32 gen = 0; bool borrowed = false; };
@@ -456,7 +469,7 @@ int32_t h2r_pow_fixed_layout(const h2r_ctx *ctx, const uint8_t *e_le, size_t e_l
     out->off_records = 0;
     out->off_result = (u64)T * lo.record_stride;
     out->off_e_bits = UINT64_MAX; out->off_selected = UINT64_MAX; out->selected_stride = 0;
-    out->elem_stride = out->off_result + round_up((u64)lo.num_limbs * lo.limb_bytes, 256);
+    out->elem_stride = odd_stride_256(out->off_result + (u64)lo.num_limbs * lo.limb_bytes);
     out->stream_bytes = (u64)T * lo.stream_bytes + (u64)lo.num_limbs * lo.limb_bytes;
     return H2R_OK;
 }
@@ -475,7 +488,7 @@ int32_t h2r_pow_var_layout(const h2r_ctx *ctx, uint32_t e_num_limbs, uint32_t ex
     out->selected_stride = limbs_bytes;
     out->off_result = out->off_selected + nbits * limbs_bytes;
     out->off_e_bits = out->off_result + limbs_bytes;
-    out->elem_stride = out->off_e_bits + round_up(nbits, 256);
+    out->elem_stride = odd_stride_256(out->off_e_bits + nbits);
     out->stream_bytes = nbits + nbits * (2 * lo.stream_bytes + (u64)lo.num_limbs * lo.limb_bytes) + (u64)lo.num_limbs * lo.limb_bytes;
     return H2R_OK;
 }
@@ -549,7 +562,7 @@ int32_t h2r_verify_layout_fixed(const h2r_ctx *ctx, const uint8_t *e_le, size_t 
     out->in_field_stream_bytes = sb;
     out->off_em = out->off_in_field + round_up(g.in_field_sz(), 256);
     out->em_stream_bytes = 2ull * ctx->L + 34;
-    out->elem_stride = out->off_em + round_up(g.em_sz(), 256);
+    out->elem_stride = odd_stride_256(out->off_em + g.em_sz());
     out->stream_bytes = out->in_field_stream_bytes + out->pow.stream_bytes + out->em_stream_bytes;
     return H2R_OK;
 }
@@ -716,7 +729,8 @@ int32_t launch_verify_aux(const h2r_ctx *ctx, const void *sig, const void *n, co
     aa.trace = static_cast<u8 *>(trace); aa.elem_stride = vl.elem_stride; aa.off_in_field = vl.off_in_field; aa.off_em = vl.off_em;
     aa.is_valid = is_valid_out; aa.status = status;
     ProfScope ps(H2R_KERNEL_AUX, st);
-    hipLaunchKernelGGL((aux_kernel<64>), dim3((unsigned)batch), dim3(64), 0, st, aa);
+    const AuxGeom ag(ctx->L, 64);
+    hipLaunchKernelGGL((aux_kernel<64>), dim3((unsigned)batch), dim3(64), (unsigned)(ag.in_field_sz() + ag.em_sz()), st, aa);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
 }
