@@ -126,6 +126,9 @@ def ensure_built():
 
 
 def main():
+    # the image exports NCCL_DEBUG=VERSION, which makes RCCL print a banner on stdout; rank 0's stdout is ONE JSON line
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        os.environ.pop("NCCL_DEBUG")
     ensure_built()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
