@@ -108,6 +108,29 @@ def test_flatten_inverts_documented_layout(w, L):
     lib().h2r_ctx_destroy(c)
 
 
+def test_element_strides_avoid_slow_interleave_residues():
+    """Element strides (pow / var-pow / verify layouts) are odd multiples of 256 bytes whose residue modulo 256 units
+    stays out of 24..62 (DESIGN section 5, profiles/r01_elem_stride_sweep.txt), and they cover everything they hold."""
+    from halo2_rsa_amd._lib import H2RVerifyLayout
+    for w, L in ((64, 32), (64, 16), (64, 64), (32, 128)):
+        c = host_ctx(w, L)
+        pl = H2RPowLayout()
+        for e in (65537, 3, (1 << 2047) | 1, (1 << 40) - 1, 0x10001 << 7):
+            eb = int(e).to_bytes(max(1, (e.bit_length() + 7) // 8), "little")
+            assert lib().h2r_pow_fixed_layout(c, eb, len(eb), ctypes.byref(pl)) == 0
+            u = pl.elem_stride // 256
+            assert pl.elem_stride % 256 == 0 and u % 2 == 1 and not 24 <= u % 256 <= 62, (w, L, e, u)
+            assert pl.elem_stride >= pl.off_result + L * (w // 8)
+            if w == 64:
+                vl = H2RVerifyLayout()
+                assert lib().h2r_verify_layout_fixed(c, eb, len(eb), ctypes.byref(vl)) == 0
+                u = vl.elem_stride // 256
+                assert u % 2 == 1 and not 24 <= u % 256 <= 62 and vl.elem_stride >= vl.off_em + vl.em_stream_bytes
+        assert lib().h2r_pow_var_layout(c, 2, 5, ctypes.byref(pl)) == 0
+        assert (pl.elem_stride // 256) % 2 == 1
+        lib().h2r_ctx_destroy(c)
+
+
 def test_verify_layout_sizes(golden):
     """in-field / EM stream sizes of h2r_verify_layout_fixed equal the oracle's (SURVEY 8f next #1, #2)."""
     from halo2_rsa_amd._lib import H2RVerifyLayout
