@@ -102,6 +102,59 @@ def test_mul_mod_random_parity(H, w, L, batch):
             pytest.fail("w=%d L=%d elem %d kind %d: first stream mismatch at byte %d of %d" % (w, L, i, i % 8, bad, len(st)))
 
 
+def _adversarial_cases(bits, rng):
+    """(a, b, n) triples that stress carry propagation across the 32-bit digits, the 64-lane groups and the waves:
+    all-ones runs, digits at the extremes, moduli just above a power of two / just below 2^bits / with long 0xff.. or
+    zero stretches, operands n-1, and quotient-estimate corner cases (top digits equal)."""
+    full = (1 << bits) - 1
+    half = bits // 2
+    mods = [full, full - 2, (1 << (bits - 1)) + 1, (1 << (bits - 1)) | 1 | (((1 << half) - 1) << 16), (1 << (bits - 1)) + (1 << 32) - 1,
+            full ^ (((1 << 64) - 1) << (bits // 2)), (1 << (bits - 1)) | (1 << 31) | 1, full - (1 << (bits - 33)),
+            (0x80000000 << (bits - 32)) | ((1 << (bits - 32)) - 1), (0xffffffff << (bits - 32)) | 1,
+            (1 << 2047 | 0xffffffffffffffff0000000000000001) if bits == 2048 else (1 << (bits - 1)) | 0xff01]
+    out = []
+    for n in mods:
+        n |= 1 << (bits - 1)
+        cands = [n - 1, n - 2, (1 << (bits - 1)) - 1, (1 << half) - 1, ((1 << half) - 1) << (half - 3), full & (n - 1), 1, 0,
+                 int("ffffffff00000000" * (bits // 64), 16) % n, int("00000000ffffffff" * (bits // 64), 16) % n, rng.randrange(n)]
+        for a in cands[:6]:
+            for b in (cands[0], cands[2], cands[8], cands[9], cands[10]):
+                out.append((a % n, b % n, n))
+    return out
+
+
+@pytest.mark.parametrize("w,L", [(64, 32), (32, 128), (64, 16), (64, 64)])
+def test_mul_mod_adversarial_operands(H, w, L):
+    """The chain kernel's ballot carries, DPP neighbour exchange and correction loop on adversarial digits: results
+    against Python integers for every triple, full traces against the oracle for a sample.  330 elements keep the
+    batch in the latency build's range (<= 512) for RSA-2048; a second, padded batch of 1,100 runs the throughput build."""
+    bits = w * L
+    chip = H.BigIntChip(w, bits)
+    o = Oracle(w, L)
+    rng = random.Random(bits + w)
+    cases = _adversarial_cases(bits, rng)
+    for reps in (1, 4) if (w, L) == (64, 32) else (1,):
+        A = [c[0] for c in cases] * reps; B = [c[1] for c in cases] * reps; N = [c[2] for c in cases] * reps
+        res = chip.mul_mod(chip.assign_integer(A), chip.assign_integer(B), chip.assign_integer(N))
+        torch.cuda.synchronize()
+        assert not res.status.cpu().numpy().any()
+        r = res.value.to_big_uint()
+        bad = [i for i in range(len(A)) if r[i] != (A[i] * B[i]) % N[i]]
+        assert not bad, (w, L, reps, bad[:5])
+        for i in rng.sample(range(len(A)), 12):
+            rc, rr, ost = o.mul_mod(o.limbs(A[i]), o.limbs(B[i]), o.limbs(N[i]))
+            assert rc == 0 and np.array_equal(ost, res.trace.flatten(i)), (w, L, i)
+    # the same moduli through a long square-and-multiply chain (errors would compound)
+    e = (1 << 17) - 1
+    n_list = sorted({c[2] for c in cases})
+    X = [n - 2 for n in n_list]
+    pres = chip.pow_mod_fixed_exp(chip.assign_integer(X), e, chip.assign_integer(n_list), want_trace=False)
+    torch.cuda.synchronize()
+    assert not pres.status.cpu().numpy().any()
+    got = pres.value.to_big_uint()
+    assert all(got[i] == pow(X[i], e, n_list[i]) for i in range(len(X)))
+
+
 def test_mul_mod_golden_identities(H, golden):
     chip = H.BigIntChip(64, 2048)
     ids = golden["mul_mod_identities"]
