@@ -163,8 +163,8 @@ inline void layout_compute(u32 w, u32 L, h2r_layout *o) {
         o->acc_lo_group_bytes = (u64)L * 16; o->acc_hi_group_bytes = (u64)L * 16;
     }
     o->record_stride = off;
-    // HBM channel interleaving: record strides of 253*256 / 257*256 bytes alias (measured -10 % on the
-    // trace kernel, profiles/r01_stride_sweep.txt); 255*256 does not.
+    // HBM channel interleaving: the record kernel is sensitive to the record stride (one 256-byte unit less or more
+    // than this choice costs 2..10 %, profiles/r01_stride_sweep.txt; re-swept after every layout change).
     if (w == 64 && L == 32) o->record_stride += 512;
     const u64 per_col = 5ull * WB + 2ull * CB + 4ull * LB + 4;
     o->stream_bytes = 2ull * L * (LB + o->limb_nsub) + 2ull * L * L * WB + (u64)L * WB + (u64)C * per_col +
