@@ -309,13 +309,13 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         // With non-temporal stores the RSA-2048 shape writes fastest with FEW concurrent store streams: alone, one
         // workgroup (4 records in flight) per CU -- 0.227 -> 0.213 ms, 5.87 TB/s; next to a chain kernel, three.
         const bool tune_lds = knobs().trace_dyn_lds < 0;
-        if (tune_lds && lo.limb_width == 64 && c->L == 32) ta.dyn_lds = 90000;
+        if (tune_lds && lo.limb_width == 64 && c->L <= 32) ta.dyn_lds = 90000;   // measured for L = 32 and L = 16
         if (trace_st) {
             // co-scheduled with the next batch's chain kernel: cap the trace kernel's residency (its store
             // stream does not need full occupancy) 
             // (measured sweep: profiles/r01_pipeline_sweep.txt -- 32000 B extra LDS = 3 blocks/CU, normal priority)
             // (a latency-build chain kernel -- at most two 4-wave workgroups per CU -- leaves room for the sparser setting)
-            if (tune_lds) ta.dyn_lds = batch <= 512 ? 45000 : 32000;
+            if (tune_lds) ta.dyn_lds = (lo.limb_width == 64 && !(c->L == 32 && batch > 512)) ? 45000 : 32000;   // sweeps: DESIGN section 5
             // a chain kernel with more than ~8 workgroups per CU queued keeps every CU full of its waves: the record
             // kernel's waves then need the raised wave priority to keep their stores issuing (batch 8192: 2.11 -> 2.05 ms)
             if (knobs().trace_prio < 0 && batch > 2048) ta.prio = 1;
