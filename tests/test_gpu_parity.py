@@ -686,6 +686,52 @@ def test_pipeline_buffer_rotation(H, depth, side_streams, toggle_profiler):
     assert H.lib().h2r_pipeline_create_ex(chip._ctx, 2, 3, ctypes.byref(bad)) == H.H2R_E_SHAPE
 
 
+@pytest.mark.parametrize("depth,side_streams", [(2, 1), (3, 2)])
+def test_pipeline_full_size_rotation(H, depth, side_streams):
+    """The rotation contract at BASELINE config 2's size (1,024 signatures per call: the record kernel of call k really
+    overlaps the chain kernel of call k+1 and, with two record streams, the record kernel of call k+1).  Five calls with
+    different inputs over `depth` buffer sets; each call's results are copied out right before its buffers are reused
+    and must equal pow(x, e, n) for every element, with byte-exact traces for sampled elements."""
+    chip = H.BigIntChip(64, 2048)
+    o = Oracle(64, 32)
+    pipe = H.Pipeline(chip, depth=depth, side_streams=side_streams)
+    pl = chip.pow_fixed_layout(65537)
+    rng = random.Random(4242 + depth)
+    B, CALLS = 1024, 5
+    sets = [dict(trace=torch.empty(B * pl.elem_stride, dtype=torch.uint8, device="cuda"),
+                 ws=torch.empty(chip.workspace_bytes(B, pl.num_mul_mods), dtype=torch.uint8, device="cuda"),
+                 out=torch.empty((B, 32), dtype=torch.int64, device="cuda"),
+                 status=torch.zeros(B, dtype=torch.uint8, device="cuda")) for _ in range(depth)]
+    base_n = [rand_modulus(rng, 2048) for _ in range(B)]
+    inputs, snaps = [], {}
+    for k in range(CALLS):
+        N = base_n[k:] + base_n[:k]                      # a different pairing of moduli and bases per call
+        X = [(n >> (k + 1)) ^ (0x9e3779b97f4a7c15 * (i + 1) * (k + 1)) for i, n in enumerate(N)]
+        X = [x % n for x, n in zip(X, N)]
+        inputs.append((N, X, chip.assign_integer(N), chip.assign_integer(X)))
+    for k in range(CALLS):
+        s = sets[k % depth]
+        if k >= depth:
+            snaps[k - depth] = (s["trace"].clone(), s["out"].clone(), s["status"].clone())
+        pipe.modpow_public_key(inputs[k][3], 65537, inputs[k][2], s["trace"], s["ws"], s["out"], s["status"])
+    pipe.join()
+    for k in range(CALLS - depth, CALLS):
+        s = sets[k % depth]
+        snaps[k] = (s["trace"].clone(), s["out"].clone(), s["status"].clone())
+    torch.cuda.synchronize()
+    for k in range(CALLS):
+        N, X = inputs[k][0], inputs[k][1]
+        trace, out, status = snaps[k]
+        assert not status.cpu().numpy().any()
+        got = H.AssignedInteger(out, 64).to_big_uint()
+        assert all(got[i] == pow(X[i], 65537, N[i]) for i in range(B)), k
+        tr = H.Trace(chip, trace, B, pl)
+        for i in (0, 511, B - 1):
+            rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(X[i]), o.limbs(N[i]), 65537)
+            assert np.array_equal(ost, tr.flatten(i)), (k, i)
+    pipe.close()
+
+
 def _check_pow_batch(H, chip, o, X, N, e, res, sample, rng):
     torch.cuda.synchronize()
     assert not res.status.cpu().numpy().any()
