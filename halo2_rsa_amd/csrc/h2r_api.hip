@@ -313,7 +313,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         if (trace_st) {
             // co-scheduled with the next batch's chain kernel: cap the trace kernel's residency (its store
             // stream does not need full occupancy) 
-            // (measured sweep: profiles/r01_pipeline_sweep.txt -- 32000 B extra LDS = 3 blocks/CU, normal priority)
+            // (first sweep: profiles/history/r01_pipeline_sweep.txt; re-swept after the streaming stores)
             // (a latency-build chain kernel -- at most two 4-wave workgroups per CU -- leaves room for the sparser setting)
             if (tune_lds) ta.dyn_lds = (lo.limb_width == 64 && !(c->L == 32 && batch > 512)) ? 45000 : 32000;   // sweeps: DESIGN section 5
             // a chain kernel with more than ~8 workgroups per CU queued keeps every CU full of its waves: the record
