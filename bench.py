@@ -176,8 +176,9 @@ def main():
         elem_stride = vl.elem_stride
         hashed_dev = torch.randint(-2**62, 2**62, (batch, 4), dtype=torch.int64, device=dev)
         valids = [torch.zeros(batch, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    trace_bufs = [torch.empty(batch * elem_stride, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    workspaces = [torch.empty(chip.workspace_bytes(batch, pl.num_mul_mods), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    # zero-filled, so every page is resident before the first (possibly un-warmed) timed step touches it
+    trace_bufs = [torch.zeros(batch * elem_stride, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    workspaces = [torch.zeros(chip.workspace_bytes(batch, pl.num_mul_mods), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     outs = [torch.empty((batch, chip.num_limbs), dtype=chip.torch_dtype, device=dev) for _ in range(nbuf)]
     statuses = [torch.zeros(batch, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     pipe = None if args.no_pipeline else H.Pipeline(chip, depth=args.pipeline_depth, side_streams=args.side_streams)
