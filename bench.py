@@ -196,6 +196,10 @@ def main():
             pipe.modpow_public_key(x_dev, e, n_dev, trace_bufs[b], workspaces[b], outs[b], statuses[b])
         return b
 
+    # initialisation that is not part of any step (code-object load, stream / event creation on first use): one call,
+    # then the W warm-up steps the caller asked for
+    step()
+    counter[0] = 0
     for _ in range(warmup):
         step()
     if pipe is not None:
