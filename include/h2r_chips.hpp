@@ -298,6 +298,16 @@ class Pipeline {
                                            static_cast<uint8_t *>(b.is_valid.get()), static_cast<uint8_t *>(b.status.get()),
                                            b.workspace.get(), stream), "h2r_pipeline_verify_pkcs1v15");
     }
+    // RSAInstructions::modpow_public_key (src/chip.rs:99-114, RSAPubE::Fix), asynchronous on `stream`; uses the
+    // trace / workspace / powed / status members of the buffer set (its trace region is large enough for the pow trace)
+    void modpow_public_key(const AssignedInteger &x, const AssignedRSAPublicKey &pk, Buffers &b, hipStream_t stream = nullptr) {
+        auto *f = std::get_if<RSAPubE::Fix>(&pk.e);
+        if (!f) throw Error(H2R_E_UNSUPPORTED, "Pipeline::modpow_public_key (takes RSAPubE::Fix)");
+        const size_t batch = x.batch();
+        check(h2r_pipeline_modpow_public_key(p_, x.data(), pk.n.data(), f->e_le.data(), f->e_le.size(), batch,
+                                             (pk.n.batch() == 1 && batch != 1) ? H2R_F_SHARED_MODULUS : 0u, b.trace.get(), b.powed.get(),
+                                             static_cast<uint8_t *>(b.status.get()), b.workspace.get(), stream), "h2r_pipeline_modpow_public_key");
+    }
     void join(hipStream_t stream = nullptr) { check(h2r_pipeline_join(p_, stream), "h2r_pipeline_join"); }
     // an element's whole verify witness in the reference's order (after join() + synchronisation)
     std::vector<uint8_t> flatten(const Buffers &b, size_t elem) const {

@@ -102,6 +102,18 @@ int main(int argc, char **argv) {
             }
         }
     }
+    // pipelined modpow_public_key: the powed limbs equal the verifier's
+    {
+        Pipeline pipe(rsa_chip, 2, 1);
+        const std::vector<uint8_t> e65537 = {0x01, 0x00, 0x01};
+        Pipeline::Buffers bufs[2] = {pipe.make_buffers(B, e65537), pipe.make_buffers(B, e65537)};
+        for (int k = 0; k < 2; ++k) pipe.modpow_public_key(sign.c, pk, bufs[k]);
+        pipe.join();
+        REQUIRE(hipDeviceSynchronize() == hipSuccess);
+        std::vector<uint64_t> got(B * 32), want = res.powed.limbs();
+        bufs[1].powed.download(got.data(), got.size() * 8);
+        REQUIRE(got == want);
+    }
     // BigIntChip::new asserts bits_len % limb_width == 0 (big_integer/chip.rs:1175) -> exception
     bool threw = false;
     try { BigIntChip bad(64, 2048 + 8); } catch (const Error &e) { threw = e.code == H2R_E_SHAPE; }
