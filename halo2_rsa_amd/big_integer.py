@@ -135,11 +135,32 @@ class Trace:
         return perm, rows
 
 
+class InFieldTrace:
+    """The assert_in_field(x, n) witness of RSAChip::modpow_public_key (src/chip.rs:106): per element the flat stream of
+    the is_in_field Fresh op, sections 16-byte aligned in the device buffer (h2r_fresh_op_flatten packs them)."""
+
+    def __init__(self, chip: "BigIntChip", buf: torch.Tensor, batch: int, elem_stride: int, stream_bytes: int):
+        self.chip, self.buf, self.batch, self.elem_stride, self.stream_bytes = chip, buf, batch, elem_stride, stream_bytes
+
+    def flatten(self, elem: int) -> np.ndarray:
+        host = np.ascontiguousarray(self.buf[elem * self.elem_stride:(elem + 1) * self.elem_stride].cpu().numpy())
+        out = np.zeros(self.stream_bytes, dtype=np.uint8)
+        check(lib().h2r_fresh_op_flatten(self.chip._ctx, _lib.FRESH_OPS.index("is_in_field"), host.ctypes.data, out.ctypes.data),
+              "h2r_fresh_op_flatten")
+        return out
+
+
 @dataclass
 class BatchResult:
     value: AssignedInteger      # a*b mod n  /  a^e mod n
     trace: Optional[Trace]
     status: torch.Tensor        # uint8 [batch], H2R_* per element
+    in_field: Optional[InFieldTrace] = None   # modpow_public_key only: the assert_in_field witness
+
+    def flatten(self, elem: int) -> np.ndarray:
+        """The element's witness in the reference's assignment order (modpow_public_key: in-field stream, then pow)."""
+        st = self.trace.flatten(elem)
+        return np.concatenate([self.in_field.flatten(elem), st]) if self.in_field is not None else st
 
 
 class BigIntChip:
@@ -235,11 +256,19 @@ class BigIntChip:
         check(lib().h2r_pow_fixed_layout(self._ctx, eb, len(eb), ctypes.byref(pl)), "h2r_pow_fixed_layout")
         return pl
 
+    def in_field_layout(self):
+        """(element stride, flat-stream bytes) of the assert_in_field witness = the is_in_field Fresh op."""
+        es, sb = ctypes.c_uint64(), ctypes.c_uint64()
+        check(lib().h2r_fresh_op_layout(self._ctx, _lib.FRESH_OPS.index("is_in_field"), ctypes.byref(es), ctypes.byref(sb), None),
+              "h2r_fresh_op_layout")
+        return es.value, sb.value
+
     def pow_mod_fixed_exp(self, a: AssignedInteger, e: int, n: AssignedInteger, want_trace: bool = True,
                           trace_buf: Optional[torch.Tensor] = None, check_in_field: bool = False,
                           workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                          status: Optional[torch.Tensor] = None) -> BatchResult:
-        """big_integer/chip.rs:710-742 (check_in_field=True: RSAChip::modpow_public_key, src/chip.rs:99-114)."""
+                          status: Optional[torch.Tensor] = None, in_field_buf: Optional[torch.Tensor] = None) -> BatchResult:
+        """big_integer/chip.rs:710-742.  check_in_field=True: RSAChip::modpow_public_key (src/chip.rs:99-114) -- the
+        assert_in_field witness goes to `in_field` of the result (allocated here unless in_field_buf is given)."""
         batch = a.batch
         dev = "cuda:%d" % self.device
         pl = self.pow_fixed_layout(e)
@@ -248,15 +277,30 @@ class BigIntChip:
             trace_buf = torch.empty(batch * pl.elem_stride, dtype=torch.uint8, device=dev)
         out = self._new_limbs(batch) if out is None else out
         status = torch.zeros(batch, dtype=torch.uint8, device=dev) if status is None else status
-        fn = lib().h2r_modpow_public_key_batch if check_in_field else lib().h2r_pow_mod_fixed_exp_batch
-        check(fn(self._ctx, a.data_ptr(), n.data_ptr(), eb, len(eb), batch, self._flags(n, batch),
-                 trace_buf.data_ptr() if want_trace else None, out.data_ptr(), status.data_ptr(),
-                 workspace.data_ptr() if workspace is not None else None, self._stream()), "pow_mod_fixed_exp")
-        return BatchResult(AssignedInteger(out, self.limb_width), Trace(self, trace_buf, batch, pl) if want_trace else None, status)
+        tp = trace_buf.data_ptr() if want_trace else None
+        wp = workspace.data_ptr() if workspace is not None else None
+        in_field = None
+        if check_in_field:
+            in_field = self._in_field_trace(batch, in_field_buf) if want_trace else None
+            check(lib().h2r_modpow_public_key_batch(self._ctx, a.data_ptr(), n.data_ptr(), eb, len(eb), batch, self._flags(n, batch), tp,
+                                                    in_field.buf.data_ptr() if in_field is not None else None, out.data_ptr(),
+                                                    status.data_ptr(), wp, self._stream()), "modpow_public_key")
+        else:
+            check(lib().h2r_pow_mod_fixed_exp_batch(self._ctx, a.data_ptr(), n.data_ptr(), eb, len(eb), batch, self._flags(n, batch), tp,
+                                                    out.data_ptr(), status.data_ptr(), wp, self._stream()), "pow_mod_fixed_exp")
+        return BatchResult(AssignedInteger(out, self.limb_width), Trace(self, trace_buf, batch, pl) if want_trace else None, status, in_field)
+
+    def _in_field_trace(self, batch, buf=None) -> "InFieldTrace":
+        es, sb = self.in_field_layout()
+        if buf is None:
+            buf = torch.zeros(batch * es, dtype=torch.uint8, device="cuda:%d" % self.device)
+        assert buf.numel() >= batch * es
+        return InFieldTrace(self, buf, batch, es, sb)
 
     def pow_mod(self, a: AssignedInteger, e: AssignedInteger, n: AssignedInteger, exp_limb_bits: int,
-                want_trace: bool = True) -> BatchResult:
-        """big_integer/chip.rs:664-696: variable exponent, `exp_limb_bits` bits used per e-limb."""
+                want_trace: bool = True, check_in_field: bool = False) -> BatchResult:
+        """big_integer/chip.rs:664-696: variable exponent, each e-limb decomposed into `exp_limb_bits` bits.
+        check_in_field=True: RSAChip::modpow_public_key with RSAPubE::Var (src/chip.rs:106-110)."""
         batch = a.batch
         dev = "cuda:%d" % self.device
         pl = H2RPowLayout()
@@ -264,10 +308,18 @@ class BigIntChip:
         trace = torch.empty(batch * pl.elem_stride, dtype=torch.uint8, device=dev) if want_trace else None
         out = self._new_limbs(batch)
         status = torch.zeros(batch, dtype=torch.uint8, device=dev)
-        check(lib().h2r_pow_mod_batch(self._ctx, a.data_ptr(), e.data_ptr(), e.num_limbs(), exp_limb_bits, n.data_ptr(), batch,
-                                      self._flags(n, batch), trace.data_ptr() if want_trace else None, out.data_ptr(),
-                                      status.data_ptr(), None, self._stream()), "pow_mod")
-        return BatchResult(AssignedInteger(out, self.limb_width), Trace(self, trace, batch, pl) if want_trace else None, status)
+        tp = trace.data_ptr() if want_trace else None
+        in_field = None
+        if check_in_field:
+            in_field = self._in_field_trace(batch) if want_trace else None
+            check(lib().h2r_modpow_public_key_var_batch(self._ctx, a.data_ptr(), e.data_ptr(), e.num_limbs(), exp_limb_bits, n.data_ptr(),
+                                                        batch, self._flags(n, batch), tp,
+                                                        in_field.buf.data_ptr() if in_field is not None else None, out.data_ptr(),
+                                                        status.data_ptr(), None, self._stream()), "modpow_public_key")
+        else:
+            check(lib().h2r_pow_mod_batch(self._ctx, a.data_ptr(), e.data_ptr(), e.num_limbs(), exp_limb_bits, n.data_ptr(), batch,
+                                          self._flags(n, batch), tp, out.data_ptr(), status.data_ptr(), None, self._stream()), "pow_mod")
+        return BatchResult(AssignedInteger(out, self.limb_width), Trace(self, trace, batch, pl) if want_trace else None, status, in_field)
 
     # ---- the Fresh-integer family (add / sub / add_mod / sub_mod / comparisons) -----------------------
     def _fresh_op(self, name: str, a: AssignedInteger, b: Optional[AssignedInteger], n: Optional[AssignedInteger]) -> "FreshResult":
@@ -390,10 +442,12 @@ class Pipeline:
         self._p = ctypes.c_void_p()
         check(lib().h2r_pipeline_create_ex(chip._ctx, depth, side_streams, ctypes.byref(self._p)), "h2r_pipeline_create_ex")
 
-    def modpow_public_key(self, x: AssignedInteger, e: int, n: AssignedInteger, trace_buf, workspace, out, status):
+    def modpow_public_key(self, x: AssignedInteger, e: int, n: AssignedInteger, trace_buf, workspace, out, status, in_field_buf=None):
+        """in_field_buf (optional): batch * in_field_layout()[0] bytes for the assert_in_field witness."""
         eb = _e_bytes(e)
         check(lib().h2r_pipeline_modpow_public_key(self._p, x.data_ptr(), n.data_ptr(), eb, len(eb), x.batch,
-                                                   self.chip._flags(n, x.batch), trace_buf.data_ptr(), out.data_ptr(),
+                                                   self.chip._flags(n, x.batch), trace_buf.data_ptr(),
+                                                   in_field_buf.data_ptr() if in_field_buf is not None else None, out.data_ptr(),
                                                    status.data_ptr(), workspace.data_ptr(), self.chip._stream()),
               "h2r_pipeline_modpow_public_key")
 

@@ -30,6 +30,22 @@ bool hip_ok(hipError_t e, const char *what) {
         if (!hip_ok((expr), #expr)) return H2R_E_HIP;   \
     } while (0)
 
+// Every export that touches the device selects the ctx's device for the duration of the call and restores the caller
+// thread's current device on return (the library has no thread-global side effects).
+struct DeviceGuard {
+    int prev = -1; bool switched = false; hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) { err = hipSetDevice(dev); switched = err == hipSuccess; }
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define H2R_ON_DEVICE(dev_)                                     \
+    DeviceGuard h2r_device_guard_(dev_);                        \
+    if (!hip_ok(h2r_device_guard_.err, "hipSetDevice")) return H2R_E_HIP
+
 // ---- optional per-kernel event timing --------------------------------------------------------------
 struct ProfRec { u32 kernel; hipEvent_t a, b; };
 std::mutex g_prof_mu;
@@ -57,14 +73,17 @@ struct ProfScope {  // start/stop events of one launch when profiling is armed
     }
 };
 
-// Developer knobs (environment, read once): they only override the measured defaults for the sweeps under tools/.
+// Developer knobs: compiled in ONLY by the -DH2R_DEV_KNOBS build (python -m halo2_rsa_amd._build <name> -DH2R_DEV_KNOBS,
+// selected with H2R_LIB by the sweeps under tools/).  The product library never reads the environment: every knob
+// keeps the measured default below.
 struct Knobs {
     int chain_nw = 0, chain_deep = -1;          // H2R_CHAIN_NW, H2R_CHAIN_DEEP
     long trace_dyn_lds = -1, trace_prio = -1;    // H2R_TRACE_DYN_LDS, H2R_TRACE_PRIO
     long chain_prio = -1, ablate = 0;            // H2R_CHAIN_PRIO, H2R_ABLATE (needs the -DH2R_ABLATION build)
-    int pipe_stream_prio = 0;                    // H2R_PIPE_STREAM_PRIO = low (default) | normal | high  -> -1 | 0 | +1
+    int pipe_stream_prio = -1;                   // H2R_PIPE_STREAM_PRIO = low (default) | normal | high  -> -1 | 0 | +1
     bool chain_timing = false;                   // H2R_CHAIN_TIMING (needs the -DH2R_CHAIN_TIMING build)
     Knobs() {
+#ifdef H2R_DEV_KNOBS
         auto num = [](const char *name, long dflt) { const char *v = std::getenv(name); return v ? std::atol(v) : dflt; };
         chain_nw = (int)num("H2R_CHAIN_NW", 0); chain_deep = (int)num("H2R_CHAIN_DEEP", -1);
         trace_dyn_lds = num("H2R_TRACE_DYN_LDS", -1); trace_prio = num("H2R_TRACE_PRIO", -1);
@@ -72,6 +91,7 @@ struct Knobs {
         const char *pe = std::getenv("H2R_PIPE_STREAM_PRIO");
         pipe_stream_prio = !pe ? -1 : (!std::strcmp(pe, "high") ? 1 : (!std::strcmp(pe, "low") ? -1 : 0));
         chain_timing = std::getenv("H2R_CHAIN_TIMING") != nullptr;
+#endif
     }
 };
 const Knobs &knobs() { static const Knobs k; return k; }
@@ -247,7 +267,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
     if (T == 0) {  // e == 0: no mul_mod at all; result is the constant 1 (chip.rs:729)
         // handled by the chain kernel (loop of zero bits); still need a dummy ops buffer
     }
-    HIP_TRY(hipSetDevice(c->params.device));
+    H2R_ON_DEVICE(c->params.device);
     const h2r_layout &lo = c->layout;
     const Workspace wp = workspace_plan(lo.limb_bytes, c->L, batch, T ? T : 1);
     ScratchGuard sg; sg.st = st;
@@ -417,7 +437,8 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
         *out = c;
         return H2R_OK;
     }
-    if (!hip_ok(hipSetDevice(params->device), "hipSetDevice") ||
+    DeviceGuard dg(params->device);
+    if (!hip_ok(dg.err, "hipSetDevice") ||
         !hip_ok(hipMalloc(reinterpret_cast<void **>(&c->const_rec_dev), lo.record_stride), "hipMalloc(const record)") ||
         !hip_ok(hipMemcpy(c->const_rec_dev, c->const_rec_host.data(), lo.record_stride, hipMemcpyHostToDevice), "hipMemcpy(const record)") ||
         !hip_ok(hipMalloc(reinterpret_cast<void **>(&c->refresh_inc_dev), sizeof c->refresh_inc), "hipMalloc(refresh aux)") ||
@@ -433,8 +454,11 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
 
 void h2r_ctx_destroy(h2r_ctx *ctx) {
     if (!ctx) return;
-    if (ctx->const_rec_dev) { (void)hipSetDevice(ctx->params.device); (void)hipFree(ctx->const_rec_dev); }
-    if (ctx->refresh_inc_dev) (void)hipFree(ctx->refresh_inc_dev);
+    if (ctx->params.device >= 0) {
+        DeviceGuard dg(ctx->params.device);
+        if (ctx->const_rec_dev) (void)hipFree(ctx->const_rec_dev);
+        if (ctx->refresh_inc_dev) (void)hipFree(ctx->refresh_inc_dev);
+    }
     delete ctx;
 }
 
@@ -511,6 +535,12 @@ int32_t h2r_square_mod_batch(const h2r_ctx *ctx, const void *a, const void *n, u
     return h2r_mul_mod_batch(ctx, a, a, n, batch, flags, trace, r_out, status, workspace, stream);  // chip.rs:648
 }
 
+namespace {
+int32_t launch_verify_aux(const h2r_ctx *ctx, const void *sig, const void *n, const uint64_t *hashed, uint64_t batch, uint32_t flags,
+                          void *trace, const h2r_verify_layout &vl, void *powed_out, uint8_t *is_valid_out, uint8_t *status, hipStream_t st);
+int32_t launch_in_field(const h2r_ctx *ctx, const void *x, const void *n, uint64_t batch, uint32_t flags, void *in_field_trace, hipStream_t st);
+}
+
 static int32_t pow_fixed_impl(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le, size_t e_len,
                               uint64_t batch, uint32_t flags, void *trace, void *out, uint8_t *status,
                               void *workspace, h2r_stream_t stream, u32 check_in_field) {
@@ -525,28 +555,46 @@ static int32_t pow_fixed_impl(const h2r_ctx *ctx, const void *x, const void *n, 
                     pl.elem_stride, pl.off_records, &pl, out, status, workspace, static_cast<hipStream_t>(stream));
 }
 
+static int32_t pow_var_impl(const h2r_ctx *ctx, const void *x, const void *e_limbs, uint32_t e_num_limbs, uint32_t exp_limb_bits,
+                            const void *n, uint64_t batch, uint32_t flags, void *trace, void *out, uint8_t *status,
+                            void *workspace, h2r_stream_t stream, u32 check_in_field) {
+    if (!ctx || !e_limbs) return H2R_E_NULL;
+    h2r_pow_layout pl;
+    int32_t rc = h2r_pow_var_layout(ctx, e_num_limbs, exp_limb_bits, &pl);
+    if (rc) return rc;
+    return run_path(ctx, CHAIN_POW_VAR, x, nullptr, n, e_limbs, e_num_limbs, exp_limb_bits, nullptr, check_in_field, batch, flags,
+                    pl.num_mul_mods, trace, pl.elem_stride, pl.off_records, &pl, out, status, workspace,
+                    static_cast<hipStream_t>(stream));
+}
+
 int32_t h2r_pow_mod_fixed_exp_batch(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le,
                                     size_t e_len, uint64_t batch, uint32_t flags, void *trace, void *out,
                                     uint8_t *status, void *workspace, h2r_stream_t stream) {
     return pow_fixed_impl(ctx, x, n, e_le, e_len, batch, flags, trace, out, status, workspace, stream, 0);
 }
 
-int32_t h2r_modpow_public_key_batch(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le,
-                                    size_t e_len, uint64_t batch, uint32_t flags, void *trace, void *out,
-                                    uint8_t *status, void *workspace, h2r_stream_t stream) {
-    return pow_fixed_impl(ctx, x, n, e_le, e_len, batch, flags, trace, out, status, workspace, stream, 1);
-}
-
 int32_t h2r_pow_mod_batch(const h2r_ctx *ctx, const void *x, const void *e_limbs, uint32_t e_num_limbs,
                           uint32_t exp_limb_bits, const void *n, uint64_t batch, uint32_t flags, void *trace,
                           void *out, uint8_t *status, void *workspace, h2r_stream_t stream) {
-    if (!ctx || !e_limbs) return H2R_E_NULL;
-    h2r_pow_layout pl;
-    int32_t rc = h2r_pow_var_layout(ctx, e_num_limbs, exp_limb_bits, &pl);
-    if (rc) return rc;
-    return run_path(ctx, CHAIN_POW_VAR, x, nullptr, n, e_limbs, e_num_limbs, exp_limb_bits, nullptr, 0, batch, flags,
-                    pl.num_mul_mods, trace, pl.elem_stride, pl.off_records, &pl, out, status, workspace,
-                    static_cast<hipStream_t>(stream));
+    return pow_var_impl(ctx, x, e_limbs, e_num_limbs, exp_limb_bits, n, batch, flags, trace, out, status, workspace, stream, 0);
+}
+
+// RSAChip::modpow_public_key (src/chip.rs:99-114): assert_in_field witness (:106), then the pow path with the in-field
+// predicate folded into the chain kernel's status.
+int32_t h2r_modpow_public_key_batch(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le,
+                                    size_t e_len, uint64_t batch, uint32_t flags, void *trace, void *in_field_trace,
+                                    void *out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+    const int32_t rc = pow_fixed_impl(ctx, x, n, e_le, e_len, batch, flags, trace, out, status, workspace, stream, 1);
+    if (rc || !in_field_trace) return rc;
+    return launch_in_field(ctx, x, n, batch, flags, in_field_trace, static_cast<hipStream_t>(stream));
+}
+
+int32_t h2r_modpow_public_key_var_batch(const h2r_ctx *ctx, const void *x, const void *e_limbs, uint32_t e_num_limbs,
+                                        uint32_t exp_limb_bits, const void *n, uint64_t batch, uint32_t flags, void *trace,
+                                        void *in_field_trace, void *out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+    const int32_t rc = pow_var_impl(ctx, x, e_limbs, e_num_limbs, exp_limb_bits, n, batch, flags, trace, out, status, workspace, stream, 1);
+    if (rc || !in_field_trace) return rc;
+    return launch_in_field(ctx, x, n, batch, flags, in_field_trace, static_cast<hipStream_t>(stream));
 }
 
 int32_t h2r_verify_layout_fixed(const h2r_ctx *ctx, const uint8_t *e_le, size_t e_len, h2r_verify_layout *out) {
@@ -567,10 +615,6 @@ int32_t h2r_verify_layout_fixed(const h2r_ctx *ctx, const uint8_t *e_le, size_t 
     return H2R_OK;
 }
 
-namespace {
-int32_t launch_verify_aux(const h2r_ctx *ctx, const void *sig, const void *n, const uint64_t *hashed, uint64_t batch, uint32_t flags,
-                          void *trace, const h2r_verify_layout &vl, void *powed_out, uint8_t *is_valid_out, uint8_t *status, hipStream_t st);
-}
 
 int32_t h2r_verify_pkcs1v15_batch(const h2r_ctx *ctx, const void *sig, const void *n, const uint8_t *e_le, size_t e_len,
                                   const uint64_t *hashed, uint64_t batch, uint32_t flags, void *trace, void *powed_out,
@@ -625,7 +669,7 @@ int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side
     *out = nullptr;
     if (depth < 2 || depth > h2r_pipeline::MAX_DEPTH || side_streams < 1 || side_streams > 2) return H2R_E_SHAPE;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
-    HIP_TRY(hipSetDevice(ctx->params.device));
+    H2R_ON_DEVICE(ctx->params.device);
     h2r_pipeline *p = new (std::nothrow) h2r_pipeline();
     if (!p) return H2R_E_HIP;
     p->ctx = ctx; p->k = 0; p->joined = 0; p->depth = depth;
@@ -654,7 +698,7 @@ int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side
 
 void h2r_pipeline_destroy(h2r_pipeline *p) {
     if (!p) return;
-    (void)hipSetDevice(p->ctx->params.device);
+    DeviceGuard dg(p->ctx->params.device);
     for (int i = 0; i < 2; ++i) if (p->aux[i]) (void)hipStreamSynchronize(p->aux[i]);
     for (int i = 0; i < h2r_pipeline::MAX_DEPTH; ++i) {
         if (p->chain_done[i]) (void)hipEventDestroy(p->chain_done[i]);
@@ -734,17 +778,43 @@ int32_t launch_verify_aux(const h2r_ctx *ctx, const void *sig, const void *n, co
     HIP_TRY(hipGetLastError());
     return H2R_OK;
 }
+
+// The assert_in_field(x, n) witness alone (src/chip.rs:106), one element every h2r_fresh_op_layout(IS_IN_FIELD) stride.
+int32_t launch_in_field(const h2r_ctx *ctx, const void *x, const void *n, uint64_t batch, uint32_t flags, void *in_field_trace, hipStream_t st) {
+    if (batch == 0) return H2R_OK;
+    u64 es = 0;
+    const int32_t rc = h2r_fresh_op_layout(ctx, FRESH_IS_IN_FIELD, &es, nullptr, nullptr);
+    if (rc) return rc;
+    H2R_ON_DEVICE(ctx->params.device);
+    AuxArgs aa;
+    std::memset(&aa, 0, sizeof aa);
+    aa.x = x; aa.n = n; aa.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
+    aa.batch = batch; aa.L = ctx->L;
+    aa.trace = static_cast<u8 *>(in_field_trace); aa.elem_stride = es; aa.off_in_field = 0;
+    const AuxGeom ag(ctx->L, ctx->layout.limb_width);
+    const unsigned lds = (unsigned)(ag.in_field_sz() + ag.em_sz());
+    ProfScope ps(H2R_KERNEL_AUX, st);
+    if (ctx->layout.limb_width == 64) hipLaunchKernelGGL((aux_kernel<64>), dim3((unsigned)batch), dim3(64), lds, st, aa);
+    else hipLaunchKernelGGL((aux_kernel<32>), dim3((unsigned)batch), dim3(64), lds, st, aa);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
 }  // namespace
 
 int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len,
-                                       uint64_t batch, uint32_t flags, void *trace, void *out, uint8_t *status,
-                                       void *workspace, h2r_stream_t stream) {
+                                       uint64_t batch, uint32_t flags, void *trace, void *in_field_trace, void *out,
+                                       uint8_t *status, void *workspace, h2r_stream_t stream) {
     if (!p || !trace || !workspace) return H2R_E_NULL;
     h2r_pow_layout pl;
     const int32_t rc = h2r_pow_fixed_layout(p->ctx, e_le, e_len, &pl);
     if (rc) return rc;
-    return pipeline_issue(p, x, n, e_le, e_len, batch, flags, trace, pl, pl.elem_stride, out, status, workspace,
-                          static_cast<hipStream_t>(stream), []() -> int32_t { return H2R_OK; });
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the in-field witness needs only x and n: its kernel runs on the caller's stream right behind the chain kernel
+    return pipeline_issue(p, x, n, e_le, e_len, batch, flags, trace, pl, pl.elem_stride, out, status, workspace, st,
+                          [&]() -> int32_t {
+                              if (!in_field_trace) return H2R_OK;
+                              return launch_in_field(p->ctx, x, n, batch, flags, in_field_trace, st);
+                          });
 }
 
 int32_t h2r_pipeline_verify_pkcs1v15(h2r_pipeline *p, const void *sig, const void *n, const uint8_t *e_le, size_t e_len,
@@ -792,7 +862,7 @@ int32_t h2r_fresh_op_batch(const h2r_ctx *ctx, uint32_t op, const void *a, const
     fa.a = a; fa.b = b; fa.n = n; fa.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
     fa.batch = batch; fa.L = ctx->L; fa.op = op; fa.trace = static_cast<u8 *>(trace); fa.elem_stride = es;
     fa.value_out = value_out; fa.value_limbs = vl; fa.flag_out = flag_out; fa.status = status;
-    HIP_TRY(hipSetDevice(ctx->params.device));
+    H2R_ON_DEVICE(ctx->params.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope ps(H2R_KERNEL_AUX, st);
     if (ctx->layout.limb_width == 64) hipLaunchKernelGGL((fresh_kernel<64>), dim3((unsigned)batch), dim3(64), 0, st, fa);
@@ -827,7 +897,7 @@ int32_t h2r_range_decompose_batch(const h2r_ctx *ctx, const void *values, uint32
     da.sub_out = sublimbs_out; da.sub_stride = sub_stride; da.hist = hist; da.comp_len = 1u << sublimb_bits;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (count == 0) return H2R_OK;
-    HIP_TRY(hipSetDevice(ctx->params.device));
+    H2R_ON_DEVICE(ctx->params.device);
     u64 blocks = (count + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     const u32 shmem = (da.comp_len + 256) * sizeof(u32);
@@ -855,7 +925,7 @@ int32_t h2r_trace_lookup_hist(const h2r_ctx *ctx, const void *trace, uint64_t fi
     ha.tab0_len = ctx->tab0_len; ha.tab1_off = ctx->tab1_off; ha.tab1_len = ctx->tab1_len;
     ha.tab2_off = ctx->tab2_off; ha.tab2_len = ctx->tab2_len; ha.hist_len = ctx->hist_len;
     ha.hist = hist_out;
-    HIP_TRY(hipSetDevice(ctx->params.device));
+    H2R_ON_DEVICE(ctx->params.device);
     ProfScope ps(H2R_KERNEL_HIST, static_cast<hipStream_t>(stream));
     hipLaunchKernelGGL(hist_kernel, dim3((unsigned)num_elems), dim3(256), ctx->hist_len * sizeof(u32),
                        static_cast<hipStream_t>(stream), ha);
@@ -893,7 +963,7 @@ int32_t h2r_trace_lookup_permutation(const h2r_ctx *ctx, const void *trace, uint
     const u64 n_cells = (u64)pa.cells_per_record * records_per_elem;
     if (n_cells >= (1ull << 31)) return H2R_E_UNSUPPORTED;
     pa.n_cells = (u32)n_cells; pa.perm = perm_out; pa.rows = rows_out;
-    HIP_TRY(hipSetDevice(ctx->params.device));
+    H2R_ON_DEVICE(ctx->params.device);
     const u64 stage_bytes = 4ull * ((2ull * lo.num_limbs * 8 + (u64)(lo.num_cols - 1) * lo.carry_sub_stride) / 16) * 16;
     const u64 staged_bytes = stage_bytes + 2ull * n_cells;
     // staged form: 16-bit cell ids in LDS (two workgroups per CU still fit next to the 27 KB of static tables)
@@ -1006,7 +1076,7 @@ int32_t h2r_mul_batch(const h2r_ctx *ctx, const void *a, const void *b, uint64_t
     ta.mode = TRACE_MUL; ta.opA = a; ta.opB = b; ta.op_stride = ctx->L; ta.n_items = batch; ta.T = 1;
     ta.trace = static_cast<u8 *>(trace); ta.elem_stride = ctx->layout.record_stride; ta.off_records = 0;
     ta.muled_out = muled_out;
-    HIP_TRY(hipSetDevice(ctx->params.device));
+    H2R_ON_DEVICE(ctx->params.device);
     ProfScope ps(H2R_KERNEL_TRACE, static_cast<hipStream_t>(stream));
     HIP_TRY(launch_trace(ctx->layout.limb_width, ctx->L, ta, static_cast<hipStream_t>(stream)));
     return H2R_OK;
@@ -1028,7 +1098,7 @@ int32_t h2r_is_equal_muled_batch(const h2r_ctx *ctx, const uint64_t *muled_a, co
     ta.mode = TRACE_EQ; ta.n_items = batch; ta.T = 1;
     ta.trace = static_cast<u8 *>(trace); ta.elem_stride = ctx->layout.record_stride; ta.off_records = 0;
     ta.muled_a = muled_a; ta.muled_b = muled_b; ta.eq_out = eq_out;
-    HIP_TRY(hipSetDevice(ctx->params.device));
+    H2R_ON_DEVICE(ctx->params.device);
     ProfScope ps(H2R_KERNEL_TRACE, static_cast<hipStream_t>(stream));
     HIP_TRY(launch_trace(ctx->layout.limb_width, ctx->L, ta, static_cast<hipStream_t>(stream)));
     return H2R_OK;
@@ -1049,7 +1119,7 @@ int32_t h2r_refresh_batch(const h2r_ctx *ctx, const uint64_t *muled, uint64_t ba
     ra.muled = muled; ra.batch = batch; ra.L = ctx->L; ra.nf = ctx->refresh_nf; ra.inc = ctx->refresh_inc_dev;
     ra.trace = static_cast<u8 *>(trace); ra.elem_stride = round_up(h2r_refresh_stream_bytes(ctx), 256);
     ra.fresh_out = fresh_out; ra.status = status; ra.WB = ctx->layout.wide_bytes; ra.CB = ctx->layout.carry_bytes;
-    HIP_TRY(hipSetDevice(ctx->params.device));
+    H2R_ON_DEVICE(ctx->params.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope ps(H2R_KERNEL_AUX, st);
     if (ctx->layout.limb_width == 64) hipLaunchKernelGGL((refresh_kernel<64>), dim3((unsigned)batch), dim3(64), 0, st, ra);

@@ -631,6 +631,17 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R
     }
     if (status == H2R_OK && args.mode != CHAIN_MULMOD && args.check_in_field && wave_ge<K>(cur, nraw, lane))
         status = H2R_E_NOT_IN_FIELD;  // src/chip.rs:106
+    if (args.mode == CHAIN_POW_VAR && args.exp_limb_bits < 32 * args.digits_per_limb) {
+        // main_gate.to_bits(limb, exp_limb_bits) (chip.rs:677) cannot be satisfied by a limb with bits at or above
+        // exp_limb_bits: the reference's circuit fails, so the element gets a status instead of a plausible trace
+        bool wide = false;
+        for (u32 l = threadIdx.x; l < args.e_num_limbs; l += 64 * NW) {
+            const u32 *ed = args.e_limbs + (elem * args.e_num_limbs + l) * args.digits_per_limb;
+            const u64 v = args.digits_per_limb == 2 ? (((u64)ed[1] << 32) | ed[0]) : (u64)ed[0];
+            wide = wide || (v >> args.exp_limb_bits) != 0;
+        }
+        if (__syncthreads_or(wide ? 1 : 0) && status == H2R_OK) status = H2R_E_SHAPE;
+    }
     if (status != H2R_OK) {  // block-uniform early exit
         if (threadIdx.x == 0) args.status[elem] = (u8)status;
         return;

@@ -74,11 +74,11 @@ class RSAChip:
         return RSASignature(self._bigint.assign_integer(signature.c))
 
     def modpow_public_key(self, x: AssignedInteger, public_key: RSAPublicKey, want_trace: bool = True) -> BatchResult:
-        """src/chip.rs:99-114: assert x < n (:106; per-element status H2R_E_NOT_IN_FIELD), then
-        Fix -> pow_mod_fixed_exp, Var -> pow_mod."""
+        """src/chip.rs:99-114: assert_in_field(x, n) (:106; witness in `result.in_field`, per-element status
+        H2R_E_NOT_IN_FIELD where it fails), then Fix -> pow_mod_fixed_exp, Var -> pow_mod with the chip's exp_limb_bits."""
         if isinstance(public_key.e, Fix):
             return self._bigint.pow_mod_fixed_exp(x, public_key.e.e, public_key.n, want_trace, check_in_field=True)
-        return self._bigint.pow_mod(x, public_key.e.e, public_key.n, self.exp_limb_bits, want_trace)
+        return self._bigint.pow_mod(x, public_key.e.e, public_key.n, self.exp_limb_bits, want_trace, check_in_field=True)
 
 
     def verify_pkcs1v15_signature(self, public_key: RSAPublicKey, hashed_msg, signature: RSASignature) -> "VerifyResult":

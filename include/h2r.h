@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define H2R_VERSION 1
+#define H2R_VERSION 2
 
 /* ---- status codes (function return values and per-element status bytes) ---------------------- */
 enum {
@@ -204,24 +204,36 @@ int32_t h2r_pow_mod_fixed_exp_batch(const h2r_ctx *ctx, const void *x, const voi
                                     void *workspace, h2r_stream_t stream);
 
 /* BigIntInstructions::pow_mod (big_integer/chip.rs:664-696): per-element variable exponent given
- * as e_num_limbs limbs (same limb type as x) of which the low exp_limb_bits bits are used
- * (main_gate.to_bits, chip.rs:677). */
+ * as e_num_limbs limbs (same limb type as x), each decomposed into exp_limb_bits bits
+ * (main_gate.to_bits, chip.rs:677).  An element with an e limb >= 2^exp_limb_bits gets status
+ * H2R_E_SHAPE (to_bits cannot be satisfied: the reference's circuit fails). */
 int32_t h2r_pow_mod_batch(const h2r_ctx *ctx, const void *x, const void *e_limbs,
                           uint32_t e_num_limbs, uint32_t exp_limb_bits, const void *n,
                           uint64_t batch, uint32_t flags, void *trace, void *out, uint8_t *status,
                           void *workspace, h2r_stream_t stream);
 
-/* RSAInstructions::modpow_public_key with RSAPubE::Fix (src/chip.rs:99-114): per element sets
- * H2R_E_NOT_IN_FIELD where bigint_chip.assert_in_field(x, n) (:106) fails, otherwise runs
- * pow_mod_fixed_exp.  Same trace layout as h2r_pow_mod_fixed_exp_batch. */
+/* RSAInstructions::modpow_public_key (src/chip.rs:99-114) = bigint_chip.assert_in_field(x, n) (:106) followed by
+ * pow_mod_fixed_exp (RSAPubE::Fix, :111) or pow_mod (RSAPubE::Var with the chip's exp_limb_bits, :108-110).
+ *   in_field_trace (nullable): batch elements holding the assert_in_field witness -- the is_in_field Fresh op
+ *     (big_integer/chip.rs:1150-1158 -> 998-1006 -> 908-919) -- laid out and flattened exactly like
+ *     h2r_fresh_op_batch(H2R_OP_IS_IN_FIELD, x, n): element stride from h2r_fresh_op_layout, flat stream from
+ *     h2r_fresh_op_flatten.  The reference's assignment order is: the in-field stream, then the pow stream
+ *     (h2r_pow_trace_flatten of `trace`).  NULL: only the status is produced.
+ *   status: H2R_E_NOT_IN_FIELD where x >= n (the in-field witness of such an element is still written; its pow
+ *     trace and `out` are not).  `trace` is laid out as for h2r_pow_mod_fixed_exp_batch / h2r_pow_mod_batch. */
 int32_t h2r_modpow_public_key_batch(const h2r_ctx *ctx, const void *x, const void *n,
                                     const uint8_t *e_le_bytes, size_t e_len, uint64_t batch,
-                                    uint32_t flags, void *trace, void *out, uint8_t *status,
-                                    void *workspace, h2r_stream_t stream);
+                                    uint32_t flags, void *trace, void *in_field_trace, void *out,
+                                    uint8_t *status, void *workspace, h2r_stream_t stream);
+int32_t h2r_modpow_public_key_var_batch(const h2r_ctx *ctx, const void *x, const void *e_limbs,
+                                        uint32_t e_num_limbs, uint32_t exp_limb_bits, const void *n,
+                                        uint64_t batch, uint32_t flags, void *trace, void *in_field_trace,
+                                        void *out, uint8_t *status, void *workspace, h2r_stream_t stream);
 
 /* ---- pipelined form (opt-in): overlap batch k+1's off-circuit chain with batch k's witness emission
  * A pipeline owns its side HIP stream(s), created at the lowest stream priority so that they get a hardware
  * queue of their own.  h2r_pipeline_modpow_public_key() is h2r_modpow_public_key_batch
+ * (the in-field witness kernel runs on `stream` right behind the chain kernel)
  * except that its record-writing kernel runs on the pipeline's stream and `stream` joins it only at
  * the NEXT pipelined call (after that call's chain kernel has been enqueued) or at h2r_pipeline_join().
  * Until then the call's trace must not be read.  Consecutive calls must use distinct trace / out /
@@ -239,8 +251,8 @@ int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side
 void h2r_pipeline_destroy(h2r_pipeline *p);
 int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const void *n,
                                        const uint8_t *e_le_bytes, size_t e_len, uint64_t batch,
-                                       uint32_t flags, void *trace, void *out, uint8_t *status,
-                                       void *workspace, h2r_stream_t stream);
+                                       uint32_t flags, void *trace, void *in_field_trace, void *out,
+                                       uint8_t *status, void *workspace, h2r_stream_t stream);
 int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream);
 
 /* ---- RSAInstructions::verify_pkcs1v15_signature after the SHA step (src/chip.rs:128-199) ------

@@ -138,30 +138,44 @@ class BigIntChip {
     // big_integer/chip.rs:642-649
     BatchResult square_mod(const AssignedInteger &a, const AssignedInteger &n) const { return mul_mod(a, a, n); }
     // big_integer/chip.rs:710-742; e = BigUint::to_bytes_le()
-    BatchResult pow_mod_fixed_exp(const AssignedInteger &a, const std::vector<uint8_t> &e_le, const AssignedInteger &n,
-                                  bool check_in_field = false) const {
-        h2r_pow_layout pl;
-        check(h2r_pow_fixed_layout(ctx_, e_le.data(), e_le.size(), &pl), "h2r_pow_fixed_layout");
-        const size_t batch = a.batch();
-        DeviceBuffer trace(batch * pl.elem_stride), out(batch * num_limbs_ * 8), st(batch);
-        auto fn = check_in_field ? h2r_modpow_public_key_batch : h2r_pow_mod_fixed_exp_batch;
-        check(fn(ctx_, a.data(), n.data(), e_le.data(), e_le.size(), batch, flags(n, batch), trace.get(), out.get(),
-                 static_cast<uint8_t *>(st.get()), nullptr, nullptr), "pow_mod_fixed_exp");
-        return finish(std::move(trace), std::move(out), st, batch, true, pl, pl.elem_stride, pl.stream_bytes);
+    BatchResult pow_mod_fixed_exp(const AssignedInteger &a, const std::vector<uint8_t> &e_le, const AssignedInteger &n) const {
+        return pow_fixed(a, e_le, n, nullptr);
     }
     // big_integer/chip.rs:664-696
     BatchResult pow_mod(const AssignedInteger &a, const AssignedInteger &e, const AssignedInteger &n, uint32_t exp_limb_bits) const {
-        h2r_pow_layout pl;
-        check(h2r_pow_var_layout(ctx_, (uint32_t)e.num_limbs(), exp_limb_bits, &pl), "h2r_pow_var_layout");
-        const size_t batch = a.batch();
-        DeviceBuffer trace(batch * pl.elem_stride), out(batch * num_limbs_ * 8), st(batch);
-        check(h2r_pow_mod_batch(ctx_, a.data(), e.data(), (uint32_t)e.num_limbs(), exp_limb_bits, n.data(), batch, flags(n, batch),
-                                trace.get(), out.get(), static_cast<uint8_t *>(st.get()), nullptr, nullptr), "pow_mod");
-        return finish(std::move(trace), std::move(out), st, batch, true, pl, pl.elem_stride, pl.stream_bytes);
+        return pow_var(a, e, n, exp_limb_bits, nullptr);
     }
 
   private:
     static uint32_t flags(const AssignedInteger &n, size_t batch) { return (n.batch() == 1 && batch != 1) ? H2R_F_SHARED_MODULUS : 0u; }
+    // in_field != nullptr: RSAChip::modpow_public_key (assert_in_field witness into *in_field, status H2R_E_NOT_IN_FIELD)
+    BatchResult pow_fixed(const AssignedInteger &a, const std::vector<uint8_t> &e_le, const AssignedInteger &n, DeviceBuffer *in_field) const {
+        h2r_pow_layout pl;
+        check(h2r_pow_fixed_layout(ctx_, e_le.data(), e_le.size(), &pl), "h2r_pow_fixed_layout");
+        const size_t batch = a.batch();
+        DeviceBuffer trace(batch * pl.elem_stride), out(batch * num_limbs_ * 8), st(batch);
+        if (in_field)
+            check(h2r_modpow_public_key_batch(ctx_, a.data(), n.data(), e_le.data(), e_le.size(), batch, flags(n, batch), trace.get(),
+                                              in_field->get(), out.get(), static_cast<uint8_t *>(st.get()), nullptr, nullptr), "modpow_public_key");
+        else
+            check(h2r_pow_mod_fixed_exp_batch(ctx_, a.data(), n.data(), e_le.data(), e_le.size(), batch, flags(n, batch), trace.get(),
+                                              out.get(), static_cast<uint8_t *>(st.get()), nullptr, nullptr), "pow_mod_fixed_exp");
+        return finish(std::move(trace), std::move(out), st, batch, true, pl, pl.elem_stride, pl.stream_bytes);
+    }
+    BatchResult pow_var(const AssignedInteger &a, const AssignedInteger &e, const AssignedInteger &n, uint32_t exp_limb_bits, DeviceBuffer *in_field) const {
+        h2r_pow_layout pl;
+        check(h2r_pow_var_layout(ctx_, (uint32_t)e.num_limbs(), exp_limb_bits, &pl), "h2r_pow_var_layout");
+        const size_t batch = a.batch();
+        DeviceBuffer trace(batch * pl.elem_stride), out(batch * num_limbs_ * 8), st(batch);
+        if (in_field)
+            check(h2r_modpow_public_key_var_batch(ctx_, a.data(), e.data(), (uint32_t)e.num_limbs(), exp_limb_bits, n.data(), batch,
+                                                  flags(n, batch), trace.get(), in_field->get(), out.get(), static_cast<uint8_t *>(st.get()),
+                                                  nullptr, nullptr), "modpow_public_key");
+        else
+            check(h2r_pow_mod_batch(ctx_, a.data(), e.data(), (uint32_t)e.num_limbs(), exp_limb_bits, n.data(), batch, flags(n, batch),
+                                    trace.get(), out.get(), static_cast<uint8_t *>(st.get()), nullptr, nullptr), "pow_mod");
+        return finish(std::move(trace), std::move(out), st, batch, true, pl, pl.elem_stride, pl.stream_bytes);
+    }
     BatchResult finish(DeviceBuffer trace, DeviceBuffer value, const DeviceBuffer &st, size_t batch, bool is_pow, h2r_pow_layout pl,
                        uint64_t elem_stride, uint64_t stream_bytes) const {
         hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
@@ -197,6 +211,23 @@ struct RSASignature { UnassignedInteger c; };
 struct AssignedRSAPublicKey { AssignedInteger n; std::variant<RSAPubE::Fix, AssignedInteger> e; };
 struct AssignedRSASignature { AssignedInteger c; };
 
+// RSAInstructions::modpow_public_key: the assert_in_field witness (src/chip.rs:106) followed by the pow path's
+struct ModpowResult {
+    BatchResult pow;               // value = x^e mod n, trace = the pow path, status (H2R_E_NOT_IN_FIELD where x >= n)
+    DeviceBuffer in_field;         // batch elements, stride in_field_stride, flat stream of in_field_stream_bytes each
+    uint64_t in_field_stride = 0, in_field_stream_bytes = 0;
+    const h2r_ctx *ctx = nullptr;
+    // the element's whole witness in the reference's assignment order: in-field stream, then the pow stream
+    std::vector<uint8_t> flatten(size_t elem) const {
+        std::vector<uint8_t> host(in_field_stride), out(in_field_stream_bytes);
+        in_field.download(host.data(), host.size(), elem * in_field_stride);
+        check(h2r_fresh_op_flatten(ctx, H2R_OP_IS_IN_FIELD, host.data(), out.data()), "h2r_fresh_op_flatten");
+        const std::vector<uint8_t> p = pow.trace.flatten(elem);
+        out.insert(out.end(), p.begin(), p.end());
+        return out;
+    }
+};
+
 struct VerifyResult {
     std::vector<uint8_t> is_valid;   // one byte per signature
     std::vector<uint8_t> status;
@@ -226,10 +257,16 @@ class RSAChip {
     }
     // src/chip.rs:80-88
     AssignedRSASignature assign_signature(const RSASignature &s) const { return AssignedRSASignature{bigint_.assign_integer(s.c)}; }
-    // src/chip.rs:99-114: assert x < n (:106, status H2R_E_NOT_IN_FIELD), then Fix -> pow_mod_fixed_exp, Var -> pow_mod
-    BatchResult modpow_public_key(const AssignedInteger &x, const AssignedRSAPublicKey &pk) const {
-        if (auto *f = std::get_if<RSAPubE::Fix>(&pk.e)) return bigint_.pow_mod_fixed_exp(x, f->e_le, pk.n, /*check_in_field=*/true);
-        return bigint_.pow_mod(x, std::get<AssignedInteger>(pk.e), pk.n, exp_limb_bits_);
+    // src/chip.rs:99-114: assert_in_field(x, n) (:106; witness + status H2R_E_NOT_IN_FIELD), then Fix -> pow_mod_fixed_exp,
+    // Var -> pow_mod with the chip's exp_limb_bits
+    ModpowResult modpow_public_key(const AssignedInteger &x, const AssignedRSAPublicKey &pk) const {
+        uint64_t es = 0, sb = 0;
+        check(h2r_fresh_op_layout(bigint_.ctx(), H2R_OP_IS_IN_FIELD, &es, &sb, nullptr), "h2r_fresh_op_layout");
+        DeviceBuffer inf(x.batch() * es);
+        BatchResult r = std::holds_alternative<RSAPubE::Fix>(pk.e)
+                            ? bigint_.pow_fixed(x, std::get<RSAPubE::Fix>(pk.e).e_le, pk.n, &inf)
+                            : bigint_.pow_var(x, std::get<AssignedInteger>(pk.e), pk.n, exp_limb_bits_, &inf);
+        return ModpowResult{std::move(r), std::move(inf), es, sb, bigint_.ctx()};
     }
     // src/chip.rs:128-199 (hashed_msg = 4 little-endian 64-bit limbs of the SHA-256 digest per signature, :141-144)
     VerifyResult verify_pkcs1v15_signature(const AssignedRSAPublicKey &pk, const AssignedInteger &hashed_msg,
@@ -300,12 +337,15 @@ class Pipeline {
     }
     // RSAInstructions::modpow_public_key (src/chip.rs:99-114, RSAPubE::Fix), asynchronous on `stream`; uses the
     // trace / workspace / powed / status members of the buffer set (its trace region is large enough for the pow trace)
-    void modpow_public_key(const AssignedInteger &x, const AssignedRSAPublicKey &pk, Buffers &b, hipStream_t stream = nullptr) {
+    // (the in-field witness goes to the element's in-field region of the verify layout: same format, stride = elem_stride)
+    void modpow_public_key(const AssignedInteger &x, const AssignedRSAPublicKey &pk, Buffers &b, hipStream_t stream = nullptr,
+                           DeviceBuffer *in_field = nullptr) {
         auto *f = std::get_if<RSAPubE::Fix>(&pk.e);
         if (!f) throw Error(H2R_E_UNSUPPORTED, "Pipeline::modpow_public_key (takes RSAPubE::Fix)");
         const size_t batch = x.batch();
         check(h2r_pipeline_modpow_public_key(p_, x.data(), pk.n.data(), f->e_le.data(), f->e_le.size(), batch,
-                                             (pk.n.batch() == 1 && batch != 1) ? H2R_F_SHARED_MODULUS : 0u, b.trace.get(), b.powed.get(),
+                                             (pk.n.batch() == 1 && batch != 1) ? H2R_F_SHARED_MODULUS : 0u, b.trace.get(),
+                                             in_field ? in_field->get() : nullptr, b.powed.get(),
                                              static_cast<uint8_t *>(b.status.get()), b.workspace.get(), stream), "h2r_pipeline_modpow_public_key");
     }
     void join(hipStream_t stream = nullptr) { check(h2r_pipeline_join(p_, stream), "h2r_pipeline_join"); }

@@ -412,6 +412,11 @@ int h2ro_pow_mod(const h2ro_params *p, const void *x, const void *e_limbs, uint3
     load_limbs(N, n, L, w); load_limbs(squared, x, L, w);               /* :683 */
     memset(acc, 0, sizeof acc); acc[0] = 1;                             /* :682 */
     wr s = {stream};
+    /* main_gate.to_bits(limb, exp_limb_bits) (:677) constrains limb == sum of its exp_limb_bits bits: a wider limb
+     * makes the reference's circuit unsatisfiable */
+    if (exp_limb_bits == 0 || exp_limb_bits > w) return H2RO_E_SHAPE;
+    for (uint32_t l = 0; l < e_num_limbs; ++l)
+        if (exp_limb_bits < 64 && (get_limb(e_limbs, l, w) >> exp_limb_bits) != 0) return H2RO_E_SHAPE;
     for (uint32_t l = 0; l < e_num_limbs; ++l)                          /* :674-681 to_bits, LSB first */
         for (uint32_t t = 0; t < exp_limb_bits; ++t) put64(&s, (get_limb(e_limbs, l, w) >> t) & 1, 1);
     for (uint32_t l = 0; l < e_num_limbs; ++l)

@@ -334,6 +334,9 @@ def pow_mod_var(p: Params, x: Sequence[int], e_limbs: Sequence[int], n: Sequence
                 exp_limb_bits: int, st: Stream) -> List[int]:
     """BigIntChip::pow_mod, big_integer/chip.rs:664-696."""
     e_bits = []
+    for limb in e_limbs:   # to_bits constrains limb == sum(bit_t 2^t, t < exp_limb_bits): a wider limb cannot be assigned
+        if limb >> exp_limb_bits:
+            raise ValueError("e limb wider than exp_limb_bits (main_gate.to_bits, big_integer/chip.rs:677)")
     for limb in e_limbs:                                # :674-681 main_gate.to_bits LSB first
         for t in range(exp_limb_bits):
             e_bits.append((limb >> t) & 1)

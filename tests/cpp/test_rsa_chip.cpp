@@ -114,6 +114,19 @@ int main(int argc, char **argv) {
         bufs[1].powed.download(got.data(), got.size() * 8);
         REQUIRE(got == want);
     }
+    // RSAInstructions::modpow_public_key (src/chip.rs:99-114): assert_in_field witness, then the pow witness
+    {
+        ModpowResult mp = rsa_chip.modpow_public_key(sign.c, pk);
+        for (size_t i = 0; i < B; ++i) {
+            REQUIRE(mp.pow.status[i] == H2R_OK);
+            std::vector<uint8_t> s_if(h2ro_in_field_stream_bytes(&op)), s_pow(h2ro_pow_fixed_stream_bytes(&op, e_le, 3));
+            int lt = -1; std::vector<uint64_t> powed(32);
+            REQUIRE(h2ro_assert_in_field(&op, kats[i].sig.data(), kats[i].n.data(), s_if.data(), &lt) == 0 && lt == 1);
+            REQUIRE(h2ro_pow_mod_fixed_exp(&op, kats[i].sig.data(), kats[i].n.data(), e_le, 3, s_pow.data(), powed.data()) == 0);
+            std::vector<uint8_t> want(s_if); want.insert(want.end(), s_pow.begin(), s_pow.end());
+            REQUIRE(mp.flatten(i) == want);
+        }
+    }
     // BigIntChip::new asserts bits_len % limb_width == 0 (big_integer/chip.rs:1175) -> exception
     bool threw = false;
     try { BigIntChip bad(64, 2048 + 8); } catch (const Error &e) { threw = e.code == H2R_E_SHAPE; }

@@ -127,11 +127,13 @@ class Oracle:
         rc = lib().h2ro_pkcs1v15_em_check(ctypes.byref(self.p), _ptr(np.ascontiguousarray(powed, np.uint64)), _ptr(h), _ptr(st), ctypes.byref(ok))
         return rc, ok.value, st
 
-    def pow_mod_fixed_exp_batch(self, x, n, e, nthreads=1, want_stream=False):
+    def pow_mod_fixed_exp_batch(self, x, n, e, nthreads=1, want_stream=False, stream_buf=None):
+        """stream_buf: a reusable [batch, stream_bytes] uint8 array (timing loops: no allocation / first-touch cost)."""
         eb = e_bytes(e)
         batch = x.shape[0]
         sb = self.pow_fixed_stream_bytes(e)
-        st = np.zeros((batch, sb), dtype=np.uint8) if want_stream else None
+        st = stream_buf if stream_buf is not None else (np.zeros((batch, sb), dtype=np.uint8) if want_stream else None)
+        assert st is None or (st.shape == (batch, sb) and st.dtype == np.uint8 and st.flags.c_contiguous)
         out = np.zeros((batch, self.L), dtype=self.dtype)
         status = np.zeros(batch, dtype=np.uint8)
         lib().h2ro_pow_mod_fixed_exp_batch(ctypes.byref(self.p), _ptr(np.ascontiguousarray(x, self.dtype)), _ptr(np.ascontiguousarray(n, self.dtype)),

@@ -57,6 +57,11 @@ def test_rsa_kats_modpow_public_key(H, golden):
         assert sha(st) == k["pow_stream_sha256"], k["name"]
         rc, out, ost = o.pow_mod_fixed_exp(o.limbs(sigs[i]), o.limbs(ns[i]), 65537)
         assert rc == 0 and np.array_equal(ost, st)
+        # the whole modpow_public_key witness in the reference's order: assert_in_field (src/chip.rs:106), then the pow path
+        rc, lt, s_if = o.assert_in_field(o.limbs(sigs[i]), o.limbs(ns[i]))
+        assert rc == 0 and lt == 1
+        assert np.array_equal(res.in_field.flatten(i), s_if) and sha(s_if) == k["in_field_stream_sha256"]
+        assert np.array_equal(res.flatten(i), np.concatenate([s_if, ost]))
         # EM check of the pkcs1v15 verifier on the GPU result (expected is_valid = 1, 1, 0)
         rc, ok, _ = o.pkcs1v15_em_check(res.value.limbs_host()[i], o.limbs(int(k["hashed"]), 4))
         assert ok == k["is_valid"]
@@ -185,6 +190,29 @@ def test_error_statuses(H):
     torch.cuda.synchronize()
     assert res.status.cpu().tolist() == [0, H.H2R_E_NOT_IN_FIELD, H.H2R_E_NOT_IN_FIELD]
     assert res.value.to_big_uint()[0] == pow(n_ok - 1, 65537, n_ok)
+    # the same on the RSAPubE::Var arm (the reference asserts x < n before BOTH arms, src/chip.rs:106), where the
+    # in-field witness of a failing element is still produced (is_less_than = 0 in its stream)
+    pkv = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints([n_ok, n_ok, n_ok], 32, 64),
+                                               H.Var(H.UnassignedInteger.from_ints([17, 17, 17], 1, 64))))
+    res = rsa.modpow_public_key(x, pkv)
+    torch.cuda.synchronize()
+    assert res.status.cpu().tolist() == [0, H.H2R_E_NOT_IN_FIELD, H.H2R_E_NOT_IN_FIELD]
+    assert res.value.to_big_uint()[0] == pow(n_ok - 1, 17, n_ok)
+    o = Oracle(64, 32)
+    for i, xv in enumerate([n_ok - 1, n_ok, n_ok + 1]):
+        rc, lt, s_if = o.assert_in_field(o.limbs(xv), o.limbs(n_ok))
+        assert lt == (1 if i == 0 else 0) and np.array_equal(res.in_field.flatten(i), s_if)
+    # pow_mod itself (BigIntInstructions, no in-field assertion) accepts x >= n as long as the quotients fit
+    res = chip.pow_mod(x, pkv.e.e, pkv.n, 5)
+    torch.cuda.synchronize()
+    assert res.status.cpu().tolist()[:2] == [0, 0] and res.value.to_big_uint()[1] == 0
+    # an exponent limb with bits at or above exp_limb_bits cannot satisfy main_gate.to_bits (big_integer/chip.rs:677)
+    pkw = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints([n_ok, n_ok, n_ok], 32, 64),
+                                               H.Var(H.UnassignedInteger.from_ints([31, 32, 1 << 63], 1, 64))))
+    res = rsa.modpow_public_key(rsa.bigint_chip().assign_integer([5, 5, 5]), pkw, want_trace=False)
+    torch.cuda.synchronize()
+    assert res.status.cpu().tolist() == [0, H.H2R_E_SHAPE, H.H2R_E_SHAPE]
+    assert o.pow_mod(o.limbs(5), np.array([32], np.uint64), 5, o.limbs(n_ok))[0] == 1   # the oracle refuses it too (H2RO_E_SHAPE)
 
 
 @pytest.mark.parametrize("w,L,batch,e", [(64, 32, 12, 65537), (64, 16, 8, 65537), (32, 128, 3, 65537), (64, 32, 4, 0b1011011), (64, 32, 3, 1), (64, 64, 2, 17)])
@@ -237,6 +265,64 @@ def test_pow_mod_var_parity(H, golden):
         assert rc == 0 and np.array_equal(ost, st)
         if i < 4:
             assert sha(st) == golden["pow_var_kat1"][i]["stream_sha256"]
+
+
+@pytest.mark.parametrize("w,L,e_num_limbs,exp_limb_bits,batch", [
+    (64, 32, 2, 33, 3),     # bits of a limb straddle the 32-bit word fetch
+    (64, 32, 2, 64, 2),     # whole 64-bit limbs, two of them
+    (64, 16, 32, 3, 2),     # many narrow limbs
+    (64, 16, 3, 17, 3),
+    (32, 32, 2, 32, 2),     # 32-bit limbs: one digit per limb
+    (32, 32, 5, 7, 2),
+    (64, 8, 32, 64, 2),     # 2048 exponent bits on a 512-bit modulus (4,096 mul_mods per element)
+])
+def test_pow_mod_var_multi_limb(H, w, L, e_num_limbs, exp_limb_bits, batch):
+    """pow_mod (reference big_integer/chip.rs:664-696) with several exponent limbs and wide exp_limb_bits: the
+    per-limb main_gate.to_bits order (:674-681), every mul_mod / select stream and the result, byte-exact vs the oracle."""
+    chip = H.BigIntChip(w, w * L)
+    o = Oracle(w, L)
+    rng = random.Random(1000 * w + 31 * L + 7 * e_num_limbs + exp_limb_bits)
+    N = [rand_modulus(rng, w * L, odd=(i != 1)) for i in range(batch)]
+    X = [rng.randrange(n) for n in N]
+    E = [[rng.getrandbits(exp_limb_bits) for _ in range(e_num_limbs)] for _ in range(batch)]
+    E[0][0] |= 1 << (exp_limb_bits - 1)      # top bit of a limb set
+    if e_num_limbs > 1:
+        E[0][1] = 0                              # an all-zero limb still costs exp_limb_bits iterations
+    ei = H.UnassignedInteger(np.array(E, dtype=chip.np_dtype))
+    e_dev = H.AssignedInteger(torch.from_numpy(ei.limbs.view(np.int64 if w == 64 else np.int32)).cuda().contiguous(), w)
+    res = chip.pow_mod(chip.assign_integer(X), e_dev, chip.assign_integer(N), exp_limb_bits)
+    torch.cuda.synchronize()
+    assert not res.status.cpu().numpy().any()
+    out = res.value.to_big_uint()
+    for i in range(batch):
+        e_int = sum(v << (exp_limb_bits * k) for k, v in enumerate(E[i]))
+        assert out[i] == pow(X[i], e_int, N[i]), i
+        rc, oo, ost = o.pow_mod(o.limbs(X[i]), np.array(E[i], dtype=o.dtype), exp_limb_bits, o.limbs(N[i]))
+        assert rc == 0 and o.to_int(oo) == out[i]
+        st = res.trace.flatten(i)
+        if not np.array_equal(ost, st):
+            pytest.fail("elem %d: first stream mismatch at byte %d of %d" % (i, int(np.nonzero(ost != st)[0][0]), len(st)))
+
+
+def test_pow_mod_var_2048_bit_exponent(H):
+    """SURVEY a3 "C5 alternative": RSA-2048 with a 2,048-bit VARIABLE exponent (32 limbs x 64 bits): 4,096 mul_mods
+    per element (263 MB of trace each).  Result vs pow(); the whole flat stream of one element vs the oracle."""
+    chip = H.BigIntChip(64, 2048)
+    o = Oracle(64, 32)
+    rng = random.Random(0x68327273 + 50)
+    N = [rand_modulus(rng, 2048) for _ in range(2)]
+    X = [rng.randrange(n) for n in N]
+    E = [[rng.getrandbits(64) for _ in range(32)] for _ in range(2)]
+    E[0][31] |= 1 << 63
+    e_dev = H.AssignedInteger(torch.from_numpy(np.array(E, dtype=np.uint64).view(np.int64)).cuda().contiguous(), 64)
+    res = chip.pow_mod(chip.assign_integer(X), e_dev, chip.assign_integer(N), 64)
+    torch.cuda.synchronize()
+    assert not res.status.cpu().numpy().any()
+    out = res.value.to_big_uint()
+    for i in range(2):
+        assert out[i] == pow(X[i], sum(v << (64 * k) for k, v in enumerate(E[i])), N[i])
+    rc, oo, ost = o.pow_mod(o.limbs(X[0]), np.array(E[0], dtype=np.uint64), 64, o.limbs(N[0]))
+    assert rc == 0 and np.array_equal(ost, res.trace.flatten(0))
 
 
 def test_shared_modulus(H):
@@ -334,7 +420,7 @@ def test_range_decompose_batch(H):
 
 def test_config2_full_batch_properties(H, golden):
     """BASELINE config 2 at full size (batch 1024, RSA-2048, e = 65537, KAT1/KAT2/BAD as elements 0-2):
-    every result equals pow(x, e, n); sampled elements are byte-exact vs the oracle; every record's
+    every result equals pow(x, e, n); ALL 1,024 elements are byte-exact vs the oracle; sampled records'
     q/r planes satisfy a*b = q*n + r."""
     chip = H.BigIntChip(64, 2048)
     o = Oracle(64, 32)
@@ -347,9 +433,22 @@ def test_config2_full_batch_properties(H, golden):
     assert not res.status.cpu().numpy().any()
     out = res.value.to_big_uint()
     assert all(out[i] == pow(X[i], 65537, N[i]) for i in range(1024))
-    for i in [0, 1, 2] + rng.sample(range(3, 1024), 13):
-        rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(X[i]), o.limbs(N[i]), 65537)
-        assert np.array_equal(ost, res.trace.flatten(i)), i
+    # EVERY element's flat stream, byte for byte, against the threaded C oracle (128 elements at a time: one D2H copy
+    # of their records, h2r_pow_trace_flatten on the host copy)
+    import os
+    from halo2_rsa_amd._lib import check, lib
+    xs, nsl = chip.assign_integer(X).limbs_host(), chip.assign_integer(N).limbs_host()
+    pl, es = res.trace.pow_layout, res.trace.elem_stride
+    got = np.zeros(pl.stream_bytes, dtype=np.uint8)
+    for lo in range(0, 1024, 128):
+        oout, ostat, ost = o.pow_mod_fixed_exp_batch(xs[lo:lo + 128], nsl[lo:lo + 128], 65537, nthreads=min(64, os.cpu_count() or 1),
+                                                     want_stream=True)
+        assert not ostat.any()
+        host = res.trace.buf[lo * es:(lo + 128) * es].cpu().numpy()
+        for k in range(128):
+            check(lib().h2r_pow_trace_flatten(chip._ctx, ctypes.byref(pl), host[k * es:(k + 1) * es].ctypes.data, got.ctypes.data), "flatten")
+            if not np.array_equal(got, ost[k]):
+                pytest.fail("element %d: first stream mismatch at byte %d" % (lo + k, int(np.nonzero(got != ost[k])[0][0])))
     # chain identity on the q/r planes of every record of 64 more elements
     for i in rng.sample(range(1024), 64):
         acc, cur, t = 1, X[i], 0

@@ -106,6 +106,32 @@ def test_pow_var_golden(golden):
         assert ["%x" % int(v) for v in out] == c["result_limbs"]
 
 
+@pytest.mark.parametrize("w,L,e_num_limbs,exp_limb_bits", [(64, 4, 2, 33), (64, 4, 2, 64), (64, 8, 32, 3), (32, 8, 2, 32), (32, 8, 5, 7),
+                                                          (64, 4, 32, 64)])
+def test_pow_var_multi_limb_c_oracle_equals_python(w, L, e_num_limbs, exp_limb_bits):
+    """pow_mod with several exponent limbs / wide exp_limb_bits (big_integer/chip.rs:664-696): main_gate.to_bits runs per
+    limb, LSB first (:674-681), so e = sum limb_k * 2^(k * exp_limb_bits); both restatements agree and match pow()."""
+    o, p = Oracle(w, L), R.Params(w, L)
+    rng = random.Random(77 * w + L + exp_limb_bits)
+    bits = w * L
+    n = rng.getrandbits(bits) | (1 << (bits - 1))
+    x = rng.randrange(n)
+    e_limbs = [rng.getrandbits(exp_limb_bits) for _ in range(e_num_limbs)]
+    e_limbs[0] |= 1 << (exp_limb_bits - 1)
+    st = R.Stream()
+    r = R.pow_mod_var(p, R.to_limbs(x, L, w), e_limbs, R.to_limbs(n, L, w), exp_limb_bits, st)
+    rc, out, cs = o.pow_mod(o.limbs(x), np.array(e_limbs, dtype=o.dtype), exp_limb_bits, o.limbs(n))
+    assert rc == 0 and bytes(cs) == st.bytes() and [int(v) for v in out] == r
+    e = sum(v << (exp_limb_bits * k) for k, v in enumerate(e_limbs))
+    assert o.to_int(out) == pow(x, e, n)
+    assert len(cs) == o.pow_var_stream_bytes(e_num_limbs, exp_limb_bits)
+    if exp_limb_bits < w:   # a limb that does not fit exp_limb_bits bits cannot satisfy to_bits (:677)
+        bad = list(e_limbs); bad[-1] = 1 << exp_limb_bits
+        assert o.pow_mod(o.limbs(x), np.array(bad, dtype=o.dtype), exp_limb_bits, o.limbs(n))[0] == 1
+        with pytest.raises(ValueError):
+            R.pow_mod_var(p, R.to_limbs(x, L, w), bad, R.to_limbs(n, L, w), exp_limb_bits, R.Stream())
+
+
 def test_rsa4096_w32_golden(golden):
     """BASELINE config 4: RSA-4096 as 128 x 32-bit limbs."""
     o = Oracle(32, 128)
