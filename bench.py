@@ -82,34 +82,28 @@ def synth_inputs(w, bits, batch, seed, golden_first=True):
     return ns, xs, un, ux
 
 
-def cpu_baseline(w, bits, e, un, ux, min_seconds=10.0, max_seconds=30.0):
-    """Time the CPU oracle (checker used as the reported baseline) on a bounded sample: the same synthetic batch,
-    full op-trace stream written into a buffer that is allocated and touched once, repeated until at least
-    `min_seconds` of wall time (every thread then ran >= 16 signatures unless the host is enormous)."""
+def cpu_baseline(w, bits, e, un, ux, target_seconds=12.0):
+    """Time the CPU oracle (checker used as the reported baseline) on a bounded sample of the same synthetic batch:
+    persistent threads (one per host core), each writing the full op-trace stream of its signatures into its own
+    reusable buffer; a short calibration pass sizes the timed run to about `target_seconds`."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from oracle_lib import Oracle
+    from oracle_lib import Oracle, pow_mod_fixed_exp_timed
     o = Oracle(w, bits // w)
     cores = os.cpu_count() or 1
     sample = min(un.limbs.shape[0], 1024)
-    x, n = np.ascontiguousarray(ux.limbs[:sample]), np.ascontiguousarray(un.limbs[:sample])
-    buf = np.zeros((sample, o.pow_fixed_stream_bytes(e)), dtype=np.uint8)
-    o.pow_mod_fixed_exp_batch(x, n, e, nthreads=cores, stream_buf=buf)   # warm-up: threads, pages
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        o.pow_mod_fixed_exp_batch(x, n, e, nthreads=cores, stream_buf=buf)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt >= max_seconds or (dt >= min_seconds and reps * sample >= 16 * cores):
-            break
-    # one thread on a small sample (SURVEY 8d asks for both the single-thread and the all-core figure)
+    x, n = ux.limbs[:sample], un.limbs[:sample]
+    cal, bad = pow_mod_fixed_exp_timed(o, x, n, e, 1, cores)
+    passes = max(1, min(100000, int(target_seconds / max(cal, 1e-4))))
+    while passes * sample < 16 * cores:   # at least 16 signatures per thread
+        passes += 1
+    sec, bad = pow_mod_fixed_exp_timed(o, x, n, e, passes, cores)
+    assert bad == 0
     one = min(sample, 64)
-    t1 = time.perf_counter()
-    o.pow_mod_fixed_exp_batch(x[:one], n[:one], e, nthreads=1, stream_buf=buf[:one])
-    single = one / (time.perf_counter() - t1)
-    return {"value": round(reps * sample / dt, 1), "unit": "assigns/s", "cores": cores, "kind": "port",
+    sec1, _ = pow_mod_fixed_exp_timed(o, x[:one], n[:one], e, 1, 1)
+    return {"value": round(passes * sample / sec, 1), "unit": "assigns/s", "cores": cores, "kind": "port",
             "sample": "%d passes over %d signatures of the same synthetic batch (%.1f s, %d threads, %.0f signatures per "
-                      "thread), full op-trace stream written" % (reps, sample, dt, cores, reps * sample / cores),
-            "single_thread_value": round(single, 1), "single_thread_sample": "%d signatures, 1 thread" % one}
+                      "thread), full op-trace stream written to per-thread buffers" % (passes, sample, sec, cores, passes * sample / cores),
+            "single_thread_value": round(one / sec1, 1), "single_thread_sample": "%d signatures, 1 thread" % one}
 
 
 def ensure_built():

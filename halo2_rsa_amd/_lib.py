@@ -70,9 +70,11 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_mul_trace_flatten", "h2r_is_equal_muled_batch", "h2r_is_equal_muled_flatten", "h2r_refresh_batch",
            "h2r_range_decompose_batch", "h2r_hist_len", "h2r_trace_lookup_hist", "h2r_lookups_per_record",
            "h2r_trace_lookup_permutation",
-           "h2r_trace_flatten", "h2r_pow_trace_flatten", "h2r_profile_enable", "h2r_profile_read", "h2r_status_str",
+           "h2r_trace_flatten", "h2r_pow_trace_flatten", "h2r_stream_bytes", "h2r_pow_stream_bytes", "h2r_trace_flatten_ex",
+           "h2r_pow_trace_flatten_ex", "h2r_trace_emit_stream", "h2r_pow_trace_emit_stream", "h2r_profile_enable", "h2r_profile_read", "h2r_status_str",
            "h2r_last_hip_error"]
-KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST, KERNEL_AUX = 0, 1, 2, 3
+KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST, KERNEL_AUX, KERNEL_EMIT = 0, 1, 2, 3, 4
+H2R_STREAM_FIELD_AB = 1
 FRESH_OPS = ["add", "sub", "add_mod", "sub_mod", "is_zero", "is_equal_fresh", "is_less_than", "is_less_than_or_equal",
              "is_greater_than", "is_greater_than_or_equal", "is_in_field"]
 
@@ -143,6 +145,14 @@ def lib():
     L.h2r_trace_lookup_permutation.argtypes = [vp, vp, u64, u64, u64, u32, vp, vp, vp]
     L.h2r_trace_flatten.argtypes = [vp, vp, vp]
     L.h2r_pow_trace_flatten.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, vp]
+    L.h2r_stream_bytes.argtypes = [vp, u32]
+    L.h2r_stream_bytes.restype = u64
+    L.h2r_pow_stream_bytes.argtypes = [vp, ctypes.POINTER(H2RPowLayout), u32]
+    L.h2r_pow_stream_bytes.restype = u64
+    L.h2r_trace_flatten_ex.argtypes = [vp, vp, u32, vp]
+    L.h2r_pow_trace_flatten_ex.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, u32, vp]
+    L.h2r_trace_emit_stream.argtypes = [vp, vp, u64, u32, vp, u64, u64, vp]
+    L.h2r_pow_trace_emit_stream.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, u64, u64, u32, vp, u64, u64, vp]
     L.h2r_profile_enable.argtypes = [u32]
     L.h2r_profile_read.argtypes = [u32, ctypes.POINTER(ctypes.c_float), u32, ctypes.POINTER(u32)]
     L.h2r_status_str.argtypes = [i32]

@@ -91,15 +91,36 @@ class Trace:
         s = self.elem_stride
         return self.buf[elem * s:(elem + 1) * s].cpu().numpy()
 
-    def flatten(self, elem: int) -> np.ndarray:
-        """The element's op-trace in the reference's assignment order (h2r_trace_flatten)."""
-        host = np.ascontiguousarray(self.elem_host(elem))
-        out = np.zeros(self.stream_bytes, dtype=np.uint8)
+    def stream_bytes_ex(self, flags: int = 0) -> int:
         if self.pow_layout is None:
-            check(lib().h2r_trace_flatten(self.chip._ctx, host.ctypes.data, out.ctypes.data), "h2r_trace_flatten")
+            return int(lib().h2r_stream_bytes(self.chip._ctx, flags))
+        return int(lib().h2r_pow_stream_bytes(self.chip._ctx, ctypes.byref(self.pow_layout), flags))
+
+    def flatten(self, elem: int, flags: int = 0) -> np.ndarray:
+        """The element's op-trace in the reference's assignment order (host walk of one element: h2r_trace_flatten_ex)."""
+        host = np.ascontiguousarray(self.elem_host(elem))
+        out = np.zeros(self.stream_bytes_ex(flags), dtype=np.uint8)
+        if self.pow_layout is None:
+            check(lib().h2r_trace_flatten_ex(self.chip._ctx, host.ctypes.data, flags, out.ctypes.data), "h2r_trace_flatten_ex")
         else:
-            check(lib().h2r_pow_trace_flatten(self.chip._ctx, ctypes.byref(self.pow_layout), host.ctypes.data, out.ctypes.data),
-                  "h2r_pow_trace_flatten")
+            check(lib().h2r_pow_trace_flatten_ex(self.chip._ctx, ctypes.byref(self.pow_layout), host.ctypes.data, flags, out.ctypes.data),
+                  "h2r_pow_trace_flatten_ex")
+        return out
+
+    def emit_stream(self, flags: int = 0, out: Optional[torch.Tensor] = None, out_stride: Optional[int] = None) -> torch.Tensor:
+        """Device-side flatten of EVERY element (h2r_trace_emit_stream / h2r_pow_trace_emit_stream): uint8
+        [batch, out_stride] in HBM whose first stream_bytes_ex(flags) bytes per row are the element's flat stream."""
+        sb = self.stream_bytes_ex(flags)
+        out_stride = sb if out_stride is None else out_stride
+        if out is None:
+            out = torch.empty((self.batch, out_stride), dtype=torch.uint8, device=self.buf.device)
+        if self.pow_layout is None:
+            check(lib().h2r_trace_emit_stream(self.chip._ctx, self.buf.data_ptr(), self.batch, flags, out.data_ptr(), out_stride, 0,
+                                              self.chip._stream()), "h2r_trace_emit_stream")
+        else:
+            check(lib().h2r_pow_trace_emit_stream(self.chip._ctx, ctypes.byref(self.pow_layout), self.buf.data_ptr(), self.elem_stride,
+                                                  self.batch, flags, out.data_ptr(), out_stride, 0, self.chip._stream()),
+                  "h2r_pow_trace_emit_stream")
         return out
 
     def plane(self, elem: int, t: int, name: str) -> np.ndarray:

@@ -136,13 +136,18 @@ struct h2r_ctx {
     u32 tab0_len, tab1_off, tab1_len, tab2_off, tab2_len, hist_len;
     // RefreshAux::new(w, L, L).increased_limbs_vec (host copy and device copy)
     u8 refresh_inc[2 * 128 + 8]; u32 refresh_nf; u8 *refresh_inc_dev;
+    u64 field_p[4];   // the field modulus (a_b encoding, chip.rs:859)
 };
 
 namespace {
 
+// Shapes with a compiled record kernel.  BigIntChip::new only asserts bits_len % limb_width == 0 (chip.rs:1175); here
+// num_limbs must also be a multiple of 4 (64-bit limbs, up to 4096 bits: RSA-1024/1536/2048/3072/4096 ...) or of 8
+// (32-bit limbs, up to 4096 bits), so that every accumulator row is a whole number of 64-byte store segments.
+constexpr u32 kLStep64 = 4, kLMax64 = 64, kLStep32 = 8, kLMax32 = 128;
 bool shape_supported(u32 w, u32 L) {
-    if (w == 64) return L == 4 || L == 8 || L == 16 || L == 32 || L == 64;
-    if (w == 32) return L == 8 || L == 32 || L == 64 || L == 128;
+    if (w == 64) return L >= kLStep64 && L <= kLMax64 && L % kLStep64 == 0;
+    if (w == 32) return L >= kLStep32 && L <= kLMax32 && L % kLStep32 == 0;
     return false;
 }
 
@@ -174,10 +179,13 @@ void build_const_record(h2r_ctx *c) {
     }
 }
 
-template <int LW, int L, int BT>
-hipError_t launch_trace_bt(const TraceArgs &ta, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
-    constexpr int TPI = 2 * L;
-    constexpr int IPB = TPI >= BT ? 1 : BT / TPI;
+template <int LW, int L>
+hipError_t launch_trace_t(const TraceArgs &ta, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
+    // the kernel hard-codes the accumulator row strides layout_compute derives for (LW, L)
+    if (ta.acc_lo_group != (LW == 64 ? 3ull * (2 * L * 16) : (u64)L * 16) || ta.acc_hi_group != ta.acc_lo_group ||
+        ta.acc_lo_row != (LW == 64 ? 2u * L * 16 : 0u) || ta.acc_spg != (LW == 64 ? 2u : 1u)) return hipErrorInvalidValue;
+    // (measured for the RSA-2048 shape: 128- and 64-thread workgroups are no better at any residency)
+    constexpr int BT = TraceGeo<L>::BT, IPB = TraceGeo<L>::IPB;
     const u64 blocks = (ta.n_items + IPB - 1) / IPB;
     if (blocks == 0) return hipSuccess;
     // dyn_lds > 0 caps the blocks resident per CU; ea/eb (nullable): start/stop events stamped by the dispatch itself
@@ -189,20 +197,19 @@ hipError_t launch_trace_bt(const TraceArgs &ta, hipStream_t st, hipEvent_t ea, h
     hipExtLaunchKernelGGL((trace_kernel<LW, L, BT>), dim3((unsigned)blocks), dim3(BT), ta.dyn_lds, st, ea, eb, 0, ta);
     return hipGetLastError();
 }
-template <int LW, int L>
-hipError_t launch_trace_t(const TraceArgs &ta, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
-    // the kernel hard-codes the accumulator row strides layout_compute derives for (LW, L)
-    if (ta.acc_lo_group != (LW == 64 ? 3ull * (2 * L * 16) : (u64)L * 16) || ta.acc_hi_group != ta.acc_lo_group ||
-        ta.acc_lo_row != (LW == 64 ? 2u * L * 16 : 0u) || ta.acc_spg != (LW == 64 ? 2u : 1u)) return hipErrorInvalidValue;
-    // (measured for the RSA-2048 shape: 128- and 64-thread workgroups are no better at any residency)
-    return launch_trace_bt<LW, L, 256>(ta, st, ea, eb);
+// one instantiation per supported num_limbs: L = STEP, 2 STEP, ..., MAXL
+template <int LW, int STEP, int I>
+hipError_t launch_trace_w(u32 L, const TraceArgs &ta, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
+    if constexpr (I == 0) return hipErrorInvalidValue;
+    else {
+        if (L == (u32)(I * STEP)) return launch_trace_t<LW, I * STEP>(ta, st, ea, eb);
+        return launch_trace_w<LW, STEP, I - 1>(L, ta, st, ea, eb);
+    }
 }
 hipError_t launch_trace(u32 w, u32 L, const TraceArgs &ta, hipStream_t st, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr) {
-#define H2R_CASE(W_, L_) if (w == W_ && L == L_) return launch_trace_t<W_, L_>(ta, st, ea, eb)
-    H2R_CASE(64, 4); H2R_CASE(64, 8); H2R_CASE(64, 16); H2R_CASE(64, 32); H2R_CASE(64, 64);
-    H2R_CASE(32, 8); H2R_CASE(32, 32); H2R_CASE(32, 64); H2R_CASE(32, 128);
-#undef H2R_CASE
-    return hipErrorInvalidValue;
+    if (!shape_supported(w, L)) return hipErrorInvalidValue;
+    if (w == 64) return launch_trace_w<64, kLStep64, kLMax64 / kLStep64>(L, ta, st, ea, eb);
+    return launch_trace_w<32, kLStep32, kLMax32 / kLStep32>(L, ta, st, ea, eb);
 }
 template <int K, int NW, bool DEEP>
 hipError_t launch_chain_t(const ChainArgs &ca, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
@@ -210,8 +217,11 @@ hipError_t launch_chain_t(const ChainArgs &ca, hipStream_t st, hipEvent_t ea, hi
     hipExtLaunchKernelGGL((chain_kernel<K, NW, DEEP>), dim3((unsigned)ca.batch), dim3(64 * NW), 0, st, ea, eb, 0, ca);
     return hipGetLastError();
 }
-hipError_t launch_chain(u32 K, const ChainArgs &ca, hipStream_t st, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr) {
-    switch (K) {  // NW = waves per element (multiple of the number of 64-column groups of the product)
+hipError_t launch_chain(const ChainArgs &ca, hipStream_t st, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr) {
+    // The chain kernel is compiled for K = 8, 16, 32, 64, 128 digits; any other size runs as the next larger one with
+    // zero high digits (ca.kreal digits in memory).  NW = waves per element (a multiple of the 64-column groups).
+    const u32 K = ca.kreal <= 8 ? 8 : ca.kreal <= 16 ? 16 : ca.kreal <= 32 ? 32 : ca.kreal <= 64 ? 64 : 128;
+    switch (K) {
         case 8: return launch_chain_t<8, 1, false>(ca, st, ea, eb);
         case 16: return launch_chain_t<16, 1, false>(ca, st, ea, eb);
         case 32: return launch_chain_t<32, 4, false>(ca, st, ea, eb);
@@ -227,8 +237,7 @@ hipError_t launch_chain(u32 K, const ChainArgs &ca, hipStream_t st, hipEvent_t e
             if (nw == 2) return launch_chain_t<64, 2, false>(ca, st, ea, eb);
             return deep ? launch_chain_t<64, 4, true>(ca, st, ea, eb) : launch_chain_t<64, 4, false>(ca, st, ea, eb);
         }
-        case 128: return launch_chain_t<128, 8, false>(ca, st, ea, eb);
-        default: return hipErrorInvalidValue;
+        default: return launch_chain_t<128, 8, false>(ca, st, ea, eb);
     }
 }
 
@@ -282,7 +291,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
     ca.a = static_cast<const u32 *>(a); ca.b = static_cast<const u32 *>(b); ca.n = static_cast<const u32 *>(n);
     ca.e_limbs = static_cast<const u32 *>(e_limbs);
     ca.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : c->K;
-    ca.batch = batch; ca.mode = mode; ca.T = T ? T : 1;
+    ca.batch = batch; ca.kreal = c->K; ca.mode = mode; ca.T = T ? T : 1;
     ca.e_num_limbs = e_num_limbs; ca.exp_limb_bits = exp_limb_bits; ca.digits_per_limb = lo.limb_width / 32;
     ca.check_in_field = check_in_field;
     ca.ops = reinterpret_cast<u32 *>(ws);
@@ -306,7 +315,8 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         ProfScope ps(H2R_KERNEL_CHAIN, st, true);
         const bool piped = trace_st && trace && T;
         chain_wait = ps.on ? ps.b : (piped ? chain_done : nullptr);
-        HIP_TRY(launch_chain(c->K, ca, st, ps.a, chain_wait));
+        if (c->K > 128) return H2R_E_UNSUPPORTED;
+        HIP_TRY(launch_chain(ca, st, ps.a, chain_wait));
     }
 #ifdef H2R_CHAIN_TIMING
     if (ca.dbg_time) {
@@ -423,6 +433,7 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
     std::memset(c->refresh_inc, 0, sizeof c->refresh_inc);
     c->refresh_nf = (L <= 128) ? refresh_aux_increased_limbs(w, L, c->refresh_inc) : 0;
     layout_compute(w, L, &c->layout);
+    field_modulus(params->field, c->field_p);
     build_const_record(c);
     // histogram rows: composition table of the limb sub-limbs, then of the carry sub-limbs when its width
     // differs, then the carry overflow table
@@ -997,7 +1008,8 @@ inline void emit_plane(Out &o, const h2r_layout &lo, const u8 *rec, int pl, u64 
 
 // parts: 1 = q/r limbs + sub-limbs (T1, T2), 2 = mul(a,b) accumulators (T3), 4 = mul(q,n) accumulators (T4),
 //        8 = eq_b (T5), 16 = is_equal_muled steps (T6)
-static u8 *flatten_parts(const h2r_layout &lo, const u8 *rec, u8 *outp, u32 parts) {
+//        32 (modifier) = a_b as the 32-byte canonical field element (modulus fp), H2R_STREAM_FIELD_AB
+static u8 *flatten_parts(const h2r_layout &lo, const u8 *rec, u8 *outp, u32 parts, const u64 *fp = nullptr) {
     const u32 L = lo.num_limbs, C = lo.num_cols;
     Out o{outp};
     if (parts & 1)   // T1/T2: q then r, each limb followed by its sub-limbs (chip.rs:588-599)
@@ -1018,7 +1030,15 @@ static u8 *flatten_parts(const h2r_layout &lo, const u8 *rec, u8 *outp, u32 part
         for (u32 i = 0; i < L; ++i) emit_wide(o, lo, rec, H2R_PL_EQB_LO, i);
     if (parts & 16)  // T6: is_equal_muled steps (chip.rs:857-893)
         for (u32 i = 0; i < C; ++i) {
-            emit_wide(o, lo, rec, H2R_PL_AMB_LO, i);
+            if ((parts & 32) && fp) {   // x >= 0 -> x, x < 0 -> p - |x| = p + x (mod 2^256)
+                u64 x[4] = {0, 0, 0, 0};
+                std::memcpy(x, rec + lo.plane_off[H2R_PL_AMB_LO] + (u64)i * 16, 16);
+                bool neg;
+                if (lo.wide_bytes > 16) { std::memcpy(&x[2], rec + lo.plane_off[H2R_PL_AMB_HI] + (u64)i * 8, 8); neg = (x[2] >> 63) != 0; x[3] = neg ? ~0ull : 0; }
+                else { neg = (x[1] >> 63) != 0; x[2] = x[3] = neg ? ~0ull : 0; }
+                if (neg) { u128 cy = 0; for (int k = 0; k < 4; ++k) { cy += (u128)x[k] + fp[k]; x[k] = (u64)cy; cy >>= 64; } }
+                emit(o, reinterpret_cast<const u8 *>(x), 32);
+            } else emit_wide(o, lo, rec, H2R_PL_AMB_LO, i);
             emit_wide(o, lo, rec, H2R_PL_SUM_LO, i);
             emit_plane(o, lo, rec, H2R_PL_CARRY, i, lo.carry_bytes);
             emit_plane(o, lo, rec, H2R_PL_CMOD, i, lo.limb_bytes);
@@ -1046,6 +1066,117 @@ int32_t h2r_trace_flatten(const h2r_ctx *ctx, const void *record_host, void *str
     u8 *end = flatten_parts(lo, static_cast<const u8 *>(record_host), static_cast<u8 *>(stream_out), 31);
     if ((u64)(end - static_cast<u8 *>(stream_out)) != lo.stream_bytes) return H2R_E_SHAPE;
     return H2R_OK;
+}
+
+uint64_t h2r_stream_bytes(const h2r_ctx *ctx, uint32_t flags) {
+    if (!ctx) return 0;
+    const h2r_layout &lo = ctx->layout;
+    return lo.stream_bytes + ((flags & H2R_STREAM_FIELD_AB) ? (u64)lo.num_cols * (32 - lo.wide_bytes) : 0);
+}
+uint64_t h2r_pow_stream_bytes(const h2r_ctx *ctx, const h2r_pow_layout *pl, uint32_t flags) {
+    if (!ctx || !pl) return 0;
+    return pl->stream_bytes + (u64)pl->num_mul_mods * (h2r_stream_bytes(ctx, flags) - ctx->layout.stream_bytes);
+}
+int32_t h2r_trace_flatten_ex(const h2r_ctx *ctx, const void *record_host, uint32_t flags, void *stream_out) {
+    if (!ctx || !record_host || !stream_out) return H2R_E_NULL;
+    if (flags & ~H2R_STREAM_FIELD_AB) return H2R_E_UNSUPPORTED;
+    u8 *end = flatten_parts(ctx->layout, static_cast<const u8 *>(record_host), static_cast<u8 *>(stream_out),
+                            31 | ((flags & H2R_STREAM_FIELD_AB) ? 32u : 0u), ctx->field_p);
+    if ((u64)(end - static_cast<u8 *>(stream_out)) != h2r_stream_bytes(ctx, flags)) return H2R_E_SHAPE;
+    return H2R_OK;
+}
+
+namespace {
+// The segment table of one record's stream for emit_kernel: q/r block, column ranges of the two accumulator planes
+// (each at most EMIT_SEG_CAP bytes), eq_b + the is_equal_muled steps.
+int32_t build_emit_segments(const h2r_layout &lo, u32 flags, EmitArgs &ea) {
+    const u32 L = lo.num_limbs, C = lo.num_cols, WB = lo.wide_bytes;
+    u32 n = 0;
+    auto push = [&](u32 kind, u32 c0, u32 c1, u64 off, u64 bytes) -> bool {
+        if (n >= (u32)EMIT_MAX_SEGS || bytes > EMIT_SEG_CAP) return false;
+        ea.seg[n++] = EmitSeg{kind, c0, c1, (u32)bytes, off};
+        return true;
+    };
+    u64 off = 0;
+    const u64 qr = 2ull * L * (lo.limb_bytes + lo.limb_nsub);
+    if (lo.limb_nsub != 8 || !push(EMIT_QR, 0, 0, off, qr)) return H2R_E_UNSUPPORTED;
+    off += qr;
+    for (u32 kind = EMIT_ACC_AB; kind <= EMIT_ACC_QN; ++kind) {
+        u32 c0 = 0;
+        while (c0 < C) {
+            u32 c1 = c0; u64 bytes = 0;
+            while (c1 < C) {
+                const u64 cb = (u64)(emit_colstart(c1 + 1, L) - emit_colstart(c1, L)) * WB;
+                if (bytes + cb > EMIT_SEG_CAP) break;
+                bytes += cb; ++c1;
+            }
+            if (c1 == c0 || !push(kind, c0, c1, off, bytes)) return H2R_E_UNSUPPORTED;
+            off += bytes; c0 = c1;
+        }
+    }
+    const u64 ab = (flags & H2R_STREAM_FIELD_AB) ? 32 : WB;
+    const u64 per_col = ab + 4ull * WB + 2ull * lo.carry_bytes + 4ull * lo.limb_bytes + 4;
+    const u64 eq = (u64)L * WB + (u64)C * per_col + (u64)(C - 1) * (lo.carry_bytes + lo.carry_nsub);
+    if (!push(EMIT_EQ, 0, 0, off, eq)) return H2R_E_UNSUPPORTED;
+    off += eq;
+    ea.nseg = n; ea.rec_bytes = off;
+    return H2R_OK;
+}
+
+int32_t launch_emit(const h2r_ctx *ctx, EmitArgs &ea, u32 flags, hipStream_t st) {
+    if (flags & ~H2R_STREAM_FIELD_AB) return H2R_E_UNSUPPORTED;
+    const h2r_layout &lo = ctx->layout;
+    const int32_t rc = build_emit_segments(lo, flags, ea);
+    if (rc) return rc;
+    if (ea.rec_bytes != h2r_stream_bytes(ctx, flags)) return H2R_E_SHAPE;
+    for (int p = 0; p < H2R_PL_COUNT; ++p) ea.off[p] = lo.plane_off[p];
+    ea.L = lo.num_limbs; ea.carry_nsub = lo.carry_nsub; ea.carry_sub_stride = lo.carry_sub_stride;
+    ea.record_stride = lo.record_stride;
+    ea.field_ab = (flags & H2R_STREAM_FIELD_AB) ? 1u : 0u;
+    for (int k = 0; k < 4; ++k) ea.p[k] = ctx->field_p[k];
+    const u64 blocks = ea.n_elems * (ea.T ? ea.T : 1);
+    if (blocks == 0) return H2R_OK;
+    if (blocks >= (1ull << 31)) return H2R_E_UNSUPPORTED;
+    H2R_ON_DEVICE(ctx->params.device);
+    ProfScope ps(H2R_KERNEL_EMIT, st, true);
+    const unsigned lds = EMIT_SEG_CAP + 64;
+    if (lo.limb_width == 64) hipExtLaunchKernelGGL((emit_kernel<64>), dim3((unsigned)blocks), dim3(256), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ea);
+    else hipExtLaunchKernelGGL((emit_kernel<32>), dim3((unsigned)blocks), dim3(256), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ea);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
+}  // namespace
+
+int32_t h2r_trace_emit_stream(const h2r_ctx *ctx, const void *trace, uint64_t num_records, uint32_t flags, void *stream_out,
+                              uint64_t out_stride, uint64_t out_off, h2r_stream_t stream) {
+    if (!ctx || !trace || !stream_out) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    if (out_stride < h2r_stream_bytes(ctx, flags)) return H2R_E_SHAPE;
+    EmitArgs ea;
+    std::memset(&ea, 0, sizeof ea);
+    ea.trace = static_cast<const u8 *>(trace); ea.elem_stride = ctx->layout.record_stride; ea.off_records = 0; ea.T = 1;
+    ea.n_elems = num_records; ea.out = static_cast<u8 *>(stream_out); ea.out_stride = out_stride; ea.out_off = out_off;
+    return launch_emit(ctx, ea, flags, static_cast<hipStream_t>(stream));
+}
+
+int32_t h2r_pow_trace_emit_stream(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *trace, uint64_t elem_stride,
+                                  uint64_t batch, uint32_t flags, void *stream_out, uint64_t out_stride, uint64_t out_off,
+                                  h2r_stream_t stream) {
+    if (!ctx || !pl || !trace || !stream_out) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    if (out_stride < out_off + h2r_pow_stream_bytes(ctx, pl, flags)) return H2R_E_SHAPE;
+    const h2r_layout &lo = ctx->layout;
+    EmitArgs ea;
+    std::memset(&ea, 0, sizeof ea);
+    ea.trace = static_cast<const u8 *>(trace); ea.elem_stride = elem_stride ? elem_stride : pl->elem_stride;
+    ea.off_records = pl->off_records; ea.T = pl->num_mul_mods; ea.n_elems = batch;
+    ea.out = static_cast<u8 *>(stream_out); ea.out_stride = out_stride; ea.out_off = out_off;
+    ea.var = pl->off_e_bits != UINT64_MAX ? 1u : 0u; ea.nbits = ea.var ? pl->num_exp_bits : 0;
+    ea.limbs_bytes = lo.num_limbs * lo.limb_bytes;
+    ea.off_e_bits = pl->off_e_bits; ea.off_selected = pl->off_selected; ea.selected_stride = pl->selected_stride;
+    ea.off_result = pl->off_result; ea.has_result = 1;
+    if (ea.var && ea.T != 2 * ea.nbits) return H2R_E_SHAPE;
+    return launch_emit(ctx, ea, flags, static_cast<hipStream_t>(stream));
 }
 
 // ---- BigIntInstructions::mul / square, is_equal_muled, refresh -----------------
@@ -1129,8 +1260,14 @@ int32_t h2r_refresh_batch(const h2r_ctx *ctx, const uint64_t *muled, uint64_t ba
 }
 
 int32_t h2r_pow_trace_flatten(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *elem_host, void *stream_out) {
+    return h2r_pow_trace_flatten_ex(ctx, pl, elem_host, 0, stream_out);
+}
+
+int32_t h2r_pow_trace_flatten_ex(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *elem_host, uint32_t flags, void *stream_out) {
     if (!ctx || !pl || !elem_host || !stream_out) return H2R_E_NULL;
+    if (flags & ~H2R_STREAM_FIELD_AB) return H2R_E_UNSUPPORTED;
     const h2r_layout &lo = ctx->layout;
+    const u64 rsb = h2r_stream_bytes(ctx, flags);
     const u8 *e = static_cast<const u8 *>(elem_host);
     u8 *o = static_cast<u8 *>(stream_out);
     const u32 limbs_bytes = lo.num_limbs * lo.limb_bytes;
@@ -1138,23 +1275,23 @@ int32_t h2r_pow_trace_flatten(const h2r_ctx *ctx, const h2r_pow_layout *pl, cons
     if (var) {
         std::memcpy(o, e + pl->off_e_bits, pl->num_exp_bits); o += pl->num_exp_bits;
         for (u32 b = 0; b < pl->num_exp_bits; ++b) {
-            int32_t rc = h2r_trace_flatten(ctx, e + pl->off_records + (u64)(2 * b) * lo.record_stride, o);
+            int32_t rc = h2r_trace_flatten_ex(ctx, e + pl->off_records + (u64)(2 * b) * lo.record_stride, flags, o);
             if (rc) return rc;
-            o += lo.stream_bytes;
+            o += rsb;
             std::memcpy(o, e + pl->off_selected + (u64)b * pl->selected_stride, limbs_bytes); o += limbs_bytes;
-            rc = h2r_trace_flatten(ctx, e + pl->off_records + (u64)(2 * b + 1) * lo.record_stride, o);
+            rc = h2r_trace_flatten_ex(ctx, e + pl->off_records + (u64)(2 * b + 1) * lo.record_stride, flags, o);
             if (rc) return rc;
-            o += lo.stream_bytes;
+            o += rsb;
         }
     } else {
         for (u32 t = 0; t < pl->num_mul_mods; ++t) {
-            int32_t rc = h2r_trace_flatten(ctx, e + pl->off_records + (u64)t * lo.record_stride, o);
+            int32_t rc = h2r_trace_flatten_ex(ctx, e + pl->off_records + (u64)t * lo.record_stride, flags, o);
             if (rc) return rc;
-            o += lo.stream_bytes;
+            o += rsb;
         }
     }
     std::memcpy(o, e + pl->off_result, limbs_bytes); o += limbs_bytes;
-    if ((u64)(o - static_cast<u8 *>(stream_out)) != pl->stream_bytes) return H2R_E_SHAPE;
+    if ((u64)(o - static_cast<u8 *>(stream_out)) != h2r_pow_stream_bytes(ctx, pl, flags)) return H2R_E_SHAPE;
     return H2R_OK;
 }
 

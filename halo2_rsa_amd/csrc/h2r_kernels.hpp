@@ -63,16 +63,18 @@ struct ExpBits {
 };
 
 struct ChainArgs {
-    const u32 *a;        // MULMOD: a operands; POW: x       [elem][K]
+    const u32 *a;        // MULMOD: a operands; POW: x       [elem][kreal]
     const u32 *b;        // MULMOD: b operands
     const u32 *n;        // moduli [elem][K] (stride 0 when shared)
     const u32 *e_limbs;  // POW_VAR: [elem][e_num_limbs * (limb_width/32)] digits
     u64 n_stride;        // digits between consecutive moduli (0 = shared)
     u64 batch;
+    u32 kreal;           // digits of the integers in memory (<= the kernel's K: a shape between two compiled sizes runs as the
+                         // next larger one with zero high digits -- Barrett's normalisation shift absorbs them)
     u32 mode, T;         // T = mul_mods per element
     u32 e_num_limbs, exp_limb_bits, digits_per_limb;
     u32 check_in_field;  // modpow_public_key: status NOT_IN_FIELD when x >= n (src/chip.rs:106)
-    u32 *ops;            // [elem*T + t][4][K]: a, b, q, r of every mul_mod (one contiguous 16K-byte run per item)
+    u32 *ops;            // [elem*T + t][4][kreal]: a, b, q, r of every mul_mod (one contiguous 16*kreal-byte run per item)
     u32 *out;            // nullable: result [elem][K]
     u8 *status;          // [elem]
     // POW_VAR extras written straight into the element traces
@@ -397,14 +399,19 @@ __device__ __forceinline__ void lds_store(u32 *dst, const u32 (&r)[(K + 63) / 64
     for (int m = 0; m < (K + 63) / 64; ++m) if (lane + 64 * m < K) dst[lane + 64 * m] = r[m];
 }
 template <int K>
+__device__ __forceinline__ void lds_store_n(u32 *dst, const u32 (&r)[(K + 63) / 64], int lane, u32 n) {   // first n digits only
+#pragma unroll
+    for (int m = 0; m < (K + 63) / 64; ++m) if ((u32)(lane + 64 * m) < n) dst[lane + 64 * m] = r[m];
+}
+template <int K>
 __device__ __forceinline__ void lds_load(u32 (&r)[(K + 63) / 64], const u32 *src, int lane) {
 #pragma unroll
     for (int m = 0; m < (K + 63) / 64; ++m) r[m] = (lane + 64 * m < K) ? src[lane + 64 * m] : 0;
 }
 template <int K>
-__device__ __forceinline__ void glb_store(u32 *dst, const u32 (&r)[(K + 63) / 64], int lane) {
+__device__ __forceinline__ void glb_store(u32 *dst, const u32 (&r)[(K + 63) / 64], int lane, u32 n) {   // first n digits
 #pragma unroll
-    for (int m = 0; m < (K + 63) / 64; ++m) if (lane + 64 * m < K) dst[lane + 64 * m] = r[m];
+    for (int m = 0; m < (K + 63) / 64; ++m) if ((u32)(lane + 64 * m) < n) dst[lane + 64 * m] = r[m];
 }
 
 // mu' = floor(((~n') * 2^(32K) + 2^(32K) - 1) / n') by wave-parallel Knuth algorithm D (n'
@@ -607,9 +614,10 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R
     const bool w0 = wave == 0;
     const u64 elem = blockIdx.x;
     const u32 *n_g = args.n + elem * args.n_stride;
+    const u32 KR = args.kreal;   // digits in memory; digits [KR, K) are zero
     u32 nraw[V];
 #pragma unroll
-    for (int m = 0; m < V; ++m) nraw[m] = (lane + 64 * m < K) ? n_g[lane + 64 * m] : 0;
+    for (int m = 0; m < V; ++m) nraw[m] = ((u32)(lane + 64 * m) < KR) ? n_g[lane + 64 * m] : 0;
     for (int i = threadIdx.x; i < 3 * K; i += 64 * NW) { s.bpad[i] = 0; s.nnpad[i] = 0; s.mupad[i] = 0; }
     if (threadIdx.x == 0) { s.dbg = (blockIdx.x == 0) ? args.dbg_time : nullptr; s.dbg_n = 0; }
     // normalisation shift: leading zero bits of n within 32K bits (every wave computes it: block-uniform)
@@ -625,8 +633,8 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R
 #pragma unroll
     for (int m = 0; m < V; ++m) {
         const int v = lane + 64 * m;
-        cur[m] = v < K ? args.a[elem * K + v] : 0;
-        bop[m] = (args.mode == CHAIN_MULMOD && v < K) ? args.b[elem * K + v] : 0;
+        cur[m] = (u32)v < KR ? args.a[elem * KR + v] : 0;
+        bop[m] = (args.mode == CHAIN_MULMOD && (u32)v < KR) ? args.b[elem * KR + v] : 0;
         acc[m] = (v == 0) ? 1u : 0u;  // acc = const 1 padded to num_limbs (:729 / :682)
     }
     if (status == H2R_OK && args.mode != CHAIN_MULMOD && args.check_in_field && wave_ge<K>(cur, nraw, lane))
@@ -677,18 +685,27 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R
             // staged through LDS so that the four K-digit values leave as 16-byte stores (one instruction for K = 64):
             // a store instruction of this wave queues behind the co-running record kernel's stores, so fewer is faster
             wave_sync();
-            lds_store<K>(s.stage, oa, lane); lds_store<K>(s.stage + K, ob, lane);
-            lds_store<K>(s.stage + 2 * K, q, lane); lds_store<K>(s.stage + 3 * K, r, lane);
+            lds_store_n<K>(s.stage, oa, lane, KR); lds_store_n<K>(s.stage + KR, ob, lane, KR);
+            lds_store_n<K>(s.stage + 2 * KR, q, lane, KR); lds_store_n<K>(s.stage + 3 * KR, r, lane, KR);
             wave_sync();
-            uint4 *dst = reinterpret_cast<uint4 *>(args.ops + it * (4 * K));
-            for (int v = lane; v < K; v += 64) dst[v] = reinterpret_cast<const uint4 *>(s.stage)[v];
+            uint4 *dst = reinterpret_cast<uint4 *>(args.ops + it * (4ull * KR));   // 4 * KR digits = KR 16-byte units
+            for (u32 v = lane; v < KR; v += 64) dst[v] = reinterpret_cast<const uint4 *>(s.stage)[v];
         }
     };
-    auto fold = [&](int st) { if (st != H2R_OK && status == H2R_OK) status = st; };
+    // a quotient that needs more than KR digits does not fit num_limbs limbs (chip.rs:583-584); only possible when KR < K
+    auto fold = [&](int st) {
+        if (KR < (u32)K && w0) {
+            bool hi = false;
+#pragma unroll
+            for (int m = 0; m < V; ++m) hi = hi || ((u32)(lane + 64 * m) >= KR && q[m] != 0);
+            if (__ballot(hi) && st == H2R_OK) st = H2R_E_NOT_REDUCED;
+        }
+        if (st != H2R_OK && status == H2R_OK) status = st;
+    };
     if (args.mode == CHAIN_MULMOD) {
         fold(block_mulmod<K, NW, DEEP>(s, shift, lane, wave, cur, bop, nn, q, r));
         emit(0, cur, bop);
-        if (w0 && status == H2R_OK && args.out) glb_store<K>(args.out + elem * K, r, lane);
+        if (w0 && status == H2R_OK && args.out) glb_store<K>(args.out + elem * KR, r, lane, KR);
     } else {
         // pow_mod_fixed_exp (chip.rs:710-742) / pow_mod (chip.rs:664-696)
         u32 t = 0;
@@ -718,7 +735,7 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R
 #pragma unroll
                 for (int m = 0; m < V; ++m) acc[m] = bit ? r[m] : acc[m];
                 if (etrace && w0 && status == H2R_OK)
-                    glb_store<K>((u32 *)(etrace + args.off_selected + (u64)bi * args.selected_stride), acc, lane);
+                    glb_store<K>((u32 *)(etrace + args.off_selected + (u64)bi * args.selected_stride), acc, lane, KR);
             }
             // squared = square_mod(cur) (:734 resp. :693)
             fold(block_mulmod<K, NW, DEEP>(s, shift, lane, wave, cur, cur, nn, q, r));
@@ -738,8 +755,8 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R
             for (int m = 0; m < V; ++m) cur[m] = sq[m];
         }
         if (status == H2R_OK && w0) {
-            if (args.out) glb_store<K>(args.out + elem * K, acc, lane);
-            if (etrace && args.write_result_to_trace) glb_store<K>((u32 *)(etrace + args.off_result), acc, lane);
+            if (args.out) glb_store<K>(args.out + elem * KR, acc, lane, KR);
+            if (etrace && args.write_result_to_trace) glb_store<K>((u32 *)(etrace + args.off_result), acc, lane, KR);
         }
     }
     if (threadIdx.x == 0) args.status[elem] = (u8)status;
@@ -917,17 +934,30 @@ template <> struct ColAcc<32> {
 #define H2R_ABLATE(bit_) false
 #endif
 
-// BT = threads per workgroup (a multiple of the 2L threads of an item, at most 256)
-template <int LW, int L, int BT = 256>
+// Thread geometry of the record kernel for num_limbs = L: an item (one mul_mod) is worked on by 2L threads -- lanes
+// [0, L) the a*b columns, lanes [L, 2L) the q*n columns, then one thread per un-carried column.  The item's thread
+// group is padded to TPI threads so that it either divides a wavefront (a power of two <= 64) or is a whole number of
+// wavefronts; the padding threads (t >= 2L, none when L is a power of two) only take part in barriers and ballots.
+template <int L>
+struct TraceGeo {
+    static constexpr int pad(int t) { if (t >= 64) return (t + 63) / 64 * 64; int p = 1; while (p < t) p <<= 1; return p; }
+    static constexpr int TPI = pad(2 * L);                 // threads per item
+    static constexpr int IPB = TPI >= 256 ? 1 : 256 / TPI;  // items per workgroup
+    static constexpr int BT = IPB * TPI;                   // threads per workgroup (256, or 192 for 64 < L <= 96)
+    static_assert(TPI <= 256, "num_limbs > 128 not supported");
+};
+
+// BT = threads per workgroup (a multiple of the padded thread group of an item, at most 256)
+template <int LW, int L, int BT = TraceGeo<L>::BT>
 __global__ __launch_bounds__(BT) void trace_kernel(TraceArgs args) {
     using limb_t = typename LimbT<LW>::type;
     using W = Wide<LW>;
-    constexpr int TPI = 2 * L;                   // threads per item
+    constexpr int TPI = TraceGeo<L>::TPI;        // threads per item (>= 2L)
     constexpr int IPB = TPI >= BT ? 1 : BT / TPI;  // items per block
-    static_assert(BT % 64 == 0 && (TPI >= BT ? TPI == BT || BT == 256 : BT % TPI == 0), "block shape");
+    static_assert(BT % 64 == 0 && (TPI >= BT ? TPI == BT : BT % TPI == 0), "block shape");
     constexpr int C = 2 * L - 1;
     constexpr int WPI = TPI / 64 > 0 ? TPI / 64 : 1;  // waves per item (when TPI >= 64)
-    static_assert(TPI <= 256, "num_limbs > 128 not supported");
+    constexpr bool POW2 = (L & (L - 1)) == 0;
     __shared__ TraceLds<LW, L> lds_all[IPB];
     __shared__ u64 xg[4], xp[4], xbad[4];  // per-wave carry masks for multi-wave items
 
@@ -942,7 +972,7 @@ __global__ __launch_bounds__(BT) void trace_kernel(TraceArgs args) {
     const u32 elem32 = in_range ? item / args.T : 0;
     const u32 tt = in_range ? item - elem32 * args.T : 0;
     const u64 elem = elem32;
-    const bool live = in_range && (args.status == nullptr || args.status[elem] == 0);
+    const bool live = in_range && t < 2 * L && (args.status == nullptr || args.status[elem] == 0);
     u8 *rec = args.trace + elem * args.elem_stride + args.off_records + (u64)tt * args.record_stride;
     const u64 *off = args.off;
     // An item that fits one wave (2L <= 64) never needs a workgroup barrier: its LDS traffic is
@@ -991,7 +1021,8 @@ __global__ __launch_bounds__(BT) void trace_kernel(TraceArgs args) {
         for (int st = 0; st < L; ++st) {
             limb_t xn, yn;
             if (H2R_ABLATE(4)) { xn = x + 3; yn = y ^ (limb_t)st; }
-            else { xn = Ah[(st + 1) & (L - 1)]; yn = Bh[(i - st - 1) & (L - 1)]; }  // prefetch next step
+            else if constexpr (POW2) { xn = Ah[(st + 1) & (L - 1)]; yn = Bh[(i - st - 1) & (L - 1)]; }  // prefetch next step
+            else { xn = Ah[st + 1 == L ? 0 : st + 1]; const int k = i - st - 1; yn = Bh[k < 0 ? k + L : k]; }   // (i - st - 1) mod L
             acc.keep_if(st != i + 1);       // column i is complete: start column i+L from zero
             if (H2R_ABLATE(8)) { acc.w[0] += (u32)x; acc.w[1] ^= (u32)y; }
             else acc.add_product(x, y);
@@ -1742,6 +1773,188 @@ __global__ __launch_bounds__(256) void perm_kernel(PermArgs p) {
                 rows[k] = (uint16_t)lo;
             }
         }
+    }
+}
+
+// ================================================================================================
+// K7: device-side flatten -- planes -> the reference's assignment order (the flat op-trace stream), in HBM
+//   What h2r_trace_flatten does on a host copy of one record, for every record of a batch, at HBM speed: a layouter
+//   shim (or a prover's advice-column builder) reads the values in the order the reference assigns them
+//   (big_integer/chip.rs:588-599 q/r + sub-limbs, :400-412 accumulators column by column, :617 eq_b, :857-893 the
+//   is_equal_muled steps) without walking the planes on the host.
+//   One workgroup per record.  The record's stream is cut into segments of at most EMIT_SEG_CAP bytes (host-built
+//   table: q/r block, column ranges of the two accumulator planes, eq_b + carry steps).  Per segment: every thread
+//   reads source entries in SOURCE order (coalesced 16-byte loads from the planes) and scatters them into an LDS image
+//   of the segment at their stream offsets; the image then leaves as 16-byte stores aligned to the OUTPUT address --
+//   streams are byte-packed, so a segment starts at an arbitrary byte of the output and the LDS image is funnel-shifted
+//   (v_alignbyte) on its way out.  Bound: HBM (reads one record, writes one stream: 2 x 64 KB per RSA-2048 mul_mod).
+// ================================================================================================
+constexpr u32 EMIT_SEG_CAP = 32 * 1024;   // bytes of stream staged in LDS at a time (4 workgroups per CU)
+constexpr int EMIT_MAX_SEGS = 40;
+enum { EMIT_QR = 0, EMIT_ACC_AB = 1, EMIT_ACC_QN = 2, EMIT_EQ = 3 };
+struct EmitSeg { u32 kind, c0, c1, bytes; u64 off; };   // columns [c0, c1) for the accumulator kinds; off/bytes within the record's stream
+
+// entries of the reference's column order before column i (column c has min(c + 1, 2L - 1 - c) accumulators)
+__host__ __device__ inline u32 emit_colstart(u32 i, u32 L) {
+    if (i <= L) return i * (i + 1) / 2;
+    return L * (L + 1) / 2 + (i - L) * (2 * L - 1) - ((i - 1) * i / 2 - (L - 1) * L / 2);
+}
+
+struct EmitArgs {
+    const u8 *trace; u64 elem_stride, off_records, record_stride; u32 T; u64 n_elems;
+    u8 *out; u64 out_stride, out_off;   // element e's stream starts at out + e * out_stride + out_off
+    u64 rec_bytes;                      // stream bytes of one record (depends on field_ab)
+    u32 var, nbits, limbs_bytes;        // pow_mod layout: e bits first, selected limbs between the records of a bit
+    u64 off_e_bits, off_selected, selected_stride, off_result;
+    u32 has_result;
+    u64 off[H2R_PL_COUNT];
+    u32 L, carry_nsub, carry_sub_stride;
+    u32 field_ab;                       // a_b as a 32-byte canonical field element (p - |x| when negative, chip.rs:859)
+    u64 p[4];                           // the field modulus
+    u32 nseg; EmitSeg seg[EMIT_MAX_SEGS];
+};
+
+template <int LW>
+__global__ __launch_bounds__(256) void emit_kernel(EmitArgs a) {
+    constexpr u32 LB = LW / 8, WB = LW == 64 ? 24 : 16, CB = LW == 64 ? 16 : 8;
+    extern __shared__ uint4 emit_lds4[];
+    u8 *const lds = reinterpret_cast<u8 *>(emit_lds4);
+    u32 *const lds32 = reinterpret_cast<u32 *>(emit_lds4);
+    const u32 tid = threadIdx.x;
+    const u32 Tn = a.T ? a.T : 1;
+    const u64 elem = blockIdx.x / Tn;
+    const u32 t = (u32)(blockIdx.x - elem * Tn);
+    const u8 *et = a.trace + elem * a.elem_stride;
+    u8 *eo = a.out + elem * a.out_stride + a.out_off;
+    const u32 L = a.L, C = 2 * L - 1;
+    // stream offset of record t within the element
+    u64 roff;
+    if (a.var) roff = (u64)a.nbits + (u64)(t >> 1) * (2 * a.rec_bytes + a.limbs_bytes) + (u64)(t & 1) * (a.rec_bytes + a.limbs_bytes);
+    else roff = (u64)t * a.rec_bytes;
+    // small extras (byte copies): e bits, the selected limbs that follow a bit's first record, the result limbs
+    if (a.var && t == 0) for (u32 k = tid; k < a.nbits; k += 256) eo[k] = et[a.off_e_bits + k];
+    if (a.var && a.T && (t & 1) == 0)
+        for (u32 k = tid; k < a.limbs_bytes; k += 256) eo[roff + a.rec_bytes + k] = et[a.off_selected + (u64)(t >> 1) * a.selected_stride + k];
+    if (a.has_result && t == Tn - 1) {
+        const u64 res_off = a.var ? (u64)a.nbits + (u64)(a.T >> 1) * (2 * a.rec_bytes + a.limbs_bytes) : (u64)a.T * a.rec_bytes;
+        for (u32 k = tid; k < a.limbs_bytes; k += 256) eo[res_off + k] = et[a.off_result + k];
+    }
+    if (a.T == 0) return;
+    const u8 *rec = et + a.off_records + (u64)t * a.record_stride;
+    const u32 ABB = a.field_ab ? 32u : WB;                                    // bytes of a_b in the stream
+    const u32 per_col = ABB + 4 * WB + 2 * CB + 4 * LB + 4;                   // one is_equal_muled step without the range assign
+    const u32 per_col_ra = per_col + CB + a.carry_nsub;                       // ... with it (every column but the last)
+    auto put_bytes = [&](u32 pos, u64 v, u32 n) { for (u32 k = 0; k < n; ++k) lds[pos + k] = (u8)(v >> (8 * k)); };
+    for (u32 sg = 0; sg < a.nseg; ++sg) {
+        const EmitSeg &S = a.seg[sg];
+        // ---- scatter: source order in, stream order in LDS -----------------------------------------------------
+        if (S.kind == EMIT_QR) {   // T1/T2: limb + its 8 sub-limb bytes, q then r (chip.rs:588-599)
+            for (u32 k = tid; k < 2 * L; k += 256) {
+                const u32 which = k >= L, kk = which ? k - L : k;
+                const u8 *pl = rec + a.off[which ? H2R_PL_R : H2R_PL_Q] + (u64)kk * LB;
+                const u64 sub = *reinterpret_cast<const u64 *>(rec + a.off[which ? H2R_PL_R_SUB : H2R_PL_Q_SUB] + (u64)kk * 8);
+                const u32 pos = k * (LB + 8);
+                if constexpr (LW == 64) { *reinterpret_cast<u64 *>(lds + pos) = *reinterpret_cast<const u64 *>(pl); *reinterpret_cast<u64 *>(lds + pos + 8) = sub; }
+                else { lds32[pos / 4] = *reinterpret_cast<const u32 *>(pl); lds32[pos / 4 + 1] = (u32)sub; lds32[pos / 4 + 2] = (u32)(sub >> 32); }
+            }
+        } else if (S.kind == EMIT_ACC_AB || S.kind == EMIT_ACC_QN) {   // T3/T4: column i ascending, then j ascending (chip.rs:400-412)
+            const bool qn = S.kind == EMIT_ACC_QN;
+            const u8 *plo = rec + a.off[qn ? H2R_PL_QN_LO : H2R_PL_AB_LO];
+            const u8 *phi = rec + a.off[qn ? H2R_PL_QN_HI : H2R_PL_AB_HI];
+            const u32 e0 = emit_colstart(S.c0, L);
+            for (u32 sidx = tid; sidx < L * L; sidx += 256) {
+                const u32 j = sidx / L, im = sidx - j * L;
+                const u32 i = im >= j ? im : im + L;            // the column this accumulator belongs to (i % L == im)
+                if (i < S.c0 || i >= S.c1) continue;
+                const u32 jmin = i >= L ? i - L + 1 : 0;
+                const u32 pos = (emit_colstart(i, L) - e0 + (j - jmin)) * WB;
+                if constexpr (LW == 64) {   // interleaved rows: two steps per group, shared HI row (h2r_layout)
+                    const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(plo + (u64)(j >> 1) * (3ull * 2 * L * 16) + (u64)(j & 1) * (2ull * L * 16) + (u64)im * 16);
+                    const u64 hi = *reinterpret_cast<const u64 *>(phi + (u64)(j >> 1) * (3ull * 2 * L * 16) + (u64)im * 16 + (j & 1) * 8);
+                    u64 *d = reinterpret_cast<u64 *>(lds + pos);
+                    d[0] = lo.x; d[1] = lo.y; d[2] = hi;
+                } else {
+                    const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(plo + (u64)j * ((u64)L * 16) + (u64)im * 16);
+                    u64 *d = reinterpret_cast<u64 *>(lds + pos);
+                    d[0] = lo.x; d[1] = lo.y;
+                }
+            }
+        } else {   // T5 eq_b (chip.rs:617) then T6, the is_equal_muled steps (chip.rs:857-893)
+            for (u32 i = tid; i < L; i += 256) {
+                const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(rec + a.off[H2R_PL_EQB_LO] + (u64)i * 16);
+                u64 *d = reinterpret_cast<u64 *>(lds + i * WB);
+                d[0] = lo.x; d[1] = lo.y;
+                if constexpr (LW == 64) d[2] = *reinterpret_cast<const u64 *>(rec + a.off[H2R_PL_EQB_HI] + (u64)i * 8);
+            }
+            for (u32 c = tid; c < C; c += 256) {
+                u32 pos = L * WB + c * per_col_ra;
+                auto wide = [&](int pl_lo, u32 nb) {   // WIDE value: 16-byte LO entry + (64-bit limbs) 8-byte HI entry
+                    const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(rec + a.off[pl_lo] + (u64)c * 16);
+                    put_bytes(pos, lo.x, 8); put_bytes(pos + 8, lo.y, 8);
+                    if constexpr (LW == 64) put_bytes(pos + 16, *reinterpret_cast<const u64 *>(rec + a.off[pl_lo + 1] + (u64)c * 8), 8);
+                    pos += nb;
+                };
+                auto limb = [&](int pl) {
+                    if constexpr (LW == 64) put_bytes(pos, *reinterpret_cast<const u64 *>(rec + a.off[pl] + (u64)c * 8), 8);
+                    else put_bytes(pos, *reinterpret_cast<const u32 *>(rec + a.off[pl] + (u64)c * 4), 4);
+                    pos += LB;
+                };
+                auto carry = [&](int pl) {
+                    put_bytes(pos, *reinterpret_cast<const u64 *>(rec + a.off[pl] + (u64)c * CB), 8);
+                    if constexpr (LW == 64) put_bytes(pos + 8, *reinterpret_cast<const u64 *>(rec + a.off[pl] + (u64)c * CB + 8), 8);
+                    pos += CB;
+                };
+                if (a.field_ab) {   // a_b as the canonical element of F: x >= 0 -> x, x < 0 -> p - |x| = p + x (mod 2^256)
+                    const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(rec + a.off[H2R_PL_AMB_LO] + (u64)c * 16);
+                    u64 x[4] = {lo.x, lo.y, 0, 0};
+                    bool neg;
+                    if constexpr (LW == 64) { x[2] = *reinterpret_cast<const u64 *>(rec + a.off[H2R_PL_AMB_HI] + (u64)c * 8); neg = (x[2] >> 63) != 0; x[3] = neg ? ~0ull : 0; }
+                    else { neg = (x[1] >> 63) != 0; x[2] = x[3] = neg ? ~0ull : 0; }
+                    if (neg) {
+                        u64 cy = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { const u64 s1 = x[k] + a.p[k]; const u64 c1 = s1 < x[k]; const u64 s2 = s1 + cy; cy = c1 | (u64)(s2 < s1); x[k] = s2; }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) put_bytes(pos + 8 * k, x[k], 8);
+                    pos += 32;
+                } else wide(H2R_PL_AMB_LO, WB);
+                wide(H2R_PL_SUM_LO, WB); carry(H2R_PL_CARRY); limb(H2R_PL_CMOD); wide(H2R_PL_NQ1_LO, WB); limb(H2R_PL_AMNQ1);
+                wide(H2R_PL_ACCX_LO, WB); carry(H2R_PL_QACC); limb(H2R_PL_MODACC); wide(H2R_PL_NQ2_LO, WB); limb(H2R_PL_AMNQ2);
+                const u32 fl = *reinterpret_cast<const u32 *>(rec + a.off[H2R_PL_FLAGS] + (u64)c * 4);
+                put_bytes(pos, fl & 0xffffu, 2); pos += 2;
+                if (c < C - 1) {
+                    carry(H2R_PL_CARRY_DUP);
+                    const u8 *sb = rec + a.off[H2R_PL_CARRY_SUB] + (u64)c * a.carry_sub_stride;
+                    const ulonglong2 sv = *reinterpret_cast<const ulonglong2 *>(sb);
+                    for (u32 k = 0; k < a.carry_nsub; ++k) lds[pos + k] = (u8)((k < 8 ? sv.x : sv.y) >> (8 * (k & 7)));
+                    pos += a.carry_nsub;
+                }
+                put_bytes(pos, fl >> 16, 2);
+            }
+        }
+        __syncthreads();
+        // ---- stream out: 16-byte stores aligned to the output address; the LDS image is shifted by the misalignment --
+        u8 *g = eo + roff + S.off;                           // output address of image byte 0
+        const u32 mis = (u32)(reinterpret_cast<u64>(g) & 15u);
+        const u32 head = mis ? (16u - mis < S.bytes ? 16u - mis : S.bytes) : 0u;   // bytes before the first aligned unit
+        if (tid < head) g[tid] = lds[tid];
+        const u32 body = (S.bytes - head) / 16;              // whole aligned 16-byte units
+        const u32 sh = head & 3u;                            // byte phase of the image relative to 32-bit LDS words
+        for (u32 u = tid; u < body; u += 256) {
+            const u32 o = head + 16 * u;                     // image offset of this unit
+            const u32 w0 = o >> 2;
+            u32 d[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) d[k] = lds32[w0 + k];
+            u32 r[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) r[k] = (u32)(((((u64)d[k + 1]) << 32) | d[k]) >> (8 * sh));
+            st16(g + o, ((u64)r[1] << 32) | r[0], ((u64)r[3] << 32) | r[2]);
+        }
+        const u32 done = head + 16 * body;
+        if (tid < S.bytes - done) g[done + tid] = lds[done + tid];
+        __syncthreads();   // the image is reused by the next segment
     }
 }
 

@@ -95,6 +95,18 @@ inline u32 field_num_bits(u32 field) {
     }
 }
 
+// The field modulus p (little-endian 64-bit words): a_b = a[i] - b[i] (big_integer/chip.rs:859) is a FIELD subtraction,
+// so a negative difference is the element p - |x|.
+inline void field_modulus(u32 field, u64 p[4]) {
+    static const u64 kP[4][4] = {
+        {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull},   // bn256::Fr
+        {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull},   // bn256::Fq
+        {0x992d30ed00000001ull, 0x224698fc094cf91bull, 0x0000000000000000ull, 0x4000000000000000ull},   // pasta::Fp
+        {0x8c46eb2100000001ull, 0x224698fc0994a8ddull, 0x0000000000000000ull, 0x4000000000000000ull},   // pasta::Fq
+    };
+    for (int i = 0; i < 4; ++i) p[i] = kP[field < 4 ? field : 0][i];
+}
+
 inline u64 round_up(u64 x, u64 a) { return (x + a - 1) / a * a; }
 
 // Fills every field of h2r_layout for (w, L).  Plane sizes are rounded up to 256 bytes so that every

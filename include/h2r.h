@@ -371,11 +371,35 @@ int32_t h2r_trace_flatten(const h2r_ctx *ctx, const void *record_host, void *str
 int32_t h2r_pow_trace_flatten(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *elem_host,
                               void *stream_out);
 
+/* ---- flat stream in HBM: the device-side flatten ----------------------------------------------------
+ * h2r_trace_flatten walks ONE host copy; these exports produce the same bytes for every record of a batch on the
+ * device, so that a layouter shim / advice-column builder consumes the witness in the reference's assignment order at
+ * HBM speed.  Element e's stream is written at stream_out + e * out_stride + out_off (any byte alignment).
+ *   flags  H2R_STREAM_FIELD_AB: a_b = a[i] - b[i] (big_integer/chip.rs:859, a FIELD subtraction) is emitted as the
+ *          canonical element of the ctx's field, 32 bytes little-endian (x >= 0 -> x, x < 0 -> p - |x|), instead of the
+ *          WIDE two's complement integer; every other value is < 2^135 << p, so its integer IS its canonical element.
+ *          The *_ex host walks take the same flags (flags = 0: identical to the plain forms).
+ *   h2r_trace_emit_stream      mul_mod batch: record i at trace + i * record_stride.
+ *   h2r_pow_trace_emit_stream  pow traces laid out per `pl`; elem_stride = 0 means pl->elem_stride (pass the enclosing
+ *                              element's stride for a pow trace embedded in a verify element).  Byte-equal to
+ *                              h2r_pow_trace_flatten_ex of every element. */
+#define H2R_STREAM_FIELD_AB 1u
+uint64_t h2r_stream_bytes(const h2r_ctx *ctx, uint32_t flags);                         /* one mul_mod record */
+uint64_t h2r_pow_stream_bytes(const h2r_ctx *ctx, const h2r_pow_layout *pl, uint32_t flags);   /* one pow element */
+int32_t h2r_trace_flatten_ex(const h2r_ctx *ctx, const void *record_host, uint32_t flags, void *stream_out);
+int32_t h2r_pow_trace_flatten_ex(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *elem_host, uint32_t flags,
+                                 void *stream_out);
+int32_t h2r_trace_emit_stream(const h2r_ctx *ctx, const void *trace, uint64_t num_records, uint32_t flags,
+                              void *stream_out, uint64_t out_stride, uint64_t out_off, h2r_stream_t stream);
+int32_t h2r_pow_trace_emit_stream(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *trace, uint64_t elem_stride,
+                                  uint64_t batch, uint32_t flags, void *stream_out, uint64_t out_stride,
+                                  uint64_t out_off, h2r_stream_t stream);
+
 /* ---- per-kernel timing (HIP events recorded on the launch stream around each kernel) -----------
  * h2r_profile_enable(capacity) arms process-wide recording of up to `capacity` launches (0 disarms
  * and frees the events).  h2r_profile_read() synchronises the recorded events of one kernel class
  * and returns their durations in milliseconds, in launch order. */
-enum { H2R_KERNEL_CHAIN = 0, H2R_KERNEL_TRACE = 1, H2R_KERNEL_HIST = 2, H2R_KERNEL_AUX = 3, H2R_KERNEL_COUNT = 4 };
+enum { H2R_KERNEL_CHAIN = 0, H2R_KERNEL_TRACE = 1, H2R_KERNEL_HIST = 2, H2R_KERNEL_AUX = 3, H2R_KERNEL_EMIT = 4, H2R_KERNEL_COUNT = 5 };
 int32_t h2r_profile_enable(uint32_t capacity);
 int32_t h2r_profile_read(uint32_t kernel, float *ms_out, uint32_t max_count, uint32_t *count);
 

@@ -787,3 +787,52 @@ int h2ro_pow_mod_fixed_exp_batch(const h2ro_params *p, const void *x, const void
     for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
     return H2RO_OK;
 }
+
+/* Timing driver for the cpu_baseline leg of bench.py: `nthreads` persistent pthreads, thread t runs elements
+ * t, t + nthreads, ... of the batch, `passes` times over, each writing the element's full op-trace stream into its own
+ * reusable buffer (allocated and touched before the clock starts).  Returns the wall seconds between the start
+ * barrier and the last thread's finish through *seconds, and the number of elements whose status was not OK. */
+#include <time.h>
+typedef struct {
+    const h2ro_params *p; const uint8_t *x, *n; const uint8_t *e_le; size_t e_len;
+    uint64_t batch, passes, stream_bytes; int tid, nthreads; pthread_barrier_t *start; uint64_t failed;
+} time_job;
+static void *time_worker(void *arg) {
+    time_job *j = (time_job *)arg;
+    size_t eb = (size_t)j->p->L * j->p->LB;
+    uint8_t *buf = (uint8_t *)malloc(j->stream_bytes ? j->stream_bytes : 1);
+    uint8_t res[MAXL * 8];
+    if (buf) memset(buf, 0, j->stream_bytes);
+    pthread_barrier_wait(j->start);
+    if (buf)
+        for (uint64_t r = 0; r < j->passes; ++r)
+            for (uint64_t i = (uint64_t)j->tid; i < j->batch; i += (uint64_t)j->nthreads)
+                if (h2ro_pow_mod_fixed_exp(j->p, j->x + i * eb, j->n + i * eb, j->e_le, j->e_len, buf, res) != H2RO_OK) j->failed++;
+    free(buf);
+    return NULL;
+}
+int h2ro_pow_mod_fixed_exp_timed(const h2ro_params *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len,
+                                 uint64_t batch, uint64_t passes, int nthreads, double *seconds, uint64_t *failed) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 1024) nthreads = 1024;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    time_job *jobs = (time_job *)malloc(sizeof(time_job) * (size_t)nthreads);
+    pthread_barrier_t start;
+    if (!th || !jobs || pthread_barrier_init(&start, NULL, (unsigned)nthreads + 1)) { free(th); free(jobs); return H2RO_E_SHAPE; }
+    uint64_t sb = h2ro_pow_fixed_stream_bytes(p, e_le, e_len);
+    for (int t = 0; t < nthreads; ++t) {
+        time_job j = {p, (const uint8_t *)x, (const uint8_t *)n, e_le, e_len, batch, passes, sb, t, nthreads, &start, 0};
+        jobs[t] = j;
+        pthread_create(&th[t], NULL, time_worker, &jobs[t]);
+    }
+    struct timespec t0, t1;
+    pthread_barrier_wait(&start);            /* every thread has its buffer and is ready */
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    uint64_t bad = 0;
+    for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], NULL); bad += jobs[t].failed; }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    if (failed) *failed = bad;
+    pthread_barrier_destroy(&start); free(th); free(jobs);
+    return H2RO_OK;
+}

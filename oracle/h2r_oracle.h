@@ -65,6 +65,10 @@ int h2ro_is_equal_muled(const h2ro_params *p, const uint64_t *a, const uint64_t 
 int h2ro_pow_mod_fixed_exp_batch(const h2ro_params *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len,
                                  uint64_t batch, uint8_t *stream, void *out, uint8_t *status, int nthreads);
 
+/* cpu_baseline timing: persistent threads, per-thread reusable stream buffers, `passes` passes over the batch. */
+int h2ro_pow_mod_fixed_exp_timed(const h2ro_params *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len,
+                                 uint64_t batch, uint64_t passes, int nthreads, double *seconds, uint64_t *failed);
+
 #ifdef __cplusplus
 }
 #endif

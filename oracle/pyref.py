@@ -25,6 +25,12 @@ sub-limb   1                                            1            1
 flag/bit   1                                            1            1
 =========  ==========================================
 
+Besides ``assign_constant`` cells, four input-independent witnesses are NOT emitted: the literal ``1`` the reference
+assigns with ``main_gate.assign_bit(Value::known(F::one()))`` as the start of a running AND / comparison
+(big_integer/chip.rs:326 ``sub``'s ``one``, :761 ``is_zero``, :791 ``is_equal_fresh``, :856 ``is_equal_muled``).
+They are constants in all but name and are treated like the ``assign_constant`` cells around them (SURVEY 8a lists
+:851-856 as the step's constant preamble; its byte counts exclude them).
+
 ``a_b = a[i]-b[i]`` (big_integer/chip.rs:859) is a *field* subtraction in the
 reference; the stream stores it as a WIDE two's-complement signed integer (the
 canonical field element is ``v mod p``).
@@ -35,6 +41,15 @@ from dataclasses import dataclass
 from typing import List, Sequence, Tuple
 
 NUM_LOOKUP_LIMBS = 8  # big_integer/chip.rs:1163
+
+# Moduli of the four fields the reference instantiates its chips with (examples/rsa_example.rs:148, benches/bench.rs:35:
+# bn256::Fr; tests big_integer/chip.rs:1461-1463: bn256::Fq, pasta::Fp, pasta::Fq)
+FIELD_MODULI = {
+    "bn254_fr": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+    "bn254_fq": 21888242871839275222246405745257275088696311157297823662689037894645226208583,
+    "pasta_fp": 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001,
+    "pasta_fq": 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001,
+}
 
 
 def bits_size(v: int) -> int:
@@ -121,6 +136,8 @@ class Params:
 
     w: int
     L: int
+    field_modulus: int = 0   # p of the circuit's field F: when set, a_b (chip.rs:859) is streamed as its canonical
+                             # 32-byte field element (a_b mod p) instead of the WIDE two's-complement integer
 
     def __post_init__(self):
         assert self.w % 8 == 0 and self.L >= 1
@@ -239,7 +256,10 @@ def is_equal_muled(p: Params, a: Sequence[int], b: Sequence[int], st: Stream) ->
     eq_bit = 1
     for i in range(num_limbs):
         a_b = a[i] - b[i]                      # :859 (field sub; signed here)
-        st.put(a_b, p.WB, signed=True)
+        if p.field_modulus:
+            st.put(a_b % p.field_modulus, 32)  # main_gate.sub on field elements: negative -> p - |a_b|
+        else:
+            st.put(a_b, p.WB, signed=True)
         s = a_b + carry[i] + W                  # :860-861
         assert s >= 0
         st.put(s, p.WB)

@@ -141,6 +141,17 @@ class Oracle:
         return out, status, st
 
 
+def pow_mod_fixed_exp_timed(o, x, n, e, passes, nthreads):
+    """cpu_baseline timing leg: (seconds, failed elements) for `passes` passes over the batch on `nthreads` threads."""
+    eb = e_bytes(e)
+    sec, bad = ctypes.c_double(0.0), ctypes.c_uint64(0)
+    x, n = np.ascontiguousarray(x, o.dtype), np.ascontiguousarray(n, o.dtype)
+    rc = lib().h2ro_pow_mod_fixed_exp_timed(ctypes.byref(o.p), _ptr(x), _ptr(n), eb, len(eb), ctypes.c_uint64(x.shape[0]),
+                                            ctypes.c_uint64(passes), int(nthreads), ctypes.byref(sec), ctypes.byref(bad))
+    assert rc == 0
+    return sec.value, bad.value
+
+
 def e_bytes(e):
     """e.to_bytes_le() (reference big_integer/chip.rs:719-720); BigUint zero is one zero byte."""
     return int(e).to_bytes(max(1, (int(e).bit_length() + 7) // 8), "little")

@@ -15,7 +15,7 @@ from layout_ref import unflatten_record
 from oracle_lib import Oracle
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHAPES = [(64, 4), (64, 8), (64, 16), (64, 32), (64, 64), (32, 8), (32, 32), (32, 64), (32, 128)]
+SHAPES = [(64, 4), (64, 8), (64, 16), (64, 32), (64, 64), (32, 8), (32, 32), (32, 64), (32, 128), (64, 48), (64, 24), (32, 96), (64, 12)]
 
 
 def host_ctx(w, L):
@@ -43,6 +43,16 @@ def test_ctx_create_status_codes():
                                    (64, 64 * 3, 0, _lib.H2R_E_UNSUPPORTED), (64, 2048, 9, _lib.H2R_E_SHAPE)]:
         p = H2RParams(w, bits, field, -1)
         assert lib().h2r_ctx_create(ctypes.byref(p), ctypes.byref(ctx)) == want
+    # num_limbs need not be a power of two (chip.rs:1174-1185 only asserts divisibility): RSA-3072 / RSA-1536 / 32-bit limbs
+    for (w, bits) in [(64, 3072), (64, 1536), (64, 768), (32, 3072), (32, 768), (64, 4096), (32, 4096)]:
+        p = H2RParams(w, bits, 0, -1)
+        assert lib().h2r_ctx_create(ctypes.byref(p), ctypes.byref(ctx)) == _lib.H2R_OK, (w, bits)
+        lo = H2RLayout()
+        assert lib().h2r_trace_layout(ctx, ctypes.byref(lo)) == 0 and lo.num_limbs == bits // w and lo.record_stride % 256 == 0
+        lib().h2r_ctx_destroy(ctx)
+    for (w, bits) in [(64, 64 * 6), (32, 32 * 12), (64, 64 * 68), (32, 32 * 136)]:   # not a multiple of 4 / 8 limbs, or too long
+        p = H2RParams(w, bits, 0, -1)
+        assert lib().h2r_ctx_create(ctypes.byref(p), ctypes.byref(ctx)) == _lib.H2R_E_UNSUPPORTED, (w, bits)
     assert lib().h2r_ctx_create(None, ctypes.byref(ctx)) == _lib.H2R_E_NULL
     assert lib().h2r_status_str(_lib.H2R_E_NOT_REDUCED).decode().startswith("quotient")
     c = host_ctx(64, 32)   # host-only ctx refuses device work
@@ -106,6 +116,44 @@ def test_flatten_inverts_documented_layout(w, L):
     assert lib().h2r_trace_flatten(c, rec.ctypes.data, out.ctypes.data) == 0
     assert np.array_equal(out, st)
     lib().h2r_ctx_destroy(c)
+
+
+@pytest.mark.parametrize("field", ["bn254_fr", "bn254_fq", "pasta_fp", "pasta_fq"])
+@pytest.mark.parametrize("w,L", [(64, 32), (32, 128), (64, 12)])
+def test_flatten_field_encoded_a_b(w, L, field):
+    """H2R_STREAM_FIELD_AB: a_b = a[i] - b[i] is a FIELD subtraction in the reference (big_integer/chip.rs:859), so a
+    negative difference is the element p - |x|.  h2r_trace_flatten_ex with the flag == the Python restatement run with
+    the field's modulus (a_b streamed as a 32-byte canonical element); both signs occur in every record."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyref as R
+    ctx = ctypes.c_void_p()
+    p = H2RParams(w, w * L, _lib.FIELDS[field], -1)
+    assert lib().h2r_ctx_create(ctypes.byref(p), ctypes.byref(ctx)) == 0
+    lo = H2RLayout()
+    lib().h2r_trace_layout(ctx, ctypes.byref(lo))
+    rng = random.Random(w * L + len(field))
+    n = rng.getrandbits(w * L) | (1 << (w * L - 1))
+    a, b = rng.randrange(n), rng.randrange(n)
+    o = Oracle(w, L)
+    rc, r, st = o.mul_mod(o.limbs(a), o.limbs(b), o.limbs(n))
+    rec = unflatten_record(st, lo, _lib.PLANES)
+    pf = R.Params(w, L, field_modulus=R.FIELD_MODULI[field])
+    want = R.Stream()
+    R.mul_mod(pf, R.to_limbs(a, L, w), R.to_limbs(b, L, w), R.to_limbs(n, L, w), want)
+    want = np.frombuffer(want.bytes(), dtype=np.uint8)
+    nb = lib().h2r_stream_bytes(ctx, _lib.H2R_STREAM_FIELD_AB)
+    assert nb == len(want) == lo.stream_bytes + lo.num_cols * (32 - lo.wide_bytes)
+    out = np.zeros(nb, dtype=np.uint8)
+    assert lib().h2r_trace_flatten_ex(ctx, rec.ctypes.data, _lib.H2R_STREAM_FIELD_AB, out.ctypes.data) == 0
+    assert np.array_equal(out, want)
+    # both signs were exercised: some a_b has its top bytes equal to p's, some is small
+    plain = R.Stream()
+    R.mul_mod(R.Params(w, L), R.to_limbs(a, L, w), R.to_limbs(b, L, w), R.to_limbs(n, L, w), plain)
+    assert plain.bytes() == bytes(st)
+    out0 = np.zeros(lo.stream_bytes, dtype=np.uint8)
+    assert lib().h2r_trace_flatten_ex(ctx, rec.ctypes.data, 0, out0.ctypes.data) == 0 and np.array_equal(out0, st)
+    lib().h2r_ctx_destroy(ctx)
 
 
 def test_element_strides_avoid_slow_interleave_residues():

@@ -67,7 +67,11 @@ def test_rsa_kats_modpow_public_key(H, golden):
         assert ok == k["is_valid"]
 
 
-@pytest.mark.parametrize("w,L,batch", [(64, 32, 48), (64, 16, 24), (32, 128, 6), (64, 64, 6), (32, 64, 8), (64, 4, 40), (32, 8, 40)])
+@pytest.mark.parametrize("w,L,batch", [(64, 32, 48), (64, 16, 24), (32, 128, 6), (64, 64, 6), (32, 64, 8), (64, 4, 40), (32, 8, 40),
+                                       # num_limbs that are not powers of two (BigIntChip::new only asserts bits_len % limb_width == 0,
+                                       # big_integer/chip.rs:1174-1185): RSA-3072 (L = 48), RSA-1536 (24), 768 bits, odd multiples of 4 / 8
+                                       (64, 48, 24), (64, 24, 24), (64, 12, 40), (64, 20, 16), (64, 60, 8), (32, 96, 8), (32, 24, 16),
+                                       (32, 72, 8), (32, 120, 6)])
 def test_mul_mod_random_parity(H, w, L, batch):
     """mul_mod (reference big_integer/chip.rs:542-629) incl. the reference's own edge identities
     (:3123-3246), even and small moduli (the reference's random n is not forced odd, :1439-1442)."""
@@ -128,7 +132,7 @@ def _adversarial_cases(bits, rng):
     return out
 
 
-@pytest.mark.parametrize("w,L", [(64, 32), (32, 128), (64, 16), (64, 64)])
+@pytest.mark.parametrize("w,L", [(64, 32), (32, 128), (64, 16), (64, 64), (64, 48), (64, 24)])
 def test_mul_mod_adversarial_operands(H, w, L):
     """The chain kernel's ballot carries, DPP neighbour exchange and correction loop on adversarial digits: results
     against Python integers for every triple, full traces against the oracle for a sample.  330 elements keep the
@@ -215,7 +219,8 @@ def test_error_statuses(H):
     assert o.pow_mod(o.limbs(5), np.array([32], np.uint64), 5, o.limbs(n_ok))[0] == 1   # the oracle refuses it too (H2RO_E_SHAPE)
 
 
-@pytest.mark.parametrize("w,L,batch,e", [(64, 32, 12, 65537), (64, 16, 8, 65537), (32, 128, 3, 65537), (64, 32, 4, 0b1011011), (64, 32, 3, 1), (64, 64, 2, 17)])
+@pytest.mark.parametrize("w,L,batch,e", [(64, 32, 12, 65537), (64, 16, 8, 65537), (32, 128, 3, 65537), (64, 32, 4, 0b1011011), (64, 32, 3, 1), (64, 64, 2, 17),
+                                         (64, 48, 6, 65537), (64, 24, 8, 65537), (32, 96, 3, 65537), (64, 36, 4, 0b1011011)])
 def test_pow_mod_fixed_exp_parity(H, w, L, batch, e):
     """pow_mod_fixed_exp (reference big_integer/chip.rs:710-742; tests :2314-2353 use a 7-bit e)."""
     chip = H.BigIntChip(w, w * L)
@@ -323,6 +328,73 @@ def test_pow_mod_var_2048_bit_exponent(H):
         assert out[i] == pow(X[i], sum(v << (64 * k) for k, v in enumerate(E[i])), N[i])
     rc, oo, ost = o.pow_mod(o.limbs(X[0]), np.array(E[0], dtype=np.uint64), 64, o.limbs(N[0]))
     assert rc == 0 and np.array_equal(ost, res.trace.flatten(0))
+
+
+@pytest.mark.parametrize("w,L,batch", [(64, 32, 9), (32, 128, 3), (64, 64, 3), (64, 48, 4), (64, 12, 11), (64, 4, 20), (32, 8, 20), (32, 96, 3),
+                                       (64, 16, 7)])
+@pytest.mark.parametrize("flags", [0, 1])
+def test_device_emit_stream_mul_mod(H, w, L, batch, flags):
+    """h2r_trace_emit_stream: the flat stream of every record, produced on the device, is byte-equal to the host walk
+    (h2r_trace_flatten_ex) and -- for flags = 0 -- to the oracle; with H2R_STREAM_FIELD_AB to the Python restatement run
+    with the field modulus (a_b = p - |x| when negative, big_integer/chip.rs:859).  Unaligned output strides included."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref as R
+    field = ["bn254_fr", "pasta_fq"][(w + L) % 2]
+    chip = H.BigIntChip(w, w * L, field=field)
+    o = Oracle(w, L)
+    rng = random.Random(5 * w + L + flags)
+    N = [rand_modulus(rng, w * L, odd=(i % 4 != 1)) for i in range(batch)]
+    A = [rng.randrange(n) for n in N]
+    B = [rng.randrange(n) for n in N]
+    res = chip.mul_mod(chip.assign_integer(A), chip.assign_integer(B), chip.assign_integer(N))
+    sb = res.trace.stream_bytes_ex(flags)
+    for stride in (sb, sb + 7, (sb + 255) // 256 * 256):   # odd strides: every record starts at another byte phase
+        out = torch.full((batch, stride), 0xEE, dtype=torch.uint8, device="cuda")
+        res.trace.emit_stream(flags, out=out, out_stride=stride)
+        torch.cuda.synchronize()
+        host = out.cpu().numpy()
+        assert (host[:, sb:] == 0xEE).all()       # nothing written past an element's stream
+        for i in range(batch):
+            want = res.trace.flatten(i, flags)
+            if not np.array_equal(host[i, :sb], want):
+                pytest.fail("w=%d L=%d flags=%d stride=%d elem %d: first mismatch at byte %d of %d" %
+                            (w, L, flags, stride, i, int(np.nonzero(host[i, :sb] != want)[0][0]), sb))
+    for i in range(min(batch, 3)):
+        st = R.Stream()
+        R.mul_mod(R.Params(w, L, field_modulus=R.FIELD_MODULI[field] if flags else 0), R.to_limbs(A[i], L, w), R.to_limbs(B[i], L, w),
+                  R.to_limbs(N[i], L, w), st)
+        assert bytes(host[i, :sb]) == st.bytes()
+
+
+@pytest.mark.parametrize("w,L,e,var_bits", [(64, 32, 65537, 0), (64, 16, 0b1011011, 0), (32, 128, 17, 0), (64, 32, 0, 5), (64, 8, 0, 13),
+                                            (64, 24, 65537, 0), (64, 32, 1, 0)])
+def test_device_emit_stream_pow(H, w, L, e, var_bits):
+    """h2r_pow_trace_emit_stream == h2r_pow_trace_flatten_ex for every element: fixed exponents (records back to back,
+    then the result limbs) and variable exponents (e bits, then per bit mul_mod record / selected limbs / square record)."""
+    chip = H.BigIntChip(w, w * L)
+    rng = random.Random(w + L + e + var_bits)
+    batch = 5
+    N = [rand_modulus(rng, w * L) for _ in range(batch)]
+    X = [rng.randrange(n) for n in N]
+    if var_bits:
+        E = np.array([[rng.getrandbits(var_bits)] for _ in range(batch)], dtype=chip.np_dtype)
+        e_dev = H.AssignedInteger(torch.from_numpy(E.view(np.int64 if w == 64 else np.int32)).cuda().contiguous(), w)
+        res = chip.pow_mod(chip.assign_integer(X), e_dev, chip.assign_integer(N), var_bits)
+    else:
+        res = chip.pow_mod_fixed_exp(chip.assign_integer(X), e, chip.assign_integer(N))
+    torch.cuda.synchronize()
+    assert not res.status.cpu().numpy().any()
+    for flags in (0, 1):
+        sb = res.trace.stream_bytes_ex(flags)
+        out = res.trace.emit_stream(flags, out_stride=sb + 3)
+        torch.cuda.synchronize()
+        host = out.cpu().numpy()
+        for i in range(batch):
+            want = res.trace.flatten(i, flags)
+            if not np.array_equal(host[i, :sb], want):
+                pytest.fail("elem %d flags %d: first mismatch at byte %d of %d" % (i, flags, int(np.nonzero(host[i, :sb] != want)[0][0]), sb))
 
 
 def test_shared_modulus(H):
@@ -440,6 +512,9 @@ def test_config2_full_batch_properties(H, golden):
     xs, nsl = chip.assign_integer(X).limbs_host(), chip.assign_integer(N).limbs_host()
     pl, es = res.trace.pow_layout, res.trace.elem_stride
     got = np.zeros(pl.stream_bytes, dtype=np.uint8)
+    dev_stream = res.trace.emit_stream()      # the device-side flatten of the whole batch (h2r_pow_trace_emit_stream)
+    torch.cuda.synchronize()
+    assert dev_stream.shape == (1024, pl.stream_bytes)
     for lo in range(0, 1024, 128):
         oout, ostat, ost = o.pow_mod_fixed_exp_batch(xs[lo:lo + 128], nsl[lo:lo + 128], 65537, nthreads=min(64, os.cpu_count() or 1),
                                                      want_stream=True)
@@ -449,6 +524,10 @@ def test_config2_full_batch_properties(H, golden):
             check(lib().h2r_pow_trace_flatten(chip._ctx, ctypes.byref(pl), host[k * es:(k + 1) * es].ctypes.data, got.ctypes.data), "flatten")
             if not np.array_equal(got, ost[k]):
                 pytest.fail("element %d: first stream mismatch at byte %d" % (lo + k, int(np.nonzero(got != ost[k])[0][0])))
+        demit = dev_stream[lo:lo + 128].cpu().numpy()
+        if not np.array_equal(demit, ost):
+            bad = np.argwhere(demit != ost)[0]
+            pytest.fail("device-side stream: element %d differs at byte %d" % (lo + int(bad[0]), int(bad[1])))
     # chain identity on the q/r planes of every record of 64 more elements
     for i in rng.sample(range(1024), 64):
         acc, cur, t = 1, X[i], 0

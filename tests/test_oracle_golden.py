@@ -141,7 +141,7 @@ def test_rsa4096_w32_golden(golden):
     assert len(st) == c["stream_bytes"] == 19 * 563052 + 512 and sha(st) == c["stream_sha256"]
 
 
-@pytest.mark.parametrize("w,L", [(64, 4), (64, 16), (64, 32), (32, 8), (32, 64), (64, 64)])
+@pytest.mark.parametrize("w,L", [(64, 4), (64, 16), (64, 32), (32, 8), (32, 64), (64, 64), (64, 48), (64, 24), (64, 12), (32, 96), (32, 24)])
 def test_c_oracle_equals_python_restatement_random(w, L):
     """Two independent restatements (C: schoolbook + Knuth D; Python: built-in big ints) agree byte for byte.
     Like the reference's random tests (big_integer/chip.rs:1439-1444) n has its top bit set and is not
