@@ -177,6 +177,27 @@ class BatchResult:
     trace: Optional[Trace]
     status: torch.Tensor        # uint8 [batch], H2R_* per element
     in_field: Optional[InFieldTrace] = None   # modpow_public_key only: the assert_in_field witness
+    workspace: Optional[torch.Tensor] = None   # pow calls: the operands buffer of every mul_mod (kept for audit())
+    inputs: Optional[tuple] = None             # (kind, a/x, b, n, e bytes or None) the call was made with
+
+    def audit(self):
+        """In-place device check of every record of the trace (h2r_mul_mod_trace_check / h2r_pow_trace_check):
+        returns (bad, first_bad) uint32 tensors [batch]; bad == 0 everywhere for a valid witness."""
+        chip = self.trace.chip
+        batch, dev = self.trace.batch, self.trace.buf.device
+        bad = torch.empty(batch, dtype=torch.int32, device=dev)
+        first = torch.empty(batch, dtype=torch.int32, device=dev)
+        kind, a, b, n, eb = self.inputs
+        flags = chip._flags(n, batch)
+        if kind == "mul_mod":
+            check(lib().h2r_mul_mod_trace_check(chip._ctx, a.data_ptr(), b.data_ptr(), n.data_ptr(), flags, self.trace.buf.data_ptr(), batch,
+                                                self.status.data_ptr(), bad.data_ptr(), first.data_ptr(), chip._stream()), "h2r_mul_mod_trace_check")
+        else:
+            check(lib().h2r_pow_trace_check(chip._ctx, ctypes.byref(self.trace.pow_layout), a.data_ptr(), n.data_ptr(), eb,
+                                            len(eb) if eb is not None else 0, flags, self.trace.buf.data_ptr(), self.trace.elem_stride,
+                                            self.workspace.data_ptr(), batch, self.status.data_ptr(), bad.data_ptr(), first.data_ptr(),
+                                            chip._stream()), "h2r_pow_trace_check")
+        return bad, first
 
     def flatten(self, elem: int) -> np.ndarray:
         """The element's witness in the reference's assignment order (modpow_public_key: in-field stream, then pow)."""
@@ -265,7 +286,8 @@ class BigIntChip:
         check(lib().h2r_mul_mod_batch(self._ctx, a.data_ptr(), b.data_ptr(), n.data_ptr(), batch, self._flags(n, batch),
                                       trace.data_ptr() if want_trace else None, r.data_ptr(), status.data_ptr(), None,
                                       self._stream()), "mul_mod")
-        return BatchResult(AssignedInteger(r, self.limb_width), Trace(self, trace, batch, None) if want_trace else None, status)
+        return BatchResult(AssignedInteger(r, self.limb_width), Trace(self, trace, batch, None) if want_trace else None, status,
+                           inputs=("mul_mod", a, b, n, None))
 
     def square_mod(self, a: AssignedInteger, n: AssignedInteger, want_trace: bool = True) -> BatchResult:
         """big_integer/chip.rs:642-649."""
@@ -299,6 +321,8 @@ class BigIntChip:
         out = self._new_limbs(batch) if out is None else out
         status = torch.zeros(batch, dtype=torch.uint8, device=dev) if status is None else status
         tp = trace_buf.data_ptr() if want_trace else None
+        if workspace is None and want_trace:   # kept with the result: audit() reads every mul_mod's operands from it
+            workspace = torch.empty(self.workspace_bytes(batch, pl.num_mul_mods), dtype=torch.uint8, device=dev)
         wp = workspace.data_ptr() if workspace is not None else None
         in_field = None
         if check_in_field:
@@ -309,7 +333,8 @@ class BigIntChip:
         else:
             check(lib().h2r_pow_mod_fixed_exp_batch(self._ctx, a.data_ptr(), n.data_ptr(), eb, len(eb), batch, self._flags(n, batch), tp,
                                                     out.data_ptr(), status.data_ptr(), wp, self._stream()), "pow_mod_fixed_exp")
-        return BatchResult(AssignedInteger(out, self.limb_width), Trace(self, trace_buf, batch, pl) if want_trace else None, status, in_field)
+        return BatchResult(AssignedInteger(out, self.limb_width), Trace(self, trace_buf, batch, pl) if want_trace else None, status, in_field,
+                           workspace, ("pow_fixed", a, None, n, eb))
 
     def _in_field_trace(self, batch, buf=None) -> "InFieldTrace":
         es, sb = self.in_field_layout()
@@ -330,17 +355,20 @@ class BigIntChip:
         out = self._new_limbs(batch)
         status = torch.zeros(batch, dtype=torch.uint8, device=dev)
         tp = trace.data_ptr() if want_trace else None
+        ws = torch.empty(self.workspace_bytes(batch, pl.num_mul_mods), dtype=torch.uint8, device=dev) if want_trace else None
+        wp = ws.data_ptr() if ws is not None else None
         in_field = None
         if check_in_field:
             in_field = self._in_field_trace(batch) if want_trace else None
             check(lib().h2r_modpow_public_key_var_batch(self._ctx, a.data_ptr(), e.data_ptr(), e.num_limbs(), exp_limb_bits, n.data_ptr(),
                                                         batch, self._flags(n, batch), tp,
                                                         in_field.buf.data_ptr() if in_field is not None else None, out.data_ptr(),
-                                                        status.data_ptr(), None, self._stream()), "modpow_public_key")
+                                                        status.data_ptr(), wp, self._stream()), "modpow_public_key")
         else:
             check(lib().h2r_pow_mod_batch(self._ctx, a.data_ptr(), e.data_ptr(), e.num_limbs(), exp_limb_bits, n.data_ptr(), batch,
-                                          self._flags(n, batch), tp, out.data_ptr(), status.data_ptr(), None, self._stream()), "pow_mod")
-        return BatchResult(AssignedInteger(out, self.limb_width), Trace(self, trace, batch, pl) if want_trace else None, status, in_field)
+                                          self._flags(n, batch), tp, out.data_ptr(), status.data_ptr(), wp, self._stream()), "pow_mod")
+        return BatchResult(AssignedInteger(out, self.limb_width), Trace(self, trace, batch, pl) if want_trace else None, status, in_field,
+                           ws, ("pow_var", a, None, n, None))
 
     # ---- the Fresh-integer family (add / sub / add_mod / sub_mod / comparisons) -----------------------
     def _fresh_op(self, name: str, a: AssignedInteger, b: Optional[AssignedInteger], n: Optional[AssignedInteger]) -> "FreshResult":

@@ -1114,11 +1114,18 @@ int32_t build_emit_segments(const h2r_layout &lo, u32 flags, EmitArgs &ea) {
             off += bytes; c0 = c1;
         }
     }
+    if (!push(EMIT_EQB, 0, 0, off, (u64)L * WB)) return H2R_E_UNSUPPORTED;
+    off += (u64)L * WB;
     const u64 ab = (flags & H2R_STREAM_FIELD_AB) ? 32 : WB;
     const u64 per_col = ab + 4ull * WB + 2ull * lo.carry_bytes + 4ull * lo.limb_bytes + 4;
-    const u64 eq = (u64)L * WB + (u64)C * per_col + (u64)(C - 1) * (lo.carry_bytes + lo.carry_nsub);
-    if (!push(EMIT_EQ, 0, 0, off, eq)) return H2R_E_UNSUPPORTED;
-    off += eq;
+    const u64 per_col_ra = per_col + lo.carry_bytes + lo.carry_nsub;   // every column but the last range-assigns its carry
+    for (u32 c0 = 0; c0 < C;) {
+        u32 c1 = c0 + (u32)(EMIT_SEG_CAP / per_col_ra);
+        if (c1 > C) c1 = C;
+        const u64 bytes = (u64)(c1 - c0) * per_col_ra - (c1 == C ? lo.carry_bytes + lo.carry_nsub : 0);
+        if (c1 == c0 || !push(EMIT_STEPS, c0, c1, off, bytes)) return H2R_E_UNSUPPORTED;
+        off += bytes; c0 = c1;
+    }
     ea.nseg = n; ea.rec_bytes = off;
     return H2R_OK;
 }
@@ -1177,6 +1184,81 @@ int32_t h2r_pow_trace_emit_stream(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
     ea.off_result = pl->off_result; ea.has_result = 1;
     if (ea.var && ea.T != 2 * ea.nbits) return H2R_E_SHAPE;
     return launch_emit(ctx, ea, flags, static_cast<hipStream_t>(stream));
+}
+
+// ---- in-place audit ----------------------------------------------------------------------------------------
+namespace {
+int32_t launch_check(const h2r_ctx *ctx, CheckArgs &ca, const uint8_t *status, uint32_t *bad_out, uint32_t *first_bad_out,
+                     u64 n_elems, hipStream_t st) {
+    const h2r_layout &lo = ctx->layout;
+    if (lo.num_limbs > 128) return H2R_E_UNSUPPORTED;
+    for (int p = 0; p < H2R_PL_COUNT; ++p) ca.off[p] = lo.plane_off[p];
+    ca.wm[0] = ctx->word_max.v[0]; ca.wm[1] = ctx->word_max.v[1]; ca.wm[2] = ctx->word_max.v[2];
+    ca.L = lo.num_limbs; ca.carry_bits = lo.carry_bits; ca.carry_sub_bits = lo.carry_sub_bits; ca.carry_nsub = lo.carry_nsub;
+    ca.carry_sub_stride = lo.carry_sub_stride; ca.record_stride = lo.record_stride;
+    ca.status = status; ca.bad = bad_out; ca.first_bad = first_bad_out;
+    HIP_TRY(hipMemsetAsync(bad_out, 0, n_elems * sizeof(uint32_t), st));
+    if (first_bad_out) HIP_TRY(hipMemsetAsync(first_bad_out, 0, n_elems * sizeof(uint32_t), st));
+    if (ca.n_items == 0) return H2R_OK;
+    if (ca.n_items >= (1ull << 31)) return H2R_E_UNSUPPORTED;
+    if (lo.limb_width == 64) hipLaunchKernelGGL((check_kernel<64>), dim3((unsigned)ca.n_items), dim3(256), 0, st, ca);
+    else hipLaunchKernelGGL((check_kernel<32>), dim3((unsigned)ca.n_items), dim3(256), 0, st, ca);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
+}  // namespace
+
+int32_t h2r_mul_mod_trace_check(const h2r_ctx *ctx, const void *a, const void *b, const void *n, uint32_t flags, const void *trace,
+                                uint64_t batch, const uint8_t *status, uint32_t *bad_out, uint32_t *first_bad_out, h2r_stream_t stream) {
+    if (!ctx || !a || !b || !n || !trace || !bad_out) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    H2R_ON_DEVICE(ctx->params.device);
+    CheckArgs ca;
+    std::memset(&ca, 0, sizeof ca);
+    ca.opA = a; ca.opB = b; ca.op_stride = ctx->L;
+    ca.n = n; ca.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
+    ca.trace = static_cast<const u8 *>(trace); ca.elem_stride = ctx->layout.record_stride; ca.off_records = 0; ca.T = 1; ca.n_items = batch;
+    return launch_check(ctx, ca, status, bad_out, first_bad_out, batch, static_cast<hipStream_t>(stream));
+}
+
+int32_t h2r_pow_trace_check(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *x, const void *n, const uint8_t *e_le,
+                            size_t e_len, uint32_t flags, const void *trace, uint64_t elem_stride, const void *workspace,
+                            uint64_t batch, const uint8_t *status, uint32_t *bad_out, uint32_t *first_bad_out, h2r_stream_t stream) {
+    if (!ctx || !pl || !x || !n || !trace || !workspace || !bad_out) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    const bool var = pl->off_e_bits != UINT64_MAX;
+    if (!var && !e_le && e_len) return H2R_E_NULL;
+    LinkArgs la;
+    std::memset(&la, 0, sizeof la);
+    if (!var) {
+        u32 T = 0;
+        const int32_t rc = exp_to_bits(e_le, e_len, &la.e, &T);
+        if (rc) return rc;
+        if (T != pl->num_mul_mods) return H2R_E_SHAPE;
+    }
+    H2R_ON_DEVICE(ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const h2r_layout &lo = ctx->layout;
+    const u64 lb = lo.limb_bytes;
+    const u8 *ws = reinterpret_cast<const u8 *>(round_up(reinterpret_cast<u64>(workspace), 256));   // as run_path carves it
+    CheckArgs ca;
+    std::memset(&ca, 0, sizeof ca);
+    ca.opA = ws; ca.opB = ws + ctx->L * lb; ca.opQ = ws + 2 * ctx->L * lb; ca.opR = ws + 3 * ctx->L * lb; ca.op_stride = 4ull * ctx->L;
+    ca.n = n; ca.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
+    ca.trace = static_cast<const u8 *>(trace); ca.elem_stride = elem_stride ? elem_stride : pl->elem_stride;
+    ca.off_records = pl->off_records; ca.T = pl->num_mul_mods ? pl->num_mul_mods : 1;
+    ca.n_items = pl->num_mul_mods ? batch * pl->num_mul_mods : 0;
+    int32_t rc = launch_check(ctx, ca, status, bad_out, first_bad_out, batch, st);
+    if (rc || batch == 0) return rc;
+    la.x = x; la.ops = ws; la.op_stride = 4ull * ctx->L; la.L = ctx->L; la.T = pl->num_mul_mods; la.var = var ? 1u : 0u;
+    la.nbits = var ? pl->num_exp_bits : la.e.nbits;
+    la.status = status; la.trace = ca.trace; la.elem_stride = ca.elem_stride;
+    la.off_e_bits = pl->off_e_bits; la.off_selected = pl->off_selected; la.selected_stride = pl->selected_stride; la.off_result = pl->off_result;
+    la.bad = bad_out; la.first_bad = first_bad_out;
+    if (lo.limb_width == 64) hipLaunchKernelGGL((link_kernel<64>), dim3((unsigned)batch), dim3(64), 0, st, la);
+    else hipLaunchKernelGGL((link_kernel<32>), dim3((unsigned)batch), dim3(64), 0, st, la);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
 }
 
 // ---- BigIntInstructions::mul / square, is_equal_muled, refresh -----------------

@@ -1789,10 +1789,10 @@ __global__ __launch_bounds__(256) void perm_kernel(PermArgs p) {
 //   streams are byte-packed, so a segment starts at an arbitrary byte of the output and the LDS image is funnel-shifted
 //   (v_alignbyte) on its way out.  Bound: HBM (reads one record, writes one stream: 2 x 64 KB per RSA-2048 mul_mod).
 // ================================================================================================
-constexpr u32 EMIT_SEG_CAP = 32 * 1024;   // bytes of stream staged in LDS at a time (4 workgroups per CU)
+constexpr u32 EMIT_SEG_CAP = 24 * 1024;   // bytes of stream staged in LDS at a time (6 workgroups per CU; one RSA-2048 accumulator plane)
 constexpr int EMIT_MAX_SEGS = 40;
-enum { EMIT_QR = 0, EMIT_ACC_AB = 1, EMIT_ACC_QN = 2, EMIT_EQ = 3 };
-struct EmitSeg { u32 kind, c0, c1, bytes; u64 off; };   // columns [c0, c1) for the accumulator kinds; off/bytes within the record's stream
+enum { EMIT_QR = 0, EMIT_ACC_AB = 1, EMIT_ACC_QN = 2, EMIT_EQB = 3, EMIT_STEPS = 4 };
+struct EmitSeg { u32 kind, c0, c1, bytes; u64 off; };   // columns [c0, c1) (accumulator and step kinds); off/bytes within the record's stream
 
 // entries of the reference's column order before column i (column c has min(c + 1, 2L - 1 - c) accumulators)
 __host__ __device__ inline u32 emit_colstart(u32 i, u32 L) {
@@ -1862,10 +1862,19 @@ __global__ __launch_bounds__(256) void emit_kernel(EmitArgs a) {
             const u8 *plo = rec + a.off[qn ? H2R_PL_QN_LO : H2R_PL_AB_LO];
             const u8 *phi = rec + a.off[qn ? H2R_PL_QN_HI : H2R_PL_AB_HI];
             const u32 e0 = emit_colstart(S.c0, L);
-            for (u32 sidx = tid; sidx < L * L; sidx += 256) {
-                const u32 j = sidx / L, im = sidx - j * L;
-                const u32 i = im >= j ? im : im + L;            // the column this accumulator belongs to (i % L == im)
-                if (i < S.c0 || i >= S.c1) continue;
+            // source rows j that hold accumulators of columns [c0, c1), and the rectangle (j, i) that covers them; a
+            // whole plane is walked as its L x L source entries instead (no holes)
+            const bool whole = S.c0 == 0 && S.c1 == C;
+            const u32 jlo = S.c0 >= L ? S.c0 - L + 1 : 0, jhi = S.c1 - 1 < L - 1 ? S.c1 - 1 : L - 1, cw = S.c1 - S.c0;
+            const u32 n_idx = whole ? L * L : (jhi - jlo + 1) * cw;
+            for (u32 sidx = tid; sidx < n_idx; sidx += 256) {
+                u32 j, i, im;
+                if (whole) { j = sidx / L; im = sidx - j * L; i = im >= j ? im : im + L; }   // column of entry (j, i % L == im)
+                else {
+                    j = jlo + sidx / cw; i = S.c0 + sidx % cw;
+                    if (i < j || i > j + L - 1) continue;       // a[j] * b[i - j] exists for 0 <= i - j < L
+                    im = i >= L ? i - L : i;
+                }
                 const u32 jmin = i >= L ? i - L + 1 : 0;
                 const u32 pos = (emit_colstart(i, L) - e0 + (j - jmin)) * WB;
                 if constexpr (LW == 64) {   // interleaved rows: two steps per group, shared HI row (h2r_layout)
@@ -1879,15 +1888,16 @@ __global__ __launch_bounds__(256) void emit_kernel(EmitArgs a) {
                     d[0] = lo.x; d[1] = lo.y;
                 }
             }
-        } else {   // T5 eq_b (chip.rs:617) then T6, the is_equal_muled steps (chip.rs:857-893)
+        } else if (S.kind == EMIT_EQB) {   // T5 eq_b (chip.rs:617)
             for (u32 i = tid; i < L; i += 256) {
                 const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(rec + a.off[H2R_PL_EQB_LO] + (u64)i * 16);
                 u64 *d = reinterpret_cast<u64 *>(lds + i * WB);
                 d[0] = lo.x; d[1] = lo.y;
                 if constexpr (LW == 64) d[2] = *reinterpret_cast<const u64 *>(rec + a.off[H2R_PL_EQB_HI] + (u64)i * 8);
             }
-            for (u32 c = tid; c < C; c += 256) {
-                u32 pos = L * WB + c * per_col_ra;
+        } else {   // T6: the is_equal_muled steps of columns [c0, c1) (chip.rs:857-893); every column but C-1 has the range assign
+            for (u32 c = S.c0 + tid; c < S.c1; c += 256) {
+                u32 pos = (c - S.c0) * per_col_ra;
                 auto wide = [&](int pl_lo, u32 nb) {   // WIDE value: 16-byte LO entry + (64-bit limbs) 8-byte HI entry
                     const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(rec + a.off[pl_lo] + (u64)c * 16);
                     put_bytes(pos, lo.x, 8); put_bytes(pos + 8, lo.y, 8);
@@ -1956,6 +1966,246 @@ __global__ __launch_bounds__(256) void emit_kernel(EmitArgs a) {
         if (tid < S.bytes - done) g[done + tid] = lds[done + tid];
         __syncthreads();   // the image is reused by the next segment
     }
+}
+
+// ================================================================================================
+// K8: in-place witness checker (test / audit instrument, not on the product path)
+//   Verifies SURVEY Appendix C invariants 1-4 on EVERY record of a batch where it lies in HBM -- traces of 10-50 GB
+//   cannot be walked on the host.  Deliberately NOT the producer's algorithm: every relation is checked pointwise from
+//   the stored values (each accumulator against its predecessor plus one product; each carry step against the stored
+//   previous carry), so nothing here shares the record kernel's scans, ballots or index maps beyond the documented
+//   plane layout.  One workgroup per record; bad[elem] counts violated relations, first_bad[elem] keeps one (t, code).
+//     code 1  q/r limb vs the operands buffer, sub-limb recomposition (chip.rs:588-599)
+//          2  accumulator chain: acc(j, i) = acc(j-1, i) + a[j] * b[i-j], first of a column = the product (chip.rs:400-412)
+//          3  eq_b[i] = qn[i] + r[i] (chip.rs:617)
+//          4  a_b = ab[i] - eq_b[i] (chip.rs:859)         5  sum = a_b + carry[i] + word_max (chip.rs:860-861)
+//          6  div_mod of sum: carry, c, nq, a - nq (chip.rs:864, 1323-1349)
+//          7  accumulated_extra chain and its div_mod (chip.rs:869-875)
+//          8  flags: cs_acc_eq, range_eq / final_carry_eq and the running eq_bit (chip.rs:873-892)
+//          9  range-assigned carry: duplicate, sub-limbs, width (chip.rs:877-885)
+//         10  r < n (chip.rs:567)                          11  final eq_bit != 1 (assert_equal_muled, chip.rs:1062)
+// ================================================================================================
+struct CheckArgs {
+    const void *opA, *opB, *opQ, *opR; u64 op_stride;   // limbs of item k at [k * op_stride, ...): the chain kernel's operands buffer
+    const void *n; u64 n_stride;
+    const u8 *status;                                   // [elem]; nonzero => element skipped
+    const u8 *trace; u64 elem_stride, off_records, record_stride; u32 T; u64 n_items;
+    u64 off[H2R_PL_COUNT]; u64 wm[3];
+    u32 L, carry_bits, carry_sub_bits, carry_nsub, carry_sub_stride;
+    u32 *bad; u32 *first_bad;
+};
+
+struct U192 {
+    u64 w[3];
+    __device__ __forceinline__ static U192 make(u64 a, u64 b, u64 c) { U192 r; r.w[0] = a; r.w[1] = b; r.w[2] = c; return r; }
+    __device__ __forceinline__ U192 operator+(const U192 &o) const {
+        U192 r; const u64 s0 = w[0] + o.w[0]; const u64 c0 = s0 < w[0];
+        const u64 s1 = w[1] + o.w[1]; const u64 c1 = s1 < w[1]; const u64 s1b = s1 + c0; const u64 c1b = s1b < s1;
+        r.w[0] = s0; r.w[1] = s1b; r.w[2] = w[2] + o.w[2] + (c1 | c1b); return r;
+    }
+    __device__ __forceinline__ U192 operator-(const U192 &o) const {
+        U192 r; const u64 d0 = w[0] - o.w[0]; const u64 b0 = w[0] < o.w[0];
+        const u64 d1 = w[1] - o.w[1]; const u64 b1 = w[1] < o.w[1]; const u64 d1b = d1 - b0; const u64 b1b = d1 < b0;
+        r.w[0] = d0; r.w[1] = d1b; r.w[2] = w[2] - o.w[2] - (b1 | b1b); return r;
+    }
+    __device__ __forceinline__ bool operator==(const U192 &o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2]; }
+    __device__ __forceinline__ U192 shr(u32 s) const {   // s = 32 or 64
+        if (s == 64) return make(w[1], w[2], 0);
+        return make((w[0] >> 32) | (w[1] << 32), (w[1] >> 32) | (w[2] << 32), w[2] >> 32);
+    }
+    __device__ __forceinline__ U192 shl(u32 s) const {
+        if (s == 64) return make(0, w[0], w[1]);
+        return make(w[0] << 32, (w[0] >> 32) | (w[1] << 32), (w[1] >> 32) | (w[2] << 32));
+    }
+};
+
+template <int LW>
+__global__ __launch_bounds__(256) void check_kernel(CheckArgs a) {
+    using limb_t = typename LimbT<LW>::type;
+    constexpr u32 LB = LW / 8, CB = LW == 64 ? 16 : 8;
+    constexpr u64 LMASK = LW == 64 ? ~0ull : 0xffffffffull;
+    __shared__ u32 s_bad, s_code;
+    __shared__ u64 sa[128], sb_[128], sq[128], sn[128], sr[128];
+    const u32 tid = threadIdx.x;
+    const u32 item = blockIdx.x;
+    const u32 elem = item / a.T, t = item - elem * a.T;
+    if (a.status && a.status[elem]) return;
+    if (tid == 0) { s_bad = 0; s_code = 0; }
+    const u32 L = a.L, C = 2 * L - 1;
+    const u8 *rec = a.trace + (u64)elem * a.elem_stride + a.off_records + (u64)t * a.record_stride;
+    u32 nbad = 0, code = 0;
+    auto fail = [&](u32 c) { ++nbad; if (!code) code = c; };
+    // sign-extending reader of a WIDE value stored as 16-byte LO (+ 8-byte HI for 64-bit limbs)
+    auto rd_wide = [&](int pl_lo, u32 idx) -> U192 {
+        const u64 *lo = reinterpret_cast<const u64 *>(rec + a.off[pl_lo] + (u64)idx * 16);
+        if constexpr (LW == 64) return U192::make(lo[0], lo[1], *reinterpret_cast<const u64 *>(rec + a.off[pl_lo + 1] + (u64)idx * 8));
+        else return U192::make(lo[0], lo[1], (u64)((i64)lo[1] >> 63));
+    };
+    auto rd_limb = [&](int pl, u32 idx) -> u64 {
+        if constexpr (LW == 64) return *reinterpret_cast<const u64 *>(rec + a.off[pl] + (u64)idx * 8);
+        else return *reinterpret_cast<const u32 *>(rec + a.off[pl] + (u64)idx * 4);
+    };
+    auto rd_carry = [&](int pl, u32 idx) -> U192 {
+        const u64 *p = reinterpret_cast<const u64 *>(rec + a.off[pl] + (u64)idx * CB);
+        if constexpr (LW == 64) return U192::make(p[0], p[1], 0); else return U192::make(p[0], 0, 0);
+    };
+    // accumulator entry (j, i % L) per the documented addressing (include/h2r.h)
+    auto rd_acc = [&](bool qn, u32 j, u32 im) -> U192 {
+        if constexpr (LW == 64) {
+            const u64 *lo = reinterpret_cast<const u64 *>(rec + a.off[qn ? H2R_PL_QN_LO : H2R_PL_AB_LO] + (u64)(j >> 1) * (3ull * 2 * L * 16) + (u64)(j & 1) * (2ull * L * 16) + (u64)im * 16);
+            const u64 hi = *reinterpret_cast<const u64 *>(rec + a.off[qn ? H2R_PL_QN_HI : H2R_PL_AB_HI] + (u64)(j >> 1) * (3ull * 2 * L * 16) + (u64)im * 16 + (j & 1) * 8);
+            return U192::make(lo[0], lo[1], hi);
+        } else {
+            const u64 *lo = reinterpret_cast<const u64 *>(rec + a.off[qn ? H2R_PL_QN_LO : H2R_PL_AB_LO] + (u64)j * ((u64)L * 16) + (u64)im * 16);
+            return U192::make(lo[0], lo[1], 0);
+        }
+    };
+    // ---- operands; q, r and their sub-limbs ------------------------------------------------------------------
+    for (u32 k = tid; k < L; k += 256) {
+        const u64 ib = (u64)item * a.op_stride + k;
+        sa[k] = reinterpret_cast<const limb_t *>(a.opA)[ib]; sb_[k] = reinterpret_cast<const limb_t *>(a.opB)[ib];
+        sn[k] = reinterpret_cast<const limb_t *>(a.n)[(u64)elem * a.n_stride + k];
+        const u64 q = rd_limb(H2R_PL_Q, k), r = rd_limb(H2R_PL_R, k);
+        sq[k] = q; sr[k] = r;
+        if (a.opQ && (q != (u64) reinterpret_cast<const limb_t *>(a.opQ)[ib] || r != (u64) reinterpret_cast<const limb_t *>(a.opR)[ib])) fail(1);
+        for (int which = 0; which < 2; ++which) {   // RangeChip::assign(v, w/8, w): 8 sub-limbs of w/8 bits
+            const u64 sub = *reinterpret_cast<const u64 *>(rec + a.off[which ? H2R_PL_R_SUB : H2R_PL_Q_SUB] + (u64)k * 8);
+            u64 v = 0; bool wide = false;
+            for (u32 s8 = 0; s8 < 8; ++s8) { const u64 sv = (sub >> (8 * s8)) & 0xff; wide = wide || (sv >> (LW / 8)) != 0; v |= sv << (s8 * (LW / 8)); }
+            if (wide || v != (which ? r : q)) fail(1);
+        }
+    }
+    __syncthreads();
+    // r < n (most significant differing limb)
+    if (tid == 0) {
+        bool lt = false;
+        for (int k = (int)L - 1; k >= 0; --k) if (sr[k] != sn[k]) { lt = sr[k] < sn[k]; break; }
+        if (!lt) fail(10);
+    }
+    // ---- accumulator chains of both products ------------------------------------------------------------------
+    for (u32 sidx = tid; sidx < 2 * L * L; sidx += 256) {
+        const bool qn = sidx >= L * L;
+        const u32 e = qn ? sidx - L * L : sidx;
+        const u32 j = e / L, im = e - j * L;
+        const u32 i = im >= j ? im : im + L;
+        const u32 jmin = i >= L ? i - L + 1 : 0;
+        const u64 x = qn ? sq[j] : sa[j], y = qn ? sn[i - j] : sb_[i - j];
+        const U192 prod = U192::make(x * y, __umul64hi(x, y), 0);
+        const U192 cur = rd_acc(qn, j, im);
+        const U192 want = j == jmin ? prod : rd_acc(qn, j - 1, im) + prod;
+        if (!(cur == want)) fail(2);
+    }
+    // ---- eq_b and the is_equal_muled steps, thread = column ---------------------------------------------------
+    const U192 W = U192::make(a.wm[0], a.wm[1], a.wm[2]);
+    for (u32 c = tid; c < C; c += 256) {
+        const u32 jmax = c < L ? c : L - 1, im = c < L ? c : c - L;
+        const U192 ab = rd_acc(false, jmax, im), qnv = rd_acc(true, jmax, im);
+        U192 eqb = qnv;
+        if (c < L) {
+            eqb = rd_wide(H2R_PL_EQB_LO, c);
+            if (!(eqb == qnv + U192::make(sr[c], 0, 0))) fail(3);
+        }
+        const U192 a_b = rd_wide(H2R_PL_AMB_LO, c);
+        if (!(a_b == ab - eqb)) fail(4);
+        const U192 cprev = c ? rd_carry(H2R_PL_CARRY, c - 1) : U192::make(0, 0, 0);
+        const U192 sum = rd_wide(H2R_PL_SUM_LO, c);
+        if (!(sum == a_b + cprev + W)) fail(5);
+        const U192 cy = rd_carry(H2R_PL_CARRY, c);
+        const u64 cmod = rd_limb(H2R_PL_CMOD, c);
+        const U192 nq1 = rd_wide(H2R_PL_NQ1_LO, c);
+        if (!(cy == sum.shr(LW)) || cmod != (sum.w[0] & LMASK) || !(nq1 == cy.shl(LW)) || rd_limb(H2R_PL_AMNQ1, c) != cmod) fail(6);
+        const U192 xprev = c ? rd_carry(H2R_PL_QACC, c - 1) : U192::make(0, 0, 0);
+        const U192 accx = rd_wide(H2R_PL_ACCX_LO, c), qacc = rd_carry(H2R_PL_QACC, c), nq2 = rd_wide(H2R_PL_NQ2_LO, c);
+        const u64 modacc = rd_limb(H2R_PL_MODACC, c);
+        if (!(accx == xprev + W) || !(qacc == accx.shr(LW)) || modacc != (accx.w[0] & LMASK) || !(nq2 == qacc.shl(LW)) ||
+            rd_limb(H2R_PL_AMNQ2, c) != modacc) fail(7);
+        const u32 fl = *reinterpret_cast<const u32 *>(rec + a.off[H2R_PL_FLAGS] + (u64)c * 4);
+        const u32 f1 = fl & 0xff, e1 = (fl >> 8) & 0xff, f2 = (fl >> 16) & 0xff, e2 = fl >> 24;
+        const u32 eprev = c ? (*reinterpret_cast<const u32 *>(rec + a.off[H2R_PL_FLAGS] + (u64)(c - 1) * 4) >> 24) : 1u;
+        const u32 want_f2 = c < C - 1 ? 1u : (cy == qacc ? 1u : 0u);   // range_eq is 1 by construction; last: carry == acc_extra
+        if (f1 != (cmod == modacc ? 1u : 0u) || f2 != want_f2 || e1 != (eprev & f1) || e2 != (e1 & f2)) fail(8);
+        if (c == C - 1 && e2 != 1) fail(11);
+        if (c < C - 1) {   // RangeChip::assign(carry, sublimb_bit_len(carry_bits), carry_bits)
+            const U192 dup = rd_carry(H2R_PL_CARRY_DUP, c);
+            const u8 *sbp = rec + a.off[H2R_PL_CARRY_SUB] + (u64)c * a.carry_sub_stride;
+            u64 v0 = 0, v1 = 0; bool wide = false;
+            const u32 ovb = a.carry_bits % a.carry_sub_bits;
+            for (u32 k = 0; k < a.carry_nsub; ++k) {
+                const u64 sv = sbp[k];
+                const u32 width = (ovb && k == a.carry_nsub - 1) ? ovb : a.carry_sub_bits;
+                wide = wide || (sv >> width) != 0;
+                const u32 sh = k * a.carry_sub_bits;
+                if (sh < 64) { v0 |= sv << sh; if (sh && sh + 8 > 64) v1 |= sv >> (64 - sh); } else v1 |= sv << (sh - 64);
+            }
+            if (wide || !(dup == cy) || v0 != cy.w[0] || v1 != cy.w[1] || cy.w[2] != 0) fail(9);
+        }
+    }
+    if (nbad) { atomicAdd(&s_bad, nbad); atomicMax(&s_code, code); }
+    __syncthreads();
+    if (tid == 0 && s_bad) {
+        atomicAdd(&a.bad[elem], s_bad);
+        if (a.first_bad) atomicCAS(&a.first_bad[elem], 0u, (t << 8) | s_code);
+    }
+}
+
+// Chain linkage of a pow trace, one wave per element: the operands of every mul_mod are the
+// results the reference's control flow feeds it (pow_mod_fixed_exp chip.rs:729-740; pow_mod :682-694), the first base
+// is x, the result limbs are the final acc.  bad[elem] += violated links.
+struct LinkArgs {
+    const void *x; const void *ops; u64 op_stride; u32 L, T, var, nbits;   // ops: [item][a | b | q | r] limbs
+    ExpBits e;                                                              // fixed exponent
+    const u8 *status; const u8 *trace; u64 elem_stride, off_e_bits, off_selected, selected_stride, off_result;
+    u32 *bad; u32 *first_bad;
+};
+template <int LW>
+__global__ __launch_bounds__(64) void link_kernel(LinkArgs a) {
+    using limb_t = typename LimbT<LW>::type;
+    const u32 lane = threadIdx.x, elem = blockIdx.x;
+    if (a.status && a.status[elem]) return;
+    const u32 L = a.L;
+    const limb_t *ops = reinterpret_cast<const limb_t *>(a.ops) + (u64)elem * a.T * a.op_stride;
+    const u8 *et = a.trace + (u64)elem * a.elem_stride;
+    u32 nbad = 0, where = 0;
+    // compare two L-limb integers held in memory / registers, two limbs per lane (L <= 128)
+    auto ld = [&](const limb_t *p, u64 (&v)[2]) { for (int m = 0; m < 2; ++m) { const u32 k = lane + 64 * m; v[m] = k < L ? (u64)p[k] : 0; } };
+    auto same = [&](const u64 (&u)[2], const u64 (&v)[2]) { return __ballot(u[0] != v[0] || u[1] != v[1]) == 0; };
+    u64 cur[2], acc[2], va[2], vb[2], vr[2];
+    ld(reinterpret_cast<const limb_t *>(a.x) + (u64)elem * L, cur);
+    acc[0] = lane == 0 ? 1 : 0; acc[1] = 0;
+    u32 t = 0;
+    auto item = [&](u32 tt, int which) { return ops + (u64)tt * a.op_stride + (u64)which * L; };
+    auto expect = [&](u32 tt, const u64 (&ea)[2], const u64 (&eb)[2]) {
+        ld(item(tt, 0), va); ld(item(tt, 1), vb);
+        if (!same(va, ea) || !same(vb, eb)) { ++nbad; if (!where) where = (tt << 8) | 20; }
+        ld(item(tt, 3), vr);
+    };
+    for (u32 bi = 0; bi < a.nbits && t < a.T; ++bi) {
+        if (a.var) {
+            const u32 bit = et[a.off_e_bits + bi];
+            if (bit > 1) { ++nbad; if (!where) where = (t << 8) | 21; }
+            expect(t, acc, cur); ++t;                                      // muled = mul_mod(acc, squared)  (:686)
+            if (bit) { acc[0] = vr[0]; acc[1] = vr[1]; }                   // select (:688-691)
+            u64 sel[2]; ld(reinterpret_cast<const limb_t *>(et + a.off_selected + (u64)bi * a.selected_stride), sel);
+            if (!same(sel, acc)) { ++nbad; if (!where) where = (t << 8) | 22; }
+            if (t >= a.T) break;
+            expect(t, cur, cur); ++t;                                      // squared = square_mod(squared)  (:693)
+            cur[0] = vr[0]; cur[1] = vr[1];
+        } else {
+            const u32 bit = (a.e.words[bi >> 5] >> (bi & 31)) & 1u;
+            expect(t, cur, cur); ++t;                                      // squared = square_mod(cur_sq)   (:734)
+            const u64 s0 = vr[0], s1 = vr[1];
+            if (bit) {
+                if (t >= a.T) break;
+                expect(t, acc, cur); ++t;                                  // acc = mul_mod(acc, cur_sq)     (:739)
+                acc[0] = vr[0]; acc[1] = vr[1];
+            }
+            cur[0] = s0; cur[1] = s1;
+        }
+    }
+    if (t != a.T) { ++nbad; if (!where) where = (t << 8) | 23; }
+    u64 res[2]; ld(reinterpret_cast<const limb_t *>(et + a.off_result), res);
+    if (!same(res, acc)) { ++nbad; if (!where) where = (a.T << 8) | 24; }
+    if (lane == 0 && nbad) { atomicAdd(&a.bad[elem], nbad); if (a.first_bad) atomicCAS(&a.first_bad[elem], 0u, where); }
 }
 
 // stand-alone RangeChip::assign decomposition of a value array (8- or 16-byte values)

@@ -395,6 +395,27 @@ int32_t h2r_pow_trace_emit_stream(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
                                   uint64_t batch, uint32_t flags, void *stream_out, uint64_t out_stride,
                                   uint64_t out_off, h2r_stream_t stream);
 
+/* ---- in-place audit of a trace (test / diagnosis instrument; not needed by a consumer) ---------------------
+ * Checks, where the records lie in HBM, that every record is a valid witness of ITS mul_mod (sub-limb recomposition,
+ * every accumulator = its predecessor + one limb product, eq_b, every is_equal_muled step against the stored previous
+ * carry, flags, range-assigned carries, r < n, final eq_bit = 1: SURVEY Appendix C 1-4, reference
+ * big_integer/chip.rs:400-412, 562-599, 617, 857-893) and -- for pow traces -- that the operands of every mul_mod are
+ * the values the reference's control flow feeds it and the result limbs are the final acc (Appendix C 5-6,
+ * chip.rs:682-694, 729-740).  Every relation is checked pointwise from stored values, independently of the kernels
+ * that produced them.  bad_out[elem] (zeroed by the call) = number of violated relations; first_bad_out (nullable)
+ * = (mul_mod index << 8) | relation code of one of them.  Elements with a nonzero status byte are skipped.
+ *   h2r_mul_mod_trace_check  records of h2r_mul_mod_batch / h2r_square_mod_batch with the same a, b, n, flags.
+ *   h2r_pow_trace_check      traces of the pow / modpow / verify exports: `workspace` is the workspace that call was
+ *                            given (it still holds the operands of every mul_mod), elem_stride = 0 means
+ *                            pl->elem_stride; e_le_bytes = NULL for a variable-exponent trace. */
+int32_t h2r_mul_mod_trace_check(const h2r_ctx *ctx, const void *a, const void *b, const void *n, uint32_t flags,
+                                const void *trace, uint64_t batch, const uint8_t *status, uint32_t *bad_out,
+                                uint32_t *first_bad_out, h2r_stream_t stream);
+int32_t h2r_pow_trace_check(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *x, const void *n,
+                            const uint8_t *e_le_bytes, size_t e_len, uint32_t flags, const void *trace,
+                            uint64_t elem_stride, const void *workspace, uint64_t batch, const uint8_t *status,
+                            uint32_t *bad_out, uint32_t *first_bad_out, h2r_stream_t stream);
+
 /* ---- per-kernel timing (HIP events recorded on the launch stream around each kernel) -----------
  * h2r_profile_enable(capacity) arms process-wide recording of up to `capacity` launches (0 disarms
  * and frees the events).  h2r_profile_read() synchronises the recorded events of one kernel class

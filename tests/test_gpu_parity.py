@@ -918,6 +918,66 @@ def _check_pow_batch(H, chip, o, X, N, e, res, sample, rng):
     for i in sample:
         rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(X[i]), o.limbs(N[i]), e)
         assert rc == 0 and np.array_equal(ost, res.trace.flatten(i)), i
+    # EVERY record of EVERY element, checked where it lies in HBM (SURVEY Appendix C invariants 1-6): sub-limbs, each
+    # accumulator against its predecessor + one product, eq_b, every carry step, flags, chain linkage, result limbs
+    bad, first = res.audit()
+    torch.cuda.synchronize()
+    nb = bad.cpu().numpy()
+    assert not nb.any(), ("audit", int(np.nonzero(nb)[0][0]), hex(int(first.cpu().numpy()[np.nonzero(nb)[0][0]])))
+
+
+@pytest.mark.parametrize("w,L", [(64, 32), (32, 128), (64, 48), (64, 8), (32, 24)])
+def test_audit_accepts_valid_and_flags_every_corruption(H, w, L):
+    """The in-place checker (h2r_*_trace_check) is itself checked: 0 violations on traces the oracle comparison accepts,
+    and the expected relation code after one byte of one plane of one record is flipped (every plane class in turn)."""
+    from halo2_rsa_amd import _lib
+    chip = H.BigIntChip(w, w * L)
+    rng = random.Random(17 * w + L)
+    batch = 6
+    N = [rand_modulus(rng, w * L, odd=(i != 2)) for i in range(batch)]
+    X = [rng.randrange(n) for n in N]
+    e = 0b100101
+    res = chip.pow_mod_fixed_exp(chip.assign_integer(X), e, chip.assign_integer(N))
+    bad, first = res.audit()
+    torch.cuda.synchronize()
+    assert not bad.cpu().numpy().any()
+    mm = chip.mul_mod(chip.assign_integer(X), chip.assign_integer(X[::-1]), chip.assign_integer(N))
+    bad, first = mm.audit()
+    torch.cuda.synchronize()
+    assert not bad.cpu().numpy().any()
+    lo, pl = chip.layout, res.trace.pow_layout
+    P = {n: k for k, n in enumerate(_lib.PLANES)}
+    T = pl.num_mul_mods
+    # (plane, entry index, expected codes): one flipped bit each, in different elements / records
+    cases = [("Q", 1, {1, 2}), ("R_SUB", 0, {1}), ("AB_LO", 5, {2, 4}), ("QN_LO", 3, {2, 3, 4}), ("EQB_LO", 2, {3, 4}), ("AMB_LO", 4, {4, 5}),
+             ("SUM_LO", 3, {5, 6}), ("CARRY", 2, {5, 6, 8, 9}), ("CMOD", 1, {6, 8}), ("NQ1_LO", 0, {6}), ("AMNQ1", 2, {6}),
+             ("ACCX_LO", 1, {7}), ("QACC", 1, {7, 8}), ("MODACC", 0, {7, 8}), ("NQ2_LO", 2, {7}), ("AMNQ2", 3, {7}),
+             ("FLAGS", 2, {8}), ("CARRY_DUP", 1, {9}), ("CARRY_SUB", 0, {9})]
+    for k, (plane, idx, codes) in enumerate(cases):
+        elem, t = k % batch, (k * 7) % T
+        if plane in ("AB_LO", "QN_LO"):
+            off = lo.plane_off[P[plane]] + idx * 16   # entry (j = 0, i = idx): the first accumulator of column idx
+        else:
+            off = lo.plane_off[P[plane]] + idx * lo.plane_elem[P[plane]]
+        pos = elem * res.trace.elem_stride + pl.off_records + t * lo.record_stride + off
+        old = int(res.trace.buf[pos].item())
+        res.trace.buf[pos] = old ^ 1
+        bad, first = res.audit()
+        torch.cuda.synchronize()
+        nb, fb = bad.cpu().numpy(), first.cpu().numpy()
+        assert nb[elem] > 0 and (nb[np.arange(batch) != elem] == 0).all(), (plane, nb)
+        assert (int(fb[elem]) >> 8) == t and (int(fb[elem]) & 0xff) in codes, (plane, hex(int(fb[elem])), codes)
+        res.trace.buf[pos] = old
+    # chain linkage: swap the result limbs of one element, then an operand in the operands buffer
+    pos = 3 * res.trace.elem_stride + pl.off_result
+    res.trace.buf[pos] ^= 1
+    bad, first = res.audit()
+    torch.cuda.synchronize()
+    assert int(bad[3].item()) == 1 and (int(first[3].item()) & 0xff) == 24
+    res.trace.buf[pos] ^= 1
+    bad, first = res.audit()
+    torch.cuda.synchronize()
+    assert not bad.cpu().numpy().any()
 
 
 def test_config3_shard_size_properties(H):
