@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--verify", action="store_true",
                     help="time the whole verify_pkcs1v15_signature witness (in-field + modpow + encoded-message check) "
                          "instead of modpow_public_key alone (RSA-2048 workloads, pipelined mode)")
+    ap.add_argument("--shared-modulus", action="store_true",
+                    help="one key, many signatures (H2R_F_SHARED_MODULUS): every element uses element 0's modulus")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="developer: do not arm the C ABI's per-kernel event timing (roofline fields become null)")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -159,6 +161,10 @@ def main():
 
     chip = H.BigIntChip(w, bits, device=env.local_rank)
     ns, xs, un, ux = synth_inputs(w, bits, batch, 0x68327273 + 2 + 1000 * env.rank)
+    if args.shared_modulus:   # SURVEY 8d's shared-n variant: x reduced modulo the one modulus
+        ns = [ns[0]] * batch
+        xs = [x % ns[0] for x in xs]
+        un, ux = H.UnassignedInteger.from_ints(ns[:1], bits // w, w), H.UnassignedInteger.from_ints(xs, bits // w, w)
     n_dev, x_dev = chip.assign_integer(un), chip.assign_integer(ux)
     pl = chip.pow_fixed_layout(e)
     dev = "cuda:%d" % env.local_rank
@@ -268,7 +274,7 @@ def main():
                          "chain_kernel_avg_ms": round(sum(chain_ms) / len(chain_ms), 4) if chain_ms else None},
             "whole_path_hbm_frac": round(env.world * batch * steps / dt * algo_bytes_per_assign / (env.world * HBM_PEAK_GBS * 1e9), 4),
         }
-        if env.world == 1 and not args.no_cpu_baseline:
+        if env.world == 1 and not args.no_cpu_baseline and not args.shared_modulus:
             line["cpu_baseline"] = cpu_baseline(w, bits, e, un, ux)
         print(json.dumps(line))
     env.finalize()

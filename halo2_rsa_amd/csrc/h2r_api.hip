@@ -82,6 +82,7 @@ struct Knobs {
     long chain_prio = -1, ablate = 0;            // H2R_CHAIN_PRIO, H2R_ABLATE (needs the -DH2R_ABLATION build)
     int pipe_stream_prio = -1;                   // H2R_PIPE_STREAM_PRIO = low (default) | normal | high  -> -1 | 0 | +1
     bool chain_timing = false;                   // H2R_CHAIN_TIMING (needs the -DH2R_CHAIN_TIMING build)
+    bool pipe_serialize = false;                 // H2R_PIPE_SERIALIZE=1: with two record streams, a record kernel also waits for the previous one
     Knobs() {
 #ifdef H2R_DEV_KNOBS
         auto num = [](const char *name, long dflt) { const char *v = std::getenv(name); return v ? std::atol(v) : dflt; };
@@ -91,6 +92,7 @@ struct Knobs {
         const char *pe = std::getenv("H2R_PIPE_STREAM_PRIO");
         pipe_stream_prio = !pe ? -1 : (!std::strcmp(pe, "high") ? 1 : (!std::strcmp(pe, "low") ? -1 : 0));
         chain_timing = std::getenv("H2R_CHAIN_TIMING") != nullptr;
+        { const char *g = std::getenv("H2R_PIPE_SERIALIZE"); pipe_serialize = g && g[0] == '1'; }
 #endif
     }
 };
@@ -113,13 +115,15 @@ inline u64 odd_stride_256(u64 bytes) {
 // stop event (borrowed; alive while g_prof_gen == gen), so that no extra marker packet sits between kernels.
 struct DoneRef { hipEvent_t ev = nullptr; u32 gen = 0; bool borrowed = false; };
 
-struct Workspace {  // carve-up of the scratch of one batch call
-    u64 total;   // one [batch * T][4][L] limb array: a, b, q, r of every mul_mod
+struct Workspace {  // carve-up of the scratch of one batch call (relative to the 256-byte aligned base)
+    u64 off_pre;   // the shared modulus' Barrett constants (recip_kernel), behind the operands
+    u64 total;     // one [batch * T][4][L] limb array: a, b, q, r of every mul_mod, then off_pre, plus alignment slack
 };
 Workspace workspace_plan(u32 limb_bytes, u32 L, u64 batch, u32 T) {
     Workspace w;
     const u64 arr = round_up(batch * T * (u64)L * limb_bytes, 256);
-    w.total = 4 * arr + 256;
+    w.off_pre = 4 * arr;
+    w.total = 4 * arr + round_up(4ull * chain_pre_words(128), 256) + 256;
     return w;
 }
 
@@ -137,6 +141,7 @@ struct h2r_ctx {
     // RefreshAux::new(w, L, L).increased_limbs_vec (host copy and device copy)
     u8 refresh_inc[2 * 128 + 8]; u32 refresh_nf; u8 *refresh_inc_dev;
     u64 field_p[4];   // the field modulus (a_b encoding, chip.rs:859)
+    u32 num_cus, lds_per_cu;   // of the ctx's device
 };
 
 namespace {
@@ -180,7 +185,7 @@ void build_const_record(h2r_ctx *c) {
 }
 
 template <int LW, int L>
-hipError_t launch_trace_t(const TraceArgs &ta, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
+hipError_t launch_trace_t(const TraceArgs &ta, u32 lds_per_cu, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
     // the kernel hard-codes the accumulator row strides layout_compute derives for (LW, L)
     if (ta.acc_lo_group != (LW == 64 ? 3ull * (2 * L * 16) : (u64)L * 16) || ta.acc_hi_group != ta.acc_lo_group ||
         ta.acc_lo_row != (LW == 64 ? 2u * L * 16 : 0u) || ta.acc_spg != (LW == 64 ? 2u : 1u)) return hipErrorInvalidValue;
@@ -188,43 +193,66 @@ hipError_t launch_trace_t(const TraceArgs &ta, hipStream_t st, hipEvent_t ea, hi
     constexpr int BT = TraceGeo<L>::BT, IPB = TraceGeo<L>::IPB;
     const u64 blocks = (ta.n_items + IPB - 1) / IPB;
     if (blocks == 0) return hipSuccess;
-    // dyn_lds > 0 caps the blocks resident per CU; ea/eb (nullable): start/stop events stamped by the dispatch itself
-    if (ta.dyn_lds > 48 * 1024) {   // large requests must be announced (once per device; harmless to repeat)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&trace_kernel<LW, L, BT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)ta.dyn_lds);
+    // Residency cap: `residency` workgroups per CU (0 = whatever fits).  The cap is enforced the way occupancy is
+    // enforced on this hardware -- by the workgroup's LDS allocation: the launch requests as much (untouched) dynamic
+    // LDS as makes exactly `residency` workgroups fill a CU's LDS.  ea/eb (nullable): start/stop events stamped by
+    // the dispatch itself.
+    u32 dyn = ta.dyn_lds;
+    if (ta.residency) {
+        static const u32 static_lds = [] {   // the kernel's own (static) LDS, once per instantiation
+            hipFuncAttributes fa;
+            return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&trace_kernel<LW, L, BT>)) == hipSuccess ? (u32)fa.sharedSizeBytes : 0u;
+        }();
+        const u32 per = lds_per_cu / ta.residency;
+        dyn = per > static_lds + 1024 ? ((per - static_lds - 512) & ~15u) : 0u;   // `residency` fit, `residency + 1` do not
+    }
+    if (dyn > 48 * 1024) {   // large requests must be announced (once per device; harmless to repeat)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&trace_kernel<LW, L, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         (void)hipGetLastError();
     }
-    hipExtLaunchKernelGGL((trace_kernel<LW, L, BT>), dim3((unsigned)blocks), dim3(BT), ta.dyn_lds, st, ea, eb, 0, ta);
+    hipExtLaunchKernelGGL((trace_kernel<LW, L, BT>), dim3((unsigned)blocks), dim3(BT), dyn, st, ea, eb, 0, ta);
     return hipGetLastError();
 }
 // one instantiation per supported num_limbs: L = STEP, 2 STEP, ..., MAXL
 template <int LW, int STEP, int I>
-hipError_t launch_trace_w(u32 L, const TraceArgs &ta, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
+hipError_t launch_trace_w(u32 L, const TraceArgs &ta, u32 lds_per_cu, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
     if constexpr (I == 0) return hipErrorInvalidValue;
     else {
-        if (L == (u32)(I * STEP)) return launch_trace_t<LW, I * STEP>(ta, st, ea, eb);
-        return launch_trace_w<LW, STEP, I - 1>(L, ta, st, ea, eb);
+        if (L == (u32)(I * STEP)) return launch_trace_t<LW, I * STEP>(ta, lds_per_cu, st, ea, eb);
+        return launch_trace_w<LW, STEP, I - 1>(L, ta, lds_per_cu, st, ea, eb);
     }
 }
-hipError_t launch_trace(u32 w, u32 L, const TraceArgs &ta, hipStream_t st, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr) {
+hipError_t launch_trace(const h2r_ctx *c, const TraceArgs &ta, hipStream_t st, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr) {
+    const u32 w = c->layout.limb_width, L = c->L;
     if (!shape_supported(w, L)) return hipErrorInvalidValue;
-    if (w == 64) return launch_trace_w<64, kLStep64, kLMax64 / kLStep64>(L, ta, st, ea, eb);
-    return launch_trace_w<32, kLStep32, kLMax32 / kLStep32>(L, ta, st, ea, eb);
+    if (w == 64) return launch_trace_w<64, kLStep64, kLMax64 / kLStep64>(L, ta, c->lds_per_cu, st, ea, eb);
+    return launch_trace_w<32, kLStep32, kLMax32 / kLStep32>(L, ta, c->lds_per_cu, st, ea, eb);
 }
+// grid_cap: upper bound on the chain kernel's workgroups (0 = one per element); a smaller grid walks the batch
 template <int K, int NW, bool DEEP>
-hipError_t launch_chain_t(const ChainArgs &ca, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
+hipError_t launch_chain_t(const ChainArgs &ca, u64 grid_cap, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
     if (ca.batch == 0) return hipSuccess;
-    hipExtLaunchKernelGGL((chain_kernel<K, NW, DEEP>), dim3((unsigned)ca.batch), dim3(64 * NW), 0, st, ea, eb, 0, ca);
+    if (ca.pre) {   // the shared modulus' Barrett constants, once, ahead of the elements' chains
+        hipLaunchKernelGGL((recip_kernel<K, NW>), dim3(1), dim3(64 * NW), 0, st, ca.n, ca.kreal, const_cast<u32 *>(ca.pre));
+        if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+    }
+    const u64 grid = grid_cap && grid_cap < ca.batch ? grid_cap : ca.batch;
+    hipExtLaunchKernelGGL((chain_kernel<K, NW, DEEP>), dim3((unsigned)grid), dim3(64 * NW), 0, st, ea, eb, 0, ca);
     return hipGetLastError();
 }
-hipError_t launch_chain(const ChainArgs &ca, hipStream_t st, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr) {
+// co_running: the call's record kernel of the PREVIOUS batch runs next to this chain kernel (pipeline mode)
+hipError_t launch_chain(const h2r_ctx *c, const ChainArgs &ca, bool co_running, hipStream_t st, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr) {
+    // Footprint next to a record kernel: at most four 4-wave (two 8-wave) workgroups per CU, the residency the
+    // batch-1024 RSA-2048 call has; a larger batch is walked by that grid instead of queueing more workgroups (a chain
+    // kernel with 8,192 workgroups kept every CU full of its waves and cost the record kernel 15 % of its store rate).
+    const u64 cap4 = co_running ? 4ull * c->num_cus : 0, cap2 = co_running ? 2ull * c->num_cus : 0;
     // The chain kernel is compiled for K = 8, 16, 32, 64, 128 digits; any other size runs as the next larger one with
     // zero high digits (ca.kreal digits in memory).  NW = waves per element (a multiple of the 64-column groups).
     const u32 K = ca.kreal <= 8 ? 8 : ca.kreal <= 16 ? 16 : ca.kreal <= 32 ? 32 : ca.kreal <= 64 ? 64 : 128;
     switch (K) {
-        case 8: return launch_chain_t<8, 1, false>(ca, st, ea, eb);
-        case 16: return launch_chain_t<16, 1, false>(ca, st, ea, eb);
-        case 32: return launch_chain_t<32, 4, false>(ca, st, ea, eb);
+        case 8: return launch_chain_t<8, 1, false>(ca, 4 * cap4, st, ea, eb);
+        case 16: return launch_chain_t<16, 1, false>(ca, 4 * cap4, st, ea, eb);
+        case 32: return launch_chain_t<32, 4, false>(ca, cap4, st, ea, eb);
         case 64: {
             // Throughput build (6 blocks per CU) when the batch fills the chip; latency build (deep operand prefetch,
             // 139 VGPRs) when there are at most two elements per CU and each chain's own latency is what the call
@@ -233,11 +261,11 @@ hipError_t launch_chain(const ChainArgs &ca, hipStream_t st, hipEvent_t ea = nul
             const bool small = ca.batch <= 512;
             const int nw = nw_env ? nw_env : 4;
             const bool deep = deep_env >= 0 ? deep_env != 0 : small;
-            if (nw == 8) return deep ? launch_chain_t<64, 8, true>(ca, st, ea, eb) : launch_chain_t<64, 8, false>(ca, st, ea, eb);
-            if (nw == 2) return launch_chain_t<64, 2, false>(ca, st, ea, eb);
-            return deep ? launch_chain_t<64, 4, true>(ca, st, ea, eb) : launch_chain_t<64, 4, false>(ca, st, ea, eb);
+            if (nw == 8) return deep ? launch_chain_t<64, 8, true>(ca, cap2, st, ea, eb) : launch_chain_t<64, 8, false>(ca, cap2, st, ea, eb);
+            if (nw == 2) return launch_chain_t<64, 2, false>(ca, 2 * cap4, st, ea, eb);
+            return deep ? launch_chain_t<64, 4, true>(ca, cap4, st, ea, eb) : launch_chain_t<64, 4, false>(ca, cap4, st, ea, eb);
         }
-        default: return launch_chain_t<128, 8, false>(ca, st, ea, eb);
+        default: return launch_chain_t<128, 8, false>(ca, cap2, st, ea, eb);
     }
 }
 
@@ -304,6 +332,9 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
     }
     if (eb) ca.e = *eb;
     if (knobs().chain_prio >= 0) ca.prio = (u32)knobs().chain_prio;
+    // one key, many elements: the Barrett constants of the shared modulus are computed once (recip_kernel) instead of by
+    // every element's workgroup (big_integer/chip.rs:562-567 divides by the same n every time)
+    if ((flags & H2R_F_SHARED_MODULUS) && batch > 1) ca.pre = reinterpret_cast<const u32 *>(ws + wp.off_pre);
     // Pipeline mode: the record stream must wait for this chain kernel.  The event it waits on is the dispatch's own
     // stop event (the profiler's when armed, else chain_done) -- no separate marker packet.
     hipEvent_t chain_wait = nullptr;
@@ -316,7 +347,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         const bool piped = trace_st && trace && T;
         chain_wait = ps.on ? ps.b : (piped ? chain_done : nullptr);
         if (c->K > 128) return H2R_E_UNSUPPORTED;
-        HIP_TRY(launch_chain(ca, st, ps.a, chain_wait));
+        HIP_TRY(launch_chain(c, ca, trace_st != nullptr, st, ps.a, chain_wait));
     }
 #ifdef H2R_CHAIN_TIMING
     if (ca.dbg_time) {
@@ -335,25 +366,24 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         ta.status = status; ta.n_items = batch * T; ta.T = T;
         ta.trace = static_cast<u8 *>(trace); ta.elem_stride = elem_stride; ta.off_records = off_records;
         hipStream_t ts = st;
-        // Residency of the record kernel (a dynamic-LDS request that is never touched caps the workgroups per CU).
-        // With non-temporal stores the RSA-2048 shape writes fastest with FEW concurrent store streams: alone, one
-        // workgroup (4 records in flight) per CU -- 0.227 -> 0.213 ms, 5.87 TB/s; next to a chain kernel, three.
-        const bool tune_lds = knobs().trace_dyn_lds < 0;
-        if (tune_lds && lo.limb_width == 64 && c->L <= 32) ta.dyn_lds = 90000;   // measured for L = 32 and L = 16
+        // Residency of the record kernel, in workgroups per CU (measured per shape).  With
+        // non-temporal stores the 64-bit-limb shapes up to RSA-2048 write fastest with FEW concurrent store streams:
+        // alone, one workgroup (4 records in flight) per CU -- 0.227 -> 0.213 ms, 5.87 TB/s for RSA-2048.  Next to the
+        // following batch's chain kernel: three for RSA-2048 at throughput batch sizes and for 32-bit limbs, two
+        // otherwise (a latency-build chain kernel -- at most two 4-wave workgroups per CU -- leaves room for the
+        // sparser setting).
+        const bool tune = knobs().trace_dyn_lds < 0;
+        if (tune && lo.limb_width == 64 && c->L <= 32) ta.residency = 1;
         if (trace_st) {
-            // co-scheduled with the next batch's chain kernel: cap the trace kernel's residency (its store
-            // stream does not need full occupancy) 
-            // (first sweep: profiles/history/r01_pipeline_sweep.txt; re-swept after the streaming stores)
-            // (a latency-build chain kernel -- at most two 4-wave workgroups per CU -- leaves room for the sparser setting)
-            if (tune_lds) ta.dyn_lds = (lo.limb_width == 64 && !(c->L == 32 && batch > 512)) ? 45000 : 32000;   // sweeps: DESIGN section 5
-            // a chain kernel with more than ~8 workgroups per CU queued keeps every CU full of its waves: the record
-            // kernel's waves then need the raised wave priority to keep their stores issuing (batch 8192: 2.11 -> 2.05 ms)
-            if (knobs().trace_prio < 0 && batch > 2048) ta.prio = 1;
+            if (tune) ta.residency = (lo.limb_width == 64 && !(c->L == 32 && batch > 512)) ? 2 : 3;
+            // (a gate kernel polling a count published by the chain blocks instead of this cross-queue wait was measured
+            //  slower: the blocks' agent-scope releases disturb the record kernel's store stream, 0.220 -> 0.245 ms, and a
+            //  one-wave kernel costs 5-7 us between two record kernels: profiles/r02_gap_experiments.txt)
             HIP_TRY(hipStreamWaitEvent(trace_st, chain_wait, 0));
             ts = trace_st;
         }
         ProfScope ps(H2R_KERNEL_TRACE, ts, true);
-        HIP_TRY(launch_trace(lo.limb_width, c->L, ta, ts, ps.a, ps.on ? ps.b : trace_done));
+        HIP_TRY(launch_trace(c, ta, ts, ps.a, ps.on ? ps.b : trace_done));
         if (done_ref) {
             if (ps.on) { std::lock_guard<std::mutex> lk(g_prof_mu); *done_ref = DoneRef{ps.b, g_prof_gen, true}; }
             else *done_ref = DoneRef{trace_done, 0, false};
@@ -429,6 +459,7 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
     h2r_ctx *c = new (std::nothrow) h2r_ctx();
     if (!c) return H2R_E_HIP;
     c->params = *params; c->L = L; c->K = params->bits_len / 32; c->word_max = wm; c->const_rec_dev = nullptr;
+    c->num_cus = 256; c->lds_per_cu = 160 * 1024;
     c->refresh_inc_dev = nullptr;
     std::memset(c->refresh_inc, 0, sizeof c->refresh_inc);
     c->refresh_nf = (L <= 128) ? refresh_aux_increased_limbs(w, L, c->refresh_inc) : 0;
@@ -449,6 +480,12 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
         return H2R_OK;
     }
     DeviceGuard dg(params->device);
+    {
+        int v = 0;
+        c->num_cus = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, params->device) == hipSuccess && v > 0) ? (u32)v : 256u;
+        c->lds_per_cu = (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, params->device) == hipSuccess && v > 0) ? (u32)v : 160u * 1024;
+        (void)hipGetLastError();
+    }
     if (!hip_ok(dg.err, "hipSetDevice") ||
         !hip_ok(hipMalloc(reinterpret_cast<void **>(&c->const_rec_dev), lo.record_stride), "hipMalloc(const record)") ||
         !hip_ok(hipMemcpy(c->const_rec_dev, c->const_rec_host.data(), lo.record_stride, hipMemcpyHostToDevice), "hipMemcpy(const record)") ||
@@ -759,6 +796,10 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
     if (rc) return rc;
     const u32 slot = p->k % p->depth;
     p->done[slot] = DoneRef{};
+    if (knobs().pipe_serialize && p->aux[0] != p->aux[1] && p->k > 0) {   // order this record stream behind the previous record kernel
+        rc = pipeline_wait_slot(p, (p->k - 1) % p->depth, p->aux[p->k & 1]);
+        if (rc) return rc;
+    }
     rc = run_path(ctx, CHAIN_POW_FIXED, x, nullptr, n, nullptr, 0, 0, &eb, 1, batch, flags, T, trace, elem_stride,
                   pl.off_records, &pl, out, status, workspace, st, p->aux[p->k & 1], p->chain_done[slot], p->trace_done[slot], &p->done[slot]);
     if (rc) return rc;
@@ -1291,7 +1332,7 @@ int32_t h2r_mul_batch(const h2r_ctx *ctx, const void *a, const void *b, uint64_t
     ta.muled_out = muled_out;
     H2R_ON_DEVICE(ctx->params.device);
     ProfScope ps(H2R_KERNEL_TRACE, static_cast<hipStream_t>(stream));
-    HIP_TRY(launch_trace(ctx->layout.limb_width, ctx->L, ta, static_cast<hipStream_t>(stream)));
+    HIP_TRY(launch_trace(ctx, ta, static_cast<hipStream_t>(stream)));
     return H2R_OK;
 }
 int32_t h2r_mul_trace_flatten(const h2r_ctx *ctx, const void *record_host, void *stream_out) {
@@ -1313,7 +1354,7 @@ int32_t h2r_is_equal_muled_batch(const h2r_ctx *ctx, const uint64_t *muled_a, co
     ta.muled_a = muled_a; ta.muled_b = muled_b; ta.eq_out = eq_out;
     H2R_ON_DEVICE(ctx->params.device);
     ProfScope ps(H2R_KERNEL_TRACE, static_cast<hipStream_t>(stream));
-    HIP_TRY(launch_trace(ctx->layout.limb_width, ctx->L, ta, static_cast<hipStream_t>(stream)));
+    HIP_TRY(launch_trace(ctx, ta, static_cast<hipStream_t>(stream)));
     return H2R_OK;
 }
 int32_t h2r_is_equal_muled_flatten(const h2r_ctx *ctx, const void *record_host, void *stream_out) {

@@ -81,6 +81,7 @@ struct ChainArgs {
     u8 *trace; u64 elem_stride, off_e_bits, off_selected, selected_stride, off_result;
     u32 write_result_to_trace;
     u32 prio;            // s_setprio level of the chain's waves (pipeline mode: they share CUs with record kernels)
+    const u32 *pre;      // nullable: the shared modulus' precomputed Barrett constants (recip_kernel)
     u64 *dbg_time;       // debug: s_memtime stamps of block 0 / wave 0 (nullable)
     ExpBits e;
 };
@@ -602,24 +603,19 @@ __device__ __forceinline__ int block_mulmod(ChainLds<K, NW> &s, u32 shift, int l
     return status;
 }
 
-// DEEP: the latency build for small batches (about one block per CU, nothing else to hide LDS latency behind): the
-// product loop preloads its operands 16 products ahead and runs four accumulators; it needs twice the registers.
-template <int K, int NW, bool DEEP>
-__global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R_CHAIN_MINB / 2)) void chain_kernel(ChainArgs args) {
-    using G = Geo<K, NW>;
-    constexpr int V = G::V;
-    __shared__ ChainLds<K, NW> s;
-    if (args.prio) __builtin_amdgcn_s_setprio(3);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool w0 = wave == 0;
-    const u64 elem = blockIdx.x;
-    const u32 *n_g = args.n + elem * args.n_stride;
-    const u32 KR = args.kreal;   // digits in memory; digits [KR, K) are zero
-    u32 nraw[V];
-#pragma unroll
-    for (int m = 0; m < V; ++m) nraw[m] = ((u32)(lane + 64 * m) < KR) ? n_g[lane + 64 * m] : 0;
-    for (int i = threadIdx.x; i < 3 * K; i += 64 * NW) { s.bpad[i] = 0; s.nnpad[i] = 0; s.mupad[i] = 0; }
-    if (threadIdx.x == 0) { s.dbg = (blockIdx.x == 0) ? args.dbg_time : nullptr; s.dbg_n = 0; }
+// Per-modulus constants of the Barrett reduction: the normalisation shift, n' = n << shift and mu' (see block_mulmod).
+// Computed by every chain block for its own modulus, or ONCE per call by recip_kernel when the batch shares one modulus
+// (H2R_F_SHARED_MODULUS: one key, many signatures -- the Knuth-D reciprocal is 17 of the 58 us of a single RSA-2048
+// chain).  Layout of the precomputed form in memory: u32 [0] = shift, [1] = status, [4, 4+K) = n', [4+K, 4+2K) = mu'.
+constexpr u32 CHAIN_PRE_HDR = 4;
+__host__ __device__ constexpr u32 chain_pre_words(u32 K) { return CHAIN_PRE_HDR + 2 * K; }
+
+// Fills s.nnpad / s.mupad and returns (status, shift, nn in wave 0's registers) for the modulus `nraw`.  Every wave
+// calls it (block barriers inside); the control flow depends only on block-uniform values.
+template <int K, int NW>
+__device__ __forceinline__ int chain_modulus_setup(ChainLds<K, NW> &s, const u32 (&nraw)[Geo<K, NW>::V], int lane, int wave, u32 &shift,
+                                                   u32 (&nn)[Geo<K, NW>::V]) {
+    constexpr int V = Geo<K, NW>::V;
     // normalisation shift: leading zero bits of n within 32K bits (every wave computes it: block-uniform)
     int top_digit = -1;
 #pragma unroll
@@ -627,7 +623,51 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R
         const u64 nz = __ballot(nraw[m] != 0);
         if (nz && top_digit < 0) top_digit = 64 * m + (63 - __builtin_clzll(nz));
     }
-    int status = top_digit < 0 ? H2R_E_ZERO_MODULUS : H2R_OK;  // reference divides by zero, chip.rs:566
+    shift = 0;
+#pragma unroll
+    for (int m = 0; m < V; ++m) nn[m] = nraw[m];
+    if (top_digit < 0) return H2R_E_ZERO_MODULUS;  // reference divides by zero, chip.rs:566
+    const u32 topv = __shfl(top_digit >= 64 ? nraw[V - 1] : nraw[0], top_digit & 63);
+    shift = 32u * (u32)(K - 1 - top_digit) + (u32)__builtin_clz(topv);
+    if (shift) {
+        u32 zero[V];
+#pragma unroll
+        for (int m = 0; m < V; ++m) zero[m] = 0;
+        block_shl2k<K, NW>(s, shift, lane, wave, nn, zero);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        lds_store<K>(s.nnpad + K, nn, lane);
+        wave_sync();
+        u32 mu[V];
+        wave_reciprocal<K, NW>(s, nn, lane, wave, mu);
+        lds_store<K>(s.mupad + K, mu, lane);
+    }
+    __syncthreads();
+    return H2R_OK;
+}
+
+// One element's chain.  Returns through `status_out` semantics of the reference's panics (see h2r.h).
+template <int K, int NW, bool DEEP>
+__device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K, NW> &s, const u64 elem) {
+    using G = Geo<K, NW>;
+    constexpr int V = G::V;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool w0 = wave == 0;
+    const u32 *n_g = args.n + elem * args.n_stride;
+    const u32 KR = args.kreal;   // digits in memory; digits [KR, K) are zero
+    u32 nraw[V];
+#pragma unroll
+    for (int m = 0; m < V; ++m) nraw[m] = ((u32)(lane + 64 * m) < KR) ? n_g[lane + 64 * m] : 0;
+    for (int i = threadIdx.x; i < 3 * K; i += 64 * NW) { s.bpad[i] = 0; s.nnpad[i] = 0; s.mupad[i] = 0; }
+    if (threadIdx.x == 0) { s.dbg = (blockIdx.x == 0) ? args.dbg_time : nullptr; s.dbg_n = 0; }
+    int status = H2R_OK;
+    {   // n = 0: the reference divides by zero (chip.rs:566); block-uniform
+        bool nz = false;
+#pragma unroll
+        for (int m = 0; m < V; ++m) nz = nz || __ballot(nraw[m] != 0) != 0;
+        if (!nz) status = H2R_E_ZERO_MODULUS;
+    }
     // operands of the first step (all waves load x so that the in-field predicate is block-uniform)
     u32 cur[V], acc[V], bop[V];
 #pragma unroll
@@ -656,26 +696,15 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R
     }
     u32 shift;
     u32 nn[V];
+    if (args.pre) {   // shared modulus: constants computed once by recip_kernel
+        shift = args.pre[0];
 #pragma unroll
-    for (int m = 0; m < V; ++m) nn[m] = nraw[m];
-    {
-        const u32 topv = __shfl(top_digit >= 64 ? nraw[V - 1] : nraw[0], top_digit & 63);
-        shift = 32u * (u32)(K - 1 - top_digit) + (u32)__builtin_clz(topv);
-        if (shift) {
-            u32 zero[V];
-#pragma unroll
-            for (int m = 0; m < V; ++m) zero[m] = 0;
-            block_shl2k<K, NW>(s, shift, lane, wave, nn, zero);
-        }
+        for (int m = 0; m < V; ++m) nn[m] = (lane + 64 * m < K) ? args.pre[CHAIN_PRE_HDR + lane + 64 * m] : 0;
+        __syncthreads();   // the zero fill above is complete
+        for (int i = threadIdx.x; i < K; i += 64 * NW) { s.nnpad[K + i] = args.pre[CHAIN_PRE_HDR + i]; s.mupad[K + i] = args.pre[CHAIN_PRE_HDR + K + i]; }
         __syncthreads();
-        if (w0) {
-            lds_store<K>(s.nnpad + K, nn, lane);
-            wave_sync();
-            u32 mu[V];
-            wave_reciprocal<K, NW>(s, nn, lane, wave, mu);
-            lds_store<K>(s.mupad + K, mu, lane);
-        }
-        __syncthreads();
+    } else {
+        (void)chain_modulus_setup<K, NW>(s, nraw, lane, wave, shift, nn);   // n != 0 was established above
     }
     u32 q[V], r[V];
     const u64 item0 = elem * args.T;
@@ -762,6 +791,39 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R
     if (threadIdx.x == 0) args.status[elem] = (u8)status;
 }
 
+// DEEP: the latency build for small batches (about one block per CU, nothing else to hide LDS latency behind): the
+// product loop preloads its operands 16 products ahead and runs four accumulators; it needs twice the registers.
+// The grid may be smaller than the batch: block b then runs elements b, b + gridDim.x, ... one after the other, which
+// bounds the kernel's footprint on the CUs whatever the batch size (a co-running record kernel keeps its store rate).
+template <int K, int NW, bool DEEP>
+__global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R_CHAIN_MINB / 2)) void chain_kernel(ChainArgs args) {
+    __shared__ ChainLds<K, NW> s;
+    if (args.prio) __builtin_amdgcn_s_setprio(3);
+    for (u64 elem = blockIdx.x; elem < args.batch; elem += gridDim.x) {
+        if (elem != blockIdx.x) __syncthreads();   // every wave is done with the previous element's LDS
+        chain_element<K, NW, DEEP>(args, s, elem);
+    }
+}
+
+// The shared modulus' Barrett constants, once per call (one workgroup).
+template <int K, int NW>
+__global__ __launch_bounds__(64 * NW) void recip_kernel(const u32 *n, u32 kreal, u32 *pre) {
+    constexpr int V = Geo<K, NW>::V;
+    __shared__ ChainLds<K, NW> s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 nraw[V], nn[V];
+#pragma unroll
+    for (int m = 0; m < V; ++m) nraw[m] = ((u32)(lane + 64 * m) < kreal) ? n[lane + 64 * m] : 0;
+    for (int i = threadIdx.x; i < 3 * K; i += 64 * NW) { s.bpad[i] = 0; s.nnpad[i] = 0; s.mupad[i] = 0; }
+    if (threadIdx.x == 0) { s.dbg = nullptr; s.dbg_n = 0; }
+    __syncthreads();
+    u32 shift;
+    const int status = chain_modulus_setup<K, NW>(s, nraw, lane, wave, shift, nn);
+    if (threadIdx.x == 0) { pre[0] = shift; pre[1] = (u32)status; pre[2] = 0; pre[3] = 0; }
+    if (status == H2R_OK)
+        for (int i = threadIdx.x; i < K; i += 64 * NW) { pre[CHAIN_PRE_HDR + i] = s.nnpad[K + i]; pre[CHAIN_PRE_HDR + K + i] = s.mupad[K + i]; }
+}
+
 // ================================================================================================
 // K1: trace kernel
 // ================================================================================================
@@ -809,7 +871,8 @@ struct TraceArgs {
     u64 wm[3];                          // word_max (chip.rs:838)
     u32 carry_bits, carry_sub_bits, carry_nsub, carry_sub_stride;
     u32 ablate;                         // timing experiments only (H2R_ABLATE); 0 in production
-    u32 dyn_lds;                        // extra dynamic LDS per block: caps residency (pipeline co-scheduling)
+    u32 dyn_lds;                        // developer override: raw dynamic LDS per block (sweeps)
+    u32 residency;                      // host only: workgroups per CU the launch is capped to (0 = uncapped)
     u32 prio;                           // raise wave priority (pipeline co-scheduling)
     u32 acc_spg, acc_lo_row; u64 acc_lo_group, acc_hi_group;   // accumulator-plane addressing (h2r_layout)
     u32 mode;                           // TRACE_FULL (mul_mod), TRACE_MUL (BigIntChip::mul only), TRACE_EQ (is_equal_muled only)
@@ -833,7 +896,19 @@ struct TraceLds {
 // these kernels, and keeping it from displacing L2 lines is worth +6..8 % on the pipelined path and +1..4 % alone
 // (same-box A/B, tools/ab_nt.sh; the sc0/sc1 scope bits make no difference with or without nt).
 // -DH2R_STORE_PLAIN restores ordinary stores for such A/B runs.
-#ifndef H2R_STORE_PLAIN
+#if defined(H2R_STORE_BITS)   // developer A/B of the cache-policy bits: -DH2R_STORE_BITS='"sc1 nt"'
+typedef u32 h2r_v4u32 __attribute__((ext_vector_type(4)));
+typedef u32 h2r_v2u32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st16(u8 *p, u64 a, u64 b) {
+    h2r_v4u32 v; v.x = (u32)a; v.y = (u32)(a >> 32); v.z = (u32)b; v.w = (u32)(b >> 32);
+    asm volatile("global_store_dwordx4 %0, %1, off " H2R_STORE_BITS :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st8(u8 *p, u64 a) {
+    h2r_v2u32 v; v.x = (u32)a; v.y = (u32)(a >> 32);
+    asm volatile("global_store_dwordx2 %0, %1, off " H2R_STORE_BITS :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st4(u8 *p, u32 a) { asm volatile("global_store_dword %0, %1, off " H2R_STORE_BITS :: "v"(p), "v"(a) : "memory"); }
+#elif !defined(H2R_STORE_PLAIN)
 typedef u64 h2r_v2u64 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void st16(u8 *p, u64 a, u64 b) {
     h2r_v2u64 v; v.x = a; v.y = b;
