@@ -1,12 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- RSA-2048 pkcs1v15 witness assignments / second on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path (RSAChip::modpow_public_key witness generation: chain kernel +
-trace kernel through the C ABI) over one batch of synthetic signatures that is already resident in
-HBM.  At N GPUs every rank processes its own shard of `--batch` signatures (weak scaling, no
-data-path collective: signatures are independent); the only collectives are the configuration
-broadcast before and the result gather after the timed region, plus the barrier / MAX-reduce that
-brackets the timing.
+One "step" = one pass of the hot path (RSAChip::modpow_public_key witness generation: assert_in_field
+witness + chain kernel + record kernel through the C ABI) over one batch of synthetic signatures that
+is already resident in HBM.
+  --gpus 1 (default): BASELINE configs[1] -- one 1,024-signature call per step.
+  --gpus N > 1: BASELINE configs[2] -- the seeded global batch (8,192 x N signatures: 65,536 at N = 8) is
+    sharded contiguously (halo2_rsa_amd.dist.shard_range); every rank walks its 8,192-signature shard as
+    eight pipelined 1,024-signature calls per step and keeps the traces resident on its own GPU.  Weak
+    scaling, no data-path collective (signatures are independent); the only collectives are the
+    configuration broadcast before and the result all-gather after the timed region (rank 0 checks
+    samples of EVERY shard against pow()), plus the barrier / MAX-reduce that brackets the timing.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     -- the dominant kernel (trace_kernel, HBM-write bound): algorithmic bytes per launch
@@ -30,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 import halo2_rsa_amd as H  # noqa: E402
 from halo2_rsa_amd import _lib  # noqa: E402
-from halo2_rsa_amd.dist import DistEnv  # noqa: E402
+from halo2_rsa_amd.dist import DistEnv, shard_range  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -63,23 +67,39 @@ WORKLOADS = {
 }
 
 
-def synth_inputs(w, bits, batch, seed, golden_first=True):
-    """Seeded synthetic batch: odd moduli with the top bit set, x uniform mod n; the
-    reference's two valid and one invalid RSA-2048 signatures occupy elements 0-2."""
-    rng = random.Random(seed)
-    L = bits // w
-    ns, xs = [], []
-    if golden_first and (w, bits) == (64, 2048):
-        with open(os.path.join(ROOT, "tests", "golden", "halo2_rsa_golden.json")) as f:
-            for k in json.load(f)["rsa_kats"]:
-                ns.append(int(k["n"])); xs.append(int(k["sig"]))
-    while len(ns) < batch:
-        n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
-        ns.append(n); xs.append(rng.randrange(n))
-    ns, xs = ns[:batch], xs[:batch]
-    un = H.UnassignedInteger.from_ints(ns, L, w)
-    ux = H.UnassignedInteger.from_ints(xs, L, w)
-    return ns, xs, un, ux
+GLOBAL_SEED = 0x68327273
+
+
+def synth_element(w, bits, g, golden):
+    """Element g of the seeded global synthetic batch: an odd modulus with the top bit set and x uniform
+    mod n; the reference's two valid and one invalid RSA-2048 signatures are global elements 0-2.  Any rank can
+    regenerate any element (rank 0 re-derives samples of every shard for the post-run check)."""
+    if golden is not None and g < len(golden):
+        return int(golden[g]["n"]), int(golden[g]["sig"])
+    rng = random.Random((GLOBAL_SEED << 24) + g)
+    n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+    return n, rng.randrange(n)
+
+
+def load_golden(w, bits):
+    if (w, bits) != (64, 2048):
+        return None
+    with open(os.path.join(ROOT, "tests", "golden", "halo2_rsa_golden.json")) as f:
+        return json.load(f)["rsa_kats"]
+
+
+def to_limbs(values, w, bits):
+    """maingate::decompose_big: little-endian limbs, [len(values), bits / w]."""
+    raw = b"".join(int(v).to_bytes(bits // 8, "little") for v in values)
+    return np.frombuffer(raw, dtype=np.uint64 if w == 64 else np.uint32).reshape(len(values), bits // w).copy()
+
+
+def synth_inputs(w, bits, lo, hi):
+    """Global elements [lo, hi) of the synthetic batch: (ns, xs, UnassignedInteger n, UnassignedInteger x)."""
+    golden = load_golden(w, bits)
+    pairs = [synth_element(w, bits, g, golden) for g in range(lo, hi)]
+    ns, xs = [p[0] for p in pairs], [p[1] for p in pairs]
+    return ns, xs, H.UnassignedInteger(to_limbs(ns, w, bits)), H.UnassignedInteger(to_limbs(xs, w, bits))
 
 
 def cpu_baseline(w, bits, e, un, ux, target_seconds=12.0):
@@ -103,7 +123,9 @@ def cpu_baseline(w, bits, e, un, ux, target_seconds=12.0):
     return {"value": round(passes * sample / sec, 1), "unit": "assigns/s", "cores": cores, "kind": "port",
             "sample": "%d passes over %d signatures of the same synthetic batch (%.1f s, %d threads, %.0f signatures per "
                       "thread), full op-trace stream written to per-thread buffers" % (passes, sample, sec, cores, passes * sample / cores),
-            "single_thread_value": round(one / sec1, 1), "single_thread_sample": "%d signatures, 1 thread" % one}
+            "single_thread_value": round(one / sec1, 1), "single_thread_sample": "%d signatures, 1 thread" % one,
+            # what the host actually delivers: os.cpu_count() threads may share far fewer physical cores / a CPU quota
+            "parallel_speedup": round((passes * sample / sec) / (one / sec1), 1)}
 
 
 def ensure_built():
@@ -133,7 +155,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=1024, help="signatures per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="signatures per call (default 1024)")
+    ap.add_argument("--chunks", type=int, default=0,
+                    help="calls per step = chunks of the GPU's shard (default: 1 at --gpus 1, 8 at --gpus > 1: 8,192 per GPU)")
     ap.add_argument("--workload", default="rsa2048_e65537", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline-depth", type=int, default=2, help="buffer sets the pipelined calls rotate through (2..4)")
@@ -155,21 +179,28 @@ def main():
     w, bits, e = WORKLOADS[args.workload]
     torch.cuda.set_device(env.local_rank)
     env.init("nccl")
-    # configuration broadcast (rank 0 decides e / batch): the only pre-run collective
-    cfg = env.broadcast_ints([e, args.batch, args.steps, args.warmup])
-    e, batch, steps, warmup = cfg
+    # Workload: N = 1 -> BASELINE configs[1] (one 1,024-signature call per step).  N > 1 -> configs[2]: every GPU owns a
+    # contiguous shard of 8,192 signatures of the global batch (65,536 at N = 8) and walks it as pipelined
+    # 1,024-signature calls; a step is one pass over the shard.  --batch / --chunks override both.
+    chunk = args.batch if args.batch else 1024
+    chunks = args.chunks if args.chunks else (1 if args.gpus == 1 else 8)
+    # configuration broadcast (rank 0 decides): the only pre-run collective
+    e, chunk, chunks, steps, warmup = env.broadcast_ints([e, chunk, chunks, args.steps, args.warmup])
+    shard = chunk * chunks
+    global_batch = shard * env.world
+    lo, hi = shard_range(global_batch, env.rank, env.world)
+    assert hi - lo == shard
 
     chip = H.BigIntChip(w, bits, device=env.local_rank)
-    ns, xs, un, ux = synth_inputs(w, bits, batch, 0x68327273 + 2 + 1000 * env.rank)
+    ns, xs, un, ux = synth_inputs(w, bits, lo, hi)
     if args.shared_modulus:   # SURVEY 8d's shared-n variant: x reduced modulo the one modulus
-        ns = [ns[0]] * batch
+        ns = [ns[0]] * shard
         xs = [x % ns[0] for x in xs]
-        un, ux = H.UnassignedInteger.from_ints(ns[:1], bits // w, w), H.UnassignedInteger.from_ints(xs, bits // w, w)
+        un, ux = H.UnassignedInteger(to_limbs(ns[:1], w, bits)), H.UnassignedInteger(to_limbs(xs, w, bits))
     n_dev, x_dev = chip.assign_integer(un), chip.assign_integer(ux)
     pl = chip.pow_fixed_layout(e)
     dev = "cuda:%d" % env.local_rank
-    # two buffer sets: in pipeline mode step k+1's chain kernel overlaps step k's trace kernel
-    nbuf = 1 if args.no_pipeline else args.pipeline_depth
+    nbuf = 1 if args.no_pipeline else args.pipeline_depth   # scratch sets the calls rotate through
     elem_stride = pl.elem_stride
     verify = args.verify and not args.no_pipeline and (w, bits) == (64, 2048)
     if verify:   # whole verifier witness: the element also holds the in-field and encoded-message regions
@@ -178,40 +209,56 @@ def main():
         eb = e.to_bytes((e.bit_length() + 7) // 8, "little")
         _lib.check(_lib.lib().h2r_verify_layout_fixed(chip._ctx, eb, len(eb), ctypes.byref(vl)), "h2r_verify_layout_fixed")
         elem_stride = vl.elem_stride
-        hashed_dev = torch.randint(-2**62, 2**62, (batch, 4), dtype=torch.int64, device=dev)
-        valids = [torch.zeros(batch, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    # zero-filled, so every page is resident before the first (possibly un-warmed) timed step touches it
-    trace_bufs = [torch.zeros(batch * elem_stride, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    workspaces = [torch.zeros(chip.workspace_bytes(batch, pl.num_mul_mods), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    outs = [torch.empty((batch, chip.num_limbs), dtype=chip.torch_dtype, device=dev) for _ in range(nbuf)]
-    statuses = [torch.zeros(batch, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    # modpow_public_key's assert_in_field witness (src/chip.rs:106): its own small buffer per set
-    in_fields = [torch.zeros(batch * chip.in_field_layout()[0], dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+        hashed_dev = torch.randint(-2**62, 2**62, (shard, 4), dtype=torch.int64, device=dev)
+        valid = torch.zeros(shard, dtype=torch.uint8, device=dev)
+    # The shard's traces stay resident on the GPU that produced them: with one call per step the calls
+    # rotate through `nbuf` trace regions, with several calls per step every call has its own region of the shard's
+    # trace.  Zero-filled, so every page is resident before the first (possibly un-warmed) timed step touches it.
+    regions = nbuf if chunks == 1 else chunks
+    trace_buf = torch.zeros(regions * chunk * elem_stride, dtype=torch.uint8, device=dev)
+    ifs = chip.in_field_layout()[0]
+    in_field_buf = torch.zeros(regions * chunk * ifs, dtype=torch.uint8, device=dev)   # assert_in_field witness (src/chip.rs:106)
+    out = torch.zeros((regions * chunk, chip.num_limbs), dtype=chip.torch_dtype, device=dev)
+    status = torch.zeros(regions * chunk, dtype=torch.uint8, device=dev)
+    workspaces = [torch.zeros(chip.workspace_bytes(chunk, pl.num_mul_mods), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    xc = [H.AssignedInteger(x_dev.limbs_dev[c * chunk:(c + 1) * chunk], w) for c in range(chunks)]
+    nc = [n_dev if args.shared_modulus else H.AssignedInteger(n_dev.limbs_dev[c * chunk:(c + 1) * chunk], w) for c in range(chunks)]
     pipe = None if args.no_pipeline else H.Pipeline(chip, depth=args.pipeline_depth, side_streams=args.side_streams)
     counter = [0]
 
-    def step():
-        b = counter[0] % nbuf
+    def call(c):
+        """One 1,024-signature (chunk) call: chunk c of the shard."""
+        k = counter[0]
         counter[0] += 1
+        r = (k % nbuf) if chunks == 1 else c          # trace / result region
+        ws = workspaces[k % nbuf]
+        sl = slice(r * chunk, (r + 1) * chunk)
+        tb = trace_buf[r * chunk * elem_stride:(r + 1) * chunk * elem_stride]
+        fb = in_field_buf[r * chunk * ifs:(r + 1) * chunk * ifs]
         if pipe is None:
-            chip.pow_mod_fixed_exp(x_dev, e, n_dev, want_trace=True, trace_buf=trace_bufs[b], check_in_field=True,
-                                   workspace=workspaces[b], out=outs[b], status=statuses[b], in_field_buf=in_fields[b])
+            chip.pow_mod_fixed_exp(xc[c], e, nc[c], want_trace=True, trace_buf=tb, check_in_field=True,
+                                   workspace=ws, out=out[sl], status=status[sl], in_field_buf=fb)
         elif verify:
-            pipe.verify_pkcs1v15(x_dev, e, n_dev, hashed_dev, trace_bufs[b], workspaces[b], outs[b], valids[b], statuses[b])
+            pipe.verify_pkcs1v15(xc[c], e, nc[c], hashed_dev[c * chunk:(c + 1) * chunk], tb, ws, out[sl], valid[sl], status[sl])
         else:
-            pipe.modpow_public_key(x_dev, e, n_dev, trace_bufs[b], workspaces[b], outs[b], statuses[b], in_fields[b])
-        return b
+            pipe.modpow_public_key(xc[c], e, nc[c], tb, ws, out[sl], status[sl], fb)
+        return r
+
+    def step():
+        for c in range(chunks):
+            last = call(c)
+        return last
 
     # initialisation that is not part of any step (code-object load, stream / event creation on first use): one call,
     # then the W warm-up steps the caller asked for
-    step()
+    call(0)
     counter[0] = 0
     for _ in range(warmup):
         step()
     if pipe is not None:
         pipe.join()
     torch.cuda.synchronize()
-    _lib.profile_enable(0 if args.no_kernel_timing else 2 * steps + 8)
+    _lib.profile_enable(0 if args.no_kernel_timing else 4 * steps * chunks + 8)   # chain + record + in-field kernel per call
     env.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -227,52 +274,73 @@ def main():
     _lib.profile_enable(0)
 
     # post-run: correctness of what was timed + the result gather (rank 0 receives every shard's x^e mod n)
-    out, status = outs[last], statuses[last]
     assert int(status.max().item()) == 0 or (w, bits) != (64, 2048), "unexpected per-element status"
-    got = H.AssignedInteger(out, w).to_big_uint()
-    # the trace that was timed is the real thing: element 0 of the last step, byte-exact vs pow() through q*n+r
-    tr = H.Trace(chip, trace_bufs[last], batch, pl)
+    c_last = chunks - 1                                    # shard chunk the last call processed
+    res = out[last * chunk:(last + 1) * chunk]
+    got = H.AssignedInteger(res.contiguous(), w).to_big_uint()
+    base = c_last * chunk
+    # the trace that was timed is the real thing: first element of the last call, byte-exact vs pow() through q*n+r
+    tr = H.Trace(chip, trace_buf[last * chunk * elem_stride:(last + 1) * chunk * elem_stride], chunk, pl)
+    tr.elem_stride = elem_stride
     q0 = int.from_bytes(tr.plane(0, 0, "Q").tobytes(), "little")
     r0 = int.from_bytes(tr.plane(0, 0, "R").tobytes(), "little")
-    assert xs[0] * xs[0] == q0 * ns[0] + r0, "first mul_mod record of the timed trace is wrong"
-    for i in (0, 1, 2, batch - 1):
-        if i < batch:
-            assert got[i] == pow(xs[i], e, ns[i]), "GPU result differs from pow(x, e, n)"
-    gathered = env.gather_to_rank0(out)
+    assert xs[base] * xs[base] == q0 * ns[base] + r0, "first mul_mod record of the timed trace is wrong"
+    for i in (0, 1, 2, chunk - 1):
+        if i < chunk:
+            assert got[i] == pow(xs[base + i], e, ns[base + i]), "GPU result differs from pow(x, e, n)"
+    shard_out = out[:shard].contiguous() if chunks > 1 else res.contiguous()
+    gathered = env.gather_to_rank0(shard_out)
     if env.rank == 0:
-        assert gathered.shape[0] == env.world * batch
+        assert gathered.shape[0] == env.world * shard_out.shape[0]
+        if chunks > 1 and not args.shared_modulus:   # samples from EVERY shard against pow() of the regenerated inputs
+            golden = load_golden(w, bits)
+            vals = H.AssignedInteger(gathered, w)
+            host = vals.limbs_host()
+            for r in range(env.world):
+                for off in (0, shard // 2 + 1, shard - 1):
+                    g = r * shard + off
+                    n_g, x_g = synth_element(w, bits, g, golden)
+                    v = sum(int(t) << (w * i) for i, t in enumerate(host[g]))
+                    if not (golden is not None and g < 3 and x_g >= n_g):
+                        assert v == pow(x_g, e, n_g), "shard %d element %d differs from pow(x, e, n)" % (r, off)
 
     if env.rank == 0:
         # written (pow stream + the assert_in_field stream of modpow_public_key) + inputs read
         algo_bytes_per_assign = pl.stream_bytes + chip.in_field_layout()[1] + 2 * chip.num_limbs * chip.layout.limb_bytes
-        trace_bytes_per_launch = batch * (pl.num_mul_mods * chip.layout.stream_bytes)         # trace_kernel's algorithmic output
+        trace_bytes_per_launch = chunk * (pl.num_mul_mods * chip.layout.stream_bytes)         # trace_kernel's algorithmic output
         avg_trace_s = (sum(trace_ms) / len(trace_ms)) / 1e3 if trace_ms else float("nan")
         achieved = trace_bytes_per_launch / avg_trace_s / 1e9 if trace_ms else None
+        if chunks == 1:
+            wl = "%s batch=%d per GPU, %d-bit limbs, full op-trace (%d B/assign)" % (args.workload, chunk, w, algo_bytes_per_assign)
+        else:
+            wl = ("%s global batch=%d sharded x%d (%d per GPU, walked as %d pipelined calls of %d), %d-bit limbs, full op-trace "
+                  "(%d B/assign), traces resident on the producing GPU" %
+                  (args.workload, global_batch, env.world, shard, chunks, chunk, w, algo_bytes_per_assign))
         line = {
             "metric": "RSA-2048 pkcs1v15 witness assigns/sec" if bits == 2048 else "RSA-%d witness assigns/sec" % bits,
-            "value": round(env.world * batch * steps / dt, 1),
+            "value": round(global_batch * steps / dt, 1),
             "unit": "assigns/s",
             "n_gpus": env.world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(1e3 * dt / steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u%d" % w, "data": "synthetic",
-            "config": {"workload": "%s batch=%d per GPU, %d-bit limbs, full op-trace (%d B/assign)" %
-                       (args.workload, batch, w, algo_bytes_per_assign),
-                       "per_gpu_batch": batch, "global_batch": env.world * batch,
+            "config": {"workload": wl,
+                       "per_gpu_batch": shard, "global_batch": global_batch, "calls_per_step": chunks, "signatures_per_call": chunk,
                        "path": "verify_pkcs1v15_signature (in-field + modpow + EM check)" if verify else "modpow_public_key",
                        "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world,
                        "pipeline": ("chain k+1 || trace k, %d buffer sets, %d record stream(s)" % (args.pipeline_depth, args.side_streams))
                                    if pipe is not None else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                         "traffic": pmc_traffic("trace_kernel<%d,%d>" % (w, chip.num_limbs), batch),
+                         "traffic": pmc_traffic("trace_kernel<%d,%d>" % (w, chip.num_limbs), chunk),
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this kernel at this batch, "
                                            "committed; PMC counters cannot be read from inside the bench process)",
                          "kernel": "trace_kernel<%d,%d>" % (w, chip.num_limbs),
+                         "launches_timed": len(trace_ms),
                          "avg_launch_ms": round(1e3 * avg_trace_s, 4) if trace_ms else None,
                          "algorithmic_bytes_per_launch": trace_bytes_per_launch,
                          "chain_kernel_avg_ms": round(sum(chain_ms) / len(chain_ms), 4) if chain_ms else None},
-            "whole_path_hbm_frac": round(env.world * batch * steps / dt * algo_bytes_per_assign / (env.world * HBM_PEAK_GBS * 1e9), 4),
+            "whole_path_hbm_frac": round(global_batch * steps / dt * algo_bytes_per_assign / (env.world * HBM_PEAK_GBS * 1e9), 4),
         }
         if env.world == 1 and not args.no_cpu_baseline and not args.shared_modulus:
             line["cpu_baseline"] = cpu_baseline(w, bits, e, un, ux)

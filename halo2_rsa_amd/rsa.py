@@ -106,6 +106,51 @@ class RSAChip:
         return VerifyResult(is_valid, AssignedInteger(powed, 64), status, trace, vl, chip)
 
 
+# ---- byte-level plumbing of the reference's example / verifier (BASELINE config 1) -------------------------------------
+def signature_from_bytes_be(sig_bytes, bits_len: int, limb_width: int = 64) -> RSASignature:
+    """examples/rsa_example.rs:175-178: the signature comes off the wire big-endian; `sign.reverse()`, then
+    BigUint::from_bytes_le and decompose_big into bits_len / limb_width little-endian limbs.  One signature or a list."""
+    sigs = [sig_bytes] if isinstance(sig_bytes, (bytes, bytearray)) else list(sig_bytes)
+    vals = [int.from_bytes(bytes(sb)[::-1], "little") for sb in sigs]
+    return RSASignature(UnassignedInteger.from_ints(vals, bits_len // limb_width, limb_width))
+
+
+def hashed_msg_from_digest(digest) -> UnassignedInteger:
+    """src/lib.rs:213-239: the 32 SHA-256 digest bytes are reversed and packed eight per limb, byte j of a limb with
+    coefficient 2^(8j) -- i.e. the digest read as a big-endian integer, cut into 4 little-endian 64-bit limbs
+    (the operand RSAChip::verify_pkcs1v15_signature compares with the low limbs of the encoded message, src/chip.rs:141-144)."""
+    digests = [digest] if isinstance(digest, (bytes, bytearray)) else list(digest)
+    out = np.zeros((len(digests), 4), dtype=np.uint64)
+    for r, d in enumerate(digests):
+        hashed_bytes = bytes(d)[::-1]                               # hashed_bytes.reverse()  (:213)
+        assert len(hashed_bytes) == 32
+        for i in range(4):                                          # bytes_len / limb_bytes limbs  (:225)
+            limb = 0
+            for j in range(8):                                      # limb_val += 2^(8j) * hashed_bytes[8i + j]  (:227-236)
+                limb += hashed_bytes[8 * i + j] << (8 * j)
+            out[r, i] = limb
+    return UnassignedInteger(out)
+
+
+class RSASignatureVerifier:
+    """src/lib.rs:149-246: SHA-256 of the message, then RSAChip::verify_pkcs1v15_signature.  The SHA-256 chip is a
+    third-party circuit outside the accelerated path; the digest is computed on the host here and only its
+    packing into the verifier's operand follows the reference."""
+
+    def __init__(self, rsa_chip: "RSAChip"):
+        self.rsa_chip = rsa_chip
+
+    def verify_pkcs1v15_signature(self, public_key: RSAPublicKey, msg, signature: RSASignature) -> "VerifyResult":
+        """msg: one message (bytes, signed by every element) or one message per element."""
+        import hashlib
+        chip = self.rsa_chip.bigint_chip()
+        sig = chip.assign_integer(signature.c)
+        msgs = [msg] * sig.batch if isinstance(msg, (bytes, bytearray)) else list(msg)
+        hashed = hashed_msg_from_digest([hashlib.sha256(bytes(m)).digest() for m in msgs])
+        hashed_dev = AssignedInteger(torch.from_numpy(hashed.limbs.view(np.int64)).to(sig.limbs_dev.device).contiguous(), 64)
+        return self.rsa_chip.verify_pkcs1v15_signature(public_key, hashed_dev, RSASignature(sig))
+
+
 @dataclass
 class VerifyResult:
     is_valid: "torch.Tensor"     # uint8 [batch]

@@ -39,6 +39,21 @@ def test_gloo_world2_harness(tmp_path):
         g = env.gather_to_rank0(shard)
         if env.rank == 0:
             assert g.shape == (10, 4) and g[:, 0].tolist() == list(range(10))
+        # bench.py's config-3 sharding: every rank synthesises ITS shard of the seeded global batch; rank 0 can
+        # regenerate any element of any shard (that is how it checks samples of every shard against pow())
+        import numpy as np
+        import bench
+        lo, hi = shard_range(12, env.rank, env.world)
+        ns, xs, un, ux = bench.synth_inputs(64, 2048, lo, hi)
+        assert un.limbs.shape == (6, 32) and all(x < n and n >> 2047 == 1 and n & 1 for n, x in zip(ns, xs))
+        gx = env.gather_to_rank0(torch.from_numpy(ux.limbs.view(np.int64)))
+        if env.rank == 0:
+            golden = bench.load_golden(64, 2048)
+            host = gx.numpy().view(np.uint64)
+            for gidx in range(12):
+                n_g, x_g = bench.synth_element(64, 2048, gidx, golden)
+                assert sum(int(t) << (64 * i) for i, t in enumerate(host[gidx])) == x_g
+            assert int(golden[0]["sig"]) == bench.synth_element(64, 2048, 0, golden)[1]
             print("GLOO_OK")
         env.finalize()
     ''' % ROOT))
