@@ -72,6 +72,7 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_trace_lookup_permutation",
            "h2r_trace_flatten", "h2r_pow_trace_flatten", "h2r_stream_bytes", "h2r_pow_stream_bytes", "h2r_trace_flatten_ex",
            "h2r_pow_trace_flatten_ex", "h2r_trace_emit_stream", "h2r_pow_trace_emit_stream", "h2r_mul_mod_trace_check", "h2r_pow_trace_check",
+           "h2r_advice_rows", "h2r_mul_mod_emit_advice", "h2r_pow_trace_emit_advice",
            "h2r_profile_enable", "h2r_profile_read", "h2r_status_str",
            "h2r_last_hip_error"]
 KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST, KERNEL_AUX, KERNEL_EMIT = 0, 1, 2, 3, 4
@@ -154,6 +155,10 @@ def lib():
     L.h2r_pow_trace_flatten_ex.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, u32, vp]
     L.h2r_trace_emit_stream.argtypes = [vp, vp, u64, u32, vp, u64, u64, vp]
     L.h2r_pow_trace_emit_stream.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, u64, u64, u32, vp, u64, u64, vp]
+    L.h2r_advice_rows.argtypes = [vp]
+    L.h2r_advice_rows.restype = u32
+    L.h2r_mul_mod_emit_advice.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp, vp, u64, vp]
+    L.h2r_pow_trace_emit_advice.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, u32, vp, u64, vp, u64, vp, vp, u64, vp]
     L.h2r_mul_mod_trace_check.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp, vp, vp, vp]
     L.h2r_pow_trace_check.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, vp, ctypes.c_char_p, ctypes.c_size_t, u32, vp, u64, vp, u64, vp,
                                       vp, vp, vp]

@@ -199,6 +199,25 @@ class BatchResult:
                                             chip._stream()), "h2r_pow_trace_check")
         return bad, first
 
+    def emit_advice(self) -> torch.Tensor:
+        """The 5-column advice image of every mul_mod record (h2r_*_emit_advice): uint8 [batch, T * rows * 160] in HBM,
+        row = 5 cells of 32 bytes (canonical elements of the chip's field); row shapes in DESIGN.md section 2b."""
+        chip = self.trace.chip
+        batch, dev = self.trace.batch, self.trace.buf.device
+        rows = int(lib().h2r_advice_rows(chip._ctx))
+        kind, a, b, n, eb = self.inputs
+        flags = chip._flags(n, batch)
+        T = self.trace.num_mul_mods
+        out = torch.empty((batch, T * rows * 160), dtype=torch.uint8, device=dev)
+        if kind == "mul_mod":
+            check(lib().h2r_mul_mod_emit_advice(chip._ctx, a.data_ptr(), b.data_ptr(), n.data_ptr(), flags, self.trace.buf.data_ptr(), batch,
+                                                self.status.data_ptr(), out.data_ptr(), out.shape[1], chip._stream()), "h2r_mul_mod_emit_advice")
+        else:
+            check(lib().h2r_pow_trace_emit_advice(chip._ctx, ctypes.byref(self.trace.pow_layout), n.data_ptr(), flags, self.trace.buf.data_ptr(),
+                                                  self.trace.elem_stride, self.workspace.data_ptr(), batch, self.status.data_ptr(),
+                                                  out.data_ptr(), out.shape[1], chip._stream()), "h2r_pow_trace_emit_advice")
+        return out
+
     def flatten(self, elem: int) -> np.ndarray:
         """The element's witness in the reference's assignment order (modpow_public_key: in-field stream, then pow)."""
         st = self.trace.flatten(elem)

@@ -1227,6 +1227,61 @@ int32_t h2r_pow_trace_emit_stream(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
     return launch_emit(ctx, ea, flags, static_cast<hipStream_t>(stream));
 }
 
+// ---- advice-column image ---------------------------------------------------------------------------------------
+uint32_t h2r_advice_rows(const h2r_ctx *ctx) { return ctx ? advice_rows_per_record(ctx->L, ctx->layout.carry_nsub) : 0; }
+
+namespace {
+int32_t launch_advice(const h2r_ctx *ctx, AdviceArgs &aa, hipStream_t st) {
+    const h2r_layout &lo = ctx->layout;
+    if (lo.num_limbs > 128 || lo.limb_nsub != 8 || lo.carry_nsub > 16) return H2R_E_UNSUPPORTED;
+    for (int p = 0; p < H2R_PL_COUNT; ++p) aa.off[p] = lo.plane_off[p];
+    aa.L = lo.num_limbs; aa.carry_bits = lo.carry_bits; aa.carry_sub_bits = lo.carry_sub_bits; aa.carry_nsub = lo.carry_nsub;
+    aa.carry_sub_stride = lo.carry_sub_stride; aa.record_stride = lo.record_stride;
+    aa.rows = h2r_advice_rows(ctx);
+    for (int k = 0; k < 4; ++k) aa.p[k] = ctx->field_p[k];
+    if (aa.out_stride < (u64)aa.T * aa.rows * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
+    if (aa.n_items == 0) return H2R_OK;
+    if (aa.n_items >= (1ull << 31)) return H2R_E_UNSUPPORTED;
+    ProfScope ps(H2R_KERNEL_EMIT, st, true);
+    if (lo.limb_width == 64) hipExtLaunchKernelGGL((advice_kernel<64>), dim3((unsigned)aa.n_items), dim3(256), 0, st, ps.a, ps.on ? ps.b : nullptr, 0, aa);
+    else hipExtLaunchKernelGGL((advice_kernel<32>), dim3((unsigned)aa.n_items), dim3(256), 0, st, ps.a, ps.on ? ps.b : nullptr, 0, aa);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
+}  // namespace
+
+int32_t h2r_mul_mod_emit_advice(const h2r_ctx *ctx, const void *a, const void *b, const void *n, uint32_t flags, const void *trace,
+                                uint64_t batch, const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
+    if (!ctx || !a || !b || !n || !trace || !advice_out) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    H2R_ON_DEVICE(ctx->params.device);
+    AdviceArgs aa;
+    std::memset(&aa, 0, sizeof aa);
+    aa.opA = a; aa.opB = b; aa.op_stride = ctx->L; aa.n = n; aa.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
+    aa.status = status; aa.trace = static_cast<const u8 *>(trace); aa.elem_stride = ctx->layout.record_stride; aa.off_records = 0;
+    aa.T = 1; aa.n_items = batch; aa.out = static_cast<u8 *>(advice_out); aa.out_stride = out_stride;
+    return launch_advice(ctx, aa, static_cast<hipStream_t>(stream));
+}
+
+int32_t h2r_pow_trace_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *n, uint32_t flags, const void *trace,
+                                  uint64_t elem_stride, const void *workspace, uint64_t batch, const uint8_t *status,
+                                  void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
+    if (!ctx || !pl || !n || !trace || !workspace || !advice_out) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    if (pl->num_mul_mods == 0 || batch == 0) return H2R_OK;
+    H2R_ON_DEVICE(ctx->params.device);
+    const u64 lb = ctx->layout.limb_bytes;
+    const u8 *ws = reinterpret_cast<const u8 *>(round_up(reinterpret_cast<u64>(workspace), 256));   // as run_path carves it
+    AdviceArgs aa;
+    std::memset(&aa, 0, sizeof aa);
+    aa.opA = ws; aa.opB = ws + ctx->L * lb; aa.op_stride = 4ull * ctx->L;
+    aa.n = n; aa.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
+    aa.status = status; aa.trace = static_cast<const u8 *>(trace); aa.elem_stride = elem_stride ? elem_stride : pl->elem_stride;
+    aa.off_records = pl->off_records; aa.T = pl->num_mul_mods; aa.n_items = batch * pl->num_mul_mods;
+    aa.out = static_cast<u8 *>(advice_out); aa.out_stride = out_stride;
+    return launch_advice(ctx, aa, static_cast<hipStream_t>(stream));
+}
+
 // ---- in-place audit ----------------------------------------------------------------------------------------
 namespace {
 int32_t launch_check(const h2r_ctx *ctx, CheckArgs &ca, const uint8_t *status, uint32_t *bad_out, uint32_t *first_bad_out,

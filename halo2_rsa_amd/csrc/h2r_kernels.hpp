@@ -2283,6 +2283,208 @@ __global__ __launch_bounds__(64) void link_kernel(LinkArgs a) {
     if (lane == 0 && nbad) { atomicAdd(&a.bad[elem], nbad); if (a.first_bad) atomicCAS(&a.first_bad[elem], 0u, where); }
 }
 
+// ================================================================================================
+// K9: advice-column image -- the witness as rows of the main gate's five advice columns (first step)
+//   The reference's prover consumes ADVICE COLUMNS of field elements: every main-gate op is a row of five cells
+//   (maingate's columns a..e), every RangeChip::assign a run of rows holding four sub-limbs and a running sum.  This
+//   kernel writes that image for every mul_mod record of a batch, in HBM, in the reference's op order, as canonical
+//   32-byte little-endian elements of the ctx's field (a_b negative -> p - |x|).  The third-party row shapes are NOT
+//   in /root/reference (maingate / halo2wrong, rev 63bde545): they are restated from SURVEY Appendix A and documented in
+//   DESIGN.md section 2b -- the VALUES are pinned by the flat-stream parity, the PLACEMENT is unpinned.
+//   Rows of one mul_mod (nr = ceil(8 / 4) = 2 rows per range-assigned limb, nrc = ceil(carry_nsub / 4) per carry):
+//     q limbs, r limbs     2L x nr   [s4r, s4r+1, s4r+2, s4r+3, running sum]            (chip.rs:588-599)
+//     mul(a,b), mul(q,n)   2 x L^2   [x_j, y_{i-j}, acc_prev, acc, 0]   column i, then j  (chip.rs:400-412, mul_add)
+//     eq_b                 L         [qn_i, r_i, eq_b_i, 0, 0]                           (chip.rs:617, add)
+//     per column i of is_equal_muled (chip.rs:857-893), 17 rows + the carry's range assign:
+//        0 sub            [ab_i, eqb_i, a_b, 0, 0]            1 add_with_constant [a_b, carry_i, sum, 0, 0]
+//        2..6 div_mod     [q] [r] [2^w, q, nq] [sum, nq, sum - nq] [r, sum - nq]          (chip.rs:1323-1349)
+//        7 add_constant   [acc_extra, acc_extra + W]          8..12 div_mod of it
+//        13 is_equal      [c, mod_acc, cs_acc_eq]             14 and [eq_bit, cs_acc_eq, eq_bit']
+//        i < C-1: nrc range rows of carry_{i+1}, then is_equal [carry, dup, range_eq], and [eq_bit', range_eq, eq_bit'']
+//        i = C-1: is_equal [carry, acc_extra, final_eq], and [eq_bit', final_eq, eq_bit'']
+//   One workgroup per record, one thread per row (ten 16-byte stores of 160 contiguous bytes).  Bound: HBM writes
+//   (554,400 bytes per RSA-2048 mul_mod: 8.6 x the flat stream -- what materialising field-element cells costs).
+// ================================================================================================
+template <int LW>
+struct RecView {   // reads of one record through the documented plane layout (include/h2r.h)
+    const u8 *rec; const u64 *off; u32 L;
+    static constexpr u32 CB = LW == 64 ? 16 : 8;
+    __device__ __forceinline__ U192 wide(int pl_lo, u32 idx) const {   // sign-extending
+        const u64 *lo = reinterpret_cast<const u64 *>(rec + off[pl_lo] + (u64)idx * 16);
+        if constexpr (LW == 64) return U192::make(lo[0], lo[1], *reinterpret_cast<const u64 *>(rec + off[pl_lo + 1] + (u64)idx * 8));
+        else return U192::make(lo[0], lo[1], (u64)((i64)lo[1] >> 63));
+    }
+    __device__ __forceinline__ u64 limb(int pl, u32 idx) const {
+        if constexpr (LW == 64) return *reinterpret_cast<const u64 *>(rec + off[pl] + (u64)idx * 8);
+        else return *reinterpret_cast<const u32 *>(rec + off[pl] + (u64)idx * 4);
+    }
+    __device__ __forceinline__ U192 carry(int pl, u32 idx) const {
+        const u64 *p = reinterpret_cast<const u64 *>(rec + off[pl] + (u64)idx * CB);
+        if constexpr (LW == 64) return U192::make(p[0], p[1], 0); else return U192::make(p[0], 0, 0);
+    }
+    __device__ __forceinline__ U192 acc(bool qn, u32 j, u32 im) const {   // accumulator entry (j, i % L)
+        if constexpr (LW == 64) {
+            const u64 *lo = reinterpret_cast<const u64 *>(rec + off[qn ? H2R_PL_QN_LO : H2R_PL_AB_LO] + (u64)(j >> 1) * (3ull * 2 * L * 16) + (u64)(j & 1) * (2ull * L * 16) + (u64)im * 16);
+            const u64 hi = *reinterpret_cast<const u64 *>(rec + off[qn ? H2R_PL_QN_HI : H2R_PL_AB_HI] + (u64)(j >> 1) * (3ull * 2 * L * 16) + (u64)im * 16 + (j & 1) * 8);
+            return U192::make(lo[0], lo[1], hi);
+        } else {
+            const u64 *lo = reinterpret_cast<const u64 *>(rec + off[qn ? H2R_PL_QN_LO : H2R_PL_AB_LO] + (u64)j * ((u64)L * 16) + (u64)im * 16);
+            return U192::make(lo[0], lo[1], 0);
+        }
+    }
+};
+
+struct AdviceArgs {
+    const void *opA, *opB; u64 op_stride; const void *n; u64 n_stride;
+    const u8 *status;
+    const u8 *trace; u64 elem_stride, off_records, record_stride; u32 T; u64 n_items;
+    u8 *out; u64 out_stride;            // element e's image at out + e * out_stride; record t at + t * rows * 160
+    u64 off[H2R_PL_COUNT];
+    u32 L, carry_bits, carry_sub_bits, carry_nsub, carry_sub_stride;
+    u32 rows;                           // rows of one record
+    u64 p[4];                           // field modulus
+};
+constexpr u32 ADVICE_ROW_BYTES = 160;
+__host__ __device__ inline u32 advice_rows_per_record(u32 L, u32 carry_nsub) {
+    const u32 C = 2 * L - 1, nrc = (carry_nsub + 3) / 4;
+    return 2 * L * 2 + 2 * L * L + L + (C - 1) * (17 + nrc) + 17;
+}
+
+template <int LW>
+__global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
+    using limb_t = typename LimbT<LW>::type;
+    __shared__ u64 sa[128], sb_[128], sq[128], sn[128], sr[128];
+    __shared__ uint4 stage[256 * (ADVICE_ROW_BYTES / 16)];   // 256 rows are built in LDS, then leave as full 16-byte-per-lane lines
+    const u32 tid = threadIdx.x;
+    const u32 item = blockIdx.x;
+    const u32 elem = item / a.T, t = item - elem * a.T;
+    if (a.status && a.status[elem]) return;
+    const u32 L = a.L, C = 2 * L - 1, nrc = (a.carry_nsub + 3) / 4;
+    const RecView<LW> rv{a.trace + (u64)elem * a.elem_stride + a.off_records + (u64)t * a.record_stride, a.off, L};
+    for (u32 k = tid; k < L; k += 256) {
+        const u64 ib = (u64)item * a.op_stride + k;
+        sa[k] = reinterpret_cast<const limb_t *>(a.opA)[ib]; sb_[k] = reinterpret_cast<const limb_t *>(a.opB)[ib];
+        sn[k] = reinterpret_cast<const limb_t *>(a.n)[(u64)elem * a.n_stride + k];
+        sq[k] = rv.limb(H2R_PL_Q, k); sr[k] = rv.limb(H2R_PL_R, k);
+    }
+    __syncthreads();
+    u8 *out = a.out + (u64)elem * a.out_stride + (u64)t * a.rows * ADVICE_ROW_BYTES;
+    const U192 Z = U192::make(0, 0, 0);
+    const U192 B = LW == 64 ? U192::make(0, 1, 0) : U192::make(1ull << 32, 0, 0);   // 2^w
+    auto cell = [&](u8 *p, const U192 &v, bool is_signed) {   // canonical field element, 32 bytes little-endian
+        u64 x[4] = {v.w[0], v.w[1], v.w[2], 0};
+        if (is_signed && (v.w[2] >> 63)) {   // x < 0 -> p + x (mod 2^256)
+            x[3] = ~0ull;
+            u64 cy = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const u64 s1 = x[k] + a.p[k]; const u64 c1 = s1 < x[k]; const u64 s2 = s1 + cy; cy = c1 | (u64)(s2 < s1); x[k] = s2; }
+        }
+        reinterpret_cast<uint4 *>(p)[0] = make_uint4((u32)x[0], (u32)(x[0] >> 32), (u32)x[1], (u32)(x[1] >> 32));
+        reinterpret_cast<uint4 *>(p)[1] = make_uint4((u32)x[2], (u32)(x[2] >> 32), (u32)x[3], (u32)(x[3] >> 32));
+    };
+    auto row = [&](u32 r, const U192 &c0, const U192 &c1, const U192 &c2, const U192 &c3, const U192 &c4, bool c2_signed = false, bool c0_signed = false) {
+        u8 *p = reinterpret_cast<u8 *>(stage) + (u64)(r & 255u) * ADVICE_ROW_BYTES;   // r - r0 == tid
+        cell(p, c0, c0_signed); cell(p + 32, c1, false); cell(p + 64, c2, c2_signed); cell(p + 96, c3, false); cell(p + 128, c4, false);
+    };
+    auto lim = [&](u64 v) { return U192::make(v, 0, 0); };
+    // a range assign's row: four sub-limbs and the running sum after them
+    auto range_row = [&](u32 r, u64 s_lo, u64 s_hi, u32 nsub, u32 sub_bits, u32 rr) {   // sub-limb bytes in (s_lo, s_hi), row rr of the assign
+        U192 c[4]; U192 run = Z;
+        for (u32 k = 0; k < 4 * (rr + 1) && k < nsub; ++k) {
+            const u64 sv = ((k < 8 ? s_lo : s_hi) >> (8 * (k & 7))) & 0xff;
+            const u32 sh = k * sub_bits;
+            U192 term = sh < 64 ? U192::make(sv << sh, sh ? sv >> (64 - sh) : 0, 0) : U192::make(0, sv << (sh - 64), 0);
+            run = run + term;
+            if (k >= 4 * rr) c[k - 4 * rr] = lim(sv);
+        }
+        for (u32 k = nsub > 4 * rr ? nsub - 4 * rr : 0; k < 4; ++k) c[k] = Z;
+        row(r, c[0], c[1], c[2], c[3], run);
+    };
+    const u32 r_T2 = 2 * L, r_T3 = 4 * L, r_T4 = r_T3 + L * L, r_T5 = r_T4 + L * L, r_T6 = r_T5 + L;
+    const u32 per_col = 17 + nrc;
+    for (u32 r0 = 0; r0 < a.rows; r0 += 256) {
+      const u32 r = r0 + tid;
+      if (r < a.rows) {
+        if (r < r_T3) {                                   // q then r limbs: RangeChip::assign(limb, w/8, w)
+            const bool isr = r >= r_T2; const u32 rr = (isr ? r - r_T2 : r);
+            const u32 k = rr >> 1;
+            const u64 sub = *reinterpret_cast<const u64 *>(rv.rec + a.off[isr ? H2R_PL_R_SUB : H2R_PL_Q_SUB] + (u64)k * 8);
+            range_row(r, sub, 0, 8, LW / 8, rr & 1);
+        } else if (r < r_T5) {                            // mul_add rows, column i ascending then j ascending
+            const bool qn = r >= r_T4; const u32 e = qn ? r - r_T4 : r - r_T3;
+            // entry e of the column order -> (i, j): columns 0..L-1 hold i+1 entries, then 2L-1-i
+            u32 i, j;
+            if (e < L * (L + 1) / 2) {
+                i = (u32)((__builtin_sqrtf(8.f * e + 1.f) - 1.f) * 0.5f);
+                while ((i + 1) * (i + 2) / 2 <= e) ++i;
+                while (i * (i + 1) / 2 > e) --i;
+                j = e - i * (i + 1) / 2;
+            } else {
+                i = L;
+                while (emit_colstart(i + 1, L) <= e) ++i;
+                j = e - emit_colstart(i, L) + (i - L + 1);
+            }
+            const u32 jmin = i >= L ? i - L + 1 : 0, im = i >= L ? i - L : i;
+            const u64 x = qn ? sq[j] : sa[j], y = qn ? sn[i - j] : sb_[i - j];
+            row(r, lim(x), lim(y), j == jmin ? Z : rv.acc(qn, j - 1, im), rv.acc(qn, j, im), Z);
+        } else if (r < r_T6) {                            // eq_b[i] = qn[i] + r[i]
+            const u32 i = r - r_T5;
+            row(r, rv.acc(true, i, i), lim(sr[i]), rv.wide(H2R_PL_EQB_LO, i), Z, Z);
+        } else {                                          // is_equal_muled step rows
+            const u32 rr = r - r_T6;
+            const u32 c = rr / per_col < C - 1 ? rr / per_col : C - 1, k = rr - c * per_col;
+            const u32 jmax = c < L ? c : L - 1, im = c < L ? c : c - L;
+            // (every case reads only what its row needs: the lanes of a wave sit in ~17 different cases)
+            auto SUM = [&] { return rv.wide(H2R_PL_SUM_LO, c); };
+            auto CY = [&] { return rv.carry(H2R_PL_CARRY, c); };
+            auto CMOD = [&] { return lim(rv.limb(H2R_PL_CMOD, c)); };
+            auto MODACC = [&] { return lim(rv.limb(H2R_PL_MODACC, c)); };
+            auto FL = [&] { return *reinterpret_cast<const u32 *>(rv.rec + a.off[H2R_PL_FLAGS] + (u64)c * 4); };
+            switch (k) {
+                case 0: row(r, rv.acc(false, jmax, im), c < L ? rv.wide(H2R_PL_EQB_LO, c) : rv.acc(true, jmax, im), rv.wide(H2R_PL_AMB_LO, c), Z, Z, true); break;
+                case 1: row(r, rv.wide(H2R_PL_AMB_LO, c), c ? rv.carry(H2R_PL_CARRY, c - 1) : Z, SUM(), Z, Z, false, true); break;
+                case 2: row(r, CY(), Z, Z, Z, Z); break;
+                case 3: row(r, CMOD(), Z, Z, Z, Z); break;
+                case 4: row(r, B, CY(), rv.wide(H2R_PL_NQ1_LO, c), Z, Z); break;
+                case 5: row(r, SUM(), rv.wide(H2R_PL_NQ1_LO, c), lim(rv.limb(H2R_PL_AMNQ1, c)), Z, Z); break;
+                case 6: row(r, CMOD(), lim(rv.limb(H2R_PL_AMNQ1, c)), Z, Z, Z); break;
+                case 7: row(r, c ? rv.carry(H2R_PL_QACC, c - 1) : Z, rv.wide(H2R_PL_ACCX_LO, c), Z, Z, Z); break;
+                case 8: row(r, rv.carry(H2R_PL_QACC, c), Z, Z, Z, Z); break;
+                case 9: row(r, MODACC(), Z, Z, Z, Z); break;
+                case 10: row(r, B, rv.carry(H2R_PL_QACC, c), rv.wide(H2R_PL_NQ2_LO, c), Z, Z); break;
+                case 11: row(r, rv.wide(H2R_PL_ACCX_LO, c), rv.wide(H2R_PL_NQ2_LO, c), lim(rv.limb(H2R_PL_AMNQ2, c)), Z, Z); break;
+                case 12: row(r, MODACC(), lim(rv.limb(H2R_PL_AMNQ2, c)), Z, Z, Z); break;
+                case 13: row(r, CMOD(), MODACC(), lim(FL() & 0xff), Z, Z); break;
+                case 14: {
+                    const u32 eprev = c ? (*reinterpret_cast<const u32 *>(rv.rec + a.off[H2R_PL_FLAGS] + (u64)(c - 1) * 4) >> 24) : 1u;
+                    const u32 fl = FL();
+                    row(r, lim(eprev), lim(fl & 0xff), lim((fl >> 8) & 0xff), Z, Z); break;
+                }
+                default: {
+                    if (c < C - 1 && k < 15 + nrc) {          // RangeChip::assign(carry, sublimb_bit_len(carry_bits), carry_bits)
+                        const ulonglong2 sv = *reinterpret_cast<const ulonglong2 *>(rv.rec + a.off[H2R_PL_CARRY_SUB] + (u64)c * a.carry_sub_stride);
+                        range_row(r, sv.x, sv.y, a.carry_nsub, a.carry_sub_bits, k - 15);
+                    } else if (k == (c < C - 1 ? 15 + nrc : 15)) {   // range_eq / final_carry_eq
+                        row(r, CY(), c < C - 1 ? rv.carry(H2R_PL_CARRY_DUP, c) : rv.carry(H2R_PL_QACC, c), lim((FL() >> 16) & 0xff), Z, Z);
+                    } else {
+                        const u32 fl = FL();
+                        row(r, lim((fl >> 8) & 0xff), lim((fl >> 16) & 0xff), lim(fl >> 24), Z, Z);
+                    }
+                }
+            }
+        }
+      }
+      __syncthreads();
+      const u32 n_rows = a.rows - r0 < 256 ? a.rows - r0 : 256;
+      uint4 *dst = reinterpret_cast<uint4 *>(out + (u64)r0 * ADVICE_ROW_BYTES);
+      for (u32 k = tid; k < n_rows * (ADVICE_ROW_BYTES / 16); k += 256) {
+          const uint4 v = stage[k];
+          st16(reinterpret_cast<u8 *>(dst + k), ((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z);
+      }
+      __syncthreads();
+    }
+}
+
 // stand-alone RangeChip::assign decomposition of a value array (8- or 16-byte values)
 struct DecompArgs {
     const u8 *values; u32 value_bytes; u64 count; u32 bit_len, sub_bits, nsub, has_ov;

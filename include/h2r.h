@@ -395,6 +395,28 @@ int32_t h2r_pow_trace_emit_stream(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
                                   uint64_t batch, uint32_t flags, void *stream_out, uint64_t out_stride,
                                   uint64_t out_off, h2r_stream_t stream);
 
+/* ---- advice-column image: the witness as rows of the main gate's five advice columns ---------------------------
+ * What a halo2 prover consumes (reference benches/bench.rs:141-142, 321-329 via RangeChip::assign / main_gate ops,
+ * big_integer/chip.rs:74, 408, 590, 598, 880-885) is not a value stream but advice columns of field elements.  These
+ * exports write, for every mul_mod record of a batch, the rows of a 5-column image in HBM: row = 5 cells (columns a..e)
+ * of 32 bytes, each the canonical little-endian element of the ctx's field; one row per main-gate op and
+ * ceil(sub-limbs / 4) rows per RangeChip::assign, in the reference's op order.  Row shapes: DESIGN.md section 2b.  The
+ * VALUES are the ones the flat stream pins; the third-party PLACEMENT (maingate / halo2wrong are not in the reference
+ * tree) is restated from SURVEY Appendix A and is unpinned.
+ *   h2r_advice_rows(ctx)            rows of one mul_mod (3,465 for RSA-2048 as 32 x 64-bit limbs)
+ *   element e's image starts at advice_out + e * out_stride; record t of the element at + t * rows * 160 bytes.
+ *   h2r_mul_mod_emit_advice         records of h2r_mul_mod_batch with the same a, b, n, flags
+ *   h2r_pow_trace_emit_advice       the records of a pow / modpow / verify trace; `workspace` is the workspace that call
+ *                                   was given (it holds every mul_mod's operands), elem_stride = 0 means pl->elem_stride. */
+#define H2R_ADVICE_ROW_BYTES 160u
+uint32_t h2r_advice_rows(const h2r_ctx *ctx);
+int32_t h2r_mul_mod_emit_advice(const h2r_ctx *ctx, const void *a, const void *b, const void *n, uint32_t flags,
+                                const void *trace, uint64_t batch, const uint8_t *status, void *advice_out,
+                                uint64_t out_stride, h2r_stream_t stream);
+int32_t h2r_pow_trace_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *n, uint32_t flags,
+                                  const void *trace, uint64_t elem_stride, const void *workspace, uint64_t batch,
+                                  const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream);
+
 /* ---- in-place audit of a trace (test / diagnosis instrument; not needed by a consumer) ---------------------
  * Checks, where the records lie in HBM, that every record is a valid witness of ITS mul_mod (sub-limb recomposition,
  * every accumulator = its predecessor + one limb product, eq_b, every is_equal_muled step against the stored previous

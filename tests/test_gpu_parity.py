@@ -397,6 +397,65 @@ def test_device_emit_stream_pow(H, w, L, e, var_bits):
                 pytest.fail("elem %d flags %d: first mismatch at byte %d of %d" % (i, flags, int(np.nonzero(host[i, :sb] != want)[0][0]), sb))
 
 
+@pytest.mark.parametrize("w,L,field", [(64, 32, "bn254_fr"), (32, 128, "pasta_fp"), (64, 12, "bn254_fq"), (64, 48, "pasta_fq"), (32, 8, "bn254_fr")])
+def test_advice_image(H, w, L, field):
+    """h2r_*_emit_advice: the 5-column advice image (rows of canonical field elements, one per main-gate op, four sub-limbs +
+    running sum per range-assign row) equals the image built in Python from the ORACLE's flat stream with the documented
+    row table (tests/advice_ref.py) -- for a mul_mod batch and for the records of a pow trace."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref as R
+    from advice_ref import advice_image_from_stream
+    from halo2_rsa_amd._lib import lib
+    chip = H.BigIntChip(w, w * L, field=field)
+    o = Oracle(w, L)
+    P = R.FIELD_MODULI[field]
+    rng = random.Random(3 * w + L)
+    batch = 3
+    N = [rand_modulus(rng, w * L, odd=(i != 1)) for i in range(batch)]
+    A = [rng.randrange(n) for n in N]
+    Bv = [rng.randrange(n) for n in N]
+    res = chip.mul_mod(chip.assign_integer(A), chip.assign_integer(Bv), chip.assign_integer(N))
+    img = res.emit_advice()
+    torch.cuda.synchronize()
+    rows = int(lib().h2r_advice_rows(chip._ctx))
+    assert img.shape == (batch, rows * 160)
+    if (w, L) == (64, 32):
+        assert rows == 3465
+    host = img.cpu().numpy()
+    for i in range(batch):
+        rc, rr, ost = o.mul_mod(o.limbs(A[i]), o.limbs(Bv[i]), o.limbs(N[i]))
+        want = advice_image_from_stream(o.p, [int(v) for v in o.limbs(A[i])], [int(v) for v in o.limbs(Bv[i])],
+                                        [int(v) for v in o.limbs(N[i])], ost, P)
+        assert want.shape == (rows, 160)
+        got = host[i].reshape(rows, 160)
+        if not np.array_equal(got, want):
+            bad = np.argwhere(got != want)[0]
+            pytest.fail("w=%d L=%d elem %d: row %d cell %d differs" % (w, L, i, int(bad[0]), int(bad[1]) // 32))
+    # the records of a pow trace (operands from the call's workspace)
+    e = 0b1011
+    pres = chip.pow_mod_fixed_exp(chip.assign_integer(A), e, chip.assign_integer(N))
+    pimg = pres.emit_advice().cpu().numpy()
+    T = pres.trace.num_mul_mods
+    rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(A[0]), o.limbs(N[0]), e)
+    msb = o.mul_mod_stream_bytes
+    acc, cur, t = 1, A[0], 0
+    for bit in [(e >> k) & 1 for k in range(e.bit_length())]:
+        ops = [(cur, cur)] + ([(acc, cur)] if bit else [])
+        nxt = cur * cur % N[0]
+        for (x, y) in ops:
+            want = advice_image_from_stream(o.p, [int(v) for v in o.limbs(x)], [int(v) for v in o.limbs(y)],
+                                            [int(v) for v in o.limbs(N[0])], ost[t * msb:(t + 1) * msb], P)
+            got = pimg[0, t * rows * 160:(t + 1) * rows * 160].reshape(rows, 160)
+            assert np.array_equal(got, want), ("pow record", t)
+            t += 1
+        if bit:
+            acc = acc * cur % N[0]
+        cur = nxt
+    assert t == T
+
+
 def test_shared_modulus(H):
     """One key, many signatures (H2R_F_SHARED_MODULUS)."""
     chip = H.BigIntChip(64, 2048)

@@ -32,3 +32,17 @@ wr = B * sb
 rd = B * tr.num_mul_mods * chip.layout.stream_bytes   # algorithmic bytes of the records read
 print("emit_kernel %s batch %d flags %d: %.3f ms per launch (min %.3f)  stream written %.2f TB/s, read+written %.2f TB/s  (%d B/element)"
       % (wl, B, flags, avg, min(ms), wr / avg / 1e9, (wr + rd) / avg / 1e9, sb))
+# the 5-column advice image of the same trace (advice_kernel): 160-byte rows of field elements
+if len(sys.argv) <= 4 or sys.argv[4] != "noadvice":
+    img = res.emit_advice(); torch.cuda.synchronize()
+    nbytes = img.numel()
+    del img
+    _lib.profile_enable(16)
+    for _ in range(3):
+        img = res.emit_advice(); del img
+    torch.cuda.synchronize()
+    ms = _lib.profile_read(_lib.KERNEL_EMIT)
+    _lib.profile_enable(0)
+    avg = sum(ms) / len(ms)
+    print("advice_kernel %s batch %d: %.3f ms per launch (min %.3f)  image written %.2f TB/s  (%d rows x 160 B per mul_mod, %.2f MB per element)"
+          % (wl, B, avg, min(ms), nbytes / avg / 1e9, int(_lib.lib().h2r_advice_rows(chip._ctx)), nbytes / B / 1e6))
