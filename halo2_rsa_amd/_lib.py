@@ -14,7 +14,7 @@ PLANES = ["Q", "R", "Q_SUB", "R_SUB", "AB_LO", "AB_HI", "QN_LO", "QN_HI", "EQB_L
 assert len(PLANES) == H2R_PL_COUNT
 
 H2R_OK, H2R_E_SHAPE, H2R_E_ZERO_MODULUS, H2R_E_NOT_REDUCED, H2R_E_FIELD_TOO_SMALL, H2R_E_HIP, H2R_E_UNSUPPORTED, \
-    H2R_E_NULL, H2R_E_NOT_IN_FIELD = range(9)
+    H2R_E_NULL, H2R_E_NOT_IN_FIELD, H2R_E_ASSERTION = range(10)
 FIELDS = {"bn254_fr": 0, "bn254_fq": 1, "pasta_fp": 2, "pasta_fq": 3}
 H2R_F_SHARED_MODULUS = 1
 

@@ -272,6 +272,77 @@ class BigIntChip:
         t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int64 if self.limb_width == 64 else np.int32))
         return AssignedInteger(t.to("cuda:%d" % self.device).contiguous(), self.limb_width)
 
+    def assign_constant(self, value: int, num_limbs: int, batch: int = 1) -> AssignedInteger:
+        """big_integer/chip.rs:1252-1281: ceil(bits / limb_width) limbs of the constant, then the shared zero cell up to
+        num_limbs (asserts that the value fits); the same constant for every element of the batch."""
+        value = int(value)
+        assert value >= 0 and value >> (self.limb_width * num_limbs) == 0      # :1266
+        arr = UnassignedInteger.from_ints([value] * batch, num_limbs, self.limb_width).limbs
+        t = torch.from_numpy(np.ascontiguousarray(arr).view(np.int64 if self.limb_width == 64 else np.int32))
+        return AssignedInteger(t.to("cuda:%d" % self.device).contiguous(), self.limb_width)
+
+    def assign_constant_fresh(self, value: int, batch: int = 1) -> AssignedInteger:
+        """big_integer/chip.rs:95-101 (instructions.rs:16): the constant as a num_limbs-limb Fresh integer."""
+        return self.assign_constant(value, self.num_limbs, batch)
+
+    def assign_constant_muled(self, value: int, num_limbs_l: int, num_limbs_r: int, batch: int = 1) -> "MuledResult":
+        """big_integer/chip.rs:119-127 (instructions.rs:23): the constant as a Muled integer of n_l + n_r - 1 limbs of
+        limb_width bits each (here n_l = n_r = num_limbs: the 2L-column Muled container of this chip)."""
+        assert num_limbs_l == self.num_limbs and num_limbs_r == self.num_limbs
+        nl = 2 * self.num_limbs - 1
+        value = int(value)
+        assert value >> (self.limb_width * nl) == 0
+        cols = np.zeros((batch, 2 * self.num_limbs, 4), dtype=np.uint64)
+        m = (1 << self.limb_width) - 1
+        for i in range(nl):
+            cols[:, i, 0] = (value >> (self.limb_width * i)) & m
+        return MuledResult(torch.from_numpy(cols.view(np.int64)).to("cuda:%d" % self.device), None, self)
+
+    def max_value(self, num_limbs: Optional[int] = None, batch: int = 1) -> AssignedInteger:
+        """big_integer/chip.rs:138-154 (instructions.rs:32): every limb = 2^limb_width - 1."""
+        nl = self.num_limbs if num_limbs is None else num_limbs
+        return self.assign_constant((1 << (self.limb_width * nl)) - 1, nl, batch)
+
+    # ---- assert_* (instructions.rs:197-254): the predicate, then main_gate.assert_one on its bit -- a violated assertion
+    # makes the reference's circuit unsatisfiable; here the element's status becomes H2R_E_ASSERTION ------------------------
+    def _assert(self, res: "FreshResult") -> "FreshResult":
+        viol = (res.flag == 0) & (res.status == 0)
+        res.status = torch.where(viol, torch.full_like(res.status, _lib.H2R_E_ASSERTION), res.status)
+        return res
+
+    def assert_zero(self, a):
+        """big_integer/chip.rs:1020-1028."""
+        return self._assert(self.is_zero(a))
+
+    def assert_equal_fresh(self, a, b):
+        """big_integer/chip.rs:1034-1042."""
+        return self._assert(self.is_equal_fresh(a, b))
+
+    def assert_equal_muled(self, a: "MuledResult", b: "MuledResult"):
+        """big_integer/chip.rs:1053-1063 -> (status uint8[batch], trace)."""
+        eq, trace = self.is_equal_muled(a, b)
+        return torch.where(eq == 0, torch.full_like(eq, _lib.H2R_E_ASSERTION), torch.zeros_like(eq)), trace
+
+    def assert_less_than(self, a, b):
+        """big_integer/chip.rs:1074-1082."""
+        return self._assert(self.is_less_than(a, b))
+
+    def assert_less_than_or_equal(self, a, b):
+        """big_integer/chip.rs:1093-1101."""
+        return self._assert(self.is_less_than_or_equal(a, b))
+
+    def assert_greater_than(self, a, b):
+        """big_integer/chip.rs:1112-1120."""
+        return self._assert(self.is_greater_than(a, b))
+
+    def assert_greater_than_or_equal(self, a, b):
+        """big_integer/chip.rs:1131-1139."""
+        return self._assert(self.is_greater_than_or_equal(a, b))
+
+    def assert_in_field(self, a, n):
+        """big_integer/chip.rs:1150-1158."""
+        return self._assert(self.is_in_field(a, n))
+
     def range_check_sublimbs(self, integer: AssignedInteger) -> torch.Tensor:
         """The RangeChip::assign(limb, limb_width/8, limb_width) decomposition that assign_integer performs for
         every limb of an input integer (big_integer/chip.rs:71-76): uint8 [batch, num_limbs, 8] sub-limbs."""

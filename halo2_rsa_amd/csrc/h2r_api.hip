@@ -1428,11 +1428,14 @@ int32_t h2r_refresh_batch(const h2r_ctx *ctx, const uint64_t *muled, uint64_t ba
     ra.muled = muled; ra.batch = batch; ra.L = ctx->L; ra.nf = ctx->refresh_nf; ra.inc = ctx->refresh_inc_dev;
     ra.trace = static_cast<u8 *>(trace); ra.elem_stride = round_up(h2r_refresh_stream_bytes(ctx), 256);
     ra.fresh_out = fresh_out; ra.status = status; ra.WB = ctx->layout.wide_bytes; ra.CB = ctx->layout.carry_bytes;
+    ra.stream_bytes = (u32)h2r_refresh_stream_bytes(ctx);
+    const unsigned stage = (unsigned)round_up(ra.stream_bytes, 16) + 32;
+    if (stage > 60 * 1024) return H2R_E_UNSUPPORTED;
     H2R_ON_DEVICE(ctx->params.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     ProfScope ps(H2R_KERNEL_AUX, st);
-    if (ctx->layout.limb_width == 64) hipLaunchKernelGGL((refresh_kernel<64>), dim3((unsigned)batch), dim3(64), 0, st, ra);
-    else hipLaunchKernelGGL((refresh_kernel<32>), dim3((unsigned)batch), dim3(64), 0, st, ra);
+    if (ctx->layout.limb_width == 64) hipLaunchKernelGGL((refresh_kernel<64>), dim3((unsigned)batch), dim3(64), stage, st, ra);
+    else hipLaunchKernelGGL((refresh_kernel<32>), dim3((unsigned)batch), dim3(64), stage, st, ra);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
 }
@@ -1512,6 +1515,7 @@ const char *h2r_status_str(int32_t s) {
         case H2R_E_UNSUPPORTED: return "unsupported shape";
         case H2R_E_NULL: return "null pointer";
         case H2R_E_NOT_IN_FIELD: return "x >= n";
+        case H2R_E_ASSERTION: return "an assert_* constraint does not hold";
         default: return "unknown";
     }
 }

@@ -1623,6 +1623,7 @@ struct RefreshArgs {
     void *fresh_out;      // [elem][2L] limbs (nullable)
     u8 *status;
     u32 WB, CB;
+    u32 stream_bytes;     // flat-stream bytes of one element (<= elem_stride)
 };
 
 template <int LW>
@@ -1630,6 +1631,7 @@ __global__ __launch_bounds__(64) void refresh_kernel(RefreshArgs a) {
     using limb_t = typename LimbT<LW>::type;
     constexpr u32 LB = LW / 8;
     __shared__ u64 r0[2 * 128 + 8], r1[2 * 128 + 8]; __shared__ u32 r2[2 * 128 + 8];   // running limbs (3 words)
+    extern __shared__ uint4 refresh_stage[];   // the element's flat stream, assembled here (stream_bytes rounded up to 16)
     const int lane = threadIdx.x;
     const u64 elem = blockIdx.x;
     const u32 C = 2 * a.L - 1, nf = a.nf;
@@ -1639,11 +1641,18 @@ __global__ __launch_bounds__(64) void refresh_kernel(RefreshArgs a) {
         r0[p] = in ? m[0] : 0; r1[p] = in ? m[1] : 0; r2[p] = in ? (u32)m[2] : 0;
     }
     wave_sync();
-    int status = H2R_OK;
+    // The second-order carry recurrence is sequential (every chunk cut off limb i lands in limbs i+1 / i+2 before those
+    // are cut): lane 0 walks it and writes the stream into LDS -- a few cycles per value instead of a dependent global store
+    // each (about 1,500 of them per RSA-2048 element) -- and the whole wave then copies the stream out as 16-byte lines.
     if (lane == 0) {
-        u8 *o = a.trace + elem * a.elem_stride;
-        auto put = [&](u64 w0, u64 w1, u64 w2, u32 nbytes) {   // little-endian value of nbytes (4, 8, 16 or 24)
-            if (nbytes == 4) { pst4(o, (u32)w0); } else { pst8(o, w0); if (nbytes >= 16) pst8(o + 8, w1); if (nbytes >= 24) pst8(o + 16, w2); }
+        int status = H2R_OK;
+        u8 *o = reinterpret_cast<u8 *>(refresh_stage);
+        auto put = [&](u64 w0, u64 w1, u64 w2, u32 nbytes) {   // little-endian value of nbytes (4, 8, 16 or 24); 4-byte granular
+            u32 *d = reinterpret_cast<u32 *>(o);
+            d[0] = (u32)w0;
+            if (nbytes >= 8) d[1] = (u32)(w0 >> 32);
+            if (nbytes >= 16) { d[2] = (u32)w1; d[3] = (u32)(w1 >> 32); }
+            if (nbytes >= 24) { d[4] = (u32)w2; d[5] = (u32)(w2 >> 32); }
             o += nbytes;
         };
         for (u32 i = 0; i < nf; ++i) {
@@ -1673,12 +1682,15 @@ __global__ __launch_bounds__(64) void refresh_kernel(RefreshArgs a) {
             const u64 v = r0[i];
             put(v, 0, 0, LB);
             const u64 sb = limb_sub_bytes<LW>(v);
-            if constexpr (LW == 64) { pst8(o, sb); } else { pst4(o, (u32)sb); pst4(o + 4, (u32)(sb >> 32)); }
-            o += 8;
-            if (a.fresh_out) reinterpret_cast<limb_t *>(a.fresh_out)[elem * nf + i] = (limb_t)v;
+            put(sb, 0, 0, 8);
         }
         a.status[elem] = (u8)status;
     }
+    wave_sync();
+    u8 *dst = a.trace + elem * a.elem_stride;
+    for (u32 k = lane; k < (a.stream_bytes + 15) / 16; k += 64) { const uint4 v = refresh_stage[k]; pst16(dst + 16ull * k, ((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z); }
+    if (a.fresh_out)
+        for (u32 i = lane; i < nf; i += 64) reinterpret_cast<limb_t *>(a.fresh_out)[elem * nf + i] = (limb_t)r0[i];
 }
 
 // ================================================================================================

@@ -95,6 +95,28 @@ struct BatchResult {
     std::vector<uint8_t> status;  // H2R_* per element
 };
 
+// result of a Fresh-integer op (add / sub / add_mod / sub_mod / comparisons): value where the op has one, the
+// predicate / overflow bit, the per-element status and the op's witness (flat stream via flatten())
+struct FreshResult {
+    DeviceBuffer value; size_t value_limbs = 0;
+    std::vector<uint8_t> flag, status;
+    DeviceBuffer trace; uint64_t elem_stride = 0, stream_bytes = 0; uint32_t op = 0; const h2r_ctx *ctx = nullptr; size_t batch = 0;
+    std::vector<uint64_t> limbs() const { std::vector<uint64_t> h(batch * value_limbs); if (!h.empty()) value.download(h.data(), h.size() * 8); return h; }
+    std::vector<uint8_t> flatten(size_t elem) const {
+        std::vector<uint8_t> host(elem_stride), out(stream_bytes);
+        trace.download(host.data(), host.size(), elem * elem_stride);
+        check(h2r_fresh_op_flatten(ctx, op, host.data(), out.data()), "h2r_fresh_op_flatten");
+        return out;
+    }
+};
+
+// reference src/big_integer/mod.rs:216-232, 306-382 (range type Muled): the un-carried product columns, 2L columns of
+// 4 x u64 per element (column 2L-1 is zero), plus the accumulator trace of the mul that produced them (if any)
+struct MuledInteger {
+    DeviceBuffer cols; size_t batch = 0, num_limbs = 0;   // num_limbs = L of the operands
+    DeviceBuffer trace;                                   // one record per element (AB planes written), may be empty
+};
+
 // reference src/big_integer/chip.rs:42-51, 1161-1249
 class BigIntChip {
   public:
@@ -126,6 +148,91 @@ class BigIntChip {
         d.upload(integer.limbs.data(), integer.limbs.size() * 8);
         return AssignedInteger(std::move(d), integer.batch, integer.num_limbs);
     }
+    // big_integer/chip.rs:1252-1281 (assign_constant): `limbs` = the constant's little-endian 64-bit limbs (at most
+    // num_limbs of them: the reference asserts that the value fits, :1266); the same constant for every batch element
+    AssignedInteger assign_constant(const std::vector<uint64_t> &limbs, size_t num_limbs, size_t batch = 1) const {
+        if (limbs.size() > num_limbs) throw Error(H2R_E_SHAPE, "assign_constant");
+        std::vector<uint64_t> h(batch * num_limbs, 0);
+        for (size_t e = 0; e < batch; ++e) std::copy(limbs.begin(), limbs.end(), h.begin() + e * num_limbs);
+        return assign_integer(UnassignedInteger::from(std::move(h), batch, num_limbs));
+    }
+    // instructions.rs:16 / big_integer/chip.rs:95-101
+    AssignedInteger assign_constant_fresh(const std::vector<uint64_t> &limbs, size_t batch = 1) const { return assign_constant(limbs, num_limbs_, batch); }
+    // instructions.rs:23 / big_integer/chip.rs:119-127: n_l + n_r - 1 limbs of limb_width bits, as Muled columns
+    MuledInteger assign_constant_muled(const std::vector<uint64_t> &limbs, size_t num_limbs_l, size_t num_limbs_r, size_t batch = 1) const {
+        if (num_limbs_l != num_limbs_ || num_limbs_r != num_limbs_ || limbs.size() > 2 * num_limbs_ - 1) throw Error(H2R_E_SHAPE, "assign_constant_muled");
+        std::vector<uint64_t> h(batch * 2 * num_limbs_ * 4, 0);
+        for (size_t e = 0; e < batch; ++e)
+            for (size_t i = 0; i < limbs.size(); ++i) h[(e * 2 * num_limbs_ + i) * 4] = limbs[i];
+        MuledInteger m; m.cols = DeviceBuffer(h.size() * 8); m.cols.upload(h.data(), h.size() * 8); m.batch = batch; m.num_limbs = num_limbs_;
+        return m;
+    }
+    // instructions.rs:32 / big_integer/chip.rs:138-154: every limb = 2^limb_width - 1
+    AssignedInteger max_value(size_t num_limbs, size_t batch = 1) const { return assign_constant(std::vector<uint64_t>(num_limbs, ~0ull), num_limbs, batch); }
+
+    // ---- the Fresh-integer family (instructions.rs:47-60, 78-95, 132-145, 157-195) ----------------------------------------
+    FreshResult add(const AssignedInteger &a, const AssignedInteger &b) const { return fresh(H2R_OP_ADD, a, &b, nullptr); }                    // chip.rs:245-297
+    FreshResult sub(const AssignedInteger &a, const AssignedInteger &b) const { return fresh(H2R_OP_SUB, a, &b, nullptr); }                    // chip.rs:310-373
+    FreshResult add_mod(const AssignedInteger &a, const AssignedInteger &b, const AssignedInteger &n) const { return fresh(H2R_OP_ADD_MOD, a, &b, &n); }   // :452-481
+    FreshResult sub_mod(const AssignedInteger &a, const AssignedInteger &b, const AssignedInteger &n) const { return fresh(H2R_OP_SUB_MOD, a, &b, &n); }   // :495-528
+    FreshResult is_zero(const AssignedInteger &a) const { return fresh(H2R_OP_IS_ZERO, a, nullptr, nullptr); }                                 // chip.rs:754-767
+    FreshResult is_equal_fresh(const AssignedInteger &a, const AssignedInteger &b) const { return fresh(H2R_OP_IS_EQUAL_FRESH, a, &b, nullptr); }   // :780-805
+    FreshResult is_less_than(const AssignedInteger &a, const AssignedInteger &b) const { return fresh(H2R_OP_IS_LESS_THAN, a, &b, nullptr); }       // :908-919
+    FreshResult is_less_than_or_equal(const AssignedInteger &a, const AssignedInteger &b) const { return fresh(H2R_OP_IS_LESS_THAN_OR_EQUAL, a, &b, nullptr); }
+    FreshResult is_greater_than(const AssignedInteger &a, const AssignedInteger &b) const { return fresh(H2R_OP_IS_GREATER_THAN, a, &b, nullptr); }
+    FreshResult is_greater_than_or_equal(const AssignedInteger &a, const AssignedInteger &b) const { return fresh(H2R_OP_IS_GREATER_THAN_OR_EQUAL, a, &b, nullptr); }
+    FreshResult is_in_field(const AssignedInteger &a, const AssignedInteger &n) const { return fresh(H2R_OP_IS_IN_FIELD, a, &n, nullptr); }         // :998-1006
+    // assert_* (instructions.rs:197-254, chip.rs:1020-1158): the predicate, then main_gate.assert_one on its bit; an
+    // element whose assertion does not hold gets status H2R_E_ASSERTION (the reference's circuit is unsatisfiable)
+    FreshResult assert_zero(const AssignedInteger &a) const { return asserted(is_zero(a)); }
+    FreshResult assert_equal_fresh(const AssignedInteger &a, const AssignedInteger &b) const { return asserted(is_equal_fresh(a, b)); }
+    FreshResult assert_less_than(const AssignedInteger &a, const AssignedInteger &b) const { return asserted(is_less_than(a, b)); }
+    FreshResult assert_less_than_or_equal(const AssignedInteger &a, const AssignedInteger &b) const { return asserted(is_less_than_or_equal(a, b)); }
+    FreshResult assert_greater_than(const AssignedInteger &a, const AssignedInteger &b) const { return asserted(is_greater_than(a, b)); }
+    FreshResult assert_greater_than_or_equal(const AssignedInteger &a, const AssignedInteger &b) const { return asserted(is_greater_than_or_equal(a, b)); }
+    FreshResult assert_in_field(const AssignedInteger &a, const AssignedInteger &n) const { return asserted(is_in_field(a, n)); }
+
+    // ---- Muled integers (instructions.rs:39-45, 63-76, 147-155, 212-220) --------------------------------------------------
+    // big_integer/chip.rs:386-419 (square = mul(a, a), :431-437)
+    MuledInteger mul(const AssignedInteger &a, const AssignedInteger &b) const {
+        const size_t batch = a.batch();
+        MuledInteger m; m.cols = DeviceBuffer(batch * 2 * num_limbs_ * 4 * 8); m.trace = DeviceBuffer(batch * layout_.record_stride);
+        m.batch = batch; m.num_limbs = num_limbs_;
+        hip_check(hipMemset(m.cols.get(), 0, m.cols.size()), "hipMemset");
+        check(h2r_mul_batch(ctx_, a.data(), b.data(), batch, m.trace.get(), static_cast<uint64_t *>(m.cols.get()), nullptr), "mul");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        return m;
+    }
+    MuledInteger square(const AssignedInteger &a) const { return mul(a, a); }
+    // big_integer/chip.rs:822-895: the eq bit per element (and the step witness in `trace_out`, one record per element)
+    std::vector<uint8_t> is_equal_muled(const MuledInteger &a, const MuledInteger &b, DeviceBuffer *trace_out = nullptr) const {
+        const size_t batch = a.batch;
+        DeviceBuffer trace(batch * layout_.record_stride), eq(batch);
+        check(h2r_is_equal_muled_batch(ctx_, static_cast<const uint64_t *>(a.cols.get()), static_cast<const uint64_t *>(b.cols.get()), batch,
+                                       trace.get(), static_cast<uint8_t *>(eq.get()), nullptr), "is_equal_muled");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        std::vector<uint8_t> bits(batch); eq.download(bits.data(), batch);
+        if (trace_out) *trace_out = std::move(trace);
+        return bits;
+    }
+    // big_integer/chip.rs:1053-1063: status H2R_E_ASSERTION where the bit is 0
+    std::vector<uint8_t> assert_equal_muled(const MuledInteger &a, const MuledInteger &b) const {
+        std::vector<uint8_t> st = is_equal_muled(a, b);
+        for (auto &v : st) v = v ? (uint8_t)H2R_OK : (uint8_t)H2R_E_ASSERTION;
+        return st;
+    }
+    // big_integer/chip.rs:168-233 with RefreshAux::new(limb_width, L, L): 2L Fresh limbs per element
+    std::pair<AssignedInteger, std::vector<uint8_t>> refresh(const MuledInteger &a, DeviceBuffer *stream_out = nullptr) const {
+        const size_t batch = a.batch;
+        const uint64_t stride = (h2r_refresh_stream_bytes(ctx_) + 255) / 256 * 256;
+        DeviceBuffer trace(batch * stride), fresh(batch * 2 * num_limbs_ * 8), st(batch);
+        check(h2r_refresh_batch(ctx_, static_cast<const uint64_t *>(a.cols.get()), batch, trace.get(), fresh.get(), static_cast<uint8_t *>(st.get()), nullptr), "refresh");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        std::vector<uint8_t> status(batch); st.download(status.data(), batch);
+        if (stream_out) *stream_out = std::move(trace);
+        return {AssignedInteger(std::move(fresh), batch, 2 * num_limbs_), std::move(status)};
+    }
+
     // big_integer/chip.rs:542-629
     BatchResult mul_mod(const AssignedInteger &a, const AssignedInteger &b, const AssignedInteger &n) const {
         if (a.num_limbs() != n.num_limbs() || a.num_limbs() != num_limbs_) throw Error(H2R_E_SHAPE, "mul_mod");  // :555
@@ -148,6 +255,26 @@ class BigIntChip {
 
   private:
     static uint32_t flags(const AssignedInteger &n, size_t batch) { return (n.batch() == 1 && batch != 1) ? H2R_F_SHARED_MODULUS : 0u; }
+    FreshResult fresh(uint32_t op, const AssignedInteger &a, const AssignedInteger *b, const AssignedInteger *n) const {
+        FreshResult r; uint32_t vl = 0;
+        check(h2r_fresh_op_layout(ctx_, op, &r.elem_stride, &r.stream_bytes, &vl), "h2r_fresh_op_layout");
+        const size_t batch = a.batch();
+        r.op = op; r.ctx = ctx_; r.batch = batch; r.value_limbs = vl;
+        r.trace = DeviceBuffer(batch * r.elem_stride); r.value = DeviceBuffer(batch * vl * 8);
+        DeviceBuffer fl(batch), st(batch);
+        hip_check(hipMemset(r.trace.get(), 0, batch * r.elem_stride), "hipMemset");
+        check(h2r_fresh_op_batch(ctx_, op, a.data(), b ? b->data() : nullptr, n ? n->data() : nullptr, batch, n ? flags(*n, batch) : 0u,
+                                 r.trace.get(), vl ? r.value.get() : nullptr, static_cast<uint8_t *>(fl.get()), static_cast<uint8_t *>(st.get()), nullptr),
+              "h2r_fresh_op_batch");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        r.flag.resize(batch); r.status.resize(batch);
+        fl.download(r.flag.data(), batch); st.download(r.status.data(), batch);
+        return r;
+    }
+    static FreshResult asserted(FreshResult r) {
+        for (size_t i = 0; i < r.status.size(); ++i) if (r.status[i] == H2R_OK && !r.flag[i]) r.status[i] = H2R_E_ASSERTION;
+        return r;
+    }
     // in_field != nullptr: RSAChip::modpow_public_key (assert_in_field witness into *in_field, status H2R_E_NOT_IN_FIELD)
     BatchResult pow_fixed(const AssignedInteger &a, const std::vector<uint8_t> &e_le, const AssignedInteger &n, DeviceBuffer *in_field) const {
         h2r_pow_layout pl;

@@ -127,6 +127,36 @@ int main(int argc, char **argv) {
             REQUIRE(mp.flatten(i) == want);
         }
     }
+    // The rest of BigIntInstructions through the mirror, in the style of the reference's tests (operands against assigned
+    // constants, big_integer/chip.rs:1470-1660, 2797-2870): add / sub / comparisons / assert_*, mul vs a Muled constant,
+    // refresh(mul(a, b)) = a * b
+    {
+        std::vector<uint64_t> n(kats[0].n), small(32, 0); small[0] = 7;
+        AssignedInteger an = bigint_chip.assign_integer(UnassignedInteger::from(n, 1, 32));
+        AssignedInteger seven = bigint_chip.assign_constant_fresh({7});
+        AssignedInteger five = bigint_chip.assign_constant_fresh({5});
+        REQUIRE(seven.limbs() == small);
+        FreshResult s = bigint_chip.add(seven, five);
+        REQUIRE(s.status[0] == H2R_OK && s.limbs()[0] == 12 && s.value_limbs == 33);
+        std::vector<uint8_t> st(h2ro_fresh_op_stream_bytes(&op, H2RO_OP_ADD)); std::vector<uint64_t> vout(40); uint32_t nv = 0; int fl = -1;
+        std::vector<uint64_t> five_l(32, 0); five_l[0] = 5;
+        REQUIRE(h2ro_fresh_op(&op, H2RO_OP_ADD, small.data(), five_l.data(), nullptr, st.data(), vout.data(), &nv, &fl) == 0);
+        REQUIRE(s.flatten(0) == st);
+        REQUIRE(bigint_chip.is_less_than(five, seven).flag[0] == 1 && bigint_chip.is_less_than(seven, five).flag[0] == 0);
+        REQUIRE(bigint_chip.assert_less_than(five, seven).status[0] == H2R_OK);
+        REQUIRE(bigint_chip.assert_less_than(seven, five).status[0] == H2R_E_ASSERTION);
+        REQUIRE(bigint_chip.assert_in_field(seven, an).status[0] == H2R_OK);
+        REQUIRE(bigint_chip.assert_equal_fresh(seven, five).status[0] == H2R_E_ASSERTION);
+        REQUIRE(bigint_chip.assert_zero(bigint_chip.assign_constant_fresh({})).status[0] == H2R_OK);
+        REQUIRE(bigint_chip.sub_mod(five, seven, an).status[0] == H2R_OK);
+        std::vector<uint64_t> mx = bigint_chip.max_value(32).limbs();
+        REQUIRE(mx == std::vector<uint64_t>(32, ~0ull));
+        MuledInteger prod = bigint_chip.mul(seven, five);
+        REQUIRE(bigint_chip.assert_equal_muled(prod, bigint_chip.assign_constant_muled({35}, 32, 32))[0] == H2R_OK);
+        REQUIRE(bigint_chip.assert_equal_muled(prod, bigint_chip.assign_constant_muled({36}, 32, 32))[0] == H2R_E_ASSERTION);
+        auto fr = bigint_chip.refresh(bigint_chip.square(an));
+        REQUIRE(fr.second[0] == H2R_OK && fr.first.num_limbs() == 64);
+    }
     // BigIntChip::new asserts bits_len % limb_width == 0 (big_integer/chip.rs:1175) -> exception
     bool threw = false;
     try { BigIntChip bad(64, 2048 + 8); } catch (const Error &e) { threw = e.code == H2R_E_SHAPE; }

@@ -1148,6 +1148,43 @@ def test_fresh_integer_family(H, w, L):
             assert fl == [int(A[i] >= B[i]) for i in range(10)]
 
 
+def test_constants_max_value_and_assertions(H):
+    """instructions.rs:16-32, 197-254: assign_constant_fresh / assign_constant_muled / max_value and the assert_* family
+    (predicate + main_gate.assert_one: a violated assertion -> status H2R_E_ASSERTION for that element only), exercised
+    like the reference's tests do (big_integer/chip.rs:1470-1660: operands vs assigned constants)."""
+    from halo2_rsa_amd import _lib
+    chip = H.BigIntChip(64, 2048)
+    rng = random.Random(41)
+    n = rand_modulus(rng, 2048)
+    vals = [rng.randrange(n) for _ in range(4)]
+    a = chip.assign_integer(vals)
+    c = chip.assign_constant_fresh(vals[2], batch=4)                      # the same constant in every element
+    assert c.to_big_uint() == [vals[2]] * 4 and c.num_limbs() == 32
+    assert chip.max_value(batch=2).to_big_uint() == [(1 << 2048) - 1] * 2   # chip.rs:138-154
+    assert chip.max_value(3).to_big_uint() == [(1 << 192) - 1]
+    with pytest.raises(AssertionError):
+        chip.assign_constant(1 << 70, 1)                                  # does not fit (chip.rs:1266)
+    r = chip.assert_equal_fresh(a, c)
+    torch.cuda.synchronize()
+    assert r.status.cpu().tolist() == [_lib.H2R_E_ASSERTION, _lib.H2R_E_ASSERTION, 0, _lib.H2R_E_ASSERTION]
+    assert chip.assert_in_field(a, chip.assign_integer([n] * 4)).status.cpu().tolist() == [0, 0, 0, 0]
+    assert chip.assert_less_than(a, c).status.cpu().tolist() == [0 if v < vals[2] else _lib.H2R_E_ASSERTION for v in vals]
+    assert chip.assert_greater_than_or_equal(a, c).status.cpu().tolist() == [0 if v >= vals[2] else _lib.H2R_E_ASSERTION for v in vals]
+    assert chip.assert_less_than_or_equal(a, c).status.cpu().tolist() == [0 if v <= vals[2] else _lib.H2R_E_ASSERTION for v in vals]
+    assert chip.assert_greater_than(a, c).status.cpu().tolist() == [0 if v > vals[2] else _lib.H2R_E_ASSERTION for v in vals]
+    z = chip.assign_constant_fresh(0, batch=4)
+    assert chip.assert_zero(z).status.cpu().tolist() == [0] * 4 and chip.assert_zero(a).status.cpu().tolist() == [_lib.H2R_E_ASSERTION] * 4
+    # mul(a, b) == the product assigned as a Muled constant ONLY when no column needs a carry: small operands
+    x, y = 3, 5
+    ax, ay = chip.assign_constant_fresh(x, 2), chip.assign_constant_fresh(y, 2)
+    prod = chip.mul(ax, ay)
+    cm = chip.assign_constant_muled(x * y, 32, 32, batch=2)
+    st, _ = chip.assert_equal_muled(prod, cm)
+    st2, _ = chip.assert_equal_muled(prod, chip.assign_constant_muled(x * y + 1, 32, 32, batch=2))
+    torch.cuda.synchronize()
+    assert st.cpu().tolist() == [0, 0] and st2.cpu().tolist() == [_lib.H2R_E_ASSERTION] * 2
+
+
 def test_mul_reference_cases_on_gpu(H, golden):
     """BigIntChip::mul known answers of the reference (big_integer/chip.rs:2797-3107, incl. the 16-limb squaring
     with all 31 un-carried columns) through h2r_mul_batch."""
