@@ -61,6 +61,7 @@ WORKLOADS = {
     "rsa2048_e65537": (64, 2048, 65537),   # BASELINE configs[1] (batch 1024) / configs[2] shards
     "rsa4096_w32_e65537": (32, 4096, 65537),  # configs[3]
     "rsa1024_e65537": (64, 1024, 65537),
+    "rsa3072_e65537": (64, 3072, 65537),      # num_limbs = 48: not a power of two
     "rsa4096_e65537": (64, 4096, 65537),      # RSAChip's own limb width at 4096 bits
     # configs[4]: full 2048-step square-and-multiply (seeded 2048-bit exponent with the top bit set)
     "rsa2048_e2048bit": (64, 2048, random.Random(0x68327273 + 5).getrandbits(2048) | (1 << 2047)),

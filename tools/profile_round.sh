@@ -6,21 +6,37 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o r -
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_serial -o r -- python $R/bench.py $ARGS --no-pipeline > $O/kt_serial.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o r -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pipeline > $O/pmc_w.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_r -o r -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-pipeline > $O/pmc_r.log 2>&1
+# the device-side flatten and the advice image of a config-2 trace: kernel stats + PMC passes
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_emit -o r -- python $R/tools/emit_timing.py 1024 rsa2048 > $O/kt_emit.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_emit_w -o r -- python $R/tools/emit_timing.py 1024 rsa2048 0 noadvice > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_emit_r -o r -- python $R/tools/emit_timing.py 1024 rsa2048 0 noadvice > /dev/null 2>&1
 cd $R
 python tools/pmc_to_json.py $O 1024 > $O/pmc_traffic.json
 python tools/timeline.py $O/kt > $O/timeline_pipeline.txt
 timeout 300 python bench.py --steps 40 --warmup 4 > $O/bench_pipeline.json 2> $O/bench_pipeline.err
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_pipeline_driver_args.json 2>/dev/null
 timeout 300 python bench.py --steps 40 --warmup 4 --no-pipeline --no-cpu-baseline > $O/bench_serial.json 2>/dev/null
 timeout 300 python bench.py --steps 40 --warmup 4 --pipeline-depth 3 --side-streams 2 --no-cpu-baseline > $O/bench_pipeline_d3s2.json 2>/dev/null
-H2R_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_torchrun1.json 2> $O/bench_torchrun1.err
+timeout 300 python bench.py --steps 40 --warmup 4 --verify --no-cpu-baseline > $O/bench_verify.json 2>/dev/null
+# BASELINE config 3 as ONE rank sees it (8,192-signature shard walked as 8 pipelined calls), through torchrun + RCCL
+H2R_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --chunks 8 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_torchrun1_config3_shard.json 2> $O/bench_torchrun1.err
 {
-  echo "# other BASELINE configs, same box (tools/sweep.py lines: step, value = assigns/s, record kernel, chain kernel)"
-  python tools/sweep.py CONFIG C3-shard-8192 --batch 8192 --steps 6 --warmup 2
+  echo "# other BASELINE configs and shapes, same box (tools/sweep.py lines: step, value = assigns/s, record kernel, chain kernel)"
+  python tools/sweep.py CONFIG C3-shard-8192-as-8-calls --chunks 8 --steps 6 --warmup 2
+  python tools/sweep.py CONFIG C3-shard-8192-one-call --batch 8192 --steps 6 --warmup 2
   python tools/sweep.py CONFIG C3-shard-8192-serial --batch 8192 --steps 6 --warmup 2 --no-pipeline
   python tools/sweep.py CONFIG C4-rsa4096-w32-4096 --workload rsa4096_w32_e65537 --batch 4096 --steps 4 --warmup 1
   python tools/sweep.py CONFIG C4-rsa4096-w32-4096-serial --workload rsa4096_w32_e65537 --batch 4096 --steps 4 --warmup 1 --no-pipeline
   python tools/sweep.py CONFIG C5-e2048bit-256 --workload rsa2048_e2048bit --batch 256 --steps 8 --warmup 2
   python tools/sweep.py CONFIG C5-e2048bit-256-serial --workload rsa2048_e2048bit --batch 256 --steps 4 --warmup 1 --no-pipeline
   python tools/sweep.py CONFIG rsa1024 --workload rsa1024_e65537 --steps 40 --warmup 4
+  python tools/sweep.py CONFIG rsa3072 --workload rsa3072_e65537 --steps 20 --warmup 3
+  python tools/sweep.py CONFIG rsa2048-shared-modulus --steps 40 --warmup 4 --shared-modulus
 } > $O/other_configs.txt 2>&1
-tail -1 $O/bench_pipeline.json | cut -c1-600; tail -1 $O/bench_serial.json | cut -c1-200; tail -1 $O/bench_pipeline_d3s2.json | cut -c1-200; tail -1 $O/bench_torchrun1.json | cut -c1-200; tail -3 $O/bench_torchrun1.err; cat $O/other_configs.txt; cat $O/pmc_traffic.json | head -30
+{
+  for wl in rsa2048 rsa3072 rsa4096w32; do python tools/emit_timing.py 1024 $wl 2>&1 | grep kernel; done
+  python tools/emit_timing.py 1024 rsa2048 1 noadvice 2>&1 | grep kernel
+} > $O/emit_timing.txt
+python tools/offpath_timing.py > $O/offpath_kernels.txt 2>&1
+python tools/lookup_timing.py > $O/lookup_timing.txt 2>&1
+tail -1 $O/bench_pipeline.json | cut -c1-700; tail -1 $O/bench_serial.json | cut -c1-200; tail -1 $O/bench_pipeline_d3s2.json | cut -c1-200; tail -1 $O/bench_torchrun1_config3_shard.json | cut -c1-300; tail -3 $O/bench_torchrun1.err; cat $O/other_configs.txt; cat $O/emit_timing.txt; cat $O/pmc_traffic.json | head -40
