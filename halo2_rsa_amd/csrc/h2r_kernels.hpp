@@ -2366,7 +2366,8 @@ template <int LW>
 __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
     using limb_t = typename LimbT<LW>::type;
     __shared__ u64 sa[128], sb_[128], sq[128], sn[128], sr[128];
-    __shared__ uint4 stage[256 * (ADVICE_ROW_BYTES / 16)];   // 256 rows are built in LDS, then leave as full 16-byte-per-lane lines
+    constexpr u32 SR = 256;                                   // rows per stage (40 KB of LDS; 208 rows = four workgroups per CU measured 3 % slower for RSA-2048, 10 % faster for 32 x 128)
+    __shared__ uint4 stage[SR * (ADVICE_ROW_BYTES / 16)];    // SR rows are built in LDS, then leave as full 16-byte-per-lane lines
     const u32 tid = threadIdx.x;
     const u32 item = blockIdx.x;
     const u32 elem = item / a.T, t = item - elem * a.T;
@@ -2395,7 +2396,7 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
         reinterpret_cast<uint4 *>(p)[1] = make_uint4((u32)x[2], (u32)(x[2] >> 32), (u32)x[3], (u32)(x[3] >> 32));
     };
     auto row = [&](u32 r, const U192 &c0, const U192 &c1, const U192 &c2, const U192 &c3, const U192 &c4, bool c2_signed = false, bool c0_signed = false) {
-        u8 *p = reinterpret_cast<u8 *>(stage) + (u64)(r & 255u) * ADVICE_ROW_BYTES;   // r - r0 == tid
+        u8 *p = reinterpret_cast<u8 *>(stage) + (u64)(r % SR) * ADVICE_ROW_BYTES;   // r - r0 == tid (r0 is a multiple of SR)
         cell(p, c0, c0_signed); cell(p + 32, c1, false); cell(p + 64, c2, c2_signed); cell(p + 96, c3, false); cell(p + 128, c4, false);
     };
     auto lim = [&](u64 v) { return U192::make(v, 0, 0); };
@@ -2414,9 +2415,9 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
     };
     const u32 r_T2 = 2 * L, r_T3 = 4 * L, r_T4 = r_T3 + L * L, r_T5 = r_T4 + L * L, r_T6 = r_T5 + L;
     const u32 per_col = 17 + nrc;
-    for (u32 r0 = 0; r0 < a.rows; r0 += 256) {
+    for (u32 r0 = 0; r0 < a.rows; r0 += SR) {
       const u32 r = r0 + tid;
-      if (r < a.rows) {
+      if (tid < SR && r < a.rows) {
         if (r < r_T3) {                                   // q then r limbs: RangeChip::assign(limb, w/8, w)
             const bool isr = r >= r_T2; const u32 rr = (isr ? r - r_T2 : r);
             const u32 k = rr >> 1;
@@ -2446,48 +2447,50 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
             const u32 rr = r - r_T6;
             const u32 c = rr / per_col < C - 1 ? rr / per_col : C - 1, k = rr - c * per_col;
             const u32 jmax = c < L ? c : L - 1, im = c < L ? c : c - L;
-            // (every case reads only what its row needs: the lanes of a wave sit in ~17 different cases)
-            auto SUM = [&] { return rv.wide(H2R_PL_SUM_LO, c); };
-            auto CY = [&] { return rv.carry(H2R_PL_CARRY, c); };
-            auto CMOD = [&] { return lim(rv.limb(H2R_PL_CMOD, c)); };
-            auto MODACC = [&] { return lim(rv.limb(H2R_PL_MODACC, c)); };
-            auto FL = [&] { return *reinterpret_cast<const u32 *>(rv.rec + a.off[H2R_PL_FLAGS] + (u64)c * 4); };
-            switch (k) {
-                case 0: row(r, rv.acc(false, jmax, im), c < L ? rv.wide(H2R_PL_EQB_LO, c) : rv.acc(true, jmax, im), rv.wide(H2R_PL_AMB_LO, c), Z, Z, true); break;
-                case 1: row(r, rv.wide(H2R_PL_AMB_LO, c), c ? rv.carry(H2R_PL_CARRY, c - 1) : Z, SUM(), Z, Z, false, true); break;
-                case 2: row(r, CY(), Z, Z, Z, Z); break;
-                case 3: row(r, CMOD(), Z, Z, Z, Z); break;
-                case 4: row(r, B, CY(), rv.wide(H2R_PL_NQ1_LO, c), Z, Z); break;
-                case 5: row(r, SUM(), rv.wide(H2R_PL_NQ1_LO, c), lim(rv.limb(H2R_PL_AMNQ1, c)), Z, Z); break;
-                case 6: row(r, CMOD(), lim(rv.limb(H2R_PL_AMNQ1, c)), Z, Z, Z); break;
-                case 7: row(r, c ? rv.carry(H2R_PL_QACC, c - 1) : Z, rv.wide(H2R_PL_ACCX_LO, c), Z, Z, Z); break;
-                case 8: row(r, rv.carry(H2R_PL_QACC, c), Z, Z, Z, Z); break;
-                case 9: row(r, MODACC(), Z, Z, Z, Z); break;
-                case 10: row(r, B, rv.carry(H2R_PL_QACC, c), rv.wide(H2R_PL_NQ2_LO, c), Z, Z); break;
-                case 11: row(r, rv.wide(H2R_PL_ACCX_LO, c), rv.wide(H2R_PL_NQ2_LO, c), lim(rv.limb(H2R_PL_AMNQ2, c)), Z, Z); break;
-                case 12: row(r, MODACC(), lim(rv.limb(H2R_PL_AMNQ2, c)), Z, Z, Z); break;
-                case 13: row(r, CMOD(), MODACC(), lim(FL() & 0xff), Z, Z); break;
-                case 14: {
-                    const u32 eprev = c ? (*reinterpret_cast<const u32 *>(rv.rec + a.off[H2R_PL_FLAGS] + (u64)(c - 1) * 4) >> 24) : 1u;
-                    const u32 fl = FL();
-                    row(r, lim(eprev), lim(fl & 0xff), lim((fl >> 8) & 0xff), Z, Z); break;
+            // The lanes of a wave sit in ~20 different rows of 3-4 columns: every lane loads ALL values of its column with
+            // the same instruction sequence (the loads overlap; lanes of one column hit the same lines) and only the choice
+            // of the row's three cells diverges -- a switch over loads serialised ~20 dependent global round trips per wave.
+            const U192 v_ab = rv.acc(false, jmax, im), v_eqb = c < L ? rv.wide(H2R_PL_EQB_LO, c) : rv.acc(true, jmax, im);
+            const U192 v_amb = rv.wide(H2R_PL_AMB_LO, c), v_sum = rv.wide(H2R_PL_SUM_LO, c), v_cy = rv.carry(H2R_PL_CARRY, c);
+            const U192 v_cprev = c ? rv.carry(H2R_PL_CARRY, c - 1) : Z, v_xprev = c ? rv.carry(H2R_PL_QACC, c - 1) : Z;
+            const U192 v_nq1 = rv.wide(H2R_PL_NQ1_LO, c), v_accx = rv.wide(H2R_PL_ACCX_LO, c), v_qacc = rv.carry(H2R_PL_QACC, c);
+            const U192 v_nq2 = rv.wide(H2R_PL_NQ2_LO, c), v_dup = c < C - 1 ? rv.carry(H2R_PL_CARRY_DUP, c) : v_qacc;
+            const U192 v_cmod = lim(rv.limb(H2R_PL_CMOD, c)), v_amnq1 = lim(rv.limb(H2R_PL_AMNQ1, c));
+            const U192 v_modacc = lim(rv.limb(H2R_PL_MODACC, c)), v_amnq2 = lim(rv.limb(H2R_PL_AMNQ2, c));
+            const u32 fl = *reinterpret_cast<const u32 *>(rv.rec + a.off[H2R_PL_FLAGS] + (u64)c * 4);
+            const u32 eprev = c ? (*reinterpret_cast<const u32 *>(rv.rec + a.off[H2R_PL_FLAGS] + (u64)(c - 1) * 4) >> 24) : 1u;
+            const ulonglong2 sv = *reinterpret_cast<const ulonglong2 *>(rv.rec + a.off[H2R_PL_CARRY_SUB] + (u64)(c < C - 1 ? c : 0) * a.carry_sub_stride);
+            const bool is_range = c < C - 1 && k >= 15 && k < 15 + nrc;
+            if (is_range) {                                   // RangeChip::assign(carry, sublimb_bit_len(carry_bits), carry_bits)
+                range_row(r, sv.x, sv.y, a.carry_nsub, a.carry_sub_bits, k - 15);
+            } else {
+                U192 c0 = Z, c1 = Z, c2 = Z; bool s0 = false, s2 = false;
+                const u32 kk = k < 15 ? k : (k == (c < C - 1 ? 15 + nrc : 15) ? 15u : 16u);
+                switch (kk) {
+                    case 0: c0 = v_ab; c1 = v_eqb; c2 = v_amb; s2 = true; break;
+                    case 1: c0 = v_amb; c1 = v_cprev; c2 = v_sum; s0 = true; break;
+                    case 2: c0 = v_cy; break;
+                    case 3: c0 = v_cmod; break;
+                    case 4: c0 = B; c1 = v_cy; c2 = v_nq1; break;
+                    case 5: c0 = v_sum; c1 = v_nq1; c2 = v_amnq1; break;
+                    case 6: c0 = v_cmod; c1 = v_amnq1; break;
+                    case 7: c0 = v_xprev; c1 = v_accx; break;
+                    case 8: c0 = v_qacc; break;
+                    case 9: c0 = v_modacc; break;
+                    case 10: c0 = B; c1 = v_qacc; c2 = v_nq2; break;
+                    case 11: c0 = v_accx; c1 = v_nq2; c2 = v_amnq2; break;
+                    case 12: c0 = v_modacc; c1 = v_amnq2; break;
+                    case 13: c0 = v_cmod; c1 = v_modacc; c2 = lim(fl & 0xff); break;
+                    case 14: c0 = lim(eprev); c1 = lim(fl & 0xff); c2 = lim((fl >> 8) & 0xff); break;
+                    case 15: c0 = v_cy; c1 = v_dup; c2 = lim((fl >> 16) & 0xff); break;          // range_eq / final_carry_eq
+                    default: c0 = lim((fl >> 8) & 0xff); c1 = lim((fl >> 16) & 0xff); c2 = lim(fl >> 24); break;
                 }
-                default: {
-                    if (c < C - 1 && k < 15 + nrc) {          // RangeChip::assign(carry, sublimb_bit_len(carry_bits), carry_bits)
-                        const ulonglong2 sv = *reinterpret_cast<const ulonglong2 *>(rv.rec + a.off[H2R_PL_CARRY_SUB] + (u64)c * a.carry_sub_stride);
-                        range_row(r, sv.x, sv.y, a.carry_nsub, a.carry_sub_bits, k - 15);
-                    } else if (k == (c < C - 1 ? 15 + nrc : 15)) {   // range_eq / final_carry_eq
-                        row(r, CY(), c < C - 1 ? rv.carry(H2R_PL_CARRY_DUP, c) : rv.carry(H2R_PL_QACC, c), lim((FL() >> 16) & 0xff), Z, Z);
-                    } else {
-                        const u32 fl = FL();
-                        row(r, lim((fl >> 8) & 0xff), lim((fl >> 16) & 0xff), lim(fl >> 24), Z, Z);
-                    }
-                }
+                row(r, c0, c1, c2, Z, Z, s2, s0);
             }
         }
       }
       __syncthreads();
-      const u32 n_rows = a.rows - r0 < 256 ? a.rows - r0 : 256;
+      const u32 n_rows = a.rows - r0 < SR ? a.rows - r0 : SR;
       uint4 *dst = reinterpret_cast<uint4 *>(out + (u64)r0 * ADVICE_ROW_BYTES);
       for (u32 k = tid; k < n_rows * (ADVICE_ROW_BYTES / 16); k += 256) {
           const uint4 v = stage[k];
