@@ -366,16 +366,26 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         ta.status = status; ta.n_items = batch * T; ta.T = T;
         ta.trace = static_cast<u8 *>(trace); ta.elem_stride = elem_stride; ta.off_records = off_records;
         hipStream_t ts = st;
-        // Residency of the record kernel, in workgroups per CU (measured per shape).  With
-        // non-temporal stores the 64-bit-limb shapes up to RSA-2048 write fastest with FEW concurrent store streams:
-        // alone, one workgroup (4 records in flight) per CU -- 0.227 -> 0.213 ms, 5.87 TB/s for RSA-2048.  Next to the
-        // following batch's chain kernel: three for RSA-2048 at throughput batch sizes and for 32-bit limbs, two
-        // otherwise (a latency-build chain kernel -- at most two 4-wave workgroups per CU -- leaves room for the
-        // sparser setting).
+        // LDS share of the record kernel's workgroups (the occupancy lever on this hardware: an LDS request the kernel never
+        // touches).  ALONE the 64-bit-limb shapes up to RSA-2048 write fastest with FEW concurrent store streams: one
+        // workgroup (4 records in flight) per CU -- 0.227 -> 0.213 ms, 5.87 TB/s for RSA-2048 (ta.residency = 1: the request
+        // is derived from the device's LDS size and the kernel's static LDS).  NEXT TO the following batch's chain kernel the
+        // request decides two things at once -- how many record workgroups share a CU and how much LDS is left for chain
+        // workgroups -- so it is a measured per-shape share of the CU's LDS, not a workgroup count
+        // (profiles/r02_residency_sweep.txt, profiles/history/r01_pipeline_sweep.txt; MI355X, 160 KB per CU).
         const bool tune = knobs().trace_dyn_lds < 0;
         if (tune && lo.limb_width == 64 && c->L <= 32) ta.residency = 1;
         if (trace_st) {
-            if (tune) ta.residency = (lo.limb_width == 64 && !(c->L == 32 && batch > 512)) ? 2 : 3;
+            if (tune) {
+                ta.residency = 0;
+                u32 share_256;   // request = share_256 / 256 of the CU's LDS
+                if (lo.limb_width == 32) share_256 = 50;                               // 32,000 B of 160 KB: three workgroups per CU
+                else if (c->L == 32 && batch > 512) share_256 = 50;                    // RSA-2048 at throughput batches: three
+                else if (c->L > 48) share_256 = 31;                                    // 4096-bit: 20,000 B (1.15 -> 1.01 ms per 1,024)
+                else if (c->L > 32) share_256 = 62;                                    // RSA-3072: 40,000 B (0.82 -> 0.71 ms)
+                else share_256 = 70;                                                   // 45,000 B: two workgroups, room for the chain's
+                ta.dyn_lds = (u32)(((u64)c->lds_per_cu * share_256 / 256) & ~15ull);
+            }
             // (a gate kernel polling a count published by the chain blocks instead of this cross-queue wait was measured
             //  slower: the blocks' agent-scope releases disturb the record kernel's store stream, 0.220 -> 0.245 ms, and a
             //  one-wave kernel costs 5-7 us between two record kernels: profiles/r02_gap_experiments.txt)

@@ -1015,7 +1015,13 @@ template <> struct ColAcc<32> {
 // wavefronts; the padding threads (t >= 2L, none when L is a power of two) only take part in barriers and ballots.
 template <int L>
 struct TraceGeo {
-    static constexpr int pad(int t) { if (t >= 64) return (t + 63) / 64 * 64; int p = 1; while (p < t) p <<= 1; return p; }
+    // (one exception to the padding: two items of 96 threads fill three wavefronts exactly -- RSA-3072 as 48 x 64-bit limbs
+    //  runs its items back to back, straddling wavefronts, instead of leaving a quarter of the lanes idle)
+    static constexpr int pad(int t) {
+        if (t > 64 && t % 64 != 0 && (2 * t) % 64 == 0 && 2 * t <= 256) return t;
+        if (t >= 64) return (t + 63) / 64 * 64;
+        int p = 1; while (p < t) p <<= 1; return p;
+    }
     static constexpr int TPI = pad(2 * L);                 // threads per item
     static constexpr int IPB = TPI >= 256 ? 1 : 256 / TPI;  // items per workgroup
     static constexpr int BT = IPB * TPI;                   // threads per workgroup (256, or 192 for 64 < L <= 96)
@@ -1187,7 +1193,9 @@ __global__ __launch_bounds__(BT) void trace_kernel(TraceArgs args) {
     } else {
         if (lane == 0) { xg[wave] = G; xp[wave] = P; }
         __syncthreads();
-        const int w0 = (wave / WPI) * WPI;  // first wave of this item
+        // chain from the item's first wave; when items straddle wavefronts, from the workgroup's first wave -- thread 2L-1
+        // of every item has no column (G = P = 0) and stops the chain between items
+        const int w0 = (TPI % 64 == 0) ? (wave / WPI) * WPI : 0;
         bool cin = false;
         for (int k = w0; k < wave; ++k) cin = carry_group(xg[k], xp[k], cin, 64).cout;
         const CarryGroup cg = carry_group(G, P, cin, 64);
@@ -1257,9 +1265,19 @@ __global__ __launch_bounds__(BT) void trace_kernel(TraceArgs args) {
     } else {
         if (lane == 0) xbad[wave] = bad;
         __syncthreads();
-        const int w0 = (wave / WPI) * WPI;
-        prev_ok = (bad & ((1ull << lane) - 1)) == 0;
-        for (int k = w0; k < wave; ++k) prev_ok = prev_ok && xbad[k] == 0;
+        if constexpr (TPI % 64 == 0) {
+            const int w0 = (wave / WPI) * WPI;
+            prev_ok = (bad & ((1ull << lane) - 1)) == 0;
+            for (int k = w0; k < wave; ++k) prev_ok = prev_ok && xbad[k] == 0;
+        } else {   // items straddle wavefronts: no failed column among the item's threads [slot * TPI, tid)
+            const int s0 = slot * TPI, ws = s0 >> 6, ls = s0 & 63;
+            prev_ok = true;
+            for (int k = ws; k <= wave; ++k) {
+                u64 m = k == wave ? bad & ((1ull << lane) - 1) : xbad[k];
+                if (k == ws) m &= ~((1ull << ls) - 1);
+                prev_ok = prev_ok && m == 0;
+            }
+        }
     }
     if (live) {
         const u32 e1 = (prev_ok && f1) ? 1u : 0u, e2 = (e1 && f2) ? 1u : 0u;
