@@ -1501,28 +1501,43 @@ __global__ __launch_bounds__(64) void aux_kernel(AuxArgs a) {
     (void)aux_less_than<LW>(sec, g, Xv, Nv, lane);   // assert_in_field = is_less_than(x, n), chip.rs:998-1006
     (void)sizeof(X);
     // ---- encoded-message check (src/chip.rs:136-198; LIMB_WIDTH = 64 only) ----------------------------
+    // One flag per lane, in the reference's order: hash limbs 0-3, the two DigestInfo limbs, the low and high half of limb 6,
+    // the 0xff.. limbs 7 .. L-2, the last limb -- L + 1 flags; the running AND (is_eq) is a ballot prefix.
     if constexpr (LW == 64) {
-        if (a.hashed != nullptr && lane == 0) {
+        if (a.hashed != nullptr) {
             u8 *e = reinterpret_cast<u8 *>(aux_stage + if_u4);
             const bool ok_status = a.status == nullptr || a.status[elem] == 0;
             const u64 *pw = reinterpret_cast<const u64 *>(a.powed) + elem * L;
             const u64 *hm = a.hashed + elem * 4;
-            u32 is_eqv = 1;
-            auto pair = [&](u8 *q, bool f) { is_eqv &= f ? 1u : 0u; *reinterpret_cast<uint16_t *>(q) = (uint16_t)((f ? 1u : 0u) | (is_eqv << 8)); };
+            const u32 S = L + 1;
+            bool all_prev = true;
             if (ok_status) {
-                for (int i = 0; i < 4; ++i) pair(e + 2 * i, pw[i] == hm[i]);                      // :141-144
-                const bool f1 = pw[4] == 217300885422736416ull, f2 = pw[5] == 938447882527703397ull;   // :150-154
-                e[8] = f1; e[9] = f2; is_eqv &= f1; e[10] = (u8)is_eqv; is_eqv &= f2; e[11] = (u8)is_eqv;   // :155-156
-                const u32 low = (u32)pw[6], high = (u32)(pw[6] >> 32);                              // :159-168
-                auto ra32 = [&](u8 *q, u32 v) { pst4(q, v); const u64 sb = limb_sub_bytes<32>(v); pst4(q + 4, (u32)sb); pst4(q + 8, (u32)(sb >> 32)); };
-                ra32(e + 12, low); ra32(e + 24, high);                                              // :170-171
-                pst4(e + 36, low); pst4(e + 40, high);                                                // :173
-                pair(e + 44, low == 3158320u);                                                      // :175-177
-                pair(e + 46, high == 4294967295u);                                                  // :180-182
-                for (u32 i = 7; i < L - 1; ++i) pair(e + 48 + 2 * (i - 7), pw[i] == 18446744073709551615ull);   // :185-188
-                pair(e + 48 + 2 * (L - 8), pw[L - 1] == 562949953421311ull);                        // :191-197
-            } else is_eqv = 0;
-            if (a.is_valid) a.is_valid[elem] = (u8)is_eqv;
+                for (u32 base = 0; base < S; base += 64) {
+                    const u32 sidx = base + lane;
+                    const bool act = sidx < S;
+                    bool flag = true; u32 pos_f = 0, pos_r = 0;
+                    if (act) {
+                        if (sidx < 4) { flag = pw[sidx] == hm[sidx]; pos_f = 2 * sidx; pos_r = 2 * sidx + 1; }                                  // :141-144
+                        else if (sidx == 4) { flag = pw[4] == 217300885422736416ull; pos_f = 8; pos_r = 10; }                                 // :150-156
+                        else if (sidx == 5) { flag = pw[5] == 938447882527703397ull; pos_f = 9; pos_r = 11; }
+                        else if (sidx == 6) { flag = (u32)pw[6] == 3158320u; pos_f = 44; pos_r = 45; }                                        // :175-177
+                        else if (sidx == 7) { flag = (u32)(pw[6] >> 32) == 4294967295u; pos_f = 46; pos_r = 47; }                             // :180-182
+                        else if (sidx < L) { flag = pw[sidx - 1] == 18446744073709551615ull; pos_f = 48 + 2 * (sidx - 8); pos_r = pos_f + 1; }   // :185-188
+                        else { flag = pw[L - 1] == 562949953421311ull; pos_f = 48 + 2 * (L - 8); pos_r = pos_f + 1; }                         // :191-197
+                    }
+                    const u64 bad = __ballot(act && !flag);
+                    const bool run = all_prev && (bad & ((2ull << lane) - 1)) == 0;   // AND over flags <= sidx
+                    if (act) { e[pos_f] = flag ? 1 : 0; e[pos_r] = run ? 1 : 0; }
+                    all_prev = all_prev && bad == 0;
+                }
+                if (lane == 6) {   // limb 6 is split with two 32-bit range assigns and recomposed (:159-173)
+                    const u32 low = (u32)pw[6], high = (u32)(pw[6] >> 32);
+                    auto ra32 = [&](u8 *q, u32 v) { pst4(q, v); const u64 sb = limb_sub_bytes<32>(v); pst4(q + 4, (u32)sb); pst4(q + 8, (u32)(sb >> 32)); };
+                    ra32(e + 12, low); ra32(e + 24, high);
+                    pst4(e + 36, low); pst4(e + 40, high);
+                }
+            } else all_prev = false;
+            if (a.is_valid && lane == 0) a.is_valid[elem] = all_prev ? 1 : 0;
         }
     }
     wave_sync();
