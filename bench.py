@@ -61,6 +61,7 @@ WORKLOADS = {
     "rsa2048_e65537": (64, 2048, 65537),   # BASELINE configs[1] (batch 1024) / configs[2] shards
     "rsa4096_w32_e65537": (32, 4096, 65537),  # configs[3]
     "rsa1024_e65537": (64, 1024, 65537),
+    "rsa1536_e65537": (64, 1536, 65537),      # num_limbs = 24
     "rsa3072_e65537": (64, 3072, 65537),      # num_limbs = 48: not a power of two
     "rsa4096_e65537": (64, 4096, 65537),      # RSAChip's own limb width at 4096 bits
     # configs[4]: full 2048-step square-and-multiply (seeded 2048-bit exponent with the top bit set)
@@ -160,7 +161,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="signatures per call (default 1024)")
     ap.add_argument("--chunks", type=int, default=0,
-                    help="calls per step = chunks of the GPU's shard (default: 1 at --gpus 1, 8 at --gpus > 1: 8,192 per GPU)")
+                    help="calls per step = chunks of the GPU's shard (default 1; per GPU 1,024 signatures at --gpus 1, 8,192 at --gpus > 1)")
     ap.add_argument("--workload", default="rsa2048_e65537", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline-depth", type=int, default=2, help="buffer sets the pipelined calls rotate through (2..4)")
@@ -174,6 +175,10 @@ def main():
                     help="one key, many signatures (H2R_F_SHARED_MODULUS): every element uses element 0's modulus")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="developer: do not arm the C ABI's per-kernel event timing (roofline fields become null)")
+    ap.add_argument("--user-stream", action="store_true",
+                    help="developer: issue the calls on a created stream instead of torch's default (null) stream")
+    ap.add_argument("--no-in-field", action="store_true",
+                    help="developer: pow_mod_fixed_exp only (no assert_in_field witness kernel) in the pipelined call")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="fully stream-ordered calls (chain then trace per step) instead of the two-stream pipeline")
     args = ap.parse_args()
@@ -182,11 +187,14 @@ def main():
     w, bits, e = WORKLOADS[args.workload]
     torch.cuda.set_device(env.local_rank)
     env.init("nccl")
+    if args.user_stream:
+        torch.cuda.set_stream(torch.cuda.Stream())
     # Workload: N = 1 -> BASELINE configs[1] (one 1,024-signature call per step).  N > 1 -> configs[2]: every GPU owns a
-    # contiguous shard of 8,192 signatures of the global batch (65,536 at N = 8) and walks it as pipelined
-    # 1,024-signature calls; a step is one pass over the shard.  --batch / --chunks override both.
-    chunk = args.batch if args.batch else 1024
-    chunks = args.chunks if args.chunks else (1 if args.gpus == 1 else 8)
+    # contiguous shard of 8,192 signatures of the global batch (65,536 at N = 8); a step is one pass over the shard = ONE
+    # pipelined call (the library walks a call that finds the pipeline empty as sub-batches, pipeline_plan in h2r_api.hip).
+    # --batch / --chunks override both (--chunks 8 --batch 1024: the shard as eight 1,024-signature calls).
+    chunks = args.chunks if args.chunks else 1
+    chunk = args.batch if args.batch else (1024 if args.gpus == 1 else 8192 // chunks)
     # configuration broadcast (rank 0 decides): the only pre-run collective
     e, chunk, chunks, steps, warmup = env.broadcast_ints([e, chunk, chunks, args.steps, args.warmup])
     shard = chunk * chunks
@@ -244,7 +252,7 @@ def main():
         elif verify:
             pipe.verify_pkcs1v15(xc[c], e, nc[c], hashed_dev[c * chunk:(c + 1) * chunk], tb, ws, out[sl], valid[sl], status[sl])
         else:
-            pipe.modpow_public_key(xc[c], e, nc[c], tb, ws, out[sl], status[sl], fb)
+            pipe.modpow_public_key(xc[c], e, nc[c], tb, ws, out[sl], status[sl], None if args.no_in_field else fb)
         return r
 
     def step():
@@ -261,7 +269,8 @@ def main():
     if pipe is not None:
         pipe.join()
     torch.cuda.synchronize()
-    _lib.profile_enable(0 if args.no_kernel_timing else 4 * steps * chunks + 8)   # chain + record + in-field kernel per call
+    # chain + record + in-field kernel per call; a pipelined call larger than the library's sub-batch is several pairs
+    _lib.profile_enable(0 if args.no_kernel_timing else (3 + 2 * (chunk // 256)) * steps * chunks + 8)
     env.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -295,7 +304,7 @@ def main():
     gathered = env.gather_to_rank0(shard_out)
     if env.rank == 0:
         assert gathered.shape[0] == env.world * shard_out.shape[0]
-        if chunks > 1 and not args.shared_modulus:   # samples from EVERY shard against pow() of the regenerated inputs
+        if (chunks > 1 or env.world > 1 or shard > 1024) and not args.shared_modulus:   # samples from EVERY shard against pow() of the regenerated inputs
             golden = load_golden(w, bits)
             vals = H.AssignedInteger(gathered, w)
             host = vals.limbs_host()
@@ -310,11 +319,21 @@ def main():
     if env.rank == 0:
         # written (pow stream + the assert_in_field stream of modpow_public_key) + inputs read
         algo_bytes_per_assign = pl.stream_bytes + chip.in_field_layout()[1] + 2 * chip.num_limbs * chip.layout.limb_bytes
-        trace_bytes_per_launch = chunk * (pl.num_mul_mods * chip.layout.stream_bytes)         # trace_kernel's algorithmic output
+        # trace_kernel's algorithmic output per launch.  A large pipelined call that finds the pipeline empty is walked by
+        # the library as sub-batches of growing size: the profile then holds more launches than calls, so the figure is
+        # the mean over the timed launches (all signatures of the timed region / launches) -- equal to chunk * bytes when
+        # every call is one launch.
+        n_launches = len(trace_ms) if trace_ms else steps * chunks
+        per_launch_batch = chunk * steps * chunks / n_launches
+        trace_bytes_per_launch = int(round(per_launch_batch * (pl.num_mul_mods * chip.layout.stream_bytes)))
         avg_trace_s = (sum(trace_ms) / len(trace_ms)) / 1e3 if trace_ms else float("nan")
         achieved = trace_bytes_per_launch / avg_trace_s / 1e9 if trace_ms else None
-        if chunks == 1:
+        if chunks == 1 and env.world == 1:
             wl = "%s batch=%d per GPU, %d-bit limbs, full op-trace (%d B/assign)" % (args.workload, chunk, w, algo_bytes_per_assign)
+        elif chunks == 1:
+            wl = ("%s global batch=%d sharded x%d (%d per GPU = one pipelined call per step), %d-bit limbs, full op-trace "
+                  "(%d B/assign), traces resident on the producing GPU" %
+                  (args.workload, global_batch, env.world, shard, w, algo_bytes_per_assign))
         else:
             wl = ("%s global batch=%d sharded x%d (%d per GPU, walked as %d pipelined calls of %d), %d-bit limbs, full op-trace "
                   "(%d B/assign), traces resident on the producing GPU" %
@@ -335,11 +354,11 @@ def main():
                                    if pipe is not None else "none"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                         "traffic": pmc_traffic("trace_kernel<%d,%d>" % (w, chip.num_limbs), chunk),
+                         "traffic": pmc_traffic("trace_kernel<%d,%d>" % (w, chip.num_limbs), int(per_launch_batch)) if per_launch_batch == chunk else None,
                          "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc passes of this kernel at this batch, "
                                            "committed; PMC counters cannot be read from inside the bench process)",
                          "kernel": "trace_kernel<%d,%d>" % (w, chip.num_limbs),
-                         "launches_timed": len(trace_ms),
+                         "launches_timed": len(trace_ms), "signatures_per_launch": round(per_launch_batch, 1),
                          "avg_launch_ms": round(1e3 * avg_trace_s, 4) if trace_ms else None,
                          "algorithmic_bytes_per_launch": trace_bytes_per_launch,
                          "chain_kernel_avg_ms": round(sum(chain_ms) / len(chain_ms), 4) if chain_ms else None},

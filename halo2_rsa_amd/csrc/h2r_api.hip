@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -83,6 +84,8 @@ struct Knobs {
     int pipe_stream_prio = -1;                   // H2R_PIPE_STREAM_PRIO = low (default) | normal | high  -> -1 | 0 | +1
     bool chain_timing = false;                   // H2R_CHAIN_TIMING (needs the -DH2R_CHAIN_TIMING build)
     bool pipe_serialize = false;                 // H2R_PIPE_SERIALIZE=1: with two record streams, a record kernel also waits for the previous one
+    long pipe_sub_batch = 0;                     // H2R_PIPE_SUB_BATCH: elements per chain + record kernel pair inside a pipelined call (multiple of 256)
+    long pipe_pace = -1;                         // H2R_PIPE_PACE=0|1: sub-batch i+1's chain kernel waits for sub-batch i-1's record kernel
     Knobs() {
 #ifdef H2R_DEV_KNOBS
         auto num = [](const char *name, long dflt) { const char *v = std::getenv(name); return v ? std::atol(v) : dflt; };
@@ -93,6 +96,7 @@ struct Knobs {
         pipe_stream_prio = !pe ? -1 : (!std::strcmp(pe, "high") ? 1 : (!std::strcmp(pe, "low") ? -1 : 0));
         chain_timing = std::getenv("H2R_CHAIN_TIMING") != nullptr;
         { const char *g = std::getenv("H2R_PIPE_SERIALIZE"); pipe_serialize = g && g[0] == '1'; }
+        pipe_sub_batch = num("H2R_PIPE_SUB_BATCH", 0); pipe_pace = num("H2R_PIPE_PACE", -1);
 #endif
     }
 };
@@ -294,7 +298,9 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
                  u32 e_num_limbs, u32 exp_limb_bits, const ExpBits *eb, u32 check_in_field, u64 batch, u32 flags,
                  u32 T, void *trace, u64 elem_stride, u64 off_records, const h2r_pow_layout *pl, void *out,
                  uint8_t *status, void *workspace, hipStream_t st, hipStream_t trace_st = nullptr,
-                 hipEvent_t chain_done = nullptr, hipEvent_t trace_done = nullptr, DoneRef *done_ref = nullptr) {
+                 hipEvent_t chain_done = nullptr, hipEvent_t trace_done = nullptr, DoneRef *done_ref = nullptr,
+                 void *shared_pre = nullptr) {
+    // shared_pre: where the shared modulus' Barrett constants go when `workspace` is a slice of a larger call's plan
     // trace_st != nullptr (pipeline mode): the record-writing kernel runs on trace_st after `chain_done`
     if (!c || !n || !a || !status) return H2R_E_NULL;
     if (trace_st && !workspace) return H2R_E_NULL;
@@ -334,7 +340,8 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
     if (knobs().chain_prio >= 0) ca.prio = (u32)knobs().chain_prio;
     // one key, many elements: the Barrett constants of the shared modulus are computed once (recip_kernel) instead of by
     // every element's workgroup (big_integer/chip.rs:562-567 divides by the same n every time)
-    if ((flags & H2R_F_SHARED_MODULUS) && batch > 1) ca.pre = reinterpret_cast<const u32 *>(ws + wp.off_pre);
+    if ((flags & H2R_F_SHARED_MODULUS) && batch > 1)
+        ca.pre = reinterpret_cast<const u32 *>(shared_pre ? static_cast<u8 *>(shared_pre) : ws + wp.off_pre);
     // Pipeline mode: the record stream must wait for this chain kernel.  The event it waits on is the dispatch's own
     // stop event (the profiler's when armed, else chain_done) -- no separate marker packet.
     hipEvent_t chain_wait = nullptr;
@@ -386,9 +393,12 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
                 else share_256 = 70;                                                   // 45,000 B: two workgroups, room for the chain's
                 ta.dyn_lds = (u32)(((u64)c->lds_per_cu * share_256 / 256) & ~15ull);
             }
-            // (a gate kernel polling a count published by the chain blocks instead of this cross-queue wait was measured
-            //  slower: the blocks' agent-scope releases disturb the record kernel's store stream, 0.220 -> 0.245 ms, and a
-            //  one-wave kernel costs 5-7 us between two record kernels: profiles/r02_gap_experiments.txt)
+            // This cross-queue wait puts a barrier packet between two record kernels: 5 us of the 10-11 us between them
+            // (tools/boundary_probe2.hip).  Measured alternatives, none shipped (profiles/r02_gap_experiments.txt): a gate
+            // kernel polling a count the chain blocks publish (their agent-scope releases disturb the record kernel's store
+            // stream, and a one-wave kernel costs as much as the barrier packet); the record kernel's own workgroups polling
+            // a number the chain stream publishes (5-7 us per step faster, but a record kernel that starts early HOLDS the
+            // LDS that the chain kernel -- or any kernel the caller queued in front of it -- needs to get onto the CUs).
             HIP_TRY(hipStreamWaitEvent(trace_st, chain_wait, 0));
             ts = trace_st;
         }
@@ -714,6 +724,7 @@ struct h2r_pipeline {
     enum { MAX_DEPTH = 4 };
     u32 depth;        // buffer sets the caller rotates through: call k may reuse call k-depth's buffers
     hipEvent_t chain_done[MAX_DEPTH], trace_done[MAX_DEPTH];
+    hipEvent_t sub_done[2];    // record kernels of the sub-batches inside one call (pipeline_issue)
     DoneRef done[MAX_DEPTH];   // what marks the end of the record kernel of the call in each slot
     hipStream_t done_stream[MAX_DEPTH];
     u32 k;            // calls issued
@@ -734,6 +745,7 @@ int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side
     const int n_aux = (int)side_streams;
     for (int i = 0; i < 2; ++i) p->aux[i] = nullptr;
     for (int i = 0; i < h2r_pipeline::MAX_DEPTH; ++i) { p->chain_done[i] = nullptr; p->trace_done[i] = nullptr; }
+    p->sub_done[0] = p->sub_done[1] = nullptr;
     bool ok = true;
     // The side streams are created at the LOWEST stream priority: HIP multiplexes streams of one priority onto a
     // few hardware queues (GPU_MAX_HW_QUEUES, default 4), and two streams that share a queue never overlap -- under
@@ -749,6 +761,7 @@ int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side
     for (u32 i = 0; ok && i < p->depth; ++i)
         ok = hip_ok(hipEventCreate(&p->chain_done[i]), "hipEventCreate") &&
              hip_ok(hipEventCreate(&p->trace_done[i]), "hipEventCreate");
+    for (int i = 0; ok && i < 2; ++i) ok = hip_ok(hipEventCreate(&p->sub_done[i]), "hipEventCreate");
     if (!ok) { h2r_pipeline_destroy(p); return H2R_E_HIP; }
     *out = p;
     return H2R_OK;
@@ -762,6 +775,7 @@ void h2r_pipeline_destroy(h2r_pipeline *p) {
         if (p->chain_done[i]) (void)hipEventDestroy(p->chain_done[i]);
         if (p->trace_done[i]) (void)hipEventDestroy(p->trace_done[i]);
     }
+    for (int i = 0; i < 2; ++i) if (p->sub_done[i]) (void)hipEventDestroy(p->sub_done[i]);
     if (p->aux[1] && p->aux[1] != p->aux[0]) (void)hipStreamDestroy(p->aux[1]);
     if (p->aux[0]) (void)hipStreamDestroy(p->aux[0]);
     delete p;
@@ -795,6 +809,58 @@ int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream) {
 }
 
 namespace {
+// Is the record kernel of the previous pipelined call still queued or running?
+bool pipeline_busy(h2r_pipeline *p) {
+    if (p->k == 0) return false;
+    const DoneRef &d = p->done[(p->k - 1) % p->depth];
+    if (!d.ev) return false;
+    if (d.borrowed) { std::lock_guard<std::mutex> lk(g_prof_mu); if (d.gen != g_prof_gen) return false; }
+    return hipEventQuery(d.ev) == hipErrorNotReady;
+}
+
+// How one pipelined call is walked: the sizes of its sub-batches (each gets its own chain and record kernel) and whether
+// sub-batch i+1's chain kernel is held back until sub-batch i's record kernel starts.  What is at stake is the start and
+// the end of a call, not its steady state: an unsplit call exposes its whole chain kernel when no record kernel is in flight
+// (0.94 ms for 8,192 RSA-2048 signatures against 1.77 ms of record kernel), while at steady state one large launch per call
+// is the fastest form (fewer kernel boundaries: 1.77-1.81 ms per 8,192 against 1.93 as eight launches).  Measured per shape
+// (tools/sub_batch_ab.sh, profiles/r02_sub_batches.txt):
+//  * record-bound shapes (64-bit limbs, RSA-1536/2048): a call that finds the pipeline EMPTY is walked as sub-batches growing
+//    by 3/2 from one chain-kernel grid (1024, 1536, 2304, ...): each chain kernel then fits next to the record kernel of the
+//    sub-batch before it; paced (an unpaced train of chain kernels slows the record kernels it overlaps by 5 %).  A call
+//    that finds a record kernel in flight is not split.
+//  * chain-bound shapes (RSA-3072: chain kernel 0.65 ms, record kernel 0.49 ms per 1,024): uniform sub-batches, unpaced --
+//    the chain kernels run back to back either way, the record kernels hide behind them, and the last record kernel of a
+//    call is a quarter as long (4,096 signatures: 1.39-1.44 -> 1.60-1.62 M assigns/s over six calls).
+//  * RSA-1024 and the 32-bit-limb shapes: no gain measured from any split; one launch.
+void pipeline_plan(h2r_pipeline *p, u64 batch, std::vector<u64> &sizes, bool &pace) {
+    const h2r_ctx *c = p->ctx;
+    sizes.clear(); pace = false;
+    const u64 unit = (u64)c->num_cus * (c->K > 64 ? 2 : 4);   // one chain-kernel grid: four 4-wave (two 8-wave) workgroups per CU
+    if (knobs().pipe_sub_batch > 0) {
+        pace = knobs().pipe_pace != 0;
+        for (u64 o = 0; o < batch; o += (u64)knobs().pipe_sub_batch) sizes.push_back(std::min<u64>((u64)knobs().pipe_sub_batch, batch - o));
+        if (sizes.empty()) sizes.push_back(batch);
+        return;
+    }
+    const bool w64 = c->layout.limb_width == 64;
+    if (w64 && c->L > 32 && batch > 3 * unit) {                         // chain-bound (RSA-3072, RSA-4096 at 64-bit limbs)
+        for (u64 o = 0; o < batch; o += 2 * unit) sizes.push_back(std::min<u64>(2 * unit, batch - o));
+        return;
+    }
+    if (w64 && c->L > 16 && c->L <= 32 && batch > unit + unit / 2 && !pipeline_busy(p)) {   // record-bound, pipeline empty
+        pace = true;
+        u64 cur = unit, left = batch;
+        while (left) {
+            u64 take = std::min(cur, left);
+            if (left - take < cur / 2) take = left;
+            sizes.push_back(take); left -= take;
+            cur = (cur * 3 / 2) & ~255ull;
+        }
+        return;
+    }
+    sizes.push_back(batch);
+}
+
 // One pipelined call: chain kernel (+ `after_chain`, e.g. the verifier's aux kernel) on the caller's stream, the
 // record kernel on a side stream, then the lazy join of the call whose buffers the next call may reuse.
 int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch,
@@ -810,9 +876,40 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
         rc = pipeline_wait_slot(p, (p->k - 1) % p->depth, p->aux[p->k & 1]);
         if (rc) return rc;
     }
-    rc = run_path(ctx, CHAIN_POW_FIXED, x, nullptr, n, nullptr, 0, 0, &eb, 1, batch, flags, T, trace, elem_stride,
-                  pl.off_records, &pl, out, status, workspace, st, p->aux[p->k & 1], p->chain_done[slot], p->trace_done[slot], &p->done[slot]);
-    if (rc) return rc;
+    // A large call may be walked as sub-batches, each with its own chain and record kernel (pipeline_plan): sub-batch
+    // i+1's chain kernel then runs next to sub-batch i's record kernel INSIDE the call, exactly as consecutive calls do.
+    // The sub-batches are slices of the caller's buffers and of the whole call's workspace plan ([batch*T][4][L],
+    // element-major), so audits and emitters see one call.
+    std::vector<u64> sizes; bool pace = false;
+    pipeline_plan(p, batch, sizes, pace);
+    const bool split = sizes.size() > 1;
+    const h2r_layout &lo = ctx->layout;
+    const Workspace wp = workspace_plan(lo.limb_bytes, ctx->L, batch, T ? T : 1);
+    u8 *ws = reinterpret_cast<u8 *>(round_up(reinterpret_cast<u64>(workspace), 256));
+    const u64 in_bytes = (u64)ctx->K * 4, ws_elem = (u64)(T ? T : 1) * 4 * ctx->L * lo.limb_bytes;
+    DoneRef prev{};   // the record kernel of the sub-batch before the current one
+    u64 o = 0;
+    for (size_t i = 0; i < sizes.size(); o += sizes[i], ++i) {
+        const u64 nb = sizes[i];
+        const bool last = i + 1 == sizes.size();
+        DoneRef cur{};
+        const u8 *xs = static_cast<const u8 *>(x) + o * in_bytes;
+        const u8 *ns = static_cast<const u8 *>(n) + ((flags & H2R_F_SHARED_MODULUS) ? 0 : o * in_bytes);
+        rc = run_path(ctx, CHAIN_POW_FIXED, xs, nullptr, ns, nullptr, 0, 0, &eb, 1, nb, flags, T,
+                      static_cast<u8 *>(trace) + o * elem_stride, elem_stride, pl.off_records, &pl,
+                      out ? static_cast<u8 *>(out) + o * in_bytes : nullptr, status + o, split ? ws + o * ws_elem : workspace,
+                      st, p->aux[p->k & 1], p->chain_done[slot], last ? p->trace_done[slot] : p->sub_done[i & 1],
+                      last ? &p->done[slot] : &cur, split ? ws + wp.off_pre : nullptr);
+        if (rc) return rc;
+        // paced: as consecutive calls are paced by the lazy join below, sub-batch i+1's chain kernel starts with sub-batch
+        // i's record kernel, not earlier
+        if (prev.ev && pace) {
+            bool alive = true;
+            if (prev.borrowed) { std::lock_guard<std::mutex> lk(g_prof_mu); alive = prev.gen == g_prof_gen; }
+            if (alive) HIP_TRY(hipStreamWaitEvent(st, prev.ev, 0));
+        }
+        prev = cur;
+    }
     p->done_stream[slot] = p->aux[p->k & 1];
     p->k += 1;
     rc = after_chain();
@@ -834,9 +931,9 @@ int32_t launch_verify_aux(const h2r_ctx *ctx, const void *sig, const void *n, co
     aa.hashed = hashed; aa.powed = powed_out; aa.batch = batch; aa.L = ctx->L;
     aa.trace = static_cast<u8 *>(trace); aa.elem_stride = vl.elem_stride; aa.off_in_field = vl.off_in_field; aa.off_em = vl.off_em;
     aa.is_valid = is_valid_out; aa.status = status;
-    ProfScope ps(H2R_KERNEL_AUX, st);
+    ProfScope ps(H2R_KERNEL_AUX, st, true);   // dispatch-stamped events: no marker packets on the caller's stream
     const AuxGeom ag(ctx->L, 64);
-    hipLaunchKernelGGL((aux_kernel<64>), dim3((unsigned)batch), dim3(64), (unsigned)(ag.in_field_sz() + ag.em_sz()), st, aa);
+    hipExtLaunchKernelGGL((aux_kernel<64>), dim3((unsigned)batch), dim3(64), (unsigned)(ag.in_field_sz() + ag.em_sz()), st, ps.a, ps.b, 0, aa);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
 }
@@ -855,9 +952,9 @@ int32_t launch_in_field(const h2r_ctx *ctx, const void *x, const void *n, uint64
     aa.trace = static_cast<u8 *>(in_field_trace); aa.elem_stride = es; aa.off_in_field = 0;
     const AuxGeom ag(ctx->L, ctx->layout.limb_width);
     const unsigned lds = (unsigned)(ag.in_field_sz() + ag.em_sz());
-    ProfScope ps(H2R_KERNEL_AUX, st);
-    if (ctx->layout.limb_width == 64) hipLaunchKernelGGL((aux_kernel<64>), dim3((unsigned)batch), dim3(64), lds, st, aa);
-    else hipLaunchKernelGGL((aux_kernel<32>), dim3((unsigned)batch), dim3(64), lds, st, aa);
+    ProfScope ps(H2R_KERNEL_AUX, st, true);
+    if (ctx->layout.limb_width == 64) hipExtLaunchKernelGGL((aux_kernel<64>), dim3((unsigned)batch), dim3(64), lds, st, ps.a, ps.b, 0, aa);
+    else hipExtLaunchKernelGGL((aux_kernel<32>), dim3((unsigned)batch), dim3(64), lds, st, ps.a, ps.b, 0, aa);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
 }

@@ -969,6 +969,59 @@ def test_pipeline_full_size_rotation(H, depth, side_streams):
     pipe.close()
 
 
+@pytest.mark.parametrize("shared", [False, True])
+def test_pipeline_call_walked_as_sub_batches(H, shared):
+    """A large pipelined call that finds the pipeline empty (3,840 RSA-2048 signatures: 1,024 + 1,536 + 1,280) is walked by
+    the library as sub-batches with their own chain and record kernels; the same call behind a record kernel in flight is
+    one launch.  The caller must not be able to tell:
+    trace, in-field witness, results and statuses equal the one-call export's byte for byte, the workspace is the whole
+    call's plan (the in-place audit of every record runs on it), also with one shared modulus."""
+    from halo2_rsa_amd import big_integer as BI
+    chip = H.BigIntChip(64, 2048)
+    pl = chip.pow_fixed_layout(65537)
+    rng = random.Random(909 + shared)
+    B = 3840
+    base = [rand_modulus(rng, 2048) for _ in range(48)]
+    N = [base[0]] if shared else [base[i % 48] ^ ((i // 48) << 70) | 1 for i in range(B)]
+    X = [((base[i % 48] >> 3) * (2 * i + 1) + i) % N[0 if shared else i] for i in range(B)]
+    if not shared:
+        X[1500] = N[1500] + 5       # not in field: status only, in the second sub-batch
+    x, n = chip.assign_integer(X), chip.assign_integer(N)
+    ref = chip.pow_mod_fixed_exp(x, 65537, n, check_in_field=True,
+                                 trace_buf=torch.zeros(B * pl.elem_stride, dtype=torch.uint8, device="cuda"))
+    sets = [dict(trace=torch.zeros(B * pl.elem_stride, dtype=torch.uint8, device="cuda"),
+                 ws=torch.zeros(chip.workspace_bytes(B, pl.num_mul_mods), dtype=torch.uint8, device="cuda"),
+                 out=torch.zeros((B, 32), dtype=torch.int64, device="cuda"),
+                 status=torch.zeros(B, dtype=torch.uint8, device="cuda"),
+                 inf=torch.zeros(B * chip.in_field_layout()[0], dtype=torch.uint8, device="cuda")) for _ in range(2)]
+    pipe = chip.pipeline()
+    torch.cuda.synchronize()
+    for b in sets:   # the first call finds the pipeline empty (sub-batches), the second one the first call's record kernels
+        pipe.modpow_public_key(x, 65537, n, b["trace"], b["ws"], b["out"], b["status"], in_field_buf=b["inf"])
+    pipe.join()
+    torch.cuda.synchronize()
+    for b in sets:
+        status, out = b["status"], b["out"]
+        assert torch.equal(status, ref.status)
+        st = status.cpu().numpy()
+        assert (st != 0).sum() == (0 if shared else 1) and (shared or st[1500] == H.H2R_E_NOT_IN_FIELD)
+        ok = torch.from_numpy(st == 0).cuda()      # the element with a status has no defined result or records
+        assert torch.equal(out[ok], ref.value.limbs_dev[ok])
+        got = H.AssignedInteger(out, 64).to_big_uint()
+        assert all(got[i] == pow(X[i], 65537, N[0 if shared else i]) for i in range(B) if st[i] == 0)
+        for lo_ in range(0, B, 512):                 # every byte of every element's records
+            sl = slice(lo_, lo_ + 512)
+            assert torch.equal(b["trace"].view(B, -1)[sl][ok[sl]], ref.trace.buf.view(B, -1)[sl][ok[sl]]), lo_
+        assert torch.equal(b["inf"].view(B, -1)[ok], ref.in_field.buf[:b["inf"].numel()].view(B, -1)[ok])
+        tr = H.Trace(chip, b["trace"], B, pl)
+        res = BI.BatchResult(H.AssignedInteger(out, 64), tr, status, workspace=b["ws"], inputs=ref.inputs)
+        bad, first = res.audit()
+        torch.cuda.synchronize()
+        nb = bad.cpu().numpy()
+        assert not nb[st == 0].any(), ("audit", int(np.nonzero(nb)[0][0]))
+    pipe.close()
+
+
 def _check_pow_batch(H, chip, o, X, N, e, res, sample, rng):
     torch.cuda.synchronize()
     assert not res.status.cpu().numpy().any()
