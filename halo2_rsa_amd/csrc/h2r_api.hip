@@ -250,9 +250,11 @@ hipError_t launch_chain(const h2r_ctx *c, const ChainArgs &ca, bool co_running, 
     // batch-1024 RSA-2048 call has; a larger batch is walked by that grid instead of queueing more workgroups (a chain
     // kernel with 8,192 workgroups kept every CU full of its waves and cost the record kernel 15 % of its store rate).
     const u64 cap4 = co_running ? 4ull * c->num_cus : 0, cap2 = co_running ? 2ull * c->num_cus : 0;
-    // The chain kernel is compiled for K = 8, 16, 32, 64, 128 digits; any other size runs as the next larger one with
+    // The chain kernel is compiled for K = 8, 16, 32, 64, 96, 128 digits; any other size runs as the next larger one with
     // zero high digits (ca.kreal digits in memory).  NW = waves per element (a multiple of the 64-column groups).
-    const u32 K = ca.kreal <= 8 ? 8 : ca.kreal <= 16 ? 16 : ca.kreal <= 32 ? 32 : ca.kreal <= 64 ? 64 : 128;
+    // K = 96 (RSA-3072) is its own build: run as K = 128 it did 1.8x the multiply-accumulates and made the chain kernel
+    // the longer leg of the pipeline (0.57-0.65 ms against a 0.49 ms record kernel per 1,024 signatures).
+    const u32 K = ca.kreal <= 8 ? 8 : ca.kreal <= 16 ? 16 : ca.kreal <= 32 ? 32 : ca.kreal <= 64 ? 64 : ca.kreal <= 96 ? 96 : 128;
     switch (K) {
         case 8: return launch_chain_t<8, 1, false>(ca, 4 * cap4, st, ea, eb);
         case 16: return launch_chain_t<16, 1, false>(ca, 4 * cap4, st, ea, eb);
@@ -269,6 +271,7 @@ hipError_t launch_chain(const h2r_ctx *c, const ChainArgs &ca, bool co_running, 
             if (nw == 2) return launch_chain_t<64, 2, false>(ca, 2 * cap4, st, ea, eb);
             return deep ? launch_chain_t<64, 4, true>(ca, cap4, st, ea, eb) : launch_chain_t<64, 4, false>(ca, cap4, st, ea, eb);
         }
+        case 96: return launch_chain_t<96, 6, false>(ca, cap4 * 2 / 3, st, ea, eb);
         default: return launch_chain_t<128, 8, false>(ca, cap2, st, ea, eb);
     }
 }

@@ -98,8 +98,13 @@ struct Geo {
     static constexpr int CG = (2 * K + 63) / 64;  // column groups
     static constexpr int SS = NW / CG;            // step slices
     static constexpr int SL = K / SS;             // steps per slice
-    static constexpr int SSMAX = (K >= 64) ? NW / (K / 64) : SS;   // slices of the half products (K columns)
-    static_assert(NW % CG == 0 && SS >= 1 && K % SS == 0, "bad chain geometry");
+    static constexpr int CGH = (K + 63) / 64;     // column groups of the half products (a window of 64 * CGH >= K columns)
+    static constexpr int SSMAX = (K >= 64) ? NW / CGH : SS;        // slices of the half products
+    static constexpr int LK = (K - 1) % 64;       // lane of digit K-1 in its group (63 unless the last group is partial)
+    // K >= 64 that is not a multiple of 64 (K = 96: RSA-3072): the last group of a number is partial -- its idle lanes
+    // PROPAGATE in every carry/borrow chain so that the carry out of digit K-1 reaches the group's carry-out
+    static constexpr bool PASS = K >= 64 && K % 64 != 0;
+    static_assert(NW % CG == 0 && SS >= 1 && K % SS == 0 && (K < 64 || NW % CGH == 0), "bad chain geometry");
 };
 
 template <int K, int NW>
@@ -161,7 +166,7 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
     using G = Geo<K, NW>;
     constexpr int V = G::V;
     constexpr bool HALF = (MODE != MUL_FULL) && (K >= 64);
-    constexpr int CGA = HALF ? K / 64 : G::CG;           // active 64-column groups
+    constexpr int CGA = HALF ? G::CGH : G::CG;           // active 64-column groups
     constexpr int SSA = NW / CGA;                         // step slices
     constexpr int SLA = K / SSA;                          // steps per slice
     constexpr int CB = (HALF && MODE == MUL_HIGH) ? K - 2 : 0;   // first column of the window
@@ -175,7 +180,9 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
         const int j0 = ss * SLA;
         u64 acc = 0;
         u32 ov = 0;
-        const u32 *bp = Bpad + K + c - j0;
+        // a window wider than the columns that exist (partial last group): the lanes beyond column 2K-1 walk the zero
+        // padding of column 2K-1 and store nothing
+        const u32 *bp = Bpad + K + (G::PASS && c > 2 * K - 1 ? 2 * K - 1 : c) - j0;
         const u32 *ap = A + j0;
         if constexpr (DEEP && SLA % 4 == 0) {
             // Latency build: one wave per SIMD, so nothing hides the LDS round trip but this wave's own instructions.
@@ -250,7 +257,7 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
             }
         }
         if (c < 2 * K) { s.part[ss][0][c] = (u32)acc; s.part[ss][1][c] = (u32)(acc >> 32); s.part[ss][2][c] = ov; }
-        if constexpr (HALF && MODE == MUL_HIGH) {
+        if constexpr (HALF && MODE == MUL_HIGH && K % 64 == 0) {
             // column 2K-2 lies one past the window: its single product A[K-1]*B[K-1]
             if (lane == 0) {
                 const u64 p = (wave == 0) ? (u64)A[K - 1] * Bpad[K + K - 1] : 0;
@@ -280,8 +287,9 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
     if (wave != 0) return;
     constexpr int GWL = K < 64 ? K : 64;        // lanes of a column group
     u32 prev_x1 = 0, prev_x2 = 0, prev_r1 = 0, prev_thi = 0;   // previous group's words, for the seam lanes
+    int seam = GWL - 1;   // lane of the previous group's last column
     auto shr1 = [&](u32 cur, u32 prev) -> u32 {   // value of lane-1; lane 0 takes the previous group's last lane
-        const u32 up = __builtin_amdgcn_readlane(prev, GWL - 1);
+        const u32 up = __builtin_amdgcn_readlane(prev, seam);
         return (u32)__builtin_amdgcn_update_dpp((int)up, (int)cur, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
     };
     auto group = [&](int c, bool active) -> u64 {   // returns lo32 t(c) + hi32 t(c-1)
@@ -312,9 +320,12 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
         const int vv = lane + 64 * (g % V);
         const int c = vv + (g >= V ? K : 0);
         const bool in_col = vv < K;
+        // the group before this one: full (lane 63), or the partial last group of the low half (lane of column K-1); the
+        // high half product enters its first group from the two-column pre-step above, which sits in lanes 62, 63
+        seam = (g % V == 0 && !(HALF && MODE == MUL_HIGH)) ? G::LK : GWL - 1;
         const u64 d = group(c, in_col && !(HALF && MODE == MUL_HIGH && c >= 2 * K - 1));   // column 2K-1 of the window is zero
         const bool gen = in_col && (d >> 32) != 0;
-        const bool prop = in_col && ((u32)d == 0xffffffffu);
+        const bool prop = in_col ? ((u32)d == 0xffffffffu) : G::PASS;
         const CarryGroup cgp = carry_group(__ballot(gen), __ballot(prop), cin, G::GW);
         cin = cgp.cout;
         const u32 digit = in_col ? (u32)d + (u32)((cgp.cin_mask >> lane) & 1) : 0u;
@@ -322,8 +333,8 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
     }
     if constexpr (HALF && MODE == MUL_LOW) {
         // digit K = lo32( x0(K) + x1(K-1) + x2(K-2) + hi32 t(K-1) + carry out of digit K-1 ); x0(K) was left in x0[K+3]
-        dk = s.x0[K + 3] + __builtin_amdgcn_readlane(prev_x1, 63) + __builtin_amdgcn_readlane(prev_r1, 63) +
-             __builtin_amdgcn_readlane(prev_thi, 63) + (cin ? 1u : 0u);
+        dk = s.x0[K + 3] + __builtin_amdgcn_readlane(prev_x1, G::LK) + __builtin_amdgcn_readlane(prev_r1, G::LK) +
+             __builtin_amdgcn_readlane(prev_thi, G::LK) + (cin ? 1u : 0u);
     } else {
         dk = 0;
     }
@@ -341,9 +352,9 @@ __device__ __forceinline__ bool wave_add(u32 (&r)[(K + 63) / 64], const u32 (&a)
     for (int m = 0; m < V; ++m) {
         const bool act = lane + 64 * m < K;
         const u64 d = act ? (u64)a[m] + b[m] : 0;
-        const CarryGroup cg = carry_group(__ballot((d >> 32) != 0), __ballot(act && (u32)d == 0xffffffffu), cin, GW);
+        const CarryGroup cg = carry_group(__ballot((d >> 32) != 0), __ballot(act ? (u32)d == 0xffffffffu : (K >= 64)), cin, GW);
         cin = cg.cout;
-        r[m] = (u32)d + (u32)((cg.cin_mask >> lane) & 1);
+        r[m] = act ? (u32)d + (u32)((cg.cin_mask >> lane) & 1) : 0u;
     }
     return cin;
 }
@@ -356,9 +367,9 @@ __device__ __forceinline__ bool wave_sub(u32 (&r)[(K + 63) / 64], const u32 (&a)
 #pragma unroll
     for (int m = 0; m < V; ++m) {
         const bool act = lane + 64 * m < K;
-        const CarryGroup cg = carry_group(__ballot(act && a[m] < b[m]), __ballot(act && a[m] == b[m]), bin, GW);
+        const CarryGroup cg = carry_group(__ballot(act && a[m] < b[m]), __ballot(act ? a[m] == b[m] : (K >= 64)), bin, GW);
         bin = cg.cout;
-        r[m] = a[m] - b[m] - (u32)((cg.cin_mask >> lane) & 1);
+        r[m] = act ? a[m] - b[m] - (u32)((cg.cin_mask >> lane) & 1) : 0u;
     }
     return bin;
 }
@@ -387,9 +398,9 @@ __device__ __forceinline__ bool wave_inc(u32 (&a)[(K + 63) / 64], int lane) {
 #pragma unroll
     for (int m = 0; m < V; ++m) {
         const bool act = lane + 64 * m < K;
-        const CarryGroup cg = carry_group(0, __ballot(act && a[m] == 0xffffffffu), cin, GW);
+        const CarryGroup cg = carry_group(0, __ballot(act ? a[m] == 0xffffffffu : (K >= 64)), cin, GW);
         cin = cg.cout;
-        a[m] += (u32)((cg.cin_mask >> lane) & 1);
+        if (act) a[m] += (u32)((cg.cin_mask >> lane) & 1);
     }
     return cin;
 }
@@ -471,9 +482,9 @@ __device__ __forceinline__ void wave_reciprocal(ChainLds<K, NW> &s, const u32 (&
             const bool act = v < K;
             if (!act) remsh[m] = 0;
             const u64 d = act ? (u64)plo[m] + phi_prev[m] : 0;
-            const CarryGroup cg = carry_group(__ballot((d >> 32) != 0), __ballot(act && (u32)d == 0xffffffffu), cin, G::GW);
+            const CarryGroup cg = carry_group(__ballot((d >> 32) != 0), __ballot(act ? (u32)d == 0xffffffffu : (K >= 64)), cin, G::GW);
             cin = cg.cout;
-            e[m] = (u32)d + (u32)((cg.cin_mask >> lane) & 1);
+            e[m] = act ? (u32)d + (u32)((cg.cin_mask >> lane) & 1) : 0u;
         }
         const u32 etop = __builtin_amdgcn_readlane(phi[MT], LT) + (cin ? 1u : 0u);
         u32 diff[V];

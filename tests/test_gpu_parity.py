@@ -71,7 +71,9 @@ def test_rsa_kats_modpow_public_key(H, golden):
                                        # num_limbs that are not powers of two (BigIntChip::new only asserts bits_len % limb_width == 0,
                                        # big_integer/chip.rs:1174-1185): RSA-3072 (L = 48), RSA-1536 (24), 768 bits, odd multiples of 4 / 8
                                        (64, 48, 24), (64, 24, 24), (64, 12, 40), (64, 20, 16), (64, 60, 8), (32, 96, 8), (32, 24, 16),
-                                       (32, 72, 8), (32, 120, 6)])
+                                       (32, 72, 8), (32, 120, 6),
+                                       # 65..96 digits: the chain kernel's K = 96 build (partial last lane group), exact and padded
+                                       (64, 40, 16), (64, 44, 16), (32, 88, 8), (64, 36, 16)])
 def test_mul_mod_random_parity(H, w, L, batch):
     """mul_mod (reference big_integer/chip.rs:542-629) incl. the reference's own edge identities
     (:3123-3246), even and small moduli (the reference's random n is not forced odd, :1439-1442)."""
@@ -132,7 +134,7 @@ def _adversarial_cases(bits, rng):
     return out
 
 
-@pytest.mark.parametrize("w,L", [(64, 32), (32, 128), (64, 16), (64, 64), (64, 48), (64, 24)])
+@pytest.mark.parametrize("w,L", [(64, 32), (32, 128), (64, 16), (64, 64), (64, 48), (64, 24), (32, 96), (64, 40)])
 def test_mul_mod_adversarial_operands(H, w, L):
     """The chain kernel's ballot carries, DPP neighbour exchange and correction loop on adversarial digits: results
     against Python integers for every triple, full traces against the oracle for a sample.  330 elements keep the
