@@ -185,8 +185,13 @@ def main():
 
     env = DistEnv.from_environment(args.gpus, force=bool(os.environ.get("H2R_FORCE_DIST")))
     w, bits, e = WORKLOADS[args.workload]
+    # developer: H2R_BENCH_ONE_GPU=1 runs every rank on GPU 0 over gloo -- the N > 1 code path (shards, gather, checks) on a
+    # one-GPU box; not a measurement of anything
+    one_gpu = bool(os.environ.get("H2R_BENCH_ONE_GPU"))
+    if one_gpu:
+        env.local_rank = 0
     torch.cuda.set_device(env.local_rank)
-    env.init("nccl")
+    env.init("gloo" if one_gpu else "nccl")
     if args.user_stream:
         torch.cuda.set_stream(torch.cuda.Stream())
     # Workload: N = 1 -> BASELINE configs[1] (one 1,024-signature call per step).  N > 1 -> configs[2]: every GPU owns a

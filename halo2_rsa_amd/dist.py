@@ -84,9 +84,10 @@ class DistEnv:
             outs = [torch.empty_like(shard) for _ in range(self.world)]
             dist.all_gather(outs, shard)  # RCCL all-gather over xGMI; results are tiny (num_limbs limbs each)
             return torch.cat(outs, 0) if self.rank == 0 else None
-        outs = [torch.empty_like(shard) for _ in range(self.world)] if self.rank == 0 else None
-        dist.gather(shard, outs, dst=0)
-        return torch.cat(outs, 0) if self.rank == 0 else None
+        host = shard.cpu()   # gloo (CPU tests, one-GPU developer runs): gather on the host, hand back on the shard's device
+        outs = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+        dist.gather(host, outs, dst=0)
+        return torch.cat(outs, 0).to(shard.device) if self.rank == 0 else None
 
     def finalize(self):
         if self.initialised:
