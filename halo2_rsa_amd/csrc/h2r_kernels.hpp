@@ -2410,7 +2410,10 @@ template <int LW>
 __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
     using limb_t = typename LimbT<LW>::type;
     __shared__ u64 sa[128], sb_[128], sq[128], sn[128], sr[128];
-    constexpr u32 SR = 256;                                   // rows per stage (40 KB of LDS; 208 rows = four workgroups per CU measured 3 % slower for RSA-2048, 10 % faster for 32 x 128)
+#ifndef H2R_ADVICE_SR
+#define H2R_ADVICE_SR 256
+#endif
+    constexpr u32 SR = H2R_ADVICE_SR;                         // rows per stage (40 KB of LDS; 208 rows = four workgroups per CU measured 3 % slower for RSA-2048, 10 % faster for 32 x 128)
     __shared__ uint4 stage[SR * (ADVICE_ROW_BYTES / 16)];    // SR rows are built in LDS, then leave as full 16-byte-per-lane lines
     const u32 tid = threadIdx.x;
     const u32 item = blockIdx.x;
@@ -2446,27 +2449,68 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
     auto lim = [&](u64 v) { return U192::make(v, 0, 0); };
     // a range assign's row: four sub-limbs and the running sum after them
     auto range_row = [&](u32 r, u64 s_lo, u64 s_hi, u32 nsub, u32 sub_bits, u32 rr) {   // sub-limb bytes in (s_lo, s_hi), row rr of the assign
-        U192 c[4]; U192 run = Z;
-        for (u32 k = 0; k < 4 * (rr + 1) && k < nsub; ++k) {
-            const u64 sv = ((k < 8 ? s_lo : s_hi) >> (8 * (k & 7))) & 0xff;
-            const u32 sh = k * sub_bits;
-            U192 term = sh < 64 ? U192::make(sv << sh, sh ? sv >> (64 - sh) : 0, 0) : U192::make(0, sv << (sh - 64), 0);
-            run = run + term;
-            if (k >= 4 * rr) c[k - 4 * rr] = lim(sv);
+        U192 c0 = Z, c1 = Z, c2 = Z, c3 = Z, run = Z;   // (no indexed array: it would live in scratch)
+#pragma unroll
+        for (u32 k = 0; k < 12; ++k) {                   // at most 9 sub-limbs (8 + overflow), three rows
+            if (k < 4 * (rr + 1) && k < nsub) {
+                const u64 sv = ((k < 8 ? s_lo : s_hi) >> (8 * (k & 7))) & 0xff;
+                const u32 sh = k * sub_bits;
+                const U192 term = sh < 64 ? U192::make(sv << sh, sh ? sv >> (64 - sh) : 0, 0) : U192::make(0, sv << (sh - 64), 0);
+                run = run + term;
+                if (k >= 4 * rr) { const u32 q = k - 4 * rr; if (q == 0) c0 = lim(sv); else if (q == 1) c1 = lim(sv); else if (q == 2) c2 = lim(sv); else c3 = lim(sv); }
+            }
         }
-        for (u32 k = nsub > 4 * rr ? nsub - 4 * rr : 0; k < 4; ++k) c[k] = Z;
-        row(r, c[0], c[1], c[2], c[3], run);
+        row(r, c0, c1, c2, c3, run);
     };
     const u32 r_T2 = 2 * L, r_T3 = 4 * L, r_T4 = r_T3 + L * L, r_T5 = r_T4 + L * L, r_T6 = r_T5 + L;
     const u32 per_col = 17 + nrc;
-    for (u32 r0 = 0; r0 < a.rows; r0 += SR) {
-      const u32 r = r0 + tid;
-      if (tid < SR && r < a.rows) {
-        if (r < r_T3) {                                   // q then r limbs: RangeChip::assign(limb, w/8, w)
+    // A row has five cells; at most three of them come from the record, the others are constants, flag bytes or staged
+    // operands.  Every row is therefore described the same way -- up to three sources (a 16-, 8- or 4-byte load plus an
+    // optional 8-byte third word) -- so that the lanes of a wave, which sit in ~20 different rows of 3-4 columns in the
+    // is_equal_muled part, issue the SAME few load instructions with different addresses (a switch over loads serialised
+    // ~20 dependent global round trips per wave; loading all 20 values of the column in every lane cost ~40 load
+    // instructions per wave).  The loads of the NEXT 256 rows are issued before the current 256 leave LDS for HBM, so
+    // their latency hides behind the write-out.
+    // The loads themselves are unconditional and of one width (16 bytes at `lo`, 8 at `hi`; what the source does not have is
+    // masked off afterwards, an absent source points at the record's first bytes): a load inside a divergent branch gets an
+    // s_waitcnt vmcnt(0) at the end of its block, which would serialise the fetches and defeat the prefetch.  A 16-byte read
+    // of an 8- or 4-byte plane entry ends at most 12 bytes behind the plane -- inside the record (its stride is padded).
+    struct Src { const u8 *lo; const u8 *hi; u32 mode; };   // mode & 3: 0 none, 1 = 4 B, 2 = 8 B, 3 = 16 B at lo; mode & 4: third word = sign of word 1; mode & 8: third word at hi
+    constexpr u32 CB = LW == 64 ? 16 : 8;
+    auto s_none = [&]() -> Src { return Src{rv.rec, rv.rec, 0u}; };
+    auto s_wide = [&](int pl_lo, u32 idx) -> Src {
+        if constexpr (LW == 64) return Src{rv.rec + a.off[pl_lo] + (u64)idx * 16, rv.rec + a.off[pl_lo + 1] + (u64)idx * 8, 3u | 8u};
+        else return Src{rv.rec + a.off[pl_lo] + (u64)idx * 16, rv.rec, 3u | 4u};
+    };
+    auto s_acc = [&](bool qn, u32 j, u32 im) -> Src {   // accumulator entry (j, i % L): RecView::acc's addressing
+        if constexpr (LW == 64)
+            return Src{rv.rec + a.off[qn ? H2R_PL_QN_LO : H2R_PL_AB_LO] + (u64)(j >> 1) * (3ull * 2 * L * 16) + (u64)(j & 1) * (2ull * L * 16) + (u64)im * 16,
+                       rv.rec + a.off[qn ? H2R_PL_QN_HI : H2R_PL_AB_HI] + (u64)(j >> 1) * (3ull * 2 * L * 16) + (u64)im * 16 + (j & 1) * 8, 3u | 8u};
+        else return Src{rv.rec + a.off[qn ? H2R_PL_QN_LO : H2R_PL_AB_LO] + (u64)j * ((u64)L * 16) + (u64)im * 16, rv.rec, 3u};
+    };
+    auto s_carry = [&](int pl, u32 idx) -> Src { return Src{rv.rec + a.off[pl] + (u64)idx * CB, rv.rec, LW == 64 ? 3u : 2u}; };
+    auto s_limb = [&](int pl, u32 idx) -> Src { return Src{rv.rec + a.off[pl] + (u64)idx * (LW / 8), rv.rec, LW == 64 ? 2u : 1u}; };
+    enum : u32 { ROW_RANGE_LIMB = 20, ROW_RANGE_CARRY = 21, ROW_MUL_ADD = 22, ROW_EQB = 23, ROW_NONE = 99 };
+    // per-row state that lives across the write-out of the previous rows
+    u32 kk = ROW_NONE, aux = 0, m0 = 0, m1 = 0, m2 = 0, fl = 0, eprev = 1, has_prev = 0;
+    u64 imm0 = 0, imm1 = 0, h0 = 0, h1 = 0, h2 = 0;
+    ulonglong2 l0 = make_ulonglong2(0, 0), l1 = l0, l2 = l0;
+    auto fetch = [&](const Src &sc, ulonglong2 &lo, u64 &hi, u32 &mode) {
+        mode = sc.mode;
+        const u64 *p = reinterpret_cast<const u64 *>(sc.lo);   // 8-byte aligned at least (4 for the 32-bit limb planes)
+        lo = make_ulonglong2(p[0], p[1]);
+        hi = *reinterpret_cast<const u64 *>(sc.hi);
+    };
+    auto plan_and_load = [&](u32 r) {
+        kk = ROW_NONE;
+        Src s0 = s_none(), s1 = s_none(), s2 = s_none();
+        const u8 *fp = rv.rec, *fpp = rv.rec;   // flag words of the column and of the one before it
+        has_prev = 0;
+        if (r >= a.rows) {
+        } else if (r < r_T3) {                                   // q then r limbs: RangeChip::assign(limb, w/8, w)
             const bool isr = r >= r_T2; const u32 rr = (isr ? r - r_T2 : r);
-            const u32 k = rr >> 1;
-            const u64 sub = *reinterpret_cast<const u64 *>(rv.rec + a.off[isr ? H2R_PL_R_SUB : H2R_PL_Q_SUB] + (u64)k * 8);
-            range_row(r, sub, 0, 8, LW / 8, rr & 1);
+            kk = ROW_RANGE_LIMB; aux = rr & 1;
+            s0 = Src{rv.rec + a.off[isr ? H2R_PL_R_SUB : H2R_PL_Q_SUB] + (u64)(rr >> 1) * 8, rv.rec, 2u};
         } else if (r < r_T5) {                            // mul_add rows, column i ascending then j ascending
             const bool qn = r >= r_T4; const u32 e = qn ? r - r_T4 : r - r_T3;
             // entry e of the column order -> (i, j): columns 0..L-1 hold i+1 entries, then 2L-1-i
@@ -2482,58 +2526,74 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
                 j = e - emit_colstart(i, L) + (i - L + 1);
             }
             const u32 jmin = i >= L ? i - L + 1 : 0, im = i >= L ? i - L : i;
-            const u64 x = qn ? sq[j] : sa[j], y = qn ? sn[i - j] : sb_[i - j];
-            row(r, lim(x), lim(y), j == jmin ? Z : rv.acc(qn, j - 1, im), rv.acc(qn, j, im), Z);
+            kk = ROW_MUL_ADD;
+            imm0 = qn ? sq[j] : sa[j]; imm1 = qn ? sn[i - j] : sb_[i - j];
+            if (j != jmin) s0 = s_acc(qn, j - 1, im);
+            s1 = s_acc(qn, j, im);
         } else if (r < r_T6) {                            // eq_b[i] = qn[i] + r[i]
             const u32 i = r - r_T5;
-            row(r, rv.acc(true, i, i), lim(sr[i]), rv.wide(H2R_PL_EQB_LO, i), Z, Z);
+            kk = ROW_EQB; imm0 = sr[i];
+            s0 = s_acc(true, i, i); s2 = s_wide(H2R_PL_EQB_LO, i);
         } else {                                          // is_equal_muled step rows
             const u32 rr = r - r_T6;
             const u32 c = rr / per_col < C - 1 ? rr / per_col : C - 1, k = rr - c * per_col;
             const u32 jmax = c < L ? c : L - 1, im = c < L ? c : c - L;
-            // The lanes of a wave sit in ~20 different rows of 3-4 columns: every lane loads ALL values of its column with
-            // the same instruction sequence (the loads overlap; lanes of one column hit the same lines) and only the choice
-            // of the row's three cells diverges -- a switch over loads serialised ~20 dependent global round trips per wave.
-            const U192 v_ab = rv.acc(false, jmax, im), v_eqb = c < L ? rv.wide(H2R_PL_EQB_LO, c) : rv.acc(true, jmax, im);
-            const U192 v_amb = rv.wide(H2R_PL_AMB_LO, c), v_sum = rv.wide(H2R_PL_SUM_LO, c), v_cy = rv.carry(H2R_PL_CARRY, c);
-            const U192 v_cprev = c ? rv.carry(H2R_PL_CARRY, c - 1) : Z, v_xprev = c ? rv.carry(H2R_PL_QACC, c - 1) : Z;
-            const U192 v_nq1 = rv.wide(H2R_PL_NQ1_LO, c), v_accx = rv.wide(H2R_PL_ACCX_LO, c), v_qacc = rv.carry(H2R_PL_QACC, c);
-            const U192 v_nq2 = rv.wide(H2R_PL_NQ2_LO, c), v_dup = c < C - 1 ? rv.carry(H2R_PL_CARRY_DUP, c) : v_qacc;
-            const U192 v_cmod = lim(rv.limb(H2R_PL_CMOD, c)), v_amnq1 = lim(rv.limb(H2R_PL_AMNQ1, c));
-            const U192 v_modacc = lim(rv.limb(H2R_PL_MODACC, c)), v_amnq2 = lim(rv.limb(H2R_PL_AMNQ2, c));
-            const u32 fl = *reinterpret_cast<const u32 *>(rv.rec + a.off[H2R_PL_FLAGS] + (u64)c * 4);
-            const u32 eprev = c ? (*reinterpret_cast<const u32 *>(rv.rec + a.off[H2R_PL_FLAGS] + (u64)(c - 1) * 4) >> 24) : 1u;
-            const ulonglong2 sv = *reinterpret_cast<const ulonglong2 *>(rv.rec + a.off[H2R_PL_CARRY_SUB] + (u64)(c < C - 1 ? c : 0) * a.carry_sub_stride);
-            const bool is_range = c < C - 1 && k >= 15 && k < 15 + nrc;
-            if (is_range) {                                   // RangeChip::assign(carry, sublimb_bit_len(carry_bits), carry_bits)
-                range_row(r, sv.x, sv.y, a.carry_nsub, a.carry_sub_bits, k - 15);
+            if (c < C - 1 && k >= 15 && k < 15 + nrc) {   // RangeChip::assign(carry, sublimb_bit_len(carry_bits), carry_bits)
+                kk = ROW_RANGE_CARRY; aux = k - 15;
+                s0 = Src{rv.rec + a.off[H2R_PL_CARRY_SUB] + (u64)c * a.carry_sub_stride, rv.rec, 3u};
             } else {
-                U192 c0 = Z, c1 = Z, c2 = Z; bool s0 = false, s2 = false;
-                const u32 kk = k < 15 ? k : (k == (c < C - 1 ? 15 + nrc : 15) ? 15u : 16u);
+                kk = k < 15 ? k : (k == (c < C - 1 ? 15 + nrc : 15) ? 15u : 16u);
                 switch (kk) {
-                    case 0: c0 = v_ab; c1 = v_eqb; c2 = v_amb; s2 = true; break;
-                    case 1: c0 = v_amb; c1 = v_cprev; c2 = v_sum; s0 = true; break;
-                    case 2: c0 = v_cy; break;
-                    case 3: c0 = v_cmod; break;
-                    case 4: c0 = B; c1 = v_cy; c2 = v_nq1; break;
-                    case 5: c0 = v_sum; c1 = v_nq1; c2 = v_amnq1; break;
-                    case 6: c0 = v_cmod; c1 = v_amnq1; break;
-                    case 7: c0 = v_xprev; c1 = v_accx; break;
-                    case 8: c0 = v_qacc; break;
-                    case 9: c0 = v_modacc; break;
-                    case 10: c0 = B; c1 = v_qacc; c2 = v_nq2; break;
-                    case 11: c0 = v_accx; c1 = v_nq2; c2 = v_amnq2; break;
-                    case 12: c0 = v_modacc; c1 = v_amnq2; break;
-                    case 13: c0 = v_cmod; c1 = v_modacc; c2 = lim(fl & 0xff); break;
-                    case 14: c0 = lim(eprev); c1 = lim(fl & 0xff); c2 = lim((fl >> 8) & 0xff); break;
-                    case 15: c0 = v_cy; c1 = v_dup; c2 = lim((fl >> 16) & 0xff); break;          // range_eq / final_carry_eq
-                    default: c0 = lim((fl >> 8) & 0xff); c1 = lim((fl >> 16) & 0xff); c2 = lim(fl >> 24); break;
+                    case 0: s0 = s_acc(false, jmax, im); s1 = c < L ? s_wide(H2R_PL_EQB_LO, c) : s_acc(true, jmax, im); s2 = s_wide(H2R_PL_AMB_LO, c); break;
+                    case 1: s0 = s_wide(H2R_PL_AMB_LO, c); if (c) s1 = s_carry(H2R_PL_CARRY, c - 1); s2 = s_wide(H2R_PL_SUM_LO, c); break;
+                    case 2: s0 = s_carry(H2R_PL_CARRY, c); break;
+                    case 3: s0 = s_limb(H2R_PL_CMOD, c); break;
+                    case 4: s1 = s_carry(H2R_PL_CARRY, c); s2 = s_wide(H2R_PL_NQ1_LO, c); break;
+                    case 5: s0 = s_wide(H2R_PL_SUM_LO, c); s1 = s_wide(H2R_PL_NQ1_LO, c); s2 = s_limb(H2R_PL_AMNQ1, c); break;
+                    case 6: s0 = s_limb(H2R_PL_CMOD, c); s1 = s_limb(H2R_PL_AMNQ1, c); break;
+                    case 7: if (c) s0 = s_carry(H2R_PL_QACC, c - 1); s1 = s_wide(H2R_PL_ACCX_LO, c); break;
+                    case 8: s0 = s_carry(H2R_PL_QACC, c); break;
+                    case 9: s0 = s_limb(H2R_PL_MODACC, c); break;
+                    case 10: s1 = s_carry(H2R_PL_QACC, c); s2 = s_wide(H2R_PL_NQ2_LO, c); break;
+                    case 11: s0 = s_wide(H2R_PL_ACCX_LO, c); s1 = s_wide(H2R_PL_NQ2_LO, c); s2 = s_limb(H2R_PL_AMNQ2, c); break;
+                    case 12: s0 = s_limb(H2R_PL_MODACC, c); s1 = s_limb(H2R_PL_AMNQ2, c); break;
+                    case 13: s0 = s_limb(H2R_PL_CMOD, c); s1 = s_limb(H2R_PL_MODACC, c); break;
+                    case 15: s0 = s_carry(H2R_PL_CARRY, c); s1 = c < C - 1 ? s_carry(H2R_PL_CARRY_DUP, c) : s_carry(H2R_PL_QACC, c); break;   // range_eq / final_carry_eq
+                    default: break;                       // 14, 16: flag bytes only
                 }
-                row(r, c0, c1, c2, Z, Z, s2, s0);
+                fp = rv.rec + a.off[H2R_PL_FLAGS] + (u64)c * 4;
+                fpp = c ? fp - 4 : fp; has_prev = c ? 1u : 0u;
             }
         }
-      }
+        fetch(s0, l0, h0, m0); fetch(s1, l1, h1, m1); fetch(s2, l2, h2, m2);
+        fl = *reinterpret_cast<const u32 *>(fp);
+        eprev = *reinterpret_cast<const u32 *>(fpp);
+    };
+    auto val = [&](const ulonglong2 &lo, u64 hi, u32 mode) -> U192 {
+        const u32 wd = mode & 3u;
+        if (!wd) return Z;
+        return U192::make(wd == 1u ? (lo.x & 0xffffffffull) : lo.x, wd == 3u ? lo.y : 0, (mode & 4u) ? (u64)((i64)lo.y >> 63) : ((mode & 8u) ? hi : 0));
+    };
+    auto build = [&](u32 r) {
+        if (kk == ROW_NONE) return;
+        if (kk == ROW_RANGE_LIMB) { range_row(r, l0.x, 0, 8, LW / 8, aux); return; }   // eight sub-limbs, one byte each
+        if (kk == ROW_RANGE_CARRY) { range_row(r, l0.x, l0.y, a.carry_nsub, a.carry_sub_bits, aux); return; }
+        U192 c0 = val(l0, h0, m0), c1 = val(l1, h1, m1), c2 = val(l2, h2, m2);
+        if (kk == ROW_MUL_ADD) { row(r, lim(imm0), lim(imm1), c0, c1, Z); return; }
+        if (kk == ROW_EQB) { row(r, c0, lim(imm0), c2, Z, Z); return; }
+        if (kk == 4 || kk == 10) c0 = B;
+        else if (kk == 13) c2 = lim(fl & 0xff);
+        else if (kk == 14) { c0 = lim(has_prev ? (eprev >> 24) : 1u); c1 = lim(fl & 0xff); c2 = lim((fl >> 8) & 0xff); }
+        else if (kk == 15) c2 = lim((fl >> 16) & 0xff);
+        else if (kk == 16) { c0 = lim((fl >> 8) & 0xff); c1 = lim((fl >> 16) & 0xff); c2 = lim(fl >> 24); }
+        row(r, c0, c1, c2, Z, Z, kk == 0, kk == 1);
+    };
+    static_assert(SR <= 256, "one row per thread and stage");
+    plan_and_load(tid < SR ? tid : a.rows);
+    for (u32 r0 = 0; r0 < a.rows; r0 += SR) {
+      build(r0 + tid);
       __syncthreads();
+      if (r0 + SR < a.rows) plan_and_load(tid < SR ? r0 + SR + tid : a.rows);   // in flight while this stage leaves for HBM
       const u32 n_rows = a.rows - r0 < SR ? a.rows - r0 : SR;
       uint4 *dst = reinterpret_cast<uint4 *>(out + (u64)r0 * ADVICE_ROW_BYTES);
       for (u32 k = tid; k < n_rows * (ADVICE_ROW_BYTES / 16); k += 256) {
