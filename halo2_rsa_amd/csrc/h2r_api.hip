@@ -84,6 +84,7 @@ struct Knobs {
     int pipe_stream_prio = -1;                   // H2R_PIPE_STREAM_PRIO = low (default) | normal | high  -> -1 | 0 | +1
     bool chain_timing = false;                   // H2R_CHAIN_TIMING (needs the -DH2R_CHAIN_TIMING build)
     bool pipe_serialize = false;                 // H2R_PIPE_SERIALIZE=1: with two record streams, a record kernel also waits for the previous one
+    long plain_overlap = -1;                     // H2R_PLAIN_OVERLAP=0: the plain pow exports never overlap their sub-batches internally
     long pipe_sub_batch = 0;                     // H2R_PIPE_SUB_BATCH: elements per chain + record kernel pair inside a pipelined call (multiple of 256)
     long pipe_pace = -1;                         // H2R_PIPE_PACE=0|1: sub-batch i+1's chain kernel waits for sub-batch i-1's record kernel
     Knobs() {
@@ -96,7 +97,7 @@ struct Knobs {
         pipe_stream_prio = !pe ? -1 : (!std::strcmp(pe, "high") ? 1 : (!std::strcmp(pe, "low") ? -1 : 0));
         chain_timing = std::getenv("H2R_CHAIN_TIMING") != nullptr;
         { const char *g = std::getenv("H2R_PIPE_SERIALIZE"); pipe_serialize = g && g[0] == '1'; }
-        pipe_sub_batch = num("H2R_PIPE_SUB_BATCH", 0); pipe_pace = num("H2R_PIPE_PACE", -1);
+        pipe_sub_batch = num("H2R_PIPE_SUB_BATCH", 0); plain_overlap = num("H2R_PLAIN_OVERLAP", -1); pipe_pace = num("H2R_PIPE_PACE", -1);
 #endif
     }
 };
@@ -146,6 +147,10 @@ struct h2r_ctx {
     u8 refresh_inc[2 * 128 + 8]; u32 refresh_nf; u8 *refresh_inc_dev;
     u64 field_p[4];   // the field modulus (a_b encoding, chip.rs:859)
     u32 num_cus, lds_per_cu;   // of the ctx's device
+    // the plain (stream-ordered) pow exports overlap chain and record kernels INSIDE a large call through this pipeline
+    // (created on first use; calls on one ctx from several threads take turns queueing)
+    mutable std::mutex pipe_mu;
+    mutable h2r_pipeline *pipe = nullptr;
 };
 
 namespace {
@@ -529,6 +534,7 @@ void h2r_ctx_destroy(h2r_ctx *ctx) {
         DeviceGuard dg(ctx->params.device);
         if (ctx->const_rec_dev) (void)hipFree(ctx->const_rec_dev);
         if (ctx->refresh_inc_dev) (void)hipFree(ctx->refresh_inc_dev);
+        if (ctx->pipe) h2r_pipeline_destroy(ctx->pipe);
     }
     delete ctx;
 }
@@ -612,6 +618,13 @@ int32_t launch_verify_aux(const h2r_ctx *ctx, const void *sig, const void *n, co
 int32_t launch_in_field(const h2r_ctx *ctx, const void *x, const void *n, uint64_t batch, uint32_t flags, void *in_field_trace, hipStream_t st);
 }
 
+namespace {
+bool plain_call_overlaps(const h2r_ctx *c, u64 batch);
+int32_t overlapped_pow_fixed(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch,
+                             uint32_t flags, void *trace, const h2r_pow_layout &pl, void *out, uint8_t *status, void *workspace,
+                             hipStream_t st, u32 check_in_field, u32 T);
+}
+
 static int32_t pow_fixed_impl(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le, size_t e_len,
                               uint64_t batch, uint32_t flags, void *trace, void *out, uint8_t *status,
                               void *workspace, h2r_stream_t stream, u32 check_in_field) {
@@ -622,6 +635,11 @@ static int32_t pow_fixed_impl(const h2r_ctx *ctx, const void *x, const void *n, 
     h2r_pow_layout pl;
     rc = h2r_pow_fixed_layout(ctx, e_le, e_len, &pl);
     if (rc) return rc;
+    // a large call with a trace: sub-batches whose chain kernels run next to the previous sub-batch's record kernel (a side
+    // stream of the ctx), joined back onto the caller's stream before returning -- stream-ordered as ever for the caller
+    if (trace && T && x && n && status && ctx->params.device >= 0 && plain_call_overlaps(ctx, batch))
+        return overlapped_pow_fixed(ctx, x, n, e_le, e_len, batch, flags, trace, pl, out, status, workspace,
+                                    static_cast<hipStream_t>(stream), check_in_field, T);
     return run_path(ctx, CHAIN_POW_FIXED, x, nullptr, n, nullptr, 0, 0, &eb, check_in_field, batch, flags, T, trace,
                     pl.elem_stride, pl.off_records, &pl, out, status, workspace, static_cast<hipStream_t>(stream));
 }
@@ -835,7 +853,7 @@ bool pipeline_busy(h2r_pipeline *p) {
 //    the chain kernels run back to back either way, the record kernels hide behind them, and the last record kernel of a
 //    call is a quarter as long (4,096 signatures: 1.39-1.44 -> 1.60-1.62 M assigns/s over six calls).
 //  * RSA-1024 and the 32-bit-limb shapes: no gain measured from any split; one launch.
-void pipeline_plan(h2r_pipeline *p, u64 batch, std::vector<u64> &sizes, bool &pace) {
+void pipeline_plan(h2r_pipeline *p, u64 batch, bool assume_empty, std::vector<u64> &sizes, bool &pace) {
     const h2r_ctx *c = p->ctx;
     sizes.clear(); pace = false;
     const u64 unit = (u64)c->num_cus * (c->K > 64 ? 2 : 4);   // one chain-kernel grid: four 4-wave (two 8-wave) workgroups per CU
@@ -850,7 +868,7 @@ void pipeline_plan(h2r_pipeline *p, u64 batch, std::vector<u64> &sizes, bool &pa
         for (u64 o = 0; o < batch; o += 2 * unit) sizes.push_back(std::min<u64>(2 * unit, batch - o));
         return;
     }
-    if (w64 && c->L > 16 && c->L <= 32 && batch > unit + unit / 2 && !pipeline_busy(p)) {   // record-bound, pipeline empty
+    if (w64 && c->L > 16 && c->L <= 32 && batch > unit + unit / 2 && (assume_empty || !pipeline_busy(p))) {   // record-bound, pipeline empty
         pace = true;
         u64 cur = unit, left = batch;
         while (left) {
@@ -868,7 +886,8 @@ void pipeline_plan(h2r_pipeline *p, u64 batch, std::vector<u64> &sizes, bool &pa
 // record kernel on a side stream, then the lazy join of the call whose buffers the next call may reuse.
 int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch,
                        uint32_t flags, void *trace, const h2r_pow_layout &pl, uint64_t elem_stride, void *out,
-                       uint8_t *status, void *workspace, hipStream_t st, const std::function<int32_t()> &after_chain) {
+                       uint8_t *status, void *workspace, hipStream_t st, const std::function<int32_t()> &after_chain,
+                       u32 check_in_field = 1, bool assume_empty = false) {
     const h2r_ctx *ctx = p->ctx;
     ExpBits eb; u32 T;
     int32_t rc = exp_to_bits(e_le, e_len, &eb, &T);
@@ -884,7 +903,7 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
     // The sub-batches are slices of the caller's buffers and of the whole call's workspace plan ([batch*T][4][L],
     // element-major), so audits and emitters see one call.
     std::vector<u64> sizes; bool pace = false;
-    pipeline_plan(p, batch, sizes, pace);
+    pipeline_plan(p, batch, assume_empty, sizes, pace);
     const bool split = sizes.size() > 1;
     const h2r_layout &lo = ctx->layout;
     const Workspace wp = workspace_plan(lo.limb_bytes, ctx->L, batch, T ? T : 1);
@@ -898,7 +917,7 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
         DoneRef cur{};
         const u8 *xs = static_cast<const u8 *>(x) + o * in_bytes;
         const u8 *ns = static_cast<const u8 *>(n) + ((flags & H2R_F_SHARED_MODULUS) ? 0 : o * in_bytes);
-        rc = run_path(ctx, CHAIN_POW_FIXED, xs, nullptr, ns, nullptr, 0, 0, &eb, 1, nb, flags, T,
+        rc = run_path(ctx, CHAIN_POW_FIXED, xs, nullptr, ns, nullptr, 0, 0, &eb, check_in_field, nb, flags, T,
                       static_cast<u8 *>(trace) + o * elem_stride, elem_stride, pl.off_records, &pl,
                       out ? static_cast<u8 *>(out) + o * in_bytes : nullptr, status + o, split ? ws + o * ws_elem : workspace,
                       st, p->aux[p->k & 1], p->chain_done[slot], last ? p->trace_done[slot] : p->sub_done[i & 1],
@@ -924,6 +943,37 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
         if (rc) return rc;
     }
     return H2R_OK;
+}
+
+// Does a plain (non-pipelined) pow call of this size gain from being walked as overlapping sub-batches?  The shapes and
+// sizes pipeline_plan splits for an empty pipeline.
+bool plain_call_overlaps(const h2r_ctx *c, u64 batch) {
+    if (knobs().plain_overlap == 0) return false;
+    const u64 unit = (u64)c->num_cus * (c->K > 64 ? 2 : 4);
+    if (c->layout.limb_width != 64) return false;
+    if (c->L > 32) return batch > 3 * unit;
+    return c->L > 16 && batch > unit + unit / 2;
+}
+
+int32_t overlapped_pow_fixed(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch,
+                             uint32_t flags, void *trace, const h2r_pow_layout &pl, void *out, uint8_t *status, void *workspace,
+                             hipStream_t st, u32 check_in_field, u32 T) {
+    H2R_ON_DEVICE(ctx->params.device);
+    std::lock_guard<std::mutex> lk(ctx->pipe_mu);
+    if (!ctx->pipe) {
+        const int32_t rc = h2r_pipeline_create_ex(ctx, 2, 1, &ctx->pipe);
+        if (rc) return rc;
+    }
+    ScratchGuard sg; sg.st = st;
+    void *ws = workspace;
+    if (!ws) {   // freed in stream order behind the join below, i.e. after the record kernels that read it
+        HIP_TRY(hipMallocAsync(&sg.p, workspace_plan(ctx->layout.limb_bytes, ctx->L, batch, T).total, st));
+        sg.owned = true; ws = sg.p;
+    }
+    const int32_t rc = pipeline_issue(ctx->pipe, x, n, e_le, e_len, batch, flags, trace, pl, pl.elem_stride, out, status, ws, st,
+                                      []() -> int32_t { return H2R_OK; }, check_in_field, true);
+    const int32_t rj = h2r_pipeline_join(ctx->pipe, st);   // also after a failed issue: whatever was queued is ordered
+    return rc ? rc : rj;
 }
 
 int32_t launch_verify_aux(const h2r_ctx *ctx, const void *sig, const void *n, const uint64_t *hashed, uint64_t batch, uint32_t flags,

@@ -199,7 +199,11 @@ int32_t h2r_square_mod_batch(const h2r_ctx *ctx, const void *a, const void *n, u
 
 /* BigIntInstructions::pow_mod_fixed_exp (big_integer/chip.rs:710-742).  `e` is a HOST buffer:
  * e.to_bytes_le() (chip.rs:719-720), the same exponent for every element (RSAPubE::Fix).
- * trace: batch elements laid out per h2r_pow_fixed_layout().  out (nullable): x^e mod n. */
+ * trace: batch elements laid out per h2r_pow_fixed_layout().  out (nullable): x^e mod n.
+ * Stream-ordered: everything the call queues is ordered within `stream`.  A large call with a trace (more than ~1.5k
+ * RSA-1536/2048 elements, ~1.5k RSA-3072/4096 ones) is walked as sub-batches whose off-circuit chains run next to the
+ * previous sub-batch's record kernel on a side stream owned by the ctx, joined back onto `stream` before the call
+ * returns (8,192 RSA-2048 elements: 3.7 -> 4.2 M assigns/s); same results, same buffers, same ordering guarantee. */
 int32_t h2r_pow_mod_fixed_exp_batch(const h2r_ctx *ctx, const void *x, const void *n,
                                     const uint8_t *e_le_bytes, size_t e_len, uint64_t batch,
                                     uint32_t flags, void *trace, void *out, uint8_t *status,
