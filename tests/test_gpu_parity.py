@@ -1024,6 +1024,42 @@ def test_pipeline_call_walked_as_sub_batches(H, shared):
     pipe.close()
 
 
+def test_plain_large_calls_from_two_threads(H):
+    """The stream-ordered export walks a large call through a pipeline the ctx owns (overlapped_pow_fixed).  Two host
+    threads, one ctx, their own streams, interleaved calls of 2,304 signatures: every call's results and every record must
+    be what a small-batch call gives (the in-place audit runs on the caller's stream right behind the call)."""
+    import threading
+    chip = H.BigIntChip(64, 2048)
+    rng = random.Random(2626)
+    B = 2304
+    base = [rand_modulus(rng, 2048) for _ in range(32)]
+    errors = []
+
+    def worker(seed):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for it in range(3):
+                    N = [base[(i + seed + it) % 32] ^ ((i // 32 + seed) << 80) | 1 for i in range(B)]
+                    X = [((base[(i * 7 + it) % 32] >> 5) * (2 * i + 3 + seed)) % N[i] for i in range(B)]
+                    res = chip.pow_mod_fixed_exp(chip.assign_integer(X), 65537, chip.assign_integer(N), check_in_field=True)
+                    bad, first = res.audit()
+                    st.synchronize()
+                    assert not res.status.cpu().numpy().any()
+                    got = res.value.to_big_uint()
+                    assert all(got[i] == pow(X[i], 65537, N[i]) for i in range(B)), (seed, it)
+                    assert not bad.cpu().numpy().any(), (seed, it)
+        except Exception as ex:   # surfaced in the main thread
+            errors.append((seed, repr(ex)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in (1, 2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def _check_pow_batch(H, chip, o, X, N, e, res, sample, rng):
     torch.cuda.synchronize()
     assert not res.status.cpu().numpy().any()
