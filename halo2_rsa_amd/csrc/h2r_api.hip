@@ -621,8 +621,8 @@ int32_t launch_in_field(const h2r_ctx *ctx, const void *x, const void *n, uint64
 namespace {
 bool plain_call_overlaps(const h2r_ctx *c, u64 batch);
 int32_t overlapped_pow_fixed(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch,
-                             uint32_t flags, void *trace, const h2r_pow_layout &pl, void *out, uint8_t *status, void *workspace,
-                             hipStream_t st, u32 check_in_field, u32 T);
+                             uint32_t flags, void *trace, const h2r_pow_layout &pl, uint64_t elem_stride, void *out, uint8_t *status,
+                             void *workspace, hipStream_t st, u32 check_in_field, u32 T);
 }
 
 static int32_t pow_fixed_impl(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le, size_t e_len,
@@ -638,7 +638,7 @@ static int32_t pow_fixed_impl(const h2r_ctx *ctx, const void *x, const void *n, 
     // a large call with a trace: sub-batches whose chain kernels run next to the previous sub-batch's record kernel (a side
     // stream of the ctx), joined back onto the caller's stream before returning -- stream-ordered as ever for the caller
     if (trace && T && x && n && status && ctx->params.device >= 0 && plain_call_overlaps(ctx, batch))
-        return overlapped_pow_fixed(ctx, x, n, e_le, e_len, batch, flags, trace, pl, out, status, workspace,
+        return overlapped_pow_fixed(ctx, x, n, e_le, e_len, batch, flags, trace, pl, pl.elem_stride, out, status, workspace,
                                     static_cast<hipStream_t>(stream), check_in_field, T);
     return run_path(ctx, CHAIN_POW_FIXED, x, nullptr, n, nullptr, 0, 0, &eb, check_in_field, batch, flags, T, trace,
                     pl.elem_stride, pl.off_records, &pl, out, status, workspace, static_cast<hipStream_t>(stream));
@@ -716,8 +716,11 @@ int32_t h2r_verify_pkcs1v15_batch(const h2r_ctx *ctx, const void *sig, const voi
     rc = exp_to_bits(e_le, e_len, &eb, &T);
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    rc = run_path(ctx, CHAIN_POW_FIXED, sig, nullptr, n, nullptr, 0, 0, &eb, 1, batch, flags, T, trace, vl.elem_stride,
-                  vl.pow.off_records, &vl.pow, powed_out, status, workspace, st);
+    if (T && ctx->params.device >= 0 && plain_call_overlaps(ctx, batch))   // large call: overlapping sub-batches, as pow_fixed_impl
+        rc = overlapped_pow_fixed(ctx, sig, n, e_le, e_len, batch, flags, trace, vl.pow, vl.elem_stride, powed_out, status, workspace, st, 1, T);
+    else
+        rc = run_path(ctx, CHAIN_POW_FIXED, sig, nullptr, n, nullptr, 0, 0, &eb, 1, batch, flags, T, trace, vl.elem_stride,
+                      vl.pow.off_records, &vl.pow, powed_out, status, workspace, st);
     if (rc || batch == 0) return rc;
     return launch_verify_aux(ctx, sig, n, hashed, batch, flags, trace, vl, powed_out, is_valid_out, status, st);
 }
@@ -956,8 +959,8 @@ bool plain_call_overlaps(const h2r_ctx *c, u64 batch) {
 }
 
 int32_t overlapped_pow_fixed(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch,
-                             uint32_t flags, void *trace, const h2r_pow_layout &pl, void *out, uint8_t *status, void *workspace,
-                             hipStream_t st, u32 check_in_field, u32 T) {
+                             uint32_t flags, void *trace, const h2r_pow_layout &pl, uint64_t elem_stride, void *out, uint8_t *status,
+                             void *workspace, hipStream_t st, u32 check_in_field, u32 T) {
     H2R_ON_DEVICE(ctx->params.device);
     std::lock_guard<std::mutex> lk(ctx->pipe_mu);
     if (!ctx->pipe) {
@@ -970,7 +973,7 @@ int32_t overlapped_pow_fixed(const h2r_ctx *ctx, const void *x, const void *n, c
         HIP_TRY(hipMallocAsync(&sg.p, workspace_plan(ctx->layout.limb_bytes, ctx->L, batch, T).total, st));
         sg.owned = true; ws = sg.p;
     }
-    const int32_t rc = pipeline_issue(ctx->pipe, x, n, e_le, e_len, batch, flags, trace, pl, pl.elem_stride, out, status, ws, st,
+    const int32_t rc = pipeline_issue(ctx->pipe, x, n, e_le, e_len, batch, flags, trace, pl, elem_stride, out, status, ws, st,
                                       []() -> int32_t { return H2R_OK; }, check_in_field, true);
     const int32_t rj = h2r_pipeline_join(ctx->pipe, st);   // also after a failed issue: whatever was queued is ordered
     return rc ? rc : rj;

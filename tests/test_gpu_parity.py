@@ -649,6 +649,43 @@ def test_verify_pkcs1v15_signature_kats(H, golden):
             assert sha(got[len(s_if):len(s_if) + len(s_pow)]) == k["pow_stream_sha256"]
 
 
+def test_verify_large_plain_call_matches_small_calls(H, golden):
+    """h2r_verify_pkcs1v15_batch with 2,304 signatures is walked as overlapping sub-batches inside the call; verdicts,
+    statuses, results and sampled witness streams must equal what two 1,152-signature calls (one launch each) give."""
+    rsa = H.RSAChip(2048, 5)
+    kats = golden["rsa_kats"]
+    rng = random.Random(29)
+    B = 2304
+    base = [rand_modulus(rng, 2048) for _ in range(24)]
+    ns = [int(q["n"]) for q in kats] + [base[i % 24] ^ ((i // 24) << 90) | 1 for i in range(B - 3)]
+    sigs = [int(q["sig"]) for q in kats] + [((base[i % 24] >> 7) * (i + 5)) % ns[i + 3] for i in range(B - 3)]
+    hashed = [int(q["hashed"]) for q in kats] + [rng.getrandbits(256) for _ in range(B - 3)]
+    sigs[1700] = ns[1700] + 3      # not in field, second sub-batch
+
+    def run(lo, hi):
+        pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns[lo:hi], 32, 64), H.Fix(65537)))
+        sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs[lo:hi], 32, 64)))
+        return rsa.verify_pkcs1v15_signature(pk, hashed[lo:hi], sg)
+
+    big = run(0, B)
+    halves = [run(0, B // 2), run(B // 2, B)]
+    torch.cuda.synchronize()
+    assert big.is_valid.cpu().tolist()[:3] == [1, 1, 0]
+    assert int(big.status[1700]) == H.H2R_E_NOT_IN_FIELD and int((big.status != 0).sum()) == 1
+    for h, half in enumerate(halves):
+        sl = slice(h * B // 2, (h + 1) * B // 2)
+        assert torch.equal(big.is_valid[sl], half.is_valid) and torch.equal(big.status[sl], half.status)
+        ok = (half.status == 0)
+        assert torch.equal(big.powed.limbs_dev[sl][ok], half.powed.limbs_dev[ok])
+        for i in (0, 1, 2, 511, 1023 - h * 1152 if h == 0 else 0, B // 2 - 1):
+            if i < 0 or int(half.status[i]) != 0:
+                continue
+            assert np.array_equal(big.flatten(h * B // 2 + i), half.flatten(i)), (h, i)
+    for i in (1023, 1024, 1151, 1152, B - 1):   # both sides of the first sub-batch boundary and of the half boundary
+        h, j = divmod(i, B // 2)
+        assert np.array_equal(big.flatten(i), halves[h].flatten(j)), i
+
+
 def test_pipelined_verify_matches_batch_call(H, golden):
     """h2r_pipeline_verify_pkcs1v15: three pipelined verifier batches over two buffer sets produce, element for
     element, the bytes and verdicts of h2r_verify_pkcs1v15_batch (itself checked against the oracle above) and the
