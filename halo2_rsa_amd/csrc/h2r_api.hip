@@ -347,7 +347,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
     if (eb) ca.e = *eb;
     // 128-digit chains (RSA-4096 at 64-bit limbs) are the longer leg next to their record kernel: their waves get issue
     // priority there (1.00 -> 1.05 M assigns/s; no effect measured for the shorter chains)
-    if (trace_st && c->K > 96) ca.prio = 1;
+    if (trace_st && c->K > 96 && lo.limb_width == 64) ca.prio = 1;   // (the 32-bit-limb 4096-bit shape is record-bound)
     if (knobs().chain_prio >= 0) ca.prio = (u32)knobs().chain_prio;
     // one key, many elements: the Barrett constants of the shared modulus are computed once (recip_kernel) instead of by
     // every element's workgroup (big_integer/chip.rs:562-567 divides by the same n every time)
