@@ -1183,12 +1183,17 @@ int32_t h2r_trace_lookup_permutation(const h2r_ctx *ctx, const void *trace, uint
     pa.n_cells = (u32)n_cells; pa.perm = perm_out; pa.rows = rows_out;
     H2R_ON_DEVICE(ctx->params.device);
     const u64 stage_bytes = 4ull * ((2ull * lo.num_limbs * 8 + (u64)(lo.num_cols - 1) * lo.carry_sub_stride) / 16) * 16;
-    const u64 staged_bytes = stage_bytes + 2ull * n_cells;
-    // staged form: 16-bit cell ids in LDS (two workgroups per CU still fit next to the 27 KB of static tables)
-    if (n_cells < 65536 && staged_bytes <= 52 * 1024)
+    const u64 same_bytes = perm_same_bytes(ctx->hist_len);   // match masks: per wave, group and table row
+    const u64 staged_bytes = stage_bytes + ((2ull * n_cells + 15) & ~15ull) + same_bytes;
+    // staged form: 16-bit cell ids in LDS (two workgroups per CU still fit next to the 10 KB of static tables)
+    if (n_cells < 65536 && staged_bytes <= 68 * 1024) {
+        if (staged_bytes > 48 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&perm_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)staged_bytes);
+            (void)hipGetLastError();
+        }
         hipLaunchKernelGGL(perm_kernel<true>, dim3((unsigned)num_elems), dim3(256), (unsigned)staged_bytes, static_cast<hipStream_t>(stream), pa);
-    else
-        hipLaunchKernelGGL(perm_kernel<false>, dim3((unsigned)num_elems), dim3(256), (unsigned)stage_bytes, static_cast<hipStream_t>(stream), pa);
+    } else
+        hipLaunchKernelGGL(perm_kernel<false>, dim3((unsigned)num_elems), dim3(256), (unsigned)(stage_bytes + same_bytes), static_cast<hipStream_t>(stream), pa);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
 }

@@ -1799,19 +1799,19 @@ constexpr int PERM_STAGE_NR = PERM_STAGE_U4 / 64;
 // STAGED (an element's cells fit 16-bit ids and LDS): positions are scattered into an LDS copy of the permutation and
 // written out as full lines, rows[] is rebuilt from the row starts -- the scattered 4- and 2-byte global stores of
 // the direct form (64 partial lines per store instruction) were the next bound after the key reads.
+constexpr int PERM_G = 2;   // 64-cell groups a wave works on at once (their LDS round trips overlap)
+__host__ __device__ constexpr u64 perm_same_bytes(u32 rows) { return 4ull * PERM_G * ((rows + 1) & ~1u) * 8; }
+
 template <bool STAGED>
 __global__ __launch_bounds__(256) void perm_kernel(PermArgs p) {
     __shared__ u32 cnt[4][PERM_MAX_ROWS];   // per-wave row counts, then per-wave running bases
     __shared__ u32 start[PERM_MAX_ROWS + 1];
-    __shared__ u64 same[4][PERM_MAX_ROWS];  // per wave: lanes of the current 64-cell group that hit each row
-    extern __shared__ uint4 dyn_lds[];      // [4][stage_u4] record staging, then (STAGED) u16 perm_s[n_cells]
+    extern __shared__ uint4 dyn_lds[];      // [4][stage_u4] record staging, (STAGED) u16 perm_s[n_cells], u64 same[4][PERM_G][R2]
     uint4 *const stage_all = dyn_lds;
     const HistArgs &a = p.h;
     const u64 elem = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const u32 R = a.hist_len;
-    for (u32 k = threadIdx.x; k < 4 * PERM_MAX_ROWS; k += 256) { (&cnt[0][0])[k] = 0; (&same[0][0])[k] = 0; }
-    __syncthreads();
+    const u32 R = a.hist_len, R2 = (R + 1) & ~1u;
     const u8 *base = a.trace + elem * a.elem_stride + a.first_record_off;
     const u32 T = a.records_per_elem, per = (T + 3) / 4;
     const u32 r0 = min(T, wave * per), r1 = min(T, r0 + per);
@@ -1819,6 +1819,12 @@ __global__ __launch_bounds__(256) void perm_kernel(PermArgs p) {
     const u32 cpr = p.cells_per_record, ncomp = a.carry_nsub - a.carry_has_ov;
     uint4 *const stage_w = stage_all + (u64)wave * n_u4;
     uint16_t *const perm_s = reinterpret_cast<uint16_t *>(stage_all + 4ull * n_u4);
+    // per wave and group: the lanes of the group's 64 cells that hit each row
+    u64 *const same_all = reinterpret_cast<u64 *>(reinterpret_cast<u8 *>(perm_s) + (STAGED ? ((2ull * p.n_cells + 15) & ~15ull) : 0));
+    u64 *const same_w = same_all + (u64)wave * PERM_G * R2;
+    for (u32 k = threadIdx.x; k < 4 * PERM_MAX_ROWS; k += 256) (&cnt[0][0])[k] = 0;
+    for (u32 k = threadIdx.x; k < 4 * PERM_G * R2; k += 256) same_all[k] = 0;
+    __syncthreads();
     uint4 regs[PERM_STAGE_NR];
     auto fetch = [&](u32 rcd) {   // 16-byte loads of record rcd's lookup bytes into registers
         const u8 *rec = base + (u64)rcd * a.record_stride;
@@ -1853,26 +1859,56 @@ __global__ __launch_bounds__(256) void perm_kernel(PermArgs p) {
             publish();
             wave_sync();
             if (rcd + 1 < r1) fetch(rcd + 1);
-            for (u32 lb = 0; lb < cpr; lb += 64) {
-                const u32 li = lb + lane;
-                const bool valid = li < cpr;
-                const u32 key = valid ? key_of(li) : 0;
+            // PERM_G groups of 64 cells per iteration: every LDS round trip below (key bytes, match masks, counts) is
+            // issued for all of them before the first result is needed -- one group at a time the loop was a chain of
+            // eight dependent LDS round trips per 64 cells (0.228 ms per 1,024 RSA-2048 traces)
+            for (u32 lb = 0; lb < cpr; lb += 64 * PERM_G) {
+                u32 key[PERM_G]; bool valid[PERM_G];
+#pragma unroll
+                for (int g = 0; g < PERM_G; ++g) {
+                    const u32 li = lb + 64 * g + lane;
+                    valid[g] = li < cpr;
+                    key[g] = valid[g] ? key_of(li) : 0;
+                }
+#ifndef H2R_PERM_ABL
+#define H2R_PERM_ABL 0
+#endif
                 if (pass == 0) {
-                    if (valid) atomicAdd(&cnt[wave][key], 1u);
-                } else {
-                    // Multi-split of 64 cells in cell order.  "Which lanes hold my row" is one LDS atomic OR of the
-                    // lane bit into same[wave][row] -- a match-any in O(1) instead of one ballot per distinct row
-                    // (with ~300 rows nearly every lane holds a different one); the rank is a popcount below the lane.
-                    if (valid) atomicOr(reinterpret_cast<unsigned long long *>(&same[wave][key]), (unsigned long long)lane_bit);
+#pragma unroll
+                    for (int g = 0; g < PERM_G; ++g) if (valid[g] && H2R_PERM_ABL != 3) atomicAdd(&cnt[wave][key[g]], 1u);
+                } else if (H2R_PERM_ABL != 2) {
+                    // Multi-split in cell order.  "Which lanes of group g hold my row" is one LDS atomic OR of the lane bit
+                    // into same[g][row] -- a match-any in O(1) instead of one ballot per distinct row (with ~300 rows nearly
+                    // every lane holds a different one); the rank is the row's count so far, plus the cells of the row in the
+                    // earlier groups of this iteration, plus a popcount below the lane.
+#pragma unroll
+                    for (int g = 0; g < PERM_G; ++g)
+                        if (valid[g]) atomicOr(reinterpret_cast<unsigned long long *>(&same_w[g * R2 + key[g]]), (unsigned long long)lane_bit);
                     wave_sync();
-                    u64 mask = 0; u32 b = 0;
-                    if (valid) { mask = same[wave][key]; b = cnt[wave][key]; }
+                    u64 mask[PERM_G]; u32 pos[PERM_G];
+#pragma unroll
+                    for (int g = 0; g < PERM_G; ++g) {
+                        mask[g] = 0; pos[g] = 0;
+                        if (valid[g]) {
+                            mask[g] = same_w[g * R2 + key[g]];
+                            u32 b = cnt[wave][key[g]];
+#pragma unroll
+                            for (int e = 0; e < g; ++e) b += (u32)__builtin_popcountll(same_w[e * R2 + key[g]]);
+                            pos[g] = b + (u32)__builtin_popcountll(mask[g] & below);
+                        }
+                    }
                     wave_sync();
-                    if (valid) {
-                        const u32 pos = b + (u32)__builtin_popcountll(mask & below);
-                        if ((mask & below) == 0) { cnt[wave][key] = b + (u32)__builtin_popcountll(mask); same[wave][key] = 0; }  // lowest lane of the row
-                        if constexpr (STAGED) perm_s[pos] = (uint16_t)(rcd * cpr + li);
-                        else { perm[pos] = rcd * cpr + li; if (rows) rows[pos] = (uint16_t)key; }
+#pragma unroll
+                    for (int g = 0; g < PERM_G; ++g) {
+                        if (valid[g]) {
+                            if ((mask[g] & below) == 0) {   // lowest lane of the row in this group
+                                atomicAdd(&cnt[wave][key[g]], (u32)__builtin_popcountll(mask[g]));
+                                same_w[g * R2 + key[g]] = 0;
+                            }
+                            const u32 id = rcd * cpr + lb + 64 * g + lane;
+                            if constexpr (STAGED) perm_s[pos[g]] = (uint16_t)id;
+                            else { perm[pos[g]] = id; if (rows) rows[pos[g]] = (uint16_t)key[g]; }
+                        }
                     }
                     wave_sync();
                 }
@@ -1881,10 +1917,23 @@ __global__ __launch_bounds__(256) void perm_kernel(PermArgs p) {
         }
         if (pass == 0) {
             __syncthreads();
-            if (threadIdx.x == 0) {  // exclusive scan over the (few hundred) table rows
-                u32 run = 0;
-                for (u32 r = 0; r < R; ++r) { start[r] = run; run += cnt[0][r] + cnt[1][r] + cnt[2][r] + cnt[3][r]; }
-                start[R] = run;
+            {   // exclusive scan over the (at most 512) table rows: two rows per thread, wave scan, four wave totals
+                // (one thread walking the rows cost 11 us per element: ~340 dependent LDS round trips)
+                __shared__ u32 wtot[4];
+                const u32 ra = 2 * threadIdx.x, rb = ra + 1;
+                const u32 ta = ra < R ? cnt[0][ra] + cnt[1][ra] + cnt[2][ra] + cnt[3][ra] : 0;
+                const u32 tb = rb < R ? cnt[0][rb] + cnt[1][rb] + cnt[2][rb] + cnt[3][rb] : 0;
+                u32 inc = ta + tb;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const u32 up = __shfl_up(inc, d); if (lane >= d) inc += up; }
+                if (lane == 63) wtot[wave] = inc;
+                __syncthreads();
+                u32 off = 0;
+                for (int w = 0; w < wave; ++w) off += wtot[w];
+                const u32 ex = off + inc - (ta + tb);
+                if (ra < R) start[ra] = ex;
+                if (rb < R) start[rb] = ex + ta;
+                if (threadIdx.x == 255) start[R] = off + inc;   // rows beyond R contribute 0: the grand total
             }
             __syncthreads();
             for (u32 r = threadIdx.x; r < R; r += 256) {  // per-wave bases keep the sort stable across the 4 record ranges
@@ -1894,14 +1943,23 @@ __global__ __launch_bounds__(256) void perm_kernel(PermArgs p) {
             __syncthreads();
         }
     }
-    if constexpr (STAGED) {
+    if constexpr (STAGED && H2R_PERM_ABL != 1) {
         __syncthreads();
+        // rows[k] = the row whose [start[r], start[r+1]) holds k.  A per-cell binary search over `start` (nine dependent LDS
+        // reads) was half of the kernel; instead the row of every 64th position is tabulated once (in the match-mask
+        // area, free now) and each cell walks on from there -- one or two steps.
+        uint16_t *const rowmap = reinterpret_cast<uint16_t *>(same_all);
+        if (rows) {
+            for (u32 r = threadIdx.x; r < R; r += 256)
+                for (u32 b = (start[r] + 63) / 64; 64 * b < start[r + 1]; ++b) rowmap[b] = (uint16_t)r;
+            __syncthreads();
+        }
         for (u32 k = threadIdx.x; k < p.n_cells; k += 256) {
             perm[k] = perm_s[k];
-            if (rows) {   // the row whose [start[r], start[r+1]) holds k
-                u32 lo = 0, hi = R;
-                while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if (start[mid] <= k) lo = mid; else hi = mid; }
-                rows[k] = (uint16_t)lo;
+            if (rows) {
+                u32 r = rowmap[k >> 6];
+                while (start[r + 1] <= k) ++r;
+                rows[k] = (uint16_t)r;
             }
         }
     }
