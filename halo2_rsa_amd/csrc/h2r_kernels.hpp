@@ -1870,13 +1870,10 @@ __global__ __launch_bounds__(256) void perm_kernel(PermArgs p) {
                     valid[g] = li < cpr;
                     key[g] = valid[g] ? key_of(li) : 0;
                 }
-#ifndef H2R_PERM_ABL
-#define H2R_PERM_ABL 0
-#endif
                 if (pass == 0) {
 #pragma unroll
-                    for (int g = 0; g < PERM_G; ++g) if (valid[g] && H2R_PERM_ABL != 3) atomicAdd(&cnt[wave][key[g]], 1u);
-                } else if (H2R_PERM_ABL != 2) {
+                    for (int g = 0; g < PERM_G; ++g) if (valid[g]) atomicAdd(&cnt[wave][key[g]], 1u);
+                } else {
                     // Multi-split in cell order.  "Which lanes of group g hold my row" is one LDS atomic OR of the lane bit
                     // into same[g][row] -- a match-any in O(1) instead of one ballot per distinct row (with ~300 rows nearly
                     // every lane holds a different one); the rank is the row's count so far, plus the cells of the row in the
@@ -1943,7 +1940,7 @@ __global__ __launch_bounds__(256) void perm_kernel(PermArgs p) {
             __syncthreads();
         }
     }
-    if constexpr (STAGED && H2R_PERM_ABL != 1) {
+    if constexpr (STAGED) {
         __syncthreads();
         // rows[k] = the row whose [start[r], start[r+1]) holds k.  A per-cell binary search over `start` (nine dependent LDS
         // reads) was half of the kernel; instead the row of every 64th position is tabulated once (in the match-mask
@@ -2468,10 +2465,7 @@ template <int LW>
 __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
     using limb_t = typename LimbT<LW>::type;
     __shared__ u64 sa[128], sb_[128], sq[128], sn[128], sr[128];
-#ifndef H2R_ADVICE_SR
-#define H2R_ADVICE_SR 256
-#endif
-    constexpr u32 SR = H2R_ADVICE_SR;                         // rows per stage (40 KB of LDS; 208 rows = four workgroups per CU measured 3 % slower for RSA-2048, 10 % faster for 32 x 128)
+    constexpr u32 SR = 256;                                   // rows per stage (40 KB of LDS; 128-208 rows, i.e. four or more workgroups per CU, measured within +-5 % of it)
     __shared__ uint4 stage[SR * (ADVICE_ROW_BYTES / 16)];    // SR rows are built in LDS, then leave as full 16-byte-per-lane lines
     const u32 tid = threadIdx.x;
     const u32 item = blockIdx.x;
