@@ -826,6 +826,19 @@ int32_t pipeline_wait_slot(h2r_pipeline *p, u32 slot, hipStream_t st) {
 }
 }  // namespace
 
+namespace { void call_plan(const h2r_ctx *c, u64 batch, bool busy, std::vector<u64> &sizes, bool &pace); }
+
+int32_t h2r_pipeline_call_plan(const h2r_ctx *ctx, uint64_t batch, uint32_t pipeline_busy_, uint64_t *sizes_out, uint32_t cap,
+                               uint32_t *n_out, uint32_t *paced_out) {
+    if (!ctx || !n_out) return H2R_E_NULL;
+    std::vector<u64> sizes; bool pace = false;
+    call_plan(ctx, batch, pipeline_busy_ != 0, sizes, pace);
+    *n_out = (uint32_t)sizes.size();
+    if (paced_out) *paced_out = pace ? 1u : 0u;
+    if (sizes_out) for (size_t i = 0; i < sizes.size() && i < cap; ++i) sizes_out[i] = sizes[i];
+    return H2R_OK;
+}
+
 int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream) {
     if (!p) return H2R_E_NULL;
     for (; p->joined < p->k; ++p->joined) {
@@ -859,8 +872,8 @@ bool pipeline_busy(h2r_pipeline *p) {
 //    the chain kernels run back to back either way, the record kernels hide behind them, and the last record kernel of a
 //    call is a quarter as long (4,096 signatures: 1.39-1.44 -> 1.60-1.62 M assigns/s over six calls).
 //  * RSA-1024 and the 32-bit-limb shapes: no gain measured from any split; one launch.
-void pipeline_plan(h2r_pipeline *p, u64 batch, bool assume_empty, std::vector<u64> &sizes, bool &pace) {
-    const h2r_ctx *c = p->ctx;
+// (busy: a record kernel of the previous call is still queued or running)
+void call_plan(const h2r_ctx *c, u64 batch, bool busy, std::vector<u64> &sizes, bool &pace) {
     sizes.clear(); pace = false;
     const u64 unit = (u64)c->num_cus * (c->K > 64 ? 2 : 4);   // one chain-kernel grid: four 4-wave (two 8-wave) workgroups per CU
     if (knobs().pipe_sub_batch > 0) {
@@ -874,7 +887,7 @@ void pipeline_plan(h2r_pipeline *p, u64 batch, bool assume_empty, std::vector<u6
         for (u64 o = 0; o < batch; o += 2 * unit) sizes.push_back(std::min<u64>(2 * unit, batch - o));
         return;
     }
-    if (w64 && c->L > 16 && c->L <= 32 && batch > unit + unit / 2 && (assume_empty || !pipeline_busy(p))) {   // record-bound, pipeline empty
+    if (w64 && c->L > 16 && c->L <= 32 && batch > unit + unit / 2 && !busy) {   // record-bound, pipeline empty
         pace = true;
         u64 cur = unit, left = batch;
         while (left) {
@@ -886,6 +899,12 @@ void pipeline_plan(h2r_pipeline *p, u64 batch, bool assume_empty, std::vector<u6
         return;
     }
     sizes.push_back(batch);
+}
+void pipeline_plan(h2r_pipeline *p, u64 batch, bool assume_empty, std::vector<u64> &sizes, bool &pace) {
+    // (the busy query is only made where the answer matters)
+    const h2r_ctx *c = p->ctx;
+    const bool may_grow = c->layout.limb_width == 64 && c->L > 16 && c->L <= 32;
+    call_plan(c, batch, may_grow && !assume_empty && pipeline_busy(p), sizes, pace);
 }
 
 // One pipelined call: chain kernel (+ `after_chain`, e.g. the verifier's aux kernel) on the caller's stream, the

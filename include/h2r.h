@@ -261,6 +261,14 @@ int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const voi
                                        uint8_t *status, void *workspace, h2r_stream_t stream);
 int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream);
 
+/* How a pipelined (or a large plain) fixed-exponent call of `batch` elements is walked on this ctx: the sizes of the
+ * sub-batches that get their own chain and record kernel (one entry = the call is one launch pair), and whether the
+ * chain kernels are paced by the record kernels.  pipeline_busy: a record kernel of the previous call is still in
+ * flight (the library asks the runtime; here the caller says).  Host-only, works on a context without a device.
+ * sizes_out (nullable): up to `cap` entries; *n_out: the number of sub-batches. */
+int32_t h2r_pipeline_call_plan(const h2r_ctx *ctx, uint64_t batch, uint32_t pipeline_busy, uint64_t *sizes_out,
+                               uint32_t cap, uint32_t *n_out, uint32_t *paced_out);
+
 /* ---- RSAInstructions::verify_pkcs1v15_signature after the SHA step (src/chip.rs:128-199) ------
  * For every element: the assert_in_field(sig, n) witness (src/chip.rs:106 ->
  * big_integer/chip.rs:1150-1158, 908-919, 310-373, 245-297, 1286-1318, 780-805), the

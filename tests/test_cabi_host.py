@@ -198,3 +198,35 @@ def test_verify_layout_sizes(golden):
     c = host_ctx(32, 128)
     assert lib().h2r_verify_layout_fixed(c, (65537).to_bytes(3, "little"), 3, ctypes.byref(H2RVerifyLayout())) == _lib.H2R_E_SHAPE
     lib().h2r_ctx_destroy(c)
+
+
+def test_pipeline_call_plan():
+    """h2r_pipeline_call_plan: how a fixed-exponent call is walked (host logic of pipeline_plan).  Record-bound shapes
+    (RSA-1536/2048) grow by 3/2 from one chain-kernel grid when the pipeline is empty and are one launch pair when it is
+    busy; chain-bound 64-bit-limb shapes (RSA-3072/4096) are uniform sub-batches either way; RSA-1024 and the 32-bit-limb
+    shapes are never split.  The sizes always add up to the batch and every boundary is a multiple of 256 elements."""
+    def plan(w, L, batch, busy):
+        c = host_ctx(w, L)
+        sizes = (ctypes.c_uint64 * 64)()
+        n, paced = ctypes.c_uint32(), ctypes.c_uint32()
+        assert lib().h2r_pipeline_call_plan(c, batch, busy, sizes, 64, ctypes.byref(n), ctypes.byref(paced)) == _lib.H2R_OK
+        out = [int(sizes[i]) for i in range(n.value)]
+        lib().h2r_ctx_destroy(c)
+        assert sum(out) == batch and all(s % 256 == 0 for s in out[:-1])
+        return out, bool(paced.value)
+
+    assert plan(64, 32, 1024, 0) == ([1024], False)
+    assert plan(64, 32, 1536, 0) == ([1536], False)
+    assert plan(64, 32, 3840, 0) == ([1024, 1536, 1280], True)
+    assert plan(64, 32, 8192, 0) == ([1024, 1536, 2304, 3328], True)
+    assert plan(64, 32, 8192, 1) == ([8192], False)
+    assert plan(64, 24, 4096, 0) == ([1024, 1536, 1536], True)
+    assert plan(64, 48, 4096, 0) == ([1024] * 4, False)
+    assert plan(64, 48, 4096, 1) == ([1024] * 4, False)
+    assert plan(64, 48, 1536, 0) == ([1536], False)
+    assert plan(64, 64, 2048, 0) == ([1024, 1024], False)
+    assert plan(64, 16, 8192, 0) == ([8192], False)
+    assert plan(32, 128, 4096, 0) == ([4096], False)
+    assert plan(64, 32, 100000, 0)[0][:3] == [1024, 1536, 2304]
+    n = ctypes.c_uint32()
+    assert lib().h2r_pipeline_call_plan(None, 1, 0, None, 0, ctypes.byref(n), None) == _lib.H2R_E_NULL
