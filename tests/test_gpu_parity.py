@@ -1097,6 +1097,59 @@ def test_plain_large_calls_from_two_threads(H):
     assert not errors, errors
 
 
+def test_pipeline_with_device_side_consumers(H):
+    """The use the pipeline is built for: while call k+1 is in flight, the caller's stream consumes call k-1's trace with
+    the device-side emitter and the advice-image kernel (both LDS-heavy kernels queued between pipelined calls) and audits
+    it in place.  Six calls over two buffer sets, 768 signatures each; every emitted stream must equal the oracle's for
+    sampled elements and the host walk for all, every audit must be clean."""
+    from halo2_rsa_amd import big_integer as BI
+    chip = H.BigIntChip(64, 2048)
+    o = Oracle(64, 32)
+    pl = chip.pow_fixed_layout(65537)
+    rng = random.Random(5151)
+    B, CALLS, depth = 768, 6, 2
+    base = [rand_modulus(rng, 2048) for _ in range(64)]
+    pipe = H.Pipeline(chip, depth=depth, side_streams=1)
+    sets = [dict(trace=torch.zeros(B * pl.elem_stride, dtype=torch.uint8, device="cuda"),
+                 ws=torch.zeros(chip.workspace_bytes(B, pl.num_mul_mods), dtype=torch.uint8, device="cuda"),
+                 out=torch.zeros((B, 32), dtype=torch.int64, device="cuda"),
+                 status=torch.zeros(B, dtype=torch.uint8, device="cuda")) for _ in range(depth)]
+    inputs, consumed = [], {}
+
+    def consume(k):   # everything here is queued on the caller's stream, ordered by the pipeline's contract
+        s = sets[k % depth]
+        tr = H.Trace(chip, s["trace"], B, pl)
+        res = BI.BatchResult(H.AssignedInteger(s["out"], 64), tr, s["status"], workspace=s["ws"],
+                             inputs=("pow_fixed", inputs[k][3], None, inputs[k][2], b"\x01\x00\x01"))
+        stream = tr.emit_stream()
+        img = res.emit_advice()
+        bad, first = res.audit()
+        consumed[k] = (stream, img[:4].clone(), bad, s["out"].clone(), s["status"].clone())
+
+    for k in range(CALLS):
+        N = [base[(i + 5 * k) % 64] ^ ((i // 64 + k) << 100) | 1 for i in range(B)]
+        X = [((base[(i * 3 + k) % 64] >> 9) * (i + 11 + k)) % N[i] for i in range(B)]
+        inputs.append((N, X, chip.assign_integer(N), chip.assign_integer(X)))
+        s = sets[k % depth]
+        pipe.modpow_public_key(inputs[k][3], 65537, inputs[k][2], s["trace"], s["ws"], s["out"], s["status"])
+        if k >= 1:
+            consume(k - 1)    # call k has returned: the stream is ordered after call k-1's records
+    pipe.join()
+    consume(CALLS - 1)
+    torch.cuda.synchronize()
+    for k in range(CALLS):
+        N, X = inputs[k][0], inputs[k][1]
+        stream, img, bad, out, status = consumed[k]
+        assert not status.cpu().numpy().any() and not bad.cpu().numpy().any(), k
+        got = H.AssignedInteger(out, 64).to_big_uint()
+        assert all(got[i] == pow(X[i], 65537, N[i]) for i in range(B)), k
+        host = stream.cpu().numpy()
+        for i in (0, 383, B - 1):
+            rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(X[i]), o.limbs(N[i]), 65537)
+            assert rc == 0 and np.array_equal(host[i, :len(ost)], ost), (k, i)
+    pipe.close()
+
+
 def _check_pow_batch(H, chip, o, X, N, e, res, sample, rng):
     torch.cuda.synchronize()
     assert not res.status.cpu().numpy().any()
