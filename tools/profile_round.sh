@@ -34,6 +34,9 @@ H2R_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-
   python tools/sweep.py CONFIG rsa1024 --workload rsa1024_e65537 --steps 40 --warmup 4
   python tools/sweep.py CONFIG rsa3072 --workload rsa3072_e65537 --steps 20 --warmup 3
   python tools/sweep.py CONFIG rsa2048-shared-modulus --steps 40 --warmup 4 --shared-modulus
+  # BASELINE config 1's shape (ONE signature per call): the latency of one witness, stream-ordered export
+  python tools/sweep.py CONFIG C1-one-signature-per-call --batch 1 --steps 200 --warmup 20 --no-pipeline
+  python tools/sweep.py CONFIG batch-64-per-call --batch 64 --steps 200 --warmup 20
 } > $O/other_configs.txt 2>&1
 {
   for wl in rsa2048 rsa3072 rsa4096w32; do python tools/emit_timing.py 1024 $wl 2>&1 | grep kernel; done
