@@ -69,7 +69,7 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_mul_stream_bytes", "h2r_is_equal_muled_stream_bytes", "h2r_refresh_stream_bytes", "h2r_mul_batch",
            "h2r_mul_trace_flatten", "h2r_is_equal_muled_batch", "h2r_is_equal_muled_flatten", "h2r_refresh_batch",
            "h2r_range_decompose_batch", "h2r_hist_len", "h2r_trace_lookup_hist", "h2r_lookups_per_record",
-           "h2r_trace_lookup_permutation",
+           "h2r_trace_lookup_permutation", "h2r_trace_lookup_permutation_hist",
            "h2r_trace_flatten", "h2r_pow_trace_flatten", "h2r_stream_bytes", "h2r_pow_stream_bytes", "h2r_trace_flatten_ex",
            "h2r_pow_trace_flatten_ex", "h2r_trace_emit_stream", "h2r_pow_trace_emit_stream", "h2r_mul_mod_trace_check", "h2r_pow_trace_check",
            "h2r_advice_rows", "h2r_mul_mod_emit_advice", "h2r_pow_trace_emit_advice",
@@ -147,6 +147,7 @@ def lib():
     L.h2r_lookups_per_record.argtypes = [vp]
     L.h2r_lookups_per_record.restype = u32
     L.h2r_trace_lookup_permutation.argtypes = [vp, vp, u64, u64, u64, u32, vp, vp, vp]
+    L.h2r_trace_lookup_permutation_hist.argtypes = [vp, vp, u64, u64, u64, u32, vp, vp, vp, vp]
     L.h2r_trace_flatten.argtypes = [vp, vp, vp]
     L.h2r_pow_trace_flatten.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, vp]
     L.h2r_stream_bytes.argtypes = [vp, u32]

@@ -144,12 +144,19 @@ class Trace:
         return hist
 
 
-    def lookup_permutation(self):
-        """(perm, rows): stable grouping of every element's lookup cells by table row (h2r_trace_lookup_permutation)."""
+    def lookup_permutation(self, with_hist: bool = False):
+        """(perm, rows): stable grouping of every element's lookup cells by table row (h2r_trace_lookup_permutation);
+        with_hist=True: (perm, rows, hist) from ONE launch (h2r_trace_lookup_permutation_hist)."""
         n = lib().h2r_lookups_per_record(self.chip._ctx) * self.num_mul_mods
         perm = torch.empty((self.batch, n), dtype=torch.int32, device=self.buf.device)
         rows = torch.empty((self.batch, n), dtype=torch.int16, device=self.buf.device)
         off = self.pow_layout.off_records if self.pow_layout is not None else 0
+        if with_hist:
+            hist = torch.empty((self.batch, int(lib().h2r_hist_len(self.chip._ctx))), dtype=torch.int32, device=self.buf.device)
+            check(lib().h2r_trace_lookup_permutation_hist(self.chip._ctx, self.buf.data_ptr(), off, self.elem_stride, self.batch,
+                                                          self.num_mul_mods, perm.data_ptr(), rows.data_ptr(), hist.data_ptr(),
+                                                          self.chip._stream()), "h2r_trace_lookup_permutation_hist")
+            return perm, rows, hist
         check(lib().h2r_trace_lookup_permutation(self.chip._ctx, self.buf.data_ptr(), off, self.elem_stride, self.batch,
                                                  self.num_mul_mods, perm.data_ptr(), rows.data_ptr(), self.chip._stream()),
               "h2r_trace_lookup_permutation")

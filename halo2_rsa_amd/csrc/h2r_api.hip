@@ -1179,6 +1179,13 @@ uint32_t h2r_lookups_per_record(const h2r_ctx *ctx) {
 int32_t h2r_trace_lookup_permutation(const h2r_ctx *ctx, const void *trace, uint64_t first_record_off, uint64_t elem_stride,
                                      uint64_t num_elems, uint32_t records_per_elem, uint32_t *perm_out, uint16_t *rows_out,
                                      h2r_stream_t stream) {
+    return h2r_trace_lookup_permutation_hist(ctx, trace, first_record_off, elem_stride, num_elems, records_per_elem, perm_out,
+                                             rows_out, nullptr, stream);
+}
+
+int32_t h2r_trace_lookup_permutation_hist(const h2r_ctx *ctx, const void *trace, uint64_t first_record_off, uint64_t elem_stride,
+                                          uint64_t num_elems, uint32_t records_per_elem, uint32_t *perm_out, uint16_t *rows_out,
+                                          uint32_t *hist_out, h2r_stream_t stream) {
     if (!ctx || !trace || !perm_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (num_elems == 0 || records_per_elem == 0) return H2R_OK;
@@ -1200,6 +1207,7 @@ int32_t h2r_trace_lookup_permutation(const h2r_ctx *ctx, const void *trace, uint
     const u64 n_cells = (u64)pa.cells_per_record * records_per_elem;
     if (n_cells >= (1ull << 31)) return H2R_E_UNSUPPORTED;
     pa.n_cells = (u32)n_cells; pa.perm = perm_out; pa.rows = rows_out;
+    ha.hist = hist_out;   // nullable: the rows' multiplicities fall out of the counting pass (= h2r_trace_lookup_hist's output)
     H2R_ON_DEVICE(ctx->params.device);
     const u64 stage_bytes = 4ull * ((2ull * lo.num_limbs * 8 + (u64)(lo.num_cols - 1) * lo.carry_sub_stride) / 16) * 16;
     const u64 same_bytes = perm_same_bytes(ctx->hist_len);   // match masks: per wave, group and table row

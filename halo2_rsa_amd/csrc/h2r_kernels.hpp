@@ -1940,6 +1940,8 @@ __global__ __launch_bounds__(256) void perm_kernel(PermArgs p) {
             __syncthreads();
         }
     }
+    if (a.hist)   // multiplicities of the table rows: what the counting pass found (start[] is final since the row scan)
+        for (u32 r = threadIdx.x; r < R; r += 256) a.hist[elem * R + r] = start[r + 1] - start[r];
     if constexpr (STAGED) {
         __syncthreads();
         // rows[k] = the row whose [start[r], start[r+1]) holds k.  A per-cell binary search over `start` (nine dependent LDS

@@ -376,6 +376,12 @@ uint32_t h2r_lookups_per_record(const h2r_ctx *ctx);
 int32_t h2r_trace_lookup_permutation(const h2r_ctx *ctx, const void *trace, uint64_t first_record_off,
                                      uint64_t elem_stride, uint64_t num_elems, uint32_t records_per_elem,
                                      uint32_t *perm_out, uint16_t *rows_out, h2r_stream_t stream);
+/* The same with the multiplicities as a by-product: hist_out (nullable) [elem][h2r_hist_len()] receives exactly what
+ * h2r_trace_lookup_hist writes (the permutation's counting pass produces them), saving that launch. */
+int32_t h2r_trace_lookup_permutation_hist(const h2r_ctx *ctx, const void *trace, uint64_t first_record_off,
+                                          uint64_t elem_stride, uint64_t num_elems, uint32_t records_per_elem,
+                                          uint32_t *perm_out, uint16_t *rows_out, uint32_t *hist_out,
+                                          h2r_stream_t stream);
 
 /* ---- host-side helpers (no device work) --------------------------------------------------------
  * h2r_trace_flatten: walk ONE record (host copy, record_stride bytes) in the reference's assignment

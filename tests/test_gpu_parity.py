@@ -836,7 +836,10 @@ def test_lookup_permutation(H, w, bits, e):
     X = [rng.randrange(n) for n in N]
     res = chip.pow_mod_fixed_exp(chip.assign_integer(X), e, chip.assign_integer(N))
     perm, rows = res.trace.lookup_permutation()
-    hist = res.trace.lookup_hist().cpu().numpy()
+    hist_dev = res.trace.lookup_hist()
+    p2, r2, h2 = res.trace.lookup_permutation(with_hist=True)   # one launch: the multiplicities are the counting pass's by-product
+    assert torch.equal(p2, perm) and torch.equal(r2, rows) and torch.equal(h2, hist_dev)
+    hist = hist_dev.cpu().numpy()
     perm, rows = perm.cpu().numpy(), rows.cpu().numpy()
     T = e.bit_length() + bin(e).count("1")
     # table row offsets as h2r_ctx_create lays them out: limb table, carry table (if its width differs), overflow table
