@@ -1,0 +1,39 @@
+"""Soak run of the pipeline: 240 pipelined calls per configuration (1,024 / 3,072 signatures, 2 or 3 buffer sets, 1 or 2 record
+streams), the oldest complete call audited in place every seventh call on the caller's stream.  usage: tools/pipeline_soak.py"""
+import os, sys, random, torch, numpy as np
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import halo2_rsa_amd as H
+from halo2_rsa_amd import big_integer as BI
+chip = H.BigIntChip(64, 2048)
+pl = chip.pow_fixed_layout(65537)
+rng = random.Random(99)
+for B, depth, side in ((1024, 2, 1), (3072, 2, 1), (1024, 3, 2)):
+    base = [rng.getrandbits(2048) | (1 << 2047) | 1 for _ in range(64)]
+    pipe = H.Pipeline(chip, depth=depth, side_streams=side)
+    sets = [dict(trace=torch.zeros(B * pl.elem_stride, dtype=torch.uint8, device="cuda"),
+                 ws=torch.zeros(chip.workspace_bytes(B, pl.num_mul_mods), dtype=torch.uint8, device="cuda"),
+                 out=torch.zeros((B, 32), dtype=torch.int64, device="cuda"),
+                 status=torch.zeros(B, dtype=torch.uint8, device="cuda")) for _ in range(depth)]
+    variants = []
+    for v in range(4):
+        N = [base[(i + v) % 64] ^ ((i // 64 + v) << 200) | 1 for i in range(B)]
+        X = [((base[(i * 5 + v) % 64] >> 3) * (i + 7 + v)) % N[i] for i in range(B)]
+        variants.append((N, X, chip.assign_integer(N), chip.assign_integer(X)))
+    bad_total, checks = 0, 0
+    CALLS = 240
+    for k in range(CALLS):
+        v = variants[k % 4]; s = sets[k % depth]
+        pipe.modpow_public_key(v[3], 65537, v[2], s["trace"], s["ws"], s["out"], s["status"])
+        if k >= depth - 1 and k % 7 == 3:     # audit the oldest complete call on the caller's stream (ordered by the contract)
+            kk = k - depth + 1
+            vv = variants[kk % 4]; ss = sets[kk % depth]
+            res = BI.BatchResult(H.AssignedInteger(ss["out"], 64), H.Trace(chip, ss["trace"], B, pl), ss["status"], workspace=ss["ws"],
+                                 inputs=("pow_fixed", vv[3], None, vv[2], b"\x01\x00\x01"))
+            bad, first = res.audit()
+            bad_total += int(bad.sum().item()) + int(ss["status"].sum().item()); checks += 1
+            got = H.AssignedInteger(ss["out"].clone(), 64).to_big_uint()
+            assert all(got[i] == pow(vv[1][i], 65537, vv[0][i]) for i in range(0, B, 37)), (B, k)
+    pipe.join(); torch.cuda.synchronize()
+    print("soak B=%d depth=%d streams=%d: %d calls, %d audits, violations %d" % (B, depth, side, CALLS, checks, bad_total))
+    assert bad_total == 0
+    pipe.close()
