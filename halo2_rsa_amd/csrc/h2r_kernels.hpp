@@ -838,6 +838,19 @@ __global__ __launch_bounds__(64 * NW) void recip_kernel(const u32 *n, u32 kreal,
 // ================================================================================================
 // K1: trace kernel
 // ================================================================================================
+// Workgroup -> work mapping of the big streaming kernels.  The hardware hands consecutive workgroups to the 8 XCDs in
+// turn (blockIdx % 8); mapped one to one, the XCDs sweep the output together, a few hundred MB wide.  Giving every XCD a
+// CONTIGUOUS EIGHTH of the work instead keeps the eight store streams far apart in the address space, and the memory system
+// likes that: the record kernel of the 44 GB config-4 trace goes from 5.3-5.5 to 6.6-6.9 TB/s, RSA-3072's from 5.3-5.5 to
+// 5.7-6.1 TB/s, RSA-2048's by 0-6 % depending on where the buffers landed (same-box A/B runs in
+// profiles/r02_xcd_mapping.txt; eighths are what matters -- chunks of 16-256 workgroups per XCD change nothing).
+// A bijection on [0, n): the n % 8 trailing workgroups keep their index.  Small launches are left alone.
+__device__ __forceinline__ u32 xcd_contiguous_block(u32 b, u32 n) {
+    const u32 n8 = n >> 3;
+    if (n < 2048 || b >= (n8 << 3)) return b;
+    return (b & 7) * n8 + (b >> 3);
+}
+
 template <int LW> struct LimbT;
 template <> struct LimbT<64> { using type = u64; };
 template <> struct LimbT<32> { using type = u32; };
@@ -1059,7 +1072,8 @@ __global__ __launch_bounds__(BT) void trace_kernel(TraceArgs args) {
     const int h = t / L, i = t % L;
     const int lane = tid & 63, wave = tid >> 6;
     TraceLds<LW, L> &s = lds_all[slot];
-    const u32 item = blockIdx.x * IPB + slot;  // n_items < 2^32 (checked by the host)
+    const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const u32 item = bid * IPB + slot;  // n_items < 2^32 (checked by the host)
     const bool in_range = item < args.n_items;
     const u32 elem32 = in_range ? item / args.T : 0;
     const u32 tt = in_range ? item - elem32 * args.T : 0;
@@ -2010,8 +2024,9 @@ __global__ __launch_bounds__(256) void emit_kernel(EmitArgs a) {
     u32 *const lds32 = reinterpret_cast<u32 *>(emit_lds4);
     const u32 tid = threadIdx.x;
     const u32 Tn = a.T ? a.T : 1;
-    const u64 elem = blockIdx.x / Tn;
-    const u32 t = (u32)(blockIdx.x - elem * Tn);
+    const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);   // every XCD reads and writes a contiguous eighth
+    const u64 elem = bid / Tn;
+    const u32 t = (u32)(bid - elem * Tn);
     const u8 *et = a.trace + elem * a.elem_stride;
     u8 *eo = a.out + elem * a.out_stride + a.out_off;
     const u32 L = a.L, C = 2 * L - 1;
@@ -2470,7 +2485,7 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
     constexpr u32 SR = 256;                                   // rows per stage (40 KB of LDS; 128-208 rows, i.e. four or more workgroups per CU, measured within +-5 % of it)
     __shared__ uint4 stage[SR * (ADVICE_ROW_BYTES / 16)];    // SR rows are built in LDS, then leave as full 16-byte-per-lane lines
     const u32 tid = threadIdx.x;
-    const u32 item = blockIdx.x;
+    const u32 item = xcd_contiguous_block(blockIdx.x, gridDim.x);   // every XCD reads and writes a contiguous eighth
     const u32 elem = item / a.T, t = item - elem * a.T;
     if (a.status && a.status[elem]) return;
     const u32 L = a.L, C = 2 * L - 1, nrc = (a.carry_nsub + 3) / 4;
