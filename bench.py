@@ -179,6 +179,11 @@ def main():
                     help="developer: issue the calls on a created stream instead of torch's default (null) stream")
     ap.add_argument("--no-in-field", action="store_true",
                     help="developer: pow_mod_fixed_exp only (no assert_in_field witness kernel) in the pipelined call")
+    ap.add_argument("--placement-candidates", type=int, default=-1,
+                    help="trace regions to allocate and measure before the run; the calls then rotate through the fastest "
+                         "ones (where a trace buffer lies physically decides whether the record kernel writes it at ~5.65 or "
+                         "~6.3 TB/s, DESIGN.md section 5).  Default 8 for calls of up to 1,536 signatures; 0 = take the buffers as "
+                         "they come")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="fully stream-ordered calls (chain then trace per step) instead of the two-stream pipeline")
     args = ap.parse_args()
@@ -231,7 +236,18 @@ def main():
     # rotate through `nbuf` trace regions, with several calls per step every call has its own region of the shard's
     # trace.  Zero-filled, so every page is resident before the first (possibly un-warmed) timed step touches it.
     regions = nbuf if chunks == 1 else chunks
-    trace_buf = torch.zeros(regions * chunk * elem_stride, dtype=torch.uint8, device=dev)
+    # Placement: the record kernel's store rate depends on where its output lies physically (binary: ~5.65 or ~6.3 TB/s
+    # per 1.25 GB region, about 40 % of the regions fast; tools/buffer_speed_probe.py).  A service allocates its trace
+    # arena once, so it can afford to look: the arena holds `cand` regions, each is timed before the run (untimed
+    # initialisation), the calls rotate through the `nbuf` fastest.
+    cand = args.placement_candidates
+    if cand < 0:
+        cand = 8
+    # (calls the library walks as sub-batches are left alone: several record kernels per call, and no consistent gain measured)
+    if chunks != 1 or chunk > 1536 or args.no_pipeline or args.no_kernel_timing or cand <= nbuf:
+        cand = 0
+    trace_regions = list(range(regions))          # region slot of a call -> region of the arena
+    trace_buf = torch.zeros(max(regions, cand) * chunk * elem_stride, dtype=torch.uint8, device=dev)
     ifs = chip.in_field_layout()[0]
     in_field_buf = torch.zeros(regions * chunk * ifs, dtype=torch.uint8, device=dev)   # assert_in_field witness (src/chip.rs:106)
     out = torch.zeros((regions * chunk, chip.num_limbs), dtype=chip.torch_dtype, device=dev)
@@ -249,7 +265,8 @@ def main():
         r = (k % nbuf) if chunks == 1 else c          # trace / result region
         ws = workspaces[k % nbuf]
         sl = slice(r * chunk, (r + 1) * chunk)
-        tb = trace_buf[r * chunk * elem_stride:(r + 1) * chunk * elem_stride]
+        tr_ = trace_regions[r]
+        tb = trace_buf[tr_ * chunk * elem_stride:(tr_ + 1) * chunk * elem_stride]
         fb = in_field_buf[r * chunk * ifs:(r + 1) * chunk * ifs]
         if pipe is None:
             chip.pow_mod_fixed_exp(xc[c], e, nc[c], want_trace=True, trace_buf=tb, check_in_field=True,
@@ -269,6 +286,27 @@ def main():
     # then the W warm-up steps the caller asked for
     call(0)
     counter[0] = 0
+    placement = None
+    if cand:   # time the record kernel in every candidate region (three pipelined calls each), keep the fastest nbuf
+        per_region = []
+        rounds = 3
+        _lib.profile_enable(4 * rounds * cand + 8)
+        for _ in range(rounds):
+            for i in range(cand):
+                trace_regions[counter[0] % nbuf] = i
+                call(0)
+        pipe.join()
+        torch.cuda.synchronize()
+        tms = _lib.profile_read(_lib.KERNEL_TRACE)
+        _lib.profile_enable(0)
+        assert len(tms) == rounds * cand, "one record kernel per measured call expected"
+        for i in range(cand):
+            v = [tms[rr * cand + i] for rr in range(rounds)]
+            per_region.append(sum(v[1:]) / (rounds - 1))       # (the first round warms the region up)
+        best = sorted(range(cand), key=lambda i: per_region[i])[:nbuf]
+        trace_regions = sorted(best)
+        placement = {"candidates": cand, "record_kernel_ms_per_region": [round(t, 4) for t in per_region], "chosen": trace_regions}
+        counter[0] = 0
     for _ in range(warmup):
         step()
     if pipe is not None:
@@ -297,7 +335,7 @@ def main():
     got = H.AssignedInteger(res.contiguous(), w).to_big_uint()
     base = c_last * chunk
     # the trace that was timed is the real thing: first element of the last call, byte-exact vs pow() through q*n+r
-    tr = H.Trace(chip, trace_buf[last * chunk * elem_stride:(last + 1) * chunk * elem_stride], chunk, pl)
+    tr = H.Trace(chip, trace_buf[trace_regions[last] * chunk * elem_stride:(trace_regions[last] + 1) * chunk * elem_stride], chunk, pl)
     tr.elem_stride = elem_stride
     q0 = int.from_bytes(tr.plane(0, 0, "Q").tobytes(), "little")
     r0 = int.from_bytes(tr.plane(0, 0, "R").tobytes(), "little")
@@ -356,7 +394,8 @@ def main():
                        "path": "verify_pkcs1v15_signature (in-field + modpow + EM check)" if verify else "modpow_public_key",
                        "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world,
                        "pipeline": ("chain k+1 || trace k, %d buffer sets, %d record stream(s)" % (args.pipeline_depth, args.side_streams))
-                                   if pipe is not None else "none"},
+                                   if pipe is not None else "none",
+                       "buffer_placement": placement if placement else "as allocated"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": pmc_traffic("trace_kernel<%d,%d>" % (w, chip.num_limbs), int(per_launch_batch)) if per_launch_batch == chunk else None,
