@@ -243,6 +243,7 @@ def main():
     cand = args.placement_candidates
     if cand < 0:
         cand = 8
+    cand = min(cand, int((24 << 30) // max(1, chunk * elem_stride)))   # the arena stays below 24 GB
     # (calls the library walks as sub-batches are left alone: several record kernels per call, and no consistent gain measured)
     if chunks != 1 or chunk > 1536 or args.no_pipeline or args.no_kernel_timing or cand <= nbuf:
         cand = 0
