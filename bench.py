@@ -180,10 +180,10 @@ def main():
     ap.add_argument("--no-in-field", action="store_true",
                     help="developer: pow_mod_fixed_exp only (no assert_in_field witness kernel) in the pipelined call")
     ap.add_argument("--placement-candidates", type=int, default=-1,
-                    help="trace regions to allocate and measure before the run; the calls then rotate through the fastest "
-                         "ones (where a trace buffer lies physically decides whether the record kernel writes it at ~5.65 or "
-                         "~6.3 TB/s, DESIGN.md section 5).  Default 8 for calls of up to 1,536 signatures; 0 = take the buffers as "
-                         "they come")
+                    help="trace regions the library's placement-aware arena (h2r_arena_create) maps and measures; the calls "
+                         "rotate through the fastest ones (where a trace buffer lies physically decides whether the record "
+                         "kernel writes it at 5.65 or up to 6.8 TB/s, DESIGN.md section 5).  Default 16 for calls of up to 1,536 "
+                         "signatures (at most 24 GB of candidates); 0 = plain allocations, taken as they come")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="fully stream-ordered calls (chain then trace per step) instead of the two-stream pipeline")
     args = ap.parse_args()
@@ -236,19 +236,31 @@ def main():
     # rotate through `nbuf` trace regions, with several calls per step every call has its own region of the shard's
     # trace.  Zero-filled, so every page is resident before the first (possibly un-warmed) timed step touches it.
     regions = nbuf if chunks == 1 else chunks
-    # Placement: the record kernel's store rate depends on where its output lies physically (binary: ~5.65 or ~6.3 TB/s
-    # per 1.25 GB region, about 40 % of the regions fast; tools/buffer_speed_probe.py).  A service allocates its trace
-    # arena once, so it can afford to look: the arena holds `cand` regions, each is timed before the run (untimed
-    # initialisation), the calls rotate through the `nbuf` fastest.
+    # Placement: the record kernel's store rate depends on where its output lies physically (per 1.25 GB region one of
+    # ~5.65 / 5.8 / 6.35 / 6.8 TB/s, stable for the life of the allocation; tools/buffer_speed_probe.py).  A service allocates
+    # its trace arena once, so it can afford to look: the library's arena (h2r_arena_create) maps `cand` candidate regions,
+    # runs the record kernel on each and keeps the `nbuf` fastest -- untimed initialisation, reported in the JSON line.
     cand = args.placement_candidates
     if cand < 0:
-        cand = 8
-    cand = min(cand, int((24 << 30) // max(1, chunk * elem_stride)))   # the arena stays below 24 GB
+        cand = 16
+    cand = min(cand, int((24 << 30) // max(1, chunk * elem_stride)))   # the candidates stay below 24 GB
     # (calls the library walks as sub-batches are left alone: several record kernels per call, and no consistent gain measured)
-    if chunks != 1 or chunk > 1536 or args.no_pipeline or args.no_kernel_timing or cand <= nbuf:
+    if chunks != 1 or chunk > 1536 or args.no_pipeline or cand <= nbuf:
         cand = 0
-    trace_regions = list(range(regions))          # region slot of a call -> region of the arena
-    trace_buf = torch.zeros(max(regions, cand) * chunk * elem_stride, dtype=torch.uint8, device=dev)
+    placement, arena = None, None
+    if cand:
+        off_rec = vl.pow.off_records if verify else pl.off_records
+        try:
+            arena = H.TraceArena(chip, elem_stride, off_rec, pl.num_mul_mods, chunk, regions=nbuf, candidates=cand)
+        except Exception as ex:   # (virtual-memory API unavailable, out of memory ...): plain allocations, said so in the line
+            arena, placement = None, "as allocated (arena failed: %s)" % str(ex)[:120]
+    if arena is not None:
+        trace_regions = arena.regions
+        placement = {"arena_candidates": cand, "record_kernel_alone_ms_per_candidate": [round(t, 4) for t in arena.measurements_ms],
+                     "kept_ms": [round(t, 4) for t in arena.region_ms]}
+    else:
+        trace_buf = torch.zeros(regions * chunk * elem_stride, dtype=torch.uint8, device=dev)
+        trace_regions = [trace_buf[r * chunk * elem_stride:(r + 1) * chunk * elem_stride] for r in range(regions)]
     ifs = chip.in_field_layout()[0]
     in_field_buf = torch.zeros(regions * chunk * ifs, dtype=torch.uint8, device=dev)   # assert_in_field witness (src/chip.rs:106)
     out = torch.zeros((regions * chunk, chip.num_limbs), dtype=chip.torch_dtype, device=dev)
@@ -266,8 +278,7 @@ def main():
         r = (k % nbuf) if chunks == 1 else c          # trace / result region
         ws = workspaces[k % nbuf]
         sl = slice(r * chunk, (r + 1) * chunk)
-        tr_ = trace_regions[r]
-        tb = trace_buf[tr_ * chunk * elem_stride:(tr_ + 1) * chunk * elem_stride]
+        tb = trace_regions[r]
         fb = in_field_buf[r * chunk * ifs:(r + 1) * chunk * ifs]
         if pipe is None:
             chip.pow_mod_fixed_exp(xc[c], e, nc[c], want_trace=True, trace_buf=tb, check_in_field=True,
@@ -287,27 +298,6 @@ def main():
     # then the W warm-up steps the caller asked for
     call(0)
     counter[0] = 0
-    placement = None
-    if cand:   # time the record kernel in every candidate region (three pipelined calls each), keep the fastest nbuf
-        per_region = []
-        rounds = 3
-        _lib.profile_enable(4 * rounds * cand + 8)
-        for _ in range(rounds):
-            for i in range(cand):
-                trace_regions[counter[0] % nbuf] = i
-                call(0)
-        pipe.join()
-        torch.cuda.synchronize()
-        tms = _lib.profile_read(_lib.KERNEL_TRACE)
-        _lib.profile_enable(0)
-        assert len(tms) == rounds * cand, "one record kernel per measured call expected"
-        for i in range(cand):
-            v = [tms[rr * cand + i] for rr in range(rounds)]
-            per_region.append(sum(v[1:]) / (rounds - 1))       # (the first round warms the region up)
-        best = sorted(range(cand), key=lambda i: per_region[i])[:nbuf]
-        trace_regions = sorted(best)
-        placement = {"candidates": cand, "record_kernel_ms_per_region": [round(t, 4) for t in per_region], "chosen": trace_regions}
-        counter[0] = 0
     for _ in range(warmup):
         step()
     if pipe is not None:
@@ -336,7 +326,7 @@ def main():
     got = H.AssignedInteger(res.contiguous(), w).to_big_uint()
     base = c_last * chunk
     # the trace that was timed is the real thing: first element of the last call, byte-exact vs pow() through q*n+r
-    tr = H.Trace(chip, trace_buf[trace_regions[last] * chunk * elem_stride:(trace_regions[last] + 1) * chunk * elem_stride], chunk, pl)
+    tr = H.Trace(chip, trace_regions[last], chunk, pl)
     tr.elem_stride = elem_stride
     q0 = int.from_bytes(tr.plane(0, 0, "Q").tobytes(), "little")
     r0 = int.from_bytes(tr.plane(0, 0, "R").tobytes(), "little")

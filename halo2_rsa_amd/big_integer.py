@@ -621,6 +621,47 @@ class Pipeline:
             pass
 
 
+class TraceArena:
+    """h2r_arena: `regions` trace regions of batch * elem_stride bytes each, the fastest of `candidates` mapped and measured
+    ones (where a trace buffer lies physically decides how fast the record kernel writes it).
+    .regions: uint8 tensors over the kept regions, fastest first; .region_ms / .measurements_ms: record-kernel times."""
+
+    class _Raw:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    def __init__(self, chip: BigIntChip, elem_stride: int, first_record_off: int, records_per_elem: int, batch: int,
+                 regions: int = 2, candidates: int = 16):
+        self.chip = chip
+        self._a = ctypes.c_void_p()
+        check(lib().h2r_arena_create(chip._ctx, elem_stride, first_record_off, records_per_elem, batch, regions, candidates,
+                                     chip._stream(), ctypes.byref(self._a)), "h2r_arena_create")
+        nbytes = int(lib().h2r_arena_region_bytes(self._a))
+        dev = "cuda:%d" % chip.device
+        self.regions = [torch.as_tensor(TraceArena._Raw(int(lib().h2r_arena_region(self._a, i)), nbytes), device=dev) for i in range(regions)]
+        self.region_ms = [float(lib().h2r_arena_region_ms(self._a, i)) for i in range(regions)]
+        buf = (ctypes.c_double * candidates)()
+        n = int(lib().h2r_arena_measurements(self._a, buf, candidates))
+        self.measurements_ms = [float(buf[i]) for i in range(n)]
+
+    @classmethod
+    def for_pow(cls, chip: BigIntChip, e: int, batch: int, regions: int = 2, candidates: int = 16) -> "TraceArena":
+        pl = chip.pow_fixed_layout(e)
+        return cls(chip, pl.elem_stride, pl.off_records, pl.num_mul_mods, batch, regions, candidates)
+
+    def close(self):
+        if self._a:
+            self.regions = []
+            lib().h2r_arena_destroy(self._a)
+            self._a = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 @dataclass
 class FreshResult:
     value: Optional[AssignedInteger]

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -757,6 +758,132 @@ struct h2r_pipeline {
     u32 k;            // calls issued
     u32 joined;       // calls whose record kernel the user stream has been ordered after
 };
+
+// ---- placement-aware trace arena ---------------------------------------------------------------------------------------
+// Where a trace buffer lies physically decides how fast the record kernel writes it: per 1.25 GB region of config 2 one of
+// 0.183 / 0.197 / 0.216 / 0.222 ms per launch (6.8 / 6.35 / 5.8 / 5.65 TB/s), stable for the life of the allocation, a few
+// regions in ten fast (tools/buffer_speed_probe.py; physically contiguous memory is always the 5.8 TB/s kind).  The cause
+// was not found, so the arena LOOKS: it maps `candidates` regions (HIP virtual-memory API, 256 MB physical chunks), runs the
+// record kernel in the production geometry on each, keeps the `regions` fastest and gives the others back.
+struct h2r_arena {
+    struct Region { void *va = nullptr; u64 mapped = 0; std::vector<hipMemGenericAllocationHandle_t> handles; float ms = 0.f; };
+    int device = 0;
+    u64 region_bytes = 0;
+    std::vector<Region> kept;          // fastest first
+    std::vector<float> measured;       // every candidate, in allocation order
+};
+
+namespace {
+void arena_free_region(h2r_arena::Region &r) {
+    if (r.va) { (void)hipMemUnmap(r.va, r.mapped); }
+    for (auto h : r.handles) (void)hipMemRelease(h);
+    if (r.va) (void)hipMemAddressFree(r.va, r.mapped);
+    r.va = nullptr; r.handles.clear();
+}
+}  // namespace
+
+int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t first_record_off, uint32_t records_per_elem,
+                         uint64_t batch, uint32_t regions, uint32_t candidates, h2r_stream_t stream, h2r_arena **out) {
+    if (!ctx || !out) return H2R_E_NULL;
+    *out = nullptr;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    const h2r_layout &lo = ctx->layout;
+    if (!regions || candidates < regions || !batch || !records_per_elem ||
+        elem_stride < first_record_off + (u64)records_per_elem * lo.record_stride) return H2R_E_SHAPE;
+    if (batch * (u64)records_per_elem >= (1ull << 32)) return H2R_E_UNSUPPORTED;
+    H2R_ON_DEVICE(ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->params.device;
+    size_t gran = 0;
+    HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    if (!gran) gran = 2u << 20;
+    const u64 region_bytes = batch * elem_stride;
+    const u64 n_chunks = (region_bytes + (256ull << 20) - 1) / (256ull << 20);
+    const u64 chunk = round_up((region_bytes + n_chunks - 1) / n_chunks, gran);
+    std::unique_ptr<h2r_arena> a(new (std::nothrow) h2r_arena());
+    if (!a) return H2R_E_HIP;
+    a->device = ctx->params.device; a->region_bytes = region_bytes;
+    // operands of the measurement launches: any values do (the record kernel's store pattern does not depend on them)
+    const u64 n_items = batch * records_per_elem;
+    const u64 ops_bytes = n_items * 4ull * ctx->L * lo.limb_bytes;
+    u8 *scratch = nullptr;
+    HIP_TRY(hipMalloc(&scratch, ops_bytes + batch + 4096));
+    struct ScratchFree { u8 *p; ~ScratchFree() { if (p) (void)hipFree(p); } } scratch_free{scratch};
+    HIP_TRY(hipMemsetAsync(scratch, 0x5a, ops_bytes, st));
+    HIP_TRY(hipMemsetAsync(scratch + ops_bytes, 0, batch + 4096, st));
+    hipEvent_t ea = nullptr, eb = nullptr;
+    HIP_TRY(hipEventCreate(&ea));
+    if (!hip_ok(hipEventCreate(&eb), "hipEventCreate")) { (void)hipEventDestroy(ea); return H2R_E_HIP; }
+    std::vector<h2r_arena::Region> cands(candidates);
+    int32_t rc = H2R_OK;
+    for (u32 ci = 0; ci < candidates && rc == H2R_OK; ++ci) {
+        h2r_arena::Region &r = cands[ci];
+        r.mapped = n_chunks * chunk;
+        if (!hip_ok(hipMemAddressReserve(&r.va, r.mapped, 0, nullptr, 0), "hipMemAddressReserve")) { r.va = nullptr; rc = H2R_E_HIP; break; }
+        for (u64 k = 0; k < n_chunks; ++k) {
+            hipMemGenericAllocationHandle_t h;
+            if (!hip_ok(hipMemCreate(&h, chunk, &prop, 0), "hipMemCreate")) { rc = H2R_E_HIP; break; }
+            r.handles.push_back(h);
+            if (!hip_ok(hipMemMap(static_cast<u8 *>(r.va) + k * chunk, chunk, 0, h, 0), "hipMemMap")) { rc = H2R_E_HIP; break; }
+        }
+        if (rc) break;
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+        if (!hip_ok(hipMemSetAccess(r.va, r.mapped, &acc, 1), "hipMemSetAccess")) { rc = H2R_E_HIP; break; }
+        if (!hip_ok(hipMemsetAsync(r.va, 0, region_bytes, st), "hipMemsetAsync")) { rc = H2R_E_HIP; break; }
+        TraceArgs ta;
+        fill_trace_args(ctx, ta);
+        const u64 lb = lo.limb_width / 8;
+        ta.opA = scratch; ta.opB = scratch + ctx->L * lb; ta.opQ = scratch + 2 * ctx->L * lb; ta.opR = scratch + 3 * ctx->L * lb;
+        ta.op_stride = 4ull * ctx->L;
+        ta.n = scratch; ta.n_stride = 0;
+        ta.status = scratch + ops_bytes; ta.n_items = n_items; ta.T = records_per_elem;
+        ta.trace = static_cast<u8 *>(r.va); ta.elem_stride = elem_stride; ta.off_records = first_record_off;
+        if (knobs().trace_dyn_lds < 0 && lo.limb_width == 64 && ctx->L <= 32) ta.residency = 1;   // the kernel's stand-alone launch shape
+        float sum = 0.f;
+        for (int rep = 0; rep < 3 && rc == H2R_OK; ++rep) {
+            if (!hip_ok(launch_trace(ctx, ta, st, ea, eb), "launch_trace")) { rc = H2R_E_HIP; break; }
+            if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) { rc = H2R_E_HIP; break; }
+            float ms = 0.f;
+            if (!hip_ok(hipEventElapsedTime(&ms, ea, eb), "hipEventElapsedTime")) { rc = H2R_E_HIP; break; }
+            if (rep) sum += ms;   // the first launch touches the pages
+        }
+        r.ms = sum / 2.f;
+    }
+    (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    if (rc) { for (auto &r : cands) arena_free_region(r); return rc; }
+    for (const auto &r : cands) a->measured.push_back(r.ms);
+    std::vector<u32> order(candidates);
+    for (u32 i = 0; i < candidates; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return cands[x].ms < cands[y].ms; });
+    for (u32 i = 0; i < candidates; ++i) {
+        if (i < regions) a->kept.push_back(std::move(cands[order[i]]));
+        else arena_free_region(cands[order[i]]);
+    }
+    *out = a.release();
+    return H2R_OK;
+}
+
+void *h2r_arena_region(const h2r_arena *a, uint32_t i) { return (a && i < a->kept.size()) ? a->kept[i].va : nullptr; }
+uint64_t h2r_arena_region_bytes(const h2r_arena *a) { return a ? a->region_bytes : 0; }
+double h2r_arena_region_ms(const h2r_arena *a, uint32_t i) { return (a && i < a->kept.size()) ? (double)a->kept[i].ms : 0.0; }
+uint32_t h2r_arena_measurements(const h2r_arena *a, double *ms_out, uint32_t cap) {
+    if (!a) return 0;
+    for (u32 i = 0; i < a->measured.size() && i < cap && ms_out; ++i) ms_out[i] = a->measured[i];
+    return (uint32_t)a->measured.size();
+}
+void h2r_arena_destroy(h2r_arena *a) {
+    if (!a) return;
+    {
+        DeviceGuard dg(a->device);
+        (void)hipDeviceSynchronize();
+        for (auto &r : a->kept) arena_free_region(r);
+    }
+    delete a;
+}
 
 int32_t h2r_pipeline_create(const h2r_ctx *ctx, h2r_pipeline **out) { return h2r_pipeline_create_ex(ctx, 2, 1, out); }
 

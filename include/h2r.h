@@ -261,6 +261,22 @@ int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const voi
                                        uint8_t *status, void *workspace, h2r_stream_t stream);
 int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream);
 
+/* ---- placement-aware trace arena ---------------------------------------------------------------
+ * How fast the record kernel writes a trace buffer depends on where the buffer lies physically: for a 1.25 GB region
+ * 5.65 .. 6.8 TB/s, stable for the life of the allocation.  The arena maps `candidates` regions of
+ * batch * elem_stride bytes (HIP virtual-memory API), times the record kernel on each in the geometry given
+ * (records_per_elem records per element from first_record_off, elem_stride apart: e.g. h2r_pow_layout's
+ * num_mul_mods / off_records / elem_stride), keeps the `regions` fastest -- h2r_arena_region(a, 0) is the fastest --
+ * and gives the others back.  Synchronises `stream`.  The regions are ordinary device memory for every other purpose. */
+typedef struct h2r_arena h2r_arena;
+int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t first_record_off, uint32_t records_per_elem,
+                         uint64_t batch, uint32_t regions, uint32_t candidates, h2r_stream_t stream, h2r_arena **out);
+void *h2r_arena_region(const h2r_arena *a, uint32_t i);
+uint64_t h2r_arena_region_bytes(const h2r_arena *a);
+double h2r_arena_region_ms(const h2r_arena *a, uint32_t i);          /* measured record-kernel time of kept region i */
+uint32_t h2r_arena_measurements(const h2r_arena *a, double *ms_out, uint32_t cap);   /* all candidates, allocation order */
+void h2r_arena_destroy(h2r_arena *a);
+
 /* How a pipelined (or a large plain) fixed-exponent call of `batch` elements is walked on this ctx: the sizes of the
  * sub-batches that get their own chain and record kernel (one entry = the call is one launch pair), and whether the
  * chain kernels are paced by the record kernels.  pipeline_busy: a record kernel of the previous call is still in

@@ -1153,6 +1153,57 @@ def test_pipeline_with_device_side_consumers(H):
     pipe.close()
 
 
+def test_trace_arena(H):
+    """h2r_arena_create: candidate regions are mapped and measured, the fastest kept (sorted), the others given back; the
+    kept regions are ordinary device memory -- a pipelined modpow_public_key into them is byte-exact against the oracle and
+    audits clean -- and a second arena can be created after the first one is destroyed.  Shape errors where the C ABI
+    defines them."""
+    from halo2_rsa_amd import big_integer as BI
+    chip = H.BigIntChip(64, 2048)
+    o = Oracle(64, 32)
+    pl = chip.pow_fixed_layout(65537)
+    B = 256
+    arena = H.TraceArena.for_pow(chip, 65537, B, regions=2, candidates=5)
+    assert len(arena.regions) == 2 and len(arena.measurements_ms) == 5
+    assert all(t > 0 for t in arena.measurements_ms)
+    assert arena.region_ms == sorted(arena.measurements_ms)[:2]
+    assert all(r.numel() == B * pl.elem_stride and r.is_cuda for r in arena.regions)
+    rng = random.Random(808)
+    N = [rand_modulus(rng, 2048) for _ in range(B)]
+    X = [rng.randrange(n) for n in N]
+    x, n = chip.assign_integer(X), chip.assign_integer(N)
+    pipe = chip.pipeline()
+    outs = []
+    for r in arena.regions:
+        ws = torch.zeros(chip.workspace_bytes(B, pl.num_mul_mods), dtype=torch.uint8, device="cuda")
+        out = torch.zeros((B, 32), dtype=torch.int64, device="cuda")
+        status = torch.zeros(B, dtype=torch.uint8, device="cuda")
+        pipe.modpow_public_key(x, 65537, n, r, ws, out, status)
+        outs.append((ws, out, status))
+    pipe.join()
+    torch.cuda.synchronize()
+    for r, (ws, out, status) in zip(arena.regions, outs):
+        assert not status.cpu().numpy().any()
+        tr = H.Trace(chip, r, B, pl)
+        for i in (0, 100, B - 1):
+            rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(X[i]), o.limbs(N[i]), 65537)
+            assert rc == 0 and np.array_equal(ost, tr.flatten(i)), i
+        res = BI.BatchResult(H.AssignedInteger(out, 64), tr, status, workspace=ws, inputs=("pow_fixed", x, None, n, b"\x01\x00\x01"))
+        bad, first = res.audit()
+        torch.cuda.synchronize()
+        assert not bad.cpu().numpy().any()
+    pipe.close()
+    arena.close()
+    again = H.TraceArena.for_pow(chip, 65537, 64, regions=1, candidates=2)
+    assert len(again.regions) == 1
+    again.close()
+    a = ctypes.c_void_p()
+    L = H.lib()
+    assert L.h2r_arena_create(chip._ctx, pl.elem_stride, pl.off_records, pl.num_mul_mods, 16, 3, 2, None, ctypes.byref(a)) == H.H2R_E_SHAPE   # fewer candidates than regions
+    assert L.h2r_arena_create(chip._ctx, 1024, pl.off_records, pl.num_mul_mods, 16, 1, 2, None, ctypes.byref(a)) == H.H2R_E_SHAPE              # element too small for its records
+    assert L.h2r_arena_create(None, pl.elem_stride, pl.off_records, pl.num_mul_mods, 16, 1, 2, None, ctypes.byref(a)) == 7   # H2R_E_NULL
+
+
 def _check_pow_batch(H, chip, o, X, N, e, res, sample, rng):
     torch.cuda.synchronize()
     assert not res.status.cpu().numpy().any()
