@@ -13,6 +13,8 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/
 cd $R
 python tools/pmc_to_json.py $O 1024 > $O/pmc_traffic.json
 python tools/timeline.py $O/kt > $O/timeline_pipeline.txt
+python tools/timed_region_stats.py $O/kt 20 > $O/kernel_stats_pipeline_timed.csv
+python tools/timed_region_stats.py $O/kt_serial 20 > $O/kernel_stats_serial_timed.csv
 timeout 300 python bench.py --steps 40 --warmup 4 > $O/bench_pipeline.json 2> $O/bench_pipeline.err
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_pipeline_driver_args.json 2>/dev/null
 timeout 300 python bench.py --steps 40 --warmup 4 --no-pipeline --no-cpu-baseline > $O/bench_serial.json 2>/dev/null
