@@ -429,6 +429,27 @@ class RSAChip {
 
 // h2r_pipeline_*: consecutive verifier batches overlap the off-circuit chain of batch k+1 with the record emission
 // of batch k.  The caller rotates through `depth` buffer sets; join() orders `stream` after every record kernel.
+// h2r_arena: the fastest `regions` of `candidates` mapped-and-measured trace regions for `batch` elements of the verifier
+// layout of public exponent e_le (where a trace buffer lies physically decides how fast the record kernel writes it).
+class TraceArena {
+  public:
+    TraceArena(const RSAChip &chip, size_t batch, const std::vector<uint8_t> &e_le, uint32_t regions = 2, uint32_t candidates = 16,
+               hipStream_t stream = nullptr) {
+        h2r_verify_layout vl{};
+        check(h2r_verify_layout_fixed(chip.bigint_chip().ctx(), e_le.data(), e_le.size(), &vl), "h2r_verify_layout_fixed");
+        check(h2r_arena_create(chip.bigint_chip().ctx(), vl.elem_stride, vl.pow.off_records, vl.pow.num_mul_mods, batch, regions, candidates,
+                               stream, &a_), "h2r_arena_create");
+    }
+    ~TraceArena() { h2r_arena_destroy(a_); }
+    TraceArena(const TraceArena &) = delete;
+    TraceArena &operator=(const TraceArena &) = delete;
+    void *region(uint32_t i) const { return h2r_arena_region(a_, i); }        // fastest first
+    double region_ms(uint32_t i) const { return h2r_arena_region_ms(a_, i); }
+    uint64_t region_bytes() const { return h2r_arena_region_bytes(a_); }
+  private:
+    h2r_arena *a_ = nullptr;
+};
+
 class Pipeline {
   public:
     struct Buffers {   // one buffer set (sized for `batch` signatures and public exponent `e_le`)
