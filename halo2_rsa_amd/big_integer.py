@@ -624,7 +624,8 @@ class Pipeline:
 class TraceArena:
     """h2r_arena: `regions` trace regions of batch * elem_stride bytes each, the fastest of `candidates` mapped and measured
     ones (where a trace buffer lies physically decides how fast the record kernel writes it).
-    .regions: uint8 tensors over the kept regions, fastest first; .region_ms / .measurements_ms: record-kernel times."""
+    .regions: uint8 tensors over the kept regions, fastest first (views of the arena's memory: drop them before close());
+    .region_ms / .measurements_ms: record-kernel times."""
 
     class _Raw:
         def __init__(self, ptr, n):
