@@ -86,6 +86,7 @@ struct Knobs {
     bool chain_timing = false;                   // H2R_CHAIN_TIMING (needs the -DH2R_CHAIN_TIMING build)
     bool pipe_serialize = false;                 // H2R_PIPE_SERIALIZE=1: with two record streams, a record kernel also waits for the previous one
     long plain_overlap = -1;                     // H2R_PLAIN_OVERLAP=0: the plain pow exports never overlap their sub-batches internally
+    long arena_chunk_mb = 0;                     // H2R_ARENA_CHUNK_MB: physical chunk size of the arena's regions
     long pipe_sub_batch = 0;                     // H2R_PIPE_SUB_BATCH: elements per chain + record kernel pair inside a pipelined call (multiple of 256)
     long pipe_pace = -1;                         // H2R_PIPE_PACE=0|1: sub-batch i+1's chain kernel waits for sub-batch i-1's record kernel
     Knobs() {
@@ -98,7 +99,7 @@ struct Knobs {
         pipe_stream_prio = !pe ? -1 : (!std::strcmp(pe, "high") ? 1 : (!std::strcmp(pe, "low") ? -1 : 0));
         chain_timing = std::getenv("H2R_CHAIN_TIMING") != nullptr;
         { const char *g = std::getenv("H2R_PIPE_SERIALIZE"); pipe_serialize = g && g[0] == '1'; }
-        pipe_sub_batch = num("H2R_PIPE_SUB_BATCH", 0); plain_overlap = num("H2R_PLAIN_OVERLAP", -1); pipe_pace = num("H2R_PIPE_PACE", -1);
+        pipe_sub_batch = num("H2R_PIPE_SUB_BATCH", 0); arena_chunk_mb = num("H2R_ARENA_CHUNK_MB", 0); plain_overlap = num("H2R_PLAIN_OVERLAP", -1); pipe_pace = num("H2R_PIPE_PACE", -1);
 #endif
     }
 };
@@ -801,7 +802,8 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
     HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
     if (!gran) gran = 2u << 20;
     const u64 region_bytes = batch * elem_stride;
-    const u64 n_chunks = (region_bytes + (256ull << 20) - 1) / (256ull << 20);
+    const u64 chunk_target = (knobs().arena_chunk_mb > 0 ? (u64)knobs().arena_chunk_mb : 256ull) << 20;
+    const u64 n_chunks = (region_bytes + chunk_target - 1) / chunk_target;
     const u64 chunk = round_up((region_bytes + n_chunks - 1) / n_chunks, gran);
     std::unique_ptr<h2r_arena> a(new (std::nothrow) h2r_arena());
     if (!a) return H2R_E_HIP;

@@ -27,3 +27,35 @@ extern "C" void *striped_alloc(size_t nbytes, size_t chunk, int spread, int devi
     if (hipMemSetAccess(base, n * chunk, &acc, 1) != hipSuccess) { std::printf("hipMemSetAccess failed\n"); return nullptr; }
     return base;   // (the pool's handles are leaked on purpose: a probe)
 }
+
+// ---- chunk pool: regions assembled from chosen physical chunks (probe for "is the speed a property of the chunks?") ----
+static std::vector<hipMemGenericAllocationHandle_t> g_pool;
+static size_t g_chunk = 0;
+static hipMemAllocationProp g_prop = {};
+extern "C" size_t pool_create(size_t n, size_t chunk, int device) {
+    g_prop.type = hipMemAllocationTypePinned; g_prop.location.type = hipMemLocationTypeDevice; g_prop.location.id = device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &g_prop, hipMemAllocationGranularityRecommended) != hipSuccess) return 0;
+    g_chunk = (chunk + gran - 1) / gran * gran;
+    g_pool.resize(n);
+    for (size_t i = 0; i < n; ++i) if (hipMemCreate(&g_pool[i], g_chunk, &g_prop, 0) != hipSuccess) { g_pool.resize(i); break; }
+    return g_pool.size();
+}
+extern "C" size_t pool_chunk_bytes() { return g_chunk; }
+// maps the chunks idx[0..n) back to back; returns the base address (0 on failure)
+static size_t g_va_align = 0;
+extern "C" void pool_set_va_alignment(size_t a) { g_va_align = a; }
+extern "C" void *pool_map(const int *idx, int n) {
+    void *base = nullptr;
+    if (hipMemAddressReserve(&base, (size_t)n * g_chunk, g_va_align, nullptr, 0) != hipSuccess) return nullptr;
+    for (int i = 0; i < n; ++i)
+        if (hipMemMap((char *)base + (size_t)i * g_chunk, g_chunk, 0, g_pool[idx[i]], 0) != hipSuccess) return nullptr;
+    hipMemAccessDesc acc = {};
+    acc.location = g_prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(base, (size_t)n * g_chunk, &acc, 1) != hipSuccess) return nullptr;
+    return base;
+}
+extern "C" int pool_unmap(void *base, int n) {
+    if (hipMemUnmap(base, (size_t)n * g_chunk) != hipSuccess) return 1;
+    return hipMemAddressFree(base, (size_t)n * g_chunk) != hipSuccess;
+}
