@@ -182,7 +182,7 @@ def main():
     ap.add_argument("--placement-candidates", type=int, default=-1,
                     help="trace regions the library's placement-aware arena (h2r_arena_create) maps and measures; the calls "
                          "rotate through the fastest ones (where a trace buffer lies physically decides whether the record "
-                         "kernel writes it at 5.65 or up to 6.8 TB/s, DESIGN.md section 5).  Default 16, at most 64 GB of "
+                         "kernel writes it at 5.65 or up to 6.8 TB/s, DESIGN.md section 5).  Default 24, at most 64 GB of "
                          "candidates (they are given back after the look); 0 = plain allocations, taken as they come")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="fully stream-ordered calls (chain then trace per step) instead of the two-stream pipeline")
@@ -242,7 +242,7 @@ def main():
     # runs the record kernel on each and keeps the `nbuf` fastest -- untimed initialisation, reported in the JSON line.
     cand = args.placement_candidates
     if cand < 0:
-        cand = 16
+        cand = 24
     cand = min(cand, int((64 << 30) // max(1, chunk * elem_stride)))   # the candidates stay below 64 GB (given back after the look)
     if chunks != 1 or cand <= nbuf:
         cand = 0
