@@ -32,6 +32,22 @@ wr = B * sb
 rd = B * tr.num_mul_mods * chip.layout.stream_bytes   # algorithmic bytes of the records read
 print("emit_kernel %s batch %d flags %d: %.3f ms per launch (min %.3f)  stream written %.2f TB/s, read+written %.2f TB/s  (%d B/element)"
       % (wl, B, flags, avg, min(ms), wr / avg / 1e9, (wr + rd) / avg / 1e9, sb))
+# the same with the stream written into a region of the placement-aware arena (where the output lies decides the store rate)
+if wl == "rsa2048" and flags == 0:
+    arena = H.TraceArena.for_pow(chip, 65537, B, regions=1, candidates=12)
+    out_a = arena.regions[0][:B * sb].view(B, sb)
+    tr.emit_stream(flags, out=out_a); torch.cuda.synchronize()
+    _lib.profile_enable(64)
+    for _ in range(10):
+        tr.emit_stream(flags, out=out_a)
+    torch.cuda.synchronize()
+    ms_a = _lib.profile_read(_lib.KERNEL_EMIT)
+    _lib.profile_enable(0)
+    avg_a = sum(ms_a) / len(ms_a)
+    print("emit_kernel %s batch %d flags %d, stream written into an arena region: %.3f ms per launch  read+written %.2f TB/s"
+          % (wl, B, flags, avg_a, (wr + rd) / avg_a / 1e9))
+    del out_a
+    arena.close()
 # the 5-column advice image of the same trace (advice_kernel): 160-byte rows of field elements
 if len(sys.argv) <= 4 or sys.argv[4] != "noadvice":
     img = res.emit_advice(); torch.cuda.synchronize()
