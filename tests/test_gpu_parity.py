@@ -1204,6 +1204,40 @@ def test_trace_arena(H):
     assert L.h2r_arena_create(None, pl.elem_stride, pl.off_records, pl.num_mul_mods, 16, 1, 2, None, ctypes.byref(a)) == 7   # H2R_E_NULL
 
 
+@pytest.mark.parametrize("w,L,batch", [(64, 32, 433), (64, 48, 217), (32, 128, 109), (64, 16, 869)])
+def test_xcd_mapping_with_ragged_grids(H, w, L, batch):
+    """The record kernel, the emitter and the advice kernel give every XCD a contiguous eighth of a launch's workgroups
+    (xcd_contiguous_block, launches of >= 2,048 workgroups).  Batches whose workgroup count is NOT a multiple of 8 and whose
+    last workgroup is partly empty: every result, sampled streams (host walk and device emitter) against the oracle, every
+    record audited in place, and the advice image of the last element against the Python restatement's row count."""
+    chip = H.BigIntChip(w, w * L)
+    o = Oracle(w, L)
+    rng = random.Random(3 * w + L + batch)
+    base = [rand_modulus(rng, w * L) for _ in range(16)]
+    N = [base[i % 16] ^ ((i // 16) << 40) | 1 for i in range(batch)]
+    X = [((base[(i * 5) % 16] >> 7) * (i + 3)) % N[i] for i in range(batch)]
+    res = chip.pow_mod_fixed_exp(chip.assign_integer(X), 65537, chip.assign_integer(N))
+    _check_pow_batch(H, chip, o, X, N, 65537, res, [0, 1, batch // 2, batch - 2, batch - 1], rng)
+    stream = res.trace.emit_stream()
+    torch.cuda.synchronize()
+    host = stream.cpu().numpy()
+    for i in (0, batch // 3, batch - 1):
+        rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(X[i]), o.limbs(N[i]), 65537)
+        assert rc == 0 and np.array_equal(host[i, :len(ost)], ost), i
+    img = res.emit_advice()
+    torch.cuda.synchronize()
+    rows = int(H.lib().h2r_advice_rows(chip._ctx))
+    assert img.shape == (batch, 19 * rows * 160)
+    last = img[batch - 1].cpu().numpy().reshape(19 * rows, 5, 32)
+    first = img[0].cpu().numpy().reshape(19 * rows, 5, 32)
+    for im, i in ((first, 0), (last, batch - 1)):   # row 0 of record 0 holds the first four sub-limbs of q[0] and their running sum
+        q0 = (X[i] * X[i]) // N[i] & ((1 << w) - 1)
+        sb = w // 8
+        subs = [(q0 >> (sb * k)) & ((1 << sb) - 1) for k in range(4)]
+        assert [int.from_bytes(im[0, k].tobytes(), "little") for k in range(4)] == subs, i
+        assert int.from_bytes(im[0, 4].tobytes(), "little") == sum(s << (sb * k) for k, s in enumerate(subs)), i
+
+
 def _check_pow_batch(H, chip, o, X, N, e, res, sample, rng):
     torch.cuda.synchronize()
     assert not res.status.cpu().numpy().any()
