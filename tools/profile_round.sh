@@ -18,6 +18,8 @@ python tools/timed_region_stats.py $O/kt_serial 20 > $O/kernel_stats_serial_time
 timeout 300 python bench.py --steps 40 --warmup 4 > $O/bench_pipeline.json 2> $O/bench_pipeline.err
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_pipeline_driver_args.json 2>/dev/null
 timeout 300 python bench.py --steps 40 --warmup 4 --no-pipeline --no-cpu-baseline > $O/bench_serial.json 2>/dev/null
+# the same box with plain allocations (no placement-aware arena): what the arena is worth
+timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --placement-candidates 0 > $O/bench_pipeline_driver_args_plain_allocations.json 2>/dev/null
 timeout 300 python bench.py --steps 40 --warmup 4 --pipeline-depth 3 --side-streams 2 --no-cpu-baseline > $O/bench_pipeline_d3s2.json 2>/dev/null
 timeout 300 python bench.py --steps 40 --warmup 4 --verify --no-cpu-baseline > $O/bench_verify.json 2>/dev/null
 # BASELINE config 3 as ONE rank sees it (8,192-signature shard = one pipelined call per step), through torchrun + RCCL
