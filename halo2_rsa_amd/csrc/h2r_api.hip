@@ -819,23 +819,20 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
     hipEvent_t ea = nullptr, eb = nullptr;
     HIP_TRY(hipEventCreate(&ea));
     if (!hip_ok(hipEventCreate(&eb), "hipEventCreate")) { (void)hipEventDestroy(ea); return H2R_E_HIP; }
-    std::vector<h2r_arena::Region> cands(candidates);
-    int32_t rc = H2R_OK;
-    for (u32 ci = 0; ci < candidates && rc == H2R_OK; ++ci) {
-        h2r_arena::Region &r = cands[ci];
+    // one candidate: reserve, create, map, touch, three launches of the record kernel in the production geometry
+    auto make_candidate = [&](h2r_arena::Region &r) -> int32_t {
         r.mapped = n_chunks * chunk;
-        if (!hip_ok(hipMemAddressReserve(&r.va, r.mapped, 0, nullptr, 0), "hipMemAddressReserve")) { r.va = nullptr; rc = H2R_E_HIP; break; }
+        if (!hip_ok(hipMemAddressReserve(&r.va, r.mapped, 0, nullptr, 0), "hipMemAddressReserve")) { r.va = nullptr; return H2R_E_HIP; }
         for (u64 k = 0; k < n_chunks; ++k) {
             hipMemGenericAllocationHandle_t h;
-            if (!hip_ok(hipMemCreate(&h, chunk, &prop, 0), "hipMemCreate")) { rc = H2R_E_HIP; break; }
+            if (!hip_ok(hipMemCreate(&h, chunk, &prop, 0), "hipMemCreate")) return H2R_E_HIP;
             r.handles.push_back(h);
-            if (!hip_ok(hipMemMap(static_cast<u8 *>(r.va) + k * chunk, chunk, 0, h, 0), "hipMemMap")) { rc = H2R_E_HIP; break; }
+            if (!hip_ok(hipMemMap(static_cast<u8 *>(r.va) + k * chunk, chunk, 0, h, 0), "hipMemMap")) return H2R_E_HIP;
         }
-        if (rc) break;
         hipMemAccessDesc acc = {};
         acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
-        if (!hip_ok(hipMemSetAccess(r.va, r.mapped, &acc, 1), "hipMemSetAccess")) { rc = H2R_E_HIP; break; }
-        if (!hip_ok(hipMemsetAsync(r.va, 0, region_bytes, st), "hipMemsetAsync")) { rc = H2R_E_HIP; break; }
+        if (!hip_ok(hipMemSetAccess(r.va, r.mapped, &acc, 1), "hipMemSetAccess")) return H2R_E_HIP;
+        if (!hip_ok(hipMemsetAsync(r.va, 0, region_bytes, st), "hipMemsetAsync")) return H2R_E_HIP;
         TraceArgs ta;
         fill_trace_args(ctx, ta);
         const u64 lb = lo.limb_width / 8;
@@ -846,25 +843,53 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
         ta.trace = static_cast<u8 *>(r.va); ta.elem_stride = elem_stride; ta.off_records = first_record_off;
         if (knobs().trace_dyn_lds < 0 && lo.limb_width == 64 && ctx->L <= 32) ta.residency = 1;   // the kernel's stand-alone launch shape
         float sum = 0.f;
-        for (int rep = 0; rep < 3 && rc == H2R_OK; ++rep) {
-            if (!hip_ok(launch_trace(ctx, ta, st, ea, eb), "launch_trace")) { rc = H2R_E_HIP; break; }
-            if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) { rc = H2R_E_HIP; break; }
+        for (int rep = 0; rep < 3; ++rep) {
+            if (!hip_ok(launch_trace(ctx, ta, st, ea, eb), "launch_trace")) return H2R_E_HIP;
+            if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) return H2R_E_HIP;
             float ms = 0.f;
-            if (!hip_ok(hipEventElapsedTime(&ms, ea, eb), "hipEventElapsedTime")) { rc = H2R_E_HIP; break; }
+            if (!hip_ok(hipEventElapsedTime(&ms, ea, eb), "hipEventElapsedTime")) return H2R_E_HIP;
             if (rep) sum += ms;   // the first launch touches the pages
         }
         r.ms = sum / 2.f;
+        return H2R_OK;
+    };
+    std::vector<h2r_arena::Region> cands;
+    int32_t rc = H2R_OK;
+    auto run_round = [&]() {
+        for (u32 ci = 0; ci < candidates && rc == H2R_OK; ++ci) {
+            cands.emplace_back();
+            rc = make_candidate(cands.back());
+            if (rc == H2R_OK) a->measured.push_back(cands.back().ms);
+        }
+    };
+    auto keep_best = [&](size_t keep) {   // sorts, gives back everything behind the first `keep`
+        std::stable_sort(cands.begin(), cands.end(), [](const h2r_arena::Region &x, const h2r_arena::Region &y) { return x.ms < y.ms; });
+        for (size_t i = keep; i < cands.size(); ++i) arena_free_region(cands[i]);
+        if (cands.size() > keep) cands.resize(keep);
+    };
+    run_round();
+    if (rc == H2R_OK && region_bytes <= (4ull << 30) && candidates >= 4) {
+        // No fast class among the candidates (the fast regions are >= 10 % faster than the rest; some boxes show none where
+        // these candidates land)?  One more round in another part of the memory: behind a large placeholder allocation.
+        std::vector<float> t(a->measured);
+        std::sort(t.begin(), t.end());
+        if (t[0] > 0.93f * t[t.size() / 2]) {
+            keep_best(regions);
+            size_t free_b = 0, total_b = 0;
+            void *placeholder = nullptr;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const u64 want = (u64)candidates * n_chunks * chunk + (8ull << 30);
+                const u64 ph = free_b > want + (16ull << 30) ? std::min<u64>(96ull << 30, free_b - want) : 0;
+                if (ph && hipMalloc(&placeholder, ph) != hipSuccess) { placeholder = nullptr; (void)hipGetLastError(); }
+            }
+            run_round();
+            if (placeholder) (void)hipFree(placeholder);
+        }
     }
     (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
     if (rc) { for (auto &r : cands) arena_free_region(r); return rc; }
-    for (const auto &r : cands) a->measured.push_back(r.ms);
-    std::vector<u32> order(candidates);
-    for (u32 i = 0; i < candidates; ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](u32 x, u32 y) { return cands[x].ms < cands[y].ms; });
-    for (u32 i = 0; i < candidates; ++i) {
-        if (i < regions) a->kept.push_back(std::move(cands[order[i]]));
-        else arena_free_region(cands[order[i]]);
-    }
+    keep_best(regions);
+    for (auto &r : cands) a->kept.push_back(std::move(r));
     *out = a.release();
     return H2R_OK;
 }

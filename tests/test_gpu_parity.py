@@ -1164,7 +1164,7 @@ def test_trace_arena(H):
     pl = chip.pow_fixed_layout(65537)
     B = 256
     arena = H.TraceArena.for_pow(chip, 65537, B, regions=2, candidates=5)
-    assert len(arena.regions) == 2 and len(arena.measurements_ms) == 5
+    assert len(arena.regions) == 2 and len(arena.measurements_ms) in (5, 10)   # (10: a second round, no fast class in the first)
     assert all(t > 0 for t in arena.measurements_ms)
     assert arena.region_ms == sorted(arena.measurements_ms)[:2]
     assert all(r.numel() == B * pl.elem_stride and r.is_cuda for r in arena.regions)
