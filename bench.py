@@ -182,8 +182,8 @@ def main():
     ap.add_argument("--placement-candidates", type=int, default=-1,
                     help="trace regions the library's placement-aware arena (h2r_arena_create) maps and measures; the calls "
                          "rotate through the fastest ones (where a trace buffer lies physically decides whether the record "
-                         "kernel writes it at 5.65 or up to 6.8 TB/s, DESIGN.md section 5).  Default 24, at most 64 GB of "
-                         "candidates (they are given back after the look); 0 = plain allocations, taken as they come")
+                         "kernel writes it at 5.65 or up to 6.8 TB/s, DESIGN.md section 5).  Default 24 (8 for regions of more than 4 GB; "
+                         "at most pipeline-depth + 1 regions are mapped at any time); 0 = plain allocations, taken as they come")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="fully stream-ordered calls (chain then trace per step) instead of the two-stream pipeline")
     args = ap.parse_args()
@@ -241,9 +241,8 @@ def main():
     # its trace arena once, so it can afford to look: the library's arena (h2r_arena_create) maps `cand` candidate regions,
     # runs the record kernel on each and keeps the `nbuf` fastest -- untimed initialisation, reported in the JSON line.
     cand = args.placement_candidates
-    if cand < 0:
-        cand = 24
-    cand = min(cand, int((64 << 30) // max(1, chunk * elem_stride)))   # the candidates stay below 64 GB (given back after the look)
+    if cand < 0:   # (the arena holds at most nbuf + 1 regions at any time: the look also fits the 44-50 GB traces of configs 4 and 5)
+        cand = 24 if chunk * elem_stride <= (4 << 30) else 8
     if chunks != 1 or cand <= nbuf:
         cand = 0
     placement, arena = None, None

@@ -855,17 +855,27 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
     };
     std::vector<h2r_arena::Region> cands;
     int32_t rc = H2R_OK;
+    // Rejected candidates keep their memory while the look goes on -- given back at once, the next candidate would be
+    // handed the very same physical blocks -- up to 64 GB of them; beyond that the oldest are released (so the look also
+    // fits traces of tens of GB, with less variety among the candidates).
+    std::vector<h2r_arena::Region> rejected;
+    const u64 held_budget = 64ull << 30;
+    auto keep_best = [&](size_t keep, bool release_all) {   // sorts; everything behind the first `keep` moves to `rejected`
+        std::stable_sort(cands.begin(), cands.end(), [](const h2r_arena::Region &x, const h2r_arena::Region &y) { return x.ms < y.ms; });
+        for (size_t i = keep; i < cands.size(); ++i) rejected.push_back(std::move(cands[i]));
+        if (cands.size() > keep) cands.resize(keep);
+        size_t first = 0;
+        if (!release_all) { u64 held = 0; first = rejected.size(); while (first > 0 && held + rejected[first - 1].mapped <= held_budget) held += rejected[--first].mapped; }
+        else first = rejected.size();
+        for (size_t i = 0; i < first; ++i) arena_free_region(rejected[i]);
+        rejected.erase(rejected.begin(), rejected.begin() + (long)first);
+    };
     auto run_round = [&]() {
         for (u32 ci = 0; ci < candidates && rc == H2R_OK; ++ci) {
             cands.emplace_back();
             rc = make_candidate(cands.back());
-            if (rc == H2R_OK) a->measured.push_back(cands.back().ms);
+            if (rc == H2R_OK) { a->measured.push_back(cands.back().ms); keep_best(regions, false); }
         }
-    };
-    auto keep_best = [&](size_t keep) {   // sorts, gives back everything behind the first `keep`
-        std::stable_sort(cands.begin(), cands.end(), [](const h2r_arena::Region &x, const h2r_arena::Region &y) { return x.ms < y.ms; });
-        for (size_t i = keep; i < cands.size(); ++i) arena_free_region(cands[i]);
-        if (cands.size() > keep) cands.resize(keep);
     };
     run_round();
     if (rc == H2R_OK && region_bytes <= (4ull << 30) && candidates >= 4) {
@@ -873,8 +883,8 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
         // these candidates land)?  One more round in another part of the memory: behind a large placeholder allocation.
         std::vector<float> t(a->measured);
         std::sort(t.begin(), t.end());
-        if (t[0] > 0.93f * t[t.size() / 2]) {
-            keep_best(regions);
+        if (t[0] > 0.93f * t.back()) {   // (best within 7 % of the WORST: one class only -- usually the slow one)
+            keep_best(regions, true);
             size_t free_b = 0, total_b = 0;
             void *placeholder = nullptr;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -887,8 +897,8 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
         }
     }
     (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
-    if (rc) { for (auto &r : cands) arena_free_region(r); return rc; }
-    keep_best(regions);
+    if (rc) { for (auto &r : cands) arena_free_region(r); for (auto &r : rejected) arena_free_region(r); return rc; }
+    keep_best(regions, true);
     for (auto &r : cands) a->kept.push_back(std::move(r));
     *out = a.release();
     return H2R_OK;
