@@ -217,7 +217,9 @@ def main():
     if args.shared_modulus:   # SURVEY 8d's shared-n variant: x reduced modulo the one modulus
         ns = [ns[0]] * shard
         xs = [x % ns[0] for x in xs]
-        un, ux = H.UnassignedInteger(to_limbs(ns[:1], w, bits)), H.UnassignedInteger(to_limbs(xs, w, bits))
+        # (H2R_BENCH_REPLICATE_N: developer check -- the one modulus handed over as a per-element array, no SHARED flag)
+        un = H.UnassignedInteger(to_limbs(ns if os.environ.get("H2R_BENCH_REPLICATE_N") else ns[:1], w, bits))
+        ux = H.UnassignedInteger(to_limbs(xs, w, bits))
     n_dev, x_dev = chip.assign_integer(un), chip.assign_integer(ux)
     pl = chip.pow_fixed_layout(e)
     dev = "cuda:%d" % env.local_rank
@@ -265,7 +267,7 @@ def main():
     status = torch.zeros(regions * chunk, dtype=torch.uint8, device=dev)
     workspaces = [torch.zeros(chip.workspace_bytes(chunk, pl.num_mul_mods), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     xc = [H.AssignedInteger(x_dev.limbs_dev[c * chunk:(c + 1) * chunk], w) for c in range(chunks)]
-    nc = [n_dev if args.shared_modulus else H.AssignedInteger(n_dev.limbs_dev[c * chunk:(c + 1) * chunk], w) for c in range(chunks)]
+    nc = [n_dev if (args.shared_modulus and not os.environ.get("H2R_BENCH_REPLICATE_N")) else H.AssignedInteger(n_dev.limbs_dev[c * chunk:(c + 1) * chunk], w) for c in range(chunks)]
     pipe = None if args.no_pipeline else H.Pipeline(chip, depth=args.pipeline_depth, side_streams=args.side_streams)
     counter = [0]
 

@@ -353,7 +353,12 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
     if (knobs().chain_prio >= 0) ca.prio = (u32)knobs().chain_prio;
     // one key, many elements: the Barrett constants of the shared modulus are computed once (recip_kernel) instead of by
     // every element's workgroup (big_integer/chip.rs:562-567 divides by the same n every time)
-    if ((flags & H2R_F_SHARED_MODULUS) && batch > 1)
+    // ... except in pipeline mode for the shapes whose chain kernel hides behind the record kernel anyway: the one-workgroup
+    // recip_kernel in front of the chain kernel makes the chain kernel start 17 us AFTER the record kernel it shares the CUs
+    // with instead of together with it, and the record kernel -- the longer leg -- then runs 0.195 -> 0.209 ms (same-box A/B,
+    // bench.py --shared-modulus: 4.49 -> 4.8 M assigns/s without the precomputation).
+    const bool chain_hidden = trace_st && trace && T && (lo.limb_width == 32 || c->L <= 32);
+    if ((flags & H2R_F_SHARED_MODULUS) && batch > 1 && !chain_hidden)
         ca.pre = reinterpret_cast<const u32 *>(shared_pre ? static_cast<u8 *>(shared_pre) : ws + wp.off_pre);
     // Pipeline mode: the record stream must wait for this chain kernel.  The event it waits on is the dispatch's own
     // stop event (the profiler's when armed, else chain_done) -- no separate marker packet.
