@@ -268,7 +268,7 @@ int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream);
  * (records_per_elem records per element from first_record_off, elem_stride apart: e.g. h2r_pow_layout's
  * num_mul_mods / off_records / elem_stride), keeps the `regions` fastest -- h2r_arena_region(a, 0) is the fastest --
  * and gives the others back (rejected candidates keep their memory during the look, up to 64 GB of them, so that the
- * next candidate lands elsewhere).  When no candidate stands out (regions of up to 4 GB: the best within 7 % of the worst) a
+ * next candidate lands elsewhere).  When no candidate stands out (regions of up to 4 GB: the best within 10 % of the worst) a
  * second round of `candidates` is tried in another part of the memory, behind a placeholder allocation.  Synchronises `stream`.  The regions are ordinary device memory for every other purpose. */
 typedef struct h2r_arena h2r_arena;
 int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t first_record_off, uint32_t records_per_elem,
