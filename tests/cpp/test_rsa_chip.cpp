@@ -114,6 +114,18 @@ int main(int argc, char **argv) {
         bufs[1].powed.download(got.data(), got.size() * 8);
         REQUIRE(got == want);
     }
+    // placement-aware trace arena: the kept regions come fastest first and are ordinary device memory
+    {
+        const std::vector<uint8_t> e65537 = {0x01, 0x00, 0x01};
+        TraceArena arena(rsa_chip, B, e65537, /*regions*/ 2, /*candidates*/ 3);
+        REQUIRE(arena.region(0) != nullptr && arena.region(1) != nullptr && arena.region(2) == nullptr);
+        REQUIRE(arena.region_ms(0) > 0.0 && arena.region_ms(0) <= arena.region_ms(1));
+        h2r_verify_layout vl{};
+        REQUIRE(h2r_verify_layout_fixed(bigint_chip.ctx(), e65537.data(), e65537.size(), &vl) == H2R_OK);
+        REQUIRE(arena.region_bytes() == B * vl.elem_stride);
+        REQUIRE(hipMemset(arena.region(0), 0xff, arena.region_bytes()) == hipSuccess);
+        REQUIRE(hipDeviceSynchronize() == hipSuccess);
+    }
     // RSAInstructions::modpow_public_key (src/chip.rs:99-114): assert_in_field witness, then the pow witness
     {
         ModpowResult mp = rsa_chip.modpow_public_key(sign.c, pk);
