@@ -161,7 +161,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="signatures per call (default 1024)")
     ap.add_argument("--chunks", type=int, default=0,
-                    help="calls per step = chunks of the GPU's shard (default 1; per GPU 1,024 signatures at --gpus 1, 8,192 at --gpus > 1)")
+                    help="calls per step = chunks of the GPU's shard (default 1 at --gpus 1: 1,024 signatures per GPU; 4 at --gpus > 1: 8,192 per GPU)")
     ap.add_argument("--workload", default="rsa2048_e65537", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline-depth", type=int, default=2, help="buffer sets the pipelined calls rotate through (2..4)")
@@ -200,10 +200,11 @@ def main():
     if args.user_stream:
         torch.cuda.set_stream(torch.cuda.Stream())
     # Workload: N = 1 -> BASELINE configs[1] (one 1,024-signature call per step).  N > 1 -> configs[2]: every GPU owns a
-    # contiguous shard of 8,192 signatures of the global batch (65,536 at N = 8); a step is one pass over the shard = ONE
-    # pipelined call (the library walks a call that finds the pipeline empty as sub-batches, pipeline_plan in h2r_api.hip).
-    # --batch / --chunks override both (--chunks 8 --batch 1024: the shard as eight 1,024-signature calls).
-    chunks = args.chunks if args.chunks else 1
+    # contiguous shard of 8,192 signatures of the global batch (65,536 at N = 8); a step is one pass over the shard as FOUR
+    # pipelined calls of 2,048 signatures, each into its own arena region (measured on one GPU: 5.30-5.32 M assigns/s; two calls
+    # of 4,096: 5.19-5.44 M; one call of 8,192: 5.00 M; eight of 1,024: 4.5-4.7 M -- fewer kernel boundaries against regions
+    # small enough for a wide candidate search).  --batch / --chunks override both.
+    chunks = args.chunks if args.chunks else (1 if args.gpus == 1 else 4)
     chunk = args.batch if args.batch else (1024 if args.gpus == 1 else 8192 // chunks)
     # configuration broadcast (rank 0 decides): the only pre-run collective
     e, chunk, chunks, steps, warmup = env.broadcast_ints([e, chunk, chunks, args.steps, args.warmup])
@@ -245,13 +246,13 @@ def main():
     cand = args.placement_candidates
     if cand < 0:   # (the arena holds at most nbuf + 1 regions at any time: the look also fits the 44-50 GB traces of configs 4 and 5)
         cand = 24 if chunk * elem_stride <= (4 << 30) else 8
-    if chunks != 1 or cand <= nbuf:
+    if cand <= regions:
         cand = 0
     placement, arena = None, None
     if cand:
         off_rec = vl.pow.off_records if verify else pl.off_records
         try:
-            arena = H.TraceArena(chip, elem_stride, off_rec, pl.num_mul_mods, chunk, regions=nbuf, candidates=cand)
+            arena = H.TraceArena(chip, elem_stride, off_rec, pl.num_mul_mods, chunk, regions=regions, candidates=cand)
         except Exception as ex:   # (virtual-memory API unavailable, out of memory ...): plain allocations, said so in the line
             arena, placement = None, "as allocated (arena failed: %s)" % str(ex)[:120]
     if arena is not None:

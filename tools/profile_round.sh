@@ -22,11 +22,13 @@ timeout 300 python bench.py --steps 40 --warmup 4 --no-pipeline --no-cpu-baselin
 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --placement-candidates 0 > $O/bench_pipeline_driver_args_plain_allocations.json 2>/dev/null
 timeout 300 python bench.py --steps 40 --warmup 4 --pipeline-depth 3 --side-streams 2 --no-cpu-baseline > $O/bench_pipeline_d3s2.json 2>/dev/null
 timeout 300 python bench.py --steps 40 --warmup 4 --verify --no-cpu-baseline > $O/bench_verify.json 2>/dev/null
-# BASELINE config 3 as ONE rank sees it (8,192-signature shard = one pipelined call per step), through torchrun + RCCL
-H2R_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --batch 8192 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_torchrun1_config3_shard.json 2> $O/bench_torchrun1.err
+# BASELINE config 3 as ONE rank sees it (8,192-signature shard = four pipelined calls of 2,048 per step, the --gpus N > 1 default), through torchrun + RCCL
+H2R_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --batch 2048 --chunks 4 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_torchrun1_config3_shard.json 2> $O/bench_torchrun1.err
 {
   echo "# other BASELINE configs and shapes, same box (tools/sweep.py lines: step, value = assigns/s, record kernel, chain kernel)"
   python tools/sweep.py CONFIG C3-shard-8192-as-8-calls --chunks 8 --steps 6 --warmup 2
+  python tools/sweep.py CONFIG C3-shard-8192-as-4-calls-20-steps --batch 2048 --chunks 4 --steps 20 --warmup 5
+  python tools/sweep.py CONFIG C3-shard-8192-as-2-calls-20-steps --batch 4096 --chunks 2 --steps 20 --warmup 5
   python tools/sweep.py CONFIG C3-shard-8192-one-call --batch 8192 --steps 6 --warmup 2
   python tools/sweep.py CONFIG C3-shard-8192-one-call-20-steps --batch 8192 --steps 20 --warmup 5
   python tools/sweep.py CONFIG rsa2048-batch-4096 --batch 4096 --steps 20 --warmup 4
