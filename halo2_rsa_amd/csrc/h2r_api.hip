@@ -880,6 +880,12 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
             cands.emplace_back();
             rc = make_candidate(cands.back());
             if (rc == H2R_OK) { a->measured.push_back(cands.back().ms); keep_best(regions, false); }
+            else if (cands.size() > regions) {   // (out of memory, most likely) with enough good regions in hand: stop looking
+                arena_free_region(cands.back()); cands.pop_back();
+                (void)hipGetLastError();
+                rc = H2R_OK;
+                return;
+            }
         }
     };
     run_round();
