@@ -663,12 +663,7 @@ template <int K, int NW, bool DEEP>
 __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K, NW> &s, const u64 elem) {
     using G = Geo<K, NW>;
     constexpr int V = G::V;
-#ifdef H2R_CHAIN_ROT
-    // experiment: the wave that owns the serial part differs between the workgroups that share a CU
-    const int lane = threadIdx.x & 63, wave = (int)(((threadIdx.x >> 6) + H2R_CHAIN_ROT(blockIdx.x)) % NW);
-#else
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#endif
     const bool w0 = wave == 0;
     const u32 *n_g = args.n + elem * args.n_stride;
     const u32 KR = args.kreal;   // digits in memory; digits [KR, K) are zero
