@@ -156,6 +156,12 @@ enum { MUL_FULL = 0, MUL_HIGH = 1, MUL_LOW = 2 };
 #else
 #define H2R_STAMP(s_) do { } while (0)
 #endif
+#ifndef H2R_CHAIN_UNROLL
+#define H2R_CHAIN_UNROLL 2     // iterations (of four products) of the throughput build's product loop unrolled together
+#endif
+#define H2R_PRAGMA_(x) _Pragma(#x)
+#define H2R_PRAGMA(x) H2R_PRAGMA_(x)
+#define H2R_CHAIN_UNROLL_PRAGMA H2R_PRAGMA(unroll H2R_CHAIN_UNROLL)
 #ifndef H2R_CHAIN_MINB
 #define H2R_CHAIN_MINB 6   // blocks per CU the register budget is sized for (K <= 64): 79 VGPRs, no scratch (8 => 64 VGPRs + spills whose reloads wait on vmcnt(0))
 #endif
@@ -245,7 +251,7 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
                              : "+v"(acc), "+v"(ov), "=&s"(carry) : "v"(av), "v"(bv));
             };
             if constexpr (SLA % 4 == 0) {
-#pragma unroll 2
+H2R_CHAIN_UNROLL_PRAGMA
                 for (int j = 0; j < SLA; j += 4) {
                     const uint4 a4 = *reinterpret_cast<const uint4 *>(ap + j);  // broadcast 16-byte read
                     const u32 b0 = bp[-j], b1 = bp[-j - 1], b2 = bp[-j - 2], b3 = bp[-j - 3];

@@ -1,5 +1,5 @@
 """Debug: per-phase s_memtime stamps of chain_kernel block 0.
-Needs the instrumented build:  python -m halo2_rsa_amd._build timing -DH2R_CHAIN_TIMING  (run before gpurun)."""
+Needs the instrumented build:  python -m halo2_rsa_amd._build timing -DH2R_CHAIN_TIMING -DH2R_DEV_KNOBS  (run before gpurun)."""
 import os, sys
 os.environ["H2R_CHAIN_TIMING"] = "1"
 os.environ.setdefault("H2R_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "halo2_rsa_amd", "lib", "variants", "timing.so"))
