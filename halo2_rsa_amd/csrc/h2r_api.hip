@@ -89,6 +89,8 @@ struct Knobs {
     long arena_chunk_mb = 0;                     // H2R_ARENA_CHUNK_MB: physical chunk size of the arena's regions
     long pipe_sub_batch = 0;                     // H2R_PIPE_SUB_BATCH: elements per chain + record kernel pair inside a pipelined call (multiple of 256)
     long pipe_pace = -1;                         // H2R_PIPE_PACE=0|1: sub-batch i+1's chain kernel waits for sub-batch i-1's record kernel
+    unsigned long pipe_cu_mask = 0;              // H2R_PIPE_CU_MASK=<hex word>: the record stream is created with this 32-bit CU mask repeated over the device (experiment)
+    long pipe_cu_mask_words = 0;                 // H2R_PIPE_CU_MASK_WORDS=n: only the first n 32-bit words carry the mask, the rest are zero
     Knobs() {
 #ifdef H2R_DEV_KNOBS
         auto num = [](const char *name, long dflt) { const char *v = std::getenv(name); return v ? std::atol(v) : dflt; };
@@ -99,6 +101,7 @@ struct Knobs {
         pipe_stream_prio = !pe ? -1 : (!std::strcmp(pe, "high") ? 1 : (!std::strcmp(pe, "low") ? -1 : 0));
         chain_timing = std::getenv("H2R_CHAIN_TIMING") != nullptr;
         { const char *g = std::getenv("H2R_PIPE_SERIALIZE"); pipe_serialize = g && g[0] == '1'; }
+        { const char *m = std::getenv("H2R_PIPE_CU_MASK"); pipe_cu_mask = m ? std::strtoul(m, nullptr, 16) : 0; pipe_cu_mask_words = num("H2R_PIPE_CU_MASK_WORDS", 0); }
         pipe_sub_batch = num("H2R_PIPE_SUB_BATCH", 0); arena_chunk_mb = num("H2R_ARENA_CHUNK_MB", 0); plain_overlap = num("H2R_PLAIN_OVERLAP", -1); pipe_pace = num("H2R_PIPE_PACE", -1);
 #endif
     }
@@ -957,8 +960,15 @@ int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     const int prio = knobs().pipe_stream_prio < 0 ? prio_least : (knobs().pipe_stream_prio > 0 ? prio_greatest : 0);
-    for (int i = 0; ok && i < n_aux; ++i)
+    for (int i = 0; ok && i < n_aux; ++i) {
+        if (knobs().pipe_cu_mask) {   // developer experiment: the record kernels on a subset of the CUs
+            uint32_t mask[8];
+            for (int w = 0; w < 8; ++w) mask[w] = (knobs().pipe_cu_mask_words == 0 || w < knobs().pipe_cu_mask_words) ? (uint32_t)knobs().pipe_cu_mask : 0u;
+            ok = hip_ok(hipExtStreamCreateWithCUMask(&p->aux[i], 8, mask), "hipExtStreamCreateWithCUMask");
+            continue;
+        }
         ok = hip_ok(hipStreamCreateWithPriority(&p->aux[i], hipStreamNonBlocking, prio), "hipStreamCreate");
+    }
     if (ok && n_aux == 1) p->aux[1] = p->aux[0];
     for (u32 i = 0; ok && i < p->depth; ++i)
         ok = hip_ok(hipEventCreate(&p->chain_done[i]), "hipEventCreate") &&

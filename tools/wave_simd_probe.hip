@@ -24,10 +24,16 @@ __global__ __launch_bounds__(64 * NW) void probe(unsigned *out, unsigned spin) {
 int main(int argc, char **argv) {
     const int NW = argc > 1 ? atoi(argv[1]) : 4, blocks = argc > 2 ? atoi(argv[2]) : 1024;
     unsigned *d; hipMalloc(&d, sizeof(unsigned) * 2 * blocks * NW);
+    hipStream_t st = nullptr;
+    if (argc > 3) {   // [mask word hex] [words carrying it]: launch on a stream with that CU mask and list the CUs that got work
+        uint32_t mask[8]; const uint32_t m = (uint32_t)strtoul(argv[3], nullptr, 16); const int words = argc > 4 ? atoi(argv[4]) : 8;
+        for (int w = 0; w < 8; ++w) mask[w] = w < words ? m : 0u;
+        if (hipExtStreamCreateWithCUMask(&st, 8, mask) != hipSuccess) { printf("hipExtStreamCreateWithCUMask failed\n"); return 1; }
+    }
     for (int rep = 0; rep < 2; ++rep) {
-        if (NW == 4) hipLaunchKernelGGL(probe<4>, dim3(blocks), dim3(256), 0, 0, d, 3000u);
-        else if (NW == 2) hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(128), 0, 0, d, 3000u);
-        else hipLaunchKernelGGL(probe<8>, dim3(blocks), dim3(512), 0, 0, d, 3000u);
+        if (NW == 4) hipLaunchKernelGGL(probe<4>, dim3(blocks), dim3(256), 0, st, d, 3000u);
+        else if (NW == 2) hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(128), 0, st, d, 3000u);
+        else hipLaunchKernelGGL(probe<8>, dim3(blocks), dim3(512), 0, st, d, 3000u);
         hipDeviceSynchronize();
     }
     std::vector<unsigned> h(2 * blocks * NW);
@@ -56,6 +62,10 @@ int main(int argc, char **argv) {
     printf("workgroups per CU:"); for (auto &kv : hist_blocks) printf("  %d -> %d CUs", kv.first, kv.second); printf("\n");
     printf("distinct SIMDs holding a wave 0, per CU:"); for (auto &kv : hist_distinct) printf("  %d -> %d CUs", kv.first, kv.second); printf("\n");
     printf("most wave 0s on one SIMD, per CU:"); for (auto &kv : hist_maxshare) printf("  %d -> %d CUs", kv.first, kv.second); printf("\n");
+    if (st) {   // CUs per XCC that got work under the mask
+        std::map<unsigned, int> per_xcc; for (auto &kv : per_cu) per_xcc[kv.first >> 12]++;
+        printf("CUs with work per XCC:"); for (auto &kv : per_xcc) printf("  xcc%u -> %d", kv.first, kv.second); printf("\n");
+    }
     int shown = 0;
     for (auto &kv : per_cu) { if (shown++ >= 4) break; printf("cu %05x blocks:", kv.first); for (int b : kv.second) printf(" %d", b); printf("  wave-0 simds:"); for (int sd : w0_simd[kv.first]) printf(" %d", sd); printf("\n"); }
     return 0;
