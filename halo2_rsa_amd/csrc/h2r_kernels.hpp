@@ -2231,7 +2231,7 @@ struct U192 {
 template <int LW>
 __global__ __launch_bounds__(256) void check_kernel(CheckArgs a) {
     using limb_t = typename LimbT<LW>::type;
-    constexpr u32 LB = LW / 8, CB = LW == 64 ? 16 : 8;
+    constexpr u32 CB = LW == 64 ? 16 : 8;
     constexpr u64 LMASK = LW == 64 ? ~0ull : 0xffffffffull;
     __shared__ u32 s_bad, s_code;
     __shared__ u64 sa[128], sb_[128], sq[128], sn[128], sr[128];
