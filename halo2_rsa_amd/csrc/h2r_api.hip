@@ -89,6 +89,7 @@ struct Knobs {
     long arena_chunk_mb = 0;                     // H2R_ARENA_CHUNK_MB: physical chunk size of the arena's regions
     long pipe_sub_batch = 0;                     // H2R_PIPE_SUB_BATCH: elements per chain + record kernel pair inside a pipelined call (multiple of 256)
     long pipe_pace = -1;                         // H2R_PIPE_PACE=0|1: sub-batch i+1's chain kernel waits for sub-batch i-1's record kernel
+    long pipe_step = -1;                         // H2R_PIPE_STEP=0: never issue a pipeline step as one launch (the two-queue form for every shape)
     unsigned long pipe_cu_mask = 0;              // H2R_PIPE_CU_MASK=<hex word>: the record stream is created with this 32-bit CU mask repeated over the device (experiment)
     long pipe_cu_mask_words = 0;                 // H2R_PIPE_CU_MASK_WORDS=n: only the first n 32-bit words carry the mask, the rest are zero
     Knobs() {
@@ -102,6 +103,7 @@ struct Knobs {
         chain_timing = std::getenv("H2R_CHAIN_TIMING") != nullptr;
         { const char *g = std::getenv("H2R_PIPE_SERIALIZE"); pipe_serialize = g && g[0] == '1'; }
         { const char *m = std::getenv("H2R_PIPE_CU_MASK"); pipe_cu_mask = m ? std::strtoul(m, nullptr, 16) : 0; pipe_cu_mask_words = num("H2R_PIPE_CU_MASK_WORDS", 0); }
+        pipe_step = num("H2R_PIPE_STEP", -1);
         pipe_sub_batch = num("H2R_PIPE_SUB_BATCH", 0); arena_chunk_mb = num("H2R_ARENA_CHUNK_MB", 0); plain_overlap = num("H2R_PLAIN_OVERLAP", -1); pipe_pace = num("H2R_PIPE_PACE", -1);
 #endif
     }
@@ -306,13 +308,15 @@ void fill_trace_args(const h2r_ctx *c, TraceArgs &ta) {
     if (knobs().trace_prio >= 0) ta.prio = (u32)knobs().trace_prio;
 }
 
+// run_path(..., args_only): fill the two kernels' arguments in and launch nothing (the pipeline issues them itself)
+struct PathArgs { ChainArgs ca; TraceArgs ta; bool has_trace = false; };
 // Common driver: chain kernel (q, r of every mul_mod) then trace kernel (the witness records).
 int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const void *n, const void *e_limbs,
                  u32 e_num_limbs, u32 exp_limb_bits, const ExpBits *eb, u32 check_in_field, u64 batch, u32 flags,
                  u32 T, void *trace, u64 elem_stride, u64 off_records, const h2r_pow_layout *pl, void *out,
                  uint8_t *status, void *workspace, hipStream_t st, hipStream_t trace_st = nullptr,
                  hipEvent_t chain_done = nullptr, hipEvent_t trace_done = nullptr, DoneRef *done_ref = nullptr,
-                 void *shared_pre = nullptr) {
+                 void *shared_pre = nullptr, PathArgs *args_only = nullptr) {
     // shared_pre: where the shared modulus' Barrett constants go when `workspace` is a slice of a larger call's plan
     // trace_st != nullptr (pipeline mode): the record-writing kernel runs on trace_st after `chain_done`
     if (!c || !n || !a || !status) return H2R_E_NULL;
@@ -370,7 +374,8 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
     static u64 *dbg_buf = nullptr;
     if (knobs().chain_timing) { if (!dbg_buf) (void)hipMalloc(&dbg_buf, 4096 * 8); (void)hipMemsetAsync(dbg_buf, 0, 4096 * 8, st); ca.dbg_time = dbg_buf; }
 #endif
-    {
+    if (args_only) args_only->ca = ca;
+    else {
         ProfScope ps(H2R_KERNEL_CHAIN, st, true);
         const bool piped = trace_st && trace && T;
         chain_wait = ps.on ? ps.b : (piped ? chain_done : nullptr);
@@ -393,6 +398,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         ta.n = n; ta.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : c->L;
         ta.status = status; ta.n_items = batch * T; ta.T = T;
         ta.trace = static_cast<u8 *>(trace); ta.elem_stride = elem_stride; ta.off_records = off_records;
+        if (args_only) { args_only->ta = ta; args_only->has_trace = true; return H2R_OK; }
         hipStream_t ts = st;
         // LDS share of the record kernel's workgroups (the occupancy lever on this hardware: an LDS request the kernel never
         // touches).  ALONE the 64-bit-limb shapes up to RSA-2048 write fastest with FEW concurrent store streams: one
@@ -629,6 +635,7 @@ namespace {
 int32_t launch_verify_aux(const h2r_ctx *ctx, const void *sig, const void *n, const uint64_t *hashed, uint64_t batch, uint32_t flags,
                           void *trace, const h2r_verify_layout &vl, void *powed_out, uint8_t *is_valid_out, uint8_t *status, hipStream_t st);
 int32_t launch_in_field(const h2r_ctx *ctx, const void *x, const void *n, uint64_t batch, uint32_t flags, void *in_field_trace, hipStream_t st);
+int32_t in_field_args(const h2r_ctx *ctx, const void *x, const void *n, uint64_t batch, uint32_t flags, void *in_field_trace, AuxArgs *aa, u32 *lds);
 }
 
 namespace {
@@ -766,6 +773,15 @@ struct h2r_pipeline {
     hipStream_t done_stream[MAX_DEPTH];
     u32 k;            // calls issued
     u32 joined;       // calls whose record kernel the user stream has been ordered after
+    // One-launch steps (step_kernel): the records of the last sub-batch issued are written by the NEXT launch, together
+    // with that launch's chains, or alone at the join.
+    bool pending = false;
+    TraceArgs pending_ta;
+    bool pending_has_aux = false;      // that call's assert_in_field witness goes out with its records
+    AuxArgs pending_aa;
+    u32 pending_aux_lds = 0;
+    hipStream_t pending_st = nullptr;
+    hipEvent_t flush_done = nullptr;   // orders another stream behind a flush
 };
 
 // ---- placement-aware trace arena ---------------------------------------------------------------------------------------
@@ -936,6 +952,55 @@ void h2r_arena_destroy(h2r_arena *a) {
     delete a;
 }
 
+namespace {
+// Which calls are issued as one-launch steps: the shape both roles of step_kernel are built for (RSA-2048: 64-bit limbs,
+// 32 limbs -- 64-digit chains on four waves, record workgroups of 256 threads), at batches the throughput chain build serves.
+// Measured against the two-queue form on the same boxes (bench.py, H2R_PIPE_STEP=0|1): 1,024 per call +1..5 %, 2,048 per call
+// +0..3 %, one call of 8,192 -4..+1 % -- calls above 4,096 keep the two-queue form.
+bool step_eligible(const h2r_ctx *c, u64 batch, const void *trace, u32 T) {
+    return knobs().pipe_step != 0 && knobs().chain_nw == 0 && c->layout.limb_width == 64 && c->L == 32 && c->K == 64 &&
+           batch > 512 && batch <= 4096 && trace && T;
+}
+// One step: the records described by `ta` (an earlier sub-batch) and the chains described by `ca`, one launch on `st`.
+hipError_t launch_step(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
+    constexpr int IPB = TraceGeo<32>::IPB;
+    const u64 rec_blocks = (ta.n_items + IPB - 1) / IPB;
+    u32 n_chain = (u32)std::min<u64>(ca.batch, 4ull * c->num_cus);   // four chain workgroups per CU, like next to a record kernel
+    n_chain = (n_chain + 7) & ~7u;                                     // keeps blockIdx % 8 (the XCD) of the record role's workgroups
+    AuxArgs none;
+    std::memset(&none, 0, sizeof none);
+    const u64 n_aux = aa ? aa->batch : 0;
+    hipExtLaunchKernelGGL((step_kernel<64, 4, 64, 32>), dim3((unsigned)(n_chain + rec_blocks + n_aux)), dim3(256), 0, st, ea, eb, 0,
+                          ca, ta, aa ? *aa : none, n_chain, (u32)rec_blocks);
+    return hipGetLastError();
+}
+hipError_t launch_aux(const h2r_ctx *c, const AuxArgs &aa, u32 lds, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
+    if (c->layout.limb_width == 64) hipExtLaunchKernelGGL((aux_kernel<64>), dim3((unsigned)aa.batch), dim3(64), lds, st, ea, eb, 0, aa);
+    else hipExtLaunchKernelGGL((aux_kernel<32>), dim3((unsigned)aa.batch), dim3(64), lds, st, ea, eb, 0, aa);
+    return hipGetLastError();
+}
+// The pending records alone (the end of a train of steps, or a call that cannot be issued as a step); `st` is ordered behind them.
+int32_t pipeline_flush(h2r_pipeline *p, hipStream_t st) {
+    if (!p->pending) return H2R_OK;
+    TraceArgs ta = p->pending_ta;
+    ta.residency = 1; ta.dyn_lds = 0;   // the record kernel's stand-alone launch shape
+    {
+        ProfScope ps(H2R_KERNEL_TRACE, p->pending_st, true);
+        HIP_TRY(launch_trace(p->ctx, ta, p->pending_st, ps.a, ps.b));
+    }
+    if (p->pending_has_aux) {
+        ProfScope ps(H2R_KERNEL_AUX, p->pending_st, true);
+        HIP_TRY(launch_aux(p->ctx, p->pending_aa, p->pending_aux_lds, p->pending_st, ps.a, ps.b));
+    }
+    p->pending = false; p->pending_has_aux = false;
+    if (st != p->pending_st) {
+        HIP_TRY(hipEventRecord(p->flush_done, p->pending_st));
+        HIP_TRY(hipStreamWaitEvent(st, p->flush_done, 0));
+    }
+    return H2R_OK;
+}
+}  // namespace
+
 int32_t h2r_pipeline_create(const h2r_ctx *ctx, h2r_pipeline **out) { return h2r_pipeline_create_ex(ctx, 2, 1, out); }
 
 int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side_streams, h2r_pipeline **out) {
@@ -974,6 +1039,7 @@ int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side
         ok = hip_ok(hipEventCreate(&p->chain_done[i]), "hipEventCreate") &&
              hip_ok(hipEventCreate(&p->trace_done[i]), "hipEventCreate");
     for (int i = 0; ok && i < 2; ++i) ok = hip_ok(hipEventCreate(&p->sub_done[i]), "hipEventCreate");
+    if (ok) ok = hip_ok(hipEventCreateWithFlags(&p->flush_done, hipEventDisableTiming), "hipEventCreate");
     if (!ok) { h2r_pipeline_destroy(p); return H2R_E_HIP; }
     *out = p;
     return H2R_OK;
@@ -982,6 +1048,8 @@ int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side
 void h2r_pipeline_destroy(h2r_pipeline *p) {
     if (!p) return;
     DeviceGuard dg(p->ctx->params.device);
+    if (p->pending) { (void)pipeline_flush(p, p->pending_st); (void)hipStreamSynchronize(p->pending_st); }   // a caller that did not join
+    if (p->flush_done) (void)hipEventDestroy(p->flush_done);
     for (int i = 0; i < 2; ++i) if (p->aux[i]) (void)hipStreamSynchronize(p->aux[i]);
     for (int i = 0; i < h2r_pipeline::MAX_DEPTH; ++i) {
         if (p->chain_done[i]) (void)hipEventDestroy(p->chain_done[i]);
@@ -1026,6 +1094,11 @@ int32_t h2r_pipeline_call_plan(const h2r_ctx *ctx, uint64_t batch, uint32_t pipe
 
 int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream) {
     if (!p) return H2R_E_NULL;
+    if (p->pending) {
+        H2R_ON_DEVICE(p->ctx->params.device);
+        const int32_t rf = pipeline_flush(p, static_cast<hipStream_t>(stream));
+        if (rf) return rf;
+    }
     for (; p->joined < p->k; ++p->joined) {
         const int32_t rc = pipeline_wait_slot(p, p->joined % p->depth, static_cast<hipStream_t>(stream));
         if (rc) return rc;
@@ -1036,6 +1109,7 @@ int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream) {
 namespace {
 // Is the record kernel of the previous pipelined call still queued or running?
 bool pipeline_busy(h2r_pipeline *p) {
+    if (p->pending) return true;
     if (p->k == 0) return false;
     const DoneRef &d = p->done[(p->k - 1) % p->depth];
     if (!d.ev) return false;
@@ -1097,7 +1171,9 @@ void pipeline_plan(h2r_pipeline *p, u64 batch, bool assume_empty, std::vector<u6
 int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch,
                        uint32_t flags, void *trace, const h2r_pow_layout &pl, uint64_t elem_stride, void *out,
                        uint8_t *status, void *workspace, hipStream_t st, const std::function<int32_t()> &after_chain,
-                       u32 check_in_field = 1, bool assume_empty = false) {
+                       u32 check_in_field = 1, bool assume_empty = false, const AuxArgs *witness_aux = nullptr, u32 witness_aux_lds = 0) {
+    // witness_aux (nullable): what `after_chain` would launch, when that is a kernel whose output belongs to the call's
+    // TRACE (the assert_in_field witness): a call issued as one-launch steps writes it together with its records
     const h2r_ctx *ctx = p->ctx;
     ExpBits eb; u32 T;
     int32_t rc = exp_to_bits(e_le, e_len, &eb, &T);
@@ -1113,12 +1189,58 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
     // The sub-batches are slices of the caller's buffers and of the whole call's workspace plan ([batch*T][4][L],
     // element-major), so audits and emitters see one call.
     std::vector<u64> sizes; bool pace = false;
-    pipeline_plan(p, batch, assume_empty, sizes, pace);
+    const bool as_steps = step_eligible(ctx, batch, trace, T);
+    if (p->pending && (!as_steps || p->pending_st != st)) {   // the records still owed go out alone, `st` behind them
+        rc = pipeline_flush(p, st);
+        if (rc) return rc;
+    }
+    if (as_steps) {
+        // every sub-batch is one launch: its chains together with the records of the sub-batch before it (of this call or of
+        // the previous one).  With records pending the call is not split; a call that starts a train is, so that its first,
+        // exposed chain kernel is short (the sizes an empty pipeline gets)
+        if (p->pending) sizes.push_back(batch); else call_plan(ctx, batch, false, sizes, pace);
+    } else {
+        pipeline_plan(p, batch, assume_empty, sizes, pace);
+    }
     const bool split = sizes.size() > 1;
     const h2r_layout &lo = ctx->layout;
     const Workspace wp = workspace_plan(lo.limb_bytes, ctx->L, batch, T ? T : 1);
     u8 *ws = reinterpret_cast<u8 *>(round_up(reinterpret_cast<u64>(workspace), 256));
     const u64 in_bytes = (u64)ctx->K * 4, ws_elem = (u64)(T ? T : 1) * 4 * ctx->L * lo.limb_bytes;
+    if (as_steps) {
+        u64 off = 0;
+        for (size_t i = 0; i < sizes.size(); off += sizes[i], ++i) {
+            const u64 nb = sizes[i];
+            const u8 *xs = static_cast<const u8 *>(x) + off * in_bytes;
+            const u8 *ns = static_cast<const u8 *>(n) + ((flags & H2R_F_SHARED_MODULUS) ? 0 : off * in_bytes);
+            PathArgs pa;
+            rc = run_path(ctx, CHAIN_POW_FIXED, xs, nullptr, ns, nullptr, 0, 0, &eb, check_in_field, nb, flags, T,
+                          static_cast<u8 *>(trace) + off * elem_stride, elem_stride, pl.off_records, &pl,
+                          out ? static_cast<u8 *>(out) + off * in_bytes : nullptr, status + off, split ? ws + off * ws_elem : workspace,
+                          st, p->aux[0], nullptr, nullptr, nullptr, split ? ws + wp.off_pre : nullptr, &pa);
+            if (rc) return rc;
+            if (!pa.has_trace) return H2R_E_SHAPE;
+            if (p->pending) {
+                ProfScope ps(H2R_KERNEL_STEP, st, true);
+                HIP_TRY(launch_step(ctx, pa.ca, p->pending_ta, p->pending_has_aux ? &p->pending_aa : nullptr, st, ps.a, ps.b));
+            } else {
+                ProfScope ps(H2R_KERNEL_CHAIN, st, true);
+                HIP_TRY(launch_chain(ctx, pa.ca, false, st, ps.a, ps.b));
+            }
+            p->pending = true; p->pending_ta = pa.ta; p->pending_st = st; p->pending_has_aux = false;
+        }
+        p->done_stream[slot] = st;
+        p->k += 1;
+        const bool aux_as_role = witness_aux && witness_aux->batch && witness_aux_lds <= sizeof(StepShared<64, 4, 64, 32>);
+        if (aux_as_role) { p->pending_has_aux = true; p->pending_aa = *witness_aux; p->pending_aux_lds = witness_aux_lds; }
+        else rc = after_chain();
+        if (rc) return rc;
+        for (; p->joined + p->depth <= p->k; ++p->joined) {   // calls issued the two-queue way earlier on
+            rc = pipeline_wait_slot(p, p->joined % p->depth, st);
+            if (rc) return rc;
+        }
+        return H2R_OK;
+    }
     DoneRef prev{};   // the record kernel of the sub-batch before the current one
     u64 o = 0;
     for (size_t i = 0; i < sizes.size(); o += sizes[i], ++i) {
@@ -1202,19 +1324,24 @@ int32_t launch_verify_aux(const h2r_ctx *ctx, const void *sig, const void *n, co
 }
 
 // The assert_in_field(x, n) witness alone (src/chip.rs:106), one element every h2r_fresh_op_layout(IS_IN_FIELD) stride.
-int32_t launch_in_field(const h2r_ctx *ctx, const void *x, const void *n, uint64_t batch, uint32_t flags, void *in_field_trace, hipStream_t st) {
-    if (batch == 0) return H2R_OK;
+int32_t in_field_args(const h2r_ctx *ctx, const void *x, const void *n, uint64_t batch, uint32_t flags, void *in_field_trace, AuxArgs *aa, u32 *lds) {
     u64 es = 0;
     const int32_t rc = h2r_fresh_op_layout(ctx, FRESH_IS_IN_FIELD, &es, nullptr, nullptr);
     if (rc) return rc;
-    H2R_ON_DEVICE(ctx->params.device);
-    AuxArgs aa;
-    std::memset(&aa, 0, sizeof aa);
-    aa.x = x; aa.n = n; aa.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
-    aa.batch = batch; aa.L = ctx->L;
-    aa.trace = static_cast<u8 *>(in_field_trace); aa.elem_stride = es; aa.off_in_field = 0;
+    std::memset(aa, 0, sizeof *aa);
+    aa->x = x; aa->n = n; aa->n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
+    aa->batch = batch; aa->L = ctx->L;
+    aa->trace = static_cast<u8 *>(in_field_trace); aa->elem_stride = es; aa->off_in_field = 0;
     const AuxGeom ag(ctx->L, ctx->layout.limb_width);
-    const unsigned lds = (unsigned)(ag.in_field_sz() + ag.em_sz());
+    *lds = (u32)(ag.in_field_sz() + ag.em_sz());
+    return H2R_OK;
+}
+int32_t launch_in_field(const h2r_ctx *ctx, const void *x, const void *n, uint64_t batch, uint32_t flags, void *in_field_trace, hipStream_t st) {
+    if (batch == 0) return H2R_OK;
+    AuxArgs aa; u32 lds = 0;
+    const int32_t rc = in_field_args(ctx, x, n, batch, flags, in_field_trace, &aa, &lds);
+    if (rc) return rc;
+    H2R_ON_DEVICE(ctx->params.device);
     ProfScope ps(H2R_KERNEL_AUX, st, true);
     if (ctx->layout.limb_width == 64) hipExtLaunchKernelGGL((aux_kernel<64>), dim3((unsigned)batch), dim3(64), lds, st, ps.a, ps.b, 0, aa);
     else hipExtLaunchKernelGGL((aux_kernel<32>), dim3((unsigned)batch), dim3(64), lds, st, ps.a, ps.b, 0, aa);
@@ -1231,12 +1358,15 @@ int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const voi
     const int32_t rc = h2r_pow_fixed_layout(p->ctx, e_le, e_len, &pl);
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // the in-field witness needs only x and n: its kernel runs on the caller's stream right behind the chain kernel
+    // the in-field witness needs only x and n: its kernel runs on the caller's stream right behind the chain kernel -- or,
+    // when the call is issued as one-launch steps, as a role of the launch that writes the call's records
+    AuxArgs aa; u32 aux_lds = 0;
+    const bool have_aux = in_field_trace && batch && in_field_args(p->ctx, x, n, batch, flags, in_field_trace, &aa, &aux_lds) == H2R_OK;
     return pipeline_issue(p, x, n, e_le, e_len, batch, flags, trace, pl, pl.elem_stride, out, status, workspace, st,
                           [&]() -> int32_t {
                               if (!in_field_trace) return H2R_OK;
                               return launch_in_field(p->ctx, x, n, batch, flags, in_field_trace, st);
-                          });
+                          }, 1, false, have_aux ? &aa : nullptr, aux_lds);
 }
 
 int32_t h2r_pipeline_verify_pkcs1v15(h2r_pipeline *p, const void *sig, const void *n, const uint8_t *e_le, size_t e_len,
@@ -1905,3 +2035,71 @@ const char *h2r_status_str(int32_t s) {
 const char *h2r_last_hip_error(void) { return g_hip_err; }
 
 }  // extern "C"
+
+
+#ifdef H2R_EXP_FUSED
+// EXPERIMENT (developer build only; tools/fused_probe.py): the steady-state period of a pipeline step issued as ONE launch.
+// RSA-2048 shape only (64-bit limbs, 32 limbs).  The same call is repeated `iters` times: the chain role recomputes the
+// batch into workspace B while the record role rewrites the trace from workspace A (filled by a normal call first), so
+// every launch does a step's full work and the results stay valid.
+//   mode 0: fused launches back to back on `stream`;  mode 1: [chain kernel, record kernel] pairs on `stream` (serial);
+//   mode 2: record kernel alone;  mode 3: chain kernel alone.
+extern "C" int32_t h2r_exp_fused_period(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch,
+                                        void *trace, void *out, uint8_t *status, void *ws_a, void *ws_b, uint32_t iters, uint32_t mode,
+                                        uint32_t dyn_lds, h2r_stream_t stream, double *ms_per_iter) {
+    if (!ctx || !trace || !ws_a || !ws_b || !ms_per_iter) return H2R_E_NULL;
+    if (ctx->layout.limb_width != 64 || ctx->L != 32) return H2R_E_UNSUPPORTED;
+    H2R_ON_DEVICE(ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    h2r_pow_layout pl;
+    int32_t rc = h2r_pow_fixed_layout(ctx, e_le, e_len, &pl);
+    if (rc) return rc;
+    ExpBits eb; u32 T;
+    rc = exp_to_bits(e_le, e_len, &eb, &T);
+    if (rc) return rc;
+    auto path = [&](void *ws) {
+        return run_path(ctx, CHAIN_POW_FIXED, x, nullptr, n, nullptr, 0, 0, &eb, 1, batch, 0, T, trace, pl.elem_stride, pl.off_records, &pl,
+                        out, status, ws, st);
+    };
+    rc = path(ws_a);   // a normal call: workspace A and the trace are valid from here on
+    if (rc) return rc;
+    PathArgs cap_a, cap_b;
+    auto args_of = [&](void *ws, PathArgs *pa) {
+        return run_path(ctx, CHAIN_POW_FIXED, x, nullptr, n, nullptr, 0, 0, &eb, 1, batch, 0, T, trace, pl.elem_stride, pl.off_records, &pl,
+                        out, status, ws, st, nullptr, nullptr, nullptr, nullptr, nullptr, pa);
+    };
+    rc = args_of(ws_a, &cap_a);
+    if (rc) return rc;
+    rc = args_of(ws_b, &cap_b);
+    if (rc) return rc;
+    const ChainArgs ca = cap_b.ca;
+    TraceArgs ta = cap_a.ta;
+    constexpr int IPB = TraceGeo<32>::IPB;
+    const u32 rec_blocks = (u32)((ta.n_items + IPB - 1) / IPB);
+    u32 n_chain = (u32)std::min<u64>(batch, 4ull * ctx->num_cus);
+    n_chain = (n_chain + 7) & ~7u;
+    if (dyn_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<64, 4, 64, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    auto one = [&]() -> hipError_t {
+        if (mode == 0) {
+            AuxArgs none; std::memset(&none, 0, sizeof none);
+            hipLaunchKernelGGL((step_kernel<64, 4, 64, 32>), dim3(n_chain + rec_blocks), dim3(256), dyn_lds, st, ca, ta, none, n_chain, rec_blocks);
+            return hipGetLastError();
+        }
+        if (mode == 1 || mode == 3) { const hipError_t e = launch_chain(ctx, ca, false, st); if (e != hipSuccess) return e; }
+        if (mode == 1 || mode == 2) { TraceArgs t2 = ta; t2.residency = 1; const hipError_t e = launch_trace(ctx, t2, st); if (e != hipSuccess) return e; }
+        return hipSuccess;
+    };
+    for (int w = 0; w < 3; ++w) HIP_TRY(one());
+    HIP_TRY(hipEventRecord(e0, st));
+    for (u32 i = 0; i < iters; ++i) HIP_TRY(one());
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_iter = (double)ms / (iters ? iters : 1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return H2R_OK;
+}
+#endif

@@ -1059,8 +1059,16 @@ struct TraceGeo {
 };
 
 // BT = threads per workgroup (a multiple of the padded thread group of an item, at most 256)
+// The LDS of one workgroup of the record kernel
 template <int LW, int L, int BT = TraceGeo<L>::BT>
-__global__ __launch_bounds__(BT) void trace_kernel(TraceArgs args) {
+struct TraceShared {
+    static constexpr int IPB = TraceGeo<L>::TPI >= BT ? 1 : BT / TraceGeo<L>::TPI;   // items per block
+    TraceLds<LW, L> lds_all[IPB];
+    u64 xg[4], xp[4], xbad[4];  // per-wave carry masks for multi-wave items
+};
+// The work of workgroup `block` of `n_blocks` (the kernel below; also callable as one role of a larger launch)
+template <int LW, int L, int BT = TraceGeo<L>::BT>
+__device__ __forceinline__ void trace_block(const TraceArgs &args, const u32 block, const u32 n_blocks, TraceShared<LW, L, BT> &sh) {
     using limb_t = typename LimbT<LW>::type;
     using W = Wide<LW>;
     constexpr int TPI = TraceGeo<L>::TPI;        // threads per item (>= 2L)
@@ -1069,8 +1077,8 @@ __global__ __launch_bounds__(BT) void trace_kernel(TraceArgs args) {
     constexpr int C = 2 * L - 1;
     constexpr int WPI = TPI / 64 > 0 ? TPI / 64 : 1;  // waves per item (when TPI >= 64)
     constexpr bool POW2 = (L & (L - 1)) == 0;
-    __shared__ TraceLds<LW, L> lds_all[IPB];
-    __shared__ u64 xg[4], xp[4], xbad[4];  // per-wave carry masks for multi-wave items
+    TraceLds<LW, L> (&lds_all)[IPB] = sh.lds_all;
+    u64 (&xg)[4] = sh.xg; u64 (&xp)[4] = sh.xp; u64 (&xbad)[4] = sh.xbad;
 
     if (args.prio) __builtin_amdgcn_s_setprio(3);  // co-scheduled with chain_kernel: keep the store stream fed
     const int tid = threadIdx.x;
@@ -1078,7 +1086,7 @@ __global__ __launch_bounds__(BT) void trace_kernel(TraceArgs args) {
     const int h = t / L, i = t % L;
     const int lane = tid & 63, wave = tid >> 6;
     TraceLds<LW, L> &s = lds_all[slot];
-    const u32 bid = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const u32 bid = xcd_contiguous_block(block, n_blocks);
     const u32 item = bid * IPB + slot;  // n_items < 2^32 (checked by the host)
     const bool in_range = item < args.n_items;
     const u32 elem32 = in_range ? item / args.T : 0;
@@ -1318,6 +1326,12 @@ __global__ __launch_bounds__(BT) void trace_kernel(TraceArgs args) {
     }
 }
 
+template <int LW, int L, int BT = TraceGeo<L>::BT>
+__global__ __launch_bounds__(BT) void trace_kernel(TraceArgs args) {
+    __shared__ TraceShared<LW, L, BT> sh;
+    trace_block<LW, L, BT>(args, blockIdx.x, gridDim.x, sh);
+}
+
 // ================================================================================================
 // K6: auxiliary witness of RSAChip::verify_pkcs1v15_signature around the pow path
 //   (a) BigIntChip::assert_in_field(x, n)  src/chip.rs:106 -> big_integer/chip.rs:1150 -> 998 -> 908-919:
@@ -1507,11 +1521,9 @@ __device__ __forceinline__ bool aux_less_than(u8 *&sec, const AuxGeom &g, const 
 }
 
 template <int LW>
-__global__ __launch_bounds__(64) void aux_kernel(AuxArgs a) {
+__device__ __forceinline__ void aux_wave(const AuxArgs &a, const u64 elem, const int lane, uint4 *aux_stage) {
     using X = AuxW<LW>;
     using limb_t = typename LimbT<LW>::type;
-    const int lane = threadIdx.x;
-    const u64 elem = blockIdx.x;
     const u32 L = a.L;
     const AuxGeom g(L, LW);
     u64 Xv[AUX_V], Nv[AUX_V];
@@ -1524,7 +1536,6 @@ __global__ __launch_bounds__(64) void aux_kernel(AuxArgs a) {
     u8 *et = a.trace + elem * a.elem_stride;
     // Both regions are assembled in LDS and leave as 16-byte streaming stores: written in place, their 4/8-byte stores
     // at an 80-byte stride slowed a co-running record kernel by 8 % (pipelined verify 0.255 vs 0.237 ms/step).
-    extern __shared__ uint4 aux_stage[];
     const u32 if_u4 = (u32)(g.in_field_sz() / 16), em_u4 = (u32)(g.em_sz() / 16);
     for (u32 k = lane; k < if_u4 + em_u4; k += 64) aux_stage[k] = make_uint4(0, 0, 0, 0);
     wave_sync();
@@ -1576,6 +1587,47 @@ __global__ __launch_bounds__(64) void aux_kernel(AuxArgs a) {
     if (LW == 64 && a.hashed != nullptr)
         for (u32 k = lane; k < em_u4; k += 64) { const uint4 v = aux_stage[if_u4 + k]; st16(et + a.off_em + 16ull * k, ((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z); }
 }
+// one wave per element; dynamic LDS: AuxGeom::in_field_sz() + em_sz() bytes
+template <int LW>
+__global__ __launch_bounds__(64) void aux_kernel(AuxArgs a) {
+    extern __shared__ uint4 aux_stage_dyn[];
+    aux_wave<LW>(a, blockIdx.x, threadIdx.x, aux_stage_dyn);
+}
+
+// ONE launch per pipeline step, three roles: workgroups [0, n_chain) run the chains of call k+1 (each walks elements b,
+// b + n_chain, ...), the next n_rec write the records of call k, the last n_aux (one wave each) write call k's
+// assert_in_field witness.  Consecutive steps then sit on ONE queue, 5 us apart, instead of on two queues with a barrier
+// packet in front of every record kernel -- and the record role keeps the store rate the record kernel has ALONE: chain
+// workgroups are dispatched first (lowest indices) and take their four slots per CU, record workgroups fill what is left
+// (80 VGPRs => six 4-wave workgroups per CU) and every slot a finished chain frees.
+// Measured (tools/fused_probe.py, 1,024 RSA-2048 signatures): 0.181 ms per step against 0.208-0.218 ms on two queues.
+// The roles share one workgroup size; their LDS is overlaid.
+template <int K, int NW, int LW, int L>
+union StepShared {
+    ChainLds<K, NW> chain; TraceShared<LW, L> trace; uint4 aux[sizeof(TraceShared<LW, L>) / 16];
+    __device__ StepShared() {}
+};
+template <int K, int NW, int LW, int L>
+__global__ __launch_bounds__(64 * NW, H2R_CHAIN_MINB) void step_kernel(ChainArgs ca, TraceArgs ta, AuxArgs aa, u32 n_chain, u32 n_rec) {
+    static_assert(TraceGeo<L>::BT == 64 * NW, "the roles use the same workgroup size");
+    __shared__ StepShared<K, NW, LW, L> sh;
+    const u32 b = blockIdx.x;
+    if (b < n_chain) {
+        for (u64 elem = b; elem < ca.batch; elem += n_chain) {
+            if (elem != b) __syncthreads();   // every wave is done with the previous element's LDS
+            chain_element<K, NW, false>(ca, sh.chain, elem);
+        }
+    } else if (b < n_chain + n_rec) {
+        // (a record role of a few workgroups per CU that WALK the records was tried: inlined into a loop the body spills 25
+        //  registers at this launch's 80, as a real call it runs at 4.1 TB/s -- one workgroup per four records it is)
+        trace_block<LW, L>(ta, b - n_chain, n_rec, sh.trace);
+    } else if (threadIdx.x < 64 && b - n_chain - n_rec < aa.batch) {
+        // last in dispatch order: these short workgroups fill the slots the record role's tail leaves (in front of the record
+        // role they cost the step 3-5 us)
+        aux_wave<LW>(aa, b - n_chain - n_rec, (int)threadIdx.x, sh.aux);
+    }
+}
+
 
 // The Fresh-integer family of BigIntInstructions as one batch op: one wave per element,
 // flat stream written section by section like aux_kernel.

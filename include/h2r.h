@@ -480,7 +480,8 @@ int32_t h2r_pow_trace_check(const h2r_ctx *ctx, const h2r_pow_layout *pl, const 
  * h2r_profile_enable(capacity) arms process-wide recording of up to `capacity` launches (0 disarms
  * and frees the events).  h2r_profile_read() synchronises the recorded events of one kernel class
  * and returns their durations in milliseconds, in launch order. */
-enum { H2R_KERNEL_CHAIN = 0, H2R_KERNEL_TRACE = 1, H2R_KERNEL_HIST = 2, H2R_KERNEL_AUX = 3, H2R_KERNEL_EMIT = 4, H2R_KERNEL_COUNT = 5 };
+enum { H2R_KERNEL_CHAIN = 0, H2R_KERNEL_TRACE = 1, H2R_KERNEL_HIST = 2, H2R_KERNEL_AUX = 3, H2R_KERNEL_EMIT = 4,
+       H2R_KERNEL_STEP = 5 /* a pipeline step as one launch: records of call k + chains of call k+1 */, H2R_KERNEL_COUNT = 6 };
 int32_t h2r_profile_enable(uint32_t capacity);
 int32_t h2r_profile_read(uint32_t kernel, float *ms_out, uint32_t max_count, uint32_t *count);
 
