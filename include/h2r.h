@@ -237,14 +237,18 @@ int32_t h2r_modpow_public_key_var_batch(const h2r_ctx *ctx, const void *x, const
                                         void *out, uint8_t *status, void *workspace, h2r_stream_t stream);
 
 /* ---- pipelined form (opt-in): overlap batch k+1's off-circuit chain with batch k's witness emission
- * A pipeline owns its side HIP stream(s), created at the lowest stream priority so that they get a hardware
- * queue of their own.  h2r_pipeline_modpow_public_key() is h2r_modpow_public_key_batch
- * (the in-field witness kernel runs on `stream` right behind the chain kernel)
- * except that its record-writing kernel runs on the pipeline's stream and `stream` joins it only at
- * the NEXT pipelined call (after that call's chain kernel has been enqueued) or at h2r_pipeline_join().
- * Until then the call's trace must not be read.  Consecutive calls must use distinct trace / out /
- * status / workspace buffers (workspace is mandatory here).  Not thread-safe: one pipeline per
- * producer thread.  The chain's results (`out`, `status`) are stream-ordered on `stream` as usual.
+ * h2r_pipeline_modpow_public_key() is h2r_modpow_public_key_batch except that the call's TRACE (records and in-field
+ * witness) is complete, in `stream` order, only once the NEXT pipelined call has returned or after h2r_pipeline_join();
+ * until then it must not be read.  Consecutive calls must use distinct trace / in_field_trace / out / status / workspace
+ * buffers (workspace is mandatory here).  Not thread-safe: one pipeline per producer thread.  The chain's results
+ * (`out`, `status`) are stream-ordered on `stream` as usual.
+ * How the overlap is obtained depends on the shape:
+ *  - RSA-2048 (64-bit limbs, 32 limbs), 513..4,096 elements per call: ONE launch per call on `stream` (step_kernel) whose
+ *    workgroups run this call's chains, write the PREVIOUS call's records and its in-field witness; the last call's
+ *    records go out alone at the join.  Everything is on the caller's stream, no side stream is involved.
+ *  - every other shape and size: the record-writing kernel runs on a side HIP stream the pipeline owns (created at the
+ *    lowest stream priority so that it gets a hardware queue of its own), behind the call's chain kernel, next to the
+ *    following call's chain kernel; the in-field witness kernel runs on `stream` right behind the chain kernel.
  *
  * h2r_pipeline_create_ex: `depth` (2..4) = buffer sets the caller rotates through -- call k may reuse
  * the buffers of call k - depth, and `stream` is ordered after call k - depth + 1's records when call k
