@@ -906,6 +906,61 @@ def test_pipelined_calls_match_oracle(H):
     pipe.close()
 
 
+def test_pipeline_one_launch_steps(H):
+    """RSA-2048 pipelined calls of 513..4,096 signatures are issued as one launch per call (step_kernel: this call's
+    chains + the previous call's records and in-field witness).  A train of such calls, interrupted by a small call (the
+    two-queue form) and by a change of the caller's stream, leaves byte-for-byte what the plain export writes -- trace,
+    in-field witness, results, status -- and the launches are the expected ones."""
+    from halo2_rsa_amd import _lib
+    chip = H.BigIntChip(64, 2048)
+    pl = chip.pow_fixed_layout(65537)
+    ies = chip.in_field_layout()[0]
+    rng = random.Random(77)
+    sizes = [640, 640, 128, 640, 640, 640]
+    sets = []
+    for k, B in enumerate(sizes):
+        N = [rand_modulus(rng, 2048) for _ in range(B)]
+        X = [rng.randrange(n) for n in N]
+        if k == 1:
+            X[7] = N[7] + 5      # not in field: status, no records for that element, its in-field witness still written
+        mk = lambda nbytes: torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+        sets.append(dict(B=B, N=N, X=X, n=chip.assign_integer(N), x=chip.assign_integer(X),
+                         trace=mk(B * pl.elem_stride), inf=mk(B * ies), ws=mk(chip.workspace_bytes(B, pl.num_mul_mods)),
+                         out=torch.zeros((B, 32), dtype=torch.int64, device="cuda"), status=mk(B),
+                         ref_trace=mk(B * pl.elem_stride), ref_inf=mk(B * ies)))
+    torch.cuda.synchronize()
+    pipe = chip.pipeline()
+    other = torch.cuda.Stream()
+    _lib.profile_enable(64)
+    for k, s in enumerate(sets):
+        if k == 4:
+            other.wait_stream(torch.cuda.current_stream())
+        ctx = torch.cuda.stream(other) if k >= 4 else torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            pipe.modpow_public_key(s["x"], 65537, s["n"], s["trace"], s["ws"], s["out"], s["status"], in_field_buf=s["inf"])
+    with torch.cuda.stream(other):
+        pipe.join()
+    torch.cuda.synchronize()
+    n_step, n_chain, n_rec = (len(_lib.profile_read(k)) for k in (_lib.KERNEL_STEP, _lib.KERNEL_CHAIN, _lib.KERNEL_TRACE))
+    _lib.profile_enable(0)
+    # calls 0,1 | small call 2 | call 3 | stream change | calls 4,5:  steps = (1 carries 0's records) + (5 carries 4's)
+    assert n_step == 2, n_step
+    assert n_chain == 4, n_chain      # calls 0, 2, 3, 4 start with a chain kernel of their own
+    assert n_rec == 4, n_rec          # records of calls 1, 2, 3, 5 written by the record kernel alone
+    for k, s in enumerate(sets):
+        ref = chip.pow_mod_fixed_exp(s["x"], 65537, s["n"], trace_buf=s["ref_trace"], check_in_field=True, in_field_buf=s["ref_inf"])
+        torch.cuda.synchronize()
+        assert torch.equal(ref.status, s["status"]), k
+        assert torch.equal(ref.value.limbs_dev, s["out"]), k
+        assert torch.equal(s["ref_trace"], s["trace"]), k
+        assert torch.equal(s["ref_inf"], s["inf"]), k
+        st = s["status"].cpu().tolist()
+        assert all(v == 0 for i, v in enumerate(st) if not (k == 1 and i == 7))
+        if k == 1:
+            assert st[7] == H.H2R_E_NOT_IN_FIELD
+    pipe.close()
+
+
 @pytest.mark.parametrize("depth,side_streams,toggle_profiler", [(2, 1, False), (2, 2, False), (3, 2, False), (4, 1, False),
                                                               (2, 1, True), (3, 2, True)])
 def test_pipeline_buffer_rotation(H, depth, side_streams, toggle_profiler):
