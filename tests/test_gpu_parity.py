@@ -951,7 +951,8 @@ def test_pipeline_one_launch_steps(H):
         ref = chip.pow_mod_fixed_exp(s["x"], 65537, s["n"], trace_buf=s["ref_trace"], check_in_field=True, in_field_buf=s["ref_inf"])
         torch.cuda.synchronize()
         assert torch.equal(ref.status, s["status"]), k
-        assert torch.equal(ref.value.limbs_dev, s["out"]), k
+        ok = ref.status == 0     # (an element with a status gets no result row: compare the rows that exist)
+        assert torch.equal(ref.value.limbs_dev[ok], s["out"][ok]), k
         assert torch.equal(s["ref_trace"], s["trace"]), k
         assert torch.equal(s["ref_inf"], s["inf"]), k
         st = s["status"].cpu().tolist()
