@@ -958,22 +958,29 @@ namespace {
 // Measured against the two-queue form on the same boxes (bench.py, H2R_PIPE_STEP=0|1): 1,024 per call +1..5 %, 2,048 per call
 // +0..3 %, one call of 8,192 -4..+1 % -- calls above 4,096 keep the two-queue form.
 bool step_eligible(const h2r_ctx *c, u64 batch, const void *trace, u32 T) {
-    return knobs().pipe_step != 0 && knobs().chain_nw == 0 && c->layout.limb_width == 64 && c->L == 32 && c->K == 64 &&
-           batch > 512 && batch <= 4096 && trace && T;
+    const bool shape = c->layout.limb_width == 64 && ((c->L == 32 && c->K == 64) || (c->L == 16 && c->K == 32));   // RSA-2048, RSA-1024
+    return knobs().pipe_step != 0 && knobs().chain_nw == 0 && shape && batch > 512 && batch <= 4096 && trace && T;
 }
 // One step: the records described by `ta` (an earlier sub-batch) and the chains described by `ca`, one launch on `st`.
-hipError_t launch_step(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
-    constexpr int IPB = TraceGeo<32>::IPB;
+extern "C++" {
+template <int K, int L>
+hipError_t launch_step_t(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
+    constexpr int IPB = TraceGeo<L>::IPB;
     const u64 rec_blocks = (ta.n_items + IPB - 1) / IPB;
     u32 n_chain = (u32)std::min<u64>(ca.batch, 4ull * c->num_cus);   // four chain workgroups per CU, like next to a record kernel
     n_chain = (n_chain + 7) & ~7u;                                     // keeps blockIdx % 8 (the XCD) of the record role's workgroups
     AuxArgs none;
     std::memset(&none, 0, sizeof none);
     const u64 n_aux = aa ? aa->batch : 0;
-    hipExtLaunchKernelGGL((step_kernel<64, 4, 64, 32>), dim3((unsigned)(n_chain + rec_blocks + n_aux)), dim3(256), 0, st, ea, eb, 0,
+    hipExtLaunchKernelGGL((step_kernel<K, 4, 64, L>), dim3((unsigned)(n_chain + rec_blocks + n_aux)), dim3(256), 0, st, ea, eb, 0,
                           ca, ta, aa ? *aa : none, n_chain, (u32)rec_blocks);
     return hipGetLastError();
 }
+}  // extern "C++"
+hipError_t launch_step(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
+    return c->L == 32 ? launch_step_t<64, 32>(c, ca, ta, aa, st, ea, eb) : launch_step_t<32, 16>(c, ca, ta, aa, st, ea, eb);
+}
+u32 step_shared_bytes(const h2r_ctx *c) { return c->L == 32 ? (u32)sizeof(StepShared<64, 4, 64, 32>) : (u32)sizeof(StepShared<32, 4, 64, 16>); }
 hipError_t launch_aux(const h2r_ctx *c, const AuxArgs &aa, u32 lds, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
     if (c->layout.limb_width == 64) hipExtLaunchKernelGGL((aux_kernel<64>), dim3((unsigned)aa.batch), dim3(64), lds, st, ea, eb, 0, aa);
     else hipExtLaunchKernelGGL((aux_kernel<32>), dim3((unsigned)aa.batch), dim3(64), lds, st, ea, eb, 0, aa);
@@ -1231,7 +1238,7 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
         }
         p->done_stream[slot] = st;
         p->k += 1;
-        const bool aux_as_role = witness_aux && witness_aux->batch && witness_aux_lds <= sizeof(StepShared<64, 4, 64, 32>);
+        const bool aux_as_role = witness_aux && witness_aux->batch && witness_aux_lds <= step_shared_bytes(ctx);
         if (aux_as_role) { p->pending_has_aux = true; p->pending_aa = *witness_aux; p->pending_aux_lds = witness_aux_lds; }
         else rc = after_chain();
         if (rc) return rc;
