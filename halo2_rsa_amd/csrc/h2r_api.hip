@@ -956,11 +956,12 @@ namespace {
 // Which calls are issued as one-launch steps: the shape both roles of step_kernel are built for (RSA-2048: 64-bit limbs,
 // 32 limbs -- 64-digit chains on four waves, record workgroups of 256 threads), at batches the throughput chain build serves.
 // Measured against the two-queue form on the same boxes (bench.py, H2R_PIPE_STEP=0|1): 1,024 per call +1..5 %, 2,048 per call
-// +0..3 %, one call of 8,192 -4..+1 % -- calls above 4,096 keep the two-queue form.
+// +0..3 %, 8,192 as ONE step launch -4..+1 % -- so a call above 4,096 is walked as several launches of at most 4,096.
 bool step_eligible(const h2r_ctx *c, u64 batch, const void *trace, u32 T) {
     const bool shape = c->layout.limb_width == 64 && ((c->L == 32 && c->K == 64) || (c->L == 16 && c->K == 32));   // RSA-2048, RSA-1024
-    return knobs().pipe_step != 0 && knobs().chain_nw == 0 && shape && batch > 512 && batch <= 4096 && trace && T;
+    return knobs().pipe_step != 0 && knobs().chain_nw == 0 && shape && batch > 512 && trace && T;
 }
+constexpr u64 kStepMax = 4096;   // elements per step launch: a larger call is walked as equal parts of at most this size
 // One step: the records described by `ta` (an earlier sub-batch) and the chains described by `ca`, one launch on `st`.
 extern "C++" {
 template <int K, int L>
@@ -1206,6 +1207,13 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
         // the previous one).  With records pending the call is not split; a call that starts a train is, so that its first,
         // exposed chain kernel is short (the sizes an empty pipeline gets)
         if (p->pending) sizes.push_back(batch); else call_plan(ctx, batch, false, sizes, pace);
+        std::vector<u64> capped;
+        for (u64 sz : sizes) {
+            const u64 parts = (sz + kStepMax - 1) / kStepMax;
+            const u64 each = round_up((sz + parts - 1) / parts, 256);
+            for (u64 o2 = 0; o2 < sz; o2 += each) capped.push_back(std::min(each, sz - o2));
+        }
+        sizes.swap(capped);
     } else {
         pipeline_plan(p, batch, assume_empty, sizes, pace);
     }

@@ -243,7 +243,8 @@ int32_t h2r_modpow_public_key_var_batch(const h2r_ctx *ctx, const void *x, const
  * buffers (workspace is mandatory here).  Not thread-safe: one pipeline per producer thread.  The chain's results
  * (`out`, `status`) are stream-ordered on `stream` as usual.
  * How the overlap is obtained depends on the shape:
- *  - RSA-2048 and RSA-1024 (64-bit limbs, 32 / 16 limbs), 513..4,096 elements per call: ONE launch per call on `stream` (step_kernel) whose
+ *  - RSA-2048 and RSA-1024 (64-bit limbs, 32 / 16 limbs), more than 512 elements per call: ONE launch per call on `stream` (step_kernel; a call above 4,096 elements is
+ *    walked as equal parts of at most 4,096, one launch each) whose
  *    workgroups run this call's chains, write the PREVIOUS call's records and its in-field witness; the last call's
  *    records go out alone at the join.  Everything is on the caller's stream, no side stream is involved.
  *  - every other shape and size: the record-writing kernel runs on a side HIP stream the pipeline owns (created at the
