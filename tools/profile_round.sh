@@ -28,7 +28,7 @@ timeout 300 python bench.py --steps 40 --warmup 4 --verify --no-cpu-baseline > $
 H2R_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --batch 2048 --chunks 4 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_torchrun1_config3_shard.json 2> $O/bench_torchrun1.err
 {
   echo "# other BASELINE configs and shapes, same box (tools/sweep.py lines: step, value = assigns/s, record kernel, chain kernel)"
-  echo "# (pipelined RSA-2048 calls of 513..4,096 signatures are issued as one-launch steps: their trace_ms is the step launch -- records + in-field witness of call k and chains of call k+1 -- and chain_ms the one chain kernel that starts the train)"
+  echo "# (pipelined RSA-2048 and RSA-1024 calls of more than 512 signatures are issued as one-launch steps (parts of at most 4,096): their trace_ms is the step launch -- records + in-field witness of call k and chains of call k+1 -- and chain_ms the one chain kernel that starts the train)"
   python tools/sweep.py CONFIG C3-shard-8192-as-8-calls --chunks 8 --steps 6 --warmup 2
   python tools/sweep.py CONFIG C3-shard-8192-as-4-calls-20-steps --batch 2048 --chunks 4 --steps 20 --warmup 5
   python tools/sweep.py CONFIG C3-shard-8192-as-2-calls-20-steps --batch 4096 --chunks 2 --steps 20 --warmup 5
