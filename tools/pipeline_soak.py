@@ -4,23 +4,24 @@ import os, sys, random, torch, numpy as np
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import halo2_rsa_amd as H
 from halo2_rsa_amd import big_integer as BI
-chip = H.BigIntChip(64, 2048)
-pl = chip.pow_fixed_layout(65537)
 rng = random.Random(99)
-for B, depth, side in ((1024, 2, 1), (3072, 2, 1), (1024, 3, 2)):
-    base = [rng.getrandbits(2048) | (1 << 2047) | 1 for _ in range(64)]
+# (bits, B, depth, side): RSA-2048 / RSA-1024 above 512 per call are one-launch steps (8,192: two launches per call), 384 per call the two-queue form
+for bits, B, depth, side in ((2048, 1024, 2, 1), (2048, 3072, 2, 1), (2048, 1024, 3, 2), (2048, 8192, 2, 1), (2048, 384, 2, 1), (1024, 2048, 2, 1)):
+    chip = H.BigIntChip(64, bits)
+    pl = chip.pow_fixed_layout(65537)
+    base = [rng.getrandbits(bits) | (1 << (bits - 1)) | 1 for _ in range(64)]
     pipe = H.Pipeline(chip, depth=depth, side_streams=side)
     sets = [dict(trace=torch.zeros(B * pl.elem_stride, dtype=torch.uint8, device="cuda"),
                  ws=torch.zeros(chip.workspace_bytes(B, pl.num_mul_mods), dtype=torch.uint8, device="cuda"),
-                 out=torch.zeros((B, 32), dtype=torch.int64, device="cuda"),
+                 out=torch.zeros((B, bits // 64), dtype=torch.int64, device="cuda"),
                  status=torch.zeros(B, dtype=torch.uint8, device="cuda")) for _ in range(depth)]
     variants = []
     for v in range(4):
-        N = [base[(i + v) % 64] ^ ((i // 64 + v) << 200) | 1 for i in range(B)]
+        N = [base[(i + v) % 64] ^ ((i // 64 + v) << (bits // 2 - 64)) | 1 for i in range(B)]
         X = [((base[(i * 5 + v) % 64] >> 3) * (i + 7 + v)) % N[i] for i in range(B)]
         variants.append((N, X, chip.assign_integer(N), chip.assign_integer(X)))
     bad_total, checks = 0, 0
-    CALLS = 240
+    CALLS = 240 if B <= 3072 else 60
     for k in range(CALLS):
         v = variants[k % 4]; s = sets[k % depth]
         pipe.modpow_public_key(v[3], 65537, v[2], s["trace"], s["ws"], s["out"], s["status"])
@@ -34,6 +35,6 @@ for B, depth, side in ((1024, 2, 1), (3072, 2, 1), (1024, 3, 2)):
             got = H.AssignedInteger(ss["out"].clone(), 64).to_big_uint()
             assert all(got[i] == pow(vv[1][i], 65537, vv[0][i]) for i in range(0, B, 37)), (B, k)
     pipe.join(); torch.cuda.synchronize()
-    print("soak B=%d depth=%d streams=%d: %d calls, %d audits, violations %d" % (B, depth, side, CALLS, checks, bad_total))
+    print("soak RSA-%d B=%d depth=%d streams=%d: %d calls, %d audits, violations %d" % (bits, B, depth, side, CALLS, checks, bad_total))
     assert bad_total == 0
     pipe.close()
