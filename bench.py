@@ -127,9 +127,103 @@ def cpu_baseline(w, bits, e, un, ux, target_seconds=8.0):
     return {"value": round(passes * sample / sec, 1), "unit": "assigns/s", "cores": cores, "kind": "port",
             "sample": "%d passes over %d signatures of the same synthetic batch (%.1f s, %d threads, %.0f signatures per "
                       "thread), full op-trace stream written to per-thread buffers" % (passes, sample, sec, cores, passes * sample / cores),
+            "host": host_cpu_info(),
             "single_thread_value": round(one / sec1, 1), "single_thread_sample": "%d signatures, 1 thread" % one,
             # what the host actually delivers: os.cpu_count() threads may share far fewer physical cores / a CPU quota
             "parallel_speedup": round((passes * sample / sec) / (one / sec1), 1)}
+
+
+def host_cpu_info():
+    """What the host can deliver, for reading cpu_baseline: logical CPUs, the CPUs this process may run on, distinct
+    physical cores (/proc/cpuinfo), and the container's CPU quota (cgroup v2 cpu.max, v1 cfs quota)."""
+    info = {"logical_cpus": os.cpu_count()}
+    try:
+        info["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        cores, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("physical id"):
+                    phys = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":")[1].strip()
+                elif not ln.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+        if cores:
+            info["physical_cores"] = len(cores)
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                info["cgroup_" + os.path.basename(path)] = f.read().strip()
+            break
+        except Exception:
+            continue
+    return info
+
+
+def measured_pmc_traffic(argv_workload, kernel_prefix, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel, measured NOW: two rocprofv3 --pmc passes (WRITE_SIZE, FETCH_SIZE: separate
+    runs, counters only with --kernel-trace, as MI355X_MICROARCH.md prescribes) of this very script on a short run of the
+    same workload.  Units: KB per dispatch (calibrated in round 1: a 1024-byte fill reports WRITE_SIZE = 1.0); FETCH_SIZE is
+    doubled (gfx950 reports half of wide coalesced reads).  Returns (bytes, description) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3")
+    if not rp:
+        return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCPROFILER_", "ROCP_TOOL", "ROCPROF_")) for k in os.environ):
+        return None, "already running under a profiler"
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="h2r_pmc_", dir="/tmp")
+    try:
+        for counter in ("WRITE_SIZE", "FETCH_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "r", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+                   "--pmc-traffic", "off", "--placement-candidates", "0"] + argv_workload
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            except Exception as ex:
+                return None, "rocprofv3 --pmc %s pass failed: %s" % (counter, str(ex)[:80])
+            fs = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True))
+            if not fs:
+                return None, "no counter_collection.csv from the %s pass" % counter
+            acc = []
+            with open(fs[0]) as f:
+                for r in csv.DictReader(f):
+                    if r.get("Counter_Name") == counter and ("h2r::" + kernel_prefix) in r.get("Kernel_Name", ""):
+                        acc.append(float(r["Counter_Value"]))
+            if not acc:
+                return None, "no %s dispatches in the %s pass" % (kernel_prefix, counter)
+            vals[counter] = sum(acc) / len(acc)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    hbm = int(round(1024 * (vals["WRITE_SIZE"] + 2 * vals["FETCH_SIZE"])))
+    return hbm, ("measured in this run: rocprofv3 --kernel-trace --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes of bench.py "
+                 "--steps 4, plain allocations), mean per %s dispatch; WRITE_SIZE %.0f KB + 2 x FETCH_SIZE %.0f KB" %
+                 (kernel_prefix, vals["WRITE_SIZE"], vals["FETCH_SIZE"]))
+
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (the driver's
+    own multi-GPU command line does exactly this; WORLD_SIZE is then set and this is skipped)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
 
 
 def ensure_built():
@@ -186,7 +280,12 @@ def main():
                          "at most pipeline-depth + 1 regions are mapped at any time); 0 = plain allocations, taken as they come")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="fully stream-ordered calls (chain then trace per step) instead of the two-stream pipeline")
+    ap.add_argument("--pmc-traffic", choices=["auto", "off"], default="auto",
+                    help="roofline.traffic: auto = measure it now with two rocprofv3 --pmc passes of a short run of the same workload "
+                         "(N = 1, rank 0; falls back to the committed profiles/pmc_traffic.json when rocprofv3 is unavailable); off = committed file only")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args.gpus)
 
     env = DistEnv.from_environment(args.gpus, force=bool(os.environ.get("H2R_FORCE_DIST")))
     w, bits, e = WORKLOADS[args.workload]
@@ -392,6 +491,7 @@ def main():
                        "per_gpu_batch": shard, "global_batch": global_batch, "calls_per_step": chunks, "signatures_per_call": chunk,
                        "path": "verify_pkcs1v15_signature (in-field + modpow + EM check)" if verify else "modpow_public_key",
                        "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world,
+                       "ranks": env.world, "collective_backend": (env.backend + (" (RCCL)" if env.backend == "nccl" else "")) if env.initialised else "none (single process)",
                        "pipeline": (("one launch per step: records of call k + chains of call k+1 (step_kernel), %d buffer sets" % args.pipeline_depth)
                                     if step_ms else
                                     ("chain k+1 || trace k, %d buffer sets, %d record stream(s)" % (args.pipeline_depth, args.side_streams)))
@@ -410,6 +510,16 @@ def main():
                          "chain_kernel_avg_ms": round(sum(chain_ms) / len(chain_ms), 4) if chain_ms else None},
             "whole_path_hbm_frac": round(global_batch * steps / dt * algo_bytes_per_assign / (env.world * HBM_PEAK_GBS * 1e9), 4),
         }
+        if env.world == 1 and args.pmc_traffic == "auto" and dom_ms and per_launch_batch == chunk:
+            wl_args = ["--workload", args.workload, "--batch", str(chunk), "--chunks", str(chunks), "--pipeline-depth", str(args.pipeline_depth)]
+            wl_args += ["--verify"] if args.verify else []
+            wl_args += ["--no-pipeline"] if args.no_pipeline else []
+            hbm, how = measured_pmc_traffic(wl_args, dom_name.split("<")[0])
+            if hbm is not None:
+                line["roofline"]["traffic"] = hbm
+                line["roofline"]["traffic_source"] = how
+            else:
+                line["roofline"]["traffic_source"] += "; live measurement skipped: " + how
         if env.world == 1 and not args.no_cpu_baseline and not args.shared_modulus:
             line["cpu_baseline"] = cpu_baseline(w, bits, e, un, ux)
         print(json.dumps(line))

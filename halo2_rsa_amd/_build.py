@@ -7,7 +7,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SRC = os.path.join(PKG, "csrc", "h2r_api.hip")
 DEPS = [SRC, os.path.join(PKG, "csrc", "h2r_kernels.hpp"), os.path.join(PKG, "csrc", "h2r_layout.hpp"),
-        os.path.join(ROOT, "include", "h2r.h")]
+        os.path.join(ROOT, "include", "h2r.h"), os.path.join(PKG, "csrc", "libh2r.map")]
 LIB = os.path.join(PKG, "lib", "libh2r.so")
 
 
@@ -32,6 +32,7 @@ def build_lib(force=False, verbose=False, out=None, defines=()):
     out = out or LIB
     os.makedirs(os.path.dirname(out), exist_ok=True)
     cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-shared", "-fPIC",
+           "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wl,--version-script=" + os.path.join(PKG, "csrc", "libh2r.map"),
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), "-o", out, SRC]
     cmd += ["-D" + d for d in defines]
     if verbose:

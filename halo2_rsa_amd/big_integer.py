@@ -478,6 +478,12 @@ class BigIntChip:
         flag = torch.zeros(batch, dtype=torch.uint8, device=dev)
         status = torch.zeros(batch, dtype=torch.uint8, device=dev)
         flags = self._flags(n, batch) if n is not None else 0
+        if b is not None and b.batch != batch:
+            # one `b` for the whole batch (the modulus of is_in_field, a shared comparand): only the ops without an `n`
+            if b.batch == 1 and n is None:
+                flags |= _lib.H2R_F_SHARED_MODULUS
+            else:
+                check(_lib.H2R_E_SHAPE, name + ": operand batches differ")
         check(lib().h2r_fresh_op_batch(self._ctx, op, a.data_ptr(), b.data_ptr() if b is not None else None,
                                        n.data_ptr() if n is not None else None, batch, flags, trace.data_ptr(),
                                        value.data_ptr() if value is not None else None, flag.data_ptr(), status.data_ptr(),

@@ -777,9 +777,6 @@ struct h2r_pipeline {
     // with that launch's chains, or alone at the join.
     bool pending = false;
     TraceArgs pending_ta;
-    bool pending_has_aux = false;      // that call's assert_in_field witness goes out with its records
-    AuxArgs pending_aa;
-    u32 pending_aux_lds = 0;
     hipStream_t pending_st = nullptr;
     hipEvent_t flush_done = nullptr;   // orders another stream behind a flush
 };
@@ -791,7 +788,7 @@ struct h2r_pipeline {
 // was not found, so the arena LOOKS: it maps `candidates` regions (HIP virtual-memory API, 256 MB physical chunks), runs the
 // record kernel in the production geometry on each, keeps the `regions` fastest and gives the others back.
 struct h2r_arena {
-    struct Region { void *va = nullptr; u64 mapped = 0; std::vector<hipMemGenericAllocationHandle_t> handles; float ms = 0.f; };
+    struct Region { void *va = nullptr; u64 mapped = 0, chunk = 0, n_mapped = 0; std::vector<hipMemGenericAllocationHandle_t> handles; float ms = 0.f; };
     int device = 0;
     u64 region_bytes = 0;
     std::vector<Region> kept;          // fastest first
@@ -800,10 +797,11 @@ struct h2r_arena {
 
 namespace {
 void arena_free_region(h2r_arena::Region &r) {
-    if (r.va) { (void)hipMemUnmap(r.va, r.mapped); }
+    // chunk k is mapped at va + k * chunk for k < n_mapped (a candidate that failed half-way has fewer than handles.size())
+    for (u64 k = 0; r.va && k < r.n_mapped; ++k) (void)hipMemUnmap(static_cast<u8 *>(r.va) + k * r.chunk, r.chunk);
     for (auto h : r.handles) (void)hipMemRelease(h);
     if (r.va) (void)hipMemAddressFree(r.va, r.mapped);
-    r.va = nullptr; r.handles.clear();
+    r.va = nullptr; r.handles.clear(); r.n_mapped = 0;
 }
 }  // namespace
 
@@ -845,13 +843,14 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
     if (!hip_ok(hipEventCreate(&eb), "hipEventCreate")) { (void)hipEventDestroy(ea); return H2R_E_HIP; }
     // one candidate: reserve, create, map, touch, three launches of the record kernel in the production geometry
     auto make_candidate = [&](h2r_arena::Region &r) -> int32_t {
-        r.mapped = n_chunks * chunk;
+        r.mapped = n_chunks * chunk; r.chunk = chunk; r.n_mapped = 0;
         if (!hip_ok(hipMemAddressReserve(&r.va, r.mapped, 0, nullptr, 0), "hipMemAddressReserve")) { r.va = nullptr; return H2R_E_HIP; }
         for (u64 k = 0; k < n_chunks; ++k) {
             hipMemGenericAllocationHandle_t h;
             if (!hip_ok(hipMemCreate(&h, chunk, &prop, 0), "hipMemCreate")) return H2R_E_HIP;
             r.handles.push_back(h);
             if (!hip_ok(hipMemMap(static_cast<u8 *>(r.va) + k * chunk, chunk, 0, h, 0), "hipMemMap")) return H2R_E_HIP;
+            r.n_mapped = k + 1;
         }
         hipMemAccessDesc acc = {};
         acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
@@ -883,7 +882,10 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
     // handed the very same physical blocks -- up to 64 GB of them; beyond that the oldest are released (so the look also
     // fits traces of tens of GB, with less variety among the candidates).
     std::vector<h2r_arena::Region> rejected;
-    const u64 held_budget = 64ull << 30;
+    u64 held_budget = 64ull << 30;
+    size_t free_at_start = 0, total_at_start = 0;
+    if (hipMemGetInfo(&free_at_start, &total_at_start) == hipSuccess) held_budget = std::min<u64>(held_budget, free_at_start / 2);
+    else (void)hipGetLastError();
     auto keep_best = [&](size_t keep, bool release_all) {   // sorts; everything behind the first `keep` moves to `rejected`
         std::stable_sort(cands.begin(), cands.end(), [](const h2r_arena::Region &x, const h2r_arena::Region &y) { return x.ms < y.ms; });
         for (size_t i = keep; i < cands.size(); ++i) rejected.push_back(std::move(cands[i]));
@@ -919,7 +921,7 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
             void *placeholder = nullptr;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                 const u64 want = (u64)candidates * n_chunks * chunk + (8ull << 30);
-                const u64 ph = free_b > want + (16ull << 30) ? std::min<u64>(96ull << 30, free_b - want) : 0;
+                const u64 ph = free_b > want + (16ull << 30) ? std::min<u64>(std::min<u64>(96ull << 30, free_b / 3), free_b - want) : 0;
                 if (ph && hipMalloc(&placeholder, ph) != hipSuccess) { placeholder = nullptr; (void)hipGetLastError(); }
             }
             run_round();
@@ -982,11 +984,6 @@ hipError_t launch_step(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &t
     return c->L == 32 ? launch_step_t<64, 32>(c, ca, ta, aa, st, ea, eb) : launch_step_t<32, 16>(c, ca, ta, aa, st, ea, eb);
 }
 u32 step_shared_bytes(const h2r_ctx *c) { return c->L == 32 ? (u32)sizeof(StepShared<64, 4, 64, 32>) : (u32)sizeof(StepShared<32, 4, 64, 16>); }
-hipError_t launch_aux(const h2r_ctx *c, const AuxArgs &aa, u32 lds, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
-    if (c->layout.limb_width == 64) hipExtLaunchKernelGGL((aux_kernel<64>), dim3((unsigned)aa.batch), dim3(64), lds, st, ea, eb, 0, aa);
-    else hipExtLaunchKernelGGL((aux_kernel<32>), dim3((unsigned)aa.batch), dim3(64), lds, st, ea, eb, 0, aa);
-    return hipGetLastError();
-}
 // The pending records alone (the end of a train of steps, or a call that cannot be issued as a step); `st` is ordered behind them.
 int32_t pipeline_flush(h2r_pipeline *p, hipStream_t st) {
     if (!p->pending) return H2R_OK;
@@ -996,11 +993,7 @@ int32_t pipeline_flush(h2r_pipeline *p, hipStream_t st) {
         ProfScope ps(H2R_KERNEL_TRACE, p->pending_st, true);
         HIP_TRY(launch_trace(p->ctx, ta, p->pending_st, ps.a, ps.b));
     }
-    if (p->pending_has_aux) {
-        ProfScope ps(H2R_KERNEL_AUX, p->pending_st, true);
-        HIP_TRY(launch_aux(p->ctx, p->pending_aa, p->pending_aux_lds, p->pending_st, ps.a, ps.b));
-    }
-    p->pending = false; p->pending_has_aux = false;
+    p->pending = false;
     if (st != p->pending_st) {
         HIP_TRY(hipEventRecord(p->flush_done, p->pending_st));
         HIP_TRY(hipStreamWaitEvent(st, p->flush_done, 0));
@@ -1056,7 +1049,9 @@ int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side
 void h2r_pipeline_destroy(h2r_pipeline *p) {
     if (!p) return;
     DeviceGuard dg(p->ctx->params.device);
-    if (p->pending) { (void)pipeline_flush(p, p->pending_st); (void)hipStreamSynchronize(p->pending_st); }   // a caller that did not join
+    // a caller that did not join: the records still owed go out on the stream of the last call (which must still exist:
+    // h2r.h asks for h2r_pipeline_join() before a stream with pipelined calls on it is destroyed)
+    if (p->pending) { (void)pipeline_flush(p, p->pending_st); (void)hipStreamSynchronize(p->pending_st); }
     if (p->flush_done) (void)hipEventDestroy(p->flush_done);
     for (int i = 0; i < 2; ++i) if (p->aux[i]) (void)hipStreamSynchronize(p->aux[i]);
     for (int i = 0; i < h2r_pipeline::MAX_DEPTH; ++i) {
@@ -1223,6 +1218,8 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
     u8 *ws = reinterpret_cast<u8 *>(round_up(reinterpret_cast<u64>(workspace), 256));
     const u64 in_bytes = (u64)ctx->K * 4, ws_elem = (u64)(T ? T : 1) * 4 * ctx->L * lo.limb_bytes;
     if (as_steps) {
+        const bool aux_as_role = witness_aux && witness_aux->batch && witness_aux_lds <= step_shared_bytes(ctx);
+        bool aux_done = false;
         u64 off = 0;
         for (size_t i = 0; i < sizes.size(); off += sizes[i], ++i) {
             const u64 nb = sizes[i];
@@ -1236,19 +1233,21 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
             if (rc) return rc;
             if (!pa.has_trace) return H2R_E_SHAPE;
             if (p->pending) {
+                // THIS call's assert_in_field witness rides on the first step launch the call issues: it needs only x and n,
+                // which are therefore read in `stream` order inside the call, like every other input
+                const bool with_aux = aux_as_role && !aux_done;
                 ProfScope ps(H2R_KERNEL_STEP, st, true);
-                HIP_TRY(launch_step(ctx, pa.ca, p->pending_ta, p->pending_has_aux ? &p->pending_aa : nullptr, st, ps.a, ps.b));
+                HIP_TRY(launch_step(ctx, pa.ca, p->pending_ta, with_aux ? witness_aux : nullptr, st, ps.a, ps.b));
+                aux_done = aux_done || with_aux;
             } else {
                 ProfScope ps(H2R_KERNEL_CHAIN, st, true);
                 HIP_TRY(launch_chain(ctx, pa.ca, false, st, ps.a, ps.b));
             }
-            p->pending = true; p->pending_ta = pa.ta; p->pending_st = st; p->pending_has_aux = false;
+            p->pending = true; p->pending_ta = pa.ta; p->pending_st = st;
         }
         p->done_stream[slot] = st;
         p->k += 1;
-        const bool aux_as_role = witness_aux && witness_aux->batch && witness_aux_lds <= step_shared_bytes(ctx);
-        if (aux_as_role) { p->pending_has_aux = true; p->pending_aa = *witness_aux; p->pending_aux_lds = witness_aux_lds; }
-        else rc = after_chain();
+        if (!aux_done) rc = after_chain();   // (a call that starts a train as one chain kernel: the in-field kernel behind it)
         if (rc) return rc;
         for (; p->joined + p->depth <= p->k; ++p->joined) {   // calls issued the two-queue way earlier on
             rc = pipeline_wait_slot(p, p->joined % p->depth, st);
@@ -1427,6 +1426,8 @@ int32_t h2r_fresh_op_batch(const h2r_ctx *ctx, uint32_t op, const void *a, const
     FreshArgs fa;
     std::memset(&fa, 0, sizeof fa);
     fa.a = a; fa.b = b; fa.n = n; fa.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
+    // the ops without an `n` (comparisons, is_in_field(a, b = modulus)): the flag says that `b` is one integer shared by the batch
+    fa.b_stride = (!needs_n && (flags & H2R_F_SHARED_MODULUS)) ? 0 : ctx->L;
     fa.batch = batch; fa.L = ctx->L; fa.op = op; fa.trace = static_cast<u8 *>(trace); fa.elem_stride = es;
     fa.value_out = value_out; fa.value_limbs = vl; fa.flag_out = flag_out; fa.status = status;
     H2R_ON_DEVICE(ctx->params.device);
@@ -1727,7 +1728,7 @@ int32_t h2r_trace_emit_stream(const h2r_ctx *ctx, const void *trace, uint64_t nu
                               uint64_t out_stride, uint64_t out_off, h2r_stream_t stream) {
     if (!ctx || !trace || !stream_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
-    if (out_stride < h2r_stream_bytes(ctx, flags)) return H2R_E_SHAPE;
+    if (out_stride < out_off + h2r_stream_bytes(ctx, flags)) return H2R_E_SHAPE;
     EmitArgs ea;
     std::memset(&ea, 0, sizeof ea);
     ea.trace = static_cast<const u8 *>(trace); ea.elem_stride = ctx->layout.record_stride; ea.off_records = 0; ea.T = 1;

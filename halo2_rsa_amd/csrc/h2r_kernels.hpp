@@ -1635,7 +1635,7 @@ enum { FRESH_ADD = 0, FRESH_SUB, FRESH_ADD_MOD, FRESH_SUB_MOD, FRESH_IS_ZERO, FR
        FRESH_IS_LESS_THAN_OR_EQUAL, FRESH_IS_GREATER_THAN, FRESH_IS_GREATER_THAN_OR_EQUAL, FRESH_IS_IN_FIELD, FRESH_OP_COUNT };
 
 struct FreshArgs {
-    const void *a, *b, *n; u64 n_stride;
+    const void *a, *b, *n; u64 n_stride, b_stride;   // b_stride = 0: one b for every element (the modulus of is_in_field)
     u64 batch; u32 L, op;
     u8 *trace; u64 elem_stride;
     void *value_out; u32 value_limbs;   // [elem][value_limbs] (nullable)
@@ -1656,7 +1656,7 @@ __global__ __launch_bounds__(64) void fresh_kernel(FreshArgs f) {
     for (int m = 0; m < AUX_V; ++m) {
         const u32 p = lane + 64 * m;
         A[m] = p < L ? (u64) reinterpret_cast<const limb_t *>(f.a)[elem * L + p] : 0;
-        B[m] = (f.b && p < L) ? (u64) reinterpret_cast<const limb_t *>(f.b)[elem * L + p] : 0;
+        B[m] = (f.b && p < L) ? (u64) reinterpret_cast<const limb_t *>(f.b)[elem * f.b_stride + p] : 0;
         N[m] = (f.n && p < L) ? (u64) reinterpret_cast<const limb_t *>(f.n)[elem * f.n_stride + p] : 0;
         OUT[m] = 0;
     }

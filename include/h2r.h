@@ -40,8 +40,13 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libh2r.so is built with -fvisibility=hidden: exactly the prototypes of this header are exported (tests/test_cabi_host.py
+ * asserts it), so that a Rust cdylib / C++ host linking the library never meets an un-prefixed internal symbol. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
-#define H2R_VERSION 2
+#define H2R_VERSION 3
 
 /* ---- status codes (function return values and per-element status bytes) ---------------------- */
 enum {
@@ -201,9 +206,11 @@ int32_t h2r_square_mod_batch(const h2r_ctx *ctx, const void *a, const void *n, u
  * e.to_bytes_le() (chip.rs:719-720), the same exponent for every element (RSAPubE::Fix).
  * trace: batch elements laid out per h2r_pow_fixed_layout().  out (nullable): x^e mod n.
  * Stream-ordered: everything the call queues is ordered within `stream`.  A large call with a trace (more than ~1.5k
- * RSA-1536/2048 elements, ~1.5k RSA-3072/4096 ones) is walked as sub-batches whose off-circuit chains run next to the
- * previous sub-batch's record kernel on a side stream owned by the ctx, joined back onto `stream` before the call
- * returns (8,192 RSA-2048 elements: 3.7 -> 4.2 M assigns/s); same results, same buffers, same ordering guarantee. */
+ * RSA-1536/2048 elements, ~1.5k RSA-3072/4096 ones) is walked as sub-batches so that a sub-batch's off-circuit chains run
+ * next to the previous sub-batch's record writes: for the shapes with a one-launch step (see h2r_pipeline_*) as step
+ * launches on `stream` itself, for the others with the record kernels on a side stream owned by the ctx, joined back onto
+ * `stream` before the call returns (8,192 RSA-2048 elements: 3.7 -> 4.8 M assigns/s); same results, same buffers, same
+ * ordering guarantee. */
 int32_t h2r_pow_mod_fixed_exp_batch(const h2r_ctx *ctx, const void *x, const void *n,
                                     const uint8_t *e_le_bytes, size_t e_len, uint64_t batch,
                                     uint32_t flags, void *trace, void *out, uint8_t *status,
@@ -240,13 +247,17 @@ int32_t h2r_modpow_public_key_var_batch(const h2r_ctx *ctx, const void *x, const
  * h2r_pipeline_modpow_public_key() is h2r_modpow_public_key_batch except that the call's TRACE (records and in-field
  * witness) is complete, in `stream` order, only once the NEXT pipelined call has returned or after h2r_pipeline_join();
  * until then it must not be read.  Consecutive calls must use distinct trace / in_field_trace / out / status / workspace
- * buffers (workspace is mandatory here).  Not thread-safe: one pipeline per producer thread.  The chain's results
- * (`out`, `status`) are stream-ordered on `stream` as usual.
+ * buffers (workspace is mandatory here).  The INPUTS x, n (and sig, hashed) are read in `stream` order inside the call that
+ * is given them, for every shape: a producer may refill its staging buffers in stream order as soon as the call has
+ * returned (the records are written from the workspace, and a call's assert_in_field witness is written by the call's own
+ * launches).  Not thread-safe: one pipeline per producer thread.  The chain's results (`out`, `status`) are stream-ordered
+ * on `stream` as usual.  h2r_pipeline_join() must be called before a stream that pipelined calls were issued on is
+ * destroyed (h2r_pipeline_destroy flushes records still owed on the stream of the last call).
  * How the overlap is obtained depends on the shape:
  *  - RSA-2048 and RSA-1024 (64-bit limbs, 32 / 16 limbs), more than 512 elements per call: ONE launch per call on `stream` (step_kernel; a call above 4,096 elements is
  *    walked as equal parts of at most 4,096, one launch each) whose
- *    workgroups run this call's chains, write the PREVIOUS call's records and its in-field witness; the last call's
- *    records go out alone at the join.  Everything is on the caller's stream, no side stream is involved.
+ *    workgroups run this call's chains and write this call's in-field witness and the PREVIOUS call's records; the
+ *    last call's records go out alone at the join.  Everything is on the caller's stream, no side stream is involved.
  *  - every other shape and size: the record-writing kernel runs on a side HIP stream the pipeline owns (created at the
  *    lowest stream priority so that it gets a hardware queue of its own), behind the call's chain kernel, next to the
  *    following call's chain kernel; the in-field witness kernel runs on `stream` right behind the chain kernel.
@@ -272,9 +283,11 @@ int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream);
  * batch * elem_stride bytes (HIP virtual-memory API), times the record kernel on each in the geometry given
  * (records_per_elem records per element from first_record_off, elem_stride apart: e.g. h2r_pow_layout's
  * num_mul_mods / off_records / elem_stride), keeps the `regions` fastest -- h2r_arena_region(a, 0) is the fastest --
- * and gives the others back (rejected candidates keep their memory during the look, up to 64 GB of them, so that the
- * next candidate lands elsewhere).  When no candidate stands out (regions of up to 4 GB: the best within 10 % of the worst) a
- * second round of `candidates` is tried in another part of the memory, behind a placeholder allocation.  Synchronises `stream`.  The regions are ordinary device memory for every other purpose. */
+ * and gives the others back (rejected candidates keep their memory during the look so that the next candidate lands
+ * elsewhere -- at most 64 GB of them and never more than half of the memory free on the device when the call starts).
+ * When no candidate stands out (regions of up to 4 GB: the best within 10 % of the worst) a second round of `candidates`
+ * is tried in another part of the memory, behind a placeholder allocation of at most a third of the free memory.
+ * Synchronises `stream`.  The regions are ordinary device memory for every other purpose. */
 typedef struct h2r_arena h2r_arena;
 int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t first_record_off, uint32_t records_per_elem,
                          uint64_t batch, uint32_t regions, uint32_t candidates, h2r_stream_t stream, h2r_arena **out);
@@ -336,7 +349,10 @@ int32_t h2r_pipeline_verify_pkcs1v15(h2r_pipeline *p, const void *sig, const voi
  * flag_out (nullable): the predicate / overflow bit.  As in the reference, sub's overflow bit is 1 iff
  * a <= b, so add_mod returns a+b un-reduced when a+b == n and sub_mod(a, a, n) returns n.
  * status: H2R_E_NOT_IN_FIELD where sub_mod's assert_zero(is_overflowed2) (:510) fails, H2R_E_NOT_REDUCED
- * where the high limbs of an add_mod/sub_mod result are non-zero (:475-478, :522-525). */
+ * where the high limbs of an add_mod/sub_mod result are non-zero (:475-478, :522-525).
+ * flags: H2R_F_SHARED_MODULUS -- add_mod / sub_mod: `n` is ONE integer used by every element; the ops without an `n`
+ * (comparisons, is_in_field(a, b = modulus)): `b` is ONE integer used by every element.  Without the flag `b` (and `n`)
+ * hold `batch` integers. */
 enum { H2R_OP_ADD = 0, H2R_OP_SUB, H2R_OP_ADD_MOD, H2R_OP_SUB_MOD, H2R_OP_IS_ZERO, H2R_OP_IS_EQUAL_FRESH,
        H2R_OP_IS_LESS_THAN, H2R_OP_IS_LESS_THAN_OR_EQUAL, H2R_OP_IS_GREATER_THAN,
        H2R_OP_IS_GREATER_THAN_OR_EQUAL, H2R_OP_IS_IN_FIELD, H2R_OP_COUNT };
@@ -493,6 +509,9 @@ int32_t h2r_profile_read(uint32_t kernel, float *ms_out, uint32_t max_count, uin
 const char *h2r_status_str(int32_t status);
 const char *h2r_last_hip_error(void);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -263,7 +263,12 @@ class BigIntChip {
         r.trace = DeviceBuffer(batch * r.elem_stride); r.value = DeviceBuffer(batch * vl * 8);
         DeviceBuffer fl(batch), st(batch);
         hip_check(hipMemset(r.trace.get(), 0, batch * r.elem_stride), "hipMemset");
-        check(h2r_fresh_op_batch(ctx_, op, a.data(), b ? b->data() : nullptr, n ? n->data() : nullptr, batch, n ? flags(*n, batch) : 0u,
+        uint32_t fl_shared = n ? flags(*n, batch) : 0u;
+        if (b && b->batch() != batch) {   // one `b` for the whole batch (is_in_field's modulus, a shared comparand): only the ops without an `n`
+            if (b->batch() == 1 && !n) fl_shared |= H2R_F_SHARED_MODULUS;
+            else check(H2R_E_SHAPE, "fresh op: operand batches differ");
+        }
+        check(h2r_fresh_op_batch(ctx_, op, a.data(), b ? b->data() : nullptr, n ? n->data() : nullptr, batch, fl_shared,
                                  r.trace.get(), vl ? r.value.get() : nullptr, static_cast<uint8_t *>(fl.get()), static_cast<uint8_t *>(st.get()), nullptr),
               "h2r_fresh_op_batch");
         hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");

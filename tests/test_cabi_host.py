@@ -34,6 +34,12 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in declared if not hasattr(L, n)]
     assert not missing, missing
     assert sorted(_lib.EXPORTS) == declared
+    # ... and nothing else: the library is built with hidden visibility and a version script, so that a Rust cdylib or a C++
+    # host linking it never meets an un-prefixed internal (call_plan, launch_step, ... in round 2) or a libstdc++ weak symbol
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.lib_path()], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == declared, sorted(set(exported) ^ set(declared))
 
 
 def test_ctx_create_status_codes():

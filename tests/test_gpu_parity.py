@@ -909,7 +909,7 @@ def test_pipelined_calls_match_oracle(H):
 @pytest.mark.parametrize("bits", [2048, 1024])
 def test_pipeline_one_launch_steps(H, bits):
     """RSA-2048 / RSA-1024 pipelined calls of 513..4,096 signatures are issued as one launch per call (step_kernel: this call's
-    chains + the previous call's records and in-field witness).  A train of such calls, interrupted by a small call (the
+    chains and in-field witness + the previous call's records).  A train of such calls, interrupted by a small call (the
     two-queue form) and by a change of the caller's stream, leaves byte-for-byte what the plain export writes -- trace,
     in-field witness, results, status -- and the launches are the expected ones."""
     from halo2_rsa_amd import _lib
@@ -1045,26 +1045,78 @@ def test_pipeline_full_size_rotation(H, depth, side_streams):
         X = [(n >> (k + 1)) ^ (0x9e3779b97f4a7c15 * (i + 1) * (k + 1)) for i, n in enumerate(N)]
         X = [x % n for x, n in zip(X, N)]
         inputs.append((N, X, chip.assign_integer(N), chip.assign_integer(X)))
+    audits = {}
+
+    def audit(k):   # EVERY record of call k, in place (its trace is complete and its workspace intact at this point)
+        s = sets[k % depth]
+        res = H.BatchResult(None, H.Trace(chip, s["trace"], B, pl), s["status"], None, s["ws"],
+                            ("pow_fixed", inputs[k][3], None, inputs[k][2], (65537).to_bytes(3, "little")))
+        audits[k] = res.audit()[0]
     for k in range(CALLS):
         s = sets[k % depth]
         if k >= depth:
+            audit(k - depth)
             snaps[k - depth] = (s["trace"].clone(), s["out"].clone(), s["status"].clone())
         pipe.modpow_public_key(inputs[k][3], 65537, inputs[k][2], s["trace"], s["ws"], s["out"], s["status"])
     pipe.join()
     for k in range(CALLS - depth, CALLS):
         s = sets[k % depth]
+        audit(k)
         snaps[k] = (s["trace"].clone(), s["out"].clone(), s["status"].clone())
     torch.cuda.synchronize()
     for k in range(CALLS):
         N, X = inputs[k][0], inputs[k][1]
         trace, out, status = snaps[k]
         assert not status.cpu().numpy().any()
+        assert not audits[k].cpu().numpy().any(), k      # the bench's exact path (step launches, 1,024 per call), every record
         got = H.AssignedInteger(out, 64).to_big_uint()
         assert all(got[i] == pow(X[i], 65537, N[i]) for i in range(B)), k
         tr = H.Trace(chip, trace, B, pl)
         for i in (0, 511, B - 1):
             rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(X[i]), o.limbs(N[i]), 65537)
             assert np.array_equal(ost, tr.flatten(i)), (k, i)
+    pipe.close()
+
+
+@pytest.mark.parametrize("B", [640, 96])
+def test_pipeline_inputs_may_be_refilled_between_calls(H, B):
+    """include/h2r.h: the inputs of a pipelined call are read in stream order INSIDE the call.  A producer with ONE x and ONE n
+    staging buffer refills them (stream-ordered copies) as soon as a call has returned; every call's in-field witness, records
+    and results must still be those of ITS inputs -- for the one-launch-step form (640 per call: round 2 computed call k's
+    in-field witness in call k+1's launch, i.e. from call k+1's x) and for the two-queue form (96 per call)."""
+    chip = H.BigIntChip(64, 2048)
+    pl = chip.pow_fixed_layout(65537)
+    ies = chip.in_field_layout()[0]
+    rng = random.Random(991 + B)
+    CALLS = 4
+    mk = lambda nbytes: torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    sets = [dict(trace=mk(B * pl.elem_stride), inf=mk(B * ies), ws=mk(chip.workspace_bytes(B, pl.num_mul_mods)),
+                 out=torch.zeros((B, 32), dtype=torch.int64, device="cuda"), status=mk(B)) for _ in range(CALLS)]
+    inputs = []
+    for k in range(CALLS):
+        N = [rand_modulus(rng, 2048) for _ in range(B)]
+        X = [rng.randrange(n) for n in N]
+        inputs.append((chip.assign_integer(N), chip.assign_integer(X)))
+    x_stage = chip.assign_integer([0] * B)
+    n_stage = chip.assign_integer([1] * B)
+    torch.cuda.synchronize()
+    pipe = chip.pipeline()
+    for k, s in enumerate(sets):
+        n_stage.limbs_dev.copy_(inputs[k][0].limbs_dev)      # refilled in stream order right after the previous call returned
+        x_stage.limbs_dev.copy_(inputs[k][1].limbs_dev)
+        pipe.modpow_public_key(x_stage, 65537, n_stage, s["trace"], s["ws"], s["out"], s["status"], in_field_buf=s["inf"])
+    n_stage.limbs_dev.zero_()
+    x_stage.limbs_dev.zero_()
+    pipe.join()
+    torch.cuda.synchronize()
+    for k, s in enumerate(sets):
+        ref_trace, ref_inf = mk(B * pl.elem_stride), mk(B * ies)
+        ref = chip.pow_mod_fixed_exp(inputs[k][1], 65537, inputs[k][0], trace_buf=ref_trace, check_in_field=True, in_field_buf=ref_inf)
+        torch.cuda.synchronize()
+        assert not s["status"].cpu().numpy().any(), k
+        assert torch.equal(ref.value.limbs_dev, s["out"]), k
+        assert torch.equal(ref_inf, s["inf"]), k
+        assert torch.equal(ref_trace, s["trace"]), k
     pipe.close()
 
 
@@ -1472,6 +1524,36 @@ def test_fresh_integer_family(H, w, L):
             assert fl == [int(A[i] < B[i]) for i in range(10)]
         if name == "is_greater_than_or_equal":
             assert fl == [int(A[i] >= B[i]) for i in range(10)]
+
+
+def test_fresh_ops_with_one_shared_comparand(H):
+    """is_in_field(a, n) / assert_in_field(a, n) / the comparisons with ONE `b` for the whole batch (the modulus): round 2's
+    wrappers passed a batch-1 modulus as `b` while the kernel read b[elem] -- out of bounds.  Now H2R_F_SHARED_MODULUS on an
+    op without `n` means a shared `b`; a batch that is neither 1 nor the operand's gets H2R_E_SHAPE."""
+    from halo2_rsa_amd import _lib
+    from oracle_lib import fresh_op
+    chip = H.BigIntChip(64, 2048)
+    o = Oracle(64, 32)
+    rng = random.Random(606)
+    n = rand_modulus(rng, 2048)
+    A = [rng.randrange(n) for _ in range(37)] + [n, n + 1, n - 1]
+    a_dev, n1 = chip.assign_integer(A), chip.assign_integer([n])
+    n_rep = chip.assign_integer([n] * len(A))
+    for name in ("is_in_field", "is_less_than", "is_greater_than_or_equal", "is_equal_fresh"):
+        shared, rep = getattr(chip, name)(a_dev, n1), getattr(chip, name)(a_dev, n_rep)
+        torch.cuda.synchronize()
+        assert torch.equal(shared.flag, rep.flag) and torch.equal(shared.status, rep.status), name
+        assert torch.equal(shared.trace, rep.trace), name
+        for i in (0, 36, 37, 38, 39):
+            rc, ov, of, ost = fresh_op(o, name, o.limbs(A[i]), o.limbs(n), o.limbs(n))
+            assert rc == 0
+            assert np.array_equal(shared.flatten(i), ost), (name, i)
+            assert int(shared.flag[i]) == of, (name, i)
+    res = chip.assert_in_field(a_dev, n1)
+    st = res.status.cpu().tolist()
+    assert st[:37] == [0] * 37 and st[37] == _lib.H2R_E_ASSERTION and st[38] == _lib.H2R_E_ASSERTION and st[39] == 0
+    with pytest.raises(_lib.H2RError):
+        chip.is_in_field(a_dev, chip.assign_integer([n, n]))
 
 
 def test_constants_max_value_and_assertions(H):
