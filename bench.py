@@ -111,7 +111,10 @@ def cpu_baseline(w, bits, e, un, ux, target_seconds=8.0):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle, pow_mod_fixed_exp_timed
     o = Oracle(w, bits // w)
-    cores = os.cpu_count() or 1
+    host = host_cpu_info()
+    # threads = what the host may actually run at once: the GPU boxes expose 256 logical CPUs under a cgroup quota of 16
+    # (cpu.max "1600000 100000"); 256 threads on 16 CPUs' worth of time measured 10x one thread, not 256x
+    cores = max(1, min(host.get("logical_cpus") or 1, host.get("affinity_cpus") or 1 << 30, host.get("quota_cpus") or 1 << 30))
     sample = min(un.limbs.shape[0], 1024)
     x, n = ux.limbs[:sample], un.limbs[:sample]
     pow_mod_fixed_exp_timed(o, x, n, e, 1, cores)                         # threads / pages warm
@@ -127,7 +130,7 @@ def cpu_baseline(w, bits, e, un, ux, target_seconds=8.0):
     return {"value": round(passes * sample / sec, 1), "unit": "assigns/s", "cores": cores, "kind": "port",
             "sample": "%d passes over %d signatures of the same synthetic batch (%.1f s, %d threads, %.0f signatures per "
                       "thread), full op-trace stream written to per-thread buffers" % (passes, sample, sec, cores, passes * sample / cores),
-            "host": host_cpu_info(),
+            "host": host,
             "single_thread_value": round(one / sec1, 1), "single_thread_sample": "%d signatures, 1 thread" % one,
             # what the host actually delivers: os.cpu_count() threads may share far fewer physical cores / a CPU quota
             "parallel_speedup": round((passes * sample / sec) / (one / sec1), 1)}
@@ -160,7 +163,15 @@ def host_cpu_info():
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
             with open(path) as f:
-                info["cgroup_" + os.path.basename(path)] = f.read().strip()
+                raw = f.read().strip()
+            info["cgroup_" + os.path.basename(path)] = raw
+            if path.endswith("cpu.max"):
+                q, per = raw.split()[0], raw.split()[1]
+                if q != "max":
+                    info["quota_cpus"] = max(1, int(int(q) / int(per)))
+            elif int(raw) > 0:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    info["quota_cpus"] = max(1, int(int(raw) / int(f.read().strip())))
             break
         except Exception:
             continue

@@ -129,13 +129,16 @@ struct DoneRef { hipEvent_t ev = nullptr; u32 gen = 0; bool borrowed = false; };
 
 struct Workspace {  // carve-up of the scratch of one batch call (relative to the 256-byte aligned base)
     u64 off_pre;   // the shared modulus' Barrett constants (recip_kernel), behind the operands
-    u64 total;     // one [batch * T][4][L] limb array: a, b, q, r of every mul_mod, then off_pre, plus alignment slack
+    u64 off_n;     // [batch][L] limbs: every element's modulus, copied by the chain kernel -- what the record writer reads, so
+                   // that the caller's n buffer is needed only while the call's own launches run (h2r.h, pipelined form)
+    u64 total;     // one [batch * T][4][L] limb array: a, b, q, r of every mul_mod, then off_pre, off_n, plus alignment slack
 };
 Workspace workspace_plan(u32 limb_bytes, u32 L, u64 batch, u32 T) {
     Workspace w;
     const u64 arr = round_up(batch * T * (u64)L * limb_bytes, 256);
     w.off_pre = 4 * arr;
-    w.total = 4 * arr + round_up(4ull * chain_pre_words(128), 256) + 256;
+    w.off_n = w.off_pre + round_up(4ull * chain_pre_words(128), 256);
+    w.total = w.off_n + round_up(batch * (u64)L * limb_bytes, 256) + 256;
     return w;
 }
 
@@ -316,8 +319,9 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
                  u32 T, void *trace, u64 elem_stride, u64 off_records, const h2r_pow_layout *pl, void *out,
                  uint8_t *status, void *workspace, hipStream_t st, hipStream_t trace_st = nullptr,
                  hipEvent_t chain_done = nullptr, hipEvent_t trace_done = nullptr, DoneRef *done_ref = nullptr,
-                 void *shared_pre = nullptr, PathArgs *args_only = nullptr) {
-    // shared_pre: where the shared modulus' Barrett constants go when `workspace` is a slice of a larger call's plan
+                 void *shared_pre = nullptr, PathArgs *args_only = nullptr, void *n_copy_at = nullptr) {
+    // shared_pre / n_copy_at: where the shared modulus' Barrett constants / the elements' moduli go when `workspace` is a
+    // slice of a larger call's plan
     // trace_st != nullptr (pipeline mode): the record-writing kernel runs on trace_st after `chain_done`
     if (!c || !n || !a || !status) return H2R_E_NULL;
     if (trace_st && !workspace) return H2R_E_NULL;
@@ -354,6 +358,8 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         if (mode != CHAIN_POW_VAR) { ca.off_e_bits = 0; ca.off_selected = 0; }
     }
     if (eb) ca.e = *eb;
+    u8 *n_copy = trace && T ? (n_copy_at ? static_cast<u8 *>(n_copy_at) : ws + wp.off_n) : nullptr;
+    ca.n_copy = reinterpret_cast<u32 *>(n_copy);
     // 128-digit chains (RSA-4096 at 64-bit limbs) are the longer leg next to their record kernel: their waves get issue
     // priority there (1.00 -> 1.05 M assigns/s; no effect measured for the shorter chains)
     if (trace_st && c->K > 96 && lo.limb_width == 64) ca.prio = 1;   // (the 32-bit-limb 4096-bit shape is record-bound)
@@ -395,7 +401,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         fill_trace_args(c, ta);
         const u64 lb = lo.limb_width / 8;   // the four values of an item are L limbs apart
         ta.opA = ws; ta.opB = ws + c->L * lb; ta.opQ = ws + 2 * c->L * lb; ta.opR = ws + 3 * c->L * lb; ta.op_stride = 4ull * c->L;
-        ta.n = n; ta.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : c->L;
+        ta.n = n_copy; ta.n_stride = c->L;   // the chain kernel's copy: the caller's n is read inside the call only
         ta.status = status; ta.n_items = batch * T; ta.T = T;
         ta.trace = static_cast<u8 *>(trace); ta.elem_stride = elem_stride; ta.off_records = off_records;
         if (args_only) { args_only->ta = ta; args_only->has_trace = true; return H2R_OK; }
@@ -1229,7 +1235,8 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
             rc = run_path(ctx, CHAIN_POW_FIXED, xs, nullptr, ns, nullptr, 0, 0, &eb, check_in_field, nb, flags, T,
                           static_cast<u8 *>(trace) + off * elem_stride, elem_stride, pl.off_records, &pl,
                           out ? static_cast<u8 *>(out) + off * in_bytes : nullptr, status + off, split ? ws + off * ws_elem : workspace,
-                          st, p->aux[0], nullptr, nullptr, nullptr, split ? ws + wp.off_pre : nullptr, &pa);
+                          st, p->aux[0], nullptr, nullptr, nullptr, split ? ws + wp.off_pre : nullptr, &pa,
+                          split ? ws + wp.off_n + off * in_bytes : nullptr);
             if (rc) return rc;
             if (!pa.has_trace) return H2R_E_SHAPE;
             if (p->pending) {
@@ -1267,7 +1274,8 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
                       static_cast<u8 *>(trace) + o * elem_stride, elem_stride, pl.off_records, &pl,
                       out ? static_cast<u8 *>(out) + o * in_bytes : nullptr, status + o, split ? ws + o * ws_elem : workspace,
                       st, p->aux[p->k & 1], p->chain_done[slot], last ? p->trace_done[slot] : p->sub_done[i & 1],
-                      last ? &p->done[slot] : &cur, split ? ws + wp.off_pre : nullptr);
+                      last ? &p->done[slot] : &cur, split ? ws + wp.off_pre : nullptr, nullptr,
+                      split ? ws + wp.off_n + o * in_bytes : nullptr);
         if (rc) return rc;
         // paced: as consecutive calls are paced by the lazy join below, sub-batch i+1's chain kernel starts with sub-batch
         // i's record kernel, not earlier

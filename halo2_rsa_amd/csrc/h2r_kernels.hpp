@@ -82,6 +82,8 @@ struct ChainArgs {
     u32 write_result_to_trace;
     u32 prio;            // s_setprio level of the chain's waves (pipeline mode: they share CUs with record kernels)
     const u32 *pre;      // nullable: the shared modulus' precomputed Barrett constants (recip_kernel)
+    u32 *n_copy;         // nullable: [elem][kreal] -- the element's modulus, kept next to the operands for the record writer
+                         // (which may run after the call has returned and the caller has refilled its n buffer)
     u64 *dbg_time;       // debug: s_memtime stamps of block 0 / wave 0 (nullable)
     ExpBits e;
 };
@@ -678,6 +680,7 @@ __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K,
     for (int m = 0; m < V; ++m) nraw[m] = ((u32)(lane + 64 * m) < KR) ? n_g[lane + 64 * m] : 0;
     for (int i = threadIdx.x; i < 3 * K; i += 64 * NW) { s.bpad[i] = 0; s.nnpad[i] = 0; s.mupad[i] = 0; }
     if (threadIdx.x == 0) { s.dbg = (blockIdx.x == 0) ? args.dbg_time : nullptr; s.dbg_n = 0; }
+    if (w0 && args.n_copy) glb_store<K>(args.n_copy + elem * KR, nraw, lane, KR);
     int status = H2R_OK;
     {   // n = 0: the reference divides by zero (chip.rs:566); block-uniform
         bool nz = false;
