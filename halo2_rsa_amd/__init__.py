@@ -5,6 +5,7 @@
 """
 from ._lib import (H2R_E_NOT_IN_FIELD, H2R_E_NOT_REDUCED, H2R_E_SHAPE, H2R_E_ZERO_MODULUS, H2R_OK, H2RError,  # noqa: F401
                    lib, lib_path)
-from .big_integer import AssignedInteger, BatchResult, BigIntChip, Pipeline, Trace, TraceArena, UnassignedInteger  # noqa: F401
+from .big_integer import (AssignedInteger, BatchResult, BigIntChip, LookupArgument, Pipeline, Trace, TraceArena,  # noqa: F401
+                          UnassignedInteger)
 from .rsa import (Fix, RSAChip, RSAPublicKey, RSASignature, RSASignatureVerifier, Var, hashed_msg_from_digest,  # noqa: F401
                   signature_from_bytes_be)

@@ -50,6 +50,11 @@ class H2RVerifyLayout(ctypes.Structure):
                 ("stream_bytes", ctypes.c_uint64)]
 
 
+class H2RLookupConfig(ctypes.Structure):
+    _fields_ = [("n_lens", ctypes.c_uint32), ("bit_len", ctypes.c_uint32 * 8), ("tag", ctypes.c_uint32 * 8),
+                ("row_off", ctypes.c_uint32 * 8), ("n_rows", ctypes.c_uint32)]
+
+
 class H2RError(RuntimeError):
     def __init__(self, code, where):
         self.code = code
@@ -73,9 +78,11 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_trace_flatten", "h2r_pow_trace_flatten", "h2r_stream_bytes", "h2r_pow_stream_bytes", "h2r_trace_flatten_ex",
            "h2r_pow_trace_flatten_ex", "h2r_trace_emit_stream", "h2r_pow_trace_emit_stream", "h2r_mul_mod_trace_check", "h2r_pow_trace_check",
            "h2r_advice_rows", "h2r_mul_mod_emit_advice", "h2r_pow_trace_emit_advice",
+           "h2r_lookup_config_default", "h2r_lookup_config_custom", "h2r_lookup_table_image", "h2r_lookup_hist_records",
+           "h2r_lookup_hist_values", "h2r_lookup_workspace_bytes", "h2r_lookup_permuted_columns", "h2r_field_eval",
            "h2r_profile_enable", "h2r_profile_read", "h2r_status_str",
            "h2r_last_hip_error"]
-KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST, KERNEL_AUX, KERNEL_EMIT, KERNEL_STEP = 0, 1, 2, 3, 4, 5
+KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST, KERNEL_AUX, KERNEL_EMIT, KERNEL_STEP, KERNEL_LOOKUP = 0, 1, 2, 3, 4, 5, 6
 H2R_STREAM_FIELD_AB = 1
 FRESH_OPS = ["add", "sub", "add_mod", "sub_mod", "is_zero", "is_equal_fresh", "is_less_than", "is_less_than_or_equal",
              "is_greater_than", "is_greater_than_or_equal", "is_in_field"]
@@ -176,6 +183,16 @@ def lib():
     L.h2r_mul_mod_trace_check.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp, vp, vp, vp]
     L.h2r_pow_trace_check.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, vp, ctypes.c_char_p, ctypes.c_size_t, u32, vp, u64, vp, u64, vp,
                                       vp, vp, vp]
+    pcfg, pu32, pu64 = ctypes.POINTER(H2RLookupConfig), ctypes.POINTER(u32), ctypes.POINTER(u64)
+    L.h2r_lookup_config_default.argtypes = [vp, u32, pcfg]
+    L.h2r_lookup_config_custom.argtypes = [pu32, pu32, u32, pcfg]
+    L.h2r_lookup_table_image.argtypes = [vp, pcfg, vp, vp]
+    L.h2r_lookup_hist_records.argtypes = [vp, pcfg, vp, u64, u64, u64, u32, vp, vp, vp]
+    L.h2r_lookup_hist_values.argtypes = [vp, pcfg, vp, u32, u64, u64, u32, u32, vp, vp]
+    L.h2r_lookup_workspace_bytes.argtypes = [pcfg, u64]
+    L.h2r_lookup_workspace_bytes.restype = u64
+    L.h2r_lookup_permuted_columns.argtypes = [vp, pcfg, vp, vp, u64, u32, u32, vp, vp, u64, vp, vp, vp]
+    L.h2r_field_eval.argtypes = [vp, u32, pu64, pu64, pu64]
     L.h2r_profile_enable.argtypes = [u32]
     L.h2r_profile_read.argtypes = [u32, ctypes.POINTER(ctypes.c_float), u32, ctypes.POINTER(u32)]
     L.h2r_status_str.argtypes = [i32]

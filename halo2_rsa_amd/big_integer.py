@@ -669,6 +669,71 @@ class TraceArena:
             pass
 
 
+class LookupArgument:
+    """halo2's lookup argument for the range checks (h2r_lookup_*): RangeChip's (tag, value) table, the per-argument
+    multiplicities of a batch of circuits and the permuted columns A' / S' for per-circuit challenges theta.
+    Third-party behaviour restated in DESIGN.md section 2c; five arguments: composition_a..d, overflow_a."""
+
+    ARGS = 5
+
+    def __init__(self, chip: BigIntChip, rsa_chip: bool = True, bit_lens: Optional[Sequence[int]] = None,
+                 tags: Optional[Sequence[int]] = None):
+        self.chip = chip
+        self.cfg = _lib.H2RLookupConfig()
+        if bit_lens is None:
+            check(lib().h2r_lookup_config_default(chip._ctx, 1 if rsa_chip else 0, ctypes.byref(self.cfg)), "h2r_lookup_config_default")
+        else:
+            n = len(bit_lens)
+            check(lib().h2r_lookup_config_custom((ctypes.c_uint32 * n)(*bit_lens), (ctypes.c_uint32 * n)(*tags), n, ctypes.byref(self.cfg)),
+                  "h2r_lookup_config_custom")
+        self.n_rows = int(self.cfg.n_rows)
+
+    def table_image(self):
+        """[(tag, value)] as load_table writes them (canonical field elements; small integers)."""
+        t = np.zeros((self.n_rows, 4), dtype=np.uint64)
+        v = np.zeros((self.n_rows, 4), dtype=np.uint64)
+        check(lib().h2r_lookup_table_image(self.chip._ctx, ctypes.byref(self.cfg), t.ctypes.data, v.ctypes.data), "h2r_lookup_table_image")
+        return [(int(a[0]), int(b[0])) for a, b in zip(t, v)]
+
+    def new_hist(self, batch: int) -> torch.Tensor:
+        return torch.zeros((batch, self.ARGS, self.n_rows), dtype=torch.int32, device="cuda:%d" % self.chip.device)
+
+    def hist_records(self, trace: Trace, hist: torch.Tensor, status: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Adds the lookups of every mul_mod record of every element (q / r limbs, range-assigned carries)."""
+        off = trace.pow_layout.off_records if trace.pow_layout is not None else 0
+        check(lib().h2r_lookup_hist_records(self.chip._ctx, ctypes.byref(self.cfg), trace.buf.data_ptr(), off, trace.elem_stride, trace.batch,
+                                            trace.num_mul_mods, status.data_ptr() if status is not None else None, hist.data_ptr(),
+                                            self.chip._stream()), "h2r_lookup_hist_records")
+        return hist
+
+    def hist_values(self, values: torch.Tensor, bit_len: int, sublimb_bits: int, hist: torch.Tensor) -> torch.Tensor:
+        """Adds RangeChip::assign(v, sublimb_bits, bit_len) of values[elem][:] (int32 / int64 elements)."""
+        assert values.dim() == 2 and values.is_contiguous()
+        check(lib().h2r_lookup_hist_values(self.chip._ctx, ctypes.byref(self.cfg), values.data_ptr(), values.element_size(), values.shape[1],
+                                           values.shape[0], bit_len, sublimb_bits, hist.data_ptr(), self.chip._stream()), "h2r_lookup_hist_values")
+        return hist
+
+    def permuted_columns(self, hist: torch.Tensor, thetas: Sequence[int], usable_rows: int, arg_mask: int = 31, out=None):
+        """(A', S', status): uint8 [batch, 5, usable_rows, 32] each -- canonical little-endian field elements."""
+        batch = hist.shape[0]
+        dev = hist.device
+        th = np.array([[(int(t) >> (64 * k)) & (2 ** 64 - 1) for k in range(4)] for t in thetas], dtype=np.uint64)
+        assert th.shape == (batch, 4)
+        th_dev = torch.from_numpy(th.view(np.int64)).to(dev)
+        if out is None:
+            a_perm = torch.empty((batch, self.ARGS, usable_rows, 32), dtype=torch.uint8, device=dev)
+            s_perm = torch.empty((batch, self.ARGS, usable_rows, 32), dtype=torch.uint8, device=dev)
+        else:
+            a_perm, s_perm = out
+        status = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        ws = torch.empty(int(lib().h2r_lookup_workspace_bytes(ctypes.byref(self.cfg), batch)), dtype=torch.uint8, device=dev)
+        check(lib().h2r_lookup_permuted_columns(self.chip._ctx, ctypes.byref(self.cfg), hist.data_ptr(), th_dev.data_ptr(), batch, usable_rows,
+                                                arg_mask, a_perm.data_ptr(), s_perm.data_ptr(), self.ARGS * usable_rows * 32, status.data_ptr(),
+                                                ws.data_ptr(), self.chip._stream()), "h2r_lookup_permuted_columns")
+        self._keep = (th_dev, ws)   # alive until the stream has run the kernels
+        return a_perm, s_perm, status
+
+
 @dataclass
 class FreshResult:
     value: Optional[AssignedInteger]

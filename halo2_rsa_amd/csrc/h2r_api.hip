@@ -15,6 +15,7 @@
 #include "h2r.h"
 #include "h2r_kernels.hpp"
 #include "h2r_layout.hpp"
+#include "h2r_lookup.hpp"
 
 using namespace h2r;
 
@@ -156,6 +157,7 @@ struct h2r_ctx {
     // RefreshAux::new(w, L, L).increased_limbs_vec (host copy and device copy)
     u8 refresh_inc[2 * 128 + 8]; u32 refresh_nf; u8 *refresh_inc_dev;
     u64 field_p[4];   // the field modulus (a_b encoding, chip.rs:859)
+    FieldConsts fc;   // its Montgomery constants (lookup compression, is_zero's inverse witness)
     u32 num_cus, lds_per_cu;   // of the ctx's device
     // the plain (stream-ordered) pow exports overlap chain and record kernels INSIDE a large call through this pipeline
     // (created on first use; calls on one ctx from several threads take turns queueing)
@@ -518,6 +520,7 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
     c->refresh_nf = (L <= 128) ? refresh_aux_increased_limbs(w, L, c->refresh_inc) : 0;
     layout_compute(w, L, &c->layout);
     field_modulus(params->field, c->field_p);
+    field_consts_init(c->field_p, &c->fc);
     build_const_record(c);
     // histogram rows: composition table of the limb sub-limbs, then of the carry sub-limbs when its width
     // differs, then the carry overflow table
@@ -1561,6 +1564,181 @@ int32_t h2r_trace_lookup_permutation_hist(const h2r_ctx *ctx, const void *trace,
     } else
         hipLaunchKernelGGL(perm_kernel<false>, dim3((unsigned)num_elems), dim3(256), (unsigned)(stage_bytes + same_bytes), static_cast<hipStream_t>(stream), pa);
     HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
+
+// ---- halo2's lookup argument: table, per-argument multiplicities, permuted columns (h2r_lookup.hpp) ---------------------
+int32_t h2r_lookup_config_custom(const uint32_t *bit_lens, const uint32_t *tags, uint32_t n, h2r_lookup_config *out) {
+    if (!bit_lens || !tags || !out) return H2R_E_NULL;
+    std::memset(out, 0, sizeof *out);
+    // RangeChip::configure: sort, de-duplicate, drop zero entries
+    std::vector<std::pair<u32, u32>> v;
+    for (u32 i = 0; i < n; ++i) {
+        if (!bit_lens[i]) continue;
+        bool dup = false;
+        for (auto &e : v) if (e.first == bit_lens[i]) { dup = true; if (e.second != tags[i]) return H2R_E_SHAPE; }
+        if (!dup) v.emplace_back(bit_lens[i], tags[i]);
+    }
+    std::sort(v.begin(), v.end());
+    if (v.empty() || v.size() > H2R_LOOKUP_MAX_LENS) return H2R_E_SHAPE;
+    u64 off = 1;
+    for (size_t i = 0; i < v.size(); ++i) {
+        if (v[i].first > 10 || v[i].second == 0) return H2R_E_SHAPE;   // tag 0 is the lookup-off row
+        for (size_t j = 0; j < i; ++j) if (v[j].second == v[i].second) return H2R_E_SHAPE;
+        out->bit_len[i] = v[i].first; out->tag[i] = v[i].second; out->row_off[i] = (u32)off;
+        off += 1ull << v[i].first;
+    }
+    if (off > (u64)LOOKUP_MAX_ROWS) return H2R_E_UNSUPPORTED;
+    out->n_lens = (u32)v.size(); out->n_rows = (u32)off;
+    return H2R_OK;
+}
+
+int32_t h2r_lookup_config_default(const h2r_ctx *ctx, uint32_t rsa_chip, h2r_lookup_config *out) {
+    if (!ctx || !out) return H2R_E_NULL;
+    u32 comp[4] = {0, 0, 0, 0}, over[3] = {0, 0, 0};
+    compute_range_lens(ctx->layout.limb_width, ctx->L, comp, over);      // big_integer/chip.rs:1220-1249
+    if (rsa_chip) comp[3] = 32 / kNumLookupLimbs;                         // src/chip.rs:252
+    u32 lens[7] = {comp[0], comp[1], comp[2], comp[3], over[0], over[1], over[2]}, uniq[7], tags[7], n = 0;
+    std::sort(lens, lens + 7);
+    for (u32 i = 0; i < 7; ++i) if (lens[i] && (n == 0 || uniq[n - 1] != lens[i])) { uniq[n] = lens[i]; tags[n] = n + 1; ++n; }
+    return h2r_lookup_config_custom(uniq, tags, n, out);
+}
+
+int32_t h2r_lookup_table_image(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint64_t *tag_col, uint64_t *value_col) {
+    if (!ctx || !cfg || !tag_col || !value_col) return H2R_E_NULL;
+    if (cfg->n_rows == 0 || cfg->n_rows > (u32)LOOKUP_MAX_ROWS) return H2R_E_SHAPE;
+    std::memset(tag_col, 0, (size_t)cfg->n_rows * 32); std::memset(value_col, 0, (size_t)cfg->n_rows * 32);
+    for (u32 i = 0; i < cfg->n_lens; ++i)
+        for (u32 v = 0; v < (1u << cfg->bit_len[i]); ++v) {
+            tag_col[(u64)(cfg->row_off[i] + v) * 4] = cfg->tag[i];   // small integers: canonical as they are
+            value_col[(u64)(cfg->row_off[i] + v) * 4] = v;
+        }
+    return H2R_OK;
+}
+
+namespace {
+// sub-limb shape of RangeChip::assign(value, s, bit_len) and the table rows its lookups hit
+int32_t range_shape(const h2r_lookup_config &cfg, u32 bit_len, u32 s, RangeShape *out) {
+    if (!s || !bit_len || s > 8) return H2R_E_SHAPE;
+    RangeShape r;
+    r.sub_bits = s; r.ov_bits = bit_len % s; r.nsub = bit_len / s + (r.ov_bits ? 1 : 0);
+    r.row_comp = r.row_ov = 0;
+    if (r.nsub == 0 || r.nsub > 16) return H2R_E_SHAPE;
+    bool fc = false, fo = r.ov_bits == 0;
+    for (u32 i = 0; i < cfg.n_lens; ++i) {
+        if (cfg.bit_len[i] == s) { r.row_comp = cfg.row_off[i]; fc = true; }
+        if (r.ov_bits && cfg.bit_len[i] == r.ov_bits) { r.row_ov = cfg.row_off[i]; fo = true; }
+    }
+    if (!fc || !fo) return H2R_E_SHAPE;   // RangeChip::assign panics: no table for that bit length
+    *out = r;
+    return H2R_OK;
+}
+}  // namespace
+
+int32_t h2r_lookup_hist_records(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const void *trace, uint64_t first_record_off,
+                                uint64_t elem_stride, uint64_t num_elems, uint32_t records_per_elem, const uint8_t *status,
+                                uint32_t *hist, h2r_stream_t stream) {
+    if (!ctx || !cfg || !trace || !hist) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    if (cfg->n_rows == 0 || cfg->n_rows > (u32)LOOKUP_MAX_ROWS) return H2R_E_SHAPE;
+    const h2r_layout &lo = ctx->layout;
+    if (lo.limb_nsub != 8 || lo.carry_nsub > 16) return H2R_E_UNSUPPORTED;
+    LookupHistArgs a;
+    std::memset(&a, 0, sizeof a);
+    int32_t rc = range_shape(*cfg, lo.limb_width, lo.limb_sub_bits, &a.limb);
+    if (rc) return rc;
+    rc = range_shape(*cfg, lo.carry_bits, lo.carry_sub_bits, &a.carry);
+    if (rc) return rc;
+    if (num_elems == 0 || records_per_elem == 0) return H2R_OK;
+    a.trace = static_cast<const u8 *>(trace); a.first_record_off = first_record_off; a.elem_stride = elem_stride;
+    a.record_stride = lo.record_stride; a.num_elems = num_elems; a.records_per_elem = records_per_elem;
+    a.off_q_sub = lo.plane_off[H2R_PL_Q_SUB]; a.off_r_sub = lo.plane_off[H2R_PL_R_SUB]; a.off_carry_sub = lo.plane_off[H2R_PL_CARRY_SUB];
+    a.L = lo.num_limbs; a.C = lo.num_cols; a.carry_sub_stride = lo.carry_sub_stride;
+    a.n_rows = cfg->n_rows; a.hist = hist; a.status = status;
+    H2R_ON_DEVICE(ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope ps(H2R_KERNEL_HIST, st);
+    hipLaunchKernelGGL(lookup_hist_records_kernel, dim3((unsigned)num_elems), dim3(256), LOOKUP_ARGS * cfg->n_rows * sizeof(u32), st, a);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
+
+int32_t h2r_lookup_hist_values(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const void *values, uint32_t value_bytes,
+                               uint64_t values_per_elem, uint64_t num_elems, uint32_t bit_len, uint32_t sublimb_bits,
+                               uint32_t *hist, h2r_stream_t stream) {
+    if (!ctx || !cfg || !values || !hist) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    if (cfg->n_rows == 0 || cfg->n_rows > (u32)LOOKUP_MAX_ROWS) return H2R_E_SHAPE;
+    if ((value_bytes != 4 && value_bytes != 8 && value_bytes != 16) || bit_len > 8 * value_bytes) return H2R_E_SHAPE;
+    LookupValuesArgs a;
+    std::memset(&a, 0, sizeof a);
+    const int32_t rc = range_shape(*cfg, bit_len, sublimb_bits, &a.shape);
+    if (rc) return rc;
+    if (num_elems == 0 || values_per_elem == 0) return H2R_OK;
+    a.values = static_cast<const u8 *>(values); a.value_bytes = value_bytes; a.values_per_elem = values_per_elem; a.num_elems = num_elems;
+    a.n_rows = cfg->n_rows; a.hist = hist;
+    H2R_ON_DEVICE(ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope ps(H2R_KERNEL_HIST, st);
+    hipLaunchKernelGGL(lookup_hist_values_kernel, dim3((unsigned)num_elems), dim3(256), LOOKUP_ARGS * cfg->n_rows * sizeof(u32), st, a);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
+
+uint64_t h2r_lookup_workspace_bytes(const h2r_lookup_config *cfg, uint64_t num_elems) {
+    if (!cfg || cfg->n_rows == 0 || cfg->n_rows > (u32)LOOKUP_MAX_ROWS) return 0;
+    return num_elems * LOOKUP_ARGS * lookup_slot_bytes(cfg->n_rows) + 256;
+}
+
+int32_t h2r_lookup_permuted_columns(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const uint32_t *hist, const uint64_t *theta,
+                                    uint64_t num_elems, uint32_t usable_rows, uint32_t arg_mask, void *a_perm_out,
+                                    void *s_perm_out, uint64_t out_elem_stride, uint8_t *status, void *workspace,
+                                    h2r_stream_t stream) {
+    if (!ctx || !cfg || !hist || !theta || !a_perm_out || !s_perm_out || !workspace) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    if (cfg->n_rows == 0 || cfg->n_rows > (u32)LOOKUP_MAX_ROWS || cfg->n_lens == 0 || cfg->n_lens > H2R_LOOKUP_MAX_LENS) return H2R_E_SHAPE;
+    if (usable_rows < cfg->n_rows || out_elem_stride < (u64)LOOKUP_ARGS * usable_rows * 32 || (out_elem_stride & 15) ||
+        (reinterpret_cast<u64>(a_perm_out) & 15) || (reinterpret_cast<u64>(s_perm_out) & 15)) return H2R_E_SHAPE;
+    if (num_elems == 0 || !(arg_mask & 31u)) return H2R_OK;
+    if (num_elems * LOOKUP_ARGS >= (1ull << 31) || num_elems > 65535) return H2R_E_UNSUPPORTED;   // grid.z
+    H2R_ON_DEVICE(ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    u8 *ws = reinterpret_cast<u8 *>(round_up(reinterpret_cast<u64>(workspace), 256));
+    if (status) HIP_TRY(hipMemsetAsync(status, 0, num_elems, st));
+    LookupSetupArgs sa;
+    std::memset(&sa, 0, sizeof sa);
+    sa.hist = hist; sa.theta = theta; sa.num_elems = num_elems; sa.usable_rows = usable_rows; sa.n_rows = cfg->n_rows;
+    sa.n_lens = cfg->n_lens; sa.arg_mask = arg_mask & 31u;
+    for (u32 i = 0; i < cfg->n_lens; ++i) { sa.tag[i] = cfg->tag[i]; sa.row_off[i] = cfg->row_off[i]; sa.bit_len[i] = cfg->bit_len[i]; }
+    sa.f = ctx->fc; sa.ws = ws; sa.status = status;
+    hipLaunchKernelGGL(lookup_setup_kernel, dim3((unsigned)(num_elems * LOOKUP_ARGS)), dim3(256), 0, st, sa);
+    HIP_TRY(hipGetLastError());
+    LookupFillArgs fa;
+    std::memset(&fa, 0, sizeof fa);
+    fa.ws = ws; fa.num_elems = num_elems; fa.usable_rows = usable_rows; fa.n_rows = cfg->n_rows; fa.arg_mask = arg_mask & 31u;
+    fa.rows_per_block = 8192; fa.status = status;
+    fa.a_perm = static_cast<u8 *>(a_perm_out); fa.s_perm = static_cast<u8 *>(s_perm_out); fa.out_elem_stride = out_elem_stride;
+    const unsigned chunks = (usable_rows + fa.rows_per_block - 1) / fa.rows_per_block;
+    const unsigned lds = (unsigned)lookup_slot_bytes(cfg->n_rows);
+    ProfScope ps(H2R_KERNEL_LOOKUP, st, true);
+    hipExtLaunchKernelGGL(lookup_fill_kernel, dim3(chunks, LOOKUP_ARGS, (unsigned)num_elems), dim3(256), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, fa);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
+
+int32_t h2r_field_eval(const h2r_ctx *ctx, uint32_t op, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
+    if (!ctx || !a || !out || (op < 3 && !b)) return H2R_E_NULL;
+    Fe x, y = fe_zero(), r;
+    for (int k = 0; k < 4; ++k) { x.v[k] = a[k]; if (b) y.v[k] = b[k]; }
+    if (ge_p(x.v, ctx->fc.p) || (op < 3 && ge_p(y.v, ctx->fc.p))) return H2R_E_SHAPE;   // canonical elements only
+    switch (op) {
+        case 0: r = fe_add(x, y, ctx->fc.p); break;
+        case 1: r = fe_sub(x, y, ctx->fc.p); break;
+        case 2: r = fe_mul(x, y, ctx->fc); break;
+        case 3: if (fe_is_zero(x)) return H2R_E_SHAPE; r = fe_inv(x, ctx->fc); break;
+        default: return H2R_E_UNSUPPORTED;
+    }
+    for (int k = 0; k < 4; ++k) out[k] = r.v[k];
     return H2R_OK;
 }
 

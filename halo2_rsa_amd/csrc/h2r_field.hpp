@@ -1,0 +1,154 @@
+// Prime-field arithmetic of the four fields the reference instantiates its chips over (bn256 Fr / Fq, pasta Fp / Fq:
+// examples/rsa_example.rs:148, big_integer/chip.rs:1461-1463), for the parts of the witness that are FIELD values rather
+// than integers: the theta-compressed lookup inputs of halo2's lookup argument (tag * theta + value) and the inverse
+// witness of main_gate.is_zero.  Elements are four little-endian 64-bit words, canonical (< p) at every interface; the
+// Montgomery form (R = 2^256) is internal to mul / inverse.  Host and device share the code (hipcc compiles both).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace h2r {
+
+struct Fe { uint64_t v[4]; };
+
+struct FieldConsts {
+    uint64_t p[4];      // modulus
+    uint64_t r2[4];     // R^2 mod p
+    uint64_t one[4];    // R mod p (Montgomery form of 1)
+    uint64_t n0inv;     // -p^{-1} mod 2^64
+};
+
+#define H2R_FD __host__ __device__ __forceinline__
+
+H2R_FD bool fe_is_zero(const Fe &a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3]) == 0; }
+H2R_FD bool fe_eq(const Fe &a, const Fe &b) { return a.v[0] == b.v[0] && a.v[1] == b.v[1] && a.v[2] == b.v[2] && a.v[3] == b.v[3]; }
+// order of the canonical integers = the fields' `Ord` (halo2curves / pasta_curves compare to_repr() from the top byte)
+H2R_FD bool fe_lt(const Fe &a, const Fe &b) {
+#pragma unroll
+    for (int k = 3; k >= 0; --k) { if (a.v[k] != b.v[k]) return a.v[k] < b.v[k]; }
+    return false;
+}
+H2R_FD bool ge_p(const uint64_t (&x)[4], const uint64_t (&p)[4]) {
+#pragma unroll
+    for (int k = 3; k >= 0; --k) { if (x[k] != p[k]) return x[k] > p[k]; }
+    return true;
+}
+H2R_FD Fe fe_zero() { Fe r; r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0; return r; }
+H2R_FD Fe fe_small(uint64_t x) { Fe r; r.v[0] = x; r.v[1] = r.v[2] = r.v[3] = 0; return r; }
+
+// a + b mod p (a, b < p < 2^255: no carry out of 256 bits)
+H2R_FD Fe fe_add(const Fe &a, const Fe &b, const uint64_t (&p)[4]) {
+    uint64_t s[4]; uint64_t cy = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint64_t t = a.v[k] + b.v[k]; const uint64_t c1 = t < a.v[k]; const uint64_t u = t + cy; cy = c1 | (uint64_t)(u < t); s[k] = u; }
+    Fe r;
+    if (ge_p(s, p)) {
+        uint64_t br = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint64_t t = s[k] - p[k]; const uint64_t b1 = s[k] < p[k]; const uint64_t u = t - br; br = b1 | (uint64_t)(t < br); r.v[k] = u; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.v[k] = s[k];
+    }
+    return r;
+}
+// a - b mod p
+H2R_FD Fe fe_sub(const Fe &a, const Fe &b, const uint64_t (&p)[4]) {
+    Fe r; uint64_t br = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint64_t t = a.v[k] - b.v[k]; const uint64_t b1 = a.v[k] < b.v[k]; const uint64_t u = t - br; br = b1 | (uint64_t)(t < br); r.v[k] = u; }
+    if (br) {
+        uint64_t cy = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint64_t t = r.v[k] + p[k]; const uint64_t c1 = t < r.v[k]; const uint64_t u = t + cy; cy = c1 | (uint64_t)(u < t); r.v[k] = u; }
+    }
+    return r;
+}
+// small * a mod p by double-and-add (tags are small integers; 32 conditional additions at most)
+H2R_FD Fe fe_mul_small(const Fe &a, uint32_t m, const uint64_t (&p)[4]) {
+    Fe acc = fe_zero(), cur = a;
+    while (m) {
+        if (m & 1u) acc = fe_add(acc, cur, p);
+        cur = fe_add(cur, cur, p);
+        m >>= 1;
+    }
+    return acc;
+}
+
+H2R_FD uint64_t mulhi64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+// t += a * b + c; returns the high word (the carry)
+H2R_FD uint64_t mac(uint64_t &t, uint64_t a, uint64_t b, uint64_t c) {
+    const uint64_t lo = a * b, hi = mulhi64(a, b);
+    const uint64_t s1 = t + lo; const uint64_t c1 = s1 < t;
+    const uint64_t s2 = s1 + c; const uint64_t c2 = s2 < s1;
+    t = s2;
+    return hi + c1 + c2;   // cannot overflow: (2^64-1)^2 + 2 (2^64-1) < 2^128
+}
+// Montgomery product a * b * R^-1 mod p (CIOS, 4 x 64-bit words); inputs < p, output < p
+H2R_FD Fe fe_mont_mul(const Fe &a, const Fe &b, const FieldConsts &f) {
+    uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = mac(t[j], a.v[j], b.v[i], c);
+        const uint64_t s = t[4] + c; t[5] = s < t[4]; t[4] = s;
+        const uint64_t m = t[0] * f.n0inv;
+        uint64_t z = t[0];
+        c = mac(z, m, f.p[0], 0);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) { c = mac(t[j], m, f.p[j], c); t[j - 1] = t[j]; }
+        const uint64_t s2 = t[4] + c; const uint64_t c2 = s2 < t[4];
+        t[3] = s2; t[4] = t[5] + c2; t[5] = 0;
+    }
+    uint64_t x[4] = {t[0], t[1], t[2], t[3]};
+    Fe r;
+    if (t[4] || ge_p(x, f.p)) {
+        uint64_t br = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint64_t u = x[k] - f.p[k]; const uint64_t b1 = x[k] < f.p[k]; const uint64_t w = u - br; br = b1 | (uint64_t)(u < br); r.v[k] = w; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r.v[k] = x[k];
+    }
+    return r;
+}
+H2R_FD Fe fe_to_mont(const Fe &a, const FieldConsts &f) { Fe r2; for (int k = 0; k < 4; ++k) r2.v[k] = f.r2[k]; return fe_mont_mul(a, r2, f); }
+H2R_FD Fe fe_from_mont(const Fe &a, const FieldConsts &f) { return fe_mont_mul(a, fe_small(1), f); }
+// canonical a * b mod p
+H2R_FD Fe fe_mul(const Fe &a, const Fe &b, const FieldConsts &f) { return fe_mont_mul(fe_to_mont(a, f), b, f); }
+// a^-1 mod p for a != 0 (Fermat: a^(p-2)), canonical in and out.  main_gate.is_zero's inverse witness.
+H2R_FD Fe fe_inv(const Fe &a, const FieldConsts &f) {
+    uint64_t e[4] = {f.p[0] - 2, f.p[1], f.p[2], f.p[3]};   // p is odd and > 2: no borrow
+    const Fe am = fe_to_mont(a, f);
+    Fe acc; for (int k = 0; k < 4; ++k) acc.v[k] = f.one[k];
+    for (int bit = 255; bit >= 0; --bit) {
+        acc = fe_mont_mul(acc, acc, f);
+        if ((e[bit >> 6] >> (bit & 63)) & 1ull) acc = fe_mont_mul(acc, am, f);
+    }
+    return fe_from_mont(acc, f);
+}
+
+// Host: derive the Montgomery constants of modulus p.
+inline void field_consts_init(const uint64_t p[4], FieldConsts *f) {
+    for (int k = 0; k < 4; ++k) f->p[k] = p[k];
+    uint64_t inv = 1;                                   // Newton: inv = p^-1 mod 2^64
+    for (int i = 0; i < 6; ++i) inv *= 2 - p[0] * inv;
+    f->n0inv = (uint64_t)0 - inv;
+    Fe x = fe_small(1);                                 // 2^k mod p by doubling
+    for (int i = 0; i < 512; ++i) {
+        x = fe_add(x, x, f->p);
+        if (i == 255) for (int k = 0; k < 4; ++k) f->one[k] = x.v[k];
+    }
+    for (int k = 0; k < 4; ++k) f->r2[k] = x.v[k];
+}
+
+}  // namespace h2r

@@ -422,6 +422,61 @@ int32_t h2r_trace_lookup_permutation_hist(const h2r_ctx *ctx, const void *trace,
                                           uint32_t *perm_out, uint16_t *rows_out, uint32_t *hist_out,
                                           h2r_stream_t stream);
 
+/* ---- halo2's lookup argument for the range checks: table image, per-argument multiplicities, permuted columns A' / S' ----
+ * What `range_chip.load_table` + `create_proof` do with the sub-limb cells (reference benches/bench.rs:141-142, 321-329; the
+ * RangeChip call sites big_integer/chip.rs:74, 590, 598, 880-885).  THIRD-PARTY behaviour (maingate / halo2wrong rev 63bde545,
+ * halo2's plonk::lookup::prover -- neither is in the reference tree), restated in DESIGN.md section 2c; parity is pinned against
+ * a Python restatement of the same algorithm run on the ORACLE's cells (tests/advice_ref.py), not against the upstream code.
+ *  - RangeChip::configure gives every distinct nonzero bit length of composition_bit_lens + overflow_bit_lens a TAG and
+ *    load_table writes ONE (tag, value) table: row 0 = (0, 0), then, bit lengths ascending, (tag_b, 0 .. 2^b - 1).
+ *    h2r_lookup_config_default: tags 1, 2, ... in ascending bit-length order for BigIntChip::compute_range_lens
+ *    (big_integer/chip.rs:1220-1249) [+ RSAChip's 32/8, src/chip.rs:252 when rsa_chip != 0]; h2r_lookup_config_custom: the
+ *    bit_len -> tag map of whatever maingate revision the caller links (a shim reads it from its RangeConfig).
+ *  - FIVE lookup arguments read the main gate's advice columns: composition_a..d = columns a..d under the fixed column
+ *    tag_composition, overflow_a = column a under tag_overflow; a row with the lookup off contributes (0, 0).
+ *    RangeChip::assign(v, s, bit_len) = main_gate.decompose: rows of four s-bit terms in columns a..d (the LAST row reversed so
+ *    that the last term -- the overflow sub-limb, if bit_len % s != 0 -- is in column a; missing terms are zero cells).
+ *    h2r_lookup_hist_*: multiplicity of every table row per element (= circuit) and argument, hist[elem][5][n_rows] uint32,
+ *    ADDED to (accumulate the mul_mod records, then the range-assigned inputs / any other range-checked values of the circuit).
+ *  - h2r_lookup_permuted_columns: for every element and argument, halo2's permute_expression_pair on the usable rows: inputs and
+ *    table compressed with the element's challenge (tag * theta + value), A' = the inputs sorted by the field's Ord (order of the
+ *    canonical integers), S'[i] = A'[i] on the first row of every run of A', the leftover table values elsewhere (ascending,
+ *    handed out from the LAST repeated row backwards, as the upstream Vec::pop does); the table column is the table's rows
+ *    followed by its default row (0, 0).  The blinding tail (random) is the caller's.  Output: canonical 32-byte little-endian
+ *    elements; element e, argument k at + e * out_elem_stride + k * usable_rows * 32 in a_perm_out and in s_perm_out.
+ *    theta: [num_elems][4] uint64 on the device (every proof has its own challenge).  status (nullable, [num_elems]):
+ *    H2R_E_SHAPE where the lookup inputs or the table do not fit usable_rows.  arg_mask: bit k = produce argument k. */
+#define H2R_LOOKUP_ARGS 5u
+#define H2R_LOOKUP_MAX_LENS 8u
+enum { H2R_LOOKUP_COMPOSITION_A = 0, H2R_LOOKUP_COMPOSITION_B, H2R_LOOKUP_COMPOSITION_C, H2R_LOOKUP_COMPOSITION_D, H2R_LOOKUP_OVERFLOW_A };
+typedef struct h2r_lookup_config {
+    uint32_t n_lens;                          /* distinct nonzero bit lengths */
+    uint32_t bit_len[H2R_LOOKUP_MAX_LENS];    /* ascending */
+    uint32_t tag[H2R_LOOKUP_MAX_LENS];        /* RangeConfig::bit_len_tag */
+    uint32_t row_off[H2R_LOOKUP_MAX_LENS];    /* table row of (tag, 0) */
+    uint32_t n_rows;                          /* 1 + sum of 2^bit_len (at most 1,024) */
+} h2r_lookup_config;
+int32_t h2r_lookup_config_default(const h2r_ctx *ctx, uint32_t rsa_chip, h2r_lookup_config *out);
+int32_t h2r_lookup_config_custom(const uint32_t *bit_lens, const uint32_t *tags, uint32_t n, h2r_lookup_config *out);
+/* the table `load_table` writes: tag_col / value_col receive n_rows canonical field elements (4 x uint64, HOST buffers) */
+int32_t h2r_lookup_table_image(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint64_t *tag_col, uint64_t *value_col);
+int32_t h2r_lookup_hist_records(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const void *trace, uint64_t first_record_off,
+                                uint64_t elem_stride, uint64_t num_elems, uint32_t records_per_elem, const uint8_t *status,
+                                uint32_t *hist, h2r_stream_t stream);
+/* RangeChip::assign(value, sublimb_bits, bit_len) of values_per_elem values (value_bytes = 4, 8 or 16) per element, e.g. the
+ * limbs of assign_integer(x), assign_integer(n) (big_integer/chip.rs:71-76: sublimb_bits = limb_width / 8, bit_len = limb_width) */
+int32_t h2r_lookup_hist_values(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const void *values, uint32_t value_bytes,
+                               uint64_t values_per_elem, uint64_t num_elems, uint32_t bit_len, uint32_t sublimb_bits,
+                               uint32_t *hist, h2r_stream_t stream);
+uint64_t h2r_lookup_workspace_bytes(const h2r_lookup_config *cfg, uint64_t num_elems);
+int32_t h2r_lookup_permuted_columns(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const uint32_t *hist, const uint64_t *theta,
+                                    uint64_t num_elems, uint32_t usable_rows, uint32_t arg_mask, void *a_perm_out,
+                                    void *s_perm_out, uint64_t out_elem_stride, uint8_t *status, void *workspace,
+                                    h2r_stream_t stream);
+/* Arithmetic of the ctx's field on canonical elements (host): op 0 = a + b, 1 = a - b, 2 = a * b, 3 = a^-1 (b ignored; a != 0).
+ * The same code the kernels run (lookup compression, main_gate.is_zero's inverse witness). */
+int32_t h2r_field_eval(const h2r_ctx *ctx, uint32_t op, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
+
 /* ---- host-side helpers (no device work) --------------------------------------------------------
  * h2r_trace_flatten: walk ONE record (host copy, record_stride bytes) in the reference's assignment
  * order and write its flat op-trace stream (layout.stream_bytes bytes; widths in h2r_layout).
@@ -502,7 +557,8 @@ int32_t h2r_pow_trace_check(const h2r_ctx *ctx, const h2r_pow_layout *pl, const 
  * and frees the events).  h2r_profile_read() synchronises the recorded events of one kernel class
  * and returns their durations in milliseconds, in launch order. */
 enum { H2R_KERNEL_CHAIN = 0, H2R_KERNEL_TRACE = 1, H2R_KERNEL_HIST = 2, H2R_KERNEL_AUX = 3, H2R_KERNEL_EMIT = 4,
-       H2R_KERNEL_STEP = 5 /* a pipeline step as one launch: records of call k + chains of call k+1 */, H2R_KERNEL_COUNT = 6 };
+       H2R_KERNEL_STEP = 5 /* a pipeline step as one launch: records of call k + chains of call k+1 */,
+       H2R_KERNEL_LOOKUP = 6 /* lookup_fill_kernel: the permuted columns */, H2R_KERNEL_COUNT = 7 };
 int32_t h2r_profile_enable(uint32_t capacity);
 int32_t h2r_profile_read(uint32_t kernel, float *ms_out, uint32_t max_count, uint32_t *count);
 

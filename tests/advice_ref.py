@@ -1,12 +1,115 @@
-"""TEST HELPER: the 5-column advice image of one mul_mod, built in plain Python from the ORACLE's flat stream and the
-operands, following ONLY the row table documented in DESIGN.md section 2b / include/h2r.h (an independent restatement of
-the placement; the values come from the oracle).  Cells are canonical field elements (32 bytes little-endian)."""
+"""TEST HELPER: the main-gate image of one mul_mod -- advice rows, fixed (selector) rows, lookup inputs, the lookup table
+and halo2's permuted lookup columns -- built in plain Python from the ORACLE's flat stream and the operands.
+
+Everything here restates THIRD-PARTY code that is not in the reference tree (maingate / halo2wrong rev 63bde545, halo2's
+lookup prover): the op -> row shapes documented in DESIGN.md section 2b and the `permute_expression_pair` algorithm.  The
+VALUES come from the oracle's stream (pinned); the PLACEMENT is this restatement (unpinned, self-consistent: every row
+satisfies the main-gate equation with its fixed row, every lookup input is a table row -- checked by the tests).
+
+Row kinds (include/h2r.h H2R_ROW_*):  cells a..e, gate
+    sa*a + sb*b + sc*c + sd*d + se*e + s_mul_ab*a*b + s_mul_cd*c*d + se_next*e(next row) + s_const = 0."""
 import numpy as np
 
+ROW_NOP, ROW_CONST0, ROW_CONST1, ROW_CONST_B, ROW_BIT, ROW_VALUE, ROW_MUL_ADD, ROW_ADD, ROW_SUB, ROW_ADD_WM, ROW_ADDC_WM, ROW_MUL, \
+    ROW_ASSERT_EQ, ROW_ISZERO_INV, ROW_ISZERO_RA = range(15)
+ROW_RANGE_LIMB = 32      # + row of the assign (0 .. nr-1)
+ROW_RANGE_CARRY = 40     # + row of the assign (0 .. nrc-1)
 
-def advice_image_from_stream(p, a, b, n, stream, field_modulus):
-    """p: oracle params (ctypes struct with w, L, LB, WB, CB, carry_bits, carry_sub_bits, carry_nsub ...);
-    a, b, n: limb lists; stream: bytes of the mul_mod flat stream.  Returns uint8 [rows, 160]."""
+ARGS = ("composition_a", "composition_b", "composition_c", "composition_d", "overflow_a")
+
+
+def word_max(w, L):
+    B = 1 << w
+    return L * (B - 1) * (B - 1) + (B - 1)
+
+
+class LookupConfig:
+    """RangeChip::configure's bit_len -> tag map and the (tag, value) table `load_table` writes: row 0 = (0, 0), then for
+    every distinct nonzero bit length in ascending order (tag = 1, 2, ...) the rows (tag, 0 .. 2^bit_len - 1)."""
+
+    def __init__(self, bit_lens, tags=None):
+        self.bit_lens = sorted(set(b for b in bit_lens if b))
+        self.tags = list(tags) if tags is not None else list(range(1, len(self.bit_lens) + 1))
+        self.tag_of = dict(zip(self.bit_lens, self.tags))
+        self.row_off = {}
+        off = 1
+        for b in self.bit_lens:
+            self.row_off[b] = off
+            off += 1 << b
+        self.n_rows = off
+
+    def table(self):
+        rows = [(0, 0)]
+        for b in self.bit_lens:
+            rows += [(self.tag_of[b], v) for v in range(1 << b)]
+        return rows
+
+
+def range_lens(w, L, rsa=False):
+    """BigIntChip::compute_range_lens (big_integer/chip.rs:1220-1249) [+ RSAChip's 32/8, src/chip.rs:252]: the bit lengths
+    RangeChip::configure is given (composition + overflow)."""
+    wm = word_max(w, L)
+    carry_bits = (2 * wm).bit_length() - w
+    comp = [w // 8, 1, max(1, carry_bits // 8)]
+    over = [0, 0, carry_bits % max(1, carry_bits // 8)]
+    if rsa:
+        comp.append(32 // 8)
+    return comp + over
+
+
+class Image:
+    """Rows of (cells[5] as canonical field elements, kind)."""
+
+    def __init__(self, w, L, P):
+        self.w, self.L, self.P = w, L, P
+        self.rows, self.kinds = [], []
+
+    def row(self, kind, *cells):
+        cells = list(cells) + [0] * (5 - len(cells))
+        self.rows.append([c % self.P for c in cells])
+        self.kinds.append(kind)
+
+    # ---- main-gate ops (maingate instructions, restated) -----------------------------------------------------
+    def assign_constant(self, c):
+        self.row({0: ROW_CONST0, 1: ROW_CONST1}.get(c, ROW_CONST_B), c)
+
+    def assign_bit(self, v):
+        self.row(ROW_BIT, v, v, v)
+
+    def assign_value(self, v):
+        self.row(ROW_VALUE, v)
+
+    def is_equal(self, x, y, flag):
+        """is_equal(x, y) = sub + is_zero: [x, y, d], assign_bit(r), [d, d', r], [r, d]; r must equal the stream's flag."""
+        d = (x - y) % self.P
+        r = 1 if d == 0 else 0
+        assert r == flag
+        inv = 1 if d == 0 else pow(d, self.P - 2, self.P)
+        self.row(ROW_SUB, x, y, d)
+        self.assign_bit(r)
+        self.row(ROW_ISZERO_INV, d, inv, r)
+        self.row(ROW_ISZERO_RA, r, d)
+
+    def range_assign(self, value, subs, sub_bits, kind0):
+        """RangeChip::assign -> main_gate.decompose: chunks of four terms (columns a..d), column e = what remains to be
+        composed (row 0: the value itself); the LAST chunk is reversed so that the last (overflow) term sits in column a."""
+        remaining = value
+        nrows = (len(subs) + 3) // 4
+        for rr in range(nrows):
+            chunk = subs[4 * rr:4 * rr + 4]
+            comp = sum(sv << ((4 * rr + k) * sub_bits) for k, sv in enumerate(chunk))
+            cells = list(chunk)
+            if rr == nrows - 1:
+                cells = cells[::-1]
+                assert comp == remaining
+            self.row(kind0 + rr, *(cells + [0] * (4 - len(cells))), remaining)
+            remaining -= comp
+        assert remaining == 0
+
+
+def mul_mod_image(p, a, b, n, stream, P):
+    """p: oracle params (w, L, LB, WB, CB, carry_bits, carry_sub_bits, carry_nsub); a, b, n: limb lists; stream: the
+    mul_mod flat stream.  Returns the Image of the whole BigIntChip::mul_mod (chip.rs:542-629), every cell included."""
     w, L = p.w, p.L
     LB, WB, CB = p.LB, p.WB, p.CB
     C = 2 * L - 1
@@ -19,46 +122,38 @@ def advice_image_from_stream(p, a, b, n, stream, field_modulus):
         pos += nb
         return v
 
-    rows = []
-
-    def row(*cells):
-        cells = list(cells) + [0] * (5 - len(cells))
-        rows.append([c % field_modulus for c in cells])
-
-    def range_rows(value, subs, sub_bits):
-        run = 0
-        for r0 in range(0, len(subs), 4):
-            chunk = subs[r0:r0 + 4]
-            for k, sv in enumerate(chunk):
-                run += sv << ((r0 + k) * sub_bits)
-            row(*(chunk + [0] * (4 - len(chunk))), run)
-        assert run == value
-
+    im = Image(w, L, P)
+    W = word_max(w, L)
     q, r = [], []
-    for which in (q, r):                                    # T1 / T2
+    for which in (q, r):                                    # T1 / T2   chip.rs:588-599
         for _ in range(L):
             v = take(LB)
             subs = [take(1) for _ in range(8)]
             which.append(v)
-            range_rows(v, subs, w // 8)
+            im.range_assign(v, subs, w // 8, ROW_RANGE_LIMB)
     ab, qn = [], []
-    for (x, y, cols) in ((a, b, ab), (q, n, qn)):           # T3 / T4: column i ascending, j ascending
+    for (x, y, cols) in ((a, b, ab), (q, n, qn)):           # T3 / T4   chip.rs:400-412
         for i in range(C):
+            im.assign_constant(0)                            # :402
             prev = 0
             for j in range(max(0, i - L + 1), min(i, L - 1) + 1):
                 acc = take(WB)
-                row(x[j], y[i - j], prev, acc)
+                im.row(ROW_MUL_ADD, x[j], y[i - j], prev, acc)
                 prev = acc
             cols.append(prev)
     eqb = []
-    for i in range(L):                                       # T5
+    for i in range(L):                                       # T5        chip.rs:617
         v = take(WB)
-        row(qn[i], r[i], v)
+        im.row(ROW_ADD, qn[i], r[i], v)
         eqb.append(v)
     eqb += qn[L:]
     B = 1 << w
+    im.assign_constant(B)                                    # limb_max          chip.rs:851
+    im.assign_constant(0)                                    # accumulated_extra :852
+    im.assign_constant(0)                                    # carry[0]          :855
+    im.assign_bit(1)                                         # eq_bit            :856
     carry_prev, x_prev, eq_prev = 0, 0, 1
-    for i in range(C):                                       # T6
+    for i in range(C):                                       # T6        chip.rs:857-893
         a_b = take(WB, signed=True)
         s = take(WB)
         cy = take(CB)
@@ -71,26 +166,149 @@ def advice_image_from_stream(p, a, b, n, stream, field_modulus):
         nq2 = take(WB)
         amnq2 = take(LB)
         f1, e1 = take(1), take(1)
-        row(ab[i], eqb[i], a_b)
-        row(a_b, carry_prev, s)
-        row(cy); row(c); row(B, cy, nq); row(s, nq, amnq); row(c, amnq)
-        row(x_prev, accx)
-        row(qacc); row(modacc); row(B, qacc, nq2); row(accx, nq2, amnq2); row(modacc, amnq2)
-        row(c, modacc, f1)
-        row(eq_prev, f1, e1)
+        im.row(ROW_SUB, ab[i], eqb[i], a_b)                                # :859
+        im.row(ROW_ADD_WM, a_b, carry_prev, s)                             # :860-861
+        im.assign_value(cy); im.assign_value(c)                            # div_mod_main_gate :1341-1344
+        im.row(ROW_MUL, B, cy, nq); im.row(ROW_SUB, s, nq, amnq); im.row(ROW_ASSERT_EQ, c, amnq)   # :1345-1347
+        im.row(ROW_ADDC_WM, x_prev, accx)                                  # :869-870
+        im.assign_value(qacc); im.assign_value(modacc)
+        im.row(ROW_MUL, B, qacc, nq2); im.row(ROW_SUB, accx, nq2, amnq2); im.row(ROW_ASSERT_EQ, modacc, amnq2)
+        im.is_equal(c, modacc, f1)                                         # :873
+        im.row(ROW_MUL, eq_prev, f1, e1)                                   # and, :874
         if i < C - 1:
             dup = take(CB)
             subs = [take(1) for _ in range(p.carry_nsub)]
-            range_rows(dup, subs, p.carry_sub_bits)
+            im.range_assign(dup, subs, p.carry_sub_bits, ROW_RANGE_CARRY)  # :879-885
             f2, e2 = take(1), take(1)
-            row(cy, dup, f2)
+            im.is_equal(cy, dup, f2)                                       # :886
         else:
             f2, e2 = take(1), take(1)
-            row(cy, qacc, f2)
-        row(e1, f2, e2)
+            im.is_equal(cy, qacc, f2)                                      # :890
+        im.row(ROW_MUL, e1, f2, e2)                                        # and, :887 / :891
         carry_prev, x_prev, eq_prev = cy, qacc, e2
     assert pos == len(st)
-    out = np.zeros((len(rows), 160), dtype=np.uint8)
-    for ri, cells in enumerate(rows):
+    return im
+
+
+def image_bytes(im):
+    out = np.zeros((len(im.rows), 160), dtype=np.uint8)
+    for ri, cells in enumerate(im.rows):
         out[ri] = np.frombuffer(b"".join(int(c).to_bytes(32, "little") for c in cells), dtype=np.uint8)
     return out
+
+
+def advice_image_from_stream(p, a, b, n, stream, field_modulus):
+    """uint8 [rows, 160]: the advice image of one mul_mod (five 32-byte little-endian cells per row)."""
+    return image_bytes(mul_mod_image(p, a, b, n, stream, field_modulus))
+
+
+# ---- fixed columns -------------------------------------------------------------------------------------------------
+FIXED_NAMES = ("sa", "sb", "sc", "sd", "se", "s_mul_ab", "s_mul_cd", "se_next", "s_const")
+
+
+def fixed_row(kind, w, L, carry_bits, carry_sub_bits, carry_nsub, cfg):
+    """Selectors of one row kind as a dict (integers, reduce mod p), plus tag_composition / tag_overflow (0 = lookup off)."""
+    f = dict.fromkeys(FIXED_NAMES, 0)
+    f["tag_composition"] = f["tag_overflow"] = 0
+    B, W = 1 << w, word_max(w, L)
+    if kind in (ROW_CONST0, ROW_CONST1, ROW_CONST_B):
+        f["sa"] = 1
+        f["s_const"] = -{ROW_CONST0: 0, ROW_CONST1: 1, ROW_CONST_B: B}[kind]
+    elif kind == ROW_BIT:
+        f["s_mul_ab"], f["sc"] = 1, -1
+    elif kind == ROW_MUL_ADD:
+        f["s_mul_ab"], f["sc"], f["sd"] = 1, 1, -1
+    elif kind == ROW_ADD:
+        f["sa"], f["sb"], f["sc"] = 1, 1, -1
+    elif kind == ROW_SUB:
+        f["sa"], f["sb"], f["sc"] = 1, -1, -1
+    elif kind == ROW_ADD_WM:
+        f["sa"], f["sb"], f["sc"], f["s_const"] = 1, 1, -1, W
+    elif kind == ROW_ADDC_WM:
+        f["sa"], f["sb"], f["s_const"] = 1, -1, W
+    elif kind == ROW_MUL:
+        f["s_mul_ab"], f["sc"] = 1, -1
+    elif kind == ROW_ASSERT_EQ:
+        f["sa"], f["sb"] = 1, -1
+    elif kind == ROW_ISZERO_INV:
+        f["s_mul_ab"], f["sc"], f["s_const"] = 1, 1, -1
+    elif kind == ROW_ISZERO_RA:
+        f["s_mul_ab"] = 1
+    elif kind >= ROW_RANGE_LIMB:
+        carry = kind >= ROW_RANGE_CARRY
+        rr = kind - (ROW_RANGE_CARRY if carry else ROW_RANGE_LIMB)
+        s = carry_sub_bits if carry else w // 8
+        nsub = carry_nsub if carry else 8
+        nrows = (nsub + 3) // 4
+        idx = list(range(4 * rr, min(4 * rr + 4, nsub)))
+        last = rr == nrows - 1
+        if last:
+            idx = idx[::-1]
+        for name, k in zip(("sa", "sb", "sc", "sd"), idx):
+            f[name] = 1 << (k * s)
+        f["se"] = -1
+        f["se_next"] = 0 if last else 1
+        f["tag_composition"] = cfg.tag_of[s]
+        ov = (carry_bits % s) if carry else 0
+        if last and ov:
+            f["tag_overflow"] = cfg.tag_of[ov]
+    return f
+
+
+def gate_residual(cells, e_next, f, P):
+    a, b, c, d, e = cells
+    return (f["sa"] * a + f["sb"] * b + f["sc"] * c + f["sd"] * d + f["se"] * e + f["s_mul_ab"] * a * b + f["s_mul_cd"] * c * d +
+            f["se_next"] * e_next + f["s_const"]) % P
+
+
+# ---- halo2's lookup argument (prover side), restated ----------------------------------------------------------------
+def lookup_inputs(rows, fixed_rows, usable_rows):
+    """Per lookup argument the (tag, value) input of every usable row: composition_a..d read columns a..d under
+    tag_composition, overflow_a reads column a under tag_overflow; value = selector * advice, so a row with the lookup off
+    contributes (0, 0).  Rows past the image (the rest of the circuit) are (0, 0)."""
+    out = {name: [(0, 0)] * usable_rows for name in ARGS}
+    for ri, (cells, f) in enumerate(zip(rows, fixed_rows)):
+        if f["tag_composition"]:
+            for k in range(4):
+                out[ARGS[k]][ri] = (f["tag_composition"], cells[k])
+        if f["tag_overflow"]:
+            out[ARGS[4]][ri] = (f["tag_overflow"], cells[0])
+    return out
+
+
+def compress(pairs, theta, P):
+    """halo2 `compress_expressions`: fold(0, |acc, e| acc * theta + e) over (tag, value) = tag * theta + value."""
+    return [(t * theta + v) % P for (t, v) in pairs]
+
+
+def permute_expression_pair(inp, table):
+    """halo2 (v0.2 / PSE fork) plonk::lookup::prover::permute_expression_pair on the usable rows, without the blinding tail:
+    sorted input A'; S' = the input value on the first row of every run, the leftover table values (ascending, popped from
+    the END of the list of repeated rows) elsewhere.  Field `Ord` = order of the canonical integers."""
+    usable = len(inp)
+    assert len(table) == usable
+    a_perm = sorted(inp)
+    leftover = {}
+    for c in table:
+        leftover[c] = leftover.get(c, 0) + 1
+    s_perm = [0] * usable
+    repeated = []
+    for row, v in enumerate(a_perm):
+        if row == 0 or v != a_perm[row - 1]:
+            s_perm[row] = v
+            assert leftover.get(v, 0) > 0, "input value not in the table"
+            leftover[v] -= 1
+        else:
+            repeated.append(row)
+    for coeff in sorted(leftover):
+        for _ in range(leftover[coeff]):
+            s_perm[repeated.pop()] = coeff
+    assert not repeated
+    return a_perm, s_perm
+
+
+def table_column(cfg, theta, usable_rows, P):
+    """The compressed table expression over the usable rows: the table's rows, then the default (first) row (0, 0)."""
+    t = compress(cfg.table(), theta, P)
+    assert len(t) <= usable_rows
+    return t + [0] * (usable_rows - len(t))

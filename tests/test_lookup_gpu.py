@@ -1,0 +1,180 @@
+"""GPU: halo2's lookup argument for the range checks (h2r_lookup_*) against the Python restatement of RangeChip's placement
+and of halo2's permute_expression_pair (tests/advice_ref.py) run on the ORACLE's cells."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import advice_ref as AR
+from oracle_lib import Oracle
+from test_maingate_image_ref import FIELDS
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    import halo2_rsa_amd as H
+    return H
+
+
+def _circuit_reference(o, chip_w, L, P, cfg, x, n, e, usable):
+    """The oracle's cells of one circuit = assign_integer(x), assign_integer(n) (big_integer/chip.rs:71-76) followed by every
+    mul_mod of pow_mod_fixed_exp(x, e, n), as main-gate rows; returns per-argument (tag, value) inputs over `usable` rows."""
+    w = chip_w
+    rows, kinds = [], []
+    pre = AR.Image(w, L, P)
+    for v in (x, n):
+        for k in range(L):
+            limb = (v >> (w * k)) & ((1 << w) - 1)
+            pre.range_assign(limb, [(limb >> ((w // 8) * t)) & ((1 << (w // 8)) - 1) for t in range(8)], w // 8, AR.ROW_RANGE_LIMB)
+    rows += pre.rows
+    kinds += pre.kinds
+    # the mul_mods in the reference's call order (chip.rs:731-740), each from the oracle's own stream
+    nl = [int(t) for t in o.limbs(n)]
+    acc, sq = 1, x
+    bits = [(e >> i) & 1 for i in range(e.bit_length())]
+    calls = []
+    for bit in bits:
+        cur = sq
+        calls.append((cur, cur))
+        sq = cur * cur % n
+        if bit:
+            calls.append((acc, cur))
+            acc = acc * cur % n
+    for (a, b) in calls:
+        rc, r, st = o.mul_mod(o.limbs(a), o.limbs(b), o.limbs(n))
+        assert rc == 0
+        im = AR.mul_mod_image(o.p, [int(t) for t in o.limbs(a)], [int(t) for t in o.limbs(b)], nl, st, P)
+        rows += im.rows
+        kinds += im.kinds
+    fixed = [AR.fixed_row(k, w, L, o.p.carry_bits, o.p.carry_sub_bits, o.p.carry_nsub, cfg) for k in kinds]
+    assert len(rows) <= usable
+    return AR.lookup_inputs(rows, fixed, usable), len(calls), acc
+
+
+@pytest.mark.parametrize("w,L,e,field,rsa", [(64, 32, 5, "bn254_fr", True), (32, 8, 0b1011, "pasta_fp", False),
+                                             (64, 4, 65537, "bn254_fq", False), (32, 128, 3, "pasta_fq", False)])
+def test_lookup_hist_and_permuted_columns(H, w, L, e, field, rsa):
+    from halo2_rsa_amd import _lib
+    P = FIELDS[field]
+    chip = H.BigIntChip(w, w * L, field=field)
+    o = Oracle(w, L)
+    rng = random.Random(31 * w + L)
+    bits = w * L
+    batch = 3
+    N = [rng.getrandbits(bits) | (1 << (bits - 1)) | 1 for _ in range(batch)]
+    X = [rng.randrange(n) for n in N]
+    x_dev, n_dev = chip.assign_integer(X), chip.assign_integer(N)
+    res = chip.pow_mod_fixed_exp(x_dev, e, n_dev)
+    la = H.LookupArgument(chip, rsa_chip=rsa)
+    cfg = AR.LookupConfig(AR.range_lens(w, L, rsa=rsa))
+    assert la.table_image() == cfg.table()
+    hist = la.new_hist(batch)
+    la.hist_values(x_dev.limbs_dev, w, w // 8, hist)          # assign_integer(x), assign_integer(n): chip.rs:71-76
+    la.hist_values(n_dev.limbs_dev, w, w // 8, hist)
+    la.hist_records(res.trace, hist, res.status)
+    torch.cuda.synchronize()
+    assert not res.status.cpu().numpy().any()
+    rows_per_circuit = 4 * L + res.trace.num_mul_mods * (4 * L + 2 * (2 * L - 1 + L * L) + L + 4 + (2 * L - 2) * (23 + (o.p.carry_nsub + 3) // 4) + 23)
+    k = max(rows_per_circuit + 6, cfg.n_rows + 6).bit_length()
+    usable = (1 << k) - 6          # blinding_factors + 1 = 6 rows of a main-gate circuit are not usable
+    thetas = [rng.randrange(P), 1, P - 1][:batch]            # theta = 1 makes table rows collide ((1,1) and (2,0) both compress to 2)
+    a_perm, s_perm, status = la.permuted_columns(hist, thetas, usable)
+    torch.cuda.synchronize()
+    assert not status.cpu().numpy().any()
+    hist_h = hist.cpu().numpy()
+    row_of = {pair: i for i, pair in enumerate(cfg.table())}
+    for b in range(batch):
+        inputs, n_calls, acc = _circuit_reference(o, w, L, P, cfg, X[b], N[b], e, usable)
+        assert n_calls == res.trace.num_mul_mods and res.value.to_big_uint()[b] == acc
+        tcol = AR.table_column(cfg, thetas[b], usable, P)
+        for k_arg, name in enumerate(AR.ARGS):
+            want_hist = np.zeros(cfg.n_rows, dtype=np.int64)
+            for pair in inputs[name]:
+                if pair != (0, 0):
+                    want_hist[row_of[pair]] += 1
+            assert np.array_equal(hist_h[b, k_arg], want_hist), (b, name)
+            A = AR.compress(inputs[name], thetas[b], P)
+            a_ref, s_ref = AR.permute_expression_pair(A, tcol)
+            got_a = a_perm[b, k_arg].cpu().numpy().tobytes()
+            got_s = s_perm[b, k_arg].cpu().numpy().tobytes()
+            assert got_a == b"".join(v.to_bytes(32, "little") for v in a_ref), (b, name, "A'")
+            assert got_s == b"".join(v.to_bytes(32, "little") for v in s_ref), (b, name, "S'")
+
+
+def test_lookup_rejects_what_does_not_fit(H):
+    from halo2_rsa_amd import _lib
+    chip = H.BigIntChip(64, 2048)
+    la = H.LookupArgument(chip)
+    hist = la.new_hist(2)
+    hist[1, 0, 5] = 1000
+    a, s, status = la.permuted_columns(hist, [7, 7], 512)     # 339 table rows fit 512 usable rows; 1,000 inputs do not
+    torch.cuda.synchronize()
+    assert status.cpu().tolist() == [0, _lib.H2R_E_SHAPE]
+    with pytest.raises(_lib.H2RError):
+        la.permuted_columns(hist, [7, 7], 300)                # fewer usable rows than table rows
+    res = chip.mul_mod(chip.assign_integer([1]), chip.assign_integer([1]), chip.assign_integer([3]))
+    no6 = H.LookupArgument(chip, bit_lens=[8, 1], tags=[1, 2])          # a table without the 6-bit overflow length of the carries
+    with pytest.raises(_lib.H2RError):
+        no6.hist_records(res.trace, no6.new_hist(1))                     # RangeChip::assign has no table for that bit length
+
+
+def test_lookup_full_size_invariants(H):
+    """BASELINE config 2's size: 1,024 circuits of k = 17 (131,066 usable rows), every argument -- the lookup argument's own
+    invariants checked on the DEVICE for every row of every column: A' sorted ascending and a permutation of the inputs
+    (multiset equality through the run lengths = the multiplicities), S' a permutation of the table column, and on every row
+    A'[i] == S'[i] or A'[i] == A'[i-1]."""
+    chip = H.BigIntChip(64, 2048)
+    rng = random.Random(2048)
+    B = 1024
+    N = [rng.getrandbits(2048) | (1 << 2047) | 1 for _ in range(B)]
+    X = [rng.randrange(n) for n in N]
+    x_dev, n_dev = chip.assign_integer(X), chip.assign_integer(N)
+    res = chip.pow_mod_fixed_exp(x_dev, 65537, n_dev)
+    la = H.LookupArgument(chip)
+    hist = la.new_hist(B)
+    la.hist_values(x_dev.limbs_dev, 64, 8, hist)
+    la.hist_values(n_dev.limbs_dev, 64, 8, hist)
+    la.hist_records(res.trace, hist, res.status)
+    usable = (1 << 17) - 6
+    P = FIELDS["bn254_fr"]
+    thetas = [rng.randrange(P) for _ in range(B)]
+    CH = 128                                   # circuits per call: 128 x 5 x 2 x 4.2 MB = 5.4 GB of columns at a time
+    tab = la.table_image()
+    for c0 in range(0, B, CH):
+        a_perm, s_perm, status = la.permuted_columns(hist[c0:c0 + CH].contiguous(), thetas[c0:c0 + CH], usable)
+        assert not status.cpu().numpy().any()
+        A = a_perm.view(torch.int64).view(CH, 5, usable, 4)      # little-endian words; values < 2^255: signed compare of the top word is fine
+        S = s_perm.view(torch.int64).view(CH, 5, usable, 4)
+        eq_as = (A == S).all(-1)
+        eq_prev = torch.zeros_like(eq_as)
+        eq_prev[:, :, 1:] = (A[:, :, 1:] == A[:, :, :-1]).all(-1)
+        assert bool((eq_as | eq_prev).all())                     # the adjacency rule of the lookup argument
+        # ascending: compare as (w3, w2, w1, w0) tuples; words are < 2^63 only for w3, so compare the others as unsigned via xor of the sign bit
+        def key(T):
+            return [T[..., 3], T[..., 2] ^ (-2 ** 63), T[..., 1] ^ (-2 ** 63), T[..., 0] ^ (-2 ** 63)]
+        ka, kb = key(A[:, :, :-1]), key(A[:, :, 1:])
+        le = torch.ones_like(ka[0], dtype=torch.bool)
+        decided = torch.zeros_like(le)
+        for u, v in zip(ka, kb):
+            le = torch.where(~decided & (u > v), torch.zeros_like(le), le)
+            decided = decided | (u != v)
+        assert bool(le.all())
+        # multiset equality: the number of run heads of A' = distinct values with inputs, and every circuit has the same number of
+        # zero inputs as rows without a lookup; S' sums (as integers mod 2^64 per word) equal the table column's sums
+        heads = (~eq_prev).sum(-1)
+        nz = (hist[c0:c0 + CH] > 0).sum(-1) + 1                 # + the (0, 0) run
+        assert torch.equal(heads.to(torch.int64), nz.to(torch.int64))
+        for b in (0, CH - 1):                                    # two circuits per chunk: exact multiset check on the host
+            th = thetas[c0 + b]
+            tcol = sorted([(t * th + v) % P for (t, v) in tab] + [0] * (usable - len(tab)))
+            for k_arg in (0, 4):
+                got = sorted(int.from_bytes(bytes(r), "little") for r in s_perm[b, k_arg].cpu().numpy())
+                assert got == tcol
+                h = hist[c0 + b, k_arg].cpu().tolist()
+                want_a = sorted([0] * (usable - sum(h)) + [((tab[i][0] * th + tab[i][1]) % P) for i, m in enumerate(h) for _ in range(m)])
+                got_a = [int.from_bytes(bytes(r), "little") for r in a_perm[b, k_arg].cpu().numpy()]
+                assert got_a == want_a
+        del a_perm, s_perm, A, S

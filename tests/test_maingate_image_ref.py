@@ -1,0 +1,76 @@
+"""CPU: the main-gate image restated in tests/advice_ref.py is a SATISFYING assignment on the oracle's cells -- every row
+fulfils the main-gate equation with its fixed row, every lookup input is a row of the (tag, value) table, and halo2's
+permuted columns built from it obey the lookup argument's invariants.  (The third-party placement itself is unpinned;
+this pins that the restatement is self-consistent, which is what the GPU image is then compared with cell for cell.)"""
+import random
+
+import pytest
+
+import advice_ref as AR
+from oracle_lib import Oracle
+
+FIELDS = {
+    "bn254_fr": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+    "bn254_fq": 21888242871839275222246405745257275088696311157297823662689037894645226208583,
+    "pasta_fp": 28948022309329048855892746252171976963363056481941560715954676764349967630337,
+    "pasta_fq": 28948022309329048855892746252171976963363056481941647379679742748393362948097,
+}
+
+
+def _case(w, L, seed):
+    o = Oracle(w, L)
+    rng = random.Random(seed)
+    bits = w * L
+    n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+    a, b = rng.randrange(n), rng.randrange(n)
+    rc, r, st = o.mul_mod(o.limbs(a), o.limbs(b), o.limbs(n))
+    assert rc == 0
+    return o, [int(x) for x in o.limbs(a)], [int(x) for x in o.limbs(b)], [int(x) for x in o.limbs(n)], st
+
+
+@pytest.mark.parametrize("w,L,field", [(64, 32, "bn254_fr"), (32, 16, "pasta_fp"), (64, 4, "bn254_fq"), (32, 128, "pasta_fq")])
+def test_image_satisfies_the_main_gate_and_the_lookups(w, L, field):
+    P = FIELDS[field]
+    o, a, b, n, st = _case(w, L, 1000 * w + L)
+    im = AR.mul_mod_image(o.p, a, b, n, st, P)
+    C = 2 * L - 1
+    nrc = (o.p.carry_nsub + 3) // 4
+    assert len(im.rows) == 4 * L + 2 * (C + L * L) + L + 4 + (C - 1) * (23 + nrc) + 23
+    cfg = AR.LookupConfig(AR.range_lens(w, L, rsa=(w == 64)))
+    fixed = [AR.fixed_row(k, w, L, o.p.carry_bits, o.p.carry_sub_bits, o.p.carry_nsub, cfg) for k in im.kinds]
+    for ri, (cells, f) in enumerate(zip(im.rows, fixed)):
+        e_next = im.rows[ri + 1][4] if ri + 1 < len(im.rows) else 0
+        assert AR.gate_residual(cells, e_next, f, P) == 0, (ri, im.kinds[ri])
+    table = set(cfg.table())
+    usable = len(im.rows) + 37
+    inputs = AR.lookup_inputs(im.rows, fixed, usable)
+    n_range_rows = 4 * L + (C - 1) * nrc
+    for name in AR.ARGS:
+        assert all(pair in table for pair in inputs[name]), name
+    assert sum(1 for pr in inputs["composition_a"] if pr[0]) == n_range_rows
+    has_ov = o.p.carry_bits % o.p.carry_sub_bits != 0
+    assert sum(1 for pr in inputs["overflow_a"] if pr[0]) == ((C - 1) if has_ov else 0)
+
+
+@pytest.mark.parametrize("theta_kind", ["random", "colliding"])
+def test_permuted_columns_invariants(theta_kind):
+    """halo2's lookup argument needs: A' is a permutation of A, S' of S, and on every row A'[i] == S'[i] or A'[i] == A'[i-1].
+    `colliding`: a theta under which two different table rows compress to the same element (theta = 1: 1 * theta + 1 == 2 * theta + 0):
+    the algorithm merges them (BTreeMap keyed by the compressed value)."""
+    w, L, P = 32, 8, FIELDS["bn254_fr"]
+    o, a, b, n, st = _case(w, L, 77)
+    im = AR.mul_mod_image(o.p, a, b, n, st, P)
+    cfg = AR.LookupConfig(AR.range_lens(w, L))
+    fixed = [AR.fixed_row(k, w, L, o.p.carry_bits, o.p.carry_sub_bits, o.p.carry_nsub, cfg) for k in im.kinds]
+    usable = 1 << 11
+    assert usable >= len(im.rows) and usable >= cfg.n_rows
+    theta = 1 if theta_kind == "colliding" else random.Random(5).randrange(P)
+    inputs = AR.lookup_inputs(im.rows, fixed, usable)
+    tcol = AR.table_column(cfg, theta, usable, P)
+    if theta_kind == "colliding":
+        assert len(set(tcol)) < cfg.n_rows
+    for name in AR.ARGS:
+        A = AR.compress(inputs[name], theta, P)
+        a_perm, s_perm = AR.permute_expression_pair(A, tcol)
+        assert sorted(A) == a_perm and sorted(tcol) == sorted(s_perm)
+        assert all(a_perm[i] == s_perm[i] or (i and a_perm[i] == a_perm[i - 1]) for i in range(usable))
