@@ -55,6 +55,16 @@ class H2RLookupConfig(ctypes.Structure):
                 ("row_off", ctypes.c_uint32 * 8), ("n_rows", ctypes.c_uint32)]
 
 
+class H2RFixedRow(ctypes.Structure):
+    NAMES = ("sa", "sb", "sc", "sd", "se", "s_mul_ab", "s_mul_cd", "se_next", "s_const")
+    _fields_ = [(nm, ctypes.c_uint64 * 4) for nm in NAMES] + [("tag_composition", ctypes.c_uint32), ("tag_overflow", ctypes.c_uint32)]
+
+    def as_dict(self):
+        d = {nm: sum(int(getattr(self, nm)[k]) << (64 * k) for k in range(4)) for nm in self.NAMES}
+        d["tag_composition"], d["tag_overflow"] = int(self.tag_composition), int(self.tag_overflow)
+        return d
+
+
 class H2RError(RuntimeError):
     def __init__(self, code, where):
         self.code = code
@@ -77,7 +87,8 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_trace_lookup_permutation", "h2r_trace_lookup_permutation_hist",
            "h2r_trace_flatten", "h2r_pow_trace_flatten", "h2r_stream_bytes", "h2r_pow_stream_bytes", "h2r_trace_flatten_ex",
            "h2r_pow_trace_flatten_ex", "h2r_trace_emit_stream", "h2r_pow_trace_emit_stream", "h2r_mul_mod_trace_check", "h2r_pow_trace_check",
-           "h2r_advice_rows", "h2r_mul_mod_emit_advice", "h2r_pow_trace_emit_advice",
+           "h2r_advice_rows", "h2r_mul_mod_emit_advice", "h2r_pow_trace_emit_advice", "h2r_pow_advice_rows", "h2r_advice_row_kinds",
+           "h2r_advice_fixed_row",
            "h2r_lookup_config_default", "h2r_lookup_config_custom", "h2r_lookup_table_image", "h2r_lookup_hist_records",
            "h2r_lookup_hist_values", "h2r_lookup_workspace_bytes", "h2r_lookup_permuted_columns", "h2r_field_eval",
            "h2r_profile_enable", "h2r_profile_read", "h2r_status_str",
@@ -178,6 +189,10 @@ def lib():
     L.h2r_pow_trace_emit_stream.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, u64, u64, u32, vp, u64, u64, vp]
     L.h2r_advice_rows.argtypes = [vp]
     L.h2r_advice_rows.restype = u32
+    L.h2r_pow_advice_rows.argtypes = [vp, ctypes.POINTER(H2RPowLayout)]
+    L.h2r_pow_advice_rows.restype = u64
+    L.h2r_advice_row_kinds.argtypes = [vp, vp]
+    L.h2r_advice_fixed_row.argtypes = [vp, ctypes.POINTER(H2RLookupConfig), u32, ctypes.POINTER(H2RFixedRow)]
     L.h2r_mul_mod_emit_advice.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp, vp, u64, vp]
     L.h2r_pow_trace_emit_advice.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, u32, vp, u64, vp, u64, vp, vp, u64, vp]
     L.h2r_mul_mod_trace_check.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp, vp, vp, vp]

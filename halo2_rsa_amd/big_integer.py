@@ -215,7 +215,11 @@ class BatchResult:
         kind, a, b, n, eb = self.inputs
         flags = chip._flags(n, batch)
         T = self.trace.num_mul_mods
-        out = torch.empty((batch, T * rows * 160), dtype=torch.uint8, device=dev)
+        if kind != "mul_mod":   # a fixed-exponent pow element starts with the two constant rows of acc = 1 (h2r_pow_advice_rows)
+            nrows = int(lib().h2r_pow_advice_rows(chip._ctx, ctypes.byref(self.trace.pow_layout)))
+        else:
+            nrows = T * rows
+        out = torch.empty((batch, nrows * 160), dtype=torch.uint8, device=dev)
         if kind == "mul_mod":
             check(lib().h2r_mul_mod_emit_advice(chip._ctx, a.data_ptr(), b.data_ptr(), n.data_ptr(), flags, self.trace.buf.data_ptr(), batch,
                                                 self.status.data_ptr(), out.data_ptr(), out.shape[1], chip._stream()), "h2r_mul_mod_emit_advice")

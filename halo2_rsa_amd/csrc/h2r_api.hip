@@ -1953,8 +1953,8 @@ int32_t launch_advice(const h2r_ctx *ctx, AdviceArgs &aa, hipStream_t st) {
     aa.L = lo.num_limbs; aa.carry_bits = lo.carry_bits; aa.carry_sub_bits = lo.carry_sub_bits; aa.carry_nsub = lo.carry_nsub;
     aa.carry_sub_stride = lo.carry_sub_stride; aa.record_stride = lo.record_stride;
     aa.rows = h2r_advice_rows(ctx);
-    for (int k = 0; k < 4; ++k) aa.p[k] = ctx->field_p[k];
-    if (aa.out_stride < (u64)aa.T * aa.rows * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
+    aa.f = ctx->fc;
+    if (aa.out_stride < ((u64)aa.pre_rows + (u64)aa.T * aa.rows) * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
     if (aa.n_items == 0) return H2R_OK;
     if (aa.n_items >= (1ull << 31)) return H2R_E_UNSUPPORTED;
     ProfScope ps(H2R_KERNEL_EMIT, st, true);
@@ -1994,7 +1994,70 @@ int32_t h2r_pow_trace_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
     aa.status = status; aa.trace = static_cast<const u8 *>(trace); aa.elem_stride = elem_stride ? elem_stride : pl->elem_stride;
     aa.off_records = pl->off_records; aa.T = pl->num_mul_mods; aa.n_items = batch * pl->num_mul_mods;
     aa.out = static_cast<u8 *>(advice_out); aa.out_stride = out_stride;
+    aa.pre_rows = pl->off_e_bits == UINT64_MAX ? 2u : 0u;   // pow_mod_fixed_exp's acc = assign_constant(1, L): [1], [0] (chip.rs:729)
     return launch_advice(ctx, aa, static_cast<hipStream_t>(stream));
+}
+
+uint64_t h2r_pow_advice_rows(const h2r_ctx *ctx, const h2r_pow_layout *pl) {
+    if (!ctx || !pl) return 0;
+    return (pl->off_e_bits == UINT64_MAX ? 2ull : 0ull) + (u64)pl->num_mul_mods * h2r_advice_rows(ctx);
+}
+
+int32_t h2r_advice_row_kinds(const h2r_ctx *ctx, uint8_t *kinds_out) {
+    if (!ctx || !kinds_out) return H2R_E_NULL;
+    const u32 rows = h2r_advice_rows(ctx), nrc = (ctx->layout.carry_nsub + 3) / 4;
+    for (u32 r = 0; r < rows; ++r) kinds_out[r] = (uint8_t)advice_decode(r, ctx->L, nrc).kind;
+    return H2R_OK;
+}
+
+int32_t h2r_advice_fixed_row(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint32_t kind, h2r_fixed_row *out) {
+    if (!ctx || !out) return H2R_E_NULL;
+    std::memset(out, 0, sizeof *out);
+    const h2r_layout &lo = ctx->layout;
+    const u64 (&p)[4] = ctx->fc.p;
+    auto put = [&](uint64_t (&dst)[4], const Fe &v, bool neg) { const Fe r = neg ? fe_sub(fe_zero(), v, p) : v; for (int k = 0; k < 4; ++k) dst[k] = r.v[k]; };
+    const Fe one = fe_small(1);
+    Fe Bv = fe_zero(); if (lo.limb_width == 64) Bv.v[1] = 1; else Bv.v[0] = 1ull << 32;
+    Fe W; for (int k = 0; k < 4; ++k) W.v[k] = ctx->word_max.v[k];
+    auto pow2 = [&](u32 sh) { Fe r = fe_zero(); r.v[sh / 64] = 1ull << (sh % 64); return r; };
+    switch (kind) {
+        case ROWK_NOP: case ROWK_VALUE: break;
+        case ROWK_CONST0: put(out->sa, one, false); break;
+        case ROWK_CONST1: put(out->sa, one, false); put(out->s_const, one, true); break;
+        case ROWK_CONST_B: put(out->sa, one, false); put(out->s_const, Bv, true); break;
+        case ROWK_BIT: case ROWK_MUL: put(out->s_mul_ab, one, false); put(out->sc, one, true); break;
+        case ROWK_MUL_ADD: put(out->s_mul_ab, one, false); put(out->sc, one, false); put(out->sd, one, true); break;
+        case ROWK_ADD: put(out->sa, one, false); put(out->sb, one, false); put(out->sc, one, true); break;
+        case ROWK_SUB: put(out->sa, one, false); put(out->sb, one, true); put(out->sc, one, true); break;
+        case ROWK_ADD_WM: put(out->sa, one, false); put(out->sb, one, false); put(out->sc, one, true); put(out->s_const, W, false); break;
+        case ROWK_ADDC_WM: put(out->sa, one, false); put(out->sb, one, true); put(out->s_const, W, false); break;
+        case ROWK_ASSERT_EQ: put(out->sa, one, false); put(out->sb, one, true); break;
+        case ROWK_ISZERO_INV: put(out->s_mul_ab, one, false); put(out->sc, one, false); put(out->s_const, one, true); break;
+        case ROWK_ISZERO_RA: put(out->s_mul_ab, one, false); break;
+        default: {
+            const bool carry = kind >= ROWK_RANGE_CARRY;
+            const u32 rr = kind - (carry ? ROWK_RANGE_CARRY : ROWK_RANGE_LIMB);
+            const u32 s = carry ? lo.carry_sub_bits : lo.limb_sub_bits, nsub = carry ? lo.carry_nsub : lo.limb_nsub;
+            const u32 nrows = (nsub + 3) / 4;
+            if (kind < ROWK_RANGE_LIMB || (!carry && kind >= ROWK_RANGE_LIMB + 8) || rr >= nrows) return H2R_E_SHAPE;
+            const bool last = rr == nrows - 1;
+            uint64_t (*sel[4])[4] = {&out->sa, &out->sb, &out->sc, &out->sd};
+            const u32 k0 = 4 * rr, k1 = std::min(4 * rr + 4, nsub);
+            for (u32 q = 0; q < k1 - k0; ++q) put(*sel[q], pow2((last ? k1 - 1 - q : k0 + q) * s), false);
+            put(out->se, one, true);
+            if (!last) put(out->se_next, one, false);
+            if (cfg) {   // the lookup tags of the row (0 = off)
+                const u32 ov = carry ? lo.carry_bits % s : 0;
+                for (u32 i = 0; i < cfg->n_lens; ++i) {
+                    if (cfg->bit_len[i] == s) out->tag_composition = cfg->tag[i];
+                    if (last && ov && cfg->bit_len[i] == ov) out->tag_overflow = cfg->tag[i];
+                }
+                if (!out->tag_composition || (last && ov && !out->tag_overflow)) return H2R_E_SHAPE;
+            }
+            break;
+        }
+    }
+    return H2R_OK;
 }
 
 // ---- in-place audit ----------------------------------------------------------------------------------------

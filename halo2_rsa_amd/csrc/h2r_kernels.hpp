@@ -20,6 +20,7 @@
 #include <cstdint>
 
 #include "h2r.h"
+#include "h2r_field.hpp"
 
 namespace h2r {
 
@@ -2473,71 +2474,118 @@ __global__ __launch_bounds__(64) void link_kernel(LinkArgs a) {
 }
 
 // ================================================================================================
-// K9: advice-column image -- the witness as rows of the main gate's five advice columns (first step)
+// K9: advice-column image -- the witness as rows of the main gate's five advice columns
 //   The reference's prover consumes ADVICE COLUMNS of field elements: every main-gate op is a row of five cells
-//   (maingate's columns a..e), every RangeChip::assign a run of rows holding four sub-limbs and a running sum.  This
-//   kernel writes that image for every mul_mod record of a batch, in HBM, in the reference's op order, as canonical
-//   32-byte little-endian elements of the ctx's field (a_b negative -> p - |x|).  The third-party row shapes are NOT
-//   in /root/reference (maingate / halo2wrong, rev 63bde545): they are restated from SURVEY Appendix A and documented in
-//   DESIGN.md section 2b -- the VALUES are pinned by the flat-stream parity, the PLACEMENT is unpinned.
-//   Rows of one mul_mod (nr = ceil(8 / 4) = 2 rows per range-assigned limb, nrc = ceil(carry_nsub / 4) per carry):
-//     q limbs, r limbs     2L x nr   [s4r, s4r+1, s4r+2, s4r+3, running sum]            (chip.rs:588-599)
-//     mul(a,b), mul(q,n)   2 x L^2   [x_j, y_{i-j}, acc_prev, acc, 0]   column i, then j  (chip.rs:400-412, mul_add)
-//     eq_b                 L         [qn_i, r_i, eq_b_i, 0, 0]                           (chip.rs:617, add)
-//     per column i of is_equal_muled (chip.rs:857-893), 17 rows + the carry's range assign:
-//        0 sub            [ab_i, eqb_i, a_b, 0, 0]            1 add_with_constant [a_b, carry_i, sum, 0, 0]
-//        2..6 div_mod     [q] [r] [2^w, q, nq] [sum, nq, sum - nq] [r, sum - nq]          (chip.rs:1323-1349)
-//        7 add_constant   [acc_extra, acc_extra + W]          8..12 div_mod of it
-//        13 is_equal      [c, mod_acc, cs_acc_eq]             14 and [eq_bit, cs_acc_eq, eq_bit']
-//        i < C-1: nrc range rows of carry_{i+1}, then is_equal [carry, dup, range_eq], and [eq_bit', range_eq, eq_bit'']
-//        i = C-1: is_equal [carry, acc_extra, final_eq], and [eq_bit', final_eq, eq_bit'']
+//   (maingate's columns a..e), every RangeChip::assign a run of rows holding four sub-limbs and what remains to be composed.
+//   This kernel writes that image for every mul_mod record of a batch, in HBM, in the reference's op order, as canonical
+//   32-byte little-endian elements of the ctx's field -- EVERY cell the ops assign: the flat stream's values, the constants
+//   (assign_constant), the literal bits (assign_bit(1)) and main_gate.is_zero's internal witnesses (difference, its inverse).
+//   The third-party row shapes are NOT in /root/reference (maingate / halo2wrong, rev 63bde545): they are restated in
+//   DESIGN.md section 2b -- the VALUES are pinned by the flat-stream parity, the PLACEMENT is unpinned but self-consistent:
+//   every row satisfies the main-gate equation with the fixed row h2r_advice_fixed_row gives for its kind (tests).
+//   Rows of one mul_mod (nr = 2 rows per range-assigned limb, nrc = ceil(carry_nsub / 4) per carry), kinds H2R_ROW_*:
+//     q limbs, r limbs     2L x nr   RANGE_LIMB  [four sub-limbs (last row reversed), remaining]      (chip.rs:588-599)
+//     mul(a,b), mul(q,n)   per column i: CONST0 [0], then MUL_ADD [x_j, y_{i-j}, acc_prev, acc]       (chip.rs:400-412)
+//     eq_b                 L         ADD [qn_i, r_i, eq_b_i]                                          (chip.rs:617)
+//     is_equal_muled       CONST_B [2^w], CONST0, CONST0, BIT [1,1,1]                                  (chip.rs:851-856)
+//     per column i (chip.rs:857-893), 23 rows + the carry's range assign:
+//        0 SUB [ab_i, eqb_i, a_b]  1 ADD_WM [a_b, carry_i, sum]  2 VALUE [q]  3 VALUE [r]  4 MUL [2^w, q, nq]  5 SUB [sum, nq, sum-nq]
+//        6 ASSERT_EQ [r, sum-nq]   7 ADDC_WM [acc_extra, acc_extra+W]   8..12 the same div_mod of it
+//        13..16 is_equal(c, mod_acc): SUB [c, mod_acc, d], BIT [f,f,f], ISZERO_INV [d, 1/d or 1, f], ISZERO_RA [f, d]   17 MUL (and) [eq_bit, f, eq_bit']
+//        i < C-1: nrc RANGE_CARRY rows of carry_{i+1}; then is_equal(carry, dup) (4 rows) and MUL (and)
+//        i = C-1: is_equal(carry, acc_extra) (4 rows) and MUL (and)
 //   One workgroup per record, one thread per row (ten 16-byte stores of 160 contiguous bytes).  Bound: HBM writes
-//   (554,400 bytes per RSA-2048 mul_mod: 8.6 x the flat stream -- what materialising field-element cells costs).
+//   (635,680 bytes per RSA-2048 mul_mod: 9.9 x the flat stream -- what materialising field-element cells costs).
 // ================================================================================================
+enum : u32 { ROWK_NOP = 0, ROWK_CONST0, ROWK_CONST1, ROWK_CONST_B, ROWK_BIT, ROWK_VALUE, ROWK_MUL_ADD, ROWK_ADD, ROWK_SUB, ROWK_ADD_WM,
+             ROWK_ADDC_WM, ROWK_MUL, ROWK_ASSERT_EQ, ROWK_ISZERO_INV, ROWK_ISZERO_RA, ROWK_RANGE_LIMB = 32, ROWK_RANGE_CARRY = 40 };
+
 template <int LW>
 struct RecView {   // reads of one record through the documented plane layout (include/h2r.h)
     const u8 *rec; const u64 *off; u32 L;
     static constexpr u32 CB = LW == 64 ? 16 : 8;
-    __device__ __forceinline__ U192 wide(int pl_lo, u32 idx) const {   // sign-extending
-        const u64 *lo = reinterpret_cast<const u64 *>(rec + off[pl_lo] + (u64)idx * 16);
-        if constexpr (LW == 64) return U192::make(lo[0], lo[1], *reinterpret_cast<const u64 *>(rec + off[pl_lo + 1] + (u64)idx * 8));
-        else return U192::make(lo[0], lo[1], (u64)((i64)lo[1] >> 63));
-    }
     __device__ __forceinline__ u64 limb(int pl, u32 idx) const {
         if constexpr (LW == 64) return *reinterpret_cast<const u64 *>(rec + off[pl] + (u64)idx * 8);
         else return *reinterpret_cast<const u32 *>(rec + off[pl] + (u64)idx * 4);
     }
-    __device__ __forceinline__ U192 carry(int pl, u32 idx) const {
-        const u64 *p = reinterpret_cast<const u64 *>(rec + off[pl] + (u64)idx * CB);
-        if constexpr (LW == 64) return U192::make(p[0], p[1], 0); else return U192::make(p[0], 0, 0);
-    }
-    __device__ __forceinline__ U192 acc(bool qn, u32 j, u32 im) const {   // accumulator entry (j, i % L)
-        if constexpr (LW == 64) {
-            const u64 *lo = reinterpret_cast<const u64 *>(rec + off[qn ? H2R_PL_QN_LO : H2R_PL_AB_LO] + (u64)(j >> 1) * (3ull * 2 * L * 16) + (u64)(j & 1) * (2ull * L * 16) + (u64)im * 16);
-            const u64 hi = *reinterpret_cast<const u64 *>(rec + off[qn ? H2R_PL_QN_HI : H2R_PL_AB_HI] + (u64)(j >> 1) * (3ull * 2 * L * 16) + (u64)im * 16 + (j & 1) * 8);
-            return U192::make(lo[0], lo[1], hi);
-        } else {
-            const u64 *lo = reinterpret_cast<const u64 *>(rec + off[qn ? H2R_PL_QN_LO : H2R_PL_AB_LO] + (u64)j * ((u64)L * 16) + (u64)im * 16);
-            return U192::make(lo[0], lo[1], 0);
-        }
-    }
 };
+
+constexpr u32 ADVICE_ROW_BYTES = 160;
+constexpr u32 ADVICE_COL_ROWS = 23;    // main-gate rows of one is_equal_muled column besides the carry's range assign
+__host__ __device__ inline u32 advice_rows_per_record(u32 L, u32 carry_nsub) {
+    const u32 C = 2 * L - 1, nrc = (carry_nsub + 3) / 4;
+    return 2 * L * 2 + 2 * (C + L * L) + L + 4 + (C - 1) * (ADVICE_COL_ROWS + nrc) + ADVICE_COL_ROWS;
+}
+
+// Row r of a mul_mod's image: which op it belongs to.  Shared by the kernel and the host export of the row kinds.
+struct AdviceRowId {
+    u32 kind;      // ROWK_*
+    u32 sect;      // 0 q/r range rows, 1 mul rows, 2 eq_b, 3 is_equal_muled preamble, 4 is_equal_muled column rows
+    u32 i, j;      // sect 0: i = limb (L.. = r limbs), j = row of the assign; sect 1: column i, step j (kind CONST0: the column's head);
+                   // sect 2: i; sect 3: i = 0..3; sect 4: column i, j = row within the column (range rows: j = 18 + row of the assign)
+    u32 qn;        // sect 1: 0 = mul(a, b), 1 = mul(q, n)
+};
+__host__ __device__ inline u32 advice_mul_colstart(u32 i, u32 L) {   // rows of a mul() before column i: its accumulators + one head row per column
+    const u32 e = i <= L ? i * (i + 1) / 2 : L * (L + 1) / 2 + (i - L) * (2 * L - 1) - ((i - 1) * i / 2 - (L - 1) * L / 2);
+    return e + i;
+}
+__host__ __device__ inline AdviceRowId advice_decode(u32 r, u32 L, u32 nrc) {
+    const u32 C = 2 * L - 1, mul_rows = C + L * L;
+    const u32 r_T3 = 4 * L, r_T5 = r_T3 + 2 * mul_rows, r_T6p = r_T5 + L, r_T6 = r_T6p + 4, per_col = ADVICE_COL_ROWS + nrc;
+    AdviceRowId id; id.kind = ROWK_NOP; id.sect = 0; id.i = id.j = id.qn = 0;
+    if (r < r_T3) { id.sect = 0; id.i = r >> 1; id.j = r & 1; id.kind = ROWK_RANGE_LIMB + id.j; return id; }
+    if (r < r_T5) {
+        id.sect = 1; id.qn = r >= r_T3 + mul_rows ? 1u : 0u;
+        const u32 e = r - r_T3 - id.qn * mul_rows;
+        u32 i;
+        if (e < advice_mul_colstart(L, L)) {   // columns 0 .. L-1 start at i (i + 3) / 2
+            i = (u32)((sqrtf(8.f * (float)e + 9.f) - 3.f) * 0.5f);
+            while (advice_mul_colstart(i + 1, L) <= e) ++i;
+            while (advice_mul_colstart(i, L) > e) --i;
+        } else {
+            i = L;
+            while (advice_mul_colstart(i + 1, L) <= e) ++i;
+        }
+        const u32 k = e - advice_mul_colstart(i, L);
+        id.i = i;
+        if (k == 0) { id.kind = ROWK_CONST0; id.j = 0; }
+        else { id.kind = ROWK_MUL_ADD; id.j = (i >= L ? i - L + 1 : 0) + (k - 1); }
+        return id;
+    }
+    if (r < r_T6p) { id.sect = 2; id.i = r - r_T5; id.kind = ROWK_ADD; return id; }
+    if (r < r_T6) { id.sect = 3; id.i = r - r_T6p; id.kind = id.i == 0 ? ROWK_CONST_B : (id.i == 3 ? ROWK_BIT : ROWK_CONST0); return id; }
+    const u32 rr = r - r_T6;
+    const u32 c = rr / per_col < C - 1 ? rr / per_col : C - 1;
+    u32 k = rr - c * per_col;
+    id.sect = 4; id.i = c;
+    if (c < C - 1 && k >= 18 && k < 18 + nrc) { id.kind = ROWK_RANGE_CARRY + (k - 18); id.j = k; return id; }
+    if (c < C - 1 && k >= 18 + nrc) k -= nrc;   // the second is_equal and its `and`: 18..22
+    id.j = k;
+    switch (k) {
+        case 0: case 5: case 11: case 13: case 18: id.kind = ROWK_SUB; break;
+        case 1: id.kind = ROWK_ADD_WM; break;
+        case 2: case 3: case 8: case 9: id.kind = ROWK_VALUE; break;
+        case 4: case 10: case 17: case 22: id.kind = ROWK_MUL; break;
+        case 6: case 12: id.kind = ROWK_ASSERT_EQ; break;
+        case 7: id.kind = ROWK_ADDC_WM; break;
+        case 14: case 19: id.kind = ROWK_BIT; break;
+        case 15: case 20: id.kind = ROWK_ISZERO_INV; break;
+        default: id.kind = ROWK_ISZERO_RA; break;   // 16, 21
+    }
+    return id;
+}
 
 struct AdviceArgs {
     const void *opA, *opB; u64 op_stride; const void *n; u64 n_stride;
     const u8 *status;
     const u8 *trace; u64 elem_stride, off_records, record_stride; u32 T; u64 n_items;
-    u8 *out; u64 out_stride;            // element e's image at out + e * out_stride; record t at + t * rows * 160
+    u8 *out; u64 out_stride;            // element e's image at out + e * out_stride: pre_rows rows, then record t at + (pre_rows + t * rows) * 160
     u64 off[H2R_PL_COUNT];
     u32 L, carry_bits, carry_sub_bits, carry_nsub, carry_sub_stride;
     u32 rows;                           // rows of one record
-    u64 p[4];                           // field modulus
+    u32 pre_rows;                       // pow_mod_fixed_exp's acc = assign_constant(1, L) (chip.rs:729 -> :1272-1276): CONST1 [1], CONST0 [0]
+    FieldConsts f;                      // field modulus + Montgomery constants (is_zero's inverse witness)
 };
-constexpr u32 ADVICE_ROW_BYTES = 160;
-__host__ __device__ inline u32 advice_rows_per_record(u32 L, u32 carry_nsub) {
-    const u32 C = 2 * L - 1, nrc = (carry_nsub + 3) / 4;
-    return 2 * L * 2 + 2 * L * L + L + (C - 1) * (17 + nrc) + 17;
-}
 
 template <int LW>
 __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
@@ -2558,7 +2606,11 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
         sq[k] = rv.limb(H2R_PL_Q, k); sr[k] = rv.limb(H2R_PL_R, k);
     }
     __syncthreads();
-    u8 *out = a.out + (u64)elem * a.out_stride + (u64)t * a.rows * ADVICE_ROW_BYTES;
+    u8 *out = a.out + (u64)elem * a.out_stride + ((u64)a.pre_rows + (u64)t * a.rows) * ADVICE_ROW_BYTES;
+    if (t == 0 && tid < a.pre_rows) {   // the constant limbs of pow_mod_fixed_exp's acc = 1: [1, 0, 0, 0, 0] then [0, ...]
+        uint4 *pr = reinterpret_cast<uint4 *>(a.out + (u64)elem * a.out_stride + (u64)tid * ADVICE_ROW_BYTES);
+        for (u32 k = 0; k < ADVICE_ROW_BYTES / 16; ++k) pr[k] = make_uint4((k == 0 && tid == 0) ? 1u : 0u, 0, 0, 0);
+    }
     const U192 Z = U192::make(0, 0, 0);
     const U192 B = LW == 64 ? U192::make(0, 1, 0) : U192::make(1ull << 32, 0, 0);   // 2^w
     auto cell = [&](u8 *p, const U192 &v, bool is_signed) {   // canonical field element, 32 bytes little-endian
@@ -2567,38 +2619,55 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
             x[3] = ~0ull;
             u64 cy = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const u64 s1 = x[k] + a.p[k]; const u64 c1 = s1 < x[k]; const u64 s2 = s1 + cy; cy = c1 | (u64)(s2 < s1); x[k] = s2; }
+            for (int k = 0; k < 4; ++k) { const u64 s1 = x[k] + a.f.p[k]; const u64 c1 = s1 < x[k]; const u64 s2 = s1 + cy; cy = c1 | (u64)(s2 < s1); x[k] = s2; }
         }
         reinterpret_cast<uint4 *>(p)[0] = make_uint4((u32)x[0], (u32)(x[0] >> 32), (u32)x[1], (u32)(x[1] >> 32));
         reinterpret_cast<uint4 *>(p)[1] = make_uint4((u32)x[2], (u32)(x[2] >> 32), (u32)x[3], (u32)(x[3] >> 32));
     };
-    auto row = [&](u32 r, const U192 &c0, const U192 &c1, const U192 &c2, const U192 &c3, const U192 &c4, bool c2_signed = false, bool c0_signed = false) {
+    auto row = [&](u32 r, const U192 &c0, const U192 &c1, const U192 &c2, const U192 &c3, const U192 &c4, bool c2_signed = false, bool c0_signed = false, bool c1_signed = false) {
         u8 *p = reinterpret_cast<u8 *>(stage) + (u64)(r % SR) * ADVICE_ROW_BYTES;   // r - r0 == tid (r0 is a multiple of SR)
-        cell(p, c0, c0_signed); cell(p + 32, c1, false); cell(p + 64, c2, c2_signed); cell(p + 96, c3, false); cell(p + 128, c4, false);
+        cell(p, c0, c0_signed); cell(p + 32, c1, c1_signed); cell(p + 64, c2, c2_signed); cell(p + 96, c3, false); cell(p + 128, c4, false);
     };
     auto lim = [&](u64 v) { return U192::make(v, 0, 0); };
-    // a range assign's row: four sub-limbs and the running sum after them
+    // 1 / d in the field for the (signed) difference d != 0 -- main_gate.is_zero's witness; rare on this path (every
+    // comparison of a valid mul_mod is between equal values), so the 380 Montgomery products sit in a divergent branch
+    auto inverse_cell = [&](u8 *p, const U192 &d) {
+        Fe x; x.v[0] = d.w[0]; x.v[1] = d.w[1]; x.v[2] = d.w[2]; x.v[3] = 0;
+        if (d.w[2] >> 63) {
+            x.v[3] = ~0ull;
+            u64 cy = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const u64 s1 = x.v[k] + a.f.p[k]; const u64 c1 = s1 < x.v[k]; const u64 s2 = s1 + cy; cy = c1 | (u64)(s2 < s1); x.v[k] = s2; }
+        }
+        const Fe iv = fe_inv(x, a.f);
+        reinterpret_cast<uint4 *>(p)[0] = make_uint4((u32)iv.v[0], (u32)(iv.v[0] >> 32), (u32)iv.v[1], (u32)(iv.v[1] >> 32));
+        reinterpret_cast<uint4 *>(p)[1] = make_uint4((u32)iv.v[2], (u32)(iv.v[2] >> 32), (u32)iv.v[3], (u32)(iv.v[3] >> 32));
+    };
+    // a range assign's row (main_gate.decompose): four sub-limbs in columns a..d -- the LAST row reversed, so that the last
+    // (overflow) term is in column a, and padded with zero terms -- and, in column e, what remains to be composed
     auto range_row = [&](u32 r, u64 s_lo, u64 s_hi, u32 nsub, u32 sub_bits, u32 rr) {   // sub-limb bytes in (s_lo, s_hi), row rr of the assign
-        U192 c0 = Z, c1 = Z, c2 = Z, c3 = Z, run = Z;   // (no indexed array: it would live in scratch)
+        U192 c0 = Z, c1 = Z, c2 = Z, c3 = Z, rem = Z;   // (no indexed array: it would live in scratch)
+        const u32 last = (nsub - 1) / 4;
 #pragma unroll
         for (u32 k = 0; k < 12; ++k) {                   // at most 9 sub-limbs (8 + overflow), three rows
-            if (k < 4 * (rr + 1) && k < nsub) {
+            if (k >= 4 * rr && k < nsub) {
                 const u64 sv = ((k < 8 ? s_lo : s_hi) >> (8 * (k & 7))) & 0xff;
                 const u32 sh = k * sub_bits;
                 const U192 term = sh < 64 ? U192::make(sv << sh, sh ? sv >> (64 - sh) : 0, 0) : U192::make(0, sv << (sh - 64), 0);
-                run = run + term;
-                if (k >= 4 * rr) { const u32 q = k - 4 * rr; if (q == 0) c0 = lim(sv); else if (q == 1) c1 = lim(sv); else if (q == 2) c2 = lim(sv); else c3 = lim(sv); }
+                rem = rem + term;
+                if (k < 4 * (rr + 1)) {
+                    const u32 q = rr < last ? k - 4 * rr : nsub - 1 - k;
+                    if (q == 0) c0 = lim(sv); else if (q == 1) c1 = lim(sv); else if (q == 2) c2 = lim(sv); else c3 = lim(sv);
+                }
             }
         }
-        row(r, c0, c1, c2, c3, run);
+        row(r, c0, c1, c2, c3, rem);
     };
-    const u32 r_T2 = 2 * L, r_T3 = 4 * L, r_T4 = r_T3 + L * L, r_T5 = r_T4 + L * L, r_T6 = r_T5 + L;
-    const u32 per_col = 17 + nrc;
     // A row has five cells; at most three of them come from the record, the others are constants, flag bytes or staged
     // operands.  Every row is therefore described the same way -- up to three sources (a 16-, 8- or 4-byte load plus an
-    // optional 8-byte third word) -- so that the lanes of a wave, which sit in ~20 different rows of 3-4 columns in the
+    // optional 8-byte third word) -- so that the lanes of a wave, which sit in ~25 different rows of 3 columns in the
     // is_equal_muled part, issue the SAME few load instructions with different addresses (a switch over loads serialised
-    // ~20 dependent global round trips per wave; loading all 20 values of the column in every lane cost ~40 load
+    // ~20 dependent global round trips per wave; loading all values of the column in every lane cost ~40 load
     // instructions per wave).  The loads of the NEXT 256 rows are issued before the current 256 leave LDS for HBM, so
     // their latency hides behind the write-out.
     // The loads themselves are unconditional and of one width (16 bytes at `lo`, 8 at `hi`; what the source does not have is
@@ -2612,7 +2681,7 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
         if constexpr (LW == 64) return Src{rv.rec + a.off[pl_lo] + (u64)idx * 16, rv.rec + a.off[pl_lo + 1] + (u64)idx * 8, 3u | 8u};
         else return Src{rv.rec + a.off[pl_lo] + (u64)idx * 16, rv.rec, 3u | 4u};
     };
-    auto s_acc = [&](bool qn, u32 j, u32 im) -> Src {   // accumulator entry (j, i % L): RecView::acc's addressing
+    auto s_acc = [&](bool qn, u32 j, u32 im) -> Src {   // accumulator entry (j, i % L)
         if constexpr (LW == 64)
             return Src{rv.rec + a.off[qn ? H2R_PL_QN_LO : H2R_PL_AB_LO] + (u64)(j >> 1) * (3ull * 2 * L * 16) + (u64)(j & 1) * (2ull * L * 16) + (u64)im * 16,
                        rv.rec + a.off[qn ? H2R_PL_QN_HI : H2R_PL_AB_HI] + (u64)(j >> 1) * (3ull * 2 * L * 16) + (u64)im * 16 + (j & 1) * 8, 3u | 8u};
@@ -2620,9 +2689,9 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
     };
     auto s_carry = [&](int pl, u32 idx) -> Src { return Src{rv.rec + a.off[pl] + (u64)idx * CB, rv.rec, LW == 64 ? 3u : 2u}; };
     auto s_limb = [&](int pl, u32 idx) -> Src { return Src{rv.rec + a.off[pl] + (u64)idx * (LW / 8), rv.rec, LW == 64 ? 2u : 1u}; };
-    enum : u32 { ROW_RANGE_LIMB = 20, ROW_RANGE_CARRY = 21, ROW_MUL_ADD = 22, ROW_EQB = 23, ROW_NONE = 99 };
     // per-row state that lives across the write-out of the previous rows
-    u32 kk = ROW_NONE, aux = 0, m0 = 0, m1 = 0, m2 = 0, fl = 0, eprev = 1, has_prev = 0;
+    AdviceRowId id; id.kind = ROWK_NOP; id.sect = 9; id.i = id.j = id.qn = 0;
+    u32 m0 = 0, m1 = 0, m2 = 0, fl = 0, eprev = 1, has_prev = 0;
     u64 imm0 = 0, imm1 = 0, h0 = 0, h1 = 0, h2 = 0;
     ulonglong2 l0 = make_ulonglong2(0, 0), l1 = l0, l2 = l0;
     auto fetch = [&](const Src &sc, ulonglong2 &lo, u64 &hi, u32 &mode) {
@@ -2632,67 +2701,52 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
         hi = *reinterpret_cast<const u64 *>(sc.hi);
     };
     auto plan_and_load = [&](u32 r) {
-        kk = ROW_NONE;
         Src s0 = s_none(), s1 = s_none(), s2 = s_none();
         const u8 *fp = rv.rec, *fpp = rv.rec;   // flag words of the column and of the one before it
         has_prev = 0;
-        if (r >= a.rows) {
-        } else if (r < r_T3) {                                   // q then r limbs: RangeChip::assign(limb, w/8, w)
-            const bool isr = r >= r_T2; const u32 rr = (isr ? r - r_T2 : r);
-            kk = ROW_RANGE_LIMB; aux = rr & 1;
-            s0 = Src{rv.rec + a.off[isr ? H2R_PL_R_SUB : H2R_PL_Q_SUB] + (u64)(rr >> 1) * 8, rv.rec, 2u};
-        } else if (r < r_T5) {                            // mul_add rows, column i ascending then j ascending
-            const bool qn = r >= r_T4; const u32 e = qn ? r - r_T4 : r - r_T3;
-            // entry e of the column order -> (i, j): columns 0..L-1 hold i+1 entries, then 2L-1-i
-            u32 i, j;
-            if (e < L * (L + 1) / 2) {
-                i = (u32)((__builtin_sqrtf(8.f * e + 1.f) - 1.f) * 0.5f);
-                while ((i + 1) * (i + 2) / 2 <= e) ++i;
-                while (i * (i + 1) / 2 > e) --i;
-                j = e - i * (i + 1) / 2;
-            } else {
-                i = L;
-                while (emit_colstart(i + 1, L) <= e) ++i;
-                j = e - emit_colstart(i, L) + (i - L + 1);
-            }
-            const u32 jmin = i >= L ? i - L + 1 : 0, im = i >= L ? i - L : i;
-            kk = ROW_MUL_ADD;
-            imm0 = qn ? sq[j] : sa[j]; imm1 = qn ? sn[i - j] : sb_[i - j];
-            if (j != jmin) s0 = s_acc(qn, j - 1, im);
-            s1 = s_acc(qn, j, im);
-        } else if (r < r_T6) {                            // eq_b[i] = qn[i] + r[i]
-            const u32 i = r - r_T5;
-            kk = ROW_EQB; imm0 = sr[i];
-            s0 = s_acc(true, i, i); s2 = s_wide(H2R_PL_EQB_LO, i);
-        } else {                                          // is_equal_muled step rows
-            const u32 rr = r - r_T6;
-            const u32 c = rr / per_col < C - 1 ? rr / per_col : C - 1, k = rr - c * per_col;
-            const u32 jmax = c < L ? c : L - 1, im = c < L ? c : c - L;
-            if (c < C - 1 && k >= 15 && k < 15 + nrc) {   // RangeChip::assign(carry, sublimb_bit_len(carry_bits), carry_bits)
-                kk = ROW_RANGE_CARRY; aux = k - 15;
-                s0 = Src{rv.rec + a.off[H2R_PL_CARRY_SUB] + (u64)c * a.carry_sub_stride, rv.rec, 3u};
-            } else {
-                kk = k < 15 ? k : (k == (c < C - 1 ? 15 + nrc : 15) ? 15u : 16u);
-                switch (kk) {
-                    case 0: s0 = s_acc(false, jmax, im); s1 = c < L ? s_wide(H2R_PL_EQB_LO, c) : s_acc(true, jmax, im); s2 = s_wide(H2R_PL_AMB_LO, c); break;
-                    case 1: s0 = s_wide(H2R_PL_AMB_LO, c); if (c) s1 = s_carry(H2R_PL_CARRY, c - 1); s2 = s_wide(H2R_PL_SUM_LO, c); break;
-                    case 2: s0 = s_carry(H2R_PL_CARRY, c); break;
-                    case 3: s0 = s_limb(H2R_PL_CMOD, c); break;
-                    case 4: s1 = s_carry(H2R_PL_CARRY, c); s2 = s_wide(H2R_PL_NQ1_LO, c); break;
-                    case 5: s0 = s_wide(H2R_PL_SUM_LO, c); s1 = s_wide(H2R_PL_NQ1_LO, c); s2 = s_limb(H2R_PL_AMNQ1, c); break;
-                    case 6: s0 = s_limb(H2R_PL_CMOD, c); s1 = s_limb(H2R_PL_AMNQ1, c); break;
-                    case 7: if (c) s0 = s_carry(H2R_PL_QACC, c - 1); s1 = s_wide(H2R_PL_ACCX_LO, c); break;
-                    case 8: s0 = s_carry(H2R_PL_QACC, c); break;
-                    case 9: s0 = s_limb(H2R_PL_MODACC, c); break;
-                    case 10: s1 = s_carry(H2R_PL_QACC, c); s2 = s_wide(H2R_PL_NQ2_LO, c); break;
-                    case 11: s0 = s_wide(H2R_PL_ACCX_LO, c); s1 = s_wide(H2R_PL_NQ2_LO, c); s2 = s_limb(H2R_PL_AMNQ2, c); break;
-                    case 12: s0 = s_limb(H2R_PL_MODACC, c); s1 = s_limb(H2R_PL_AMNQ2, c); break;
-                    case 13: s0 = s_limb(H2R_PL_CMOD, c); s1 = s_limb(H2R_PL_MODACC, c); break;
-                    case 15: s0 = s_carry(H2R_PL_CARRY, c); s1 = c < C - 1 ? s_carry(H2R_PL_CARRY_DUP, c) : s_carry(H2R_PL_QACC, c); break;   // range_eq / final_carry_eq
-                    default: break;                       // 14, 16: flag bytes only
+        if (r >= a.rows) { id.kind = ROWK_NOP; id.sect = 9; }
+        else {
+            id = advice_decode(r, L, nrc);
+            if (id.sect == 0) {                                 // q then r limbs: RangeChip::assign(limb, w/8, w)
+                const bool isr = id.i >= L;
+                s0 = Src{rv.rec + a.off[isr ? H2R_PL_R_SUB : H2R_PL_Q_SUB] + (u64)(isr ? id.i - L : id.i) * 8, rv.rec, 2u};
+            } else if (id.sect == 1) {                          // mul(): the column's constant 0, then its mul_add rows
+                if (id.kind == ROWK_MUL_ADD) {
+                    const u32 i = id.i, j = id.j, jmin = i >= L ? i - L + 1 : 0, im = i >= L ? i - L : i;
+                    imm0 = id.qn ? sq[j] : sa[j]; imm1 = id.qn ? sn[i - j] : sb_[i - j];
+                    if (j != jmin) s0 = s_acc(id.qn, j - 1, im);
+                    s1 = s_acc(id.qn, j, im);
                 }
-                fp = rv.rec + a.off[H2R_PL_FLAGS] + (u64)c * 4;
-                fpp = c ? fp - 4 : fp; has_prev = c ? 1u : 0u;
+            } else if (id.sect == 2) {                          // eq_b[i] = qn[i] + r[i]
+                imm0 = sr[id.i];
+                s0 = s_acc(true, id.i, id.i); s2 = s_wide(H2R_PL_EQB_LO, id.i);
+            } else if (id.sect == 4) {                          // is_equal_muled column rows
+                const u32 c = id.i;
+                const u32 jmax = c < L ? c : L - 1, im = c < L ? c : c - L;
+                if (id.kind >= ROWK_RANGE_CARRY) s0 = Src{rv.rec + a.off[H2R_PL_CARRY_SUB] + (u64)c * a.carry_sub_stride, rv.rec, 3u};
+                else {
+                    switch (id.j) {
+                        case 0: s0 = s_acc(false, jmax, im); s1 = c < L ? s_wide(H2R_PL_EQB_LO, c) : s_acc(true, jmax, im); s2 = s_wide(H2R_PL_AMB_LO, c); break;
+                        case 1: s0 = s_wide(H2R_PL_AMB_LO, c); if (c) s1 = s_carry(H2R_PL_CARRY, c - 1); s2 = s_wide(H2R_PL_SUM_LO, c); break;
+                        case 2: s0 = s_carry(H2R_PL_CARRY, c); break;
+                        case 3: s0 = s_limb(H2R_PL_CMOD, c); break;
+                        case 4: s1 = s_carry(H2R_PL_CARRY, c); s2 = s_wide(H2R_PL_NQ1_LO, c); break;
+                        case 5: s0 = s_wide(H2R_PL_SUM_LO, c); s1 = s_wide(H2R_PL_NQ1_LO, c); s2 = s_limb(H2R_PL_AMNQ1, c); break;
+                        case 6: s0 = s_limb(H2R_PL_CMOD, c); s1 = s_limb(H2R_PL_AMNQ1, c); break;
+                        case 7: if (c) s0 = s_carry(H2R_PL_QACC, c - 1); s1 = s_wide(H2R_PL_ACCX_LO, c); break;
+                        case 8: s0 = s_carry(H2R_PL_QACC, c); break;
+                        case 9: s0 = s_limb(H2R_PL_MODACC, c); break;
+                        case 10: s1 = s_carry(H2R_PL_QACC, c); s2 = s_wide(H2R_PL_NQ2_LO, c); break;
+                        case 11: s0 = s_wide(H2R_PL_ACCX_LO, c); s1 = s_wide(H2R_PL_NQ2_LO, c); s2 = s_limb(H2R_PL_AMNQ2, c); break;
+                        case 12: s0 = s_limb(H2R_PL_MODACC, c); s1 = s_limb(H2R_PL_AMNQ2, c); break;
+                        case 13: case 15: case 16: s0 = s_limb(H2R_PL_CMOD, c); s1 = s_limb(H2R_PL_MODACC, c); break;      // is_equal(c, mod_acc)
+                        case 18: case 20: case 21:                                                                         // is_equal(carry, dup | acc_extra)
+                            s0 = s_carry(H2R_PL_CARRY, c); s1 = c < C - 1 ? s_carry(H2R_PL_CARRY_DUP, c) : s_carry(H2R_PL_QACC, c); break;
+                        default: break;                       // 14, 17, 19, 22: flag bytes only
+                    }
+                    fp = rv.rec + a.off[H2R_PL_FLAGS] + (u64)c * 4;
+                    fpp = c ? fp - 4 : fp; has_prev = c ? 1u : 0u;
+                }
             }
         }
         fetch(s0, l0, h0, m0); fetch(s1, l1, h1, m1); fetch(s2, l2, h2, m2);
@@ -2705,18 +2759,31 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
         return U192::make(wd == 1u ? (lo.x & 0xffffffffull) : lo.x, wd == 3u ? lo.y : 0, (mode & 4u) ? (u64)((i64)lo.y >> 63) : ((mode & 8u) ? hi : 0));
     };
     auto build = [&](u32 r) {
-        if (kk == ROW_NONE) return;
-        if (kk == ROW_RANGE_LIMB) { range_row(r, l0.x, 0, 8, LW / 8, aux); return; }   // eight sub-limbs, one byte each
-        if (kk == ROW_RANGE_CARRY) { range_row(r, l0.x, l0.y, a.carry_nsub, a.carry_sub_bits, aux); return; }
-        U192 c0 = val(l0, h0, m0), c1 = val(l1, h1, m1), c2 = val(l2, h2, m2);
-        if (kk == ROW_MUL_ADD) { row(r, lim(imm0), lim(imm1), c0, c1, Z); return; }
-        if (kk == ROW_EQB) { row(r, c0, lim(imm0), c2, Z, Z); return; }
-        if (kk == 4 || kk == 10) c0 = B;
-        else if (kk == 13) c2 = lim(fl & 0xff);
-        else if (kk == 14) { c0 = lim(has_prev ? (eprev >> 24) : 1u); c1 = lim(fl & 0xff); c2 = lim((fl >> 8) & 0xff); }
-        else if (kk == 15) c2 = lim((fl >> 16) & 0xff);
-        else if (kk == 16) { c0 = lim((fl >> 8) & 0xff); c1 = lim((fl >> 16) & 0xff); c2 = lim(fl >> 24); }
-        row(r, c0, c1, c2, Z, Z, kk == 0, kk == 1);
+        if (id.sect == 9) return;
+        if (id.sect == 0) { range_row(r, l0.x, 0, 8, LW / 8, id.j); return; }   // eight sub-limbs, one byte each
+        const U192 c0 = val(l0, h0, m0), c1 = val(l1, h1, m1), c2 = val(l2, h2, m2);
+        if (id.sect == 1) { if (id.kind == ROWK_MUL_ADD) row(r, lim(imm0), lim(imm1), c0, c1, Z); else row(r, Z, Z, Z, Z, Z); return; }
+        if (id.sect == 2) { row(r, c0, lim(imm0), c2, Z, Z); return; }
+        if (id.sect == 3) { if (id.i == 0) row(r, B, Z, Z, Z, Z); else if (id.i == 3) row(r, lim(1), lim(1), lim(1), Z, Z); else row(r, Z, Z, Z, Z, Z); return; }
+        if (id.kind >= ROWK_RANGE_CARRY) { range_row(r, l0.x, l0.y, a.carry_nsub, a.carry_sub_bits, id.kind - ROWK_RANGE_CARRY); return; }
+        const u32 f1 = fl & 0xff, e1 = (fl >> 8) & 0xff, f2 = (fl >> 16) & 0xff, e2 = fl >> 24;
+        switch (id.j) {
+            case 4: case 10: row(r, B, c1, c2, Z, Z); return;
+            case 13: case 18: row(r, c0, c1, c0 - c1, Z, Z, true); return;                        // sub: d = x - y in the field
+            case 14: row(r, lim(f1), lim(f1), lim(f1), Z, Z); return;
+            case 19: row(r, lim(f2), lim(f2), lim(f2), Z, Z); return;
+            case 15: case 20: {                                                                   // [d, 1/d (1 when d = 0), r]
+                const U192 d = c0 - c1;
+                const bool zero = d == Z;
+                row(r, d, lim(1), lim(id.j == 15 ? f1 : f2), Z, Z, false, true);
+                if (!zero) inverse_cell(reinterpret_cast<u8 *>(stage) + (u64)(r % SR) * ADVICE_ROW_BYTES + 32, d);
+                return;
+            }
+            case 16: case 21: row(r, lim(id.j == 16 ? f1 : f2), c0 - c1, Z, Z, Z, false, false, true); return;   // [r, d]
+            case 17: row(r, lim(has_prev ? (eprev >> 24) : 1u), lim(f1), lim(e1), Z, Z); return;  // and
+            case 22: row(r, lim(e1), lim(f2), lim(e2), Z, Z); return;                              // and
+            default: row(r, c0, c1, c2, Z, Z, id.j == 0, id.j == 1); return;
+        }
     };
     static_assert(SR <= 256, "one row per thread and stage");
     plan_and_load(tid < SR ? tid : a.rows);

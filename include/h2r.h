@@ -517,12 +517,36 @@ int32_t h2r_pow_trace_emit_stream(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
  * ceil(sub-limbs / 4) rows per RangeChip::assign, in the reference's op order.  Row shapes: DESIGN.md section 2b.  The
  * VALUES are the ones the flat stream pins; the third-party PLACEMENT (maingate / halo2wrong are not in the reference
  * tree) is restated from SURVEY Appendix A and is unpinned.
- *   h2r_advice_rows(ctx)            rows of one mul_mod (3,465 for RSA-2048 as 32 x 64-bit limbs)
- *   element e's image starts at advice_out + e * out_stride; record t of the element at + t * rows * 160 bytes.
+ *   h2r_advice_rows(ctx)            rows of one mul_mod (3,973 for RSA-2048 as 32 x 64-bit limbs): EVERY cell the ops assign --
+ *                                   the flat stream's values, the assign_constant cells, the assign_bit(1) seeds, is_zero's inverses
+ *   element e's image starts at advice_out + e * out_stride; record t of the element at + (pre + t * rows) * 160 bytes
+ *   (pre = 2 constant rows for h2r_pow_trace_emit_advice of a fixed-exponent trace, else 0: h2r_pow_advice_rows).
+ *   A variable-exponent trace gets its mul_mod blocks only (to_bits / select rows are not emitted).
  *   h2r_mul_mod_emit_advice         records of h2r_mul_mod_batch with the same a, b, n, flags
  *   h2r_pow_trace_emit_advice       the records of a pow / modpow / verify trace; `workspace` is the workspace that call
  *                                   was given (it holds every mul_mod's operands), elem_stride = 0 means pl->elem_stride. */
 #define H2R_ADVICE_ROW_BYTES 160u
+/* Row kinds (one per main-gate op shape) and their FIXED columns.  The gate every row satisfies:
+ *   sa*a + sb*b + sc*c + sd*d + se*e + s_mul_ab*a*b + s_mul_cd*c*d + se_next*e(next row) + s_const = 0
+ * RANGE_LIMB + j / RANGE_CARRY + j = row j of RangeChip::assign of a limb / of a carry: four sub-limb terms in a..d (the LAST
+ * row reversed and zero-padded), e = what remains to be composed; tag_composition / tag_overflow = the lookup tags enabled on
+ * the row (0 = off).  h2r_advice_row_kinds: the kind of each of the h2r_advice_rows() rows of a mul_mod (host, input-independent);
+ * h2r_advice_fixed_row: the selectors of a kind as canonical field elements (cfg nullable: no tags). */
+enum { H2R_ROW_NOP = 0, H2R_ROW_CONST0, H2R_ROW_CONST1, H2R_ROW_CONST_B /* assign_constant(0 / 1 / 2^w) */, H2R_ROW_BIT /* assign_bit [v,v,v] */,
+       H2R_ROW_VALUE /* assign_value [v] */, H2R_ROW_MUL_ADD /* [a,b,c,a*b+c] */, H2R_ROW_ADD, H2R_ROW_SUB /* [a,b,a+-b] */,
+       H2R_ROW_ADD_WM /* add_with_constant(word_max) */, H2R_ROW_ADDC_WM /* add_constant(word_max): [a, a+W] */, H2R_ROW_MUL /* mul, and */,
+       H2R_ROW_ASSERT_EQ /* [a,b] */, H2R_ROW_ISZERO_INV /* is_zero: [a, 1/a or 1, r], a*a' + r - 1 = 0 */, H2R_ROW_ISZERO_RA /* [r, a], r*a = 0 */,
+       H2R_ROW_RANGE_LIMB = 32, H2R_ROW_RANGE_CARRY = 40 };
+typedef struct h2r_fixed_row {
+    uint64_t sa[4], sb[4], sc[4], sd[4], se[4], s_mul_ab[4], s_mul_cd[4], se_next[4], s_const[4];
+    uint32_t tag_composition, tag_overflow;
+} h2r_fixed_row;
+struct h2r_lookup_config;
+int32_t h2r_advice_row_kinds(const h2r_ctx *ctx, uint8_t *kinds_out);
+int32_t h2r_advice_fixed_row(const h2r_ctx *ctx, const struct h2r_lookup_config *cfg, uint32_t kind, h2r_fixed_row *out);
+/* rows of one element of h2r_pow_trace_emit_advice: for a fixed exponent two constant rows first -- CONST1 [1], CONST0 [0], the
+ * limbs of pow_mod_fixed_exp's acc = assign_constant(1, num_limbs) (big_integer/chip.rs:729 -> :1272-1276) -- then the records */
+uint64_t h2r_pow_advice_rows(const h2r_ctx *ctx, const h2r_pow_layout *pl);
 uint32_t h2r_advice_rows(const h2r_ctx *ctx);
 int32_t h2r_mul_mod_emit_advice(const h2r_ctx *ctx, const void *a, const void *b, const void *n, uint32_t flags,
                                 const void *trace, uint64_t batch, const uint8_t *status, void *advice_out,

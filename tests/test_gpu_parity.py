@@ -401,14 +401,18 @@ def test_device_emit_stream_pow(H, w, L, e, var_bits):
 
 @pytest.mark.parametrize("w,L,field", [(64, 32, "bn254_fr"), (32, 128, "pasta_fp"), (64, 12, "bn254_fq"), (64, 48, "pasta_fq"), (32, 8, "bn254_fr")])
 def test_advice_image(H, w, L, field):
-    """h2r_*_emit_advice: the 5-column advice image (rows of canonical field elements, one per main-gate op, four sub-limbs +
-    running sum per range-assign row) equals the image built in Python from the ORACLE's flat stream with the documented
-    row table (tests/advice_ref.py) -- for a mul_mod batch and for the records of a pow trace."""
+    """h2r_*_emit_advice: the COMPLETE 5-column advice image -- every cell the reference's ops assign: the flat stream's
+    values, the assign_constant cells, the assign_bit(1) seeds, main_gate.is_zero's difference / inverse witnesses -- equals
+    the image built in Python from the ORACLE's flat stream with the documented row table (tests/advice_ref.py), for a
+    mul_mod batch and for a pow trace (with its two constant rows); and it is a SATISFYING assignment: every row fulfils the
+    main-gate equation with the fixed row the C ABI reports for its kind (h2r_advice_row_kinds / h2r_advice_fixed_row)."""
+    import ctypes
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import pyref as R
-    from advice_ref import advice_image_from_stream
+    import advice_ref as AR
+    from halo2_rsa_amd import _lib
     from halo2_rsa_amd._lib import lib
     chip = H.BigIntChip(w, w * L, field=field)
     o = Oracle(w, L)
@@ -424,22 +428,50 @@ def test_advice_image(H, w, L, field):
     rows = int(lib().h2r_advice_rows(chip._ctx))
     assert img.shape == (batch, rows * 160)
     if (w, L) == (64, 32):
-        assert rows == 3465
+        assert rows == 3973
+    # the fixed side, from the C ABI: row kinds and the selectors of every kind
+    kinds = np.zeros(rows, dtype=np.uint8)
+    assert lib().h2r_advice_row_kinds(chip._ctx, kinds.ctypes.data) == 0
+    la = H.LookupArgument(chip, rsa_chip=(w == 64))
+    cfg = AR.LookupConfig(AR.range_lens(w, L, rsa=(w == 64)))
+    fixed = {}
+    for k in sorted(set(kinds.tolist())):
+        fr = _lib.H2RFixedRow()
+        assert lib().h2r_advice_fixed_row(chip._ctx, ctypes.byref(la.cfg), k, ctypes.byref(fr)) == 0
+        fixed[k] = fr.as_dict()
+        ref = AR.fixed_row(k, w, L, o.p.carry_bits, o.p.carry_sub_bits, o.p.carry_nsub, cfg)
+        assert {nm: v % P for nm, v in ref.items() if nm in AR.FIXED_NAMES} == {nm: fixed[k][nm] for nm in AR.FIXED_NAMES}, k
+        assert (ref["tag_composition"], ref["tag_overflow"]) == (fixed[k]["tag_composition"], fixed[k]["tag_overflow"])
     host = img.cpu().numpy()
+    table = set(cfg.table())
     for i in range(batch):
         rc, rr, ost = o.mul_mod(o.limbs(A[i]), o.limbs(Bv[i]), o.limbs(N[i]))
-        want = advice_image_from_stream(o.p, [int(v) for v in o.limbs(A[i])], [int(v) for v in o.limbs(Bv[i])],
-                                        [int(v) for v in o.limbs(N[i])], ost, P)
+        im = AR.mul_mod_image(o.p, [int(v) for v in o.limbs(A[i])], [int(v) for v in o.limbs(Bv[i])], [int(v) for v in o.limbs(N[i])], ost, P)
+        assert im.kinds == kinds.tolist()
+        want = AR.image_bytes(im)
         assert want.shape == (rows, 160)
         got = host[i].reshape(rows, 160)
         if not np.array_equal(got, want):
             bad = np.argwhere(got != want)[0]
-            pytest.fail("w=%d L=%d elem %d: row %d cell %d differs" % (w, L, i, int(bad[0]), int(bad[1]) // 32))
-    # the records of a pow trace (operands from the call's workspace)
+            pytest.fail("w=%d L=%d elem %d: row %d (kind %d) cell %d differs" % (w, L, i, int(bad[0]), int(kinds[int(bad[0])]), int(bad[1]) // 32))
+        if i == 0:   # gate equation + lookup membership on the GPU's own cells
+            cells = [[int.from_bytes(got[r, 32 * c:32 * c + 32].tobytes(), "little") for c in range(5)] for r in range(rows)]
+            for r in range(rows):
+                f = fixed[int(kinds[r])]
+                assert AR.gate_residual(cells[r], cells[r + 1][4] if r + 1 < rows else 0, f, P) == 0, (r, int(kinds[r]))
+                if f["tag_composition"]:
+                    assert all((f["tag_composition"], cells[r][c]) in table for c in range(4)), r
+                if f["tag_overflow"]:
+                    assert (f["tag_overflow"], cells[r][0]) in table, r
+    # the records of a pow trace (operands from the call's workspace), behind the two constant rows of acc = 1
     e = 0b1011
     pres = chip.pow_mod_fixed_exp(chip.assign_integer(A), e, chip.assign_integer(N))
     pimg = pres.emit_advice().cpu().numpy()
     T = pres.trace.num_mul_mods
+    assert pimg.shape[1] == (2 + T * rows) * 160
+    one = np.zeros((2, 160), dtype=np.uint8)
+    one[0, 0] = 1
+    assert np.array_equal(pimg[0, :320].reshape(2, 160), one)
     rc, oo, ost = o.pow_mod_fixed_exp(o.limbs(A[0]), o.limbs(N[0]), e)
     msb = o.mul_mod_stream_bytes
     acc, cur, t = 1, A[0], 0
@@ -447,15 +479,78 @@ def test_advice_image(H, w, L, field):
         ops = [(cur, cur)] + ([(acc, cur)] if bit else [])
         nxt = cur * cur % N[0]
         for (x, y) in ops:
-            want = advice_image_from_stream(o.p, [int(v) for v in o.limbs(x)], [int(v) for v in o.limbs(y)],
-                                            [int(v) for v in o.limbs(N[0])], ost[t * msb:(t + 1) * msb], P)
-            got = pimg[0, t * rows * 160:(t + 1) * rows * 160].reshape(rows, 160)
+            want = AR.advice_image_from_stream(o.p, [int(v) for v in o.limbs(x)], [int(v) for v in o.limbs(y)],
+                                               [int(v) for v in o.limbs(N[0])], ost[t * msb:(t + 1) * msb], P)
+            got = pimg[0, (2 + t * rows) * 160:(2 + (t + 1) * rows) * 160].reshape(rows, 160)
             assert np.array_equal(got, want), ("pow record", t)
             t += 1
         if bit:
             acc = acc * cur % N[0]
         cur = nxt
     assert t == T
+
+
+@pytest.mark.parametrize("w,L,field", [(64, 32, "bn254_fr"), (32, 8, "pasta_fq")])
+def test_advice_image_is_zero_inverse_witness(H, w, L, field):
+    """main_gate.is_equal on UNEQUAL values (never the case in a valid mul_mod): corrupt the stored mod_acc, the carry duplicate and
+    the final acc_extra of a record and rebuild the image -- the is_equal rows must then hold d = x - y != 0 (a field element,
+    p - |d| when negative), its inverse d^-1 and r from the (unchanged) flag bytes; the rows [d, 1/d, r] must satisfy
+    d * (1/d) + r - 1 = 0 with r = 0, i.e. the inverse is right.  Exercises the kernel's field inversion (380 Montgomery products)."""
+    import ctypes
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref as R
+    from halo2_rsa_amd._lib import lib
+    chip = H.BigIntChip(w, w * L, field=field)
+    P = R.FIELD_MODULI[field]
+    rng = random.Random(w + L)
+    n = rand_modulus(rng, w * L)
+    a, b = rng.randrange(n), rng.randrange(n)
+    res = chip.mul_mod(chip.assign_integer([a]), chip.assign_integer([b]), chip.assign_integer([n]))
+    torch.cuda.synchronize()
+    lo = chip.layout
+    from halo2_rsa_amd import _lib
+    P_IDX = {nm: k for k, nm in enumerate(_lib.PLANES)}
+    buf = res.trace.buf
+    LB, CB = lo.limb_bytes, lo.carry_bytes
+    C = 2 * L - 1
+
+    def bump(plane, idx, nbytes, delta):   # little-endian += delta on a stored value
+        off = lo.plane_off[P_IDX[plane]] + idx * lo.plane_elem[P_IDX[plane]]
+        v = int.from_bytes(buf[off:off + nbytes].cpu().numpy().tobytes(), "little") + delta
+        buf[off:off + nbytes] = torch.from_numpy(np.frombuffer((v % (1 << (8 * nbytes))).to_bytes(nbytes, "little"), dtype=np.uint8).copy()).to(buf.device)
+        return v
+
+    vals = {}
+    for nm, idx, nb in (("CMOD", 1, LB), ("MODACC", 1, LB), ("CARRY", 2, CB), ("CARRY_DUP", 2, CB), ("CARRY", C - 1, CB), ("QACC", C - 1, CB)):
+        off = lo.plane_off[P_IDX[nm]] + idx * lo.plane_elem[P_IDX[nm]]
+        vals[(nm, idx)] = int.from_bytes(buf[off:off + nb].cpu().numpy().tobytes(), "little")
+    bump("MODACC", 1, LB, 5)                 # c - mod_acc = -5 (or +2^w - 5 after wrap: use the stored values below)
+    bump("CARRY_DUP", 2, CB, -3)             # carry - dup = +3
+    bump("QACC", C - 1, CB, 1)               # final carry - acc_extra = -1
+    img = res.emit_advice().cpu().numpy()
+    rows = int(lib().h2r_advice_rows(chip._ctx))
+    got = img[0].reshape(rows, 160)
+    cell = lambda r, c: int.from_bytes(got[r, 32 * c:32 * c + 32].tobytes(), "little")
+    nrc = (lo.carry_nsub + 3) // 4
+    r_T6 = 4 * L + 2 * (C + L * L) + L + 4
+    per_col = 23 + nrc
+
+    def check(col, k_sub, x, y):
+        r0 = r_T6 + col * per_col + k_sub + (nrc if (k_sub == 18 and col < C - 1) else 0)
+        d = (x - y) % P
+        assert d != 0
+        assert [cell(r0, 0), cell(r0, 1), cell(r0, 2)] == [x, y, d], (col, k_sub)
+        assert cell(r0 + 2, 0) == d and (cell(r0 + 2, 0) * cell(r0 + 2, 1)) % P == 1, (col, k_sub)       # d * d^-1 = 1
+        assert cell(r0 + 2, 1) == pow(d, P - 2, P)
+        assert cell(r0 + 3, 1) == d
+    mod1 = (vals[("MODACC", 1)] + 5) % (1 << (8 * LB))
+    check(1, 13, vals[("CMOD", 1)], mod1)
+    dup2 = (vals[("CARRY_DUP", 2)] - 3) % (1 << (8 * CB))
+    check(2, 18, vals[("CARRY", 2)], dup2)
+    qlast = vals[("QACC", C - 1)] + 1
+    check(C - 1, 18, vals[("CARRY", C - 1)], qlast)
 
 
 def test_shared_modulus(H):
