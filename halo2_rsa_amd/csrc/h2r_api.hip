@@ -151,6 +151,7 @@ struct h2r_ctx {
     u32 L, K;           // limbs, 32-bit digits
     U256 word_max;
     u8 *const_rec_dev;  // device copy of the constant record
+    u32 *advice_desc_dev = nullptr;   // [h2r_advice_rows] packed row descriptors of the advice image (advice_pack)
     std::vector<u8> const_rec_host;
     // lookup-table row offsets for the multiplicity histogram
     u32 tab0_len, tab1_off, tab1_len, tab2_off, tab2_len, hist_len;
@@ -552,6 +553,16 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
         delete c;
         return H2R_E_HIP;
     }
+    {   // the advice image's row table
+        const u32 rows = advice_rows_per_record(L, lo.carry_nsub), nrc = (lo.carry_nsub + 3) / 4;
+        std::vector<u32> desc(rows);
+        for (u32 r = 0; r < rows; ++r) desc[r] = advice_pack(advice_decode(r, L, nrc));
+        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&c->advice_desc_dev), rows * sizeof(u32)), "hipMalloc(advice rows)") ||
+            !hip_ok(hipMemcpy(c->advice_desc_dev, desc.data(), rows * sizeof(u32), hipMemcpyHostToDevice), "hipMemcpy(advice rows)")) {
+            h2r_ctx_destroy(c);
+            return H2R_E_HIP;
+        }
+    }
     *out = c;
     return H2R_OK;
 }
@@ -562,6 +573,7 @@ void h2r_ctx_destroy(h2r_ctx *ctx) {
         DeviceGuard dg(ctx->params.device);
         if (ctx->const_rec_dev) (void)hipFree(ctx->const_rec_dev);
         if (ctx->refresh_inc_dev) (void)hipFree(ctx->refresh_inc_dev);
+        if (ctx->advice_desc_dev) (void)hipFree(ctx->advice_desc_dev);
         if (ctx->pipe) h2r_pipeline_destroy(ctx->pipe);
     }
     delete ctx;
@@ -1953,7 +1965,7 @@ int32_t launch_advice(const h2r_ctx *ctx, AdviceArgs &aa, hipStream_t st) {
     aa.L = lo.num_limbs; aa.carry_bits = lo.carry_bits; aa.carry_sub_bits = lo.carry_sub_bits; aa.carry_nsub = lo.carry_nsub;
     aa.carry_sub_stride = lo.carry_sub_stride; aa.record_stride = lo.record_stride;
     aa.rows = h2r_advice_rows(ctx);
-    aa.f = ctx->fc;
+    aa.f = ctx->fc; aa.desc = ctx->advice_desc_dev;
     if (aa.out_stride < ((u64)aa.pre_rows + (u64)aa.T * aa.rows) * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
     if (aa.n_items == 0) return H2R_OK;
     if (aa.n_items >= (1ull << 31)) return H2R_E_UNSUPPORTED;

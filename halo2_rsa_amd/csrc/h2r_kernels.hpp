@@ -2510,6 +2510,9 @@ struct RecView {   // reads of one record through the documented plane layout (i
     }
 };
 
+#ifndef H2R_ADVICE_INV
+#define H2R_ADVICE_INV 1
+#endif
 constexpr u32 ADVICE_ROW_BYTES = 160;
 constexpr u32 ADVICE_COL_ROWS = 23;    // main-gate rows of one is_equal_muled column besides the carry's range assign
 __host__ __device__ inline u32 advice_rows_per_record(u32 L, u32 carry_nsub) {
@@ -2537,16 +2540,15 @@ __host__ __device__ inline AdviceRowId advice_decode(u32 r, u32 L, u32 nrc) {
     if (r < r_T5) {
         id.sect = 1; id.qn = r >= r_T3 + mul_rows ? 1u : 0u;
         const u32 e = r - r_T3 - id.qn * mul_rows;
-        u32 i;
-        if (e < advice_mul_colstart(L, L)) {   // columns 0 .. L-1 start at i (i + 3) / 2
-            i = (u32)((sqrtf(8.f * (float)e + 9.f) - 3.f) * 0.5f);
-            while (advice_mul_colstart(i + 1, L) <= e) ++i;
-            while (advice_mul_colstart(i, L) > e) --i;
-        } else {
-            i = L;
-            while (advice_mul_colstart(i + 1, L) <= e) ++i;
-        }
-        const u32 k = e - advice_mul_colstart(i, L);
+        // Columns 0 .. L-1 hold 2, 3, ..., L + 1 rows (head + accumulators): column i starts at i (i + 3) / 2.  Columns
+        // L .. 2L-2 mirror columns L-2 .. 0, so counted from the END of the section the same closed form applies.
+        const bool back = e >= advice_mul_colstart(L, L);
+        const u32 ee = back ? mul_rows - 1 - e : e;
+        u32 ii = (u32)((sqrtf(8.f * (float)ee + 9.f) - 3.f) * 0.5f);
+        if ((ii + 1) * (ii + 4) / 2 <= ee) ++ii;          // the float estimate is off by at most one
+        else if (ii * (ii + 3) / 2 > ee) --ii;
+        const u32 kk = ee - ii * (ii + 3) / 2;            // position within the (mirrored) column, 0 .. ii + 1
+        const u32 i = back ? C - 1 - ii : ii, k = back ? ii + 1 - kk : kk;
         id.i = i;
         if (k == 0) { id.kind = ROWK_CONST0; id.j = 0; }
         else { id.kind = ROWK_MUL_ADD; id.j = (i >= L ? i - L + 1 : 0) + (k - 1); }
@@ -2575,7 +2577,16 @@ __host__ __device__ inline AdviceRowId advice_decode(u32 r, u32 L, u32 nrc) {
     return id;
 }
 
+// the decode of every row is input-independent: the ctx keeps it as a table (one 32-bit word per row, L2-resident) so that the
+// kernel's per-row decode is one coalesced load instead of ~100 integer instructions (3.3 -> see profiles/r03_emit_timing.txt)
+__host__ __device__ inline u32 advice_pack(const AdviceRowId &id) { return id.kind | (id.sect << 6) | (id.qn << 9) | (id.i << 10) | (id.j << 18); }
+__host__ __device__ inline AdviceRowId advice_unpack(u32 v) {
+    AdviceRowId id; id.kind = v & 63u; id.sect = (v >> 6) & 7u; id.qn = (v >> 9) & 1u; id.i = (v >> 10) & 255u; id.j = v >> 18;
+    return id;
+}
+
 struct AdviceArgs {
+    const u32 *desc;                    // [rows] advice_pack(advice_decode(r))
     const void *opA, *opB; u64 op_stride; const void *n; u64 n_stride;
     const u8 *status;
     const u8 *trace; u64 elem_stride, off_records, record_stride; u32 T; u64 n_items;
@@ -2591,7 +2602,10 @@ template <int LW>
 __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
     using limb_t = typename LimbT<LW>::type;
     __shared__ u64 sa[128], sb_[128], sq[128], sn[128], sr[128];
-    constexpr u32 SR = 256;                                   // rows per stage (40 KB of LDS; 128-208 rows, i.e. four or more workgroups per CU, measured within +-5 % of it)
+#ifndef H2R_ADVICE_SR
+#define H2R_ADVICE_SR 256
+#endif
+    constexpr u32 SR = H2R_ADVICE_SR;                         // rows per stage (40 KB of LDS; 128-208 rows, i.e. four or more workgroups per CU, measured within +-5 % of it)
     __shared__ uint4 stage[SR * (ADVICE_ROW_BYTES / 16)];    // SR rows are built in LDS, then leave as full 16-byte-per-lane lines
     const u32 tid = threadIdx.x;
     const u32 item = xcd_contiguous_block(blockIdx.x, gridDim.x);   // every XCD reads and writes a contiguous eighth
@@ -2706,7 +2720,7 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
         has_prev = 0;
         if (r >= a.rows) { id.kind = ROWK_NOP; id.sect = 9; }
         else {
-            id = advice_decode(r, L, nrc);
+            id = advice_unpack(a.desc[r]);
             if (id.sect == 0) {                                 // q then r limbs: RangeChip::assign(limb, w/8, w)
                 const bool isr = id.i >= L;
                 s0 = Src{rv.rec + a.off[isr ? H2R_PL_R_SUB : H2R_PL_Q_SUB] + (u64)(isr ? id.i - L : id.i) * 8, rv.rec, 2u};
@@ -2776,7 +2790,7 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
                 const U192 d = c0 - c1;
                 const bool zero = d == Z;
                 row(r, d, lim(1), lim(id.j == 15 ? f1 : f2), Z, Z, false, true);
-                if (!zero) inverse_cell(reinterpret_cast<u8 *>(stage) + (u64)(r % SR) * ADVICE_ROW_BYTES + 32, d);
+                if (!zero && H2R_ADVICE_INV) inverse_cell(reinterpret_cast<u8 *>(stage) + (u64)(r % SR) * ADVICE_ROW_BYTES + 32, d);
                 return;
             }
             case 16: case 21: row(r, lim(id.j == 16 ? f1 : f2), c0 - c1, Z, Z, Z, false, false, true); return;   // [r, d]

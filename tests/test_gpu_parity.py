@@ -1431,15 +1431,16 @@ def test_xcd_mapping_with_ragged_grids(H, w, L, batch):
     img = res.emit_advice()
     torch.cuda.synchronize()
     rows = int(H.lib().h2r_advice_rows(chip._ctx))
-    assert img.shape == (batch, 19 * rows * 160)
-    last = img[batch - 1].cpu().numpy().reshape(19 * rows, 5, 32)
-    first = img[0].cpu().numpy().reshape(19 * rows, 5, 32)
-    for im, i in ((first, 0), (last, batch - 1)):   # row 0 of record 0 holds the first four sub-limbs of q[0] and their running sum
+    assert img.shape == (batch, (2 + 19 * rows) * 160)          # two constant rows (acc = 1), then the 19 records
+    last = img[batch - 1].cpu().numpy().reshape(2 + 19 * rows, 5, 32)
+    first = img[0].cpu().numpy().reshape(2 + 19 * rows, 5, 32)
+    for im, i in ((first, 0), (last, batch - 1)):   # row 0 of record 0 holds the first four sub-limbs of q[0] and, in column e, q[0]
+        assert int.from_bytes(im[0, 0].tobytes(), "little") == 1 and not im[0, 1:].any() and not im[1].any()
         q0 = (X[i] * X[i]) // N[i] & ((1 << w) - 1)
         sb = w // 8
         subs = [(q0 >> (sb * k)) & ((1 << sb) - 1) for k in range(4)]
-        assert [int.from_bytes(im[0, k].tobytes(), "little") for k in range(4)] == subs, i
-        assert int.from_bytes(im[0, 4].tobytes(), "little") == sum(s << (sb * k) for k, s in enumerate(subs)), i
+        assert [int.from_bytes(im[2, k].tobytes(), "little") for k in range(4)] == subs, i
+        assert int.from_bytes(im[2, 4].tobytes(), "little") == q0, i
 
 
 def _check_pow_batch(H, chip, o, X, N, e, res, sample, rng):
