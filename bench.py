@@ -26,8 +26,13 @@ import random
 import sys
 import time
 
-import numpy as np
-import torch
+# the image exports NCCL_DEBUG=VERSION, which makes RCCL print a banner on stdout when a communicator is created (the library
+# reads the variable when it is loaded, i.e. at `import torch`); rank 0's stdout is ONE JSON line
+if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+    os.environ.pop("NCCL_DEBUG")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -291,6 +296,9 @@ def main():
                          "at most pipeline-depth + 1 regions are mapped at any time); 0 = plain allocations, taken as they come")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="fully stream-ordered calls (chain then trace per step) instead of the two-stream pipeline")
+    ap.add_argument("--collectives", choices=["h2r", "torch"], default="h2r",
+                    help="N > 1: the broadcast / result all-gather / timing barrier go through libh2r's RCCL exports (h2r_dist_*, default) "
+                         "or through torch.distributed")
     ap.add_argument("--pmc-traffic", choices=["auto", "off"], default="auto",
                     help="roofline.traffic: auto = measure it now with two rocprofv3 --pmc passes of a short run of the same workload "
                          "(N = 1, rank 0; falls back to the committed profiles/pmc_traffic.json when rocprofv3 is unavailable); off = committed file only")
@@ -306,7 +314,12 @@ def main():
     if one_gpu:
         env.local_rank = 0
     torch.cuda.set_device(env.local_rank)
-    env.init("gloo" if one_gpu else "nccl")
+    # Collectives: world > 1 (or H2R_FORCE_DIST) goes through libh2r's own RCCL exports (h2r_dist_*: what a Rust host binds);
+    # --collectives torch keeps torch.distributed ("nccl" = RCCL), which is also the automatic fall-back if the C-ABI
+    # communicator cannot be created -- config.collective_backend says which one ran.
+    use_h2r_dist = args.collectives == "h2r" and not one_gpu and (env.world > 1 or env.force)
+    if not use_h2r_dist:
+        env.init("gloo" if one_gpu else "nccl")
     if args.user_stream:
         torch.cuda.set_stream(torch.cuda.Stream())
     # Workload: N = 1 -> BASELINE configs[1] (one 1,024-signature call per step).  N > 1 -> configs[2]: every GPU owns a
@@ -316,6 +329,13 @@ def main():
     # small enough for a wide candidate search).  --batch / --chunks override both.
     chunks = args.chunks if args.chunks else (1 if args.gpus == 1 else 4)
     chunk = args.batch if args.batch else (1024 if args.gpus == 1 else 8192 // chunks)
+    if use_h2r_dist:
+        from halo2_rsa_amd.dist import H2RDist
+        try:
+            env = H2RDist(H.BigIntChip(w, bits, device=env.local_rank), env.rank, env.world, env.local_rank)
+        except Exception as ex:   # no librccl, communicator refused ...: torch.distributed instead (every rank fails alike)
+            sys.stderr.write("h2r_dist unavailable (%s): falling back to torch.distributed\n" % str(ex)[:200])
+            env.init("nccl")
     # configuration broadcast (rank 0 decides): the only pre-run collective
     e, chunk, chunks, steps, warmup = env.broadcast_ints([e, chunk, chunks, args.steps, args.warmup])
     shard = chunk * chunks

@@ -91,6 +91,8 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_advice_fixed_row",
            "h2r_lookup_config_default", "h2r_lookup_config_custom", "h2r_lookup_table_image", "h2r_lookup_hist_records",
            "h2r_lookup_hist_values", "h2r_lookup_workspace_bytes", "h2r_lookup_permuted_columns", "h2r_field_eval",
+           "h2r_dist_unique_id", "h2r_dist_init", "h2r_dist_destroy", "h2r_dist_rank", "h2r_dist_world", "h2r_dist_shard_range",
+           "h2r_dist_bcast", "h2r_dist_gather_results", "h2r_dist_allreduce_max_f64",
            "h2r_profile_enable", "h2r_profile_read", "h2r_status_str",
            "h2r_last_hip_error"]
 KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST, KERNEL_AUX, KERNEL_EMIT, KERNEL_STEP, KERNEL_LOOKUP = 0, 1, 2, 3, 4, 5, 6
@@ -208,6 +210,18 @@ def lib():
     L.h2r_lookup_workspace_bytes.restype = u64
     L.h2r_lookup_permuted_columns.argtypes = [vp, pcfg, vp, vp, u64, u32, u32, vp, vp, u64, vp, vp, vp]
     L.h2r_field_eval.argtypes = [vp, u32, pu64, pu64, pu64]
+    L.h2r_dist_unique_id.argtypes = [vp]
+    L.h2r_dist_init.argtypes = [vp, vp, u32, u32, ctypes.POINTER(vp)]
+    L.h2r_dist_destroy.argtypes = [vp]
+    L.h2r_dist_destroy.restype = None
+    L.h2r_dist_rank.argtypes = [vp]
+    L.h2r_dist_rank.restype = u32
+    L.h2r_dist_world.argtypes = [vp]
+    L.h2r_dist_world.restype = u32
+    L.h2r_dist_shard_range.argtypes = [u64, u32, u32, pu64, pu64]
+    L.h2r_dist_bcast.argtypes = [vp, vp, u64, u32, vp]
+    L.h2r_dist_gather_results.argtypes = [vp, vp, vp, u64, vp, vp, vp]
+    L.h2r_dist_allreduce_max_f64.argtypes = [vp, vp, u64, vp]
     L.h2r_profile_enable.argtypes = [u32]
     L.h2r_profile_read.argtypes = [u32, ctypes.POINTER(ctypes.c_float), u32, ctypes.POINTER(u32)]
     L.h2r_status_str.argtypes = [i32]

@@ -1,6 +1,8 @@
 // C ABI of libh2r (see include/h2r.h).  Host side: context, layouts, kernel launches, flatten.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and enums only: the functions are resolved with dlsym (no link-time dependency on librccl)
 
 #include <algorithm>
 #include <cstdio>
@@ -801,6 +803,149 @@ struct h2r_pipeline {
     hipStream_t pending_st = nullptr;
     hipEvent_t flush_done = nullptr;   // orders another stream behind a flush
 };
+
+// ---- multi-GPU: RCCL behind the C ABI --------------------------------------------------------------------------------------
+extern "C++" {
+namespace {
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+const Rccl &rccl() {
+    static const Rccl r = [] {
+        Rccl x;
+        // the copy the process already has (torch's librccl.so, an application's) wins; else the system's
+        for (const char *name : {"librccl.so.1", "librccl.so"}) if (!x.handle) x.handle = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if (!x.handle) x.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (!x.handle) return x;
+        auto sym = [&](const char *n) { return dlsym(x.handle, n); };
+        x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(sym("ncclGetUniqueId"));
+        x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(sym("ncclCommInitRank"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(sym("ncclCommDestroy"));
+        x.Broadcast = reinterpret_cast<decltype(x.Broadcast)>(sym("ncclBroadcast"));
+        x.AllGather = reinterpret_cast<decltype(x.AllGather)>(sym("ncclAllGather"));
+        x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(sym("ncclAllReduce"));
+        x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
+        x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+        x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.Broadcast && x.AllGather && x.AllReduce && x.GroupStart && x.GroupEnd && x.GetErrorString;
+        return x;
+    }();
+    return r;
+}
+bool rccl_ok(ncclResult_t e, const char *what) {
+    if (e == ncclSuccess) return true;
+    std::snprintf(g_hip_err, sizeof g_hip_err, "%s: %s", what, rccl().GetErrorString ? rccl().GetErrorString(e) : "RCCL error");
+    return false;
+}
+#define RCCL_TRY(expr) do { if (!rccl_ok((expr), #expr)) return H2R_E_HIP; } while (0)
+int32_t rccl_ready() {
+    if (rccl().ok) return H2R_OK;
+    std::snprintf(g_hip_err, sizeof g_hip_err, "librccl.so.1 could not be loaded: %s", rccl().handle ? "symbols missing" : (dlerror() ? dlerror() : "not found"));
+    return H2R_E_HIP;
+}
+}  // namespace
+}  // extern "C++"
+
+struct h2r_dist {
+    const h2r_ctx *ctx; ncclComm_t comm; u32 rank, world;
+};
+
+int32_t h2r_dist_unique_id(uint8_t id_out[H2R_DIST_ID_BYTES]) {
+    if (!id_out) return H2R_E_NULL;
+    const int32_t rc = rccl_ready();
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == H2R_DIST_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    RCCL_TRY(rccl().GetUniqueId(&id));
+    std::memcpy(id_out, &id, sizeof id);
+    return H2R_OK;
+}
+
+int32_t h2r_dist_init(const h2r_ctx *ctx, const uint8_t id[H2R_DIST_ID_BYTES], uint32_t rank, uint32_t world, h2r_dist **out) {
+    if (!ctx || !id || !out) return H2R_E_NULL;
+    *out = nullptr;
+    if (world == 0 || rank >= world) return H2R_E_SHAPE;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    const int32_t rc = rccl_ready();
+    if (rc) return rc;
+    H2R_ON_DEVICE(ctx->params.device);
+    ncclUniqueId nid;
+    std::memcpy(&nid, id, sizeof nid);
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(rccl().CommInitRank(&comm, (int)world, nid, (int)rank));
+    h2r_dist *d = new (std::nothrow) h2r_dist{ctx, comm, rank, world};
+    if (!d) { (void)rccl().CommDestroy(comm); return H2R_E_HIP; }
+    *out = d;
+    return H2R_OK;
+}
+
+void h2r_dist_destroy(h2r_dist *d) {
+    if (!d) return;
+    { DeviceGuard dg(d->ctx->params.device); (void)hipDeviceSynchronize(); (void)rccl().CommDestroy(d->comm); }
+    delete d;
+}
+uint32_t h2r_dist_rank(const h2r_dist *d) { return d ? d->rank : 0; }
+uint32_t h2r_dist_world(const h2r_dist *d) { return d ? d->world : 0; }
+
+int32_t h2r_dist_shard_range(uint64_t total, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi) {
+    if (!lo || !hi) return H2R_E_NULL;
+    if (world == 0 || rank >= world) return H2R_E_SHAPE;
+    const u64 base = total / world, rem = total % world;
+    *lo = rank * base + std::min<u64>(rank, rem);
+    *hi = *lo + base + (rank < rem ? 1 : 0);
+    return H2R_OK;
+}
+
+int32_t h2r_dist_bcast(h2r_dist *d, void *buf, uint64_t bytes, uint32_t root, h2r_stream_t stream) {
+    if (!d || !buf) return H2R_E_NULL;
+    if (root >= d->world) return H2R_E_SHAPE;
+    if (bytes == 0) return H2R_OK;
+    H2R_ON_DEVICE(d->ctx->params.device);
+    RCCL_TRY(rccl().Broadcast(buf, buf, bytes, ncclUint8, (int)root, d->comm, static_cast<hipStream_t>(stream)));
+    return H2R_OK;
+}
+
+int32_t h2r_dist_gather_results(h2r_dist *d, const void *results_shard, const uint8_t *status_shard, uint64_t shard_elems,
+                                void *results_all, uint8_t *status_all, h2r_stream_t stream) {
+    if (!d || !results_shard || !results_all || (!status_shard != !status_all)) return H2R_E_NULL;
+    if (shard_elems == 0) return H2R_OK;
+    H2R_ON_DEVICE(d->ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const u64 bytes = shard_elems * (u64)d->ctx->L * d->ctx->layout.limb_bytes;
+    RCCL_TRY(rccl().GroupStart());
+    const ncclResult_t r1 = rccl().AllGather(results_shard, results_all, bytes, ncclUint8, d->comm, st);
+    const ncclResult_t r2 = status_shard ? rccl().AllGather(status_shard, status_all, shard_elems, ncclUint8, d->comm, st) : ncclSuccess;
+    const ncclResult_t r3 = rccl().GroupEnd();
+    RCCL_TRY(r1); RCCL_TRY(r2); RCCL_TRY(r3);
+    return H2R_OK;
+}
+
+int32_t h2r_dist_allreduce_max_f64(h2r_dist *d, double *values, uint64_t count, h2r_stream_t stream) {
+    if (!d) return H2R_E_NULL;
+    H2R_ON_DEVICE(d->ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (count == 0 || !values) {   // barrier: a one-element reduction on a scratch word, ordered on `stream`
+        double *tmp = nullptr;
+        HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&tmp), sizeof(double), st));
+        HIP_TRY(hipMemsetAsync(tmp, 0, sizeof(double), st));
+        const ncclResult_t r = rccl().AllReduce(tmp, tmp, 1, ncclDouble, ncclMax, d->comm, st);
+        (void)hipFreeAsync(tmp, st);
+        RCCL_TRY(r);
+        return H2R_OK;
+    }
+    RCCL_TRY(rccl().AllReduce(values, values, count, ncclDouble, ncclMax, d->comm, st));
+    return H2R_OK;
+}
 
 // ---- placement-aware trace arena ---------------------------------------------------------------------------------------
 // Where a trace buffer lies physically decides how fast the record kernel writes it: per 1.25 GB region of config 2 one of

@@ -94,3 +94,68 @@ class DistEnv:
             dist.barrier() if self.backend != "nccl" else dist.barrier(device_ids=[self.local_rank])
             dist.destroy_process_group()
             self.initialised = False
+
+
+class H2RDist:
+    """The same plumbing over libh2r's own RCCL exports (h2r_dist_*: SURVEY section 2 component C1 behind the C ABI) -- what a
+    Rust prover service binds.  Only the 128-byte RCCL id travels out of band: here through a torch.distributed.TCPStore at
+    MASTER_ADDR:MASTER_PORT (a key-value socket, no process group); a service uses its own launcher."""
+
+    def __init__(self, chip, rank: int, world: int, local_rank: int):
+        import ctypes
+        from datetime import timedelta
+        from ._lib import check, lib
+        self.chip, self.rank, self.world, self.local_rank = chip, rank, world, local_rank
+        self._lib, self._check, self._ct = lib(), check, ctypes
+        idb = (ctypes.c_uint8 * 128)()
+        if world > 1:
+            # under torchrun the agent already serves a TCPStore at MASTER_ADDR:MASTER_PORT (every worker is a client of it);
+            # launched any other way, rank 0 serves one itself
+            agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true"
+            store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29531")), world,
+                                  is_master=(rank == 0 and not agent), timeout=timedelta(seconds=120))
+            if rank == 0:
+                check(self._lib.h2r_dist_unique_id(idb), "h2r_dist_unique_id")
+                store.set("h2r_dist_id", bytes(idb))
+            else:
+                raw = store.get("h2r_dist_id")
+                ctypes.memmove(idb, raw, 128)
+            self._store = store
+        else:
+            check(self._lib.h2r_dist_unique_id(idb), "h2r_dist_unique_id")
+        self._d = ctypes.c_void_p()
+        check(self._lib.h2r_dist_init(chip._ctx, idb, rank, world, ctypes.byref(self._d)), "h2r_dist_init")
+        self.initialised, self.backend = True, "h2r_dist (RCCL via the C ABI)"
+        self._dev = torch.device("cuda", local_rank)
+
+    def _stream(self):
+        return self.chip._stream()
+
+    def barrier(self):
+        self._check(self._lib.h2r_dist_allreduce_max_f64(self._d, None, 0, self._stream()), "h2r_dist barrier")
+        torch.cuda.synchronize(self._dev)
+
+    def max_over_ranks(self, value: float) -> float:
+        t = torch.tensor([value], dtype=torch.float64, device=self._dev)
+        self._check(self._lib.h2r_dist_allreduce_max_f64(self._d, t.data_ptr(), 1, self._stream()), "h2r_dist_allreduce_max_f64")
+        return float(t.item())
+
+    def broadcast_ints(self, values: List[int]) -> List[int]:
+        t = torch.tensor(values, dtype=torch.int64, device=self._dev)
+        self._check(self._lib.h2r_dist_bcast(self._d, t.data_ptr(), t.numel() * 8, 0, self._stream()), "h2r_dist_bcast")
+        return [int(v) for v in t.tolist()]
+
+    def gather_to_rank0(self, shard: torch.Tensor):
+        """shard: [elems, num_limbs] limbs.  Every rank receives every shard (all-gather); rank 0 returns the concatenation."""
+        shard = shard.contiguous()
+        out = torch.empty((self.world * shard.shape[0],) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+        self._check(self._lib.h2r_dist_gather_results(self._d, shard.data_ptr(), None, shard.shape[0], out.data_ptr(), None, self._stream()),
+                    "h2r_dist_gather_results")
+        torch.cuda.synchronize(self._dev)
+        return out if self.rank == 0 else None
+
+    def finalize(self):
+        if self._d:
+            self.barrier()
+            self._lib.h2r_dist_destroy(self._d)
+            self._d = self._ct.c_void_p()

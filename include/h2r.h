@@ -277,6 +277,32 @@ int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const voi
                                        uint8_t *status, void *workspace, h2r_stream_t stream);
 int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream);
 
+/* ---- multi-GPU: one process per GPU, signatures sharded, RCCL over xGMI behind the C ABI ---------------------------------
+ * Signatures are independent: every rank owns a contiguous shard of the batch (h2r_dist_shard_range), runs the
+ * exports above on it and keeps its traces resident on its own GPU -- there is NO data-path collective.  What a prover
+ * service exchanges is small: the call's parameters (exponent, sizes; a shared modulus) from rank 0, the per-signature
+ * results (num_limbs limbs + one status byte) to every rank, and a barrier / MAX for timing.  These exports are that, over
+ * RCCL directly (librccl.so.1 is dlopen'ed on first use -- the copy already loaded in the process, e.g. torch's, if any --
+ * so the library has no link-time dependency on it); a Rust host needs no torch / MPI for the collectives, only a way to hand
+ * rank 0's 128-byte id to the other ranks (its launcher, a file, a socket).  All buffers are DEVICE pointers on the ctx's
+ * device; calls enqueue on `stream`.  H2R_E_HIP with h2r_last_hip_error() carrying RCCL's message on failure. */
+#define H2R_DIST_ID_BYTES 128u
+typedef struct h2r_dist h2r_dist;
+int32_t h2r_dist_unique_id(uint8_t id_out[H2R_DIST_ID_BYTES]);                     /* rank 0: ncclGetUniqueId */
+int32_t h2r_dist_init(const h2r_ctx *ctx, const uint8_t id[H2R_DIST_ID_BYTES], uint32_t rank, uint32_t world, h2r_dist **out);
+void h2r_dist_destroy(h2r_dist *d);
+uint32_t h2r_dist_rank(const h2r_dist *d);
+uint32_t h2r_dist_world(const h2r_dist *d);
+/* contiguous shards: rank g gets [g * total / world, (g + 1) * total / world), the remainder spread over the low ranks */
+int32_t h2r_dist_shard_range(uint64_t total, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi);
+int32_t h2r_dist_bcast(h2r_dist *d, void *buf, uint64_t bytes, uint32_t root, h2r_stream_t stream);            /* ncclBroadcast */
+/* all-gather of equally sized shards: results_all[rank] = results_shard (shard_elems * num_limbs limbs), status likewise
+ * (status_shard / status_all nullable).  256 B + 1 B per RSA-2048 signature: 16.8 MB for BASELINE config 3. */
+int32_t h2r_dist_gather_results(h2r_dist *d, const void *results_shard, const uint8_t *status_shard, uint64_t shard_elems,
+                                void *results_all, uint8_t *status_all, h2r_stream_t stream);
+/* in-place MAX over the ranks of `count` doubles (timing); with count = 0 it is a barrier on `stream` */
+int32_t h2r_dist_allreduce_max_f64(h2r_dist *d, double *values, uint64_t count, h2r_stream_t stream);
+
 /* ---- placement-aware trace arena ---------------------------------------------------------------
  * How fast the record kernel writes a trace buffer depends on where the buffer lies physically: for a 1.25 GB region
  * 5.65 .. 6.8 TB/s, stable for the life of the allocation.  The arena maps `candidates` regions of

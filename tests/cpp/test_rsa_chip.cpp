@@ -173,6 +173,43 @@ int main(int argc, char **argv) {
     bool threw = false;
     try { BigIntChip bad(64, 2048 + 8); } catch (const Error &e) { threw = e.code == H2R_E_SHAPE; }
     REQUIRE(threw);
+    // The multi-GPU exports over RCCL (h2r_dist_*, SURVEY section 2 component C1), as a Rust host would call them: a ONE-rank
+    // communicator on this box's single GPU -- id, init, shard ranges, parameter broadcast, result all-gather, MAX, barrier.
+    {
+        uint8_t id[H2R_DIST_ID_BYTES];
+        REQUIRE(h2r_dist_unique_id(id) == H2R_OK);
+        h2r_dist *d = nullptr;
+        REQUIRE(h2r_dist_init(bigint_chip.ctx(), id, 1, 1, &d) == H2R_E_SHAPE);   // rank >= world
+        REQUIRE(h2r_dist_init(bigint_chip.ctx(), id, 0, 1, &d) == H2R_OK && d);
+        REQUIRE(h2r_dist_rank(d) == 0 && h2r_dist_world(d) == 1);
+        uint64_t lo = 0, hi = 0;
+        REQUIRE(h2r_dist_shard_range(65536, 3, 8, &lo, &hi) == H2R_OK && lo == 3 * 8192 && hi == 4 * 8192);   // BASELINE config 3
+        REQUIRE(h2r_dist_shard_range(10, 2, 3, &lo, &hi) == H2R_OK && lo == 7 && hi == 10);
+        std::vector<uint64_t> cfg = {65537, 1024, 4}, back(3, 0);
+        DeviceBuffer cb(sizeof(uint64_t) * 3), all(res.powed.limbs().size() * 8), st_all(B);
+        cb.upload(cfg.data(), sizeof(uint64_t) * 3);
+        DeviceBuffer st_dev(B);
+        st_dev.upload(res.status.data(), B);
+        REQUIRE(h2r_dist_bcast(d, cb.get(), sizeof(uint64_t) * 3, 0, nullptr) == H2R_OK);
+        REQUIRE(h2r_dist_gather_results(d, res.powed.data(), static_cast<const uint8_t *>(st_dev.get()), B, all.get(), static_cast<uint8_t *>(st_all.get()), nullptr) == H2R_OK);
+        DeviceBuffer tm(sizeof(double));
+        double t = 1.25;
+        tm.upload(&t, sizeof t);
+        REQUIRE(h2r_dist_allreduce_max_f64(d, static_cast<double *>(tm.get()), 1, nullptr) == H2R_OK);
+        REQUIRE(h2r_dist_allreduce_max_f64(d, nullptr, 0, nullptr) == H2R_OK);    // barrier
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        cb.download(back.data(), sizeof(uint64_t) * 3);
+        REQUIRE(back == cfg);
+        std::vector<uint64_t> gathered(res.powed.limbs().size());
+        all.download(gathered.data(), gathered.size() * 8);
+        REQUIRE(gathered == res.powed.limbs());
+        std::vector<uint8_t> gst(B);
+        st_all.download(gst.data(), B);
+        REQUIRE(gst == res.status);
+        tm.download(&t, sizeof t);
+        REQUIRE(t == 1.25);
+        h2r_dist_destroy(d);
+    }
     std::printf("CPP_HOST_MIRROR_OK %zu signatures\n", B);
     return 0;
 }

@@ -1745,3 +1745,32 @@ def test_mul_is_equal_muled_refresh(H, w, L):
         assert e == int(neq[i].item()) and np.array_equal(chip.flatten_is_equal_muled(trn, i), est), i
         rc, rl, rst = refresh(o, cols_ab)
         assert rc == 0 and np.array_equal(rstream[i].cpu().numpy(), rst), i
+
+
+def test_dist_exports_one_rank(H):
+    """h2r_dist_* (RCCL behind the C ABI) with a one-rank communicator on this box's GPU, through the Python mirror bench.py uses
+    for N > 1 (halo2_rsa_amd.dist.H2RDist): parameter broadcast, all-gather of the per-signature results, MAX, barrier; and
+    the shard ranges against halo2_rsa_amd.dist.shard_range."""
+    import ctypes
+    from halo2_rsa_amd import _lib
+    from halo2_rsa_amd.dist import H2RDist, shard_range
+    chip = H.BigIntChip(64, 2048)
+    lo, hi = ctypes.c_uint64(), ctypes.c_uint64()
+    for total in (0, 1, 7, 1024, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                assert _lib.lib().h2r_dist_shard_range(total, r, world, ctypes.byref(lo), ctypes.byref(hi)) == 0
+                assert (lo.value, hi.value) == shard_range(total, r, world)
+    assert _lib.lib().h2r_dist_shard_range(10, 3, 3, ctypes.byref(lo), ctypes.byref(hi)) == _lib.H2R_E_SHAPE
+    d = H2RDist(chip, 0, 1, 0)
+    assert d.broadcast_ints([65537, 2048, 4, 20, 5]) == [65537, 2048, 4, 20, 5]
+    assert d.max_over_ranks(0.75) == 0.75
+    d.barrier()
+    rng = random.Random(12)
+    N = [rand_modulus(rng, 2048) for _ in range(5)]
+    X = [rng.randrange(n) for n in N]
+    res = chip.pow_mod_fixed_exp(chip.assign_integer(X), 65537, chip.assign_integer(N), want_trace=False)
+    g = d.gather_to_rank0(res.value.limbs_dev)
+    assert torch.equal(g, res.value.limbs_dev)
+    assert H.AssignedInteger(g, 64).to_big_uint() == [pow(x, 65537, n) for x, n in zip(X, N)]
+    d.finalize()
