@@ -1076,6 +1076,18 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
         }
     };
     run_round();
+    // The kept regions should be of ONE class: a pipeline rotates through all of them, and a step into a second-class region
+    // is 8 % longer (driver box of round 2: 1 fast candidate of 24, kept 0.183 / 0.199 ms).  While the slowest kept region is
+    // more than 4 % behind the fastest, keep looking -- up to three more rounds' worth of candidates, one at a time.
+    if (rc == H2R_OK && regions > 1 && region_bytes <= (4ull << 30)) {
+        for (u32 extra = 0; extra < 3 * candidates && rc == H2R_OK && cands.size() == regions && cands.back().ms > 1.04f * cands.front().ms; ++extra) {
+            cands.emplace_back();
+            const int32_t r1 = make_candidate(cands.back());
+            if (r1 != H2R_OK) { arena_free_region(cands.back()); cands.pop_back(); (void)hipGetLastError(); break; }   // out of memory: what we have
+            a->measured.push_back(cands.back().ms);
+            keep_best(regions, false);
+        }
+    }
     if (rc == H2R_OK && region_bytes <= (4ull << 30) && candidates >= 4) {
         // No fast class among the candidates (the fast regions are >= 10 % faster than the rest; some boxes show none where
         // these candidates land)?  One more round in another part of the memory: behind a large placeholder allocation.
