@@ -1,0 +1,98 @@
+// AddressSanitizer / UBSan build of the HOST side (SURVEY section 5's sanitizer build): the C oracle compiled instrumented, and
+// every host-only export of libh2r.so driven through exact-size heap buffers (the library's writes into caller memory are
+// memcpy / memset calls, which the sanitizer's interceptors bound-check even though libh2r.so itself is not instrumented).
+// No device work: contexts are host-only (device = -1).  TEST CODE: links the oracle (checker).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "h2r.h"
+#include "../../oracle/h2r_oracle.h"
+
+#define REQUIRE(cond) do { if (!(cond)) { std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } } while (0)
+
+static uint64_t rng_state = 0x68327273ull;
+static uint64_t next64() { uint64_t z = (rng_state += 0x9e3779b97f4a7c15ull); z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); }
+
+template <typename T> static std::unique_ptr<T[]> heap(size_t n) { return std::unique_ptr<T[]>(new T[n]()); }
+
+static int one_shape(uint32_t w, uint32_t L, uint32_t field) {
+    h2r_params prm{w, w * L, field, -1};
+    h2r_ctx *ctx = nullptr;
+    REQUIRE(h2r_ctx_create(&prm, &ctx) == H2R_OK);
+    h2r_layout lo;
+    REQUIRE(h2r_trace_layout(ctx, &lo) == H2R_OK && lo.num_limbs == L);
+    h2ro_params op;
+    REQUIRE(h2ro_params_init(&op, w, L) == 0 && op.mul_mod_stream_bytes == lo.stream_bytes);
+    // oracle: a random mul_mod and a short pow, streams into exact-size heap buffers
+    const size_t lb = w / 8;
+    auto a = heap<uint8_t>(L * lb), b = heap<uint8_t>(L * lb), n = heap<uint8_t>(L * lb), r = heap<uint8_t>(L * lb);
+    for (size_t i = 0; i < L * lb; ++i) { a[i] = (uint8_t)next64(); b[i] = (uint8_t)next64(); n[i] = (uint8_t)next64(); }
+    n[0] |= 1; n[L * lb - 1] |= 0x80; a[L * lb - 1] &= 0x7f; b[L * lb - 1] &= 0x7f;   // a, b < n
+    auto st = heap<uint8_t>(op.mul_mod_stream_bytes);
+    REQUIRE(h2ro_mul_mod(&op, a.get(), b.get(), n.get(), st.get(), r.get()) == 0);
+    const uint8_t e_le[1] = {0x0b};
+    const uint64_t psb = h2ro_pow_fixed_stream_bytes(&op, e_le, 1);
+    auto pst = heap<uint8_t>(psb); auto pout = heap<uint8_t>(L * lb), ref = heap<uint8_t>(L * lb);
+    REQUIRE(h2ro_pow_mod_fixed_exp(&op, a.get(), n.get(), e_le, 1, pst.get(), pout.get()) == 0);
+    REQUIRE(h2ro_big_pow_mod(&op, a.get(), e_le, 1, n.get(), ref.get()) == 0 && std::memcmp(pout.get(), ref.get(), L * lb) == 0);
+    auto ist = heap<uint8_t>(h2ro_in_field_stream_bytes(&op)); int lt = -1;
+    REQUIRE(h2ro_assert_in_field(&op, a.get(), n.get(), ist.get(), &lt) == 0 && lt == 1);
+    // libh2r host-only exports: layouts, flatten of a record (zero planes: only the walk's bounds matter), streams
+    h2r_pow_layout pl, vpl;
+    REQUIRE(h2r_pow_fixed_layout(ctx, e_le, 1, &pl) == H2R_OK && pl.stream_bytes == psb);
+    REQUIRE(h2r_pow_var_layout(ctx, 2, 5, &vpl) == H2R_OK);
+    auto rec = heap<uint8_t>(lo.record_stride);
+    for (uint32_t flags = 0; flags < 2; ++flags) {
+        const uint64_t sb = h2r_stream_bytes(ctx, flags);
+        auto out = heap<uint8_t>(sb);
+        REQUIRE(h2r_trace_flatten_ex(ctx, rec.get(), flags, out.get()) == H2R_OK);
+        auto elem = heap<uint8_t>(pl.elem_stride), pout2 = heap<uint8_t>(h2r_pow_stream_bytes(ctx, &pl, flags));
+        REQUIRE(h2r_pow_trace_flatten_ex(ctx, &pl, elem.get(), flags, pout2.get()) == H2R_OK);
+        auto velem = heap<uint8_t>(vpl.elem_stride), vout = heap<uint8_t>(h2r_pow_stream_bytes(ctx, &vpl, flags));
+        REQUIRE(h2r_pow_trace_flatten_ex(ctx, &vpl, velem.get(), flags, vout.get()) == H2R_OK);
+    }
+    { auto out = heap<uint8_t>(h2r_mul_stream_bytes(ctx)); REQUIRE(h2r_mul_trace_flatten(ctx, rec.get(), out.get()) == H2R_OK); }
+    { auto out = heap<uint8_t>(h2r_is_equal_muled_stream_bytes(ctx)); REQUIRE(h2r_is_equal_muled_flatten(ctx, rec.get(), out.get()) == H2R_OK); }
+    for (uint32_t opk = 0; opk < H2R_OP_COUNT; ++opk) {
+        uint64_t es = 0, sb = 0; uint32_t vl = 0;
+        REQUIRE(h2r_fresh_op_layout(ctx, opk, &es, &sb, &vl) == H2R_OK);
+        auto e = heap<uint8_t>(es), o = heap<uint8_t>(sb ? sb : 1);
+        REQUIRE(h2r_fresh_op_flatten(ctx, opk, e.get(), o.get()) == H2R_OK);
+    }
+    if (w == 64 && L >= 9) {
+        h2r_verify_layout vl;
+        const uint8_t e3[3] = {1, 0, 1};
+        REQUIRE(h2r_verify_layout_fixed(ctx, e3, 3, &vl) == H2R_OK);
+        auto e = heap<uint8_t>(vl.elem_stride), o = heap<uint8_t>(vl.stream_bytes);
+        REQUIRE(h2r_verify_trace_flatten(ctx, &vl, e.get(), o.get()) == H2R_OK);
+    }
+    // lookup argument + advice image: host side
+    h2r_lookup_config cfg;
+    REQUIRE(h2r_lookup_config_default(ctx, w == 64, &cfg) == H2R_OK);
+    auto tcol = heap<uint64_t>(4 * cfg.n_rows), vcol = heap<uint64_t>(4 * cfg.n_rows);
+    REQUIRE(h2r_lookup_table_image(ctx, &cfg, tcol.get(), vcol.get()) == H2R_OK);
+    const uint32_t rows = h2r_advice_rows(ctx);
+    auto kinds = heap<uint8_t>(rows);
+    REQUIRE(h2r_advice_row_kinds(ctx, kinds.get()) == H2R_OK);
+    for (uint32_t i = 0; i < rows; ++i) { h2r_fixed_row fr; REQUIRE(h2r_advice_fixed_row(ctx, &cfg, kinds[i], &fr) == H2R_OK); }
+    uint64_t x[4] = {5, 0, 0, 0}, y[4] = {7, 0, 0, 0}, z[4], zi[4], one[4];
+    REQUIRE(h2r_field_eval(ctx, 2, x, y, z) == H2R_OK && z[0] == 35);
+    REQUIRE(h2r_field_eval(ctx, 3, z, nullptr, zi) == H2R_OK && h2r_field_eval(ctx, 2, z, zi, one) == H2R_OK && one[0] == 1 && !one[1] && !one[2] && !one[3]);
+    uint64_t sizes[64]; uint32_t ns = 0, paced = 0;
+    REQUIRE(h2r_pipeline_call_plan(ctx, 8192, 0, sizes, 64, &ns, &paced) == H2R_OK && ns >= 1);
+    uint64_t s_lo = 0, s_hi = 0;
+    REQUIRE(h2r_dist_shard_range(65536, 7, 8, &s_lo, &s_hi) == H2R_OK && s_hi == 65536);
+    REQUIRE(h2r_workspace_bytes(ctx, 1024, 19) > 0);
+    h2r_ctx_destroy(ctx);
+    return 0;
+}
+
+int main() {
+    const uint32_t shapes[][3] = {{64, 32, H2R_FIELD_BN254_FR}, {32, 128, H2R_FIELD_PASTA_FP}, {64, 4, H2R_FIELD_BN254_FQ}, {64, 48, H2R_FIELD_PASTA_FQ}, {32, 8, H2R_FIELD_BN254_FR}};
+    for (auto &s : shapes) if (one_shape(s[0], s[1], s[2])) return 1;
+    std::printf("ASAN_HOST_OK %zu shapes\n", sizeof shapes / sizeof shapes[0]);
+    return 0;
+}
