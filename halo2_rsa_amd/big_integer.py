@@ -717,6 +717,12 @@ class LookupArgument:
                                            values.shape[0], bit_len, sublimb_bits, hist.data_ptr(), self.chip._stream()), "h2r_lookup_hist_values")
         return hist
 
+    def hist_fresh_op(self, op_name: str, trace_buf: torch.Tensor, elem_stride: int, batch: int, hist: torch.Tensor, first_off: int = 0):
+        """Adds the range assigns inside a Fresh-op witness (e.g. "is_in_field": the assert_in_field witness of modpow_public_key)."""
+        check(lib().h2r_lookup_hist_fresh_op(self.chip._ctx, ctypes.byref(self.cfg), _lib.FRESH_OPS.index(op_name), trace_buf.data_ptr(), first_off,
+                                             elem_stride, batch, hist.data_ptr(), self.chip._stream()), "h2r_lookup_hist_fresh_op")
+        return hist
+
     def permuted_columns(self, hist: torch.Tensor, thetas: Sequence[int], usable_rows: int, arg_mask: int = 31, out=None):
         """(A', S', status): uint8 [batch, 5, usable_rows, 32] each -- canonical little-endian field elements."""
         batch = hist.shape[0]

@@ -1854,6 +1854,64 @@ int32_t h2r_lookup_hist_values(const h2r_ctx *ctx, const h2r_lookup_config *cfg,
     return H2R_OK;
 }
 
+extern "C++" {
+namespace {
+// The RangeChip::assign entries of a Fresh-op region, in the region's own geometry (fresh_sections): add(n) holds two per step
+// (c and the carry, chip.rs:279-282), sub_unchecked's difference one per limb (chip.rs:1307-1308).
+template <typename F>
+void fresh_range_runs(const AuxGeom &g, u32 op, F &&run) {
+    u64 off = 0;
+    const u32 L = g.L;
+    auto add = [&](u32 n) { run(off + 2 * g.SB, n, g.STEP); run(off + 2 * g.SB + g.RA, n, g.STEP); off += g.add_sz(n); };
+    auto eq = [&](u32 n) { off += g.eq_sz(n); };
+    auto subu = [&](u32 n1) { run(off, n1, g.RA); off += g.cl_sz(n1); add(n1); eq(n1 + 1); };
+    auto sub = [&](u32 nA, u32 nB) {
+        const u32 m = nA > nB ? nA : nB, n1 = m + 1;
+        add(m); subu(n1);
+        off += 16; off += AuxGeom::a16((u64)n1 * g.LB); off += AuxGeom::a16((u64)m * g.LB);
+        subu(n1);
+    };
+    auto lt = [&]() { sub(L, L); eq(L); off += 16; };
+    switch (op) {
+        case FRESH_ADD: add(L); break;
+        case FRESH_SUB: case FRESH_IS_LESS_THAN_OR_EQUAL: case FRESH_IS_GREATER_THAN: sub(L, L); break;
+        case FRESH_ADD_MOD: add(L); sub(L + 1, L); break;
+        case FRESH_SUB_MOD: sub(L, L); sub(L, L + 1); break;
+        case FRESH_IS_LESS_THAN: case FRESH_IS_IN_FIELD: case FRESH_IS_GREATER_THAN_OR_EQUAL: lt(); break;
+        default: break;   // is_zero, is_equal_fresh: no range assign
+    }
+}
+}  // namespace
+}  // extern "C++"
+
+int32_t h2r_lookup_hist_fresh_op(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint32_t op, const void *trace, uint64_t first_off,
+                                 uint64_t elem_stride, uint64_t num_elems, uint32_t *hist, h2r_stream_t stream) {
+    if (!ctx || !cfg || !trace || !hist) return H2R_E_NULL;
+    if (ctx->params.device < 0 || op >= FRESH_OP_COUNT) return H2R_E_UNSUPPORTED;
+    if (cfg->n_rows == 0 || cfg->n_rows > (u32)LOOKUP_MAX_ROWS) return H2R_E_SHAPE;
+    const h2r_layout &lo = ctx->layout;
+    LookupFreshArgs a;
+    std::memset(&a, 0, sizeof a);
+    const int32_t rc = range_shape(*cfg, lo.limb_width, lo.limb_sub_bits, &a.limb);
+    if (rc) return rc;
+    const AuxGeom g(ctx->L, lo.limb_width);
+    bool too_many = false;
+    fresh_range_runs(g, op, [&](u64 off, u32 n, u32 stride) {
+        if (a.n_runs >= 16) { too_many = true; return; }
+        a.run_off[a.n_runs] = (u32)off; a.run_n[a.n_runs] = n; a.run_stride[a.n_runs] = stride; ++a.n_runs;
+    });
+    if (too_many) return H2R_E_UNSUPPORTED;
+    if (num_elems == 0 || a.n_runs == 0) return H2R_OK;
+    a.trace = static_cast<const u8 *>(trace); a.first_off = first_off; a.elem_stride = elem_stride; a.num_elems = num_elems;
+    a.sub_off = lo.limb_bytes; a.n_rows = cfg->n_rows; a.hist = hist;
+    H2R_ON_DEVICE(ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope ps(H2R_KERNEL_HIST, st);
+    hipLaunchKernelGGL(lookup_hist_fresh_kernel, dim3((unsigned)num_elems), dim3(64), LOOKUP_ARGS * cfg->n_rows * sizeof(u32), st, a);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
+
 uint64_t h2r_lookup_workspace_bytes(const h2r_lookup_config *cfg, uint64_t num_elems) {
     if (!cfg || cfg->n_rows == 0 || cfg->n_rows > (u32)LOOKUP_MAX_ROWS) return 0;
     return num_elems * LOOKUP_ARGS * lookup_slot_bytes(cfg->n_rows) + 256;

@@ -102,6 +102,31 @@ __global__ __launch_bounds__(256) void lookup_hist_values_kernel(LookupValuesArg
     for (u32 k = tid; k < n; k += 256) if (lh[k]) out[k] += lh[k];
 }
 
+// The range assigns inside a Fresh-op witness (assert_in_field's add / sub_unchecked steps: every one a
+// RangeChip::assign(limb, w/8, w), big_integer/chip.rs:279-282, 1307-1308): runs of entries {limb, 8 sub-limb bytes} at a stride
+struct LookupFreshArgs {
+    const u8 *trace; u64 first_off, elem_stride, num_elems;
+    u32 n_runs; u32 run_off[16], run_n[16], run_stride[16]; u32 sub_off;   // sub-limb bytes at entry + sub_off
+    RangeShape limb; u32 n_rows; u32 *hist; const u8 *status;
+};
+__global__ __launch_bounds__(64) void lookup_hist_fresh_kernel(LookupFreshArgs a) {
+    extern __shared__ u32 lh[];
+    const u32 tid = threadIdx.x, n = LOOKUP_ARGS * a.n_rows;
+    const u64 elem = blockIdx.x;
+    for (u32 k = tid; k < n; k += 64) lh[k] = 0;
+    __syncthreads();
+    const u8 *base = a.trace + elem * a.elem_stride + a.first_off;
+    for (u32 r = 0; r < a.n_runs; ++r)
+        for (u32 i = tid; i < a.run_n[r]; i += 64) {
+            const u8 *p = base + a.run_off[r] + (u64)i * a.run_stride[r] + a.sub_off;
+            const u64 sb = (u64) * reinterpret_cast<const u32 *>(p) | ((u64) * reinterpret_cast<const u32 *>(p + 4) << 32);   // 4-byte aligned for 32-bit limbs
+            range_count(lh, a.n_rows, a.limb, [&](u32 t) { return (u32)((sb >> (8 * t)) & 0xff); });
+        }
+    __syncthreads();
+    u32 *out = a.hist + elem * n;
+    for (u32 k = tid; k < n; k += 64) if (lh[k]) out[k] += lh[k];
+}
+
 // ---- tables of one (element, argument) in the workspace ---------------------------------------------------------------
 // [0, 32 G)  val      sorted distinct compressed values (Fe)
 // then u32 a_start[G + 1] (prefix of the run lengths of A'), a_rank[G] (non-empty runs before g), l_start[G + 1] (prefix of the

@@ -496,6 +496,12 @@ int32_t h2r_lookup_hist_records(const h2r_ctx *ctx, const h2r_lookup_config *cfg
 int32_t h2r_lookup_hist_values(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const void *values, uint32_t value_bytes,
                                uint64_t values_per_elem, uint64_t num_elems, uint32_t bit_len, uint32_t sublimb_bits,
                                uint32_t *hist, h2r_stream_t stream);
+/* the range assigns INSIDE a Fresh-op witness (h2r_fresh_op_batch's trace; op = H2R_OP_IS_IN_FIELD for the in_field_trace of
+ * h2r_modpow_public_key_batch, or for the in-field region of a verify element with first_off = h2r_verify_layout.off_in_field):
+ * add's c / carry per limb (big_integer/chip.rs:279-282) and sub_unchecked's difference limbs (:1307-1308), each a
+ * RangeChip::assign(limb, limb_width / 8, limb_width) */
+int32_t h2r_lookup_hist_fresh_op(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint32_t op, const void *trace, uint64_t first_off,
+                                 uint64_t elem_stride, uint64_t num_elems, uint32_t *hist, h2r_stream_t stream);
 uint64_t h2r_lookup_workspace_bytes(const h2r_lookup_config *cfg, uint64_t num_elems);
 int32_t h2r_lookup_permuted_columns(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const uint32_t *hist, const uint64_t *theta,
                                     uint64_t num_elems, uint32_t usable_rows, uint32_t arg_mask, void *a_perm_out,

@@ -178,3 +178,80 @@ def test_lookup_full_size_invariants(H):
                 got_a = [int.from_bytes(bytes(r), "little") for r in a_perm[b, k_arg].cpu().numpy()]
                 assert got_a == want_a
         del a_perm, s_perm, A, S
+
+
+def _in_field_range_assigns(stream, L, w):
+    """(value, [8 sub-limbs]) of every RangeChip::assign inside the oracle's is_in_field stream (big_integer/chip.rs:908-919 ->
+    sub :310-373 -> add :245-297 (c and carry per limb, :279-282) and sub_unchecked :1286-1318 (difference limbs, :1307-1308))."""
+    LB = w // 8
+    SB = RA = LB + 8
+    st = bytes(stream)
+    pos = 0
+    out = []
+
+    def ra():
+        nonlocal pos
+        v = int.from_bytes(st[pos:pos + LB], "little")
+        subs = list(st[pos + LB:pos + LB + 8])
+        assert v == sum(s << ((w // 8) * t) for t, s in enumerate(subs))
+        out.append((v, subs))
+        pos += RA
+
+    def add(n):
+        nonlocal pos
+        for _ in range(n):
+            pos += 2 * SB
+            ra(); ra()
+            pos += SB
+
+    def eq(n):
+        nonlocal pos
+        pos += 2 * n
+
+    def subu(n1):
+        for _ in range(n1):
+            ra()
+        add(n1); eq(n1 + 1)
+
+    def sub(nA, nB):
+        nonlocal pos
+        m = max(nA, nB)
+        n1 = m + 1
+        add(m); subu(n1)
+        pos += 2 + n1 * LB + m * LB
+        subu(n1)
+    sub(L, L); eq(L)
+    pos += 2
+    assert pos == len(st)
+    return out
+
+
+@pytest.mark.parametrize("w,L", [(64, 32), (32, 16)])
+def test_lookup_hist_of_the_in_field_witness(H, w, L):
+    """h2r_lookup_hist_fresh_op on the assert_in_field witness of modpow_public_key: the multiplicities of its 8 L + 6 range
+    assigns per argument against a count over the ORACLE's in-field stream."""
+    chip = H.BigIntChip(w, w * L)
+    o = Oracle(w, L)
+    rng = random.Random(w * L)
+    bits = w * L
+    N = [rng.getrandbits(bits) | (1 << (bits - 1)) | 1 for _ in range(4)]
+    X = [rng.randrange(n) for n in N]
+    X[3] = N[3] + 1 if N[3] + 1 < (1 << bits) else N[3]          # not in the field: the witness is still written
+    res = chip.pow_mod_fixed_exp(chip.assign_integer(X), 3, chip.assign_integer(N), check_in_field=True, want_trace=True)
+    la = H.LookupArgument(chip, rsa_chip=False)
+    cfg = AR.LookupConfig(AR.range_lens(w, L))
+    hist = la.new_hist(4)
+    es = chip.in_field_layout()[0]
+    la.hist_fresh_op("is_in_field", res.in_field.buf, es, 4, hist)
+    torch.cuda.synchronize()
+    got = hist.cpu().numpy()
+    off = cfg.row_off[w // 8]
+    for b in range(4):
+        rc, lt, st = o.assert_in_field(o.limbs(X[b]), o.limbs(N[b]))
+        ras = _in_field_range_assigns(st, L, w)
+        assert len(ras) == 8 * L + 6            # add(L): 2L, two sub_unchecked of L + 1 limbs: 2 (L + 1) + 2 * 2 (L + 1)
+        want = np.zeros((5, cfg.n_rows), dtype=np.int64)
+        for (_, subs) in ras:
+            for t, sv in enumerate(subs):
+                want[t if t < 4 else 7 - t, off + sv] += 1
+        assert np.array_equal(got[b], want), b
