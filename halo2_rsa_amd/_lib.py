@@ -83,6 +83,8 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_verify_trace_flatten", "h2r_fresh_op_layout", "h2r_fresh_op_batch", "h2r_fresh_op_flatten",
            "h2r_mul_stream_bytes", "h2r_is_equal_muled_stream_bytes", "h2r_refresh_stream_bytes", "h2r_mul_batch",
            "h2r_mul_trace_flatten", "h2r_is_equal_muled_batch", "h2r_is_equal_muled_flatten", "h2r_refresh_batch",
+           "h2r_mul_stream_bytes_ex", "h2r_mul_batch_ex", "h2r_mul_trace_flatten_ex", "h2r_refresh_layout", "h2r_refresh_batch_ex",
+           "h2r_is_equal_muled_stream_bytes_ex", "h2r_is_equal_muled_batch_ex",
            "h2r_range_decompose_batch", "h2r_hist_len", "h2r_trace_lookup_hist", "h2r_lookups_per_record",
            "h2r_trace_lookup_permutation", "h2r_trace_lookup_permutation_hist",
            "h2r_trace_flatten", "h2r_pow_trace_flatten", "h2r_stream_bytes", "h2r_pow_stream_bytes", "h2r_trace_flatten_ex",
@@ -171,6 +173,15 @@ def lib():
     L.h2r_is_equal_muled_batch.argtypes = [vp, vp, vp, u64, vp, vp, vp]
     L.h2r_is_equal_muled_flatten.argtypes = [vp, vp, vp]
     L.h2r_refresh_batch.argtypes = [vp, vp, u64, vp, vp, vp, vp]
+    L.h2r_mul_stream_bytes_ex.argtypes = [vp, u32, u32]
+    L.h2r_mul_stream_bytes_ex.restype = u64
+    L.h2r_mul_batch_ex.argtypes = [vp, vp, u32, vp, u32, u64, vp, vp, vp]
+    L.h2r_mul_trace_flatten_ex.argtypes = [vp, vp, u32, u32, vp]
+    L.h2r_refresh_layout.argtypes = [vp, u32, u32, ctypes.POINTER(u32), ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    L.h2r_refresh_batch_ex.argtypes = [vp, vp, u64, u32, u32, u64, vp, vp, vp, vp]
+    L.h2r_is_equal_muled_stream_bytes_ex.argtypes = [vp, u32, u32, u32]
+    L.h2r_is_equal_muled_stream_bytes_ex.restype = u64
+    L.h2r_is_equal_muled_batch_ex.argtypes = [vp, vp, vp, u64, u32, u32, u64, u32, vp, u64, vp, vp]
     L.h2r_range_decompose_batch.argtypes = [vp, vp, u32, u64, u32, u32, vp, u32, vp, vp]
     L.h2r_hist_len.argtypes = [vp]
     L.h2r_hist_len.restype = u32

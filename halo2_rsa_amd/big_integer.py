@@ -568,6 +568,52 @@ class BigIntChip:
         check(lib().h2r_is_equal_muled_flatten(self._ctx, host.ctypes.data, out.ctypes.data), "h2r_is_equal_muled_flatten")
         return out
 
+    # ---- any operand shape (d0 != d1, RefreshAux::new(w, n_l, n_r), n_l != n_r): h2r_*_ex ----------------------------------
+    def mul_ex(self, a: AssignedInteger, b: AssignedInteger) -> "MuledResult":
+        """BigIntChip::mul for operands of d0 = a.num_limbs() and d1 = b.num_limbs() limbs (both <= num_limbs)."""
+        batch, dev = a.batch, a.limbs_dev.device
+        lo = self.layout
+        trace = torch.zeros(batch * lo.record_stride, dtype=torch.uint8, device=dev)
+        cols = torch.zeros((batch, 2 * self.num_limbs, 4), dtype=torch.int64, device=dev)
+        check(lib().h2r_mul_batch_ex(self._ctx, a.data_ptr(), a.num_limbs(), b.data_ptr(), b.num_limbs(), batch, trace.data_ptr(),
+                                     cols.data_ptr(), self._stream()), "h2r_mul_batch_ex")
+        r = MuledResult(cols, trace, self)
+        r.shape = (a.num_limbs(), b.num_limbs())
+        return r
+
+    def mul_ex_flatten(self, m: "MuledResult", elem: int) -> np.ndarray:
+        d0, d1 = m.shape
+        rs = self.layout.record_stride
+        host = np.ascontiguousarray(m.trace[elem * rs:(elem + 1) * rs].cpu().numpy())
+        out = np.zeros(int(lib().h2r_mul_stream_bytes_ex(self._ctx, d0, d1)), dtype=np.uint8)
+        check(lib().h2r_mul_trace_flatten_ex(self._ctx, host.ctypes.data, d0, d1, out.ctypes.data), "h2r_mul_trace_flatten_ex")
+        return out
+
+    def refresh_ex(self, cols: torch.Tensor, n_l: int, n_r: int):
+        """BigIntChip::refresh with RefreshAux::new(limb_width, n_l, n_r): (Fresh limbs [batch, nf], streams [batch, stride], status)."""
+        nf, sb, es = ctypes.c_uint32(), ctypes.c_uint64(), ctypes.c_uint64()
+        check(lib().h2r_refresh_layout(self._ctx, n_l, n_r, ctypes.byref(nf), ctypes.byref(sb), ctypes.byref(es)), "h2r_refresh_layout")
+        batch, dev = cols.shape[0], cols.device
+        trace = torch.zeros((batch, es.value), dtype=torch.uint8, device=dev)
+        fresh = torch.zeros((batch, nf.value), dtype=self.torch_dtype, device=dev)
+        status = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        check(lib().h2r_refresh_batch_ex(self._ctx, cols.data_ptr(), cols.shape[1], n_l, n_r, batch, trace.data_ptr(), fresh.data_ptr(),
+                                         status.data_ptr(), self._stream()), "h2r_refresh_batch_ex")
+        return AssignedInteger(fresh, self.limb_width), trace[:, :sb.value], status
+
+    def is_equal_muled_ex(self, a_cols: torch.Tensor, b_cols: torch.Tensor, n_l: int, n_r: int, flags: int = 0):
+        """BigIntChip::is_equal_muled for n_l + n_r - 1 columns: (flat streams [batch, stream_bytes], eq bits)."""
+        sb = int(lib().h2r_is_equal_muled_stream_bytes_ex(self._ctx, n_l, n_r, flags))
+        if sb == 0:
+            check(_lib.H2R_E_SHAPE, "is_equal_muled_ex")
+        stride = (sb + 15) // 16 * 16
+        batch, dev = a_cols.shape[0], a_cols.device
+        out = torch.zeros((batch, stride), dtype=torch.uint8, device=dev)
+        eq = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        check(lib().h2r_is_equal_muled_batch_ex(self._ctx, a_cols.data_ptr(), b_cols.data_ptr(), a_cols.shape[1], n_l, n_r, batch, flags,
+                                                out.data_ptr(), stride, eq.data_ptr(), self._stream()), "h2r_is_equal_muled_batch_ex")
+        return out[:, :sb], eq
+
     def refresh(self, a: "MuledResult"):
         """big_integer/chip.rs:168-233 with RefreshAux::new(limb_width, L, L) -> (Fresh 2L limbs, stream tensor, status)."""
         batch, dev = a.cols.shape[0], a.cols.device

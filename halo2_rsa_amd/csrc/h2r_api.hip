@@ -18,6 +18,7 @@
 #include "h2r_kernels.hpp"
 #include "h2r_layout.hpp"
 #include "h2r_lookup.hpp"
+#include "h2r_muled.hpp"
 
 using namespace h2r;
 
@@ -520,7 +521,7 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
     c->num_cus = 256; c->lds_per_cu = 160 * 1024;
     c->refresh_inc_dev = nullptr;
     std::memset(c->refresh_inc, 0, sizeof c->refresh_inc);
-    c->refresh_nf = (L <= 128) ? refresh_aux_increased_limbs(w, L, c->refresh_inc) : 0;
+    c->refresh_nf = (L <= 128) ? refresh_aux_increased_limbs(w, L, L, c->refresh_inc) : 0;
     layout_compute(w, L, &c->layout);
     field_modulus(params->field, c->field_p);
     field_consts_init(c->field_p, &c->fc);
@@ -2423,24 +2424,158 @@ int32_t h2r_is_equal_muled_flatten(const h2r_ctx *ctx, const void *record_host, 
     return H2R_OK;
 }
 
-int32_t h2r_refresh_batch(const h2r_ctx *ctx, const uint64_t *muled, uint64_t batch, void *trace, void *fresh_out,
-                          uint8_t *status, h2r_stream_t stream) {
+namespace {
+// RefreshAux::new(w, n_l, n_r) and the stream geometry of BigIntChip::refresh with it
+struct RefreshPlan { u32 nf = 0; u8 inc[MULED_MAX] = {}; u32 off[MULED_MAX] = {}; u32 range_off = 0, stream_bytes = 0; };
+int32_t refresh_plan(const h2r_ctx *ctx, u32 n_l, u32 n_r, RefreshPlan &rp) {
+    const h2r_layout &lo = ctx->layout;
+    if (n_l == 0 || n_r == 0 || n_l > ctx->L || n_r > ctx->L) return H2R_E_SHAPE;   // the stream widths are the ctx's: values of longer operands need not fit
+    u8 inc[2 * 128 + 8] = {};
+    rp.nf = refresh_aux_increased_limbs(lo.limb_width, n_l, n_r, inc);
+    if (rp.nf > (u32)MULED_MAX) return H2R_E_UNSUPPORTED;
+    u64 off = 0;
+    for (u32 i = 0; i < rp.nf; ++i) {
+        if (inc[i] > 2) return H2R_E_UNSUPPORTED;
+        rp.inc[i] = inc[i]; rp.off[i] = (u32)off;
+        off += (u64)(inc[i] + 1) * (lo.carry_bytes + 2ull * lo.limb_bytes + lo.wide_bytes) + (u64)inc[i] * lo.wide_bytes;
+    }
+    rp.range_off = (u32)off;
+    rp.stream_bytes = (u32)(off + (u64)rp.nf * (lo.limb_bytes + lo.limb_nsub));
+    return H2R_OK;
+}
+}  // namespace
+
+int32_t h2r_refresh_layout(const h2r_ctx *ctx, uint32_t num_limbs_l, uint32_t num_limbs_r, uint32_t *num_limbs_fresh,
+                           uint64_t *stream_bytes, uint64_t *elem_stride) {
+    if (!ctx) return H2R_E_NULL;
+    RefreshPlan rp;
+    const int32_t rc = refresh_plan(ctx, num_limbs_l, num_limbs_r, rp);
+    if (rc) return rc;
+    if (num_limbs_fresh) *num_limbs_fresh = rp.nf;
+    if (stream_bytes) *stream_bytes = rp.stream_bytes;
+    if (elem_stride) *elem_stride = round_up(rp.stream_bytes, 256);
+    return H2R_OK;
+}
+
+int32_t h2r_refresh_batch_ex(const h2r_ctx *ctx, const uint64_t *muled, uint64_t muled_stride_cols, uint32_t num_limbs_l,
+                             uint32_t num_limbs_r, uint64_t batch, void *trace, void *fresh_out, uint8_t *status, h2r_stream_t stream) {
     if (!ctx || !muled || !trace || !status) return H2R_E_NULL;
-    if (ctx->params.device < 0 || ctx->refresh_nf == 0) return H2R_E_UNSUPPORTED;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    RefreshPlan rp;
+    const int32_t rc = refresh_plan(ctx, num_limbs_l, num_limbs_r, rp);
+    if (rc) return rc;
+    if (muled_stride_cols < num_limbs_l + num_limbs_r - 1) return H2R_E_SHAPE;
     if (batch == 0) return H2R_OK;
+    const h2r_layout &lo = ctx->layout;
     RefreshArgs ra;
     std::memset(&ra, 0, sizeof ra);
-    ra.muled = muled; ra.batch = batch; ra.L = ctx->L; ra.nf = ctx->refresh_nf; ra.inc = ctx->refresh_inc_dev;
-    ra.trace = static_cast<u8 *>(trace); ra.elem_stride = round_up(h2r_refresh_stream_bytes(ctx), 256);
-    ra.fresh_out = fresh_out; ra.status = status; ra.WB = ctx->layout.wide_bytes; ra.CB = ctx->layout.carry_bytes;
-    ra.stream_bytes = (u32)h2r_refresh_stream_bytes(ctx);
-    const unsigned stage = (unsigned)round_up(ra.stream_bytes, 16) + 32;
+    ra.muled = muled; ra.muled_stride = muled_stride_cols; ra.batch = batch; ra.d = num_limbs_l + num_limbs_r - 1; ra.nf = rp.nf; ra.w = lo.limb_width;
+    std::memcpy(ra.inc, rp.inc, sizeof ra.inc); std::memcpy(ra.off, rp.off, sizeof ra.off);
+    ra.range_off = rp.range_off; ra.trace = static_cast<u8 *>(trace); ra.elem_stride = round_up(rp.stream_bytes, 256);
+    ra.fresh_out = fresh_out; ra.status = status; ra.LB = lo.limb_bytes; ra.WB = lo.wide_bytes; ra.CB = lo.carry_bytes; ra.stream_bytes = rp.stream_bytes;
+    const unsigned stage = (unsigned)round_up(rp.stream_bytes, 16) + 32;
     if (stage > 60 * 1024) return H2R_E_UNSUPPORTED;
     H2R_ON_DEVICE(ctx->params.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (stage > 40 * 1024) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&refresh_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage); (void)hipGetLastError(); }
     ProfScope ps(H2R_KERNEL_AUX, st);
-    if (ctx->layout.limb_width == 64) hipLaunchKernelGGL((refresh_kernel<64>), dim3((unsigned)batch), dim3(64), stage, st, ra);
-    else hipLaunchKernelGGL((refresh_kernel<32>), dim3((unsigned)batch), dim3(64), stage, st, ra);
+    hipLaunchKernelGGL(refresh_kernel, dim3((unsigned)batch), dim3(256), stage, st, ra);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
+
+int32_t h2r_refresh_batch(const h2r_ctx *ctx, const uint64_t *muled, uint64_t batch, void *trace, void *fresh_out,
+                          uint8_t *status, h2r_stream_t stream) {
+    if (!ctx) return H2R_E_NULL;
+    return h2r_refresh_batch_ex(ctx, muled, 2ull * ctx->L, ctx->L, ctx->L, batch, trace, fresh_out, status, stream);
+}
+
+// ---- general operand shapes: mul(d0, d1), is_equal_muled(n_l, n_r) --------------------------------------------------------
+uint64_t h2r_mul_stream_bytes_ex(const h2r_ctx *ctx, uint32_t d0, uint32_t d1) { return ctx ? (u64)d0 * d1 * ctx->layout.wide_bytes : 0; }
+
+int32_t h2r_mul_batch_ex(const h2r_ctx *ctx, const void *a, uint32_t d0, const void *b, uint32_t d1, uint64_t batch, void *trace,
+                         uint64_t *muled_out, h2r_stream_t stream) {
+    if (!ctx || !a || !b || !trace || !muled_out) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    if (d0 == 0 || d1 == 0 || d0 > ctx->L || d1 > ctx->L) return H2R_E_SHAPE;
+    if (d0 == ctx->L && d1 == ctx->L) return h2r_mul_batch(ctx, a, b, batch, trace, muled_out, stream);
+    if (batch == 0) return H2R_OK;
+    // zero-padded to num_limbs limbs the products are the same (padding adds zero terms only); the reference's partial
+    // accumulators are the entries (j, i) with j < d0, i - j < d1 of the padded record (h2r_mul_trace_flatten_ex walks those)
+    H2R_ON_DEVICE(ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const u64 lb = ctx->layout.limb_bytes, one = batch * ctx->L * lb;
+    u8 *pad = nullptr;
+    HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&pad), 2 * one, st));
+    for (int k = 0; k < 2; ++k) {
+        PadArgs pa{static_cast<const u8 *>(k ? b : a), pad + k * one, batch, k ? d1 : d0, ctx->L, (u32)lb};
+        hipLaunchKernelGGL(pad_limbs_kernel, dim3((unsigned)std::min<u64>(2048, (batch * ctx->L + 255) / 256)), dim3(256), 0, st, pa);
+    }
+    const int32_t rc = hipGetLastError() == hipSuccess ? h2r_mul_batch(ctx, pad, pad + one, batch, trace, muled_out, stream) : H2R_E_HIP;
+    (void)hipFreeAsync(pad, st);
+    return rc;
+}
+
+int32_t h2r_mul_trace_flatten_ex(const h2r_ctx *ctx, const void *record_host, uint32_t d0, uint32_t d1, void *stream_out) {
+    if (!ctx || !record_host || !stream_out) return H2R_E_NULL;
+    if (d0 == 0 || d1 == 0 || d0 > ctx->L || d1 > ctx->L) return H2R_E_SHAPE;
+    const h2r_layout &lo = ctx->layout;
+    Out o{static_cast<u8 *>(stream_out)};
+    const u8 *rec = static_cast<const u8 *>(record_host);
+    for (u32 i = 0; i < d0 + d1 - 1; ++i) {   // chip.rs:400-412 with (d0, d1)
+        u32 j = (d1 >= i + 1) ? 0 : i + 1 - d1;
+        for (; j < d0 && j <= i; ++j) emit_acc(o, lo, rec, H2R_PL_AB_LO, j, i % lo.num_limbs);
+    }
+    return H2R_OK;
+}
+
+namespace {
+struct EqPlan { U256 wm; u32 carry_bits, sub_bits, nsub, per_col; u64 stream_bytes; };
+int32_t eq_plan(const h2r_ctx *ctx, u32 n_l, u32 n_r, u32 flags, EqPlan &ep) {
+    const h2r_layout &lo = ctx->layout;
+    if (n_l == 0 || n_r == 0 || n_l > ctx->L || n_r > ctx->L || n_l + n_r - 1 > 255) return H2R_E_SHAPE;
+    if (flags & ~H2R_STREAM_FIELD_AB) return H2R_E_UNSUPPORTED;
+    ep.wm = compute_mul_word_max(lo.limb_width, std::min(n_l, n_r));                 // chip.rs:838
+    ep.carry_bits = (ep.wm + ep.wm).bits() - lo.limb_width;                           // :841-842
+    ep.sub_bits = sublimb_bit_len(ep.carry_bits); ep.nsub = n_sublimbs(ep.carry_bits);
+    const u32 AB = (flags & H2R_STREAM_FIELD_AB) ? 32 : lo.wide_bytes;
+    ep.per_col = AB + 4 * lo.wide_bytes + 2 * lo.carry_bytes + 4 * lo.limb_bytes + 4 + lo.carry_bytes + ep.nsub;
+    ep.stream_bytes = (u64)(n_l + n_r - 1) * ep.per_col - (lo.carry_bytes + ep.nsub);
+    return H2R_OK;
+}
+}  // namespace
+
+uint64_t h2r_is_equal_muled_stream_bytes_ex(const h2r_ctx *ctx, uint32_t num_limbs_l, uint32_t num_limbs_r, uint32_t flags) {
+    EqPlan ep;
+    return (ctx && eq_plan(ctx, num_limbs_l, num_limbs_r, flags, ep) == H2R_OK) ? ep.stream_bytes : 0;
+}
+
+int32_t h2r_is_equal_muled_batch_ex(const h2r_ctx *ctx, const uint64_t *muled_a, const uint64_t *muled_b, uint64_t muled_stride_cols,
+                                    uint32_t num_limbs_l, uint32_t num_limbs_r, uint64_t batch, uint32_t flags, void *stream_out,
+                                    uint64_t out_stride, uint8_t *eq_out, h2r_stream_t stream) {
+    if (!ctx || !muled_a || !muled_b || !stream_out) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    EqPlan ep;
+    const int32_t rc = eq_plan(ctx, num_limbs_l, num_limbs_r, flags, ep);
+    if (rc) return rc;
+    if (muled_stride_cols < num_limbs_l + num_limbs_r - 1 || out_stride < ep.stream_bytes || (out_stride & 15)) return H2R_E_SHAPE;
+    if (batch == 0) return H2R_OK;
+    const h2r_layout &lo = ctx->layout;
+    EqMuledArgs ea;
+    std::memset(&ea, 0, sizeof ea);
+    ea.ma = muled_a; ea.mb = muled_b; ea.muled_stride = muled_stride_cols; ea.batch = batch; ea.C = num_limbs_l + num_limbs_r - 1; ea.w = lo.limb_width;
+    ea.wm[0] = ep.wm.v[0]; ea.wm[1] = ep.wm.v[1]; ea.wm[2] = ep.wm.v[2];
+    ea.carry_bits = ep.carry_bits; ea.carry_sub_bits = ep.sub_bits; ea.carry_nsub = ep.nsub;
+    ea.LB = lo.limb_bytes; ea.WB = lo.wide_bytes; ea.CB = lo.carry_bytes; ea.AB = (flags & H2R_STREAM_FIELD_AB) ? 32 : lo.wide_bytes;
+    for (int k = 0; k < 4; ++k) ea.p[k] = ctx->field_p[k];
+    ea.per_col = ep.per_col; ea.stream_bytes = (u32)ep.stream_bytes; ea.trace = static_cast<u8 *>(stream_out); ea.elem_stride = out_stride; ea.eq_out = eq_out;
+    const unsigned stage = (unsigned)round_up((u64)ea.C * ep.per_col, 16) + 32;
+    if (stage > 60 * 1024) return H2R_E_UNSUPPORTED;
+    H2R_ON_DEVICE(ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (stage > 36 * 1024) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&is_equal_muled_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)stage); (void)hipGetLastError(); }
+    ProfScope ps(H2R_KERNEL_AUX, st);
+    hipLaunchKernelGGL(is_equal_muled_kernel, dim3((unsigned)batch), dim3(256), stage, st, ea);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
 }

@@ -1732,86 +1732,7 @@ __global__ __launch_bounds__(64) void fresh_kernel(FreshArgs f) {
     if (lane == 0) { if (f.flag_out) f.flag_out[elem] = (u8)flag; f.status[elem] = (u8)status; }
 }
 
-// BigIntChip::refresh (chip.rs:168-233) with aux = RefreshAux::new(w, L, L): Muled (2L-1 columns) -> Fresh (2L limbs).
-// Off the RSA path: one wave per element, lane 0 walks the second-order carry recurrence and
-// writes the flat stream directly (every field is 4/8-byte aligned, so no section padding is needed).
-struct RefreshArgs {
-    const u64 *muled;     // [elem][2L] x 4 u64
-    u64 batch; u32 L, nf;
-    const u8 *inc;        // increased_limbs_vec (device), nf entries
-    u8 *trace; u64 elem_stride;
-    void *fresh_out;      // [elem][2L] limbs (nullable)
-    u8 *status;
-    u32 WB, CB;
-    u32 stream_bytes;     // flat-stream bytes of one element (<= elem_stride)
-};
-
-template <int LW>
-__global__ __launch_bounds__(64) void refresh_kernel(RefreshArgs a) {
-    using limb_t = typename LimbT<LW>::type;
-    constexpr u32 LB = LW / 8;
-    __shared__ u64 r0[2 * 128 + 8], r1[2 * 128 + 8]; __shared__ u32 r2[2 * 128 + 8];   // running limbs (3 words)
-    extern __shared__ uint4 refresh_stage[];   // the element's flat stream, assembled here (stream_bytes rounded up to 16)
-    const int lane = threadIdx.x;
-    const u64 elem = blockIdx.x;
-    const u32 C = 2 * a.L - 1, nf = a.nf;
-    for (u32 p = lane; p < nf + 4; p += 64) {
-        const u64 *m = a.muled + (elem * (2 * a.L) + p) * 4;
-        const bool in = p < C;
-        r0[p] = in ? m[0] : 0; r1[p] = in ? m[1] : 0; r2[p] = in ? (u32)m[2] : 0;
-    }
-    wave_sync();
-    // The second-order carry recurrence is sequential (every chunk cut off limb i lands in limbs i+1 / i+2 before those
-    // are cut): lane 0 walks it and writes the stream into LDS -- a few cycles per value instead of a dependent global store
-    // each (about 1,500 of them per RSA-2048 element) -- and the whole wave then copies the stream out as 16-byte lines.
-    if (lane == 0) {
-        int status = H2R_OK;
-        u8 *o = reinterpret_cast<u8 *>(refresh_stage);
-        auto put = [&](u64 w0, u64 w1, u64 w2, u32 nbytes) {   // little-endian value of nbytes (4, 8, 16 or 24); 4-byte granular
-            u32 *d = reinterpret_cast<u32 *>(o);
-            d[0] = (u32)w0;
-            if (nbytes >= 8) d[1] = (u32)(w0 >> 32);
-            if (nbytes >= 16) { d[2] = (u32)w1; d[3] = (u32)(w1 >> 32); }
-            if (nbytes >= 24) { d[4] = (u32)w2; d[5] = (u32)(w2 >> 32); }
-            o += nbytes;
-        };
-        for (u32 i = 0; i < nf; ++i) {
-            u64 l0 = r0[i], l1 = r1[i]; u32 l2 = r2[i];                  // limb = refreshed_limbs[i]  (:197)
-            const u32 reps = (u32)a.inc[i] + 1;
-            for (u32 j = 0; j < reps; ++j) {                             // :198
-                // (q, n) = divmod(limb, 2^w)  (:201 -> :1323-1349)
-                u64 q0, q1, n; u32 q2 = 0;
-                if constexpr (LW == 64) { n = l0; q0 = l1; q1 = l2; }
-                else { n = l0 & 0xffffffffull; q0 = (l0 >> 32) | (l1 << 32); q1 = (l1 >> 32) | ((u64)l2 << 32); }
-                put(q0, q1, 0, a.CB); put(n, 0, 0, LB);
-                // nq = 2^w * q, a - nq = n
-                if constexpr (LW == 64) put(0, q0, q1, a.WB); else put(l0 & ~0xffffffffull, l1, 0, a.WB);
-                put(n, 0, 0, LB);
-                if (j == 0) { r0[i] = n; r1[i] = 0; r2[i] = 0; }          // :204
-                else {                                                   // refreshed_limbs[i+j] += n  (:207)
-                    const u64 t0 = r0[i + j] + n; const u64 c0 = t0 < n ? 1 : 0;
-                    const u64 t1 = r1[i + j] + c0; const u32 c1 = t1 < c0 ? 1u : 0u;
-                    r0[i + j] = t0; r1[i + j] = t1; r2[i + j] += c1;
-                    put(t0, t1, r2[i + j], a.WB);
-                }
-                l0 = q0; l1 = q1; l2 = q2;                               // limb = q
-            }
-            if (l0 | l1 | l2) status = H2R_E_NOT_REDUCED;                // assert_zero(limb), :213
-        }
-        for (u32 i = 0; i < nf; ++i) {                                   // range-assign every refreshed limb, :217-226
-            const u64 v = r0[i];
-            put(v, 0, 0, LB);
-            const u64 sb = limb_sub_bytes<LW>(v);
-            put(sb, 0, 0, 8);
-        }
-        a.status[elem] = (u8)status;
-    }
-    wave_sync();
-    u8 *dst = a.trace + elem * a.elem_stride;
-    for (u32 k = lane; k < (a.stream_bytes + 15) / 16; k += 64) { const uint4 v = refresh_stage[k]; pst16(dst + 16ull * k, ((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z); }
-    if (a.fresh_out)
-        for (u32 i = lane; i < nf; i += 64) reinterpret_cast<limb_t *>(a.fresh_out)[elem * nf + i] = (limb_t)r0[i];
-}
+// (BigIntChip::refresh and the general-shape is_equal_muled live in h2r_muled.hpp)
 
 // ================================================================================================
 // K4: lookup multiplicities of the range-check sub-limbs of a set of records

@@ -183,18 +183,18 @@ inline void layout_compute(u32 w, u32 L, h2r_layout *o) {
                       (u64)(C - 1) * (CB + o->carry_nsub);
 }
 
-// RefreshAux::new(limb_width, L, L).increased_limbs_vec (big_integer/mod.rs:428-482): how many extra limbs the
-// i-th Muled limb spills into when it is cut into limb_width-bit chunks.  Returns the vector length (2L).
-inline u32 refresh_aux_increased_limbs(u32 w, u32 L, u8 *inc /* >= 2L + 2 entries */) {
-    const u32 d = 2 * L - 1;
+// RefreshAux::new(limb_width, n_l, n_r).increased_limbs_vec (big_integer/mod.rs:428-482): how many extra limbs the
+// i-th Muled limb spills into when it is cut into limb_width-bit chunks.  Returns the vector length.
+inline u32 refresh_aux_increased_limbs(u32 w, u32 n_l, u32 n_r, u8 *inc /* >= n_l + n_r + 2 entries */) {
+    const u32 d = n_l + n_r - 1;
     U256 muled[2 * 128 + 8];
     u32 len = d;
     const u64 bm1 = w == 64 ? ~0ull : ((1ull << w) - 1);
     const u128 sq = (u128)bm1 * bm1;
     U256 sqv; sqv.v[0] = (u64)sq; sqv.v[1] = (u64)(sq >> 64);
-    for (u32 i = 0; i < d; ++i) {
-        const u32 cnt = (i < L) ? i + 1 : 2 * L - 1 - i;
-        for (u32 k = 0; k < cnt; ++k) muled[i] = muled[i] + sqv;
+    for (u32 i = 0; i < d; ++i) {   // products a[j] * b[i-j] in column i: j from max(0, i+1-n_r) to min(i, n_l-1)  (mod.rs:438-447)
+        const u32 j0 = n_r >= i + 1 ? 0 : i + 1 - n_r, j1 = i < n_l - 1 ? i : n_l - 1;
+        for (u32 k = j0; k <= j1; ++k) muled[i] = muled[i] + sqv;
     }
     u32 n = 0;
     for (u32 cur = 0; cur <= d; ++cur) {

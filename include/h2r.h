@@ -414,6 +414,32 @@ int32_t h2r_is_equal_muled_flatten(const h2r_ctx *ctx, const void *record_host, 
 int32_t h2r_refresh_batch(const h2r_ctx *ctx, const uint64_t *muled, uint64_t batch, void *trace,
                           void *fresh_out, uint8_t *status, h2r_stream_t stream);
 
+/* General operand shapes (the reference's mul takes d0 != d1 limbs, big_integer/chip.rs:395-397; refresh any
+ * RefreshAux::new(limb_width, n_l, n_r), mod.rs:428 + chip.rs:178-181; is_equal_muled n_l != n_r, chip.rs:822-835), for
+ * operands of at most the ctx's num_limbs limbs (the stream's WIDE / CARRY widths are the ctx's).  Muled integers are passed
+ * as muled_stride_cols columns of 4 x uint64_t per element, of which the first n_l + n_r - 1 are read.
+ *  h2r_mul_batch_ex            a: [batch][d0] limbs, b: [batch][d1] limbs; trace = one (num_limbs-shaped) record per element,
+ *                              muled_out [batch][2 * num_limbs][4] with d0 + d1 - 1 columns of the product;
+ *                              h2r_mul_trace_flatten_ex walks the record in the reference's (d0, d1) order.
+ *  h2r_refresh_batch_ex        any (n_l, n_r): h2r_refresh_layout gives the number of Fresh limbs (RefreshAux), the stream size and
+ *                              the element stride of `trace` (which IS the flat stream); status H2R_E_NOT_REDUCED where a limb
+ *                              does not fit increased_limbs_vec (assert_zero, chip.rs:213).  h2r_refresh_batch == (L, L).
+ *  h2r_is_equal_muled_batch_ex word_max = compute_mul_word_max(limb_width, min(n_l, n_r)) (chip.rs:838), carry range check of
+ *                              bits(2 word_max) - limb_width bits; stream_out: element e's flat stream at + e * out_stride
+ *                              (a multiple of 16); flags: H2R_STREAM_FIELD_AB as for the emitters; eq_out nullable. */
+uint64_t h2r_mul_stream_bytes_ex(const h2r_ctx *ctx, uint32_t d0, uint32_t d1);
+int32_t h2r_mul_batch_ex(const h2r_ctx *ctx, const void *a, uint32_t d0, const void *b, uint32_t d1, uint64_t batch, void *trace,
+                         uint64_t *muled_out, h2r_stream_t stream);
+int32_t h2r_mul_trace_flatten_ex(const h2r_ctx *ctx, const void *record_host, uint32_t d0, uint32_t d1, void *stream_out);
+int32_t h2r_refresh_layout(const h2r_ctx *ctx, uint32_t num_limbs_l, uint32_t num_limbs_r, uint32_t *num_limbs_fresh,
+                           uint64_t *stream_bytes, uint64_t *elem_stride);
+int32_t h2r_refresh_batch_ex(const h2r_ctx *ctx, const uint64_t *muled, uint64_t muled_stride_cols, uint32_t num_limbs_l,
+                             uint32_t num_limbs_r, uint64_t batch, void *trace, void *fresh_out, uint8_t *status, h2r_stream_t stream);
+uint64_t h2r_is_equal_muled_stream_bytes_ex(const h2r_ctx *ctx, uint32_t num_limbs_l, uint32_t num_limbs_r, uint32_t flags);
+int32_t h2r_is_equal_muled_batch_ex(const h2r_ctx *ctx, const uint64_t *muled_a, const uint64_t *muled_b, uint64_t muled_stride_cols,
+                                    uint32_t num_limbs_l, uint32_t num_limbs_r, uint64_t batch, uint32_t flags, void *stream_out,
+                                    uint64_t out_stride, uint8_t *eq_out, h2r_stream_t stream);
+
 /* ---- the lookup range-check batch --------------------------------------------------------------
  * RangeChip::assign(value, sublimb_bits, bit_len) decomposition of `count` values of `value_bytes`
  * bytes each (8 or 16) into ceil(bit_len/sublimb_bits) one-byte sub-limbs (stride sub_stride),

@@ -245,12 +245,17 @@ def mul_columns(a: Sequence[int], b: Sequence[int], st: Stream | None, WB: int) 
     return cols
 
 
-def is_equal_muled(p: Params, a: Sequence[int], b: Sequence[int], st: Stream) -> int:
-    """BigIntChip::is_equal_muled, big_integer/chip.rs:822-895 (num_limbs_l = num_limbs_r = L)."""
-    w, B, W = p.w, p.B, p.word_max
+def is_equal_muled(p: Params, a: Sequence[int], b: Sequence[int], st: Stream, n_l: int | None = None, n_r: int | None = None) -> int:
+    """BigIntChip::is_equal_muled, big_integer/chip.rs:822-895.  Default num_limbs_l = num_limbs_r = L; any (n_l, n_r) with
+    operands of at most L limbs otherwise (the stream's WIDE / CARRY widths stay those of the chip's L)."""
+    w, B = p.w, p.B
+    n_l = p.L if n_l is None else n_l
+    n_r = p.L if n_r is None else n_r
+    W = compute_mul_word_max(w, min(n_l, n_r))          # :832-838
     num_limbs = len(a)
-    assert num_limbs == len(b) == 2 * p.L - 1
-    carry_bits = p.carry_bits
+    assert num_limbs == len(b) == n_l + n_r - 1          # :839
+    carry_bits = bits_size(W * 2) - w                    # :841-842
+    carry_sub_bits = sublimb_bit_len(carry_bits)
     acc_extra = 0
     carry = [0]
     eq_bit = 1
@@ -285,7 +290,7 @@ def is_equal_muled(p: Params, a: Sequence[int], b: Sequence[int], st: Stream) ->
         acc_extra = q_acc                       # :875
         if i < num_limbs - 1:
             # :879-887 -- range-assign the carry, compare, AND
-            emit_range_assign(st, new_carry, p.carry_sub_bits, carry_bits, p.CB)
+            emit_range_assign(st, new_carry, carry_sub_bits, carry_bits, p.CB)
             range_eq = 1
             st.put(range_eq, 1)
             eq_bit &= range_eq
@@ -501,12 +506,14 @@ def assert_in_field(p: Params, a: Sequence[int], n: Sequence[int], st: Stream) -
     return is_less_than(p, a, n, st)
 
 
-def refresh(p: Params, a: Sequence[int], st: Stream) -> List[int]:
-    """BigIntChip::refresh, big_integer/chip.rs:168-233, with aux = RefreshAux::new(w, L, L) (mod.rs:428-482).
-    `a` holds the 2L-1 Muled limbs; returns the 2L Fresh limbs."""
+def refresh(p: Params, a: Sequence[int], st: Stream, n_l: int | None = None, n_r: int | None = None) -> List[int]:
+    """BigIntChip::refresh, big_integer/chip.rs:168-233, with aux = RefreshAux::new(w, n_l, n_r) (mod.rs:428-482; default
+    n_l = n_r = L).  `a` holds the n_l + n_r - 1 Muled limbs; returns the Fresh limbs."""
     w, B, L = p.w, p.B, p.L
-    inc = refresh_aux_increased_limbs(w, L, L)
-    assert len(a) == 2 * L - 1                       # :181
+    n_l = L if n_l is None else n_l
+    n_r = L if n_r is None else n_r
+    inc = refresh_aux_increased_limbs(w, n_l, n_r)
+    assert len(a) == n_l + n_r - 1                   # :181
     num_limbs_fresh = len(inc)
     r = list(a) + [0] * (num_limbs_fresh - len(a))   # :186-192
     for i in range(num_limbs_fresh):                 # :195

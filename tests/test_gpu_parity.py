@@ -1774,3 +1774,88 @@ def test_dist_exports_one_rank(H):
     assert torch.equal(g, res.value.limbs_dev)
     assert H.AssignedInteger(g, 64).to_big_uint() == [pow(x, 65537, n) for x, n in zip(X, N)]
     d.finalize()
+
+
+def _u256_tensor(cols_list, ncols):
+    arr = np.zeros((len(cols_list), ncols, 4), dtype=np.uint64)
+    for e, cols in enumerate(cols_list):
+        for c, v in enumerate(cols):
+            for k in range(4):
+                arr[e, c, k] = (v >> (64 * k)) & (2 ** 64 - 1)
+    return torch.from_numpy(arr.view(np.int64)).cuda()
+
+
+@pytest.mark.parametrize("w,L,shapes", [(64, 32, [(32, 32), (7, 32), (32, 1), (5, 12), (1, 1), (16, 17)]),
+                                        (32, 128, [(128, 128), (3, 128), (100, 9)]), (64, 8, [(8, 8), (2, 5)])])
+def test_general_operand_shapes_mul_refresh_is_equal_muled(H, w, L, shapes):
+    """The reference's mul takes d0 != d1 (big_integer/chip.rs:395-397), refresh any RefreshAux::new(w, n_l, n_r) (mod.rs:428,
+    chip.rs:178-181), is_equal_muled n_l != n_r with word_max from min(n_l, n_r) (chip.rs:822-842): h2r_mul_batch_ex,
+    h2r_refresh_batch_ex (parallel fixed-point carries), h2r_is_equal_muled_batch_ex against oracle/pyref.py value for value --
+    columns, Fresh limbs (== the product as an integer), every streamed intermediate, equal and unequal pairs, a_b as a field
+    element, and a limb that does not fit RefreshAux (status)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref as R
+    from halo2_rsa_amd import _lib
+    chip = H.BigIntChip(w, w * L)
+    p = R.Params(w, L)
+    pf = R.Params(w, L, field_modulus=R.FIELD_MODULI["bn254_fr"])
+    rng = random.Random(w * L + len(shapes))
+    np_dt = np.uint64 if w == 64 else np.uint32
+    for (d0, d1) in shapes:
+        batch = 4
+        A = [[rng.getrandbits(w) for _ in range(d0)] for _ in range(batch)]
+        Bs = [[rng.getrandbits(w) for _ in range(d1)] for _ in range(batch)]
+        A[1] = [(1 << w) - 1] * d0                       # all-ones operands: the largest columns, long carry ripples in refresh
+        Bs[1] = [(1 << w) - 1] * d1
+        A[2] = [0] * d0
+        to_dev = lambda rows: H.AssignedInteger(torch.from_numpy(np.array(rows, dtype=np_dt).view(np.int64 if w == 64 else np.int32)).cuda(), w)
+        m = chip.mul_ex(to_dev(A), to_dev(Bs))
+        torch.cuda.synchronize()
+        ncols = d0 + d1 - 1
+        cols_host = m.cols.cpu().numpy().view(np.uint64)
+        ref_cols = []
+        for e in range(batch):
+            st = R.Stream()
+            cols = R.mul_columns(A[e], Bs[e], st, p.WB)
+            ref_cols.append(cols)
+            got = [sum(int(cols_host[e, c, k]) << (64 * k) for k in range(4)) for c in range(ncols)]
+            assert got == cols, (d0, d1, e)
+            assert bytes(chip.mul_ex_flatten(m, e)) == st.bytes(), (d0, d1, e)
+        # refresh with RefreshAux::new(w, d0, d1)
+        fresh, streams, status = chip.refresh_ex(m.cols, d0, d1)
+        torch.cuda.synchronize()
+        assert not status.cpu().numpy().any()
+        fl = fresh.to_big_uint()
+        sh = streams.cpu().numpy()
+        for e in range(batch):
+            st = R.Stream()
+            want = R.refresh(p, ref_cols[e], st, d0, d1)
+            assert fl[e] == R.from_limbs(want, w) == R.from_limbs(A[e], w) * R.from_limbs(Bs[e], w), (d0, d1, e)
+            assert bytes(sh[e]) == st.bytes(), (d0, d1, e)
+        # is_equal_muled(n_l = d0, n_r = d1): a * b against itself, and against a copy with one column changed
+        other = [list(c) for c in ref_cols]
+        other[0][ncols // 2] += 3
+        other[3][ncols - 1] = max(0, other[3][ncols - 1] - 1) if other[3][ncols - 1] else 1
+        a_dev, b_dev = _u256_tensor(ref_cols, 2 * L), _u256_tensor(other, 2 * L)
+        for flags, pp in ((0, p), (1, pf)):
+            for (x_dev, y_dev, ys) in ((a_dev, a_dev, ref_cols), (a_dev, b_dev, other), (b_dev, a_dev, None)):
+                out, eq = chip.is_equal_muled_ex(x_dev, y_dev, d0, d1, flags)
+                torch.cuda.synchronize()
+                oh, eqh = out.cpu().numpy(), eq.cpu().tolist()
+                for e in range(batch):
+                    xa = ref_cols[e] if x_dev is a_dev else other[e]
+                    yb = (ref_cols[e] if y_dev is a_dev else other[e])
+                    st = R.Stream()
+                    want_eq = R.is_equal_muled(pp, xa, yb, st, d0, d1)
+                    assert eqh[e] == want_eq, (d0, d1, e, flags)
+                    assert bytes(oh[e]) == st.bytes(), (d0, d1, e, flags)
+    # a Muled limb too large for RefreshAux::new(w, 2, 2): assert_zero(limb) fails (chip.rs:213) -> status, other elements fine
+    big = [[1 << (2 * w + 9), 5, 6], [7, 8, 9]]
+    fresh, streams, status = chip.refresh_ex(_u256_tensor(big, 3), 2, 2)
+    torch.cuda.synchronize()
+    assert status.cpu().tolist() == [_lib.H2R_E_NOT_REDUCED, 0]
+    assert fresh.to_big_uint()[1] == 7 + (8 << w) + (9 << (2 * w))
+    with pytest.raises(_lib.H2RError):
+        chip.refresh_ex(_u256_tensor(big, 3), L + 1, 1)          # operands longer than the chip's num_limbs
