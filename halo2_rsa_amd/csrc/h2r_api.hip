@@ -94,6 +94,7 @@ struct Knobs {
     long pipe_sub_batch = 0;                     // H2R_PIPE_SUB_BATCH: elements per chain + record kernel pair inside a pipelined call (multiple of 256)
     long pipe_pace = -1;                         // H2R_PIPE_PACE=0|1: sub-batch i+1's chain kernel waits for sub-batch i-1's record kernel
     long pipe_step = -1;                         // H2R_PIPE_STEP=0: never issue a pipeline step as one launch (the two-queue form for every shape)
+    long step_chain_x2_per_cu = 0;               // H2R_STEP_CHAIN_X2_PER_CU=n: n/2 chain workgroups per CU in a step launch (0 = the measured default)
     unsigned long pipe_cu_mask = 0;              // H2R_PIPE_CU_MASK=<hex word>: the record stream is created with this 32-bit CU mask repeated over the device (experiment)
     long pipe_cu_mask_words = 0;                 // H2R_PIPE_CU_MASK_WORDS=n: only the first n 32-bit words carry the mask, the rest are zero
     Knobs() {
@@ -107,7 +108,7 @@ struct Knobs {
         chain_timing = std::getenv("H2R_CHAIN_TIMING") != nullptr;
         { const char *g = std::getenv("H2R_PIPE_SERIALIZE"); pipe_serialize = g && g[0] == '1'; }
         { const char *m = std::getenv("H2R_PIPE_CU_MASK"); pipe_cu_mask = m ? std::strtoul(m, nullptr, 16) : 0; pipe_cu_mask_words = num("H2R_PIPE_CU_MASK_WORDS", 0); }
-        pipe_step = num("H2R_PIPE_STEP", -1);
+        pipe_step = num("H2R_PIPE_STEP", -1); step_chain_x2_per_cu = num("H2R_STEP_CHAIN_X2_PER_CU", 0);
         pipe_sub_batch = num("H2R_PIPE_SUB_BATCH", 0); arena_chunk_mb = num("H2R_ARENA_CHUNK_MB", 0); plain_overlap = num("H2R_PLAIN_OVERLAP", -1); pipe_pace = num("H2R_PIPE_PACE", -1);
 #endif
     }
@@ -1138,36 +1139,61 @@ namespace {
 // 32 limbs -- 64-digit chains on four waves, record workgroups of 256 threads), at batches the throughput chain build serves.
 // Measured against the two-queue form on the same boxes (bench.py, H2R_PIPE_STEP=0|1): 1,024 per call +1..5 %, 2,048 per call
 // +0..3 %, 8,192 as ONE step launch -4..+1 % -- so a call above 4,096 is walked as several launches of at most 4,096.
+// The shapes with a step build: (limb width, limbs) -> (chain digits K, waves NW).  A step's workgroup is the chain role's.
+struct StepShape { u32 w, L, K, NW; };
+constexpr StepShape kStepShapes[] = {{64, 32, 64, 4}, {64, 16, 32, 4}, {32, 128, 128, 8}, {64, 64, 128, 8}, {64, 48, 96, 6}};
+const StepShape *step_shape(const h2r_ctx *c) {
+    for (const StepShape &s : kStepShapes) if (c->layout.limb_width == s.w && c->L == s.L && c->K == s.K) return &s;
+    return nullptr;
+}
 bool step_eligible(const h2r_ctx *c, u64 batch, const void *trace, u32 T) {
-    const bool shape = c->layout.limb_width == 64 && ((c->L == 32 && c->K == 64) || (c->L == 16 && c->K == 32));   // RSA-2048, RSA-1024
-    return knobs().pipe_step != 0 && knobs().chain_nw == 0 && shape && batch > 512 && trace && T;
+    return knobs().pipe_step != 0 && knobs().chain_nw == 0 && step_shape(c) && batch > 512 && trace && T;
 }
 constexpr u64 kStepMax = 4096;   // elements per step launch: a larger call is walked as equal parts of at most this size
 // One step: the records described by `ta` (an earlier sub-batch) and the chains described by `ca`, one launch on `st`.
 extern "C++" {
-template <int K, int L>
+template <int K, int NW, int LW, int L>
 hipError_t launch_step_t(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
-    constexpr int IPB = TraceGeo<L>::IPB;
+    constexpr int IPB = (64 * NW) / TraceGeo<L>::TPI;                   // record items per workgroup of this launch
     const u64 rec_blocks = (ta.n_items + IPB - 1) / IPB;
-    u32 n_chain = (u32)std::min<u64>(ca.batch, 4ull * c->num_cus);   // four chain workgroups per CU, like next to a record kernel
+    // chain workgroups per CU: four 4-wave ones (what runs next to a record kernel on two queues), two 6- or 8-wave ones
+    // (measured, tools/step_shapes_ab.sh, profiles/r03_step_shapes.txt: RSA-3072 1.5 / 2 / 3 / 4 per CU -> 1.91 / 2.12 / 1.79 / 1.77 M
+    //  assigns/s; RSA-4096 1 / 1.5 / 2 / 3 -> 1.04 / 1.22 / 1.44 / 1.18 M; 128 x 32-bit limbs 1 / 1.5 / 2 / 3 -> 0.599 / 0.606 / 0.606 / 0.544 M)
+    u64 per_cu4 = NW == 4 ? 4ull * c->num_cus : 2ull * c->num_cus;
+    if (knobs().step_chain_x2_per_cu > 0) per_cu4 = (u64)knobs().step_chain_x2_per_cu * c->num_cus / 2;
+    u32 n_chain = (u32)std::min<u64>(ca.batch, per_cu4);
     n_chain = (n_chain + 7) & ~7u;                                     // keeps blockIdx % 8 (the XCD) of the record role's workgroups
     AuxArgs none;
     std::memset(&none, 0, sizeof none);
     const u64 n_aux = aa ? aa->batch : 0;
-    hipExtLaunchKernelGGL((step_kernel<K, 4, 64, L>), dim3((unsigned)(n_chain + rec_blocks + n_aux)), dim3(256), 0, st, ea, eb, 0,
+    hipExtLaunchKernelGGL((step_kernel<K, NW, LW, L>), dim3((unsigned)(n_chain + rec_blocks + n_aux)), dim3(64 * NW), 0, st, ea, eb, 0,
                           ca, ta, aa ? *aa : none, n_chain, (u32)rec_blocks);
     return hipGetLastError();
 }
 }  // extern "C++"
 hipError_t launch_step(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
-    return c->L == 32 ? launch_step_t<64, 32>(c, ca, ta, aa, st, ea, eb) : launch_step_t<32, 16>(c, ca, ta, aa, st, ea, eb);
+    const StepShape *s = step_shape(c);
+    if (!s) return hipErrorInvalidValue;
+    if (s->L == 32) return launch_step_t<64, 4, 64, 32>(c, ca, ta, aa, st, ea, eb);
+    if (s->L == 16) return launch_step_t<32, 4, 64, 16>(c, ca, ta, aa, st, ea, eb);
+    if (s->L == 128) return launch_step_t<128, 8, 32, 128>(c, ca, ta, aa, st, ea, eb);
+    if (s->L == 64) return launch_step_t<128, 8, 64, 64>(c, ca, ta, aa, st, ea, eb);
+    return launch_step_t<96, 6, 64, 48>(c, ca, ta, aa, st, ea, eb);
 }
-u32 step_shared_bytes(const h2r_ctx *c) { return c->L == 32 ? (u32)sizeof(StepShared<64, 4, 64, 32>) : (u32)sizeof(StepShared<32, 4, 64, 16>); }
+u32 step_shared_bytes(const h2r_ctx *c) {
+    const StepShape *s = step_shape(c);
+    if (!s) return 0;
+    if (s->L == 32) return (u32)sizeof(StepShared<64, 4, 64, 32>);
+    if (s->L == 16) return (u32)sizeof(StepShared<32, 4, 64, 16>);
+    if (s->L == 128) return (u32)sizeof(StepShared<128, 8, 32, 128>);
+    if (s->L == 64) return (u32)sizeof(StepShared<128, 8, 64, 64>);
+    return (u32)sizeof(StepShared<96, 6, 64, 48>);
+}
 // The pending records alone (the end of a train of steps, or a call that cannot be issued as a step); `st` is ordered behind them.
 int32_t pipeline_flush(h2r_pipeline *p, hipStream_t st) {
     if (!p->pending) return H2R_OK;
     TraceArgs ta = p->pending_ta;
-    ta.residency = 1; ta.dyn_lds = 0;   // the record kernel's stand-alone launch shape
+    ta.residency = (p->ctx->layout.limb_width == 64 && p->ctx->L <= 32) ? 1 : 0; ta.dyn_lds = 0;   // the record kernel's stand-alone launch shape
     {
         ProfScope ps(H2R_KERNEL_TRACE, p->pending_st, true);
         HIP_TRY(launch_trace(p->ctx, ta, p->pending_st, ps.a, ps.b));

@@ -816,8 +816,11 @@ __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K,
 // product loop preloads its operands 16 products ahead and runs four accumulators; it needs twice the registers.
 // The grid may be smaller than the batch: block b then runs elements b, b + gridDim.x, ... one after the other, which
 // bounds the kernel's footprint on the CUs whatever the batch size (a co-running record kernel keeps its store rate).
+#ifndef H2R_CHAIN_MINB_BIG
+#define H2R_CHAIN_MINB_BIG (H2R_CHAIN_MINB / 2)   // waves per SIMD the register budget of the K > 64 builds is sized for
+#endif
 template <int K, int NW, bool DEEP>
-__global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R_CHAIN_MINB / 2)) void chain_kernel(ChainArgs args) {
+__global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R_CHAIN_MINB_BIG)) void chain_kernel(ChainArgs args) {
     __shared__ ChainLds<K, NW> s;
     if (args.prio) __builtin_amdgcn_s_setprio(3);
     for (u64 elem = blockIdx.x; elem < args.batch; elem += gridDim.x) {
@@ -1068,7 +1071,7 @@ template <int LW, int L, int BT = TraceGeo<L>::BT>
 struct TraceShared {
     static constexpr int IPB = TraceGeo<L>::TPI >= BT ? 1 : BT / TraceGeo<L>::TPI;   // items per block
     TraceLds<LW, L> lds_all[IPB];
-    u64 xg[4], xp[4], xbad[4];  // per-wave carry masks for multi-wave items
+    u64 xg[8], xp[8], xbad[8];  // per-wave carry masks for multi-wave items (a workgroup has at most eight waves: the step launch of the 4096-bit shapes)
 };
 // The work of workgroup `block` of `n_blocks` (the kernel below; also callable as one role of a larger launch)
 template <int LW, int L, int BT = TraceGeo<L>::BT>
@@ -1082,7 +1085,7 @@ __device__ __forceinline__ void trace_block(const TraceArgs &args, const u32 blo
     constexpr int WPI = TPI / 64 > 0 ? TPI / 64 : 1;  // waves per item (when TPI >= 64)
     constexpr bool POW2 = (L & (L - 1)) == 0;
     TraceLds<LW, L> (&lds_all)[IPB] = sh.lds_all;
-    u64 (&xg)[4] = sh.xg; u64 (&xp)[4] = sh.xp; u64 (&xbad)[4] = sh.xbad;
+    u64 (&xg)[8] = sh.xg; u64 (&xp)[8] = sh.xp; u64 (&xbad)[8] = sh.xbad;
 
     if (args.prio) __builtin_amdgcn_s_setprio(3);  // co-scheduled with chain_kernel: keep the store stream fed
     const int tid = threadIdx.x;
@@ -1606,14 +1609,17 @@ __global__ __launch_bounds__(64) void aux_kernel(AuxArgs a) {
 // (80 VGPRs => six 4-wave workgroups per CU) and every slot a finished chain frees.
 // Measured (tools/fused_probe.py, 1,024 RSA-2048 signatures): 0.181 ms per step against 0.208-0.218 ms on two queues.
 // The roles share one workgroup size; their LDS is overlaid.
+// The workgroup size is the chain role's (64 * NW threads); the record role packs as many items into it as fit
+// (trace_block<LW, L, 64 * NW>: RSA-2048 four items in 256 threads as ever; 128 x 32-bit limbs two 256-thread items in the
+// 512 threads of an eight-wave chain workgroup; RSA-3072 four 96-thread items in the 384 threads of a six-wave one).
 template <int K, int NW, int LW, int L>
 union StepShared {
-    ChainLds<K, NW> chain; TraceShared<LW, L> trace; uint4 aux[sizeof(TraceShared<LW, L>) / 16];
+    ChainLds<K, NW> chain; TraceShared<LW, L, 64 * NW> trace; uint4 aux[sizeof(TraceShared<LW, L, 64 * NW>) / 16];
     __device__ StepShared() {}
 };
 template <int K, int NW, int LW, int L>
 __global__ __launch_bounds__(64 * NW, H2R_CHAIN_MINB) void step_kernel(ChainArgs ca, TraceArgs ta, AuxArgs aa, u32 n_chain, u32 n_rec) {
-    static_assert(TraceGeo<L>::BT == 64 * NW, "the roles use the same workgroup size");
+    static_assert((64 * NW) % TraceGeo<L>::TPI == 0, "the record role's items tile the chain role's workgroup");
     __shared__ StepShared<K, NW, LW, L> sh;
     const u32 b = blockIdx.x;
     if (b < n_chain) {
@@ -1624,7 +1630,7 @@ __global__ __launch_bounds__(64 * NW, H2R_CHAIN_MINB) void step_kernel(ChainArgs
     } else if (b < n_chain + n_rec) {
         // (a record role of a few workgroups per CU that WALK the records was tried: inlined into a loop the body spills 25
         //  registers at this launch's 80, as a real call it runs at 4.1 TB/s -- one workgroup per four records it is)
-        trace_block<LW, L>(ta, b - n_chain, n_rec, sh.trace);
+        trace_block<LW, L, 64 * NW>(ta, b - n_chain, n_rec, sh.trace);
     } else if (threadIdx.x < 64 && b - n_chain - n_rec < aa.batch) {
         // last in dispatch order: these short workgroups fill the slots the record role's tail leaves (in front of the record
         // role they cost the step 3-5 us)

@@ -254,7 +254,8 @@ int32_t h2r_modpow_public_key_var_batch(const h2r_ctx *ctx, const void *x, const
  * on `stream` as usual.  h2r_pipeline_join() must be called before a stream that pipelined calls were issued on is
  * destroyed (h2r_pipeline_destroy flushes records still owed on the stream of the last call).
  * How the overlap is obtained depends on the shape:
- *  - RSA-2048 and RSA-1024 (64-bit limbs, 32 / 16 limbs), more than 512 elements per call: ONE launch per call on `stream` (step_kernel; a call above 4,096 elements is
+ *  - RSA-2048, RSA-1024, RSA-3072, RSA-4096 (64-bit limbs: 32 / 16 / 48 / 64 limbs) and 128 x 32-bit limbs (BASELINE config 4), more
+ *    than 512 elements per call: ONE launch per call on `stream` (step_kernel; a call above 4,096 elements is
  *    walked as equal parts of at most 4,096, one launch each) whose
  *    workgroups run this call's chains and write this call's in-field witness and the PREVIOUS call's records; the
  *    last call's records go out alone at the join.  Everything is on the caller's stream, no side stream is involved.

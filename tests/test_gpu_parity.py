@@ -1001,14 +1001,14 @@ def test_pipelined_calls_match_oracle(H):
     pipe.close()
 
 
-@pytest.mark.parametrize("bits", [2048, 1024])
-def test_pipeline_one_launch_steps(H, bits):
+@pytest.mark.parametrize("w,bits", [(64, 2048), (64, 1024), (64, 3072), (64, 4096), (32, 4096)])
+def test_pipeline_one_launch_steps(H, w, bits):
     """RSA-2048 / RSA-1024 pipelined calls of 513..4,096 signatures are issued as one launch per call (step_kernel: this call's
     chains and in-field witness + the previous call's records).  A train of such calls, interrupted by a small call (the
     two-queue form) and by a change of the caller's stream, leaves byte-for-byte what the plain export writes -- trace,
     in-field witness, results, status -- and the launches are the expected ones."""
     from halo2_rsa_amd import _lib
-    chip = H.BigIntChip(64, bits)
+    chip = H.BigIntChip(w, bits)
     pl = chip.pow_fixed_layout(65537)
     ies = chip.in_field_layout()[0]
     rng = random.Random(77)
@@ -1022,7 +1022,7 @@ def test_pipeline_one_launch_steps(H, bits):
         mk = lambda nbytes: torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
         sets.append(dict(B=B, N=N, X=X, n=chip.assign_integer(N), x=chip.assign_integer(X),
                          trace=mk(B * pl.elem_stride), inf=mk(B * ies), ws=mk(chip.workspace_bytes(B, pl.num_mul_mods)),
-                         out=torch.zeros((B, bits // 64), dtype=torch.int64, device="cuda"), status=mk(B),
+                         out=torch.zeros((B, bits // w), dtype=chip.torch_dtype, device="cuda"), status=mk(B),
                          ref_trace=mk(B * pl.elem_stride), ref_inf=mk(B * ies)))
     torch.cuda.synchronize()
     pipe = chip.pipeline()
