@@ -394,6 +394,11 @@ class BigIntChip:
         """big_integer/chip.rs:642-649."""
         return self.mul_mod(a, a, n, want_trace)
 
+    def pow_var_layout(self, e_num_limbs: int, exp_limb_bits: int) -> H2RPowLayout:
+        pl = H2RPowLayout()
+        check(lib().h2r_pow_var_layout(self._ctx, e_num_limbs, exp_limb_bits, ctypes.byref(pl)), "h2r_pow_var_layout")
+        return pl
+
     def pow_fixed_layout(self, e: int) -> H2RPowLayout:
         pl = H2RPowLayout()
         eb = _e_bytes(e)
@@ -652,6 +657,15 @@ class Pipeline:
                                                    in_field_buf.data_ptr() if in_field_buf is not None else None, out.data_ptr(),
                                                    status.data_ptr(), workspace.data_ptr(), self.chip._stream()),
               "h2r_pipeline_modpow_public_key")
+
+    def modpow_public_key_var(self, x: AssignedInteger, e: AssignedInteger, exp_limb_bits: int, n: AssignedInteger, trace_buf, workspace,
+                              out, status, in_field_buf=None):
+        """RSAPubE::Var: per-element exponents `e` ([batch, e_num_limbs] limbs); buffers sized by pow_var_layout."""
+        check(lib().h2r_pipeline_modpow_public_key_var(self._p, x.data_ptr(), e.data_ptr(), e.num_limbs(), exp_limb_bits, n.data_ptr(), x.batch,
+                                                       self.chip._flags(n, x.batch), trace_buf.data_ptr(),
+                                                       in_field_buf.data_ptr() if in_field_buf is not None else None, out.data_ptr(),
+                                                       status.data_ptr(), workspace.data_ptr(), self.chip._stream()),
+              "h2r_pipeline_modpow_public_key_var")
 
     def verify_pkcs1v15(self, sig: AssignedInteger, e: int, n: AssignedInteger, hashed, trace_buf, workspace, powed, is_valid, status):
         """Pipelined RSAInstructions::verify_pkcs1v15_signature (after the SHA step); `hashed`: int64 [batch, 4] on the

@@ -1379,13 +1379,19 @@ void pipeline_plan(h2r_pipeline *p, u64 batch, bool assume_empty, std::vector<u6
 int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch,
                        uint32_t flags, void *trace, const h2r_pow_layout &pl, uint64_t elem_stride, void *out,
                        uint8_t *status, void *workspace, hipStream_t st, const std::function<int32_t()> &after_chain,
-                       u32 check_in_field = 1, bool assume_empty = false, const AuxArgs *witness_aux = nullptr, u32 witness_aux_lds = 0) {
+                       u32 check_in_field = 1, bool assume_empty = false, const AuxArgs *witness_aux = nullptr, u32 witness_aux_lds = 0,
+                       const void *e_limbs = nullptr, u32 e_num_limbs = 0, u32 exp_limb_bits = 0) {
     // witness_aux (nullable): what `after_chain` would launch, when that is a kernel whose output belongs to the call's
     // TRACE (the assert_in_field witness): a call issued as one-launch steps writes it together with its records
+    // e_limbs (nullable): per-element variable exponents (BigIntChip::pow_mod, chip.rs:664-696) instead of the fixed e_le
     const h2r_ctx *ctx = p->ctx;
     ExpBits eb; u32 T;
-    int32_t rc = exp_to_bits(e_le, e_len, &eb, &T);
+    int32_t rc = H2R_OK;
+    const u32 mode = e_limbs ? CHAIN_POW_VAR : CHAIN_POW_FIXED;
+    if (e_limbs) { std::memset(&eb, 0, sizeof eb); T = pl.num_mul_mods; }
+    else rc = exp_to_bits(e_le, e_len, &eb, &T);
     if (rc) return rc;
+    const u64 e_bytes = (u64)e_num_limbs * ctx->layout.limb_bytes;   // per element
     const u32 slot = p->k % p->depth;
     p->done[slot] = DoneRef{};
     if (knobs().pipe_serialize && p->aux[0] != p->aux[1] && p->k > 0) {   // order this record stream behind the previous record kernel
@@ -1431,7 +1437,8 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
             const u8 *xs = static_cast<const u8 *>(x) + off * in_bytes;
             const u8 *ns = static_cast<const u8 *>(n) + ((flags & H2R_F_SHARED_MODULUS) ? 0 : off * in_bytes);
             PathArgs pa;
-            rc = run_path(ctx, CHAIN_POW_FIXED, xs, nullptr, ns, nullptr, 0, 0, &eb, check_in_field, nb, flags, T,
+            rc = run_path(ctx, mode, xs, nullptr, ns, e_limbs ? static_cast<const u8 *>(e_limbs) + off * e_bytes : nullptr, e_num_limbs, exp_limb_bits,
+                          e_limbs ? nullptr : &eb, check_in_field, nb, flags, T,
                           static_cast<u8 *>(trace) + off * elem_stride, elem_stride, pl.off_records, &pl,
                           out ? static_cast<u8 *>(out) + off * in_bytes : nullptr, status + off, split ? ws + off * ws_elem : workspace,
                           st, p->aux[0], nullptr, nullptr, nullptr, split ? ws + wp.off_pre : nullptr, &pa,
@@ -1469,7 +1476,8 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
         DoneRef cur{};
         const u8 *xs = static_cast<const u8 *>(x) + o * in_bytes;
         const u8 *ns = static_cast<const u8 *>(n) + ((flags & H2R_F_SHARED_MODULUS) ? 0 : o * in_bytes);
-        rc = run_path(ctx, CHAIN_POW_FIXED, xs, nullptr, ns, nullptr, 0, 0, &eb, check_in_field, nb, flags, T,
+        rc = run_path(ctx, mode, xs, nullptr, ns, e_limbs ? static_cast<const u8 *>(e_limbs) + o * e_bytes : nullptr, e_num_limbs, exp_limb_bits,
+                      e_limbs ? nullptr : &eb, check_in_field, nb, flags, T,
                       static_cast<u8 *>(trace) + o * elem_stride, elem_stride, pl.off_records, &pl,
                       out ? static_cast<u8 *>(out) + o * in_bytes : nullptr, status + o, split ? ws + o * ws_elem : workspace,
                       st, p->aux[p->k & 1], p->chain_done[slot], last ? p->trace_done[slot] : p->sub_done[i & 1],
@@ -1588,6 +1596,24 @@ int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const voi
                               if (!in_field_trace) return H2R_OK;
                               return launch_in_field(p->ctx, x, n, batch, flags, in_field_trace, st);
                           }, 1, false, have_aux ? &aa : nullptr, aux_lds);
+}
+
+// RSAPubE::Var (src/chip.rs:108-110): per-element exponents; the same pipelining as the fixed-exponent form
+int32_t h2r_pipeline_modpow_public_key_var(h2r_pipeline *p, const void *x, const void *e_limbs, uint32_t e_num_limbs, uint32_t exp_limb_bits,
+                                           const void *n, uint64_t batch, uint32_t flags, void *trace, void *in_field_trace, void *out,
+                                           uint8_t *status, void *workspace, h2r_stream_t stream) {
+    if (!p || !trace || !workspace || !e_limbs) return H2R_E_NULL;
+    h2r_pow_layout pl;
+    const int32_t rc = h2r_pow_var_layout(p->ctx, e_num_limbs, exp_limb_bits, &pl);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    AuxArgs aa; u32 aux_lds = 0;
+    const bool have_aux = in_field_trace && batch && in_field_args(p->ctx, x, n, batch, flags, in_field_trace, &aa, &aux_lds) == H2R_OK;
+    return pipeline_issue(p, x, n, nullptr, 0, batch, flags, trace, pl, pl.elem_stride, out, status, workspace, st,
+                          [&]() -> int32_t {
+                              if (!in_field_trace) return H2R_OK;
+                              return launch_in_field(p->ctx, x, n, batch, flags, in_field_trace, st);
+                          }, 1, false, have_aux ? &aa : nullptr, aux_lds, e_limbs, e_num_limbs, exp_limb_bits);
 }
 
 int32_t h2r_pipeline_verify_pkcs1v15(h2r_pipeline *p, const void *sig, const void *n, const uint8_t *e_le, size_t e_len,

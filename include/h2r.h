@@ -276,6 +276,10 @@ int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const voi
                                        const uint8_t *e_le_bytes, size_t e_len, uint64_t batch,
                                        uint32_t flags, void *trace, void *in_field_trace, void *out,
                                        uint8_t *status, void *workspace, h2r_stream_t stream);
+/* the RSAPubE::Var arm (per-element exponents, as h2r_modpow_public_key_var_batch), pipelined the same way */
+int32_t h2r_pipeline_modpow_public_key_var(h2r_pipeline *p, const void *x, const void *e_limbs, uint32_t e_num_limbs,
+                                           uint32_t exp_limb_bits, const void *n, uint64_t batch, uint32_t flags, void *trace,
+                                           void *in_field_trace, void *out, uint8_t *status, void *workspace, h2r_stream_t stream);
 int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream);
 
 /* ---- multi-GPU: one process per GPU, signatures sharded, RCCL over xGMI behind the C ABI ---------------------------------

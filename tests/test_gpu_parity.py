@@ -1859,3 +1859,48 @@ def test_general_operand_shapes_mul_refresh_is_equal_muled(H, w, L, shapes):
     assert fresh.to_big_uint()[1] == 7 + (8 << w) + (9 << (2 * w))
     with pytest.raises(_lib.H2RError):
         chip.refresh_ex(_u256_tensor(big, 3), L + 1, 1)          # operands longer than the chip's num_limbs
+
+
+def test_pipelined_variable_exponent_calls(H):
+    """h2r_pipeline_modpow_public_key_var (RSAPubE::Var, src/chip.rs:108-110): three pipelined calls with per-element 5-limb x 13-bit
+    exponents over two buffer sets leave byte for byte what the stream-ordered export writes (trace incl. e bits and selected
+    limbs, in-field witness, results, status), and the results are pow(x, e, n)."""
+    chip = H.BigIntChip(64, 2048)
+    rng = random.Random(808)
+    B, NL, EB = 48, 5, 13
+    pl = chip.pow_var_layout(NL, EB)
+    ies = chip.in_field_layout()[0]
+    mk = lambda nbytes: torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+    sets = [dict(trace=mk(B * pl.elem_stride), inf=mk(B * ies), ws=mk(chip.workspace_bytes(B, pl.num_mul_mods)),
+                 out=torch.zeros((B, 32), dtype=torch.int64, device="cuda"), status=mk(B)) for _ in range(2)]
+    pipe = chip.pipeline()
+    calls, snaps = [], []
+    for k in range(3):
+        N = [rand_modulus(rng, 2048) for _ in range(B)]
+        X = [rng.randrange(n) for n in N]
+        E = [[rng.getrandbits(EB) for _ in range(NL)] for _ in range(B)]
+        e_dev = H.AssignedInteger(torch.tensor(E, dtype=torch.int64, device="cuda"), 64)
+        calls.append((N, X, E, chip.assign_integer(N), chip.assign_integer(X), e_dev))
+        s = sets[k % 2]
+        if k >= 2:
+            snaps.append((s["trace"].clone(), s["inf"].clone(), s["out"].clone(), s["status"].clone()))
+        pipe.modpow_public_key_var(calls[k][4], e_dev, EB, calls[k][3], s["trace"], s["ws"], s["out"], s["status"], in_field_buf=s["inf"])
+    pipe.join()
+    for k in (1, 2):
+        s = sets[k % 2]
+        snaps.append((s["trace"].clone(), s["inf"].clone(), s["out"].clone(), s["status"].clone()))
+    torch.cuda.synchronize()
+    for k in range(3):
+        N, X, E, n_dev, x_dev, e_dev = calls[k]
+        trace, inf, out, status = snaps[k]
+        ref = chip.pow_mod(x_dev, e_dev, n_dev, EB, check_in_field=True)
+        torch.cuda.synchronize()
+        assert not status.cpu().numpy().any()
+        # (the stream-ordered export's buffers come from torch.empty: compare the flat streams -- every witness byte -- not the padding)
+        assert torch.equal(ref.trace.emit_stream(), H.Trace(chip, trace, B, pl).emit_stream()), k
+        assert torch.equal(ref.value.limbs_dev, out), k
+        for i in (0, B // 2, B - 1):
+            assert np.array_equal(ref.in_field.flatten(i), H.big_integer.InFieldTrace(chip, inf, B, ies, chip.in_field_layout()[1]).flatten(i)), (k, i)
+        got = H.AssignedInteger(out, 64).to_big_uint()
+        assert all(got[i] == pow(X[i], sum(v << (EB * j) for j, v in enumerate(E[i])), N[i]) for i in range(B)), k
+    pipe.close()
