@@ -233,6 +233,43 @@ class BigIntChip {
         return {AssignedInteger(std::move(fresh), batch, 2 * num_limbs_), std::move(status)};
     }
 
+    // ---- any operand shape (the reference's mul takes d0 != d1, chip.rs:395-397; refresh any RefreshAux::new(w, n_l, n_r),
+    //      mod.rs:428; is_equal_muled n_l != n_r, chip.rs:822-842), operands of at most num_limbs limbs ----
+    MuledInteger mul_general(const AssignedInteger &a, const AssignedInteger &b) const {
+        const size_t batch = a.batch();
+        MuledInteger m; m.cols = DeviceBuffer(batch * 2 * num_limbs_ * 4 * 8); m.trace = DeviceBuffer(batch * layout_.record_stride);
+        m.batch = batch; m.num_limbs = num_limbs_;
+        hip_check(hipMemset(m.cols.get(), 0, m.cols.size()), "hipMemset");
+        check(h2r_mul_batch_ex(ctx_, a.data(), (uint32_t)a.num_limbs(), b.data(), (uint32_t)b.num_limbs(), batch, m.trace.get(),
+                               static_cast<uint64_t *>(m.cols.get()), nullptr), "mul_general");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        return m;
+    }
+    // refresh with RefreshAux::new(limb_width, n_l, n_r): (Fresh limbs, status); stream_out receives the flat streams
+    std::pair<AssignedInteger, std::vector<uint8_t>> refresh_general(const MuledInteger &a, uint32_t n_l, uint32_t n_r, DeviceBuffer *stream_out = nullptr) const {
+        uint32_t nf = 0; uint64_t sb = 0, stride = 0;
+        check(h2r_refresh_layout(ctx_, n_l, n_r, &nf, &sb, &stride), "h2r_refresh_layout");
+        const size_t batch = a.batch;
+        DeviceBuffer trace(batch * stride), fresh(batch * nf * 8), st(batch);
+        check(h2r_refresh_batch_ex(ctx_, static_cast<const uint64_t *>(a.cols.get()), 2 * num_limbs_, n_l, n_r, batch, trace.get(), fresh.get(),
+                                   static_cast<uint8_t *>(st.get()), nullptr), "refresh_general");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        std::vector<uint8_t> status(batch); st.download(status.data(), batch);
+        if (stream_out) *stream_out = std::move(trace);
+        return {AssignedInteger(std::move(fresh), batch, nf), std::move(status)};
+    }
+    std::vector<uint8_t> is_equal_muled_general(const MuledInteger &a, const MuledInteger &b, uint32_t n_l, uint32_t n_r) const {
+        const uint64_t sb = h2r_is_equal_muled_stream_bytes_ex(ctx_, n_l, n_r, 0), stride = (sb + 15) / 16 * 16;
+        if (!sb) throw Error(H2R_E_SHAPE, "is_equal_muled_general");
+        const size_t batch = a.batch;
+        DeviceBuffer out(batch * stride), eq(batch);
+        check(h2r_is_equal_muled_batch_ex(ctx_, static_cast<const uint64_t *>(a.cols.get()), static_cast<const uint64_t *>(b.cols.get()), 2 * num_limbs_,
+                                          n_l, n_r, batch, 0, out.get(), stride, static_cast<uint8_t *>(eq.get()), nullptr), "is_equal_muled_general");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        std::vector<uint8_t> bits(batch); eq.download(bits.data(), batch);
+        return bits;
+    }
+
     // big_integer/chip.rs:542-629
     BatchResult mul_mod(const AssignedInteger &a, const AssignedInteger &b, const AssignedInteger &n) const {
         if (a.num_limbs() != n.num_limbs() || a.num_limbs() != num_limbs_) throw Error(H2R_E_SHAPE, "mul_mod");  // :555

@@ -173,6 +173,49 @@ int main(int argc, char **argv) {
     bool threw = false;
     try { BigIntChip bad(64, 2048 + 8); } catch (const Error &e) { threw = e.code == H2R_E_SHAPE; }
     REQUIRE(threw);
+    // operands of different lengths: mul(d0 = 3, d1 = 32), refresh with RefreshAux::new(64, 3, 32), is_equal_muled(3, 32)
+    {
+        AssignedInteger three = bigint_chip.assign_integer(UnassignedInteger::from({7, 1, 2}, 1, 3));
+        AssignedInteger nn = bigint_chip.assign_integer(UnassignedInteger::from(kats[0].n, 1, 32));
+        MuledInteger p1 = bigint_chip.mul_general(three, nn), p2 = bigint_chip.mul_general(three, nn);
+        REQUIRE(bigint_chip.is_equal_muled_general(p1, p2, 3, 32)[0] == 1);
+        auto fr = bigint_chip.refresh_general(p1, 3, 32);
+        REQUIRE(fr.second[0] == H2R_OK && fr.first.num_limbs() == 35);
+        // (7 + 2^64 + 2 * 2^128) * n, limb 0 = 7 * n[0] mod 2^64
+        REQUIRE(fr.first.limbs()[0] == 7 * kats[0].n[0]);
+    }
+    // halo2's lookup argument for the range checks of these three circuits: table, multiplicities, permuted columns
+    {
+        h2r_lookup_config cfg;
+        REQUIRE(h2r_lookup_config_default(bigint_chip.ctx(), 1, &cfg) == H2R_OK && cfg.n_rows == 339);   // bit lengths 1, 4, 6, 8
+        std::vector<uint64_t> tag_col(4 * cfg.n_rows), val_col(4 * cfg.n_rows);
+        REQUIRE(h2r_lookup_table_image(bigint_chip.ctx(), &cfg, tag_col.data(), val_col.data()) == H2R_OK);
+        REQUIRE(tag_col[0] == 0 && val_col[0] == 0 && tag_col[4 * 338] == 4 && val_col[4 * 338] == 255);
+        const uint32_t usable = (1u << 17) - 6;
+        DeviceBuffer hist(B * 5 * cfg.n_rows * 4), theta(B * 32), a_perm(B * 5ull * usable * 32), s_perm(B * 5ull * usable * 32), lst(B),
+            lws(h2r_lookup_workspace_bytes(&cfg, B));
+        hip_check(hipMemset(hist.get(), 0, hist.size()), "hipMemset");
+        REQUIRE(h2r_lookup_hist_records(bigint_chip.ctx(), &cfg, res.trace.get(), res.layout.pow.off_records, res.layout.elem_stride, B,
+                                        res.layout.pow.num_mul_mods, nullptr, static_cast<uint32_t *>(hist.get()), nullptr) == H2R_OK);
+        std::vector<uint64_t> th(B * 4, 0);
+        for (size_t i = 0; i < B; ++i) { th[4 * i] = 0x1234567 + i; th[4 * i + 2] = 99; }
+        theta.upload(th.data(), th.size() * 8);
+        REQUIRE(h2r_lookup_permuted_columns(bigint_chip.ctx(), &cfg, static_cast<const uint32_t *>(hist.get()), static_cast<const uint64_t *>(theta.get()), B,
+                                            usable, 31, a_perm.get(), s_perm.get(), 5ull * usable * 32, static_cast<uint8_t *>(lst.get()),
+                                            lws.get(), nullptr) == H2R_OK);
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        // the lookup argument's rule on circuit 1 (BAD: no pow trace -> all-zero columns), and on circuit 0, argument composition_a
+        std::vector<uint64_t> A(4ull * usable), S(4ull * usable);
+        a_perm.download(A.data(), A.size() * 8); s_perm.download(S.data(), S.size() * 8);
+        size_t heads = 0;
+        for (uint32_t r = 0; r < usable; ++r) {
+            const bool eq_s = std::equal(A.begin() + 4 * r, A.begin() + 4 * r + 4, S.begin() + 4 * r);
+            const bool eq_p = r && std::equal(A.begin() + 4 * r, A.begin() + 4 * r + 4, A.begin() + 4 * (r - 1));
+            REQUIRE(eq_s || eq_p);
+            heads += !eq_p;
+        }
+        REQUIRE(heads > 200 && heads <= 339);   // the zero run + every looked-up 8-bit value
+    }
     // The multi-GPU exports over RCCL (h2r_dist_*, SURVEY section 2 component C1), as a Rust host would call them: a ONE-rank
     // communicator on this box's single GPU -- id, init, shard ranges, parameter broadcast, result all-gather, MAX, barrier.
     {
