@@ -711,8 +711,8 @@ class TraceArena:
         dev = "cuda:%d" % chip.device
         self.regions = [torch.as_tensor(TraceArena._Raw(int(lib().h2r_arena_region(self._a, i)), nbytes), device=dev) for i in range(regions)]
         self.region_ms = [float(lib().h2r_arena_region_ms(self._a, i)) for i in range(regions)]
-        buf = (ctypes.c_double * (8 * candidates))()   # (further candidates while the kept regions are not of one class, a second round when none stands out)
-        n = int(lib().h2r_arena_measurements(self._a, buf, 8 * candidates))
+        buf = (ctypes.c_double * (12 * candidates))()   # (further candidates while the kept regions are not of one class, a second round when none stands out)
+        n = int(lib().h2r_arena_measurements(self._a, buf, 12 * candidates))
         self.measurements_ms = [float(buf[i]) for i in range(n)]
 
     @classmethod

@@ -318,8 +318,9 @@ int32_t h2r_dist_allreduce_max_f64(h2r_dist *d, double *values, uint64_t count, 
  * elsewhere -- at most 64 GB of them and never more than half of the memory free on the device when the call starts).
  * While the kept regions are not of one class (regions of up to 4 GB: the slowest kept more than 4 % behind the fastest) up to
  * 3 x `candidates` further candidates are tried one at a time.
- * When no candidate stands out (regions of up to 4 GB: the best within 10 % of the worst) a second round of `candidates`
- * is tried in another part of the memory, behind a placeholder allocation of at most a third of the free memory.
+ * While the kept regions are not 7 % faster than the median of everything measured (regions of up to 4 GB) up to four more rounds
+ * of `candidates` are tried, each after giving everything back and behind a placeholder allocation of another size (48, 96, ...
+ * GB, at most half of the free memory): fresh, unchurned device memory hands out the slow class only.
  * Synchronises `stream`.  The regions are ordinary device memory for every other purpose. */
 typedef struct h2r_arena h2r_arena;
 int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t first_record_off, uint32_t records_per_elem,
