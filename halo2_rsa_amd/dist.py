@@ -96,6 +96,31 @@ class DistEnv:
             self.initialised = False
 
 
+def exchange_bytes(key: str, payload, rank: int, world: int) -> bytes:
+    """Rank 0's `payload` (bytes) to every rank, out of band of any collective library: through the TCPStore torchrun's agent
+    already serves at MASTER_ADDR:MASTER_PORT (every worker is a client of it), or -- launched any other way -- one that rank 0
+    serves itself.  This is all the rendezvous h2r_dist_init needs (the 128-byte RCCL id)."""
+    from datetime import timedelta
+    if world == 1:
+        return bytes(payload)
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true"
+    store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29531")), world,
+                          is_master=(rank == 0 and not agent), timeout=timedelta(seconds=120))
+    if rank == 0:
+        store.set(key, bytes(payload))
+        out = bytes(payload)
+    else:
+        out = bytes(store.get(key))
+    # keep the store alive until every rank has read the key (rank 0 may be its server)
+    store.add(key + "/seen", 1)
+    if rank == 0:
+        import time
+        deadline = time.time() + 120
+        while int(store.add(key + "/seen", 0)) < world and time.time() < deadline:
+            time.sleep(0.01)
+    return out
+
+
 class H2RDist:
     """The same plumbing over libh2r's own RCCL exports (h2r_dist_*: SURVEY section 2 component C1 behind the C ABI) -- what a
     Rust prover service binds.  Only the 128-byte RCCL id travels out of band: here through a torch.distributed.TCPStore at
@@ -103,26 +128,14 @@ class H2RDist:
 
     def __init__(self, chip, rank: int, world: int, local_rank: int):
         import ctypes
-        from datetime import timedelta
         from ._lib import check, lib
         self.chip, self.rank, self.world, self.local_rank = chip, rank, world, local_rank
         self._lib, self._check, self._ct = lib(), check, ctypes
         idb = (ctypes.c_uint8 * 128)()
-        if world > 1:
-            # under torchrun the agent already serves a TCPStore at MASTER_ADDR:MASTER_PORT (every worker is a client of it);
-            # launched any other way, rank 0 serves one itself
-            agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true"
-            store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29531")), world,
-                                  is_master=(rank == 0 and not agent), timeout=timedelta(seconds=120))
-            if rank == 0:
-                check(self._lib.h2r_dist_unique_id(idb), "h2r_dist_unique_id")
-                store.set("h2r_dist_id", bytes(idb))
-            else:
-                raw = store.get("h2r_dist_id")
-                ctypes.memmove(idb, raw, 128)
-            self._store = store
-        else:
+        if rank == 0:
             check(self._lib.h2r_dist_unique_id(idb), "h2r_dist_unique_id")
+        raw = exchange_bytes("h2r_dist_id", bytes(idb), rank, world)
+        ctypes.memmove(idb, raw, 128)
         self._d = ctypes.c_void_p()
         check(self._lib.h2r_dist_init(chip._ctx, idb, rank, world, ctypes.byref(self._d)), "h2r_dist_init")
         self.initialised, self.backend = True, "h2r_dist (RCCL via the C ABI)"

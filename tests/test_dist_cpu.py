@@ -56,6 +56,13 @@ def test_gloo_world2_harness(tmp_path):
             assert int(golden[0]["sig"]) == bench.synth_element(64, 2048, 0, golden)[1]
             print("GLOO_OK")
         env.finalize()
+        # the out-of-band rendezvous of the C-ABI communicator (h2r_dist_init needs rank 0's 128-byte RCCL id on every rank):
+        # through the agent's TCPStore under torchrun, exactly as bench.py --gpus N does before h2r_dist_init
+        from halo2_rsa_amd.dist import exchange_bytes
+        payload = bytes(range(128)) if env.rank == 0 else bytes(128)
+        got = exchange_bytes("test_id", payload, env.rank, env.world)
+        assert got == bytes(range(128))
+        print("ID_OK %%d" %% env.rank)
     ''' % ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
@@ -63,3 +70,4 @@ def test_gloo_world2_harness(tmp_path):
                          capture_output=True, text=True, timeout=240, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "GLOO_OK" in out.stdout
+    assert "ID_OK 0" in out.stdout and "ID_OK 1" in out.stdout
