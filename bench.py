@@ -495,7 +495,9 @@ def main():
         per_launch_batch = chunk * steps * chunks / n_launches
         trace_bytes_per_launch = int(round(per_launch_batch * (pl.num_mul_mods * chip.layout.stream_bytes)))
         if step_ms:   # the dominant kernel is the step launch; its algorithmic bytes are the records it writes
-            dom_ms, dom_name = step_ms, "step_kernel<%d,4,%d,%d> (records of call k + chains of call k+1, one launch)" % (bits // 32, w, chip.num_limbs)
+            kd = bits // 32
+            dom_ms, dom_name = step_ms, "step_kernel<%d,%d,%d,%d> (records of call k + chains of call k+1, one launch)" % (
+                kd, 4 if kd <= 64 else (6 if kd == 96 else 8), w, chip.num_limbs)
         else:
             dom_ms, dom_name = trace_ms, "trace_kernel<%d,%d>" % (w, chip.num_limbs)
         avg_trace_s = (sum(dom_ms) / len(dom_ms)) / 1e3 if dom_ms else float("nan")

@@ -1081,7 +1081,7 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
     // The kept regions should be of ONE class: a pipeline rotates through all of them, and a step into a second-class region
     // is 8 % longer (driver box of round 2: 1 fast candidate of 24, kept 0.183 / 0.199 ms).  While the slowest kept region is
     // more than 4 % behind the fastest, keep looking -- up to three more rounds' worth of candidates, one at a time.
-    if (rc == H2R_OK && regions > 1 && region_bytes <= (4ull << 30)) {
+    if (rc == H2R_OK && regions > 1 && region_bytes <= (12ull << 30)) {
         for (u32 extra = 0; extra < 3 * candidates && rc == H2R_OK && cands.size() == regions && cands.back().ms > 1.04f * cands.front().ms; ++extra) {
             cands.emplace_back();
             const int32_t r1 = make_candidate(cands.back());
@@ -1090,7 +1090,7 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
             keep_best(regions, false);
         }
     }
-    if (rc == H2R_OK && region_bytes <= (4ull << 30) && candidates >= 4) {
+    if (rc == H2R_OK && region_bytes <= (12ull << 30) && candidates >= 4) {
         // No fast class among the candidates?  On a box whose memory has not been churned yet (about one in five) the first
         // ~60 GB handed out are ALL of the slow class -- as physically contiguous memory always is -- while regions mapped after
         // some allocate / free traffic, or behind a large allocation, do contain fast ones (tools/no_fast_box_probe.py,

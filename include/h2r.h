@@ -316,9 +316,9 @@ int32_t h2r_dist_allreduce_max_f64(h2r_dist *d, double *values, uint64_t count, 
  * num_mul_mods / off_records / elem_stride), keeps the `regions` fastest -- h2r_arena_region(a, 0) is the fastest --
  * and gives the others back (rejected candidates keep their memory during the look so that the next candidate lands
  * elsewhere -- at most 64 GB of them and never more than half of the memory free on the device when the call starts).
- * While the kept regions are not of one class (regions of up to 4 GB: the slowest kept more than 4 % behind the fastest) up to
+ * While the kept regions are not of one class (regions of up to 12 GB: the slowest kept more than 4 % behind the fastest) up to
  * 3 x `candidates` further candidates are tried one at a time.
- * While the kept regions are not 7 % faster than the median of everything measured (regions of up to 4 GB) up to four more rounds
+ * While the kept regions are not 7 % faster than the median of everything measured (regions of up to 12 GB) up to four more rounds
  * of `candidates` are tried, each after giving everything back and behind a placeholder allocation of another size (48, 96, ...
  * GB, at most half of the free memory): fresh, unchurned device memory hands out the slow class only.
  * Synchronises `stream`.  The regions are ordinary device memory for every other purpose. */

@@ -5,7 +5,7 @@ import json, os, subprocess, sys
 var, vals, rest = sys.argv[1], sys.argv[2].split(","), sys.argv[3:]
 for v in vals:
     env = dict(os.environ); env[var] = v
-    out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline"] + rest, env=env, capture_output=True, text=True)
+    out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline", "--pmc-traffic", "off"] + [a for a in rest if a not in ("--pmc-traffic", "off")], env=env, capture_output=True, text=True)
     try:
         d = json.loads(out.stdout.strip().splitlines()[-1])
         r = d["roofline"]
