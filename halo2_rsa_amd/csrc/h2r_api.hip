@@ -160,7 +160,7 @@ struct h2r_ctx {
     // lookup-table row offsets for the multiplicity histogram
     u32 tab0_len, tab1_off, tab1_len, tab2_off, tab2_len, hist_len;
     // RefreshAux::new(w, L, L).increased_limbs_vec (host copy and device copy)
-    u8 refresh_inc[2 * 128 + 8]; u32 refresh_nf; u8 *refresh_inc_dev;
+    u8 refresh_inc[2 * 128 + 8]; u32 refresh_nf;
     u64 field_p[4];   // the field modulus (a_b encoding, chip.rs:859)
     FieldConsts fc;   // its Montgomery constants (lookup compression, is_zero's inverse witness)
     u32 num_cus, lds_per_cu;   // of the ctx's device
@@ -520,7 +520,6 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
     if (!c) return H2R_E_HIP;
     c->params = *params; c->L = L; c->K = params->bits_len / 32; c->word_max = wm; c->const_rec_dev = nullptr;
     c->num_cus = 256; c->lds_per_cu = 160 * 1024;
-    c->refresh_inc_dev = nullptr;
     std::memset(c->refresh_inc, 0, sizeof c->refresh_inc);
     c->refresh_nf = (L <= 128) ? refresh_aux_increased_limbs(w, L, L, c->refresh_inc) : 0;
     layout_compute(w, L, &c->layout);
@@ -549,11 +548,8 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
     }
     if (!hip_ok(dg.err, "hipSetDevice") ||
         !hip_ok(hipMalloc(reinterpret_cast<void **>(&c->const_rec_dev), lo.record_stride), "hipMalloc(const record)") ||
-        !hip_ok(hipMemcpy(c->const_rec_dev, c->const_rec_host.data(), lo.record_stride, hipMemcpyHostToDevice), "hipMemcpy(const record)") ||
-        !hip_ok(hipMalloc(reinterpret_cast<void **>(&c->refresh_inc_dev), sizeof c->refresh_inc), "hipMalloc(refresh aux)") ||
-        !hip_ok(hipMemcpy(c->refresh_inc_dev, c->refresh_inc, sizeof c->refresh_inc, hipMemcpyHostToDevice), "hipMemcpy(refresh aux)")) {
+        !hip_ok(hipMemcpy(c->const_rec_dev, c->const_rec_host.data(), lo.record_stride, hipMemcpyHostToDevice), "hipMemcpy(const record)")) {
         if (c->const_rec_dev) (void)hipFree(c->const_rec_dev);
-        if (c->refresh_inc_dev) (void)hipFree(c->refresh_inc_dev);
         delete c;
         return H2R_E_HIP;
     }
@@ -576,7 +572,6 @@ void h2r_ctx_destroy(h2r_ctx *ctx) {
     if (ctx->params.device >= 0) {
         DeviceGuard dg(ctx->params.device);
         if (ctx->const_rec_dev) (void)hipFree(ctx->const_rec_dev);
-        if (ctx->refresh_inc_dev) (void)hipFree(ctx->refresh_inc_dev);
         if (ctx->advice_desc_dev) (void)hipFree(ctx->advice_desc_dev);
         if (ctx->pipe) h2r_pipeline_destroy(ctx->pipe);
     }
@@ -860,6 +855,8 @@ int32_t rccl_ready() {
 
 struct h2r_dist {
     const h2r_ctx *ctx; ncclComm_t comm; u32 rank, world;
+    double *scratch;   // one word of plain device memory for the barrier (RCCL looks its buffers up in the runtime's allocation
+                       // map: a stream-ordered pool allocation is not in it -- "Memobj map does not have ptr", seen once in five runs)
 };
 
 int32_t h2r_dist_unique_id(uint8_t id_out[H2R_DIST_ID_BYTES]) {
@@ -885,15 +882,17 @@ int32_t h2r_dist_init(const h2r_ctx *ctx, const uint8_t id[H2R_DIST_ID_BYTES], u
     std::memcpy(&nid, id, sizeof nid);
     ncclComm_t comm = nullptr;
     RCCL_TRY(rccl().CommInitRank(&comm, (int)world, nid, (int)rank));
-    h2r_dist *d = new (std::nothrow) h2r_dist{ctx, comm, rank, world};
-    if (!d) { (void)rccl().CommDestroy(comm); return H2R_E_HIP; }
+    double *scratch = nullptr;
+    if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&scratch), sizeof(double)), "hipMalloc(barrier word)")) { (void)rccl().CommDestroy(comm); return H2R_E_HIP; }
+    h2r_dist *d = new (std::nothrow) h2r_dist{ctx, comm, rank, world, scratch};
+    if (!d) { (void)hipFree(scratch); (void)rccl().CommDestroy(comm); return H2R_E_HIP; }
     *out = d;
     return H2R_OK;
 }
 
 void h2r_dist_destroy(h2r_dist *d) {
     if (!d) return;
-    { DeviceGuard dg(d->ctx->params.device); (void)hipDeviceSynchronize(); (void)rccl().CommDestroy(d->comm); }
+    { DeviceGuard dg(d->ctx->params.device); (void)hipDeviceSynchronize(); (void)rccl().CommDestroy(d->comm); (void)hipFree(d->scratch); }
     delete d;
 }
 uint32_t h2r_dist_rank(const h2r_dist *d) { return d ? d->rank : 0; }
@@ -936,13 +935,9 @@ int32_t h2r_dist_allreduce_max_f64(h2r_dist *d, double *values, uint64_t count, 
     if (!d) return H2R_E_NULL;
     H2R_ON_DEVICE(d->ctx->params.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (count == 0 || !values) {   // barrier: a one-element reduction on a scratch word, ordered on `stream`
-        double *tmp = nullptr;
-        HIP_TRY(hipMallocAsync(reinterpret_cast<void **>(&tmp), sizeof(double), st));
-        HIP_TRY(hipMemsetAsync(tmp, 0, sizeof(double), st));
-        const ncclResult_t r = rccl().AllReduce(tmp, tmp, 1, ncclDouble, ncclMax, d->comm, st);
-        (void)hipFreeAsync(tmp, st);
-        RCCL_TRY(r);
+    if (count == 0 || !values) {   // barrier: a one-element reduction on the communicator's scratch word, ordered on `stream`
+        HIP_TRY(hipMemsetAsync(d->scratch, 0, sizeof(double), st));
+        RCCL_TRY(rccl().AllReduce(d->scratch, d->scratch, 1, ncclDouble, ncclMax, d->comm, st));
         return H2R_OK;
     }
     RCCL_TRY(rccl().AllReduce(values, values, count, ncclDouble, ncclMax, d->comm, st));

@@ -196,8 +196,12 @@ __global__ __launch_bounds__(256) void lookup_setup_kernel(LookupSetupArgs a) {
     __syncthreads();
     const u32 usable = a.usable_rows;
     const bool fits = total_in <= usable && n <= usable;
-    if (!fits) {   // more lookup inputs (or table rows) than usable rows: no such circuit
-        if (tid == 0 && a.status) a.status[elem] = (u8)H2R_E_SHAPE;
+    if (!fits) {   // more lookup inputs (or table rows) than usable rows: no such circuit.  G = 0 tells the fill kernel to leave the columns alone
+        if (tid == 0) {
+            if (a.status) a.status[elem] = (u8)H2R_E_SHAPE;
+            u32 *gc = reinterpret_cast<u32 *>(a.ws + (elem * LOOKUP_ARGS + arg) * lookup_slot_bytes(n) + (u64)n * 32) + (3 * n + 2);
+            gc[0] = 0; gc[1] = 0;
+        }
         return;
     }
     // 2. rank sort by the field's Ord (ties by row index), 3. scatter
@@ -264,6 +268,7 @@ __global__ __launch_bounds__(256) void lookup_fill_kernel(LookupFillArgs a) {
     const Fe *val = reinterpret_cast<const Fe *>(slot);
     const u32 *a_start = reinterpret_cast<const u32 *>(slot + (u64)n * 32), *a_rank = a_start + n + 1, *l_start = a_rank + n, *gcount = l_start + n + 1;
     const u32 G = gcount[0], n_heads = gcount[1];
+    if (G == 0) return;   // the set-up refused this circuit (status H2R_E_SHAPE)
     const u32 usable = a.usable_rows, n_rep = usable - n_heads;   // repeated rows = leftover table entries
     u8 *ap = a.a_perm + elem * a.out_elem_stride + (u64)arg * usable * 32;
     u8 *sp = a.s_perm + elem * a.out_elem_stride + (u64)arg * usable * 32;

@@ -1368,7 +1368,9 @@ def test_trace_arena(H):
     pl = chip.pow_fixed_layout(65537)
     B = 256
     arena = H.TraceArena.for_pow(chip, 65537, B, regions=2, candidates=5)
-    assert len(arena.regions) == 2 and len(arena.measurements_ms) in (5, 10)   # (10: a second round, no fast class in the first)
+    # 5 candidates, then further ones while the kept regions are not of one fast class (up to 3 x 5 one at a time, then up to four
+    # more rounds of 5 behind placeholders)
+    assert len(arena.regions) == 2 and 5 <= len(arena.measurements_ms) <= 5 + 15 + 20
     assert all(t > 0 for t in arena.measurements_ms)
     assert arena.region_ms == sorted(arena.measurements_ms)[:2]
     assert all(r.numel() == B * pl.elem_stride and r.is_cuda for r in arena.regions)
