@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void lookup_setup_kernel(LookupSetupArgs a) {
     atomicAdd(&total_in, my_in);
     __syncthreads();
     const u32 usable = a.usable_rows;
-    const bool fits = total_in <= usable && n <= usable;
+    const bool fits = total_in <= usable && n <= usable && !ge_p(theta.v, a.f.p);   // (a challenge that is not a canonical element is refused too)
     if (!fits) {   // more lookup inputs (or table rows) than usable rows: no such circuit.  G = 0 tells the fill kernel to leave the columns alone
         if (tid == 0) {
             if (a.status) a.status[elem] = (u8)H2R_E_SHAPE;

@@ -104,6 +104,42 @@ def test_lookup_hist_and_permuted_columns(H, w, L, e, field, rsa):
             assert got_s == b"".join(v.to_bytes(32, "little") for v in s_ref), (b, name, "S'")
 
 
+def test_lookup_with_a_custom_tag_map(H):
+    """h2r_lookup_config_custom: a maingate revision that tags every bit length with the bit length itself (instead of 1, 2, ...):
+    table image, multiplicities and permuted columns against the Python restatement configured the same way."""
+    w, L, P = 64, 8, FIELDS["bn254_fr"]
+    chip = H.BigIntChip(w, w * L)
+    o = Oracle(w, L)
+    lens = sorted(set(b for b in AR.range_lens(w, L) if b))
+    la = H.LookupArgument(chip, bit_lens=lens, tags=lens)
+    cfg = AR.LookupConfig(lens, tags=lens)
+    assert la.table_image() == cfg.table()
+    rng = random.Random(99)
+    n = rng.getrandbits(w * L) | (1 << (w * L - 1)) | 1
+    x = rng.randrange(n)
+    x_dev, n_dev = chip.assign_integer([x]), chip.assign_integer([n])
+    res = chip.pow_mod_fixed_exp(x_dev, 3, n_dev)
+    hist = la.new_hist(1)
+    la.hist_values(x_dev.limbs_dev, w, 8, hist)
+    la.hist_values(n_dev.limbs_dev, w, 8, hist)
+    la.hist_records(res.trace, hist, res.status)
+    usable = (1 << 12) - 6
+    theta = rng.randrange(P)
+    a_perm, s_perm, status = la.permuted_columns(hist, [theta], usable)
+    torch.cuda.synchronize()
+    assert status.cpu().tolist() == [0]
+    inputs, n_calls, acc = _circuit_reference(o, w, L, P, cfg, x, n, 3, usable)
+    tcol = AR.table_column(cfg, theta, usable, P)
+    for k_arg, name in enumerate(AR.ARGS):
+        a_ref, s_ref = AR.permute_expression_pair(AR.compress(inputs[name], theta, P), tcol)
+        assert a_perm[0, k_arg].cpu().numpy().tobytes() == b"".join(v.to_bytes(32, "little") for v in a_ref), name
+        assert s_perm[0, k_arg].cpu().numpy().tobytes() == b"".join(v.to_bytes(32, "little") for v in s_ref), name
+    # a challenge that is not a canonical field element is refused (status), the columns are left alone
+    a2, s2, st2 = la.permuted_columns(hist, [P + 5], usable, out=(torch.zeros_like(a_perm), torch.zeros_like(s_perm)))
+    torch.cuda.synchronize()
+    assert st2.cpu().tolist() == [H.H2R_E_SHAPE] and not a2.any() and not s2.any()
+
+
 def test_lookup_rejects_what_does_not_fit(H):
     from halo2_rsa_amd import _lib
     chip = H.BigIntChip(64, 2048)
