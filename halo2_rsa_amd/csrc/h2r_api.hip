@@ -282,6 +282,20 @@ hipError_t launch_chain(const h2r_ctx *c, const ChainArgs &ca, bool co_running, 
         case 16: return launch_chain_t<16, 1, false>(ca, 4 * cap4, st, ea, eb);
         case 32: return launch_chain_t<32, 4, false>(ca, cap4, st, ea, eb);
         case 64: {
+            // Two chains per element side by side (chain_dual_kernel: squarings and multiplies of one exponent bit in lockstep, eight
+            // waves): for latency-bound batches -- at most two elements per CU -- of variable exponents (two independent mul_mods per
+            // bit) and of DENSE fixed exponents (a zero bit costs the multiply group a dropped mul_mod).  BASELINE config 5: 3,072
+            // dependent mul_mods become 2,048 steps.
+            if (knobs().chain_nw == 0 && knobs().chain_deep < 0 && ca.mode != CHAIN_MULMOD && !ca.pre && ca.batch <= 2ull * c->num_cus) {
+                u32 pop = 0;
+                for (u32 wi = 0; wi < (ca.e.nbits + 31) / 32; ++wi) pop += (u32)__builtin_popcount(ca.e.words[wi]);
+                const bool dense = ca.mode == CHAIN_POW_VAR || (ca.e.nbits >= 64 && 4 * pop >= ca.e.nbits);
+                if (dense) {
+                    const u64 grid = cap2 && cap2 < ca.batch ? cap2 : ca.batch;
+                    hipExtLaunchKernelGGL((chain_dual_kernel<64, true>), dim3((unsigned)grid), dim3(512), 0, st, ea, eb, 0, ca);
+                    return hipGetLastError();
+                }
+            }
             // Throughput build (6 blocks per CU) when the batch fills the chip; latency build (deep operand prefetch,
             // 139 VGPRs) when there are at most two elements per CU and each chain's own latency is what the call
             // waits for (BASELINE config 5: 256 elements x 3,072 dependent mul_mods: 9.4 -> 7.8 ms, tools/c5_sweep.sh).

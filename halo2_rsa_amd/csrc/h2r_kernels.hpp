@@ -829,6 +829,148 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R
     }
 }
 
+// ---- two chains per element, side by side (round 3) -----------------------------------------------------------------
+// pow_mod_fixed_exp (chip.rs:731-740) is TWO dependent chains, not one: the squarings s[i+1] = s[i]^2 mod n and the running product
+// acc <- acc * s[i] mod n for the set bits -- and the multiply of bit i needs s[i], not s[i+1].  pow_mod (Var, chip.rs:684-694) likewise:
+// muled = acc * s[i] (always) and s[i+1] = s[i]^2 are independent given (acc, s[i]).  This build gives an element EIGHT waves in two groups
+// of four: group 0 walks the squarings, group 1 the multiplies of the same exponent bit, each with its own LDS and owner wave, in
+// lockstep (block_mulmod's barriers are data-independent, so both groups meet at every one).  The critical path of an element is one
+// mul_mod per exponent bit instead of 1 + bit (fixed) or 2 (Var): BASELINE config 5's 3,072 dependent mul_mods become 2,048 steps,
+// the Var path's 4,096 become 2,048.  A zero bit costs group 1 a mul_mod whose result is dropped, so this build is chosen only for
+// latency-bound batches (at most two elements per CU) and, for fixed exponents, dense ones.  The values, the items of the operand
+// buffer and every status are those of chain_element.
+template <int K, bool DEEP>
+__device__ __forceinline__ void chain_element_dual(const ChainArgs &args, ChainLds<K, 4> (&s2)[2], u32 (&xch)[K], int (&xst)[2], const u64 elem) {
+    constexpr int NW = 4;
+    using G = Geo<K, NW>;
+    constexpr int V = G::V;
+    const int g = threadIdx.x >> 8, tg = threadIdx.x & 255;          // group, thread within the group
+    const int lane = tg & 63, wave = tg >> 6;
+    const bool w0 = wave == 0;
+    ChainLds<K, NW> &s = s2[g];
+    const u32 *n_g = args.n + elem * args.n_stride;
+    const u32 KR = args.kreal;
+    u32 nraw[V];
+#pragma unroll
+    for (int m = 0; m < V; ++m) nraw[m] = ((u32)(lane + 64 * m) < KR) ? n_g[lane + 64 * m] : 0;
+    for (int i = tg; i < 3 * K; i += 256) { s.bpad[i] = 0; s.nnpad[i] = 0; s.mupad[i] = 0; }
+    if (tg == 0) { s.dbg = nullptr; s.dbg_n = 0; }
+    if (g == 0 && w0 && args.n_copy) glb_store<K>(args.n_copy + elem * KR, nraw, lane, KR);
+    int status = H2R_OK;
+    {
+        bool nz = false;
+#pragma unroll
+        for (int m = 0; m < V; ++m) nz = nz || __ballot(nraw[m] != 0) != 0;
+        if (!nz) status = H2R_E_ZERO_MODULUS;
+    }
+    u32 cur[V], acc[V];
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+        const int v = lane + 64 * m;
+        cur[m] = (u32)v < KR ? args.a[elem * KR + v] : 0;
+        acc[m] = (v == 0) ? 1u : 0u;
+    }
+    if (status == H2R_OK && args.check_in_field && wave_ge<K>(cur, nraw, lane)) status = H2R_E_NOT_IN_FIELD;
+    const bool var = args.mode == CHAIN_POW_VAR;
+    if (var && args.exp_limb_bits < 32 * args.digits_per_limb) {
+        bool wide = false;
+        for (u32 l = threadIdx.x; l < args.e_num_limbs; l += 512) {
+            const u32 *ed = args.e_limbs + (elem * args.e_num_limbs + l) * args.digits_per_limb;
+            const u64 v = args.digits_per_limb == 2 ? (((u64)ed[1] << 32) | ed[0]) : (u64)ed[0];
+            wide = wide || (v >> args.exp_limb_bits) != 0;
+        }
+        if (__syncthreads_or(wide ? 1 : 0) && status == H2R_OK) status = H2R_E_SHAPE;
+    }
+    if (status != H2R_OK) {   // block-uniform early exit
+        if (threadIdx.x == 0) args.status[elem] = (u8)status;
+        return;
+    }
+    u32 shift, nn[V];
+    (void)chain_modulus_setup<K, NW>(s, nraw, lane, wave, shift, nn);   // both groups, each into its own LDS (same barriers)
+    u32 q[V], r[V];
+    const u64 item0 = elem * args.T;
+    auto emit = [&](u32 t, const u32 (&oa)[V], const u32 (&ob)[V]) {
+        if (w0 && status == H2R_OK) {
+            wave_sync();
+            lds_store_n<K>(s.stage, oa, lane, KR); lds_store_n<K>(s.stage + KR, ob, lane, KR);
+            lds_store_n<K>(s.stage + 2 * KR, q, lane, KR); lds_store_n<K>(s.stage + 3 * KR, r, lane, KR);
+            wave_sync();
+            uint4 *dst = reinterpret_cast<uint4 *>(args.ops + (item0 + t) * (4ull * KR));
+            for (u32 v = lane; v < KR; v += 64) dst[v] = reinterpret_cast<const uint4 *>(s.stage)[v];
+        }
+    };
+    auto fold = [&](int st) {
+        if (KR < (u32)K && w0) {
+            bool hi = false;
+#pragma unroll
+            for (int m = 0; m < V; ++m) hi = hi || ((u32)(lane + 64 * m) >= KR && q[m] != 0);
+            if (__ballot(hi) && st == H2R_OK) st = H2R_E_NOT_REDUCED;
+        }
+        if (st != H2R_OK && status == H2R_OK) status = st;
+    };
+    u32 t = 0;
+    const u32 nbits = var ? args.e_num_limbs * args.exp_limb_bits : args.e.nbits;
+    u8 *etrace = args.trace ? args.trace + elem * args.elem_stride : nullptr;
+    u32 eword = 0;
+    for (u32 bi = 0; bi < nbits; ++bi) {
+        u32 bit;
+        if (var) {
+            const u32 limb = bi / args.exp_limb_bits, pos = bi % args.exp_limb_bits;
+            if ((pos & 31) == 0) eword = (args.e_limbs + (elem * args.e_num_limbs + limb) * args.digits_per_limb)[pos >> 5];
+            bit = (eword >> (pos & 31)) & 1u;
+            if (etrace && threadIdx.x == 0) etrace[args.off_e_bits + bi] = (u8)bit;
+        } else {
+            if ((bi & 31) == 0) eword = args.e.words[bi >> 5];
+            bit = (eword >> (bi & 31)) & 1u;
+        }
+        // group 0: squared = square_mod(cur) (:734 / :693);  group 1: acc * cur (:686 always for Var; :739 for a set bit of a fixed
+        // exponent -- for a zero bit the same arithmetic runs and is dropped: the barriers inside are what both groups share)
+        if (g == 0) fold(block_mulmod<K, NW, DEEP>(s, shift, lane, wave, cur, cur, nn, q, r));
+        else {
+            const int st1 = block_mulmod<K, NW, DEEP>(s, shift, lane, wave, acc, cur, nn, q, r);
+            if (var || bit) fold(st1);
+        }
+        // items of the operand buffer in the reference's call order: Var: multiply 2 bi, square 2 bi + 1; fixed: square t, multiply t + 1
+        if (g == 0) emit(var ? 2 * bi + 1 : t, cur, cur);
+        else if (var || bit) emit(var ? 2 * bi : t + 1, acc, cur);
+        t += 1 + ((var || bit) ? 1u : 0u);
+        if (g == 1) {
+            if (var) {
+#pragma unroll
+                for (int m = 0; m < V; ++m) acc[m] = bit ? r[m] : acc[m];            // select(muled, acc, bit), :688-691
+                if (etrace && w0 && status == H2R_OK)
+                    glb_store<K>((u32 *)(etrace + args.off_selected + (u64)bi * args.selected_stride), acc, lane, KR);
+            } else if (bit) {
+#pragma unroll
+                for (int m = 0; m < V; ++m) acc[m] = r[m];
+            }
+        } else if (w0) lds_store<K>(xch, r, lane);                                   // s[i+1] for both groups
+        __syncthreads();
+        if (w0) lds_load<K>(cur, xch, lane);   // (xch is rewritten only behind the next mul_mod, whose barriers every wave passes first)
+    }
+    // the two groups' statuses; the result is group 1's acc
+    if (tg == 0) xst[g] = status;
+    __syncthreads();
+    const int st_all = xst[0] != H2R_OK ? xst[0] : xst[1];
+    if (g == 1 && w0 && st_all == H2R_OK) {
+        if (args.out) glb_store<K>(args.out + elem * KR, acc, lane, KR);
+        if (etrace && args.write_result_to_trace) glb_store<K>((u32 *)(etrace + args.off_result), acc, lane, KR);
+    }
+    if (threadIdx.x == 0) args.status[elem] = (u8)st_all;
+}
+
+template <int K, bool DEEP>
+__global__ __launch_bounds__(512, 2) void chain_dual_kernel(ChainArgs args) {
+    __shared__ ChainLds<K, 4> s2[2];
+    __shared__ u32 xch[K];
+    __shared__ int xst[2];
+    if (args.prio) __builtin_amdgcn_s_setprio(3);
+    for (u64 elem = blockIdx.x; elem < args.batch; elem += gridDim.x) {
+        if (elem != blockIdx.x) __syncthreads();
+        chain_element_dual<K, DEEP>(args, s2, xch, xst, elem);
+    }
+}
+
 // The shared modulus' Barrett constants, once per call (one workgroup).
 template <int K, int NW>
 __global__ __launch_bounds__(64 * NW) void recip_kernel(const u32 *n, u32 kreal, u32 *pre) {
