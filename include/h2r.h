@@ -504,7 +504,7 @@ int32_t h2r_trace_lookup_permutation_hist(const h2r_ctx *ctx, const void *trace,
  *    handed out from the LAST repeated row backwards, as the upstream Vec::pop does); the table column is the table's rows
  *    followed by its default row (0, 0).  The blinding tail (random) is the caller's.  Output: canonical 32-byte little-endian
  *    elements; element e, argument k at + e * out_elem_stride + k * usable_rows * 32 in a_perm_out and in s_perm_out.
- *    theta: [num_elems][4] uint64 on the device, canonical (< p) little-endian (every proof has its own challenge).  status
+ *    At most 65,535 circuits per call.  theta: [num_elems][4] uint64 on the device, canonical (< p) little-endian (every proof has its own challenge).  status
  *    (nullable, [num_elems]): H2R_E_SHAPE where the lookup inputs or the table do not fit usable_rows or theta is not canonical
  *    (that circuit's columns are left untouched).  arg_mask: bit k = produce argument k. */
 #define H2R_LOOKUP_ARGS 5u

@@ -1863,13 +1863,14 @@ def test_general_operand_shapes_mul_refresh_is_equal_muled(H, w, L, shapes):
         chip.refresh_ex(_u256_tensor(big, 3), L + 1, 1)          # operands longer than the chip's num_limbs
 
 
-def test_pipelined_variable_exponent_calls(H):
+@pytest.mark.parametrize("B,NL,EB", [(48, 5, 13), (640, 1, 5)])
+def test_pipelined_variable_exponent_calls(H, B, NL, EB):
     """h2r_pipeline_modpow_public_key_var (RSAPubE::Var, src/chip.rs:108-110): three pipelined calls with per-element 5-limb x 13-bit
     exponents over two buffer sets leave byte for byte what the stream-ordered export writes (trace incl. e bits and selected
     limbs, in-field witness, results, status), and the results are pow(x, e, n)."""
+    # (640 per call: issued as one-launch steps -- the chain role runs the variable-exponent walk inside step_kernel)
     chip = H.BigIntChip(64, 2048)
-    rng = random.Random(808)
-    B, NL, EB = 48, 5, 13
+    rng = random.Random(808 + B)
     pl = chip.pow_var_layout(NL, EB)
     ies = chip.in_field_layout()[0]
     mk = lambda nbytes: torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
