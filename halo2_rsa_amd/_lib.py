@@ -90,13 +90,14 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_trace_flatten", "h2r_pow_trace_flatten", "h2r_stream_bytes", "h2r_pow_stream_bytes", "h2r_trace_flatten_ex",
            "h2r_pow_trace_flatten_ex", "h2r_trace_emit_stream", "h2r_pow_trace_emit_stream", "h2r_mul_mod_trace_check", "h2r_pow_trace_check",
            "h2r_advice_rows", "h2r_mul_mod_emit_advice", "h2r_pow_trace_emit_advice", "h2r_pow_advice_rows", "h2r_advice_row_kinds",
-           "h2r_advice_fixed_row",
+           "h2r_advice_fixed_row", "h2r_fresh_op_advice_rows", "h2r_fresh_op_row_kinds", "h2r_fresh_op_emit_advice",
            "h2r_lookup_config_default", "h2r_lookup_config_custom", "h2r_lookup_table_image", "h2r_lookup_hist_records",
            "h2r_lookup_hist_values", "h2r_lookup_hist_fresh_op", "h2r_lookup_workspace_bytes", "h2r_lookup_permuted_columns", "h2r_field_eval",
            "h2r_dist_unique_id", "h2r_dist_init", "h2r_dist_destroy", "h2r_dist_rank", "h2r_dist_world", "h2r_dist_shard_range",
            "h2r_dist_bcast", "h2r_dist_gather_results", "h2r_dist_allreduce_max_f64",
            "h2r_profile_enable", "h2r_profile_read", "h2r_status_str",
            "h2r_last_hip_error"]
+H2R_ADVICE_ASSERT_ONE = 0x100
 KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST, KERNEL_AUX, KERNEL_EMIT, KERNEL_STEP, KERNEL_LOOKUP = 0, 1, 2, 3, 4, 5, 6
 H2R_STREAM_FIELD_AB = 1
 FRESH_OPS = ["add", "sub", "add_mod", "sub_mod", "is_zero", "is_equal_fresh", "is_less_than", "is_less_than_or_equal",
@@ -207,6 +208,10 @@ def lib():
     L.h2r_pow_advice_rows.restype = u64
     L.h2r_advice_row_kinds.argtypes = [vp, vp]
     L.h2r_advice_fixed_row.argtypes = [vp, ctypes.POINTER(H2RLookupConfig), u32, ctypes.POINTER(H2RFixedRow)]
+    L.h2r_fresh_op_advice_rows.argtypes = [vp, u32, u32]
+    L.h2r_fresh_op_advice_rows.restype = u32
+    L.h2r_fresh_op_row_kinds.argtypes = [vp, u32, u32, vp]
+    L.h2r_fresh_op_emit_advice.argtypes = [vp, u32, u32, vp, vp, vp, vp, u64, u64, u64, vp, vp, u64, vp]
     L.h2r_mul_mod_emit_advice.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp, vp, u64, vp]
     L.h2r_pow_trace_emit_advice.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, u32, vp, u64, vp, u64, vp, vp, u64, vp]
     L.h2r_mul_mod_trace_check.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp, vp, vp, vp]

@@ -170,6 +170,12 @@ class InFieldTrace:
     def __init__(self, chip: "BigIntChip", buf: torch.Tensor, batch: int, elem_stride: int, stream_bytes: int):
         self.chip, self.buf, self.batch, self.elem_stride, self.stream_bytes = chip, buf, batch, elem_stride, stream_bytes
 
+    def emit_advice(self, x: "AssignedInteger", n: "AssignedInteger") -> torch.Tensor:
+        """assert_in_field(x, n) as advice rows (is_less_than's cells + the assert_one row): uint8 [batch, rows * 160]."""
+        flags = _lib.H2R_F_SHARED_MODULUS if (n.batch == 1 and self.batch != 1) else 0
+        return self.chip.fresh_op_emit_advice(_lib.FRESH_OPS.index("is_in_field"), x, n, None, flags, self.buf, 0, self.elem_stride,
+                                              self.batch, None, assert_one=True)
+
     def flatten(self, elem: int) -> np.ndarray:
         host = np.ascontiguousarray(self.buf[elem * self.elem_stride:(elem + 1) * self.elem_stride].cpu().numpy())
         out = np.zeros(self.stream_bytes, dtype=np.uint8)
@@ -498,7 +504,27 @@ class BigIntChip:
                                        value.data_ptr() if value is not None else None, flag.data_ptr(), status.data_ptr(),
                                        self._stream()), name)
         return FreshResult(AssignedInteger(value, self.limb_width) if value is not None else None, flag, status, trace,
-                           es.value, sb.value, op, self)
+                           es.value, sb.value, op, self, (a, b, n, flags))
+
+    def fresh_op_emit_advice(self, op: int, a, b, n, flags: int, trace: torch.Tensor, first_off: int, elem_stride: int, batch: int,
+                             status: Optional[torch.Tensor] = None, assert_one: bool = False) -> torch.Tensor:
+        """h2r_fresh_op_emit_advice: the rows of a Fresh-integer op as a 5-column advice image, uint8 [batch, rows * 160] in HBM."""
+        fl = flags | (_lib.H2R_ADVICE_ASSERT_ONE if assert_one else 0)
+        rows = int(lib().h2r_fresh_op_advice_rows(self._ctx, op, fl))
+        if rows == 0:
+            check(_lib.H2R_E_UNSUPPORTED, "h2r_fresh_op_advice_rows")
+        out = torch.empty((batch, rows * 160), dtype=torch.uint8, device=trace.device)
+        check(lib().h2r_fresh_op_emit_advice(self._ctx, op, fl, a.data_ptr(), b.data_ptr() if b is not None else None,
+                                             n.data_ptr() if n is not None else None, trace.data_ptr(), first_off, elem_stride, batch,
+                                             status.data_ptr() if status is not None else None, out.data_ptr(), out.shape[1],
+                                             self._stream()), "h2r_fresh_op_emit_advice")
+        return out
+
+    def fresh_op_row_kinds(self, op: int, assert_one: bool = False) -> np.ndarray:
+        fl = _lib.H2R_ADVICE_ASSERT_ONE if assert_one else 0
+        kinds = np.zeros(int(lib().h2r_fresh_op_advice_rows(self._ctx, op, fl)), dtype=np.uint8)
+        check(lib().h2r_fresh_op_row_kinds(self._ctx, op, fl, kinds.ctypes.data), "h2r_fresh_op_row_kinds")
+        return kinds
 
     def add(self, a, b):
         """big_integer/chip.rs:245-297 -> num_limbs + 1 limbs."""
@@ -814,6 +840,12 @@ class FreshResult:
     stream_bytes: int
     op: int
     chip: BigIntChip
+    inputs: Optional[tuple] = None   # (a, b, n, flags) the op was called with
+
+    def emit_advice(self, assert_one: bool = False) -> torch.Tensor:
+        """Every cell of the op as rows of the main gate's advice columns (h2r_fresh_op_emit_advice)."""
+        a, b, n, flags = self.inputs
+        return self.chip.fresh_op_emit_advice(self.op, a, b, n, flags, self.trace, 0, self.elem_stride, a.batch, self.status, assert_one)
 
     def flatten(self, elem: int) -> np.ndarray:
         host = np.ascontiguousarray(self.trace[elem * self.elem_stride:(elem + 1) * self.elem_stride].cpu().numpy())

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -19,6 +20,7 @@
 #include "h2r_layout.hpp"
 #include "h2r_lookup.hpp"
 #include "h2r_muled.hpp"
+#include "h2r_rowprog.hpp"
 
 using namespace h2r;
 
@@ -168,6 +170,10 @@ struct h2r_ctx {
     // (created on first use; calls on one ctx from several threads take turns queueing)
     mutable std::mutex pipe_mu;
     mutable h2r_pipeline *pipe = nullptr;
+    // row programs of the Fresh-op advice images (h2r_rowprog.hpp), built on first use; key = op | assert_one << 8
+    struct RowProg { std::vector<RpRow> host; RpRow *dev = nullptr; };
+    mutable std::mutex prog_mu;
+    mutable std::map<u32, RowProg> progs;
 };
 
 namespace {
@@ -587,6 +593,7 @@ void h2r_ctx_destroy(h2r_ctx *ctx) {
         DeviceGuard dg(ctx->params.device);
         if (ctx->const_rec_dev) (void)hipFree(ctx->const_rec_dev);
         if (ctx->advice_desc_dev) (void)hipFree(ctx->advice_desc_dev);
+        for (auto &kv : ctx->progs) if (kv.second.dev) (void)hipFree(kv.second.dev);
         if (ctx->pipe) h2r_pipeline_destroy(ctx->pipe);
     }
     delete ctx;
@@ -2338,6 +2345,11 @@ int32_t h2r_advice_fixed_row(const h2r_ctx *ctx, const h2r_lookup_config *cfg, u
         case ROWK_ASSERT_EQ: put(out->sa, one, false); put(out->sb, one, true); break;
         case ROWK_ISZERO_INV: put(out->s_mul_ab, one, false); put(out->sc, one, false); put(out->s_const, one, true); break;
         case ROWK_ISZERO_RA: put(out->s_mul_ab, one, false); break;
+        case ROWK_SELECT: put(out->s_mul_ab, one, false); put(out->s_mul_cd, one, true); put(out->sd, one, false); put(out->se, one, true); break;
+        case ROWK_NOT: put(out->sa, one, false); put(out->sb, one, false); put(out->s_const, one, true); break;
+        case ROWK_ASSERT_ONE: put(out->sa, one, false); put(out->s_const, one, true); break;
+        case ROWK_CONST_BM1: put(out->sa, one, false); put(out->s_const, fe_sub(Bv, one, p), true); break;
+        case ROWK_ASSERT_ZERO: put(out->sa, one, false); break;
         default: {
             const bool carry = kind >= ROWK_RANGE_CARRY;
             const u32 rr = kind - (carry ? ROWK_RANGE_CARRY : ROWK_RANGE_LIMB);
@@ -2361,6 +2373,85 @@ int32_t h2r_advice_fixed_row(const h2r_ctx *ctx, const h2r_lookup_config *cfg, u
             break;
         }
     }
+    return H2R_OK;
+}
+
+// ---- advice rows of the Fresh-integer family (h2r_rowprog.hpp) ---------------------------------------------------------------
+namespace {
+// the row program of (op, assert_one): built by the symbolic walk on first use, uploaded when the ctx has a device
+int32_t fresh_row_prog(const h2r_ctx *ctx, uint32_t op, uint32_t flags, const h2r_ctx::RowProg **out) {
+    if (op >= FRESH_OP_COUNT) return H2R_E_UNSUPPORTED;
+    if (ctx->L + 3 > 64 * AUX_V) return H2R_E_UNSUPPORTED;
+    const bool assert_one = (flags & H2R_ADVICE_ASSERT_ONE) != 0;
+    const u32 key = op | (assert_one ? 256u : 0u);
+    std::lock_guard<std::mutex> lk(ctx->prog_mu);
+    auto it = ctx->progs.find(key);
+    if (it == ctx->progs.end()) {
+        RowProgBuilder rb(AuxGeom(ctx->L, ctx->layout.limb_width));
+        if (!rb.build(op, assert_one)) return H2R_E_UNSUPPORTED;   // assert_one on an op without a bit
+        h2r_ctx::RowProg rp;
+        rp.host = std::move(rb.rows);
+        if (ctx->params.device >= 0) {
+            DeviceGuard dg(ctx->params.device);
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&rp.dev), rp.host.size() * sizeof(RpRow)));
+            if (hipMemcpy(rp.dev, rp.host.data(), rp.host.size() * sizeof(RpRow), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(rp.dev); return H2R_E_HIP; }
+        }
+        it = ctx->progs.emplace(key, std::move(rp)).first;
+    }
+    *out = &it->second;
+    return H2R_OK;
+}
+}  // namespace
+
+uint32_t h2r_fresh_op_advice_rows(const h2r_ctx *ctx, uint32_t op, uint32_t flags) {
+    const h2r_ctx::RowProg *rp = nullptr;
+    if (!ctx || fresh_row_prog(ctx, op, flags, &rp)) return 0;
+    return (uint32_t)rp->host.size();
+}
+
+int32_t h2r_fresh_op_row_kinds(const h2r_ctx *ctx, uint32_t op, uint32_t flags, uint8_t *kinds_out) {
+    if (!ctx || !kinds_out) return H2R_E_NULL;
+    const h2r_ctx::RowProg *rp = nullptr;
+    const int32_t rc = fresh_row_prog(ctx, op, flags, &rp);
+    if (rc) return rc;
+    for (size_t r = 0; r < rp->host.size(); ++r) kinds_out[r] = (uint8_t)rp->host[r].kind;
+    return H2R_OK;
+}
+
+int32_t h2r_fresh_op_emit_advice(const h2r_ctx *ctx, uint32_t op, uint32_t flags, const void *a, const void *b, const void *n,
+                                 const void *trace, uint64_t first_off, uint64_t elem_stride, uint64_t batch, const uint8_t *status,
+                                 void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
+    if (!ctx || !a || !trace || !advice_out) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    const h2r_ctx::RowProg *rp = nullptr;
+    int32_t rc = fresh_row_prog(ctx, op, flags, &rp);
+    if (rc) return rc;
+    const bool needs_b = op != FRESH_IS_ZERO, needs_n = op == FRESH_ADD_MOD || op == FRESH_SUB_MOD;
+    if ((needs_b && !b) || (needs_n && !n)) return H2R_E_NULL;
+    u64 es = 0;
+    rc = h2r_fresh_op_layout(ctx, op, &es, nullptr, nullptr);
+    if (rc) return rc;
+    if (elem_stride == 0) elem_stride = es;
+    const u64 rows = rp->host.size();
+    if (out_stride < rows * ADVICE_ROW_BYTES || (first_off & 15) || (elem_stride & 15)) return H2R_E_SHAPE;
+    if (batch == 0) return H2R_OK;
+    RowProgArgs ra;
+    std::memset(&ra, 0, sizeof ra);
+    ra.prog = rp->dev; ra.rows = (u32)rows;
+    ra.a = a; ra.b = b ? b : a; ra.n = n ? n : a;
+    ra.a_stride = ctx->L;
+    ra.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
+    ra.b_stride = (!needs_n && (flags & H2R_F_SHARED_MODULUS)) ? 0 : ctx->L;   // as h2r_fresh_op_batch
+    ra.trace = static_cast<const u8 *>(trace); ra.elem_stride = elem_stride; ra.first_off = first_off;
+    ra.status = status; ra.batch = batch; ra.out = static_cast<u8 *>(advice_out); ra.out_stride = out_stride; ra.f = ctx->fc;
+    const u64 blocks = batch * ((rows + 255) / 256);
+    if (blocks >= (1ull << 31)) return H2R_E_UNSUPPORTED;
+    H2R_ON_DEVICE(ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ProfScope ps(H2R_KERNEL_EMIT, st, true);
+    if (ctx->layout.limb_width == 64) hipExtLaunchKernelGGL((rowprog_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, st, ps.a, ps.on ? ps.b : nullptr, 0, ra);
+    else hipExtLaunchKernelGGL((rowprog_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, ps.a, ps.on ? ps.b : nullptr, 0, ra);
+    HIP_TRY(hipGetLastError());
     return H2R_OK;
 }
 

@@ -603,6 +603,8 @@ enum { H2R_ROW_NOP = 0, H2R_ROW_CONST0, H2R_ROW_CONST1, H2R_ROW_CONST_B /* assig
        H2R_ROW_VALUE /* assign_value [v] */, H2R_ROW_MUL_ADD /* [a,b,c,a*b+c] */, H2R_ROW_ADD, H2R_ROW_SUB /* [a,b,a+-b] */,
        H2R_ROW_ADD_WM /* add_with_constant(word_max) */, H2R_ROW_ADDC_WM /* add_constant(word_max): [a, a+W] */, H2R_ROW_MUL /* mul, and */,
        H2R_ROW_ASSERT_EQ /* [a,b] */, H2R_ROW_ISZERO_INV /* is_zero: [a, 1/a or 1, r], a*a' + r - 1 = 0 */, H2R_ROW_ISZERO_RA /* [r, a], r*a = 0 */,
+       H2R_ROW_SELECT /* select(a,b,cond): [cond,a,cond,b,res], cond*a - cond*b + b - res = 0 */, H2R_ROW_NOT /* [c, 1-c] */,
+       H2R_ROW_ASSERT_ONE /* [a], a - 1 = 0 */, H2R_ROW_CONST_BM1 /* assign_constant(2^w - 1) */, H2R_ROW_ASSERT_ZERO /* [a] */,
        H2R_ROW_RANGE_LIMB = 32, H2R_ROW_RANGE_CARRY = 40 };
 typedef struct h2r_fixed_row {
     uint64_t sa[4], sb[4], sc[4], sd[4], se[4], s_mul_ab[4], s_mul_cd[4], se_next[4], s_const[4];
@@ -614,6 +616,22 @@ int32_t h2r_advice_fixed_row(const h2r_ctx *ctx, const struct h2r_lookup_config 
 /* rows of one element of h2r_pow_trace_emit_advice: for a fixed exponent two constant rows first -- CONST1 [1], CONST0 [0], the
  * limbs of pow_mod_fixed_exp's acc = assign_constant(1, num_limbs) (big_integer/chip.rs:729 -> :1272-1276) -- then the records */
 uint64_t h2r_pow_advice_rows(const h2r_ctx *ctx, const h2r_pow_layout *pl);
+/* The Fresh-integer family as advice rows: every cell of BigIntChip::add / sub / add_mod / sub_mod / is_zero / is_equal_fresh /
+ * the comparisons / is_in_field (big_integer/chip.rs:245-373, 452-528, 754-805, 908-1006; helpers max_value :138-154,
+ * sub_unchecked :1286-1318), in the reference's op order, from the witness h2r_fresh_op_batch wrote (or the in_field_trace of
+ * h2r_modpow_public_key_batch / the in-field region of a verify element: op = H2R_OP_IS_IN_FIELD, first_off =
+ * h2r_verify_layout.off_in_field, elem_stride = the verify element's).  elem_stride = 0: h2r_fresh_op_layout's.
+ * flags: H2R_F_SHARED_MODULUS as for h2r_fresh_op_batch (a, b, n are the operands that call was given);
+ *        H2R_ADVICE_ASSERT_ONE  the op's bit is then given to main_gate.assert_one -- assert_in_field (:1150-1158), assert_equal_fresh,
+ *        assert_less_than ... (instructions.rs:197-254): one more row; H2R_E_UNSUPPORTED for add / sub / add_mod / sub_mod.
+ * Rows (kinds from h2r_fresh_op_row_kinds; fixed columns from h2r_advice_fixed_row): 1,532 for assert_in_field of RSA-2048
+ * (32 x 64-bit limbs).  Elements with a nonzero status byte (nullable) are skipped. */
+#define H2R_ADVICE_ASSERT_ONE 0x100u
+uint32_t h2r_fresh_op_advice_rows(const h2r_ctx *ctx, uint32_t op, uint32_t flags);
+int32_t h2r_fresh_op_row_kinds(const h2r_ctx *ctx, uint32_t op, uint32_t flags, uint8_t *kinds_out);
+int32_t h2r_fresh_op_emit_advice(const h2r_ctx *ctx, uint32_t op, uint32_t flags, const void *a, const void *b, const void *n,
+                                 const void *trace, uint64_t first_off, uint64_t elem_stride, uint64_t batch,
+                                 const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream);
 uint32_t h2r_advice_rows(const h2r_ctx *ctx);
 int32_t h2r_mul_mod_emit_advice(const h2r_ctx *ctx, const void *a, const void *b, const void *n, uint32_t flags,
                                 const void *trace, uint64_t batch, const uint8_t *status, void *advice_out,

@@ -234,6 +234,16 @@ def fixed_row(kind, w, L, carry_bits, carry_sub_bits, carry_nsub, cfg):
         f["s_mul_ab"], f["sc"], f["s_const"] = 1, 1, -1
     elif kind == ROW_ISZERO_RA:
         f["s_mul_ab"] = 1
+    elif kind == 15:      # ROW_SELECT: cond*a - cond*b + b - res = 0 on [cond, a, cond, b, res]
+        f["s_mul_ab"], f["s_mul_cd"], f["sd"], f["se"] = 1, -1, 1, -1
+    elif kind == 16:      # ROW_NOT: c + not_c - 1 = 0
+        f["sa"], f["sb"], f["s_const"] = 1, 1, -1
+    elif kind == 17:      # ROW_ASSERT_ONE
+        f["sa"], f["s_const"] = 1, -1
+    elif kind == 18:      # ROW_CONST_BM1: assign_constant(2^w - 1)
+        f["sa"], f["s_const"] = 1, -(B - 1)
+    elif kind == 19:      # ROW_ASSERT_ZERO
+        f["sa"] = 1
     elif kind >= ROW_RANGE_LIMB:
         carry = kind >= ROW_RANGE_CARRY
         rr = kind - (ROW_RANGE_CARRY if carry else ROW_RANGE_LIMB)
@@ -312,3 +322,201 @@ def table_column(cfg, theta, usable_rows, P):
     t = compress(cfg.table(), theta, P)
     assert len(t) <= usable_rows
     return t + [0] * (usable_rows - len(t))
+
+
+# ---- the Fresh-integer family as advice rows: add, sub, add_mod, sub_mod, is_zero, comparisons, assert_in_field --
+ROW_SELECT, ROW_NOT, ROW_ASSERT_ONE, ROW_CONST_BM1, ROW_ASSERT_ZERO = 15, 16, 17, 18, 19
+
+
+def fresh_image(p, name, a, b, n, stream, P, assert_one=False):
+    """Rows of one Fresh-integer op of BigIntChip (big_integer/chip.rs: add :245-297, sub :310-373, add_mod :452-481, sub_mod
+    :495-528, is_zero :754-767, is_equal_fresh :780-805, is_less_than :908-919, is_less_than_or_equal :932-941, is_greater_than
+    :954-963, is_greater_than_or_equal :976-985, is_in_field :998-1006; helpers max_value :138-154, sub_unchecked :1286-1318),
+    every cell, built from the ORACLE's stream of the op (values in its order) and the operands' limbs.  assert_one: the op's bit
+    is then given to main_gate.assert_one (assert_in_field :1150-1158 and the other assert_* of instructions.rs).
+    maingate rows as in mul_mod_image, plus select(a, b, cond) = [cond, a, cond, b, res] (cond*a - cond*b + b - res = 0),
+    not(c) = [c, 1 - c], assert_one(a) = [a], assert_zero(a) = [a]."""
+    w, L = p.w, p.L
+    LB = p.LB
+    SB = LB + 8
+    B = 1 << w
+    st = bytes(stream)
+    pos = 0
+
+    def take(nb):
+        nonlocal pos
+        v = int.from_bytes(st[pos:pos + nb], "little")
+        pos += nb
+        return v
+
+    im = Image(w, L, P)
+
+    def const(c):
+        im.row({0: ROW_CONST0, 1: ROW_CONST1, B: ROW_CONST_B, B - 1: ROW_CONST_BM1}[c], c)
+
+    def range_limb():
+        v = take(LB)
+        subs = [take(1) for _ in range(8)]
+        im.range_assign(v, subs, w // 8, ROW_RANGE_LIMB)
+        return v
+
+    def add(a, b):                                          # chip.rs:245-297
+        max_n = max(len(a), len(b))
+        const(0)                                            # zero_value :254
+        a = list(a) + [0] * (max_n - len(a))
+        b = list(b) + [0] * (max_n - len(b))
+        const(B)                                            # limb_max_val :267
+        carry, out = 0, []
+        for i in range(max_n):
+            a_b = take(SB); im.row(ROW_ADD, a[i], b[i], a_b)             # :272
+            assert a_b == a[i] + b[i]
+            s = take(SB); im.row(ROW_ADD, a_b, carry, s)                 # :273
+            c = range_limb()                                             # :279-280
+            new_carry = range_limb()                                     # :281-282
+            cac = take(SB); im.row(ROW_MUL_ADD, new_carry, B, c, cac)    # :283
+            im.row(ROW_ASSERT_EQ, s, cac)                                # :285
+            out.append(c)
+            carry = new_carry
+        return out + [carry]                                # :290
+
+    def is_zero_rows(a_val, flag):                          # main_gate.is_zero: assign_bit(r), [a, a', r], [r, a]
+        r = 1 if a_val % P == 0 else 0
+        assert r == flag
+        inv = 1 if r else pow(a_val % P, P - 2, P)
+        im.assign_bit(r)
+        im.row(ROW_ISZERO_INV, a_val, inv, r)
+        im.row(ROW_ISZERO_RA, r, a_val)
+
+    def is_equal_fresh(a, b):                               # chip.rs:780-805
+        n1, n2 = len(a), len(b)
+        larger = n1 > n2
+        max_n = n1 if larger else n2
+        im.assign_bit(1)
+        eq = 1
+        for i in range(max_n):
+            flag, run = take(1), take(1)
+            if larger and i >= n2:
+                is_zero_rows(a[i], flag)
+            elif (not larger) and i >= n1:
+                is_zero_rows(b[i], flag)
+            else:
+                im.is_equal(a[i], b[i], flag)
+            im.row(ROW_MUL, eq, flag, run)                  # and
+            assert run == (eq & flag)
+            eq = run
+        return eq
+
+    def is_zero(a):                                         # chip.rs:754-767
+        im.assign_bit(1)
+        bit = 1
+        for v in a:
+            flag, run = take(1), take(1)
+            is_zero_rows(v, flag)
+            im.row(ROW_MUL, bit, flag, run)
+            bit = run
+        return bit
+
+    def sub_unchecked(a, b):                                # chip.rs:1286-1318
+        c = [range_limb() for _ in range(len(a))]
+        added = add(b, c)
+        ok = is_equal_fresh(a, added)
+        im.row(ROW_ASSERT_ONE, ok)                          # assert_equal_fresh -> assert_one
+        return c
+
+    def sub(a, b):                                          # chip.rs:310-373
+        n2 = len(b)
+        max_int = [B - 1] * n2
+        for _ in range(n2):
+            const(B - 1)                                    # max_value :138-154
+        inflated_a = add(a, max_int)
+        inflated_subed = sub_unchecked(inflated_a, b)
+        im.assign_bit(1)                                    # one :326
+        not_ov, ov = take(1), take(1)
+        im.is_equal(inflated_subed[n2], 1, not_ov)          # :330
+        im.row(ROW_NOT, not_ov, ov)                         # :331
+        const(0)                                            # zero_value :343
+        sel_l, sel_r = [], []
+        for i in range(len(inflated_subed)):                # :345-357
+            v = take(LB)
+            bsrc = 0 if i >= n2 else b[i]
+            im.row(ROW_SELECT, not_ov, inflated_subed[i], not_ov, bsrc, v)
+            sel_l.append(v)
+        for i in range(max(len(a), n2)):                    # :358-367
+            v = take(LB)
+            if i >= len(a):
+                aa, bb = max_int[i], 0
+            elif i >= n2:
+                aa, bb = 0, a[i]
+            else:
+                aa, bb = max_int[i], a[i]
+            im.row(ROW_SELECT, not_ov, aa, not_ov, bb, v)
+            sel_r.append(v)
+        real = sub_unchecked(sel_l, sel_r)
+        return real, ov
+
+    def is_less_than(a, b):                                 # chip.rs:908-919
+        _, is_ov = sub(a, b)                                # is_less_than_or_equal :932-941
+        is_eq = is_equal_fresh(a, b)                        # :916
+        is_not_eq, lt = take(1), take(1)
+        im.row(ROW_NOT, is_eq, is_not_eq)                   # :917
+        im.row(ROW_MUL, is_ov, is_not_eq, lt)               # :918
+        return lt
+
+    def select_mod(x, y, cond, n_limbs):                    # the tail of add_mod :466-478 / sub_mod :512-525
+        const(0)                                            # zero_value
+        num = max(len(x), len(y))
+        x = list(x) + [0] * (num - len(x))
+        y = list(y) + [0] * (num - len(y))
+        res = []
+        for i in range(num):
+            v = take(LB)
+            im.row(ROW_SELECT, cond, x[i], cond, y[i], v)
+            res.append(v)
+        for i in range(n_limbs, num):
+            im.row(ROW_ASSERT_ZERO, res[i])
+        return res[:n_limbs]
+
+    a = [int(v) for v in a]
+    b = [int(v) for v in b] if b is not None else None
+    n = [int(v) for v in n] if n is not None else None
+    bit = None
+    if name == "add":
+        add(a, b)
+    elif name == "sub":
+        sub(a, b)
+    elif name == "add_mod":                                 # chip.rs:452-481
+        added = add(a, b)
+        subed, ov = sub(added, n)
+        select_mod(added, subed, ov, len(n))
+    elif name == "sub_mod":                                 # chip.rs:495-528
+        subed1, ov1 = sub(a, b)
+        subed2, ov2 = sub(n, subed1)
+        im.row(ROW_ASSERT_ZERO, ov2)                        # :510
+        select_mod(subed2, subed1, ov1, len(n))
+    elif name == "is_zero":
+        bit = is_zero(a)
+    elif name == "is_equal_fresh":
+        bit = is_equal_fresh(a, b)
+    elif name in ("is_less_than", "is_in_field"):
+        bit = is_less_than(a, b)
+    elif name == "is_less_than_or_equal":
+        bit = sub(a, b)[1]
+    elif name == "is_greater_than":                         # chip.rs:954-963
+        le = sub(a, b)[1]
+        bit = take(1)
+        im.row(ROW_NOT, le, bit)
+    elif name == "is_greater_than_or_equal":                # chip.rs:976-985
+        lt = is_less_than(a, b)
+        bit = take(1)
+        im.row(ROW_NOT, lt, bit)
+    else:
+        raise ValueError(name)
+    if assert_one:
+        im.row(ROW_ASSERT_ONE, bit)                         # e.g. assert_in_field :1157
+    assert pos == len(st), (pos, len(st))
+    return im
+
+
+def in_field_image(p, x, n, stream, P):
+    """assert_in_field(x, n) = is_less_than(x, n) + assert_one (big_integer/chip.rs:1150-1158)."""
+    return fresh_image(p, "is_in_field", x, n, None, stream, P, assert_one=True)

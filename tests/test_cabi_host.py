@@ -307,3 +307,45 @@ def test_lookup_config_and_table_image():
     assert lib().h2r_lookup_config_custom(lens, tags, 5, ctypes.byref(cfg)) == _lib.H2R_E_SHAPE
     tags[3] = 8; tags[2] = 8                        # two bit lengths with one tag
     assert lib().h2r_lookup_config_custom(lens, tags, 5, ctypes.byref(cfg)) == _lib.H2R_E_SHAPE
+
+
+def test_fresh_op_row_programs_follow_the_restated_op_order():
+    """The row program of every Fresh-integer op (h2r_fresh_op_row_kinds: the host's symbolic walk of the reference's control flow,
+    no GPU needed) has the row kinds -- hence the op order and row count -- of the independent Python restatement built from the
+    ORACLE's stream (tests/advice_ref.fresh_image), and the fixed rows of the new kinds (select / not / assert_one / assert_zero /
+    the 2^w - 1 constant) agree with the Python table in the ctx's field."""
+    import random
+    import advice_ref as AR
+    from oracle_lib import FRESH_OPS, fresh_op
+    for (w, L) in [(64, 32), (32, 16), (64, 4)]:
+        ctx = host_ctx(w, L)
+        o = Oracle(w, L)
+        rng = random.Random(w * L)
+        n = rng.getrandbits(w * L) | (1 << (w * L - 1)) | 1
+        a, b = rng.randrange(n), rng.randrange(n)
+        P = AR.FIELD_MODULI["bn254_fr"] if hasattr(AR, "FIELD_MODULI") else 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+        for k, name in enumerate(FRESH_OPS):
+            rc, ov, of, st = fresh_op(o, name, o.limbs(a), o.limbs(b), o.limbs(n))
+            assert rc == 0
+            for assert_one in (False, True):
+                fl = _lib.H2R_ADVICE_ASSERT_ONE if assert_one else 0
+                rows = int(lib().h2r_fresh_op_advice_rows(ctx, k, fl))
+                if assert_one and name in ("add", "sub", "add_mod", "sub_mod"):
+                    assert rows == 0          # no bit to assert
+                    continue
+                im = AR.fresh_image(o.p, name, o.limbs(a), None if name == "is_zero" else o.limbs(b),
+                                    o.limbs(n) if name in ("add_mod", "sub_mod") else None, st, P, assert_one=assert_one)
+                kinds = np.zeros(rows, dtype=np.uint8)
+                assert lib().h2r_fresh_op_row_kinds(ctx, k, fl, kinds.ctypes.data) == 0
+                assert kinds.tolist() == im.kinds, (w, L, name, assert_one)
+        if (w, L) == (64, 32):
+            assert int(lib().h2r_fresh_op_advice_rows(ctx, FRESH_OPS.index("is_in_field"), _lib.H2R_ADVICE_ASSERT_ONE)) == 1532
+        cfg = AR.LookupConfig(AR.range_lens(w, L))
+        for kind in (15, 16, 17, 18, 19):
+            fr = _lib.H2RFixedRow()
+            assert lib().h2r_advice_fixed_row(ctx, None, kind, ctypes.byref(fr)) == 0
+            ref = AR.fixed_row(kind, w, L, o.p.carry_bits, o.p.carry_sub_bits, o.p.carry_nsub, cfg)
+            got = fr.as_dict()
+            assert {nm: v % P for nm, v in ref.items() if nm in AR.FIXED_NAMES} == {nm: got[nm] for nm in AR.FIXED_NAMES}, kind
+        assert int(lib().h2r_fresh_op_advice_rows(ctx, 99, 0)) == 0
+        lib().h2r_ctx_destroy(ctx)

@@ -1907,3 +1907,105 @@ def test_pipelined_variable_exponent_calls(H, B, NL, EB):
         got = H.AssignedInteger(out, 64).to_big_uint()
         assert all(got[i] == pow(X[i], sum(v << (EB * j) for j, v in enumerate(E[i])), N[i]) for i in range(B)), k
     pipe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,L,field", [(64, 32, "bn254_fr"), (32, 16, "pasta_fq"), (64, 16, "bn254_fq")])
+def test_fresh_family_advice_rows(H, w, L, field):
+    """h2r_fresh_op_emit_advice: the rows of EVERY op of the Fresh-integer family (and of the asserting variants) -- every cell
+    -- equal the image built in Python from the ORACLE's stream of the op (tests/advice_ref.fresh_image), incl. the a == b,
+    a + b == n and zero corner cases and main_gate.is_zero's inverse witnesses; and the GPU's cells satisfy the main-gate
+    equation with the fixed rows the C ABI reports, with every range row's cells in the lookup table."""
+    import ctypes
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref as R
+    import advice_ref as AR
+    from halo2_rsa_amd import _lib
+    from halo2_rsa_amd._lib import lib
+    from oracle_lib import FRESH_OPS, fresh_op
+    chip = H.BigIntChip(w, w * L, field=field)
+    o = Oracle(w, L)
+    P = R.FIELD_MODULI[field]
+    rng = random.Random(11 * w + L)
+    n = rand_modulus(rng, w * L)
+    A = [rng.randrange(n) for _ in range(6)]
+    B = [rng.randrange(n) for _ in range(6)]
+    B[0] = n - A[0]
+    B[1] = A[1]
+    A[2] = 0
+    A[3], B[3] = 1, 0
+    if A[4] > B[4]:
+        A[4], B[4] = B[4], A[4]          # a < b: the asserting variants of the comparisons hold for this element
+    a_dev, b_dev, n_dev = chip.assign_integer(A), chip.assign_integer(B), chip.assign_integer([n])
+    cfg = AR.LookupConfig(AR.range_lens(w, L, rsa=(w == 64)))
+    la = H.LookupArgument(chip, rsa_chip=(w == 64))
+    table = set(cfg.table())
+    fixed = {}
+    for name in FRESH_OPS:
+        fn = getattr(chip, name)
+        res = fn(a_dev, b_dev, n_dev) if name in ("add_mod", "sub_mod") else (fn(a_dev) if name == "is_zero" else fn(a_dev, b_dev))
+        variants = [False] if name in ("add", "sub", "add_mod", "sub_mod") else [False, True]
+        for assert_one in variants:
+            img = res.emit_advice(assert_one=assert_one)
+            torch.cuda.synchronize()
+            kinds = chip.fresh_op_row_kinds(res.op, assert_one)
+            host = img.cpu().numpy()
+            st = res.status.cpu().tolist()
+            for i in range(6):
+                rc, ov, of, ost = fresh_op(o, name, o.limbs(A[i]), o.limbs(B[i]), o.limbs(n))
+                if rc != 0:
+                    assert st[i] != 0
+                    continue
+                im = AR.fresh_image(o.p, name, o.limbs(A[i]), None if name == "is_zero" else o.limbs(B[i]),
+                                    o.limbs(n) if name in ("add_mod", "sub_mod") else None, ost, P, assert_one=assert_one)
+                assert im.kinds == kinds.tolist()
+                want = AR.image_bytes(im)
+                got = host[i].reshape(len(kinds), 160)
+                if not np.array_equal(got, want):
+                    bad = np.argwhere(got != want)[0]
+                    pytest.fail("%s w=%d L=%d elem %d: row %d (kind %d) cell %d differs" % (name, w, L, i, int(bad[0]), int(kinds[int(bad[0])]), int(bad[1]) // 32))
+                if i in (1, 4) and not assert_one:   # gate equation + lookup membership on the GPU's own cells
+                    rows = len(kinds)
+                    cells = [[int.from_bytes(got[r, 32 * c:32 * c + 32].tobytes(), "little") for c in range(5)] for r in range(rows)]
+                    for r in range(rows):
+                        k = int(kinds[r])
+                        if k not in fixed:
+                            fr = _lib.H2RFixedRow()
+                            assert lib().h2r_advice_fixed_row(chip._ctx, ctypes.byref(la.cfg), k, ctypes.byref(fr)) == 0
+                            fixed[k] = fr.as_dict()
+                        f = fixed[k]
+                        assert AR.gate_residual(cells[r], cells[r + 1][4] if r + 1 < rows else 0, f, P) == 0, (name, r, k)
+                        if f["tag_composition"]:
+                            assert all((f["tag_composition"], cells[r][c]) in table for c in range(4)), (name, r)
+
+
+@pytest.mark.gpu
+def test_assert_in_field_advice_rows_of_a_modpow_call(H):
+    """The in_field_trace of modpow_public_key as advice rows (InFieldTrace.emit_advice -> h2r_fresh_op_emit_advice with
+    H2R_ADVICE_ASSERT_ONE, shared modulus): equal to advice_ref.in_field_image of the oracle's assert_in_field stream; 1,532 rows for
+    RSA-2048; the last row ([lt], assert_one) is the only unsatisfied one for x >= n."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref as R
+    import advice_ref as AR
+    chip = H.BigIntChip(64, 2048)
+    o = Oracle(64, 32)
+    P = R.FIELD_MODULI["bn254_fr"]
+    rng = random.Random(2048)
+    n = rand_modulus(rng, 2048)
+    X = [rng.randrange(n) for _ in range(5)] + [n + 5]
+    x_dev, n_dev = chip.assign_integer(X), chip.assign_integer([n])
+    res = chip.pow_mod_fixed_exp(x_dev, 65537, n_dev, check_in_field=True)     # = RSAChip::modpow_public_key (src/chip.rs:99-114)
+    img = res.in_field.emit_advice(x_dev, n_dev)
+    torch.cuda.synchronize()
+    assert res.status.cpu().tolist()[:5] == [0] * 5 and int(res.status[5]) != 0
+    host = img.cpu().numpy()
+    assert img.shape[1] == 1532 * 160
+    for i in range(6):
+        rc, lt, st = o.assert_in_field(o.limbs(X[i]), o.limbs(n))
+        im = AR.in_field_image(o.p, o.limbs(X[i]), o.limbs(n), st, P)
+        assert np.array_equal(host[i].reshape(1532, 160), AR.image_bytes(im)), i
+        assert int.from_bytes(host[i].reshape(1532, 160)[-1, :32].tobytes(), "little") == (1 if X[i] < n else 0)

@@ -74,3 +74,56 @@ def test_permuted_columns_invariants(theta_kind):
         a_perm, s_perm = AR.permute_expression_pair(A, tcol)
         assert sorted(A) == a_perm and sorted(tcol) == sorted(s_perm)
         assert all(a_perm[i] == s_perm[i] or (i and a_perm[i] == a_perm[i - 1]) for i in range(usable))
+
+
+@pytest.mark.parametrize("w,L,field,case", [(64, 32, "bn254_fr", "lt"), (32, 16, "pasta_fp", "lt"), (64, 4, "bn254_fq", "ge"), (64, 8, "pasta_fq", "eq")])
+def test_in_field_image_satisfies_the_main_gate(w, L, field, case):
+    """The rows of assert_in_field(x, n) restated in tests/advice_ref.in_field_image from the oracle's in-field stream: every row
+    fulfils the main-gate equation (incl. select / not / assert_one), every range row's cells are table rows; x >= n makes the
+    final assert_one row -- and only that row -- unsatisfied."""
+    P = FIELDS[field]
+    o = Oracle(w, L)
+    rng = random.Random(7 * w + L)
+    bits = w * L
+    n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+    x = {"lt": rng.randrange(n), "ge": min(n + 3, (1 << bits) - 1), "eq": n}[case]
+    rc, lt, st = o.assert_in_field(o.limbs(x), o.limbs(n))
+    assert lt == (1 if x < n else 0)
+    im = AR.in_field_image(o.p, [int(v) for v in o.limbs(x)], [int(v) for v in o.limbs(n)], st, P)
+    cfg = AR.LookupConfig(AR.range_lens(w, L))
+    table = set(cfg.table())
+    bad = []
+    for ri, (cells, kind) in enumerate(zip(im.rows, im.kinds)):
+        f = AR.fixed_row(kind, w, L, o.p.carry_bits, o.p.carry_sub_bits, o.p.carry_nsub, cfg)
+        e_next = im.rows[ri + 1][4] if ri + 1 < len(im.rows) else 0
+        if AR.gate_residual(cells, e_next, f, P) != 0:
+            bad.append(ri)
+        if f["tag_composition"]:
+            assert all((f["tag_composition"], cells[c]) in table for c in range(4)), ri
+    assert bad == ([] if x < n else [len(im.rows) - 1]), bad[:5]
+    assert sum(1 for k in im.kinds if k == AR.ROW_RANGE_LIMB) == 8 * L + 6      # the range assigns h2r_lookup_hist_fresh_op counts
+
+
+@pytest.mark.parametrize("w,L,field", [(64, 8, "bn254_fr"), (32, 16, "pasta_fp")])
+def test_fresh_family_images_satisfy_the_main_gate(w, L, field):
+    """Every op of the Fresh-integer family restated as rows (tests/advice_ref.fresh_image) from the oracle's stream of the op."""
+    from oracle_lib import FRESH_OPS, fresh_op
+    P = FIELDS[field]
+    o = Oracle(w, L)
+    rng = random.Random(w + L)
+    bits = w * L
+    n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+    cfg = AR.LookupConfig(AR.range_lens(w, L))
+    fixed = {}
+    for a, b in [(rng.randrange(n), rng.randrange(n)), (5, 5), (0, n - 1), (n - 1, 0)]:
+        for name in FRESH_OPS:
+            rc, ov, of, st = fresh_op(o, name, o.limbs(a), o.limbs(b), o.limbs(n))
+            if rc != 0:
+                continue
+            im = AR.fresh_image(o.p, name, o.limbs(a), None if name == "is_zero" else o.limbs(b),
+                                o.limbs(n) if name in ("add_mod", "sub_mod") else None, st, P)
+            for ri, (cells, kind) in enumerate(zip(im.rows, im.kinds)):
+                if kind not in fixed:
+                    fixed[kind] = AR.fixed_row(kind, w, L, o.p.carry_bits, o.p.carry_sub_bits, o.p.carry_nsub, cfg)
+                e_next = im.rows[ri + 1][4] if ri + 1 < len(im.rows) else 0
+                assert AR.gate_residual(cells, e_next, fixed[kind], P) == 0, (name, ri, kind)
