@@ -91,6 +91,7 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_pow_trace_flatten_ex", "h2r_trace_emit_stream", "h2r_pow_trace_emit_stream", "h2r_mul_mod_trace_check", "h2r_pow_trace_check",
            "h2r_advice_rows", "h2r_mul_mod_emit_advice", "h2r_pow_trace_emit_advice", "h2r_pow_advice_rows", "h2r_advice_row_kinds",
            "h2r_advice_fixed_row", "h2r_fresh_op_advice_rows", "h2r_fresh_op_row_kinds", "h2r_fresh_op_emit_advice",
+           "h2r_verify_advice_rows", "h2r_verify_row_kinds", "h2r_verify_emit_advice",
            "h2r_lookup_config_default", "h2r_lookup_config_custom", "h2r_lookup_table_image", "h2r_lookup_hist_records",
            "h2r_lookup_hist_values", "h2r_lookup_hist_fresh_op", "h2r_lookup_workspace_bytes", "h2r_lookup_permuted_columns", "h2r_field_eval",
            "h2r_dist_unique_id", "h2r_dist_init", "h2r_dist_destroy", "h2r_dist_rank", "h2r_dist_world", "h2r_dist_shard_range",
@@ -212,6 +213,10 @@ def lib():
     L.h2r_fresh_op_advice_rows.restype = u32
     L.h2r_fresh_op_row_kinds.argtypes = [vp, u32, u32, vp]
     L.h2r_fresh_op_emit_advice.argtypes = [vp, u32, u32, vp, vp, vp, vp, u64, u64, u64, vp, vp, u64, vp]
+    L.h2r_verify_advice_rows.argtypes = [vp, ctypes.POINTER(H2RVerifyLayout), vp]
+    L.h2r_verify_advice_rows.restype = u64
+    L.h2r_verify_row_kinds.argtypes = [vp, ctypes.POINTER(H2RVerifyLayout), vp]
+    L.h2r_verify_emit_advice.argtypes = [vp, ctypes.POINTER(H2RVerifyLayout), vp, vp, vp, vp, u32, vp, vp, u64, vp, vp, u64, vp]
     L.h2r_mul_mod_emit_advice.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp, vp, u64, vp]
     L.h2r_pow_trace_emit_advice.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, u32, vp, u64, vp, u64, vp, vp, u64, vp]
     L.h2r_mul_mod_trace_check.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp, vp, vp, vp]

@@ -171,7 +171,7 @@ struct h2r_ctx {
     mutable std::mutex pipe_mu;
     mutable h2r_pipeline *pipe = nullptr;
     // row programs of the Fresh-op advice images (h2r_rowprog.hpp), built on first use; key = op | assert_one << 8
-    struct RowProg { std::vector<RpRow> host; RpRow *dev = nullptr; };
+    struct RowProg { std::vector<RpRow> host; RpRow *dev = nullptr; std::vector<u32> inv_rows; u32 *inv_dev = nullptr; };
     mutable std::mutex prog_mu;
     mutable std::map<u32, RowProg> progs;
 };
@@ -593,7 +593,7 @@ void h2r_ctx_destroy(h2r_ctx *ctx) {
         DeviceGuard dg(ctx->params.device);
         if (ctx->const_rec_dev) (void)hipFree(ctx->const_rec_dev);
         if (ctx->advice_desc_dev) (void)hipFree(ctx->advice_desc_dev);
-        for (auto &kv : ctx->progs) if (kv.second.dev) (void)hipFree(kv.second.dev);
+        for (auto &kv : ctx->progs) { if (kv.second.dev) (void)hipFree(kv.second.dev); if (kv.second.inv_dev) (void)hipFree(kv.second.inv_dev); }
         if (ctx->pipe) h2r_pipeline_destroy(ctx->pipe);
     }
     delete ctx;
@@ -2047,6 +2047,7 @@ int32_t h2r_field_eval(const h2r_ctx *ctx, uint32_t op, const uint64_t a[4], con
         case 1: r = fe_sub(x, y, ctx->fc.p); break;
         case 2: r = fe_mul(x, y, ctx->fc); break;
         case 3: if (fe_is_zero(x)) return H2R_E_SHAPE; r = fe_inv(x, ctx->fc); break;
+        case 4: if (fe_is_zero(x)) return H2R_E_SHAPE; r = fe_inv_fermat(x, ctx->fc); break;
         default: return H2R_E_UNSUPPORTED;
     }
     for (int k = 0; k < 4; ++k) out[k] = r.v[k];
@@ -2350,6 +2351,20 @@ int32_t h2r_advice_fixed_row(const h2r_ctx *ctx, const h2r_lookup_config *cfg, u
         case ROWK_ASSERT_ONE: put(out->sa, one, false); put(out->s_const, one, true); break;
         case ROWK_CONST_BM1: put(out->sa, one, false); put(out->s_const, fe_sub(Bv, one, p), true); break;
         case ROWK_ASSERT_ZERO: put(out->sa, one, false); break;
+        case ROWK_CONST_EM: case ROWK_CONST_EM + 1: case ROWK_CONST_EM + 2: case ROWK_CONST_EM + 3: case ROWK_CONST_EM + 4: case ROWK_CONST_EM + 5:
+            put(out->sa, one, false); put(out->s_const, fe_small(em_const(kind - ROWK_CONST_EM)), true); break;
+        case ROWK_RANGE_U32: case ROWK_RANGE_U32 + 1: {   // RangeChip::assign(value, 4, 32): eight 4-bit sub-limbs, two rows
+            const bool last = kind == ROWK_RANGE_U32 + 1;
+            uint64_t (*sel[4])[4] = {&out->sa, &out->sb, &out->sc, &out->sd};
+            for (u32 q = 0; q < 4; ++q) put(*sel[q], pow2((last ? 7 - q : q) * 4), false);
+            put(out->se, one, true);
+            if (!last) put(out->se_next, one, false);
+            if (cfg) {
+                for (u32 i = 0; i < cfg->n_lens; ++i) if (cfg->bit_len[i] == 4) out->tag_composition = cfg->tag[i];
+                if (!out->tag_composition) return H2R_E_SHAPE;   // a table without RSAChip's 4-bit range (src/chip.rs:252)
+            }
+            break;
+        }
         default: {
             const bool carry = kind >= ROWK_RANGE_CARRY;
             const u32 rr = kind - (carry ? ROWK_RANGE_CARRY : ROWK_RANGE_LIMB);
@@ -2378,27 +2393,57 @@ int32_t h2r_advice_fixed_row(const h2r_ctx *ctx, const h2r_lookup_config *cfg, u
 
 // ---- advice rows of the Fresh-integer family (h2r_rowprog.hpp) ---------------------------------------------------------------
 namespace {
-// the row program of (op, assert_one): built by the symbolic walk on first use, uploaded when the ctx has a device
-int32_t fresh_row_prog(const h2r_ctx *ctx, uint32_t op, uint32_t flags, const h2r_ctx::RowProg **out) {
-    if (op >= FRESH_OP_COUNT) return H2R_E_UNSUPPORTED;
+// a row program, built by the symbolic walk on first use and uploaded when the ctx has a device
+constexpr u32 kProgEm = 0x1000, kProgVerifyPre = 0x1001;
+int32_t row_prog(const h2r_ctx *ctx, u32 key, const std::function<bool(RowProgBuilder &)> &build, const h2r_ctx::RowProg **out) {
     if (ctx->L + 3 > 64 * AUX_V) return H2R_E_UNSUPPORTED;
-    const bool assert_one = (flags & H2R_ADVICE_ASSERT_ONE) != 0;
-    const u32 key = op | (assert_one ? 256u : 0u);
     std::lock_guard<std::mutex> lk(ctx->prog_mu);
     auto it = ctx->progs.find(key);
     if (it == ctx->progs.end()) {
         RowProgBuilder rb(AuxGeom(ctx->L, ctx->layout.limb_width));
-        if (!rb.build(op, assert_one)) return H2R_E_UNSUPPORTED;   // assert_one on an op without a bit
+        if (!build(rb)) return H2R_E_UNSUPPORTED;
         h2r_ctx::RowProg rp;
         rp.host = std::move(rb.rows);
+        for (u32 r = 0; r < rp.host.size(); ++r) if (rp.host[r].c[1].type == RP_INV34) rp.inv_rows.push_back(r);
         if (ctx->params.device >= 0) {
             DeviceGuard dg(ctx->params.device);
             HIP_TRY(hipMalloc(reinterpret_cast<void **>(&rp.dev), rp.host.size() * sizeof(RpRow)));
             if (hipMemcpy(rp.dev, rp.host.data(), rp.host.size() * sizeof(RpRow), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(rp.dev); return H2R_E_HIP; }
+            if (!rp.inv_rows.empty()) {
+                if (hipMalloc(reinterpret_cast<void **>(&rp.inv_dev), rp.inv_rows.size() * sizeof(u32)) != hipSuccess ||
+                    hipMemcpy(rp.inv_dev, rp.inv_rows.data(), rp.inv_rows.size() * sizeof(u32), hipMemcpyHostToDevice) != hipSuccess) {
+                    (void)hipFree(rp.dev); if (rp.inv_dev) (void)hipFree(rp.inv_dev);
+                    return H2R_E_HIP;
+                }
+            }
         }
         it = ctx->progs.emplace(key, std::move(rp)).first;
     }
     *out = &it->second;
+    return H2R_OK;
+}
+int32_t fresh_row_prog(const h2r_ctx *ctx, uint32_t op, uint32_t flags, const h2r_ctx::RowProg **out) {
+    if (op >= FRESH_OP_COUNT) return H2R_E_UNSUPPORTED;
+    const bool assert_one = (flags & H2R_ADVICE_ASSERT_ONE) != 0;   // on an op without a bit: unsupported
+    return row_prog(ctx, op | (assert_one ? 256u : 0u), [&](RowProgBuilder &rb) { return rb.build(op, assert_one); }, out);
+}
+int32_t launch_row_prog(const h2r_ctx *ctx, const h2r_ctx::RowProg *rp, RowProgArgs &ra, hipStream_t st) {
+    ra.prog = rp->dev; ra.rows = (u32)rp->host.size(); ra.f = ctx->fc;
+    ra.inv_rows = rp->inv_dev; ra.n_inv = (u32)rp->inv_rows.size();
+    const u64 blocks = ra.batch * ((ra.rows + 255) / 256);
+    if (blocks == 0) return H2R_OK;
+    if (blocks >= (1ull << 31)) return H2R_E_UNSUPPORTED;
+    ProfScope ps(H2R_KERNEL_EMIT, st, true);
+    if (ctx->layout.limb_width == 64) hipExtLaunchKernelGGL((rowprog_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, st, ps.a, ps.on ? ps.b : nullptr, 0, ra);
+    else hipExtLaunchKernelGGL((rowprog_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, ps.a, ps.on ? ps.b : nullptr, 0, ra);
+    HIP_TRY(hipGetLastError());
+    if (ra.n_inv) {   // is_zero's inverse witnesses, packed into full waves (rowprog_inv_kernel)
+        const u64 ib = (ra.batch * ra.n_inv + 255) / 256;
+        if (ib >= (1ull << 31)) return H2R_E_UNSUPPORTED;
+        if (ctx->layout.limb_width == 64) hipLaunchKernelGGL((rowprog_inv_kernel<64>), dim3((unsigned)ib), dim3(256), 0, st, ra);
+        else hipLaunchKernelGGL((rowprog_inv_kernel<32>), dim3((unsigned)ib), dim3(256), 0, st, ra);
+        HIP_TRY(hipGetLastError());
+    }
     return H2R_OK;
 }
 }  // namespace
@@ -2437,22 +2482,82 @@ int32_t h2r_fresh_op_emit_advice(const h2r_ctx *ctx, uint32_t op, uint32_t flags
     if (batch == 0) return H2R_OK;
     RowProgArgs ra;
     std::memset(&ra, 0, sizeof ra);
-    ra.prog = rp->dev; ra.rows = (u32)rows;
     ra.a = a; ra.b = b ? b : a; ra.n = n ? n : a;
     ra.a_stride = ctx->L;
     ra.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
     ra.b_stride = (!needs_n && (flags & H2R_F_SHARED_MODULUS)) ? 0 : ctx->L;   // as h2r_fresh_op_batch
     ra.trace = static_cast<const u8 *>(trace); ra.elem_stride = elem_stride; ra.first_off = first_off;
-    ra.status = status; ra.batch = batch; ra.out = static_cast<u8 *>(advice_out); ra.out_stride = out_stride; ra.f = ctx->fc;
-    const u64 blocks = batch * ((rows + 255) / 256);
-    if (blocks >= (1ull << 31)) return H2R_E_UNSUPPORTED;
+    ra.status = status; ra.batch = batch; ra.out = static_cast<u8 *>(advice_out); ra.out_stride = out_stride;
+    H2R_ON_DEVICE(ctx->params.device);
+    return launch_row_prog(ctx, rp, ra, static_cast<hipStream_t>(stream));
+}
+
+// ---- the whole verify_pkcs1v15_signature element as advice rows ------------------------------------------------------------
+namespace {
+int32_t verify_progs(const h2r_ctx *ctx, const h2r_ctx::RowProg **pre, const h2r_ctx::RowProg **inf, const h2r_ctx::RowProg **em) {
+    if (ctx->layout.limb_width != 64 || ctx->L < 8) return H2R_E_UNSUPPORTED;   // RSAChip::LIMB_WIDTH
+    int32_t rc = row_prog(ctx, kProgVerifyPre, [](RowProgBuilder &rb) { rb.build_verify_preamble(); return true; }, pre);
+    if (!rc) rc = fresh_row_prog(ctx, FRESH_IS_IN_FIELD, H2R_ADVICE_ASSERT_ONE, inf);
+    if (!rc) rc = row_prog(ctx, kProgEm, [](RowProgBuilder &rb) { rb.build_em(); return true; }, em);
+    return rc;
+}
+}  // namespace
+
+uint64_t h2r_verify_advice_rows(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint64_t section_rows[4]) {
+    if (!ctx || !vl) return 0;
+    const h2r_ctx::RowProg *pre, *inf, *em;
+    if (verify_progs(ctx, &pre, &inf, &em)) return 0;
+    const u64 r[4] = {pre->host.size(), inf->host.size(), h2r_pow_advice_rows(ctx, &vl->pow), em->host.size()};
+    if (section_rows) for (int k = 0; k < 4; ++k) section_rows[k] = r[k];
+    return r[0] + r[1] + r[2] + r[3];
+}
+
+int32_t h2r_verify_row_kinds(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint8_t *kinds_out) {
+    if (!ctx || !vl || !kinds_out) return H2R_E_NULL;
+    const h2r_ctx::RowProg *pre, *inf, *em;
+    const int32_t rc = verify_progs(ctx, &pre, &inf, &em);
+    if (rc) return rc;
+    uint8_t *k = kinds_out;
+    for (const RpRow &r : pre->host) *k++ = (uint8_t)r.kind;
+    for (const RpRow &r : inf->host) *k++ = (uint8_t)r.kind;
+    if (vl->pow.off_e_bits == UINT64_MAX) { *k++ = ROWK_CONST1; *k++ = ROWK_CONST0; }
+    const u32 rows = h2r_advice_rows(ctx), nrc = (ctx->layout.carry_nsub + 3) / 4;
+    for (u32 t = 0; t < vl->pow.num_mul_mods; ++t)
+        for (u32 r = 0; r < rows; ++r) *k++ = (uint8_t)advice_decode(r, ctx->L, nrc).kind;
+    for (const RpRow &r : em->host) *k++ = (uint8_t)r.kind;
+    return H2R_OK;
+}
+
+int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, const void *sig, const void *n, const uint64_t *hashed,
+                               const void *powed, uint32_t flags, const void *trace, const void *workspace, uint64_t batch,
+                               const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
+    if (!ctx || !vl || !sig || !n || !hashed || !powed || !trace || !workspace || !advice_out) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    const h2r_ctx::RowProg *pre, *inf, *em;
+    int32_t rc = verify_progs(ctx, &pre, &inf, &em);
+    if (rc) return rc;
+    u64 sec[4];
+    const u64 rows = h2r_verify_advice_rows(ctx, vl, sec);
+    if (out_stride < rows * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
+    if (batch == 0) return H2R_OK;
     H2R_ON_DEVICE(ctx->params.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    ProfScope ps(H2R_KERNEL_EMIT, st, true);
-    if (ctx->layout.limb_width == 64) hipExtLaunchKernelGGL((rowprog_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, st, ps.a, ps.on ? ps.b : nullptr, 0, ra);
-    else hipExtLaunchKernelGGL((rowprog_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, ps.a, ps.on ? ps.b : nullptr, 0, ra);
-    HIP_TRY(hipGetLastError());
-    return H2R_OK;
+    u8 *out = static_cast<u8 *>(advice_out);
+    RowProgArgs ra;
+    std::memset(&ra, 0, sizeof ra);
+    ra.a = sig; ra.b = n; ra.n = n; ra.a_stride = ctx->L; ra.b_stride = ra.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
+    ra.trace = static_cast<const u8 *>(trace); ra.elem_stride = vl->elem_stride; ra.first_off = vl->off_in_field;
+    ra.status = status; ra.batch = batch; ra.out_stride = out_stride;
+    ra.out = out;                                   // is_eq = assign_constant(1), src/chip.rs:137
+    if ((rc = launch_row_prog(ctx, pre, ra, st))) return rc;
+    ra.out = out + sec[0] * ADVICE_ROW_BYTES;       // assert_in_field(sig, n), :106
+    if ((rc = launch_row_prog(ctx, inf, ra, st))) return rc;
+    rc = h2r_pow_trace_emit_advice(ctx, &vl->pow, n, flags, trace, vl->elem_stride, workspace, batch, status,
+                                   out + (sec[0] + sec[1]) * ADVICE_ROW_BYTES, out_stride, stream);   // pow_mod_fixed_exp, :111
+    if (rc) return rc;
+    ra.a = powed; ra.b = hashed; ra.b_stride = 4; ra.first_off = vl->off_em;
+    ra.out = out + (sec[0] + sec[1] + sec[2]) * ADVICE_ROW_BYTES;                                      // :138-198
+    return launch_row_prog(ctx, em, ra, st);
 }
 
 // ---- in-place audit ----------------------------------------------------------------------------------------

@@ -19,7 +19,22 @@
 namespace h2r {
 
 // row kinds beyond the mul_mod image's (h2r.h H2R_ROW_*)
-enum { ROWK_SELECT = 15, ROWK_NOT = 16, ROWK_ASSERT_ONE = 17, ROWK_CONST_BM1 = 18, ROWK_ASSERT_ZERO = 19 };
+enum { ROWK_SELECT = 15, ROWK_NOT = 16, ROWK_ASSERT_ONE = 17, ROWK_CONST_BM1 = 18, ROWK_ASSERT_ZERO = 19,
+       ROWK_CONST_EM = 20,    // + j: assign_constant of the j-th constant of the encoded-message check (em_const)
+       ROWK_RANGE_U32 = 48 }; // + row of RangeChip::assign(value, 4, 32): eight 4-bit sub-limbs (src/chip.rs:170-171)
+
+// the constants RSAChip::verify_pkcs1v15_signature assigns (src/chip.rs:149-152, 169, 174, 179, 190)
+constexpr u32 EM_CONSTS = 6;
+__host__ __device__ inline u64 em_const(u32 j) {
+    switch (j) {
+        case 0: return 217300885422736416ull;    // prefix_64_1
+        case 1: return 938447882527703397ull;    // prefix_64_2
+        case 2: return 1ull << 32;               // u32_v
+        case 3: return 3158320ull;               // prefix_32
+        case 4: return 4294967295ull;            // ff_32
+        default: return 562949953421311ull;      // last_em
+    }
+}
 
 enum : u8 {
     RP_ZERO = 0, RP_ONE, RP_B /* 2^w */, RP_BM1 /* 2^w - 1 */,
@@ -28,6 +43,7 @@ enum : u8 {
     RP_DIFF01,              // cell 0 - cell 1 (field subtraction): main_gate.sub's result
     RP_DIFF34,              // operand 3 - operand 4: the value is_zero is asked about
     RP_INV34,               // its inverse, or 1 when it is zero: is_zero's witness
+    RP_CONST64,             // em_const(off)
     RP_HIDDEN = 0x80        // operand only: the cell itself is unassigned (zero)
 };
 struct RpCell { u32 off; u8 type, width; uint16_t pad; };
@@ -182,6 +198,33 @@ struct RowProgBuilder {
         for (u32 i = n_limbs; i < num; ++i) row(ROWK_ASSERT_ZERO, st(off + (u64)i * g.LB, g.LB));
     }
 
+    void range_u32(u64 ra_off) { row(ROWK_RANGE_U32 + 0, st(ra_off, 4)); row(ROWK_RANGE_U32 + 1, st(ra_off, 4)); }
+    // RSAChip::verify_pkcs1v15_signature after the modpow (src/chip.rs:138-198; 64-bit limbs): operand A = powed, B = hashed (4 limbs);
+    // region = the encoded-message region the aux role wrote (flags, the two 32-bit range assigns, the recomposed limb)
+    void build_em() {
+        const u32 L = g.L;
+        const Int A = operand(RP_IN_A, L), H = operand(RP_IN_B, 4);
+        auto K = [&](u32 j) { return mk(RP_CONST64, j); };
+        V is_eq = one();                                    // the cell of the preamble's assign_constant(1), :137
+        auto and_ = [&](V flag, V run) { row(ROWK_MUL, is_eq, flag, run); is_eq = run; };
+        for (u32 i = 0; i < 4; ++i) { is_equal(A[i], H[i], st(2 * i, 1)); and_(st(2 * i, 1), st(2 * i + 1, 1)); }   // :141-144
+        row(ROWK_CONST_EM + 0, K(0)); row(ROWK_CONST_EM + 1, K(1));                                                  // :149-152
+        is_equal(A[4], K(0), st(8, 1)); is_equal(A[5], K(1), st(9, 1));                                              // :153-154
+        and_(st(8, 1), st(10, 1)); and_(st(9, 1), st(11, 1));                                                        // :155-156
+        range_u32(12); range_u32(24);                                                                                // :170-171
+        const V low = st(12, 4), high = st(24, 4), concat = st(36, 8);
+        row(ROWK_CONST_EM + 2, K(2));                                                                                // :172
+        row(ROWK_MUL_ADD, high, K(2), low, concat);                                                                  // :173
+        row(ROWK_ASSERT_EQ, A[6], concat);                                                                           // :174
+        row(ROWK_CONST_EM + 3, K(3)); is_equal(low, K(3), st(44, 1)); and_(st(44, 1), st(45, 1));                    // :175-177
+        row(ROWK_CONST_EM + 4, K(4)); is_equal(high, K(4), st(46, 1)); and_(st(46, 1), st(47, 1));                   // :180-182
+        row(ROWK_CONST_BM1, mk(RP_BM1));                                                                             // ff_64 :183-184
+        for (u32 i = 7; i + 1 < L; ++i) { const u64 f = 48 + 2ull * (i - 7); is_equal(A[i], mk(RP_BM1), st(f, 1)); and_(st(f, 1), st(f + 1, 1)); }   // :185-188
+        const u64 f = 48 + 2ull * (L - 8);
+        row(ROWK_CONST_EM + 5, K(5)); is_equal(A[L - 1], K(5), st(f, 1)); and_(st(f, 1), st(f + 1, 1));              // :190-197
+    }
+    void build_verify_preamble() { row(ROWK_CONST1, one()); }   // is_eq = assign_constant(1), src/chip.rs:137 (before the modpow)
+
     // returns false for an unknown op
     bool build(u32 op, bool assert_one) {
         const u32 L = g.L;
@@ -218,7 +261,37 @@ struct RowProgArgs {
     const u8 *status; u64 batch;
     u8 *out; u64 out_stride;
     FieldConsts f;
+    const u32 *inv_rows; u32 n_inv;     // the rows with an RP_INV34 cell (rowprog_inv_kernel fills those cells)
 };
+
+// the value a cell descriptor names, for element `elem` whose region starts at `reg`
+template <int LW>
+__device__ __forceinline__ Fe rp_fetch(const RowProgArgs &a, const u8 *reg, u32 elem, const RpCell &c) {
+    using limb_t = typename LimbT<LW>::type;
+    Fe v = fe_zero();
+    switch (c.type & 0x7f) {
+        case RP_ONE: v.v[0] = 1; break;
+        case RP_B: if (LW == 64) v.v[1] = 1; else v.v[0] = 1ull << 32; break;
+        case RP_BM1: v.v[0] = LW == 64 ? ~0ull : 0xffffffffull; break;
+        case RP_STREAM: {
+            const u8 *p = reg + c.off;
+            if (c.width == 1) v.v[0] = p[0];
+            else {   // 4, 8, 12 or 16 bytes on a 4-byte boundary
+                const u32 *p4 = reinterpret_cast<const u32 *>(p);
+                const u32 nw = c.width / 4;
+                const u32 w0 = p4[0], w1 = nw > 1 ? p4[1] : 0, w2 = nw > 2 ? p4[2] : 0, w3 = nw > 3 ? p4[3] : 0;
+                v.v[0] = ((u64)w1 << 32) | w0; v.v[1] = ((u64)w3 << 32) | w2;
+            }
+            break;
+        }
+        case RP_CONST64: v.v[0] = em_const(c.off); break;
+        case RP_IN_A: v.v[0] = reinterpret_cast<const limb_t *>(a.a)[(u64)elem * a.a_stride + c.off]; break;
+        case RP_IN_B: v.v[0] = reinterpret_cast<const limb_t *>(a.b)[(u64)elem * a.b_stride + c.off]; break;
+        case RP_IN_N: v.v[0] = reinterpret_cast<const limb_t *>(a.n)[(u64)elem * a.n_stride + c.off]; break;
+        default: break;
+    }
+    return v;
+}
 
 template <int LW>
 __global__ __launch_bounds__(256) void rowprog_kernel(RowProgArgs a) {
@@ -237,39 +310,18 @@ __global__ __launch_bounds__(256) void rowprog_kernel(RowProgArgs a) {
         union { uint4 q[3]; RpRow row; } u;
         u.q[0] = pr[0]; u.q[1] = pr[1]; u.q[2] = pr[2];
         const RpRow &rw = u.row;
-        auto fetch = [&](const RpCell &c) -> Fe {
-            Fe v = fe_zero();
-            switch (c.type & 0x7f) {
-                case RP_ONE: v.v[0] = 1; break;
-                case RP_B: if (LW == 64) v.v[1] = 1; else v.v[0] = 1ull << 32; break;
-                case RP_BM1: v.v[0] = LW == 64 ? ~0ull : 0xffffffffull; break;
-                case RP_STREAM: {
-                    const u8 *p = reg + c.off;
-                    if (c.width == 1) v.v[0] = p[0];
-                    else {   // 4, 8, 12 or 16 bytes on a 4-byte boundary
-                        const u32 *p4 = reinterpret_cast<const u32 *>(p);
-                        const u32 nw = c.width / 4;
-                        const u32 w0 = p4[0], w1 = nw > 1 ? p4[1] : 0, w2 = nw > 2 ? p4[2] : 0, w3 = nw > 3 ? p4[3] : 0;
-                        v.v[0] = ((u64)w1 << 32) | w0; v.v[1] = ((u64)w3 << 32) | w2;
-                    }
-                    break;
-                }
-                case RP_IN_A: v.v[0] = reinterpret_cast<const limb_t *>(a.a)[(u64)elem * a.a_stride + c.off]; break;
-                case RP_IN_B: v.v[0] = reinterpret_cast<const limb_t *>(a.b)[(u64)elem * a.b_stride + c.off]; break;
-                case RP_IN_N: v.v[0] = reinterpret_cast<const limb_t *>(a.n)[(u64)elem * a.n_stride + c.off]; break;
-                default: break;
-            }
-            return v;
-        };
+        auto fetch = [&](const RpCell &c) -> Fe { return rp_fetch<LW>(a, reg, elem, c); };
         Fe c[5];
-        if (rw.kind >= ROWK_RANGE_LIMB && rw.kind < ROWK_RANGE_LIMB + 2) {
-            // main_gate.decompose of a limb: four sub-limb bytes per row (the last row reversed), column e = what remains
+        const bool u32r = rw.kind >= ROWK_RANGE_U32 && rw.kind < ROWK_RANGE_U32 + 2;
+        if ((rw.kind >= ROWK_RANGE_LIMB && rw.kind < ROWK_RANGE_LIMB + 2) || u32r) {
+            // main_gate.decompose of a limb (eight w/8-bit sub-limbs) or of a 32-bit half (eight 4-bit ones): four sub-limb
+            // bytes per row (the last row reversed), column e = what remains
             const u8 *p = reg + rw.c[0].off;
-            const u32 *ps = reinterpret_cast<const u32 *>(p + LW / 8);
+            const u32 *ps = reinterpret_cast<const u32 *>(p + (u32r ? 4 : LW / 8));
             const u64 subs = ((u64)ps[1] << 32) | ps[0];
-            constexpr u32 sb = LW / 8;
+            const u32 sb = u32r ? 4 : LW / 8;
             u64 rem = 0;
-            const u32 k0 = rw.kind == ROWK_RANGE_LIMB ? 0u : 4u;
+            const u32 k0 = (rw.kind & 1) ? 4u : 0u;
 #pragma unroll
             for (u32 k = 0; k < 8; ++k) if (k >= k0) rem += ((subs >> (8 * k)) & 0xff) << (k * sb);
             for (int q = 0; q < 5; ++q) c[q] = fe_zero();
@@ -285,7 +337,7 @@ __global__ __launch_bounds__(256) void rowprog_kernel(RowProgArgs a) {
             Fe d34 = fe_zero(), inv = fe_zero();
             if (need34) {
                 d34 = fe_sub(c[3], c[4], a.f.p);
-                if (need_inv) { inv.v[0] = 1; if (!fe_eq(d34, fe_zero())) inv = fe_inv(d34, a.f); }
+                if (need_inv) inv.v[0] = 1;   // d = 0: is_zero's witness is 1; d != 0: rowprog_inv_kernel overwrites the cell with 1/d
             }
             const Fe d01 = fe_sub(c[0], c[1], a.f.p);
 #pragma unroll
@@ -310,6 +362,38 @@ __global__ __launch_bounds__(256) void rowprog_kernel(RowProgArgs a) {
     for (u32 k = tid; k < n_rows * (ADVICE_ROW_BYTES / 16); k += 256) {
         const uint4 v = stage[k];
         st16(dst + 16ull * k, ((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z);
+    }
+}
+
+
+// main_gate.is_zero's inverse witnesses, in their own launch: a Fermat inversion is ~380 Montgomery products (~0.5 ms for a
+// wave), and inside rowprog_kernel the few rows that need one (d != 0: e.g. the 32 limb comparisons of is_equal_fresh(x, n) in an
+// assert_in_field) are spread thinly over waves whose other lanes wait -- 5.1 ms for 1,024 RSA-2048 elements.  Here one thread
+// looks at one (element, is_zero row); the rows with d != 0 are packed into a dense list in LDS, so the waves that invert are
+// full, and every cell 1 = 1/d goes out as two 16-byte stores behind the image rowprog_kernel wrote.
+template <int LW>
+__global__ __launch_bounds__(256) void rowprog_inv_kernel(RowProgArgs a) {
+    __shared__ u32 cnt;
+    __shared__ u32 l_elem[256], l_row[256];
+    __shared__ Fe l_d[256];
+    const u32 tid = threadIdx.x;
+    if (tid == 0) cnt = 0;
+    __syncthreads();
+    const u64 g = (u64)blockIdx.x * 256 + tid;
+    if (g < a.batch * a.n_inv) {
+        const u32 elem = (u32)(g / a.n_inv), r = a.inv_rows[g - (u64)elem * a.n_inv];
+        if (!(a.status && a.status[elem])) {
+            const RpRow *rw = a.prog + r;
+            const u8 *reg = a.trace + (u64)elem * a.elem_stride + a.first_off;
+            const Fe d = fe_sub(rp_fetch<LW>(a, reg, elem, rw->c[3]), rp_fetch<LW>(a, reg, elem, rw->c[4]), a.f.p);
+            if (!fe_is_zero(d)) { const u32 slot = atomicAdd(&cnt, 1u); l_elem[slot] = elem; l_row[slot] = r; l_d[slot] = d; }
+        }
+    }
+    __syncthreads();
+    if (tid < cnt) {
+        const Fe iv = fe_inv(l_d[tid], a.f);
+        u8 *p = a.out + (u64)l_elem[tid] * a.out_stride + (u64)l_row[tid] * ADVICE_ROW_BYTES + 32;
+        st16(p, iv.v[0], iv.v[1]); st16(p + 16, iv.v[2], iv.v[3]);
     }
 }
 

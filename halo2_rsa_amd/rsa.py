@@ -100,10 +100,11 @@ class RSAChip:
         powed = torch.empty((batch, chip.num_limbs), dtype=torch.int64, device=dev)
         is_valid = torch.zeros(batch, dtype=torch.uint8, device=dev)
         status = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        ws = torch.empty(chip.workspace_bytes(batch, vl.pow.num_mul_mods), dtype=torch.uint8, device=dev)   # kept: emit_advice reads it
         check(lib().h2r_verify_pkcs1v15_batch(chip._ctx, sig.data_ptr(), n.data_ptr(), eb, len(eb), hashed.data_ptr(), batch,
                                               chip._flags(n, batch), trace.data_ptr(), powed.data_ptr(), is_valid.data_ptr(),
-                                              status.data_ptr(), None, chip._stream()), "verify_pkcs1v15_signature")
-        return VerifyResult(is_valid, AssignedInteger(powed, 64), status, trace, vl, chip)
+                                              status.data_ptr(), ws.data_ptr(), chip._stream()), "verify_pkcs1v15_signature")
+        return VerifyResult(is_valid, AssignedInteger(powed, 64), status, trace, vl, chip, ws, (sig, n, hashed))
 
 
 # ---- byte-level plumbing of the reference's example / verifier (BASELINE config 1) -------------------------------------
@@ -159,6 +160,33 @@ class VerifyResult:
     trace: "torch.Tensor"
     layout: H2RVerifyLayout
     chip: BigIntChip
+    workspace: "torch.Tensor" = None
+    inputs: tuple = None         # (sig, n, hashed)
+
+    def advice_sections(self):
+        """Row counts of the image's four sections: is_eq seed, assert_in_field, pow_mod_fixed_exp, encoded-message check."""
+        sec = (ctypes.c_uint64 * 4)()
+        total = int(lib().h2r_verify_advice_rows(self.chip._ctx, ctypes.byref(self.layout), sec))
+        return total, [int(v) for v in sec]
+
+    def row_kinds(self) -> "np.ndarray":
+        total, _ = self.advice_sections()
+        kinds = np.zeros(total, dtype=np.uint8)
+        check(lib().h2r_verify_row_kinds(self.chip._ctx, ctypes.byref(self.layout), kinds.ctypes.data), "h2r_verify_row_kinds")
+        return kinds
+
+    def emit_advice(self) -> "torch.Tensor":
+        """Every cell of the whole verify_pkcs1v15_signature element as rows of the main gate's five advice columns
+        (h2r_verify_emit_advice): uint8 [batch, rows * 160] in HBM."""
+        sig, n, hashed = self.inputs
+        batch = sig.batch
+        total, _ = self.advice_sections()
+        out = torch.empty((batch, total * 160), dtype=torch.uint8, device=self.trace.device)
+        check(lib().h2r_verify_emit_advice(self.chip._ctx, ctypes.byref(self.layout), sig.data_ptr(), n.data_ptr(), hashed.data_ptr(),
+                                           self.powed.data_ptr(), self.chip._flags(n, batch), self.trace.data_ptr(),
+                                           self.workspace.data_ptr(), batch, self.status.data_ptr(), out.data_ptr(), out.shape[1],
+                                           self.chip._stream()), "h2r_verify_emit_advice")
+        return out
 
     def flatten(self, elem: int) -> "np.ndarray":
         s = self.layout.elem_stride

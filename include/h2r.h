@@ -540,7 +540,8 @@ int32_t h2r_lookup_permuted_columns(const h2r_ctx *ctx, const h2r_lookup_config 
                                     uint64_t num_elems, uint32_t usable_rows, uint32_t arg_mask, void *a_perm_out,
                                     void *s_perm_out, uint64_t out_elem_stride, uint8_t *status, void *workspace,
                                     h2r_stream_t stream);
-/* Arithmetic of the ctx's field on canonical elements (host): op 0 = a + b, 1 = a - b, 2 = a * b, 3 = a^-1 (b ignored; a != 0).
+/* Arithmetic of the ctx's field on canonical elements (host): op 0 = a + b, 1 = a - b, 2 = a * b, 3 = a^-1 (b ignored; a != 0;
+ * binary extended Euclid), 4 = a^(p-2) (Fermat: the cross-check of 3).
  * The same code the kernels run (lookup compression, main_gate.is_zero's inverse witness). */
 int32_t h2r_field_eval(const h2r_ctx *ctx, uint32_t op, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
 
@@ -605,6 +606,8 @@ enum { H2R_ROW_NOP = 0, H2R_ROW_CONST0, H2R_ROW_CONST1, H2R_ROW_CONST_B /* assig
        H2R_ROW_ASSERT_EQ /* [a,b] */, H2R_ROW_ISZERO_INV /* is_zero: [a, 1/a or 1, r], a*a' + r - 1 = 0 */, H2R_ROW_ISZERO_RA /* [r, a], r*a = 0 */,
        H2R_ROW_SELECT /* select(a,b,cond): [cond,a,cond,b,res], cond*a - cond*b + b - res = 0 */, H2R_ROW_NOT /* [c, 1-c] */,
        H2R_ROW_ASSERT_ONE /* [a], a - 1 = 0 */, H2R_ROW_CONST_BM1 /* assign_constant(2^w - 1) */, H2R_ROW_ASSERT_ZERO /* [a] */,
+       H2R_ROW_CONST_EM /* + j, j < 6: the encoded-message constants prefix_64_1, prefix_64_2, 2^32, prefix_32, ff_32, last_em */,
+       H2R_ROW_RANGE_U32 = 48 /* + row of RangeChip::assign(value, 4, 32): eight 4-bit sub-limbs (src/chip.rs:170-171) */,
        H2R_ROW_RANGE_LIMB = 32, H2R_ROW_RANGE_CARRY = 40 };
 typedef struct h2r_fixed_row {
     uint64_t sa[4], sb[4], sc[4], sd[4], se[4], s_mul_ab[4], s_mul_cd[4], se_next[4], s_const[4];
@@ -629,6 +632,19 @@ uint64_t h2r_pow_advice_rows(const h2r_ctx *ctx, const h2r_pow_layout *pl);
 #define H2R_ADVICE_ASSERT_ONE 0x100u
 uint32_t h2r_fresh_op_advice_rows(const h2r_ctx *ctx, uint32_t op, uint32_t flags);
 int32_t h2r_fresh_op_row_kinds(const h2r_ctx *ctx, uint32_t op, uint32_t flags, uint8_t *kinds_out);
+/* One whole RSAChip::verify_pkcs1v15_signature element (src/chip.rs:128-199, after the SHA step) as advice rows, in the
+ * reference's op order: [is_eq = assign_constant(1) :137] [assert_in_field(sig, n) :106] [pow_mod_fixed_exp :111 -- the rows of
+ * h2r_pow_trace_emit_advice] [the encoded-message check :138-198: is_equal / and per limb, the constants (H2R_ROW_CONST_EM + j),
+ * the two RangeChip::assign(half, 4, 32) of limb 6 (H2R_ROW_RANGE_U32 + row), their mul_add recomposition and assert_equal].
+ * section_rows (nullable): the four sections' row counts (1, 1,532, 75,489, 178 for RSA-2048 with e = 65537).
+ * sig, n, hashed, flags, trace, workspace: what h2r_verify_pkcs1v15_batch / h2r_pipeline_verify_pkcs1v15 were given (a caller
+ * workspace is required: it holds every mul_mod's operands); powed: their powed_out.  Elements with a nonzero status are skipped. */
+uint64_t h2r_verify_advice_rows(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint64_t section_rows[4]);
+int32_t h2r_verify_row_kinds(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint8_t *kinds_out);
+int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, const void *sig, const void *n,
+                               const uint64_t *hashed, const void *powed, uint32_t flags, const void *trace,
+                               const void *workspace, uint64_t batch, const uint8_t *status, void *advice_out,
+                               uint64_t out_stride, h2r_stream_t stream);
 int32_t h2r_fresh_op_emit_advice(const h2r_ctx *ctx, uint32_t op, uint32_t flags, const void *a, const void *b, const void *n,
                                  const void *trace, uint64_t first_off, uint64_t elem_stride, uint64_t batch,
                                  const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream);

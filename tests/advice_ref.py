@@ -244,6 +244,16 @@ def fixed_row(kind, w, L, carry_bits, carry_sub_bits, carry_nsub, cfg):
         f["sa"], f["s_const"] = 1, -(B - 1)
     elif kind == 19:      # ROW_ASSERT_ZERO
         f["sa"] = 1
+    elif 20 <= kind < 26:  # ROW_CONST_EM + j
+        f["sa"], f["s_const"] = 1, -EM_CONSTS[kind - 20]
+    elif kind in (48, 49):  # ROW_RANGE_U32 + row: RangeChip::assign(value, 4, 32), eight 4-bit sub-limbs
+        last = kind == 49
+        for q, nm in enumerate(("sa", "sb", "sc", "sd")):
+            f[nm] = 1 << (4 * ((7 - q) if last else q))
+        f["se"] = -1
+        if not last:
+            f["se_next"] = 1
+        f["tag_composition"] = cfg.tag_of.get(4, 0) if cfg is not None else 0
     elif kind >= ROW_RANGE_LIMB:
         carry = kind >= ROW_RANGE_CARRY
         rr = kind - (ROW_RANGE_CARRY if carry else ROW_RANGE_LIMB)
@@ -520,3 +530,66 @@ def fresh_image(p, name, a, b, n, stream, P, assert_one=False):
 def in_field_image(p, x, n, stream, P):
     """assert_in_field(x, n) = is_less_than(x, n) + assert_one (big_integer/chip.rs:1150-1158)."""
     return fresh_image(p, "is_in_field", x, n, None, stream, P, assert_one=True)
+
+
+# ---- RSAChip::verify_pkcs1v15_signature after the modpow (src/chip.rs:138-198) as advice rows ----------------------------------------
+ROW_CONST_EM, ROW_RANGE_U32 = 20, 48
+EM_CONSTS = [217300885422736416, 938447882527703397, 1 << 32, 3158320, 4294967295, 562949953421311]
+
+
+def em_image(p, powed, hashed, stream, P):
+    """The encoded-message check of RSAChip::verify_pkcs1v15_signature (src/chip.rs:138-198, 64-bit limbs) as rows, built from the
+    ORACLE's EM stream: is_equal + and per compared limb, the assigned constants, the two RangeChip::assign(half, 4, 32) of limb 6
+    with their mul_add recomposition and assert_equal.  (is_eq's seed, assign_constant(1) :137, sits BEFORE the modpow.)"""
+    L = p.L
+    st = bytes(stream)
+    pos = 0
+
+    def take(nb):
+        nonlocal pos
+        v = int.from_bytes(st[pos:pos + nb], "little")
+        pos += nb
+        return v
+
+    im = Image(64, L, P)
+    powed = [int(v) for v in powed]
+    hashed = [int(v) for v in hashed]
+    is_eq = 1
+
+    def and_(flag, run):
+        nonlocal is_eq
+        im.row(ROW_MUL, is_eq, flag, run)
+        assert run == (is_eq & flag)
+        is_eq = run
+
+    for i in range(4):                                       # :141-144
+        f, r = take(1), take(1)
+        im.is_equal(powed[i], hashed[i], f)
+        and_(f, r)
+    im.row(ROW_CONST_EM + 0, EM_CONSTS[0]); im.row(ROW_CONST_EM + 1, EM_CONSTS[1])     # :149-152
+    f1, f2, r1, r2 = take(1), take(1), take(1), take(1)
+    im.is_equal(powed[4], EM_CONSTS[0], f1); im.is_equal(powed[5], EM_CONSTS[1], f2)   # :153-154
+    and_(f1, r1); and_(f2, r2)                               # :155-156
+    halves = []
+    for _ in range(2):                                       # :170-171
+        v = take(4)
+        subs = [take(1) for _ in range(8)]
+        im.range_assign(v, subs, 4, ROW_RANGE_U32)
+        halves.append(v)
+    low, high = halves
+    concat = take(8)
+    im.row(ROW_CONST_EM + 2, EM_CONSTS[2])                   # :172
+    im.row(ROW_MUL_ADD, high, EM_CONSTS[2], low, concat)     # :173
+    im.row(ROW_ASSERT_EQ, powed[6], concat)                  # :174
+    f, r = take(1), take(1)
+    im.row(ROW_CONST_EM + 3, EM_CONSTS[3]); im.is_equal(low, EM_CONSTS[3], f); and_(f, r)     # :175-177
+    f, r = take(1), take(1)
+    im.row(ROW_CONST_EM + 4, EM_CONSTS[4]); im.is_equal(high, EM_CONSTS[4], f); and_(f, r)    # :180-182
+    im.row(ROW_CONST_BM1, (1 << 64) - 1)                     # ff_64 :183-184
+    for i in range(7, L - 1):                                # :185-188
+        f, r = take(1), take(1)
+        im.is_equal(powed[i], (1 << 64) - 1, f); and_(f, r)
+    f, r = take(1), take(1)
+    im.row(ROW_CONST_EM + 5, EM_CONSTS[5]); im.is_equal(powed[L - 1], EM_CONSTS[5], f); and_(f, r)   # :190-197
+    assert pos == len(st), (pos, len(st))
+    return im, is_eq

@@ -263,7 +263,7 @@ def test_field_arithmetic_matches_python(field):
     p = H2RParams(64, 2048, _lib.FIELDS[field], -1)
     assert lib().h2r_ctx_create(ctypes.byref(p), ctypes.byref(ctx)) == 0
     rng = random.Random(hash(field) & 0xffff)
-    vals = [0, 1, 2, P - 1, P - 2, (1 << 64) - 1, 1 << 64, 1 << 128, (1 << 135) + 12345] + [rng.randrange(P) for _ in range(40)]
+    vals = [0, 1, 2, P - 1, P - 2, (1 << 64) - 1, 1 << 64, 1 << 128, (1 << 135) + 12345] + [rng.randrange(P) for _ in range(400)] + [P - (1 << k) for k in range(1, 250, 7)] + [1 << k for k in range(0, 254, 5)]
     out = (ctypes.c_uint64 * 4)()
     for i, a in enumerate(vals):
         b = vals[(7 * i + 3) % len(vals)]
@@ -273,6 +273,7 @@ def test_field_arithmetic_matches_python(field):
         if a:
             assert lib().h2r_field_eval(ctx, 3, _fe(a), None, out) == 0
             assert _int(out) == pow(a, P - 2, P) and (_int(out) * a) % P == 1
+            assert lib().h2r_field_eval(ctx, 4, _fe(a), None, out) == 0 and _int(out) == pow(a, P - 2, P)      # Fermat cross-check
     assert lib().h2r_field_eval(ctx, 3, _fe(0), None, out) == _lib.H2R_E_SHAPE        # no inverse of zero
     assert lib().h2r_field_eval(ctx, 0, _fe(P), _fe(1), out) == _lib.H2R_E_SHAPE       # canonical elements only
     lib().h2r_ctx_destroy(ctx)

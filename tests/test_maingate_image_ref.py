@@ -127,3 +127,30 @@ def test_fresh_family_images_satisfy_the_main_gate(w, L, field):
                     fixed[kind] = AR.fixed_row(kind, w, L, o.p.carry_bits, o.p.carry_sub_bits, o.p.carry_nsub, cfg)
                 e_next = im.rows[ri + 1][4] if ri + 1 < len(im.rows) else 0
                 assert AR.gate_residual(cells, e_next, fixed[kind], P) == 0, (name, ri, kind)
+
+
+def test_em_check_image_satisfies_the_main_gate():
+    """The encoded-message check of verify_pkcs1v15_signature (src/chip.rs:138-198) restated as rows (advice_ref.em_image) from
+    the oracle's EM stream, for KAT 1 (valid) and a tampered digest: every row fulfils the gate, the 4-bit sub-limbs of the two
+    32-bit range assigns are rows of RSAChip's table; the final running AND is is_valid."""
+    import json
+    import os
+    P = FIELDS["bn254_fr"]
+    o = Oracle(64, 32)
+    k = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "halo2_rsa_golden.json")))["rsa_kats"][0]
+    n, sig, hashed = int(k["n"]), int(k["sig"]), int(k["hashed"])
+    powed = o.limbs(pow(sig, 65537, n))
+    cfg = AR.LookupConfig(AR.range_lens(64, 32, rsa=True))
+    table = set(cfg.table())
+    for tamper in (0, 1):
+        h4 = o.limbs(hashed ^ tamper, 4)
+        rc, valid, st = o.pkcs1v15_em_check(powed, h4)
+        im, is_eq = AR.em_image(o.p, powed, h4, st, P)
+        assert is_eq == valid == (1 - tamper)
+        assert len(im.rows) == 178      # 33 comparisons x 5 rows, 7 constants, 4 range rows, mul_add, assert_equal
+        for ri, (cells, kind) in enumerate(zip(im.rows, im.kinds)):
+            f = AR.fixed_row(kind, 64, 32, o.p.carry_bits, o.p.carry_sub_bits, o.p.carry_nsub, cfg)
+            e_next = im.rows[ri + 1][4] if ri + 1 < len(im.rows) else 0
+            assert AR.gate_residual(cells, e_next, f, P) == 0, (ri, kind)
+            if f["tag_composition"]:
+                assert all((f["tag_composition"], cells[c]) in table for c in range(4)), ri
