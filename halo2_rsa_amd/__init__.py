@@ -8,4 +8,4 @@ from ._lib import (H2R_E_NOT_IN_FIELD, H2R_E_NOT_REDUCED, H2R_E_SHAPE, H2R_E_ZER
 from .big_integer import (AssignedInteger, BatchResult, BigIntChip, LookupArgument, Pipeline, Trace, TraceArena,  # noqa: F401
                           UnassignedInteger)
 from .rsa import (Fix, RSAChip, RSAPublicKey, RSASignature, RSASignatureVerifier, Var, hashed_msg_from_digest,  # noqa: F401
-                  signature_from_bytes_be)
+                  pack_messages, sha256_hashed_msg, signature_from_bytes_be)

@@ -92,6 +92,8 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_advice_rows", "h2r_mul_mod_emit_advice", "h2r_pow_trace_emit_advice", "h2r_pow_advice_rows", "h2r_advice_row_kinds",
            "h2r_advice_fixed_row", "h2r_fresh_op_advice_rows", "h2r_fresh_op_row_kinds", "h2r_fresh_op_emit_advice",
            "h2r_verify_advice_rows", "h2r_verify_row_kinds", "h2r_verify_emit_advice",
+           "h2r_sha256_hashed_msg_batch", "h2r_signature_verifier_batch", "h2r_hashed_msg_advice_rows", "h2r_hashed_msg_row_kinds",
+           "h2r_hashed_msg_emit_advice",
            "h2r_lookup_config_default", "h2r_lookup_config_custom", "h2r_lookup_table_image", "h2r_lookup_hist_records",
            "h2r_lookup_hist_values", "h2r_lookup_hist_fresh_op", "h2r_lookup_workspace_bytes", "h2r_lookup_permuted_columns", "h2r_field_eval",
            "h2r_dist_unique_id", "h2r_dist_init", "h2r_dist_destroy", "h2r_dist_rank", "h2r_dist_world", "h2r_dist_shard_range",
@@ -99,7 +101,8 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_profile_enable", "h2r_profile_read", "h2r_status_str",
            "h2r_last_hip_error"]
 H2R_ADVICE_ASSERT_ONE = 0x100
-KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST, KERNEL_AUX, KERNEL_EMIT, KERNEL_STEP, KERNEL_LOOKUP = 0, 1, 2, 3, 4, 5, 6
+KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST, KERNEL_AUX, KERNEL_EMIT, KERNEL_STEP, KERNEL_LOOKUP, KERNEL_SHA256 = 0, 1, 2, 3, 4, 5, 6, 7
+H2R_HASHED_MSG_STREAM_BYTES = 288
 H2R_STREAM_FIELD_AB = 1
 FRESH_OPS = ["add", "sub", "add_mod", "sub_mod", "is_zero", "is_equal_fresh", "is_less_than", "is_less_than_or_equal",
              "is_greater_than", "is_greater_than_or_equal", "is_in_field"]
@@ -217,6 +220,13 @@ def lib():
     L.h2r_verify_advice_rows.restype = u64
     L.h2r_verify_row_kinds.argtypes = [vp, ctypes.POINTER(H2RVerifyLayout), vp]
     L.h2r_verify_emit_advice.argtypes = [vp, ctypes.POINTER(H2RVerifyLayout), vp, vp, vp, vp, u32, vp, vp, u64, vp, vp, u64, vp]
+    L.h2r_sha256_hashed_msg_batch.argtypes = [vp, vp, vp, u64, u64, vp, vp, vp, u64, vp]
+    L.h2r_signature_verifier_batch.argtypes = [vp, vp, vp, u64, vp, vp, ctypes.c_char_p, ctypes.c_size_t, u64, u32, vp, vp, u64, vp, vp, vp,
+                                               vp, vp, vp, vp]
+    L.h2r_hashed_msg_advice_rows.argtypes = [vp]
+    L.h2r_hashed_msg_advice_rows.restype = u32
+    L.h2r_hashed_msg_row_kinds.argtypes = [vp, vp]
+    L.h2r_hashed_msg_emit_advice.argtypes = [vp, vp, u64, u64, vp, vp, u64, vp]
     L.h2r_mul_mod_emit_advice.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp, vp, u64, vp]
     L.h2r_pow_trace_emit_advice.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, u32, vp, u64, vp, u64, vp, vp, u64, vp]
     L.h2r_mul_mod_trace_check.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp, vp, vp, vp]

@@ -21,6 +21,7 @@
 #include "h2r_lookup.hpp"
 #include "h2r_muled.hpp"
 #include "h2r_rowprog.hpp"
+#include "h2r_sha256.hpp"
 
 using namespace h2r;
 
@@ -798,6 +799,40 @@ int32_t h2r_verify_trace_flatten(const h2r_ctx *ctx, const h2r_verify_layout *vl
     std::memcpy(o, e + vl->off_em, vl->em_stream_bytes); o += vl->em_stream_bytes;
     if ((u64)(o - static_cast<u8 *>(stream_out)) != vl->stream_bytes) return H2R_E_SHAPE;
     return H2R_OK;
+}
+
+// ---- the caller of the path: RSASignatureVerifier::verify_pkcs1v15_signature (src/lib.rs:183-246) ---------------------
+// SHA-256 of every element's message, the reversed digest packed into the four hashed-message limbs (:213-239), and -- in
+// h2r_signature_verifier_batch -- RSAChip::verify_pkcs1v15_signature on them, all in stream order on the caller's stream.
+int32_t h2r_sha256_hashed_msg_batch(const h2r_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, uint64_t fixed_len, uint64_t batch,
+                                    uint8_t *digest_out, uint64_t *hashed_out, void *hm_trace, uint64_t hm_stride, h2r_stream_t stream) {
+    if (!ctx || (!msgs && (msg_off || fixed_len))) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    if (hm_trace && hm_stride == 0) hm_stride = HM_REGION;
+    if ((reinterpret_cast<u64>(digest_out) | reinterpret_cast<u64>(hashed_out) | reinterpret_cast<u64>(hm_trace) | hm_stride) & 15) return H2R_E_SHAPE;
+    if (hm_trace && hm_stride < HM_REGION) return H2R_E_SHAPE;
+    if (batch == 0) return H2R_OK;
+    if (batch >= (1ull << 37)) return H2R_E_UNSUPPORTED;
+    H2R_ON_DEVICE(ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Sha256Args sa;
+    sa.msgs = msgs; sa.off = msg_off; sa.fixed_len = fixed_len; sa.batch = batch;
+    sa.digest = digest_out; sa.hashed = hashed_out; sa.region = static_cast<u8 *>(hm_trace); sa.region_stride = hm_stride;
+    ProfScope ps(H2R_KERNEL_SHA256, st, true);
+    hipExtLaunchKernelGGL(sha256_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, ps.a, ps.on ? ps.b : nullptr, 0, sa);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
+
+int32_t h2r_signature_verifier_batch(const h2r_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, uint64_t fixed_len, const void *sig,
+                                     const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch, uint32_t flags, void *trace,
+                                     void *hm_trace, uint64_t hm_stride, uint8_t *digest_out, uint64_t *hashed_out, void *powed_out,
+                                     uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+    if (!hashed_out) return H2R_E_NULL;
+    if (ctx && (ctx->layout.limb_width != 64 || ctx->L < 9)) return H2R_E_SHAPE;   // before any launch: RSAChip::LIMB_WIDTH
+    const int32_t rc = h2r_sha256_hashed_msg_batch(ctx, msgs, msg_off, fixed_len, batch, digest_out, hashed_out, hm_trace, hm_stride, stream);
+    if (rc) return rc;
+    return h2r_verify_pkcs1v15_batch(ctx, sig, n, e_le, e_len, hashed_out, batch, flags, trace, powed_out, is_valid_out, status, workspace, stream);
 }
 
 struct h2r_pipeline {
@@ -2353,6 +2388,9 @@ int32_t h2r_advice_fixed_row(const h2r_ctx *ctx, const h2r_lookup_config *cfg, u
         case ROWK_ASSERT_ZERO: put(out->sa, one, false); break;
         case ROWK_CONST_EM: case ROWK_CONST_EM + 1: case ROWK_CONST_EM + 2: case ROWK_CONST_EM + 3: case ROWK_CONST_EM + 4: case ROWK_CONST_EM + 5:
             put(out->sa, one, false); put(out->s_const, fe_small(em_const(kind - ROWK_CONST_EM)), true); break;
+        case ROWK_CONST_COEFF8: case ROWK_CONST_COEFF8 + 1: case ROWK_CONST_COEFF8 + 2: case ROWK_CONST_COEFF8 + 3:
+        case ROWK_CONST_COEFF8 + 4: case ROWK_CONST_COEFF8 + 5: case ROWK_CONST_COEFF8 + 6: case ROWK_CONST_COEFF8 + 7:
+            put(out->sa, one, false); put(out->s_const, pow2(8 * (kind - ROWK_CONST_COEFF8)), true); break;
         case ROWK_RANGE_U32: case ROWK_RANGE_U32 + 1: {   // RangeChip::assign(value, 4, 32): eight 4-bit sub-limbs, two rows
             const bool last = kind == ROWK_RANGE_U32 + 1;
             uint64_t (*sel[4])[4] = {&out->sa, &out->sb, &out->sc, &out->sd};
@@ -2558,6 +2596,49 @@ int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, 
     ra.a = powed; ra.b = hashed; ra.b_stride = 4; ra.first_off = vl->off_em;
     ra.out = out + (sec[0] + sec[1] + sec[2]) * ADVICE_ROW_BYTES;                                      // :138-198
     return launch_row_prog(ctx, em, ra, st);
+}
+
+// ---- the hashed-message limbs of RSASignatureVerifier as advice rows (src/lib.rs:225-239) ---------------------------------
+namespace {
+constexpr u32 kProgHashedMsg = 0x1002;
+int32_t hashed_msg_prog(const h2r_ctx *ctx, const h2r_ctx::RowProg **out) {
+    if (ctx->layout.limb_width != 64) return H2R_E_UNSUPPORTED;   // RSAChip::LIMB_WIDTH (limb_bytes = 8, src/lib.rs:215)
+    return row_prog(ctx, kProgHashedMsg, [](RowProgBuilder &rb) { rb.build_hashed_msg(); return true; }, out);
+}
+}  // namespace
+
+uint32_t h2r_hashed_msg_advice_rows(const h2r_ctx *ctx) {
+    const h2r_ctx::RowProg *rp = nullptr;
+    if (!ctx || hashed_msg_prog(ctx, &rp)) return 0;
+    return (uint32_t)rp->host.size();
+}
+
+int32_t h2r_hashed_msg_row_kinds(const h2r_ctx *ctx, uint8_t *kinds_out) {
+    if (!ctx || !kinds_out) return H2R_E_NULL;
+    const h2r_ctx::RowProg *rp = nullptr;
+    const int32_t rc = hashed_msg_prog(ctx, &rp);
+    if (rc) return rc;
+    for (size_t r = 0; r < rp->host.size(); ++r) kinds_out[r] = (uint8_t)rp->host[r].kind;
+    return H2R_OK;
+}
+
+int32_t h2r_hashed_msg_emit_advice(const h2r_ctx *ctx, const void *hm_trace, uint64_t hm_stride, uint64_t batch, const uint8_t *status,
+                                   void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
+    if (!ctx || !hm_trace || !advice_out) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    const h2r_ctx::RowProg *rp = nullptr;
+    const int32_t rc = hashed_msg_prog(ctx, &rp);
+    if (rc) return rc;
+    if (hm_stride == 0) hm_stride = HM_REGION;
+    if (out_stride < rp->host.size() * ADVICE_ROW_BYTES || (hm_stride & 15) || hm_stride < HM_REGION) return H2R_E_SHAPE;
+    if (batch == 0) return H2R_OK;
+    RowProgArgs ra;
+    std::memset(&ra, 0, sizeof ra);
+    ra.a = ra.b = ra.n = hm_trace;   // no operand cells in this program
+    ra.trace = static_cast<const u8 *>(hm_trace); ra.elem_stride = hm_stride; ra.first_off = 0;
+    ra.status = status; ra.batch = batch; ra.out = static_cast<u8 *>(advice_out); ra.out_stride = out_stride;
+    H2R_ON_DEVICE(ctx->params.device);
+    return launch_row_prog(ctx, rp, ra, static_cast<hipStream_t>(stream));
 }
 
 // ---- in-place audit ----------------------------------------------------------------------------------------

@@ -21,7 +21,8 @@ namespace h2r {
 // row kinds beyond the mul_mod image's (h2r.h H2R_ROW_*)
 enum { ROWK_SELECT = 15, ROWK_NOT = 16, ROWK_ASSERT_ONE = 17, ROWK_CONST_BM1 = 18, ROWK_ASSERT_ZERO = 19,
        ROWK_CONST_EM = 20,    // + j: assign_constant of the j-th constant of the encoded-message check (em_const)
-       ROWK_RANGE_U32 = 48 }; // + row of RangeChip::assign(value, 4, 32): eight 4-bit sub-limbs (src/chip.rs:170-171)
+       ROWK_RANGE_U32 = 48,   // + row of RangeChip::assign(value, 4, 32): eight 4-bit sub-limbs (src/chip.rs:170-171)
+       ROWK_CONST_COEFF8 = 56 }; // + j: assign_constant(2^(8j)), the byte coefficients of the hashed-message limbs (src/lib.rs:228-229)
 
 // the constants RSAChip::verify_pkcs1v15_signature assigns (src/chip.rs:149-152, 169, 174, 179, 190)
 constexpr u32 EM_CONSTS = 6;
@@ -44,6 +45,7 @@ enum : u8 {
     RP_DIFF34,              // operand 3 - operand 4: the value is_zero is asked about
     RP_INV34,               // its inverse, or 1 when it is zero: is_zero's witness
     RP_CONST64,             // em_const(off)
+    RP_POW2,                // 2^off, off < 64
     RP_HIDDEN = 0x80        // operand only: the cell itself is unassigned (zero)
 };
 struct RpCell { u32 off; u8 type, width; uint16_t pad; };
@@ -223,6 +225,20 @@ struct RowProgBuilder {
         const u64 f = 48 + 2ull * (L - 8);
         row(ROWK_CONST_EM + 5, K(5)); is_equal(A[L - 1], K(5), st(f, 1)); and_(st(f, 1), st(f + 1, 1));              // :190-197
     }
+    // RSASignatureVerifier::verify_pkcs1v15_signature, src/lib.rs:225-239: the four hashed-message limbs composed from the 32
+    // reversed digest bytes; region = [32 byte cells][32 running limb values, 8 bytes each] (sha256_kernel, h2r_sha256.hpp)
+    void build_hashed_msg() {
+        for (u32 i = 0; i < 4; ++i) {
+            row(ROWK_CONST0);                                                        // limb_val = assign_constant(0) :226
+            V limb = zero();
+            for (u32 j = 0; j < 8; ++j) {
+                const V coeff = mk(RP_POW2, 8 * j), nv = st(32 + 8ull * (8 * i + j), 8);
+                row(ROWK_CONST_COEFF8 + j, coeff);                                   // :228-229
+                row(ROWK_MUL_ADD, coeff, st(8 * i + j, 1), limb, nv);                // :230-235
+                limb = nv;
+            }
+        }
+    }
     void build_verify_preamble() { row(ROWK_CONST1, one()); }   // is_eq = assign_constant(1), src/chip.rs:137 (before the modpow)
 
     // returns false for an unknown op
@@ -285,6 +301,7 @@ __device__ __forceinline__ Fe rp_fetch(const RowProgArgs &a, const u8 *reg, u32 
             break;
         }
         case RP_CONST64: v.v[0] = em_const(c.off); break;
+        case RP_POW2: v.v[0] = 1ull << c.off; break;
         case RP_IN_A: v.v[0] = reinterpret_cast<const limb_t *>(a.a)[(u64)elem * a.a_stride + c.off]; break;
         case RP_IN_B: v.v[0] = reinterpret_cast<const limb_t *>(a.b)[(u64)elem * a.b_stride + c.off]; break;
         case RP_IN_N: v.v[0] = reinterpret_cast<const limb_t *>(a.n)[(u64)elem * a.n_stride + c.off]; break;

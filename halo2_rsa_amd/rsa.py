@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 import torch
 
-from ._lib import H2RVerifyLayout, check, lib
+from ._lib import H2R_HASHED_MSG_STREAM_BYTES, H2RVerifyLayout, check, lib
 from .big_integer import AssignedInteger, BatchResult, BigIntChip, UnassignedInteger, _e_bytes
 
 
@@ -133,23 +133,75 @@ def hashed_msg_from_digest(digest) -> UnassignedInteger:
     return UnassignedInteger(out)
 
 
-class RSASignatureVerifier:
-    """src/lib.rs:149-246: SHA-256 of the message, then RSAChip::verify_pkcs1v15_signature.  The SHA-256 chip is a
-    third-party circuit outside the accelerated path; the digest is computed on the host here and only its
-    packing into the verifier's operand follows the reference."""
+def pack_messages(msgs, device):
+    """Ragged message bytes for the device: (uint8 buffer, int64 offsets [batch + 1]) -- element e's message is
+    buffer[offsets[e]:offsets[e + 1]].  Host-side packing of the caller's byte strings only; no hashing happens here."""
+    msgs = [bytes(m) for m in msgs]
+    off = np.zeros(len(msgs) + 1, dtype=np.int64)
+    np.cumsum([len(m) for m in msgs], out=off[1:])
+    buf = np.frombuffer(b"".join(msgs) or b"\x00", dtype=np.uint8).copy()
+    return torch.from_numpy(buf).to(device), torch.from_numpy(off).to(device)
 
-    def __init__(self, rsa_chip: "RSAChip"):
+
+class RSASignatureVerifier:
+    """src/lib.rs:149-246: SHA-256 of the message, the reversed digest packed into the hashed-message limbs, then
+    RSAChip::verify_pkcs1v15_signature -- all on the device (h2r_signature_verifier_batch).  The SHA-256 chip's own circuit
+    cells (third-party Table16 region) are outside the accelerated path; its digest VALUES and the limb composition rows of
+    the verifier's region (:225-239) are produced.  sha256_max_byte_size mirrors the chip's configured capacity
+    (Sha256Config::new(..., max_byte_size), src/lib.rs:321): a longer message is refused as the reference's circuit would."""
+
+    def __init__(self, rsa_chip: "RSAChip", sha256_max_byte_size: int = None):
         self.rsa_chip = rsa_chip
+        self.sha256_max_byte_size = sha256_max_byte_size
 
     def verify_pkcs1v15_signature(self, public_key: RSAPublicKey, msg, signature: RSASignature) -> "VerifyResult":
-        """msg: one message (bytes, signed by every element) or one message per element."""
-        import hashlib
-        chip = self.rsa_chip.bigint_chip()
-        sig = chip.assign_integer(signature.c)
-        msgs = [msg] * sig.batch if isinstance(msg, (bytes, bytearray)) else list(msg)
-        hashed = hashed_msg_from_digest([hashlib.sha256(bytes(m)).digest() for m in msgs])
-        hashed_dev = AssignedInteger(torch.from_numpy(hashed.limbs.view(np.int64)).to(sig.limbs_dev.device).contiguous(), 64)
-        return self.rsa_chip.verify_pkcs1v15_signature(public_key, hashed_dev, RSASignature(sig))
+        """msg: one message (bytes, signed by every element), one message per element (list of bytes), or an already packed
+        pair (uint8 device tensor, int64 device offsets [batch + 1])."""
+        if not isinstance(public_key.e, Fix):
+            raise NotImplementedError("verify_pkcs1v15_signature batch path takes RSAPubE::Fix")
+        chip, e = self.rsa_chip.bigint_chip(), public_key.e.e
+        n, sig = chip.assign_integer(public_key.n), chip.assign_integer(signature.c)
+        batch, dev = sig.batch, sig.limbs_dev.device
+        if isinstance(msg, tuple):
+            buf, off = msg
+        else:
+            msgs = [msg] * batch if isinstance(msg, (bytes, bytearray)) else list(msg)
+            if len(msgs) != batch:
+                raise ValueError("one message per signature")
+            if self.sha256_max_byte_size is not None and any(len(m) > self.sha256_max_byte_size for m in msgs):
+                raise ValueError("message longer than the SHA-256 chip's max_byte_size")
+            buf, off = pack_messages(msgs, dev)
+        vl = H2RVerifyLayout()
+        eb = _e_bytes(e)
+        check(lib().h2r_verify_layout_fixed(chip._ctx, eb, len(eb), ctypes.byref(vl)), "h2r_verify_layout_fixed")
+        trace = torch.empty(batch * vl.elem_stride, dtype=torch.uint8, device=dev)
+        powed = torch.empty((batch, chip.num_limbs), dtype=torch.int64, device=dev)
+        is_valid = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        status = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        digest = torch.empty((batch, 32), dtype=torch.uint8, device=dev)
+        hashed = torch.empty((batch, 4), dtype=torch.int64, device=dev)
+        hm = torch.empty((batch, H2R_HASHED_MSG_STREAM_BYTES), dtype=torch.uint8, device=dev)
+        ws = torch.empty(chip.workspace_bytes(batch, vl.pow.num_mul_mods), dtype=torch.uint8, device=dev)
+        check(lib().h2r_signature_verifier_batch(chip._ctx, buf.data_ptr(), off.data_ptr(), 0, sig.data_ptr(), n.data_ptr(), eb, len(eb),
+                                                 batch, chip._flags(n, batch), trace.data_ptr(), hm.data_ptr(), hm.shape[1],
+                                                 digest.data_ptr(), hashed.data_ptr(), powed.data_ptr(), is_valid.data_ptr(),
+                                                 status.data_ptr(), ws.data_ptr(), chip._stream()), "h2r_signature_verifier_batch")
+        return VerifyResult(is_valid, AssignedInteger(powed, 64), status, trace, vl, chip, ws, (sig, n, hashed), digest, hm)
+
+
+def sha256_hashed_msg(chip: BigIntChip, msgs, want_trace: bool = True):
+    """Step 1 of the verifier alone (h2r_sha256_hashed_msg_batch): (digest uint8 [batch, 32], hashed limbs int64 [batch, 4],
+    the step's flat stream uint8 [batch, 288] or None), all on the device."""
+    dev = torch.device("cuda", chip.device)
+    buf, off = msgs if isinstance(msgs, tuple) else pack_messages(msgs, dev)
+    batch = off.numel() - 1
+    digest = torch.empty((batch, 32), dtype=torch.uint8, device=dev)
+    hashed = torch.empty((batch, 4), dtype=torch.int64, device=dev)
+    hm = torch.empty((batch, H2R_HASHED_MSG_STREAM_BYTES), dtype=torch.uint8, device=dev) if want_trace else None
+    check(lib().h2r_sha256_hashed_msg_batch(chip._ctx, buf.data_ptr(), off.data_ptr(), 0, batch, digest.data_ptr(), hashed.data_ptr(),
+                                            hm.data_ptr() if want_trace else None, H2R_HASHED_MSG_STREAM_BYTES if want_trace else 0,
+                                            chip._stream()), "h2r_sha256_hashed_msg_batch")
+    return digest, hashed, hm
 
 
 @dataclass
@@ -162,6 +214,8 @@ class VerifyResult:
     chip: BigIntChip
     workspace: "torch.Tensor" = None
     inputs: tuple = None         # (sig, n, hashed)
+    digest: "torch.Tensor" = None        # RSASignatureVerifier only: uint8 [batch, 32], the `hashed_bytes` the reference returns (src/lib.rs:243-245)
+    hashed_msg_trace: "torch.Tensor" = None   # RSASignatureVerifier only: the limb composition's flat stream, uint8 [batch, 288]
 
     def advice_sections(self):
         """Row counts of the image's four sections: is_eq seed, assert_in_field, pow_mod_fixed_exp, encoded-message check."""
@@ -175,16 +229,21 @@ class VerifyResult:
         check(lib().h2r_verify_row_kinds(self.chip._ctx, ctypes.byref(self.layout), kinds.ctypes.data), "h2r_verify_row_kinds")
         return kinds
 
-    def emit_advice(self) -> "torch.Tensor":
+    def emit_advice(self, with_hashed_msg: bool = False) -> "torch.Tensor":
         """Every cell of the whole verify_pkcs1v15_signature element as rows of the main gate's five advice columns
-        (h2r_verify_emit_advice): uint8 [batch, rows * 160] in HBM."""
+        (h2r_verify_emit_advice): uint8 [batch, rows * 160] in HBM.  with_hashed_msg (a result of RSASignatureVerifier): the
+        region of src/lib.rs:220-241 -- the hashed-message limb composition rows (h2r_hashed_msg_emit_advice) in front."""
         sig, n, hashed = self.inputs
         batch = sig.batch
         total, _ = self.advice_sections()
-        out = torch.empty((batch, total * 160), dtype=torch.uint8, device=self.trace.device)
+        pre = int(lib().h2r_hashed_msg_advice_rows(self.chip._ctx)) if with_hashed_msg else 0
+        out = torch.empty((batch, (pre + total) * 160), dtype=torch.uint8, device=self.trace.device)
+        if with_hashed_msg:
+            check(lib().h2r_hashed_msg_emit_advice(self.chip._ctx, self.hashed_msg_trace.data_ptr(), self.hashed_msg_trace.shape[1], batch,
+                                                   None, out.data_ptr(), out.shape[1], self.chip._stream()), "h2r_hashed_msg_emit_advice")
         check(lib().h2r_verify_emit_advice(self.chip._ctx, ctypes.byref(self.layout), sig.data_ptr(), n.data_ptr(), hashed.data_ptr(),
                                            self.powed.data_ptr(), self.chip._flags(n, batch), self.trace.data_ptr(),
-                                           self.workspace.data_ptr(), batch, self.status.data_ptr(), out.data_ptr(), out.shape[1],
+                                           self.workspace.data_ptr(), batch, self.status.data_ptr(), out.data_ptr() + pre * 160, out.shape[1],
                                            self.chip._stream()), "h2r_verify_emit_advice")
         return out
 

@@ -373,6 +373,39 @@ int32_t h2r_pipeline_verify_pkcs1v15(h2r_pipeline *p, const void *sig, const voi
                                      uint8_t *is_valid_out, uint8_t *status, void *workspace,
                                      h2r_stream_t stream);
 
+/* ---- the CALLER of the path: RSASignatureVerifier::verify_pkcs1v15_signature (src/lib.rs:183-246) ----------
+ * The reference hashes the signed message bytes with its SHA-256 chip (:205-209), reverses the 32 digest bytes (:210-213),
+ * composes them eight at a time into four 64-bit limbs -- limb_val = 0; limb_val = mul_add(2^(8j), hashed_bytes[8i + j], limb_val)
+ * (:225-239) -- and hands that integer to RSAChip::verify_pkcs1v15_signature (:240-241); it returns (is_valid, hashed_bytes in
+ * digest order) (:243-245).  Here, per element, on the device:
+ *   h2r_sha256_hashed_msg_batch   SHA-256 (FIPS 180-4; the values the sha2 crate / the SHA chip's digest cells hold) of message e =
+ *                                 msgs[msg_off[e], msg_off[e+1]) (msg_off: batch + 1 byte offsets in device memory; NULL: every
+ *                                 message has fixed_len bytes, message e at e * fixed_len; empty messages are fine).
+ *                                 digest_out (nullable): 32 bytes per element, digest order.  hashed_out (nullable): the 4 limbs.
+ *                                 hm_trace (nullable): the step's flat stream, H2R_HASHED_MSG_STREAM_BYTES per element every
+ *                                 hm_stride bytes (0 = packed): the 32 reversed byte cells (1 byte each), then the 32 limb_val
+ *                                 cells the mul_add chain assigns, 8 bytes little-endian each.  The constants are not streamed.
+ *                                 The SHA chip's own cells (its message schedule / compression witness: third-party Table16
+ *                                 circuit) are NOT produced.  Output pointers and hm_stride must be multiples of 16.
+ *   h2r_signature_verifier_batch  that, then h2r_verify_pkcs1v15_batch on hashed_out (required), in stream order: the whole
+ *                                 RSASignatureVerifier call from message and signature limbs to is_valid.
+ *   h2r_hashed_msg_*advice*       the limb composition as advice rows (4 x (CONST0 + 8 x (CONST_COEFF8 + j, MUL_ADD)) = 68 rows),
+ *                                 placed in front of the h2r_verify_emit_advice rows in the reference's region (:220-241). */
+#define H2R_SHA256_DIGEST_BYTES 32u
+#define H2R_HASHED_MSG_STREAM_BYTES 288u
+int32_t h2r_sha256_hashed_msg_batch(const h2r_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, uint64_t fixed_len,
+                                    uint64_t batch, uint8_t *digest_out, uint64_t *hashed_out, void *hm_trace,
+                                    uint64_t hm_stride, h2r_stream_t stream);
+int32_t h2r_signature_verifier_batch(const h2r_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, uint64_t fixed_len,
+                                     const void *sig, const void *n, const uint8_t *e_le_bytes, size_t e_len, uint64_t batch,
+                                     uint32_t flags, void *trace, void *hm_trace, uint64_t hm_stride, uint8_t *digest_out,
+                                     uint64_t *hashed_out, void *powed_out, uint8_t *is_valid_out, uint8_t *status,
+                                     void *workspace, h2r_stream_t stream);
+uint32_t h2r_hashed_msg_advice_rows(const h2r_ctx *ctx);
+int32_t h2r_hashed_msg_row_kinds(const h2r_ctx *ctx, uint8_t *kinds_out);
+int32_t h2r_hashed_msg_emit_advice(const h2r_ctx *ctx, const void *hm_trace, uint64_t hm_stride, uint64_t batch,
+                                   const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream);
+
 /* ---- the Fresh-integer family of BigIntInstructions ---------------------------
  * add (big_integer/chip.rs:245-297), sub (:310-373; flag = is_overflowed, value = |a-b|), add_mod (:452-481),
  * sub_mod (:495-528), is_zero (:754-767), is_equal_fresh (:780-805), is_less_than (:908-919),
@@ -608,6 +641,7 @@ enum { H2R_ROW_NOP = 0, H2R_ROW_CONST0, H2R_ROW_CONST1, H2R_ROW_CONST_B /* assig
        H2R_ROW_ASSERT_ONE /* [a], a - 1 = 0 */, H2R_ROW_CONST_BM1 /* assign_constant(2^w - 1) */, H2R_ROW_ASSERT_ZERO /* [a] */,
        H2R_ROW_CONST_EM /* + j, j < 6: the encoded-message constants prefix_64_1, prefix_64_2, 2^32, prefix_32, ff_32, last_em */,
        H2R_ROW_RANGE_U32 = 48 /* + row of RangeChip::assign(value, 4, 32): eight 4-bit sub-limbs (src/chip.rs:170-171) */,
+       H2R_ROW_CONST_COEFF8 = 56 /* + j, j < 8: assign_constant(2^(8j)), the byte coefficients of a hashed-message limb (src/lib.rs:228-229) */,
        H2R_ROW_RANGE_LIMB = 32, H2R_ROW_RANGE_CARRY = 40 };
 typedef struct h2r_fixed_row {
     uint64_t sa[4], sb[4], sc[4], sd[4], se[4], s_mul_ab[4], s_mul_cd[4], se_next[4], s_const[4];
@@ -683,7 +717,8 @@ int32_t h2r_pow_trace_check(const h2r_ctx *ctx, const h2r_pow_layout *pl, const 
  * and returns their durations in milliseconds, in launch order. */
 enum { H2R_KERNEL_CHAIN = 0, H2R_KERNEL_TRACE = 1, H2R_KERNEL_HIST = 2, H2R_KERNEL_AUX = 3, H2R_KERNEL_EMIT = 4,
        H2R_KERNEL_STEP = 5 /* a pipeline step as one launch: records of call k + chains of call k+1 */,
-       H2R_KERNEL_LOOKUP = 6 /* lookup_fill_kernel: the permuted columns */, H2R_KERNEL_COUNT = 7 };
+       H2R_KERNEL_LOOKUP = 6 /* lookup_fill_kernel: the permuted columns */, H2R_KERNEL_SHA256 = 7 /* sha256_kernel */,
+       H2R_KERNEL_COUNT = 8 };
 int32_t h2r_profile_enable(uint32_t capacity);
 int32_t h2r_profile_read(uint32_t kernel, float *ms_out, uint32_t max_count, uint32_t *count);
 

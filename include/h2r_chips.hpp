@@ -358,6 +358,7 @@ class BigIntChip {
     h2r_layout layout_{};
     friend class Trace;
     friend class RSAChip;
+    friend class RSASignatureVerifier;
 };
 
 inline std::vector<uint8_t> Trace::flatten(size_t elem) const {
@@ -467,6 +468,61 @@ class RSAChip {
   private:
     uint32_t bits_len_, exp_limb_bits_;
     BigIntChip bigint_;
+};
+
+// reference src/lib.rs:149-246: RSASignatureVerifier { rsa_chip, sha256_chip }.  The SHA-256 chip's own circuit is third-party and
+// outside the accelerated path; its digest values, the reversed-byte limb composition of the verifier's region (:210-239) and the
+// RSAChip verification run on the device (h2r_signature_verifier_batch).
+struct SignatureVerifyResult {
+    VerifyResult verify;                 // is_valid (:243), status, powed, trace
+    std::vector<uint8_t> hashed_bytes;   // 32 per signature, digest order: the second return value of the reference (:243-245)
+    DeviceBuffer hashed_msg;             // 4 limbs per signature (the operand of RSAChip::verify_pkcs1v15_signature)
+    DeviceBuffer hashed_msg_trace;       // H2R_HASHED_MSG_STREAM_BYTES per signature
+};
+class RSASignatureVerifier {
+  public:
+    // sha256_max_byte_size: the capacity the reference's Sha256Config is created with (src/lib.rs:321); 0 = unbounded
+    explicit RSASignatureVerifier(const RSAChip &rsa_chip, size_t sha256_max_byte_size = 0) : rsa_(rsa_chip), max_(sha256_max_byte_size) {}
+    // msgs: one message per signature (ragged; empty allowed)
+    SignatureVerifyResult verify_pkcs1v15_signature(const AssignedRSAPublicKey &pk, const std::vector<std::vector<uint8_t>> &msgs,
+                                                    const AssignedRSASignature &sig) const {
+        auto *f = std::get_if<RSAPubE::Fix>(&pk.e);
+        if (!f) throw Error(H2R_E_UNSUPPORTED, "RSASignatureVerifier::verify_pkcs1v15_signature (batch path takes RSAPubE::Fix)");
+        const BigIntChip &bi = rsa_.bigint_chip();
+        const size_t batch = sig.c.batch();
+        if (msgs.size() != batch) throw Error(H2R_E_SHAPE, "one message per signature");
+        std::vector<uint64_t> off(batch + 1, 0);
+        std::vector<uint8_t> bytes;
+        for (size_t i = 0; i < batch; ++i) {
+            if (max_ && msgs[i].size() > max_) throw Error(H2R_E_SHAPE, "message longer than the SHA-256 chip's max_byte_size");
+            bytes.insert(bytes.end(), msgs[i].begin(), msgs[i].end());
+            off[i + 1] = bytes.size();
+        }
+        DeviceBuffer dmsg(bytes.size() + 16), doff(off.size() * 8);
+        if (!bytes.empty()) dmsg.upload(bytes.data(), bytes.size());
+        doff.upload(off.data(), off.size() * 8);
+        h2r_verify_layout vl;
+        check(h2r_verify_layout_fixed(bi.ctx(), f->e_le.data(), f->e_le.size(), &vl), "h2r_verify_layout_fixed");
+        DeviceBuffer trace(batch * vl.elem_stride), powed(batch * bi.num_limbs() * 8), valid(batch), st(batch), digest(batch * 32),
+            hashed(batch * 32), hm(batch * H2R_HASHED_MSG_STREAM_BYTES);
+        check(h2r_signature_verifier_batch(bi.ctx(), static_cast<const uint8_t *>(dmsg.get()), static_cast<const uint64_t *>(doff.get()), 0,
+                                           sig.c.data(), pk.n.data(), f->e_le.data(), f->e_le.size(), batch, BigIntChip::flags(pk.n, batch),
+                                           trace.get(), hm.get(), H2R_HASHED_MSG_STREAM_BYTES, static_cast<uint8_t *>(digest.get()),
+                                           static_cast<uint64_t *>(hashed.get()), powed.get(), static_cast<uint8_t *>(valid.get()),
+                                           static_cast<uint8_t *>(st.get()), nullptr, nullptr), "h2r_signature_verifier_batch");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        SignatureVerifyResult r{VerifyResult{std::vector<uint8_t>(batch), std::vector<uint8_t>(batch),
+                                             AssignedInteger(std::move(powed), batch, bi.num_limbs()), std::move(trace), vl},
+                                std::vector<uint8_t>(batch * 32), std::move(hashed), std::move(hm)};
+        valid.download(r.verify.is_valid.data(), batch);
+        st.download(r.verify.status.data(), batch);
+        digest.download(r.hashed_bytes.data(), batch * 32);
+        return r;
+    }
+
+  private:
+    const RSAChip &rsa_;
+    size_t max_;
 };
 
 // h2r_pipeline_*: consecutive verifier batches overlap the off-circuit chain of batch k+1 with the record emission

@@ -836,3 +836,75 @@ int h2ro_pow_mod_fixed_exp_timed(const h2ro_params *p, const void *x, const void
     pthread_barrier_destroy(&start); free(th); free(jobs);
     return H2RO_OK;
 }
+
+/* -----------------------------------------------------------------------------------------------------------------
+ * The caller of the path: RSASignatureVerifier::verify_pkcs1v15_signature, src/lib.rs:183-246.
+ * Step 1 (:205-209) is SHA-256 of the message bytes.  The reference gets the digest VALUES from the third-party crates
+ * sha2 0.10.6 (tests, benches: Sha256::digest) and halo2-dynamic-sha256 (the chip's digest cells); both compute
+ * FIPS 180-4 SHA-256, restated here from the standard (section 4.1.2 functions, 4.2.2 constants, 5.1.1 padding, 5.3.3 initial
+ * hash value, 6.2.2 computation) and pinned by the standard's own example digests in tests/golden/sha256_kat.json.
+ */
+static uint32_t sha_rotr(uint32_t x, unsigned n) { return (x >> n) | (x << (32 - n)); }
+static const uint32_t SHA_K[64] = {
+    0x428a2f98u, 0x71374491u, 0xb5c0fbcfu, 0xe9b5dba5u, 0x3956c25bu, 0x59f111f1u, 0x923f82a4u, 0xab1c5ed5u, 0xd807aa98u, 0x12835b01u,
+    0x243185beu, 0x550c7dc3u, 0x72be5d74u, 0x80deb1feu, 0x9bdc06a7u, 0xc19bf174u, 0xe49b69c1u, 0xefbe4786u, 0x0fc19dc6u, 0x240ca1ccu,
+    0x2de92c6fu, 0x4a7484aau, 0x5cb0a9dcu, 0x76f988dau, 0x983e5152u, 0xa831c66du, 0xb00327c8u, 0xbf597fc7u, 0xc6e00bf3u, 0xd5a79147u,
+    0x06ca6351u, 0x14292967u, 0x27b70a85u, 0x2e1b2138u, 0x4d2c6dfcu, 0x53380d13u, 0x650a7354u, 0x766a0abbu, 0x81c2c92eu, 0x92722c85u,
+    0xa2bfe8a1u, 0xa81a664bu, 0xc24b8b70u, 0xc76c51a3u, 0xd192e819u, 0xd6990624u, 0xf40e3585u, 0x106aa070u, 0x19a4c116u, 0x1e376c08u,
+    0x2748774cu, 0x34b0bcb5u, 0x391c0cb3u, 0x4ed8aa4au, 0x5b9cca4fu, 0x682e6ff3u, 0x748f82eeu, 0x78a5636fu, 0x84c87814u, 0x8cc70208u,
+    0x90befffau, 0xa4506cebu, 0xbef9a3f7u, 0xc67178f2u};
+static void sha_block(uint32_t H[8], const uint8_t blk[64]) {
+    uint32_t W[64];
+    for (int t = 0; t < 16; ++t) W[t] = ((uint32_t)blk[4 * t] << 24) | ((uint32_t)blk[4 * t + 1] << 16) | ((uint32_t)blk[4 * t + 2] << 8) | blk[4 * t + 3];
+    for (int t = 16; t < 64; ++t) {
+        uint32_t s0 = sha_rotr(W[t - 15], 7) ^ sha_rotr(W[t - 15], 18) ^ (W[t - 15] >> 3);
+        uint32_t s1 = sha_rotr(W[t - 2], 17) ^ sha_rotr(W[t - 2], 19) ^ (W[t - 2] >> 10);
+        W[t] = s1 + W[t - 7] + s0 + W[t - 16];
+    }
+    uint32_t v[8];
+    memcpy(v, H, sizeof v);
+    for (int t = 0; t < 64; ++t) {
+        uint32_t S1 = sha_rotr(v[4], 6) ^ sha_rotr(v[4], 11) ^ sha_rotr(v[4], 25);
+        uint32_t ch = (v[4] & v[5]) ^ (~v[4] & v[6]);
+        uint32_t T1 = v[7] + S1 + ch + SHA_K[t] + W[t];
+        uint32_t S0 = sha_rotr(v[0], 2) ^ sha_rotr(v[0], 13) ^ sha_rotr(v[0], 22);
+        uint32_t mj = (v[0] & v[1]) ^ (v[0] & v[2]) ^ (v[1] & v[2]);
+        uint32_t T2 = S0 + mj;
+        v[7] = v[6]; v[6] = v[5]; v[5] = v[4]; v[4] = v[3] + T1; v[3] = v[2]; v[2] = v[1]; v[1] = v[0]; v[0] = T1 + T2;
+    }
+    for (int k = 0; k < 8; ++k) H[k] += v[k];
+}
+void h2ro_sha256(const uint8_t *msg, uint64_t len, uint8_t digest[32]) {
+    uint32_t H[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    uint64_t full = len / 64;
+    for (uint64_t b = 0; b < full; ++b) sha_block(H, msg + 64 * b);
+    uint8_t tail[128];
+    uint64_t rem = len - 64 * full;
+    memset(tail, 0, sizeof tail);
+    if (rem) memcpy(tail, msg + 64 * full, rem);
+    tail[rem] = 0x80;
+    uint64_t tl = rem + 9 <= 64 ? 64 : 128, bits = len * 8;
+    for (int k = 0; k < 8; ++k) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
+    sha_block(H, tail);
+    if (tl == 128) sha_block(H, tail + 64);
+    for (int k = 0; k < 8; ++k) { digest[4 * k] = (uint8_t)(H[k] >> 24); digest[4 * k + 1] = (uint8_t)(H[k] >> 16); digest[4 * k + 2] = (uint8_t)(H[k] >> 8); digest[4 * k + 3] = (uint8_t)H[k]; }
+}
+
+/* src/lib.rs:210-239: hashed_bytes.reverse(); for each of the 32 / 8 limbs: limb_val = assign_constant(0), then for j in 0..8
+ * limb_val = mul_add(assign_constant(2^(8j)), hashed_bytes[8i + j], limb_val).  Stream (288 bytes): the 32 reversed byte
+ * cells, one byte each, then every limb_val the mul_add chain assigns, 8 bytes little-endian each; constants are not streamed. */
+uint64_t h2ro_hashed_msg_stream_bytes(void) { return 32 + 32 * 8; }
+void h2ro_hashed_msg(const uint8_t digest[32], uint64_t hashed[4], uint8_t *stream) {
+    uint8_t hb[32];
+    for (int k = 0; k < 32; ++k) hb[k] = digest[31 - k];                   /* :213 */
+    if (stream) memcpy(stream, hb, 32);
+    for (int i = 0; i < 4; ++i) {                                           /* :225 */
+        uint64_t limb_val = 0;                                              /* :226 */
+        for (int j = 0; j < 8; ++j) {
+            uint64_t coeff = 1ull << (8 * j);                               /* :228-229 */
+            limb_val = coeff * hb[8 * i + j] + limb_val;                    /* :230-235 */
+            if (stream) for (int k = 0; k < 8; ++k) stream[32 + 8 * (8 * i + j) + k] = (uint8_t)(limb_val >> (8 * k));
+        }
+        hashed[i] = limb_val;                                               /* :237 */
+    }
+}

@@ -60,6 +60,12 @@ int h2ro_refresh(const h2ro_params *p, const uint64_t *muled, uint8_t *stream, v
 uint64_t h2ro_is_equal_muled_stream_bytes(const h2ro_params *p);
 int h2ro_is_equal_muled(const h2ro_params *p, const uint64_t *a, const uint64_t *b, uint8_t *stream, int *eq_bit);
 
+/* The caller of the path, RSASignatureVerifier::verify_pkcs1v15_signature (src/lib.rs:183-246): FIPS 180-4 SHA-256 of the
+ * message (:205-209) and the hashed-message limbs composed from the reversed digest bytes (:210-239). */
+void h2ro_sha256(const uint8_t *msg, uint64_t len, uint8_t digest[32]);
+uint64_t h2ro_hashed_msg_stream_bytes(void);
+void h2ro_hashed_msg(const uint8_t digest[32], uint64_t hashed[4], uint8_t *stream);
+
 /* Batch drivers used by the CPU-baseline timing leg: element-major inputs, `nthreads` pthreads,
  * one element per task.  stream (nullable) holds batch*stream_bytes bytes. */
 int h2ro_pow_mod_fixed_exp_batch(const h2ro_params *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len,

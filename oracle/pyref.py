@@ -682,6 +682,56 @@ def pkcs1v15_em_check(powed: Sequence[int], hashed: Sequence[int], bits_len: int
     return is_eq
 
 
+def sha256(msg: bytes) -> bytes:
+    """FIPS 180-4 SHA-256, restated from the standard (the reference takes the values from the third-party sha2 0.10.6 crate
+    and the halo2-dynamic-sha256 chip, src/lib.rs:205-209, :283-343); pinned by tests/golden/sha256_kat.json."""
+    K = [0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+         0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+         0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+         0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+         0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+         0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+         0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2]
+    M = 0xffffffff
+    rotr = lambda x, n: ((x >> n) | (x << (32 - n))) & M
+    H = [0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19]
+    data = bytes(msg) + b"\x80"
+    data += b"\x00" * ((56 - len(data)) % 64) + (8 * len(msg)).to_bytes(8, "big")
+    for b in range(0, len(data), 64):
+        W = [int.from_bytes(data[b + 4 * t:b + 4 * t + 4], "big") for t in range(16)]
+        for t in range(16, 64):
+            s0 = rotr(W[t - 15], 7) ^ rotr(W[t - 15], 18) ^ (W[t - 15] >> 3)
+            s1 = rotr(W[t - 2], 17) ^ rotr(W[t - 2], 19) ^ (W[t - 2] >> 10)
+            W.append((s1 + W[t - 7] + s0 + W[t - 16]) & M)
+        a, bb, c, d, e, f, g, h = H
+        for t in range(64):
+            T1 = (h + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & M & g)) + K[t] + W[t]) & M
+            T2 = ((rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & bb) ^ (a & c) ^ (bb & c))) & M
+            h, g, f, e, d, c, bb, a = g, f, e, (d + T1) & M, c, bb, a, (T1 + T2) & M
+        H = [(x + y) & M for x, y in zip(H, [a, bb, c, d, e, f, g, h])]
+    return b"".join(x.to_bytes(4, "big") for x in H)
+
+
+def hashed_msg(digest: bytes, st: Stream | None = None) -> List[int]:
+    """RSASignatureVerifier::verify_pkcs1v15_signature, src/lib.rs:210-239: the digest bytes reversed, composed eight at a time
+    into 64-bit limbs by a mul_add chain.  Stream: the 32 reversed byte cells (1 byte each), then every limb_val the chain assigns."""
+    hashed_bytes = list(bytes(digest))[::-1]                 # :213
+    assert len(hashed_bytes) == 32
+    if st is not None:
+        for b in hashed_bytes:
+            st.put(b, 1)
+    limbs = []
+    for i in range(len(hashed_bytes) // 8):                  # :225
+        limb_val = 0                                         # :226
+        for j in range(8):
+            coeff = 1 << (8 * j)                             # :228-229
+            limb_val = coeff * hashed_bytes[8 * i + j] + limb_val   # :230-235
+            if st is not None:
+                st.put(limb_val, 8)
+        limbs.append(limb_val)                               # :237
+    return limbs
+
+
 def modpow_public_key_fixed(p: Params, x: Sequence[int], e: int, n: Sequence[int], st: Stream,
                             with_in_field: bool = True) -> List[int]:
     """RSAChip::modpow_public_key with RSAPubE::Fix, src/chip.rs:99-114."""

@@ -246,6 +246,8 @@ def fixed_row(kind, w, L, carry_bits, carry_sub_bits, carry_nsub, cfg):
         f["sa"] = 1
     elif 20 <= kind < 26:  # ROW_CONST_EM + j
         f["sa"], f["s_const"] = 1, -EM_CONSTS[kind - 20]
+    elif 56 <= kind < 64:  # ROW_CONST_COEFF8 + j: assign_constant(2^(8j)) (src/lib.rs:228-229)
+        f["sa"], f["s_const"] = 1, -(1 << (8 * (kind - 56)))
     elif kind in (48, 49):  # ROW_RANGE_U32 + row: RangeChip::assign(value, 4, 32), eight 4-bit sub-limbs
         last = kind == 49
         for q, nm in enumerate(("sa", "sb", "sc", "sd")):
@@ -593,3 +595,29 @@ def em_image(p, powed, hashed, stream, P):
     im.row(ROW_CONST_EM + 5, EM_CONSTS[5]); im.is_equal(powed[L - 1], EM_CONSTS[5], f); and_(f, r)   # :190-197
     assert pos == len(st), (pos, len(st))
     return im, is_eq
+
+
+# ---- RSASignatureVerifier::verify_pkcs1v15_signature, the hashed-message limbs (src/lib.rs:225-239) as advice rows -------------------
+ROW_CONST_COEFF8 = 56
+
+
+def hashed_msg_image(stream, P):
+    """limb_val = assign_constant(0); for j in 0..8: coeff = assign_constant(2^(8j)); limb_val = mul_add(coeff, hashed_bytes[8i+j],
+    limb_val) -- built from the ORACLE's 288-byte stream (32 reversed byte cells, then the 32 limb_val cells)."""
+    st = bytes(stream)
+    assert len(st) == 288
+    hb = list(st[:32])
+    im = Image(64, 4, P)
+    limbs = []
+    for i in range(4):
+        im.row(ROW_CONST0, 0)                                 # :226
+        limb_val = 0
+        for j in range(8):
+            coeff = 1 << (8 * j)
+            im.row(ROW_CONST_COEFF8 + j, coeff)               # :228-229
+            nv = int.from_bytes(st[32 + 8 * (8 * i + j):32 + 8 * (8 * i + j) + 8], "little")
+            assert nv == coeff * hb[8 * i + j] + limb_val
+            im.row(ROW_MUL_ADD, coeff, hb[8 * i + j], limb_val, nv)   # :230-235
+            limb_val = nv
+        limbs.append(limb_val)
+    return im, limbs

@@ -3,6 +3,7 @@
 //   test_rsa_signature_circuit1 / circuit2 : valid pkcs1v15 signatures  -> is_valid == 1
 //   test_bad_rsa_signature_circuit2        : one digit off              -> is_valid == 0
 // TEST CODE: links the oracle (checker).  Build: see tests/test_cpp_host.py.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -71,6 +72,34 @@ int main(int argc, char **argv) {
         REQUIRE(got == want);
         std::vector<uint64_t> gp = res.powed.limbs();
         REQUIRE(std::vector<uint64_t>(gp.begin() + 32 * i, gp.begin() + 32 * (i + 1)) == powed);
+    }
+    // RSASignatureVerifier::verify_pkcs1v15_signature (src/lib.rs:183-246) from the message BYTES: the three KATs sign b"hello world"
+    // (src/chip.rs:713 is its SHA-256); a different message for the first signature must fail
+    {
+        RSASignatureVerifier verifier(rsa_chip, 128 + 64);
+        const std::string hw = "hello world";
+        std::vector<std::vector<uint8_t>> msgs(B, std::vector<uint8_t>(hw.begin(), hw.end()));
+        SignatureVerifyResult sv = verifier.verify_pkcs1v15_signature(pk, msgs, sign);
+        std::vector<uint64_t> hl(4 * B);
+        sv.hashed_msg.download(hl.data(), hl.size() * 8);
+        for (size_t i = 0; i < B; ++i) {
+            REQUIRE(sv.verify.status[i] == H2R_OK && sv.verify.is_valid[i] == kats[i].is_valid);
+            uint8_t d[32]; uint64_t h4[4]; std::vector<uint8_t> st(h2ro_hashed_msg_stream_bytes()), got(st.size());
+            h2ro_sha256(reinterpret_cast<const uint8_t *>(hw.data()), hw.size(), d);
+            h2ro_hashed_msg(d, h4, st.data());
+            REQUIRE(std::equal(d, d + 32, sv.hashed_bytes.begin() + 32 * i));
+            REQUIRE(std::equal(h4, h4 + 4, hl.begin() + 4 * i) && std::equal(h4, h4 + 4, kats[i].hashed.begin()));
+            sv.hashed_msg_trace.download(got.data(), got.size(), i * H2R_HASHED_MSG_STREAM_BYTES);
+            REQUIRE(got == st);
+            REQUIRE(rsa_chip.flatten(sv.verify, i) == rsa_chip.flatten(res, i));
+        }
+        msgs[0].push_back('!'); msgs[1].clear();
+        SignatureVerifyResult sv2 = verifier.verify_pkcs1v15_signature(pk, msgs, sign);
+        REQUIRE(sv2.verify.is_valid[0] == 0 && sv2.verify.is_valid[1] == 0 && sv2.verify.is_valid[2] == 0);
+        bool refused = false;
+        msgs[2].assign(193, 0);
+        try { verifier.verify_pkcs1v15_signature(pk, msgs, sign); } catch (const Error &e) { refused = e.code == H2R_E_SHAPE; }
+        REQUIRE(refused);
     }
     // BigIntInstructions::mul_mod identity (n - 1) * (n - 1) mod n = 1   (big_integer/chip.rs:3204)
     {

@@ -205,3 +205,18 @@ def mul_stream(o, a, b):
     cols = np.zeros((2 * o.L - 1, 4), dtype=np.uint64)
     lib().h2ro_mul_columns(ctypes.byref(o.p), _ptr(np.ascontiguousarray(a, o.dtype)), _ptr(np.ascontiguousarray(b, o.dtype)), _ptr(st), _ptr(cols))
     return [sum(int(cols[i, k]) << (64 * k) for k in range(4)) for i in range(2 * o.L - 1)], st
+
+
+def sha256(msg: bytes) -> bytes:
+    """h2ro_sha256: the C restatement of FIPS 180-4 (the caller-side step, reference src/lib.rs:205-209)."""
+    d = (ctypes.c_uint8 * 32)()
+    lib().h2ro_sha256(bytes(msg), ctypes.c_uint64(len(msg)), d)
+    return bytes(d)
+
+
+def hashed_msg(digest: bytes):
+    """h2ro_hashed_msg (reference src/lib.rs:210-239): (4 limbs as uint64, the step's 288-byte flat stream)."""
+    h = np.zeros(4, dtype=np.uint64)
+    st = np.zeros(288, dtype=np.uint8)
+    lib().h2ro_hashed_msg(bytes(digest), _ptr(h), _ptr(st))
+    return h, st
