@@ -2083,6 +2083,7 @@ int32_t h2r_field_eval(const h2r_ctx *ctx, uint32_t op, const uint64_t a[4], con
         case 2: r = fe_mul(x, y, ctx->fc); break;
         case 3: if (fe_is_zero(x)) return H2R_E_SHAPE; r = fe_inv(x, ctx->fc); break;
         case 4: if (fe_is_zero(x)) return H2R_E_SHAPE; r = fe_inv_fermat(x, ctx->fc); break;
+        case 5: if (fe_is_zero(x)) return H2R_E_SHAPE; r = fe_inv_fast(x, ctx->fc); break;
         default: return H2R_E_UNSUPPORTED;
     }
     for (int k = 0; k < 4; ++k) out[k] = r.v[k];

@@ -173,6 +173,40 @@ H2R_FD Fe fe_inv(const Fe &a, const FieldConsts &f) {
     return is_one(u) ? x1 : x2;
 }
 
+// s^-1 mod p for a one-word s, 2 <= s < 2^64 < p: classical Euclid on (p, s).  After the first step (p = q0 * s + r: a restoring
+// division, one bit per round) every remainder fits one word, so a step is one 64-bit division and one 64 x 256-bit
+// multiply-accumulate on the cofactor's magnitude (|t[i+1]| = |t[i-1]| + q[i] * |t[i]|, signs alternate, |t| < p throughout):
+// <= 93 steps, ~35 on average -- an order of magnitude less work than the 510 rounds of 256-bit shifts of fe_inv.  The difference
+// main_gate.is_zero is asked about in this path is always of that kind: +-(limb - limb), +-(limb - constant), a flag.
+H2R_FD Fe fe_inv_word(uint64_t s, const FieldConsts &f) {
+    uint64_t tc[4] = {0, 0, 0, 0}, tp[4] = {1, 0, 0, 0};   // |t_cur| (starts as q0), |t_prev|
+    uint64_t rc = 0, rp = s;
+    for (int bit = 255; bit >= 0; --bit) {
+        const uint64_t top = rc >> 63;
+        rc = (rc << 1) | ((f.p[bit >> 6] >> (bit & 63)) & 1ull);
+        if (top || rc >= s) { rc -= s; tc[bit >> 6] |= 1ull << (bit & 63); }
+    }
+    bool neg = true;                                        // t_cur = -q0
+    while (rc > 1) {
+        const uint64_t q = rp / rc, rn = rp - q * rc;
+        uint64_t c = 0, tn[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { tn[k] = tp[k]; c = mac(tn[k], q, tc[k], c); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { tp[k] = tc[k]; tc[k] = tn[k]; }
+        rp = rc; rc = rn; neg = !neg;
+    }
+    Fe t; for (int k = 0; k < 4; ++k) t.v[k] = tc[k];
+    return neg ? fe_sub(fe_zero(), t, f.p) : t;
+}
+// a^-1 mod p, a in [1, p): the one-word Euclid when a or p - a fits a word, the binary algorithm otherwise
+H2R_FD Fe fe_inv_fast(const Fe &a, const FieldConsts &f) {
+    if ((a.v[1] | a.v[2] | a.v[3]) == 0) return a.v[0] == 1 ? a : fe_inv_word(a.v[0], f);
+    const Fe na = fe_sub(fe_zero(), a, f.p);
+    if ((na.v[1] | na.v[2] | na.v[3]) == 0) return na.v[0] == 1 ? a : fe_sub(fe_zero(), fe_inv_word(na.v[0], f), f.p);
+    return fe_inv(a, f);
+}
+
 // Host: derive the Montgomery constants of modulus p.
 inline void field_consts_init(const uint64_t p[4], FieldConsts *f) {
     for (int k = 0; k < 4; ++k) f->p[k] = p[k];

@@ -2722,7 +2722,7 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { const u64 s1 = x.v[k] + a.f.p[k]; const u64 c1 = s1 < x.v[k]; const u64 s2 = s1 + cy; cy = c1 | (u64)(s2 < s1); x.v[k] = s2; }
         }
-        const Fe iv = fe_inv(x, a.f);
+        const Fe iv = fe_inv_fast(x, a.f);
         reinterpret_cast<uint4 *>(p)[0] = make_uint4((u32)iv.v[0], (u32)(iv.v[0] >> 32), (u32)iv.v[1], (u32)(iv.v[1] >> 32));
         reinterpret_cast<uint4 *>(p)[1] = make_uint4((u32)iv.v[2], (u32)(iv.v[2] >> 32), (u32)iv.v[3], (u32)(iv.v[3] >> 32));
     };

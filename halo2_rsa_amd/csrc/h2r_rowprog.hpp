@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void rowprog_inv_kernel(RowProgArgs a) {
     }
     __syncthreads();
     if (tid < cnt) {
-        const Fe iv = fe_inv(l_d[tid], a.f);
+        const Fe iv = fe_inv_fast(l_d[tid], a.f);
         u8 *p = a.out + (u64)l_elem[tid] * a.out_stride + (u64)l_row[tid] * ADVICE_ROW_BYTES + 32;
         st16(p, iv.v[0], iv.v[1]); st16(p + 16, iv.v[2], iv.v[3]);
     }

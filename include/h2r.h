@@ -574,7 +574,8 @@ int32_t h2r_lookup_permuted_columns(const h2r_ctx *ctx, const h2r_lookup_config 
                                     void *s_perm_out, uint64_t out_elem_stride, uint8_t *status, void *workspace,
                                     h2r_stream_t stream);
 /* Arithmetic of the ctx's field on canonical elements (host): op 0 = a + b, 1 = a - b, 2 = a * b, 3 = a^-1 (b ignored; a != 0;
- * binary extended Euclid), 4 = a^(p-2) (Fermat: the cross-check of 3).
+ * binary extended Euclid), 4 = a^(p-2) (Fermat: the cross-check of 3), 5 = a^-1 as the kernels compute main_gate.is_zero's witness
+ * (classical Euclid on (p, s) when a = +-s with s < 2^64 -- the only differences this path produces --, op 3 otherwise).
  * The same code the kernels run (lookup compression, main_gate.is_zero's inverse witness). */
 int32_t h2r_field_eval(const h2r_ctx *ctx, uint32_t op, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
 

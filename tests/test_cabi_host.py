@@ -274,6 +274,14 @@ def test_field_arithmetic_matches_python(field):
             assert lib().h2r_field_eval(ctx, 3, _fe(a), None, out) == 0
             assert _int(out) == pow(a, P - 2, P) and (_int(out) * a) % P == 1
             assert lib().h2r_field_eval(ctx, 4, _fe(a), None, out) == 0 and _int(out) == pow(a, P - 2, P)      # Fermat cross-check
+            assert lib().h2r_field_eval(ctx, 5, _fe(a), None, out) == 0 and _int(out) == pow(a, P - 2, P)      # one-word Euclid / fall-back
+    # op 5's fast path: +-(one word), the differences main_gate.is_zero sees on this path (limb - limb, limb - constant, flags)
+    words = [2, 3, 255, 256, (1 << 32) - 1, 1 << 32, (1 << 63) - 1, 1 << 63, (1 << 64) - 1, (1 << 64) - 2, P % (1 << 64) or 7,
+             0x0304020105000420, 0x0001ffffffffffff] + [rng.getrandbits(64) | 1 for _ in range(300)] + [rng.getrandbits(rng.randrange(2, 65)) or 5 for _ in range(300)]
+    for w in words:
+        for a in (w, P - w):
+            assert lib().h2r_field_eval(ctx, 5, _fe(a), None, out) == 0
+            assert (_int(out) * a) % P == 1 and _int(out) < P, (field, a)
     assert lib().h2r_field_eval(ctx, 3, _fe(0), None, out) == _lib.H2R_E_SHAPE        # no inverse of zero
     assert lib().h2r_field_eval(ctx, 0, _fe(P), _fe(1), out) == _lib.H2R_E_SHAPE       # canonical elements only
     lib().h2r_ctx_destroy(ctx)
