@@ -95,7 +95,7 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_sha256_hashed_msg_batch", "h2r_signature_verifier_batch", "h2r_hashed_msg_advice_rows", "h2r_hashed_msg_row_kinds",
            "h2r_hashed_msg_emit_advice",
            "h2r_lookup_config_default", "h2r_lookup_config_custom", "h2r_lookup_table_image", "h2r_lookup_hist_records",
-           "h2r_lookup_hist_values", "h2r_lookup_hist_fresh_op", "h2r_lookup_workspace_bytes", "h2r_lookup_permuted_columns", "h2r_field_eval",
+           "h2r_lookup_hist_values", "h2r_lookup_hist_values_strided", "h2r_lookup_hist_verify", "h2r_lookup_hist_fresh_op", "h2r_lookup_workspace_bytes", "h2r_lookup_permuted_columns", "h2r_field_eval",
            "h2r_dist_unique_id", "h2r_dist_init", "h2r_dist_destroy", "h2r_dist_rank", "h2r_dist_world", "h2r_dist_shard_range",
            "h2r_dist_bcast", "h2r_dist_gather_results", "h2r_dist_allreduce_max_f64",
            "h2r_profile_enable", "h2r_profile_read", "h2r_status_str",
@@ -238,6 +238,8 @@ def lib():
     L.h2r_lookup_table_image.argtypes = [vp, pcfg, vp, vp]
     L.h2r_lookup_hist_records.argtypes = [vp, pcfg, vp, u64, u64, u64, u32, vp, vp, vp]
     L.h2r_lookup_hist_values.argtypes = [vp, pcfg, vp, u32, u64, u64, u32, u32, vp, vp]
+    L.h2r_lookup_hist_values_strided.argtypes = [vp, pcfg, vp, u32, u64, u64, u64, u64, u32, u32, vp, vp, vp]
+    L.h2r_lookup_hist_verify.argtypes = [vp, pcfg, ctypes.POINTER(H2RVerifyLayout), vp, u64, vp, vp, vp]
     L.h2r_lookup_hist_fresh_op.argtypes = [vp, pcfg, u32, vp, u64, u64, u64, vp, vp]
     L.h2r_lookup_workspace_bytes.argtypes = [pcfg, u64]
     L.h2r_lookup_workspace_bytes.restype = u64

@@ -809,6 +809,13 @@ class LookupArgument:
                                              elem_stride, batch, hist.data_ptr(), self.chip._stream()), "h2r_lookup_hist_fresh_op")
         return hist
 
+    def hist_verify(self, res, hist: torch.Tensor) -> torch.Tensor:
+        """Every lookup inside the witness of a verify_pkcs1v15_signature batch (rsa.VerifyResult): assert_in_field's range assigns,
+        the records' limbs and carries, the encoded-message check's two 4-bit range assigns (h2r_lookup_hist_verify)."""
+        check(lib().h2r_lookup_hist_verify(self.chip._ctx, ctypes.byref(self.cfg), ctypes.byref(res.layout), res.trace.data_ptr(),
+                                           res.is_valid.numel(), res.status.data_ptr(), hist.data_ptr(), self.chip._stream()), "h2r_lookup_hist_verify")
+        return hist
+
     def permuted_columns(self, hist: torch.Tensor, thetas: Sequence[int], usable_rows: int, arg_mask: int = 31, out=None):
         """(A', S', status): uint8 [batch, 5, usable_rows, 32] each -- canonical little-endian field elements."""
         batch = hist.shape[0]

@@ -1951,19 +1951,23 @@ int32_t h2r_lookup_hist_records(const h2r_ctx *ctx, const h2r_lookup_config *cfg
     return H2R_OK;
 }
 
-int32_t h2r_lookup_hist_values(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const void *values, uint32_t value_bytes,
-                               uint64_t values_per_elem, uint64_t num_elems, uint32_t bit_len, uint32_t sublimb_bits,
-                               uint32_t *hist, h2r_stream_t stream) {
+namespace {
+int32_t lookup_hist_values_impl(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const void *values, uint32_t value_bytes,
+                                uint64_t values_per_elem, uint64_t num_elems, uint64_t elem_stride, uint64_t value_stride,
+                                uint32_t bit_len, uint32_t sublimb_bits, const uint8_t *status, uint32_t *hist, h2r_stream_t stream) {
     if (!ctx || !cfg || !values || !hist) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (cfg->n_rows == 0 || cfg->n_rows > (u32)LOOKUP_MAX_ROWS) return H2R_E_SHAPE;
     if ((value_bytes != 4 && value_bytes != 8 && value_bytes != 16) || bit_len > 8 * value_bytes) return H2R_E_SHAPE;
+    const u32 align = value_bytes == 4 ? 4 : 8;
+    if (value_stride < value_bytes || (value_stride % align) || (elem_stride % align) || (reinterpret_cast<u64>(values) % align)) return H2R_E_SHAPE;
     LookupValuesArgs a;
     std::memset(&a, 0, sizeof a);
     const int32_t rc = range_shape(*cfg, bit_len, sublimb_bits, &a.shape);
     if (rc) return rc;
     if (num_elems == 0 || values_per_elem == 0) return H2R_OK;
     a.values = static_cast<const u8 *>(values); a.value_bytes = value_bytes; a.values_per_elem = values_per_elem; a.num_elems = num_elems;
+    a.elem_stride = elem_stride; a.value_stride = value_stride; a.status = status;
     a.n_rows = cfg->n_rows; a.hist = hist;
     H2R_ON_DEVICE(ctx->params.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1971,6 +1975,35 @@ int32_t h2r_lookup_hist_values(const h2r_ctx *ctx, const h2r_lookup_config *cfg,
     hipLaunchKernelGGL(lookup_hist_values_kernel, dim3((unsigned)num_elems), dim3(256), LOOKUP_ARGS * cfg->n_rows * sizeof(u32), st, a);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
+}
+}  // namespace
+
+int32_t h2r_lookup_hist_values(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const void *values, uint32_t value_bytes,
+                               uint64_t values_per_elem, uint64_t num_elems, uint32_t bit_len, uint32_t sublimb_bits,
+                               uint32_t *hist, h2r_stream_t stream) {
+    return lookup_hist_values_impl(ctx, cfg, values, value_bytes, values_per_elem, num_elems, values_per_elem * value_bytes, value_bytes,
+                                   bit_len, sublimb_bits, nullptr, hist, stream);
+}
+
+int32_t h2r_lookup_hist_values_strided(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const void *values, uint32_t value_bytes,
+                                       uint64_t values_per_elem, uint64_t num_elems, uint64_t elem_stride, uint64_t value_stride,
+                                       uint32_t bit_len, uint32_t sublimb_bits, const uint8_t *status, uint32_t *hist,
+                                       h2r_stream_t stream) {
+    return lookup_hist_values_impl(ctx, cfg, values, value_bytes, values_per_elem, num_elems, elem_stride, value_stride, bit_len,
+                                   sublimb_bits, status, hist, stream);
+}
+
+// Every lookup of one verify_pkcs1v15_signature element that the witness holds (src/chip.rs:99-199): the range assigns inside
+// assert_in_field, the q / r limbs and carries of every mul_mod record, and the two RangeChip::assign(half, 4, 32) of the
+// encoded-message check (:170-171; the halves sit at bytes 12 and 24 of the EM region, aux_em).
+int32_t h2r_lookup_hist_verify(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const h2r_verify_layout *vl, const void *trace,
+                               uint64_t num_elems, const uint8_t *status, uint32_t *hist, h2r_stream_t stream) {
+    if (!ctx || !cfg || !vl || !trace || !hist) return H2R_E_NULL;
+    int32_t rc = h2r_lookup_hist_fresh_op(ctx, cfg, H2R_OP_IS_IN_FIELD, trace, vl->off_in_field, vl->elem_stride, num_elems, hist, stream);
+    if (!rc) rc = h2r_lookup_hist_records(ctx, cfg, trace, vl->pow.off_records, vl->elem_stride, num_elems, vl->pow.num_mul_mods, status, hist, stream);
+    if (!rc) rc = lookup_hist_values_impl(ctx, cfg, static_cast<const u8 *>(trace) + vl->off_em + 12, 4, 2, num_elems, vl->elem_stride, 12, 32, 4,
+                                          status, hist, stream);
+    return rc;
 }
 
 extern "C++" {

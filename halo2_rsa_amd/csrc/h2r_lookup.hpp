@@ -82,17 +82,20 @@ __global__ __launch_bounds__(256) void lookup_hist_records_kernel(LookupHistArgs
 
 struct LookupValuesArgs {
     const u8 *values; u32 value_bytes; u64 values_per_elem, num_elems;
+    u64 elem_stride, value_stride;      // bytes between the elements' first values / between the values of an element
+    const u8 *status;                   // nullable: elements with a nonzero status are skipped
     RangeShape shape; u32 n_rows; u32 *hist;
 };
 __global__ __launch_bounds__(256) void lookup_hist_values_kernel(LookupValuesArgs a) {
     extern __shared__ u32 lh[];
     const u32 tid = threadIdx.x, n = LOOKUP_ARGS * a.n_rows;
     const u64 elem = blockIdx.x;
+    if (a.status && a.status[elem]) return;
     for (u32 k = tid; k < n; k += 256) lh[k] = 0;
     __syncthreads();
     const u32 m = (1u << a.shape.sub_bits) - 1;
     for (u64 idx = tid; idx < a.values_per_elem; idx += 256) {
-        const u8 *p = a.values + (elem * a.values_per_elem + idx) * a.value_bytes;
+        const u8 *p = a.values + elem * a.elem_stride + idx * a.value_stride;
         u128 v = a.value_bytes == 4 ? (u128) * reinterpret_cast<const u32 *>(p) : (u128) * reinterpret_cast<const u64 *>(p);
         if (a.value_bytes == 16) v |= (u128)(*reinterpret_cast<const u64 *>(p + 8)) << 64;
         range_count(lh, a.n_rows, a.shape, [&](u32 i) { return (u32)(v >> (i * a.shape.sub_bits)) & m; });

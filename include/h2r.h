@@ -562,6 +562,20 @@ int32_t h2r_lookup_hist_records(const h2r_ctx *ctx, const h2r_lookup_config *cfg
 int32_t h2r_lookup_hist_values(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const void *values, uint32_t value_bytes,
                                uint64_t values_per_elem, uint64_t num_elems, uint32_t bit_len, uint32_t sublimb_bits,
                                uint32_t *hist, h2r_stream_t stream);
+/* the same for values that are not packed: element e's value k at values + e * elem_stride + k * value_stride (bytes; multiples of 4
+ * for 4-byte values, of 8 otherwise); elements with a nonzero status byte (nullable) are skipped */
+int32_t h2r_lookup_hist_values_strided(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const void *values, uint32_t value_bytes,
+                                       uint64_t values_per_elem, uint64_t num_elems, uint64_t elem_stride, uint64_t value_stride,
+                                       uint32_t bit_len, uint32_t sublimb_bits, const uint8_t *status, uint32_t *hist,
+                                       h2r_stream_t stream);
+/* every lookup the witness of one verify_pkcs1v15_signature element holds (trace of h2r_verify_pkcs1v15_batch / h2r_signature_verifier_batch):
+ * the range assigns inside assert_in_field (= h2r_lookup_hist_fresh_op), the q / r limbs and carries of every mul_mod record
+ * (= h2r_lookup_hist_records) and the two RangeChip::assign(half, 4, 32) of the encoded-message check (src/chip.rs:170-171; cfg
+ * must hold RSAChip's 4-bit length: h2r_lookup_config_default(ctx, 1, ..)).  In-field rows are counted for every element (that
+ * witness is written whatever the status), records and EM rows only where status is 0.  What the caller adds: assign_integer of
+ * the signature and of n (h2r_lookup_hist_values). */
+int32_t h2r_lookup_hist_verify(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const h2r_verify_layout *vl, const void *trace,
+                               uint64_t num_elems, const uint8_t *status, uint32_t *hist, h2r_stream_t stream);
 /* the range assigns INSIDE a Fresh-op witness (h2r_fresh_op_batch's trace; op = H2R_OP_IS_IN_FIELD for the in_field_trace of
  * h2r_modpow_public_key_batch, or for the in-field region of a verify element with first_off = h2r_verify_layout.off_in_field):
  * add's c / carry per limb (big_integer/chip.rs:279-282) and sub_unchecked's difference limbs (:1307-1308), each a

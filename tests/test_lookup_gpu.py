@@ -291,3 +291,72 @@ def test_lookup_hist_of_the_in_field_witness(H, w, L):
             for t, sv in enumerate(subs):
                 want[t if t < 4 else 7 - t, off + sv] += 1
         assert np.array_equal(got[b], want), b
+
+
+def test_lookup_hist_of_a_whole_verify_element(H, golden):
+    """h2r_lookup_hist_verify + h2r_lookup_hist_values(sig), (n): the multiplicities of EVERY lookup of one
+    RSAChip::verify_pkcs1v15_signature circuit (assign_signature, assign_public_key, assert_in_field, pow_mod_fixed_exp, the
+    encoded-message check's 4-bit range rows) equal a count over the Python restatement's rows built from the ORACLE's streams;
+    the permuted columns of that circuit satisfy the lookup argument's invariants."""
+    import ctypes
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref as R
+    from halo2_rsa_amd._lib import lib
+    P = R.FIELD_MODULI["bn254_fr"]
+    e = 5                                                        # 4 mul_mods: keeps the Python image small
+    k = golden["rsa_kats"][0]
+    rng = random.Random(31)
+    ns = [int(k["n"]), rng.getrandbits(2048) | (1 << 2047) | 1]
+    sigs = [int(k["sig"]), rng.randrange(ns[1])]
+    hashed = [int(k["hashed"]), rng.getrandbits(256)]
+    rsa = H.RSAChip(2048, 5)
+    chip = rsa.bigint_chip()
+    pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Fix(e)))
+    sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64)))
+    res = rsa.verify_pkcs1v15_signature(pk, hashed, sg)
+    la = H.LookupArgument(chip, rsa_chip=True)
+    hist = la.new_hist(2)
+    sig_d, n_d, _ = res.inputs
+    la.hist_values(sig_d.limbs_dev, 64, 8, hist)
+    la.hist_values(n_d.limbs_dev, 64, 8, hist)
+    la.hist_verify(res, hist)
+    torch.cuda.synchronize()
+    assert res.status.cpu().tolist() == [0, 0]
+    got = hist.cpu().numpy()
+    cfg = AR.LookupConfig(AR.range_lens(64, 32, rsa=True))
+    o = Oracle(64, 32)
+    usable = 1 << 15
+    for b in range(2):
+        inputs, n_calls, acc = _circuit_reference(o, 64, 32, P, cfg, sigs[b], ns[b], e, usable)    # assign_integer x 2 + the mul_mods
+        rc, lt, s_if = o.assert_in_field(o.limbs(sigs[b]), o.limbs(ns[b]))
+        im_if = AR.in_field_image(o.p, o.limbs(sigs[b]), o.limbs(ns[b]), s_if, P)
+        powed = o.limbs(pow(sigs[b], e, ns[b]))
+        rc, valid, s_em = o.pkcs1v15_em_check(powed, o.limbs(hashed[b], 4))
+        im_em, _ = AR.em_image(o.p, powed, o.limbs(hashed[b], 4), s_em, P)
+        rows = im_if.rows + im_em.rows
+        fixed = [AR.fixed_row(kk, 64, 32, o.p.carry_bits, o.p.carry_sub_bits, o.p.carry_nsub, cfg) for kk in im_if.kinds + im_em.kinds]
+        extra = AR.lookup_inputs(rows, fixed, len(rows))
+        want = np.zeros((5, cfg.n_rows), dtype=np.int64)
+        row_of = {tv: i for i, tv in enumerate(cfg.table())}
+        for a, name in enumerate(AR.ARGS):
+            for (tag, val) in list(inputs[name]) + list(extra[name]):
+                if tag:
+                    want[a, row_of[(tag, val)]] += 1
+        g = got[b].astype(np.int64).copy()
+        g[:, 0] = 0                                              # row 0 = (0, 0): the rows with the lookup off, a function of usable_rows
+        want[:, 0] = 0
+        assert np.array_equal(g, want), (b, np.argwhere(g != want)[:5])
+        assert want[:, cfg.row_off[4]:cfg.row_off[4] + 16].sum() == 16      # the EM check's sixteen 4-bit sub-limbs
+    # strided form: the same two halves counted from powed limb 6 viewed as two 32-bit words
+    h2 = la.new_hist(2)
+    assert lib().h2r_lookup_hist_values_strided(chip._ctx, ctypes.byref(la.cfg), res.powed.limbs_dev.data_ptr() + 48, 4, 2, 2, 32 * 8, 4, 32, 4,
+                                                None, h2.data_ptr(), chip._stream()) == 0
+    h3 = la.new_hist(2)
+    assert lib().h2r_lookup_hist_values_strided(chip._ctx, ctypes.byref(la.cfg), res.trace.data_ptr() + res.layout.off_em + 12, 4, 2, 2,
+                                                res.layout.elem_stride, 12, 32, 4, res.status.data_ptr(), h3.data_ptr(), chip._stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(h2, h3) and int(h2.sum()) == 2 * 16
+    assert lib().h2r_lookup_hist_values_strided(chip._ctx, ctypes.byref(la.cfg), res.trace.data_ptr() + 2, 4, 2, 2, 256, 12, 32, 4, None,
+                                                h3.data_ptr(), chip._stream()) == H.H2R_E_SHAPE
