@@ -787,6 +787,39 @@ int32_t h2r_verify_pkcs1v15_batch(const h2r_ctx *ctx, const void *sig, const voi
     return launch_verify_aux(ctx, sig, n, hashed, batch, flags, trace, vl, powed_out, is_valid_out, status, st);
 }
 
+// RSAPubE::Var arm of the same call (src/chip.rs:108-110: pow_mod with the chip's exp_limb_bits)
+int32_t h2r_verify_layout_var(const h2r_ctx *ctx, uint32_t e_num_limbs, uint32_t exp_limb_bits, h2r_verify_layout *out) {
+    if (!ctx || !out) return H2R_E_NULL;
+    if (ctx->layout.limb_width != 64 || ctx->L < 9) return H2R_E_SHAPE;
+    std::memset(out, 0, sizeof *out);
+    int32_t rc = h2r_pow_var_layout(ctx, e_num_limbs, exp_limb_bits, &out->pow);
+    if (rc) return rc;
+    const AuxGeom g(ctx->L, 64);
+    out->off_in_field = out->pow.elem_stride;
+    u64 sb = 0;
+    in_field_sections(g, [&](u64, u64 len) { sb += len; });
+    out->in_field_stream_bytes = sb;
+    out->off_em = out->off_in_field + round_up(g.in_field_sz(), 256);
+    out->em_stream_bytes = 2ull * ctx->L + 34;
+    out->elem_stride = odd_stride_256(out->off_em + g.em_sz());
+    out->stream_bytes = out->in_field_stream_bytes + out->pow.stream_bytes + out->em_stream_bytes;
+    return H2R_OK;
+}
+
+int32_t h2r_verify_pkcs1v15_var_batch(const h2r_ctx *ctx, const void *sig, const void *n, const void *e_limbs, uint32_t e_num_limbs,
+                                      uint32_t exp_limb_bits, const uint64_t *hashed, uint64_t batch, uint32_t flags, void *trace,
+                                      void *powed_out, uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+    if (!ctx || !sig || !n || !e_limbs || !hashed || !trace || !powed_out || !status) return H2R_E_NULL;
+    h2r_verify_layout vl;
+    int32_t rc = h2r_verify_layout_var(ctx, e_num_limbs, exp_limb_bits, &vl);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = run_path(ctx, CHAIN_POW_VAR, sig, nullptr, n, e_limbs, e_num_limbs, exp_limb_bits, nullptr, 1, batch, flags, vl.pow.num_mul_mods, trace,
+                  vl.elem_stride, vl.pow.off_records, &vl.pow, powed_out, status, workspace, st);
+    if (rc || batch == 0) return rc;
+    return launch_verify_aux(ctx, sig, n, hashed, batch, flags, trace, vl, powed_out, is_valid_out, status, st);
+}
+
 int32_t h2r_verify_trace_flatten(const h2r_ctx *ctx, const h2r_verify_layout *vl, const void *elem_host, void *stream_out) {
     if (!ctx || !vl || !elem_host || !stream_out) return H2R_E_NULL;
     const u8 *e = static_cast<const u8 *>(elem_host);
@@ -2577,6 +2610,7 @@ int32_t verify_progs(const h2r_ctx *ctx, const h2r_ctx::RowProg **pre, const h2r
 
 uint64_t h2r_verify_advice_rows(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint64_t section_rows[4]) {
     if (!ctx || !vl) return 0;
+    if (vl->pow.off_e_bits != UINT64_MAX) return 0;   // a Var element's to_bits / select rows are not emitted: no whole-element image
     const h2r_ctx::RowProg *pre, *inf, *em;
     if (verify_progs(ctx, &pre, &inf, &em)) return 0;
     const u64 r[4] = {pre->host.size(), inf->host.size(), h2r_pow_advice_rows(ctx, &vl->pow), em->host.size()};
@@ -2586,6 +2620,7 @@ uint64_t h2r_verify_advice_rows(const h2r_ctx *ctx, const h2r_verify_layout *vl,
 
 int32_t h2r_verify_row_kinds(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint8_t *kinds_out) {
     if (!ctx || !vl || !kinds_out) return H2R_E_NULL;
+    if (vl->pow.off_e_bits != UINT64_MAX) return H2R_E_UNSUPPORTED;
     const h2r_ctx::RowProg *pre, *inf, *em;
     const int32_t rc = verify_progs(ctx, &pre, &inf, &em);
     if (rc) return rc;
@@ -2604,7 +2639,7 @@ int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, 
                                const void *powed, uint32_t flags, const void *trace, const void *workspace, uint64_t batch,
                                const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
     if (!ctx || !vl || !sig || !n || !hashed || !powed || !trace || !workspace || !advice_out) return H2R_E_NULL;
-    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    if (ctx->params.device < 0 || vl->pow.off_e_bits != UINT64_MAX) return H2R_E_UNSUPPORTED;
     const h2r_ctx::RowProg *pre, *inf, *em;
     int32_t rc = verify_progs(ctx, &pre, &inf, &em);
     if (rc) return rc;

@@ -83,28 +83,55 @@ class RSAChip:
 
     def verify_pkcs1v15_signature(self, public_key: RSAPublicKey, hashed_msg, signature: RSASignature) -> "VerifyResult":
         """src/chip.rs:128-199 (after the SHA step): assert_in_field + modpow_public_key + encoded-message check.
-        hashed_msg: per element the SHA-256 digest as an integer / 4 little-endian 64-bit limbs (src/chip.rs:141-144)."""
-        if not isinstance(public_key.e, Fix):
-            raise NotImplementedError("verify_pkcs1v15_signature batch path takes RSAPubE::Fix")
-        chip, e = self._bigint, public_key.e.e
+        hashed_msg: per element the SHA-256 digest as an integer / 4 little-endian 64-bit limbs (src/chip.rs:141-144).
+        RSAPubE::Fix -> h2r_verify_pkcs1v15_batch, RSAPubE::Var -> h2r_verify_pkcs1v15_var_batch (the chip's exp_limb_bits)."""
+        chip = self._bigint
         n, sig = chip.assign_integer(public_key.n), chip.assign_integer(signature.c)
         batch, dev = sig.batch, sig.limbs_dev.device
         if isinstance(hashed_msg, AssignedInteger):
             hashed = hashed_msg.limbs_dev
+        elif isinstance(hashed_msg, torch.Tensor):
+            hashed = hashed_msg
         else:
             hashed = torch.from_numpy(UnassignedInteger.from_ints(list(hashed_msg), 4, 64).limbs.view(np.int64)).to(dev)
-        vl = H2RVerifyLayout()
-        eb = _e_bytes(e)
-        check(lib().h2r_verify_layout_fixed(chip._ctx, eb, len(eb), ctypes.byref(vl)), "h2r_verify_layout_fixed")
-        trace = torch.empty(batch * vl.elem_stride, dtype=torch.uint8, device=dev)
-        powed = torch.empty((batch, chip.num_limbs), dtype=torch.int64, device=dev)
-        is_valid = torch.zeros(batch, dtype=torch.uint8, device=dev)
-        status = torch.zeros(batch, dtype=torch.uint8, device=dev)
-        ws = torch.empty(chip.workspace_bytes(batch, vl.pow.num_mul_mods), dtype=torch.uint8, device=dev)   # kept: emit_advice reads it
-        check(lib().h2r_verify_pkcs1v15_batch(chip._ctx, sig.data_ptr(), n.data_ptr(), eb, len(eb), hashed.data_ptr(), batch,
-                                              chip._flags(n, batch), trace.data_ptr(), powed.data_ptr(), is_valid.data_ptr(),
-                                              status.data_ptr(), ws.data_ptr(), chip._stream()), "verify_pkcs1v15_signature")
-        return VerifyResult(is_valid, AssignedInteger(powed, 64), status, trace, vl, chip, ws, (sig, n, hashed))
+        vl = self._verify_layout(public_key)
+        bufs = _VerifyBuffers(chip, batch, vl, dev)
+        self._verify_call(public_key, sig, n, hashed, batch, vl, bufs)
+        return VerifyResult(bufs.is_valid, AssignedInteger(bufs.powed, 64), bufs.status, bufs.trace, vl, chip, bufs.ws, (sig, n, hashed))
+
+    def _verify_layout(self, public_key: RSAPublicKey) -> H2RVerifyLayout:
+        chip, vl = self._bigint, H2RVerifyLayout()
+        if isinstance(public_key.e, Fix):
+            eb = _e_bytes(public_key.e.e)
+            check(lib().h2r_verify_layout_fixed(chip._ctx, eb, len(eb), ctypes.byref(vl)), "h2r_verify_layout_fixed")
+        else:
+            check(lib().h2r_verify_layout_var(chip._ctx, public_key.e.e.num_limbs(), self.exp_limb_bits, ctypes.byref(vl)), "h2r_verify_layout_var")
+        return vl
+
+    def _verify_call(self, public_key, sig, n, hashed, batch, vl, b):
+        chip = self._bigint
+        if isinstance(public_key.e, Fix):
+            eb = _e_bytes(public_key.e.e)
+            check(lib().h2r_verify_pkcs1v15_batch(chip._ctx, sig.data_ptr(), n.data_ptr(), eb, len(eb), hashed.data_ptr(), batch,
+                                                  chip._flags(n, batch), b.trace.data_ptr(), b.powed.data_ptr(), b.is_valid.data_ptr(),
+                                                  b.status.data_ptr(), b.ws.data_ptr(), chip._stream()), "verify_pkcs1v15_signature")
+        else:
+            e = public_key.e.e
+            if not isinstance(e, AssignedInteger):
+                raise TypeError("RSAPubE::Var: assign the public key first (RSAChip.assign_public_key)")
+            check(lib().h2r_verify_pkcs1v15_var_batch(chip._ctx, sig.data_ptr(), n.data_ptr(), e.data_ptr(), e.num_limbs(), self.exp_limb_bits,
+                                                      hashed.data_ptr(), batch, chip._flags(n, batch), b.trace.data_ptr(), b.powed.data_ptr(),
+                                                      b.is_valid.data_ptr(), b.status.data_ptr(), b.ws.data_ptr(), chip._stream()),
+                  "verify_pkcs1v15_signature (Var)")
+
+
+class _VerifyBuffers:
+    def __init__(self, chip, batch, vl, dev):
+        self.trace = torch.empty(batch * vl.elem_stride, dtype=torch.uint8, device=dev)
+        self.powed = torch.empty((batch, chip.num_limbs), dtype=torch.int64, device=dev)
+        self.is_valid = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        self.status = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        self.ws = torch.empty(chip.workspace_bytes(batch, vl.pow.num_mul_mods), dtype=torch.uint8, device=dev)   # kept: emit_advice reads it
 
 
 # ---- byte-level plumbing of the reference's example / verifier (BASELINE config 1) -------------------------------------
@@ -157,9 +184,7 @@ class RSASignatureVerifier:
     def verify_pkcs1v15_signature(self, public_key: RSAPublicKey, msg, signature: RSASignature) -> "VerifyResult":
         """msg: one message (bytes, signed by every element), one message per element (list of bytes), or an already packed
         pair (uint8 device tensor, int64 device offsets [batch + 1])."""
-        if not isinstance(public_key.e, Fix):
-            raise NotImplementedError("verify_pkcs1v15_signature batch path takes RSAPubE::Fix")
-        chip, e = self.rsa_chip.bigint_chip(), public_key.e.e
+        rsa, chip = self.rsa_chip, self.rsa_chip.bigint_chip()
         n, sig = chip.assign_integer(public_key.n), chip.assign_integer(signature.c)
         batch, dev = sig.batch, sig.limbs_dev.device
         if isinstance(msg, tuple):
@@ -171,22 +196,22 @@ class RSASignatureVerifier:
             if self.sha256_max_byte_size is not None and any(len(m) > self.sha256_max_byte_size for m in msgs):
                 raise ValueError("message longer than the SHA-256 chip's max_byte_size")
             buf, off = pack_messages(msgs, dev)
-        vl = H2RVerifyLayout()
-        eb = _e_bytes(e)
-        check(lib().h2r_verify_layout_fixed(chip._ctx, eb, len(eb), ctypes.byref(vl)), "h2r_verify_layout_fixed")
-        trace = torch.empty(batch * vl.elem_stride, dtype=torch.uint8, device=dev)
-        powed = torch.empty((batch, chip.num_limbs), dtype=torch.int64, device=dev)
-        is_valid = torch.zeros(batch, dtype=torch.uint8, device=dev)
-        status = torch.zeros(batch, dtype=torch.uint8, device=dev)
+        vl = rsa._verify_layout(public_key)
+        b = _VerifyBuffers(chip, batch, vl, dev)
         digest = torch.empty((batch, 32), dtype=torch.uint8, device=dev)
         hashed = torch.empty((batch, 4), dtype=torch.int64, device=dev)
         hm = torch.empty((batch, H2R_HASHED_MSG_STREAM_BYTES), dtype=torch.uint8, device=dev)
-        ws = torch.empty(chip.workspace_bytes(batch, vl.pow.num_mul_mods), dtype=torch.uint8, device=dev)
-        check(lib().h2r_signature_verifier_batch(chip._ctx, buf.data_ptr(), off.data_ptr(), 0, sig.data_ptr(), n.data_ptr(), eb, len(eb),
-                                                 batch, chip._flags(n, batch), trace.data_ptr(), hm.data_ptr(), hm.shape[1],
-                                                 digest.data_ptr(), hashed.data_ptr(), powed.data_ptr(), is_valid.data_ptr(),
-                                                 status.data_ptr(), ws.data_ptr(), chip._stream()), "h2r_signature_verifier_batch")
-        return VerifyResult(is_valid, AssignedInteger(powed, 64), status, trace, vl, chip, ws, (sig, n, hashed), digest, hm)
+        if isinstance(public_key.e, Fix):     # one call: SHA-256, limb packing, verification (h2r_signature_verifier_batch)
+            eb = _e_bytes(public_key.e.e)
+            check(lib().h2r_signature_verifier_batch(chip._ctx, buf.data_ptr(), off.data_ptr(), 0, sig.data_ptr(), n.data_ptr(), eb, len(eb),
+                                                     batch, chip._flags(n, batch), b.trace.data_ptr(), hm.data_ptr(), hm.shape[1],
+                                                     digest.data_ptr(), hashed.data_ptr(), b.powed.data_ptr(), b.is_valid.data_ptr(),
+                                                     b.status.data_ptr(), b.ws.data_ptr(), chip._stream()), "h2r_signature_verifier_batch")
+        else:                                  # RSAPubE::Var: the two steps in stream order
+            check(lib().h2r_sha256_hashed_msg_batch(chip._ctx, buf.data_ptr(), off.data_ptr(), 0, batch, digest.data_ptr(), hashed.data_ptr(),
+                                                    hm.data_ptr(), hm.shape[1], chip._stream()), "h2r_sha256_hashed_msg_batch")
+            rsa._verify_call(public_key, sig, n, hashed, batch, vl, b)
+        return VerifyResult(b.is_valid, AssignedInteger(b.powed, 64), b.status, b.trace, vl, chip, b.ws, (sig, n, hashed), digest, hm)
 
 
 def sha256_hashed_msg(chip: BigIntChip, msgs, want_trace: bool = True):

@@ -362,6 +362,13 @@ int32_t h2r_verify_pkcs1v15_batch(const h2r_ctx *ctx, const void *sig, const voi
                                   uint64_t batch, uint32_t flags, void *trace, void *powed_out,
                                   uint8_t *is_valid_out, uint8_t *status, void *workspace,
                                   h2r_stream_t stream);
+/* the RSAPubE::Var arm (src/chip.rs:108-110): e_limbs = e_num_limbs limbs per element, as h2r_pow_mod_batch takes them; the chip's
+ * exp_limb_bits.  An exponent limb wider than exp_limb_bits gets H2R_E_SHAPE (to_bits cannot be satisfied). */
+int32_t h2r_verify_layout_var(const h2r_ctx *ctx, uint32_t e_num_limbs, uint32_t exp_limb_bits, h2r_verify_layout *out);
+int32_t h2r_verify_pkcs1v15_var_batch(const h2r_ctx *ctx, const void *sig, const void *n, const void *e_limbs,
+                                      uint32_t e_num_limbs, uint32_t exp_limb_bits, const uint64_t *hashed, uint64_t batch,
+                                      uint32_t flags, void *trace, void *powed_out, uint8_t *is_valid_out, uint8_t *status,
+                                      void *workspace, h2r_stream_t stream);
 int32_t h2r_verify_trace_flatten(const h2r_ctx *ctx, const h2r_verify_layout *vl,
                                  const void *elem_host, void *stream_out);
 /* Pipelined form of h2r_verify_pkcs1v15_batch (see h2r_pipeline_create): the in-field / encoded-message
@@ -687,7 +694,9 @@ int32_t h2r_fresh_op_row_kinds(const h2r_ctx *ctx, uint32_t op, uint32_t flags, 
  * the two RangeChip::assign(half, 4, 32) of limb 6 (H2R_ROW_RANGE_U32 + row), their mul_add recomposition and assert_equal].
  * section_rows (nullable): the four sections' row counts (1, 1,532, 75,489, 178 for RSA-2048 with e = 65537).
  * sig, n, hashed, flags, trace, workspace: what h2r_verify_pkcs1v15_batch / h2r_pipeline_verify_pkcs1v15 were given (a caller
- * workspace is required: it holds every mul_mod's operands); powed: their powed_out.  Elements with a nonzero status are skipped. */
+ * workspace is required: it holds every mul_mod's operands); powed: their powed_out.  Elements with a nonzero status are skipped.
+ * Fixed-exponent layouts only: a Var element (h2r_verify_layout_var) has to_bits / select rows this image does not hold -- rows = 0,
+ * H2R_E_UNSUPPORTED; its sections are available one by one (h2r_fresh_op_emit_advice, h2r_pow_trace_emit_advice: the records). */
 uint64_t h2r_verify_advice_rows(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint64_t section_rows[4]);
 int32_t h2r_verify_row_kinds(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint8_t *kinds_out);
 int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, const void *sig, const void *n,

@@ -442,15 +442,23 @@ class RSAChip {
     VerifyResult verify_pkcs1v15_signature(const AssignedRSAPublicKey &pk, const AssignedInteger &hashed_msg,
                                            const AssignedRSASignature &sig) const {
         auto *f = std::get_if<RSAPubE::Fix>(&pk.e);
-        if (!f) throw Error(H2R_E_UNSUPPORTED, "verify_pkcs1v15_signature (batch path takes RSAPubE::Fix)");
         h2r_verify_layout vl;
-        check(h2r_verify_layout_fixed(bigint_.ctx(), f->e_le.data(), f->e_le.size(), &vl), "h2r_verify_layout_fixed");
         const size_t batch = sig.c.batch();
+        if (f) check(h2r_verify_layout_fixed(bigint_.ctx(), f->e_le.data(), f->e_le.size(), &vl), "h2r_verify_layout_fixed");
+        else check(h2r_verify_layout_var(bigint_.ctx(), (uint32_t)std::get<AssignedInteger>(pk.e).num_limbs(), exp_limb_bits_, &vl), "h2r_verify_layout_var");
         DeviceBuffer trace(batch * vl.elem_stride), powed(batch * bigint_.num_limbs() * 8), valid(batch), st(batch);
-        check(h2r_verify_pkcs1v15_batch(bigint_.ctx(), sig.c.data(), pk.n.data(), f->e_le.data(), f->e_le.size(),
-                                        static_cast<const uint64_t *>(hashed_msg.data()), batch, BigIntChip::flags(pk.n, batch), trace.get(),
-                                        powed.get(), static_cast<uint8_t *>(valid.get()), static_cast<uint8_t *>(st.get()), nullptr, nullptr),
-              "verify_pkcs1v15_signature");
+        if (f)
+            check(h2r_verify_pkcs1v15_batch(bigint_.ctx(), sig.c.data(), pk.n.data(), f->e_le.data(), f->e_le.size(),
+                                            static_cast<const uint64_t *>(hashed_msg.data()), batch, BigIntChip::flags(pk.n, batch), trace.get(),
+                                            powed.get(), static_cast<uint8_t *>(valid.get()), static_cast<uint8_t *>(st.get()), nullptr, nullptr),
+                  "verify_pkcs1v15_signature");
+        else {   // RSAPubE::Var (src/chip.rs:108-110)
+            const AssignedInteger &e = std::get<AssignedInteger>(pk.e);
+            check(h2r_verify_pkcs1v15_var_batch(bigint_.ctx(), sig.c.data(), pk.n.data(), e.data(), (uint32_t)e.num_limbs(), exp_limb_bits_,
+                                                static_cast<const uint64_t *>(hashed_msg.data()), batch, BigIntChip::flags(pk.n, batch), trace.get(),
+                                                powed.get(), static_cast<uint8_t *>(valid.get()), static_cast<uint8_t *>(st.get()), nullptr, nullptr),
+                  "verify_pkcs1v15_signature (Var)");
+        }
         hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
         VerifyResult r{std::vector<uint8_t>(batch), std::vector<uint8_t>(batch), AssignedInteger(std::move(powed), batch, bigint_.num_limbs()),
                        std::move(trace), vl};

@@ -101,6 +101,18 @@ int main(int argc, char **argv) {
         try { verifier.verify_pkcs1v15_signature(pk, msgs, sign); } catch (const Error &e) { refused = e.code == H2R_E_SHAPE; }
         REQUIRE(refused);
     }
+    // RSAPubE::Var arm of verify_pkcs1v15_signature (src/chip.rs:108-110): e = 65537 = 1 + 2 * 32^3 as four 5-bit limbs
+    // (EXP_LIMB_BITS = 5): same verdicts and powed limbs as the Fix arm
+    {
+        std::vector<uint64_t> e_limbs;
+        for (size_t i = 0; i < B; ++i) { const uint64_t el[4] = {1, 0, 0, 2}; e_limbs.insert(e_limbs.end(), el, el + 4); }
+        RSAPublicKey pk_var{UnassignedInteger::from(n_limbs, B, 32), RSAPubE{RSAPubE::Var{UnassignedInteger::from(e_limbs, B, 4)}}};
+        AssignedRSAPublicKey pkv = rsa_chip.assign_public_key(pk_var);
+        VerifyResult rv = rsa_chip.verify_pkcs1v15_signature(pkv, hashed_msg_assigned, sign);
+        for (size_t i = 0; i < B; ++i) REQUIRE(rv.status[i] == H2R_OK && rv.is_valid[i] == kats[i].is_valid);
+        REQUIRE(rv.powed.limbs() == res.powed.limbs());
+        REQUIRE(rv.layout.pow.num_mul_mods == 2 * 20);
+    }
     // BigIntInstructions::mul_mod identity (n - 1) * (n - 1) mod n = 1   (big_integer/chip.rs:3204)
     {
         std::vector<uint64_t> n(kats[0].n), a(n); a[0] -= 1;   // n is odd -> no borrow

@@ -288,3 +288,44 @@ def test_hashed_msg_advice_rows(H, golden):
             assert AR.gate_residual(cells[r], 0, f, P) == 0, (r, kinds[r])
         # the last limb_val of each limb is the cell handed to RSAChip::verify_pkcs1v15_signature (src/lib.rs:237-241)
         assert [cells[17 * k + 16][3] for k in range(4)] == ref_limbs
+
+
+@pytest.mark.gpu
+def test_verify_with_a_variable_exponent(H, golden):
+    """RSAChip::verify_pkcs1v15_signature / RSASignatureVerifier with RSAPubE::Var (src/chip.rs:108-110: pow_mod with the chip's
+    exp_limb_bits): h2r_verify_pkcs1v15_var_batch on the reference's KATs with e = 65537 given as ONE 17-bit exponent limb and as
+    four 5-bit limbs (the reference's EXP_LIMB_BITS = 5, src/chip.rs:364) -- is_valid 1, 1, 0; the element's stream = the oracle's
+    in-field + variable-exponent pow + encoded-message streams; an exponent limb wider than exp_limb_bits gets H2R_E_SHAPE; the
+    whole-element advice image is refused for a Var layout."""
+    import torch
+    from halo2_rsa_amd._lib import lib
+    kats = golden["rsa_kats"]
+    ns = [int(k["n"]) for k in kats]
+    sigs = [int(k["sig"]) for k in kats]
+    hashed = [int(k["hashed"]) for k in kats]
+    o = Oracle(64, 32)
+    for exp_limb_bits, e_limbs in ((17, [65537]), (5, [1, 0, 0, 2])):       # 65537 = 1 + 2 * 32^3
+        assert sum(v << (exp_limb_bits * i) for i, v in enumerate(e_limbs)) == 65537
+        rsa = H.RSAChip(2048, exp_limb_bits)
+        e_un = H.UnassignedInteger(np.array([e_limbs] * 3, dtype=np.uint64))
+        pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Var(e_un)))
+        sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64)))
+        res = rsa.verify_pkcs1v15_signature(pk, hashed, sg)
+        res_m = H.RSASignatureVerifier(rsa).verify_pkcs1v15_signature(pk, b"hello world", sg)
+        torch.cuda.synchronize()
+        for r in (res, res_m):
+            assert r.status.cpu().tolist() == [0, 0, 0] and r.is_valid.cpu().tolist() == [1, 1, 0]
+        assert res.advice_sections()[0] == 0                             # no whole-element image for a Var layout
+        for i in range(3):
+            _, _, s_if = o.assert_in_field(o.limbs(sigs[i]), o.limbs(ns[i]))
+            rc, out, s_pow = o.pow_mod(o.limbs(sigs[i]), np.array(e_limbs, dtype=np.uint64), exp_limb_bits, o.limbs(ns[i]))
+            assert rc == 0 and R.from_limbs([int(v) for v in out], 64) == pow(sigs[i], 65537, ns[i])
+            _, valid, s_em = o.pkcs1v15_em_check(out, o.limbs(hashed[i], 4))
+            want = np.concatenate([s_if, s_pow, s_em])
+            assert np.array_equal(res.flatten(i), want) and np.array_equal(res_m.flatten(i), want), (exp_limb_bits, i)
+    # a limb that does not fit exp_limb_bits: main_gate.to_bits cannot be satisfied (big_integer/chip.rs:677)
+    rsa = H.RSAChip(2048, 5)
+    pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Var(H.UnassignedInteger(np.array([[1, 0, 0, 32]] * 3, dtype=np.uint64)))))
+    res = rsa.verify_pkcs1v15_signature(pk, hashed, rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64))))
+    torch.cuda.synchronize()
+    assert res.status.cpu().tolist() == [H.H2R_E_SHAPE] * 3 and res.is_valid.cpu().tolist() == [0, 0, 0]
