@@ -281,6 +281,9 @@ def main():
     ap.add_argument("--verify", action="store_true",
                     help="time the whole verify_pkcs1v15_signature witness (in-field + modpow + encoded-message check) "
                          "instead of modpow_public_key alone (RSA-2048 workloads, pipelined mode)")
+    ap.add_argument("--messages", type=int, default=0, metavar="LEN",
+                    help="with --verify: start every call from LEN-byte message bytes (RSASignatureVerifier, src/lib.rs:183-246: "
+                         "SHA-256 + hashed-message limbs on the device in the timed region) instead of precomputed digests")
     ap.add_argument("--shared-modulus", action="store_true",
                     help="one key, many signatures (H2R_F_SHARED_MODULUS): every element uses element 0's modulus")
     ap.add_argument("--no-kernel-timing", action="store_true",
@@ -368,6 +371,10 @@ def main():
         elem_stride = vl.elem_stride
         hashed_dev = torch.randint(-2**62, 2**62, (shard, 4), dtype=torch.int64, device=dev)
         valid = torch.zeros(shard, dtype=torch.uint8, device=dev)
+        if args.messages:   # the caller's step: message bytes -> SHA-256 -> hashed-message limbs, per call, on the device
+            msgs_dev = torch.randint(0, 256, (shard, args.messages), dtype=torch.uint8, device=dev)
+            digest_dev = torch.zeros((shard, 32), dtype=torch.uint8, device=dev)
+            hm_dev = torch.zeros((shard, _lib.H2R_HASHED_MSG_STREAM_BYTES), dtype=torch.uint8, device=dev)
     # The shard's traces stay resident on the GPU that produced them: with one call per step the calls
     # rotate through `nbuf` trace regions, with several calls per step every call has its own region of the shard's
     # trace.  Zero-filled, so every page is resident before the first (possibly un-warmed) timed step touches it.
@@ -418,6 +425,11 @@ def main():
             chip.pow_mod_fixed_exp(xc[c], e, nc[c], want_trace=True, trace_buf=tb, check_in_field=True,
                                    workspace=ws, out=out[sl], status=status[sl], in_field_buf=fb)
         elif verify:
+            if args.messages:
+                cs = slice(c * chunk, (c + 1) * chunk)
+                _lib.check(_lib.lib().h2r_sha256_hashed_msg_batch(chip._ctx, msgs_dev[cs].data_ptr(), None, args.messages, chunk,
+                                                                  digest_dev[cs].data_ptr(), hashed_dev[cs].data_ptr(), hm_dev[cs].data_ptr(),
+                                                                  hm_dev.shape[1], chip._stream()), "h2r_sha256_hashed_msg_batch")
             pipe.verify_pkcs1v15(xc[c], e, nc[c], hashed_dev[c * chunk:(c + 1) * chunk], tb, ws, out[sl], valid[sl], status[sl])
         else:
             pipe.modpow_public_key(xc[c], e, nc[c], tb, ws, out[sl], status[sl], None if args.no_in_field else fb)
@@ -540,7 +552,9 @@ def main():
             "dtype": "u%d" % w, "data": "synthetic",
             "config": {"workload": wl,
                        "per_gpu_batch": shard, "global_batch": global_batch, "calls_per_step": chunks, "signatures_per_call": chunk,
-                       "path": "verify_pkcs1v15_signature (in-field + modpow + EM check)" if verify else "modpow_public_key",
+                       "path": ("RSASignatureVerifier from %d-byte messages (SHA-256 + hashed-message limbs + in-field + modpow + EM check)" % args.messages
+                                if verify and args.messages else
+                                "verify_pkcs1v15_signature (in-field + modpow + EM check)" if verify else "modpow_public_key"),
                        "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world,
                        "ranks": env.world, "collective_backend": (env.backend + (" (RCCL)" if env.backend == "nccl" else "")) if env.initialised else "none (single process)",
                        "pipeline": (("one launch per step: records of call k + chains of call k+1 (step_kernel), %d buffer sets" % args.pipeline_depth)
@@ -565,6 +579,7 @@ def main():
         if env.world == 1 and args.pmc_traffic == "auto" and dom_ms and per_launch_batch == chunk:
             wl_args = ["--workload", args.workload, "--batch", str(chunk), "--chunks", str(chunks), "--pipeline-depth", str(args.pipeline_depth)]
             wl_args += ["--verify"] if args.verify else []
+            wl_args += ["--messages", str(args.messages)] if args.messages else []
             wl_args += ["--no-pipeline"] if args.no_pipeline else []
             hbm, how = measured_pmc_traffic(wl_args, dom_name.split("<")[0])
             if hbm is not None:

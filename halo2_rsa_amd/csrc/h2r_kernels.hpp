@@ -2728,8 +2728,8 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
     };
     // a range assign's row (main_gate.decompose): four sub-limbs in columns a..d -- the LAST row reversed, so that the last
     // (overflow) term is in column a, and padded with zero terms -- and, in column e, what remains to be composed
-    auto range_row = [&](u32 r, u64 s_lo, u64 s_hi, u32 nsub, u32 sub_bits, u32 rr) {   // sub-limb bytes in (s_lo, s_hi), row rr of the assign
-        U192 c0 = Z, c1 = Z, c2 = Z, c3 = Z, rem = Z;   // (no indexed array: it would live in scratch)
+    auto range_vals = [&](u64 s_lo, u64 s_hi, u32 nsub, u32 sub_bits, u32 rr, U192 &c0, U192 &c1, U192 &c2, U192 &c3, U192 &rem) {   // sub-limb bytes in (s_lo, s_hi), row rr of the assign
+        c0 = Z; c1 = Z; c2 = Z; c3 = Z; rem = Z;        // (no indexed array: it would live in scratch)
         const u32 last = (nsub - 1) / 4;
 #pragma unroll
         for (u32 k = 0; k < 12; ++k) {                   // at most 9 sub-limbs (8 + overflow), three rows
@@ -2744,7 +2744,6 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
                 }
             }
         }
-        row(r, c0, c1, c2, c3, rem);
     };
     // A row has five cells; at most three of them come from the record, the others are constants, flag bytes or staged
     // operands.  Every row is therefore described the same way -- up to three sources (a 16-, 8- or 4-byte load plus an
@@ -2841,32 +2840,38 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
         if (!wd) return Z;
         return U192::make(wd == 1u ? (lo.x & 0xffffffffull) : lo.x, wd == 3u ? lo.y : 0, (mode & 4u) ? (u64)((i64)lo.y >> 63) : ((mode & 8u) ? hi : 0));
     };
+    // Every branch below only CHOOSES the five cell values; the row is staged once, after them.  (With the staging inlined into each
+    // case the lanes of a wave -- which sit in ~25 different row kinds in the is_equal_muled part -- ran ~15 copies of the ten
+    // ds_write_b128 one after the other under disjoint exec masks.)
     auto build = [&](u32 r) {
         if (id.sect == 9) return;
-        if (id.sect == 0) { range_row(r, l0.x, 0, 8, LW / 8, id.j); return; }   // eight sub-limbs, one byte each
-        const U192 c0 = val(l0, h0, m0), c1 = val(l1, h1, m1), c2 = val(l2, h2, m2);
-        if (id.sect == 1) { if (id.kind == ROWK_MUL_ADD) row(r, lim(imm0), lim(imm1), c0, c1, Z); else row(r, Z, Z, Z, Z, Z); return; }
-        if (id.sect == 2) { row(r, c0, lim(imm0), c2, Z, Z); return; }
-        if (id.sect == 3) { if (id.i == 0) row(r, B, Z, Z, Z, Z); else if (id.i == 3) row(r, lim(1), lim(1), lim(1), Z, Z); else row(r, Z, Z, Z, Z, Z); return; }
-        if (id.kind >= ROWK_RANGE_CARRY) { range_row(r, l0.x, l0.y, a.carry_nsub, a.carry_sub_bits, id.kind - ROWK_RANGE_CARRY); return; }
-        const u32 f1 = fl & 0xff, e1 = (fl >> 8) & 0xff, f2 = (fl >> 16) & 0xff, e2 = fl >> 24;
-        switch (id.j) {
-            case 4: case 10: row(r, B, c1, c2, Z, Z); return;
-            case 13: case 18: row(r, c0, c1, c0 - c1, Z, Z, true); return;                        // sub: d = x - y in the field
-            case 14: row(r, lim(f1), lim(f1), lim(f1), Z, Z); return;
-            case 19: row(r, lim(f2), lim(f2), lim(f2), Z, Z); return;
-            case 15: case 20: {                                                                   // [d, 1/d (1 when d = 0), r]
+        U192 v0 = Z, v1 = Z, v2 = Z, v3 = Z, v4 = Z;
+        bool sg0 = false, sg1 = false, sg2 = false, need_inv = false;
+        if (id.sect == 0) range_vals(l0.x, 0, 8, LW / 8, id.j, v0, v1, v2, v3, v4);   // eight sub-limbs, one byte each
+        else if (id.sect == 4 && id.kind >= ROWK_RANGE_CARRY) range_vals(l0.x, l0.y, a.carry_nsub, a.carry_sub_bits, id.kind - ROWK_RANGE_CARRY, v0, v1, v2, v3, v4);
+        else {
+            const U192 c0 = val(l0, h0, m0), c1 = val(l1, h1, m1), c2 = val(l2, h2, m2);
+            if (id.sect == 1) { if (id.kind == ROWK_MUL_ADD) { v0 = lim(imm0); v1 = lim(imm1); v2 = c0; v3 = c1; } }
+            else if (id.sect == 2) { v0 = c0; v1 = lim(imm0); v2 = c2; }
+            else if (id.sect == 3) { if (id.i == 0) v0 = B; else if (id.i == 3) { v0 = lim(1); v1 = lim(1); v2 = lim(1); } }
+            else {
+                const u32 f1 = fl & 0xff, e1 = (fl >> 8) & 0xff, f2 = (fl >> 16) & 0xff, e2 = fl >> 24;
                 const U192 d = c0 - c1;
-                const bool zero = d == Z;
-                row(r, d, lim(1), lim(id.j == 15 ? f1 : f2), Z, Z, false, true);
-                if (!zero && H2R_ADVICE_INV) inverse_cell(reinterpret_cast<u8 *>(stage) + (u64)(r % SR) * ADVICE_ROW_BYTES + 32, d);
-                return;
+                switch (id.j) {
+                    case 4: case 10: v0 = B; v1 = c1; v2 = c2; break;
+                    case 13: case 18: v0 = c0; v1 = c1; v2 = d; sg2 = true; break;                    // sub: d = x - y in the field
+                    case 14: v0 = lim(f1); v1 = v0; v2 = v0; break;
+                    case 19: v0 = lim(f2); v1 = v0; v2 = v0; break;
+                    case 15: case 20: v0 = d; sg0 = true; v1 = lim(1); v2 = lim(id.j == 15 ? f1 : f2); need_inv = !(d == Z); break;   // [d, 1/d (1 when d = 0), r]
+                    case 16: case 21: v0 = lim(id.j == 16 ? f1 : f2); v1 = d; sg1 = true; break;      // [r, d]
+                    case 17: v0 = lim(has_prev ? (eprev >> 24) : 1u); v1 = lim(f1); v2 = lim(e1); break;   // and
+                    case 22: v0 = lim(e1); v1 = lim(f2); v2 = lim(e2); break;                           // and
+                    default: v0 = c0; v1 = c1; v2 = c2; sg2 = id.j == 0; sg0 = id.j == 1; break;
+                }
             }
-            case 16: case 21: row(r, lim(id.j == 16 ? f1 : f2), c0 - c1, Z, Z, Z, false, false, true); return;   // [r, d]
-            case 17: row(r, lim(has_prev ? (eprev >> 24) : 1u), lim(f1), lim(e1), Z, Z); return;  // and
-            case 22: row(r, lim(e1), lim(f2), lim(e2), Z, Z); return;                              // and
-            default: row(r, c0, c1, c2, Z, Z, id.j == 0, id.j == 1); return;
         }
+        row(r, v0, v1, v2, v3, v4, sg2, sg0, sg1);
+        if (need_inv && H2R_ADVICE_INV) inverse_cell(reinterpret_cast<u8 *>(stage) + (u64)(r % SR) * ADVICE_ROW_BYTES + 32, v0);
     };
     static_assert(SR <= 256, "one row per thread and stage");
     plan_and_load(tid < SR ? tid : a.rows);
