@@ -2654,6 +2654,32 @@ __host__ __device__ inline AdviceRowId advice_unpack(u32 v) {
     return id;
 }
 
+// Sources of the is_equal_muled column rows 1..22 (row 0 reads accumulator entries and is planned on its own): per row three
+// codes {type, plane, index = column or column - 1}.  type 1: 16-byte LO entry + 8-byte HI plane behind it (s_wide), 2: a carry-sized
+// entry, 3: a limb-sized entry, 4: the range-assigned carry (CARRY_DUP; the last column compares with QACC instead).
+__host__ __device__ constexpr u32 adv_src(u32 type, u32 plane, u32 minus1 = 0) { return type | (plane << 3) | (minus1 << 9); }
+__host__ __device__ constexpr u32 advice_col_src(u32 j, u32 k) {
+    switch (j * 3 + k) {
+        case 1 * 3 + 0: return adv_src(1, H2R_PL_AMB_LO); case 1 * 3 + 1: return adv_src(2, H2R_PL_CARRY, 1); case 1 * 3 + 2: return adv_src(1, H2R_PL_SUM_LO);
+        case 2 * 3 + 0: return adv_src(2, H2R_PL_CARRY);
+        case 3 * 3 + 0: return adv_src(3, H2R_PL_CMOD);
+        case 4 * 3 + 1: return adv_src(2, H2R_PL_CARRY); case 4 * 3 + 2: return adv_src(1, H2R_PL_NQ1_LO);
+        case 5 * 3 + 0: return adv_src(1, H2R_PL_SUM_LO); case 5 * 3 + 1: return adv_src(1, H2R_PL_NQ1_LO); case 5 * 3 + 2: return adv_src(3, H2R_PL_AMNQ1);
+        case 6 * 3 + 0: return adv_src(3, H2R_PL_CMOD); case 6 * 3 + 1: return adv_src(3, H2R_PL_AMNQ1);
+        case 7 * 3 + 0: return adv_src(2, H2R_PL_QACC, 1); case 7 * 3 + 1: return adv_src(1, H2R_PL_ACCX_LO);
+        case 8 * 3 + 0: return adv_src(2, H2R_PL_QACC);
+        case 9 * 3 + 0: return adv_src(3, H2R_PL_MODACC);
+        case 10 * 3 + 1: return adv_src(2, H2R_PL_QACC); case 10 * 3 + 2: return adv_src(1, H2R_PL_NQ2_LO);
+        case 11 * 3 + 0: return adv_src(1, H2R_PL_ACCX_LO); case 11 * 3 + 1: return adv_src(1, H2R_PL_NQ2_LO); case 11 * 3 + 2: return adv_src(3, H2R_PL_AMNQ2);
+        case 12 * 3 + 0: return adv_src(3, H2R_PL_MODACC); case 12 * 3 + 1: return adv_src(3, H2R_PL_AMNQ2);
+        case 13 * 3 + 0: case 15 * 3 + 0: case 16 * 3 + 0: return adv_src(3, H2R_PL_CMOD);         // is_equal(c, mod_acc)
+        case 13 * 3 + 1: case 15 * 3 + 1: case 16 * 3 + 1: return adv_src(3, H2R_PL_MODACC);
+        case 18 * 3 + 0: case 20 * 3 + 0: case 21 * 3 + 0: return adv_src(2, H2R_PL_CARRY);         // is_equal(carry, dup | acc_extra)
+        case 18 * 3 + 1: case 20 * 3 + 1: case 21 * 3 + 1: return adv_src(4, H2R_PL_CARRY_DUP);
+        default: return 0;                                                                          // 14, 17, 19, 22: flag bytes only
+    }
+}
+
 struct AdviceArgs {
     const u32 *desc;                    // [rows] advice_pack(advice_decode(r))
     const void *opA, *opB; u64 op_stride; const void *n; u64 n_stride;
@@ -2676,7 +2702,11 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
 #endif
     constexpr u32 SR = H2R_ADVICE_SR;                         // rows per stage (40 KB of LDS; 128-208 rows, i.e. four or more workgroups per CU, measured within +-5 % of it)
     __shared__ uint4 stage[SR * (ADVICE_ROW_BYTES / 16)];    // SR rows are built in LDS, then leave as full 16-byte-per-lane lines
+    __shared__ u64 s_off[H2R_PL_COUNT];                      // plane offsets and the column rows' source codes, indexed per LANE below
+    __shared__ u32 s_col_src[ADVICE_COL_ROWS * 3];
     const u32 tid = threadIdx.x;
+    if (tid < H2R_PL_COUNT) s_off[tid] = a.off[tid];
+    if (tid >= 64 && tid < 64 + ADVICE_COL_ROWS * 3) s_col_src[tid - 64] = advice_col_src((tid - 64) / 3, (tid - 64) % 3);
     const u32 item = xcd_contiguous_block(blockIdx.x, gridDim.x);   // every XCD reads and writes a contiguous eighth
     const u32 elem = item / a.T, t = item - elem * a.T;
     if (a.status && a.status[elem]) return;
@@ -2806,26 +2836,27 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
                 const u32 c = id.i;
                 const u32 jmax = c < L ? c : L - 1, im = c < L ? c : c - L;
                 if (id.kind >= ROWK_RANGE_CARRY) s0 = Src{rv.rec + a.off[H2R_PL_CARRY_SUB] + (u64)c * a.carry_sub_stride, rv.rec, 3u};
+                else if (id.j == 0) { s0 = s_acc(false, jmax, im); s1 = c < L ? s_wide(H2R_PL_EQB_LO, c) : s_acc(true, jmax, im); s2 = s_wide(H2R_PL_AMB_LO, c); }
                 else {
-                    switch (id.j) {
-                        case 0: s0 = s_acc(false, jmax, im); s1 = c < L ? s_wide(H2R_PL_EQB_LO, c) : s_acc(true, jmax, im); s2 = s_wide(H2R_PL_AMB_LO, c); break;
-                        case 1: s0 = s_wide(H2R_PL_AMB_LO, c); if (c) s1 = s_carry(H2R_PL_CARRY, c - 1); s2 = s_wide(H2R_PL_SUM_LO, c); break;
-                        case 2: s0 = s_carry(H2R_PL_CARRY, c); break;
-                        case 3: s0 = s_limb(H2R_PL_CMOD, c); break;
-                        case 4: s1 = s_carry(H2R_PL_CARRY, c); s2 = s_wide(H2R_PL_NQ1_LO, c); break;
-                        case 5: s0 = s_wide(H2R_PL_SUM_LO, c); s1 = s_wide(H2R_PL_NQ1_LO, c); s2 = s_limb(H2R_PL_AMNQ1, c); break;
-                        case 6: s0 = s_limb(H2R_PL_CMOD, c); s1 = s_limb(H2R_PL_AMNQ1, c); break;
-                        case 7: if (c) s0 = s_carry(H2R_PL_QACC, c - 1); s1 = s_wide(H2R_PL_ACCX_LO, c); break;
-                        case 8: s0 = s_carry(H2R_PL_QACC, c); break;
-                        case 9: s0 = s_limb(H2R_PL_MODACC, c); break;
-                        case 10: s1 = s_carry(H2R_PL_QACC, c); s2 = s_wide(H2R_PL_NQ2_LO, c); break;
-                        case 11: s0 = s_wide(H2R_PL_ACCX_LO, c); s1 = s_wide(H2R_PL_NQ2_LO, c); s2 = s_limb(H2R_PL_AMNQ2, c); break;
-                        case 12: s0 = s_limb(H2R_PL_MODACC, c); s1 = s_limb(H2R_PL_AMNQ2, c); break;
-                        case 13: case 15: case 16: s0 = s_limb(H2R_PL_CMOD, c); s1 = s_limb(H2R_PL_MODACC, c); break;      // is_equal(c, mod_acc)
-                        case 18: case 20: case 21:                                                                         // is_equal(carry, dup | acc_extra)
-                            s0 = s_carry(H2R_PL_CARRY, c); s1 = c < C - 1 ? s_carry(H2R_PL_CARRY_DUP, c) : s_carry(H2R_PL_QACC, c); break;
-                        default: break;                       // 14, 17, 19, 22: flag bytes only
-                    }
+                    // rows 1..22: the lanes of a wave sit in ~22 different rows -- one table-driven plan for all of them instead
+                    // of a switch whose cases ran one after the other under disjoint exec masks
+                    auto tab_src = [&](u32 code) -> Src {
+                        const u32 type = code & 7u, minus1 = (code >> 9) & 1u;
+                        u32 pl = (code >> 3) & 63u;
+                        if (type == 0u || (minus1 && c == 0)) return s_none();
+                        if (type == 4u && c == C - 1) pl = H2R_PL_QACC;
+                        const u32 idx = c - minus1;
+                        const u32 esz = type == 1u ? 16u : (type == 3u ? LW / 8 : CB);
+                        const u8 *lo = rv.rec + s_off[pl] + (u64)idx * esz;
+                        if (type == 1u) {
+                            if constexpr (LW == 64) return Src{lo, rv.rec + s_off[pl + 1] + (u64)idx * 8, 3u | 8u};
+                            else return Src{lo, rv.rec, 3u | 4u};
+                        }
+                        return Src{lo, rv.rec, type == 3u ? (LW == 64 ? 2u : 1u) : (LW == 64 ? 3u : 2u)};
+                    };
+                    s0 = tab_src(s_col_src[id.j * 3]); s1 = tab_src(s_col_src[id.j * 3 + 1]); s2 = tab_src(s_col_src[id.j * 3 + 2]);
+                }
+                if (id.kind < ROWK_RANGE_CARRY) {
                     fp = rv.rec + a.off[H2R_PL_FLAGS] + (u64)c * 4;
                     fpp = c ? fp - 4 : fp; has_prev = c ? 1u : 0u;
                 }
