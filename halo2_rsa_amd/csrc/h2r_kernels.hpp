@@ -2583,6 +2583,7 @@ struct RecView {   // reads of one record through the documented plane layout (i
 #define H2R_ADVICE_INV 1
 #endif
 constexpr u32 ADVICE_ROW_BYTES = 160;
+constexpr u32 ADVICE_STAGE_ROWS = 256;   // rows built in LDS per stage (= the workgroup size)
 constexpr u32 ADVICE_COL_ROWS = 23;    // main-gate rows of one is_equal_muled column besides the carry's range assign
 __host__ __device__ inline u32 advice_rows_per_record(u32 L, u32 carry_nsub) {
     const u32 C = 2 * L - 1, nrc = (carry_nsub + 3) / 4;
@@ -2693,14 +2694,14 @@ struct AdviceArgs {
     FieldConsts f;                      // field modulus + Montgomery constants (is_zero's inverse witness)
 };
 
+#ifndef H2R_ADV_ABL
+#define H2R_ADV_ABL 0   // developer ablations: 1 no build, 2 no plan, no build, 3 no write-out, 4 range / column rows built as zero rows, 5 their loads dropped
+#endif
 template <int LW>
 __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
     using limb_t = typename LimbT<LW>::type;
     __shared__ u64 sa[128], sb_[128], sq[128], sn[128], sr[128];
-#ifndef H2R_ADVICE_SR
-#define H2R_ADVICE_SR 256
-#endif
-    constexpr u32 SR = H2R_ADVICE_SR;                         // rows per stage (40 KB of LDS; 128-208 rows, i.e. four or more workgroups per CU, measured within +-5 % of it)
+    constexpr u32 SR = ADVICE_STAGE_ROWS;                         // rows per stage (40 KB of LDS; 128-208 rows, i.e. four or more workgroups per CU, measured within +-5 % of it)
     __shared__ uint4 stage[SR * (ADVICE_ROW_BYTES / 16)];    // SR rows are built in LDS, then leave as full 16-byte-per-lane lines
     __shared__ u64 s_off[H2R_PL_COUNT];                      // plane offsets and the column rows' source codes, indexed per LANE below
     __shared__ u32 s_col_src[ADVICE_COL_ROWS * 3];
@@ -2761,6 +2762,18 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
     auto range_vals = [&](u64 s_lo, u64 s_hi, u32 nsub, u32 sub_bits, u32 rr, U192 &c0, U192 &c1, U192 &c2, U192 &c3, U192 &rem) {   // sub-limb bytes in (s_lo, s_hi), row rr of the assign
         c0 = Z; c1 = Z; c2 = Z; c3 = Z; rem = Z;        // (no indexed array: it would live in scratch)
         const u32 last = (nsub - 1) / 4;
+        if (sub_bits == 8) {   // byte sub-limbs (every 64-bit-limb shape): the bytes ARE the value -- what remains = the value with its low 4 rr bytes cleared
+            const u64 hi = nsub > 8 ? s_hi & ((1ull << (8 * (nsub - 8))) - 1) : 0;
+            auto byte = [&](u32 k) -> u64 { return k < nsub ? ((k < 8 ? s_lo >> (8 * k) : hi >> (8 * (k - 8))) & 0xff) : 0; };
+            const u32 k0 = rr < last ? 4 * rr : nsub - 1;        // the last row is reversed: cell q holds sub-limb nsub - 1 - q
+            const u32 n_last = nsub - 4 * last;                  // terms of the last row
+            c0 = lim(byte(k0));
+            c1 = lim(rr < last ? byte(k0 + 1) : (n_last > 1 ? byte(k0 - 1) : 0));
+            c2 = lim(rr < last ? byte(k0 + 2) : (n_last > 2 ? byte(k0 - 2) : 0));
+            c3 = lim(rr < last ? byte(k0 + 3) : (n_last > 3 ? byte(k0 - 3) : 0));
+            rem = rr == 0 ? U192::make(s_lo, hi, 0) : (rr == 1 ? U192::make(s_lo & ~0xffffffffull, hi, 0) : (rr == 2 ? U192::make(0, hi, 0) : U192::make(0, hi & ~0xffffffffull, 0)));
+            return;
+        }
 #pragma unroll
         for (u32 k = 0; k < 12; ++k) {                   // at most 9 sub-limbs (8 + overflow), three rows
             if (k >= 4 * rr && k < nsub) {
@@ -2803,7 +2816,7 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
     auto s_limb = [&](int pl, u32 idx) -> Src { return Src{rv.rec + a.off[pl] + (u64)idx * (LW / 8), rv.rec, LW == 64 ? 2u : 1u}; };
     // per-row state that lives across the write-out of the previous rows
     AdviceRowId id; id.kind = ROWK_NOP; id.sect = 9; id.i = id.j = id.qn = 0;
-    u32 m0 = 0, m1 = 0, m2 = 0, fl = 0, eprev = 1, has_prev = 0;
+    u32 m0 = 0, m1 = 0, m2 = 0, fl = 0, eprev = 1, has_prev = 0, rcur = 0;   // rcur: the row planned last (built next)
     u64 imm0 = 0, imm1 = 0, h0 = 0, h1 = 0, h2 = 0;
     ulonglong2 l0 = make_ulonglong2(0, 0), l1 = l0, l2 = l0;
     auto fetch = [&](const Src &sc, ulonglong2 &lo, u64 &hi, u32 &mode) {
@@ -2813,6 +2826,7 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
         hi = *reinterpret_cast<const u64 *>(sc.hi);
     };
     auto plan_and_load = [&](u32 r) {
+        rcur = r;
         Src s0 = s_none(), s1 = s_none(), s2 = s_none();
         const u8 *fp = rv.rec, *fpp = rv.rec;   // flag words of the column and of the one before it
         has_prev = 0;
@@ -2862,6 +2876,7 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
                 }
             }
         }
+        if (H2R_ADV_ABL == 5 && (id.sect == 4 || id.sect == 0)) { s0 = s_none(); s1 = s_none(); s2 = s_none(); fp = rv.rec; fpp = rv.rec; }
         fetch(s0, l0, h0, m0); fetch(s1, l1, h1, m1); fetch(s2, l2, h2, m2);
         fl = *reinterpret_cast<const u32 *>(fp);
         eprev = *reinterpret_cast<const u32 *>(fpp);
@@ -2876,6 +2891,7 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
     // ds_write_b128 one after the other under disjoint exec masks.)
     auto build = [&](u32 r) {
         if (id.sect == 9) return;
+        if (H2R_ADV_ABL == 4 && (id.sect == 4 || id.sect == 0)) { row(r, Z, Z, Z, Z, Z); return; }
         U192 v0 = Z, v1 = Z, v2 = Z, v3 = Z, v4 = Z;
         bool sg0 = false, sg1 = false, sg2 = false, need_inv = false;
         if (id.sect == 0) range_vals(l0.x, 0, 8, LW / 8, id.j, v0, v1, v2, v3, v4);   // eight sub-limbs, one byte each
@@ -2905,13 +2921,14 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
         if (need_inv && H2R_ADVICE_INV) inverse_cell(reinterpret_cast<u8 *>(stage) + (u64)(r % SR) * ADVICE_ROW_BYTES + 32, v0);
     };
     static_assert(SR <= 256, "one row per thread and stage");
-    plan_and_load(tid < SR ? tid : a.rows);
+    if (H2R_ADV_ABL != 2) plan_and_load(tid < SR ? tid : a.rows);
     for (u32 r0 = 0; r0 < a.rows; r0 += SR) {
-      build(r0 + tid);
+      if (H2R_ADV_ABL != 1 && H2R_ADV_ABL != 2) build(rcur);
       __syncthreads();
-      if (r0 + SR < a.rows) plan_and_load(tid < SR ? r0 + SR + tid : a.rows);   // in flight while this stage leaves for HBM
+      if (H2R_ADV_ABL != 2) if (r0 + SR < a.rows) plan_and_load(tid < SR ? r0 + SR + tid : a.rows);   // in flight while this stage leaves for HBM
       const u32 n_rows = a.rows - r0 < SR ? a.rows - r0 : SR;
       uint4 *dst = reinterpret_cast<uint4 *>(out + (u64)r0 * ADVICE_ROW_BYTES);
+      if (H2R_ADV_ABL != 3)
       for (u32 k = tid; k < n_rows * (ADVICE_ROW_BYTES / 16); k += 256) {
           const uint4 v = stage[k];
           st16(reinterpret_cast<u8 *>(dst + k), ((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z);
