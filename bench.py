@@ -336,11 +336,19 @@ def main():
     chunks = args.chunks if args.chunks else (1 if args.gpus == 1 else 4)
     chunk = args.batch if args.batch else (1024 if args.gpus == 1 else 8192 // chunks)
     if use_h2r_dist:
-        from halo2_rsa_amd.dist import H2RDist
+        from halo2_rsa_amd.dist import H2RDist, agree_all
+        h2r_env = None
         try:
-            env = H2RDist(H.BigIntChip(w, bits, device=env.local_rank), env.rank, env.world, env.local_rank)
-        except Exception as ex:   # no librccl, communicator refused ...: torch.distributed instead (every rank fails alike)
-            sys.stderr.write("h2r_dist unavailable (%s): falling back to torch.distributed\n" % str(ex)[:200])
+            h2r_env = H2RDist(H.BigIntChip(w, bits, device=env.local_rank), env.rank, env.world, env.local_rank)
+        except Exception as ex:   # no librccl, communicator refused ...: torch.distributed instead
+            sys.stderr.write("h2r_dist unavailable on rank %d (%s)\n" % (env.rank, str(ex)[:200]))
+        # every rank takes the same backend: the C-ABI communicator only if it came up everywhere
+        if agree_all("h2r_dist_up", h2r_env is not None, env.rank, env.world):
+            env = h2r_env
+        else:
+            if h2r_env is not None:
+                h2r_env._lib.h2r_dist_destroy(h2r_env._d)
+            sys.stderr.write("rank %d: falling back to torch.distributed\n" % env.rank)
             env.init("nccl")
     # configuration broadcast (rank 0 decides): the only pre-run collective
     e, chunk, chunks, steps, warmup = env.broadcast_ints([e, chunk, chunks, args.steps, args.warmup])

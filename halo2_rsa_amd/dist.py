@@ -121,6 +121,32 @@ def exchange_bytes(key: str, payload, rank: int, world: int) -> bytes:
     return out
 
 
+def agree_all(key: str, ok: bool, rank: int, world: int, timeout_s: float = 120.0) -> bool:
+    """True iff EVERY rank passed ok = True (same out-of-band key-value socket as exchange_bytes; no collective library
+    involved).  bench.py uses it so that all ranks take the same collective backend: a communicator that came up on some
+    ranks only must not leave the others waiting in a different library."""
+    import time
+    from datetime import timedelta
+    if world == 1:
+        return bool(ok)
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true"
+    store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29531")), world,
+                          is_master=(rank == 0 and not agent), timeout=timedelta(seconds=timeout_s))
+    store.add(key + "/bad", 0 if ok else 1)
+    store.add(key + "/n", 1)
+    deadline = time.time() + timeout_s
+    while int(store.add(key + "/n", 0)) < world:
+        if time.time() > deadline:
+            return False
+        time.sleep(0.01)
+    all_ok = int(store.add(key + "/bad", 0)) == 0
+    store.add(key + "/seen", 1)                 # keep rank 0's server alive until everybody has read the verdict
+    if rank == 0 and not agent:
+        while int(store.add(key + "/seen", 0)) < world and time.time() < deadline:
+            time.sleep(0.01)
+    return all_ok
+
+
 class H2RDist:
     """The same plumbing over libh2r's own RCCL exports (h2r_dist_*: SURVEY section 2 component C1 behind the C ABI) -- what a
     Rust prover service binds.  Only the 128-byte RCCL id travels out of band: here through a torch.distributed.TCPStore at

@@ -63,6 +63,11 @@ def test_gloo_world2_harness(tmp_path):
         got = exchange_bytes("test_id", payload, env.rank, env.world)
         assert got == bytes(range(128))
         print("ID_OK %%d" %% env.rank)
+        # the backend agreement of bench.py: all ranks ok -> True everywhere; one rank not ok -> False everywhere
+        from halo2_rsa_amd.dist import agree_all
+        assert agree_all("agree_a", True, env.rank, env.world) is True
+        assert agree_all("agree_b", env.rank != 1, env.rank, env.world) is False
+        print("AGREE_OK %%d" %% env.rank)
     ''' % ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
@@ -71,3 +76,4 @@ def test_gloo_world2_harness(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     assert "GLOO_OK" in out.stdout
     assert "ID_OK 0" in out.stdout and "ID_OK 1" in out.stdout
+    assert "AGREE_OK 0" in out.stdout and "AGREE_OK 1" in out.stdout
