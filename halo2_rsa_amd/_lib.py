@@ -91,7 +91,7 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_pow_trace_flatten_ex", "h2r_trace_emit_stream", "h2r_pow_trace_emit_stream", "h2r_mul_mod_trace_check", "h2r_pow_trace_check",
            "h2r_advice_rows", "h2r_mul_mod_emit_advice", "h2r_pow_trace_emit_advice", "h2r_pow_advice_rows", "h2r_advice_row_kinds",
            "h2r_advice_fixed_row", "h2r_fresh_op_advice_rows", "h2r_fresh_op_row_kinds", "h2r_fresh_op_emit_advice",
-           "h2r_verify_advice_rows", "h2r_verify_row_kinds", "h2r_verify_emit_advice", "h2r_verify_layout_var", "h2r_verify_pkcs1v15_var_batch",
+           "h2r_verify_advice_rows", "h2r_verify_row_kinds", "h2r_verify_emit_advice", "h2r_verify_layout_var", "h2r_verify_pkcs1v15_var_batch", "h2r_pipeline_verify_pkcs1v15_var",
            "h2r_sha256_hashed_msg_batch", "h2r_signature_verifier_batch", "h2r_hashed_msg_advice_rows", "h2r_hashed_msg_row_kinds",
            "h2r_hashed_msg_emit_advice",
            "h2r_lookup_config_default", "h2r_lookup_config_custom", "h2r_lookup_table_image", "h2r_lookup_hist_records",
@@ -169,6 +169,7 @@ def lib():
     L.h2r_verify_trace_flatten.argtypes = [vp, ctypes.POINTER(H2RVerifyLayout), vp, vp]
     L.h2r_verify_layout_var.argtypes = [vp, u32, u32, ctypes.POINTER(H2RVerifyLayout)]
     L.h2r_verify_pkcs1v15_var_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp, u64, u32, vp, vp, vp, vp, vp, vp]
+    L.h2r_pipeline_verify_pkcs1v15_var.argtypes = [vp, vp, vp, vp, u32, u32, vp, u64, u32, vp, vp, vp, vp, vp, vp]
     L.h2r_pipeline_verify_pkcs1v15.argtypes = L.h2r_verify_pkcs1v15_batch.argtypes
     L.h2r_fresh_op_layout.argtypes = [vp, u32, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u32)]
     L.h2r_fresh_op_batch.argtypes = [vp, u32, vp, vp, vp, u64, u32, vp, vp, vp, vp, vp]

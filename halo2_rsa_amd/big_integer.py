@@ -702,6 +702,14 @@ class Pipeline:
                                                  is_valid.data_ptr(), status.data_ptr(), workspace.data_ptr(), self.chip._stream()),
               "h2r_pipeline_verify_pkcs1v15")
 
+    def verify_pkcs1v15_var(self, sig: AssignedInteger, e: AssignedInteger, exp_limb_bits: int, n: AssignedInteger, hashed, trace_buf, workspace,
+                            powed, is_valid, status):
+        """The RSAPubE::Var arm (src/chip.rs:108-110); `trace_buf` sized batch * h2r_verify_layout_var's elem_stride."""
+        check(lib().h2r_pipeline_verify_pkcs1v15_var(self._p, sig.data_ptr(), n.data_ptr(), e.data_ptr(), e.num_limbs(), exp_limb_bits,
+                                                     hashed.data_ptr(), sig.batch, self.chip._flags(n, sig.batch), trace_buf.data_ptr(),
+                                                     powed.data_ptr(), is_valid.data_ptr(), status.data_ptr(), workspace.data_ptr(),
+                                                     self.chip._stream()), "h2r_pipeline_verify_pkcs1v15_var")
+
     def join(self):
         check(lib().h2r_pipeline_join(self._p, self.chip._stream()), "h2r_pipeline_join")
 

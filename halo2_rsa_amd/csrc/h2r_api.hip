@@ -1732,6 +1732,22 @@ int32_t h2r_pipeline_verify_pkcs1v15(h2r_pipeline *p, const void *sig, const voi
                           });
 }
 
+// RSAPubE::Var arm of the pipelined verifier (src/chip.rs:108-110)
+int32_t h2r_pipeline_verify_pkcs1v15_var(h2r_pipeline *p, const void *sig, const void *n, const void *e_limbs, uint32_t e_num_limbs,
+                                         uint32_t exp_limb_bits, const uint64_t *hashed, uint64_t batch, uint32_t flags, void *trace,
+                                         void *powed_out, uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+    if (!p || !sig || !n || !e_limbs || !hashed || !trace || !powed_out || !status || !workspace) return H2R_E_NULL;
+    h2r_verify_layout vl;
+    const int32_t rc = h2r_verify_layout_var(p->ctx, e_num_limbs, exp_limb_bits, &vl);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return pipeline_issue(p, sig, n, nullptr, 0, batch, flags, trace, vl.pow, vl.elem_stride, powed_out, status, workspace, st,
+                          [&]() -> int32_t {
+                              if (batch == 0) return H2R_OK;
+                              return launch_verify_aux(p->ctx, sig, n, hashed, batch, flags, trace, vl, powed_out, is_valid_out, status, st);
+                          }, 1, false, nullptr, 0, e_limbs, e_num_limbs, exp_limb_bits);
+}
+
 int32_t h2r_fresh_op_layout(const h2r_ctx *ctx, uint32_t op, uint64_t *elem_stride, uint64_t *stream_bytes, uint32_t *value_limbs) {
     if (!ctx) return H2R_E_NULL;
     if (op >= FRESH_OP_COUNT) return H2R_E_UNSUPPORTED;

@@ -380,6 +380,11 @@ int32_t h2r_pipeline_verify_pkcs1v15(h2r_pipeline *p, const void *sig, const voi
                                      uint8_t *is_valid_out, uint8_t *status, void *workspace,
                                      h2r_stream_t stream);
 
+int32_t h2r_pipeline_verify_pkcs1v15_var(h2r_pipeline *p, const void *sig, const void *n, const void *e_limbs,
+                                         uint32_t e_num_limbs, uint32_t exp_limb_bits, const uint64_t *hashed,
+                                         uint64_t batch, uint32_t flags, void *trace, void *powed_out,
+                                         uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream);
+
 /* ---- the CALLER of the path: RSASignatureVerifier::verify_pkcs1v15_signature (src/lib.rs:183-246) ----------
  * The reference hashes the signed message bytes with its SHA-256 chip (:205-209), reverses the 32 digest bytes (:210-213),
  * composes them eight at a time into four 64-bit limbs -- limb_val = 0; limb_val = mul_add(2^(8j), hashed_bytes[8i + j], limb_val)

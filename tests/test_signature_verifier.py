@@ -323,6 +323,31 @@ def test_verify_with_a_variable_exponent(H, golden):
             _, valid, s_em = o.pkcs1v15_em_check(out, o.limbs(hashed[i], 4))
             want = np.concatenate([s_if, s_pow, s_em])
             assert np.array_equal(res.flatten(i), want) and np.array_equal(res_m.flatten(i), want), (exp_limb_bits, i)
+    # the pipelined form (h2r_pipeline_verify_pkcs1v15_var): three calls over two buffer sets give the batch export's element bytes
+    import ctypes
+    rsa = H.RSAChip(2048, 5)
+    chip = rsa.bigint_chip()
+    pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Var(H.UnassignedInteger(np.array([[1, 0, 0, 2]] * 3, dtype=np.uint64)))))
+    sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64)))
+    ref = rsa.verify_pkcs1v15_signature(pk, hashed, sg)
+    vl = ref.layout
+    hashed_dev = ref.inputs[2]
+    pipe = H.Pipeline(chip, depth=2)
+    bufs = [dict(trace=torch.zeros(3 * vl.elem_stride, dtype=torch.uint8, device="cuda"), powed=torch.zeros((3, 32), dtype=torch.int64, device="cuda"),
+                 valid=torch.zeros(3, dtype=torch.uint8, device="cuda"), status=torch.zeros(3, dtype=torch.uint8, device="cuda"),
+                 ws=torch.zeros(chip.workspace_bytes(3, vl.pow.num_mul_mods), dtype=torch.uint8, device="cuda")) for _ in range(2)]
+    for k in range(3):
+        b = bufs[k & 1]
+        pipe.verify_pkcs1v15_var(sg.c, pk.e.e, 5, pk.n, hashed_dev, b["trace"], b["ws"], b["powed"], b["valid"], b["status"])
+    pipe.join()
+    torch.cuda.synchronize()
+    for b in bufs:
+        assert b["valid"].cpu().tolist() == [1, 1, 0] and b["status"].cpu().tolist() == [0, 0, 0]
+        assert torch.equal(b["powed"], ref.powed.limbs_dev)
+        got = H.rsa.VerifyResult(b["valid"], H.AssignedInteger(b["powed"], 64), b["status"], b["trace"], vl, chip)
+        for i in range(3):
+            assert np.array_equal(got.flatten(i), ref.flatten(i)), i
+    pipe.close()
     # a limb that does not fit exp_limb_bits: main_gate.to_bits cannot be satisfied (big_integer/chip.rs:677)
     rsa = H.RSAChip(2048, 5)
     pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Var(H.UnassignedInteger(np.array([[1, 0, 0, 32]] * 3, dtype=np.uint64)))))

@@ -55,4 +55,9 @@ python tools/offpath_timing.py > $O/offpath_kernels.txt 2>&1
 python tools/var_exponent_timing.py > $O/var_exponent.txt 2>&1
 python tools/sweep.py CONFIG rsa4096-w64 --workload rsa4096_e65537 --steps 20 --warmup 3 >> $O/other_configs.txt 2>&1
 python tools/lookup_timing.py > $O/lookup_timing.txt 2>&1
+# the caller side (RSASignatureVerifier from message bytes) and the row-program images: kernel stats of the whole verifier, their timing tools
+(cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_verify_msgs -o r -- python $R/bench.py --verify --messages 128 --steps 20 --warmup 3 --no-cpu-baseline --pmc-traffic off > $O/kt_verify_msgs.log 2>&1)
+timeout 300 python bench.py --steps 40 --warmup 4 --verify --messages 128 --no-cpu-baseline --pmc-traffic off > $O/bench_verify_from_messages.json 2>/dev/null
+python tools/sha256_timing.py > $O/sha256_timing.txt 2>&1
+python tools/fresh_advice_timing.py > $O/fresh_advice_timing.txt 2>&1
 tail -1 $O/bench_pipeline.json | cut -c1-700; tail -1 $O/bench_serial.json | cut -c1-200; tail -1 $O/bench_pipeline_d3s2.json | cut -c1-200; tail -1 $O/bench_torchrun1_config3_shard.json | cut -c1-300; tail -3 $O/bench_torchrun1.err; cat $O/other_configs.txt; cat $O/emit_timing.txt; cat $O/pmc_traffic.json | head -40
