@@ -370,7 +370,7 @@ def main():
     dev = "cuda:%d" % env.local_rank
     nbuf = 1 if args.no_pipeline else args.pipeline_depth   # scratch sets the calls rotate through
     elem_stride = pl.elem_stride
-    verify = args.verify and not args.no_pipeline and (w, bits) == (64, 2048)
+    verify = (args.verify or args.messages > 0) and not args.no_pipeline and (w, bits) == (64, 2048)   # --messages implies --verify
     if verify:   # whole verifier witness: the element also holds the in-field and encoded-message regions
         import ctypes
         vl = _lib.H2RVerifyLayout()

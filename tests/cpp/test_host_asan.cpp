@@ -68,6 +68,38 @@ static int one_shape(uint32_t w, uint32_t L, uint32_t field) {
         REQUIRE(h2r_verify_layout_fixed(ctx, e3, 3, &vl) == H2R_OK);
         auto e = heap<uint8_t>(vl.elem_stride), o = heap<uint8_t>(vl.stream_bytes);
         REQUIRE(h2r_verify_trace_flatten(ctx, &vl, e.get(), o.get()) == H2R_OK);
+        // the Var arm's layout and its flatten; the row programs of the verify element and of the hashed-message limbs (host-side walks)
+        h2r_verify_layout vv;
+        REQUIRE(h2r_verify_layout_var(ctx, 4, 5, &vv) == H2R_OK && vv.pow.num_mul_mods == 40);
+        auto ve = heap<uint8_t>(vv.elem_stride), vo = heap<uint8_t>(vv.stream_bytes);
+        REQUIRE(h2r_verify_trace_flatten(ctx, &vv, ve.get(), vo.get()) == H2R_OK);
+        uint64_t sec[4];
+        const uint64_t vr = h2r_verify_advice_rows(ctx, &vl, sec);
+        REQUIRE(vr == sec[0] + sec[1] + sec[2] + sec[3] && h2r_verify_advice_rows(ctx, &vv, nullptr) == 0);
+        auto vk = heap<uint8_t>(vr);
+        REQUIRE(h2r_verify_row_kinds(ctx, &vl, vk.get()) == H2R_OK);
+        const uint32_t hr = h2r_hashed_msg_advice_rows(ctx);
+        REQUIRE(hr == 68);
+        auto hk = heap<uint8_t>(hr);
+        REQUIRE(h2r_hashed_msg_row_kinds(ctx, hk.get()) == H2R_OK);
+        for (uint32_t i = 0; i < hr; ++i) { h2r_fixed_row fr; REQUIRE(h2r_advice_fixed_row(ctx, nullptr, hk[i], &fr) == H2R_OK); }
+    }
+    for (uint32_t opk = 0; opk < H2R_OP_COUNT; ++opk) {   // row programs of the Fresh-integer family
+        const uint32_t fr_rows = h2r_fresh_op_advice_rows(ctx, opk, 0);
+        REQUIRE(fr_rows > 0);
+        auto fk = heap<uint8_t>(fr_rows);
+        REQUIRE(h2r_fresh_op_row_kinds(ctx, opk, 0, fk.get()) == H2R_OK);
+    }
+    {   // the oracle's SHA-256 / hashed-message restatement through exact-size buffers (55 / 56 / 64-byte padding edges)
+        for (size_t len : {0u, 1u, 55u, 56u, 63u, 64u, 65u, 119u, 120u, 128u, 200u}) {
+            auto m = heap<uint8_t>(len ? len : 1), d = heap<uint8_t>(32), hs = heap<uint8_t>(h2ro_hashed_msg_stream_bytes());
+            for (size_t i = 0; i < len; ++i) m[i] = (uint8_t)next64();
+            uint64_t h4[4];
+            h2ro_sha256(m.get(), len, d.get());
+            h2ro_hashed_msg(d.get(), h4, hs.get());
+            REQUIRE(h4[0] == (((uint64_t)d[24] << 56) | ((uint64_t)d[25] << 48) | ((uint64_t)d[26] << 40) | ((uint64_t)d[27] << 32) |
+                              ((uint64_t)d[28] << 24) | ((uint64_t)d[29] << 16) | ((uint64_t)d[30] << 8) | d[31]));
+        }
     }
     // lookup argument + advice image: host side
     h2r_lookup_config cfg;
