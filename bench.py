@@ -433,11 +433,11 @@ def main():
             chip.pow_mod_fixed_exp(xc[c], e, nc[c], want_trace=True, trace_buf=tb, check_in_field=True,
                                    workspace=ws, out=out[sl], status=status[sl], in_field_buf=fb)
         elif verify:
-            if args.messages:
+            if args.messages:   # the SHA-256 / hashed-message step rides on the call's step launch (h2r_pipeline_signature_verifier)
                 cs = slice(c * chunk, (c + 1) * chunk)
-                _lib.check(_lib.lib().h2r_sha256_hashed_msg_batch(chip._ctx, msgs_dev[cs].data_ptr(), None, args.messages, chunk,
-                                                                  digest_dev[cs].data_ptr(), hashed_dev[cs].data_ptr(), hm_dev[cs].data_ptr(),
-                                                                  hm_dev.shape[1], chip._stream()), "h2r_sha256_hashed_msg_batch")
+                pipe.signature_verifier(msgs_dev[cs], None, args.messages, xc[c], e, nc[c], tb, ws, out[sl], valid[sl], status[sl],
+                                        hashed_dev[cs], digest_dev[cs], hm_dev[cs])
+                return r
             pipe.verify_pkcs1v15(xc[c], e, nc[c], hashed_dev[c * chunk:(c + 1) * chunk], tb, ws, out[sl], valid[sl], status[sl])
         else:
             pipe.modpow_public_key(xc[c], e, nc[c], tb, ws, out[sl], status[sl], None if args.no_in_field else fb)

@@ -92,7 +92,7 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_advice_rows", "h2r_mul_mod_emit_advice", "h2r_pow_trace_emit_advice", "h2r_pow_advice_rows", "h2r_advice_row_kinds",
            "h2r_advice_fixed_row", "h2r_fresh_op_advice_rows", "h2r_fresh_op_row_kinds", "h2r_fresh_op_emit_advice",
            "h2r_verify_advice_rows", "h2r_verify_row_kinds", "h2r_verify_emit_advice", "h2r_verify_layout_var", "h2r_verify_pkcs1v15_var_batch", "h2r_pipeline_verify_pkcs1v15_var",
-           "h2r_sha256_hashed_msg_batch", "h2r_signature_verifier_batch", "h2r_hashed_msg_advice_rows", "h2r_hashed_msg_row_kinds",
+           "h2r_sha256_hashed_msg_batch", "h2r_signature_verifier_batch", "h2r_pipeline_signature_verifier", "h2r_hashed_msg_advice_rows", "h2r_hashed_msg_row_kinds",
            "h2r_hashed_msg_emit_advice",
            "h2r_lookup_config_default", "h2r_lookup_config_custom", "h2r_lookup_table_image", "h2r_lookup_hist_records",
            "h2r_lookup_hist_values", "h2r_lookup_hist_values_strided", "h2r_lookup_hist_verify", "h2r_lookup_hist_fresh_op", "h2r_lookup_workspace_bytes", "h2r_lookup_permuted_columns", "h2r_field_eval",
@@ -226,6 +226,8 @@ def lib():
     L.h2r_sha256_hashed_msg_batch.argtypes = [vp, vp, vp, u64, u64, vp, vp, vp, u64, vp]
     L.h2r_signature_verifier_batch.argtypes = [vp, vp, vp, u64, vp, vp, ctypes.c_char_p, ctypes.c_size_t, u64, u32, vp, vp, u64, vp, vp, vp,
                                                vp, vp, vp, vp]
+    L.h2r_pipeline_signature_verifier.argtypes = [vp, vp, vp, u64, vp, vp, ctypes.c_char_p, ctypes.c_size_t, u64, u32, vp, vp, u64, vp, vp, vp,
+                                                  vp, vp, vp, vp]
     L.h2r_hashed_msg_advice_rows.argtypes = [vp]
     L.h2r_hashed_msg_advice_rows.restype = u32
     L.h2r_hashed_msg_row_kinds.argtypes = [vp, vp]

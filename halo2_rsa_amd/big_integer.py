@@ -702,6 +702,20 @@ class Pipeline:
                                                  is_valid.data_ptr(), status.data_ptr(), workspace.data_ptr(), self.chip._stream()),
               "h2r_pipeline_verify_pkcs1v15")
 
+    def signature_verifier(self, msgs, msg_off, fixed_len: int, sig: AssignedInteger, e: int, n: AssignedInteger, trace_buf, workspace, powed,
+                           is_valid, status, hashed, digest=None, hm_trace=None):
+        """Pipelined RSASignatureVerifier::verify_pkcs1v15_signature from message bytes (src/lib.rs:183-246): `msgs` uint8 on the device,
+        `msg_off` int64 [batch + 1] (or None: every message has fixed_len bytes); the SHA-256 / hashed-message step rides on the call's
+        step launch.  `hashed`: int64 [batch, 4] output (the verifier's operand), digest uint8 [batch, 32] / hm_trace uint8 [batch, 288] optional."""
+        eb = _e_bytes(e)
+        check(lib().h2r_pipeline_signature_verifier(self._p, msgs.data_ptr(), msg_off.data_ptr() if msg_off is not None else None, fixed_len,
+                                                    sig.data_ptr(), n.data_ptr(), eb, len(eb), sig.batch, self.chip._flags(n, sig.batch),
+                                                    trace_buf.data_ptr(), hm_trace.data_ptr() if hm_trace is not None else None,
+                                                    hm_trace.shape[1] if hm_trace is not None else 0,
+                                                    digest.data_ptr() if digest is not None else None, hashed.data_ptr(), powed.data_ptr(),
+                                                    is_valid.data_ptr(), status.data_ptr(), workspace.data_ptr(), self.chip._stream()),
+              "h2r_pipeline_signature_verifier")
+
     def verify_pkcs1v15_var(self, sig: AssignedInteger, e: AssignedInteger, exp_limb_bits: int, n: AssignedInteger, hashed, trace_buf, workspace,
                             powed, is_valid, status):
         """The RSAPubE::Var arm (src/chip.rs:108-110); `trace_buf` sized batch * h2r_verify_layout_var's elem_stride."""

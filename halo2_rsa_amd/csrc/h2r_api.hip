@@ -1252,7 +1252,7 @@ constexpr u64 kStepMax = 4096;   // elements per step launch: a larger call is w
 // One step: the records described by `ta` (an earlier sub-batch) and the chains described by `ca`, one launch on `st`.
 extern "C++" {
 template <int K, int NW, int LW, int L>
-hipError_t launch_step_t(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
+hipError_t launch_step_t(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, const Sha256Args *sha, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
     constexpr int IPB = (64 * NW) / TraceGeo<L>::TPI;                   // record items per workgroup of this launch
     const u64 rec_blocks = (ta.n_items + IPB - 1) / IPB;
     // chain workgroups per CU: four 4-wave ones (what runs next to a record kernel on two queues), two 6- or 8-wave ones
@@ -1265,19 +1265,22 @@ hipError_t launch_step_t(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs 
     AuxArgs none;
     std::memset(&none, 0, sizeof none);
     const u64 n_aux = aa ? aa->batch : 0;
-    hipExtLaunchKernelGGL((step_kernel<K, NW, LW, L>), dim3((unsigned)(n_chain + rec_blocks + n_aux)), dim3(64 * NW), 0, st, ea, eb, 0,
-                          ca, ta, aa ? *aa : none, n_chain, (u32)rec_blocks);
+    Sha256Args no_sha;
+    std::memset(&no_sha, 0, sizeof no_sha);
+    const u64 n_sha = sha ? ((sha->batch + 64 * NW - 1) / (64 * NW) + 7) & ~7ull : 0;   // one thread per message; a multiple of 8 (the XCD of what follows)
+    hipExtLaunchKernelGGL((step_kernel<K, NW, LW, L>), dim3((unsigned)(n_sha + n_chain + rec_blocks + n_aux)), dim3(64 * NW), 0, st, ea, eb, 0,
+                          ca, ta, aa ? *aa : none, sha ? *sha : no_sha, (u32)n_sha, n_chain, (u32)rec_blocks);
     return hipGetLastError();
 }
 }  // extern "C++"
-hipError_t launch_step(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
+hipError_t launch_step(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, const Sha256Args *sha, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
     const StepShape *s = step_shape(c);
     if (!s) return hipErrorInvalidValue;
-    if (s->L == 32) return launch_step_t<64, 4, 64, 32>(c, ca, ta, aa, st, ea, eb);
-    if (s->L == 16) return launch_step_t<32, 4, 64, 16>(c, ca, ta, aa, st, ea, eb);
-    if (s->L == 128) return launch_step_t<128, 8, 32, 128>(c, ca, ta, aa, st, ea, eb);
-    if (s->L == 64) return launch_step_t<128, 8, 64, 64>(c, ca, ta, aa, st, ea, eb);
-    return launch_step_t<96, 6, 64, 48>(c, ca, ta, aa, st, ea, eb);
+    if (s->L == 32) return launch_step_t<64, 4, 64, 32>(c, ca, ta, aa, sha, st, ea, eb);
+    if (s->L == 16) return launch_step_t<32, 4, 64, 16>(c, ca, ta, aa, sha, st, ea, eb);
+    if (s->L == 128) return launch_step_t<128, 8, 32, 128>(c, ca, ta, aa, sha, st, ea, eb);
+    if (s->L == 64) return launch_step_t<128, 8, 64, 64>(c, ca, ta, aa, sha, st, ea, eb);
+    return launch_step_t<96, 6, 64, 48>(c, ca, ta, aa, sha, st, ea, eb);
 }
 u32 step_shared_bytes(const h2r_ctx *c) {
     const StepShape *s = step_shape(c);
@@ -1479,7 +1482,9 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
                        uint32_t flags, void *trace, const h2r_pow_layout &pl, uint64_t elem_stride, void *out,
                        uint8_t *status, void *workspace, hipStream_t st, const std::function<int32_t()> &after_chain,
                        u32 check_in_field = 1, bool assume_empty = false, const AuxArgs *witness_aux = nullptr, u32 witness_aux_lds = 0,
-                       const void *e_limbs = nullptr, u32 e_num_limbs = 0, u32 exp_limb_bits = 0) {
+                       const void *e_limbs = nullptr, u32 e_num_limbs = 0, u32 exp_limb_bits = 0, const Sha256Args *sha = nullptr) {
+    // sha (nullable): the SHA-256 / hashed-message step of RSASignatureVerifier for THIS call's messages; `after_chain` consumes
+    // its output.  It rides on the call's first step launch when there is one, and is a kernel of its own on `st` otherwise.
     // witness_aux (nullable): what `after_chain` would launch, when that is a kernel whose output belongs to the call's
     // TRACE (the assert_in_field witness): a call issued as one-launch steps writes it together with its records
     // e_limbs (nullable): per-element variable exponents (BigIntChip::pow_mod, chip.rs:664-696) instead of the fixed e_le
@@ -1527,9 +1532,21 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
     const Workspace wp = workspace_plan(lo.limb_bytes, ctx->L, batch, T ? T : 1);
     u8 *ws = reinterpret_cast<u8 *>(round_up(reinterpret_cast<u64>(workspace), 256));
     const u64 in_bytes = (u64)ctx->K * 4, ws_elem = (u64)(T ? T : 1) * 4 * ctx->L * lo.limb_bytes;
+    auto launch_sha_alone = [&]() -> int32_t {
+        if (!sha || sha->batch == 0) return H2R_OK;
+        ProfScope ps(H2R_KERNEL_SHA256, st, true);
+        hipExtLaunchKernelGGL(sha256_kernel, dim3((unsigned)((sha->batch + 63) / 64)), dim3(64), 0, st, ps.a, ps.on ? ps.b : nullptr, 0, *sha);
+        HIP_TRY(hipGetLastError());
+        return H2R_OK;
+    };
+    if (!as_steps || !p->pending) {   // no step launch to ride on (two-queue form, or a call that starts a train with a chain kernel)
+        rc = launch_sha_alone();
+        if (rc) return rc;
+    }
     if (as_steps) {
         const bool aux_as_role = witness_aux && witness_aux->batch && witness_aux_lds <= step_shared_bytes(ctx);
         bool aux_done = false;
+        bool sha_done = !sha || !p->pending;
         u64 off = 0;
         for (size_t i = 0; i < sizes.size(); off += sizes[i], ++i) {
             const u64 nb = sizes[i];
@@ -1549,8 +1566,9 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
                 // which are therefore read in `stream` order inside the call, like every other input
                 const bool with_aux = aux_as_role && !aux_done;
                 ProfScope ps(H2R_KERNEL_STEP, st, true);
-                HIP_TRY(launch_step(ctx, pa.ca, p->pending_ta, with_aux ? witness_aux : nullptr, st, ps.a, ps.b));
+                HIP_TRY(launch_step(ctx, pa.ca, p->pending_ta, with_aux ? witness_aux : nullptr, sha_done ? nullptr : sha, st, ps.a, ps.b));
                 aux_done = aux_done || with_aux;
+                sha_done = true;
             } else {
                 ProfScope ps(H2R_KERNEL_CHAIN, st, true);
                 HIP_TRY(launch_chain(ctx, pa.ca, false, st, ps.a, ps.b));
@@ -1746,6 +1764,31 @@ int32_t h2r_pipeline_verify_pkcs1v15_var(h2r_pipeline *p, const void *sig, const
                               if (batch == 0) return H2R_OK;
                               return launch_verify_aux(p->ctx, sig, n, hashed, batch, flags, trace, vl, powed_out, is_valid_out, status, st);
                           }, 1, false, nullptr, 0, e_limbs, e_num_limbs, exp_limb_bits);
+}
+
+// RSASignatureVerifier::verify_pkcs1v15_signature (src/lib.rs:183-246) as a pipelined call: the SHA-256 / hashed-message step of this
+// call's messages is a role of the call's step launch (hidden next to the records of the previous call), the in-field /
+// encoded-message kernel follows on `stream`.
+int32_t h2r_pipeline_signature_verifier(h2r_pipeline *p, const uint8_t *msgs, const uint64_t *msg_off, uint64_t fixed_len, const void *sig,
+                                        const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch, uint32_t flags, void *trace,
+                                        void *hm_trace, uint64_t hm_stride, uint8_t *digest_out, uint64_t *hashed_out, void *powed_out,
+                                        uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+    if (!p || !sig || !n || !hashed_out || !trace || !powed_out || !status || !workspace || (!msgs && (msg_off || fixed_len))) return H2R_E_NULL;
+    if (hm_trace && hm_stride == 0) hm_stride = HM_REGION;
+    if ((reinterpret_cast<u64>(digest_out) | reinterpret_cast<u64>(hashed_out) | reinterpret_cast<u64>(hm_trace) | hm_stride) & 15) return H2R_E_SHAPE;
+    if (hm_trace && hm_stride < HM_REGION) return H2R_E_SHAPE;
+    h2r_verify_layout vl;
+    const int32_t rc = h2r_verify_layout_fixed(p->ctx, e_le, e_len, &vl);
+    if (rc) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Sha256Args sa;
+    sa.msgs = msgs; sa.off = msg_off; sa.fixed_len = fixed_len; sa.batch = batch;
+    sa.digest = digest_out; sa.hashed = hashed_out; sa.region = static_cast<u8 *>(hm_trace); sa.region_stride = hm_stride;
+    return pipeline_issue(p, sig, n, e_le, e_len, batch, flags, trace, vl.pow, vl.elem_stride, powed_out, status, workspace, st,
+                          [&]() -> int32_t {
+                              if (batch == 0) return H2R_OK;
+                              return launch_verify_aux(p->ctx, sig, n, hashed_out, batch, flags, trace, vl, powed_out, is_valid_out, status, st);
+                          }, 1, false, nullptr, 0, nullptr, 0, 0, &sa);
 }
 
 int32_t h2r_fresh_op_layout(const h2r_ctx *ctx, uint32_t op, uint64_t *elem_stride, uint64_t *stream_bytes, uint32_t *value_limbs) {

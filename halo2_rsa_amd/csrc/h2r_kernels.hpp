@@ -1754,16 +1754,35 @@ __global__ __launch_bounds__(64) void aux_kernel(AuxArgs a) {
 // The workgroup size is the chain role's (64 * NW threads); the record role packs as many items into it as fit
 // (trace_block<LW, L, 64 * NW>: RSA-2048 four items in 256 threads as ever; 128 x 32-bit limbs two 256-thread items in the
 // 512 threads of an eight-wave chain workgroup; RSA-3072 four 96-thread items in the 384 threads of a six-wave one).
+// SHA-256 of ragged messages + the hashed-message limbs (h2r_sha256.hpp; RSASignatureVerifier, reference src/lib.rs:205-239).  The
+// arguments live here because the step launch can carry that work as one more role.
+struct Sha256Args {
+    const u8 *msgs; const u64 *off; u64 fixed_len;   // off == nullptr: message e = msgs[e * fixed_len, (e + 1) * fixed_len)
+    u64 batch;
+    u8 *digest;          // nullable, 32 bytes per element
+    u64 *hashed;         // nullable, 4 limbs per element
+    u8 *region; u64 region_stride;   // nullable
+};
+template <int NT> __device__ void sha256_role(const Sha256Args &a, u32 blk, u32 *w);   // h2r_sha256.hpp
+
 template <int K, int NW, int LW, int L>
 union StepShared {
     ChainLds<K, NW> chain; TraceShared<LW, L, 64 * NW> trace; uint4 aux[sizeof(TraceShared<LW, L, 64 * NW>) / 16];
     __device__ StepShared() {}
 };
 template <int K, int NW, int LW, int L>
-__global__ __launch_bounds__(64 * NW, H2R_CHAIN_MINB) void step_kernel(ChainArgs ca, TraceArgs ta, AuxArgs aa, u32 n_chain, u32 n_rec) {
+__global__ __launch_bounds__(64 * NW, H2R_CHAIN_MINB) void step_kernel(ChainArgs ca, TraceArgs ta, AuxArgs aa, Sha256Args sa, u32 n_sha, u32 n_chain, u32 n_rec) {
     static_assert((64 * NW) % TraceGeo<L>::TPI == 0, "the record role's items tile the chain role's workgroup");
+    static_assert(sizeof(StepShared<K, NW, LW, L>) >= 64 * 64 * NW, "the SHA role keeps sixteen schedule words per thread in the roles' LDS");
     __shared__ StepShared<K, NW, LW, L> sh;
-    const u32 b = blockIdx.x;
+    if (blockIdx.x < n_sha) {
+        // FIRST in dispatch order (n_sha is a multiple of 8, like n_chain): the verifier's SHA-256 of THIS call's messages, one thread
+        // per message -- a long, latency-bound role (three compressions of 64 dependent rounds), so it has to start with the launch;
+        // dispatched last it stretched the launch's tail by 40 us.  Its consumer (the encoded-message kernel) runs behind the launch.
+        sha256_role<64 * NW>(sa, blockIdx.x, reinterpret_cast<u32 *>(&sh));
+        return;
+    }
+    const u32 b = blockIdx.x - n_sha;
     if (b < n_chain) {
         for (u64 elem = b; elem < ca.batch; elem += n_chain) {
             if (elem != b) __syncthreads();   // every wave is done with the previous element's LDS
@@ -1773,10 +1792,10 @@ __global__ __launch_bounds__(64 * NW, H2R_CHAIN_MINB) void step_kernel(ChainArgs
         // (a record role of a few workgroups per CU that WALK the records was tried: inlined into a loop the body spills 25
         //  registers at this launch's 80, as a real call it runs at 4.1 TB/s -- one workgroup per four records it is)
         trace_block<LW, L, 64 * NW>(ta, b - n_chain, n_rec, sh.trace);
-    } else if (threadIdx.x < 64 && b - n_chain - n_rec < aa.batch) {
+    } else if (b - n_chain - n_rec < aa.batch) {
         // last in dispatch order: these short workgroups fill the slots the record role's tail leaves (in front of the record
         // role they cost the step 3-5 us)
-        aux_wave<LW>(aa, b - n_chain - n_rec, (int)threadIdx.x, sh.aux);
+        if (threadIdx.x < 64) aux_wave<LW>(aa, b - n_chain - n_rec, (int)threadIdx.x, sh.aux);
     }
 }
 

@@ -21,14 +21,6 @@ namespace h2r {
 
 constexpr u32 HM_BYTES_OFF = 0, HM_RUN_OFF = 32, HM_REGION = 288;   // == H2R_HASHED_MSG_STREAM_BYTES
 
-struct Sha256Args {
-    const u8 *msgs; const u64 *off; u64 fixed_len;   // off == nullptr: message e = msgs[e * fixed_len, (e + 1) * fixed_len)
-    u64 batch;
-    u8 *digest;          // nullable, 32 bytes per element
-    u64 *hashed;         // nullable, 4 limbs per element
-    u8 *region; u64 region_stride;   // nullable
-};
-
 __device__ __forceinline__ u32 sha_rotr(u32 x, u32 n) { return __builtin_amdgcn_alignbit(x, x, n); }
 
 #define H2R_SHA_K(X) \
@@ -68,6 +60,38 @@ __device__ __forceinline__ void sha256_compress(u32 (&h)[8], u32 (&w)[16]) {
     h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
 
+// digest, hashed-message limbs and the composition stream of element e from its final state
+__device__ __forceinline__ void sha256_outputs(const Sha256Args &a, u64 e, const u32 (&h)[8]) {
+    if (a.digest) {
+        uint4 *d = reinterpret_cast<uint4 *>(a.digest + e * 32);
+        d[0] = make_uint4(__builtin_bswap32(h[0]), __builtin_bswap32(h[1]), __builtin_bswap32(h[2]), __builtin_bswap32(h[3]));
+        d[1] = make_uint4(__builtin_bswap32(h[4]), __builtin_bswap32(h[5]), __builtin_bswap32(h[6]), __builtin_bswap32(h[7]));
+    }
+    // hashed_bytes.reverse() (src/lib.rs:213) makes byte k the digest's byte 31 - k, so limb i = sum_j byte[8i + j] 2^(8j)
+    // (:225-237) is the big-endian pair (h[6 - 2i], h[7 - 2i])
+    u64 limb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) limb[i] = ((u64)h[6 - 2 * i] << 32) | h[7 - 2 * i];
+    if (a.hashed) {
+        ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(a.hashed + e * 4);
+        ho[0] = make_ulonglong2(limb[0], limb[1]); ho[1] = make_ulonglong2(limb[2], limb[3]);
+    }
+    if (a.region) {
+        u8 *r = a.region + e * a.region_stride;
+        // the reversed byte cells, little-endian inside each limb: the 32 bytes ARE the four limbs' bytes in memory order
+        pst16(r + HM_BYTES_OFF, limb[0], limb[1]); pst16(r + HM_BYTES_OFF + 16, limb[2], limb[3]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {   // limb_val after byte j and after byte j + 1
+                const u64 lo = j == 6 ? limb[i] & 0x00ffffffffffffffull : limb[i] & ((1ull << (8 * (j + 1))) - 1);
+                const u64 hi = j == 6 ? limb[i] : limb[i] & ((1ull << (8 * (j + 2))) - 1);
+                pst16(r + HM_RUN_OFF + 8 * (8 * i + j), lo, hi);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void sha256_kernel(Sha256Args a) {
     const u64 e = (u64)blockIdx.x * 64 + threadIdx.x;
     if (e >= a.batch) return;
@@ -101,34 +125,60 @@ __global__ __launch_bounds__(64) void sha256_kernel(Sha256Args a) {
         }
         sha256_compress(h, w);
     }
-    if (a.digest) {
-        uint4 *d = reinterpret_cast<uint4 *>(a.digest + e * 32);
-        d[0] = make_uint4(__builtin_bswap32(h[0]), __builtin_bswap32(h[1]), __builtin_bswap32(h[2]), __builtin_bswap32(h[3]));
-        d[1] = make_uint4(__builtin_bswap32(h[4]), __builtin_bswap32(h[5]), __builtin_bswap32(h[6]), __builtin_bswap32(h[7]));
-    }
-    // hashed_bytes.reverse() (src/lib.rs:213) makes byte k the digest's byte 31 - k, so limb i = sum_j byte[8i + j] 2^(8j)
-    // (:225-237) is the big-endian pair (h[6 - 2i], h[7 - 2i])
-    u64 limb[4];
+    sha256_outputs(a, e, h);
+}
+
+// ---- the same hash as a ROLE of the step launch (step_kernel, h2r_kernels.hpp) -------------------------------------------------------
+// The register budget there is the chain role's (80 VGPRs), so the sixteen-word schedule window lives in LDS (word-major: thread
+// tid's word t at w[t * NT + tid], no bank conflicts, no barriers -- every thread owns its column) and the 64 rounds are a loop.
+// About three times the instructions of sha256_kernel per block, which does not matter inside a 190 us launch.
+__constant__ u32 SHA256_K[64] = {
+#define X(v) v##u,
+    H2R_SHA_K(X)
+#undef X
+};
+template <int NT>
+__device__ void sha256_role(const Sha256Args &a, u32 blk, u32 *w) {
+    const u32 tid = threadIdx.x;
+    const u64 e = (u64)blk * NT + tid;
+    if (e >= a.batch) return;
+    u64 beg, len;
+    if (a.off) { beg = a.off[e]; const u64 end = a.off[e + 1]; len = end >= beg ? end - beg : 0; }
+    else { beg = e * a.fixed_len; len = a.fixed_len; }
+    const u8 *m = a.msgs + beg;
+    u32 h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    const u64 n_blocks = (len + 9 + 63) / 64;
+    u32 *wt = w + tid;
+    for (u64 bk = 0; bk < n_blocks; ++bk) {
+        const u64 p0 = bk * 64;
+#pragma unroll 1
+        for (u32 t = 0; t < 16; ++t) {
+            u32 v = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) limb[i] = ((u64)h[6 - 2 * i] << 32) | h[7 - 2 * i];
-    if (a.hashed) {
-        ulonglong2 *ho = reinterpret_cast<ulonglong2 *>(a.hashed + e * 4);
-        ho[0] = make_ulonglong2(limb[0], limb[1]); ho[1] = make_ulonglong2(limb[2], limb[3]);
-    }
-    if (a.region) {
-        u8 *r = a.region + e * a.region_stride;
-        // the reversed byte cells, little-endian inside each limb: the 32 bytes ARE the four limbs' bytes in memory order
-        pst16(r + HM_BYTES_OFF, limb[0], limb[1]); pst16(r + HM_BYTES_OFF + 16, limb[2], limb[3]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {   // limb_val after byte j and after byte j + 1
-                const u64 lo = j == 6 ? limb[i] & 0x00ffffffffffffffull : limb[i] & ((1ull << (8 * (j + 1))) - 1);
-                const u64 hi = j == 6 ? limb[i] : limb[i] & ((1ull << (8 * (j + 2))) - 1);
-                pst16(r + HM_RUN_OFF + 8 * (8 * i + j), lo, hi);
+            for (u32 q = 0; q < 4; ++q) {
+                const u64 p = p0 + 4 * t + q;
+                const u32 byte = p < len ? m[p] : (p == len ? 0x80u : 0u);
+                v = (v << 8) | byte;
             }
+            wt[t * NT] = v;
         }
+        if (bk == n_blocks - 1) { const u64 bits = len * 8; wt[14 * NT] = (u32)(bits >> 32); wt[15 * NT] = (u32)bits; }
+        u32 va = h[0], vb = h[1], vc = h[2], vd = h[3], ve = h[4], vf = h[5], vg = h[6], vh = h[7];
+#pragma unroll 2
+        for (u32 t = 0; t < 64; ++t) {
+            u32 x = wt[(t & 15) * NT];
+            if (t >= 16) {
+                const u32 w15 = wt[((t + 1) & 15) * NT], w2 = wt[((t + 14) & 15) * NT], w7 = wt[((t + 9) & 15) * NT];
+                x += (sha_rotr(w15, 7) ^ sha_rotr(w15, 18) ^ (w15 >> 3)) + w7 + (sha_rotr(w2, 17) ^ sha_rotr(w2, 19) ^ (w2 >> 10));
+                wt[(t & 15) * NT] = x;
+            }
+            const u32 t1 = vh + (sha_rotr(ve, 6) ^ sha_rotr(ve, 11) ^ sha_rotr(ve, 25)) + ((ve & vf) ^ (~ve & vg)) + SHA256_K[t] + x;
+            const u32 t2 = (sha_rotr(va, 2) ^ sha_rotr(va, 13) ^ sha_rotr(va, 22)) + ((va & vb) ^ (va & vc) ^ (vb & vc));
+            vh = vg; vg = vf; vf = ve; ve = vd + t1; vd = vc; vc = vb; vb = va; va = t1 + t2;
+        }
+        h[0] += va; h[1] += vb; h[2] += vc; h[3] += vd; h[4] += ve; h[5] += vf; h[6] += vg; h[7] += vh;
     }
+    sha256_outputs(a, e, h);
 }
 
 }  // namespace h2r

@@ -413,6 +413,16 @@ int32_t h2r_signature_verifier_batch(const h2r_ctx *ctx, const uint8_t *msgs, co
                                      uint32_t flags, void *trace, void *hm_trace, uint64_t hm_stride, uint8_t *digest_out,
                                      uint64_t *hashed_out, void *powed_out, uint8_t *is_valid_out, uint8_t *status,
                                      void *workspace, h2r_stream_t stream);
+/* Pipelined form (see h2r_pipeline_create): the SHA-256 / hashed-message step of THIS call's messages rides on the call's step launch
+ * as one more role -- next to the records of the previous call, at no cost to the step -- where the shape has one-launch steps and a
+ * call is in flight; otherwise it is a kernel of its own on `stream` in front of the call.  The messages are read in stream order
+ * inside the call, like every other input; digest_out / hashed_out / hm_trace / powed_out / is_valid_out / status are
+ * stream-ordered on `stream`, the trace follows the pipeline's join rule. */
+int32_t h2r_pipeline_signature_verifier(h2r_pipeline *p, const uint8_t *msgs, const uint64_t *msg_off, uint64_t fixed_len,
+                                        const void *sig, const void *n, const uint8_t *e_le_bytes, size_t e_len, uint64_t batch,
+                                        uint32_t flags, void *trace, void *hm_trace, uint64_t hm_stride, uint8_t *digest_out,
+                                        uint64_t *hashed_out, void *powed_out, uint8_t *is_valid_out, uint8_t *status,
+                                        void *workspace, h2r_stream_t stream);
 uint32_t h2r_hashed_msg_advice_rows(const h2r_ctx *ctx);
 int32_t h2r_hashed_msg_row_kinds(const h2r_ctx *ctx, uint8_t *kinds_out);
 int32_t h2r_hashed_msg_emit_advice(const h2r_ctx *ctx, const void *hm_trace, uint64_t hm_stride, uint64_t batch,

@@ -354,3 +354,62 @@ def test_verify_with_a_variable_exponent(H, golden):
     res = rsa.verify_pkcs1v15_signature(pk, hashed, rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64))))
     torch.cuda.synchronize()
     assert res.status.cpu().tolist() == [H.H2R_E_SHAPE] * 3 and res.is_valid.cpu().tolist() == [0, 0, 0]
+
+
+@pytest.mark.gpu
+def test_pipelined_signature_verifier_sha_role(H, golden):
+    """h2r_pipeline_signature_verifier: calls of 1,024 signatures (one-launch steps: the SHA-256 / hashed-message role rides inside the
+    step launch from the second call on; the first call of the train hashes in a kernel of its own) and calls of 3 signatures
+    (two-queue form) over two buffer sets, ragged messages with a different length mix per call: every digest / limb set / stream
+    equals the C oracle's, is_valid and the element bytes of sampled signatures equal the batch export's; the messages of a call
+    may be overwritten as soon as the call returns (they are read in stream order inside it)."""
+    import torch
+    kats = golden["rsa_kats"]
+    rng = random.Random(21)
+    rsa = H.RSAChip(2048, 5)
+    chip = rsa.bigint_chip()
+    for B in (1024, 3):
+        ns = [int(kats[i % 3]["n"]) for i in range(B)]
+        sigs = [int(kats[i % 3]["sig"]) for i in range(B)]
+        pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Fix(65537)))
+        sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64)))
+        vl = rsa._verify_layout(pk)
+        pipe = H.Pipeline(chip, depth=2)
+        sets = [dict(trace=torch.zeros(B * vl.elem_stride, dtype=torch.uint8, device="cuda"), powed=torch.zeros((B, 32), dtype=torch.int64, device="cuda"),
+                     valid=torch.zeros(B, dtype=torch.uint8, device="cuda"), status=torch.zeros(B, dtype=torch.uint8, device="cuda"),
+                     hashed=torch.zeros((B, 4), dtype=torch.int64, device="cuda"), digest=torch.zeros((B, 32), dtype=torch.uint8, device="cuda"),
+                     hm=torch.zeros((B, 288), dtype=torch.uint8, device="cuda"),
+                     ws=torch.zeros(chip.workspace_bytes(B, vl.pow.num_mul_mods), dtype=torch.uint8, device="cuda")) for _ in range(2)]
+        staging = torch.zeros(B * 200 + 16, dtype=torch.uint8, device="cuda")     # ONE message staging buffer, refilled per call
+        off_dev = torch.zeros(B + 1, dtype=torch.int64, device="cuda")
+        calls = []
+        for k in range(4):
+            msgs = [b"hello world" if (i % 3 != 2 and (i + k) % 5) else bytes(rng.getrandbits(8) for _ in range(rng.choice([0, 1, 55, 56, 64, 119, 128, 190])))
+                    for i in range(B)]
+            buf, off = H.pack_messages(msgs, torch.device("cuda", 0))
+            staging[:buf.numel()].copy_(buf)            # stream-ordered refill of the staging buffers, right behind the previous call
+            off_dev.copy_(off)
+            b = sets[k & 1]
+            pipe.signature_verifier(staging, off_dev, 0, sg.c, 65537, pk.n, b["trace"], b["ws"], b["powed"], b["valid"], b["status"], b["hashed"],
+                                    b["digest"], b["hm"])
+            calls.append(msgs)
+            if k >= 2:                                   # check the set this call used before it is reused (k + 2)
+                pass
+        pipe.join()
+        torch.cuda.synchronize()
+        for k in (2, 3):                                 # the last user of each buffer set
+            b, msgs = sets[k & 1], calls[k]
+            digest, hm, hashed = b["digest"].cpu().numpy(), b["hm"].cpu().numpy(), b["hashed"].cpu().numpy().view(np.uint64)
+            valid = b["valid"].cpu().tolist()
+            assert b["status"].cpu().tolist() == [0] * B
+            for i in range(B):
+                d = OL.sha256(msgs[i])
+                limbs, st = OL.hashed_msg(d)
+                assert digest[i].tobytes() == d and np.array_equal(hashed[i], limbs) and np.array_equal(hm[i], st), (B, k, i)
+                assert valid[i] == (1 if (msgs[i] == b"hello world" and i % 3 != 2) else 0), (B, k, i)
+            ref = rsa.verify_pkcs1v15_signature(pk, b["hashed"], sg)
+            torch.cuda.synchronize()
+            got = H.rsa.VerifyResult(b["valid"], H.AssignedInteger(b["powed"], 64), b["status"], b["trace"], vl, chip)
+            for i in ([0, 1, 2, 511, 1023] if B == 1024 else [0, 1, 2]):
+                assert np.array_equal(got.flatten(i), ref.flatten(i)), (B, k, i)
+        pipe.close()
