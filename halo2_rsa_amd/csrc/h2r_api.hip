@@ -676,6 +676,8 @@ int32_t h2r_square_mod_batch(const h2r_ctx *ctx, const void *a, const void *n, u
 namespace {
 int32_t launch_verify_aux(const h2r_ctx *ctx, const void *sig, const void *n, const uint64_t *hashed, uint64_t batch, uint32_t flags,
                           void *trace, const h2r_verify_layout &vl, void *powed_out, uint8_t *is_valid_out, uint8_t *status, hipStream_t st);
+AuxArgs verify_aux_args(const h2r_ctx *ctx, const void *sig, const void *n, const uint64_t *hashed, uint64_t batch, uint32_t flags,
+                        void *trace, const h2r_verify_layout &vl, void *powed_out, uint8_t *is_valid_out, uint8_t *status);
 int32_t launch_in_field(const h2r_ctx *ctx, const void *x, const void *n, uint64_t batch, uint32_t flags, void *in_field_trace, hipStream_t st);
 int32_t in_field_args(const h2r_ctx *ctx, const void *x, const void *n, uint64_t batch, uint32_t flags, void *in_field_trace, AuxArgs *aa, u32 *lds);
 }
@@ -1252,7 +1254,7 @@ constexpr u64 kStepMax = 4096;   // elements per step launch: a larger call is w
 // One step: the records described by `ta` (an earlier sub-batch) and the chains described by `ca`, one launch on `st`.
 extern "C++" {
 template <int K, int NW, int LW, int L>
-hipError_t launch_step_t(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, const Sha256Args *sha, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
+hipError_t launch_step_t(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, const AuxArgs *va, const Sha256Args *sha, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
     constexpr int IPB = (64 * NW) / TraceGeo<L>::TPI;                   // record items per workgroup of this launch
     const u64 rec_blocks = (ta.n_items + IPB - 1) / IPB;
     // chain workgroups per CU: four 4-wave ones (what runs next to a record kernel on two queues), two 6- or 8-wave ones
@@ -1268,19 +1270,22 @@ hipError_t launch_step_t(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs 
     Sha256Args no_sha;
     std::memset(&no_sha, 0, sizeof no_sha);
     const u64 n_sha = sha ? ((sha->batch + 64 * NW - 1) / (64 * NW) + 7) & ~7ull : 0;   // one thread per message; a multiple of 8 (the XCD of what follows)
-    hipExtLaunchKernelGGL((step_kernel<K, NW, LW, L>), dim3((unsigned)(n_sha + n_chain + rec_blocks + n_aux)), dim3(64 * NW), 0, st, ea, eb, 0,
-                          ca, ta, aa ? *aa : none, sha ? *sha : no_sha, (u32)n_sha, n_chain, (u32)rec_blocks);
+    const dim3 grid((unsigned)(n_sha + n_chain + rec_blocks + n_aux));
+    if (va) hipExtLaunchKernelGGL((step_kernel<K, NW, LW, L, true>), grid, dim3(64 * NW), 0, st, ea, eb, 0,
+                                  ca, ta, aa ? *aa : none, *va, sha ? *sha : no_sha, (u32)n_sha, n_chain, (u32)rec_blocks);
+    else hipExtLaunchKernelGGL((step_kernel<K, NW, LW, L, false>), grid, dim3(64 * NW), 0, st, ea, eb, 0,
+                               ca, ta, aa ? *aa : none, none, sha ? *sha : no_sha, (u32)n_sha, n_chain, (u32)rec_blocks);
     return hipGetLastError();
 }
 }  // extern "C++"
-hipError_t launch_step(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, const Sha256Args *sha, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
+hipError_t launch_step(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, const AuxArgs *va, const Sha256Args *sha, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
     const StepShape *s = step_shape(c);
     if (!s) return hipErrorInvalidValue;
-    if (s->L == 32) return launch_step_t<64, 4, 64, 32>(c, ca, ta, aa, sha, st, ea, eb);
-    if (s->L == 16) return launch_step_t<32, 4, 64, 16>(c, ca, ta, aa, sha, st, ea, eb);
-    if (s->L == 128) return launch_step_t<128, 8, 32, 128>(c, ca, ta, aa, sha, st, ea, eb);
-    if (s->L == 64) return launch_step_t<128, 8, 64, 64>(c, ca, ta, aa, sha, st, ea, eb);
-    return launch_step_t<96, 6, 64, 48>(c, ca, ta, aa, sha, st, ea, eb);
+    if (s->L == 32) return launch_step_t<64, 4, 64, 32>(c, ca, ta, aa, va, sha, st, ea, eb);
+    if (s->L == 16) return launch_step_t<32, 4, 64, 16>(c, ca, ta, aa, va, sha, st, ea, eb);
+    if (s->L == 128) return launch_step_t<128, 8, 32, 128>(c, ca, ta, aa, va, sha, st, ea, eb);
+    if (s->L == 64) return launch_step_t<128, 8, 64, 64>(c, ca, ta, aa, va, sha, st, ea, eb);
+    return launch_step_t<96, 6, 64, 48>(c, ca, ta, aa, va, sha, st, ea, eb);
 }
 u32 step_shared_bytes(const h2r_ctx *c) {
     const StepShape *s = step_shape(c);
@@ -1482,7 +1487,10 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
                        uint32_t flags, void *trace, const h2r_pow_layout &pl, uint64_t elem_stride, void *out,
                        uint8_t *status, void *workspace, hipStream_t st, const std::function<int32_t()> &after_chain,
                        u32 check_in_field = 1, bool assume_empty = false, const AuxArgs *witness_aux = nullptr, u32 witness_aux_lds = 0,
-                       const void *e_limbs = nullptr, u32 e_num_limbs = 0, u32 exp_limb_bits = 0, const Sha256Args *sha = nullptr) {
+                       const void *e_limbs = nullptr, u32 e_num_limbs = 0, u32 exp_limb_bits = 0, const Sha256Args *sha = nullptr,
+                       const AuxArgs *verify_aux = nullptr) {
+    // verify_aux (nullable): the verifier's in-field + encoded-message witness of the whole call (what `after_chain` launches as a
+    // kernel): when every sub-batch of the call goes out as a step launch, the chain role writes it element by element instead
     // sha (nullable): the SHA-256 / hashed-message step of RSASignatureVerifier for THIS call's messages; `after_chain` consumes
     // its output.  It rides on the call's first step launch when there is one, and is a kernel of its own on `st` otherwise.
     // witness_aux (nullable): what `after_chain` would launch, when that is a kernel whose output belongs to the call's
@@ -1547,6 +1555,11 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
         const bool aux_as_role = witness_aux && witness_aux->batch && witness_aux_lds <= step_shared_bytes(ctx);
         bool aux_done = false;
         bool sha_done = !sha || !p->pending;
+        // the verifier's witness inside the chain role: only when the whole call is step launches (a call that starts a train keeps
+        // the kernel behind it), the roles' LDS holds its staging, and -- the hashed limbs being an INPUT of that role -- only when
+        // they were there before the launch (not when this very launch's SHA role produces them)
+        const AuxGeom vg(ctx->L, lo.limb_width);
+        const bool fold_verify = verify_aux && verify_aux->batch && p->pending && !sha && vg.in_field_sz() + vg.em_sz() <= step_shared_bytes(ctx);
         u64 off = 0;
         for (size_t i = 0; i < sizes.size(); off += sizes[i], ++i) {
             const u64 nb = sizes[i];
@@ -1566,7 +1579,18 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
                 // which are therefore read in `stream` order inside the call, like every other input
                 const bool with_aux = aux_as_role && !aux_done;
                 ProfScope ps(H2R_KERNEL_STEP, st, true);
-                HIP_TRY(launch_step(ctx, pa.ca, p->pending_ta, with_aux ? witness_aux : nullptr, sha_done ? nullptr : sha, st, ps.a, ps.b));
+                AuxArgs va;
+                if (fold_verify) {   // the slice of the call this launch's chains cover
+                    va = *verify_aux;
+                    va.x = xs; va.n = ns;
+                    va.hashed = verify_aux->hashed + off * 4;
+                    va.powed = static_cast<const u8 *>(verify_aux->powed) + off * in_bytes;
+                    va.batch = nb;
+                    va.trace = verify_aux->trace + off * elem_stride;
+                    va.is_valid = verify_aux->is_valid ? verify_aux->is_valid + off : nullptr;
+                    va.status = verify_aux->status + off;
+                }
+                HIP_TRY(launch_step(ctx, pa.ca, p->pending_ta, with_aux ? witness_aux : nullptr, fold_verify ? &va : nullptr, sha_done ? nullptr : sha, st, ps.a, ps.b));
                 aux_done = aux_done || with_aux;
                 sha_done = true;
             } else {
@@ -1577,7 +1601,7 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
         }
         p->done_stream[slot] = st;
         p->k += 1;
-        if (!aux_done) rc = after_chain();   // (a call that starts a train as one chain kernel: the in-field kernel behind it)
+        if (!aux_done && !fold_verify) rc = after_chain();   // (a call that starts a train as one chain kernel: the in-field kernel behind it)
         if (rc) return rc;
         for (; p->joined + p->depth <= p->k; ++p->joined) {   // calls issued the two-queue way earlier on
             rc = pipeline_wait_slot(p, p->joined % p->depth, st);
@@ -1654,14 +1678,19 @@ int32_t overlapped_pow_fixed(const h2r_ctx *ctx, const void *x, const void *n, c
     return rc ? rc : rj;
 }
 
-int32_t launch_verify_aux(const h2r_ctx *ctx, const void *sig, const void *n, const uint64_t *hashed, uint64_t batch, uint32_t flags,
-                          void *trace, const h2r_verify_layout &vl, void *powed_out, uint8_t *is_valid_out, uint8_t *status, hipStream_t st) {
+AuxArgs verify_aux_args(const h2r_ctx *ctx, const void *sig, const void *n, const uint64_t *hashed, uint64_t batch, uint32_t flags,
+                        void *trace, const h2r_verify_layout &vl, void *powed_out, uint8_t *is_valid_out, uint8_t *status) {
     AuxArgs aa;
     std::memset(&aa, 0, sizeof aa);
     aa.x = sig; aa.n = n; aa.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
     aa.hashed = hashed; aa.powed = powed_out; aa.batch = batch; aa.L = ctx->L;
     aa.trace = static_cast<u8 *>(trace); aa.elem_stride = vl.elem_stride; aa.off_in_field = vl.off_in_field; aa.off_em = vl.off_em;
     aa.is_valid = is_valid_out; aa.status = status;
+    return aa;
+}
+int32_t launch_verify_aux(const h2r_ctx *ctx, const void *sig, const void *n, const uint64_t *hashed, uint64_t batch, uint32_t flags,
+                          void *trace, const h2r_verify_layout &vl, void *powed_out, uint8_t *is_valid_out, uint8_t *status, hipStream_t st) {
+    const AuxArgs aa = verify_aux_args(ctx, sig, n, hashed, batch, flags, trace, vl, powed_out, is_valid_out, status);
     ProfScope ps(H2R_KERNEL_AUX, st, true);   // dispatch-stamped events: no marker packets on the caller's stream
     const AuxGeom ag(ctx->L, 64);
     hipExtLaunchKernelGGL((aux_kernel<64>), dim3((unsigned)batch), dim3(64), (unsigned)(ag.in_field_sz() + ag.em_sz()), st, ps.a, ps.b, 0, aa);
@@ -1743,11 +1772,12 @@ int32_t h2r_pipeline_verify_pkcs1v15(h2r_pipeline *p, const void *sig, const voi
     hipStream_t st = static_cast<hipStream_t>(stream);
     // the in-field / encoded-message kernel needs only the chain's result: it runs on the caller's stream right
     // behind the chain kernel and writes the element's in-field and EM regions (disjoint from the records)
+    const AuxArgs va = verify_aux_args(p->ctx, sig, n, hashed, batch, flags, trace, vl, powed_out, is_valid_out, status);
     return pipeline_issue(p, sig, n, e_le, e_len, batch, flags, trace, vl.pow, vl.elem_stride, powed_out, status, workspace, st,
                           [&]() -> int32_t {
                               if (batch == 0) return H2R_OK;
                               return launch_verify_aux(p->ctx, sig, n, hashed, batch, flags, trace, vl, powed_out, is_valid_out, status, st);
-                          });
+                          }, 1, false, nullptr, 0, nullptr, 0, 0, nullptr, &va);
 }
 
 // RSAPubE::Var arm of the pipelined verifier (src/chip.rs:108-110)

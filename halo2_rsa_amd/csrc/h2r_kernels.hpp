@@ -1669,7 +1669,9 @@ __device__ __forceinline__ bool aux_less_than(u8 *&sec, const AuxGeom &g, const 
     return lt;
 }
 
-template <int LW>
+// OWN: powed[elem] and status[elem] were stored by THIS wave a moment ago (the step launch's chain role): they are read back with
+// agent-scope loads, i.e. from the L2 the stores went to, not from a possibly older L1 line.
+template <int LW, bool OWN = false>
 __device__ __forceinline__ void aux_wave(const AuxArgs &a, const u64 elem, const int lane, uint4 *aux_stage) {
     using X = AuxW<LW>;
     using limb_t = typename LimbT<LW>::type;
@@ -1697,8 +1699,12 @@ __device__ __forceinline__ void aux_wave(const AuxArgs &a, const u64 elem, const
     if constexpr (LW == 64) {
         if (a.hashed != nullptr) {
             u8 *e = reinterpret_cast<u8 *>(aux_stage + if_u4);
-            const bool ok_status = a.status == nullptr || a.status[elem] == 0;
-            const u64 *pw = reinterpret_cast<const u64 *>(a.powed) + elem * L;
+            if (OWN) __threadfence_block();   // the result / status stores of this wave have left it
+            auto ld8 = [](const u8 *q) -> u8 { return OWN ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q; };
+            const bool ok_status = a.status == nullptr || ld8(a.status + elem) == 0;
+            const u64 *pwp = reinterpret_cast<const u64 *>(a.powed) + elem * L;
+            struct PW { const u64 *p; __device__ u64 operator[](u32 i) const { return OWN ? __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p[i]; } };
+            const PW pw{pwp};
             const u64 *hm = a.hashed + elem * 4;
             const u32 S = L + 1;
             bool all_prev = true;
@@ -1770,8 +1776,10 @@ union StepShared {
     ChainLds<K, NW> chain; TraceShared<LW, L, 64 * NW> trace; uint4 aux[sizeof(TraceShared<LW, L, 64 * NW>) / 16];
     __device__ StepShared() {}
 };
-template <int K, int NW, int LW, int L>
-__global__ __launch_bounds__(64 * NW, H2R_CHAIN_MINB) void step_kernel(ChainArgs ca, TraceArgs ta, AuxArgs aa, Sha256Args sa, u32 n_sha, u32 n_chain, u32 n_rec) {
+// FOLD: the chain role also writes the verifier's in-field + encoded-message witness (va).  A build of its own: with that code in it the
+// kernel spills 33 registers instead of 2 (RSA-2048), so the launches of modpow_public_key calls keep the build without it.
+template <int K, int NW, int LW, int L, bool FOLD>
+__global__ __launch_bounds__(64 * NW, H2R_CHAIN_MINB) void step_kernel(ChainArgs ca, TraceArgs ta, AuxArgs aa, AuxArgs va, Sha256Args sa, u32 n_sha, u32 n_chain, u32 n_rec) {
     static_assert((64 * NW) % TraceGeo<L>::TPI == 0, "the record role's items tile the chain role's workgroup");
     static_assert(sizeof(StepShared<K, NW, LW, L>) >= 64 * 64 * NW, "the SHA role keeps sixteen schedule words per thread in the roles' LDS");
     __shared__ StepShared<K, NW, LW, L> sh;
@@ -1787,6 +1795,13 @@ __global__ __launch_bounds__(64 * NW, H2R_CHAIN_MINB) void step_kernel(ChainArgs
         for (u64 elem = b; elem < ca.batch; elem += n_chain) {
             if (elem != b) __syncthreads();   // every wave is done with the previous element's LDS
             chain_element<K, NW, false>(ca, sh.chain, elem);
+            if (FOLD && va.batch) {
+                // the verifier's assert_in_field + encoded-message witness of THIS element (src/chip.rs:106, 136-198), by the wave that
+                // has just stored its result and status: no kernel of its own behind the launch.  Wave 0 reads its own stores back
+                // through the L2 (aux_wave: agent-scope loads of powed / status).
+                __syncthreads();
+                if (threadIdx.x < 64) aux_wave<LW, true>(va, elem, (int)threadIdx.x, reinterpret_cast<uint4 *>(&sh));
+            }
         }
     } else if (b < n_chain + n_rec) {
         // (a record role of a few workgroups per CU that WALK the records was tried: inlined into a loop the body spills 25

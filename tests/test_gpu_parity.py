@@ -842,6 +842,61 @@ def test_pipelined_verify_matches_batch_call(H, golden):
     pipe.close()
 
 
+def test_pipelined_verify_folded_into_the_step_launch(H, golden):
+    """h2r_pipeline_verify_pkcs1v15 at 1,024 signatures per call (one-launch steps): from the second call on the chain role of the
+    step launch writes the verifier's in-field + encoded-message witness itself (step_kernel<..., FOLD>), the first call of the
+    train keeps the kernel behind its chain kernel.  Four calls over two buffer sets, different signatures / digests per call,
+    one element not in the field: verdicts, statuses and results equal h2r_verify_pkcs1v15_batch for EVERY element, element bytes
+    for sampled ones (KATs, the rejected one, both ends), and every record passes the in-place audit."""
+    rsa = H.RSAChip(2048, 5)
+    chip = rsa.bigint_chip()
+    kats = golden["rsa_kats"]
+    rng = random.Random(29)
+    B = 1024
+    pipe = H.Pipeline(chip, depth=2, side_streams=1)
+    calls = []
+    for k in range(4):
+        ns = [int(kats[i % 3]["n"]) for i in range(B)]
+        sigs = [int(kats[i % 3]["sig"]) if i < 6 else rng.randrange(ns[i]) for i in range(B)]
+        hashed = [int(kats[i % 3]["hashed"]) if (i + k) % 2 == 0 else rng.getrandbits(256) for i in range(B)]
+        sigs[100 + k] = ns[100 + k] + 1                         # not in the field
+        pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Fix(65537)))
+        sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64)))
+        ref = rsa.verify_pkcs1v15_signature(pk, hashed, sg)
+        hd = torch.from_numpy(H.UnassignedInteger.from_ints(hashed, 4, 64).limbs.view(np.int64)).cuda()
+        calls.append(dict(ref=ref, n=chip.assign_integer(pk.n), s=chip.assign_integer(sg.c), h=hd, k=k))
+    vl = calls[0]["ref"].layout
+    sets = [dict(trace=torch.zeros(B * vl.elem_stride, dtype=torch.uint8, device="cuda"),
+                 ws=torch.zeros(chip.workspace_bytes(B, vl.pow.num_mul_mods), dtype=torch.uint8, device="cuda"),
+                 powed=torch.zeros((B, 32), dtype=torch.int64, device="cuda"), valid=torch.zeros(B, dtype=torch.uint8, device="cuda"),
+                 status=torch.zeros(B, dtype=torch.uint8, device="cuda")) for _ in range(2)]
+    for k, c in enumerate(calls):
+        s = sets[k % 2]
+        pipe.verify_pkcs1v15(c["s"], 65537, c["n"], c["h"], s["trace"], s["ws"], s["powed"], s["valid"], s["status"])
+    pipe.join()
+    torch.cuda.synchronize()
+    for k in (2, 3):                                            # the last users of the two buffer sets: both were folded launches
+        s, c = sets[k % 2], calls[k]
+        ref = c["ref"]
+        assert torch.equal(s["valid"], ref.is_valid) and torch.equal(s["status"], ref.status)
+        st = s["status"].cpu().tolist()
+        assert st[100 + k] == H.H2R_E_NOT_IN_FIELD and sum(1 for v in st if v) == 1
+        v = s["valid"].cpu().tolist()
+        assert v[:6] == [1 if ((i + k) % 2 == 0 and i % 3 != 2) else 0 for i in range(6)]
+        ok_rows = (s["status"] == 0).nonzero().flatten()
+        assert torch.equal(s["powed"][ok_rows], ref.powed.limbs_dev[ok_rows])
+        got = H.rsa.VerifyResult(s["valid"], H.AssignedInteger(s["powed"], 64), s["status"], s["trace"], vl, chip)
+        for i in (0, 1, 2, 3, 99 + k, 101 + k, 511, 512, B - 1):
+            assert np.array_equal(got.flatten(i), ref.flatten(i)), (k, i)
+        # the in-field region of the rejected element is written as well (the witness of the failed comparison)
+        i = 100 + k
+        es = vl.elem_stride
+        a = s["trace"][i * es + vl.off_in_field:i * es + vl.off_in_field + vl.in_field_stream_bytes]
+        b = ref.trace[i * es + vl.off_in_field:i * es + vl.off_in_field + vl.in_field_stream_bytes]
+        assert torch.equal(a, b)
+    pipe.close()
+
+
 def test_verify_pkcs1v15_1024(H):
     """RSA-1024 (the reference bench's key size, benches/bench.rs:393-407): a genuinely valid signature built
     with a known factorisation, plus tampered variants."""
