@@ -853,6 +853,7 @@ int32_t h2r_sha256_hashed_msg_batch(const h2r_ctx *ctx, const uint8_t *msgs, con
     Sha256Args sa;
     sa.msgs = msgs; sa.off = msg_off; sa.fixed_len = fixed_len; sa.batch = batch;
     sa.digest = digest_out; sa.hashed = hashed_out; sa.region = static_cast<u8 *>(hm_trace); sa.region_stride = hm_stride;
+    sa.done = nullptr; sa.target = 0;
     ProfScope ps(H2R_KERNEL_SHA256, st, true);
     hipExtLaunchKernelGGL(sha256_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, ps.a, ps.on ? ps.b : nullptr, 0, sa);
     HIP_TRY(hipGetLastError());
@@ -886,6 +887,8 @@ struct h2r_pipeline {
     u32 joined;       // calls whose record kernel the user stream has been ordered after
     // One-launch steps (step_kernel): the records of the last sub-batch issued are written by the NEXT launch, together
     // with that launch's chains, or alone at the join.
+    u32 *sha_done_dev = nullptr;   // messages hashed by SHA roles of this pipeline's step launches (device word, monotonic)
+    u32 sha_issued = 0;            // ... as issued by the host
     bool pending = false;
     TraceArgs pending_ta;
     hipStream_t pending_st = nullptr;
@@ -1271,8 +1274,8 @@ hipError_t launch_step_t(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs 
     std::memset(&no_sha, 0, sizeof no_sha);
     const u64 n_sha = sha ? ((sha->batch + 64 * NW - 1) / (64 * NW) + 7) & ~7ull : 0;   // one thread per message; a multiple of 8 (the XCD of what follows)
     const dim3 grid((unsigned)(n_sha + n_chain + rec_blocks + n_aux));
-    if (va) hipExtLaunchKernelGGL((step_kernel<K, NW, LW, L, true>), grid, dim3(64 * NW), 0, st, ea, eb, 0,
-                                  ca, ta, aa ? *aa : none, *va, sha ? *sha : no_sha, (u32)n_sha, n_chain, (u32)rec_blocks);
+    if (va || sha) hipExtLaunchKernelGGL((step_kernel<K, NW, LW, L, true>), grid, dim3(64 * NW), 0, st, ea, eb, 0,
+                                         ca, ta, aa ? *aa : none, va ? *va : none, sha ? *sha : no_sha, (u32)n_sha, n_chain, (u32)rec_blocks);
     else hipExtLaunchKernelGGL((step_kernel<K, NW, LW, L, false>), grid, dim3(64 * NW), 0, st, ea, eb, 0,
                                ca, ta, aa ? *aa : none, none, sha ? *sha : no_sha, (u32)n_sha, n_chain, (u32)rec_blocks);
     return hipGetLastError();
@@ -1353,6 +1356,8 @@ int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side
              hip_ok(hipEventCreate(&p->trace_done[i]), "hipEventCreate");
     for (int i = 0; ok && i < 2; ++i) ok = hip_ok(hipEventCreate(&p->sub_done[i]), "hipEventCreate");
     if (ok) ok = hip_ok(hipEventCreateWithFlags(&p->flush_done, hipEventDisableTiming), "hipEventCreate");
+    if (ok) ok = hip_ok(hipMalloc(reinterpret_cast<void **>(&p->sha_done_dev), 256), "hipMalloc(sha count)") &&
+                 hip_ok(hipMemset(p->sha_done_dev, 0, 256), "hipMemset(sha count)");
     if (!ok) { h2r_pipeline_destroy(p); return H2R_E_HIP; }
     *out = p;
     return H2R_OK;
@@ -1365,6 +1370,7 @@ void h2r_pipeline_destroy(h2r_pipeline *p) {
     // h2r.h asks for h2r_pipeline_join() before a stream with pipelined calls on it is destroyed)
     if (p->pending) { (void)pipeline_flush(p, p->pending_st); (void)hipStreamSynchronize(p->pending_st); }
     if (p->flush_done) (void)hipEventDestroy(p->flush_done);
+    if (p->sha_done_dev) (void)hipFree(p->sha_done_dev);
     for (int i = 0; i < 2; ++i) if (p->aux[i]) (void)hipStreamSynchronize(p->aux[i]);
     for (int i = 0; i < h2r_pipeline::MAX_DEPTH; ++i) {
         if (p->chain_done[i]) (void)hipEventDestroy(p->chain_done[i]);
@@ -1556,10 +1562,10 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
         bool aux_done = false;
         bool sha_done = !sha || !p->pending;
         // the verifier's witness inside the chain role: only when the whole call is step launches (a call that starts a train keeps
-        // the kernel behind it), the roles' LDS holds its staging, and -- the hashed limbs being an INPUT of that role -- only when
-        // they were there before the launch (not when this very launch's SHA role produces them)
+        // the kernel behind it) and the roles' LDS holds its staging.  When this very launch's SHA role produces the hashed limbs
+        // the chain role waits for that role's message count (Sha256Args::done / target)
         const AuxGeom vg(ctx->L, lo.limb_width);
-        const bool fold_verify = verify_aux && verify_aux->batch && p->pending && !sha && vg.in_field_sz() + vg.em_sz() <= step_shared_bytes(ctx);
+        const bool fold_verify = verify_aux && verify_aux->batch && p->pending && (!sha || p->sha_done_dev) && vg.in_field_sz() + vg.em_sz() <= step_shared_bytes(ctx);
         u64 off = 0;
         for (size_t i = 0; i < sizes.size(); off += sizes[i], ++i) {
             const u64 nb = sizes[i];
@@ -1590,7 +1596,12 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
                     va.is_valid = verify_aux->is_valid ? verify_aux->is_valid + off : nullptr;
                     va.status = verify_aux->status + off;
                 }
-                HIP_TRY(launch_step(ctx, pa.ca, p->pending_ta, with_aux ? witness_aux : nullptr, fold_verify ? &va : nullptr, sha_done ? nullptr : sha, st, ps.a, ps.b));
+                Sha256Args sr;
+                if (!sha_done) {
+                    sr = *sha;
+                    if (fold_verify) { p->sha_issued += (u32)sha->batch; sr.done = p->sha_done_dev; sr.target = p->sha_issued; }
+                }
+                HIP_TRY(launch_step(ctx, pa.ca, p->pending_ta, with_aux ? witness_aux : nullptr, fold_verify ? &va : nullptr, sha_done ? nullptr : &sr, st, ps.a, ps.b));
                 aux_done = aux_done || with_aux;
                 sha_done = true;
             } else {
@@ -1814,11 +1825,13 @@ int32_t h2r_pipeline_signature_verifier(h2r_pipeline *p, const uint8_t *msgs, co
     Sha256Args sa;
     sa.msgs = msgs; sa.off = msg_off; sa.fixed_len = fixed_len; sa.batch = batch;
     sa.digest = digest_out; sa.hashed = hashed_out; sa.region = static_cast<u8 *>(hm_trace); sa.region_stride = hm_stride;
+    sa.done = nullptr; sa.target = 0;
+    const AuxArgs va = verify_aux_args(p->ctx, sig, n, hashed_out, batch, flags, trace, vl, powed_out, is_valid_out, status);
     return pipeline_issue(p, sig, n, e_le, e_len, batch, flags, trace, vl.pow, vl.elem_stride, powed_out, status, workspace, st,
                           [&]() -> int32_t {
                               if (batch == 0) return H2R_OK;
                               return launch_verify_aux(p->ctx, sig, n, hashed_out, batch, flags, trace, vl, powed_out, is_valid_out, status, st);
-                          }, 1, false, nullptr, 0, nullptr, 0, 0, &sa);
+                          }, 1, false, nullptr, 0, nullptr, 0, 0, &sa, &va);
 }
 
 int32_t h2r_fresh_op_layout(const h2r_ctx *ctx, uint32_t op, uint64_t *elem_stride, uint64_t *stream_bytes, uint32_t *value_limbs) {

@@ -1705,7 +1705,7 @@ __device__ __forceinline__ void aux_wave(const AuxArgs &a, const u64 elem, const
             const u64 *pwp = reinterpret_cast<const u64 *>(a.powed) + elem * L;
             struct PW { const u64 *p; __device__ u64 operator[](u32 i) const { return OWN ? __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p[i]; } };
             const PW pw{pwp};
-            const u64 *hm = a.hashed + elem * 4;
+            const PW hm{a.hashed + elem * 4};   // (OWN: possibly written by this launch's SHA role on another XCD)
             const u32 S = L + 1;
             bool all_prev = true;
             if (ok_status) {
@@ -1768,6 +1768,7 @@ struct Sha256Args {
     u8 *digest;          // nullable, 32 bytes per element
     u64 *hashed;         // nullable, 4 limbs per element
     u8 *region; u64 region_stride;   // nullable
+    u32 *done; u32 target;           // step launch only (nullable): messages hashed so far on this pipeline / the count that means "this launch's are done"
 };
 template <int NT> __device__ void sha256_role(const Sha256Args &a, u32 blk, u32 *w);   // h2r_sha256.hpp
 
@@ -1776,21 +1777,21 @@ union StepShared {
     ChainLds<K, NW> chain; TraceShared<LW, L, 64 * NW> trace; uint4 aux[sizeof(TraceShared<LW, L, 64 * NW>) / 16];
     __device__ StepShared() {}
 };
-// FOLD: the chain role also writes the verifier's in-field + encoded-message witness (va).  A build of its own: with that code in it the
-// kernel spills 33 registers instead of 2 (RSA-2048), so the launches of modpow_public_key calls keep the build without it.
+// FOLD: the verifier's build -- the chain role also writes the verifier's in-field + encoded-message witness (va), and the launch may
+// carry the SHA-256 role (sa).  A build of its own: with that code in it the kernel spills 41 registers instead of 2 (RSA-2048), so the
+// launches of modpow_public_key calls keep the build without it, whose registers and scratch are what they were.
 template <int K, int NW, int LW, int L, bool FOLD>
 __global__ __launch_bounds__(64 * NW, H2R_CHAIN_MINB) void step_kernel(ChainArgs ca, TraceArgs ta, AuxArgs aa, AuxArgs va, Sha256Args sa, u32 n_sha, u32 n_chain, u32 n_rec) {
     static_assert((64 * NW) % TraceGeo<L>::TPI == 0, "the record role's items tile the chain role's workgroup");
-    static_assert(sizeof(StepShared<K, NW, LW, L>) >= 64 * 64 * NW, "the SHA role keeps sixteen schedule words per thread in the roles' LDS");
     __shared__ StepShared<K, NW, LW, L> sh;
-    if (blockIdx.x < n_sha) {
+    if (FOLD && blockIdx.x < n_sha) {
         // FIRST in dispatch order (n_sha is a multiple of 8, like n_chain): the verifier's SHA-256 of THIS call's messages, one thread
         // per message -- a long, latency-bound role (three compressions of 64 dependent rounds), so it has to start with the launch;
         // dispatched last it stretched the launch's tail by 40 us.  Its consumer (the encoded-message kernel) runs behind the launch.
         sha256_role<64 * NW>(sa, blockIdx.x, reinterpret_cast<u32 *>(&sh));
         return;
     }
-    const u32 b = blockIdx.x - n_sha;
+    const u32 b = blockIdx.x - (FOLD ? n_sha : 0u);
     if (b < n_chain) {
         for (u64 elem = b; elem < ca.batch; elem += n_chain) {
             if (elem != b) __syncthreads();   // every wave is done with the previous element's LDS
@@ -1800,7 +1801,24 @@ __global__ __launch_bounds__(64 * NW, H2R_CHAIN_MINB) void step_kernel(ChainArgs
                 // has just stored its result and status: no kernel of its own behind the launch.  Wave 0 reads its own stores back
                 // through the L2 (aux_wave: agent-scope loads of powed / status).
                 __syncthreads();
-                if (threadIdx.x < 64) aux_wave<LW, true>(va, elem, (int)threadIdx.x, reinterpret_cast<uint4 *>(&sh));
+                if (threadIdx.x < 64) {
+                    bool ready = true;
+                    if (sa.done) {
+                        // the hashed limbs come from THIS launch's SHA role (other workgroups, other XCDs): wait for its count.  Those
+                        // workgroups have the lowest indices of the launch, so they were dispatched before this one and wait for
+                        // nothing -- the spin ends; it is bounded all the same (a chain takes >= 90 us, the hashing ~40).
+                        u32 it = 0;
+                        if (threadIdx.x == 0)
+                            while ((int)(__hip_atomic_load(sa.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - sa.target) < 0 && ++it < (1u << 20)) __builtin_amdgcn_s_sleep(64);
+                        ready = __shfl((int)(it < (1u << 20)), 0) != 0;
+                        // acquire, once, and without the write-back a full fence would add (a thousand chain workgroups flushing
+                        // their XCD's L2 next to the record role cost the launch 50 us); the limbs themselves are then read with
+                        // agent-scope loads (aux_wave<.., OWN>)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    if (ready) aux_wave<LW, true>(va, elem, (int)threadIdx.x, reinterpret_cast<uint4 *>(&sh));
+                    else if (threadIdx.x == 0) { ca.status[elem] = (u8)H2R_E_HIP; if (va.is_valid) va.is_valid[elem] = 0; }
+                }
             }
         }
     } else if (b < n_chain + n_rec) {

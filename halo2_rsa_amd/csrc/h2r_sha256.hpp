@@ -129,56 +129,69 @@ __global__ __launch_bounds__(64) void sha256_kernel(Sha256Args a) {
 }
 
 // ---- the same hash as a ROLE of the step launch (step_kernel, h2r_kernels.hpp) -------------------------------------------------------
-// The register budget there is the chain role's (80 VGPRs), so the sixteen-word schedule window lives in LDS (word-major: thread
-// tid's word t at w[t * NT + tid], no bank conflicts, no barriers -- every thread owns its column) and the 64 rounds are a loop.
-// About three times the instructions of sha256_kernel per block, which does not matter inside a 190 us launch.
+// The register budget there is the chain role's (80 VGPRs; the fully unrolled sha256_kernel takes 94), so the rounds run as four
+// passes of sixteen unrolled rounds -- the schedule window stays in registers with static indices, the round constants come from
+// constant memory -- about 45 VGPRs.  The role is one latency-bound wave per 64 messages next to five busy workgroups per CU: it
+// raises its wave priority, because the chain role of the same launch may wait for its limbs (Sha256Args::done).
 __constant__ u32 SHA256_K[64] = {
 #define X(v) v##u,
     H2R_SHA_K(X)
 #undef X
 };
 template <int NT>
-__device__ void sha256_role(const Sha256Args &a, u32 blk, u32 *w) {
+__device__ void sha256_role(const Sha256Args &a, u32 blk, u32 *) {
     const u32 tid = threadIdx.x;
     const u64 e = (u64)blk * NT + tid;
     if (e >= a.batch) return;
+    __builtin_amdgcn_s_setprio(3);
     u64 beg, len;
     if (a.off) { beg = a.off[e]; const u64 end = a.off[e + 1]; len = end >= beg ? end - beg : 0; }
     else { beg = e * a.fixed_len; len = a.fixed_len; }
     const u8 *m = a.msgs + beg;
     u32 h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
     const u64 n_blocks = (len + 9 + 63) / 64;
-    u32 *wt = w + tid;
+    const bool aligned = (reinterpret_cast<u64>(m) & 3) == 0;
+    u32 w[16];
     for (u64 bk = 0; bk < n_blocks; ++bk) {
         const u64 p0 = bk * 64;
-#pragma unroll 1
-        for (u32 t = 0; t < 16; ++t) {
-            u32 v = 0;
+        if (p0 + 64 <= len && aligned) {
+            const u32 *m4 = reinterpret_cast<const u32 *>(m + p0);
 #pragma unroll
-            for (u32 q = 0; q < 4; ++q) {
-                const u64 p = p0 + 4 * t + q;
-                const u32 byte = p < len ? m[p] : (p == len ? 0x80u : 0u);
-                v = (v << 8) | byte;
+            for (int t = 0; t < 16; ++t) w[t] = __builtin_bswap32(m4[t]);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                u32 v = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u64 p = p0 + 4 * t + q;
+                    const u32 byte = p < len ? m[p] : (p == len ? 0x80u : 0u);
+                    v = (v << 8) | byte;
+                }
+                w[t] = v;
             }
-            wt[t * NT] = v;
+            if (bk == n_blocks - 1) { const u64 bits = len * 8; w[14] = (u32)(bits >> 32); w[15] = (u32)bits; }
         }
-        if (bk == n_blocks - 1) { const u64 bits = len * 8; wt[14 * NT] = (u32)(bits >> 32); wt[15 * NT] = (u32)bits; }
         u32 va = h[0], vb = h[1], vc = h[2], vd = h[3], ve = h[4], vf = h[5], vg = h[6], vh = h[7];
-#pragma unroll 2
-        for (u32 t = 0; t < 64; ++t) {
-            u32 x = wt[(t & 15) * NT];
-            if (t >= 16) {
-                const u32 w15 = wt[((t + 1) & 15) * NT], w2 = wt[((t + 14) & 15) * NT], w7 = wt[((t + 9) & 15) * NT];
-                x += (sha_rotr(w15, 7) ^ sha_rotr(w15, 18) ^ (w15 >> 3)) + w7 + (sha_rotr(w2, 17) ^ sha_rotr(w2, 19) ^ (w2 >> 10));
-                wt[(t & 15) * NT] = x;
+#pragma unroll 1
+        for (u32 g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (g) {
+                    const u32 w15 = w[(i + 1) & 15], w2 = w[(i + 14) & 15];
+                    w[i] += (sha_rotr(w15, 7) ^ sha_rotr(w15, 18) ^ (w15 >> 3)) + w[(i + 9) & 15] + (sha_rotr(w2, 17) ^ sha_rotr(w2, 19) ^ (w2 >> 10));
+                }
+                const u32 t1 = vh + (sha_rotr(ve, 6) ^ sha_rotr(ve, 11) ^ sha_rotr(ve, 25)) + ((ve & vf) ^ (~ve & vg)) + SHA256_K[16 * g + i] + w[i];
+                const u32 t2 = (sha_rotr(va, 2) ^ sha_rotr(va, 13) ^ sha_rotr(va, 22)) + ((va & vb) ^ (va & vc) ^ (vb & vc));
+                vh = vg; vg = vf; vf = ve; ve = vd + t1; vd = vc; vc = vb; vb = va; va = t1 + t2;
             }
-            const u32 t1 = vh + (sha_rotr(ve, 6) ^ sha_rotr(ve, 11) ^ sha_rotr(ve, 25)) + ((ve & vf) ^ (~ve & vg)) + SHA256_K[t] + x;
-            const u32 t2 = (sha_rotr(va, 2) ^ sha_rotr(va, 13) ^ sha_rotr(va, 22)) + ((va & vb) ^ (va & vc) ^ (vb & vc));
-            vh = vg; vg = vf; vf = ve; ve = vd + t1; vd = vc; vc = vb; vb = va; va = t1 + t2;
         }
         h[0] += va; h[1] += vb; h[2] += vc; h[3] += vd; h[4] += ve; h[5] += vf; h[6] += vg; h[7] += vh;
     }
     sha256_outputs(a, e, h);
+    if (a.done) {   // the chain role of the same launch consumes the limbs: publish them, then count (release / agent scope)
+        __hip_atomic_fetch_add(a.done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 }  // namespace h2r
