@@ -3229,13 +3229,14 @@ extern "C" int32_t h2r_exp_fused_period(const h2r_ctx *ctx, const void *x, const
     const u32 rec_blocks = (u32)((ta.n_items + IPB - 1) / IPB);
     u32 n_chain = (u32)std::min<u64>(batch, 4ull * ctx->num_cus);
     n_chain = (n_chain + 7) & ~7u;
-    if (dyn_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<64, 4, 64, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
+    if (dyn_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<64, 4, 64, 32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     auto one = [&]() -> hipError_t {
         if (mode == 0) {
             AuxArgs none; std::memset(&none, 0, sizeof none);
-            hipLaunchKernelGGL((step_kernel<64, 4, 64, 32>), dim3(n_chain + rec_blocks), dim3(256), dyn_lds, st, ca, ta, none, n_chain, rec_blocks);
+            Sha256Args no_sha; std::memset(&no_sha, 0, sizeof no_sha);
+            hipLaunchKernelGGL((step_kernel<64, 4, 64, 32, false>), dim3(n_chain + rec_blocks), dim3(256), dyn_lds, st, ca, ta, none, none, no_sha, 0u, n_chain, rec_blocks);
             return hipGetLastError();
         }
         if (mode == 1 || mode == 3) { const hipError_t e = launch_chain(ctx, ca, false, st); if (e != hipSuccess) return e; }

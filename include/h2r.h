@@ -371,8 +371,9 @@ int32_t h2r_verify_pkcs1v15_var_batch(const h2r_ctx *ctx, const void *sig, const
                                       void *workspace, h2r_stream_t stream);
 int32_t h2r_verify_trace_flatten(const h2r_ctx *ctx, const h2r_verify_layout *vl,
                                  const void *elem_host, void *stream_out);
-/* Pipelined form of h2r_verify_pkcs1v15_batch (see h2r_pipeline_create): the in-field / encoded-message
- * kernel runs on `stream` right behind the chain kernel; powed_out / is_valid_out / status are
+/* Pipelined form of h2r_verify_pkcs1v15_batch (see h2r_pipeline_create).  Where the call is issued as one-launch steps and a call is
+ * in flight, the chain role of the step launch writes the element's in-field / encoded-message witness and is_valid itself (no kernel
+ * of its own); otherwise that kernel runs on `stream` right behind the chain kernel.  Either way powed_out / is_valid_out / status are
  * stream-ordered on `stream`, the trace follows the pipeline's join rule. */
 int32_t h2r_pipeline_verify_pkcs1v15(h2r_pipeline *p, const void *sig, const void *n,
                                      const uint8_t *e_le_bytes, size_t e_len, const uint64_t *hashed,
@@ -415,7 +416,8 @@ int32_t h2r_signature_verifier_batch(const h2r_ctx *ctx, const uint8_t *msgs, co
                                      void *workspace, h2r_stream_t stream);
 /* Pipelined form (see h2r_pipeline_create): the SHA-256 / hashed-message step of THIS call's messages rides on the call's step launch
  * as one more role -- next to the records of the previous call, at no cost to the step -- where the shape has one-launch steps and a
- * call is in flight; otherwise it is a kernel of its own on `stream` in front of the call.  The messages are read in stream order
+ * call is in flight (the chain role of the same launch then consumes its limbs inside the launch: message count + acquire at agent
+ * scope); otherwise it is a kernel of its own on `stream` in front of the call.  The messages are read in stream order
  * inside the call, like every other input; digest_out / hashed_out / hm_trace / powed_out / is_valid_out / status are
  * stream-ordered on `stream`, the trace follows the pipeline's join rule. */
 int32_t h2r_pipeline_signature_verifier(h2r_pipeline *p, const uint8_t *msgs, const uint64_t *msg_off, uint64_t fixed_len,
