@@ -1800,16 +1800,17 @@ int32_t h2r_pipeline_verify_pkcs1v15_var(h2r_pipeline *p, const void *sig, const
     const int32_t rc = h2r_verify_layout_var(p->ctx, e_num_limbs, exp_limb_bits, &vl);
     if (rc) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const AuxArgs va = verify_aux_args(p->ctx, sig, n, hashed, batch, flags, trace, vl, powed_out, is_valid_out, status);
     return pipeline_issue(p, sig, n, nullptr, 0, batch, flags, trace, vl.pow, vl.elem_stride, powed_out, status, workspace, st,
                           [&]() -> int32_t {
                               if (batch == 0) return H2R_OK;
                               return launch_verify_aux(p->ctx, sig, n, hashed, batch, flags, trace, vl, powed_out, is_valid_out, status, st);
-                          }, 1, false, nullptr, 0, e_limbs, e_num_limbs, exp_limb_bits);
+                          }, 1, false, nullptr, 0, e_limbs, e_num_limbs, exp_limb_bits, nullptr, &va);
 }
 
 // RSASignatureVerifier::verify_pkcs1v15_signature (src/lib.rs:183-246) as a pipelined call: the SHA-256 / hashed-message step of this
-// call's messages is a role of the call's step launch (hidden next to the records of the previous call), the in-field /
-// encoded-message kernel follows on `stream`.
+// call's messages is a role of the call's step launch (hidden next to the records of the previous call) and the chain role of the same
+// launch writes the in-field / encoded-message witness from its limbs; where the call is not issued as steps, both are kernels on `stream`.
 int32_t h2r_pipeline_signature_verifier(h2r_pipeline *p, const uint8_t *msgs, const uint64_t *msg_off, uint64_t fixed_len, const void *sig,
                                         const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch, uint32_t flags, void *trace,
                                         void *hm_trace, uint64_t hm_stride, uint8_t *digest_out, uint64_t *hashed_out, void *powed_out,

@@ -348,6 +348,32 @@ def test_verify_with_a_variable_exponent(H, golden):
         for i in range(3):
             assert np.array_equal(got.flatten(i), ref.flatten(i)), i
     pipe.close()
+    # the same at 1,024 signatures per call (one-launch steps: the chain role of the verifier's build writes the witness): every verdict,
+    # status and result equals the batch export's, sampled element bytes too
+    B = 1024
+    nsB = [ns[i % 3] for i in range(B)]
+    sgB = [sigs[i % 3] if i % 7 else (sigs[i % 3] ^ 4) for i in range(B)]
+    hsB = [hashed[i % 3] for i in range(B)]
+    pkB = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(nsB, 32, 64), H.Var(H.UnassignedInteger(np.array([[1, 0, 0, 2]] * B, dtype=np.uint64)))))
+    sB = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sgB, 32, 64)))
+    refB = rsa.verify_pkcs1v15_signature(pkB, hsB, sB)
+    vlB = refB.layout
+    pipe = H.Pipeline(chip, depth=2)
+    bufsB = [dict(trace=torch.zeros(B * vlB.elem_stride, dtype=torch.uint8, device="cuda"), powed=torch.zeros((B, 32), dtype=torch.int64, device="cuda"),
+                  valid=torch.zeros(B, dtype=torch.uint8, device="cuda"), status=torch.zeros(B, dtype=torch.uint8, device="cuda"),
+                  ws=torch.zeros(chip.workspace_bytes(B, vlB.pow.num_mul_mods), dtype=torch.uint8, device="cuda")) for _ in range(2)]
+    for k in range(3):
+        b = bufsB[k & 1]
+        pipe.verify_pkcs1v15_var(sB.c, pkB.e.e, 5, pkB.n, refB.inputs[2], b["trace"], b["ws"], b["powed"], b["valid"], b["status"])
+    pipe.join()
+    torch.cuda.synchronize()
+    for b in bufsB:
+        assert torch.equal(b["valid"], refB.is_valid) and torch.equal(b["status"], refB.status) and torch.equal(b["powed"], refB.powed.limbs_dev)
+        got = H.rsa.VerifyResult(b["valid"], H.AssignedInteger(b["powed"], 64), b["status"], b["trace"], vlB, chip)
+        for i in (0, 1, 2, 7, 1023):
+            assert np.array_equal(got.flatten(i), refB.flatten(i)), i
+    assert refB.is_valid[:3].cpu().tolist() == [0, 1, 0] and int(refB.is_valid.sum()) > 500
+    pipe.close()
     # a limb that does not fit exp_limb_bits: main_gate.to_bits cannot be satisfied (big_integer/chip.rs:677)
     rsa = H.RSAChip(2048, 5)
     pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Var(H.UnassignedInteger(np.array([[1, 0, 0, 32]] * 3, dtype=np.uint64)))))
