@@ -589,6 +589,21 @@ class Pipeline {
                                            static_cast<uint8_t *>(b.is_valid.get()), static_cast<uint8_t *>(b.status.get()),
                                            b.workspace.get(), stream), "h2r_pipeline_verify_pkcs1v15");
     }
+    // RSASignatureVerifier::verify_pkcs1v15_signature from message BYTES (src/lib.rs:183-246), asynchronous on `stream`:
+    // msgs / msg_off are DEVICE buffers (message i = msgs[msg_off[i], msg_off[i + 1])), digest / hashed receive 32 bytes / 4 limbs
+    // per signature.  On the one-launch-step shapes the SHA-256 step and the verifier's witness ride inside the step launch.
+    void signature_verifier(const AssignedRSAPublicKey &pk, const DeviceBuffer &msgs, const DeviceBuffer &msg_off, const AssignedRSASignature &sig,
+                            Buffers &b, DeviceBuffer &digest, DeviceBuffer &hashed, hipStream_t stream = nullptr) {
+        auto *f = std::get_if<RSAPubE::Fix>(&pk.e);
+        if (!f) throw Error(H2R_E_UNSUPPORTED, "Pipeline::signature_verifier (takes RSAPubE::Fix)");
+        const size_t batch = sig.c.batch();
+        check(h2r_pipeline_signature_verifier(p_, static_cast<const uint8_t *>(msgs.get()), static_cast<const uint64_t *>(msg_off.get()), 0,
+                                              sig.c.data(), pk.n.data(), f->e_le.data(), f->e_le.size(), batch,
+                                              (pk.n.batch() == 1 && batch != 1) ? H2R_F_SHARED_MODULUS : 0u, b.trace.get(), nullptr, 0,
+                                              static_cast<uint8_t *>(digest.get()), static_cast<uint64_t *>(hashed.get()), b.powed.get(),
+                                              static_cast<uint8_t *>(b.is_valid.get()), static_cast<uint8_t *>(b.status.get()),
+                                              b.workspace.get(), stream), "h2r_pipeline_signature_verifier");
+    }
     // RSAInstructions::modpow_public_key (src/chip.rs:99-114, RSAPubE::Fix), asynchronous on `stream`; uses the
     // trace / workspace / powed / status members of the buffer set (its trace region is large enough for the pow trace)
     // (the in-field witness goes to the element's in-field region of the verify layout: same format, stride = elem_stride)

@@ -143,6 +143,31 @@ int main(int argc, char **argv) {
             }
         }
     }
+    // pipelined RSASignatureVerifier from message bytes: same verdicts and element bytes as the batch call on the digests
+    {
+        Pipeline pipe(rsa_chip, 2, 1);
+        const std::vector<uint8_t> e65537 = {0x01, 0x00, 0x01};
+        Pipeline::Buffers bufs[2] = {pipe.make_buffers(B, e65537), pipe.make_buffers(B, e65537)};
+        const std::string hw = "hello world";
+        std::vector<uint8_t> bytes; std::vector<uint64_t> off(B + 1, 0);
+        for (size_t i = 0; i < B; ++i) { bytes.insert(bytes.end(), hw.begin(), hw.end()); off[i + 1] = bytes.size(); }
+        DeviceBuffer dmsg(bytes.size()), doff(off.size() * 8), digest(B * 32), hashed(B * 32);
+        dmsg.upload(bytes.data(), bytes.size()); doff.upload(off.data(), off.size() * 8);
+        for (int k = 0; k < 3; ++k) pipe.signature_verifier(pk, dmsg, doff, sign, bufs[k & 1], digest, hashed);
+        pipe.join();
+        REQUIRE(hipDeviceSynchronize() == hipSuccess);
+        std::vector<uint64_t> hl(4 * B);
+        hashed.download(hl.data(), hl.size() * 8);
+        for (int s = 0; s < 2; ++s) {
+            std::vector<uint8_t> valid(B);
+            bufs[s].is_valid.download(valid.data(), B);
+            for (size_t i = 0; i < B; ++i) {
+                REQUIRE(valid[i] == kats[i].is_valid);
+                REQUIRE(std::equal(kats[i].hashed.begin(), kats[i].hashed.end(), hl.begin() + 4 * i));
+                REQUIRE(pipe.flatten(bufs[s], i) == rsa_chip.flatten(res, i));
+            }
+        }
+    }
     // pipelined modpow_public_key: the powed limbs equal the verifier's
     {
         Pipeline pipe(rsa_chip, 2, 1);
