@@ -370,7 +370,7 @@ def main():
     dev = "cuda:%d" % env.local_rank
     nbuf = 1 if args.no_pipeline else args.pipeline_depth   # scratch sets the calls rotate through
     elem_stride = pl.elem_stride
-    verify = (args.verify or args.messages > 0) and not args.no_pipeline and (w, bits) == (64, 2048)   # --messages implies --verify
+    verify = (args.verify or args.messages > 0) and not args.no_pipeline and w == 64 and bits >= 1024   # --messages implies --verify; RSAChip::LIMB_WIDTH = 64
     if verify:   # whole verifier witness: the element also holds the in-field and encoded-message regions
         import ctypes
         vl = _lib.H2RVerifyLayout()

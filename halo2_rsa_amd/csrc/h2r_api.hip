@@ -100,6 +100,7 @@ struct Knobs {
     long step_chain_x2_per_cu = 0;               // H2R_STEP_CHAIN_X2_PER_CU=n: n/2 chain workgroups per CU in a step launch (0 = the measured default)
     unsigned long pipe_cu_mask = 0;              // H2R_PIPE_CU_MASK=<hex word>: the record stream is created with this 32-bit CU mask repeated over the device (experiment)
     long pipe_cu_mask_words = 0;                 // H2R_PIPE_CU_MASK_WORDS=n: only the first n 32-bit words carry the mask, the rest are zero
+    long verify_fold = -1;                       // H2R_VERIFY_FOLD=0|1: the verifier's witness inside the step launch's chain role (-1 = the measured default per shape)
     Knobs() {
 #ifdef H2R_DEV_KNOBS
         auto num = [](const char *name, long dflt) { const char *v = std::getenv(name); return v ? std::atol(v) : dflt; };
@@ -111,6 +112,7 @@ struct Knobs {
         chain_timing = std::getenv("H2R_CHAIN_TIMING") != nullptr;
         { const char *g = std::getenv("H2R_PIPE_SERIALIZE"); pipe_serialize = g && g[0] == '1'; }
         { const char *m = std::getenv("H2R_PIPE_CU_MASK"); pipe_cu_mask = m ? std::strtoul(m, nullptr, 16) : 0; pipe_cu_mask_words = num("H2R_PIPE_CU_MASK_WORDS", 0); }
+        verify_fold = num("H2R_VERIFY_FOLD", -1);
         pipe_step = num("H2R_PIPE_STEP", -1); step_chain_x2_per_cu = num("H2R_STEP_CHAIN_X2_PER_CU", 0);
         pipe_sub_batch = num("H2R_PIPE_SUB_BATCH", 0); arena_chunk_mb = num("H2R_ARENA_CHUNK_MB", 0); plain_overlap = num("H2R_PLAIN_OVERLAP", -1); pipe_pace = num("H2R_PIPE_PACE", -1);
 #endif
@@ -1565,7 +1567,8 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
         // the kernel behind it) and the roles' LDS holds its staging.  When this very launch's SHA role produces the hashed limbs
         // the chain role waits for that role's message count (Sha256Args::done / target)
         const AuxGeom vg(ctx->L, lo.limb_width);
-        const bool fold_verify = verify_aux && verify_aux->batch && p->pending && (!sha || p->sha_done_dev) && vg.in_field_sz() + vg.em_sz() <= step_shared_bytes(ctx);
+        const bool fold_shape = knobs().verify_fold >= 0 ? knobs().verify_fold != 0 : true;
+        const bool fold_verify = fold_shape && verify_aux && verify_aux->batch && p->pending && (!sha || p->sha_done_dev) && vg.in_field_sz() + vg.em_sz() <= step_shared_bytes(ctx);
         u64 off = 0;
         for (size_t i = 0; i < sizes.size(); off += sizes[i], ++i) {
             const u64 nb = sizes[i];
