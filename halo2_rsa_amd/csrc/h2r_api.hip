@@ -1567,7 +1567,10 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
         // the kernel behind it) and the roles' LDS holds its staging.  When this very launch's SHA role produces the hashed limbs
         // the chain role waits for that role's message count (Sha256Args::done / target)
         const AuxGeom vg(ctx->L, lo.limb_width);
-        const bool fold_shape = knobs().verify_fold >= 0 ? knobs().verify_fold != 0 : true;
+        // measured per shape (tools/verify_fold_ab.sh, ms per 1,024-signature step, digests / messages): RSA-2048 0.2040 / 0.2079 -> 0.1973 /
+        // 0.1989 with the fold; the chain-bound shapes do not gain -- RSA-1024 0.0975 / 0.1097 -> 0.0988 / 0.1080, RSA-4096 0.6745 / 0.6854 ->
+        // 0.6773 / 0.6795 -- or lose: RSA-3072 0.4195 / 0.4258 -> 0.4381 / 0.4601 (the witness lengthens the role the launch waits for)
+        const bool fold_shape = knobs().verify_fold >= 0 ? knobs().verify_fold != 0 : ctx->L == 32;
         const bool fold_verify = fold_shape && verify_aux && verify_aux->batch && p->pending && (!sha || p->sha_done_dev) && vg.in_field_sz() + vg.em_sz() <= step_shared_bytes(ctx);
         u64 off = 0;
         for (size_t i = 0; i < sizes.size(); off += sizes[i], ++i) {
