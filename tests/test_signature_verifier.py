@@ -394,7 +394,7 @@ def test_pipelined_signature_verifier_sha_role(H, golden):
     rng = random.Random(21)
     rsa = H.RSAChip(2048, 5)
     chip = rsa.bigint_chip()
-    for B in (1024, 3):
+    for B in (1024, 3, 5000):   # 5,000: walked as two step launches (2,560 + 2,440), the SHA role of the whole call in the first
         ns = [int(kats[i % 3]["n"]) for i in range(B)]
         sigs = [int(kats[i % 3]["sig"]) for i in range(B)]
         pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Fix(65537)))
@@ -436,6 +436,6 @@ def test_pipelined_signature_verifier_sha_role(H, golden):
             ref = rsa.verify_pkcs1v15_signature(pk, b["hashed"], sg)
             torch.cuda.synchronize()
             got = H.rsa.VerifyResult(b["valid"], H.AssignedInteger(b["powed"], 64), b["status"], b["trace"], vl, chip)
-            for i in ([0, 1, 2, 511, 1023] if B == 1024 else [0, 1, 2]):
+            for i in ([0, 1, 2, 511, B - 1] + ([2559, 2560, 2561] if B == 5000 else []) if B >= 1024 else [0, 1, 2]):
                 assert np.array_equal(got.flatten(i), ref.flatten(i)), (B, k, i)
         pipe.close()
