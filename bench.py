@@ -278,6 +278,10 @@ def main():
     ap.add_argument("--side-streams", type=int, default=1,
                     help="streams the record kernels alternate between; 2 lets consecutive record kernels overlap "
                          "(higher throughput, but each launch's duration then includes the overlap)")
+    ap.add_argument("--producers", type=int, default=1,
+                    help="independent producers: P pipelines, each on a stream of its own with its own pipeline-depth buffer sets; the calls "
+                         "alternate between them (one pipeline per producer thread is the C ABI's threading contract).  For latency-bound "
+                         "shapes (BASELINE config 5: 256 chains of 3,072 dependent mul_mods) the chain kernels of two calls then run side by side")
     ap.add_argument("--verify", action="store_true",
                     help="time the whole verify_pkcs1v15_signature witness (in-field + modpow + encoded-message check) "
                          "instead of modpow_public_key alone (RSA-2048 workloads, pipelined mode)")
@@ -368,7 +372,8 @@ def main():
     n_dev, x_dev = chip.assign_integer(un), chip.assign_integer(ux)
     pl = chip.pow_fixed_layout(e)
     dev = "cuda:%d" % env.local_rank
-    nbuf = 1 if args.no_pipeline else args.pipeline_depth   # scratch sets the calls rotate through
+    producers = 1 if args.no_pipeline else max(1, args.producers)
+    nbuf = 1 if args.no_pipeline else args.pipeline_depth * producers   # scratch sets the calls rotate through
     elem_stride = pl.elem_stride
     verify = (args.verify or args.messages > 0) and not args.no_pipeline and w == 64 and bits >= 1024   # --messages implies --verify; RSAChip::LIMB_WIDTH = 64
     if verify:   # whole verifier witness: the element also holds the in-field and encoded-message regions
@@ -417,11 +422,25 @@ def main():
     workspaces = [torch.zeros(chip.workspace_bytes(chunk, pl.num_mul_mods), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     xc = [H.AssignedInteger(x_dev.limbs_dev[c * chunk:(c + 1) * chunk], w) for c in range(chunks)]
     nc = [n_dev if (args.shared_modulus and not os.environ.get("H2R_BENCH_REPLICATE_N")) else H.AssignedInteger(n_dev.limbs_dev[c * chunk:(c + 1) * chunk], w) for c in range(chunks)]
-    pipe = None if args.no_pipeline else H.Pipeline(chip, depth=args.pipeline_depth, side_streams=args.side_streams)
+    pipes = [] if args.no_pipeline else [H.Pipeline(chip, depth=args.pipeline_depth, side_streams=args.side_streams) for _ in range(producers)]
+    pipe = pipes[0] if pipes else None
+    # producer p issues calls p, p + P, p + 2P, ... on its own stream; buffer set k % (depth * P) belongs to producer k % P
+    prod_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(producers - 1)]
     counter = [0]
+
+    def join_all():
+        for pp, ss in zip(pipes, prod_streams):
+            with torch.cuda.stream(ss):
+                pp.join()
 
     def call(c):
         """One 1,024-signature (chunk) call: chunk c of the shard."""
+        if producers > 1:
+            with torch.cuda.stream(prod_streams[counter[0] % producers]):
+                return call_on(c, pipes[counter[0] % producers])
+        return call_on(c, pipe)
+
+    def call_on(c, pipe):
         k = counter[0]
         counter[0] += 1
         r = (k % nbuf) if chunks == 1 else c          # trace / result region
@@ -452,6 +471,9 @@ def main():
     # then the W warm-up steps the caller asked for
     call(0)
     counter[0] = 0
+    if pipe is not None:   # the next call reuses buffer set 0: its records are complete first (and every producer stream starts behind the set-up)
+        join_all()
+    torch.cuda.synchronize()
     # Clock ramp: after the idle stretch of the set-up above (allocations, arena search, host work) the first ~50 launches of
     # sustained work run 3-12 % slower than the rest (tools/clock_ramp_probe.py, profiles/r03_clock_ramp.txt: step launch 0.196 /
     # 0.207 / 0.188 ms for launches 0-19 / 20-39 / 40-59, 0.184 ms from then on) -- the device's power management, not this code.
@@ -470,17 +492,17 @@ def main():
     for _ in range(warmup):
         step()
     if pipe is not None:
-        pipe.join()
+        join_all()
     torch.cuda.synchronize()
     # chain + record + in-field kernel per call; a pipelined call larger than the library's sub-batch is several pairs
-    _lib.profile_enable(0 if args.no_kernel_timing else (3 + 2 * (chunk // 256)) * steps * chunks + 8)
+    _lib.profile_enable(0 if args.no_kernel_timing else (3 + 16 + 2 * (chunk // 256)) * steps * chunks + 8)   # (+16: a long exponent walked as up to 8 segments)
     env.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         last = step()
     if pipe is not None:
-        pipe.join()   # every step's trace is complete before the clock stops
+        join_all()   # every step's trace is complete before the clock stops
     torch.cuda.synchronize()
     env.barrier()
     dt = env.max_over_ranks(time.perf_counter() - t0)
@@ -567,7 +589,8 @@ def main():
                        "ranks": env.world, "collective_backend": (env.backend + (" (RCCL)" if env.backend == "nccl" else "")) if env.initialised else "none (single process)",
                        "pipeline": (("one launch per step: records of call k + chains of call k+1 (step_kernel), %d buffer sets" % args.pipeline_depth)
                                     if step_ms else
-                                    ("chain k+1 || trace k, %d buffer sets, %d record stream(s)" % (args.pipeline_depth, args.side_streams)))
+                                    ("chain k+1 || trace k, %d buffer sets, %d record stream(s)" % (args.pipeline_depth, args.side_streams)) +
+                                    (", %d producers (a pipeline and a stream each, calls alternate)" % producers if producers > 1 else ""))
                                    if pipe is not None else "none",
                        "untimed_clock_warmup_calls": ramp_steps * chunks,
                        "buffer_placement": placement if placement else "as allocated"},

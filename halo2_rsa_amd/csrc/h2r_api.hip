@@ -101,6 +101,7 @@ struct Knobs {
     unsigned long pipe_cu_mask = 0;              // H2R_PIPE_CU_MASK=<hex word>: the record stream is created with this 32-bit CU mask repeated over the device (experiment)
     long pipe_cu_mask_words = 0;                 // H2R_PIPE_CU_MASK_WORDS=n: only the first n 32-bit words carry the mask, the rest are zero
     long verify_fold = -1;                       // H2R_VERIFY_FOLD=0|1: the verifier's witness inside the step launch's chain role (-1 = the measured default per shape)
+    long exp_segments = -1;                      // H2R_EXP_SEGMENTS=n: segments a long exponent is walked in (0 / 1 = never; -1 = the default rule, exp_segment_count)
     Knobs() {
 #ifdef H2R_DEV_KNOBS
         auto num = [](const char *name, long dflt) { const char *v = std::getenv(name); return v ? std::atol(v) : dflt; };
@@ -112,7 +113,7 @@ struct Knobs {
         chain_timing = std::getenv("H2R_CHAIN_TIMING") != nullptr;
         { const char *g = std::getenv("H2R_PIPE_SERIALIZE"); pipe_serialize = g && g[0] == '1'; }
         { const char *m = std::getenv("H2R_PIPE_CU_MASK"); pipe_cu_mask = m ? std::strtoul(m, nullptr, 16) : 0; pipe_cu_mask_words = num("H2R_PIPE_CU_MASK_WORDS", 0); }
-        verify_fold = num("H2R_VERIFY_FOLD", -1);
+        verify_fold = num("H2R_VERIFY_FOLD", -1); exp_segments = num("H2R_EXP_SEGMENTS", -1);
         pipe_step = num("H2R_PIPE_STEP", -1); step_chain_x2_per_cu = num("H2R_STEP_CHAIN_X2_PER_CU", 0);
         pipe_sub_batch = num("H2R_PIPE_SUB_BATCH", 0); arena_chunk_mb = num("H2R_ARENA_CHUNK_MB", 0); plain_overlap = num("H2R_PLAIN_OVERLAP", -1); pipe_pace = num("H2R_PIPE_PACE", -1);
 #endif
@@ -141,14 +142,16 @@ struct Workspace {  // carve-up of the scratch of one batch call (relative to th
     u64 off_pre;   // the shared modulus' Barrett constants (recip_kernel), behind the operands
     u64 off_n;     // [batch][L] limbs: every element's modulus, copied by the chain kernel -- what the record writer reads, so
                    // that the caller's n buffer is needed only while the call's own launches run (h2r.h, pipelined form)
-    u64 total;     // one [batch * T][4][L] limb array: a, b, q, r of every mul_mod, then off_pre, off_n, plus alignment slack
+    u64 off_state; // [batch][2][L] limbs: the (squared, acc) pair of every element between two segments of a long exponent
+    u64 total;     // one [batch * T][4][L] limb array: a, b, q, r of every mul_mod, then off_pre, off_n, off_state, plus alignment slack
 };
 Workspace workspace_plan(u32 limb_bytes, u32 L, u64 batch, u32 T) {
     Workspace w;
     const u64 arr = round_up(batch * T * (u64)L * limb_bytes, 256);
     w.off_pre = 4 * arr;
     w.off_n = w.off_pre + round_up(4ull * chain_pre_words(128), 256);
-    w.total = w.off_n + round_up(batch * (u64)L * limb_bytes, 256) + 256;
+    w.off_state = w.off_n + round_up(batch * (u64)L * limb_bytes, 256);
+    w.total = w.off_state + round_up(2 * batch * (u64)L * limb_bytes, 256) + 256;
     return w;
 }
 
@@ -343,13 +346,15 @@ void fill_trace_args(const h2r_ctx *c, TraceArgs &ta) {
 
 // run_path(..., args_only): fill the two kernels' arguments in and launch nothing (the pipeline issues them itself)
 struct PathArgs { ChainArgs ca; TraceArgs ta; bool has_trace = false; };
+// A long exponent walked as segments of its bits (ChainArgs::state): bits [bit_lo, bit_hi) = the mul_mods [t_lo, t_lo + t_cnt) of every element
+struct ExpSegment { u32 bit_lo, bit_hi, t_lo, t_cnt; };
 // Common driver: chain kernel (q, r of every mul_mod) then trace kernel (the witness records).
 int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const void *n, const void *e_limbs,
                  u32 e_num_limbs, u32 exp_limb_bits, const ExpBits *eb, u32 check_in_field, u64 batch, u32 flags,
                  u32 T, void *trace, u64 elem_stride, u64 off_records, const h2r_pow_layout *pl, void *out,
                  uint8_t *status, void *workspace, hipStream_t st, hipStream_t trace_st = nullptr,
                  hipEvent_t chain_done = nullptr, hipEvent_t trace_done = nullptr, DoneRef *done_ref = nullptr,
-                 void *shared_pre = nullptr, PathArgs *args_only = nullptr, void *n_copy_at = nullptr) {
+                 void *shared_pre = nullptr, PathArgs *args_only = nullptr, void *n_copy_at = nullptr, const ExpSegment *seg = nullptr) {
     // shared_pre / n_copy_at: where the shared modulus' Barrett constants / the elements' moduli go when `workspace` is a
     // slice of a larger call's plan
     // trace_st != nullptr (pipeline mode): the record-writing kernel runs on trace_st after `chain_done`
@@ -388,6 +393,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         if (mode != CHAIN_POW_VAR) { ca.off_e_bits = 0; ca.off_selected = 0; }
     }
     if (eb) ca.e = *eb;
+    if (seg) { ca.state = reinterpret_cast<u32 *>(ws + wp.off_state); ca.bit_lo = seg->bit_lo; ca.bit_hi = seg->bit_hi; ca.t_base = seg->t_lo; }
     u8 *n_copy = trace && T ? (n_copy_at ? static_cast<u8 *>(n_copy_at) : ws + wp.off_n) : nullptr;
     ca.n_copy = reinterpret_cast<u32 *>(n_copy);
     // 128-digit chains (RSA-4096 at 64-bit limbs) are the longer leg next to their record kernel: their waves get issue
@@ -433,6 +439,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         ta.opA = ws; ta.opB = ws + c->L * lb; ta.opQ = ws + 2 * c->L * lb; ta.opR = ws + 3 * c->L * lb; ta.op_stride = 4ull * c->L;
         ta.n = n_copy; ta.n_stride = c->L;   // the chain kernel's copy: the caller's n is read inside the call only
         ta.status = status; ta.n_items = batch * T; ta.T = T;
+        if (seg) { ta.n_items = batch * seg->t_cnt; ta.T = seg->t_cnt; ta.t_lo = seg->t_lo; ta.T_ops = T; }   // this segment's mul_mods of every element
         ta.trace = static_cast<u8 *>(trace); ta.elem_stride = elem_stride; ta.off_records = off_records;
         if (args_only) { args_only->ta = ta; args_only->has_trace = true; return H2R_OK; }
         hipStream_t ts = st;
@@ -686,6 +693,7 @@ int32_t in_field_args(const h2r_ctx *ctx, const void *x, const void *n, uint64_t
 
 namespace {
 bool plain_call_overlaps(const h2r_ctx *c, u64 batch);
+u32 exp_segment_count(const h2r_ctx *c, u64 batch, u32 nbits, bool has_trace);
 int32_t overlapped_pow_fixed(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch,
                              uint32_t flags, void *trace, const h2r_pow_layout &pl, uint64_t elem_stride, void *out, uint8_t *status,
                              void *workspace, hipStream_t st, u32 check_in_field, u32 T);
@@ -703,7 +711,7 @@ static int32_t pow_fixed_impl(const h2r_ctx *ctx, const void *x, const void *n, 
     if (rc) return rc;
     // a large call with a trace: sub-batches whose chain kernels run next to the previous sub-batch's record kernel (a side
     // stream of the ctx), joined back onto the caller's stream before returning -- stream-ordered as ever for the caller
-    if (trace && T && x && n && status && ctx->params.device >= 0 && plain_call_overlaps(ctx, batch))
+    if (trace && T && x && n && status && ctx->params.device >= 0 && (plain_call_overlaps(ctx, batch) || exp_segment_count(ctx, batch, eb.nbits, true) > 1))
         return overlapped_pow_fixed(ctx, x, n, e_le, e_len, batch, flags, trace, pl, pl.elem_stride, out, status, workspace,
                                     static_cast<hipStream_t>(stream), check_in_field, T);
     return run_path(ctx, CHAIN_POW_FIXED, x, nullptr, n, nullptr, 0, 0, &eb, check_in_field, batch, flags, T, trace,
@@ -1482,6 +1490,17 @@ void call_plan(const h2r_ctx *c, u64 batch, bool busy, std::vector<u64> &sizes, 
     }
     sizes.push_back(batch);
 }
+// A LONG exponent on a latency-bound batch (at most two elements per CU: every chain's own length is what the call waits for --
+// BASELINE config 5: 256 elements x 3,072 dependent mul_mods, 7-8.5 ms of chain and 7.9 ms of record kernel) is walked as SEGMENTS of
+// its bits: the chain kernel of bits [lo, hi) of every element, then -- on the record stream -- the record kernel of those bits'
+// mul_mods, next to the chain kernel of the following segment.  A call's records then trail its own chains by one segment instead of
+// by the whole chain: a single call drops from chain + records to chain + 1/S records, and a train of pipelined calls loses the
+// exposed first chain / last record kernel.  Same values, same buffers; the (squared, acc) pair crosses launches in the workspace.
+u32 exp_segment_count(const h2r_ctx *c, u64 batch, u32 nbits, bool has_trace) {
+    if (!has_trace || batch == 0 || batch > 2ull * c->num_cus || nbits < 512) return 1;
+    if (knobs().exp_segments >= 0) return knobs().exp_segments > 1 ? (u32)std::min<long>(knobs().exp_segments, nbits / 32) : 1;
+    return std::min<u32>(8, nbits / 256);   // >= 256 bits (256-512 mul_mods per element) per segment
+}
 void pipeline_plan(h2r_pipeline *p, u64 batch, bool assume_empty, std::vector<u64> &sizes, bool &pace) {
     // (the busy query is only made where the answer matters)
     const h2r_ctx *c = p->ctx;
@@ -1621,6 +1640,33 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
         if (!aux_done && !fold_verify) rc = after_chain();   // (a call that starts a train as one chain kernel: the in-field kernel behind it)
         if (rc) return rc;
         for (; p->joined + p->depth <= p->k; ++p->joined) {   // calls issued the two-queue way earlier on
+            rc = pipeline_wait_slot(p, p->joined % p->depth, st);
+            if (rc) return rc;
+        }
+        return H2R_OK;
+    }
+    const u32 nbits_all = e_limbs ? e_num_limbs * exp_limb_bits : eb.nbits;
+    const u32 n_seg = sizes.size() == 1 ? exp_segment_count(ctx, batch, nbits_all, trace && T) : 1;
+    if (n_seg > 1) {
+        u32 t_lo = 0;
+        for (u32 sgi = 0; sgi < n_seg; ++sgi) {
+            ExpSegment sg;
+            sg.bit_lo = (u32)((u64)nbits_all * sgi / n_seg) & ~31u; sg.bit_hi = sgi + 1 == n_seg ? nbits_all : (u32)((u64)nbits_all * (sgi + 1) / n_seg) & ~31u;
+            sg.t_lo = t_lo; sg.t_cnt = 0;
+            for (u32 bi = sg.bit_lo; bi < sg.bit_hi; ++bi) sg.t_cnt += e_limbs ? 2u : 1u + ((eb.words[bi >> 5] >> (bi & 31)) & 1u);
+            t_lo += sg.t_cnt;
+            const bool last = sgi + 1 == n_seg;
+            DoneRef cur{};
+            rc = run_path(ctx, mode, x, nullptr, n, e_limbs, e_num_limbs, exp_limb_bits, e_limbs ? nullptr : &eb, check_in_field, batch, flags, T,
+                          trace, elem_stride, pl.off_records, &pl, out, status, workspace, st, p->aux[p->k & 1], p->chain_done[slot],
+                          last ? p->trace_done[slot] : p->sub_done[sgi & 1], last ? &p->done[slot] : &cur, nullptr, nullptr, nullptr, &sg);
+            if (rc) return rc;
+        }
+        p->done_stream[slot] = p->aux[p->k & 1];
+        p->k += 1;
+        rc = after_chain();
+        if (rc) return rc;
+        for (; p->joined + p->depth <= p->k; ++p->joined) {
             rc = pipeline_wait_slot(p, p->joined % p->depth, st);
             if (rc) return rc;
         }

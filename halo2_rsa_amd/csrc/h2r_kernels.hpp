@@ -86,6 +86,10 @@ struct ChainArgs {
     u32 *n_copy;         // nullable: [elem][kreal] -- the element's modulus, kept next to the operands for the record writer
                          // (which may run after the call has returned and the caller has refilled its n buffer)
     u64 *dbg_time;       // debug: s_memtime stamps of block 0 / wave 0 (nullable)
+    // A long exponent walked as SEGMENTS of its bits (nullable `state`: the whole exponent in one launch): this launch covers bits
+    // [bit_lo, bit_hi) of every element, its first mul_mod is item t_base of the element, and the running (squared, acc) pair
+    // crosses launches in state[elem][2][kreal].  The record kernel of a segment then runs next to the chains of the next one.
+    u32 *state; u32 bit_lo, bit_hi, t_base;
     ExpBits e;
 };
 
@@ -698,9 +702,19 @@ __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K,
         bop[m] = (args.mode == CHAIN_MULMOD && (u32)v < KR) ? args.b[elem * KR + v] : 0;
         acc[m] = (v == 0) ? 1u : 0u;  // acc = const 1 padded to num_limbs (:729 / :682)
     }
-    if (status == H2R_OK && args.mode != CHAIN_MULMOD && args.check_in_field && wave_ge<K>(cur, nraw, lane))
+    const bool resumed = args.state && args.bit_lo > 0;   // a later segment of a long exponent: block-uniform
+    if (resumed) {
+        if (args.status[elem] != 0) return;   // the element failed in an earlier segment: its status stands
+#pragma unroll
+        for (int m = 0; m < V; ++m) {
+            const int v = lane + 64 * m;
+            cur[m] = (u32)v < KR ? args.state[(elem * 2 + 0) * KR + v] : 0;
+            acc[m] = (u32)v < KR ? args.state[(elem * 2 + 1) * KR + v] : 0;
+        }
+    }
+    if (!resumed && status == H2R_OK && args.mode != CHAIN_MULMOD && args.check_in_field && wave_ge<K>(cur, nraw, lane))
         status = H2R_E_NOT_IN_FIELD;  // src/chip.rs:106
-    if (args.mode == CHAIN_POW_VAR && args.exp_limb_bits < 32 * args.digits_per_limb) {
+    if (!resumed && args.mode == CHAIN_POW_VAR && args.exp_limb_bits < 32 * args.digits_per_limb) {
         // main_gate.to_bits(limb, exp_limb_bits) (chip.rs:677) cannot be satisfied by a limb with bits at or above
         // exp_limb_bits: the reference's circuit fails, so the element gets a status instead of a plausible trace
         bool wide = false;
@@ -758,23 +772,24 @@ __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K,
         if (w0 && status == H2R_OK && args.out) glb_store<K>(args.out + elem * KR, r, lane, KR);
     } else {
         // pow_mod_fixed_exp (chip.rs:710-742) / pow_mod (chip.rs:664-696)
-        u32 t = 0;
+        u32 t = args.state ? args.t_base : 0;
         const bool var = args.mode == CHAIN_POW_VAR;
         const u32 nbits = var ? args.e_num_limbs * args.exp_limb_bits : args.e.nbits;
+        const u32 b_lo = args.state ? args.bit_lo : 0, b_hi = args.state ? args.bit_hi : nbits;
         u8 *etrace = args.trace ? args.trace + elem * args.elem_stride : nullptr;
         // Exponent bits are fetched one 32-bit word at a time: a per-bit load would put an s_waitcnt vmcnt(0) into
         // every iteration, which also waits for the previous mul_mod's operand stores (slow while a record kernel
         // saturates HBM next to this one).
         u32 eword = 0;
-        for (u32 bi = 0; bi < nbits; ++bi) {
+        for (u32 bi = b_lo; bi < b_hi; ++bi) {
             u32 bit;
             if (var) {  // main_gate.to_bits per e-limb, LSB first (chip.rs:674-681)
                 const u32 limb = bi / args.exp_limb_bits, pos = bi % args.exp_limb_bits;
-                if ((pos & 31) == 0) eword = (args.e_limbs + (elem * args.e_num_limbs + limb) * args.digits_per_limb)[pos >> 5];
+                if ((pos & 31) == 0 || bi == b_lo) eword = (args.e_limbs + (elem * args.e_num_limbs + limb) * args.digits_per_limb)[pos >> 5];
                 bit = (eword >> (pos & 31)) & 1u;
                 if (etrace && threadIdx.x == 0) etrace[args.off_e_bits + bi] = (u8)bit;
             } else {
-                if ((bi & 31) == 0) eword = args.e.words[bi >> 5];
+                if ((bi & 31) == 0 || bi == b_lo) eword = args.e.words[bi >> 5];
                 bit = (eword >> (bi & 31)) & 1u;
             }
             if (var) {
@@ -805,8 +820,13 @@ __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K,
             for (int m = 0; m < V; ++m) cur[m] = sq[m];
         }
         if (status == H2R_OK && w0) {
-            if (args.out) glb_store<K>(args.out + elem * KR, acc, lane, KR);
-            if (etrace && args.write_result_to_trace) glb_store<K>((u32 *)(etrace + args.off_result), acc, lane, KR);
+            if (b_hi < nbits) {   // not the last segment: the pair the next launch resumes from
+                glb_store<K>(args.state + (elem * 2 + 0) * KR, cur, lane, KR);
+                glb_store<K>(args.state + (elem * 2 + 1) * KR, acc, lane, KR);
+            } else {
+                if (args.out) glb_store<K>(args.out + elem * KR, acc, lane, KR);
+                if (etrace && args.write_result_to_trace) glb_store<K>((u32 *)(etrace + args.off_result), acc, lane, KR);
+            }
         }
     }
     if (threadIdx.x == 0) args.status[elem] = (u8)status;
@@ -870,9 +890,19 @@ __device__ __forceinline__ void chain_element_dual(const ChainArgs &args, ChainL
         cur[m] = (u32)v < KR ? args.a[elem * KR + v] : 0;
         acc[m] = (v == 0) ? 1u : 0u;
     }
-    if (status == H2R_OK && args.check_in_field && wave_ge<K>(cur, nraw, lane)) status = H2R_E_NOT_IN_FIELD;
+    const bool resumed = args.state && args.bit_lo > 0;   // a later segment of a long exponent (chain_element)
+    if (resumed) {
+        if (args.status[elem] != 0) return;
+#pragma unroll
+        for (int m = 0; m < V; ++m) {
+            const int v = lane + 64 * m;
+            cur[m] = (u32)v < KR ? args.state[(elem * 2 + 0) * KR + v] : 0;
+            acc[m] = (u32)v < KR ? args.state[(elem * 2 + 1) * KR + v] : 0;
+        }
+    }
+    if (!resumed && status == H2R_OK && args.check_in_field && wave_ge<K>(cur, nraw, lane)) status = H2R_E_NOT_IN_FIELD;
     const bool var = args.mode == CHAIN_POW_VAR;
-    if (var && args.exp_limb_bits < 32 * args.digits_per_limb) {
+    if (!resumed && var && args.exp_limb_bits < 32 * args.digits_per_limb) {
         bool wide = false;
         for (u32 l = threadIdx.x; l < args.e_num_limbs; l += 512) {
             const u32 *ed = args.e_limbs + (elem * args.e_num_limbs + l) * args.digits_per_limb;
@@ -908,19 +938,20 @@ __device__ __forceinline__ void chain_element_dual(const ChainArgs &args, ChainL
         }
         if (st != H2R_OK && status == H2R_OK) status = st;
     };
-    u32 t = 0;
+    u32 t = args.state ? args.t_base : 0;
     const u32 nbits = var ? args.e_num_limbs * args.exp_limb_bits : args.e.nbits;
+    const u32 b_lo = args.state ? args.bit_lo : 0, b_hi = args.state ? args.bit_hi : nbits;
     u8 *etrace = args.trace ? args.trace + elem * args.elem_stride : nullptr;
     u32 eword = 0;
-    for (u32 bi = 0; bi < nbits; ++bi) {
+    for (u32 bi = b_lo; bi < b_hi; ++bi) {
         u32 bit;
         if (var) {
             const u32 limb = bi / args.exp_limb_bits, pos = bi % args.exp_limb_bits;
-            if ((pos & 31) == 0) eword = (args.e_limbs + (elem * args.e_num_limbs + limb) * args.digits_per_limb)[pos >> 5];
+            if ((pos & 31) == 0 || bi == b_lo) eword = (args.e_limbs + (elem * args.e_num_limbs + limb) * args.digits_per_limb)[pos >> 5];
             bit = (eword >> (pos & 31)) & 1u;
             if (etrace && threadIdx.x == 0) etrace[args.off_e_bits + bi] = (u8)bit;
         } else {
-            if ((bi & 31) == 0) eword = args.e.words[bi >> 5];
+            if ((bi & 31) == 0 || bi == b_lo) eword = args.e.words[bi >> 5];
             bit = (eword >> (bi & 31)) & 1u;
         }
         // group 0: squared = square_mod(cur) (:734 / :693);  group 1: acc * cur (:686 always for Var; :739 for a set bit of a fixed
@@ -952,7 +983,9 @@ __device__ __forceinline__ void chain_element_dual(const ChainArgs &args, ChainL
     if (tg == 0) xst[g] = status;
     __syncthreads();
     const int st_all = xst[0] != H2R_OK ? xst[0] : xst[1];
-    if (g == 1 && w0 && st_all == H2R_OK) {
+    if (b_hi < nbits) {   // not the last segment: the pair the next launch resumes from (group 0 holds the squarings, group 1 the product)
+        if (w0 && st_all == H2R_OK) glb_store<K>(args.state + (elem * 2 + g) * KR, g == 0 ? cur : acc, lane, KR);
+    } else if (g == 1 && w0 && st_all == H2R_OK) {
         if (args.out) glb_store<K>(args.out + elem * KR, acc, lane, KR);
         if (etrace && args.write_result_to_trace) glb_store<K>((u32 *)(etrace + args.off_result), acc, lane, KR);
     }
@@ -1044,6 +1077,8 @@ struct TraceArgs {
     u64 n_stride;                       // limbs between moduli (0 = shared)
     const u8 *status;                   // [elem]; nonzero => skip the element's items
     u64 n_items; u32 T;                 // item = elem*T + t
+    u32 t_lo, T_ops;                    // T_ops != 0 (a segment of a long exponent): item = elem*T + (t - t_lo) covers the mul_mods
+                                        // [t_lo, t_lo + T) of every element, whose operands sit at item elem*T_ops + t of the ops buffer
     u8 *trace; u64 elem_stride, off_records, record_stride;
     const u8 *const_rec;                // a record whose ACCX/QACC/MODACC/NQ2/AMNQ2 planes hold the (w,L) constants
     u64 off[H2R_PL_COUNT];
@@ -1239,8 +1274,9 @@ __device__ __forceinline__ void trace_block(const TraceArgs &args, const u32 blo
     const u32 item = bid * IPB + slot;  // n_items < 2^32 (checked by the host)
     const bool in_range = item < args.n_items;
     const u32 elem32 = in_range ? item / args.T : 0;
-    const u32 tt = in_range ? item - elem32 * args.T : 0;
+    const u32 tt = in_range ? item - elem32 * args.T + args.t_lo : 0;
     const u64 elem = elem32;
+    const u64 op_item = args.T_ops ? elem * args.T_ops + tt : (u64)item;
     const bool live = in_range && t < 2 * L && (args.status == nullptr || args.status[elem] == 0);
     u8 *rec = args.trace + elem * args.elem_stride + args.off_records + (u64)tt * args.record_stride;
     const u64 *off = args.off;
@@ -1256,7 +1292,7 @@ __device__ __forceinline__ void trace_block(const TraceArgs &args, const u32 blo
         s.B[0][i] = reinterpret_cast<const limb_t *>(args.opB)[(u64)item * args.op_stride + i];
     }
     if (live && mode == TRACE_FULL) {
-        const u64 ib = (u64)item * args.op_stride;
+        const u64 ib = op_item * args.op_stride;
         const limb_t *gQ = reinterpret_cast<const limb_t *>(args.opQ) + ib;
         const limb_t *gA = h == 0 ? reinterpret_cast<const limb_t *>(args.opA) + ib : gQ;
         const limb_t *gB = h == 0 ? reinterpret_cast<const limb_t *>(args.opB) + ib
