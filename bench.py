@@ -495,7 +495,7 @@ def main():
         join_all()
     torch.cuda.synchronize()
     # chain + record + in-field kernel per call; a pipelined call larger than the library's sub-batch is several pairs
-    _lib.profile_enable(0 if args.no_kernel_timing else (3 + 16 + 2 * (chunk // 256)) * steps * chunks + 8)   # (+16: a long exponent walked as up to 8 segments)
+    _lib.profile_enable(0 if args.no_kernel_timing else (3 + 32 + 2 * (chunk // 256)) * steps * chunks + 8)   # (+32: a long exponent walked as up to 16 segments)
     env.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -601,6 +601,7 @@ def main():
                                            "committed; PMC counters cannot be read from inside the bench process)",
                          "kernel": dom_name,
                          "launches_timed": len(dom_ms), "signatures_per_launch": round(per_launch_batch, 1),
+                         "launches_per_call": round(n_launches / (steps * chunks), 2),   # > 1: sub-batches of a large call, or segments of a long exponent
                          "avg_launch_ms": round(1e3 * avg_trace_s, 4) if dom_ms else None,
                          "algorithmic_bytes_per_launch": trace_bytes_per_launch,
                          "record_kernel_alone_avg_ms": round(sum(trace_ms) / len(trace_ms), 4) if (step_ms and trace_ms) else None,

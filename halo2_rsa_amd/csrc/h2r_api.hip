@@ -696,7 +696,8 @@ bool plain_call_overlaps(const h2r_ctx *c, u64 batch);
 u32 exp_segment_count(const h2r_ctx *c, u64 batch, u32 nbits, bool has_trace);
 int32_t overlapped_pow_fixed(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch,
                              uint32_t flags, void *trace, const h2r_pow_layout &pl, uint64_t elem_stride, void *out, uint8_t *status,
-                             void *workspace, hipStream_t st, u32 check_in_field, u32 T);
+                             void *workspace, hipStream_t st, u32 check_in_field, u32 T,
+                             const void *e_limbs = nullptr, u32 e_num_limbs = 0, u32 exp_limb_bits = 0);
 }
 
 static int32_t pow_fixed_impl(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le, size_t e_len,
@@ -725,6 +726,10 @@ static int32_t pow_var_impl(const h2r_ctx *ctx, const void *x, const void *e_lim
     h2r_pow_layout pl;
     int32_t rc = h2r_pow_var_layout(ctx, e_num_limbs, exp_limb_bits, &pl);
     if (rc) return rc;
+    // a long exponent on a latency-bound batch: walked as segments of its bits, each segment's records next to the next one's chains
+    if (trace && pl.num_mul_mods && x && n && status && ctx->params.device >= 0 && exp_segment_count(ctx, batch, e_num_limbs * exp_limb_bits, true) > 1)
+        return overlapped_pow_fixed(ctx, x, n, nullptr, 0, batch, flags, trace, pl, pl.elem_stride, out, status, workspace,
+                                    static_cast<hipStream_t>(stream), check_in_field, pl.num_mul_mods, e_limbs, e_num_limbs, exp_limb_bits);
     return run_path(ctx, CHAIN_POW_VAR, x, nullptr, n, e_limbs, e_num_limbs, exp_limb_bits, nullptr, check_in_field, batch, flags,
                     pl.num_mul_mods, trace, pl.elem_stride, pl.off_records, &pl, out, status, workspace,
                     static_cast<hipStream_t>(stream));
@@ -1499,7 +1504,9 @@ void call_plan(const h2r_ctx *c, u64 batch, bool busy, std::vector<u64> &sizes, 
 u32 exp_segment_count(const h2r_ctx *c, u64 batch, u32 nbits, bool has_trace) {
     if (!has_trace || batch == 0 || batch > 2ull * c->num_cus || nbits < 512) return 1;
     if (knobs().exp_segments >= 0) return knobs().exp_segments > 1 ? (u32)std::min<long>(knobs().exp_segments, nbits / 32) : 1;
-    return std::min<u32>(8, nbits / 256);   // >= 256 bits (256-512 mul_mods per element) per segment
+    // measured (tools/exp_segments_ab.sh, config 5, same box, 1 / 2 / 4 / 8 / 16 / 32 segments): pipelined 26.2 / 28.1 / 29.3 / 30.5 / 30.3 / 29.3 k
+    // assigns/s, single calls 17.4 / 21.4 / 25.2 / 27.4 / 28.7 / 27.6 k
+    return std::min<u32>(16, nbits / 128);   // >= 128 bits (128-256 mul_mods per element, ~0.5 ms of chain) per segment
 }
 void pipeline_plan(h2r_pipeline *p, u64 batch, bool assume_empty, std::vector<u64> &sizes, bool &pace) {
     // (the busy query is only made where the answer matters)
@@ -1722,7 +1729,9 @@ bool plain_call_overlaps(const h2r_ctx *c, u64 batch) {
 
 int32_t overlapped_pow_fixed(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch,
                              uint32_t flags, void *trace, const h2r_pow_layout &pl, uint64_t elem_stride, void *out, uint8_t *status,
-                             void *workspace, hipStream_t st, u32 check_in_field, u32 T) {
+                             void *workspace, hipStream_t st, u32 check_in_field, u32 T,
+                             const void *e_limbs, u32 e_num_limbs, u32 exp_limb_bits) {
+    // (e_limbs: per-element variable exponents -- BigIntChip::pow_mod -- instead of e_le; only its long-exponent walk comes this way)
     H2R_ON_DEVICE(ctx->params.device);
     std::lock_guard<std::mutex> lk(ctx->pipe_mu);
     if (!ctx->pipe) {
@@ -1736,7 +1745,7 @@ int32_t overlapped_pow_fixed(const h2r_ctx *ctx, const void *x, const void *n, c
         sg.owned = true; ws = sg.p;
     }
     const int32_t rc = pipeline_issue(ctx->pipe, x, n, e_le, e_len, batch, flags, trace, pl, elem_stride, out, status, ws, st,
-                                      []() -> int32_t { return H2R_OK; }, check_in_field, true);
+                                      []() -> int32_t { return H2R_OK; }, check_in_field, true, nullptr, 0, e_limbs, e_num_limbs, exp_limb_bits);
     const int32_t rj = h2r_pipeline_join(ctx->pipe, st);   // also after a failed issue: whatever was queued is ordered
     return rc ? rc : rj;
 }

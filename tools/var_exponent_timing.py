@@ -27,7 +27,7 @@ torch.cuda.synchronize()
 assert not bad.cpu().numpy().any()
 sb = res.trace.stream_bytes
 del res
-_lib.profile_enable(64)
+_lib.profile_enable(512)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(CALLS):
@@ -39,8 +39,9 @@ chain, trace = _lib.profile_read(_lib.KERNEL_CHAIN), _lib.profile_read(_lib.KERN
 _lib.profile_enable(0)
 print("pow_mod (Var, 2,048-bit exponents, 4,096 mul_mods per signature) batch %d: %.2f ms per call = %.0f assigns/s = %.2f TB/s of witness "
       "(%.1f MB per signature); chain kernel %.2f ms, record kernel %.2f ms (%.2f TB/s); every record audited in place: ok"
-      % (B, dt * 1e3, B / dt, B * sb / dt / 1e12, sb / 1e6, sum(chain) / len(chain), sum(trace) / len(trace),
-         B * 4096 * chip.layout.stream_bytes / (sum(trace) / len(trace)) / 1e9))
+      % (B, dt * 1e3, B / dt, B * sb / dt / 1e12, sb / 1e6, sum(chain) / CALLS, sum(trace) / CALLS,
+         B * 4096 * chip.layout.stream_bytes / (sum(trace) / CALLS) / 1e9)
+      + " [per call: %d chain + %d record launches -- the exponent is walked as segments of its bits]" % (len(chain) // CALLS, len(trace) // CALLS))
 
 # ---- the same through h2r_pipeline_modpow_public_key_var: call k+1's chains next to call k's record kernel (two buffer sets) ----
 pl = chip.pow_var_layout(32, 64)
@@ -53,7 +54,7 @@ def call(k):
     s = sets[k % 2]
     pipe.modpow_public_key_var(x, e, 64, n, s["trace"], s["ws"], s["out"], s["status"], in_field_buf=s["inf"])
 call(0); call(1); pipe.join(); torch.cuda.synchronize()
-_lib.profile_enable(64)
+_lib.profile_enable(512)
 K = 2 * CALLS
 t0 = time.perf_counter()
 for k in range(K):
@@ -66,6 +67,6 @@ _lib.profile_enable(0)
 got = H.AssignedInteger(sets[(K - 1) % 2]["out"], 64).to_big_uint()
 assert all(got[i] == pow(X[i], E[i], N[i]) for i in (0, B - 1))
 print("pipelined (h2r_pipeline_modpow_public_key_var, %d calls): %.2f ms per call = %.0f assigns/s = %.2f TB/s of witness; chain kernel %.2f ms, "
-      "record kernel %.2f ms (%.2f TB/s)" % (K, dt * 1e3, B / dt, B * sb / dt / 1e12, sum(chain) / len(chain), sum(trace) / len(trace),
-                                             B * 4096 * chip.layout.stream_bytes / (sum(trace) / len(trace)) / 1e9))
+      "record kernel %.2f ms (%.2f TB/s)" % (K, dt * 1e3, B / dt, B * sb / dt / 1e12, sum(chain) / K, sum(trace) / K,
+                                             B * 4096 * chip.layout.stream_bytes / (sum(trace) / K) / 1e9))
 pipe.close()
