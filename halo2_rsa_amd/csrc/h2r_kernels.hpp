@@ -856,8 +856,9 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R
 // of four: group 0 walks the squarings, group 1 the multiplies of the same exponent bit, each with its own LDS and owner wave, in
 // lockstep (block_mulmod's barriers are data-independent, so both groups meet at every one).  The critical path of an element is one
 // mul_mod per exponent bit instead of 1 + bit (fixed) or 2 (Var): BASELINE config 5's 3,072 dependent mul_mods become 2,048 steps,
-// the Var path's 4,096 become 2,048.  A zero bit costs group 1 a mul_mod whose result is dropped, so this build is chosen only for
-// latency-bound batches (at most two elements per CU) and, for fixed exponents, dense ones.  The values, the items of the operand
+// the Var path's 4,096 become 2,048.  On a zero bit of a fixed exponent group 1 only meets the barriers (it used to run a mul_mod whose
+// result was dropped, which took issue slots from the squaring next to it).  The build is chosen for latency-bound batches (at most two
+// elements per CU) and, for fixed exponents, dense ones.  The values, the items of the operand
 // buffer and every status are those of chain_element.
 template <int K, bool DEEP>
 __device__ __forceinline__ void chain_element_dual(const ChainArgs &args, ChainLds<K, 4> (&s2)[2], u32 (&xch)[K], int (&xst)[2], const u64 elem) {
@@ -957,9 +958,13 @@ __device__ __forceinline__ void chain_element_dual(const ChainArgs &args, ChainL
         // group 0: squared = square_mod(cur) (:734 / :693);  group 1: acc * cur (:686 always for Var; :739 for a set bit of a fixed
         // exponent -- for a zero bit the same arithmetic runs and is dropped: the barriers inside are what both groups share)
         if (g == 0) fold(block_mulmod<K, NW, DEEP>(s, shift, lane, wave, cur, cur, nn, q, r));
+        else if (var || bit) fold(block_mulmod<K, NW, DEEP>(s, shift, lane, wave, acc, cur, nn, q, r));
         else {
-            const int st1 = block_mulmod<K, NW, DEEP>(s, shift, lane, wave, acc, cur, nn, q, r);
-            if (var || bit) fold(st1);
+            // a zero bit of a fixed exponent: no multiply (chip.rs:735-739).  The group only keeps the workgroup's barrier count --
+            // block_mulmod's is 2 per product + 2 per shift when the modulus needs normalising (block-uniform) -- and leaves the
+            // SIMDs to the squaring, which is the critical path
+            const int nbar = 6 + (shift ? 4 : 0);
+            for (int b = 0; b < nbar; ++b) __syncthreads();
         }
         // items of the operand buffer in the reference's call order: Var: multiply 2 bi, square 2 bi + 1; fixed: square t, multiply t + 1
         if (g == 0) emit(var ? 2 * bi + 1 : t, cur, cur);
