@@ -102,6 +102,7 @@ struct Knobs {
     long pipe_cu_mask_words = 0;                 // H2R_PIPE_CU_MASK_WORDS=n: only the first n 32-bit words carry the mask, the rest are zero
     long verify_fold = -1;                       // H2R_VERIFY_FOLD=0|1: the verifier's witness inside the step launch's chain role (-1 = the measured default per shape)
     long exp_segments = -1;                      // H2R_EXP_SEGMENTS=n: segments a long exponent is walked in (0 / 1 = never; -1 = the default rule, exp_segment_count)
+    long single_call_segments = -1;              // H2R_SINGLE_CALL_SEGMENTS=n: segments of a SHORT exponent in a single stream-ordered call of 513..1,536 RSA-2048 elements
     Knobs() {
 #ifdef H2R_DEV_KNOBS
         auto num = [](const char *name, long dflt) { const char *v = std::getenv(name); return v ? std::atol(v) : dflt; };
@@ -113,7 +114,7 @@ struct Knobs {
         chain_timing = std::getenv("H2R_CHAIN_TIMING") != nullptr;
         { const char *g = std::getenv("H2R_PIPE_SERIALIZE"); pipe_serialize = g && g[0] == '1'; }
         { const char *m = std::getenv("H2R_PIPE_CU_MASK"); pipe_cu_mask = m ? std::strtoul(m, nullptr, 16) : 0; pipe_cu_mask_words = num("H2R_PIPE_CU_MASK_WORDS", 0); }
-        verify_fold = num("H2R_VERIFY_FOLD", -1); exp_segments = num("H2R_EXP_SEGMENTS", -1);
+        verify_fold = num("H2R_VERIFY_FOLD", -1); exp_segments = num("H2R_EXP_SEGMENTS", -1); single_call_segments = num("H2R_SINGLE_CALL_SEGMENTS", -1);
         pipe_step = num("H2R_PIPE_STEP", -1); step_chain_x2_per_cu = num("H2R_STEP_CHAIN_X2_PER_CU", 0);
         pipe_sub_batch = num("H2R_PIPE_SUB_BATCH", 0); arena_chunk_mb = num("H2R_ARENA_CHUNK_MB", 0); plain_overlap = num("H2R_PLAIN_OVERLAP", -1); pipe_pace = num("H2R_PIPE_PACE", -1);
 #endif
@@ -693,7 +694,7 @@ int32_t in_field_args(const h2r_ctx *ctx, const void *x, const void *n, uint64_t
 
 namespace {
 bool plain_call_overlaps(const h2r_ctx *c, u64 batch);
-u32 exp_segment_count(const h2r_ctx *c, u64 batch, u32 nbits, bool has_trace);
+u32 exp_segment_count(const h2r_ctx *c, u64 batch, u32 nbits, bool has_trace, bool single_call = false);
 int32_t overlapped_pow_fixed(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch,
                              uint32_t flags, void *trace, const h2r_pow_layout &pl, uint64_t elem_stride, void *out, uint8_t *status,
                              void *workspace, hipStream_t st, u32 check_in_field, u32 T,
@@ -712,7 +713,7 @@ static int32_t pow_fixed_impl(const h2r_ctx *ctx, const void *x, const void *n, 
     if (rc) return rc;
     // a large call with a trace: sub-batches whose chain kernels run next to the previous sub-batch's record kernel (a side
     // stream of the ctx), joined back onto the caller's stream before returning -- stream-ordered as ever for the caller
-    if (trace && T && x && n && status && ctx->params.device >= 0 && (plain_call_overlaps(ctx, batch) || exp_segment_count(ctx, batch, eb.nbits, true) > 1))
+    if (trace && T && x && n && status && ctx->params.device >= 0 && (plain_call_overlaps(ctx, batch) || exp_segment_count(ctx, batch, eb.nbits, true, true) > 1))
         return overlapped_pow_fixed(ctx, x, n, e_le, e_len, batch, flags, trace, pl, pl.elem_stride, out, status, workspace,
                                     static_cast<hipStream_t>(stream), check_in_field, T);
     return run_path(ctx, CHAIN_POW_FIXED, x, nullptr, n, nullptr, 0, 0, &eb, check_in_field, batch, flags, T, trace,
@@ -1501,8 +1502,16 @@ void call_plan(const h2r_ctx *c, u64 batch, bool busy, std::vector<u64> &sizes, 
 // mul_mods, next to the chain kernel of the following segment.  A call's records then trail its own chains by one segment instead of
 // by the whole chain: a single call drops from chain + records to chain + 1/S records, and a train of pipelined calls loses the
 // exposed first chain / last record kernel.  Same values, same buffers; the (squared, acc) pair crosses launches in the workspace.
-u32 exp_segment_count(const h2r_ctx *c, u64 batch, u32 nbits, bool has_trace) {
-    if (!has_trace || batch == 0 || batch > 2ull * c->num_cus || nbits < 512) return 1;
+u32 exp_segment_count(const h2r_ctx *c, u64 batch, u32 nbits, bool has_trace, bool single_call) {
+    if (!has_trace || batch == 0) return 1;
+    // single_call: a stream-ordered export that neither follows nor is followed by another call's kernels.  With a SHORT exponent
+    // (e = 65537: 19 mul_mods) and a batch that fills the chip but is too small to be walked as sub-batches of elements, the same cut
+    // applies: the records of the first bits' mul_mods are written while the chain kernel walks the remaining bits
+    if (single_call && nbits >= 8 && nbits < 512 && c->layout.limb_width == 64 && c->L == 32 && batch > 512 && !plain_call_overlaps(c, batch)) {
+        const long k = knobs().single_call_segments;
+        return k >= 0 ? (u32)std::max<long>(1, std::min<long>(k, nbits / 2)) : 1;
+    }
+    if (batch > 2ull * c->num_cus || nbits < 512) return 1;
     if (knobs().exp_segments >= 0) return knobs().exp_segments > 1 ? (u32)std::min<long>(knobs().exp_segments, nbits / 32) : 1;
     // measured (tools/exp_segments_ab.sh, config 5, same box, 1 / 2 / 4 / 8 / 16 / 32 segments): pipelined 26.2 / 28.1 / 29.3 / 30.5 / 30.3 / 29.3 k
     // assigns/s, single calls 17.4 / 21.4 / 25.2 / 27.4 / 28.7 / 27.6 k
@@ -1549,7 +1558,9 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
     // The sub-batches are slices of the caller's buffers and of the whole call's workspace plan ([batch*T][4][L],
     // element-major), so audits and emitters see one call.
     std::vector<u64> sizes; bool pace = false;
-    const bool as_steps = step_eligible(ctx, batch, trace, T);
+    const u32 nbits_all = e_limbs ? e_num_limbs * exp_limb_bits : eb.nbits;
+    const u32 n_seg_single = assume_empty ? exp_segment_count(ctx, batch, nbits_all, trace && T, true) : 1;   // (a single stream-ordered call)
+    const bool as_steps = step_eligible(ctx, batch, trace, T) && n_seg_single <= 1;
     if (p->pending && (!as_steps || p->pending_st != st)) {   // the records still owed go out alone, `st` behind them
         rc = pipeline_flush(p, st);
         if (rc) return rc;
@@ -1652,13 +1663,13 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
         }
         return H2R_OK;
     }
-    const u32 nbits_all = e_limbs ? e_num_limbs * exp_limb_bits : eb.nbits;
-    const u32 n_seg = sizes.size() == 1 ? exp_segment_count(ctx, batch, nbits_all, trace && T) : 1;
+    const u32 n_seg = n_seg_single > 1 ? n_seg_single : (sizes.size() == 1 ? exp_segment_count(ctx, batch, nbits_all, trace && T) : 1);
     if (n_seg > 1) {
         u32 t_lo = 0;
         for (u32 sgi = 0; sgi < n_seg; ++sgi) {
             ExpSegment sg;
-            sg.bit_lo = (u32)((u64)nbits_all * sgi / n_seg) & ~31u; sg.bit_hi = sgi + 1 == n_seg ? nbits_all : (u32)((u64)nbits_all * (sgi + 1) / n_seg) & ~31u;
+            const u32 word = nbits_all >= 512 ? ~31u : ~0u;   // long exponents: boundaries on 32-bit words of e
+            sg.bit_lo = (u32)((u64)nbits_all * sgi / n_seg) & word; sg.bit_hi = sgi + 1 == n_seg ? nbits_all : (u32)((u64)nbits_all * (sgi + 1) / n_seg) & word;
             sg.t_lo = t_lo; sg.t_cnt = 0;
             for (u32 bi = sg.bit_lo; bi < sg.bit_hi; ++bi) sg.t_cnt += e_limbs ? 2u : 1u + ((eb.words[bi >> 5] >> (bi & 31)) & 1u);
             t_lo += sg.t_cnt;
