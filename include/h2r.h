@@ -213,7 +213,7 @@ int32_t h2r_square_mod_batch(const h2r_ctx *ctx, const void *a, const void *n, u
  * ordering guarantee.  A LONG exponent (512 bits or more) on a small batch (at most two elements per CU; here and in
  * h2r_pow_mod_batch, the modpow_public_key exports and the pipelined forms) is walked as up to 16 segments of its bits the
  * same way: the records of a segment are written next to the chains of the next one (256 RSA-2048 elements with a 2,048-bit
- * exponent, one call: 17.4 -> 28.7 k assigns/s); the running (squared, acc) pair crosses launches in the workspace (included
+ * exponent, one call: 17.4 -> 30.3 k assigns/s); the running (squared, acc) pair crosses launches in the workspace (included
  * in h2r_workspace_bytes).  The trace of an element whose status is not H2R_OK is unspecified, as ever. */
 int32_t h2r_pow_mod_fixed_exp_batch(const h2r_ctx *ctx, const void *x, const void *n,
                                     const uint8_t *e_le_bytes, size_t e_len, uint64_t batch,
