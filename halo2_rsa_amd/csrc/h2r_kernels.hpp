@@ -672,7 +672,8 @@ __device__ __forceinline__ int chain_modulus_setup(ChainLds<K, NW> &s, const u32
 }
 
 // One element's chain.  Returns through `status_out` semantics of the reference's panics (see h2r.h).
-template <int K, int NW, bool DEEP>
+// SEG = false (the step launches' chain role, whose register budget is tight): the code for segments of a long exponent is compiled out.
+template <int K, int NW, bool DEEP, bool SEG = true>
 __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K, NW> &s, const u64 elem) {
     using G = Geo<K, NW>;
     constexpr int V = G::V;
@@ -702,7 +703,8 @@ __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K,
         bop[m] = (args.mode == CHAIN_MULMOD && (u32)v < KR) ? args.b[elem * KR + v] : 0;
         acc[m] = (v == 0) ? 1u : 0u;  // acc = const 1 padded to num_limbs (:729 / :682)
     }
-    const bool resumed = args.state && args.bit_lo > 0;   // a later segment of a long exponent: block-uniform
+    const bool seg = SEG && args.state != nullptr;
+    const bool resumed = seg && args.bit_lo > 0;   // a later segment of a long exponent: block-uniform
     if (resumed) {
         if (args.status[elem] != 0) return;   // the element failed in an earlier segment: its status stands
 #pragma unroll
@@ -772,10 +774,10 @@ __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K,
         if (w0 && status == H2R_OK && args.out) glb_store<K>(args.out + elem * KR, r, lane, KR);
     } else {
         // pow_mod_fixed_exp (chip.rs:710-742) / pow_mod (chip.rs:664-696)
-        u32 t = args.state ? args.t_base : 0;
+        u32 t = seg ? args.t_base : 0;
         const bool var = args.mode == CHAIN_POW_VAR;
         const u32 nbits = var ? args.e_num_limbs * args.exp_limb_bits : args.e.nbits;
-        const u32 b_lo = args.state ? args.bit_lo : 0, b_hi = args.state ? args.bit_hi : nbits;
+        const u32 b_lo = seg ? args.bit_lo : 0, b_hi = seg ? args.bit_hi : nbits;
         u8 *etrace = args.trace ? args.trace + elem * args.elem_stride : nullptr;
         // Exponent bits are fetched one 32-bit word at a time: a per-bit load would put an s_waitcnt vmcnt(0) into
         // every iteration, which also waits for the previous mul_mod's operand stores (slow while a record kernel
@@ -785,11 +787,11 @@ __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K,
             u32 bit;
             if (var) {  // main_gate.to_bits per e-limb, LSB first (chip.rs:674-681)
                 const u32 limb = bi / args.exp_limb_bits, pos = bi % args.exp_limb_bits;
-                if ((pos & 31) == 0 || bi == b_lo) eword = (args.e_limbs + (elem * args.e_num_limbs + limb) * args.digits_per_limb)[pos >> 5];
+                if ((pos & 31) == 0 || (SEG && bi == b_lo)) eword = (args.e_limbs + (elem * args.e_num_limbs + limb) * args.digits_per_limb)[pos >> 5];
                 bit = (eword >> (pos & 31)) & 1u;
                 if (etrace && threadIdx.x == 0) etrace[args.off_e_bits + bi] = (u8)bit;
             } else {
-                if ((bi & 31) == 0 || bi == b_lo) eword = args.e.words[bi >> 5];
+                if ((bi & 31) == 0 || (SEG && bi == b_lo)) eword = args.e.words[bi >> 5];
                 bit = (eword >> (bi & 31)) & 1u;
             }
             if (var) {
@@ -820,7 +822,7 @@ __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K,
             for (int m = 0; m < V; ++m) cur[m] = sq[m];
         }
         if (status == H2R_OK && w0) {
-            if (b_hi < nbits) {   // not the last segment: the pair the next launch resumes from
+            if (SEG && b_hi < nbits) {   // not the last segment: the pair the next launch resumes from
                 glb_store<K>(args.state + (elem * 2 + 0) * KR, cur, lane, KR);
                 glb_store<K>(args.state + (elem * 2 + 1) * KR, acc, lane, KR);
             } else {
@@ -1256,7 +1258,8 @@ struct TraceShared {
     u64 xg[8], xp[8], xbad[8];  // per-wave carry masks for multi-wave items (a workgroup has at most eight waves: the step launch of the 4096-bit shapes)
 };
 // The work of workgroup `block` of `n_blocks` (the kernel below; also callable as one role of a larger launch)
-template <int LW, int L, int BT = TraceGeo<L>::BT>
+// TSEG = false (the step launches' record role, whose register allocation is tuned): no segment addressing (t_lo / T_ops) in the code.
+template <int LW, int L, int BT = TraceGeo<L>::BT, bool TSEG = true>
 __device__ __forceinline__ void trace_block(const TraceArgs &args, const u32 block, const u32 n_blocks, TraceShared<LW, L, BT> &sh) {
     using limb_t = typename LimbT<LW>::type;
     using W = Wide<LW>;
@@ -1279,9 +1282,9 @@ __device__ __forceinline__ void trace_block(const TraceArgs &args, const u32 blo
     const u32 item = bid * IPB + slot;  // n_items < 2^32 (checked by the host)
     const bool in_range = item < args.n_items;
     const u32 elem32 = in_range ? item / args.T : 0;
-    const u32 tt = in_range ? item - elem32 * args.T + args.t_lo : 0;
+    const u32 tt = in_range ? item - elem32 * args.T + (TSEG ? args.t_lo : 0u) : 0;
     const u64 elem = elem32;
-    const u64 op_item = args.T_ops ? elem * args.T_ops + tt : (u64)item;
+    const u64 op_item = (TSEG && args.T_ops) ? elem * args.T_ops + tt : (u64)item;
     const bool live = in_range && t < 2 * L && (args.status == nullptr || args.status[elem] == 0);
     u8 *rec = args.trace + elem * args.elem_stride + args.off_records + (u64)tt * args.record_stride;
     const u64 *off = args.off;
@@ -1836,7 +1839,7 @@ __global__ __launch_bounds__(64 * NW, H2R_CHAIN_MINB) void step_kernel(ChainArgs
     if (b < n_chain) {
         for (u64 elem = b; elem < ca.batch; elem += n_chain) {
             if (elem != b) __syncthreads();   // every wave is done with the previous element's LDS
-            chain_element<K, NW, false>(ca, sh.chain, elem);
+            chain_element<K, NW, false, false>(ca, sh.chain, elem);
             if (FOLD && va.batch) {
                 // the verifier's assert_in_field + encoded-message witness of THIS element (src/chip.rs:106, 136-198), by the wave that
                 // has just stored its result and status: no kernel of its own behind the launch.  Wave 0 reads its own stores back
@@ -1865,7 +1868,7 @@ __global__ __launch_bounds__(64 * NW, H2R_CHAIN_MINB) void step_kernel(ChainArgs
     } else if (b < n_chain + n_rec) {
         // (a record role of a few workgroups per CU that WALK the records was tried: inlined into a loop the body spills 25
         //  registers at this launch's 80, as a real call it runs at 4.1 TB/s -- one workgroup per four records it is)
-        trace_block<LW, L, 64 * NW>(ta, b - n_chain, n_rec, sh.trace);
+        trace_block<LW, L, 64 * NW, false>(ta, b - n_chain, n_rec, sh.trace);
     } else if (b - n_chain - n_rec < aa.batch) {
         // last in dispatch order: these short workgroups fill the slots the record role's tail leaves (in front of the record
         // role they cost the step 3-5 us)
