@@ -276,7 +276,8 @@ hipError_t launch_chain_t(const ChainArgs &ca, u64 grid_cap, hipStream_t st, hip
         if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
     }
     const u64 grid = grid_cap && grid_cap < ca.batch ? grid_cap : ca.batch;
-    hipExtLaunchKernelGGL((chain_kernel<K, NW, DEEP>), dim3((unsigned)grid), dim3(64 * NW), 0, st, ea, eb, 0, ca);
+    if (ca.state) hipExtLaunchKernelGGL((chain_kernel<K, NW, DEEP, true>), dim3((unsigned)grid), dim3(64 * NW), 0, st, ea, eb, 0, ca);   // a segment of a long exponent
+    else hipExtLaunchKernelGGL((chain_kernel<K, NW, DEEP, false>), dim3((unsigned)grid), dim3(64 * NW), 0, st, ea, eb, 0, ca);
     return hipGetLastError();
 }
 // co_running: the call's record kernel of the PREVIOUS batch runs next to this chain kernel (pipeline mode)

@@ -841,13 +841,15 @@ __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K,
 #ifndef H2R_CHAIN_MINB_BIG
 #define H2R_CHAIN_MINB_BIG (H2R_CHAIN_MINB / 2)   // waves per SIMD the register budget of the K > 64 builds is sized for
 #endif
-template <int K, int NW, bool DEEP>
+// SEG: the build that can walk a segment of a long exponent (ChainArgs::state); the calls without one keep the build whose registers are
+// what they were (the 64-digit throughput build: 80 VGPRs, no scratch).
+template <int K, int NW, bool DEEP, bool SEG = false>
 __global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R_CHAIN_MINB_BIG)) void chain_kernel(ChainArgs args) {
     __shared__ ChainLds<K, NW> s;
     if (args.prio) __builtin_amdgcn_s_setprio(3);
     for (u64 elem = blockIdx.x; elem < args.batch; elem += gridDim.x) {
         if (elem != blockIdx.x) __syncthreads();   // every wave is done with the previous element's LDS
-        chain_element<K, NW, DEEP>(args, s, elem);
+        chain_element<K, NW, DEEP, SEG>(args, s, elem);
     }
 }
 
