@@ -2144,7 +2144,7 @@ def test_verify_element_advice_image(H, golden):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,L,dense", [(64, 32, True), (64, 32, False), (64, 16, True)])
+@pytest.mark.parametrize("w,L,dense", [(64, 32, True), (64, 32, False), (64, 16, True), (64, 48, True)])
 def test_long_exponent_walked_as_segments(H, w, L, dense):
     """A long exponent on a latency-bound batch is walked as SEGMENTS of its bits (chain kernel of a segment, then its record kernel
     next to the following segment's chains; the running (squared, acc) pair crosses launches in the workspace): the plain export and
@@ -2163,6 +2163,18 @@ def test_long_exponent_walked_as_segments(H, w, L, dense):
     assert res.trace.num_mul_mods == 700 + bin(e).count("1")
     _check_pow_batch(H, chip, o, X, N, e, res, list(range(B)), rng)
     ref_stream = res.trace.emit_stream().clone()
+    # one key, many elements (H2R_F_SHARED_MODULUS: for the 96-digit chains the Barrett constants come from recip_kernel, once per segment launch)
+    Xs = [x % N[0] for x in X]
+    shared = chip.pow_mod_fixed_exp(chip.assign_integer(Xs), e, chip.assign_integer(N[:1]))
+    torch.cuda.synchronize()
+    assert not shared.status.cpu().numpy().any()
+    assert shared.value.to_big_uint() == [pow(x, e, N[0]) for x in Xs]
+    bad, _first = shared.audit()
+    torch.cuda.synchronize()
+    assert not bad.cpu().numpy().any()
+    rc, _oo, ost = o.pow_mod_fixed_exp(o.limbs(Xs[B - 1]), o.limbs(N[0]), e)
+    assert rc == 0 and np.array_equal(ost, shared.trace.flatten(B - 1))
+    del shared
     # pipelined, with the in-field check: element 2 of the second call has x >= n
     pl = chip.pow_fixed_layout(e)
     ies = chip.in_field_layout()[0]
