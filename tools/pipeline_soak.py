@@ -6,9 +6,13 @@ import halo2_rsa_amd as H
 from halo2_rsa_amd import big_integer as BI
 rng = random.Random(99)
 # (bits, B, depth, side): RSA-2048 / RSA-1024 above 512 per call are one-launch steps (8,192: two launches per call), 384 per call the two-queue form
-for bits, B, depth, side in ((2048, 1024, 2, 1), (2048, 3072, 2, 1), (2048, 1024, 3, 2), (2048, 8192, 2, 1), (2048, 384, 2, 1), (1024, 2048, 2, 1)):
+# (last two: a 640-bit exponent on a small batch -- every call is walked as 5 segments of the exponent's bits, dense (two chains side by side) / sparse)
+E_DENSE = rng.getrandbits(640) | (1 << 639)
+E_SPARSE = (1 << 639) | (1 << 401) | (1 << 77) | 1
+for bits, B, depth, side, E in ((2048, 1024, 2, 1, 65537), (2048, 3072, 2, 1, 65537), (2048, 1024, 3, 2, 65537), (2048, 8192, 2, 1, 65537), (2048, 384, 2, 1, 65537),
+                                (1024, 2048, 2, 1, 65537), (2048, 24, 2, 1, E_DENSE), (2048, 40, 3, 2, E_SPARSE)):
     chip = H.BigIntChip(64, bits)
-    pl = chip.pow_fixed_layout(65537)
+    pl = chip.pow_fixed_layout(E)
     base = [rng.getrandbits(bits) | (1 << (bits - 1)) | 1 for _ in range(64)]
     pipe = H.Pipeline(chip, depth=depth, side_streams=side)
     sets = [dict(trace=torch.zeros(B * pl.elem_stride, dtype=torch.uint8, device="cuda"),
@@ -22,19 +26,20 @@ for bits, B, depth, side in ((2048, 1024, 2, 1), (2048, 3072, 2, 1), (2048, 1024
         variants.append((N, X, chip.assign_integer(N), chip.assign_integer(X)))
     bad_total, checks = 0, 0
     CALLS = 240 if B <= 3072 else 60
+    e_bytes = E.to_bytes((E.bit_length() + 7) // 8, "little")
     for k in range(CALLS):
         v = variants[k % 4]; s = sets[k % depth]
-        pipe.modpow_public_key(v[3], 65537, v[2], s["trace"], s["ws"], s["out"], s["status"])
+        pipe.modpow_public_key(v[3], E, v[2], s["trace"], s["ws"], s["out"], s["status"])
         if k >= depth - 1 and k % 7 == 3:     # audit the oldest complete call on the caller's stream (ordered by the contract)
             kk = k - depth + 1
             vv = variants[kk % 4]; ss = sets[kk % depth]
             res = BI.BatchResult(H.AssignedInteger(ss["out"], 64), H.Trace(chip, ss["trace"], B, pl), ss["status"], workspace=ss["ws"],
-                                 inputs=("pow_fixed", vv[3], None, vv[2], b"\x01\x00\x01"))
+                                 inputs=("pow_fixed", vv[3], None, vv[2], e_bytes))
             bad, first = res.audit()
             bad_total += int(bad.sum().item()) + int(ss["status"].sum().item()); checks += 1
             got = H.AssignedInteger(ss["out"].clone(), 64).to_big_uint()
-            assert all(got[i] == pow(vv[1][i], 65537, vv[0][i]) for i in range(0, B, 37)), (B, k)
+            assert all(got[i] == pow(vv[1][i], E, vv[0][i]) for i in range(0, B, 37)), (B, k)
     pipe.join(); torch.cuda.synchronize()
-    print("soak RSA-%d B=%d depth=%d streams=%d: %d calls, %d audits, violations %d" % (bits, B, depth, side, CALLS, checks, bad_total))
+    print("soak RSA-%d B=%d depth=%d streams=%d e=%d bits: %d calls, %d audits, violations %d" % (bits, B, depth, side, E.bit_length(), CALLS, checks, bad_total))
     assert bad_total == 0
     pipe.close()
