@@ -1505,9 +1505,10 @@ void call_plan(const h2r_ctx *c, u64 batch, bool busy, std::vector<u64> &sizes, 
 // exposed first chain / last record kernel.  Same values, same buffers; the (squared, acc) pair crosses launches in the workspace.
 u32 exp_segment_count(const h2r_ctx *c, u64 batch, u32 nbits, bool has_trace, bool single_call) {
     if (!has_trace || batch == 0) return 1;
-    // single_call: a stream-ordered export that neither follows nor is followed by another call's kernels.  With a SHORT exponent
-    // (e = 65537: 19 mul_mods) and a batch that fills the chip but is too small to be walked as sub-batches of elements, the same cut
-    // applies: the records of the first bits' mul_mods are written while the chain kernel walks the remaining bits
+    // single_call: a stream-ordered export that neither follows nor is followed by another call's kernels.  EXPERIMENT, off in the
+    // product (the knob's default): the same cut for a SHORT exponent (e = 65537: 19 mul_mods) on a batch that fills the chip but is
+    // too small to be walked as sub-batches of elements -- measured +2 % with two segments at 1,024 RSA-2048 elements and a loss
+    // everywhere else (a 9-mul_mod chain kernel is latency-bound, every segment adds a cross-queue wait): profiles/r03_exp_segments.txt
     if (single_call && nbits >= 8 && nbits < 512 && c->layout.limb_width == 64 && c->L == 32 && batch > 512 && !plain_call_overlaps(c, batch)) {
         const long k = knobs().single_call_segments;
         return k >= 0 ? (u32)std::max<long>(1, std::min<long>(k, nbits / 2)) : 1;
