@@ -587,9 +587,9 @@ def main():
                                 "verify_pkcs1v15_signature (in-field + modpow + EM check)" if verify else "modpow_public_key"),
                        "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world,
                        "ranks": env.world, "collective_backend": (env.backend + (" (RCCL)" if env.backend == "nccl" else "")) if env.initialised else "none (single process)",
-                       "pipeline": (("one launch per step: records of call k + chains of call k+1 (step_kernel), %d buffer sets" % args.pipeline_depth)
-                                    if step_ms else
-                                    ("chain k+1 || trace k, %d buffer sets, %d record stream(s)" % (args.pipeline_depth, args.side_streams)) +
+                       "pipeline": ((("one launch per step: records of call k + chains of call k+1 (step_kernel), %d buffer sets" % args.pipeline_depth)
+                                     if step_ms else
+                                     ("chain k+1 || trace k, %d buffer sets, %d record stream(s)" % (args.pipeline_depth, args.side_streams))) +
                                     (", %d producers (a pipeline and a stream each, calls alternate)" % producers if producers > 1 else ""))
                                    if pipe is not None else "none",
                        "untimed_clock_warmup_calls": ramp_steps * chunks,

@@ -42,3 +42,15 @@ def test_bench_default_line_has_roofline_and_cpu_baseline():
     # traffic is measured by this very run when rocprofv3 is on the box (else the committed figure): within 0.9 .. 1.3 x algorithmic
     assert rf["traffic"] is None or 0.9 < rf["traffic"] / rf["algorithmic_bytes_per_launch"] < 1.3, rf
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "logical_cpus" in cb["host"]
+
+
+def test_bench_long_exponent_and_two_producers():
+    """A small BASELINE-config-5-shaped run (2,048-bit exponent: every call walked as 16 segments of the exponent's bits, 16 chain + 16
+    record launches per call) and `--producers 2` (two pipelines on two streams, calls alternate): both finish with the post-run checks
+    of bench.py green (results = pow(x, e, n), first record of the timed trace)."""
+    line = _run(["--workload", "rsa2048_e2048bit", "--batch", "8", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                 "--placement-candidates", "0", "--pmc-traffic", "off"])
+    assert line["value"] > 0 and line["config"]["mul_mods_per_assign"] > 2048
+    assert line["roofline"]["launches_per_call"] == 16
+    line = _run(["--producers", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--placement-candidates", "0", "--pmc-traffic", "off"])
+    assert line["value"] > 0 and "2 producers" in line["config"]["pipeline"]
