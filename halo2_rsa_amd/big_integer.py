@@ -212,9 +212,11 @@ class BatchResult:
                                             chip._stream()), "h2r_pow_trace_check")
         return bad, first
 
-    def emit_advice(self) -> torch.Tensor:
+    def emit_advice(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The 5-column advice image of every mul_mod record (h2r_*_emit_advice): uint8 [batch, T * rows * 160] in HBM,
-        row = 5 cells of 32 bytes (canonical elements of the chip's field); row shapes in DESIGN.md section 2b."""
+        row = 5 cells of 32 bytes (canonical elements of the chip's field); row shapes in DESIGN.md section 2b.
+        out (optional): a uint8 buffer of at least batch * T * rows * 160 bytes to write the image into (e.g. a region of the
+        placement-aware arena: where the image lies physically decides the store rate, as for the trace)."""
         chip = self.trace.chip
         batch, dev = self.trace.batch, self.trace.buf.device
         rows = int(lib().h2r_advice_rows(chip._ctx))
@@ -225,7 +227,12 @@ class BatchResult:
             nrows = int(lib().h2r_pow_advice_rows(chip._ctx, ctypes.byref(self.trace.pow_layout)))
         else:
             nrows = T * rows
-        out = torch.empty((batch, nrows * 160), dtype=torch.uint8, device=dev)
+        if out is None:
+            out = torch.empty((batch, nrows * 160), dtype=torch.uint8, device=dev)
+        else:
+            if out.dtype != torch.uint8 or out.numel() < batch * nrows * 160 or not out.is_contiguous():
+                raise ValueError("emit_advice: out must be a contiguous uint8 buffer of at least batch * rows * 160 bytes")
+            out = out.view(-1)[:batch * nrows * 160].view(batch, nrows * 160)
         if kind == "mul_mod":
             check(lib().h2r_mul_mod_emit_advice(chip._ctx, a.data_ptr(), b.data_ptr(), n.data_ptr(), flags, self.trace.buf.data_ptr(), batch,
                                                 self.status.data_ptr(), out.data_ptr(), out.shape[1], chip._stream()), "h2r_mul_mod_emit_advice")

@@ -62,3 +62,23 @@ if len(sys.argv) <= 4 or sys.argv[4] != "noadvice":
     avg = sum(ms) / len(ms)
     print("advice_kernel %s batch %d: %.3f ms per launch (min %.3f)  image written %.2f TB/s  (%d rows x 160 B per mul_mod, %.2f MB per element)"
           % (wl, B, avg, min(ms), nbytes / avg / 1e9, int(_lib.lib().h2r_advice_rows(chip._ctx)), nbytes / B / 1e6))
+
+    # the same image written into a region of the placement-aware arena (one region of ten trace regions' size, the fastest of 6 candidates)
+    if wl == "rsa2048":
+        try:
+            arena = H.TraceArena.for_pow(chip, 65537, 10 * B, regions=1, candidates=6)
+            reg = arena.regions[0]
+            img = res.emit_advice(out=reg); torch.cuda.synchronize()
+            _lib.profile_enable(16)
+            for _ in range(3):
+                res.emit_advice(out=reg)
+            torch.cuda.synchronize()
+            ms = _lib.profile_read(_lib.KERNEL_EMIT)
+            _lib.profile_enable(0)
+            avg = sum(ms) / len(ms)
+            print("advice_kernel %s batch %d, image written into an arena region (kept %.3f ms, candidates %s): %.3f ms per launch (min %.3f)  image written %.2f TB/s"
+                  % (wl, B, arena.region_ms[0], ["%.2f" % t for t in arena.measurements_ms], avg, min(ms), nbytes / avg / 1e9))
+            del img, reg
+            arena.close()
+        except Exception as ex:
+            print("advice_kernel into an arena region: skipped (%s)" % str(ex)[:200])
