@@ -2144,7 +2144,7 @@ def test_verify_element_advice_image(H, golden):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,L,dense", [(64, 32, True), (64, 32, False), (64, 16, True), (64, 48, True)])
+@pytest.mark.parametrize("w,L,dense", [(64, 32, True), (64, 32, False), (64, 16, True), (64, 48, True), (32, 128, True)])
 def test_long_exponent_walked_as_segments(H, w, L, dense):
     """A long exponent on a latency-bound batch is walked as SEGMENTS of its bits (chain kernel of a segment, then its record kernel
     next to the following segment's chains; the running (squared, acc) pair crosses launches in the workspace): the plain export and
