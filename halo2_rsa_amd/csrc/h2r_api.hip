@@ -1430,6 +1430,31 @@ int32_t h2r_pipeline_call_plan(const h2r_ctx *ctx, uint64_t batch, uint32_t pipe
     return H2R_OK;
 }
 
+namespace {
+u32 exp_segment_count(const h2r_ctx *c, u64 batch, u32 nbits, bool has_trace, bool single_call);
+void exp_segment_plan(u32 n_seg, u32 nbits, const ExpBits *eb, std::vector<ExpSegment> &out);
+}
+int32_t h2r_exp_segment_plan(const h2r_ctx *ctx, uint64_t batch, const uint8_t *e_le_bytes, size_t e_len, uint32_t var_exp_bits,
+                             uint32_t *bit_bounds_out, uint32_t *mul_mod_bounds_out, uint32_t cap, uint32_t *n_out) {
+    if (!ctx || !n_out) return H2R_E_NULL;
+    ExpBits eb; u32 T = 0;
+    u32 nbits = var_exp_bits;
+    if (!var_exp_bits) {
+        const int32_t rc = exp_to_bits(e_le_bytes, e_len, &eb, &T);
+        if (rc) return rc;
+        nbits = eb.nbits;
+    }
+    const u32 n_seg = exp_segment_count(ctx, batch, nbits, true, false);
+    std::vector<ExpSegment> segs;
+    exp_segment_plan(n_seg, nbits, var_exp_bits ? nullptr : &eb, segs);
+    *n_out = n_seg;
+    for (u32 i = 0; i <= n_seg && i < cap; ++i) {
+        if (bit_bounds_out) bit_bounds_out[i] = i < n_seg ? segs[i].bit_lo : nbits;
+        if (mul_mod_bounds_out) mul_mod_bounds_out[i] = i < n_seg ? segs[i].t_lo : segs[n_seg - 1].t_lo + segs[n_seg - 1].t_cnt;
+    }
+    return H2R_OK;
+}
+
 int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream) {
     if (!p) return H2R_E_NULL;
     if (p->pending) {
@@ -1518,6 +1543,22 @@ u32 exp_segment_count(const h2r_ctx *c, u64 batch, u32 nbits, bool has_trace, bo
     // measured (tools/exp_segments_ab.sh, config 5, same box, 1 / 2 / 4 / 8 / 16 / 32 segments): pipelined 26.2 / 28.1 / 29.3 / 30.5 / 30.3 / 29.3 k
     // assigns/s, single calls 17.4 / 21.4 / 25.2 / 27.4 / 28.7 / 27.6 k
     return std::min<u32>(16, nbits / 128);   // >= 128 bits (128-256 mul_mods per element, ~0.5 ms of chain) per segment
+}
+// The segments themselves: equal parts of the exponent's bits (long exponents: boundaries on 32-bit words of e) with the mul_mods each covers
+// -- one squaring per bit plus one multiply per set bit of a fixed exponent `eb`, two per bit of a variable one (eb == nullptr).
+void exp_segment_plan(u32 n_seg, u32 nbits, const ExpBits *eb, std::vector<ExpSegment> &out) {
+    out.clear();
+    const u32 word = nbits >= 512 ? ~31u : ~0u;
+    u32 t_lo = 0;
+    for (u32 sgi = 0; sgi < n_seg; ++sgi) {
+        ExpSegment sg;
+        sg.bit_lo = (u32)((u64)nbits * sgi / n_seg) & word;
+        sg.bit_hi = sgi + 1 == n_seg ? nbits : (u32)((u64)nbits * (sgi + 1) / n_seg) & word;
+        sg.t_lo = t_lo; sg.t_cnt = 0;
+        for (u32 bi = sg.bit_lo; bi < sg.bit_hi; ++bi) sg.t_cnt += eb ? 1u + ((eb->words[bi >> 5] >> (bi & 31)) & 1u) : 2u;
+        t_lo += sg.t_cnt;
+        out.push_back(sg);
+    }
 }
 void pipeline_plan(h2r_pipeline *p, u64 batch, bool assume_empty, std::vector<u64> &sizes, bool &pace) {
     // (the busy query is only made where the answer matters)
@@ -1667,14 +1708,10 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
     }
     const u32 n_seg = n_seg_single > 1 ? n_seg_single : (sizes.size() == 1 ? exp_segment_count(ctx, batch, nbits_all, trace && T) : 1);
     if (n_seg > 1) {
-        u32 t_lo = 0;
+        std::vector<ExpSegment> segs;
+        exp_segment_plan(n_seg, nbits_all, e_limbs ? nullptr : &eb, segs);
         for (u32 sgi = 0; sgi < n_seg; ++sgi) {
-            ExpSegment sg;
-            const u32 word = nbits_all >= 512 ? ~31u : ~0u;   // long exponents: boundaries on 32-bit words of e
-            sg.bit_lo = (u32)((u64)nbits_all * sgi / n_seg) & word; sg.bit_hi = sgi + 1 == n_seg ? nbits_all : (u32)((u64)nbits_all * (sgi + 1) / n_seg) & word;
-            sg.t_lo = t_lo; sg.t_cnt = 0;
-            for (u32 bi = sg.bit_lo; bi < sg.bit_hi; ++bi) sg.t_cnt += e_limbs ? 2u : 1u + ((eb.words[bi >> 5] >> (bi & 31)) & 1u);
-            t_lo += sg.t_cnt;
+            const ExpSegment &sg = segs[sgi];
             const bool last = sgi + 1 == n_seg;
             DoneRef cur{};
             rc = run_path(ctx, mode, x, nullptr, n, e_limbs, e_num_limbs, exp_limb_bits, e_limbs ? nullptr : &eb, check_in_field, batch, flags, T,

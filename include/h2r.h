@@ -343,6 +343,15 @@ void h2r_arena_destroy(h2r_arena *a);
 int32_t h2r_pipeline_call_plan(const h2r_ctx *ctx, uint64_t batch, uint32_t pipeline_busy, uint64_t *sizes_out,
                                uint32_t cap, uint32_t *n_out, uint32_t *paced_out);
 
+/* How a call of `batch` elements with a LONG exponent is walked on this ctx (see h2r_pow_mod_fixed_exp_batch): the segments of
+ * the exponent's bits, each with its own chain kernel and record kernel.  e_le_bytes / e_len: the fixed exponent
+ * (RSAPubE::Fix; pow_mod_fixed_exp, big_integer/chip.rs:710-742: one squaring per bit and one multiply per set bit);
+ * var_exp_bits != 0: a variable exponent of that many bits instead (pow_mod, chip.rs:664-696: two mul_mods per bit).
+ * *n_out: the number of segments (1 = the call is not cut); bit_bounds_out / mul_mod_bounds_out (nullable, up to `cap` entries
+ * each): the n + 1 boundaries in exponent bits and in mul_mods per element.  Host-only, works on a context without a device. */
+int32_t h2r_exp_segment_plan(const h2r_ctx *ctx, uint64_t batch, const uint8_t *e_le_bytes, size_t e_len, uint32_t var_exp_bits,
+                             uint32_t *bit_bounds_out, uint32_t *mul_mod_bounds_out, uint32_t cap, uint32_t *n_out);
+
 /* ---- RSAInstructions::verify_pkcs1v15_signature after the SHA step (src/chip.rs:128-199) ------
  * For every element: the assert_in_field(sig, n) witness (src/chip.rs:106 ->
  * big_integer/chip.rs:1150-1158, 908-919, 310-373, 245-297, 1286-1318, 780-805), the

@@ -206,6 +206,43 @@ def test_verify_layout_sizes(golden):
     lib().h2r_ctx_destroy(c)
 
 
+def test_exp_segment_plan():
+    """h2r_exp_segment_plan: how a long exponent on a latency-bound batch is walked (host logic of exp_segment_count /
+    exp_segment_plan): up to 16 segments of at least 128 bits, boundaries on 32-bit words of e, the mul_mod boundaries follow the
+    reference's call order (pow_mod_fixed_exp, big_integer/chip.rs:731-740: one squaring per bit + one multiply per set bit; pow_mod,
+    :684-694: two per bit).  Short exponents, batches of more than two elements per CU (256 CUs on a host-only ctx) are not cut."""
+    import random
+    c = host_ctx(64, 32)
+
+    def plan(batch, e=None, var_bits=0):
+        bits, muls, n = (ctypes.c_uint32 * 40)(), (ctypes.c_uint32 * 40)(), ctypes.c_uint32()
+        eb = e.to_bytes((e.bit_length() + 7) // 8, "little") if e is not None else None
+        assert lib().h2r_exp_segment_plan(c, batch, eb, len(eb) if eb else 0, var_bits, bits, muls, 40, ctypes.byref(n)) == _lib.H2R_OK
+        return n.value, [int(bits[i]) for i in range(n.value + 1)], [int(muls[i]) for i in range(n.value + 1)]
+
+    rng = random.Random(7)
+    e = rng.getrandbits(2048) | (1 << 2047)
+    n, bits, muls = plan(256, e)
+    assert n == 16 and bits == list(range(0, 2049, 128))
+    assert muls[0] == 0 and muls[-1] == 2048 + bin(e).count("1")
+    for i in range(n):   # a segment's mul_mods: its bits + its set bits
+        seg = (e >> bits[i]) & ((1 << (bits[i + 1] - bits[i])) - 1)
+        assert muls[i + 1] - muls[i] == (bits[i + 1] - bits[i]) + bin(seg).count("1")
+    e700 = rng.getrandbits(700) | (1 << 699)
+    n, bits, muls = plan(5, e700)
+    assert n == 5 and bits[0] == 0 and bits[-1] == 700 and all(b % 32 == 0 for b in bits[:-1]) and bits == sorted(set(bits))
+    assert muls[-1] == 700 + bin(e700).count("1")
+    assert plan(256, 65537)[0] == 1 and plan(256, (1 << 511) - 1)[0] == 1      # short exponents
+    assert plan(513, e)[0] == 1 and plan(512, e)[0] == 16                       # more than two elements per CU: not cut
+    n, bits, muls = plan(256, None, 2048)                                       # variable exponent: two mul_mods per bit
+    assert n == 16 and muls == [2 * b for b in bits]
+    assert plan(6, None, 600)[0] == 4
+    nn = ctypes.c_uint32()
+    assert lib().h2r_exp_segment_plan(None, 1, None, 0, 600, None, None, 0, ctypes.byref(nn)) == _lib.H2R_E_NULL
+    assert lib().h2r_exp_segment_plan(c, 256, None, 0, 2048, None, None, 0, ctypes.byref(nn)) == _lib.H2R_OK and nn.value == 16
+    lib().h2r_ctx_destroy(c)
+
+
 def test_pipeline_call_plan():
     """h2r_pipeline_call_plan: how a fixed-exponent call is walked (host logic of pipeline_plan).  Record-bound shapes
     (RSA-1536/2048) grow by 3/2 from one chain-kernel grid when the pipeline is empty and are one launch pair when it is
