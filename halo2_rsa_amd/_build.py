@@ -6,8 +6,14 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 SRC = os.path.join(PKG, "csrc", "h2r_api.hip")
-DEPS = [SRC, os.path.join(PKG, "csrc", "h2r_kernels.hpp"), os.path.join(PKG, "csrc", "h2r_layout.hpp"),
-        os.path.join(ROOT, "include", "h2r.h"), os.path.join(PKG, "csrc", "libh2r.map")]
+
+
+def _deps():   # every file the library is compiled from: a newer one makes the shipped .so stale
+    import glob
+    return sorted(glob.glob(os.path.join(PKG, "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*")))
+
+
+DEPS = _deps()
 LIB = os.path.join(PKG, "lib", "libh2r.so")
 
 

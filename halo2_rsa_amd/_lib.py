@@ -101,6 +101,7 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_profile_enable", "h2r_profile_read", "h2r_status_str",
            "h2r_last_hip_error"]
 H2R_ADVICE_ASSERT_ONE = 0x100
+H2R_ADVICE_DIRECT = 0x200
 KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST, KERNEL_AUX, KERNEL_EMIT, KERNEL_STEP, KERNEL_LOOKUP, KERNEL_SHA256 = 0, 1, 2, 3, 4, 5, 6, 7
 H2R_HASHED_MSG_STREAM_BYTES = 288
 H2R_STREAM_FIELD_AB = 1

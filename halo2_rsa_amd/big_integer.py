@@ -192,6 +192,8 @@ class BatchResult:
     in_field: Optional[InFieldTrace] = None   # modpow_public_key only: the assert_in_field witness
     workspace: Optional[torch.Tensor] = None   # pow calls: the operands buffer of every mul_mod (kept for audit())
     inputs: Optional[tuple] = None             # (kind, a/x, b, n, e bytes or None) the call was made with
+    chip: Optional["BigIntChip"] = None        # (results without a trace: the chip and the pow layout of the call)
+    pow_layout: Optional[H2RPowLayout] = None
 
     def audit(self):
         """In-place device check of every record of the trace (h2r_mul_mod_trace_check / h2r_pow_trace_check):
@@ -212,19 +214,24 @@ class BatchResult:
                                             chip._stream()), "h2r_pow_trace_check")
         return bad, first
 
-    def emit_advice(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def emit_advice(self, out: Optional[torch.Tensor] = None, direct: bool = False) -> torch.Tensor:
         """The 5-column advice image of every mul_mod record (h2r_*_emit_advice): uint8 [batch, T * rows * 160] in HBM,
         row = 5 cells of 32 bytes (canonical elements of the chip's field); row shapes in DESIGN.md section 2b.
         out (optional): a uint8 buffer of at least batch * T * rows * 160 bytes to write the image into (e.g. a region of the
-        placement-aware arena: where the image lies physically decides the store rate, as for the trace)."""
-        chip = self.trace.chip
-        batch, dev = self.trace.batch, self.trace.buf.device
-        rows = int(lib().h2r_advice_rows(chip._ctx))
+        placement-aware arena: where the image lies physically decides the store rate, as for the trace).
+        direct=True (H2R_ADVICE_DIRECT): the cells are recomputed from the operands, the records are not read -- a pow result
+        made with want_trace=False (and a workspace) has only this form."""
         kind, a, b, n, eb = self.inputs
-        flags = chip._flags(n, batch)
-        T = self.trace.num_mul_mods
+        chip = self.trace.chip if self.trace is not None else self.chip
+        batch, dev = a.batch, a.limbs_dev.device
+        rows = int(lib().h2r_advice_rows(chip._ctx))
+        flags = chip._flags(n, batch) | (_lib.H2R_ADVICE_DIRECT if direct else 0)
+        if self.trace is None and not (direct and kind != "mul_mod" and self.workspace is not None):
+            raise ValueError("emit_advice: a result without records has only the direct form of a pow call's image (direct=True, workspace kept)")
+        pl = self.trace.pow_layout if self.trace is not None else self.pow_layout
+        T = pl.num_mul_mods if pl is not None else 1
         if kind != "mul_mod":   # a fixed-exponent pow element starts with the two constant rows of acc = 1 (h2r_pow_advice_rows)
-            nrows = int(lib().h2r_pow_advice_rows(chip._ctx, ctypes.byref(self.trace.pow_layout)))
+            nrows = int(lib().h2r_pow_advice_rows(chip._ctx, ctypes.byref(pl)))
         else:
             nrows = T * rows
         if out is None:
@@ -237,9 +244,10 @@ class BatchResult:
             check(lib().h2r_mul_mod_emit_advice(chip._ctx, a.data_ptr(), b.data_ptr(), n.data_ptr(), flags, self.trace.buf.data_ptr(), batch,
                                                 self.status.data_ptr(), out.data_ptr(), out.shape[1], chip._stream()), "h2r_mul_mod_emit_advice")
         else:
-            check(lib().h2r_pow_trace_emit_advice(chip._ctx, ctypes.byref(self.trace.pow_layout), n.data_ptr(), flags, self.trace.buf.data_ptr(),
-                                                  self.trace.elem_stride, self.workspace.data_ptr(), batch, self.status.data_ptr(),
-                                                  out.data_ptr(), out.shape[1], chip._stream()), "h2r_pow_trace_emit_advice")
+            check(lib().h2r_pow_trace_emit_advice(chip._ctx, ctypes.byref(pl), n.data_ptr(), flags,
+                                                  self.trace.buf.data_ptr() if self.trace is not None else None,
+                                                  self.trace.elem_stride if self.trace is not None else 0, self.workspace.data_ptr(), batch,
+                                                  self.status.data_ptr(), out.data_ptr(), out.shape[1], chip._stream()), "h2r_pow_trace_emit_advice")
         return out
 
     def flatten(self, elem: int) -> np.ndarray:
@@ -453,7 +461,7 @@ class BigIntChip:
             check(lib().h2r_pow_mod_fixed_exp_batch(self._ctx, a.data_ptr(), n.data_ptr(), eb, len(eb), batch, self._flags(n, batch), tp,
                                                     out.data_ptr(), status.data_ptr(), wp, self._stream()), "pow_mod_fixed_exp")
         return BatchResult(AssignedInteger(out, self.limb_width), Trace(self, trace_buf, batch, pl) if want_trace else None, status, in_field,
-                           workspace, ("pow_fixed", a, None, n, eb))
+                           workspace, ("pow_fixed", a, None, n, eb), self, pl)
 
     def _in_field_trace(self, batch, buf=None) -> "InFieldTrace":
         es, sb = self.in_field_layout()

@@ -17,6 +17,7 @@
 
 #include "h2r.h"
 #include "h2r_kernels.hpp"
+#include "h2r_cells.hpp"
 #include "h2r_layout.hpp"
 #include "h2r_lookup.hpp"
 #include "h2r_muled.hpp"
@@ -165,6 +166,7 @@ struct h2r_ctx {
     U256 word_max;
     u8 *const_rec_dev;  // device copy of the constant record
     u32 *advice_desc_dev = nullptr;   // [h2r_advice_rows] packed row descriptors of the advice image (advice_pack)
+    u64 *cells_ktab_dev = nullptr;    // cells_kernel: columns 0, 1, >= 2 of the accumulated_extra constants (CELLS_KT_WORDS words)
     std::vector<u8> const_rec_host;
     // lookup-table row offsets for the multiplicity histogram
     u32 tab0_len, tab1_off, tab1_len, tab2_off, tab2_len, hist_len;
@@ -595,6 +597,33 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
             return H2R_E_HIP;
         }
     }
+    {   // cells_kernel's table of the input-independent accumulated_extra chain (chip.rs:869-875): X[0] = 0, X[i+1] = (X[i] + W) >> w
+        // is at its fixed point L 2^w - L from i = 2 on (W = (2^w - 1)(L 2^w - L + 1)), so three columns describe every column
+        const u8 *r = c->const_rec_host.data();
+        auto col = [&](u32 i, u64 (&e)[10]) {
+            std::memset(e, 0, sizeof e);
+            std::memcpy(&e[0], r + lo.plane_off[H2R_PL_ACCX_LO] + (u64)i * 16, 16);
+            std::memcpy(&e[6], r + lo.plane_off[H2R_PL_NQ2_LO] + (u64)i * 16, 16);
+            if (lo.plane_elem[H2R_PL_ACCX_HI]) {
+                std::memcpy(&e[2], r + lo.plane_off[H2R_PL_ACCX_HI] + (u64)i * 8, 8);
+                std::memcpy(&e[8], r + lo.plane_off[H2R_PL_NQ2_HI] + (u64)i * 8, 8);
+            }
+            std::memcpy(&e[3], r + lo.plane_off[H2R_PL_QACC] + (u64)i * lo.carry_bytes, lo.carry_bytes);
+            std::memcpy(&e[5], r + lo.plane_off[H2R_PL_MODACC] + (u64)i * lo.limb_bytes, lo.limb_bytes);
+            std::memcpy(&e[9], r + lo.plane_off[H2R_PL_AMNQ2] + (u64)i * lo.limb_bytes, lo.limb_bytes);
+        };
+        u64 kt[CELLS_KT_WORDS] = {0}, e[10], e2[10];
+        for (u32 i = 0; i < 3; ++i) { col(i, e); std::memcpy(&kt[10 * i], e, sizeof e); }
+        col(2, e2);
+        bool fixed_point = true;
+        for (u32 i = 3; i < lo.num_cols; ++i) { col(i, e); fixed_point = fixed_point && std::memcmp(e, e2, sizeof e) == 0; }
+        if (!fixed_point) { h2r_ctx_destroy(c); return H2R_E_UNSUPPORTED; }
+        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&c->cells_ktab_dev), sizeof kt), "hipMalloc(cells table)") ||
+            !hip_ok(hipMemcpy(c->cells_ktab_dev, kt, sizeof kt, hipMemcpyHostToDevice), "hipMemcpy(cells table)")) {
+            h2r_ctx_destroy(c);
+            return H2R_E_HIP;
+        }
+    }
     *out = c;
     return H2R_OK;
 }
@@ -605,6 +634,7 @@ void h2r_ctx_destroy(h2r_ctx *ctx) {
         DeviceGuard dg(ctx->params.device);
         if (ctx->const_rec_dev) (void)hipFree(ctx->const_rec_dev);
         if (ctx->advice_desc_dev) (void)hipFree(ctx->advice_desc_dev);
+        if (ctx->cells_ktab_dev) (void)hipFree(ctx->cells_ktab_dev);
         for (auto &kv : ctx->progs) { if (kv.second.dev) (void)hipFree(kv.second.dev); if (kv.second.inv_dev) (void)hipFree(kv.second.inv_dev); }
         if (ctx->pipe) h2r_pipeline_destroy(ctx->pipe);
     }
@@ -2591,6 +2621,25 @@ int32_t launch_advice(const h2r_ctx *ctx, AdviceArgs &aa, hipStream_t st) {
     HIP_TRY(hipGetLastError());
     return H2R_OK;
 }
+// The same image written directly from the operands (cells_kernel, h2r_cells.hpp): one wave per mul_mod, no record read.
+int32_t launch_cells(const h2r_ctx *ctx, CellsArgs &ca, hipStream_t st) {
+    const h2r_layout &lo = ctx->layout;
+    if (lo.num_limbs > 128 || lo.limb_nsub != 8 || lo.carry_nsub > 16) return H2R_E_UNSUPPORTED;
+    ca.desc = ctx->advice_desc_dev; ca.ktab = ctx->cells_ktab_dev;
+    ca.L = lo.num_limbs; ca.carry_sub_bits = lo.carry_sub_bits; ca.carry_nsub = lo.carry_nsub;
+    ca.rows = h2r_advice_rows(ctx);
+    ca.wm[0] = ctx->word_max.v[0]; ca.wm[1] = ctx->word_max.v[1]; ca.wm[2] = ctx->word_max.v[2];
+    ca.f = ctx->fc;
+    if (ca.out_stride < ((u64)ca.pre_rows + (u64)ca.T * ca.rows) * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
+    if (ca.n_items == 0) return H2R_OK;
+    if (ca.n_items >= (1ull << 31)) return H2R_E_UNSUPPORTED;
+    const u32 lds = cells_lds_bytes(lo.limb_width, lo.num_limbs);
+    ProfScope ps(H2R_KERNEL_CELLS, st, true);
+    if (lo.limb_width == 64) hipExtLaunchKernelGGL((cells_kernel<64>), dim3((unsigned)ca.n_items), dim3(64), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ca);
+    else hipExtLaunchKernelGGL((cells_kernel<32>), dim3((unsigned)ca.n_items), dim3(64), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ca);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+}
 }  // namespace
 
 int32_t h2r_mul_mod_emit_advice(const h2r_ctx *ctx, const void *a, const void *b, const void *n, uint32_t flags, const void *trace,
@@ -2598,6 +2647,17 @@ int32_t h2r_mul_mod_emit_advice(const h2r_ctx *ctx, const void *a, const void *b
     if (!ctx || !a || !b || !n || !trace || !advice_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     H2R_ON_DEVICE(ctx->params.device);
+    if (flags & H2R_ADVICE_DIRECT) {   // recomputed from (a, b, n) and the record's q, r limbs; nothing else of the record is read
+        const h2r_layout &lo = ctx->layout;
+        CellsArgs ca;
+        std::memset(&ca, 0, sizeof ca);
+        ca.opA = a; ca.opB = b; ca.op_stride = ctx->L;
+        ca.opQ = static_cast<const u8 *>(trace) + lo.plane_off[H2R_PL_Q]; ca.opR = static_cast<const u8 *>(trace) + lo.plane_off[H2R_PL_R];
+        ca.qr_stride = lo.record_stride / lo.limb_bytes;
+        ca.n = n; ca.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
+        ca.status = status; ca.T = 1; ca.n_items = batch; ca.out = static_cast<u8 *>(advice_out); ca.out_stride = out_stride;
+        return launch_cells(ctx, ca, static_cast<hipStream_t>(stream));
+    }
     AdviceArgs aa;
     std::memset(&aa, 0, sizeof aa);
     aa.opA = a; aa.opB = b; aa.op_stride = ctx->L; aa.n = n; aa.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
@@ -2609,12 +2669,24 @@ int32_t h2r_mul_mod_emit_advice(const h2r_ctx *ctx, const void *a, const void *b
 int32_t h2r_pow_trace_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *n, uint32_t flags, const void *trace,
                                   uint64_t elem_stride, const void *workspace, uint64_t batch, const uint8_t *status,
                                   void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
-    if (!ctx || !pl || !n || !trace || !workspace || !advice_out) return H2R_E_NULL;
+    if (!ctx || !pl || !n || !workspace || !advice_out) return H2R_E_NULL;
+    if (!trace && !(flags & H2R_ADVICE_DIRECT)) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (pl->num_mul_mods == 0 || batch == 0) return H2R_OK;
     H2R_ON_DEVICE(ctx->params.device);
     const u64 lb = ctx->layout.limb_bytes;
     const u8 *ws = reinterpret_cast<const u8 *>(round_up(reinterpret_cast<u64>(workspace), 256));   // as run_path carves it
+    if (flags & H2R_ADVICE_DIRECT) {   // from the call's operands alone (trace may be NULL: a call that wrote no records)
+        CellsArgs ca;
+        std::memset(&ca, 0, sizeof ca);
+        ca.opA = ws; ca.opB = ws + ctx->L * lb; ca.opQ = ws + 2 * ctx->L * lb; ca.opR = ws + 3 * ctx->L * lb;
+        ca.op_stride = 4ull * ctx->L; ca.qr_stride = ca.op_stride;
+        ca.n = n; ca.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
+        ca.status = status; ca.T = pl->num_mul_mods; ca.n_items = batch * pl->num_mul_mods;
+        ca.out = static_cast<u8 *>(advice_out); ca.out_stride = out_stride;
+        ca.pre_rows = pl->off_e_bits == UINT64_MAX ? 2u : 0u;
+        return launch_cells(ctx, ca, static_cast<hipStream_t>(stream));
+    }
     AdviceArgs aa;
     std::memset(&aa, 0, sizeof aa);
     aa.opA = ws; aa.opB = ws + ctx->L * lb; aa.op_stride = 4ull * ctx->L;

@@ -679,6 +679,13 @@ int32_t h2r_pow_trace_emit_stream(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
  *   h2r_pow_trace_emit_advice       the records of a pow / modpow / verify trace; `workspace` is the workspace that call
  *                                   was given (it holds every mul_mod's operands), elem_stride = 0 means pl->elem_stride. */
 #define H2R_ADVICE_ROW_BYTES 160u
+/* flags bit of h2r_mul_mod_emit_advice / h2r_pow_trace_emit_advice / h2r_verify_emit_advice: write the mul_mod rows DIRECTLY from
+ * the operands (a, b, q, r, n) -- one wave per mul_mod recomputes every cell the reference assigns (main_gate.mul_add
+ * big_integer/chip.rs:408, range_chip.assign :590, :598, :880-885, the is_equal_muled ops :851-893) and nothing of the record planes
+ * is read (mul_mod form: only its q, r limbs).  Byte-identical to the image of the stored records for every valid witness, and the
+ * store-bound form: the record-reading kernel is bound by its scattered loads.  With this flag h2r_pow_trace_emit_advice accepts
+ * trace = NULL (a pow call that wrote no records: trace = NULL, caller workspace -- the workspace holds every mul_mod's operands). */
+#define H2R_ADVICE_DIRECT 0x200u
 /* Row kinds (one per main-gate op shape) and their FIXED columns.  The gate every row satisfies:
  *   sa*a + sb*b + sc*c + sd*d + se*e + s_mul_ab*a*b + s_mul_cd*c*d + se_next*e(next row) + s_const = 0
  * RANGE_LIMB + j / RANGE_CARRY + j = row j of RangeChip::assign of a limb / of a carry: four sub-limb terms in a..d (the LAST
@@ -772,7 +779,8 @@ int32_t h2r_pow_trace_check(const h2r_ctx *ctx, const h2r_pow_layout *pl, const 
 enum { H2R_KERNEL_CHAIN = 0, H2R_KERNEL_TRACE = 1, H2R_KERNEL_HIST = 2, H2R_KERNEL_AUX = 3, H2R_KERNEL_EMIT = 4,
        H2R_KERNEL_STEP = 5 /* a pipeline step as one launch: records of call k + chains of call k+1 */,
        H2R_KERNEL_LOOKUP = 6 /* lookup_fill_kernel: the permuted columns */, H2R_KERNEL_SHA256 = 7 /* sha256_kernel */,
-       H2R_KERNEL_COUNT = 8 };
+       H2R_KERNEL_CELLS = 8 /* cells_kernel: the advice image written directly from the operands */,
+       H2R_KERNEL_COUNT = 9 };
 int32_t h2r_profile_enable(uint32_t capacity);
 int32_t h2r_profile_read(uint32_t kernel, float *ms_out, uint32_t max_count, uint32_t *count);
 
