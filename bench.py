@@ -260,6 +260,148 @@ def ensure_built():
             time.sleep(0.5)
 
 
+def advice_bench(args):
+    """--advice: the PROVER-CONSUMABLE witness as the product.  One step = one 1,024-signature RSAChip::modpow_public_key call whose
+    output is the 5-column advice image (what the reference writes cell by cell, main_gate.mul_add
+    big_integer/chip.rs:408, range_chip.assign :590, :598, :880-885, is_equal_muled :851-893): chain kernel (no record planes) +
+    assert_in_field witness and its rows + cells_kernel, which writes the pow rows directly from the operands.  The chain kernels of
+    call k + 1 run on a second stream next to the cells kernel of call k (two workspaces, two images; plain stream-ordered exports
+    and events -- no pipeline object).  roofline: cells_kernel, HBM-write bound, algorithmic bytes = the pow rows it writes
+    (12,078,240 B per RSA-2048 e = 65537 element)."""
+    import ctypes
+    env = DistEnv.from_environment(args.gpus, force=bool(os.environ.get("H2R_FORCE_DIST")))
+    w, bits, e = WORKLOADS[args.workload]
+    one_gpu = bool(os.environ.get("H2R_BENCH_ONE_GPU"))
+    if one_gpu:
+        env.local_rank = 0
+    torch.cuda.set_device(env.local_rank)
+    if env.world > 1 or env.force:
+        env.init("gloo" if one_gpu else "nccl")
+    chunk = args.batch if args.batch else 1024
+    e, chunk, steps, warmup = env.broadcast_ints([e, chunk, args.steps, args.warmup])
+    global_batch = chunk * env.world
+    lo, hi = shard_range(global_batch, env.rank, env.world)
+    chip = H.BigIntChip(w, bits, device=env.local_rank)
+    ns, xs, un, ux = synth_inputs(w, bits, lo, hi)
+    n_dev, x_dev = chip.assign_integer(un), chip.assign_integer(ux)
+    pl = chip.pow_fixed_layout(e)
+    dev = "cuda:%d" % env.local_rank
+    L = _lib.lib()
+    sec = (ctypes.c_uint64 * 2)()
+    rows = int(L.h2r_modpow_public_key_advice_rows(chip._ctx, ctypes.byref(pl), sec))
+    pow_rows = int(sec[1])
+    elem_bytes = rows * 160
+    nimg = 2
+    images = [torch.zeros(chunk * elem_bytes, dtype=torch.uint8, device=dev) for _ in range(nimg)]
+    wss = [torch.zeros(chip.workspace_bytes(chunk, pl.num_mul_mods), dtype=torch.uint8, device=dev) for _ in range(nimg)]
+    ifs = chip.in_field_layout()[0]
+    ifb = [torch.zeros(chunk * ifs, dtype=torch.uint8, device=dev) for _ in range(nimg)]
+    outs = [torch.zeros((chunk, chip.num_limbs), dtype=chip.torch_dtype, device=dev) for _ in range(nimg)]
+    sts = [torch.zeros(chunk, dtype=torch.uint8, device=dev) for _ in range(nimg)]
+    s_chain, s_cells = torch.cuda.Stream(priority=-1), torch.cuda.Stream()   # (the short kernels first when a CU frees up)
+    chain_done = [torch.cuda.Event() for _ in range(nimg)]
+    cells_done = [torch.cuda.Event() for _ in range(nimg)]
+    issued = [0]
+    results = [None] * nimg
+
+    def step():
+        k = issued[0] % nimg
+        with torch.cuda.stream(s_chain):
+            if issued[0] >= nimg:
+                s_chain.wait_event(cells_done[k])        # the workspace / witness of call k - 2 have been consumed
+            results[k] = chip.pow_mod_fixed_exp(x_dev, e, n_dev, want_trace=False, check_in_field=True, workspace=wss[k], out=outs[k],
+                                                status=sts[k], in_field_buf=ifb[k])
+            chain_done[k].record(s_chain)                # (the cells kernel needs the operands only)
+            # the assert_in_field rows of the element (2 % of its bytes) on this stream too: next to the previous call's cells kernel
+            _lib.check(L.h2r_fresh_op_emit_advice(chip._ctx, _lib.FRESH_OPS.index("is_in_field"), _lib.H2R_ADVICE_ASSERT_ONE, x_dev.data_ptr(),
+                                                  n_dev.data_ptr(), None, ifb[k].data_ptr(), 0, 0, chunk, sts[k].data_ptr(), images[k].data_ptr(),
+                                                  elem_bytes, chip._stream()), "h2r_fresh_op_emit_advice")
+        with torch.cuda.stream(s_cells):
+            s_cells.wait_event(chain_done[k])
+            # the pow rows, written directly from the call's operands (h2r_modpow_public_key_emit_advice = the two exports in a row)
+            _lib.check(L.h2r_pow_trace_emit_advice(chip._ctx, ctypes.byref(pl), n_dev.data_ptr(), _lib.H2R_ADVICE_DIRECT, None, 0, wss[k].data_ptr(),
+                                                   chunk, sts[k].data_ptr(), images[k].data_ptr() + int(sec[0]) * 160, elem_bytes, chip._stream()),
+                       "h2r_pow_trace_emit_advice")
+            cells_done[k].record(s_cells)
+        issued[0] += 1
+        return k
+
+    step()
+    torch.cuda.synchronize()
+    t_ramp = time.perf_counter()
+    ramp = 0
+    while ramp < args.clock_warmup_calls // 8 and time.perf_counter() - t_ramp < 0.5:   # (a call is 2 ms: a dozen keep the clocks up)
+        step()
+        ramp += 1
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    _lib.profile_enable(0 if args.no_kernel_timing else 8 * steps + 8)
+    env.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        last = step()
+    torch.cuda.synchronize()
+    env.barrier()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
+    cells_ms = _lib.profile_read(_lib.KERNEL_CELLS)
+    chain_ms = _lib.profile_read(_lib.KERNEL_CHAIN)
+    emit_ms = _lib.profile_read(_lib.KERNEL_EMIT)
+    _lib.profile_enable(0)
+    # what was timed is the real thing: results against pow(), and the timed image against the image of a call WITH records
+    assert int(sts[last].max().item()) == 0 or (w, bits) != (64, 2048)
+    got = H.AssignedInteger(outs[last].contiguous(), w).to_big_uint()
+    for i in (0, 1, 2, chunk - 1):
+        if i < chunk and xs[i] < ns[i]:
+            assert got[i] == pow(xs[i], e, ns[i]), "GPU result differs from pow(x, e, n)"
+    sample = min(chunk, 8)
+    ref = chip.pow_mod_fixed_exp(H.AssignedInteger(x_dev.limbs_dev[:sample].contiguous(), w), e, H.AssignedInteger(n_dev.limbs_dev[:sample].contiguous(), w),
+                                 check_in_field=True)
+    ref_img = ref.emit_modpow_advice(direct=False)
+    torch.cuda.synchronize()
+    timed = images[last].view(chunk, elem_bytes)[:sample]
+    ok = ref.status.cpu().numpy() == 0
+    assert torch.equal(timed[torch.from_numpy(ok).to(timed.device)], ref_img[torch.from_numpy(ok).to(ref_img.device)]), \
+        "the timed advice image differs from the image of the records"
+    if env.rank == 0:
+        algo = chunk * pow_rows * 160
+        avg_s = (sum(cells_ms) / len(cells_ms)) / 1e3 if cells_ms else float("nan")
+        achieved = algo / avg_s / 1e9 if cells_ms else None
+        line = {
+            "metric": "RSA-2048 pkcs1v15 witness assigns/sec" if bits == 2048 else "RSA-%d witness assigns/sec" % bits,
+            "value": round(global_batch * steps / dt, 1), "unit": "assigns/s", "n_gpus": env.world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(1e3 * dt / steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u%d" % w, "data": "synthetic",
+            "config": {"workload": "%s batch=%d per GPU, %d-bit limbs, advice image (%d rows = %d B/assign: %d assert_in_field rows + %d pow rows)" %
+                                   (args.workload, chunk, w, rows, elem_bytes, int(sec[0]), pow_rows),
+                       "path": "advice image",
+                       "per_gpu_batch": chunk, "global_batch": global_batch, "calls_per_step": 1, "signatures_per_call": chunk,
+                       "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world, "ranks": env.world,
+                       "pipeline": "chain kernels of call k+1 on a second stream next to cells_kernel of call k (2 workspaces, 2 images), stream-ordered exports + events",
+                       "untimed_clock_warmup_calls": ramp, "buffer_placement": "as allocated"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
+                         "traffic_source": "not measured", "kernel": "cells_kernel<%d>" % w, "launches_timed": len(cells_ms),
+                         "signatures_per_launch": chunk, "avg_launch_ms": round(1e3 * avg_s, 4) if cells_ms else None,
+                         "algorithmic_bytes_per_launch": algo,
+                         "chain_kernel_avg_ms": round(sum(chain_ms) / len(chain_ms), 4) if chain_ms else None,
+                         "in_field_rows_kernel_avg_ms": round(sum(emit_ms) / len(emit_ms), 4) if emit_ms else None},
+            "whole_path_hbm_frac": round(global_batch * steps / dt * elem_bytes / (env.world * HBM_PEAK_GBS * 1e9), 4),
+        }
+        if env.world == 1 and args.pmc_traffic == "auto" and cells_ms:
+            hbm, how = measured_pmc_traffic(["--advice", "--workload", args.workload, "--batch", str(chunk)], "cells_kernel")
+            if hbm is not None:
+                line["roofline"]["traffic"] = hbm
+                line["roofline"]["traffic_source"] = how
+            else:
+                line["roofline"]["traffic_source"] = "live measurement skipped: " + how
+        if env.world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(w, bits, e, un, ux)
+        print(json.dumps(line))
+    env.finalize()
+
+
 def main():
     # the image exports NCCL_DEBUG=VERSION, which makes RCCL print a banner on stdout; rank 0's stdout is ONE JSON line
     if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
@@ -288,6 +430,9 @@ def main():
     ap.add_argument("--messages", type=int, default=0, metavar="LEN",
                     help="with --verify: start every call from LEN-byte message bytes (RSASignatureVerifier, src/lib.rs:183-246: "
                          "SHA-256 + hashed-message limbs on the device in the timed region) instead of precomputed digests")
+    ap.add_argument("--advice", action="store_true",
+                    help="time the prover-consumable witness: every step's output is the 5-column advice image of its modpow_public_key "
+                         "elements (assert_in_field rows + pow rows written directly from the operands by cells_kernel), no record planes")
     ap.add_argument("--shared-modulus", action="store_true",
                     help="one key, many signatures (H2R_F_SHARED_MODULUS): every element uses element 0's modulus")
     ap.add_argument("--no-kernel-timing", action="store_true",
@@ -315,6 +460,8 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args.gpus)
+    if args.advice:
+        return advice_bench(args)
 
     env = DistEnv.from_environment(args.gpus, force=bool(os.environ.get("H2R_FORCE_DIST")))
     w, bits, e = WORKLOADS[args.workload]

@@ -89,6 +89,7 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_trace_lookup_permutation", "h2r_trace_lookup_permutation_hist",
            "h2r_trace_flatten", "h2r_pow_trace_flatten", "h2r_stream_bytes", "h2r_pow_stream_bytes", "h2r_trace_flatten_ex",
            "h2r_pow_trace_flatten_ex", "h2r_trace_emit_stream", "h2r_pow_trace_emit_stream", "h2r_mul_mod_trace_check", "h2r_pow_trace_check",
+           "h2r_modpow_public_key_advice_rows", "h2r_modpow_public_key_emit_advice",
            "h2r_advice_rows", "h2r_mul_mod_emit_advice", "h2r_pow_trace_emit_advice", "h2r_pow_advice_rows", "h2r_advice_row_kinds",
            "h2r_advice_fixed_row", "h2r_fresh_op_advice_rows", "h2r_fresh_op_row_kinds", "h2r_fresh_op_emit_advice",
            "h2r_verify_advice_rows", "h2r_verify_row_kinds", "h2r_verify_emit_advice", "h2r_verify_layout_var", "h2r_verify_pkcs1v15_var_batch", "h2r_pipeline_verify_pkcs1v15_var",
@@ -102,7 +103,7 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_last_hip_error"]
 H2R_ADVICE_ASSERT_ONE = 0x100
 H2R_ADVICE_DIRECT = 0x200
-KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST, KERNEL_AUX, KERNEL_EMIT, KERNEL_STEP, KERNEL_LOOKUP, KERNEL_SHA256 = 0, 1, 2, 3, 4, 5, 6, 7
+KERNEL_CHAIN, KERNEL_TRACE, KERNEL_HIST, KERNEL_AUX, KERNEL_EMIT, KERNEL_STEP, KERNEL_LOOKUP, KERNEL_SHA256, KERNEL_CELLS = 0, 1, 2, 3, 4, 5, 6, 7, 8
 H2R_HASHED_MSG_STREAM_BYTES = 288
 H2R_STREAM_FIELD_AB = 1
 FRESH_OPS = ["add", "sub", "add_mod", "sub_mod", "is_zero", "is_equal_fresh", "is_less_than", "is_less_than_or_equal",
@@ -236,6 +237,9 @@ def lib():
     L.h2r_hashed_msg_row_kinds.argtypes = [vp, vp]
     L.h2r_hashed_msg_emit_advice.argtypes = [vp, vp, u64, u64, vp, vp, u64, vp]
     L.h2r_mul_mod_emit_advice.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp, vp, u64, vp]
+    L.h2r_modpow_public_key_advice_rows.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp]
+    L.h2r_modpow_public_key_advice_rows.restype = u64
+    L.h2r_modpow_public_key_emit_advice.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, vp, u32, vp, vp, vp, u64, vp, vp, u64, vp]
     L.h2r_pow_trace_emit_advice.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, u32, vp, u64, vp, u64, vp, vp, u64, vp]
     L.h2r_mul_mod_trace_check.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp, vp, vp, vp]
     L.h2r_pow_trace_check.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, vp, ctypes.c_char_p, ctypes.c_size_t, u32, vp, u64, vp, u64, vp,

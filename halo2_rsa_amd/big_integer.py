@@ -250,6 +250,32 @@ class BatchResult:
                                                   self.status.data_ptr(), out.data_ptr(), out.shape[1], chip._stream()), "h2r_pow_trace_emit_advice")
         return out
 
+    def emit_modpow_advice(self, out: Optional[torch.Tensor] = None, direct: Optional[bool] = None) -> torch.Tensor:
+        """One RSAChip::modpow_public_key element as advice rows (h2r_modpow_public_key_emit_advice): [assert_in_field(x, n)]
+        [pow_mod_fixed_exp], uint8 [batch, rows * 160] in HBM.  A result made with want_trace=False (chain + in-field witness only)
+        gets its pow rows written directly from the operands; direct=True asks for that with records present too."""
+        kind, x, _, n, eb = self.inputs
+        if kind == "mul_mod" or self.in_field is None or self.workspace is None:
+            raise ValueError("emit_modpow_advice: a modpow_public_key result with its in-field witness and workspace")
+        chip = self.trace.chip if self.trace is not None else self.chip
+        pl = self.trace.pow_layout if self.trace is not None else self.pow_layout
+        batch = x.batch
+        if direct is None:
+            direct = self.trace is None
+        nrows = int(lib().h2r_modpow_public_key_advice_rows(chip._ctx, ctypes.byref(pl), None))
+        if out is None:
+            out = torch.empty((batch, nrows * 160), dtype=torch.uint8, device=x.limbs_dev.device)
+        else:
+            if out.dtype != torch.uint8 or out.numel() < batch * nrows * 160 or not out.is_contiguous():
+                raise ValueError("emit_modpow_advice: out must be a contiguous uint8 buffer of at least batch * rows * 160 bytes")
+            out = out.view(-1)[:batch * nrows * 160].view(batch, nrows * 160)
+        flags = chip._flags(n, batch) | (_lib.H2R_ADVICE_DIRECT if direct else 0)
+        check(lib().h2r_modpow_public_key_emit_advice(chip._ctx, ctypes.byref(pl), x.data_ptr(), n.data_ptr(), flags, self.in_field.buf.data_ptr(),
+                                                      self.trace.buf.data_ptr() if (self.trace is not None and not direct) else None,
+                                                      self.workspace.data_ptr(), batch, self.status.data_ptr(), out.data_ptr(), out.shape[1],
+                                                      chip._stream()), "h2r_modpow_public_key_emit_advice")
+        return out
+
     def flatten(self, elem: int) -> np.ndarray:
         """The element's witness in the reference's assignment order (modpow_public_key: in-field stream, then pow)."""
         st = self.trace.flatten(elem)
@@ -453,7 +479,7 @@ class BigIntChip:
         wp = workspace.data_ptr() if workspace is not None else None
         in_field = None
         if check_in_field:
-            in_field = self._in_field_trace(batch, in_field_buf) if want_trace else None
+            in_field = self._in_field_trace(batch, in_field_buf) if (want_trace or in_field_buf is not None or workspace is not None) else None
             check(lib().h2r_modpow_public_key_batch(self._ctx, a.data_ptr(), n.data_ptr(), eb, len(eb), batch, self._flags(n, batch), tp,
                                                     in_field.buf.data_ptr() if in_field is not None else None, out.data_ptr(),
                                                     status.data_ptr(), wp, self._stream()), "modpow_public_key")

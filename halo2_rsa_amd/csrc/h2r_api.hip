@@ -612,12 +612,23 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
             std::memcpy(&e[5], r + lo.plane_off[H2R_PL_MODACC] + (u64)i * lo.limb_bytes, lo.limb_bytes);
             std::memcpy(&e[9], r + lo.plane_off[H2R_PL_AMNQ2] + (u64)i * lo.limb_bytes, lo.limb_bytes);
         };
-        u64 kt[CELLS_KT_WORDS] = {0}, e[10], e2[10];
+        u64 kt[CELLS_TAB_WORDS] = {0}, e[10], e2[10];
         for (u32 i = 0; i < 3; ++i) { col(i, e); std::memcpy(&kt[10 * i], e, sizeof e); }
         col(2, e2);
         bool fixed_point = true;
         for (u32 i = 3; i < lo.num_cols; ++i) { col(i, e); fixed_point = fixed_point && std::memcmp(e, e2, sizeof e) == 0; }
         if (!fixed_point) { h2r_ctx_destroy(c); return H2R_E_UNSUPPORTED; }
+        for (int k = 0; k < 3; ++k) kt[CELLS_KT_WM + k] = c->word_max.v[k];
+        for (int k = 0; k < 4; ++k) kt[CELLS_KT_P + k] = c->fc.p[k];
+        std::memcpy(&kt[CELLS_KT_FC], &c->fc, sizeof c->fc);
+        {   // the column rows' fast-path sources, packed against this shape's LDS plan
+            const CellsLds lp = cells_lds_plan(w, L);
+            u32 *fs = reinterpret_cast<u32 *>(&kt[CELLS_KT_FSRC]);
+            for (u32 k = 0; k < ADVICE_COL_ROWS * 3; ++k) {
+                fs[k] = cells_pack_fast_src(lp, w, cells_fast_src(k / 3, k % 3, false));
+                fs[CELLS_SRC_WORDS + k] = cells_pack_fast_src(lp, w, cells_fast_src(k / 3, k % 3, true));
+            }
+        }
         if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&c->cells_ktab_dev), sizeof kt), "hipMalloc(cells table)") ||
             !hip_ok(hipMemcpy(c->cells_ktab_dev, kt, sizeof kt, hipMemcpyHostToDevice), "hipMemcpy(cells table)")) {
             h2r_ctx_destroy(c);
@@ -2625,15 +2636,23 @@ int32_t launch_advice(const h2r_ctx *ctx, AdviceArgs &aa, hipStream_t st) {
 int32_t launch_cells(const h2r_ctx *ctx, CellsArgs &ca, hipStream_t st) {
     const h2r_layout &lo = ctx->layout;
     if (lo.num_limbs > 128 || lo.limb_nsub != 8 || lo.carry_nsub > 16) return H2R_E_UNSUPPORTED;
-    ca.desc = ctx->advice_desc_dev; ca.ktab = ctx->cells_ktab_dev;
+    ca.ktab = ctx->cells_ktab_dev;
+    ca.per_col_magic = (u32)(((1ull << 32) + (ADVICE_COL_ROWS + (lo.carry_nsub + 3) / 4) - 1) / (ADVICE_COL_ROWS + (lo.carry_nsub + 3) / 4));
     ca.L = lo.num_limbs; ca.carry_sub_bits = lo.carry_sub_bits; ca.carry_nsub = lo.carry_nsub;
     ca.rows = h2r_advice_rows(ctx);
-    ca.wm[0] = ctx->word_max.v[0]; ca.wm[1] = ctx->word_max.v[1]; ca.wm[2] = ctx->word_max.v[2];
-    ca.f = ctx->fc;
     if (ca.out_stride < ((u64)ca.pre_rows + (u64)ca.T * ca.rows) * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
     if (ca.n_items == 0) return H2R_OK;
     if (ca.n_items >= (1ull << 31)) return H2R_E_UNSUPPORTED;
-    const u32 lds = cells_lds_bytes(lo.limb_width, lo.num_limbs);
+    // Residency: FOUR waves per CU, one per SIMD (measured: 6.64-6.67 TB/s against 6.47 with the six the RSA-2048 shape's 26 KB would
+    // allow, 4.2 with three -- profiles/r04_cells_kernel.txt).  Enforced the way occupancy is enforced on this hardware: by the LDS request.
+    u32 lds = cells_lds_bytes(lo.limb_width, lo.num_limbs);
+    const u32 quarter = (ctx->lds_per_cu / 4 - 512) & ~15u;
+    if (lds < quarter) lds = quarter;
+    if (lds > 48 * 1024) {
+        if (lo.limb_width == 64) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cells_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        else (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cells_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipGetLastError();
+    }
     ProfScope ps(H2R_KERNEL_CELLS, st, true);
     if (lo.limb_width == 64) hipExtLaunchKernelGGL((cells_kernel<64>), dim3((unsigned)ca.n_items), dim3(64), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ca);
     else hipExtLaunchKernelGGL((cells_kernel<32>), dim3((unsigned)ca.n_items), dim3(64), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ca);
@@ -2951,6 +2970,30 @@ int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, 
     ra.a = powed; ra.b = hashed; ra.b_stride = 4; ra.first_off = vl->off_em;
     ra.out = out + (sec[0] + sec[1] + sec[2]) * ADVICE_ROW_BYTES;                                      // :138-198
     return launch_row_prog(ctx, em, ra, st);
+}
+
+// ---- one RSAChip::modpow_public_key element as advice rows: [assert_in_field(x, n)] [pow_mod_fixed_exp] (src/chip.rs:106-111) ----
+uint64_t h2r_modpow_public_key_advice_rows(const h2r_ctx *ctx, const h2r_pow_layout *pl, uint64_t section_rows[2]) {
+    if (!ctx || !pl) return 0;
+    const u64 r[2] = {h2r_fresh_op_advice_rows(ctx, FRESH_IS_IN_FIELD, H2R_ADVICE_ASSERT_ONE), h2r_pow_advice_rows(ctx, pl)};
+    if (!r[0]) return 0;
+    if (section_rows) { section_rows[0] = r[0]; section_rows[1] = r[1]; }
+    return r[0] + r[1];
+}
+
+int32_t h2r_modpow_public_key_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *x, const void *n, uint32_t flags,
+                                          const void *in_field_trace, const void *trace, const void *workspace, uint64_t batch,
+                                          const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
+    if (!ctx || !pl || !x || !n || !in_field_trace || !workspace || !advice_out) return H2R_E_NULL;
+    u64 sec[2];
+    const u64 rows = h2r_modpow_public_key_advice_rows(ctx, pl, sec);
+    if (!rows) return H2R_E_UNSUPPORTED;
+    if (out_stride < rows * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
+    int32_t rc = h2r_fresh_op_emit_advice(ctx, FRESH_IS_IN_FIELD, (flags & H2R_F_SHARED_MODULUS) | H2R_ADVICE_ASSERT_ONE, x, n, nullptr, in_field_trace, 0, 0,
+                                          batch, status, advice_out, out_stride, stream);
+    if (rc) return rc;
+    return h2r_pow_trace_emit_advice(ctx, pl, n, flags | (trace ? 0u : H2R_ADVICE_DIRECT), trace, 0, workspace, batch, status,
+                                     static_cast<u8 *>(advice_out) + sec[0] * ADVICE_ROW_BYTES, out_stride, stream);
 }
 
 // ---- the hashed-message limbs of RSASignatureVerifier as advice rows (src/lib.rs:225-239) ---------------------------------

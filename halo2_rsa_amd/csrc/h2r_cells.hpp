@@ -11,13 +11,17 @@
 //     previous chunk's last accumulator from lane 63 (v_readlane).  The last row of a column leaves its total in LDS.
 //   * eq_b and is_equal_muled (chip.rs:617, :857-893): once the last mul row is built, the 2L - 1 un-carried columns get
 //     a_b, the carries (three-level reduction, the last level a generate / propagate chain solved by ballot: the record
-//     kernel's scheme) and the running eq_bit into four LDS planes; the 23 + nrc rows of a column then read their cells from
-//     those planes through one table-driven fetch (no per-row-kind branches around the loads).  The input-independent
+//     kernel's scheme) and the running eq_bit into LDS planes of ready-made cells; the 23 + nrc rows of a column then COPY their
+//     cells from those planes through one table-driven fetch (no per-row-kind branches).  The input-independent
 //     accumulated_extra chain (:869-875) reaches its fixed point at column 2, so its values are a 3-entry table.
 //   * range rows (main_gate.decompose of a limb / carry) are cut from the value itself.
-// 64 rows = 10,240 bytes are staged in LDS and leave as ten 1 KB store instructions (16 bytes per lane, non-temporal), so the
-// only HBM traffic is the image itself: 635,680 bytes written per RSA-2048 mul_mod against 1.3 KB read.  No workgroup barrier
-// anywhere (a workgroup IS a wave); ~18 KB of LDS per wave for RSA-2048 = 8 waves per CU, a few store streams per CU.
+// 64 rows = 10,240 bytes are staged in LDS and leave as ten 1 KB store instructions (16 bytes per lane) that cover whole
+// 128-byte lines (the first chunk of an item is cut so that every later one starts on a line), so the only HBM traffic is the
+// image itself: 635,680 bytes written per RSA-2048 mul_mod against 1.3 KB read.  No workgroup barrier anywhere (a workgroup IS a
+// wave) and no global load inside the row loop (vmcnt counts loads and stores alike: waiting for a load would wait for the
+// previous chunk's stores).  Chunks that lie wholly inside the mul rows or the column rows of a VALID mul_mod take a branch-free
+// fast path; chunks that straddle sections, and a mul_mod whose q, r are not its quotient and remainder (never produced by this
+// library: is_zero's inverse witnesses appear), take the general path.
 // Bound: HBM writes.  The image is byte-identical to advice_kernel's for every valid record (tests).
 #pragma once
 
@@ -26,9 +30,10 @@
 namespace h2r {
 
 struct CellsArgs {
-    const u32 *desc;                     // [rows] advice_pack(advice_decode(r)) -- the ctx's row table (L2-resident)
-    const u64 *ktab;                     // [3][10] + pad: columns 0, 1, >= 2 of the accumulated_extra constants:
-                                         //   acc_extra + W [3 words], q_acc [2], mod_acc [1], nq [3], a - nq [1]
+    const u64 *ktab;                     // CELLS_TAB_WORDS words (one table per ctx): [3][10] columns 0, 1, >= 2 of the accumulated_extra
+                                         // constants (acc_extra + W [3 words], q_acc [2], mod_acc [1], nq [3], a - nq [1]); word_max
+                                         // (chip.rs:838) at 32; the field modulus at 36; the field's FieldConsts at 40; the column rows'
+                                         // packed fast-path sources (cells_pack_fast_src) at 56
     const void *opA, *opB, *opQ, *opR;   // limbs of item k at [k * op_stride, k * op_stride + L)
     u64 op_stride, qr_stride;            // (limbs) of opA / opB and of opQ / opR
     const void *n; u64 n_stride;         // [elem][L] limbs (stride 0 = shared)
@@ -37,15 +42,18 @@ struct CellsArgs {
     u8 *out; u64 out_stride;             // element e's image at out + e * out_stride: pre_rows rows, then record t at + (pre_rows + t * rows) * 160
     u32 rows, pre_rows;
     u32 L, carry_sub_bits, carry_nsub;
-    u64 wm[3];                           // word_max (chip.rs:838)
-    FieldConsts f;
+    u32 per_col_magic;                   // ceil(2^32 / (23 + nrc)): row of the column part -> column index by one mul_hi
+    u64 *dbg;                            // developer build (ABL & 256): s_memtime stamps of item dbg_item's chunks
+    u32 dbg_item;
 };
 
-constexpr u32 CELLS_KT_WORDS = 32;       // 3 x 10 words + padding (the generic fetch reads three words)
+constexpr u32 CELLS_KT_WORDS = 40;       // the table's words kept in LDS: 3 x 10 + padding (the general fetch reads three words), word_max, p
+constexpr u32 CELLS_KT_WM = 32, CELLS_KT_P = 36, CELLS_KT_FC = 40, CELLS_KT_FSRC = 56;   // (FieldConsts: 13 words)
+constexpr u32 CELLS_TAB_WORDS = CELLS_KT_FSRC + 72;   // + the fast path's packed source codes: 2 x 72 32-bit words
 constexpr u32 CELLS_SRC_WORDS = 72;      // the column rows' source codes (23 x 3) + padding
 
-// Source of one cell of an is_equal_muled column row (rows 0..22 of the column, cells a, b, c):
-//   bits 0-2 base (0 none, 1 AB, 2 EQB, 3 AMB, 4 SUM, 5 the constants' table), bits 3-6 word offset in a table entry,
+// ---- general path: source of one cell of an is_equal_muled column row (rows 0..22 of the column, cells a, b, c) ----
+//   bits 0-2 base (0 none, 1 AB, 2 EQB, 3 a_b = AB - EQB, 4 SUM, 5 the constants' table), bits 3-6 word offset in a table entry,
 //   bits 7-8 words - 1 of a table entry, bit 9 column c - 1 (zero for c = 0), bits 10-11 transform (0 the value, 1 value >> w,
 //   2 value mod 2^w, 3 value with its low limb cleared), bit 12 two's complement (field subtraction), bit 13 "the carry's
 //   range-assigned duplicate": the last column compares with q_acc instead (chip.rs:888-892)
@@ -81,10 +89,80 @@ __host__ __device__ constexpr u32 cells_col_src(u32 j, u32 k) {
     }
 }
 
-// dynamic LDS of one wave (bytes): stage, operands, four column planes, flags, the constants' table
-__host__ __device__ inline u32 cells_lds_bytes(u32 limb_width, u32 L) {
-    const u32 ww = limb_width == 64 ? 3u : 2u;
-    return 64u * ADVICE_ROW_BYTES + 5u * L * 8u + 4u * (2u * L * ww + 2u) * 8u + CELLS_KT_WORDS * 8u + 2u * L * 4u + CELLS_SRC_WORDS * 4u;
+// ---- fast path (a valid mul_mod): every cell of a column row is a COPY of a ready-made entry in LDS ----
+// Constant entries (32 bytes): 0, 1, 2^w and, for columns 0, 1, >= 2, the five values of the accumulated_extra step.  Per-column
+// entries (planes of 2L entries): AB, EQB, a_b (as its field element), SUM, NQ1 (32 bytes) and the carry, c (16 bytes: their
+// high halves are zero).  A source code: bits 0-3 entry kind, bit 4 column c - 1 (the zero entry for c = 0).
+enum : u32 { CE_ZERO = 0, CE_ONE, CE_BW, CE_K_ACCX, CE_K_QACC, CE_K_MODACC, CE_K_NQ2, CE_K_AMNQ2,     // constants (K_*: by min(c, 2))
+             CE_AB, CE_EQB, CE_AMB, CE_SUM, CE_NQ1, CE_COUT, CE_CMOD, CE_M1 = 16 };
+constexpr u32 CELLS_CONST_ENTRIES = 3 + 3 * 5;   // 0, 1, 2^w, then [3][ACCX, QACC, MODACC, NQ2, AMNQ2]
+__host__ __device__ constexpr u32 cells_fast_src(u32 j, u32 k, bool last_col) {
+    switch (j * 3 + k) {
+        case 0 * 3 + 0: return CE_AB; case 0 * 3 + 1: return CE_EQB; case 0 * 3 + 2: return CE_AMB;
+        case 1 * 3 + 0: return CE_AMB; case 1 * 3 + 1: return CE_COUT | CE_M1; case 1 * 3 + 2: return CE_SUM;
+        case 2 * 3 + 0: return CE_COUT;
+        case 3 * 3 + 0: return CE_CMOD;
+        case 4 * 3 + 0: return CE_BW; case 4 * 3 + 1: return CE_COUT; case 4 * 3 + 2: return CE_NQ1;
+        case 5 * 3 + 0: return CE_SUM; case 5 * 3 + 1: return CE_NQ1; case 5 * 3 + 2: return CE_CMOD;
+        case 6 * 3 + 0: return CE_CMOD; case 6 * 3 + 1: return CE_CMOD;
+        case 7 * 3 + 0: return CE_K_QACC | CE_M1; case 7 * 3 + 1: return CE_K_ACCX;
+        case 8 * 3 + 0: return CE_K_QACC;
+        case 9 * 3 + 0: return CE_K_MODACC;
+        case 10 * 3 + 0: return CE_BW; case 10 * 3 + 1: return CE_K_QACC; case 10 * 3 + 2: return CE_K_NQ2;
+        case 11 * 3 + 0: return CE_K_ACCX; case 11 * 3 + 1: return CE_K_NQ2; case 11 * 3 + 2: return CE_K_AMNQ2;
+        case 12 * 3 + 0: return CE_K_MODACC; case 12 * 3 + 1: return CE_K_AMNQ2;
+        // a valid mul_mod: every comparison holds -- d = 0, its "inverse" witness 1, every flag 1
+        case 13 * 3 + 0: return CE_CMOD; case 13 * 3 + 1: return CE_K_MODACC;                  // sub [c, mod_acc, 0]
+        case 14 * 3 + 0: case 14 * 3 + 1: case 14 * 3 + 2: return CE_ONE;                       // bit
+        case 15 * 3 + 1: case 15 * 3 + 2: return CE_ONE;                                         // [0, 1, 1]
+        case 16 * 3 + 0: return CE_ONE;                                                          // [1, 0]
+        case 17 * 3 + 0: case 17 * 3 + 1: case 17 * 3 + 2: return CE_ONE;                       // and
+        case 18 * 3 + 0: return CE_COUT; case 18 * 3 + 1: return last_col ? CE_K_QACC : CE_COUT;   // sub [carry, dup | acc_extra, 0]
+        case 19 * 3 + 0: case 19 * 3 + 1: case 19 * 3 + 2: return CE_ONE;
+        case 20 * 3 + 1: case 20 * 3 + 2: return CE_ONE;
+        case 21 * 3 + 0: return CE_ONE;
+        case 22 * 3 + 0: case 22 * 3 + 1: case 22 * 3 + 2: return CE_ONE;
+        default: return CE_ZERO;
+    }
+}
+
+// dynamic LDS of one wave (byte offsets): stage, operands, constants, column planes, flags, code tables
+struct CellsLds { u32 ops, kt, ce, ab, eqb, sum, amb, nq1, cout, cmod, fl, src, fsrc, total; };
+__host__ __device__ inline CellsLds cells_lds_plan(u32 limb_width, u32 L) {
+    // 64-bit limbs: 32-byte entries AB, EQB, SUM, a_b, NQ1 and 16-byte entries carry, c.  32-bit limbs (every value but a_b's field
+    // element is below 2^128): 16-byte entries AB, EQB, SUM, a 32-byte a_b; NQ1, the carry and c are cut from the SUM entry on the way.
+    const bool w64 = limb_width == 64;
+    const u32 es = w64 ? 32u : 16u, n = 2u * L + 1u;
+    CellsLds p; u32 o = 64u * ADVICE_ROW_BYTES;
+    p.ops = o; o += 5u * L * 8u;
+    p.kt = o; o += CELLS_KT_WORDS * 8u;
+    p.ce = o; o += CELLS_CONST_ENTRIES * 32u;
+    p.ab = o; o += n * es; p.eqb = o; o += n * es; p.sum = o; o += n * es;
+    p.amb = o; o += n * 32u; p.nq1 = o; o += w64 ? n * 32u : 0u;
+    p.cout = o; o += w64 ? n * 16u : 0u; p.cmod = o; o += w64 ? n * 16u : 0u;
+    p.fl = o; o += 2u * L * 4u;
+    p.src = o; o += CELLS_SRC_WORDS * 4u;
+    p.fsrc = o; o += 2u * CELLS_SRC_WORDS * 4u;
+    p.total = (o + 15u) & ~15u;
+    return p;
+}
+__host__ __device__ inline u32 cells_lds_bytes(u32 limb_width, u32 L) { return cells_lds_plan(limb_width, L).total; }
+// A fast-path source as the kernel wants it: bits 0-11 LDS offset / 16 of the plane's (or constant's) first entry, bits 12-15 entry
+// stride / 16, bit 16 column c - 1, bit 17 indexed by min(column, 2) (the accumulated_extra constants), bit 18 the entry has a high
+// half, bits 19-22 (32-bit limbs) the cut of the SUM entry (CE_NQ1 / CE_COUT / CE_CMOD)
+__host__ __device__ inline u32 cells_pack_fast_src(const CellsLds &lp, u32 limb_width, u32 code) {
+    const u32 kind = code & 15u, m1 = (code & CE_M1) ? 1u : 0u;
+    u32 base, stride = 0, byk = 0, hi = 1, xf = 0;
+    if (kind < 3) base = lp.ce + kind * 32;
+    else if (kind < CE_AB) { base = lp.ce + (3 + (kind - 3)) * 32; stride = 5 * 32; byk = 1; }
+    else if (limb_width == 64) {
+        if (kind < CE_COUT) { base = kind == CE_AB ? lp.ab : kind == CE_EQB ? lp.eqb : kind == CE_AMB ? lp.amb : kind == CE_SUM ? lp.sum : lp.nq1; stride = 32; }
+        else { base = kind == CE_COUT ? lp.cout : lp.cmod; stride = 16; hi = 0; }
+    } else {
+        if (kind == CE_AMB) { base = lp.amb; stride = 32; }
+        else { base = kind == CE_AB ? lp.ab : kind == CE_EQB ? lp.eqb : lp.sum; stride = 16; hi = 0; xf = kind >= CE_NQ1 ? kind : 0; }
+    }
+    return (base / 16) | ((stride / 16) << 12) | (m1 << 16) | (byk << 17) | (hi << 18) | (xf << 19);
 }
 
 // Segmented inclusive scan of an NWD-dword unsigned value over the 64 lanes: lane l receives the sum of the values of lanes
@@ -113,22 +191,53 @@ __device__ __forceinline__ void cells_seg_scan(u32 (&v)[NWD], bool head) {
     step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast:31 into rows 2 and 3
 }
 
-template <int LW>
+// Inclusive prefix sums of an NWD-dword value over the 64 lanes (no segments: the caller subtracts the sum in front of a lane's
+// segment, fetched with ds_bpermute); the sums of 64 limb products cannot overflow NWD dwords.  One DPP add-with-carry per dword and
+// step: row_shr 1/2/4/8 inside the 16-lane rows (lanes without a source add zero), then row_bcast 15 / 31 across them.  (Written as
+// assembly: from the builtin the compiler makes a zero move, a DPP move and an add per dword.  The s_nop covers the two wait
+// states between a VALU write of a register and a DPP read of it, which the assembler does not insert in inline code.)
+#define H2R_DPP_STEP3(ctrl_) \
+    "v_add_co_u32_dpp %0, vcc, %0, %0 " ctrl_ "\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " ctrl_ "\n\tv_addc_co_u32_dpp %2, vcc, %2, %2, vcc " ctrl_ "\n\ts_nop 1\n\t"
+#define H2R_DPP_STEP5(ctrl_) \
+    "v_add_co_u32_dpp %0, vcc, %0, %0 " ctrl_ "\n\tv_addc_co_u32_dpp %1, vcc, %1, %1, vcc " ctrl_ "\n\tv_addc_co_u32_dpp %2, vcc, %2, %2, vcc " ctrl_ \
+    "\n\tv_addc_co_u32_dpp %3, vcc, %3, %3, vcc " ctrl_ "\n\tv_addc_co_u32_dpp %4, vcc, %4, %4, vcc " ctrl_ "\n\ts_nop 1\n\t"
+#define H2R_DPP_SHR(n_) "row_shr:" #n_ " row_mask:0xf bank_mask:0xf bound_ctrl:0"
+template <int NWD>
+__device__ __forceinline__ void cells_prefix_sum(u32 (&v)[NWD]) {
+    static_assert(NWD == 3 || NWD == 5, "dwords of a column sum");
+    if constexpr (NWD == 3) {
+        asm volatile("s_nop 1\n\t" H2R_DPP_STEP3(H2R_DPP_SHR(1)) H2R_DPP_STEP3(H2R_DPP_SHR(2)) H2R_DPP_STEP3(H2R_DPP_SHR(4)) H2R_DPP_STEP3(H2R_DPP_SHR(8))
+                     H2R_DPP_STEP3("row_bcast:15 row_mask:0xa bank_mask:0xf") H2R_DPP_STEP3("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]) :: "vcc");
+    } else {
+        asm volatile("s_nop 1\n\t" H2R_DPP_STEP5(H2R_DPP_SHR(1)) H2R_DPP_STEP5(H2R_DPP_SHR(2)) H2R_DPP_STEP5(H2R_DPP_SHR(4)) H2R_DPP_STEP5(H2R_DPP_SHR(8))
+                     H2R_DPP_STEP5("row_bcast:15 row_mask:0xa bank_mask:0xf") H2R_DPP_STEP5("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]) :: "vcc");
+    }
+}
+
+// ABL (developer ablations, tools/cells_bench.hip; 0 in the library): 1 no row building, 2 no global stores, 4 plain instead of
+// non-temporal stores, 8 no is_equal_muled rows (zero rows) and no column phase, 16 no mul rows, 64 no fast paths, 128 chunks not
+// aligned to 128-byte lines
+template <int LW, int ABL = 0>
 __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
     using limb_t = typename LimbT<LW>::type;
-    constexpr int WW = LW == 64 ? 3 : 2;     // 64-bit words of a wide value in the planes
+    constexpr bool FAST = !(ABL & 64);
+    constexpr int WW = LW == 64 ? 3 : 2;     // 64-bit words of a wide value
+    constexpr int ESW = LW == 64 ? 4 : 2;    // 64-bit words of a plane entry
     constexpr int NWD = LW == 64 ? 5 : 3;    // dwords of a running column sum (133 / 71 bits)
     constexpr u64 LMASK = LW == 64 ? ~0ull : 0xffffffffull;
+    constexpr u32 NP = ADVICE_ROW_BYTES / 16;   // 16-byte pieces of a row
     extern __shared__ uint4 cells_smem[];
     const u32 lane = threadIdx.x;
     const u32 L = a.L, L2 = 2 * L, C = 2 * L - 1;
+    const CellsLds lp = cells_lds_plan(LW, L);
+    u8 *smem = reinterpret_cast<u8 *>(cells_smem);
     uint4 *stage = cells_smem;                                       // 64 rows x 160 bytes
-    u64 *sa = reinterpret_cast<u64 *>(cells_smem + 64 * (ADVICE_ROW_BYTES / 16));
-    u64 *sb = sa + L, *sq = sb + L, *sn = sq + L, *sr = sn + L;
-    u64 *pAB = sr + L, *pEQB = pAB + (L2 * WW + 2), *pAMB = pEQB + (L2 * WW + 2), *pSUM = pAMB + (L2 * WW + 2);
-    u64 *kt = pSUM + (L2 * WW + 2);
-    u32 *pFL = reinterpret_cast<u32 *>(kt + CELLS_KT_WORDS);
-    u32 *s_src = pFL + L2;
+    u64 *sa = reinterpret_cast<u64 *>(smem + lp.ops), *sb = sa + L, *sq = sb + L, *sn = sq + L, *sr = sn + L;
+    u64 *kt = reinterpret_cast<u64 *>(smem + lp.kt);
+    u64 *pAB = reinterpret_cast<u64 *>(smem + lp.ab), *pEQB = reinterpret_cast<u64 *>(smem + lp.eqb), *pSUM = reinterpret_cast<u64 *>(smem + lp.sum);
+    u32 *pFL = reinterpret_cast<u32 *>(smem + lp.fl), *s_src = reinterpret_cast<u32 *>(smem + lp.src), *f_src = reinterpret_cast<u32 *>(smem + lp.fsrc);
     // the column phase's scratch lives in the stage (free between two chunks)
     u64 *xDH0 = reinterpret_cast<u64 *>(stage), *xDH1 = xDH0 + L2, *xSLO = xDH1 + L2;
     u32 *xSHI = reinterpret_cast<u32 *>(xSLO + L2);
@@ -146,65 +255,91 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
         if (lane < CELLS_KT_WORDS) kt[lane] = a.ktab[lane];
     }
     u8 *out = a.out + (u64)elem * a.out_stride + ((u64)a.pre_rows + (u64)t * a.rows) * ADVICE_ROW_BYTES;
-    if (t == 0 && lane < a.pre_rows * (ADVICE_ROW_BYTES / 16)) {   // pow_mod_fixed_exp's acc = assign_constant(1, L): [1, 0, 0, 0, 0] then [0, ...]
+    if (t == 0 && lane < a.pre_rows * NP) {   // pow_mod_fixed_exp's acc = assign_constant(1, L): [1, 0, 0, 0, 0] then [0, ...]
         uint4 *pr = reinterpret_cast<uint4 *>(a.out + (u64)elem * a.out_stride);
         pr[lane] = make_uint4(lane == 0 ? 1u : 0u, 0, 0, 0);
     }
     const U192 Z = U192::make(0, 0, 0);
     const U192 Bw = LW == 64 ? U192::make(0, 1, 0) : U192::make(1ull << 32, 0, 0);   // 2^w
-    const U192 Wm = U192::make(a.wm[0], a.wm[1], a.wm[2]);
+    // (word_max and the field modulus are read from the LDS copy of the table where they are needed: kernel arguments live in SGPRs)
+    const uint4 Z4 = make_uint4(0, 0, 0, 0);
     auto lim = [&](u64 v) { return U192::make(v, 0, 0); };
-    auto rdp = [&](const u64 *pl, u32 c) -> U192 { return U192::make(pl[(u64)c * WW], pl[(u64)c * WW + 1], WW == 3 ? pl[(u64)c * WW + 2] : 0); };
-    auto rdp_s = [&](const u64 *pl, u32 c) -> U192 {   // two's complement
-        const u64 w1 = pl[(u64)c * WW + 1];
-        return U192::make(pl[(u64)c * WW], w1, WW == 3 ? pl[(u64)c * WW + 2] : (u64)((i64)w1 >> 63));
+    auto rdp = [&](const u64 *pl, u32 c) -> U192 { return U192::make(pl[(u64)c * ESW], pl[(u64)c * ESW + 1], WW == 3 ? pl[(u64)c * ESW + 2] : 0); };
+    auto wrp = [&](u64 *pl, u32 c, const U192 &v) {   // (a whole entry: the fast path copies it as two 16-byte pieces)
+        pl[(u64)c * ESW] = v.w[0]; pl[(u64)c * ESW + 1] = v.w[1];
+        if constexpr (ESW == 4) { pl[(u64)c * ESW + 2] = v.w[2]; pl[(u64)c * ESW + 3] = 0; }
     };
-    auto wrp = [&](u64 *pl, u32 c, const U192 &v) { pl[(u64)c * WW] = v.w[0]; pl[(u64)c * WW + 1] = v.w[1]; if constexpr (WW == 3) pl[(u64)c * WW + 2] = v.w[2]; };
     auto shr_limb = [&](const U192 &v) -> U192 { return v.shr(LW); };
-    auto cell = [&](uint4 *p, const U192 &v, bool is_signed) {   // canonical field element, 32 bytes little-endian
-        u64 x[4] = {v.w[0], v.w[1], v.w[2], 0};
+    auto field4 = [&](const U192 &v, bool is_signed, u64 (&x)[4]) {   // canonical field element of a (two's complement) value
+        x[0] = v.w[0]; x[1] = v.w[1]; x[2] = v.w[2]; x[3] = 0;
         if (is_signed && (v.w[2] >> 63)) {   // x < 0 -> p + x (mod 2^256)
             x[3] = ~0ull;
             u64 cy = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const u64 s1 = x[k] + a.f.p[k]; const u64 c1 = s1 < x[k]; const u64 s2 = s1 + cy; cy = c1 | (u64)(s2 < s1); x[k] = s2; }
+            for (int k = 0; k < 4; ++k) { const u64 s1 = x[k] + kt[CELLS_KT_P + k]; const u64 c1 = s1 < x[k]; const u64 s2 = s1 + cy; cy = c1 | (u64)(s2 < s1); x[k] = s2; }
         }
+    };
+    auto cell = [&](uint4 *p, const U192 &v, bool is_signed) {   // 32 bytes little-endian
+        u64 x[4];
+        field4(v, is_signed, x);
         p[0] = make_uint4((u32)x[0], (u32)(x[0] >> 32), (u32)x[1], (u32)(x[1] >> 32));
         p[1] = make_uint4((u32)x[2], (u32)(x[2] >> 32), (u32)x[3], (u32)(x[3] >> 32));
     };
     // row rr of RangeChip::assign of the value v (nsub sub-limbs of sub_bits bits, the last one possibly shorter): four sub-limbs in
     // columns a..d -- the LAST row reversed, so that the last (overflow) term is in column a, and zero-padded -- and in column e what
     // remains to be composed (main_gate.decompose)
-    auto range_vals = [&](u64 v_lo, u64 v_hi, u32 nsub, u32 sub_bits, u32 rr, U192 &c0, U192 &c1, U192 &c2, U192 &c3, U192 &rem) {
+    // (64-bit limbs: sub-limbs are bytes -- 8 of a limb, 8 + a shorter ninth of a carry; 32-bit limbs: the value fits 64 bits)
+    auto range_vals = [&](u64 v_lo, u64 v_hi, u32 nsub, u32 sub_bits, u32 rr, u64 &c0, u64 &c1, u64 &c2, u64 &c3, u64 &rem_lo, u64 &rem_hi) {
         const u32 last = (nsub - 1) / 4, n_last = nsub - 4 * last;
-        const u64 sm = (1ull << sub_bits) - 1;
         auto sub = [&](u32 k) -> u64 {
-            const u32 sh = k * sub_bits;
-            const u64 x = sh >= 64 ? v_hi >> (sh - 64) : ((v_lo >> sh) | (sh ? v_hi << (64 - sh) : 0));
-            return k < nsub ? x & sm : 0;
+            if constexpr (LW == 64) return k < 8 ? (v_lo >> (8 * k)) & 0xff : (k == 8 ? v_hi & 0xff : 0);
+            else return k < nsub ? (v_lo >> (k * sub_bits)) & ((1u << sub_bits) - 1) : 0;
         };
         const bool rev = rr >= last;
         const u32 k0 = rev ? nsub - 1 : 4 * rr;
-        c0 = lim(sub(k0));
-        c1 = lim(rev ? (n_last > 1 ? sub(k0 - 1) : 0) : sub(k0 + 1));
-        c2 = lim(rev ? (n_last > 2 ? sub(k0 - 2) : 0) : sub(k0 + 2));
-        c3 = lim(rev ? (n_last > 3 ? sub(k0 - 3) : 0) : sub(k0 + 3));
-        const u32 cl = 4 * rr * sub_bits;   // low bits already composed: cleared
-        rem = cl >= 64 ? U192::make(0, cl >= 128 ? 0 : (v_hi >> (cl - 64)) << (cl - 64), 0)
-                       : U192::make(cl ? (v_lo >> cl) << cl : v_lo, v_hi, 0);
+        c0 = sub(k0);
+        c1 = rev ? (n_last > 1 ? sub(k0 - 1) : 0) : sub(k0 + 1);
+        c2 = rev ? (n_last > 2 ? sub(k0 - 2) : 0) : sub(k0 + 2);
+        c3 = rev ? (n_last > 3 ? sub(k0 - 3) : 0) : sub(k0 + 3);
+        if constexpr (LW == 64) {   // low bytes already composed: cleared (4 rr bytes)
+            rem_lo = rr == 0 ? v_lo : (rr == 1 ? v_lo & ~0xffffffffull : 0);
+            rem_hi = rr <= 2 ? v_hi : 0;
+        } else {
+            const u32 cl = 4 * rr * sub_bits;
+            rem_lo = cl >= 64 ? 0 : (v_lo >> cl) << cl;
+            rem_hi = 0;
+        }
     };
     for (u32 k = lane; k < ADVICE_COL_ROWS * 3; k += 64) s_src[k] = cells_col_src(k / 3, k % 3);
+    if constexpr (FAST) {
+        const u32 *packed = reinterpret_cast<const u32 *>(a.ktab + CELLS_KT_FSRC);
+        for (u32 k = lane; k < 2 * CELLS_SRC_WORDS; k += 64) f_src[k] = packed[k];
+    }
     wave_sync();
+    if constexpr (FAST) {   // the constant entries
+        uint4 *ce = reinterpret_cast<uint4 *>(smem + lp.ce);
+        if (lane < CELLS_CONST_ENTRIES) {
+            U192 v = Z;
+            if (lane == CE_ONE) v = lim(1);
+            else if (lane == CE_BW) v = Bw;
+            else if (lane >= 3) {
+                const u32 kc = (lane - 3) / 5, s = (lane - 3) % 5;
+                const u64 *e = kt + kc * 10;
+                v = s == 0 ? U192::make(e[0], e[1], e[2]) : s == 1 ? U192::make(e[3], e[4], 0) : s == 2 ? lim(e[5]) : s == 3 ? U192::make(e[6], e[7], e[8]) : lim(e[9]);
+            }
+            cell(ce + 2 * lane, v, false);
+        }
+    }
 
     // ---- the 2L - 1 un-carried columns: eq_b, a_b, the carries and the running eq_bit (chip.rs:614-623, 857-893) -> planes ----
+    bool item_ok = true;
     auto column_phase = [&]() {
+        const U192 Wm = U192::make(kt[CELLS_KT_WM], kt[CELLS_KT_WM + 1], kt[CELLS_KT_WM + 2]);
         for (u32 c = lane; c < C; c += 64) {
             const U192 A = rdp(pAB, c);
             U192 Q = rdp(pEQB, c);                 // (holds the q*n column until here)
             if (c < L) { Q = Q + lim(sr[c]); wrp(pEQB, c, Q); }                // eq_b[i] = qn[i] + r[i]  :617
-            const U192 amb = A - Q;               // :859 (two's complement)
-            wrp(pAMB, c, amb);
-            const U192 D = amb + Wm;              // >= 0
+            const U192 D = (A - Q) + Wm;          // a_b + word_max >= 0  :859-860
             const U192 dhi = shr_limb(D);
             xSLO[c] = D.w[0] & LMASK; xDH0[c] = dhi.w[0]; xDH1[c] = dhi.w[1];
         }
@@ -230,12 +365,20 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
             if (col) {
                 const U192 dhp = c ? U192::make(xDH0[c - 1], xDH1[c - 1], 0) : Z;
                 const U192 carry_in = dhp + lim((u64)shp + (f ? 1u : 0u));
-                const U192 sum = rdp_s(pAMB, c) + Wm + carry_in;               // :860-861
+                const U192 amb = rdp(pAB, c) - rdp(pEQB, c);
+                const U192 sum = amb + Wm + carry_in;                          // :860-861
                 wrp(pSUM, c, sum);
                 const U192 cout = shr_limb(sum);
                 const u32 kc = c < 2 ? c : 2;
                 f1 = (sum.w[0] & LMASK) == kt[kc * 10 + 5];                      // cs_acc_eq  :873
                 if (c == C - 1) f2 = cout.w[0] == kt[kc * 10 + 3] && cout.w[1] == kt[kc * 10 + 4];   // final_carry_eq  :890
+                if constexpr (FAST) cell(reinterpret_cast<uint4 *>(smem + lp.amb) + 2 * c, amb, true);   // the ready-made cells of the column
+                if constexpr (FAST && LW == 64) {
+                    cell(reinterpret_cast<uint4 *>(smem + lp.nq1) + 2 * c, U192::make(sum.w[0] & ~LMASK, sum.w[1], sum.w[2]), false);
+                    reinterpret_cast<uint4 *>(smem + lp.cout)[c] = make_uint4((u32)cout.w[0], (u32)(cout.w[0] >> 32), (u32)cout.w[1], (u32)(cout.w[1] >> 32));
+                    const u64 cm = sum.w[0] & LMASK;
+                    reinterpret_cast<uint4 *>(smem + lp.cmod)[c] = make_uint4((u32)cm, (u32)(cm >> 32), 0, 0);
+                }
             }
             const u64 bad = __ballot(col && !(f1 && f2));
             const bool prev_ok = all_ok && (bad & ((1ull << lane) - 1)) == 0;
@@ -245,26 +388,171 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
             }
             all_ok = all_ok && bad == 0;
         }
+        item_ok = all_ok;
         wave_sync();
     };
 
-    const u32 mul_rows = C + L * L, r_T5 = 4 * L + 2 * mul_rows;
+    const u32 mul_rows = C + L * L, r_T3 = 4 * L, r_T5 = r_T3 + 2 * mul_rows, r_T6 = r_T5 + L + 4;
+    const u32 nrc = (a.carry_nsub + 3) / 4, per_col = ADVICE_COL_ROWS + nrc;
     u32 carry[NWD];
 #pragma unroll
     for (int k = 0; k < NWD; ++k) carry[k] = 0;
-    u32 dnext = lane < a.rows ? a.desc[lane] : 0u;
     bool columns_done = false;
-    for (u32 r0 = 0; r0 < a.rows; r0 += 64) {
+    u32 dec_r0 = ~0u, dec_I = 0, dec_k = 0, dec_len = 1;   // the mul rows' fast path: row r0 + lane = position dec_k of column dec_I (both muls: 2C columns)
+    // the first chunk ends where the image reaches a 128-byte line (160 = 128 + 32: at most three rows), every later chunk of 64
+    // rows (80 lines) then starts on one
+    u32 n_rows = 64;
+    if constexpr (!(ABL & 128)) {
+        const u32 mis = (u32)(reinterpret_cast<u64>(out) & 127u);
+        if (mis && (mis & 31u) == 0) n_rows = (128u - mis) / 32u;
+    }
+    for (u32 r0 = 0; r0 < a.rows; r0 += n_rows, n_rows = 64) {
+        if (a.rows - r0 < n_rows) n_rows = a.rows - r0;
         const u32 r = r0 + lane;
-        const bool valid = r < a.rows;
-        AdviceRowId id = advice_unpack(dnext);
+        const bool valid = lane < n_rows;
+        uint4 *srow = stage + (u64)lane * NP;
+        bool built = (ABL & 1) != 0;
+        u64 t_0 = 0; u32 path = 0;
+        if constexpr (ABL & 256) t_0 = __builtin_amdgcn_s_memtime();
+        // ================= fast path: a chunk of mul(a, b) / mul(q, n) rows (not the one that holds the last of them) =================
+        if (!built && !(ABL & (16 | 64)) && n_rows == 64 && r0 >= r_T3 && r0 + 64 < r_T5) {
+            // row -> (mul, column i, position k in the column: 0 = the column's constant 0).  The first such chunk decodes its rows
+            // in closed form; every later one moves each lane's (column, position) 64 rows on.
+            if (dec_r0 != r0) {
+                u32 e = r - r_T3;
+                const u32 qn0 = e >= mul_rows ? 1u : 0u;
+                e -= qn0 * mul_rows;
+                // Columns 0 .. L-1 hold 2, 3, ..., L + 1 rows (head + accumulators): column i starts at i (i + 3) / 2.  Columns
+                // L .. 2L-2 mirror columns L-2 .. 0, so counted from the END of the section the same closed form applies.
+                const bool back = e >= L * (L + 3) / 2;
+                const u32 ee = back ? mul_rows - 1 - e : e;
+                u32 ii = (u32)((sqrtf(8.f * (float)ee + 9.f) - 3.f) * 0.5f);
+                if ((ii + 1) * (ii + 4) / 2 <= ee) ++ii;          // the float estimate is off by at most one
+                else if (ii * (ii + 3) / 2 > ee) --ii;
+                const u32 kk = ee - ii * (ii + 3) / 2;
+                const u32 i0 = back ? C - 1 - ii : ii;
+                dec_k = back ? ii + 1 - kk : kk;
+                dec_I = qn0 * C + i0;
+                dec_len = (i0 < L ? i0 : C - 1 - i0) + 2;
+            } else {
+                dec_k += 64;
+                while (__ballot(dec_k >= dec_len) != 0) {
+                    if (dec_k >= dec_len) {
+                        dec_k -= dec_len; ++dec_I;
+                        const u32 i1 = dec_I >= C ? dec_I - C : dec_I;
+                        dec_len = (i1 < L ? i1 : C - 1 - i1) + 2;
+                    }
+                }
+            }
+            dec_r0 = r0 + 64;
+            const u32 qn = dec_I >= C ? 1u : 0u, i = dec_I - qn * C, k = dec_k;
+            const bool is_ma = k != 0;
+            const u32 jmin = i >= L ? i - L + 1 : 0, j = jmin + k - 1;
+            u64 x = 0, y = 0;
+            if (is_ma) { x = (qn ? sq : sa)[j]; y = (qn ? sn : sb)[i - j]; }
+            u32 p[NWD], own[NWD];
+#pragma unroll
+            for (int w = 0; w < NWD; ++w) p[w] = 0;
+            if constexpr (LW == 64) {
+                const u128 pr = (u128)x * y;
+                p[0] = (u32)pr; p[1] = (u32)(pr >> 32); p[2] = (u32)(pr >> 64); p[3] = (u32)(pr >> 96);
+            } else {
+                const u64 pr = (u64)(u32)x * (u32)y;
+                p[0] = (u32)pr; p[1] = (u32)(pr >> 32);
+            }
+#pragma unroll
+            for (int w = 0; w < NWD; ++w) own[w] = p[w];
+            // the column's running sum = (prefix sum over the lanes) - (prefix sum at the column's head row: lane - k), or + what
+            // the column had gathered in the previous chunk when it began there
+            cells_prefix_sum<NWD>(p);
+            {
+                const bool here = k <= lane;
+                u32 base[NWD], c = 0;
+#pragma unroll
+                for (int w = 0; w < NWD; ++w) {
+                    const u32 sh = (u32)__builtin_amdgcn_ds_bpermute((int)((lane - k) << 2), (int)p[w]);
+                    base[w] = here ? ~sh : carry[w];                 // p - sh = p + ~sh + 1
+                }
+                c = here ? 1u : 0u;
+#pragma unroll
+                for (int w = 0; w < NWD; ++w) p[w] = __builtin_addc(p[w], base[w], c, &c);
+            }
+#pragma unroll
+            for (int w = 0; w < NWD; ++w) carry[w] = (u32)__builtin_amdgcn_readlane((int)p[w], 63);
+            u32 q[NWD], br = 0;
+#pragma unroll
+            for (int w = 0; w < NWD; ++w) q[w] = __builtin_subc(p[w], own[w], br, &br);
+            if (is_ma && k == (i < L ? i + 1 : C - i)) {   // the column's last row: its total
+                u64 *pl = qn ? pEQB : pAB;
+                if constexpr (LW == 64) wrp(pl, i, U192::make(((u64)p[1] << 32) | p[0], ((u64)p[3] << 32) | p[2], p[4]));
+                else wrp(pl, i, U192::make(((u64)p[1] << 32) | p[0], p[2], 0));
+            }
+            // [x_j, y_{i-j}, acc_prev, acc, 0]  :408 (a column's head row: all zero)
+            srow[0] = make_uint4((u32)x, (u32)(x >> 32), 0, 0); srow[1] = Z4;
+            srow[2] = make_uint4((u32)y, (u32)(y >> 32), 0, 0); srow[3] = Z4;
+            if constexpr (LW == 64) {
+                srow[4] = make_uint4(q[0], q[1], q[2], q[3]); srow[5] = make_uint4(q[4], 0, 0, 0);
+                srow[6] = make_uint4(p[0], p[1], p[2], p[3]); srow[7] = make_uint4(p[4], 0, 0, 0);
+            } else {
+                srow[4] = make_uint4(q[0], q[1], q[2], 0); srow[5] = Z4;
+                srow[6] = make_uint4(p[0], p[1], p[2], 0); srow[7] = Z4;
+            }
+            srow[8] = Z4; srow[9] = Z4;
+            built = true; path = 1;
+        }
+        // ================= fast path: a chunk of is_equal_muled column rows of a valid mul_mod =================
+        if constexpr (FAST) {
+            if (!built && !(ABL & 8) && columns_done && item_ok && n_rows == 64 && r0 >= r_T6) {
+                const u32 rr = r - r_T6;
+                const u32 c = __umulhi(rr, a.per_col_magic);
+                u32 k = rr - c * per_col;
+                const bool lastc = c == C - 1;
+                const bool is_range = !lastc && k >= 18 && k < 18 + nrc;
+                if (!lastc && k >= 18 + nrc) k -= nrc;
+                const u32 *codes = f_src + (lastc ? CELLS_SRC_WORDS : 0u) + (is_range ? 0u : k * 3);
+                const u32 kc = c < 2 ? c : 2, kcp = c < 3 ? c - 1 : 2;   // (kcp is used for c >= 1 only)
+                auto entry = [&](u32 code, u32 &hi_off, u32 &xf) -> u32 {   // LDS byte address of the cell's entry; hi_off: of its high half
+                    const bool m1 = (code >> 16) & 1u, byk = (code >> 17) & 1u;
+                    const u32 idx = byk ? (m1 ? kcp : kc) : (m1 ? c - 1 : c);
+                    const bool zero = m1 && c == 0;
+                    const u32 addr = zero ? lp.ce : ((code & 0xfffu) + idx * ((code >> 12) & 15u)) << 4;
+                    hi_off = (!zero && ((code >> 18) & 1u)) ? addr + 16 : lp.ce;   // (no high half: the zero entry)
+                    xf = zero ? 0u : (code >> 19) & 15u;
+                    return addr;
+                };
+                auto cut = [&](const uint4 &l, u32 xf) -> uint4 {   // 32-bit limbs: value >> 32, value mod 2^32, value with its low limb cleared
+                    if constexpr (LW == 64) return l;
+                    else return xf == CE_COUT ? make_uint4(l.y, l.z, l.w, 0) : xf == CE_CMOD ? make_uint4(l.x, 0, 0, 0) : xf == CE_NQ1 ? make_uint4(0, l.y, l.z, l.w) : l;
+                };
+                u32 h0, h1, h2, x0, x1, x2;
+                const u32 a0 = entry(codes[0], h0, x0), a1 = entry(codes[1], h1, x1), a2 = entry(codes[2], h2, x2);
+                const uint4 l0 = cut(*reinterpret_cast<const uint4 *>(smem + a0), x0), g0 = *reinterpret_cast<const uint4 *>(smem + h0);
+                const uint4 l1 = cut(*reinterpret_cast<const uint4 *>(smem + a1), x1), g1 = *reinterpret_cast<const uint4 *>(smem + h1);
+                const uint4 l2 = cut(*reinterpret_cast<const uint4 *>(smem + a2), x2), g2 = *reinterpret_cast<const uint4 *>(smem + h2);
+                uint4 o[NP] = {l0, g0, l1, g1, l2, g2, Z4, Z4, Z4, Z4};
+                if (is_range) {   // RangeChip::assign(carry, ...)  :880-885
+                    uint4 cv;
+                    if constexpr (LW == 64) cv = reinterpret_cast<const uint4 *>(smem + lp.cout)[c];
+                    else cv = cut(reinterpret_cast<const uint4 *>(smem + lp.sum)[c], CE_COUT);
+                    u64 c0, c1, c2, c3, rl, rh;
+                    range_vals(((u64)cv.y << 32) | cv.x, ((u64)cv.w << 32) | cv.z, a.carry_nsub, a.carry_sub_bits, k - 18, c0, c1, c2, c3, rl, rh);
+                    o[0] = make_uint4((u32)c0, 0, 0, 0); o[1] = Z4; o[2] = make_uint4((u32)c1, 0, 0, 0); o[3] = Z4;
+                    o[4] = make_uint4((u32)c2, 0, 0, 0); o[5] = Z4; o[6] = make_uint4((u32)c3, 0, 0, 0); o[7] = Z4;
+                    o[8] = make_uint4((u32)rl, (u32)(rl >> 32), (u32)rh, (u32)(rh >> 32)); o[9] = Z4;
+                }
+#pragma unroll
+                for (u32 w = 0; w < NP; ++w) srow[w] = o[w];
+                built = true; path = 2;
+            }
+        }
+        // ================= general path: any chunk (sections may meet inside it) =================
+        if (!built) {
+        AdviceRowId id = advice_decode(valid ? r : 0u, L, nrc);
         if (!valid) { id.kind = ROWK_NOP; id.sect = 9; }
-        if (r0 + 64 < a.rows) dnext = r + 64 < a.rows ? a.desc[r + 64] : 0u;   // in flight while this chunk is built
         U192 v0 = Z, v1 = Z, v2 = Z, v3 = Z, v4 = Z;
         bool sg0 = false, sg1 = false, sg2 = false, need_inv = false;
-
         // ---- mul(a, b), mul(q, n): one limb product per lane, the column's running sums by a segmented scan ----
-        if (__ballot(id.sect == 1) != 0) {
+        if (!(ABL & 16) && __ballot(id.sect == 1) != 0) {
             const bool is_ma = id.sect == 1 && id.kind == ROWK_MUL_ADD;
             u32 p[NWD], own[NWD];
 #pragma unroll
@@ -306,7 +594,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 if (id.j == (id.i < L ? id.i : L - 1)) wrp(id.qn ? pEQB : pAB, id.i, acc);   // the column's total
             }
         }
-        if (!columns_done && r0 + 64 >= r_T5) {   // every mul row is built: the columns' carries before any row that needs them
+        if (!(ABL & 8) && !columns_done && r0 + n_rows >= r_T5) {   // every mul row is built: the columns' carries before any row that needs them
             wave_sync();
             column_phase();
             columns_done = true;
@@ -314,17 +602,21 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
         // ---- the other sections: range rows, eq_b, the is_equal_muled preamble and its column rows ----
         if (id.sect == 0) {                                          // RangeChip::assign(q[k] / r[k], w / 8, w)  :590, :598
             const u64 v = id.i < L ? sq[id.i] : sr[id.i - L];
-            range_vals(v, 0, 8, LW / 8, id.j, v0, v1, v2, v3, v4);
+            u64 c0, c1, c2, c3, rl, rh;
+            range_vals(v, 0, 8, LW / 8, id.j, c0, c1, c2, c3, rl, rh);
+            v0 = lim(c0); v1 = lim(c1); v2 = lim(c2); v3 = lim(c3); v4 = U192::make(rl, rh, 0);
         } else if (id.sect == 2) {                                   // eq_b[i] = qn[i] + r[i]  :617
             const U192 e = rdp(pEQB, id.i);
             v1 = lim(sr[id.i]); v0 = e - v1; v2 = e;
         } else if (id.sect == 3) {                                   // :851-856
             if (id.i == 0) v0 = Bw; else if (id.i == 3) { v0 = lim(1); v1 = v0; v2 = v0; }
-        } else if (id.sect == 4) {
+        } else if (!(ABL & 8) && id.sect == 4) {
             const u32 c = id.i;
             if (id.kind >= ROWK_RANGE_CARRY) {                       // RangeChip::assign(carry, ...)  :880-885
                 const U192 cout = shr_limb(rdp(pSUM, c));
-                range_vals(cout.w[0], cout.w[1], a.carry_nsub, a.carry_sub_bits, id.kind - ROWK_RANGE_CARRY, v0, v1, v2, v3, v4);
+                u64 c0, c1, c2, c3, rl, rh;
+                range_vals(cout.w[0], cout.w[1], a.carry_nsub, a.carry_sub_bits, id.kind - ROWK_RANGE_CARRY, c0, c1, c2, c3, rl, rh);
+                v0 = lim(c0); v1 = lim(c1); v2 = lim(c2); v3 = lim(c3); v4 = U192::make(rl, rh, 0);
             } else {
                 const u32 j = id.j;
                 auto fetch = [&](u32 code, bool &sg) -> U192 {
@@ -333,17 +625,17 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                     sg = ((code >> 12) & 1u) != 0;
                     if (base == 0 || (m1 && c == 0)) return Z;
                     const u32 idx = c - m1;
-                    const u64 *ptr; u32 nw;
-                    if (base == CS_KT) { ptr = kt + (idx < 2 ? idx : 2) * 10 + ((code >> 3) & 15u); nw = ((code >> 7) & 3u) + 1; }
-                    else { ptr = (base == CS_AB ? pAB : base == CS_EQB ? pEQB : base == CS_AMB ? pAMB : pSUM) + (u64)idx * WW; nw = WW; }
-                    const u64 w0 = ptr[0], w1r = ptr[1], w2r = ptr[2];
-                    const u64 w1 = nw > 1 ? w1r : 0;
-                    const u64 w2 = nw > 2 ? w2r : (sg ? (u64)((i64)w1 >> 63) : 0);
-                    const U192 val = U192::make(w0, w1, w2);
+                    if (base == CS_AMB) return rdp(pAB, idx) - rdp(pEQB, idx);   // a_b  :859 (two's complement)
+                    U192 val;
+                    if (base == CS_KT) {
+                        const u64 *ptr = kt + (idx < 2 ? idx : 2) * 10 + ((code >> 3) & 15u);
+                        const u32 nw = ((code >> 7) & 3u) + 1;
+                        val = U192::make(ptr[0], nw > 1 ? ptr[1] : 0, nw > 2 ? ptr[2] : 0);
+                    } else val = rdp(base == CS_AB ? pAB : base == CS_EQB ? pEQB : pSUM, idx);
                     if (xf == 0) return val;
                     if (xf == 1) return shr_limb(val);
-                    if (xf == 2) return lim(w0 & LMASK);
-                    return U192::make(w0 & ~LMASK, w1, w2);
+                    if (xf == 2) return lim(val.w[0] & LMASK);
+                    return U192::make(val.w[0] & ~LMASK, val.w[1], val.w[2]);
                 };
                 bool s0, s1, s2;
                 const U192 c0 = fetch(s_src[j * 3], s0), c1 = fetch(s_src[j * 3 + 1], s1), c2 = fetch(s_src[j * 3 + 2], s2);
@@ -363,37 +655,46 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 }
             }
         }
-        // ---- stage the row, then the chunk leaves as whole 16-byte-per-lane lines ----
         if (valid) {
-            uint4 *p = stage + (u64)lane * (ADVICE_ROW_BYTES / 16);
-            cell(p, v0, sg0); cell(p + 2, v1, sg1); cell(p + 4, v2, sg2); cell(p + 6, v3, false); cell(p + 8, v4, false);
+            cell(srow, v0, sg0); cell(srow + 2, v1, sg1); cell(srow + 4, v2, sg2); cell(srow + 6, v3, false); cell(srow + 8, v4, false);
             if (need_inv) {
-                u64 x[4] = {v0.w[0], v0.w[1], v0.w[2], 0};
-                if (v0.w[2] >> 63) {
-                    x[3] = ~0ull;
-                    u64 cy = 0;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { const u64 s1 = x[k] + a.f.p[k]; const u64 c1 = s1 < x[k]; const u64 s2 = s1 + cy; cy = c1 | (u64)(s2 < s1); x[k] = s2; }
-                }
                 // 1 / d, main_gate.is_zero's witness: never taken for a valid mul_mod (every comparison is between equal values)
-                Fe xe; xe.v[0] = x[0]; xe.v[1] = x[1]; xe.v[2] = x[2]; xe.v[3] = x[3];
-                const Fe iv = fe_inv_fast(xe, a.f);
-                p[2] = make_uint4((u32)iv.v[0], (u32)(iv.v[0] >> 32), (u32)iv.v[1], (u32)(iv.v[1] >> 32));
-                p[3] = make_uint4((u32)iv.v[2], (u32)(iv.v[2] >> 32), (u32)iv.v[3], (u32)(iv.v[3] >> 32));
+                Fe xe;
+                field4(v0, true, xe.v);
+                const FieldConsts fc = *reinterpret_cast<const FieldConsts *>(a.ktab + CELLS_KT_FC);
+                const Fe iv = fe_inv_fast(xe, fc);
+                srow[2] = make_uint4((u32)iv.v[0], (u32)(iv.v[0] >> 32), (u32)iv.v[1], (u32)(iv.v[1] >> 32));
+                srow[3] = make_uint4((u32)iv.v[2], (u32)(iv.v[2] >> 32), (u32)iv.v[3], (u32)(iv.v[3] >> 32));
             }
         }
+        }   // general path
+        // ---- the chunk leaves as whole 16-byte-per-lane lines ----
         wave_sync();
-        const u32 n_rows = a.rows - r0 < 64 ? a.rows - r0 : 64;
+        u64 t_1 = 0;
+        if constexpr (ABL & 256) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_1 = __builtin_amdgcn_s_memtime(); }
         u8 *dst = out + (u64)r0 * ADVICE_ROW_BYTES;
+        auto put = [&](u32 u, const uint4 &v) {
+            if constexpr (ABL & 4) pst16(dst + (u64)u * 16, ((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z);
+            else if constexpr (!(ABL & 2)) st16(dst + (u64)u * 16, ((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z);
+            else if (v.x == 0x12345678u && v.w == 0x9abcdef0u) pst16(dst, 1, 2);   // (keeps the LDS reads alive)
+        };
+        if (n_rows == 64) {   // ten LDS reads in flight, then ten 1 KB stores
+            uint4 v[NP];
 #pragma unroll
-        for (u32 k = 0; k < ADVICE_ROW_BYTES / 16; ++k) {
-            const u32 u = k * 64 + lane;
-            if (u < n_rows * (ADVICE_ROW_BYTES / 16)) {
-                const uint4 v = stage[u];
-                st16(dst + (u64)u * 16, ((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z);
-            }
+            for (u32 k = 0; k < NP; ++k) v[k] = stage[k * 64 + lane];
+#pragma unroll
+            for (u32 k = 0; k < NP; ++k) put(k * 64 + lane, v[k]);
+        } else {
+            for (u32 u = lane; u < n_rows * NP; u += 64) put(u, stage[u]);
         }
         wave_sync();
+        if constexpr (ABL & 256) {
+            if (item == a.dbg_item && a.dbg && lane == 0) {
+                const u64 t_2 = __builtin_amdgcn_s_memtime();
+                const u32 ci = r0 / 64 + (r0 % 64 ? 1 : 0);
+                if (ci < 1000) { a.dbg[3 * ci] = path; a.dbg[3 * ci + 1] = t_1 - t_0; a.dbg[3 * ci + 2] = t_2 - t_1; }
+            }
+        }
     }
 }
 

@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 import torch
 
-from ._lib import H2R_HASHED_MSG_STREAM_BYTES, H2RVerifyLayout, check, lib
+from ._lib import H2R_ADVICE_DIRECT, H2R_HASHED_MSG_STREAM_BYTES, H2RVerifyLayout, check, lib
 from .big_integer import AssignedInteger, BatchResult, BigIntChip, UnassignedInteger, _e_bytes
 
 
@@ -254,10 +254,11 @@ class VerifyResult:
         check(lib().h2r_verify_row_kinds(self.chip._ctx, ctypes.byref(self.layout), kinds.ctypes.data), "h2r_verify_row_kinds")
         return kinds
 
-    def emit_advice(self, with_hashed_msg: bool = False) -> "torch.Tensor":
+    def emit_advice(self, with_hashed_msg: bool = False, direct: bool = False) -> "torch.Tensor":
         """Every cell of the whole verify_pkcs1v15_signature element as rows of the main gate's five advice columns
         (h2r_verify_emit_advice): uint8 [batch, rows * 160] in HBM.  with_hashed_msg (a result of RSASignatureVerifier): the
-        region of src/lib.rs:220-241 -- the hashed-message limb composition rows (h2r_hashed_msg_emit_advice) in front."""
+        region of src/lib.rs:220-241 -- the hashed-message limb composition rows (h2r_hashed_msg_emit_advice) in front.
+        direct=True (H2R_ADVICE_DIRECT): the pow rows are written from the operands, the records are not read."""
         sig, n, hashed = self.inputs
         batch = sig.batch
         total, _ = self.advice_sections()
@@ -267,7 +268,7 @@ class VerifyResult:
             check(lib().h2r_hashed_msg_emit_advice(self.chip._ctx, self.hashed_msg_trace.data_ptr(), self.hashed_msg_trace.shape[1], batch,
                                                    None, out.data_ptr(), out.shape[1], self.chip._stream()), "h2r_hashed_msg_emit_advice")
         check(lib().h2r_verify_emit_advice(self.chip._ctx, ctypes.byref(self.layout), sig.data_ptr(), n.data_ptr(), hashed.data_ptr(),
-                                           self.powed.data_ptr(), self.chip._flags(n, batch), self.trace.data_ptr(),
+                                           self.powed.data_ptr(), self.chip._flags(n, batch) | (H2R_ADVICE_DIRECT if direct else 0), self.trace.data_ptr(),
                                            self.workspace.data_ptr(), batch, self.status.data_ptr(), out.data_ptr() + pre * 160, out.shape[1],
                                            self.chip._stream()), "h2r_verify_emit_advice")
         return out

@@ -743,6 +743,16 @@ int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, 
 int32_t h2r_fresh_op_emit_advice(const h2r_ctx *ctx, uint32_t op, uint32_t flags, const void *a, const void *b, const void *n,
                                  const void *trace, uint64_t first_off, uint64_t elem_stride, uint64_t batch,
                                  const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream);
+/* One RSAChip::modpow_public_key element (src/chip.rs:99-114) as advice rows, in the reference's op order: [assert_in_field(x, n) :106:
+ * the rows of h2r_fresh_op_emit_advice(H2R_OP_IS_IN_FIELD, H2R_ADVICE_ASSERT_ONE)] [pow_mod_fixed_exp / pow_mod :108-111: the rows of
+ * h2r_pow_trace_emit_advice].  x, n, flags, in_field_trace, trace, workspace: what h2r_modpow_public_key_batch was given (a caller
+ * workspace is required).  trace = NULL: that call wrote no records -- the pow rows are written directly from the operands
+ * (H2R_ADVICE_DIRECT, also selectable in flags with a trace): the prover-consumable witness without the record planes in between.
+ * section_rows (nullable): {1,533, 75,489} for RSA-2048, e = 65537. */
+uint64_t h2r_modpow_public_key_advice_rows(const h2r_ctx *ctx, const h2r_pow_layout *pl, uint64_t section_rows[2]);
+int32_t h2r_modpow_public_key_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *x, const void *n, uint32_t flags,
+                                          const void *in_field_trace, const void *trace, const void *workspace, uint64_t batch,
+                                          const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream);
 uint32_t h2r_advice_rows(const h2r_ctx *ctx);
 int32_t h2r_mul_mod_emit_advice(const h2r_ctx *ctx, const void *a, const void *b, const void *n, uint32_t flags,
                                 const void *trace, uint64_t batch, const uint8_t *status, void *advice_out,

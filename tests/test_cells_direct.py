@@ -1,0 +1,218 @@
+"""cells_kernel (H2R_ADVICE_DIRECT): the 5-column advice image written DIRECTLY from a mul_mod's operands -- what the reference does
+when it puts every value straight into main-gate cells (main_gate.mul_add big_integer/chip.rs:408, range_chip.assign :590, :598,
+:880-885, is_equal_muled :851-893).  The record-reading form (advice_kernel) is pinned cell for cell against the Python restatement
+run on the ORACLE's stream (tests/test_gpu_parity.py::test_advice_image); here the direct form must equal it byte for byte --
+every supported limb shape, mul_mod batches, pow traces, calls that wrote no records at all, whole modpow_public_key / verify
+elements, BASELINE config 2 at full size -- and, on a mul_mod whose q, r are NOT its quotient and remainder (never produced by the
+library: the general path with main_gate.is_zero's inverse witnesses), every row must still satisfy the main-gate equation."""
+import ctypes
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def H():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import halo2_rsa_amd as H_
+    return H_
+
+
+def rand_modulus(rng, bits, odd=True):
+    n = rng.getrandbits(bits) | (1 << (bits - 1))
+    return n | 1 if odd else n & ~1
+
+
+def _first_diff(got, want, rows, kinds):
+    g, w = got.reshape(-1, rows, 160), want.reshape(-1, rows, 160)
+    bad = np.argwhere(g != w)
+    if not len(bad):
+        return None
+    e, r, b = (int(v) for v in bad[0])
+    return "elem %d row %d (kind %d) cell %d" % (e, r, int(kinds[r]), b // 32)
+
+
+@pytest.mark.parametrize("w,L,field", [(64, 32, "bn254_fr"), (64, 16, "bn254_fq"), (32, 128, "pasta_fp"), (64, 12, "bn254_fq"), (64, 48, "pasta_fq"),
+                                       (32, 8, "bn254_fr"), (64, 64, "bn254_fr"), (64, 4, "pasta_fq"), (32, 96, "pasta_fq"), (64, 24, "bn254_fr")])
+def test_direct_image_equals_record_image(H, w, L, field):
+    """mul_mod batches (even / all-ones / zero operands among them), a short and the RSA exponent, and pow calls that wrote no records:
+    the direct image is the record image, byte for byte; the two constant rows of a fixed-exponent pow element included."""
+    from halo2_rsa_amd._lib import lib
+    chip = H.BigIntChip(w, w * L, field=field)
+    rng = random.Random(w * 1000 + L)
+    batch = 5
+    N = [rand_modulus(rng, w * L, odd=(i != 1)) for i in range(batch)]
+    A = [rng.randrange(n) for n in N]
+    B = [rng.randrange(n) for n in N]
+    A[2] = B[2] = N[2] - 1
+    A[3] = 0
+    rows = int(lib().h2r_advice_rows(chip._ctx))
+    kinds = np.zeros(rows, dtype=np.uint8)
+    assert lib().h2r_advice_row_kinds(chip._ctx, kinds.ctypes.data) == 0
+    res = chip.mul_mod(chip.assign_integer(A), chip.assign_integer(B), chip.assign_integer(N))
+    want = res.emit_advice().cpu().numpy()
+    got = res.emit_advice(direct=True).cpu().numpy()
+    assert _first_diff(got, want, rows, kinds) is None, _first_diff(got, want, rows, kinds)
+    for e in (0b1011, 65537):
+        pres = chip.pow_mod_fixed_exp(chip.assign_integer(A), e, chip.assign_integer(N))
+        want = pres.emit_advice().cpu().numpy()
+        got = pres.emit_advice(direct=True).cpu().numpy()
+        assert np.array_equal(got[:, :320], want[:, :320])
+        assert _first_diff(got[:, 320:], want[:, 320:], rows, kinds) is None, (e, _first_diff(got[:, 320:], want[:, 320:], rows, kinds))
+        T = pres.trace.num_mul_mods
+        bare = chip.pow_mod_fixed_exp(chip.assign_integer(A), e, chip.assign_integer(N), want_trace=False,
+                                      workspace=torch.empty(chip.workspace_bytes(batch, T), dtype=torch.uint8, device="cuda"))
+        assert bare.trace is None
+        assert np.array_equal(bare.emit_advice(direct=True).cpu().numpy(), want), ("no-record call", e)
+        with pytest.raises(ValueError):
+            bare.emit_advice()
+
+
+def test_direct_image_into_unaligned_rows(H):
+    """The kernel cuts an item's first chunk so that later ones start on 128-byte lines: every start alignment (row offsets 0..3 of
+    the element, i.e. out_stride not a multiple of 128) gives the same bytes."""
+    from halo2_rsa_amd._lib import lib
+    from halo2_rsa_amd import _lib
+    chip = H.BigIntChip(64, 2048)
+    rng = random.Random(5)
+    N = [rand_modulus(rng, 2048) for _ in range(3)]
+    X = [rng.randrange(n) for n in N]
+    pres = chip.pow_mod_fixed_exp(chip.assign_integer(X), 17, chip.assign_integer(N))
+    want = pres.emit_advice().cpu().numpy()
+    nbytes = want.shape[1]
+    n_dev = pres.inputs[3]
+    for extra_rows in (1, 2, 3):
+        stride = nbytes + extra_rows * 160
+        buf = torch.full((3 * stride + 4096,), 0xA5, dtype=torch.uint8, device="cuda")
+        base = (-buf.data_ptr()) % 256   # a 256-byte aligned start inside the buffer
+        assert lib().h2r_pow_trace_emit_advice(chip._ctx, ctypes.byref(pres.trace.pow_layout), n_dev.data_ptr(), _lib.H2R_ADVICE_DIRECT, None, 0,
+                                               pres.workspace.data_ptr(), 3, pres.status.data_ptr(), buf.data_ptr() + base, stride, chip._stream()) == 0
+        torch.cuda.synchronize()
+        host = buf.cpu().numpy()
+        for e in range(3):
+            assert np.array_equal(host[base + e * stride:base + e * stride + nbytes], want[e]), (extra_rows, e)
+            assert (host[base + e * stride + nbytes:base + (e + 1) * stride] == 0xA5).all(), "bytes behind an element's image were written"
+
+
+@pytest.mark.parametrize("w,L,field", [(64, 32, "bn254_fr"), (32, 16, "pasta_fq")])
+def test_direct_image_of_an_inconsistent_mul_mod_satisfies_the_gate(H, w, L, field):
+    """q, r that are NOT the quotient and remainder of a * b (the record's R plane bumped by one): the kernel's general path --
+    d = x - y != 0 in is_equal, its inverse witness, eq_bit falling to 0 -- must still give a satisfying assignment of every row
+    (the main-gate equation with the fixed row of the row's kind), and the final eq_bit must be 0."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref as R
+    import advice_ref as AR
+    from halo2_rsa_amd import _lib
+    from halo2_rsa_amd._lib import lib
+    chip = H.BigIntChip(w, w * L, field=field)
+    P = R.FIELD_MODULI[field]
+    rng = random.Random(11 * w + L)
+    n = rand_modulus(rng, w * L)
+    a, b = rng.randrange(n), rng.randrange(n)
+    res = chip.mul_mod(chip.assign_integer([a, a]), chip.assign_integer([b, b]), chip.assign_integer([n, n]))
+    torch.cuda.synchronize()
+    lo = chip.layout
+    P_IDX = {nm: k for k, nm in enumerate(_lib.PLANES)}
+    off = lo.record_stride + lo.plane_off[P_IDX["R"]]             # element 1's r limb 0: + 1 (r < n - 1 with overwhelming probability)
+    v = int.from_bytes(res.trace.buf[off:off + lo.limb_bytes].cpu().numpy().tobytes(), "little")
+    assert v + 1 < (1 << w)
+    res.trace.buf[off:off + lo.limb_bytes] = torch.from_numpy(np.frombuffer((v + 1).to_bytes(lo.limb_bytes, "little"), dtype=np.uint8).copy()).cuda()
+    rows = int(lib().h2r_advice_rows(chip._ctx))
+    kinds = np.zeros(rows, dtype=np.uint8)
+    assert lib().h2r_advice_row_kinds(chip._ctx, kinds.ctypes.data) == 0
+    img = res.emit_advice(direct=True).cpu().numpy().reshape(2, rows, 160)
+    good = res.emit_advice().cpu().numpy().reshape(2, rows, 160)
+    assert np.array_equal(img[0], good[0])                        # the untouched element
+    la = H.LookupArgument(chip, rsa_chip=(w == 64))
+    fixed = {}
+    for k in sorted(set(kinds.tolist())):
+        fr = _lib.H2RFixedRow()
+        assert lib().h2r_advice_fixed_row(chip._ctx, ctypes.byref(la.cfg), k, ctypes.byref(fr)) == 0
+        fixed[k] = fr.as_dict()
+    cells = [[int.from_bytes(img[1, r, 32 * c:32 * c + 32].tobytes(), "little") for c in range(5)] for r in range(rows)]
+    n_inv = 0
+    for r in range(rows):
+        f = fixed[int(kinds[r])]
+        assert AR.gate_residual(cells[r], cells[r + 1][4] if r + 1 < rows else 0, f, P) == 0, (r, int(kinds[r]))
+        if int(kinds[r]) == AR.ROW_ISZERO_INV and cells[r][0] != 0:
+            assert cells[r][0] * cells[r][1] % P == 1 and cells[r][2] == 0
+            n_inv += 1
+    assert n_inv >= 1, "no is_zero inverse witness in the image of an inconsistent mul_mod"
+    assert cells[rows - 1][2] == 0, "final eq_bit of an inconsistent mul_mod"   # the last `and` row: [e1, f2, e2]
+
+
+def test_modpow_public_key_element_without_records(H, golden):
+    """RSAChip::modpow_public_key as cells only: the call writes no records (chain + assert_in_field witness), and
+    h2r_modpow_public_key_emit_advice gives [assert_in_field rows] [pow rows] -- equal to the rows the record-based exports give
+    for the same inputs (KAT1 / KAT2 / BAD + random signatures, one of them not in the field: skipped, its bytes untouched)."""
+    from halo2_rsa_amd import _lib
+    from halo2_rsa_amd._lib import lib
+    chip = H.BigIntChip(64, 2048)
+    kats = golden["rsa_kats"]
+    rng = random.Random(21)
+    ns = [int(k["n"]) for k in kats] + [rand_modulus(rng, 2048) for _ in range(3)]
+    xs = [int(k["sig"]) for k in kats] + [rng.randrange(n) for n in ns[3:]]
+    xs[4] = ns[4] + 5
+    full = chip.pow_mod_fixed_exp(chip.assign_integer(xs), 65537, chip.assign_integer(ns), check_in_field=True)
+    want_if = full.in_field.emit_advice(chip.assign_integer(xs), chip.assign_integer(ns)).cpu().numpy()
+    want_pow = full.emit_advice().cpu().numpy()
+    pl = full.trace.pow_layout
+    sec = (ctypes.c_uint64 * 2)()
+    total = int(lib().h2r_modpow_public_key_advice_rows(chip._ctx, ctypes.byref(pl), sec))
+    assert list(sec) == [want_if.shape[1] // 160, want_pow.shape[1] // 160] and total == sum(sec)
+    assert list(sec) == [1532, 2 + 19 * 3973]
+    bare = chip.pow_mod_fixed_exp(chip.assign_integer(xs), 65537, chip.assign_integer(ns), want_trace=False, check_in_field=True,
+                                  workspace=torch.empty(chip.workspace_bytes(6, pl.num_mul_mods), dtype=torch.uint8, device="cuda"))
+    assert bare.trace is None and bare.in_field is not None
+    out = torch.full((6, total * 160), 0x5A, dtype=torch.uint8, device="cuda")
+    img = bare.emit_modpow_advice(out=out).cpu().numpy()
+    assert bare.status.cpu().tolist() == [0, 0, 0, 0, H.H2R_E_NOT_IN_FIELD, 0]
+    for i in range(6):
+        if i == 4:
+            assert (img[i] == 0x5A).all()
+            continue
+        assert np.array_equal(img[i, :sec[0] * 160], want_if[i]), ("in_field", i)
+        assert np.array_equal(img[i, sec[0] * 160:], want_pow[i]), ("pow", i)
+    # the same export on the call that has records: from the records, and directly
+    assert np.array_equal(full.emit_modpow_advice().cpu().numpy()[:4], img[:4])
+    assert np.array_equal(full.emit_modpow_advice(direct=True).cpu().numpy()[:4], img[:4])
+
+
+def test_verify_element_direct(H, golden):
+    """h2r_verify_emit_advice with H2R_ADVICE_DIRECT: the pow section written from the operands, the whole element unchanged."""
+    rsa = H.RSAChip(2048, 5)
+    kats = golden["rsa_kats"]
+    ns = [int(k["n"]) for k in kats]
+    sigs = [int(k["sig"]) for k in kats]
+    hashed = [int(k["hashed"]) for k in kats]
+    pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Fix(65537)))
+    sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64)))
+    res = rsa.verify_pkcs1v15_signature(pk, hashed, sg)
+    assert torch.equal(res.emit_advice(direct=True), res.emit_advice())
+
+
+def test_config2_full_size_direct_image(H):
+    """BASELINE config 2 (1,024 RSA-2048 signatures, e = 65537): the 12.4 GB image written directly equals the image of the
+    records, every byte, compared on the device."""
+    chip = H.BigIntChip(64, 2048)
+    rng = random.Random(0x68327273 + 2)
+    B = 1024
+    N = [rand_modulus(rng, 2048) for _ in range(B)]
+    X = [rng.randrange(n) for n in N]
+    pres = chip.pow_mod_fixed_exp(chip.assign_integer(X), 65537, chip.assign_integer(N))
+    a = pres.emit_advice()
+    b = pres.emit_advice(direct=True)
+    torch.cuda.synchronize()
+    assert int(pres.status.max().item()) == 0
+    step = 64
+    for lo in range(0, B, step):
+        assert torch.equal(a[lo:lo + step], b[lo:lo + step]), "elements %d.." % lo
