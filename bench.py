@@ -292,13 +292,49 @@ def advice_bench(args):
     pow_rows = int(sec[1])
     elem_bytes = rows * 160
     nimg = 2
-    images = [torch.zeros(chunk * elem_bytes, dtype=torch.uint8, device=dev) for _ in range(nimg)]
     wss = [torch.zeros(chip.workspace_bytes(chunk, pl.num_mul_mods), dtype=torch.uint8, device=dev) for _ in range(nimg)]
+    # Placement: like the record kernel's trace regions an image buffer has a store rate of its own, stable for
+    # the life of the allocation -- 5.1-5.4, 6.1-6.3, 6.6-6.8 or 7.0-7.2 TB/s for the same launch, by buffer (profiles/r04_cells_placement.txt;
+    # the cause is not known).  A prover allocates its image buffers once, so the bench looks: `cand` allocations, the cells kernel
+    # timed on each (all held during the look so that they are different memory), the fastest two kept.  --placement-candidates 0: as allocated.
+    cand = args.placement_candidates if args.placement_candidates >= 0 else 8
+    free_b = torch.cuda.mem_get_info(env.local_rank)[0]
+    cand = max(0, min(cand, int(free_b * 0.5) // (chunk * elem_bytes)))
+    placement = "as allocated"
+    if cand > nimg:
+        first = chip.pow_mod_fixed_exp(x_dev, e, n_dev, want_trace=False, check_in_field=True, workspace=wss[0])
+        torch.cuda.synchronize()
+        pool, ms = [], []
+        for _ in range(cand):
+            buf = torch.empty(chunk * elem_bytes, dtype=torch.uint8, device=dev)
+            first.emit_modpow_advice(out=buf)            # (pages touched, code loaded)
+            ta, tb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ta.record()
+            for _ in range(2):
+                _lib.check(L.h2r_pow_trace_emit_advice(chip._ctx, ctypes.byref(pl), n_dev.data_ptr(), _lib.H2R_ADVICE_DIRECT, None, 0, wss[0].data_ptr(),
+                                                       chunk, first.status.data_ptr(), buf.data_ptr() + int(sec[0]) * 160, elem_bytes, chip._stream()),
+                           "h2r_pow_trace_emit_advice")
+            tb.record()
+            torch.cuda.synchronize()
+            pool.append(buf)
+            ms.append(ta.elapsed_time(tb) / 2)
+        order = sorted(range(cand), key=lambda i: ms[i])
+        images = [pool[i] for i in order[:nimg]]
+        placement = {"candidates": cand, "cells_kernel_alone_ms_per_candidate": [round(t, 4) for t in ms], "kept_ms": [round(ms[i], 4) for i in order[:nimg]]}
+        del pool, buf, first
+        torch.cuda.empty_cache()
+    else:
+        images = [torch.zeros(chunk * elem_bytes, dtype=torch.uint8, device=dev) for _ in range(nimg)]
     ifs = chip.in_field_layout()[0]
     ifb = [torch.zeros(chunk * ifs, dtype=torch.uint8, device=dev) for _ in range(nimg)]
     outs = [torch.zeros((chunk, chip.num_limbs), dtype=chip.torch_dtype, device=dev) for _ in range(nimg)]
     sts = [torch.zeros(chunk, dtype=torch.uint8, device=dev) for _ in range(nimg)]
-    s_chain, s_cells = torch.cuda.Stream(priority=-1), torch.cuda.Stream()   # (the short kernels first when a CU frees up)
+    # The chain stream has the higher priority: its short kernels get the CUs a retiring cells wave frees (same-box A/B,
+    # profiles/r04_advice_ab.txt: 1.955 against 1.989 ms per step; everything on one stream: 2.146).  Developer A/B:
+    # H2R_BENCH_ADV=noprio | serial.
+    adv_mode = os.environ.get("H2R_BENCH_ADV", "")
+    s_chain = torch.cuda.Stream() if adv_mode == "noprio" else torch.cuda.Stream(priority=-1)
+    s_cells = s_chain if adv_mode == "serial" else torch.cuda.Stream()
     chain_done = [torch.cuda.Event() for _ in range(nimg)]
     cells_done = [torch.cuda.Event() for _ in range(nimg)]
     issued = [0]
@@ -379,7 +415,7 @@ def advice_bench(args):
                        "per_gpu_batch": chunk, "global_batch": global_batch, "calls_per_step": 1, "signatures_per_call": chunk,
                        "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world, "ranks": env.world,
                        "pipeline": "chain kernels of call k+1 on a second stream next to cells_kernel of call k (2 workspaces, 2 images), stream-ordered exports + events",
-                       "untimed_clock_warmup_calls": ramp, "buffer_placement": "as allocated"},
+                       "untimed_clock_warmup_calls": ramp, "buffer_placement": placement},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
                          "traffic_source": "not measured", "kernel": "cells_kernel<%d>" % w, "launches_timed": len(cells_ms),
@@ -390,7 +426,7 @@ def advice_bench(args):
             "whole_path_hbm_frac": round(global_batch * steps / dt * elem_bytes / (env.world * HBM_PEAK_GBS * 1e9), 4),
         }
         if env.world == 1 and args.pmc_traffic == "auto" and cells_ms:
-            hbm, how = measured_pmc_traffic(["--advice", "--workload", args.workload, "--batch", str(chunk)], "cells_kernel")
+            hbm, how = measured_pmc_traffic(["--advice", "--workload", args.workload, "--batch", str(chunk)], "cells_kernel")   # (the passes run with --placement-candidates 0)
             if hbm is not None:
                 line["roofline"]["traffic"] = hbm
                 line["roofline"]["traffic_source"] = how

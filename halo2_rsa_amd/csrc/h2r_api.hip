@@ -2646,7 +2646,10 @@ int32_t launch_cells(const h2r_ctx *ctx, CellsArgs &ca, hipStream_t st) {
     // Residency: FOUR waves per CU, one per SIMD (measured: 6.64-6.67 TB/s against 6.47 with the six the RSA-2048 shape's 26 KB would
     // allow, 4.2 with three -- profiles/r04_cells_kernel.txt).  Enforced the way occupancy is enforced on this hardware: by the LDS request.
     u32 lds = cells_lds_bytes(lo.limb_width, lo.num_limbs);
-    const u32 quarter = (ctx->lds_per_cu / 4 - 512) & ~15u;
+#ifndef H2R_CELLS_WAVES
+#define H2R_CELLS_WAVES 4   // (developer variants: 0 = whatever fits)
+#endif
+    const u32 quarter = H2R_CELLS_WAVES ? (ctx->lds_per_cu / H2R_CELLS_WAVES - 512) & ~15u : 0u;
     if (lds < quarter) lds = quarter;
     if (lds > 48 * 1024) {
         if (lo.limb_width == 64) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cells_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

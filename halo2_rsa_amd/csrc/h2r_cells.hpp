@@ -45,6 +45,7 @@ struct CellsArgs {
     u32 per_col_magic;                   // ceil(2^32 / (23 + nrc)): row of the column part -> column index by one mul_hi
     u64 *dbg;                            // developer build (ABL & 256): s_memtime stamps of item dbg_item's chunks
     u32 dbg_item;
+    u32 spread;                          // developer build (ABL & 1024): workgroup b -> item (b % spread) * (n / spread) + b / spread
 };
 
 constexpr u32 CELLS_KT_WORDS = 40;       // the table's words kept in LDS: 3 x 10 + padding (the general fetch reads three words), word_max, p
@@ -218,7 +219,7 @@ __device__ __forceinline__ void cells_prefix_sum(u32 (&v)[NWD]) {
 
 // ABL (developer ablations, tools/cells_bench.hip; 0 in the library): 1 no row building, 2 no global stores, 4 plain instead of
 // non-temporal stores, 8 no is_equal_muled rows (zero rows) and no column phase, 16 no mul rows, 64 no fast paths, 128 chunks not
-// aligned to 128-byte lines
+// aligned to 128-byte lines, 512 workgroup = item (no XCD-contiguous mapping)
 template <int LW, int ABL = 0>
 __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
     using limb_t = typename LimbT<LW>::type;
@@ -242,7 +243,11 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
     u64 *xDH0 = reinterpret_cast<u64 *>(stage), *xDH1 = xDH0 + L2, *xSLO = xDH1 + L2;
     u32 *xSHI = reinterpret_cast<u32 *>(xSLO + L2);
 
-    const u32 item = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    u32 item = (ABL & 512) ? blockIdx.x : xcd_contiguous_block(blockIdx.x, gridDim.x);
+    if constexpr (ABL & 1024) {
+        const u32 g = gridDim.x / a.spread;
+        item = blockIdx.x < g * a.spread ? (blockIdx.x % a.spread) * g + blockIdx.x / a.spread : blockIdx.x;
+    }
     const u32 elem = item / a.T, t = item - elem * a.T;
     if (a.status && a.status[elem]) return;
     {

@@ -133,6 +133,67 @@ int main(int argc, char **argv) {
         }
         CK(hipFree(ddbg));
     }
+    if (argc > 4 && !std::strcmp(argv[4], "vmm")) {   // images stitched from physical chunks of one size (HIP virtual-memory API), in creation order and shuffled
+        const u32 l4 = (160u * 1024 / 4 - 512) & ~15u, lds = l4 > base ? l4 : base;
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
+        size_t gran = 0; CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+        std::printf("  allocation granularity %zu\n", gran);
+        for (size_t chunk_mb : {2, 16, 64, 256, 1024, 4096}) {
+            for (int shuffled = 0; shuffled < 2; ++shuffled) {
+                for (int rep = 0; rep < 3; ++rep) {
+                    const size_t chunk = ((chunk_mb << 20) + gran - 1) / gran * gran, n = (img + chunk - 1) / chunk;
+                    void *va = nullptr;
+                    if (hipMemAddressReserve(&va, n * chunk, 0, nullptr, 0) != hipSuccess) { std::printf("reserve failed\n"); return 1; }
+                    std::vector<hipMemGenericAllocationHandle_t> hs(n);
+                    bool ok = true;
+                    for (size_t i = 0; i < n && ok; ++i) ok = hipMemCreate(&hs[i], chunk, &prop, 0) == hipSuccess;
+                    if (!ok) { std::printf("  chunk %zu MB: out of memory\n", chunk_mb); (void)hipGetLastError(); break; }
+                    std::vector<size_t> order(n);
+                    for (size_t i = 0; i < n; ++i) order[i] = i;
+                    if (shuffled) for (size_t i = n - 1; i > 0; --i) std::swap(order[i], order[rnd() % (i + 1)]);
+                    for (size_t i = 0; i < n; ++i) CK(hipMemMap((char *)va + i * chunk, chunk, 0, hs[order[i]], 0));
+                    hipMemAccessDesc acc = {}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+                    CK(hipMemSetAccess(va, n * chunk, &acc, 1));
+                    CellsArgs c2 = ca; c2.out = static_cast<u8 *>(va);
+                    const float ms = w == 64 ? run<64, 0>(c2, lds, 3) : run<32, 0>(c2, lds, 3);
+                    std::printf("  chunks of %4zu MB%s (%zu): full %.3f ms %.2f TB/s\n", chunk_mb, shuffled ? ", shuffled" : "          ", n, ms, gb / ms); std::fflush(stdout);
+                    if (rep == 2 || chunk_mb >= 1024) {   // (keep two images of every kind allocated so that later ones land elsewhere; the big-chunk ones are freed)
+                        CK(hipDeviceSynchronize()); CK(hipMemUnmap(va, n * chunk));
+                        for (size_t i = 0; i < n; ++i) CK(hipMemRelease(hs[i]));
+                        CK(hipMemAddressFree(va, n * chunk));
+                    }
+                }
+            }
+        }
+        return 0;
+    }
+    if (argc > 4 && !std::strcmp(argv[4], "placement")) {   // the same launch into images allocated one after the other (all kept)
+        const u32 l4 = (160u * 1024 / 4 - 512) & ~15u;
+        std::vector<u8 *> keep;
+        for (int i = 0; i < 12; ++i) {
+            u8 *p = nullptr;
+            if (hipMalloc(reinterpret_cast<void **>(&p), img) != hipSuccess) { (void)hipGetLastError(); break; }
+            keep.push_back(p);
+            CellsArgs c2 = ca; c2.out = p;
+            const float ms = w == 64 ? run<64, 0>(c2, l4 > base ? l4 : base, 3) : run<32, 0>(c2, l4 > base ? l4 : base, 3);
+            const float ms1 = w == 64 ? run<64, 1>(c2, l4 > base ? l4 : base, 3) : run<32, 1>(c2, l4 > base ? l4 : base, 3);
+            std::printf("  image %2d at %p: full %.3f ms %.2f TB/s   stores alone %.3f ms %.2f TB/s\n", i, (void *)p, ms, gb / ms, ms1, gb / ms1); std::fflush(stdout);
+        }
+        if (w == 64) {
+            std::printf("  stores alone, TB/s:  xcd nt 4w | xcd plain 4w | identity nt 4w | identity plain 4w | xcd nt 2w | xcd nt 6w | xcd nt 8w || full xcd nt 4w | full identity nt 4w\n");
+            const u32 l2 = (160u * 1024 / 2 - 512) & ~15u, l8 = (160u * 1024 / 8 - 512) & ~15u;
+            for (size_t i = 0; i < keep.size(); ++i) {
+                CellsArgs c2 = ca; c2.out = keep[i];
+                const float a0 = run<64, 1>(c2, l4, 3), a1 = run<64, 1 | 4>(c2, l4, 3), a2 = run<64, 1 | 512>(c2, l4, 3), a3 = run<64, 1 | 4 | 512>(c2, l4, 3),
+                            a4 = run<64, 1>(c2, l2, 3), a5 = run<64, 1>(c2, base, 3), a6 = run<64, 1>(c2, l8 > base ? l8 : base, 3), f0 = run<64, 0>(c2, l4, 3), f1 = run<64, 512>(c2, l4, 3);
+                std::printf("  image %2zu: %.2f | %.2f | %.2f | %.2f | %.2f | %.2f | %.2f || %.2f | %.2f   spread (full, nt, 4w):", i, gb / a0, gb / a1, gb / a2, gb / a3, gb / a4, gb / a5, gb / a6, gb / f0, gb / f1);
+                for (u32 sp : {8u, 16u, 64u, 256u, 1024u, 2048u, 4864u}) { c2.spread = sp; std::printf(" %u: %.2f", sp, gb / run<64, 1024>(c2, l4, 3)); }
+                std::printf("\n"); std::fflush(stdout);
+            }
+        }
+        return 0;
+    }
     if (w == 64) {
         line("full", run<64, 0>(ca, base, R));
         line("no build (stores of the stage)", run<64, 1>(ca, base, R));
