@@ -41,7 +41,7 @@ class H2RPowLayout(ctypes.Structure):
     _fields_ = [("num_mul_mods", ctypes.c_uint32), ("num_exp_bits", ctypes.c_uint32),
                 ("elem_stride", ctypes.c_uint64), ("off_records", ctypes.c_uint64), ("off_result", ctypes.c_uint64),
                 ("off_e_bits", ctypes.c_uint64), ("off_selected", ctypes.c_uint64), ("selected_stride", ctypes.c_uint64),
-                ("stream_bytes", ctypes.c_uint64)]
+                ("stream_bytes", ctypes.c_uint64), ("exp_limb_bits", ctypes.c_uint32), ("e_num_limbs", ctypes.c_uint32)]
 
 
 class H2RVerifyLayout(ctypes.Structure):
@@ -90,7 +90,7 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_trace_flatten", "h2r_pow_trace_flatten", "h2r_stream_bytes", "h2r_pow_stream_bytes", "h2r_trace_flatten_ex",
            "h2r_pow_trace_flatten_ex", "h2r_trace_emit_stream", "h2r_pow_trace_emit_stream", "h2r_mul_mod_trace_check", "h2r_pow_trace_check",
            "h2r_modpow_public_key_advice_rows", "h2r_modpow_public_key_emit_advice",
-           "h2r_advice_rows", "h2r_mul_mod_emit_advice", "h2r_pow_trace_emit_advice", "h2r_pow_advice_rows", "h2r_advice_row_kinds",
+           "h2r_advice_rows", "h2r_mul_mod_emit_advice", "h2r_pow_trace_emit_advice", "h2r_pow_advice_rows", "h2r_pow_row_kinds", "h2r_advice_row_kinds",
            "h2r_advice_fixed_row", "h2r_fresh_op_advice_rows", "h2r_fresh_op_row_kinds", "h2r_fresh_op_emit_advice",
            "h2r_verify_advice_rows", "h2r_verify_row_kinds", "h2r_verify_emit_advice", "h2r_verify_layout_var", "h2r_verify_pkcs1v15_var_batch", "h2r_pipeline_verify_pkcs1v15_var",
            "h2r_sha256_hashed_msg_batch", "h2r_signature_verifier_batch", "h2r_pipeline_signature_verifier", "h2r_hashed_msg_advice_rows", "h2r_hashed_msg_row_kinds",
@@ -237,6 +237,7 @@ def lib():
     L.h2r_hashed_msg_row_kinds.argtypes = [vp, vp]
     L.h2r_hashed_msg_emit_advice.argtypes = [vp, vp, u64, u64, vp, vp, u64, vp]
     L.h2r_mul_mod_emit_advice.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp, vp, u64, vp]
+    L.h2r_pow_row_kinds.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp]
     L.h2r_modpow_public_key_advice_rows.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp]
     L.h2r_modpow_public_key_advice_rows.restype = u64
     L.h2r_modpow_public_key_emit_advice.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, vp, u32, vp, vp, vp, u64, vp, vp, u64, vp]

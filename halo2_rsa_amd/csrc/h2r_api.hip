@@ -18,6 +18,7 @@
 #include "h2r.h"
 #include "h2r_kernels.hpp"
 #include "h2r_cells.hpp"
+#include "h2r_varrows.hpp"
 #include "h2r_layout.hpp"
 #include "h2r_lookup.hpp"
 #include "h2r_muled.hpp"
@@ -696,6 +697,7 @@ int32_t h2r_pow_var_layout(const h2r_ctx *ctx, uint32_t e_num_limbs, uint32_t ex
     if (nbits > (1u << 20)) return H2R_E_UNSUPPORTED;
     std::memset(out, 0, sizeof *out);
     out->num_mul_mods = (u32)(2 * nbits); out->num_exp_bits = (u32)nbits;
+    out->exp_limb_bits = exp_limb_bits; out->e_num_limbs = e_num_limbs;
     out->off_records = 0;
     const u64 limbs_bytes = round_up((u64)lo.num_limbs * lo.limb_bytes, 256);
     out->off_selected = 2 * nbits * lo.record_stride;
@@ -2623,7 +2625,7 @@ int32_t launch_advice(const h2r_ctx *ctx, AdviceArgs &aa, hipStream_t st) {
     aa.carry_sub_stride = lo.carry_sub_stride; aa.record_stride = lo.record_stride;
     aa.rows = h2r_advice_rows(ctx);
     aa.f = ctx->fc; aa.desc = ctx->advice_desc_dev;
-    if (aa.out_stride < ((u64)aa.pre_rows + (u64)aa.T * aa.rows) * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
+    if (aa.out_stride < ((u64)aa.pre_rows + (u64)aa.T * aa.rows + (u64)(aa.T / 2) * aa.sel_rows) * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
     if (aa.n_items == 0) return H2R_OK;
     if (aa.n_items >= (1ull << 31)) return H2R_E_UNSUPPORTED;
     ProfScope ps(H2R_KERNEL_EMIT, st, true);
@@ -2640,7 +2642,7 @@ int32_t launch_cells(const h2r_ctx *ctx, CellsArgs &ca, hipStream_t st) {
     ca.per_col_magic = (u32)(((1ull << 32) + (ADVICE_COL_ROWS + (lo.carry_nsub + 3) / 4) - 1) / (ADVICE_COL_ROWS + (lo.carry_nsub + 3) / 4));
     ca.L = lo.num_limbs; ca.carry_sub_bits = lo.carry_sub_bits; ca.carry_nsub = lo.carry_nsub;
     ca.rows = h2r_advice_rows(ctx);
-    if (ca.out_stride < ((u64)ca.pre_rows + (u64)ca.T * ca.rows) * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
+    if (ca.out_stride < ((u64)ca.pre_rows + (u64)ca.T * ca.rows + (u64)(ca.T / 2) * ca.sel_rows) * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
     if (ca.n_items == 0) return H2R_OK;
     if (ca.n_items >= (1ull << 31)) return H2R_E_UNSUPPORTED;
     // Residency: FOUR waves per CU, one per SIMD (measured: 6.64-6.67 TB/s against 6.47 with the six the RSA-2048 shape's 26 KB would
@@ -2692,22 +2694,46 @@ int32_t h2r_pow_trace_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
                                   uint64_t elem_stride, const void *workspace, uint64_t batch, const uint8_t *status,
                                   void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
     if (!ctx || !pl || !n || !workspace || !advice_out) return H2R_E_NULL;
-    if (!trace && !(flags & H2R_ADVICE_DIRECT)) return H2R_E_NULL;
+    const bool var = pl->off_e_bits != UINT64_MAX;
+    if (!trace && (var || !(flags & H2R_ADVICE_DIRECT))) return H2R_E_NULL;   // (a Var element's e_bits / selected planes live in the trace)
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (pl->num_mul_mods == 0 || batch == 0) return H2R_OK;
+    if (out_stride < h2r_pow_advice_rows(ctx, pl) * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
     H2R_ON_DEVICE(ctx->params.device);
     const u64 lb = ctx->layout.limb_bytes;
     const u8 *ws = reinterpret_cast<const u8 *>(round_up(reinterpret_cast<u64>(workspace), 256));   // as run_path carves it
-    if (flags & H2R_ADVICE_DIRECT) {   // from the call's operands alone (trace may be NULL: a call that wrote no records)
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    u8 *out = static_cast<u8 *>(advice_out);
+    u32 sel_rows = 0;
+    if (var) {   // pow_mod: the to_bits rows of every exponent limb in front, the select rows of every bit behind its mul_mod (chip.rs:674-691)
+        if (!pl->exp_limb_bits || !pl->e_num_limbs || pl->num_mul_mods != 2 * pl->num_exp_bits) return H2R_E_SHAPE;
+        VarRowsArgs va;
+        std::memset(&va, 0, sizeof va);
+        va.trace = static_cast<const u8 *>(trace); va.elem_stride = elem_stride ? elem_stride : pl->elem_stride;
+        va.off_e_bits = pl->off_e_bits; va.off_selected = pl->off_selected; va.selected_stride = pl->selected_stride;
+        va.opA = ws; va.opR = ws + 3 * ctx->L * lb; va.op_stride = 4ull * ctx->L;
+        va.status = status; va.batch = batch; va.L = ctx->L; va.T = pl->num_mul_mods; va.nbits = pl->num_exp_bits;
+        va.exp_limb_bits = pl->exp_limb_bits; va.e_num_limbs = pl->e_num_limbs; va.rows = h2r_advice_rows(ctx);
+        va.out = out; va.out_stride = out_stride;
+        const u64 per_elem = (u64)va.e_num_limbs * var_to_bits_rows(va.exp_limb_bits) + (u64)va.nbits * va.L;
+        const u64 blocks = (batch * per_elem + 255) / 256;
+        if (blocks >= (1ull << 31)) return H2R_E_UNSUPPORTED;
+        if (ctx->layout.limb_width == 64) hipLaunchKernelGGL((var_rows_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, st, va);
+        else hipLaunchKernelGGL((var_rows_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, va);
+        HIP_TRY(hipGetLastError());
+        out += (u64)va.e_num_limbs * var_to_bits_rows(va.exp_limb_bits) * ADVICE_ROW_BYTES;
+        sel_rows = ctx->L;
+    }
+    if (flags & H2R_ADVICE_DIRECT) {   // from the call's operands alone (trace may be NULL: a fixed-exponent call that wrote no records)
         CellsArgs ca;
         std::memset(&ca, 0, sizeof ca);
         ca.opA = ws; ca.opB = ws + ctx->L * lb; ca.opQ = ws + 2 * ctx->L * lb; ca.opR = ws + 3 * ctx->L * lb;
         ca.op_stride = 4ull * ctx->L; ca.qr_stride = ca.op_stride;
         ca.n = n; ca.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
         ca.status = status; ca.T = pl->num_mul_mods; ca.n_items = batch * pl->num_mul_mods;
-        ca.out = static_cast<u8 *>(advice_out); ca.out_stride = out_stride;
-        ca.pre_rows = pl->off_e_bits == UINT64_MAX ? 2u : 0u;
-        return launch_cells(ctx, ca, static_cast<hipStream_t>(stream));
+        ca.out = out; ca.out_stride = out_stride;
+        ca.pre_rows = 2u; ca.sel_rows = sel_rows;   // acc = assign_constant(1, L): [1], [0] (chip.rs:729 resp. :682)
+        return launch_cells(ctx, ca, st);
     }
     AdviceArgs aa;
     std::memset(&aa, 0, sizeof aa);
@@ -2715,14 +2741,32 @@ int32_t h2r_pow_trace_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
     aa.n = n; aa.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
     aa.status = status; aa.trace = static_cast<const u8 *>(trace); aa.elem_stride = elem_stride ? elem_stride : pl->elem_stride;
     aa.off_records = pl->off_records; aa.T = pl->num_mul_mods; aa.n_items = batch * pl->num_mul_mods;
-    aa.out = static_cast<u8 *>(advice_out); aa.out_stride = out_stride;
-    aa.pre_rows = pl->off_e_bits == UINT64_MAX ? 2u : 0u;   // pow_mod_fixed_exp's acc = assign_constant(1, L): [1], [0] (chip.rs:729)
-    return launch_advice(ctx, aa, static_cast<hipStream_t>(stream));
+    aa.out = out; aa.out_stride = out_stride;
+    aa.pre_rows = 2u; aa.sel_rows = sel_rows;
+    return launch_advice(ctx, aa, st);
 }
 
 uint64_t h2r_pow_advice_rows(const h2r_ctx *ctx, const h2r_pow_layout *pl) {
     if (!ctx || !pl) return 0;
-    return (pl->off_e_bits == UINT64_MAX ? 2ull : 0ull) + (u64)pl->num_mul_mods * h2r_advice_rows(ctx);
+    const u64 recs = 2ull + (u64)pl->num_mul_mods * h2r_advice_rows(ctx);   // acc = assign_constant(1): CONST1, CONST0, then the mul_mods
+    if (pl->off_e_bits == UINT64_MAX) return recs;
+    return (u64)pl->e_num_limbs * var_to_bits_rows(pl->exp_limb_bits) + recs + (u64)pl->num_exp_bits * ctx->L;
+}
+
+int32_t h2r_pow_row_kinds(const h2r_ctx *ctx, const h2r_pow_layout *pl, uint8_t *kinds_out) {
+    if (!ctx || !pl || !kinds_out) return H2R_E_NULL;
+    const u32 rows = h2r_advice_rows(ctx), nrc = (ctx->layout.carry_nsub + 3) / 4;
+    const bool var = pl->off_e_bits != UINT64_MAX;
+    uint8_t *k = kinds_out;
+    if (var)
+        for (u32 l = 0; l < pl->e_num_limbs; ++l)
+            for (u32 i = 0; i < var_to_bits_rows(pl->exp_limb_bits); ++i) *k++ = (uint8_t)var_to_bits_kind(i, pl->exp_limb_bits);
+    *k++ = ROWK_CONST1; *k++ = ROWK_CONST0;
+    for (u32 t = 0; t < pl->num_mul_mods; ++t) {
+        for (u32 r = 0; r < rows; ++r) *k++ = (uint8_t)advice_decode(r, ctx->L, nrc).kind;
+        if (var && !(t & 1)) for (u32 j = 0; j < ctx->L; ++j) *k++ = (uint8_t)ROWK_SELECT;
+    }
+    return H2R_OK;
 }
 
 int32_t h2r_advice_row_kinds(const h2r_ctx *ctx, uint8_t *kinds_out) {
@@ -2779,6 +2823,15 @@ int32_t h2r_advice_fixed_row(const h2r_ctx *ctx, const h2r_lookup_config *cfg, u
             break;
         }
         default: {
+            if (kind >= ROWK_BITS_COMPOSE && kind < ROWK_BITS_COMPOSE_LAST + 64) {   // to_bits' compose rows: coefficients 2^(bit index), no lookup
+                const bool last = kind >= ROWK_BITS_COMPOSE_LAST;
+                const u32 rr = last ? (kind - ROWK_BITS_COMPOSE_LAST) / 4 : kind - ROWK_BITS_COMPOSE, terms = last ? (kind - ROWK_BITS_COMPOSE_LAST) % 4 + 1 : 4;
+                uint64_t (*sel[4])[4] = {&out->sa, &out->sb, &out->sc, &out->sd};
+                for (u32 q = 0; q < terms; ++q) { const u32 b = last ? 4 * rr + terms - 1 - q : 4 * rr + q; if (b >= 64) return H2R_E_SHAPE; put(*sel[q], pow2(b), false); }
+                put(out->se, one, true);
+                if (!last) put(out->se_next, one, false);
+                break;
+            }
             const bool carry = kind >= ROWK_RANGE_CARRY;
             const u32 rr = kind - (carry ? ROWK_RANGE_CARRY : ROWK_RANGE_LIMB);
             const u32 s = carry ? lo.carry_sub_bits : lo.limb_sub_bits, nsub = carry ? lo.carry_nsub : lo.limb_nsub;
@@ -2918,7 +2971,6 @@ int32_t verify_progs(const h2r_ctx *ctx, const h2r_ctx::RowProg **pre, const h2r
 
 uint64_t h2r_verify_advice_rows(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint64_t section_rows[4]) {
     if (!ctx || !vl) return 0;
-    if (vl->pow.off_e_bits != UINT64_MAX) return 0;   // a Var element's to_bits / select rows are not emitted: no whole-element image
     const h2r_ctx::RowProg *pre, *inf, *em;
     if (verify_progs(ctx, &pre, &inf, &em)) return 0;
     const u64 r[4] = {pre->host.size(), inf->host.size(), h2r_pow_advice_rows(ctx, &vl->pow), em->host.size()};
@@ -2928,17 +2980,14 @@ uint64_t h2r_verify_advice_rows(const h2r_ctx *ctx, const h2r_verify_layout *vl,
 
 int32_t h2r_verify_row_kinds(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint8_t *kinds_out) {
     if (!ctx || !vl || !kinds_out) return H2R_E_NULL;
-    if (vl->pow.off_e_bits != UINT64_MAX) return H2R_E_UNSUPPORTED;
     const h2r_ctx::RowProg *pre, *inf, *em;
     const int32_t rc = verify_progs(ctx, &pre, &inf, &em);
     if (rc) return rc;
     uint8_t *k = kinds_out;
     for (const RpRow &r : pre->host) *k++ = (uint8_t)r.kind;
     for (const RpRow &r : inf->host) *k++ = (uint8_t)r.kind;
-    if (vl->pow.off_e_bits == UINT64_MAX) { *k++ = ROWK_CONST1; *k++ = ROWK_CONST0; }
-    const u32 rows = h2r_advice_rows(ctx), nrc = (ctx->layout.carry_nsub + 3) / 4;
-    for (u32 t = 0; t < vl->pow.num_mul_mods; ++t)
-        for (u32 r = 0; r < rows; ++r) *k++ = (uint8_t)advice_decode(r, ctx->L, nrc).kind;
+    if (int32_t rk = h2r_pow_row_kinds(ctx, &vl->pow, k)) return rk;
+    k += h2r_pow_advice_rows(ctx, &vl->pow);
     for (const RpRow &r : em->host) *k++ = (uint8_t)r.kind;
     return H2R_OK;
 }
@@ -2947,7 +2996,7 @@ int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, 
                                const void *powed, uint32_t flags, const void *trace, const void *workspace, uint64_t batch,
                                const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
     if (!ctx || !vl || !sig || !n || !hashed || !powed || !trace || !workspace || !advice_out) return H2R_E_NULL;
-    if (ctx->params.device < 0 || vl->pow.off_e_bits != UINT64_MAX) return H2R_E_UNSUPPORTED;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     const h2r_ctx::RowProg *pre, *inf, *em;
     int32_t rc = verify_progs(ctx, &pre, &inf, &em);
     if (rc) return rc;

@@ -41,6 +41,7 @@ struct CellsArgs {
     u32 T; u64 n_items;                  // item = elem * T + t
     u8 *out; u64 out_stride;             // element e's image at out + e * out_stride: pre_rows rows, then record t at + (pre_rows + t * rows) * 160
     u32 rows, pre_rows;
+    u32 sel_rows;                        // pow_mod (Var): rows left free behind every EVEN record for the bit's select rows
     u32 L, carry_sub_bits, carry_nsub;
     u32 per_col_magic;                   // ceil(2^32 / (23 + nrc)): row of the column part -> column index by one mul_hi
     u64 *dbg;                            // developer build (ABL & 256): s_memtime stamps of item dbg_item's chunks
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
         }
         if (lane < CELLS_KT_WORDS) kt[lane] = a.ktab[lane];
     }
-    u8 *out = a.out + (u64)elem * a.out_stride + ((u64)a.pre_rows + (u64)t * a.rows) * ADVICE_ROW_BYTES;
+    u8 *out = a.out + (u64)elem * a.out_stride + ((u64)a.pre_rows + (u64)t * a.rows + (u64)((t + 1) >> 1) * a.sel_rows) * ADVICE_ROW_BYTES;
     if (t == 0 && lane < a.pre_rows * NP) {   // pow_mod_fixed_exp's acc = assign_constant(1, L): [1, 0, 0, 0, 0] then [0, ...]
         uint4 *pr = reinterpret_cast<uint4 *>(a.out + (u64)elem * a.out_stride);
         pr[lane] = make_uint4(lane == 0 ? 1u : 0u, 0, 0, 0);

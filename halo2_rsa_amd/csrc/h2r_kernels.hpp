@@ -2789,6 +2789,7 @@ struct AdviceArgs {
     u32 L, carry_bits, carry_sub_bits, carry_nsub, carry_sub_stride;
     u32 rows;                           // rows of one record
     u32 pre_rows;                       // pow_mod_fixed_exp's acc = assign_constant(1, L) (chip.rs:729 -> :1272-1276): CONST1 [1], CONST0 [0]
+    u32 sel_rows;                       // pow_mod (Var): rows left free behind every EVEN record for the bit's select rows (chip.rs:688-691)
     FieldConsts f;                      // field modulus + Montgomery constants (is_zero's inverse witness)
 };
 
@@ -2818,7 +2819,7 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
         sq[k] = rv.limb(H2R_PL_Q, k); sr[k] = rv.limb(H2R_PL_R, k);
     }
     __syncthreads();
-    u8 *out = a.out + (u64)elem * a.out_stride + ((u64)a.pre_rows + (u64)t * a.rows) * ADVICE_ROW_BYTES;
+    u8 *out = a.out + (u64)elem * a.out_stride + ((u64)a.pre_rows + (u64)t * a.rows + (u64)((t + 1) >> 1) * a.sel_rows) * ADVICE_ROW_BYTES;
     if (t == 0 && tid < a.pre_rows) {   // the constant limbs of pow_mod_fixed_exp's acc = 1: [1, 0, 0, 0, 0] then [0, ...]
         uint4 *pr = reinterpret_cast<uint4 *>(a.out + (u64)elem * a.out_stride + (u64)tid * ADVICE_ROW_BYTES);
         for (u32 k = 0; k < ADVICE_ROW_BYTES / 16; ++k) pr[k] = make_uint4((k == 0 && tid == 0) ? 1u : 0u, 0, 0, 0);

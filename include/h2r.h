@@ -163,6 +163,8 @@ typedef struct h2r_pow_layout {
     uint64_t off_selected;    /* variable exponent only: [bit][limb] */
     uint64_t selected_stride; /* bytes between consecutive bits' selected[] */
     uint64_t stream_bytes;    /* flat-stream bytes of one element */
+    uint32_t exp_limb_bits;   /* variable exponent only (else 0): bits main_gate.to_bits takes from every exponent limb */
+    uint32_t e_num_limbs;     /* variable exponent only (else 0): limbs of the exponent; num_exp_bits = e_num_limbs * exp_limb_bits */
 } h2r_pow_layout;
 
 /* ---- context ---------------------------------------------------------------------------------- */
@@ -673,8 +675,13 @@ int32_t h2r_pow_trace_emit_stream(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
  *   h2r_advice_rows(ctx)            rows of one mul_mod (3,973 for RSA-2048 as 32 x 64-bit limbs): EVERY cell the ops assign --
  *                                   the flat stream's values, the assign_constant cells, the assign_bit(1) seeds, is_zero's inverses
  *   element e's image starts at advice_out + e * out_stride; record t of the element at + (pre + t * rows) * 160 bytes
- *   (pre = 2 constant rows for h2r_pow_trace_emit_advice of a fixed-exponent trace, else 0: h2r_pow_advice_rows).
- *   A variable-exponent trace gets its mul_mod blocks only (to_bits / select rows are not emitted).
+ *   h2r_pow_trace_emit_advice: a pow element = [acc = assign_constant(1): CONST1 [1], CONST0 [0]] then its records back to back
+ *   (pow_mod_fixed_exp, big_integer/chip.rs:729-740).  A VARIABLE-exponent element (pow_mod, :674-694) is
+ *       [main_gate.to_bits(limb, exp_limb_bits) of every exponent limb: exp_limb_bits x BIT [b, b, b], ceil(exp_limb_bits / 4) x
+ *        BITS_COMPOSE [four bits, what remains to be composed] (the last row reversed and zero-padded, as RangeChip's rows), ASSERT_EQ [result, limb]]
+ *       [CONST1, CONST0]  per exponent bit: [mul_mod(acc, squared) rows] [num_limbs x SELECT [e_bit, muled_j, e_bit, acc_j, selected_j] :688-691]
+ *       [square_mod rows];  its trace must be given (the e_bits / selected planes live there), also with H2R_ADVICE_DIRECT.
+ *   h2r_pow_advice_rows / h2r_pow_row_kinds: rows of one such element and their kinds.
  *   h2r_mul_mod_emit_advice         records of h2r_mul_mod_batch with the same a, b, n, flags
  *   h2r_pow_trace_emit_advice       the records of a pow / modpow / verify trace; `workspace` is the workspace that call
  *                                   was given (it holds every mul_mod's operands), elem_stride = 0 means pl->elem_stride. */
@@ -701,6 +708,8 @@ enum { H2R_ROW_NOP = 0, H2R_ROW_CONST0, H2R_ROW_CONST1, H2R_ROW_CONST_B /* assig
        H2R_ROW_CONST_EM /* + j, j < 6: the encoded-message constants prefix_64_1, prefix_64_2, 2^32, prefix_32, ff_32, last_em */,
        H2R_ROW_RANGE_U32 = 48 /* + row of RangeChip::assign(value, 4, 32): eight 4-bit sub-limbs (src/chip.rs:170-171) */,
        H2R_ROW_CONST_COEFF8 = 56 /* + j, j < 8: assign_constant(2^(8j)), the byte coefficients of a hashed-message limb (src/lib.rs:228-229) */,
+       H2R_ROW_BITS_COMPOSE = 64 /* + row: main_gate.to_bits' composition of four bits 4 row .. 4 row + 3 (coefficients 2^bit), e = what remains */,
+       H2R_ROW_BITS_COMPOSE_LAST = 80 /* + 4 row + (terms - 1): its last row, `terms` bits reversed (the highest in column a), zero-padded */,
        H2R_ROW_RANGE_LIMB = 32, H2R_ROW_RANGE_CARRY = 40 };
 typedef struct h2r_fixed_row {
     uint64_t sa[4], sb[4], sc[4], sd[4], se[4], s_mul_ab[4], s_mul_cd[4], se_next[4], s_const[4];
@@ -712,6 +721,7 @@ int32_t h2r_advice_fixed_row(const h2r_ctx *ctx, const struct h2r_lookup_config 
 /* rows of one element of h2r_pow_trace_emit_advice: for a fixed exponent two constant rows first -- CONST1 [1], CONST0 [0], the
  * limbs of pow_mod_fixed_exp's acc = assign_constant(1, num_limbs) (big_integer/chip.rs:729 -> :1272-1276) -- then the records */
 uint64_t h2r_pow_advice_rows(const h2r_ctx *ctx, const h2r_pow_layout *pl);
+int32_t h2r_pow_row_kinds(const h2r_ctx *ctx, const h2r_pow_layout *pl, uint8_t *kinds_out);
 /* The Fresh-integer family as advice rows: every cell of BigIntChip::add / sub / add_mod / sub_mod / is_zero / is_equal_fresh /
  * the comparisons / is_in_field (big_integer/chip.rs:245-373, 452-528, 754-805, 908-1006; helpers max_value :138-154,
  * sub_unchecked :1286-1318), in the reference's op order, from the witness h2r_fresh_op_batch wrote (or the in_field_trace of
@@ -732,8 +742,8 @@ int32_t h2r_fresh_op_row_kinds(const h2r_ctx *ctx, uint32_t op, uint32_t flags, 
  * section_rows (nullable): the four sections' row counts (1, 1,532, 75,489, 178 for RSA-2048 with e = 65537).
  * sig, n, hashed, flags, trace, workspace: what h2r_verify_pkcs1v15_batch / h2r_pipeline_verify_pkcs1v15 were given (a caller
  * workspace is required: it holds every mul_mod's operands); powed: their powed_out.  Elements with a nonzero status are skipped.
- * Fixed-exponent layouts only: a Var element (h2r_verify_layout_var) has to_bits / select rows this image does not hold -- rows = 0,
- * H2R_E_UNSUPPORTED; its sections are available one by one (h2r_fresh_op_emit_advice, h2r_pow_trace_emit_advice: the records). */
+ * Both exponent arms (src/chip.rs:108-111): a Var element (h2r_verify_layout_var) has the pow_mod rows of h2r_pow_trace_emit_advice
+ * (to_bits, select) in its third section. */
 uint64_t h2r_verify_advice_rows(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint64_t section_rows[4]);
 int32_t h2r_verify_row_kinds(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint8_t *kinds_out);
 int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, const void *sig, const void *n,

@@ -621,3 +621,91 @@ def hashed_msg_image(stream, P):
             limb_val = nv
         limbs.append(limb_val)
     return im, limbs
+
+
+# ---- BigIntChip::pow_mod (variable exponent, big_integer/chip.rs:664-696) as advice rows ------------------------------------------
+ROW_BITS_COMPOSE, ROW_BITS_COMPOSE_LAST = 64, 80
+
+
+def to_bits_rows(im, limb, nb):
+    """main_gate.to_bits(limb, nb) (maingate, restated): assign_bit per bit, `compose` = decompose's rows (four terms per row in
+    columns a..d, the last row reversed and zero-padded, column e = what remains to be composed), assert_equal(result, limb)."""
+    bits = [(limb >> t) & 1 for t in range(nb)]
+    for b in bits:
+        im.assign_bit(b)
+    nc = (nb + 3) // 4
+    remaining = sum(b << t for t, b in enumerate(bits))
+    result = remaining
+    for rr in range(nc):
+        chunk = bits[4 * rr:4 * rr + 4]
+        comp = sum(b << (4 * rr + k) for k, b in enumerate(chunk))
+        last = rr == nc - 1
+        cells = chunk[::-1] if last else chunk
+        im.row((ROW_BITS_COMPOSE_LAST + 4 * rr + len(chunk) - 1) if last else (ROW_BITS_COMPOSE + rr), *(cells + [0] * (4 - len(cells))), remaining)
+        remaining -= comp
+    assert remaining == 0
+    im.row(ROW_ASSERT_EQ, result, limb)
+
+
+def pow_var_image(p, x, e_limbs, nb, n, stream, P, mul_mod_stream_bytes):
+    """The whole pow_mod element from the ORACLE's Var stream (e bits, then per bit: mul_mod stream, selected limbs, square_mod
+    stream; then the result limbs): [to_bits rows of every limb] [acc = assign_constant_fresh(1): CONST1, CONST0] per bit
+    [mul_mod(acc, squared) rows] [select rows] [square_mod rows]."""
+    w, L, LB = p.w, p.L, p.LB
+    st = bytes(stream)
+    nbits = len(e_limbs) * nb
+    im = Image(w, L, P)
+    for limb in e_limbs:
+        to_bits_rows(im, limb, nb)
+    bits = list(st[:nbits])
+    assert bits == [(limb >> t) & 1 for limb in e_limbs for t in range(nb)]
+    im.assign_constant(1)
+    im.assign_constant(0)
+    pos = nbits
+    msb = mul_mod_stream_bytes
+    B = 1 << w
+    acc = [1] + [0] * (L - 1)
+    squared = list(x)
+    N = sum(int(v) << (w * i) for i, v in enumerate(n))
+
+    def val(limbs):
+        return sum(int(v) << (w * i) for i, v in enumerate(limbs))
+
+    def to_l(v):
+        return [(v >> (w * i)) & (B - 1) for i in range(L)]
+
+    for bit in bits:
+        sub = mul_mod_image(p, acc, squared, n, st[pos:pos + msb], P)
+        im.rows += sub.rows
+        im.kinds += sub.kinds
+        pos += msb
+        muled = to_l(val(acc) * val(squared) % N)
+        sel = []
+        for j in range(L):
+            v = int.from_bytes(st[pos:pos + LB], "little")
+            pos += LB
+            assert v == (muled[j] if bit else acc[j])
+            im.row(ROW_SELECT, bit, muled[j], bit, acc[j], v)
+            sel.append(v)
+        acc = sel
+        sub = mul_mod_image(p, squared, squared, n, st[pos:pos + msb], P)
+        im.rows += sub.rows
+        im.kinds += sub.kinds
+        pos += msb
+        squared = to_l(val(squared) * val(squared) % N)
+    assert pos + L * LB == len(st)
+    return im
+
+
+def fixed_row_bits_compose(kind):
+    """Selectors of to_bits' compose rows (h2r_advice_fixed_row of H2R_ROW_BITS_COMPOSE / _LAST kinds)."""
+    f = dict.fromkeys(FIXED_NAMES, 0)
+    f["tag_composition"] = f["tag_overflow"] = 0
+    last = kind >= ROW_BITS_COMPOSE_LAST
+    rr = (kind - ROW_BITS_COMPOSE_LAST) // 4 if last else kind - ROW_BITS_COMPOSE
+    terms = (kind - ROW_BITS_COMPOSE_LAST) % 4 + 1 if last else 4
+    for q, nm in enumerate(("sa", "sb", "sc", "sd")[:terms]):
+        f[nm] = 1 << ((4 * rr + terms - 1 - q) if last else (4 * rr + q))
+    f["se"] = -1
+    f["se_next"] = 0 if last else 1
+    return f

@@ -75,9 +75,20 @@ static int one_shape(uint32_t w, uint32_t L, uint32_t field) {
         REQUIRE(h2r_verify_trace_flatten(ctx, &vv, ve.get(), vo.get()) == H2R_OK);
         uint64_t sec[4];
         const uint64_t vr = h2r_verify_advice_rows(ctx, &vl, sec);
-        REQUIRE(vr == sec[0] + sec[1] + sec[2] + sec[3] && h2r_verify_advice_rows(ctx, &vv, nullptr) == 0);
+        REQUIRE(vr == sec[0] + sec[1] + sec[2] + sec[3]);
         auto vk = heap<uint8_t>(vr);
         REQUIRE(h2r_verify_row_kinds(ctx, &vl, vk.get()) == H2R_OK);
+        // the Var element: to_bits rows of the four 5-bit limbs, acc = 1, per bit mul_mod / select / square_mod (big_integer/chip.rs:674-694)
+        uint64_t vsec[4];
+        const uint64_t vvr = h2r_verify_advice_rows(ctx, &vv, vsec);
+        REQUIRE(vvr == vsec[0] + vsec[1] + vsec[2] + vsec[3] && vsec[2] == h2r_pow_advice_rows(ctx, &vv.pow));
+        REQUIRE(vsec[2] == 4 * (5 + 2 + 1) + 2 + 20ull * (2ull * h2r_advice_rows(ctx) + L));
+        auto vvk = heap<uint8_t>(vvr);
+        REQUIRE(h2r_verify_row_kinds(ctx, &vv, vvk.get()) == H2R_OK);
+        auto pk = heap<uint8_t>(vsec[2]);
+        REQUIRE(h2r_pow_row_kinds(ctx, &vv.pow, pk.get()) == H2R_OK);
+        for (uint64_t i = 0; i < 4 * 8; ++i) { h2r_fixed_row fr; REQUIRE(h2r_advice_fixed_row(ctx, nullptr, pk[i], &fr) == H2R_OK); }
+        REQUIRE(pk[5] == H2R_ROW_BITS_COMPOSE && pk[6] == H2R_ROW_BITS_COMPOSE_LAST + 4 * 1 + 0 && pk[7] == H2R_ROW_ASSERT_EQ);
         const uint32_t hr = h2r_hashed_msg_advice_rows(ctx);
         REQUIRE(hr == 68);
         auto hk = heap<uint8_t>(hr);

@@ -216,3 +216,103 @@ def test_config2_full_size_direct_image(H):
     step = 64
     for lo in range(0, B, step):
         assert torch.equal(a[lo:lo + step], b[lo:lo + step]), "elements %d.." % lo
+
+
+@pytest.mark.parametrize("w,L,field,e_limbs,nb", [(64, 32, "bn254_fr", [0b10001, 0b00000, 0b00000, 0b00010], 5), (64, 16, "bn254_fq", [0x8000000000000003, 5], 64),
+                                                   (32, 8, "pasta_fq", [0b1011011, 0b0000001, 0b1111111], 7), (32, 16, "pasta_fp", [0xC0000001], 32)])
+def test_pow_var_advice_image(H, w, L, field, e_limbs, nb):
+    """BigIntChip::pow_mod (RSAPubE::Var, big_integer/chip.rs:664-696; src/chip.rs:108-110) as advice rows: main_gate.to_bits of every
+    exponent limb, acc = 1, per bit mul_mod / select / square_mod -- the GPU image (from the records and with H2R_ADVICE_DIRECT) equals
+    the Python restatement run on the ORACLE's Var stream, the kinds are h2r_pow_row_kinds', the new kinds' fixed rows are the
+    restatement's, and every to_bits / select row of the GPU image satisfies the main gate."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import pyref as R
+    import advice_ref as AR
+    from oracle_lib import Oracle
+    from halo2_rsa_amd import _lib
+    from halo2_rsa_amd._lib import lib
+    chip = H.BigIntChip(w, w * L, field=field)
+    P = R.FIELD_MODULI[field]
+    o = Oracle(w, L)
+    rng = random.Random(13 * w + L + nb)
+    batch = 3
+    N = [rand_modulus(rng, w * L, odd=(i != 1)) for i in range(batch)]
+    X = [rng.randrange(n) for n in N]
+    E = [list(e_limbs), [rng.getrandbits(nb) for _ in e_limbs], [0] * len(e_limbs)]
+    e_dev = chip.assign_integer(H.UnassignedInteger(np.array(E, dtype=np.uint64 if w == 64 else np.uint32)))
+    res = chip.pow_mod(chip.assign_integer(X), e_dev, chip.assign_integer(N), nb)
+    torch.cuda.synchronize()
+    assert res.status.cpu().tolist() == [0, 0, 0]
+    pl = res.trace.pow_layout
+    assert (pl.exp_limb_bits, pl.e_num_limbs) == (nb, len(e_limbs))
+    total = int(lib().h2r_pow_advice_rows(chip._ctx, ctypes.byref(pl)))
+    kinds = np.zeros(total, dtype=np.uint8)
+    assert lib().h2r_pow_row_kinds(chip._ctx, ctypes.byref(pl), kinds.ctypes.data) == 0
+    img = res.emit_advice().cpu().numpy().reshape(batch, total, 160)
+    img_d = res.emit_advice(direct=True).cpu().numpy().reshape(batch, total, 160)
+    assert np.array_equal(img, img_d)
+    cfg = AR.LookupConfig(AR.range_lens(w, L, rsa=(w == 64)))
+    la = H.LookupArgument(chip, rsa_chip=(w == 64))
+    for i in range(batch):
+        rc, out, st = o.pow_mod(o.limbs(X[i]), E[i], nb, o.limbs(N[i]))
+        assert rc == 0
+        im = AR.pow_var_image(o.p, [int(v) for v in o.limbs(X[i])], E[i], nb, [int(v) for v in o.limbs(N[i])], st, P, o.mul_mod_stream_bytes)
+        assert im.kinds == kinds.tolist()
+        want = AR.image_bytes(im)
+        if not np.array_equal(img[i], want):
+            bad = np.argwhere(img[i] != want)[0]
+            pytest.fail("elem %d: row %d (kind %d) cell %d differs" % (i, int(bad[0]), int(kinds[int(bad[0])]), int(bad[1]) // 32))
+    # the fixed side of the new kinds, and the gate on the GPU's own to_bits / select rows
+    fixed = {}
+    for k in sorted(set(kinds.tolist())):
+        fr = _lib.H2RFixedRow()
+        assert lib().h2r_advice_fixed_row(chip._ctx, ctypes.byref(la.cfg), k, ctypes.byref(fr)) == 0, k
+        fixed[k] = fr.as_dict()
+        if AR.ROW_BITS_COMPOSE <= k < AR.ROW_BITS_COMPOSE_LAST + 64:
+            ref = AR.fixed_row_bits_compose(k)
+            assert {nm: v % P for nm, v in ref.items() if nm in AR.FIXED_NAMES} == {nm: fixed[k][nm] for nm in AR.FIXED_NAMES}, k
+            assert fixed[k]["tag_composition"] == 0 and fixed[k]["tag_overflow"] == 0
+    per_limb = nb + (nb + 3) // 4 + 1
+    head = len(e_limbs) * per_limb + 2
+    cells = lambda r: [int.from_bytes(img[0, r, 32 * c:32 * c + 32].tobytes(), "little") for c in range(5)]
+    check_rows = list(range(head)) + [r for r in range(head, total) if kinds[r] == AR.ROW_SELECT]
+    for r in check_rows:
+        nxt = cells(r + 1)[4] if r + 1 < total else 0
+        assert AR.gate_residual(cells(r), nxt, fixed[int(kinds[r])], P) == 0, (r, int(kinds[r]))
+
+
+def test_verify_element_with_a_variable_exponent_as_advice_rows(H, golden):
+    """RSAChip::verify_pkcs1v15_signature with RSAPubE::Var (src/chip.rs:108-110): the whole element's image exists (it used to be
+    H2R_E_UNSUPPORTED) -- [is_eq] [assert_in_field] [pow_mod: to_bits, acc = 1, mul_mod / select / square_mod per bit] [EM check] --
+    its pow section is h2r_pow_trace_emit_advice's, and for the reference's KATs with e = 65537 as four 5-bit limbs... the result rows
+    agree with the fixed-exponent element where both hold the same values (in-field and EM sections)."""
+    from halo2_rsa_amd._lib import lib
+    rsa = H.RSAChip(2048, 5)
+    chip = rsa.bigint_chip()
+    kats = golden["rsa_kats"]
+    ns = [int(k["n"]) for k in kats]
+    sigs = [int(k["sig"]) for k in kats]
+    hashed = [int(k["hashed"]) for k in kats]
+    e = 65537
+    e_limbs = [[(e >> (5 * i)) & 31 for i in range(4)] for _ in kats]
+    assert sum(v << (5 * i) for i, v in enumerate(e_limbs[0])) == e
+    pk_var = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Var(H.UnassignedInteger(np.array(e_limbs, dtype=np.uint64)))))
+    pk_fix = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Fix(e)))
+    sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64)))
+    rv = rsa.verify_pkcs1v15_signature(pk_var, hashed, sg)
+    rf = rsa.verify_pkcs1v15_signature(pk_fix, hashed, sg)
+    total, sec = rv.advice_sections()
+    _, sec_f = rf.advice_sections()
+    rows = 3973
+    assert sec[0] == 1 and sec[1] == 1532 and sec[3] == sec_f[3]
+    assert sec[2] == 4 * (5 + 2 + 1) + 2 + 20 * (2 * rows + 32)
+    assert rv.is_valid.cpu().tolist() == [1, 1, 0]
+    img = rv.emit_advice().cpu().numpy().reshape(3, total, 160)
+    imf = rf.emit_advice().cpu().numpy().reshape(3, sum(sec_f), 160)
+    assert np.array_equal(img[:, :1 + sec[1]], imf[:, :1 + sec_f[1]])            # is_eq seed + assert_in_field
+    assert np.array_equal(img[:, total - sec[3]:], imf[:, sum(sec_f) - sec_f[3]:])   # the encoded-message check (same powed)
+    assert torch.equal(rv.emit_advice(direct=True), rv.emit_advice())
+    kinds = rv.row_kinds()
+    pk = np.zeros(sec[2], dtype=np.uint8)
+    assert lib().h2r_pow_row_kinds(chip._ctx, ctypes.byref(rv.layout.pow), pk.ctypes.data) == 0
+    assert np.array_equal(kinds[1 + sec[1]:1 + sec[1] + sec[2]], pk)

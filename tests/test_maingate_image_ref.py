@@ -154,3 +154,44 @@ def test_em_check_image_satisfies_the_main_gate():
             assert AR.gate_residual(cells, e_next, f, P) == 0, (ri, kind)
             if f["tag_composition"]:
                 assert all((f["tag_composition"], cells[c]) in table for c in range(4)), ri
+
+
+@pytest.mark.parametrize("w,L,field,e_limbs,nb", [(64, 4, "bn254_fr", [0b10110, 0b00001, 0b11111, 0], 5), (32, 8, "pasta_fq", [0x5A5A5A5A, 1], 32),
+                                                   (64, 4, "bn254_fq", [0x8000000000000001], 64), (32, 8, "pasta_fp", [0b1011011, 0b0000001, 0b1111111], 7)])
+def test_pow_var_image_satisfies_the_main_gate(w, L, field, e_limbs, nb):
+    """BigIntChip::pow_mod (big_integer/chip.rs:664-696) restated as rows: main_gate.to_bits of every exponent limb (bits, their
+    composition rows, assert_equal), acc = 1, then per bit mul_mod / select / square_mod -- every row satisfies the main gate with its
+    fixed row, the composition rows carry no lookup, and the SELECT rows hold select(muled, acc, e_bit)."""
+    P = FIELDS[field]
+    o = Oracle(w, L)
+    rng = random.Random(w + L + nb)
+    bits = w * L
+    n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+    x = rng.randrange(n)
+    rc, out, st = o.pow_mod(o.limbs(x), e_limbs, nb, o.limbs(n))
+    assert rc == 0
+    e = sum(v << (nb * i) for i, v in enumerate(e_limbs))
+    assert sum(int(v) << (w * i) for i, v in enumerate(out)) == pow(x, e, n)
+    im = AR.pow_var_image(o.p, [int(v) for v in o.limbs(x)], e_limbs, nb, [int(v) for v in o.limbs(n)], st, P, o.mul_mod_stream_bytes)
+    nbits = len(e_limbs) * nb
+    per_limb = nb + (nb + 3) // 4 + 1
+    C = 2 * L - 1
+    nrc = (o.p.carry_nsub + 3) // 4
+    rows_mm = 4 * L + 2 * (C + L * L) + L + 4 + (C - 1) * (23 + nrc) + 23
+    assert len(im.rows) == len(e_limbs) * per_limb + 2 + nbits * (2 * rows_mm + L)
+    cfg = AR.LookupConfig(AR.range_lens(w, L, rsa=(w == 64)))
+
+    def fixed_of(k):
+        if AR.ROW_BITS_COMPOSE <= k < AR.ROW_BITS_COMPOSE_LAST + 64:
+            return AR.fixed_row_bits_compose(k)
+        return AR.fixed_row(k, w, L, o.p.carry_bits, o.p.carry_sub_bits, o.p.carry_nsub, cfg)
+    cache = {}
+    for ri, (cells, k) in enumerate(zip(im.rows, im.kinds)):
+        f = cache.setdefault(k, fixed_of(k))
+        e_next = im.rows[ri + 1][4] if ri + 1 < len(im.rows) else 0
+        assert AR.gate_residual(cells, e_next, f, P) == 0, (ri, k)
+    # the first limb's to_bits rows, spelled out
+    lb = e_limbs[0]
+    assert [r[0] for r in im.rows[:nb]] == [(lb >> t) & 1 for t in range(nb)] and im.kinds[:nb] == [AR.ROW_BIT] * nb
+    assert im.rows[nb][4] == lb and im.rows[per_limb - 1][:2] == [lb, lb] and im.kinds[per_limb - 1] == AR.ROW_ASSERT_EQ
+    assert im.kinds.count(AR.ROW_SELECT) == nbits * L
