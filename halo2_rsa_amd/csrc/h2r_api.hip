@@ -36,6 +36,12 @@ bool hip_ok(hipError_t e, const char *what) {
     std::snprintf(g_hip_err, sizeof g_hip_err, "%s: %s", what, hipGetErrorString(e));
     return false;
 }
+// No C++ exception crosses the C ABI ("never abort/throw across the boundary"): every export is a function-try-block.
+// A failed host allocation (std::vector, std::map, new) becomes H2R_E_NOMEM, anything else H2R_E_INTERNAL; the size queries return 0.
+#define H2R_CATCH_STATUS catch (const std::bad_alloc &) { return H2R_E_NOMEM; } catch (...) { return H2R_E_INTERNAL; }
+#define H2R_CATCH_ZERO catch (...) { return 0; }
+#define H2R_CATCH_VOID catch (...) { }
+#define H2R_CATCH_STR catch (...) { return ""; }
 #define HIP_TRY(expr)                                   \
     do {                                                \
         if (!hip_ok((expr), #expr)) return H2R_E_HIP;   \
@@ -538,7 +544,7 @@ void in_field_sections(const AuxGeom &g, F &&emit) { fresh_sections(g, FRESH_IS_
 
 extern "C" {
 
-int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
+int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) try {
     if (!params || !out) return H2R_E_NULL;
     *out = nullptr;
     const u32 w = params->limb_width;
@@ -552,7 +558,8 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
     if (wm.bits() > fbits) return H2R_E_FIELD_TOO_SMALL;  // chip.rs:1178
     if (!shape_supported(w, L)) return H2R_E_UNSUPPORTED;
     h2r_ctx *c = new (std::nothrow) h2r_ctx();
-    if (!c) return H2R_E_HIP;
+    if (!c) return H2R_E_NOMEM;
+    std::unique_ptr<h2r_ctx, void (*)(h2r_ctx *)> guard(c, h2r_ctx_destroy);   // (released on success: an exception below must not leak the ctx)
     c->params = *params; c->L = L; c->K = params->bits_len / 32; c->word_max = wm; c->const_rec_dev = nullptr;
     c->num_cus = 256; c->lds_per_cu = 160 * 1024;
     std::memset(c->refresh_inc, 0, sizeof c->refresh_inc);
@@ -571,7 +578,7 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
     c->tab2_off = c->tab0_len + c->tab1_len; c->tab2_len = ovb ? (1u << ovb) : 0;
     c->hist_len = c->tab2_off + c->tab2_len;
     if (params->device < 0) {  // host-only context: layouts, flatten and parameter queries; no device work
-        *out = c;
+        *out = guard.release();
         return H2R_OK;
     }
     DeviceGuard dg(params->device);
@@ -584,8 +591,6 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
     if (!hip_ok(dg.err, "hipSetDevice") ||
         !hip_ok(hipMalloc(reinterpret_cast<void **>(&c->const_rec_dev), lo.record_stride), "hipMalloc(const record)") ||
         !hip_ok(hipMemcpy(c->const_rec_dev, c->const_rec_host.data(), lo.record_stride, hipMemcpyHostToDevice), "hipMemcpy(const record)")) {
-        if (c->const_rec_dev) (void)hipFree(c->const_rec_dev);
-        delete c;
         return H2R_E_HIP;
     }
     {   // the advice image's row table
@@ -594,7 +599,6 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
         for (u32 r = 0; r < rows; ++r) desc[r] = advice_pack(advice_decode(r, L, nrc));
         if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&c->advice_desc_dev), rows * sizeof(u32)), "hipMalloc(advice rows)") ||
             !hip_ok(hipMemcpy(c->advice_desc_dev, desc.data(), rows * sizeof(u32), hipMemcpyHostToDevice), "hipMemcpy(advice rows)")) {
-            h2r_ctx_destroy(c);
             return H2R_E_HIP;
         }
     }
@@ -618,7 +622,7 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
         col(2, e2);
         bool fixed_point = true;
         for (u32 i = 3; i < lo.num_cols; ++i) { col(i, e); fixed_point = fixed_point && std::memcmp(e, e2, sizeof e) == 0; }
-        if (!fixed_point) { h2r_ctx_destroy(c); return H2R_E_UNSUPPORTED; }
+        if (!fixed_point) return H2R_E_UNSUPPORTED;
         for (int k = 0; k < 3; ++k) kt[CELLS_KT_WM + k] = c->word_max.v[k];
         for (int k = 0; k < 4; ++k) kt[CELLS_KT_P + k] = c->fc.p[k];
         std::memcpy(&kt[CELLS_KT_FC], &c->fc, sizeof c->fc);
@@ -632,15 +636,14 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) {
         }
         if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&c->cells_ktab_dev), sizeof kt), "hipMalloc(cells table)") ||
             !hip_ok(hipMemcpy(c->cells_ktab_dev, kt, sizeof kt, hipMemcpyHostToDevice), "hipMemcpy(cells table)")) {
-            h2r_ctx_destroy(c);
             return H2R_E_HIP;
         }
     }
-    *out = c;
+    *out = guard.release();
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-void h2r_ctx_destroy(h2r_ctx *ctx) {
+void h2r_ctx_destroy(h2r_ctx *ctx) try {
     if (!ctx) return;
     if (ctx->params.device >= 0) {
         DeviceGuard dg(ctx->params.device);
@@ -651,29 +654,29 @@ void h2r_ctx_destroy(h2r_ctx *ctx) {
         if (ctx->pipe) h2r_pipeline_destroy(ctx->pipe);
     }
     delete ctx;
-}
+} H2R_CATCH_VOID
 
-int32_t h2r_compute_range_lens(uint32_t limb_width, uint32_t num_limbs, uint32_t comp[3], uint32_t over[3]) {
+int32_t h2r_compute_range_lens(uint32_t limb_width, uint32_t num_limbs, uint32_t comp[3], uint32_t over[3]) try {
     if (!comp || !over) return H2R_E_NULL;
     if (limb_width < kNumLookupLimbs || limb_width > 64 || num_limbs == 0) return H2R_E_SHAPE;
     compute_range_lens(limb_width, num_limbs, comp, over);
     return H2R_OK;
-}
-int32_t h2r_rsa_compute_range_lens(uint32_t num_limbs, uint32_t comp[4], uint32_t over[3]) {
+} H2R_CATCH_STATUS
+int32_t h2r_rsa_compute_range_lens(uint32_t num_limbs, uint32_t comp[4], uint32_t over[3]) try {
     if (!comp || !over) return H2R_E_NULL;
     if (num_limbs == 0) return H2R_E_SHAPE;
     compute_range_lens(64, num_limbs, comp, over);  // src/chip.rs:250-251, LIMB_WIDTH = 64
     comp[3] = 32 / kNumLookupLimbs;                 // src/chip.rs:252
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_trace_layout(const h2r_ctx *ctx, h2r_layout *out) {
+int32_t h2r_trace_layout(const h2r_ctx *ctx, h2r_layout *out) try {
     if (!ctx || !out) return H2R_E_NULL;
     *out = ctx->layout;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_pow_fixed_layout(const h2r_ctx *ctx, const uint8_t *e_le, size_t e_len, h2r_pow_layout *out) {
+int32_t h2r_pow_fixed_layout(const h2r_ctx *ctx, const uint8_t *e_le, size_t e_len, h2r_pow_layout *out) try {
     if (!ctx || !out) return H2R_E_NULL;
     ExpBits eb; u32 T;
     int32_t rc = exp_to_bits(e_le, e_len, &eb, &T);
@@ -687,9 +690,9 @@ int32_t h2r_pow_fixed_layout(const h2r_ctx *ctx, const uint8_t *e_le, size_t e_l
     out->elem_stride = odd_stride_256(out->off_result + (u64)lo.num_limbs * lo.limb_bytes);
     out->stream_bytes = (u64)T * lo.stream_bytes + (u64)lo.num_limbs * lo.limb_bytes;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_pow_var_layout(const h2r_ctx *ctx, uint32_t e_num_limbs, uint32_t exp_limb_bits, h2r_pow_layout *out) {
+int32_t h2r_pow_var_layout(const h2r_ctx *ctx, uint32_t e_num_limbs, uint32_t exp_limb_bits, h2r_pow_layout *out) try {
     if (!ctx || !out) return H2R_E_NULL;
     const h2r_layout &lo = ctx->layout;
     if (e_num_limbs == 0 || exp_limb_bits == 0 || exp_limb_bits > lo.limb_width) return H2R_E_SHAPE;
@@ -707,25 +710,25 @@ int32_t h2r_pow_var_layout(const h2r_ctx *ctx, uint32_t e_num_limbs, uint32_t ex
     out->elem_stride = odd_stride_256(out->off_e_bits + nbits);
     out->stream_bytes = nbits + nbits * (2 * lo.stream_bytes + (u64)lo.num_limbs * lo.limb_bytes) + (u64)lo.num_limbs * lo.limb_bytes;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-uint64_t h2r_workspace_bytes(const h2r_ctx *ctx, uint64_t batch, uint32_t num_mul_mods) {
+uint64_t h2r_workspace_bytes(const h2r_ctx *ctx, uint64_t batch, uint32_t num_mul_mods) try {
     if (!ctx) return 0;
     return workspace_plan(ctx->layout.limb_bytes, ctx->L, batch, num_mul_mods ? num_mul_mods : 1).total;
-}
+} H2R_CATCH_ZERO
 
 int32_t h2r_mul_mod_batch(const h2r_ctx *ctx, const void *a, const void *b, const void *n, uint64_t batch,
                           uint32_t flags, void *trace, void *r_out, uint8_t *status, void *workspace,
-                          h2r_stream_t stream) {
+                          h2r_stream_t stream) try {
     if (!ctx || !b) return H2R_E_NULL;
     return run_path(ctx, CHAIN_MULMOD, a, b, n, nullptr, 0, 0, nullptr, 0, batch, flags, 1, trace,
                     ctx->layout.record_stride, 0, nullptr, r_out, status, workspace, static_cast<hipStream_t>(stream));
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_square_mod_batch(const h2r_ctx *ctx, const void *a, const void *n, uint64_t batch, uint32_t flags,
-                             void *trace, void *r_out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+                             void *trace, void *r_out, uint8_t *status, void *workspace, h2r_stream_t stream) try {
     return h2r_mul_mod_batch(ctx, a, a, n, batch, flags, trace, r_out, status, workspace, stream);  // chip.rs:648
-}
+} H2R_CATCH_STATUS
 
 namespace {
 int32_t launch_verify_aux(const h2r_ctx *ctx, const void *sig, const void *n, const uint64_t *hashed, uint64_t batch, uint32_t flags,
@@ -782,35 +785,35 @@ static int32_t pow_var_impl(const h2r_ctx *ctx, const void *x, const void *e_lim
 
 int32_t h2r_pow_mod_fixed_exp_batch(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le,
                                     size_t e_len, uint64_t batch, uint32_t flags, void *trace, void *out,
-                                    uint8_t *status, void *workspace, h2r_stream_t stream) {
+                                    uint8_t *status, void *workspace, h2r_stream_t stream) try {
     return pow_fixed_impl(ctx, x, n, e_le, e_len, batch, flags, trace, out, status, workspace, stream, 0);
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_pow_mod_batch(const h2r_ctx *ctx, const void *x, const void *e_limbs, uint32_t e_num_limbs,
                           uint32_t exp_limb_bits, const void *n, uint64_t batch, uint32_t flags, void *trace,
-                          void *out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+                          void *out, uint8_t *status, void *workspace, h2r_stream_t stream) try {
     return pow_var_impl(ctx, x, e_limbs, e_num_limbs, exp_limb_bits, n, batch, flags, trace, out, status, workspace, stream, 0);
-}
+} H2R_CATCH_STATUS
 
 // RSAChip::modpow_public_key (src/chip.rs:99-114): assert_in_field witness (:106), then the pow path with the in-field
 // predicate folded into the chain kernel's status.
 int32_t h2r_modpow_public_key_batch(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le,
                                     size_t e_len, uint64_t batch, uint32_t flags, void *trace, void *in_field_trace,
-                                    void *out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+                                    void *out, uint8_t *status, void *workspace, h2r_stream_t stream) try {
     const int32_t rc = pow_fixed_impl(ctx, x, n, e_le, e_len, batch, flags, trace, out, status, workspace, stream, 1);
     if (rc || !in_field_trace) return rc;
     return launch_in_field(ctx, x, n, batch, flags, in_field_trace, static_cast<hipStream_t>(stream));
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_modpow_public_key_var_batch(const h2r_ctx *ctx, const void *x, const void *e_limbs, uint32_t e_num_limbs,
                                         uint32_t exp_limb_bits, const void *n, uint64_t batch, uint32_t flags, void *trace,
-                                        void *in_field_trace, void *out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+                                        void *in_field_trace, void *out, uint8_t *status, void *workspace, h2r_stream_t stream) try {
     const int32_t rc = pow_var_impl(ctx, x, e_limbs, e_num_limbs, exp_limb_bits, n, batch, flags, trace, out, status, workspace, stream, 1);
     if (rc || !in_field_trace) return rc;
     return launch_in_field(ctx, x, n, batch, flags, in_field_trace, static_cast<hipStream_t>(stream));
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_verify_layout_fixed(const h2r_ctx *ctx, const uint8_t *e_le, size_t e_len, h2r_verify_layout *out) {
+int32_t h2r_verify_layout_fixed(const h2r_ctx *ctx, const uint8_t *e_le, size_t e_len, h2r_verify_layout *out) try {
     if (!ctx || !out) return H2R_E_NULL;
     if (ctx->layout.limb_width != 64 || ctx->L < 9) return H2R_E_SHAPE;  // RSAChip::LIMB_WIDTH, src/chip.rs:203
     std::memset(out, 0, sizeof *out);
@@ -826,12 +829,12 @@ int32_t h2r_verify_layout_fixed(const h2r_ctx *ctx, const uint8_t *e_le, size_t 
     out->elem_stride = odd_stride_256(out->off_em + g.em_sz());
     out->stream_bytes = out->in_field_stream_bytes + out->pow.stream_bytes + out->em_stream_bytes;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 
 int32_t h2r_verify_pkcs1v15_batch(const h2r_ctx *ctx, const void *sig, const void *n, const uint8_t *e_le, size_t e_len,
                                   const uint64_t *hashed, uint64_t batch, uint32_t flags, void *trace, void *powed_out,
-                                  uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+                                  uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) try {
     if (!ctx || !sig || !n || !hashed || !trace || !powed_out || !status) return H2R_E_NULL;
     h2r_verify_layout vl;
     int32_t rc = h2r_verify_layout_fixed(ctx, e_le, e_len, &vl);
@@ -847,10 +850,10 @@ int32_t h2r_verify_pkcs1v15_batch(const h2r_ctx *ctx, const void *sig, const voi
                       vl.pow.off_records, &vl.pow, powed_out, status, workspace, st);
     if (rc || batch == 0) return rc;
     return launch_verify_aux(ctx, sig, n, hashed, batch, flags, trace, vl, powed_out, is_valid_out, status, st);
-}
+} H2R_CATCH_STATUS
 
 // RSAPubE::Var arm of the same call (src/chip.rs:108-110: pow_mod with the chip's exp_limb_bits)
-int32_t h2r_verify_layout_var(const h2r_ctx *ctx, uint32_t e_num_limbs, uint32_t exp_limb_bits, h2r_verify_layout *out) {
+int32_t h2r_verify_layout_var(const h2r_ctx *ctx, uint32_t e_num_limbs, uint32_t exp_limb_bits, h2r_verify_layout *out) try {
     if (!ctx || !out) return H2R_E_NULL;
     if (ctx->layout.limb_width != 64 || ctx->L < 9) return H2R_E_SHAPE;
     std::memset(out, 0, sizeof *out);
@@ -866,11 +869,11 @@ int32_t h2r_verify_layout_var(const h2r_ctx *ctx, uint32_t e_num_limbs, uint32_t
     out->elem_stride = odd_stride_256(out->off_em + g.em_sz());
     out->stream_bytes = out->in_field_stream_bytes + out->pow.stream_bytes + out->em_stream_bytes;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_verify_pkcs1v15_var_batch(const h2r_ctx *ctx, const void *sig, const void *n, const void *e_limbs, uint32_t e_num_limbs,
                                       uint32_t exp_limb_bits, const uint64_t *hashed, uint64_t batch, uint32_t flags, void *trace,
-                                      void *powed_out, uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+                                      void *powed_out, uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) try {
     if (!ctx || !sig || !n || !e_limbs || !hashed || !trace || !powed_out || !status) return H2R_E_NULL;
     h2r_verify_layout vl;
     int32_t rc = h2r_verify_layout_var(ctx, e_num_limbs, exp_limb_bits, &vl);
@@ -880,9 +883,9 @@ int32_t h2r_verify_pkcs1v15_var_batch(const h2r_ctx *ctx, const void *sig, const
                   vl.elem_stride, vl.pow.off_records, &vl.pow, powed_out, status, workspace, st);
     if (rc || batch == 0) return rc;
     return launch_verify_aux(ctx, sig, n, hashed, batch, flags, trace, vl, powed_out, is_valid_out, status, st);
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_verify_trace_flatten(const h2r_ctx *ctx, const h2r_verify_layout *vl, const void *elem_host, void *stream_out) {
+int32_t h2r_verify_trace_flatten(const h2r_ctx *ctx, const h2r_verify_layout *vl, const void *elem_host, void *stream_out) try {
     if (!ctx || !vl || !elem_host || !stream_out) return H2R_E_NULL;
     const u8 *e = static_cast<const u8 *>(elem_host);
     u8 *o = static_cast<u8 *>(stream_out);
@@ -894,13 +897,13 @@ int32_t h2r_verify_trace_flatten(const h2r_ctx *ctx, const h2r_verify_layout *vl
     std::memcpy(o, e + vl->off_em, vl->em_stream_bytes); o += vl->em_stream_bytes;
     if ((u64)(o - static_cast<u8 *>(stream_out)) != vl->stream_bytes) return H2R_E_SHAPE;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 // ---- the caller of the path: RSASignatureVerifier::verify_pkcs1v15_signature (src/lib.rs:183-246) ---------------------
 // SHA-256 of every element's message, the reversed digest packed into the four hashed-message limbs (:213-239), and -- in
 // h2r_signature_verifier_batch -- RSAChip::verify_pkcs1v15_signature on them, all in stream order on the caller's stream.
 int32_t h2r_sha256_hashed_msg_batch(const h2r_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, uint64_t fixed_len, uint64_t batch,
-                                    uint8_t *digest_out, uint64_t *hashed_out, void *hm_trace, uint64_t hm_stride, h2r_stream_t stream) {
+                                    uint8_t *digest_out, uint64_t *hashed_out, void *hm_trace, uint64_t hm_stride, h2r_stream_t stream) try {
     if (!ctx || (!msgs && (msg_off || fixed_len))) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (hm_trace && hm_stride == 0) hm_stride = HM_REGION;
@@ -918,18 +921,18 @@ int32_t h2r_sha256_hashed_msg_batch(const h2r_ctx *ctx, const uint8_t *msgs, con
     hipExtLaunchKernelGGL(sha256_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, st, ps.a, ps.on ? ps.b : nullptr, 0, sa);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_signature_verifier_batch(const h2r_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, uint64_t fixed_len, const void *sig,
                                      const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch, uint32_t flags, void *trace,
                                      void *hm_trace, uint64_t hm_stride, uint8_t *digest_out, uint64_t *hashed_out, void *powed_out,
-                                     uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+                                     uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) try {
     if (!hashed_out) return H2R_E_NULL;
     if (ctx && (ctx->layout.limb_width != 64 || ctx->L < 9)) return H2R_E_SHAPE;   // before any launch: RSAChip::LIMB_WIDTH
     const int32_t rc = h2r_sha256_hashed_msg_batch(ctx, msgs, msg_off, fixed_len, batch, digest_out, hashed_out, hm_trace, hm_stride, stream);
     if (rc) return rc;
     return h2r_verify_pkcs1v15_batch(ctx, sig, n, e_le, e_len, hashed_out, batch, flags, trace, powed_out, is_valid_out, status, workspace, stream);
-}
+} H2R_CATCH_STATUS
 
 struct h2r_pipeline {
     const h2r_ctx *ctx;
@@ -1013,7 +1016,7 @@ struct h2r_dist {
                        // map: a stream-ordered pool allocation is not in it -- "Memobj map does not have ptr", seen once in five runs)
 };
 
-int32_t h2r_dist_unique_id(uint8_t id_out[H2R_DIST_ID_BYTES]) {
+int32_t h2r_dist_unique_id(uint8_t id_out[H2R_DIST_ID_BYTES]) try {
     if (!id_out) return H2R_E_NULL;
     const int32_t rc = rccl_ready();
     if (rc) return rc;
@@ -1022,9 +1025,9 @@ int32_t h2r_dist_unique_id(uint8_t id_out[H2R_DIST_ID_BYTES]) {
     RCCL_TRY(rccl().GetUniqueId(&id));
     std::memcpy(id_out, &id, sizeof id);
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_dist_init(const h2r_ctx *ctx, const uint8_t id[H2R_DIST_ID_BYTES], uint32_t rank, uint32_t world, h2r_dist **out) {
+int32_t h2r_dist_init(const h2r_ctx *ctx, const uint8_t id[H2R_DIST_ID_BYTES], uint32_t rank, uint32_t world, h2r_dist **out) try {
     if (!ctx || !id || !out) return H2R_E_NULL;
     *out = nullptr;
     if (world == 0 || rank >= world) return H2R_E_SHAPE;
@@ -1042,36 +1045,36 @@ int32_t h2r_dist_init(const h2r_ctx *ctx, const uint8_t id[H2R_DIST_ID_BYTES], u
     if (!d) { (void)hipFree(scratch); (void)rccl().CommDestroy(comm); return H2R_E_HIP; }
     *out = d;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-void h2r_dist_destroy(h2r_dist *d) {
+void h2r_dist_destroy(h2r_dist *d) try {
     if (!d) return;
     { DeviceGuard dg(d->ctx->params.device); (void)hipDeviceSynchronize(); (void)rccl().CommDestroy(d->comm); (void)hipFree(d->scratch); }
     delete d;
-}
-uint32_t h2r_dist_rank(const h2r_dist *d) { return d ? d->rank : 0; }
-uint32_t h2r_dist_world(const h2r_dist *d) { return d ? d->world : 0; }
+} H2R_CATCH_VOID
+uint32_t h2r_dist_rank(const h2r_dist *d) try { return d ? d->rank : 0; } H2R_CATCH_ZERO
+uint32_t h2r_dist_world(const h2r_dist *d) try { return d ? d->world : 0; } H2R_CATCH_ZERO
 
-int32_t h2r_dist_shard_range(uint64_t total, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi) {
+int32_t h2r_dist_shard_range(uint64_t total, uint32_t rank, uint32_t world, uint64_t *lo, uint64_t *hi) try {
     if (!lo || !hi) return H2R_E_NULL;
     if (world == 0 || rank >= world) return H2R_E_SHAPE;
     const u64 base = total / world, rem = total % world;
     *lo = rank * base + std::min<u64>(rank, rem);
     *hi = *lo + base + (rank < rem ? 1 : 0);
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_dist_bcast(h2r_dist *d, void *buf, uint64_t bytes, uint32_t root, h2r_stream_t stream) {
+int32_t h2r_dist_bcast(h2r_dist *d, void *buf, uint64_t bytes, uint32_t root, h2r_stream_t stream) try {
     if (!d || !buf) return H2R_E_NULL;
     if (root >= d->world) return H2R_E_SHAPE;
     if (bytes == 0) return H2R_OK;
     H2R_ON_DEVICE(d->ctx->params.device);
     RCCL_TRY(rccl().Broadcast(buf, buf, bytes, ncclUint8, (int)root, d->comm, static_cast<hipStream_t>(stream)));
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_dist_gather_results(h2r_dist *d, const void *results_shard, const uint8_t *status_shard, uint64_t shard_elems,
-                                void *results_all, uint8_t *status_all, h2r_stream_t stream) {
+                                void *results_all, uint8_t *status_all, h2r_stream_t stream) try {
     if (!d || !results_shard || !results_all || (!status_shard != !status_all)) return H2R_E_NULL;
     if (shard_elems == 0) return H2R_OK;
     H2R_ON_DEVICE(d->ctx->params.device);
@@ -1083,9 +1086,9 @@ int32_t h2r_dist_gather_results(h2r_dist *d, const void *results_shard, const ui
     const ncclResult_t r3 = rccl().GroupEnd();
     RCCL_TRY(r1); RCCL_TRY(r2); RCCL_TRY(r3);
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_dist_allreduce_max_f64(h2r_dist *d, double *values, uint64_t count, h2r_stream_t stream) {
+int32_t h2r_dist_allreduce_max_f64(h2r_dist *d, double *values, uint64_t count, h2r_stream_t stream) try {
     if (!d) return H2R_E_NULL;
     H2R_ON_DEVICE(d->ctx->params.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1096,7 +1099,7 @@ int32_t h2r_dist_allreduce_max_f64(h2r_dist *d, double *values, uint64_t count, 
     }
     RCCL_TRY(rccl().AllReduce(values, values, count, ncclDouble, ncclMax, d->comm, st));
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 // ---- placement-aware trace arena ---------------------------------------------------------------------------------------
 // Where a trace buffer lies physically decides how fast the record kernel writes it: per 1.25 GB region of config 2 one of
@@ -1123,7 +1126,7 @@ void arena_free_region(h2r_arena::Region &r) {
 }  // namespace
 
 int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t first_record_off, uint32_t records_per_elem,
-                         uint64_t batch, uint32_t regions, uint32_t candidates, h2r_stream_t stream, h2r_arena **out) {
+                         uint64_t batch, uint32_t regions, uint32_t candidates, h2r_stream_t stream, h2r_arena **out) try {
     if (!ctx || !out) return H2R_E_NULL;
     *out = nullptr;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
@@ -1278,17 +1281,17 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
     for (auto &r : cands) a->kept.push_back(std::move(r));
     *out = a.release();
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-void *h2r_arena_region(const h2r_arena *a, uint32_t i) { return (a && i < a->kept.size()) ? a->kept[i].va : nullptr; }
-uint64_t h2r_arena_region_bytes(const h2r_arena *a) { return a ? a->region_bytes : 0; }
-double h2r_arena_region_ms(const h2r_arena *a, uint32_t i) { return (a && i < a->kept.size()) ? (double)a->kept[i].ms : 0.0; }
-uint32_t h2r_arena_measurements(const h2r_arena *a, double *ms_out, uint32_t cap) {
+void *h2r_arena_region(const h2r_arena *a, uint32_t i) try { return (a && i < a->kept.size()) ? a->kept[i].va : nullptr; } catch (...) { return nullptr; }
+uint64_t h2r_arena_region_bytes(const h2r_arena *a) try { return a ? a->region_bytes : 0; } H2R_CATCH_ZERO
+double h2r_arena_region_ms(const h2r_arena *a, uint32_t i) try { return (a && i < a->kept.size()) ? (double)a->kept[i].ms : 0.0; } catch (...) { return 0.0; }
+uint32_t h2r_arena_measurements(const h2r_arena *a, double *ms_out, uint32_t cap) try {
     if (!a) return 0;
     for (u32 i = 0; i < a->measured.size() && i < cap && ms_out; ++i) ms_out[i] = a->measured[i];
     return (uint32_t)a->measured.size();
-}
-void h2r_arena_destroy(h2r_arena *a) {
+} H2R_CATCH_ZERO
+void h2r_arena_destroy(h2r_arena *a) try {
     if (!a) return;
     {
         DeviceGuard dg(a->device);
@@ -1296,7 +1299,7 @@ void h2r_arena_destroy(h2r_arena *a) {
         for (auto &r : a->kept) arena_free_region(r);
     }
     delete a;
-}
+} H2R_CATCH_VOID
 
 namespace {
 // Which calls are issued as one-launch steps: the shape both roles of step_kernel are built for (RSA-2048: 64-bit limbs,
@@ -1377,9 +1380,9 @@ int32_t pipeline_flush(h2r_pipeline *p, hipStream_t st) {
 }
 }  // namespace
 
-int32_t h2r_pipeline_create(const h2r_ctx *ctx, h2r_pipeline **out) { return h2r_pipeline_create_ex(ctx, 2, 1, out); }
+int32_t h2r_pipeline_create(const h2r_ctx *ctx, h2r_pipeline **out) try { return h2r_pipeline_create_ex(ctx, 2, 1, out); } H2R_CATCH_STATUS
 
-int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side_streams, h2r_pipeline **out) {
+int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side_streams, h2r_pipeline **out) try {
     if (!ctx || !out) return H2R_E_NULL;
     *out = nullptr;
     if (depth < 2 || depth > h2r_pipeline::MAX_DEPTH || side_streams < 1 || side_streams > 2) return H2R_E_SHAPE;
@@ -1421,9 +1424,9 @@ int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side
     if (!ok) { h2r_pipeline_destroy(p); return H2R_E_HIP; }
     *out = p;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-void h2r_pipeline_destroy(h2r_pipeline *p) {
+void h2r_pipeline_destroy(h2r_pipeline *p) try {
     if (!p) return;
     DeviceGuard dg(p->ctx->params.device);
     // a caller that did not join: the records still owed go out on the stream of the last call (which must still exist:
@@ -1440,7 +1443,7 @@ void h2r_pipeline_destroy(h2r_pipeline *p) {
     if (p->aux[1] && p->aux[1] != p->aux[0]) (void)hipStreamDestroy(p->aux[1]);
     if (p->aux[0]) (void)hipStreamDestroy(p->aux[0]);
     delete p;
-}
+} H2R_CATCH_VOID
 
 namespace {
 // Order `st` after the record kernel of the call in `slot`.
@@ -1463,7 +1466,7 @@ int32_t pipeline_wait_slot(h2r_pipeline *p, u32 slot, hipStream_t st) {
 namespace { void call_plan(const h2r_ctx *c, u64 batch, bool busy, std::vector<u64> &sizes, bool &pace); }
 
 int32_t h2r_pipeline_call_plan(const h2r_ctx *ctx, uint64_t batch, uint32_t pipeline_busy_, uint64_t *sizes_out, uint32_t cap,
-                               uint32_t *n_out, uint32_t *paced_out) {
+                               uint32_t *n_out, uint32_t *paced_out) try {
     if (!ctx || !n_out) return H2R_E_NULL;
     std::vector<u64> sizes; bool pace = false;
     call_plan(ctx, batch, pipeline_busy_ != 0, sizes, pace);
@@ -1471,14 +1474,14 @@ int32_t h2r_pipeline_call_plan(const h2r_ctx *ctx, uint64_t batch, uint32_t pipe
     if (paced_out) *paced_out = pace ? 1u : 0u;
     if (sizes_out) for (size_t i = 0; i < sizes.size() && i < cap; ++i) sizes_out[i] = sizes[i];
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 namespace {
 u32 exp_segment_count(const h2r_ctx *c, u64 batch, u32 nbits, bool has_trace, bool single_call);
 void exp_segment_plan(u32 n_seg, u32 nbits, const ExpBits *eb, std::vector<ExpSegment> &out);
 }
 int32_t h2r_exp_segment_plan(const h2r_ctx *ctx, uint64_t batch, const uint8_t *e_le_bytes, size_t e_len, uint32_t var_exp_bits,
-                             uint32_t *bit_bounds_out, uint32_t *mul_mod_bounds_out, uint32_t cap, uint32_t *n_out) {
+                             uint32_t *bit_bounds_out, uint32_t *mul_mod_bounds_out, uint32_t cap, uint32_t *n_out) try {
     if (!ctx || !n_out) return H2R_E_NULL;
     ExpBits eb; u32 T = 0;
     u32 nbits = var_exp_bits;
@@ -1496,9 +1499,9 @@ int32_t h2r_exp_segment_plan(const h2r_ctx *ctx, uint64_t batch, const uint8_t *
         if (mul_mod_bounds_out) mul_mod_bounds_out[i] = i < n_seg ? segs[i].t_lo : segs[n_seg - 1].t_lo + segs[n_seg - 1].t_cnt;
     }
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream) {
+int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream) try {
     if (!p) return H2R_E_NULL;
     if (p->pending) {
         H2R_ON_DEVICE(p->ctx->params.device);
@@ -1510,7 +1513,7 @@ int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream) {
         if (rc) return rc;
     }
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 namespace {
 // Is the record kernel of the previous pipelined call still queued or running?
@@ -1726,11 +1729,13 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
                     va.status = verify_aux->status + off;
                 }
                 Sha256Args sr;
+                u32 sha_target = p->sha_issued;
                 if (!sha_done) {
                     sr = *sha;
-                    if (fold_verify) { p->sha_issued += (u32)sha->batch; sr.done = p->sha_done_dev; sr.target = p->sha_issued; }
+                    if (fold_verify) { sha_target += (u32)sha->batch; sr.done = p->sha_done_dev; sr.target = sha_target; }
                 }
                 HIP_TRY(launch_step(ctx, pa.ca, p->pending_ta, with_aux ? witness_aux : nullptr, fold_verify ? &va : nullptr, sha_done ? nullptr : &sr, st, ps.a, ps.b));
+                p->sha_issued = sha_target;   // (only a launch that went out counts: the device word never runs behind the host's target)
                 aux_done = aux_done || with_aux;
                 sha_done = true;
             } else {
@@ -1892,7 +1897,7 @@ int32_t launch_in_field(const h2r_ctx *ctx, const void *x, const void *n, uint64
 
 int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len,
                                        uint64_t batch, uint32_t flags, void *trace, void *in_field_trace, void *out,
-                                       uint8_t *status, void *workspace, h2r_stream_t stream) {
+                                       uint8_t *status, void *workspace, h2r_stream_t stream) try {
     if (!p || !trace || !workspace) return H2R_E_NULL;
     h2r_pow_layout pl;
     const int32_t rc = h2r_pow_fixed_layout(p->ctx, e_le, e_len, &pl);
@@ -1907,12 +1912,12 @@ int32_t h2r_pipeline_modpow_public_key(h2r_pipeline *p, const void *x, const voi
                               if (!in_field_trace) return H2R_OK;
                               return launch_in_field(p->ctx, x, n, batch, flags, in_field_trace, st);
                           }, 1, false, have_aux ? &aa : nullptr, aux_lds);
-}
+} H2R_CATCH_STATUS
 
 // RSAPubE::Var (src/chip.rs:108-110): per-element exponents; the same pipelining as the fixed-exponent form
 int32_t h2r_pipeline_modpow_public_key_var(h2r_pipeline *p, const void *x, const void *e_limbs, uint32_t e_num_limbs, uint32_t exp_limb_bits,
                                            const void *n, uint64_t batch, uint32_t flags, void *trace, void *in_field_trace, void *out,
-                                           uint8_t *status, void *workspace, h2r_stream_t stream) {
+                                           uint8_t *status, void *workspace, h2r_stream_t stream) try {
     if (!p || !trace || !workspace || !e_limbs) return H2R_E_NULL;
     h2r_pow_layout pl;
     const int32_t rc = h2r_pow_var_layout(p->ctx, e_num_limbs, exp_limb_bits, &pl);
@@ -1925,11 +1930,11 @@ int32_t h2r_pipeline_modpow_public_key_var(h2r_pipeline *p, const void *x, const
                               if (!in_field_trace) return H2R_OK;
                               return launch_in_field(p->ctx, x, n, batch, flags, in_field_trace, st);
                           }, 1, false, have_aux ? &aa : nullptr, aux_lds, e_limbs, e_num_limbs, exp_limb_bits);
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_pipeline_verify_pkcs1v15(h2r_pipeline *p, const void *sig, const void *n, const uint8_t *e_le, size_t e_len,
                                      const uint64_t *hashed, uint64_t batch, uint32_t flags, void *trace, void *powed_out,
-                                     uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+                                     uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) try {
     if (!p || !sig || !n || !hashed || !trace || !powed_out || !status || !workspace) return H2R_E_NULL;
     h2r_verify_layout vl;
     const int32_t rc = h2r_verify_layout_fixed(p->ctx, e_le, e_len, &vl);
@@ -1943,12 +1948,12 @@ int32_t h2r_pipeline_verify_pkcs1v15(h2r_pipeline *p, const void *sig, const voi
                               if (batch == 0) return H2R_OK;
                               return launch_verify_aux(p->ctx, sig, n, hashed, batch, flags, trace, vl, powed_out, is_valid_out, status, st);
                           }, 1, false, nullptr, 0, nullptr, 0, 0, nullptr, &va);
-}
+} H2R_CATCH_STATUS
 
 // RSAPubE::Var arm of the pipelined verifier (src/chip.rs:108-110)
 int32_t h2r_pipeline_verify_pkcs1v15_var(h2r_pipeline *p, const void *sig, const void *n, const void *e_limbs, uint32_t e_num_limbs,
                                          uint32_t exp_limb_bits, const uint64_t *hashed, uint64_t batch, uint32_t flags, void *trace,
-                                         void *powed_out, uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+                                         void *powed_out, uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) try {
     if (!p || !sig || !n || !e_limbs || !hashed || !trace || !powed_out || !status || !workspace) return H2R_E_NULL;
     h2r_verify_layout vl;
     const int32_t rc = h2r_verify_layout_var(p->ctx, e_num_limbs, exp_limb_bits, &vl);
@@ -1960,7 +1965,7 @@ int32_t h2r_pipeline_verify_pkcs1v15_var(h2r_pipeline *p, const void *sig, const
                               if (batch == 0) return H2R_OK;
                               return launch_verify_aux(p->ctx, sig, n, hashed, batch, flags, trace, vl, powed_out, is_valid_out, status, st);
                           }, 1, false, nullptr, 0, e_limbs, e_num_limbs, exp_limb_bits, nullptr, &va);
-}
+} H2R_CATCH_STATUS
 
 // RSASignatureVerifier::verify_pkcs1v15_signature (src/lib.rs:183-246) as a pipelined call: the SHA-256 / hashed-message step of this
 // call's messages is a role of the call's step launch (hidden next to the records of the previous call) and the chain role of the same
@@ -1968,7 +1973,7 @@ int32_t h2r_pipeline_verify_pkcs1v15_var(h2r_pipeline *p, const void *sig, const
 int32_t h2r_pipeline_signature_verifier(h2r_pipeline *p, const uint8_t *msgs, const uint64_t *msg_off, uint64_t fixed_len, const void *sig,
                                         const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch, uint32_t flags, void *trace,
                                         void *hm_trace, uint64_t hm_stride, uint8_t *digest_out, uint64_t *hashed_out, void *powed_out,
-                                        uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) {
+                                        uint8_t *is_valid_out, uint8_t *status, void *workspace, h2r_stream_t stream) try {
     if (!p || !sig || !n || !hashed_out || !trace || !powed_out || !status || !workspace || (!msgs && (msg_off || fixed_len))) return H2R_E_NULL;
     if (hm_trace && hm_stride == 0) hm_stride = HM_REGION;
     if ((reinterpret_cast<u64>(digest_out) | reinterpret_cast<u64>(hashed_out) | reinterpret_cast<u64>(hm_trace) | hm_stride) & 15) return H2R_E_SHAPE;
@@ -1987,9 +1992,9 @@ int32_t h2r_pipeline_signature_verifier(h2r_pipeline *p, const uint8_t *msgs, co
                               if (batch == 0) return H2R_OK;
                               return launch_verify_aux(p->ctx, sig, n, hashed_out, batch, flags, trace, vl, powed_out, is_valid_out, status, st);
                           }, 1, false, nullptr, 0, nullptr, 0, 0, &sa, &va);
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_fresh_op_layout(const h2r_ctx *ctx, uint32_t op, uint64_t *elem_stride, uint64_t *stream_bytes, uint32_t *value_limbs) {
+int32_t h2r_fresh_op_layout(const h2r_ctx *ctx, uint32_t op, uint64_t *elem_stride, uint64_t *stream_bytes, uint32_t *value_limbs) try {
     if (!ctx) return H2R_E_NULL;
     if (op >= FRESH_OP_COUNT) return H2R_E_UNSUPPORTED;
     if (ctx->L + 3 > 64 * AUX_V) return H2R_E_UNSUPPORTED;
@@ -2000,10 +2005,10 @@ int32_t h2r_fresh_op_layout(const h2r_ctx *ctx, uint32_t op, uint64_t *elem_stri
     if (stream_bytes) *stream_bytes = sb;
     if (value_limbs) *value_limbs = (op == FRESH_ADD || op == FRESH_SUB) ? ctx->L + 1 : ((op == FRESH_ADD_MOD || op == FRESH_SUB_MOD) ? ctx->L : 0);
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_fresh_op_batch(const h2r_ctx *ctx, uint32_t op, const void *a, const void *b, const void *n, uint64_t batch,
-                           uint32_t flags, void *trace, void *value_out, uint8_t *flag_out, uint8_t *status, h2r_stream_t stream) {
+                           uint32_t flags, void *trace, void *value_out, uint8_t *flag_out, uint8_t *status, h2r_stream_t stream) try {
     if (!ctx || !a || !trace || !status) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     u64 es; u32 vl;
@@ -2026,9 +2031,9 @@ int32_t h2r_fresh_op_batch(const h2r_ctx *ctx, uint32_t op, const void *a, const
     else hipLaunchKernelGGL((fresh_kernel<32>), dim3((unsigned)batch), dim3(64), 0, st, fa);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_fresh_op_flatten(const h2r_ctx *ctx, uint32_t op, const void *elem_host, void *stream_out) {
+int32_t h2r_fresh_op_flatten(const h2r_ctx *ctx, uint32_t op, const void *elem_host, void *stream_out) try {
     if (!ctx || !elem_host || !stream_out) return H2R_E_NULL;
     if (op >= FRESH_OP_COUNT) return H2R_E_UNSUPPORTED;
     const u8 *e = static_cast<const u8 *>(elem_host);
@@ -2036,11 +2041,11 @@ int32_t h2r_fresh_op_flatten(const h2r_ctx *ctx, uint32_t op, const void *elem_h
     const AuxGeom g(ctx->L, ctx->layout.limb_width);
     fresh_sections(g, op, [&](u64 off, u64 len) { std::memcpy(o, e + off, len); o += len; });
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_range_decompose_batch(const h2r_ctx *ctx, const void *values, uint32_t value_bytes, uint64_t count,
                                   uint32_t bit_len, uint32_t sublimb_bits, uint8_t *sublimbs_out,
-                                  uint32_t sub_stride, uint32_t *hist, h2r_stream_t stream) {
+                                  uint32_t sub_stride, uint32_t *hist, h2r_stream_t stream) try {
     if (!ctx || !values) return H2R_E_NULL;
     if ((value_bytes != 8 && value_bytes != 16) || bit_len == 0 || bit_len > 8 * value_bytes || sublimb_bits == 0 ||
         sublimb_bits > 8)
@@ -2061,12 +2066,12 @@ int32_t h2r_range_decompose_batch(const h2r_ctx *ctx, const void *values, uint32
     hipLaunchKernelGGL(decompose_kernel, dim3((unsigned)blocks), dim3(256), shmem, static_cast<hipStream_t>(stream), da);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-uint32_t h2r_hist_len(const h2r_ctx *ctx) { return ctx ? ctx->hist_len : 0; }
+uint32_t h2r_hist_len(const h2r_ctx *ctx) try { return ctx ? ctx->hist_len : 0; } H2R_CATCH_ZERO
 
 int32_t h2r_trace_lookup_hist(const h2r_ctx *ctx, const void *trace, uint64_t first_record_off, uint64_t elem_stride,
-                              uint64_t num_elems, uint32_t records_per_elem, uint32_t *hist_out, h2r_stream_t stream) {
+                              uint64_t num_elems, uint32_t records_per_elem, uint32_t *hist_out, h2r_stream_t stream) try {
     if (!ctx || !trace || !hist_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (num_elems == 0) return H2R_OK;
@@ -2088,24 +2093,24 @@ int32_t h2r_trace_lookup_hist(const h2r_ctx *ctx, const void *trace, uint64_t fi
                        static_cast<hipStream_t>(stream), ha);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-uint32_t h2r_lookups_per_record(const h2r_ctx *ctx) {
+uint32_t h2r_lookups_per_record(const h2r_ctx *ctx) try {
     if (!ctx) return 0;
     const h2r_layout &lo = ctx->layout;
     return 2 * lo.num_limbs * lo.limb_nsub + (lo.num_cols - 1) * lo.carry_nsub;
-}
+} H2R_CATCH_ZERO
 
 int32_t h2r_trace_lookup_permutation(const h2r_ctx *ctx, const void *trace, uint64_t first_record_off, uint64_t elem_stride,
                                      uint64_t num_elems, uint32_t records_per_elem, uint32_t *perm_out, uint16_t *rows_out,
-                                     h2r_stream_t stream) {
+                                     h2r_stream_t stream) try {
     return h2r_trace_lookup_permutation_hist(ctx, trace, first_record_off, elem_stride, num_elems, records_per_elem, perm_out,
                                              rows_out, nullptr, stream);
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_trace_lookup_permutation_hist(const h2r_ctx *ctx, const void *trace, uint64_t first_record_off, uint64_t elem_stride,
                                           uint64_t num_elems, uint32_t records_per_elem, uint32_t *perm_out, uint16_t *rows_out,
-                                          uint32_t *hist_out, h2r_stream_t stream) {
+                                          uint32_t *hist_out, h2r_stream_t stream) try {
     if (!ctx || !trace || !perm_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (num_elems == 0 || records_per_elem == 0) return H2R_OK;
@@ -2143,10 +2148,10 @@ int32_t h2r_trace_lookup_permutation_hist(const h2r_ctx *ctx, const void *trace,
         hipLaunchKernelGGL(perm_kernel<false>, dim3((unsigned)num_elems), dim3(256), (unsigned)(stage_bytes + same_bytes), static_cast<hipStream_t>(stream), pa);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 // ---- halo2's lookup argument: table, per-argument multiplicities, permuted columns (h2r_lookup.hpp) ---------------------
-int32_t h2r_lookup_config_custom(const uint32_t *bit_lens, const uint32_t *tags, uint32_t n, h2r_lookup_config *out) {
+int32_t h2r_lookup_config_custom(const uint32_t *bit_lens, const uint32_t *tags, uint32_t n, h2r_lookup_config *out) try {
     if (!bit_lens || !tags || !out) return H2R_E_NULL;
     std::memset(out, 0, sizeof *out);
     // RangeChip::configure: sort, de-duplicate, drop zero entries
@@ -2169,9 +2174,9 @@ int32_t h2r_lookup_config_custom(const uint32_t *bit_lens, const uint32_t *tags,
     if (off > (u64)LOOKUP_MAX_ROWS) return H2R_E_UNSUPPORTED;
     out->n_lens = (u32)v.size(); out->n_rows = (u32)off;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_lookup_config_default(const h2r_ctx *ctx, uint32_t rsa_chip, h2r_lookup_config *out) {
+int32_t h2r_lookup_config_default(const h2r_ctx *ctx, uint32_t rsa_chip, h2r_lookup_config *out) try {
     if (!ctx || !out) return H2R_E_NULL;
     u32 comp[4] = {0, 0, 0, 0}, over[3] = {0, 0, 0};
     compute_range_lens(ctx->layout.limb_width, ctx->L, comp, over);      // big_integer/chip.rs:1220-1249
@@ -2180,9 +2185,9 @@ int32_t h2r_lookup_config_default(const h2r_ctx *ctx, uint32_t rsa_chip, h2r_loo
     std::sort(lens, lens + 7);
     for (u32 i = 0; i < 7; ++i) if (lens[i] && (n == 0 || uniq[n - 1] != lens[i])) { uniq[n] = lens[i]; tags[n] = n + 1; ++n; }
     return h2r_lookup_config_custom(uniq, tags, n, out);
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_lookup_table_image(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint64_t *tag_col, uint64_t *value_col) {
+int32_t h2r_lookup_table_image(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint64_t *tag_col, uint64_t *value_col) try {
     if (!ctx || !cfg || !tag_col || !value_col) return H2R_E_NULL;
     if (cfg->n_rows == 0 || cfg->n_rows > (u32)LOOKUP_MAX_ROWS) return H2R_E_SHAPE;
     std::memset(tag_col, 0, (size_t)cfg->n_rows * 32); std::memset(value_col, 0, (size_t)cfg->n_rows * 32);
@@ -2192,7 +2197,7 @@ int32_t h2r_lookup_table_image(const h2r_ctx *ctx, const h2r_lookup_config *cfg,
             value_col[(u64)(cfg->row_off[i] + v) * 4] = v;
         }
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 namespace {
 // sub-limb shape of RangeChip::assign(value, s, bit_len) and the table rows its lookups hit
@@ -2215,7 +2220,7 @@ int32_t range_shape(const h2r_lookup_config &cfg, u32 bit_len, u32 s, RangeShape
 
 int32_t h2r_lookup_hist_records(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const void *trace, uint64_t first_record_off,
                                 uint64_t elem_stride, uint64_t num_elems, uint32_t records_per_elem, const uint8_t *status,
-                                uint32_t *hist, h2r_stream_t stream) {
+                                uint32_t *hist, h2r_stream_t stream) try {
     if (!ctx || !cfg || !trace || !hist) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (cfg->n_rows == 0 || cfg->n_rows > (u32)LOOKUP_MAX_ROWS) return H2R_E_SHAPE;
@@ -2239,7 +2244,7 @@ int32_t h2r_lookup_hist_records(const h2r_ctx *ctx, const h2r_lookup_config *cfg
     hipLaunchKernelGGL(lookup_hist_records_kernel, dim3((unsigned)num_elems), dim3(256), LOOKUP_ARGS * cfg->n_rows * sizeof(u32), st, a);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 namespace {
 int32_t lookup_hist_values_impl(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const void *values, uint32_t value_bytes,
@@ -2270,31 +2275,38 @@ int32_t lookup_hist_values_impl(const h2r_ctx *ctx, const h2r_lookup_config *cfg
 
 int32_t h2r_lookup_hist_values(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const void *values, uint32_t value_bytes,
                                uint64_t values_per_elem, uint64_t num_elems, uint32_t bit_len, uint32_t sublimb_bits,
-                               uint32_t *hist, h2r_stream_t stream) {
+                               uint32_t *hist, h2r_stream_t stream) try {
     return lookup_hist_values_impl(ctx, cfg, values, value_bytes, values_per_elem, num_elems, values_per_elem * value_bytes, value_bytes,
                                    bit_len, sublimb_bits, nullptr, hist, stream);
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_lookup_hist_values_strided(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const void *values, uint32_t value_bytes,
                                        uint64_t values_per_elem, uint64_t num_elems, uint64_t elem_stride, uint64_t value_stride,
                                        uint32_t bit_len, uint32_t sublimb_bits, const uint8_t *status, uint32_t *hist,
-                                       h2r_stream_t stream) {
+                                       h2r_stream_t stream) try {
     return lookup_hist_values_impl(ctx, cfg, values, value_bytes, values_per_elem, num_elems, elem_stride, value_stride, bit_len,
                                    sublimb_bits, status, hist, stream);
-}
+} H2R_CATCH_STATUS
+
+extern "C++" {
+namespace {
+int32_t lookup_hist_fresh_impl(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint32_t op, const void *trace, uint64_t first_off,
+                               uint64_t elem_stride, uint64_t num_elems, const uint8_t *status, uint32_t *hist, h2r_stream_t stream);
+}  // namespace
+}  // extern "C++"
 
 // Every lookup of one verify_pkcs1v15_signature element that the witness holds (src/chip.rs:99-199): the range assigns inside
 // assert_in_field, the q / r limbs and carries of every mul_mod record, and the two RangeChip::assign(half, 4, 32) of the
 // encoded-message check (:170-171; the halves sit at bytes 12 and 24 of the EM region, aux_em).
 int32_t h2r_lookup_hist_verify(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const h2r_verify_layout *vl, const void *trace,
-                               uint64_t num_elems, const uint8_t *status, uint32_t *hist, h2r_stream_t stream) {
+                               uint64_t num_elems, const uint8_t *status, uint32_t *hist, h2r_stream_t stream) try {
     if (!ctx || !cfg || !vl || !trace || !hist) return H2R_E_NULL;
-    int32_t rc = h2r_lookup_hist_fresh_op(ctx, cfg, H2R_OP_IS_IN_FIELD, trace, vl->off_in_field, vl->elem_stride, num_elems, hist, stream);
+    int32_t rc = lookup_hist_fresh_impl(ctx, cfg, H2R_OP_IS_IN_FIELD, trace, vl->off_in_field, vl->elem_stride, num_elems, status, hist, stream);   // (a failed element counts nothing, as in the two passes below)
     if (!rc) rc = h2r_lookup_hist_records(ctx, cfg, trace, vl->pow.off_records, vl->elem_stride, num_elems, vl->pow.num_mul_mods, status, hist, stream);
     if (!rc) rc = lookup_hist_values_impl(ctx, cfg, static_cast<const u8 *>(trace) + vl->off_em + 12, 4, 2, num_elems, vl->elem_stride, 12, 32, 4,
                                           status, hist, stream);
     return rc;
-}
+} H2R_CATCH_STATUS
 
 extern "C++" {
 namespace {
@@ -2326,14 +2338,17 @@ void fresh_range_runs(const AuxGeom &g, u32 op, F &&run) {
 }  // namespace
 }  // extern "C++"
 
-int32_t h2r_lookup_hist_fresh_op(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint32_t op, const void *trace, uint64_t first_off,
-                                 uint64_t elem_stride, uint64_t num_elems, uint32_t *hist, h2r_stream_t stream) {
+extern "C++" {
+namespace {
+int32_t lookup_hist_fresh_impl(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint32_t op, const void *trace, uint64_t first_off,
+                               uint64_t elem_stride, uint64_t num_elems, const uint8_t *status, uint32_t *hist, h2r_stream_t stream) {
     if (!ctx || !cfg || !trace || !hist) return H2R_E_NULL;
     if (ctx->params.device < 0 || op >= FRESH_OP_COUNT) return H2R_E_UNSUPPORTED;
     if (cfg->n_rows == 0 || cfg->n_rows > (u32)LOOKUP_MAX_ROWS) return H2R_E_SHAPE;
     const h2r_layout &lo = ctx->layout;
     LookupFreshArgs a;
     std::memset(&a, 0, sizeof a);
+    a.status = status;
     const int32_t rc = range_shape(*cfg, lo.limb_width, lo.limb_sub_bits, &a.limb);
     if (rc) return rc;
     const AuxGeom g(ctx->L, lo.limb_width);
@@ -2353,16 +2368,23 @@ int32_t h2r_lookup_hist_fresh_op(const h2r_ctx *ctx, const h2r_lookup_config *cf
     HIP_TRY(hipGetLastError());
     return H2R_OK;
 }
+}  // namespace
+}  // extern "C++"
 
-uint64_t h2r_lookup_workspace_bytes(const h2r_lookup_config *cfg, uint64_t num_elems) {
+int32_t h2r_lookup_hist_fresh_op(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint32_t op, const void *trace, uint64_t first_off,
+                                 uint64_t elem_stride, uint64_t num_elems, uint32_t *hist, h2r_stream_t stream) try {
+    return lookup_hist_fresh_impl(ctx, cfg, op, trace, first_off, elem_stride, num_elems, nullptr, hist, stream);
+} H2R_CATCH_STATUS
+
+uint64_t h2r_lookup_workspace_bytes(const h2r_lookup_config *cfg, uint64_t num_elems) try {
     if (!cfg || cfg->n_rows == 0 || cfg->n_rows > (u32)LOOKUP_MAX_ROWS) return 0;
     return num_elems * LOOKUP_ARGS * lookup_slot_bytes(cfg->n_rows) + 256;
-}
+} H2R_CATCH_ZERO
 
 int32_t h2r_lookup_permuted_columns(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const uint32_t *hist, const uint64_t *theta,
                                     uint64_t num_elems, uint32_t usable_rows, uint32_t arg_mask, void *a_perm_out,
                                     void *s_perm_out, uint64_t out_elem_stride, uint8_t *status, void *workspace,
-                                    h2r_stream_t stream) {
+                                    h2r_stream_t stream) try {
     if (!ctx || !cfg || !hist || !theta || !a_perm_out || !s_perm_out || !workspace) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (cfg->n_rows == 0 || cfg->n_rows > (u32)LOOKUP_MAX_ROWS || cfg->n_lens == 0 || cfg->n_lens > H2R_LOOKUP_MAX_LENS) return H2R_E_SHAPE;
@@ -2393,9 +2415,9 @@ int32_t h2r_lookup_permuted_columns(const h2r_ctx *ctx, const h2r_lookup_config 
     hipExtLaunchKernelGGL(lookup_fill_kernel, dim3(chunks, LOOKUP_ARGS, (unsigned)num_elems), dim3(256), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, fa);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_field_eval(const h2r_ctx *ctx, uint32_t op, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) {
+int32_t h2r_field_eval(const h2r_ctx *ctx, uint32_t op, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]) try {
     if (!ctx || !a || !out || (op < 3 && !b)) return H2R_E_NULL;
     Fe x, y = fe_zero(), r;
     for (int k = 0; k < 4; ++k) { x.v[k] = a[k]; if (b) y.v[k] = b[k]; }
@@ -2411,7 +2433,7 @@ int32_t h2r_field_eval(const h2r_ctx *ctx, uint32_t op, const uint64_t a[4], con
     }
     for (int k = 0; k < 4; ++k) out[k] = r.v[k];
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 // ---- host-side flatten: planes -> the reference's assignment order -----------------------------------
 namespace {
@@ -2487,31 +2509,31 @@ static u8 *flatten_parts(const h2r_layout &lo, const u8 *rec, u8 *outp, u32 part
     return o.p;
 }
 
-int32_t h2r_trace_flatten(const h2r_ctx *ctx, const void *record_host, void *stream_out) {
+int32_t h2r_trace_flatten(const h2r_ctx *ctx, const void *record_host, void *stream_out) try {
     if (!ctx || !record_host || !stream_out) return H2R_E_NULL;
     const h2r_layout &lo = ctx->layout;
     u8 *end = flatten_parts(lo, static_cast<const u8 *>(record_host), static_cast<u8 *>(stream_out), 31);
     if ((u64)(end - static_cast<u8 *>(stream_out)) != lo.stream_bytes) return H2R_E_SHAPE;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-uint64_t h2r_stream_bytes(const h2r_ctx *ctx, uint32_t flags) {
+uint64_t h2r_stream_bytes(const h2r_ctx *ctx, uint32_t flags) try {
     if (!ctx) return 0;
     const h2r_layout &lo = ctx->layout;
     return lo.stream_bytes + ((flags & H2R_STREAM_FIELD_AB) ? (u64)lo.num_cols * (32 - lo.wide_bytes) : 0);
-}
-uint64_t h2r_pow_stream_bytes(const h2r_ctx *ctx, const h2r_pow_layout *pl, uint32_t flags) {
+} H2R_CATCH_ZERO
+uint64_t h2r_pow_stream_bytes(const h2r_ctx *ctx, const h2r_pow_layout *pl, uint32_t flags) try {
     if (!ctx || !pl) return 0;
     return pl->stream_bytes + (u64)pl->num_mul_mods * (h2r_stream_bytes(ctx, flags) - ctx->layout.stream_bytes);
-}
-int32_t h2r_trace_flatten_ex(const h2r_ctx *ctx, const void *record_host, uint32_t flags, void *stream_out) {
+} H2R_CATCH_ZERO
+int32_t h2r_trace_flatten_ex(const h2r_ctx *ctx, const void *record_host, uint32_t flags, void *stream_out) try {
     if (!ctx || !record_host || !stream_out) return H2R_E_NULL;
     if (flags & ~H2R_STREAM_FIELD_AB) return H2R_E_UNSUPPORTED;
     u8 *end = flatten_parts(ctx->layout, static_cast<const u8 *>(record_host), static_cast<u8 *>(stream_out),
                             31 | ((flags & H2R_STREAM_FIELD_AB) ? 32u : 0u), ctx->field_p);
     if ((u64)(end - static_cast<u8 *>(stream_out)) != h2r_stream_bytes(ctx, flags)) return H2R_E_SHAPE;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 namespace {
 // The segment table of one record's stream for emit_kernel: q/r block, column ranges of the two accumulator planes
@@ -2582,7 +2604,7 @@ int32_t launch_emit(const h2r_ctx *ctx, EmitArgs &ea, u32 flags, hipStream_t st)
 }  // namespace
 
 int32_t h2r_trace_emit_stream(const h2r_ctx *ctx, const void *trace, uint64_t num_records, uint32_t flags, void *stream_out,
-                              uint64_t out_stride, uint64_t out_off, h2r_stream_t stream) {
+                              uint64_t out_stride, uint64_t out_off, h2r_stream_t stream) try {
     if (!ctx || !trace || !stream_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (out_stride < out_off + h2r_stream_bytes(ctx, flags)) return H2R_E_SHAPE;
@@ -2591,11 +2613,11 @@ int32_t h2r_trace_emit_stream(const h2r_ctx *ctx, const void *trace, uint64_t nu
     ea.trace = static_cast<const u8 *>(trace); ea.elem_stride = ctx->layout.record_stride; ea.off_records = 0; ea.T = 1;
     ea.n_elems = num_records; ea.out = static_cast<u8 *>(stream_out); ea.out_stride = out_stride; ea.out_off = out_off;
     return launch_emit(ctx, ea, flags, static_cast<hipStream_t>(stream));
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_pow_trace_emit_stream(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *trace, uint64_t elem_stride,
                                   uint64_t batch, uint32_t flags, void *stream_out, uint64_t out_stride, uint64_t out_off,
-                                  h2r_stream_t stream) {
+                                  h2r_stream_t stream) try {
     if (!ctx || !pl || !trace || !stream_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (out_stride < out_off + h2r_pow_stream_bytes(ctx, pl, flags)) return H2R_E_SHAPE;
@@ -2611,10 +2633,10 @@ int32_t h2r_pow_trace_emit_stream(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
     ea.off_result = pl->off_result; ea.has_result = 1;
     if (ea.var && ea.T != 2 * ea.nbits) return H2R_E_SHAPE;
     return launch_emit(ctx, ea, flags, static_cast<hipStream_t>(stream));
-}
+} H2R_CATCH_STATUS
 
 // ---- advice-column image ---------------------------------------------------------------------------------------
-uint32_t h2r_advice_rows(const h2r_ctx *ctx) { return ctx ? advice_rows_per_record(ctx->L, ctx->layout.carry_nsub) : 0; }
+uint32_t h2r_advice_rows(const h2r_ctx *ctx) try { return ctx ? advice_rows_per_record(ctx->L, ctx->layout.carry_nsub) : 0; } H2R_CATCH_ZERO
 
 namespace {
 int32_t launch_advice(const h2r_ctx *ctx, AdviceArgs &aa, hipStream_t st) {
@@ -2667,7 +2689,7 @@ int32_t launch_cells(const h2r_ctx *ctx, CellsArgs &ca, hipStream_t st) {
 }  // namespace
 
 int32_t h2r_mul_mod_emit_advice(const h2r_ctx *ctx, const void *a, const void *b, const void *n, uint32_t flags, const void *trace,
-                                uint64_t batch, const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
+                                uint64_t batch, const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream) try {
     if (!ctx || !a || !b || !n || !trace || !advice_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     H2R_ON_DEVICE(ctx->params.device);
@@ -2688,11 +2710,11 @@ int32_t h2r_mul_mod_emit_advice(const h2r_ctx *ctx, const void *a, const void *b
     aa.status = status; aa.trace = static_cast<const u8 *>(trace); aa.elem_stride = ctx->layout.record_stride; aa.off_records = 0;
     aa.T = 1; aa.n_items = batch; aa.out = static_cast<u8 *>(advice_out); aa.out_stride = out_stride;
     return launch_advice(ctx, aa, static_cast<hipStream_t>(stream));
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_pow_trace_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *n, uint32_t flags, const void *trace,
                                   uint64_t elem_stride, const void *workspace, uint64_t batch, const uint8_t *status,
-                                  void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
+                                  void *advice_out, uint64_t out_stride, h2r_stream_t stream) try {
     if (!ctx || !pl || !n || !workspace || !advice_out) return H2R_E_NULL;
     const bool var = pl->off_e_bits != UINT64_MAX;
     if (!trace && (var || !(flags & H2R_ADVICE_DIRECT))) return H2R_E_NULL;   // (a Var element's e_bits / selected planes live in the trace)
@@ -2744,16 +2766,16 @@ int32_t h2r_pow_trace_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
     aa.out = out; aa.out_stride = out_stride;
     aa.pre_rows = 2u; aa.sel_rows = sel_rows;
     return launch_advice(ctx, aa, st);
-}
+} H2R_CATCH_STATUS
 
-uint64_t h2r_pow_advice_rows(const h2r_ctx *ctx, const h2r_pow_layout *pl) {
+uint64_t h2r_pow_advice_rows(const h2r_ctx *ctx, const h2r_pow_layout *pl) try {
     if (!ctx || !pl) return 0;
     const u64 recs = 2ull + (u64)pl->num_mul_mods * h2r_advice_rows(ctx);   // acc = assign_constant(1): CONST1, CONST0, then the mul_mods
     if (pl->off_e_bits == UINT64_MAX) return recs;
     return (u64)pl->e_num_limbs * var_to_bits_rows(pl->exp_limb_bits) + recs + (u64)pl->num_exp_bits * ctx->L;
-}
+} H2R_CATCH_ZERO
 
-int32_t h2r_pow_row_kinds(const h2r_ctx *ctx, const h2r_pow_layout *pl, uint8_t *kinds_out) {
+int32_t h2r_pow_row_kinds(const h2r_ctx *ctx, const h2r_pow_layout *pl, uint8_t *kinds_out) try {
     if (!ctx || !pl || !kinds_out) return H2R_E_NULL;
     const u32 rows = h2r_advice_rows(ctx), nrc = (ctx->layout.carry_nsub + 3) / 4;
     const bool var = pl->off_e_bits != UINT64_MAX;
@@ -2767,16 +2789,16 @@ int32_t h2r_pow_row_kinds(const h2r_ctx *ctx, const h2r_pow_layout *pl, uint8_t 
         if (var && !(t & 1)) for (u32 j = 0; j < ctx->L; ++j) *k++ = (uint8_t)ROWK_SELECT;
     }
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_advice_row_kinds(const h2r_ctx *ctx, uint8_t *kinds_out) {
+int32_t h2r_advice_row_kinds(const h2r_ctx *ctx, uint8_t *kinds_out) try {
     if (!ctx || !kinds_out) return H2R_E_NULL;
     const u32 rows = h2r_advice_rows(ctx), nrc = (ctx->layout.carry_nsub + 3) / 4;
     for (u32 r = 0; r < rows; ++r) kinds_out[r] = (uint8_t)advice_decode(r, ctx->L, nrc).kind;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_advice_fixed_row(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint32_t kind, h2r_fixed_row *out) {
+int32_t h2r_advice_fixed_row(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint32_t kind, h2r_fixed_row *out) try {
     if (!ctx || !out) return H2R_E_NULL;
     std::memset(out, 0, sizeof *out);
     const h2r_layout &lo = ctx->layout;
@@ -2855,7 +2877,7 @@ int32_t h2r_advice_fixed_row(const h2r_ctx *ctx, const h2r_lookup_config *cfg, u
         }
     }
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 // ---- advice rows of the Fresh-integer family (h2r_rowprog.hpp) ---------------------------------------------------------------
 namespace {
@@ -2914,24 +2936,24 @@ int32_t launch_row_prog(const h2r_ctx *ctx, const h2r_ctx::RowProg *rp, RowProgA
 }
 }  // namespace
 
-uint32_t h2r_fresh_op_advice_rows(const h2r_ctx *ctx, uint32_t op, uint32_t flags) {
+uint32_t h2r_fresh_op_advice_rows(const h2r_ctx *ctx, uint32_t op, uint32_t flags) try {
     const h2r_ctx::RowProg *rp = nullptr;
     if (!ctx || fresh_row_prog(ctx, op, flags, &rp)) return 0;
     return (uint32_t)rp->host.size();
-}
+} H2R_CATCH_ZERO
 
-int32_t h2r_fresh_op_row_kinds(const h2r_ctx *ctx, uint32_t op, uint32_t flags, uint8_t *kinds_out) {
+int32_t h2r_fresh_op_row_kinds(const h2r_ctx *ctx, uint32_t op, uint32_t flags, uint8_t *kinds_out) try {
     if (!ctx || !kinds_out) return H2R_E_NULL;
     const h2r_ctx::RowProg *rp = nullptr;
     const int32_t rc = fresh_row_prog(ctx, op, flags, &rp);
     if (rc) return rc;
     for (size_t r = 0; r < rp->host.size(); ++r) kinds_out[r] = (uint8_t)rp->host[r].kind;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_fresh_op_emit_advice(const h2r_ctx *ctx, uint32_t op, uint32_t flags, const void *a, const void *b, const void *n,
                                  const void *trace, uint64_t first_off, uint64_t elem_stride, uint64_t batch, const uint8_t *status,
-                                 void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
+                                 void *advice_out, uint64_t out_stride, h2r_stream_t stream) try {
     if (!ctx || !a || !trace || !advice_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     const h2r_ctx::RowProg *rp = nullptr;
@@ -2956,7 +2978,7 @@ int32_t h2r_fresh_op_emit_advice(const h2r_ctx *ctx, uint32_t op, uint32_t flags
     ra.status = status; ra.batch = batch; ra.out = static_cast<u8 *>(advice_out); ra.out_stride = out_stride;
     H2R_ON_DEVICE(ctx->params.device);
     return launch_row_prog(ctx, rp, ra, static_cast<hipStream_t>(stream));
-}
+} H2R_CATCH_STATUS
 
 // ---- the whole verify_pkcs1v15_signature element as advice rows ------------------------------------------------------------
 namespace {
@@ -2969,16 +2991,16 @@ int32_t verify_progs(const h2r_ctx *ctx, const h2r_ctx::RowProg **pre, const h2r
 }
 }  // namespace
 
-uint64_t h2r_verify_advice_rows(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint64_t section_rows[4]) {
+uint64_t h2r_verify_advice_rows(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint64_t section_rows[4]) try {
     if (!ctx || !vl) return 0;
     const h2r_ctx::RowProg *pre, *inf, *em;
     if (verify_progs(ctx, &pre, &inf, &em)) return 0;
     const u64 r[4] = {pre->host.size(), inf->host.size(), h2r_pow_advice_rows(ctx, &vl->pow), em->host.size()};
     if (section_rows) for (int k = 0; k < 4; ++k) section_rows[k] = r[k];
     return r[0] + r[1] + r[2] + r[3];
-}
+} H2R_CATCH_ZERO
 
-int32_t h2r_verify_row_kinds(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint8_t *kinds_out) {
+int32_t h2r_verify_row_kinds(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint8_t *kinds_out) try {
     if (!ctx || !vl || !kinds_out) return H2R_E_NULL;
     const h2r_ctx::RowProg *pre, *inf, *em;
     const int32_t rc = verify_progs(ctx, &pre, &inf, &em);
@@ -2990,11 +3012,11 @@ int32_t h2r_verify_row_kinds(const h2r_ctx *ctx, const h2r_verify_layout *vl, ui
     k += h2r_pow_advice_rows(ctx, &vl->pow);
     for (const RpRow &r : em->host) *k++ = (uint8_t)r.kind;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, const void *sig, const void *n, const uint64_t *hashed,
                                const void *powed, uint32_t flags, const void *trace, const void *workspace, uint64_t batch,
-                               const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
+                               const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream) try {
     if (!ctx || !vl || !sig || !n || !hashed || !powed || !trace || !workspace || !advice_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     const h2r_ctx::RowProg *pre, *inf, *em;
@@ -3022,20 +3044,20 @@ int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, 
     ra.a = powed; ra.b = hashed; ra.b_stride = 4; ra.first_off = vl->off_em;
     ra.out = out + (sec[0] + sec[1] + sec[2]) * ADVICE_ROW_BYTES;                                      // :138-198
     return launch_row_prog(ctx, em, ra, st);
-}
+} H2R_CATCH_STATUS
 
 // ---- one RSAChip::modpow_public_key element as advice rows: [assert_in_field(x, n)] [pow_mod_fixed_exp] (src/chip.rs:106-111) ----
-uint64_t h2r_modpow_public_key_advice_rows(const h2r_ctx *ctx, const h2r_pow_layout *pl, uint64_t section_rows[2]) {
+uint64_t h2r_modpow_public_key_advice_rows(const h2r_ctx *ctx, const h2r_pow_layout *pl, uint64_t section_rows[2]) try {
     if (!ctx || !pl) return 0;
     const u64 r[2] = {h2r_fresh_op_advice_rows(ctx, FRESH_IS_IN_FIELD, H2R_ADVICE_ASSERT_ONE), h2r_pow_advice_rows(ctx, pl)};
     if (!r[0]) return 0;
     if (section_rows) { section_rows[0] = r[0]; section_rows[1] = r[1]; }
     return r[0] + r[1];
-}
+} H2R_CATCH_ZERO
 
 int32_t h2r_modpow_public_key_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *x, const void *n, uint32_t flags,
                                           const void *in_field_trace, const void *trace, const void *workspace, uint64_t batch,
-                                          const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
+                                          const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream) try {
     if (!ctx || !pl || !x || !n || !in_field_trace || !workspace || !advice_out) return H2R_E_NULL;
     u64 sec[2];
     const u64 rows = h2r_modpow_public_key_advice_rows(ctx, pl, sec);
@@ -3046,7 +3068,7 @@ int32_t h2r_modpow_public_key_emit_advice(const h2r_ctx *ctx, const h2r_pow_layo
     if (rc) return rc;
     return h2r_pow_trace_emit_advice(ctx, pl, n, flags | (trace ? 0u : H2R_ADVICE_DIRECT), trace, 0, workspace, batch, status,
                                      static_cast<u8 *>(advice_out) + sec[0] * ADVICE_ROW_BYTES, out_stride, stream);
-}
+} H2R_CATCH_STATUS
 
 // ---- the hashed-message limbs of RSASignatureVerifier as advice rows (src/lib.rs:225-239) ---------------------------------
 namespace {
@@ -3057,23 +3079,23 @@ int32_t hashed_msg_prog(const h2r_ctx *ctx, const h2r_ctx::RowProg **out) {
 }
 }  // namespace
 
-uint32_t h2r_hashed_msg_advice_rows(const h2r_ctx *ctx) {
+uint32_t h2r_hashed_msg_advice_rows(const h2r_ctx *ctx) try {
     const h2r_ctx::RowProg *rp = nullptr;
     if (!ctx || hashed_msg_prog(ctx, &rp)) return 0;
     return (uint32_t)rp->host.size();
-}
+} H2R_CATCH_ZERO
 
-int32_t h2r_hashed_msg_row_kinds(const h2r_ctx *ctx, uint8_t *kinds_out) {
+int32_t h2r_hashed_msg_row_kinds(const h2r_ctx *ctx, uint8_t *kinds_out) try {
     if (!ctx || !kinds_out) return H2R_E_NULL;
     const h2r_ctx::RowProg *rp = nullptr;
     const int32_t rc = hashed_msg_prog(ctx, &rp);
     if (rc) return rc;
     for (size_t r = 0; r < rp->host.size(); ++r) kinds_out[r] = (uint8_t)rp->host[r].kind;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_hashed_msg_emit_advice(const h2r_ctx *ctx, const void *hm_trace, uint64_t hm_stride, uint64_t batch, const uint8_t *status,
-                                   void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
+                                   void *advice_out, uint64_t out_stride, h2r_stream_t stream) try {
     if (!ctx || !hm_trace || !advice_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     const h2r_ctx::RowProg *rp = nullptr;
@@ -3089,7 +3111,7 @@ int32_t h2r_hashed_msg_emit_advice(const h2r_ctx *ctx, const void *hm_trace, uin
     ra.status = status; ra.batch = batch; ra.out = static_cast<u8 *>(advice_out); ra.out_stride = out_stride;
     H2R_ON_DEVICE(ctx->params.device);
     return launch_row_prog(ctx, rp, ra, static_cast<hipStream_t>(stream));
-}
+} H2R_CATCH_STATUS
 
 // ---- in-place audit ----------------------------------------------------------------------------------------
 namespace {
@@ -3114,7 +3136,7 @@ int32_t launch_check(const h2r_ctx *ctx, CheckArgs &ca, const uint8_t *status, u
 }  // namespace
 
 int32_t h2r_mul_mod_trace_check(const h2r_ctx *ctx, const void *a, const void *b, const void *n, uint32_t flags, const void *trace,
-                                uint64_t batch, const uint8_t *status, uint32_t *bad_out, uint32_t *first_bad_out, h2r_stream_t stream) {
+                                uint64_t batch, const uint8_t *status, uint32_t *bad_out, uint32_t *first_bad_out, h2r_stream_t stream) try {
     if (!ctx || !a || !b || !n || !trace || !bad_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     H2R_ON_DEVICE(ctx->params.device);
@@ -3124,11 +3146,11 @@ int32_t h2r_mul_mod_trace_check(const h2r_ctx *ctx, const void *a, const void *b
     ca.n = n; ca.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
     ca.trace = static_cast<const u8 *>(trace); ca.elem_stride = ctx->layout.record_stride; ca.off_records = 0; ca.T = 1; ca.n_items = batch;
     return launch_check(ctx, ca, status, bad_out, first_bad_out, batch, static_cast<hipStream_t>(stream));
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_pow_trace_check(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *x, const void *n, const uint8_t *e_le,
                             size_t e_len, uint32_t flags, const void *trace, uint64_t elem_stride, const void *workspace,
-                            uint64_t batch, const uint8_t *status, uint32_t *bad_out, uint32_t *first_bad_out, h2r_stream_t stream) {
+                            uint64_t batch, const uint8_t *status, uint32_t *bad_out, uint32_t *first_bad_out, h2r_stream_t stream) try {
     if (!ctx || !pl || !x || !n || !trace || !workspace || !bad_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     const bool var = pl->off_e_bits != UINT64_MAX;
@@ -3164,27 +3186,27 @@ int32_t h2r_pow_trace_check(const h2r_ctx *ctx, const h2r_pow_layout *pl, const 
     else hipLaunchKernelGGL((link_kernel<32>), dim3((unsigned)batch), dim3(64), 0, st, la);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 // ---- BigIntInstructions::mul / square, is_equal_muled, refresh -----------------
-uint64_t h2r_mul_stream_bytes(const h2r_ctx *ctx) { return ctx ? (u64)ctx->L * ctx->L * ctx->layout.wide_bytes : 0; }
-uint64_t h2r_is_equal_muled_stream_bytes(const h2r_ctx *ctx) {
+uint64_t h2r_mul_stream_bytes(const h2r_ctx *ctx) try { return ctx ? (u64)ctx->L * ctx->L * ctx->layout.wide_bytes : 0; } H2R_CATCH_ZERO
+uint64_t h2r_is_equal_muled_stream_bytes(const h2r_ctx *ctx) try {
     if (!ctx) return 0;
     const h2r_layout &lo = ctx->layout;
     return (u64)lo.num_cols * (5ull * lo.wide_bytes + 2ull * lo.carry_bytes + 4ull * lo.limb_bytes + 4) +
            (u64)(lo.num_cols - 1) * (lo.carry_bytes + lo.carry_nsub);
-}
-uint64_t h2r_refresh_stream_bytes(const h2r_ctx *ctx) {
+} H2R_CATCH_ZERO
+uint64_t h2r_refresh_stream_bytes(const h2r_ctx *ctx) try {
     if (!ctx) return 0;
     const h2r_layout &lo = ctx->layout;
     u64 b = 0;
     for (u32 i = 0; i < ctx->refresh_nf; ++i)
         b += (u64)(ctx->refresh_inc[i] + 1) * (lo.carry_bytes + lo.limb_bytes + lo.wide_bytes + lo.limb_bytes) + (u64)ctx->refresh_inc[i] * lo.wide_bytes;
     return b + (u64)ctx->refresh_nf * (lo.limb_bytes + lo.limb_nsub);
-}
+} H2R_CATCH_ZERO
 
 int32_t h2r_mul_batch(const h2r_ctx *ctx, const void *a, const void *b, uint64_t batch, void *trace, uint64_t *muled_out,
-                      h2r_stream_t stream) {
+                      h2r_stream_t stream) try {
     if (!ctx || !a || !b || !trace || !muled_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (batch == 0) return H2R_OK;
@@ -3198,15 +3220,15 @@ int32_t h2r_mul_batch(const h2r_ctx *ctx, const void *a, const void *b, uint64_t
     ProfScope ps(H2R_KERNEL_TRACE, static_cast<hipStream_t>(stream));
     HIP_TRY(launch_trace(ctx, ta, static_cast<hipStream_t>(stream)));
     return H2R_OK;
-}
-int32_t h2r_mul_trace_flatten(const h2r_ctx *ctx, const void *record_host, void *stream_out) {
+} H2R_CATCH_STATUS
+int32_t h2r_mul_trace_flatten(const h2r_ctx *ctx, const void *record_host, void *stream_out) try {
     if (!ctx || !record_host || !stream_out) return H2R_E_NULL;
     flatten_parts(ctx->layout, static_cast<const u8 *>(record_host), static_cast<u8 *>(stream_out), 2);
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_is_equal_muled_batch(const h2r_ctx *ctx, const uint64_t *muled_a, const uint64_t *muled_b, uint64_t batch,
-                                 void *trace, uint8_t *eq_out, h2r_stream_t stream) {
+                                 void *trace, uint8_t *eq_out, h2r_stream_t stream) try {
     if (!ctx || !muled_a || !muled_b || !trace) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (batch == 0) return H2R_OK;
@@ -3220,12 +3242,12 @@ int32_t h2r_is_equal_muled_batch(const h2r_ctx *ctx, const uint64_t *muled_a, co
     ProfScope ps(H2R_KERNEL_TRACE, static_cast<hipStream_t>(stream));
     HIP_TRY(launch_trace(ctx, ta, static_cast<hipStream_t>(stream)));
     return H2R_OK;
-}
-int32_t h2r_is_equal_muled_flatten(const h2r_ctx *ctx, const void *record_host, void *stream_out) {
+} H2R_CATCH_STATUS
+int32_t h2r_is_equal_muled_flatten(const h2r_ctx *ctx, const void *record_host, void *stream_out) try {
     if (!ctx || !record_host || !stream_out) return H2R_E_NULL;
     flatten_parts(ctx->layout, static_cast<const u8 *>(record_host), static_cast<u8 *>(stream_out), 16);
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 namespace {
 // RefreshAux::new(w, n_l, n_r) and the stream geometry of BigIntChip::refresh with it
@@ -3249,7 +3271,7 @@ int32_t refresh_plan(const h2r_ctx *ctx, u32 n_l, u32 n_r, RefreshPlan &rp) {
 }  // namespace
 
 int32_t h2r_refresh_layout(const h2r_ctx *ctx, uint32_t num_limbs_l, uint32_t num_limbs_r, uint32_t *num_limbs_fresh,
-                           uint64_t *stream_bytes, uint64_t *elem_stride) {
+                           uint64_t *stream_bytes, uint64_t *elem_stride) try {
     if (!ctx) return H2R_E_NULL;
     RefreshPlan rp;
     const int32_t rc = refresh_plan(ctx, num_limbs_l, num_limbs_r, rp);
@@ -3258,10 +3280,10 @@ int32_t h2r_refresh_layout(const h2r_ctx *ctx, uint32_t num_limbs_l, uint32_t nu
     if (stream_bytes) *stream_bytes = rp.stream_bytes;
     if (elem_stride) *elem_stride = round_up(rp.stream_bytes, 256);
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_refresh_batch_ex(const h2r_ctx *ctx, const uint64_t *muled, uint64_t muled_stride_cols, uint32_t num_limbs_l,
-                             uint32_t num_limbs_r, uint64_t batch, void *trace, void *fresh_out, uint8_t *status, h2r_stream_t stream) {
+                             uint32_t num_limbs_r, uint64_t batch, void *trace, void *fresh_out, uint8_t *status, h2r_stream_t stream) try {
     if (!ctx || !muled || !trace || !status) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     RefreshPlan rp;
@@ -3285,19 +3307,19 @@ int32_t h2r_refresh_batch_ex(const h2r_ctx *ctx, const uint64_t *muled, uint64_t
     hipLaunchKernelGGL(refresh_kernel, dim3((unsigned)batch), dim3(256), stage, st, ra);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 int32_t h2r_refresh_batch(const h2r_ctx *ctx, const uint64_t *muled, uint64_t batch, void *trace, void *fresh_out,
-                          uint8_t *status, h2r_stream_t stream) {
+                          uint8_t *status, h2r_stream_t stream) try {
     if (!ctx) return H2R_E_NULL;
     return h2r_refresh_batch_ex(ctx, muled, 2ull * ctx->L, ctx->L, ctx->L, batch, trace, fresh_out, status, stream);
-}
+} H2R_CATCH_STATUS
 
 // ---- general operand shapes: mul(d0, d1), is_equal_muled(n_l, n_r) --------------------------------------------------------
-uint64_t h2r_mul_stream_bytes_ex(const h2r_ctx *ctx, uint32_t d0, uint32_t d1) { return ctx ? (u64)d0 * d1 * ctx->layout.wide_bytes : 0; }
+uint64_t h2r_mul_stream_bytes_ex(const h2r_ctx *ctx, uint32_t d0, uint32_t d1) try { return ctx ? (u64)d0 * d1 * ctx->layout.wide_bytes : 0; } H2R_CATCH_ZERO
 
 int32_t h2r_mul_batch_ex(const h2r_ctx *ctx, const void *a, uint32_t d0, const void *b, uint32_t d1, uint64_t batch, void *trace,
-                         uint64_t *muled_out, h2r_stream_t stream) {
+                         uint64_t *muled_out, h2r_stream_t stream) try {
     if (!ctx || !a || !b || !trace || !muled_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (d0 == 0 || d1 == 0 || d0 > ctx->L || d1 > ctx->L) return H2R_E_SHAPE;
@@ -3317,9 +3339,9 @@ int32_t h2r_mul_batch_ex(const h2r_ctx *ctx, const void *a, uint32_t d0, const v
     const int32_t rc = hipGetLastError() == hipSuccess ? h2r_mul_batch(ctx, pad, pad + one, batch, trace, muled_out, stream) : H2R_E_HIP;
     (void)hipFreeAsync(pad, st);
     return rc;
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_mul_trace_flatten_ex(const h2r_ctx *ctx, const void *record_host, uint32_t d0, uint32_t d1, void *stream_out) {
+int32_t h2r_mul_trace_flatten_ex(const h2r_ctx *ctx, const void *record_host, uint32_t d0, uint32_t d1, void *stream_out) try {
     if (!ctx || !record_host || !stream_out) return H2R_E_NULL;
     if (d0 == 0 || d1 == 0 || d0 > ctx->L || d1 > ctx->L) return H2R_E_SHAPE;
     const h2r_layout &lo = ctx->layout;
@@ -3330,7 +3352,7 @@ int32_t h2r_mul_trace_flatten_ex(const h2r_ctx *ctx, const void *record_host, ui
         for (; j < d0 && j <= i; ++j) emit_acc(o, lo, rec, H2R_PL_AB_LO, j, i % lo.num_limbs);
     }
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
 namespace {
 struct EqPlan { U256 wm; u32 carry_bits, sub_bits, nsub, per_col; u64 stream_bytes; };
@@ -3348,14 +3370,14 @@ int32_t eq_plan(const h2r_ctx *ctx, u32 n_l, u32 n_r, u32 flags, EqPlan &ep) {
 }
 }  // namespace
 
-uint64_t h2r_is_equal_muled_stream_bytes_ex(const h2r_ctx *ctx, uint32_t num_limbs_l, uint32_t num_limbs_r, uint32_t flags) {
+uint64_t h2r_is_equal_muled_stream_bytes_ex(const h2r_ctx *ctx, uint32_t num_limbs_l, uint32_t num_limbs_r, uint32_t flags) try {
     EqPlan ep;
     return (ctx && eq_plan(ctx, num_limbs_l, num_limbs_r, flags, ep) == H2R_OK) ? ep.stream_bytes : 0;
-}
+} H2R_CATCH_ZERO
 
 int32_t h2r_is_equal_muled_batch_ex(const h2r_ctx *ctx, const uint64_t *muled_a, const uint64_t *muled_b, uint64_t muled_stride_cols,
                                     uint32_t num_limbs_l, uint32_t num_limbs_r, uint64_t batch, uint32_t flags, void *stream_out,
-                                    uint64_t out_stride, uint8_t *eq_out, h2r_stream_t stream) {
+                                    uint64_t out_stride, uint8_t *eq_out, h2r_stream_t stream) try {
     if (!ctx || !muled_a || !muled_b || !stream_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     EqPlan ep;
@@ -3381,13 +3403,13 @@ int32_t h2r_is_equal_muled_batch_ex(const h2r_ctx *ctx, const uint64_t *muled_a,
     hipLaunchKernelGGL(is_equal_muled_kernel, dim3((unsigned)batch), dim3(256), stage, st, ea);
     HIP_TRY(hipGetLastError());
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_pow_trace_flatten(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *elem_host, void *stream_out) {
+int32_t h2r_pow_trace_flatten(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *elem_host, void *stream_out) try {
     return h2r_pow_trace_flatten_ex(ctx, pl, elem_host, 0, stream_out);
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_pow_trace_flatten_ex(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *elem_host, uint32_t flags, void *stream_out) {
+int32_t h2r_pow_trace_flatten_ex(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *elem_host, uint32_t flags, void *stream_out) try {
     if (!ctx || !pl || !elem_host || !stream_out) return H2R_E_NULL;
     if (flags & ~H2R_STREAM_FIELD_AB) return H2R_E_UNSUPPORTED;
     const h2r_layout &lo = ctx->layout;
@@ -3417,9 +3439,9 @@ int32_t h2r_pow_trace_flatten_ex(const h2r_ctx *ctx, const h2r_pow_layout *pl, c
     std::memcpy(o, e + pl->off_result, limbs_bytes); o += limbs_bytes;
     if ((u64)(o - static_cast<u8 *>(stream_out)) != h2r_pow_stream_bytes(ctx, pl, flags)) return H2R_E_SHAPE;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_profile_enable(uint32_t capacity) {
+int32_t h2r_profile_enable(uint32_t capacity) try {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (auto &r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof.clear();
@@ -3427,9 +3449,9 @@ int32_t h2r_profile_enable(uint32_t capacity) {
     g_prof_cap = capacity;
     if (capacity) g_prof.reserve(capacity);
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-int32_t h2r_profile_read(uint32_t kernel, float *ms_out, uint32_t max_count, uint32_t *count) {
+int32_t h2r_profile_read(uint32_t kernel, float *ms_out, uint32_t max_count, uint32_t *count) try {
     if (!count) return H2R_E_NULL;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     u32 n = 0;
@@ -3445,9 +3467,9 @@ int32_t h2r_profile_read(uint32_t kernel, float *ms_out, uint32_t max_count, uin
     }
     *count = n;
     return H2R_OK;
-}
+} H2R_CATCH_STATUS
 
-const char *h2r_status_str(int32_t s) {
+const char *h2r_status_str(int32_t s) try {
     switch (s) {
         case H2R_OK: return "ok";
         case H2R_E_SHAPE: return "shape";
@@ -3459,10 +3481,12 @@ const char *h2r_status_str(int32_t s) {
         case H2R_E_NULL: return "null pointer";
         case H2R_E_NOT_IN_FIELD: return "x >= n";
         case H2R_E_ASSERTION: return "an assert_* constraint does not hold";
+        case H2R_E_NOMEM: return "a host allocation failed inside the library";
+        case H2R_E_INTERNAL: return "an unexpected C++ exception was stopped at the boundary";
         default: return "unknown";
     }
-}
-const char *h2r_last_hip_error(void) { return g_hip_err; }
+} H2R_CATCH_STR
+const char *h2r_last_hip_error(void) try { return g_hip_err; } H2R_CATCH_STR
 
 }  // extern "C"
 

@@ -576,6 +576,13 @@ __device__ __forceinline__ void block_shr(ChainLds<K, NW> &s, u32 sh, int lane, 
 // (q, r) = divmod(a * b, n) by Barrett reduction with the per-modulus mu'.  a, b, nn, q, r and the
 // returned status are meaningful in WAVE 0 only; every wave must call it (block barriers inside, and
 // the control flow never depends on the data).
+// Workgroup barriers block_mulmod executes, as a function of the (block-uniform) normalisation shift: every block_mul has two
+// (operands published / partial sums published), block_shl2k and block_shr two each.  chain_element_dual's idle group meets exactly
+// these barriers on a zero bit -- ONE definition, next to the code it counts: change it together with any barrier in block_mul,
+// block_shl2k, block_shr or block_mulmod.
+constexpr int BLOCK_MUL_BARRIERS = 2, BLOCK_SHIFT_BARRIERS = 2;
+__device__ __forceinline__ constexpr int block_mulmod_barriers(bool shifted) { return 3 * BLOCK_MUL_BARRIERS + (shifted ? 2 * BLOCK_SHIFT_BARRIERS : 0); }
+
 template <int K, int NW, bool DEEP>
 __device__ __forceinline__ int block_mulmod(ChainLds<K, NW> &s, u32 shift, int lane, int wave,
                                             const u32 (&a)[Geo<K, NW>::V], const u32 (&b)[Geo<K, NW>::V],
@@ -967,7 +974,7 @@ __device__ __forceinline__ void chain_element_dual(const ChainArgs &args, ChainL
             // a zero bit of a fixed exponent: no multiply (chip.rs:735-739).  The group only keeps the workgroup's barrier count --
             // block_mulmod's is 2 per product + 2 per shift when the modulus needs normalising (block-uniform) -- and leaves the
             // SIMDs to the squaring, which is the critical path
-            const int nbar = 6 + (shift ? 4 : 0);
+            const int nbar = block_mulmod_barriers(shift != 0);
             for (int b = 0; b < nbar; ++b) __syncthreads();
         }
         // items of the operand buffer in the reference's call order: Var: multiply 2 bi, square 2 bi + 1; fixed: square t, multiply t + 1

@@ -116,6 +116,7 @@ __global__ __launch_bounds__(64) void lookup_hist_fresh_kernel(LookupFreshArgs a
     extern __shared__ u32 lh[];
     const u32 tid = threadIdx.x, n = LOOKUP_ARGS * a.n_rows;
     const u64 elem = blockIdx.x;
+    if (a.status && a.status[elem]) return;   // (a failed element's witness is not written: nothing to count)
     for (u32 k = tid; k < n; k += 64) lh[k] = 0;
     __syncthreads();
     const u8 *base = a.trace + elem * a.elem_stride + a.first_off;

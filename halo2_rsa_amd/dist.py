@@ -96,6 +96,18 @@ class DistEnv:
             self.initialised = False
 
 
+_key_uses = {}
+
+
+def _run_key(key: str) -> str:
+    """Keys in torchrun's long-lived agent store are namespaced per run, per worker restart and per use: a restarted worker group
+    (or a second H2RDist in one job) must not read the previous incarnation's RCCL id or find its counters already at `world`.
+    Every rank makes the same sequence of calls, so the per-process use counter agrees across ranks."""
+    k = _key_uses.get(key, 0)
+    _key_uses[key] = k + 1
+    return "%s/%s/%s/%d" % (key, os.environ.get("TORCHELASTIC_RUN_ID", "norun"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), k)
+
+
 def exchange_bytes(key: str, payload, rank: int, world: int) -> bytes:
     """Rank 0's `payload` (bytes) to every rank, out of band of any collective library: through the TCPStore torchrun's agent
     already serves at MASTER_ADDR:MASTER_PORT (every worker is a client of it), or -- launched any other way -- one that rank 0
@@ -103,6 +115,7 @@ def exchange_bytes(key: str, payload, rank: int, world: int) -> bytes:
     from datetime import timedelta
     if world == 1:
         return bytes(payload)
+    key = _run_key(key)
     agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true"
     store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29531")), world,
                           is_master=(rank == 0 and not agent), timeout=timedelta(seconds=120))
@@ -129,6 +142,7 @@ def agree_all(key: str, ok: bool, rank: int, world: int, timeout_s: float = 120.
     from datetime import timedelta
     if world == 1:
         return bool(ok)
+    key = _run_key(key)
     agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "").lower() == "true"
     store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29531")), world,
                           is_master=(rank == 0 and not agent), timeout=timedelta(seconds=timeout_s))
@@ -136,8 +150,8 @@ def agree_all(key: str, ok: bool, rank: int, world: int, timeout_s: float = 120.
     store.add(key + "/n", 1)
     deadline = time.time() + timeout_s
     while int(store.add(key + "/n", 0)) < world:
-        if time.time() > deadline:
-            return False
+        if time.time() > deadline:   # a rank never arrived: raise on every rank that notices, rather than a verdict some ranks do not share
+            raise TimeoutError("agree_all(%s): %d of %d ranks after %.0f s" % (key, int(store.add(key + "/n", 0)), world, timeout_s))
         time.sleep(0.01)
     all_ok = int(store.add(key + "/bad", 0)) == 0
     store.add(key + "/seen", 1)                 # keep rank 0's server alive until everybody has read the verdict

@@ -170,6 +170,27 @@ def pack_messages(msgs, device):
     return torch.from_numpy(buf).to(device), torch.from_numpy(off).to(device)
 
 
+def check_packed_messages(buf, off, batch: int, device, max_byte_size=None):
+    """A caller-packed (uint8 buffer, int64 offsets [batch + 1]) pair: the kernels take message e from off[e] to off[e + 1]
+    unchecked, so the pair is validated here -- shapes, dtypes, device, monotonic offsets inside the buffer, and the SHA-256
+    chip's max_byte_size (src/lib.rs:321) -- with one device reduction."""
+    if not (isinstance(buf, torch.Tensor) and isinstance(off, torch.Tensor)):
+        raise TypeError("packed messages: (uint8 tensor, int64 offsets tensor)")
+    if buf.dtype != torch.uint8 or off.dtype != torch.int64 or buf.dim() != 1 or off.dim() != 1 or not buf.is_contiguous() or not off.is_contiguous():
+        raise ValueError("packed messages: a contiguous uint8 buffer and contiguous int64 offsets")
+    if off.numel() != batch + 1:
+        raise ValueError("packed messages: offsets must have batch + 1 entries")
+    if buf.device != torch.device(device) or off.device != torch.device(device):
+        raise ValueError("packed messages: buffer and offsets must be on the chip's device")
+    diff = off[1:] - off[:-1]
+    facts = torch.stack([(diff >= 0).all(), off[0] >= 0, off[-1] <= buf.numel(),
+                         (diff.max() <= max_byte_size) if (max_byte_size is not None and batch) else torch.ones((), dtype=torch.bool, device=off.device)]).cpu().tolist()
+    if not (facts[0] and facts[1] and facts[2]):
+        raise ValueError("packed messages: offsets must be non-negative, non-decreasing and end inside the buffer")
+    if not facts[3]:
+        raise ValueError("message longer than the SHA-256 chip's max_byte_size")
+
+
 class RSASignatureVerifier:
     """src/lib.rs:149-246: SHA-256 of the message, the reversed digest packed into the hashed-message limbs, then
     RSAChip::verify_pkcs1v15_signature -- all on the device (h2r_signature_verifier_batch).  The SHA-256 chip's own circuit
@@ -189,6 +210,7 @@ class RSASignatureVerifier:
         batch, dev = sig.batch, sig.limbs_dev.device
         if isinstance(msg, tuple):
             buf, off = msg
+            check_packed_messages(buf, off, batch, dev, self.sha256_max_byte_size)
         else:
             msgs = [msg] * batch if isinstance(msg, (bytes, bytearray)) else list(msg)
             if len(msgs) != batch:
@@ -220,6 +242,8 @@ def sha256_hashed_msg(chip: BigIntChip, msgs, want_trace: bool = True):
     dev = torch.device("cuda", chip.device)
     buf, off = msgs if isinstance(msgs, tuple) else pack_messages(msgs, dev)
     batch = off.numel() - 1
+    if isinstance(msgs, tuple):
+        check_packed_messages(buf, off, batch, dev)
     digest = torch.empty((batch, 32), dtype=torch.uint8, device=dev)
     hashed = torch.empty((batch, 4), dtype=torch.int64, device=dev)
     hm = torch.empty((batch, H2R_HASHED_MSG_STREAM_BYTES), dtype=torch.uint8, device=dev) if want_trace else None

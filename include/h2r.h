@@ -59,8 +59,10 @@ enum {
     H2R_E_UNSUPPORTED = 6,     /* (limb_width, num_limbs) has no compiled kernel */
     H2R_E_NULL = 7,            /* required pointer is NULL */
     H2R_E_NOT_IN_FIELD = 8,    /* x >= n: assert_in_field fails, src/chip.rs:106 */
-    H2R_E_ASSERTION = 9        /* an assert_* constraint does not hold (main_gate.assert_one / assert_zero on the
+    H2R_E_ASSERTION = 9,       /* an assert_* constraint does not hold (main_gate.assert_one / assert_zero on the
                                   predicate bit, big_integer/chip.rs:1020-1158): set by the host mirrors */
+    H2R_E_NOMEM = 10,          /* a host allocation failed inside the library (no C++ exception crosses the boundary) */
+    H2R_E_INTERNAL = 11        /* any other C++ exception, stopped at the boundary */
 };
 
 /* ---- fields (only F::NUM_BITS and the encoding of negative a_b depend on it) ------------------ */

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <memory>
 #include <vector>
 
@@ -133,7 +134,72 @@ static int one_shape(uint32_t w, uint32_t L, uint32_t field) {
     return 0;
 }
 
+// ---- no C++ exception crosses the C ABI: allocation failures injected through a replaced operator new ----
+// (libh2r.so's own `new` / std::vector / std::map allocations resolve to this definition: the executable comes first in symbol lookup)
+static bool g_fail_new = false;
+static long g_fail_after = -1;   // >= 0: that many allocations still succeed, then every one fails
+static unsigned long g_new_calls = 0;
+static bool fail_now() {
+    ++g_new_calls;
+    if (g_fail_after == 0) return true;
+    if (g_fail_after > 0) --g_fail_after;
+    return g_fail_new;
+}
+void *operator new(std::size_t n) {
+    if (fail_now()) throw std::bad_alloc();
+    void *p = std::malloc(n ? n : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void *operator new[](std::size_t n) { return operator new(n); }
+void *operator new(std::size_t n, const std::nothrow_t &) noexcept { return fail_now() ? nullptr : std::malloc(n ? n : 1); }
+void *operator new[](std::size_t n, const std::nothrow_t &) noexcept { return fail_now() ? nullptr : std::malloc(n ? n : 1); }
+void operator delete(void *p) noexcept { std::free(p); }
+void operator delete[](void *p) noexcept { std::free(p); }
+void operator delete(void *p, std::size_t) noexcept { std::free(p); }
+void operator delete[](void *p, std::size_t) noexcept { std::free(p); }
+
+static int allocation_failures_stay_inside() {
+    h2r_params pr;
+    std::memset(&pr, 0, sizeof pr);
+    pr.limb_width = 64; pr.bits_len = 2048; pr.field = H2R_FIELD_BN254_FR; pr.device = -1;
+    h2r_ctx *ctx = nullptr;
+    // h2r_ctx_create builds the constant record in a std::vector: with every allocation failing it must return a status, not unwind
+    g_fail_new = true;
+    int32_t rc = h2r_ctx_create(&pr, &ctx);
+    g_fail_new = false;
+    REQUIRE((rc == H2R_E_NOMEM) && ctx == nullptr);
+    for (long ok_allocs = 1; ok_allocs <= 3; ++ok_allocs) {   // the ctx itself is allocated, a later std::vector is not: the exception path
+        g_fail_after = ok_allocs;
+        rc = h2r_ctx_create(&pr, &ctx);
+        g_fail_after = -1;
+        REQUIRE((rc == H2R_E_NOMEM || rc == H2R_OK) && (rc == H2R_OK) == (ctx != nullptr));
+        if (ctx) { h2r_ctx_destroy(ctx); ctx = nullptr; }
+    }
+    REQUIRE(std::strcmp(h2r_status_str(H2R_E_NOMEM), "unknown") != 0 && std::strcmp(h2r_status_str(H2R_E_INTERNAL), "unknown") != 0);
+    REQUIRE(h2r_ctx_create(&pr, &ctx) == H2R_OK && ctx);
+    // the row programs of the Fresh-integer family are built on first use (std::vector / std::map / std::function inside the export)
+    const unsigned long before = g_new_calls;
+    g_fail_new = true;
+    const uint32_t r0 = h2r_fresh_op_advice_rows(ctx, 10 /* is_in_field */, 0);   // a size query: 0 on failure
+    h2r_verify_layout vl;
+    const uint8_t e3[3] = {1, 0, 1};
+    const int32_t lrc = h2r_verify_layout_fixed(ctx, e3, 3, &vl);   // (allocates nothing)
+    const uint64_t vr = h2r_verify_advice_rows(ctx, &vl, nullptr);
+    uint8_t kinds[8];
+    const int32_t krc = h2r_fresh_op_row_kinds(ctx, 10, 0, kinds);
+    g_fail_new = false;
+    REQUIRE(g_new_calls > before);              // the library's allocations do come through here
+    REQUIRE(r0 == 0 && lrc == H2R_OK && vr == 0 && krc == H2R_E_NOMEM);
+    // and the same calls succeed afterwards (nothing was left half-built)
+    const uint32_t r1 = h2r_fresh_op_advice_rows(ctx, 10, 0);
+    REQUIRE(r1 > 1000 && h2r_verify_advice_rows(ctx, &vl, nullptr) > r1);
+    h2r_ctx_destroy(ctx);
+    return 0;
+}
+
 int main() {
+    if (allocation_failures_stay_inside()) return 1;
     const uint32_t shapes[][3] = {{64, 32, H2R_FIELD_BN254_FR}, {32, 128, H2R_FIELD_PASTA_FP}, {64, 4, H2R_FIELD_BN254_FQ}, {64, 48, H2R_FIELD_PASTA_FQ}, {32, 8, H2R_FIELD_BN254_FR}};
     for (auto &s : shapes) if (one_shape(s[0], s[1], s[2])) return 1;
     std::printf("ASAN_HOST_OK %zu shapes\n", sizeof shapes / sizeof shapes[0]);

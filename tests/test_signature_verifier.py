@@ -439,3 +439,29 @@ def test_pipelined_signature_verifier_sha_role(H, golden):
             for i in ([0, 1, 2, 511, B - 1] + ([2559, 2560, 2561] if B == 5000 else []) if B >= 1024 else [0, 1, 2]):
                 assert np.array_equal(got.flatten(i), ref.flatten(i)), (B, k, i)
         pipe.close()
+
+
+@pytest.mark.gpu
+def test_packed_messages_are_validated(H, golden):
+    """A caller-packed (buffer, offsets) pair is checked before the kernels take message e from off[e] to off[e + 1]: wrong
+    length / dtype / device, decreasing offsets, an end behind the buffer, and a message above sha256_max_byte_size are refused;
+    a well-formed pair gives the same verdicts as the list form."""
+    import halo2_rsa_amd.rsa as R
+    rsa = H.RSAChip(2048, 5)
+    kats = golden["rsa_kats"]
+    ns, sigs = [int(k["n"]) for k in kats], [int(k["sig"]) for k in kats]
+    pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Fix(65537)))
+    sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64)))
+    ver = H.RSASignatureVerifier(rsa, sha256_max_byte_size=64)
+    msgs = [b"hello world"] * 3
+    want = ver.verify_pkcs1v15_signature(pk, msgs, sg).is_valid.cpu().tolist()
+    buf, off = R.pack_messages(msgs, torch.device("cuda", 0))
+    assert ver.verify_pkcs1v15_signature(pk, (buf, off), sg).is_valid.cpu().tolist() == want == [1, 1, 0]
+    bad = [(buf, off[:-1].contiguous()), (buf, off.to(torch.int32)), (buf, off.cpu()), (buf, torch.flip(off, [0]).contiguous()),
+           (buf, off + buf.numel()), (buf[:5].contiguous(), off)]
+    for pair in bad:
+        with pytest.raises((ValueError, TypeError)):
+            ver.verify_pkcs1v15_signature(pk, pair, sg)
+    big = R.pack_messages([b"x" * 65, b"y", b"z"], torch.device("cuda", 0))
+    with pytest.raises(ValueError):
+        ver.verify_pkcs1v15_signature(pk, big, sg)
