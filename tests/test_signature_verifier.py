@@ -296,7 +296,7 @@ def test_verify_with_a_variable_exponent(H, golden):
     exp_limb_bits): h2r_verify_pkcs1v15_var_batch on the reference's KATs with e = 65537 given as ONE 17-bit exponent limb and as
     four 5-bit limbs (the reference's EXP_LIMB_BITS = 5, src/chip.rs:364) -- is_valid 1, 1, 0; the element's stream = the oracle's
     in-field + variable-exponent pow + encoded-message streams; an exponent limb wider than exp_limb_bits gets H2R_E_SHAPE; the
-    whole-element advice image is refused for a Var layout."""
+    whole-element advice image holds the pow_mod rows (tests/test_cells_direct.py checks them cell by cell)."""
     import torch
     from halo2_rsa_amd._lib import lib
     kats = golden["rsa_kats"]
@@ -315,7 +315,8 @@ def test_verify_with_a_variable_exponent(H, golden):
         torch.cuda.synchronize()
         for r in (res, res_m):
             assert r.status.cpu().tolist() == [0, 0, 0] and r.is_valid.cpu().tolist() == [1, 1, 0]
-        assert res.advice_sections()[0] == 0                             # no whole-element image for a Var layout
+        nbits = exp_limb_bits * len(e_limbs)                              # [is_eq] [assert_in_field] [to_bits, acc = 1, per bit mul_mod / select / square_mod] [EM]
+        assert res.advice_sections()[1][2] == len(e_limbs) * (exp_limb_bits + (exp_limb_bits + 3) // 4 + 1) + 2 + nbits * (2 * 3973 + 32)
         for i in range(3):
             _, _, s_if = o.assert_in_field(o.limbs(sigs[i]), o.limbs(ns[i]))
             rc, out, s_pow = o.pow_mod(o.limbs(sigs[i]), np.array(e_limbs, dtype=np.uint64), exp_limb_bits, o.limbs(ns[i]))
@@ -446,7 +447,8 @@ def test_packed_messages_are_validated(H, golden):
     """A caller-packed (buffer, offsets) pair is checked before the kernels take message e from off[e] to off[e + 1]: wrong
     length / dtype / device, decreasing offsets, an end behind the buffer, and a message above sha256_max_byte_size are refused;
     a well-formed pair gives the same verdicts as the list form."""
-    import halo2_rsa_amd.rsa as R
+    import torch
+    import halo2_rsa_amd.rsa as RS
     rsa = H.RSAChip(2048, 5)
     kats = golden["rsa_kats"]
     ns, sigs = [int(k["n"]) for k in kats], [int(k["sig"]) for k in kats]
@@ -455,13 +457,13 @@ def test_packed_messages_are_validated(H, golden):
     ver = H.RSASignatureVerifier(rsa, sha256_max_byte_size=64)
     msgs = [b"hello world"] * 3
     want = ver.verify_pkcs1v15_signature(pk, msgs, sg).is_valid.cpu().tolist()
-    buf, off = R.pack_messages(msgs, torch.device("cuda", 0))
+    buf, off = RS.pack_messages(msgs, torch.device("cuda", 0))
     assert ver.verify_pkcs1v15_signature(pk, (buf, off), sg).is_valid.cpu().tolist() == want == [1, 1, 0]
     bad = [(buf, off[:-1].contiguous()), (buf, off.to(torch.int32)), (buf, off.cpu()), (buf, torch.flip(off, [0]).contiguous()),
            (buf, off + buf.numel()), (buf[:5].contiguous(), off)]
     for pair in bad:
         with pytest.raises((ValueError, TypeError)):
             ver.verify_pkcs1v15_signature(pk, pair, sg)
-    big = R.pack_messages([b"x" * 65, b"y", b"z"], torch.device("cuda", 0))
+    big = RS.pack_messages([b"x" * 65, b"y", b"z"], torch.device("cuda", 0))
     with pytest.raises(ValueError):
         ver.verify_pkcs1v15_signature(pk, big, sg)
