@@ -7,7 +7,7 @@ is already resident in HBM.
   --gpus 1 (default): BASELINE configs[1] -- one 1,024-signature call per step.
   --gpus N > 1: BASELINE configs[2] -- the seeded global batch (8,192 x N signatures: 65,536 at N = 8) is
     sharded contiguously (halo2_rsa_amd.dist.shard_range); every rank walks its 8,192-signature shard as
-    eight pipelined 1,024-signature calls per step and keeps the traces resident on its own GPU.  Weak
+    four pipelined 2,048-signature calls per step and keeps the traces resident on its own GPU.  Weak
     scaling, no data-path collective (signatures are independent); the only collectives are the
     configuration broadcast before and the result all-gather after the timed region (rank 0 checks
     samples of EVERY shard against pow()), plus the barrier / MAX-reduce that brackets the timing.
@@ -415,7 +415,7 @@ def advice_bench(args):
                        "per_gpu_batch": chunk, "global_batch": global_batch, "calls_per_step": 1, "signatures_per_call": chunk,
                        "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world, "ranks": env.world,
                        "pipeline": "chain kernels of call k+1 on a second stream next to cells_kernel of call k (2 workspaces, 2 images), stream-ordered exports + events",
-                       "untimed_clock_warmup_calls": ramp, "buffer_placement": placement},
+                       "untimed_clock_warmup_calls": ramp, "warmup_calls_total": 1 + ramp + warmup, "buffer_placement": placement},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
                          "traffic_source": "not measured", "kernel": "cells_kernel<%d>" % w, "launches_timed": len(cells_ms),
@@ -776,6 +776,8 @@ def main():
                                     (", %d producers (a pipeline and a stream each, calls alternate)" % producers if producers > 1 else ""))
                                    if pipe is not None else "none",
                        "untimed_clock_warmup_calls": ramp_steps * chunks,
+                       # everything that ran before the timed region: 1 set-up call + the clock warm-up calls + the W warm-up steps
+                       "warmup_calls_total": 1 + ramp_steps * chunks + warmup * chunks,
                        "buffer_placement": placement if placement else "as allocated"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
