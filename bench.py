@@ -205,7 +205,7 @@ def measured_pmc_traffic(argv_workload, kernel_prefix, timeout_s=150):
             d = os.path.join(tmp, counter)
             cmd = [rp, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "r", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
-                   "--pmc-traffic", "off", "--placement-candidates", "0"] + argv_workload
+                   "--pmc-traffic", "off", "--scale-anchor", "off", "--placement-candidates", "0"] + argv_workload
             env = dict(os.environ, TMPDIR="/tmp")
             try:
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
@@ -490,6 +490,9 @@ def main():
     ap.add_argument("--collectives", choices=["h2r", "torch"], default="h2r",
                     help="N > 1: the broadcast / result all-gather / timing barrier go through libh2r's RCCL exports (h2r_dist_*, default) "
                          "or through torch.distributed")
+    ap.add_argument("--scale-anchor", choices=["auto", "off"], default="auto",
+                    help="N = 1, default workload: also run the N > 1 per-GPU workload (8,192 signatures per step as four calls of 2,048) on this "
+                         "GPU and report it as `scale_anchor`: the like-for-like origin of a 1 -> 8 scaling curve")
     ap.add_argument("--pmc-traffic", choices=["auto", "off"], default="auto",
                     help="roofline.traffic: auto = measure it now with two rocprofv3 --pmc passes of a short run of the same workload "
                          "(N = 1, rank 0; falls back to the committed profiles/pmc_traffic.json when rocprofv3 is unavailable); off = committed file only")
@@ -588,7 +591,9 @@ def main():
     if cand:
         off_rec = vl.pow.off_records if verify else pl.off_records
         try:
-            arena = H.TraceArena(chip, elem_stride, off_rec, pl.num_mul_mods, chunk, regions=regions, candidates=cand)
+            # N > 1: every rank bounds what its look may hold besides the kept regions (a tenth of the device's free memory)
+            look_cap = int(torch.cuda.mem_get_info(env.local_rank)[0] // 10) if env.world > 1 else 0
+            arena = H.TraceArena(chip, elem_stride, off_rec, pl.num_mul_mods, chunk, regions=regions, candidates=cand, max_look_bytes=look_cap)
         except Exception as ex:   # (virtual-memory API unavailable, out of memory ...): plain allocations, said so in the line
             arena, placement = None, "as allocated (arena failed: %s)" % str(ex)[:120]
     if arena is not None:
@@ -711,10 +716,30 @@ def main():
     for i in (0, 1, 2, chunk - 1):
         if i < chunk:
             assert got[i] == pow(xs[base + i], e, ns[base + i]), "GPU result differs from pow(x, e, n)"
+    # one FULL call per shard audited in place on the device (h2r_pow_trace_check: every record of every element of the LAST call
+    # against SURVEY Appendix C's relations, independently of the producing kernels); the verdict bytes travel with the results
+    import ctypes as _ct
+    bad = torch.zeros(chunk, dtype=torch.int32, device=dev)
+    first_bad = torch.zeros(chunk, dtype=torch.int32, device=dev)
+    eb_ = e.to_bytes((e.bit_length() + 7) // 8, "little")
+    st_last = status[last * chunk:(last + 1) * chunk]
+    _lib.check(_lib.lib().h2r_pow_trace_check(chip._ctx, _ct.byref(vl.pow if verify else pl), xc[c_last].data_ptr(), nc[c_last].data_ptr(), eb_, len(eb_),
+                                              chip._flags(nc[c_last], chunk), trace_regions[last].data_ptr(), elem_stride,
+                                              workspaces[(counter[0] - 1) % nbuf].data_ptr(), chunk, st_last.data_ptr(), bad.data_ptr(),
+                                              first_bad.data_ptr(), chip._stream()), "h2r_pow_trace_check")
+    torch.cuda.synchronize()
+    audit = status[:shard].clone() if chunks > 1 else st_last.clone()
+    aud_last = ((bad != 0) | (st_last != 0)).to(torch.uint8)
+    if chunks > 1:
+        audit[last * chunk:(last + 1) * chunk] = aud_last
+    else:
+        audit = aud_last
     shard_out = out[:shard].contiguous() if chunks > 1 else res.contiguous()
-    gathered = env.gather_to_rank0(shard_out)
+    gathered, audit_all = env.gather_to_rank0(shard_out, audit.contiguous())
     if env.rank == 0:
         assert gathered.shape[0] == env.world * shard_out.shape[0]
+        n_flagged = int((audit_all != 0).sum().item())
+        assert n_flagged == 0 or (w, bits) != (64, 2048) or args.shared_modulus, "%d elements with a status or a violated witness relation" % n_flagged
         if (chunks > 1 or env.world > 1 or shard > 1024) and not args.shared_modulus:   # samples from EVERY shard against pow() of the regenerated inputs
             golden = load_golden(w, bits)
             vals = H.AssignedInteger(gathered, w)
@@ -769,7 +794,9 @@ def main():
                                 if verify and args.messages else
                                 "verify_pkcs1v15_signature (in-field + modpow + EM check)" if verify else "modpow_public_key"),
                        "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world,
-                       "ranks": env.world, "collective_backend": (env.backend + (" (RCCL)" if env.backend == "nccl" else "")) if env.initialised else "none (single process)",
+                       "ranks": env.describe()["ranks"], "rccl_version": env.describe()["rccl_version"], "communicator": env.describe()["communicator"],
+                       "collective_backend": (env.backend + (" (RCCL)" if env.backend == "nccl" else "")) if env.initialised else "none (single process)",
+                       "post_run_check": "results of every shard vs pow(); last call of every shard audited in place (all %d elements, every record), verdict bytes gathered with the results" % chunk,
                        "pipeline": ((("one launch per step: records of call k + chains of call k+1 (step_kernel), %d buffer sets" % args.pipeline_depth)
                                      if step_ms else
                                      ("chain k+1 || trace k, %d buffer sets, %d record stream(s)" % (args.pipeline_depth, args.side_streams))) +
@@ -806,8 +833,27 @@ def main():
                 line["roofline"]["traffic_source"] += "; live measurement skipped: " + how
         if env.world == 1 and not args.no_cpu_baseline and not args.shared_modulus:
             line["cpu_baseline"] = cpu_baseline(w, bits, e, un, ux)
+        if env.world == 1 and args.gpus == 1 and args.scale_anchor == "auto" and chunks == 1 and chunk == 1024 and not verify and args.workload == "rsa2048_e65537":
+            # The driver's N = 1 point is BASELINE config 2 (1,024 signatures per step), its N > 1 points config 3 (8,192 per GPU as four
+            # calls of 2,048): a like-for-like origin for the 1 -> 8 curve is the N > 1 per-GPU workload run on this one GPU.
+            line["scale_anchor"] = scale_anchor_line(args)
         print(json.dumps(line))
     env.finalize()
+
+
+def scale_anchor_line(args):
+    """`bench.py --gpus 1 --batch 2048 --chunks 4` (the per-GPU workload of every N > 1 run) in a fresh process, same steps / warm-up."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--batch", "2048", "--chunks", "4", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--no-cpu-baseline", "--pmc-traffic", "off", "--scale-anchor", "off"]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, check=True).stdout.strip().splitlines()[-1]
+        d = json.loads(out)
+        return {"what": "the N > 1 per-GPU workload (8,192 signatures per step as four pipelined calls of 2,048) on this one GPU: compare per-GPU values of the N > 1 runs with THIS",
+                "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "per_gpu_batch": d["config"]["per_gpu_batch"],
+                "calls_per_step": d["config"]["calls_per_step"], "roofline_frac": d["roofline"]["frac"], "whole_path_hbm_frac": d["whole_path_hbm_frac"]}
+    except Exception as ex:
+        return {"error": str(ex)[:200]}
 
 
 if __name__ == "__main__":

@@ -791,11 +791,11 @@ class TraceArena:
             self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
     def __init__(self, chip: BigIntChip, elem_stride: int, first_record_off: int, records_per_elem: int, batch: int,
-                 regions: int = 2, candidates: int = 16):
+                 regions: int = 2, candidates: int = 16, max_look_bytes: int = 0):
         self.chip = chip
         self._a = ctypes.c_void_p()
-        check(lib().h2r_arena_create(chip._ctx, elem_stride, first_record_off, records_per_elem, batch, regions, candidates,
-                                     chip._stream(), ctypes.byref(self._a)), "h2r_arena_create")
+        check(lib().h2r_arena_create_ex(chip._ctx, elem_stride, first_record_off, records_per_elem, batch, regions, candidates, max_look_bytes,
+                                        chip._stream(), ctypes.byref(self._a)), "h2r_arena_create_ex")
         nbytes = int(lib().h2r_arena_region_bytes(self._a))
         dev = "cuda:%d" % chip.device
         self.regions = [torch.as_tensor(TraceArena._Raw(int(lib().h2r_arena_region(self._a, i)), nbytes), device=dev) for i in range(regions)]

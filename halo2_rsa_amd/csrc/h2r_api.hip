@@ -972,6 +972,7 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
     bool ok = false;
 };
 const Rccl &rccl() {
@@ -991,6 +992,7 @@ const Rccl &rccl() {
         x.GroupStart = reinterpret_cast<decltype(x.GroupStart)>(sym("ncclGroupStart"));
         x.GroupEnd = reinterpret_cast<decltype(x.GroupEnd)>(sym("ncclGroupEnd"));
         x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(sym("ncclGetErrorString"));
+        x.GetVersion = reinterpret_cast<decltype(x.GetVersion)>(sym("ncclGetVersion"));
         x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.Broadcast && x.AllGather && x.AllReduce && x.GroupStart && x.GroupEnd && x.GetErrorString;
         return x;
     }();
@@ -1052,6 +1054,8 @@ void h2r_dist_destroy(h2r_dist *d) try {
     { DeviceGuard dg(d->ctx->params.device); (void)hipDeviceSynchronize(); (void)rccl().CommDestroy(d->comm); (void)hipFree(d->scratch); }
     delete d;
 } H2R_CATCH_VOID
+// the version of the RCCL the exports above run on (ncclGetVersion: major * 10000 + minor * 100 + patch), 0 when it cannot be loaded
+int32_t h2r_dist_version(void) try { int v = 0; return (rccl().ok && rccl().GetVersion && rccl().GetVersion(&v) == ncclSuccess) ? v : 0; } catch (...) { return 0; }
 uint32_t h2r_dist_rank(const h2r_dist *d) try { return d ? d->rank : 0; } H2R_CATCH_ZERO
 uint32_t h2r_dist_world(const h2r_dist *d) try { return d ? d->world : 0; } H2R_CATCH_ZERO
 
@@ -1127,6 +1131,14 @@ void arena_free_region(h2r_arena::Region &r) {
 
 int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t first_record_off, uint32_t records_per_elem,
                          uint64_t batch, uint32_t regions, uint32_t candidates, h2r_stream_t stream, h2r_arena **out) try {
+    return h2r_arena_create_ex(ctx, elem_stride, first_record_off, records_per_elem, batch, regions, candidates, 0, stream, out);
+} H2R_CATCH_STATUS
+
+// max_look_bytes != 0: an upper bound on the device memory the look may hold at any time BESIDES the kept regions (rejected
+// candidates kept so that the next one lands elsewhere; the placeholder rounds are skipped) -- a service that shares the device
+int32_t h2r_arena_create_ex(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t first_record_off, uint32_t records_per_elem,
+                            uint64_t batch, uint32_t regions, uint32_t candidates, uint64_t max_look_bytes, h2r_stream_t stream,
+                            h2r_arena **out) try {
     if (!ctx || !out) return H2R_E_NULL;
     *out = nullptr;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
@@ -1206,6 +1218,7 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
     size_t free_at_start = 0, total_at_start = 0;
     if (hipMemGetInfo(&free_at_start, &total_at_start) == hipSuccess) held_budget = std::min<u64>(held_budget, free_at_start / 2);
     else (void)hipGetLastError();
+    if (max_look_bytes) held_budget = std::min<u64>(held_budget, max_look_bytes);
     auto keep_best = [&](size_t keep, bool release_all) {   // sorts; everything behind the first `keep` moves to `rejected`
         std::stable_sort(cands.begin(), cands.end(), [](const h2r_arena::Region &x, const h2r_arena::Region &y) { return x.ms < y.ms; });
         for (size_t i = keep; i < cands.size(); ++i) rejected.push_back(std::move(cands[i]));
@@ -1242,7 +1255,7 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
             keep_best(regions, false);
         }
     }
-    if (rc == H2R_OK && region_bytes <= (12ull << 30) && candidates >= 4) {
+    if (rc == H2R_OK && region_bytes <= (12ull << 30) && candidates >= 4 && !max_look_bytes) {
         // No fast class among the candidates?  On a box whose memory has not been churned yet (about one in five) the first
         // ~60 GB handed out are ALL of the slow class -- as physically contiguous memory always is -- while regions mapped after
         // some allocate / free traffic, or behind a large allocation, do contain fast ones (tools/no_fast_box_probe.py,

@@ -76,8 +76,14 @@ class DistEnv:
         dist.broadcast(t, src=0)
         return [int(v) for v in t.tolist()]
 
-    def gather_to_rank0(self, shard: torch.Tensor):
-        """Gather equally sized per-rank result tensors; rank 0 returns the concatenation, others None."""
+    def gather_to_rank0(self, shard: torch.Tensor, status: torch.Tensor = None):
+        """Gather equally sized per-rank result tensors; rank 0 returns the concatenation, others None.  With `status` (uint8
+        [elems]) the pair (results, status) -- (None, None) on the other ranks."""
+        if status is not None:
+            return self._gather_one(shard), self._gather_one(status)
+        return self._gather_one(shard)
+
+    def _gather_one(self, shard: torch.Tensor):
         if not self.initialised:
             return shard
         if self.backend == "nccl":
@@ -88,6 +94,10 @@ class DistEnv:
         outs = [torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
         dist.gather(host, outs, dst=0)
         return torch.cat(outs, 0).to(shard.device) if self.rank == 0 else None
+
+    def describe(self) -> dict:
+        return {"ranks": (dist.get_world_size() if self.initialised else 1), "rank0": (dist.get_rank() if self.initialised else 0),
+                "rccl_version": None, "communicator": ("torch.distributed " + self.backend) if self.initialised else "none (single process)"}
 
     def finalize(self):
         if self.initialised:
@@ -198,14 +208,24 @@ class H2RDist:
         self._check(self._lib.h2r_dist_bcast(self._d, t.data_ptr(), t.numel() * 8, 0, self._stream()), "h2r_dist_bcast")
         return [int(v) for v in t.tolist()]
 
-    def gather_to_rank0(self, shard: torch.Tensor):
-        """shard: [elems, num_limbs] limbs.  Every rank receives every shard (all-gather); rank 0 returns the concatenation."""
+    def gather_to_rank0(self, shard: torch.Tensor, status: torch.Tensor = None):
+        """shard: [elems, num_limbs] limbs.  Every rank receives every shard (all-gather); rank 0 returns the concatenation.
+        status (uint8 [elems], optional) travels in the same group call: rank 0 then returns (results, status)."""
         shard = shard.contiguous()
         out = torch.empty((self.world * shard.shape[0],) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
-        self._check(self._lib.h2r_dist_gather_results(self._d, shard.data_ptr(), None, shard.shape[0], out.data_ptr(), None, self._stream()),
-                    "h2r_dist_gather_results")
+        st_all = torch.empty(self.world * shard.shape[0], dtype=torch.uint8, device=shard.device) if status is not None else None
+        self._check(self._lib.h2r_dist_gather_results(self._d, shard.data_ptr(), status.contiguous().data_ptr() if status is not None else None,
+                                                      shard.shape[0], out.data_ptr(), st_all.data_ptr() if st_all is not None else None,
+                                                      self._stream()), "h2r_dist_gather_results")
         torch.cuda.synchronize(self._dev)
+        if status is not None:
+            return (out, st_all) if self.rank == 0 else (None, None)
         return out if self.rank == 0 else None
+
+    def describe(self) -> dict:
+        """What ran: ranks as the communicator reports them, and the RCCL the C ABI's collectives went through."""
+        return {"ranks": int(self._lib.h2r_dist_world(self._d)), "rank0": int(self._lib.h2r_dist_rank(self._d)),
+                "rccl_version": int(self._lib.h2r_dist_version()), "communicator": "h2r_dist_init on every rank (agreed out of band before the first collective)"}
 
     def finalize(self):
         if self._d:

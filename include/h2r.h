@@ -304,6 +304,7 @@ typedef struct h2r_dist h2r_dist;
 int32_t h2r_dist_unique_id(uint8_t id_out[H2R_DIST_ID_BYTES]);                     /* rank 0: ncclGetUniqueId */
 int32_t h2r_dist_init(const h2r_ctx *ctx, const uint8_t id[H2R_DIST_ID_BYTES], uint32_t rank, uint32_t world, h2r_dist **out);
 void h2r_dist_destroy(h2r_dist *d);
+int32_t h2r_dist_version(void);   /* ncclGetVersion of the RCCL these exports run on (major * 10000 + minor * 100 + patch); 0: not loadable */
 uint32_t h2r_dist_rank(const h2r_dist *d);
 uint32_t h2r_dist_world(const h2r_dist *d);
 /* contiguous shards: rank g gets [g * total / world, (g + 1) * total / world), the remainder spread over the low ranks */
@@ -333,6 +334,12 @@ int32_t h2r_dist_allreduce_max_f64(h2r_dist *d, double *values, uint64_t count, 
 typedef struct h2r_arena h2r_arena;
 int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t first_record_off, uint32_t records_per_elem,
                          uint64_t batch, uint32_t regions, uint32_t candidates, h2r_stream_t stream, h2r_arena **out);
+/* The same with a bound on the memory the look may hold: max_look_bytes != 0 caps the rejected candidates kept mapped during the look
+ * (besides the `regions` best so far) and skips the placeholder rounds -- for a process that shares the device's memory with others
+ * (e.g. max_look_bytes = a tenth of hipMemGetInfo's free bytes).  0 = the policy above. */
+int32_t h2r_arena_create_ex(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t first_record_off, uint32_t records_per_elem,
+                            uint64_t batch, uint32_t regions, uint32_t candidates, uint64_t max_look_bytes, h2r_stream_t stream,
+                            h2r_arena **out);
 void *h2r_arena_region(const h2r_arena *a, uint32_t i);
 uint64_t h2r_arena_region_bytes(const h2r_arena *a);
 double h2r_arena_region_ms(const h2r_arena *a, uint32_t i);          /* measured record-kernel time of kept region i */

@@ -28,9 +28,22 @@ def test_bench_launches_its_own_ranks():
     (H2R_BENCH_ONE_GPU=1: a functional check of the N > 1 path -- shards, result gather, per-shard checks -- not a measurement)."""
     line = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "640", "--chunks", "2", "--no-cpu-baseline",
                  "--placement-candidates", "0", "--pmc-traffic", "off"], {"H2R_BENCH_ONE_GPU": "1"})
-    assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2
+    assert line["n_gpus"] == 2 and line["config"]["ranks"] == 2        # (ranks: what the communicator / process group reports)
+    assert "communicator" in line["config"] and "rccl_version" in line["config"]
+    assert "audited in place" in line["config"]["post_run_check"]       # one full call per shard checked on the device, verdicts gathered
     assert line["config"]["global_batch"] == 2 * 2 * 640 and line["scaling"] == "weak"
     assert line["value"] > 0 and line["roofline"]["frac"] > 0
+    assert "scale_anchor" not in line                                   # (the anchor belongs to the N = 1 line)
+
+
+def test_bench_n1_line_carries_the_scale_anchor():
+    """The driver's N = 1 point is config 2 (1,024 signatures per step), its N > 1 points run 8,192 per GPU as four calls of 2,048: the
+    N = 1 line also reports that per-GPU workload on the one GPU (`scale_anchor`), the like-for-like origin of a 1 -> 8 curve."""
+    line = _run(["--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--pmc-traffic", "off", "--placement-candidates", "4"])
+    sa = line["scale_anchor"]
+    assert "error" not in sa, sa
+    assert sa["per_gpu_batch"] == 8192 and sa["calls_per_step"] == 4 and sa["value"] > 0 and 0.2 < sa["roofline_frac"] < 1.0
+    assert line["config"]["warmup_calls_total"] >= 1 + 2
 
 
 def test_bench_default_line_has_roofline_and_cpu_baseline():
@@ -54,3 +67,13 @@ def test_bench_long_exponent_and_two_producers():
     assert line["roofline"]["launches_per_call"] == 16
     line = _run(["--producers", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--placement-candidates", "0", "--pmc-traffic", "off"])
     assert line["value"] > 0 and "2 producers" in line["config"]["pipeline"]
+
+
+def test_bench_advice_line():
+    """--advice: the prover-consumable witness as the product -- one line with path = "advice image", the cells kernel's roofline on the
+    pow rows it writes, and bench.py's own check of the timed image against the image of a call with records."""
+    line = _run(["--advice", "--batch", "256", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--pmc-traffic", "off", "--placement-candidates", "3"])
+    assert line["config"]["path"] == "advice image" and line["roofline"]["kernel"].startswith("cells_kernel")
+    assert line["roofline"]["algorithmic_bytes_per_launch"] == 256 * (2 + 19 * 3973) * 160
+    assert line["value"] > 0 and 0.2 < line["roofline"]["frac"] < 1.0
+    assert line["config"]["buffer_placement"]["candidates"] == 3

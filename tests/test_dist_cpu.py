@@ -39,6 +39,11 @@ def test_gloo_world2_harness(tmp_path):
         g = env.gather_to_rank0(shard)
         if env.rank == 0:
             assert g.shape == (10, 4) and g[:, 0].tolist() == list(range(10))
+        # results + one status byte per element in one call (bench.py's post-run audit verdicts travel this way)
+        g2, st2 = env.gather_to_rank0(shard, torch.full((hi - lo,), env.rank + 1, dtype=torch.uint8))
+        if env.rank == 0:
+            assert g2.shape == (10, 4) and st2.tolist() == [1] * 5 + [2] * 5
+        assert env.describe()["ranks"] == 2
         # bench.py's config-3 sharding: every rank synthesises ITS shard of the seeded global batch; rank 0 can
         # regenerate any element of any shard (that is how it checks samples of every shard against pow())
         import numpy as np
@@ -67,6 +72,11 @@ def test_gloo_world2_harness(tmp_path):
         from halo2_rsa_amd.dist import agree_all
         assert agree_all("agree_a", True, env.rank, env.world) is True
         assert agree_all("agree_b", env.rank != 1, env.rank, env.world) is False
+        # the same key a second time in one job (a second communicator, a restarted worker group): a fresh namespace, not the
+        # first use's stale id / counters
+        got2 = exchange_bytes("test_id", bytes(reversed(range(128))) if env.rank == 0 else bytes(128), env.rank, env.world)
+        assert got2 == bytes(reversed(range(128)))
+        assert agree_all("agree_b", True, env.rank, env.world) is True
         print("AGREE_OK %%d" %% env.rank)
     ''' % ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
