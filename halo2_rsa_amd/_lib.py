@@ -44,6 +44,18 @@ class H2RPowLayout(ctypes.Structure):
                 ("stream_bytes", ctypes.c_uint64), ("exp_limb_bits", ctypes.c_uint32), ("e_num_limbs", ctypes.c_uint32)]
 
 
+class H2RCopy(ctypes.Structure):
+    _fields_ = [("row", ctypes.c_uint32), ("col", ctypes.c_uint32), ("src_row", ctypes.c_uint32), ("src_col", ctypes.c_uint32)]
+
+
+class H2RAdviceLayout(ctypes.Structure):
+    _fields_ = [("version", ctypes.c_uint32), ("column_of", (ctypes.c_uint8 * 5) * 256)]
+
+
+H2R_COPY_SRC_A, H2R_COPY_SRC_B, H2R_COPY_SRC_N = 0xFFFFFF01, 0xFFFFFF02, 0xFFFFFF03
+H2R_SRC_X, H2R_SRC_ONE = -1, -2
+
+
 class H2RVerifyLayout(ctypes.Structure):
     _fields_ = [("pow", H2RPowLayout), ("off_in_field", ctypes.c_uint64), ("in_field_stream_bytes", ctypes.c_uint64),
                 ("off_em", ctypes.c_uint64), ("em_stream_bytes", ctypes.c_uint64), ("elem_stride", ctypes.c_uint64),
@@ -90,6 +102,8 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_r
            "h2r_trace_flatten", "h2r_pow_trace_flatten", "h2r_stream_bytes", "h2r_pow_stream_bytes", "h2r_trace_flatten_ex",
            "h2r_pow_trace_flatten_ex", "h2r_trace_emit_stream", "h2r_pow_trace_emit_stream", "h2r_mul_mod_trace_check", "h2r_pow_trace_check",
            "h2r_modpow_public_key_advice_rows", "h2r_modpow_public_key_emit_advice",
+           "h2r_advice_copy_map", "h2r_pow_operand_sources", "h2r_advice_layout_default", "h2r_advice_layout_custom", "h2r_advice_fixed_row_ex",
+           "h2r_advice_apply_layout",
            "h2r_advice_rows", "h2r_mul_mod_emit_advice", "h2r_pow_trace_emit_advice", "h2r_pow_advice_rows", "h2r_pow_row_kinds", "h2r_advice_row_kinds",
            "h2r_advice_fixed_row", "h2r_fresh_op_advice_rows", "h2r_fresh_op_row_kinds", "h2r_fresh_op_emit_advice",
            "h2r_verify_advice_rows", "h2r_verify_row_kinds", "h2r_verify_emit_advice", "h2r_verify_layout_var", "h2r_verify_pkcs1v15_var_batch", "h2r_pipeline_verify_pkcs1v15_var",
@@ -241,6 +255,13 @@ def lib():
     L.h2r_hashed_msg_emit_advice.argtypes = [vp, vp, u64, u64, vp, vp, u64, vp]
     L.h2r_mul_mod_emit_advice.argtypes = [vp, vp, vp, vp, u32, vp, u64, vp, vp, u64, vp]
     L.h2r_pow_row_kinds.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp]
+    L.h2r_advice_copy_map.argtypes = [vp, vp, u32]
+    L.h2r_advice_copy_map.restype = u32
+    L.h2r_pow_operand_sources.argtypes = [vp, ctypes.POINTER(H2RPowLayout), ctypes.c_char_p, ctypes.c_size_t, vp, vp]
+    L.h2r_advice_layout_default.argtypes = [vp]
+    L.h2r_advice_layout_custom.argtypes = [vp, vp, vp, u32, vp]
+    L.h2r_advice_fixed_row_ex.argtypes = [vp, vp, vp, u32, vp]
+    L.h2r_advice_apply_layout.argtypes = [vp, vp, vp, u64, vp, u64, u64, vp, vp]
     L.h2r_modpow_public_key_advice_rows.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp]
     L.h2r_modpow_public_key_advice_rows.restype = u64
     L.h2r_modpow_public_key_emit_advice.argtypes = [vp, ctypes.POINTER(H2RPowLayout), vp, vp, u32, vp, vp, vp, u64, vp, vp, u64, vp]

@@ -19,6 +19,7 @@
 #include "h2r_kernels.hpp"
 #include "h2r_cells.hpp"
 #include "h2r_varrows.hpp"
+#include "h2r_copymap.hpp"
 #include "h2r_layout.hpp"
 #include "h2r_lookup.hpp"
 #include "h2r_muled.hpp"
@@ -3057,6 +3058,88 @@ int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, 
     ra.a = powed; ra.b = hashed; ra.b_stride = 4; ra.first_off = vl->off_em;
     ra.out = out + (sec[0] + sec[1] + sec[2]) * ADVICE_ROW_BYTES;                                      // :138-198
     return launch_row_prog(ctx, em, ra, st);
+} H2R_CATCH_STATUS
+
+// ---- copy constraints of the image, and its layout as data (h2r_copymap.hpp) -------------------------------------------------
+uint32_t h2r_advice_copy_map(const h2r_ctx *ctx, h2r_copy *out, uint32_t cap) try {
+    if (!ctx) return 0;
+    std::vector<h2r_copy> v;
+    copy_map_record(ctx->L, (ctx->layout.carry_nsub + 3) / 4, v);
+    for (u32 i = 0; out && i < cap && i < v.size(); ++i) out[i] = v[i];
+    return (uint32_t)v.size();
+} H2R_CATCH_ZERO
+
+int32_t h2r_pow_operand_sources(const h2r_ctx *ctx, const h2r_pow_layout *pl, const uint8_t *e_le_bytes, size_t e_len, int32_t *a_src, int32_t *b_src) try {
+    if (!ctx || !pl || !a_src || !b_src) return H2R_E_NULL;
+    if (pl->off_e_bits != UINT64_MAX) return H2R_E_UNSUPPORTED;   // (a Var element: acc comes from the bit's select rows, squared from record 2 bit - 1)
+    ExpBits eb; u32 T;
+    const int32_t rc = exp_to_bits(e_le_bytes, e_len, &eb, &T);
+    if (rc) return rc;
+    if (T != pl->num_mul_mods) return H2R_E_SHAPE;
+    int32_t cur = H2R_SRC_X, acc = H2R_SRC_ONE;
+    u32 t = 0;
+    for (u32 bi = 0; bi < eb.nbits; ++bi) {   // square first, then the multiply with the value BEFORE the squaring (chip.rs:731-740)
+        const int32_t sq = (int32_t)t;
+        a_src[t] = b_src[t] = cur; ++t;
+        if (exp_bit(eb.bytes, bi)) { a_src[t] = acc; b_src[t] = cur; acc = (int32_t)t; ++t; }
+        cur = sq;
+    }
+    return H2R_OK;
+} H2R_CATCH_STATUS
+
+int32_t h2r_advice_layout_default(h2r_advice_layout *out) try {
+    if (!out) return H2R_E_NULL;
+    out->version = H2R_ADVICE_LAYOUT_VERSION;
+    for (int k = 0; k < 256; ++k) for (int c = 0; c < 5; ++c) out->column_of[k][c] = (uint8_t)c;
+    return H2R_OK;
+} H2R_CATCH_STATUS
+
+int32_t h2r_advice_layout_custom(const h2r_ctx *ctx, const uint8_t *kinds, const uint8_t (*column_of)[5], uint32_t n_kinds, h2r_advice_layout *out) try {
+    if (!ctx || !out || (n_kinds && (!kinds || !column_of))) return H2R_E_NULL;
+    h2r_advice_layout_default(out);
+    for (u32 i = 0; i < n_kinds; ++i) {
+        h2r_fixed_row f;
+        const int32_t rc = h2r_advice_fixed_row(ctx, nullptr, kinds[i], &f);
+        if (rc) return rc;
+        const u32 k = kinds[i];
+        const bool decompose = (k >= ROWK_RANGE_LIMB && k < ROWK_RANGE_CARRY + 8) || (k >= ROWK_RANGE_U32 && k < ROWK_RANGE_U32 + 8) ||
+                               (k >= ROWK_BITS_COMPOSE && k < ROWK_BITS_COMPOSE_LAST + 64);
+        u8 col[5];
+        for (int c = 0; c < 5; ++c) col[c] = column_of[i][c];
+        if (!layout_perm_valid(col, f, decompose)) return H2R_E_SHAPE;
+        for (int c = 0; c < 5; ++c) out->column_of[k][c] = col[c];
+    }
+    return H2R_OK;
+} H2R_CATCH_STATUS
+
+int32_t h2r_advice_fixed_row_ex(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const h2r_advice_layout *layout, uint32_t kind, h2r_fixed_row *out) try {
+    if (!layout || kind > 255) return layout ? H2R_E_SHAPE : H2R_E_NULL;
+    if (layout->version != H2R_ADVICE_LAYOUT_VERSION) return H2R_E_UNSUPPORTED;
+    h2r_fixed_row f;
+    const int32_t rc = h2r_advice_fixed_row(ctx, cfg, kind, &f);
+    if (rc) return rc;
+    u8 col[5];
+    for (int c = 0; c < 5; ++c) col[c] = layout->column_of[kind][c];
+    layout_permute_fixed(col, f, out);
+    return H2R_OK;
+} H2R_CATCH_STATUS
+
+int32_t h2r_advice_apply_layout(const h2r_ctx *ctx, const h2r_advice_layout *layout, const uint8_t *kinds_dev, uint64_t rows, void *image,
+                                uint64_t out_stride, uint64_t batch, const uint8_t *status, h2r_stream_t stream) try {
+    if (!ctx || !layout || !kinds_dev || !image) return H2R_E_NULL;
+    if (ctx->params.device < 0 || layout->version != H2R_ADVICE_LAYOUT_VERSION) return H2R_E_UNSUPPORTED;
+    if (out_stride < rows * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
+    if (!rows || !batch) return H2R_OK;
+    H2R_ON_DEVICE(ctx->params.device);
+    LayoutArgs la;
+    std::memset(&la, 0, sizeof la);
+    la.kinds = kinds_dev; la.rows = rows; la.image = static_cast<u8 *>(image); la.out_stride = out_stride; la.batch = batch; la.status = status;
+    std::memcpy(la.perm, layout->column_of, sizeof la.perm);
+    const u64 blocks = (rows * batch + 255) / 256;
+    if (blocks >= (1ull << 31)) return H2R_E_UNSUPPORTED;
+    hipLaunchKernelGGL(advice_layout_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), la);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
 } H2R_CATCH_STATUS
 
 // ---- one RSAChip::modpow_public_key element as advice rows: [assert_in_field(x, n)] [pow_mod_fixed_exp] (src/chip.rs:106-111) ----

@@ -762,6 +762,38 @@ int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, 
 int32_t h2r_fresh_op_emit_advice(const h2r_ctx *ctx, uint32_t op, uint32_t flags, const void *a, const void *b, const void *n,
                                  const void *trace, uint64_t first_off, uint64_t elem_stride, uint64_t batch,
                                  const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream);
+/* ---- what a layouter backend needs besides the cells: the copy constraints, and the layout as data --------------------------
+ * COPY MAP.  maingate gives every op a fresh row and ties the row's INPUT cells to the cells where their values were first assigned
+ * with equality constraints (`AssignedValue::from(a.limb(j))` into main_gate.mul_add big_integer/chip.rs:406-408, `carry` across the
+ * steps of is_equal_muled :861, ...).  The image repeats the values; h2r_advice_copy_map lists, for ONE mul_mod record (rows of
+ * h2r_advice_rows), every input cell (row, col) with its origin: (src_row, src_col) of the same record, or -- src_row =
+ * H2R_COPY_SRC_A / _B / _N -- limb src_col of the mul_mod's operand a / b / n, assigned outside the record.  Returns the number of
+ * pairs (out may be NULL / cap 0 to ask).  h2r_pow_operand_sources says where those operands come from in a fixed-exponent pow
+ * element (pow_mod_fixed_exp, :729-740), per record t: a_src[t], b_src[t] = t' >= 0: the r limbs of record t' (limb j = column e of
+ * its row 2 (num_limbs + j)); H2R_SRC_X: the assigned input x; H2R_SRC_ONE: acc = assign_constant(1) (limb 0 = CONST1 row, the others
+ * the CONST0 row in front of the records).  n always comes from the assigned modulus.
+ * LAYOUT.  The placement of an op's cells in the five columns is third-party (restated, unpinned).  h2r_advice_layout
+ * holds per row kind the PHYSICAL column of each of the restated shape's five cells (default: identity).  A maintainer who re-pins a
+ * row shape against upstream maingate edits data: h2r_advice_layout_custom validates a table (a permutation per kind; a * b / c * d
+ * products stay on one of the gate's column pairs; decompose rows keep their running value in e and their first term in a),
+ * h2r_advice_apply_layout permutes an emitted image in place (kinds_dev: the rows' kinds on the device, e.g. h2r_pow_row_kinds
+ * uploaded once), h2r_advice_fixed_row_ex gives the selectors of a kind under the layout. */
+typedef struct h2r_copy { uint32_t row, col, src_row, src_col; } h2r_copy;
+#define H2R_COPY_SRC_A 0xFFFFFF01u
+#define H2R_COPY_SRC_B 0xFFFFFF02u
+#define H2R_COPY_SRC_N 0xFFFFFF03u
+#define H2R_SRC_X (-1)
+#define H2R_SRC_ONE (-2)
+uint32_t h2r_advice_copy_map(const h2r_ctx *ctx, h2r_copy *out, uint32_t cap);
+int32_t h2r_pow_operand_sources(const h2r_ctx *ctx, const h2r_pow_layout *pl, const uint8_t *e_le_bytes, size_t e_len, int32_t *a_src, int32_t *b_src);
+#define H2R_ADVICE_LAYOUT_VERSION 1u
+typedef struct h2r_advice_layout { uint32_t version; uint8_t column_of[256][5]; } h2r_advice_layout;
+int32_t h2r_advice_layout_default(h2r_advice_layout *out);
+int32_t h2r_advice_layout_custom(const h2r_ctx *ctx, const uint8_t *kinds, const uint8_t (*column_of)[5], uint32_t n_kinds, h2r_advice_layout *out);
+int32_t h2r_advice_fixed_row_ex(const h2r_ctx *ctx, const struct h2r_lookup_config *cfg, const h2r_advice_layout *layout, uint32_t kind, h2r_fixed_row *out);
+int32_t h2r_advice_apply_layout(const h2r_ctx *ctx, const h2r_advice_layout *layout, const uint8_t *kinds_dev, uint64_t rows, void *image,
+                                uint64_t out_stride, uint64_t batch, const uint8_t *status, h2r_stream_t stream);
+
 /* One RSAChip::modpow_public_key element (src/chip.rs:99-114) as advice rows, in the reference's op order: [assert_in_field(x, n) :106:
  * the rows of h2r_fresh_op_emit_advice(H2R_OP_IS_IN_FIELD, H2R_ADVICE_ASSERT_ONE)] [pow_mod_fixed_exp / pow_mod :108-111: the rows of
  * h2r_pow_trace_emit_advice].  x, n, flags, in_field_trace, trace, workspace: what h2r_modpow_public_key_batch was given (a caller
