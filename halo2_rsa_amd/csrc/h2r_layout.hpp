@@ -177,7 +177,10 @@ inline void layout_compute(u32 w, u32 L, h2r_layout *o) {
     o->record_stride = off;
     // HBM channel interleaving: the record kernel is sensitive to the record stride (one 256-byte unit less or more
     // than this choice costs 2..10 %, profiles/r01_stride_sweep.txt; re-swept after every layout change).
-    if (w == 64 && L == 32) o->record_stride += 512;
+#ifndef H2R_RECORD_PAD_UNITS
+#define H2R_RECORD_PAD_UNITS 2   // (developer variants: tools/record_pad_ab.sh)
+#endif
+    if (w == 64 && L == 32) o->record_stride += 256ull * H2R_RECORD_PAD_UNITS;
     const u64 per_col = 5ull * WB + 2ull * CB + 4ull * LB + 4;
     o->stream_bytes = 2ull * L * (LB + o->limb_nsub) + 2ull * L * L * WB + (u64)L * WB + (u64)C * per_col +
                       (u64)(C - 1) * (CB + o->carry_nsub);
