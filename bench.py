@@ -471,6 +471,9 @@ def main():
                          "elements (assert_in_field rows + pow rows written directly from the operands by cells_kernel), no record planes")
     ap.add_argument("--shared-modulus", action="store_true",
                     help="one key, many signatures (H2R_F_SHARED_MODULUS): every element uses element 0's modulus")
+    ap.add_argument("--per-launch-timing", action="store_true",
+                    help="stamp every dispatch of the timed region with its own events (the round-3 way: costs 6-7 us per 1,024-signature step) "
+                         "instead of two events over the region")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="developer: do not arm the C ABI's per-kernel event timing (roofline fields become null)")
     ap.add_argument("--user-stream", action="store_true",
@@ -677,29 +680,53 @@ def main():
                 torch.cuda.synchronize()
                 if time.perf_counter() - t_ramp > 0.3:
                     break
+    # The W warm-up steps run with the library's per-launch timing armed: that is where the bench learns how a call is issued (one step
+    # launch per call?) and gets per-launch durations -- NOT in the timed region, where stamping every dispatch costs 6-7 us per
+    # 1,024-signature step (same-box A/B, profiles/r04_kernel_timing_tax.txt: 0.2001 -> 0.1932 ms per step).
+    n_prof = (3 + 32 + 2 * (chunk // 256)) * max(steps, warmup) * chunks + 8   # chain + record + in-field kernel per call; (+32: a long exponent walked as up to 16 segments)
+    _lib.profile_enable(0 if args.no_kernel_timing else n_prof)
     for _ in range(warmup):
         step()
     if pipe is not None:
         join_all()
     torch.cuda.synchronize()
-    # chain + record + in-field kernel per call; a pipelined call larger than the library's sub-batch is several pairs
-    _lib.profile_enable(0 if args.no_kernel_timing else (3 + 32 + 2 * (chunk // 256)) * steps * chunks + 8)   # (+32: a long exponent walked as up to 16 segments)
+    w_trace, w_chain, w_step = _lib.profile_read(_lib.KERNEL_TRACE), _lib.profile_read(_lib.KERNEL_CHAIN), _lib.profile_read(_lib.KERNEL_STEP)
+    _lib.profile_enable(0)
+    # One step launch per call (the RSA-2048 / RSA-1024 pipeline): the timed region carries TWO events on the launch stream instead -- behind
+    # the first call (a chain kernel: the pipeline starts empty) and behind the last step launch -- and the dominant kernel's average
+    # launch time is their distance / (calls - 1): the period of back-to-back launches, an upper bound of the kernel's own duration.
+    span_ok = (not args.no_kernel_timing and not args.per_launch_timing and pipe is not None and producers == 1 and steps * chunks >= 2
+               and warmup * chunks > 0 and len(w_step) == warmup * chunks)
+    if not span_ok:
+        _lib.profile_enable(0 if args.no_kernel_timing else n_prof)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     env.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        last = step()
+    for s_i in range(steps):
+        for c_i in range(chunks):
+            last = call(c_i)
+            if span_ok and s_i == 0 and c_i == 0:
+                ev0.record()
+    if span_ok:
+        ev1.record()
     if pipe is not None:
         join_all()   # every step's trace is complete before the clock stops
     torch.cuda.synchronize()
     env.barrier()
     dt = env.max_over_ranks(time.perf_counter() - t0)
-    trace_ms = _lib.profile_read(_lib.KERNEL_TRACE)
-    chain_ms = _lib.profile_read(_lib.KERNEL_CHAIN)
-    # RSA-2048 pipelined: the library issues a step as ONE launch (records of call k + chains of call k+1); the record kernel
-    # alone then appears once, at the join
-    step_ms = _lib.profile_read(_lib.KERNEL_STEP)
-    _lib.profile_enable(0)
+    if span_ok:
+        period_ms = ev0.elapsed_time(ev1) / (steps * chunks - 1)
+        step_ms = [period_ms] * (steps * chunks - 1)
+        trace_ms = [sum(w_trace) / len(w_trace)] if w_trace else []      # (the record kernel alone appears once, at the join: the warm-up's)
+        chain_ms = w_chain
+    else:
+        trace_ms = _lib.profile_read(_lib.KERNEL_TRACE)
+        chain_ms = _lib.profile_read(_lib.KERNEL_CHAIN)
+        # RSA-2048 pipelined: the library issues a step as ONE launch (records of call k + chains of call k+1); the record kernel
+        # alone then appears once, at the join
+        step_ms = _lib.profile_read(_lib.KERNEL_STEP)
+        _lib.profile_enable(0)
 
     # post-run: correctness of what was timed + the result gather (rank 0 receives every shard's x^e mod n)
     assert int(status.max().item()) == 0 or (w, bits) != (64, 2048), "unexpected per-element status"
@@ -813,6 +840,11 @@ def main():
                                            "committed; PMC counters cannot be read from inside the bench process)",
                          "kernel": dom_name,
                          "launches_timed": len(dom_ms), "signatures_per_launch": round(per_launch_batch, 1),
+                         "timing": ("two HIP events on the launch stream over the timed region (behind the first call and behind the last step launch): "
+                                    "avg_launch_ms = the launches' period, an upper bound of the kernel's duration; per-launch dispatch stamps "
+                                    "(which cost 6-7 us per step) only in the warm-up steps: avg_launch_ms_stamped_warmup") if span_ok else
+                                   "per-launch HIP events stamped by the dispatch packets, in the timed region",
+                         "avg_launch_ms_stamped_warmup": round(sum(w_step) / len(w_step), 4) if w_step else None,
                          "launches_per_call": round(n_launches / (steps * chunks), 2),   # > 1: sub-batches of a large call, or segments of a long exponent
                          "avg_launch_ms": round(1e3 * avg_trace_s, 4) if dom_ms else None,
                          "algorithmic_bytes_per_launch": trace_bytes_per_launch,
