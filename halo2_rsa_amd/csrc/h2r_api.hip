@@ -187,6 +187,11 @@ struct h2r_ctx {
     // (created on first use; calls on one ctx from several threads take turns queueing)
     mutable std::mutex pipe_mu;
     mutable h2r_pipeline *pipe = nullptr;
+    // a side stream of the ctx for the short row-program kernels of a whole-element image: they write other rows than the pow rows'
+    // kernel and are latency-bound (is_zero's inverse witnesses), so they run NEXT to it instead of in front of it (created on first use)
+    mutable std::mutex side_mu;
+    mutable hipStream_t side_stream = nullptr;
+    mutable hipEvent_t side_fork = nullptr, side_join = nullptr;
     // row programs of the Fresh-op advice images (h2r_rowprog.hpp), built on first use; key = op | assert_one << 8
     struct RowProg { std::vector<RpRow> host; RpRow *dev = nullptr; std::vector<u32> inv_rows; u32 *inv_dev = nullptr; };
     mutable std::mutex prog_mu;
@@ -652,6 +657,9 @@ void h2r_ctx_destroy(h2r_ctx *ctx) try {
         if (ctx->advice_desc_dev) (void)hipFree(ctx->advice_desc_dev);
         if (ctx->cells_ktab_dev) (void)hipFree(ctx->cells_ktab_dev);
         for (auto &kv : ctx->progs) { if (kv.second.dev) (void)hipFree(kv.second.dev); if (kv.second.inv_dev) (void)hipFree(kv.second.inv_dev); }
+        if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+        if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
+        if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
         if (ctx->pipe) h2r_pipeline_destroy(ctx->pipe);
     }
     delete ctx;
@@ -2996,6 +3004,28 @@ int32_t h2r_fresh_op_emit_advice(const h2r_ctx *ctx, uint32_t op, uint32_t flags
 
 // ---- the whole verify_pkcs1v15_signature element as advice rows ------------------------------------------------------------
 namespace {
+// Fork / join around the short kernels of a whole-element image.  Holds the ctx's side-stream mutex for the duration of the enqueue
+// (the two events are re-recorded by every call: their meaning is fixed at enqueue time, so enqueues must not interleave).
+struct SideFork {
+    const h2r_ctx *ctx; hipStream_t main; std::unique_lock<std::mutex> lk; bool ok = false;
+    SideFork(const h2r_ctx *c, hipStream_t st) : ctx(c), main(st), lk(c->side_mu) {
+        if (!ctx->side_stream) {
+            if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+        }
+        ok = hipEventRecord(ctx->side_fork, main) == hipSuccess && hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+    }
+    hipStream_t side() const { return ok ? ctx->side_stream : main; }   // (no side stream: everything in order on the caller's)
+    int32_t join() {
+        if (!ok) return H2R_OK;
+        HIP_TRY(hipEventRecord(ctx->side_join, ctx->side_stream));
+        HIP_TRY(hipStreamWaitEvent(main, ctx->side_join, 0));
+        return H2R_OK;
+    }
+};
+
 int32_t verify_progs(const h2r_ctx *ctx, const h2r_ctx::RowProg **pre, const h2r_ctx::RowProg **inf, const h2r_ctx::RowProg **em) {
     if (ctx->layout.limb_width != 64 || ctx->L < 8) return H2R_E_UNSUPPORTED;   // RSAChip::LIMB_WIDTH
     int32_t rc = row_prog(ctx, kProgVerifyPre, [](RowProgBuilder &rb) { rb.build_verify_preamble(); return true; }, pre);
@@ -3043,21 +3073,26 @@ int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, 
     H2R_ON_DEVICE(ctx->params.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
     u8 *out = static_cast<u8 *>(advice_out);
+    // the three row programs (seed row, assert_in_field, encoded-message check: 2 % of the bytes, latency-bound inverse launches among them)
+    // run on the ctx's side stream NEXT to the pow rows' kernel -- other rows of the same image -- and are joined before returning
+    SideFork fork(ctx, st);
+    hipStream_t ss = fork.side();
     RowProgArgs ra;
     std::memset(&ra, 0, sizeof ra);
     ra.a = sig; ra.b = n; ra.n = n; ra.a_stride = ctx->L; ra.b_stride = ra.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
     ra.trace = static_cast<const u8 *>(trace); ra.elem_stride = vl->elem_stride; ra.first_off = vl->off_in_field;
     ra.status = status; ra.batch = batch; ra.out_stride = out_stride;
     ra.out = out;                                   // is_eq = assign_constant(1), src/chip.rs:137
-    if ((rc = launch_row_prog(ctx, pre, ra, st))) return rc;
+    if ((rc = launch_row_prog(ctx, pre, ra, ss))) return rc;
     ra.out = out + sec[0] * ADVICE_ROW_BYTES;       // assert_in_field(sig, n), :106
-    if ((rc = launch_row_prog(ctx, inf, ra, st))) return rc;
-    rc = h2r_pow_trace_emit_advice(ctx, &vl->pow, n, flags, trace, vl->elem_stride, workspace, batch, status,
-                                   out + (sec[0] + sec[1]) * ADVICE_ROW_BYTES, out_stride, stream);   // pow_mod_fixed_exp, :111
-    if (rc) return rc;
+    if ((rc = launch_row_prog(ctx, inf, ra, ss))) return rc;
     ra.a = powed; ra.b = hashed; ra.b_stride = 4; ra.first_off = vl->off_em;
     ra.out = out + (sec[0] + sec[1] + sec[2]) * ADVICE_ROW_BYTES;                                      // :138-198
-    return launch_row_prog(ctx, em, ra, st);
+    if ((rc = launch_row_prog(ctx, em, ra, ss))) return rc;
+    rc = h2r_pow_trace_emit_advice(ctx, &vl->pow, n, flags, trace, vl->elem_stride, workspace, batch, status,
+                                   out + (sec[0] + sec[1]) * ADVICE_ROW_BYTES, out_stride, stream);   // pow_mod_fixed_exp / pow_mod, :108-111
+    if (rc) return rc;
+    return fork.join();
 } H2R_CATCH_STATUS
 
 // ---- copy constraints of the image, and its layout as data (h2r_copymap.hpp) -------------------------------------------------
@@ -3159,11 +3194,15 @@ int32_t h2r_modpow_public_key_emit_advice(const h2r_ctx *ctx, const h2r_pow_layo
     const u64 rows = h2r_modpow_public_key_advice_rows(ctx, pl, sec);
     if (!rows) return H2R_E_UNSUPPORTED;
     if (out_stride < rows * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
+    H2R_ON_DEVICE(ctx->params.device);
+    SideFork fork(ctx, static_cast<hipStream_t>(stream));   // the in-field rows next to the pow rows (see h2r_verify_emit_advice)
     int32_t rc = h2r_fresh_op_emit_advice(ctx, FRESH_IS_IN_FIELD, (flags & H2R_F_SHARED_MODULUS) | H2R_ADVICE_ASSERT_ONE, x, n, nullptr, in_field_trace, 0, 0,
-                                          batch, status, advice_out, out_stride, stream);
+                                          batch, status, advice_out, out_stride, static_cast<h2r_stream_t>(fork.side()));
     if (rc) return rc;
-    return h2r_pow_trace_emit_advice(ctx, pl, n, flags | (trace ? 0u : H2R_ADVICE_DIRECT), trace, 0, workspace, batch, status,
-                                     static_cast<u8 *>(advice_out) + sec[0] * ADVICE_ROW_BYTES, out_stride, stream);
+    rc = h2r_pow_trace_emit_advice(ctx, pl, n, flags | (trace ? 0u : H2R_ADVICE_DIRECT), trace, 0, workspace, batch, status,
+                                   static_cast<u8 *>(advice_out) + sec[0] * ADVICE_ROW_BYTES, out_stride, stream);
+    if (rc) return rc;
+    return fork.join();
 } H2R_CATCH_STATUS
 
 // ---- the hashed-message limbs of RSASignatureVerifier as advice rows (src/lib.rs:225-239) ---------------------------------

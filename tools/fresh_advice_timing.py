@@ -53,3 +53,51 @@ for _ in range(3):
 total, sec = vres.advice_sections()
 print("verify element image rsa2048 batch %d: %.2f ms wall (min of 3; 4 launches + torch.empty), sections %s rows, %.2f GB, %.2f TB/s"
       % (Bv, min(t), sec, nbytes / 1e9, nbytes / min(t) / 1e9))
+
+# the same element with the pow rows written directly from the operands (H2R_ADVICE_DIRECT: cells_kernel), into a reused buffer
+import ctypes
+outv = torch.empty((Bv, nbytes // Bv), dtype=torch.uint8, device="cuda")
+sig_d, n_d, hashed_d = vres.inputs
+for direct in (0, _lib.H2R_ADVICE_DIRECT):
+    def vcall():
+        _lib.check(_lib.lib().h2r_verify_emit_advice(chip._ctx, ctypes.byref(vres.layout), sig_d.data_ptr(), n_d.data_ptr(), hashed_d.data_ptr(),
+                                                     vres.powed.data_ptr(), chip._flags(n_d, Bv) | direct, vres.trace.data_ptr(), vres.workspace.data_ptr(),
+                                                     Bv, vres.status.data_ptr(), outv.data_ptr(), outv.shape[1], chip._stream()), "verify_emit")
+    vcall(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        vcall()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print("verify element image, %s, reused buffer: %.3f ms per call = %.2f TB/s of image (%.2f of the HBM peak)" %
+          ("pow rows DIRECT (cells_kernel)" if direct else "pow rows from the records (advice_kernel)", ms, nbytes / ms / 1e9, nbytes / ms / 8e9))
+
+# the same DIRECT call over several candidate image buffers (the placement classes of profiles/r04_cells_placement.txt apply to the image
+# like to any buffer: a consumer that reuses its image buffer keeps the best of a few), and the share of the pow rows' kernel in the call
+cands = [outv] + [torch.empty_like(outv) for _ in range(3)]
+def vcall_into(buf):
+    _lib.check(_lib.lib().h2r_verify_emit_advice(chip._ctx, ctypes.byref(vres.layout), sig_d.data_ptr(), n_d.data_ptr(), hashed_d.data_ptr(),
+                                                 vres.powed.data_ptr(), chip._flags(n_d, Bv) | _lib.H2R_ADVICE_DIRECT, vres.trace.data_ptr(), vres.workspace.data_ptr(),
+                                                 Bv, vres.status.data_ptr(), buf.data_ptr(), buf.shape[1], chip._stream()), "verify_emit")
+best = None
+for i, buf in enumerate(cands):
+    vcall_into(buf); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        vcall_into(buf)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print("  candidate buffer %d: %.3f ms per call = %.2f TB/s of image (%.3f of the HBM peak)" % (i, ms, nbytes / ms / 1e9, nbytes / ms / 8e9))
+    if best is None or ms < best[0]:
+        best = (ms, buf)
+_lib.profile_enable(256)
+for _ in range(5):
+    vcall_into(best[1])
+torch.cuda.synchronize()
+cells = _lib.profile_read(_lib.KERNEL_CELLS)
+emit = _lib.profile_read(_lib.KERNEL_EMIT)
+_lib.profile_enable(0)
+print("  best buffer, per-kernel stamps: cells_kernel %.3f ms avg of %d (%.2f TB/s on its rows); %d row-program launches, %.3f ms summed per call (they run on the ctx's side stream)"
+      % (sum(cells) / len(cells), len(cells), Bv * sec[2] * 160 / (sum(cells) / len(cells)) / 1e9, len(emit), sum(emit) / 5))
