@@ -752,7 +752,12 @@ int32_t h2r_fresh_op_row_kinds(const h2r_ctx *ctx, uint32_t op, uint32_t flags, 
  * sig, n, hashed, flags, trace, workspace: what h2r_verify_pkcs1v15_batch / h2r_pipeline_verify_pkcs1v15 were given (a caller
  * workspace is required: it holds every mul_mod's operands); powed: their powed_out.  Elements with a nonzero status are skipped.
  * Both exponent arms (src/chip.rs:108-111): a Var element (h2r_verify_layout_var) has the pow_mod rows of h2r_pow_trace_emit_advice
- * (to_bits, select) in its third section. */
+ * (to_bits, select) in its third section.
+ * Stream semantics: the call is ordered on `stream` like every export (its inputs are read, and the image is complete, in `stream`
+ * order).  Inside, the three short row programs run on a side stream the ctx owns NEXT to the pow rows' kernel -- forked from and
+ * joined back into `stream` with events, so nothing is visible to the caller but the shorter call (legal inside a stream capture;
+ * concurrent callers on one ctx are serialised for the enqueue by a mutex of the ctx).  h2r_modpow_public_key_emit_advice does the
+ * same with its assert_in_field rows. */
 uint64_t h2r_verify_advice_rows(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint64_t section_rows[4]);
 int32_t h2r_verify_row_kinds(const h2r_ctx *ctx, const h2r_verify_layout *vl, uint8_t *kinds_out);
 int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, const void *sig, const void *n,

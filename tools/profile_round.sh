@@ -60,4 +60,10 @@ python tools/lookup_timing.py > $O/lookup_timing.txt 2>&1
 timeout 300 python bench.py --steps 40 --warmup 4 --verify --messages 128 --no-cpu-baseline --pmc-traffic off > $O/bench_verify_from_messages.json 2>/dev/null
 python tools/sha256_timing.py > $O/sha256_timing.txt 2>&1
 python tools/fresh_advice_timing.py > $O/fresh_advice_timing.txt 2>&1
+# [round 4] the advice image as the product: kernel stats under rocprofv3, the bench line, the cells kernel alone by shape
+(cd /tmp; timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_advice -o r -- python $R/bench.py --advice --steps 10 --warmup 2 --no-cpu-baseline --pmc-traffic off > $O/kt_advice.log 2>&1)
+timeout 600 python bench.py --advice --steps 20 --warmup 5 > $O/bench_advice.json 2> $O/bench_advice.err
+if [ -x tools/_bin/cells_bench ]; then
+  { LD_LIBRARY_PATH=$R/halo2_rsa_amd/lib timeout 300 tools/_bin/cells_bench 64 2048 1024; LD_LIBRARY_PATH=$R/halo2_rsa_amd/lib timeout 300 tools/_bin/cells_bench 32 4096 431; } > $O/cells_kernel.txt 2>&1
+fi
 tail -1 $O/bench_pipeline.json | cut -c1-700; tail -1 $O/bench_serial.json | cut -c1-200; tail -1 $O/bench_pipeline_d3s2.json | cut -c1-200; tail -1 $O/bench_torchrun1_config3_shard.json | cut -c1-300; tail -3 $O/bench_torchrun1.err; cat $O/other_configs.txt; cat $O/emit_timing.txt; cat $O/pmc_traffic.json | head -40
