@@ -200,6 +200,74 @@ def test_verify_element_direct(H, golden):
     assert torch.equal(res.emit_advice(direct=True), res.emit_advice())
 
 
+def test_verify_element_from_two_threads_and_streams(H, golden):
+    """h2r_verify_emit_advice forks its short row programs onto a side stream of the ctx and joins them: two host threads calling it on
+    ONE ctx at the same time, each on a stream and into an image of its own, both get the image a lone call writes (every round)."""
+    import threading
+    rsa = H.RSAChip(2048, 5)
+    kats = golden["rsa_kats"]
+    rng = random.Random(0x68327273 + 44)
+    B = 48
+    N = [rand_modulus(rng, 2048) for _ in range(B)]
+    pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(N, 32, 64), H.Fix(65537)))
+    sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints([rng.randrange(n) for n in N], 32, 64)))
+    res = rsa.verify_pkcs1v15_signature(pk, [rng.getrandbits(256) for _ in range(B)], sg)
+    want = res.emit_advice(direct=True)
+    assert torch.equal(want, res.emit_advice())
+    torch.cuda.synchronize()
+    got, errs = {}, []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            for rnd in range(6):
+                with torch.cuda.stream(st):
+                    img = res.emit_advice(direct=(i + rnd) % 2 == 0)
+                st.synchronize()
+                if not torch.equal(img, want):
+                    errs.append((i, rnd))
+                got[i] = rnd
+        except Exception as ex:   # noqa: BLE001 -- reported below
+            errs.append((i, repr(ex)))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs and got == {0: 5, 1: 5}, errs
+
+
+def test_verify_element_inside_a_stream_capture(H, golden):
+    """The fork onto the ctx's side stream and the join are event dependencies, so the export can be captured into a HIP graph like any
+    stream-ordered call: the replayed graph writes the image a plain call writes."""
+    import ctypes
+    from halo2_rsa_amd import _lib
+    rsa = H.RSAChip(2048, 5)
+    rng = random.Random(0x68327273 + 45)
+    B = 16
+    N = [rand_modulus(rng, 2048) for _ in range(B)]
+    pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(N, 32, 64), H.Fix(65537)))
+    sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints([rng.randrange(n) for n in N], 32, 64)))
+    res = rsa.verify_pkcs1v15_signature(pk, [rng.getrandbits(256) for _ in range(B)], sg)
+    want = res.emit_advice(direct=True)          # (also: first use of every kernel and of the side stream, outside the capture)
+    out = torch.zeros_like(want)
+    sig, n, hashed = res.inputs
+    chip = res.chip
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        _lib.check(_lib.lib().h2r_verify_emit_advice(chip._ctx, ctypes.byref(res.layout), sig.data_ptr(), n.data_ptr(), hashed.data_ptr(), res.powed.data_ptr(),
+                                                     chip._flags(n, B) | _lib.H2R_ADVICE_DIRECT, res.trace.data_ptr(), res.workspace.data_ptr(), B,
+                                                     res.status.data_ptr(), out.data_ptr(), out.shape[1], chip._stream()), "h2r_verify_emit_advice")
+    assert int(out.max().item()) == 0            # captured, not run
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+
+
 def test_config2_full_size_direct_image(H):
     """BASELINE config 2 (1,024 RSA-2048 signatures, e = 65537): the 12.4 GB image written directly equals the image of the
     records, every byte, compared on the device."""
