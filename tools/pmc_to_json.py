@@ -28,13 +28,14 @@ w, rd = per_kernel(["pmc_w", "pmc_step_w"], "WRITE_SIZE"), per_kernel(["pmc_r", 
 out = {}
 for k in sorted(set(w) | set(rd)):
     wk, rk = w.get(k, 0.0), rd.get(k, 0.0)
-    # units: KB (a 1024-byte fill reports WRITE_SIZE = 1.0); gfx950 reports half of wide coalesced reads => x2
+    # units: KiB (calibrated on 4 GiB fills / reads, tools/pmc_calibration.sh, profiles/r04_pmc_calibration.txt: WRITE_SIZE 1.0028 per KiB of nt stores,
+    # 1.0000 of plain stores; FETCH_SIZE 0.5 per KiB read); gfx950 reports half of wide coalesced reads => x2
     out[k] = {"WRITE_SIZE_KB_per_launch": round(wk, 2), "FETCH_SIZE_KB_per_launch": round(rk, 2),
               "hbm_bytes_per_launch": int(round(1024 * (wk + 2 * rk))), "batch": batch}
 out["_note"] = ("rocprofv3 --kernel-trace --pmc WRITE_SIZE and --pmc FETCH_SIZE, separate passes, bench.py --steps 5 "
                 "--no-pipeline (step_kernel: the same without --no-pipeline; one launch = the records and the in-field witness of "
-                "one call plus the chains of the next), batch %d RSA-2048 e=65537. Units KB (calibrated: a 1024-byte torch fill reports "
-                "WRITE_SIZE = 1.0). FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide "
+                "one call plus the chains of the next), batch %d RSA-2048 e=65537. Units KiB (calibrated on 4 GiB fills and reads, profiles/r04_pmc_calibration.txt: WRITE_SIZE "
+                "1.0028 per KiB of nt stores, FETCH_SIZE 0.5 per KiB read). FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide "
                 "coalesced reads)." % batch)
 json.dump(out, sys.stdout, indent=1)
 print()
