@@ -3020,10 +3020,16 @@ struct SideFork {
     hipStream_t side() const { return ok ? ctx->side_stream : main; }   // (no side stream: everything in order on the caller's)
     int32_t join() {
         if (!ok) return H2R_OK;
+        ok = false;
         HIP_TRY(hipEventRecord(ctx->side_join, ctx->side_stream));
         HIP_TRY(hipStreamWaitEvent(main, ctx->side_join, 0));
         return H2R_OK;
     }
+    // an export that fails after the fork still joins: what it has queued on the side stream writes into the caller's image, and the
+    // caller's stream is what the caller will order the image's release behind
+    ~SideFork() { if (ok) (void)join(); }
+    SideFork(const SideFork &) = delete;
+    SideFork &operator=(const SideFork &) = delete;
 };
 
 int32_t verify_progs(const h2r_ctx *ctx, const h2r_ctx::RowProg **pre, const h2r_ctx::RowProg **inf, const h2r_ctx::RowProg **em) {
