@@ -295,11 +295,11 @@ def advice_bench(args):
     wss = [torch.zeros(chip.workspace_bytes(chunk, pl.num_mul_mods), dtype=torch.uint8, device=dev) for _ in range(nimg)]
     # Placement: like the record kernel's trace regions an image buffer has a store rate of its own, stable for
     # the life of the allocation -- 5.1-5.4, 6.1-6.3, 6.6-6.8 or 7.0-7.2 TB/s for the same launch, by buffer (profiles/r04_cells_placement.txt;
-    # the cause is not known).  A prover allocates its image buffers once, so the bench looks: `cand` allocations, the cells kernel
+    # the cause is not known).  A prover allocates its image buffers once, so the bench looks: `cand` allocations (16, or what three quarters of the free memory hold), the cells kernel
     # timed on each (all held during the look so that they are different memory), the fastest two kept.  --placement-candidates 0: as allocated.
-    cand = args.placement_candidates if args.placement_candidates >= 0 else 8
+    cand = args.placement_candidates if args.placement_candidates >= 0 else 16
     free_b = torch.cuda.mem_get_info(env.local_rank)[0]
-    cand = max(0, min(cand, int(free_b * 0.5) // (chunk * elem_bytes)))
+    cand = max(0, min(cand, int(free_b * 0.75) // (chunk * elem_bytes)))
     placement = "as allocated"
     if cand > nimg:
         first = chip.pow_mod_fixed_exp(x_dev, e, n_dev, want_trace=False, check_in_field=True, workspace=wss[0])

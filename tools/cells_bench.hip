@@ -3,6 +3,7 @@
 // rebuilt here the way h2r_ctx_create builds them.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -Ihalo2_rsa_amd/csrc tools/cells_bench.hip -o /tmp/cells_bench -Lhalo2_rsa_amd/lib -lh2r -Wl,-rpath,$PWD/halo2_rsa_amd/lib
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -165,6 +166,49 @@ int main(int argc, char **argv) {
                     }
                 }
             }
+        }
+        return 0;
+    }
+    if (argc > 4 && !std::strcmp(argv[4], "fragment")) {
+        // Does memory that the driver has to ASSEMBLE from scattered free blocks land in the fast class?  (1) six images as allocated;
+        // (2) the free memory taken as chunks of argv[5] MB, every other chunk released, six images allocated from the holes.
+        const u32 l4 = (160u * 1024 / 4 - 512) & ~15u, lds = l4 > base ? l4 : base;
+        auto rate = [&](u8 *p) { CellsArgs c2 = ca; c2.out = p; const float ms = w == 64 ? run<64, 0>(c2, lds, 3) : run<32, 0>(c2, lds, 3); return gb / ms; };
+        const int NI = argc > 6 ? std::atoi(argv[6]) : 6;
+        {
+            std::vector<u8 *> keep;
+            std::printf("  as allocated:");
+            for (int i = 0; i < NI; ++i) { u8 *p = nullptr; if (hipMalloc(reinterpret_cast<void **>(&p), img) != hipSuccess) { (void)hipGetLastError(); break; } keep.push_back(p); std::printf(" %.2f", rate(p)); std::fflush(stdout); }
+            std::printf(" TB/s\n");
+            for (u8 *p : keep) CK(hipFree(p));
+        }
+        for (int rep = 0; rep < 2; ++rep) {
+            const size_t chunk = (size_t)(argc > 5 ? std::atoi(argv[5]) : 16) << 20;
+            size_t fr = 0, tot = 0; CK(hipMemGetInfo(&fr, &tot));
+            std::vector<void *> ballast;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (true) {
+                size_t f2 = 0; CK(hipMemGetInfo(&f2, &tot));
+                if (f2 < (4ull << 30)) break;
+                void *q = nullptr; if (hipMalloc(&q, chunk) != hipSuccess) { (void)hipGetLastError(); break; }
+                ballast.push_back(q);
+            }
+            size_t freed = 0;
+            if (rep == 0 && !std::getenv("FRAG_RANDOM_ONLY")) { for (size_t i = 0; i < ballast.size(); i += 2) { CK(hipFree(ballast[i])); ballast[i] = nullptr; ++freed; } }
+            else {   // pseudo-random half
+                u64 x = 0x9e3779b97f4a7c15ull + 77u * (u64)rep;
+                for (size_t i = 0; i < ballast.size(); ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; if (x & 1) { CK(hipFree(ballast[i])); ballast[i] = nullptr; ++freed; } }
+            }
+            const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::printf("  %zu chunks of %zu MB taken, %zu released (%s) in %.2f s; images from the holes:", ballast.size(), chunk >> 20, freed, (rep || std::getenv("FRAG_RANDOM_ONLY")) ? "a random half" : "every other one", secs);
+            std::vector<u8 *> keep;
+            for (int i = 0; i < NI; ++i) { u8 *p = nullptr; if (hipMalloc(reinterpret_cast<void **>(&p), img) != hipSuccess) { (void)hipGetLastError(); break; } keep.push_back(p); std::printf(" %.2f", rate(p)); std::fflush(stdout); }
+            std::printf(" TB/s\n");
+            for (void *q : ballast) if (q) CK(hipFree(q));
+            std::printf("    the same images after the ballast is released:");
+            for (u8 *p : keep) std::printf(" %.2f", rate(p));
+            std::printf(" TB/s\n");
+            for (u8 *p : keep) CK(hipFree(p));
         }
         return 0;
     }
