@@ -169,6 +169,42 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+    if (argc > 4 && !std::strcmp(argv[4], "vmm2")) {   // eight images as allocated, then eight stitched from 256 MB / 1 GB physical chunks (all eight held): is the stitched kind consistently one class?
+        const u32 l4 = (160u * 1024 / 4 - 512) & ~15u, lds = l4 > base ? l4 : base;
+        auto rate = [&](u8 *p) { CellsArgs c2 = ca; c2.out = p; const float ms = w == 64 ? run<64, 0>(c2, lds, 3) : run<32, 0>(c2, lds, 3); return gb / ms; };
+        {
+            std::vector<u8 *> keep;
+            std::printf("  as allocated (hipMalloc):");
+            for (int i = 0; i < 8; ++i) { u8 *p = nullptr; if (hipMalloc(reinterpret_cast<void **>(&p), img) != hipSuccess) { (void)hipGetLastError(); break; } keep.push_back(p); std::printf(" %.2f", rate(p)); std::fflush(stdout); }
+            std::printf(" TB/s\n");
+            for (u8 *p : keep) CK(hipFree(p));
+        }
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
+        size_t gran = 0; CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+        for (size_t chunk_mb : {256, 1024, 128, 512}) {
+            const size_t chunk = ((chunk_mb << 20) + gran - 1) / gran * gran, n = (img + chunk - 1) / chunk;
+            struct Img { void *va; std::vector<hipMemGenericAllocationHandle_t> hs; };
+            std::vector<Img> imgs;
+            std::printf("  stitched from %4zu MB chunks (%zu per image):", chunk_mb, n);
+            for (int k = 0; k < 8; ++k) {
+                Img im; im.va = nullptr; im.hs.resize(n);
+                if (hipMemAddressReserve(&im.va, n * chunk, 0, nullptr, 0) != hipSuccess) { std::printf(" reserve failed"); break; }
+                bool ok = true; size_t made = 0;
+                for (; made < n && ok; ++made) ok = hipMemCreate(&im.hs[made], chunk, &prop, 0) == hipSuccess;
+                if (!ok) { (void)hipGetLastError(); for (size_t i = 0; i + 1 < made; ++i) (void)hipMemRelease(im.hs[i]); (void)hipMemAddressFree(im.va, n * chunk); std::printf(" (out of memory)"); break; }
+                for (size_t i = 0; i < n; ++i) CK(hipMemMap((char *)im.va + i * chunk, chunk, 0, im.hs[i], 0));
+                hipMemAccessDesc acc = {}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+                CK(hipMemSetAccess(im.va, n * chunk, &acc, 1));
+                std::printf(" %.2f", rate(static_cast<u8 *>(im.va))); std::fflush(stdout);
+                imgs.push_back(std::move(im));
+            }
+            std::printf(" TB/s\n");
+            CK(hipDeviceSynchronize());
+            for (Img &im : imgs) { CK(hipMemUnmap(im.va, n * chunk)); for (auto h : im.hs) CK(hipMemRelease(h)); CK(hipMemAddressFree(im.va, n * chunk)); }
+        }
+        return 0;
+    }
     if (argc > 4 && !std::strcmp(argv[4], "fragment")) {
         // Does memory that the driver has to ASSEMBLE from scattered free blocks land in the fast class?  (1) six images as allocated;
         // (2) the free memory taken as chunks of argv[5] MB, every other chunk released, six images allocated from the holes.
