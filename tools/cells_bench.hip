@@ -205,6 +205,101 @@ int main(int argc, char **argv) {
         }
         return 0;
     }
+    if (argc > 4 && !std::strcmp(argv[4], "fragrec")) {
+        // The RECORD kernel's regions (one call's op-trace: batch x elem_stride bytes) as allocated, and allocated from the holes of a
+        // fragmented free memory (chunks of argv[5] MB, a random half released): does conditioning the allocator give fast regions?
+        const u64 region = batch * pl.elem_stride + 4096;
+        auto rec_ms = [&](void *p) {
+            void *t = reinterpret_cast<void *>(round_up(reinterpret_cast<u64>(p), 256));
+            for (int i = 0; i < 2; ++i) (void)h2r_pow_mod_fixed_exp_batch(ctx, dx, dn, e_le, 3, batch, 0, t, dout, dst, dws, nullptr);
+            CK(hipDeviceSynchronize());
+            (void)h2r_profile_enable(16);
+            for (int i = 0; i < 4; ++i) (void)h2r_pow_mod_fixed_exp_batch(ctx, dx, dn, e_le, 3, batch, 0, t, dout, dst, dws, nullptr);
+            CK(hipDeviceSynchronize());
+            float ms[16]; u32 n = 0; (void)h2r_profile_read(H2R_KERNEL_TRACE, ms, 16, &n);
+            (void)h2r_profile_enable(0);
+            float sum = 0; for (u32 i = 0; i < n && i < 16; ++i) sum += ms[i];
+            return n ? sum / (n < 16 ? n : 16) : 0.f;
+        };
+        const int NR = argc > 6 ? std::atoi(argv[6]) : 8;
+        std::printf("  region %.2f GB; record kernel alone, ms per launch\n", (double)region / 1e9);
+        for (int round = 0; round < 2; ++round) {
+            {
+                std::vector<void *> keep;
+                std::printf("  as allocated:      ");
+                for (int i = 0; i < NR; ++i) { void *p = nullptr; CK(hipMalloc(&p, region)); keep.push_back(p); std::printf(" %.4f", rec_ms(p)); std::fflush(stdout); }
+                std::printf("\n");
+                for (void *p : keep) CK(hipFree(p));
+            }
+            const size_t chunk = (size_t)(argc > 5 ? std::atoi(argv[5]) : 16) << 20;
+            std::vector<void *> ballast;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (true) {
+                size_t f2 = 0, tot = 0; CK(hipMemGetInfo(&f2, &tot));
+                if (f2 < (4ull << 30)) break;
+                void *q = nullptr; if (hipMalloc(&q, chunk) != hipSuccess) { (void)hipGetLastError(); break; }
+                ballast.push_back(q);
+            }
+            u64 x = 0x9e3779b97f4a7c15ull + 1315423911ull * (u64)round; size_t freed = 0;
+            for (size_t i = 0; i < ballast.size(); ++i) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; if (x & 1) { CK(hipFree(ballast[i])); ballast[i] = nullptr; ++freed; } }
+            const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::vector<void *> keep;
+            std::printf("  from random holes: ");
+            for (int i = 0; i < NR; ++i) { void *p = nullptr; if (hipMalloc(&p, region) != hipSuccess) { (void)hipGetLastError(); break; } keep.push_back(p); std::printf(" %.4f", rec_ms(p)); std::fflush(stdout); }
+            std::printf("   (%zu chunks of %zu MB, %zu released, %.1f s)\n", ballast.size(), chunk >> 20, freed, secs);
+            for (void *q : ballast) if (q) CK(hipFree(q));
+            std::printf("  ballast released:  ");
+            for (void *p : keep) std::printf(" %.4f", rec_ms(p));
+            std::printf("\n");
+            for (void *p : keep) CK(hipFree(p));
+        }
+        return 0;
+    }
+    if (argc > 4 && !std::strcmp(argv[4], "churn")) {
+        // Regions of the record kernel as allocated in a fresh process, then after the whole free memory has been taken as chunks of argv[5] MB
+        // and released again (in allocation order / argv[6] = 1: in a pseudo-random order): does a churned allocator hand out fast regions?
+        const u64 region = batch * pl.elem_stride + 4096;
+        auto rec_ms = [&](void *p) {
+            void *t = reinterpret_cast<void *>(round_up(reinterpret_cast<u64>(p), 256));
+            for (int i = 0; i < 2; ++i) (void)h2r_pow_mod_fixed_exp_batch(ctx, dx, dn, e_le, 3, batch, 0, t, dout, dst, dws, nullptr);
+            CK(hipDeviceSynchronize());
+            (void)h2r_profile_enable(16);
+            for (int i = 0; i < 4; ++i) (void)h2r_pow_mod_fixed_exp_batch(ctx, dx, dn, e_le, 3, batch, 0, t, dout, dst, dws, nullptr);
+            CK(hipDeviceSynchronize());
+            float ms[16]; u32 n = 0; (void)h2r_profile_read(H2R_KERNEL_TRACE, ms, 16, &n);
+            (void)h2r_profile_enable(0);
+            float sum = 0; for (u32 i = 0; i < n && i < 16; ++i) sum += ms[i];
+            return n ? sum / (n < 16 ? n : 16) : 0.f;
+        };
+        auto look = [&](const char *what, int nr) {
+            std::vector<void *> keep;
+            std::printf("  %-28s", what);
+            for (int i = 0; i < nr; ++i) { void *p = nullptr; if (hipMalloc(&p, region) != hipSuccess) { (void)hipGetLastError(); break; } keep.push_back(p); std::printf(" %.3f", rec_ms(p)); std::fflush(stdout); }
+            std::printf("\n");
+            for (void *p : keep) CK(hipFree(p));
+        };
+        const bool shuffle = argc > 6 && std::atoi(argv[6]) != 0;
+        look("fresh process:", 12);
+        look("again:", 12);
+        for (int round = 0; round < 2; ++round) {
+            const size_t chunk = (size_t)(argc > 5 ? std::atoi(argv[5]) : 2) << 20;
+            std::vector<void *> ballast;
+            const auto t0 = std::chrono::steady_clock::now();
+            while (true) {
+                size_t f2 = 0, tot = 0; CK(hipMemGetInfo(&f2, &tot));
+                if (f2 < (2ull << 30)) break;
+                void *q = nullptr; if (hipMalloc(&q, chunk) != hipSuccess) { (void)hipGetLastError(); break; }
+                ballast.push_back(q);
+            }
+            if (shuffle) for (size_t i = ballast.size() - 1; i > 0; --i) std::swap(ballast[i], ballast[rnd() % (i + 1)]);
+            for (void *q : ballast) CK(hipFree(q));
+            const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::printf("  churn: %zu chunks of %zu MB taken and released%s, %.1f s\n", ballast.size(), chunk >> 20, shuffle ? " in a random order" : "", secs);
+            look("after the churn:", 16);
+            look("again:", 16);
+        }
+        return 0;
+    }
     if (argc > 4 && !std::strcmp(argv[4], "fragment")) {
         // Does memory that the driver has to ASSEMBLE from scattered free blocks land in the fast class?  (1) six images as allocated;
         // (2) the free memory taken as chunks of argv[5] MB, every other chunk released, six images allocated from the holes.
