@@ -804,7 +804,7 @@ int32_t h2r_advice_apply_layout(const h2r_ctx *ctx, const h2r_advice_layout *lay
  * h2r_pow_trace_emit_advice].  x, n, flags, in_field_trace, trace, workspace: what h2r_modpow_public_key_batch was given (a caller
  * workspace is required).  trace = NULL: that call wrote no records -- the pow rows are written directly from the operands
  * (H2R_ADVICE_DIRECT, also selectable in flags with a trace): the prover-consumable witness without the record planes in between.
- * section_rows (nullable): {1,533, 75,489} for RSA-2048, e = 65537. */
+ * section_rows (nullable): {1,532, 75,489} for RSA-2048, e = 65537. */
 uint64_t h2r_modpow_public_key_advice_rows(const h2r_ctx *ctx, const h2r_pow_layout *pl, uint64_t section_rows[2]);
 int32_t h2r_modpow_public_key_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *x, const void *n, uint32_t flags,
                                           const void *in_field_trace, const void *trace, const void *workspace, uint64_t batch,

@@ -93,6 +93,11 @@ struct BatchResult {
     AssignedInteger value;        // a*b mod n  /  a^e mod n
     Trace trace;
     std::vector<uint8_t> status;  // H2R_* per element
+    // kept for the advice image (BigIntChip::emit_advice): the per-element status on the device, a pow call's workspace (it holds every
+    // mul_mod's operands) and layout
+    DeviceBuffer status_dev, workspace;
+    h2r_pow_layout pow_layout{};
+    bool is_pow = false;
 };
 
 // result of a Fresh-integer op (add / sub / add_mod / sub_mod / comparisons): value where the op has one, the
@@ -277,7 +282,7 @@ class BigIntChip {
         DeviceBuffer trace(batch * layout_.record_stride), r(batch * num_limbs_ * 8), st(batch);
         check(h2r_mul_mod_batch(ctx_, a.data(), b.data(), n.data(), batch, flags(n, batch), trace.get(), r.get(),
                                 static_cast<uint8_t *>(st.get()), nullptr, nullptr), "mul_mod");
-        return finish(std::move(trace), std::move(r), st, batch, false, h2r_pow_layout{}, layout_.record_stride, layout_.stream_bytes);
+        return finish(std::move(trace), std::move(r), std::move(st), DeviceBuffer(), batch, false, h2r_pow_layout{}, layout_.record_stride, layout_.stream_bytes);
     }
     // big_integer/chip.rs:642-649
     BatchResult square_mod(const AssignedInteger &a, const AssignedInteger &n) const { return mul_mod(a, a, n); }
@@ -288,6 +293,47 @@ class BigIntChip {
     // big_integer/chip.rs:664-696
     BatchResult pow_mod(const AssignedInteger &a, const AssignedInteger &e, const AssignedInteger &n, uint32_t exp_limb_bits) const {
         return pow_var(a, e, n, exp_limb_bits, nullptr);
+    }
+
+    // ---- the witness as cells: rows of the main gate's five advice columns, 160 bytes per row (h2r.h "advice image"; what the reference
+    // assigns cell by cell: main_gate.mul_add chip.rs:408, range_chip.assign :590, :598, :880-885, the is_equal_muled ops :851-893) ----
+    // rows of one element of `r` and their kinds (H2R_ROW_*)
+    uint64_t advice_rows(const BatchResult &r) const { return r.is_pow ? h2r_pow_advice_rows(ctx_, &r.pow_layout) : h2r_advice_rows(ctx_); }
+    std::vector<uint8_t> advice_row_kinds(const BatchResult &r) const {
+        std::vector<uint8_t> k(advice_rows(r));
+        check(r.is_pow ? h2r_pow_row_kinds(ctx_, &r.pow_layout, k.data()) : h2r_advice_row_kinds(ctx_, k.data()), "advice row kinds");
+        return k;
+    }
+    // the image of a mul_mod result (a, b, n: the call's operands); direct = H2R_ADVICE_DIRECT: written from the operands and the record's
+    // q, r limbs by cells_kernel instead of converted from the record planes -- the same bytes
+    DeviceBuffer emit_advice(const BatchResult &r, const AssignedInteger &a, const AssignedInteger &b, const AssignedInteger &n, bool direct = false) const {
+        if (r.is_pow) throw Error(H2R_E_SHAPE, "emit_advice(a, b, n) is for mul_mod results");
+        const size_t batch = a.batch();
+        const uint64_t stride = advice_rows(r) * H2R_ADVICE_ROW_BYTES;
+        DeviceBuffer out(batch * stride);
+        check(h2r_mul_mod_emit_advice(ctx_, a.data(), b.data(), n.data(), flags(n, batch) | (direct ? H2R_ADVICE_DIRECT : 0u), r.trace.data(), batch,
+                                      static_cast<const uint8_t *>(r.status_dev.get()), out.get(), stride, nullptr), "h2r_mul_mod_emit_advice");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        return out;
+    }
+    // the image of a pow_mod_fixed_exp / pow_mod result: [to_bits rows (Var)] [acc = 1: CONST1, CONST0] [every mul_mod's rows (+ select rows)]
+    DeviceBuffer emit_advice(const BatchResult &r, const AssignedInteger &n, bool direct = false) const {
+        if (!r.is_pow) throw Error(H2R_E_SHAPE, "emit_advice(n) is for pow results");
+        const size_t batch = r.status.size();
+        const uint64_t stride = advice_rows(r) * H2R_ADVICE_ROW_BYTES;
+        DeviceBuffer out(batch * stride);
+        check(h2r_pow_trace_emit_advice(ctx_, &r.pow_layout, n.data(), flags(n, batch) | (direct ? H2R_ADVICE_DIRECT : 0u), r.trace.data(), 0,
+                                        r.workspace.get(), batch, static_cast<const uint8_t *>(r.status_dev.get()), out.get(), stride, nullptr),
+              "h2r_pow_trace_emit_advice");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        return out;
+    }
+    // the equality (copy) constraints of one mul_mod record's rows: (row, col) <- (src_row, src_col) | limb src_col of operand a / b / n
+    std::vector<h2r_copy> advice_copy_map() const {
+        const uint32_t n = h2r_advice_copy_map(ctx_, nullptr, 0);
+        std::vector<h2r_copy> v(n);
+        if (n && h2r_advice_copy_map(ctx_, v.data(), n) != n) throw Error(H2R_E_INTERNAL, "h2r_advice_copy_map");
+        return v;
     }
 
   private:
@@ -322,36 +368,36 @@ class BigIntChip {
         h2r_pow_layout pl;
         check(h2r_pow_fixed_layout(ctx_, e_le.data(), e_le.size(), &pl), "h2r_pow_fixed_layout");
         const size_t batch = a.batch();
-        DeviceBuffer trace(batch * pl.elem_stride), out(batch * num_limbs_ * 8), st(batch);
+        DeviceBuffer trace(batch * pl.elem_stride), out(batch * num_limbs_ * 8), st(batch), ws(h2r_workspace_bytes(ctx_, batch, pl.num_mul_mods));
         if (in_field)
             check(h2r_modpow_public_key_batch(ctx_, a.data(), n.data(), e_le.data(), e_le.size(), batch, flags(n, batch), trace.get(),
-                                              in_field->get(), out.get(), static_cast<uint8_t *>(st.get()), nullptr, nullptr), "modpow_public_key");
+                                              in_field->get(), out.get(), static_cast<uint8_t *>(st.get()), ws.get(), nullptr), "modpow_public_key");
         else
             check(h2r_pow_mod_fixed_exp_batch(ctx_, a.data(), n.data(), e_le.data(), e_le.size(), batch, flags(n, batch), trace.get(),
-                                              out.get(), static_cast<uint8_t *>(st.get()), nullptr, nullptr), "pow_mod_fixed_exp");
-        return finish(std::move(trace), std::move(out), st, batch, true, pl, pl.elem_stride, pl.stream_bytes);
+                                              out.get(), static_cast<uint8_t *>(st.get()), ws.get(), nullptr), "pow_mod_fixed_exp");
+        return finish(std::move(trace), std::move(out), std::move(st), std::move(ws), batch, true, pl, pl.elem_stride, pl.stream_bytes);
     }
     BatchResult pow_var(const AssignedInteger &a, const AssignedInteger &e, const AssignedInteger &n, uint32_t exp_limb_bits, DeviceBuffer *in_field) const {
         h2r_pow_layout pl;
         check(h2r_pow_var_layout(ctx_, (uint32_t)e.num_limbs(), exp_limb_bits, &pl), "h2r_pow_var_layout");
         const size_t batch = a.batch();
-        DeviceBuffer trace(batch * pl.elem_stride), out(batch * num_limbs_ * 8), st(batch);
+        DeviceBuffer trace(batch * pl.elem_stride), out(batch * num_limbs_ * 8), st(batch), ws(h2r_workspace_bytes(ctx_, batch, pl.num_mul_mods));
         if (in_field)
             check(h2r_modpow_public_key_var_batch(ctx_, a.data(), e.data(), (uint32_t)e.num_limbs(), exp_limb_bits, n.data(), batch,
                                                   flags(n, batch), trace.get(), in_field->get(), out.get(), static_cast<uint8_t *>(st.get()),
-                                                  nullptr, nullptr), "modpow_public_key");
+                                                  ws.get(), nullptr), "modpow_public_key");
         else
             check(h2r_pow_mod_batch(ctx_, a.data(), e.data(), (uint32_t)e.num_limbs(), exp_limb_bits, n.data(), batch, flags(n, batch),
-                                    trace.get(), out.get(), static_cast<uint8_t *>(st.get()), nullptr, nullptr), "pow_mod");
-        return finish(std::move(trace), std::move(out), st, batch, true, pl, pl.elem_stride, pl.stream_bytes);
+                                    trace.get(), out.get(), static_cast<uint8_t *>(st.get()), ws.get(), nullptr), "pow_mod");
+        return finish(std::move(trace), std::move(out), std::move(st), std::move(ws), batch, true, pl, pl.elem_stride, pl.stream_bytes);
     }
-    BatchResult finish(DeviceBuffer trace, DeviceBuffer value, const DeviceBuffer &st, size_t batch, bool is_pow, h2r_pow_layout pl,
+    BatchResult finish(DeviceBuffer trace, DeviceBuffer value, DeviceBuffer st, DeviceBuffer ws, size_t batch, bool is_pow, h2r_pow_layout pl,
                        uint64_t elem_stride, uint64_t stream_bytes) const {
         hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
         std::vector<uint8_t> status(batch);
         st.download(status.data(), batch);
         return BatchResult{AssignedInteger(std::move(value), batch, num_limbs_), Trace(this, std::move(trace), batch, is_pow, pl, elem_stride, stream_bytes),
-                           std::move(status)};
+                           std::move(status), std::move(st), std::move(ws), pl, is_pow};
     }
     uint32_t limb_width_, num_limbs_;
     h2r_ctx *ctx_ = nullptr;
@@ -403,6 +449,7 @@ struct VerifyResult {
     std::vector<uint8_t> status;
     AssignedInteger powed;
     DeviceBuffer trace; h2r_verify_layout layout;
+    DeviceBuffer status_dev, workspace;   // kept for RSAChip::emit_advice (the workspace holds every mul_mod's operands)
 };
 
 // reference src/chip.rs:38-255
@@ -446,25 +493,56 @@ class RSAChip {
         const size_t batch = sig.c.batch();
         if (f) check(h2r_verify_layout_fixed(bigint_.ctx(), f->e_le.data(), f->e_le.size(), &vl), "h2r_verify_layout_fixed");
         else check(h2r_verify_layout_var(bigint_.ctx(), (uint32_t)std::get<AssignedInteger>(pk.e).num_limbs(), exp_limb_bits_, &vl), "h2r_verify_layout_var");
-        DeviceBuffer trace(batch * vl.elem_stride), powed(batch * bigint_.num_limbs() * 8), valid(batch), st(batch);
+        DeviceBuffer trace(batch * vl.elem_stride), powed(batch * bigint_.num_limbs() * 8), valid(batch), st(batch),
+            ws(h2r_workspace_bytes(bigint_.ctx(), batch, vl.pow.num_mul_mods));
         if (f)
             check(h2r_verify_pkcs1v15_batch(bigint_.ctx(), sig.c.data(), pk.n.data(), f->e_le.data(), f->e_le.size(),
                                             static_cast<const uint64_t *>(hashed_msg.data()), batch, BigIntChip::flags(pk.n, batch), trace.get(),
-                                            powed.get(), static_cast<uint8_t *>(valid.get()), static_cast<uint8_t *>(st.get()), nullptr, nullptr),
+                                            powed.get(), static_cast<uint8_t *>(valid.get()), static_cast<uint8_t *>(st.get()), ws.get(), nullptr),
                   "verify_pkcs1v15_signature");
         else {   // RSAPubE::Var (src/chip.rs:108-110)
             const AssignedInteger &e = std::get<AssignedInteger>(pk.e);
             check(h2r_verify_pkcs1v15_var_batch(bigint_.ctx(), sig.c.data(), pk.n.data(), e.data(), (uint32_t)e.num_limbs(), exp_limb_bits_,
                                                 static_cast<const uint64_t *>(hashed_msg.data()), batch, BigIntChip::flags(pk.n, batch), trace.get(),
-                                                powed.get(), static_cast<uint8_t *>(valid.get()), static_cast<uint8_t *>(st.get()), nullptr, nullptr),
+                                                powed.get(), static_cast<uint8_t *>(valid.get()), static_cast<uint8_t *>(st.get()), ws.get(), nullptr),
                   "verify_pkcs1v15_signature (Var)");
         }
         hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
         VerifyResult r{std::vector<uint8_t>(batch), std::vector<uint8_t>(batch), AssignedInteger(std::move(powed), batch, bigint_.num_limbs()),
-                       std::move(trace), vl};
+                       std::move(trace), vl, DeviceBuffer(), std::move(ws)};
         valid.download(r.is_valid.data(), batch);
         st.download(r.status.data(), batch);
+        r.status_dev = std::move(st);
         return r;
+    }
+    // ---- the witness as cells (h2r.h "advice image") ----
+    // one whole verify_pkcs1v15_signature element (src/chip.rs:128-199): [is_eq = 1] [assert_in_field rows] [pow rows] [encoded-message check];
+    // pk, hashed_msg, sig: what the call was given.  direct: the pow rows written from the operands (H2R_ADVICE_DIRECT), the same bytes.
+    uint64_t advice_rows(const VerifyResult &r, uint64_t section_rows[4] = nullptr) const { return h2r_verify_advice_rows(bigint_.ctx(), &r.layout, section_rows); }
+    DeviceBuffer emit_advice(const VerifyResult &r, const AssignedRSAPublicKey &pk, const AssignedInteger &hashed_msg, const AssignedRSASignature &sig,
+                             bool direct = false) const {
+        const size_t batch = sig.c.batch();
+        const uint64_t stride = advice_rows(r) * H2R_ADVICE_ROW_BYTES;
+        DeviceBuffer out(batch * stride);
+        check(h2r_verify_emit_advice(bigint_.ctx(), &r.layout, sig.c.data(), pk.n.data(), static_cast<const uint64_t *>(hashed_msg.data()), r.powed.data(),
+                                     BigIntChip::flags(pk.n, batch) | (direct ? H2R_ADVICE_DIRECT : 0u), r.trace.get(), r.workspace.get(), batch,
+                                     static_cast<const uint8_t *>(r.status_dev.get()), out.get(), stride, nullptr), "h2r_verify_emit_advice");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        return out;
+    }
+    // one modpow_public_key element (src/chip.rs:99-114): [assert_in_field rows] [pow rows]; with_records = false: as if the call had
+    // written no records (the pow rows come from the operands alone)
+    uint64_t advice_rows(const ModpowResult &r, uint64_t section_rows[2] = nullptr) const { return h2r_modpow_public_key_advice_rows(bigint_.ctx(), &r.pow.pow_layout, section_rows); }
+    DeviceBuffer emit_advice(const ModpowResult &r, const AssignedInteger &x, const AssignedRSAPublicKey &pk, bool with_records = true) const {
+        const size_t batch = x.batch();
+        const uint64_t stride = advice_rows(r) * H2R_ADVICE_ROW_BYTES;
+        DeviceBuffer out(batch * stride);
+        check(h2r_modpow_public_key_emit_advice(bigint_.ctx(), &r.pow.pow_layout, x.data(), pk.n.data(), BigIntChip::flags(pk.n, batch), r.in_field.get(),
+                                                with_records ? r.pow.trace.data() : nullptr, r.pow.workspace.get(), batch,
+                                                static_cast<const uint8_t *>(r.pow.status_dev.get()), out.get(), stride, nullptr),
+              "h2r_modpow_public_key_emit_advice");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        return out;
     }
     std::vector<uint8_t> flatten(const VerifyResult &r, size_t elem) const {
         std::vector<uint8_t> host(r.layout.elem_stride), out(r.layout.stream_bytes);

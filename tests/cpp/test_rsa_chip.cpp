@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 #include <string>
@@ -125,6 +126,53 @@ int main(int argc, char **argv) {
         std::vector<uint8_t> st(op.mul_mod_stream_bytes); std::vector<uint64_t> rr(32);
         REQUIRE(h2ro_mul_mod(&op, a.data(), a.data(), n.data(), st.data(), rr.data()) == 0);
         REQUIRE(r.trace.flatten(0) == st);
+        // the same mul_mod as cells (what main_gate.mul_add / range_chip.assign / the is_equal_muled ops assign, chip.rs:408, :590, :598, :851-893):
+        // converted from the record and written directly from the operands -- the same bytes; the copy map holds value for value
+        const uint64_t rows = bigint_chip.advice_rows(r);
+        REQUIRE(rows == 3973 && bigint_chip.advice_row_kinds(r).size() == rows);
+        DeviceBuffer img = bigint_chip.emit_advice(r, aa, aa, an), img_d = bigint_chip.emit_advice(r, aa, aa, an, true);
+        std::vector<uint8_t> ia(rows * H2R_ADVICE_ROW_BYTES), ib(ia.size());
+        img.download(ia.data(), ia.size()); img_d.download(ib.data(), ib.size());
+        REQUIRE(ia == ib);
+        size_t inside = 0, outside = 0;
+        for (const h2r_copy &c : bigint_chip.advice_copy_map()) {
+            const uint8_t *cell = ia.data() + (size_t)c.row * 160 + c.col * 32;
+            if (c.src_row < 0xFFFFFF00u) { REQUIRE(c.src_row < rows && !std::memcmp(cell, ia.data() + (size_t)c.src_row * 160 + c.src_col * 32, 32)); ++inside; }
+            else {   // limb src_col of operand a / b / n
+                const uint64_t want = c.src_row == H2R_COPY_SRC_N ? n[c.src_col] : a[c.src_col];
+                uint64_t got[4]; std::memcpy(got, cell, 32);
+                REQUIRE(got[0] == want && got[1] == 0 && got[2] == 0 && got[3] == 0);
+                ++outside;
+            }
+        }
+        REQUIRE(inside > 0 && outside == 3u * 32 * 32);   // x_j, y_{i-j} of both muls: 2 L^2 from a, b (here a = b) and L^2 from n
+    }
+    // one verify_pkcs1v15_signature element and one modpow_public_key element as cells (src/chip.rs:128-199, :99-114)
+    {
+        uint64_t sec[4], sec2[2];
+        const uint64_t rows = rsa_chip.advice_rows(res, sec);
+        REQUIRE(sec[0] == 1 && sec[1] == 1532 && sec[2] == 75489 && sec[3] == 178 && rows == 77200);
+        DeviceBuffer img = rsa_chip.emit_advice(res, pk, hashed_msg_assigned, sign), img_d = rsa_chip.emit_advice(res, pk, hashed_msg_assigned, sign, true);
+        std::vector<uint8_t> ia(B * rows * H2R_ADVICE_ROW_BYTES), ib(ia.size());
+        img.download(ia.data(), ia.size()); img_d.download(ib.data(), ib.size());
+        REQUIRE(ia == ib);
+        for (size_t i = 0; i < B; ++i) REQUIRE(ia[i * rows * 160] == 1);   // is_eq = assign_constant(1), :137
+        ModpowResult mp = rsa_chip.modpow_public_key(sign.c, pk);
+        REQUIRE(rsa_chip.advice_rows(mp, sec2) == 1532 + 75489 && sec2[0] == 1532);
+        DeviceBuffer m1 = rsa_chip.emit_advice(mp, sign.c, pk, true), m2 = rsa_chip.emit_advice(mp, sign.c, pk, false);
+        std::vector<uint8_t> ma(B * (1532 + 75489) * H2R_ADVICE_ROW_BYTES), mb(ma.size());
+        m1.download(ma.data(), ma.size()); m2.download(mb.data(), mb.size());
+        REQUIRE(ma == mb);
+        // the pow rows of both elements are the same rows (same x = sig, same n, same e)
+        for (size_t i = 0; i < B; ++i)
+            REQUIRE(!std::memcmp(ma.data() + (i * (1532 + 75489) + 1532) * 160, ia.data() + (i * rows + 1 + 1532) * 160, 75489ull * 160));
+        BatchResult pw = bigint_chip.pow_mod_fixed_exp(sign.c, {0x01, 0x00, 0x01}, pk.n);
+        REQUIRE(bigint_chip.advice_rows(pw) == 75489);
+        DeviceBuffer p1 = bigint_chip.emit_advice(pw, pk.n), p2 = bigint_chip.emit_advice(pw, pk.n, true);
+        std::vector<uint8_t> pa(B * 75489ull * 160), pb(pa.size());
+        p1.download(pa.data(), pa.size()); p2.download(pb.data(), pb.size());
+        REQUIRE(pa == pb);
+        for (size_t i = 0; i < B; ++i) REQUIRE(!std::memcmp(pa.data() + i * 75489ull * 160, ia.data() + (i * rows + 1 + 1532) * 160, 75489ull * 160));
     }
     // pipelined verifier: three back-to-back batches over two buffer sets give the same witnesses as the batch call
     {
