@@ -113,6 +113,17 @@ struct FreshResult {
         check(h2r_fresh_op_flatten(ctx, op, host.data(), out.data()), "h2r_fresh_op_flatten");
         return out;
     }
+    // the op as cells (rows of the main gate's five advice columns); a, b, n: the call's operands (b / n null where the op has none),
+    // shared_flags: H2R_F_SHARED_MODULUS as in the call; assert_form: the assert_* twin (main_gate.assert_one at the end)
+    uint64_t advice_rows(bool assert_form = false) const { return h2r_fresh_op_advice_rows(ctx, op, assert_form ? H2R_ADVICE_ASSERT_ONE : 0u); }
+    DeviceBuffer emit_advice(const void *a, const void *b, const void *n, uint32_t shared_flags = 0, bool assert_form = false) const {
+        const uint64_t stride = advice_rows(assert_form) * H2R_ADVICE_ROW_BYTES;
+        DeviceBuffer out(batch * stride);
+        check(h2r_fresh_op_emit_advice(ctx, op, shared_flags | (assert_form ? H2R_ADVICE_ASSERT_ONE : 0u), a, b, n, trace.get(), 0, elem_stride, batch,
+                                       nullptr, out.get(), stride, nullptr), "h2r_fresh_op_emit_advice");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        return out;
+    }
 };
 
 // reference src/big_integer/mod.rs:216-232, 306-382 (range type Muled): the un-carried product columns, 2L columns of

@@ -157,6 +157,13 @@ int main(int argc, char **argv) {
         img.download(ia.data(), ia.size()); img_d.download(ib.data(), ib.size());
         REQUIRE(ia == ib);
         for (size_t i = 0; i < B; ++i) REQUIRE(ia[i * rows * 160] == 1);   // is_eq = assign_constant(1), :137
+        // assert_in_field(sig, n) on its own (src/chip.rs:106) = the second section of the element
+        FreshResult inf = bigint_chip.assert_in_field(sign.c, pk.n);
+        REQUIRE(inf.advice_rows(true) == 1532);
+        DeviceBuffer fimg = inf.emit_advice(sign.c.data(), pk.n.data(), nullptr, 0, true);
+        std::vector<uint8_t> fa(B * 1532 * H2R_ADVICE_ROW_BYTES);
+        fimg.download(fa.data(), fa.size());
+        for (size_t i = 0; i < B; ++i) REQUIRE(!std::memcmp(fa.data() + i * 1532 * 160, ia.data() + (i * rows + 1) * 160, 1532 * 160));
         ModpowResult mp = rsa_chip.modpow_public_key(sign.c, pk);
         REQUIRE(rsa_chip.advice_rows(mp, sec2) == 1532 + 75489 && sec2[0] == 1532);
         DeviceBuffer m1 = rsa_chip.emit_advice(mp, sign.c, pk, true), m2 = rsa_chip.emit_advice(mp, sign.c, pk, false);
