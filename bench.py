@@ -265,8 +265,8 @@ def advice_bench(args):
     output is the 5-column advice image (what the reference writes cell by cell, main_gate.mul_add
     big_integer/chip.rs:408, range_chip.assign :590, :598, :880-885, is_equal_muled :851-893): chain kernel (no record planes) +
     assert_in_field witness and its rows + cells_kernel, which writes the pow rows directly from the operands.  The chain kernels of
-    call k + 1 run on a second stream next to the cells kernel of call k (two workspaces, two images; plain stream-ordered exports
-    and events -- no pipeline object).  roofline: cells_kernel, HBM-write bound, algorithmic bytes = the pow rows it writes
+    call k + 1 run next to the cells kernel of call k (two workspaces, two images): ONE export per call,
+    h2r_pipeline_modpow_public_key_advice (the pipeline owns the side streams and the events).  roofline: cells_kernel, HBM-write bound, algorithmic bytes = the pow rows it writes
     (12,078,240 B per RSA-2048 e = 65537 element)."""
     import ctypes
     env = DistEnv.from_environment(args.gpus, force=bool(os.environ.get("H2R_FORCE_DIST")))
@@ -291,7 +291,7 @@ def advice_bench(args):
     rows = int(L.h2r_modpow_public_key_advice_rows(chip._ctx, ctypes.byref(pl), sec))
     pow_rows = int(sec[1])
     elem_bytes = rows * 160
-    nimg = 2
+    nimg = int(os.environ.get("H2R_BENCH_ADV_DEPTH", "2"))   # image / workspace sets the calls rotate through (developer: 2..4)
     wss = [torch.zeros(chip.workspace_bytes(chunk, pl.num_mul_mods), dtype=torch.uint8, device=dev) for _ in range(nimg)]
     # Placement: like the record kernel's trace regions an image buffer has a store rate of its own, stable for
     # the life of the allocation -- 5.1-5.4, 6.1-6.3, 6.6-6.8 or 7.0-7.2 TB/s for the same launch, by buffer (profiles/r04_cells_placement.txt;
@@ -333,6 +333,9 @@ def advice_bench(args):
     # profiles/r04_advice_ab.txt: 1.955 against 1.989 ms per step; everything on one stream: 2.146).  Developer A/B:
     # H2R_BENCH_ADV=noprio | serial.
     adv_mode = os.environ.get("H2R_BENCH_ADV", "")
+    # default: ONE export per call, h2r_pipeline_modpow_public_key_advice (the pipeline owns the side streams and the events); the
+    # developer modes streams | noprio | serial compose the same thing here from plain exports, two torch streams and events
+    pipe = H.Pipeline(chip, nimg, 2) if adv_mode == "" else None
     s_chain = torch.cuda.Stream() if adv_mode == "noprio" else torch.cuda.Stream(priority=-1)
     s_cells = s_chain if adv_mode == "serial" else torch.cuda.Stream()
     chain_done = [torch.cuda.Event() for _ in range(nimg)]
@@ -340,8 +343,18 @@ def advice_bench(args):
     issued = [0]
     results = [None] * nimg
 
+    class _Res:     # what the post-run check reads of a call
+        pass
+
     def step():
         k = issued[0] % nimg
+        if pipe is not None:
+            with torch.cuda.stream(s_chain):
+                pipe.modpow_public_key_advice(x_dev, e, n_dev, wss[k], outs[k], sts[k], ifb[k], images[k].view(chunk, elem_bytes))
+            r = _Res(); r.status = sts[k]; r.value = outs[k]
+            results[k] = r
+            issued[0] += 1
+            return k
         with torch.cuda.stream(s_chain):
             if issued[0] >= nimg:
                 s_chain.wait_event(cells_done[k])        # the workspace / witness of call k - 2 have been consumed
@@ -378,6 +391,9 @@ def advice_bench(args):
     t0 = time.perf_counter()
     for _ in range(steps):
         last = step()
+    if pipe is not None:
+        with torch.cuda.stream(s_chain):
+            pipe.join()
     torch.cuda.synchronize()
     env.barrier()
     dt = env.max_over_ranks(time.perf_counter() - t0)
@@ -402,7 +418,12 @@ def advice_bench(args):
         "the timed advice image differs from the image of the records"
     if env.rank == 0:
         algo = chunk * pow_rows * 160
-        avg_s = (sum(cells_ms) / len(cells_ms)) / 1e3 if cells_ms else float("nan")
+        stamped_s = (sum(cells_ms) / len(cells_ms)) / 1e3 if cells_ms else float("nan")
+        # The pipelined export keeps TWO cells launches in flight (the pipeline's two side streams: call k + 1's starts as soon as its chains
+        # are done and fills what call k's tail leaves), so a launch's own duration counts the time it shares: the roofline takes the
+        # launches' PERIOD -- the timed region's wall time per launch, an upper bound of what one launch costs -- instead.
+        overlapped = pipe is not None
+        avg_s = (dt / steps) if overlapped else stamped_s
         achieved = algo / avg_s / 1e9 if cells_ms else None
         line = {
             "metric": "RSA-2048 pkcs1v15 witness assigns/sec" if bits == 2048 else "RSA-%d witness assigns/sec" % bits,
@@ -414,12 +435,18 @@ def advice_bench(args):
                        "path": "advice image",
                        "per_gpu_batch": chunk, "global_batch": global_batch, "calls_per_step": 1, "signatures_per_call": chunk,
                        "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world, "ranks": env.world,
-                       "pipeline": "chain kernels of call k+1 on a second stream next to cells_kernel of call k (2 workspaces, 2 images), stream-ordered exports + events",
+                       "pipeline": ("h2r_pipeline_modpow_public_key_advice: chain kernels of call k+1 on the caller's stream next to cells_kernel of call k on the "
+                                    "pipeline's side stream (2 workspaces, 2 images)") if pipe is not None else
+                                   "chain kernels of call k+1 on a second stream next to cells_kernel of call k (2 workspaces, 2 images), stream-ordered exports + events (H2R_BENCH_ADV=%s)" % adv_mode,
                        "untimed_clock_warmup_calls": ramp, "warmup_calls_total": 1 + ramp + warmup, "buffer_placement": placement},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
                          "traffic_source": "not measured", "kernel": "cells_kernel<%d>" % w, "launches_timed": len(cells_ms),
                          "signatures_per_launch": chunk, "avg_launch_ms": round(1e3 * avg_s, 4) if cells_ms else None,
+                         "timing": ("avg_launch_ms = the launches' period (timed wall time / launches): two cells launches are in flight at a time; "
+                                    "avg_launch_ms_in_flight = a launch's own start-to-end time (HIP events stamped by the dispatch)") if overlapped else
+                                   "per-launch HIP events stamped by the dispatch packets",
+                         "avg_launch_ms_in_flight": round(1e3 * stamped_s, 4) if (overlapped and cells_ms) else None,
                          "algorithmic_bytes_per_launch": algo,
                          "chain_kernel_avg_ms": round(sum(chain_ms) / len(chain_ms), 4) if chain_ms else None,
                          "in_field_rows_kernel_avg_ms": round(sum(emit_ms) / len(emit_ms), 4) if emit_ms else None},
@@ -452,10 +479,12 @@ def main():
                     help="calls per step = chunks of the GPU's shard (default 1 at --gpus 1: 1,024 signatures per GPU; 4 at --gpus > 1: 8,192 per GPU)")
     ap.add_argument("--workload", default="rsa2048_e65537", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline-depth", type=int, default=2, help="buffer sets the pipelined calls rotate through (2..4)")
-    ap.add_argument("--side-streams", type=int, default=1,
-                    help="streams the record kernels alternate between; 2 lets consecutive record kernels overlap "
-                         "(higher throughput, but each launch's duration then includes the overlap)")
+    ap.add_argument("--pipeline-depth", type=int, default=0, help="buffer sets the pipelined calls rotate through (2..4; default: 3 for the "
+                                                                    "RSA-2048 shape, 2 otherwise)")
+    ap.add_argument("--side-streams", type=int, default=0,
+                    help="streams the record kernels alternate between (default: 2 for the RSA-2048 shape, whose pipelined calls then go out as "
+                         "chain kernels on the caller's stream and record kernels alternating between two side streams -- call k + 1's record "
+                         "kernel starts while call k's tail drains; 1 otherwise: one launch per call, or one side stream)")
     ap.add_argument("--producers", type=int, default=1,
                     help="independent producers: P pipelines, each on a stream of its own with its own pipeline-depth buffer sets; the calls "
                          "alternate between them (one pipeline per producer thread is the C ABI's threading contract).  For latency-bound "
@@ -507,6 +536,12 @@ def main():
 
     env = DistEnv.from_environment(args.gpus, force=bool(os.environ.get("H2R_FORCE_DIST")))
     w, bits, e = WORKLOADS[args.workload]
+    # RSA-2048 (32 x 64-bit limbs): three buffer sets and two record streams select the library's overlapped two-queue form (h2r.h,
+    # h2r_pipeline_create_ex; same-box A/B against the one-launch step: tools/two_queue_ab.sh, profiles/r04_two_queue.txt)
+    if args.pipeline_depth == 0:
+        args.pipeline_depth = 3 if (w, bits) == (64, 2048) else 2
+    if args.side_streams == 0:
+        args.side_streams = 2 if (w, bits) == (64, 2048) else 1
     # developer: H2R_BENCH_ONE_GPU=1 runs every rank on GPU 0 over gloo -- the N > 1 code path (shards, gather, checks) on a
     # one-GPU box; not a measurement of anything
     one_gpu = bool(os.environ.get("H2R_BENCH_ONE_GPU"))
@@ -697,7 +732,12 @@ def main():
     # launch time is their distance / (calls - 1): the period of back-to-back launches, an upper bound of the kernel's own duration.
     span_ok = (not args.no_kernel_timing and not args.per_launch_timing and pipe is not None and producers == 1 and steps * chunks >= 2
                and warmup * chunks > 0 and len(w_step) == warmup * chunks)
-    if not span_ok:
+    # Record kernels alternating between two side streams (no step launches, one record launch per call in the warm-up): two of them are in
+    # flight at a time, so a launch's own duration counts the time it shares -- the roofline takes the launches' PERIOD (timed wall time /
+    # launches) instead, and the timed region carries no per-launch stamps at all.
+    overlap_ok = (not span_ok and not args.no_kernel_timing and not args.per_launch_timing and pipe is not None and producers == 1 and args.side_streams == 2
+                  and not w_step and warmup * chunks > 0 and len(w_trace) == warmup * chunks)
+    if not span_ok and not overlap_ok:
         _lib.profile_enable(0 if args.no_kernel_timing else n_prof)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     env.barrier()
@@ -719,6 +759,10 @@ def main():
         period_ms = ev0.elapsed_time(ev1) / (steps * chunks - 1)
         step_ms = [period_ms] * (steps * chunks - 1)
         trace_ms = [sum(w_trace) / len(w_trace)] if w_trace else []      # (the record kernel alone appears once, at the join: the warm-up's)
+        chain_ms = w_chain
+    elif overlap_ok:
+        step_ms = []
+        trace_ms = [1e3 * dt / (steps * chunks)] * (steps * chunks)
         chain_ms = w_chain
     else:
         trace_ms = _lib.profile_read(_lib.KERNEL_TRACE)
@@ -840,11 +884,14 @@ def main():
                                            "committed; PMC counters cannot be read from inside the bench process)",
                          "kernel": dom_name,
                          "launches_timed": len(dom_ms), "signatures_per_launch": round(per_launch_batch, 1),
-                         "timing": ("two HIP events on the launch stream over the timed region (behind the first call and behind the last step launch): "
+                         "timing": ("avg_launch_ms = the record launches' period (timed wall time / launches): the record kernels alternate between two side "
+                                    "streams and two are in flight at a time; avg_launch_ms_in_flight = a launch's own start-to-end time in the stamped warm-up steps") if overlap_ok else
+                                   ("two HIP events on the launch stream over the timed region (behind the first call and behind the last step launch): "
                                     "avg_launch_ms = the launches' period, an upper bound of the kernel's duration; per-launch dispatch stamps "
                                     "(which cost 6-7 us per step) only in the warm-up steps: avg_launch_ms_stamped_warmup") if span_ok else
                                    "per-launch HIP events stamped by the dispatch packets, in the timed region",
                          "avg_launch_ms_stamped_warmup": round(sum(w_step) / len(w_step), 4) if w_step else None,
+                         "avg_launch_ms_in_flight": round(sum(w_trace) / len(w_trace), 4) if (overlap_ok and w_trace) else None,
                          "launches_per_call": round(n_launches / (steps * chunks), 2),   # > 1: sub-batches of a large call, or segments of a long exponent
                          "avg_launch_ms": round(1e3 * avg_trace_s, 4) if dom_ms else None,
                          "algorithmic_bytes_per_launch": trace_bytes_per_launch,
@@ -853,7 +900,8 @@ def main():
             "whole_path_hbm_frac": round(global_batch * steps / dt * algo_bytes_per_assign / (env.world * HBM_PEAK_GBS * 1e9), 4),
         }
         if env.world == 1 and args.pmc_traffic == "auto" and dom_ms and per_launch_batch == chunk:
-            wl_args = ["--workload", args.workload, "--batch", str(chunk), "--chunks", str(chunks), "--pipeline-depth", str(args.pipeline_depth)]
+            wl_args = ["--workload", args.workload, "--batch", str(chunk), "--chunks", str(chunks), "--pipeline-depth", str(args.pipeline_depth),
+                       "--side-streams", str(args.side_streams)]
             wl_args += ["--verify"] if args.verify else []
             wl_args += ["--messages", str(args.messages)] if args.messages else []
             wl_args += ["--no-pipeline"] if args.no_pipeline else []

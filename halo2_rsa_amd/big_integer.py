@@ -725,6 +725,16 @@ class Pipeline:
                                                    status.data_ptr(), workspace.data_ptr(), self.chip._stream()),
               "h2r_pipeline_modpow_public_key")
 
+    def modpow_public_key_advice(self, x: AssignedInteger, e: int, n: AssignedInteger, workspace, out, status, in_field_buf, advice_out):
+        """The call WITHOUT records whose product is the element's advice image (h2r_pipeline_modpow_public_key_advice): chains, in-field
+        witness and in-field rows on the current stream, the pow rows (cells_kernel) on the pipeline's side stream next to the following
+        call's chains.  advice_out: uint8 [batch, rows * 160], complete after depth - 1 further calls or join()."""
+        eb = _e_bytes(e)
+        check(lib().h2r_pipeline_modpow_public_key_advice(self._p, x.data_ptr(), n.data_ptr(), eb, len(eb), x.batch, self.chip._flags(n, x.batch),
+                                                          in_field_buf.data_ptr(), out.data_ptr(), status.data_ptr(), workspace.data_ptr(),
+                                                          advice_out.data_ptr(), advice_out.shape[-1] if advice_out.dim() > 1 else advice_out.numel() // x.batch,
+                                                          self.chip._stream()), "h2r_pipeline_modpow_public_key_advice")
+
     def modpow_public_key_var(self, x: AssignedInteger, e: AssignedInteger, exp_limb_bits: int, n: AssignedInteger, trace_buf, workspace,
                               out, status, in_field_buf=None):
         """RSAPubE::Var: per-element exponents `e` ([batch, e_num_limbs] limbs); buffers sized by pow_var_layout."""

@@ -1671,7 +1671,13 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
     std::vector<u64> sizes; bool pace = false;
     const u32 nbits_all = e_limbs ? e_num_limbs * exp_limb_bits : eb.nbits;
     const u32 n_seg_single = assume_empty ? exp_segment_count(ctx, batch, nbits_all, trace && T, true) : 1;   // (a single stream-ordered call)
-    const bool as_steps = step_eligible(ctx, batch, trace, T) && n_seg_single <= 1;
+    // RSA-2048 on a pipeline created with TWO side streams and three or more buffer sets: the two-queue form -- chain kernels on the caller's
+    // stream, record kernels alternating between the side streams, so that call k + 1's record kernel starts while call k's tail drains --
+    // beats the one-launch step (same box, alternating: 5.41 / 5.41 M assigns/s against 5.18 / 5.32 M at 1,024 per call, 5.55-5.58 against
+    // 5.50-5.51 M at 2,048).  Every other step shape is chain-bound enough to lose that way (RSA-1024 9.4 against 12.4 M, RSA-3072 2.1
+    // against 2.5 M, RSA-4096 1.2 against 1.5 M; 128 x 32-bit limbs: the same): tools/two_queue_ab.sh, profiles/r04_two_queue.txt.
+    const bool overlap_records = ctx->layout.limb_width == 64 && ctx->L == 32 && p->aux[0] != p->aux[1] && p->depth >= 3 && knobs().pipe_step < 1;
+    const bool as_steps = step_eligible(ctx, batch, trace, T) && n_seg_single <= 1 && !overlap_records;
     if (p->pending && (!as_steps || p->pending_st != st)) {   // the records still owed go out alone, `st` behind them
         rc = pipeline_flush(p, st);
         if (rc) return rc;
@@ -3209,6 +3215,60 @@ int32_t h2r_modpow_public_key_emit_advice(const h2r_ctx *ctx, const h2r_pow_layo
                                    static_cast<u8 *>(advice_out) + sec[0] * ADVICE_ROW_BYTES, out_stride, stream);
     if (rc) return rc;
     return fork.join();
+} H2R_CATCH_STATUS
+
+// The same element, PIPELINED (see h2r_pipeline_create): the chains and the assert_in_field witness of call k and its in-field rows on the
+// caller's stream, its pow rows (cells_kernel, from the operands in the workspace) on a side stream of the pipeline, next to the chains
+// of call k + 1.  No records are written.  The moduli the cells kernel needs are copied into the workspace inside the call, so x and n
+// are read in `stream` order inside the call like every other pipelined form's inputs.
+int32_t h2r_pipeline_modpow_public_key_advice(h2r_pipeline *p, const void *x, const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch,
+                                              uint32_t flags, void *in_field_trace, void *out, uint8_t *status, void *workspace,
+                                              void *advice_out, uint64_t out_stride, h2r_stream_t stream) try {
+    if (!p || !x || !n || !e_le || !in_field_trace || !status || !workspace || !advice_out) return H2R_E_NULL;
+    const h2r_ctx *ctx = p->ctx;
+    h2r_pow_layout pl;
+    int32_t rc = h2r_pow_fixed_layout(ctx, e_le, e_len, &pl);
+    if (rc) return rc;
+    u64 sec[2];
+    const u64 rows = h2r_modpow_public_key_advice_rows(ctx, &pl, sec);
+    if (!rows) return H2R_E_UNSUPPORTED;
+    if (out_stride < rows * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
+    if (batch == 0) return H2R_OK;
+    H2R_ON_DEVICE(ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p->pending) {   // records still owed by a call of another form: they go out alone, `st` behind them
+        rc = pipeline_flush(p, st);
+        if (rc) return rc;
+    }
+    const u32 slot = p->k % p->depth;
+    p->done[slot] = DoneRef{};
+    rc = h2r_modpow_public_key_batch(ctx, x, n, e_le, e_len, batch, flags, nullptr, in_field_trace, out, status, workspace, stream);
+    if (rc) return rc;
+    // the elements' moduli, where the record writers of the other forms find them too (Workspace::off_n)
+    const h2r_layout &lo = ctx->layout;
+    const Workspace wp = workspace_plan(lo.limb_bytes, ctx->L, batch, pl.num_mul_mods ? pl.num_mul_mods : 1);
+    u8 *ws = reinterpret_cast<u8 *>(round_up(reinterpret_cast<u64>(workspace), 256));
+    const bool shared = (flags & H2R_F_SHARED_MODULUS) != 0;
+    HIP_TRY(hipMemcpyAsync(ws + wp.off_n, n, (shared ? 1ull : batch) * ctx->L * lo.limb_bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipEventRecord(p->chain_done[slot], st));
+    rc = h2r_fresh_op_emit_advice(ctx, FRESH_IS_IN_FIELD, (flags & H2R_F_SHARED_MODULUS) | H2R_ADVICE_ASSERT_ONE, x, n, nullptr, in_field_trace, 0, 0,
+                                  batch, status, advice_out, out_stride, stream);
+    if (rc) return rc;
+    hipStream_t side = p->aux[p->k & 1];
+    HIP_TRY(hipStreamWaitEvent(side, p->chain_done[slot], 0));
+    rc = h2r_pow_trace_emit_advice(ctx, &pl, ws + wp.off_n, (flags & H2R_F_SHARED_MODULUS) | H2R_ADVICE_DIRECT, nullptr, 0, workspace, batch, status,
+                                   static_cast<u8 *>(advice_out) + sec[0] * ADVICE_ROW_BYTES, out_stride, static_cast<h2r_stream_t>(side));
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(p->trace_done[slot], side));
+    p->done[slot] = DoneRef{p->trace_done[slot], 0, false};
+    p->done_stream[slot] = side;
+    p->k += 1;
+    // lazy join, as in the other forms: the NEXT call reuses the buffers of call k - depth
+    for (; p->joined + p->depth <= p->k; ++p->joined) {
+        rc = pipeline_wait_slot(p, p->joined % p->depth, st);
+        if (rc) return rc;
+    }
+    return H2R_OK;
 } H2R_CATCH_STATUS
 
 // ---- the hashed-message limbs of RSASignatureVerifier as advice rows (src/lib.rs:225-239) ---------------------------------

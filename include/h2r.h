@@ -267,6 +267,10 @@ int32_t h2r_modpow_public_key_var_batch(const h2r_ctx *ctx, const void *x, const
  *    walked as equal parts of at most 4,096, one launch each) whose
  *    workgroups run this call's chains and write this call's in-field witness and the PREVIOUS call's records; the
  *    last call's records go out alone at the join.  Everything is on the caller's stream, no side stream is involved.
+ *    EXCEPT RSA-2048 (32 x 64-bit limbs) on a pipeline created with side_streams = 2 and depth >= 3: those calls take the two-queue
+ *    form below with the record kernels alternating between the two side streams, so that call k + 1's record kernel starts while
+ *    call k's tail workgroups drain -- 5.40-5.47 M assigns/s against 5.2-5.3 M as one-launch steps at 1,024 per call (the other
+ *    step shapes are chain-bound enough to lose that way and keep the step whatever the pipeline's streams).
  *  - every other shape and size: the record-writing kernel runs on a side HIP stream the pipeline owns (created at the
  *    lowest stream priority so that it gets a hardware queue of its own), behind the call's chain kernel, next to the
  *    following call's chain kernel; the in-field witness kernel runs on `stream` right behind the chain kernel.
@@ -809,6 +813,16 @@ uint64_t h2r_modpow_public_key_advice_rows(const h2r_ctx *ctx, const h2r_pow_lay
 int32_t h2r_modpow_public_key_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *x, const void *n, uint32_t flags,
                                           const void *in_field_trace, const void *trace, const void *workspace, uint64_t batch,
                                           const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream);
+/* Pipelined form of the two calls above for a fixed exponent (see h2r_pipeline_create): h2r_modpow_public_key_batch WITHOUT records --
+ * the chains, `out`, `status`, the assert_in_field witness -- and the element's in-field rows on `stream`; its pow rows (cells_kernel,
+ * H2R_ADVICE_DIRECT) on a side stream of the pipeline, next to the chains of the following call.  The IMAGE follows the pipeline's join
+ * rule (complete, in `stream` order, once `depth` - 1 further pipelined calls have returned or after h2r_pipeline_join); `out` and `status`
+ * are stream-ordered as usual; x and n are read inside the call (the moduli are copied into the workspace).  Consecutive calls rotate
+ * through `depth` sets of in_field_trace / out / status / workspace / advice_out.  This is what `bench.py --advice` measures
+ * (RSA-2048, 1,024 per call: 0.5 M elements/s of 12.3 MB each, the cells kernel at 0.79-0.82 of the HBM peak). */
+int32_t h2r_pipeline_modpow_public_key_advice(h2r_pipeline *p, const void *x, const void *n, const uint8_t *e_le_bytes, size_t e_len,
+                                              uint64_t batch, uint32_t flags, void *in_field_trace, void *out, uint8_t *status,
+                                              void *workspace, void *advice_out, uint64_t out_stride, h2r_stream_t stream);
 uint32_t h2r_advice_rows(const h2r_ctx *ctx);
 int32_t h2r_mul_mod_emit_advice(const h2r_ctx *ctx, const void *a, const void *b, const void *n, uint32_t flags,
                                 const void *trace, uint64_t batch, const uint8_t *status, void *advice_out,

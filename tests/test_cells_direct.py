@@ -187,6 +187,60 @@ def test_modpow_public_key_element_without_records(H, golden):
     assert np.array_equal(full.emit_modpow_advice(direct=True).cpu().numpy()[:4], img[:4])
 
 
+def test_pipelined_modpow_advice_calls(H, golden):
+    """h2r_pipeline_modpow_public_key_advice: five pipelined calls over two buffer sets (different inputs per call, one element not in the
+    field, one call with ONE modulus for the whole batch), inputs overwritten right after each call returns -- every image equals the
+    image of a plain call on the same inputs; an element with a status keeps its bytes."""
+    chip = H.BigIntChip(64, 2048)
+    rng = random.Random(0x68327273 + 46)
+    B, depth = 24, 2
+    pl = chip.pow_fixed_layout(65537)
+    sec = (ctypes.c_uint64 * 2)()
+    from halo2_rsa_amd._lib import lib
+    rows = int(lib().h2r_modpow_public_key_advice_rows(chip._ctx, ctypes.byref(pl), sec))
+    ifs = chip.in_field_layout()[0]
+    sets = [dict(ws=torch.empty(chip.workspace_bytes(B, pl.num_mul_mods), dtype=torch.uint8, device="cuda"),
+                 out=torch.zeros((B, chip.num_limbs), dtype=chip.torch_dtype, device="cuda"), st=torch.zeros(B, dtype=torch.uint8, device="cuda"),
+                 inf=torch.zeros(B * ifs, dtype=torch.uint8, device="cuda"), img=torch.empty((B, rows * 160), dtype=torch.uint8, device="cuda"))
+            for _ in range(depth)]
+    pipe = H.Pipeline(chip, depth, 2)
+    calls, got = [], []
+    x_stage = n_stage = None
+    for k in range(5):
+        shared = k == 3
+        N = [rand_modulus(rng, 2048) for _ in range(1 if shared else B)]
+        X = [rng.randrange(N[0] if shared else N[i]) for i in range(B)]
+        if k == 1:
+            X[5] = N[5] + 1
+        calls.append((X, N))
+        x_new, n_new = chip.assign_integer(X), chip.assign_integer(N)
+        if x_stage is not None and x_stage.limbs_dev.shape == x_new.limbs_dev.shape and n_stage.limbs_dev.shape == n_new.limbs_dev.shape:
+            x_stage.limbs_dev.copy_(x_new.limbs_dev); n_stage.limbs_dev.copy_(n_new.limbs_dev)     # a producer refilling its staging buffers
+        else:
+            x_stage, n_stage = x_new, n_new
+        s = sets[k % depth]
+        if k >= depth:
+            got.append((k - depth, s["img"].clone(), s["st"].clone()))     # (stream-ordered behind the join the previous call made)
+        s["img"].fill_(0x5A)
+        pipe.modpow_public_key_advice(x_stage, 65537, n_stage, s["ws"], s["out"], s["st"], s["inf"], s["img"])
+    pipe.join()
+    for k in range(5 - depth, 5):
+        got.append((k, sets[k % depth]["img"].clone(), sets[k % depth]["st"].clone()))
+    pipe.close()
+    torch.cuda.synchronize()
+    assert sorted(g[0] for g in got) == list(range(5))
+    for k, img, st in got:
+        X, N = calls[k]
+        plain = chip.pow_mod_fixed_exp(chip.assign_integer(X), 65537, chip.assign_integer(N), want_trace=False, check_in_field=True,
+                                       workspace=torch.empty(chip.workspace_bytes(B, pl.num_mul_mods), dtype=torch.uint8, device="cuda"))
+        want = torch.full_like(img, 0x5A)
+        plain.emit_modpow_advice(out=want)
+        assert torch.equal(st, plain.status), k
+        assert torch.equal(img, want), k
+        if k == 1:
+            assert int(st[5]) == H.H2R_E_NOT_IN_FIELD and bool((img[5] == 0x5A).all())
+
+
 def test_verify_element_direct(H, golden):
     """h2r_verify_emit_advice with H2R_ADVICE_DIRECT: the pow section written from the operands, the whole element unchanged."""
     rsa = H.RSAChip(2048, 5)
