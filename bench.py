@@ -31,6 +31,12 @@ import time
 if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
     os.environ.pop("NCCL_DEBUG")
 
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), handed out in creation order, and kernels of two
+# streams that share a queue do not overlap: the pipeline's side streams then sometimes land behind torch's or RCCL's (under torchrun the
+# overlapped RSA-2048 form ran at 4.8 M assigns/s instead of 5.5 M on every run, a plain process now and then at 5.3 instead of 5.45 M).
+# Eight queues make room (same-box A/B: profiles/r04_two_queue.txt).  The runtime reads the variable when it initialises: before `import torch`.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

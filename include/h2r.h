@@ -270,7 +270,11 @@ int32_t h2r_modpow_public_key_var_batch(const h2r_ctx *ctx, const void *x, const
  *    EXCEPT RSA-2048 (32 x 64-bit limbs) on a pipeline created with side_streams = 2 and depth >= 3: those calls take the two-queue
  *    form below with the record kernels alternating between the two side streams, so that call k + 1's record kernel starts while
  *    call k's tail workgroups drain -- 5.40-5.47 M assigns/s against 5.2-5.3 M as one-launch steps at 1,024 per call (the other
- *    step shapes are chain-bound enough to lose that way and keep the step whatever the pipeline's streams).
+ *    step shapes are chain-bound enough to lose that way and keep the step whatever the pipeline's streams).  The overlap needs the
+ *    caller's stream and the two side streams on three different HARDWARE queues: HIP hands a process's streams GPU_MAX_HW_QUEUES
+ *    queues (default 4) in creation order, so a host that also runs RCCL or many streams of its own should export
+ *    GPU_MAX_HW_QUEUES=8 before the runtime initialises (4.8 M against 5.6 M assigns/s per GPU under torchrun without it:
+ *    profiles/r04_two_queue.txt), or create the pipeline with one side stream (the one-launch step: 5.5 M).
  *  - every other shape and size: the record-writing kernel runs on a side HIP stream the pipeline owns (created at the
  *    lowest stream priority so that it gets a hardware queue of its own), behind the call's chain kernel, next to the
  *    following call's chain kernel; the in-field witness kernel runs on `stream` right behind the chain kernel.
