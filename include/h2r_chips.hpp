@@ -706,6 +706,20 @@ class Pipeline {
                                              in_field ? in_field->get() : nullptr, b.powed.get(),
                                              static_cast<uint8_t *>(b.status.get()), b.workspace.get(), stream), "h2r_pipeline_modpow_public_key");
     }
+    // The same call WITHOUT records whose product is the element's advice image ([assert_in_field rows] [pow rows], 160 bytes per row:
+    // RSAChip::advice_rows(ModpowResult) rows per element): chains, in-field witness and in-field rows on `stream`, the pow rows
+    // (cells_kernel) on the pipeline's side streams next to the following call's chains.  `advice` is complete after depth - 1 further
+    // calls or join().  in_field: batch * h2r_fresh_op_layout(H2R_OP_IS_IN_FIELD) stride bytes.
+    void modpow_public_key_advice(const AssignedInteger &x, const AssignedRSAPublicKey &pk, Buffers &b, DeviceBuffer &in_field, DeviceBuffer &advice,
+                                  uint64_t advice_stride, hipStream_t stream = nullptr) {
+        auto *f = std::get_if<RSAPubE::Fix>(&pk.e);
+        if (!f) throw Error(H2R_E_UNSUPPORTED, "Pipeline::modpow_public_key_advice (takes RSAPubE::Fix)");
+        const size_t batch = x.batch();
+        check(h2r_pipeline_modpow_public_key_advice(p_, x.data(), pk.n.data(), f->e_le.data(), f->e_le.size(), batch,
+                                                    (pk.n.batch() == 1 && batch != 1) ? H2R_F_SHARED_MODULUS : 0u, in_field.get(), b.powed.get(),
+                                                    static_cast<uint8_t *>(b.status.get()), b.workspace.get(), advice.get(), advice_stride, stream),
+              "h2r_pipeline_modpow_public_key_advice");
+    }
     void join(hipStream_t stream = nullptr) { check(h2r_pipeline_join(p_, stream), "h2r_pipeline_join"); }
     // an element's whole verify witness in the reference's order (after join() + synchronisation)
     std::vector<uint8_t> flatten(const Buffers &b, size_t elem) const {

@@ -173,6 +173,20 @@ int main(int argc, char **argv) {
         // the pow rows of both elements are the same rows (same x = sig, same n, same e)
         for (size_t i = 0; i < B; ++i)
             REQUIRE(!std::memcmp(ma.data() + (i * (1532 + 75489) + 1532) * 160, ia.data() + (i * rows + 1 + 1532) * 160, 75489ull * 160));
+        // ... and the pipelined form of it: three calls over two buffer sets and two side streams, every image = the plain one
+        {
+            Pipeline apipe(rsa_chip, 2, 2);
+            const std::vector<uint8_t> e65537 = {0x01, 0x00, 0x01};
+            Pipeline::Buffers ab[2] = {apipe.make_buffers(B, e65537), apipe.make_buffers(B, e65537)};
+            uint64_t es = 0;
+            REQUIRE(h2r_fresh_op_layout(bigint_chip.ctx(), H2R_OP_IS_IN_FIELD, &es, nullptr, nullptr) == H2R_OK);
+            const uint64_t stride = (1532 + 75489) * (uint64_t)H2R_ADVICE_ROW_BYTES;
+            DeviceBuffer inf2[2] = {DeviceBuffer(B * es), DeviceBuffer(B * es)}, adv[2] = {DeviceBuffer(B * stride), DeviceBuffer(B * stride)};
+            for (int k = 0; k < 3; ++k) apipe.modpow_public_key_advice(sign.c, pk, ab[k & 1], inf2[k & 1], adv[k & 1], stride);
+            apipe.join();
+            REQUIRE(hipDeviceSynchronize() == hipSuccess);
+            for (int s2 = 0; s2 < 2; ++s2) { adv[s2].download(mb.data(), mb.size()); REQUIRE(ma == mb); }
+        }
         BatchResult pw = bigint_chip.pow_mod_fixed_exp(sign.c, {0x01, 0x00, 0x01}, pk.n);
         REQUIRE(bigint_chip.advice_rows(pw) == 75489);
         DeviceBuffer p1 = bigint_chip.emit_advice(pw, pk.n), p2 = bigint_chip.emit_advice(pw, pk.n, true);
