@@ -742,7 +742,9 @@ def main():
     # flight at a time, so a launch's own duration counts the time it shares -- the roofline takes the launches' PERIOD (timed wall time /
     # launches) instead, and the timed region carries no per-launch stamps at all.
     overlap_ok = (not span_ok and not args.no_kernel_timing and not args.per_launch_timing and pipe is not None and producers == 1 and args.side_streams == 2
-                  and not w_step and warmup * chunks > 0 and len(w_trace) == warmup * chunks)
+                  and not w_step and warmup * chunks > 0 and len(w_trace) >= warmup * chunks)
+    # (record launches per call, from the warm-up: 1, or more where the library walks a large call as sub-batches)
+    launches_per_call_w = len(w_trace) / float(warmup * chunks) if (overlap_ok and warmup * chunks) else 1.0
     if not span_ok and not overlap_ok:
         _lib.profile_enable(0 if args.no_kernel_timing else n_prof)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -768,7 +770,8 @@ def main():
         chain_ms = w_chain
     elif overlap_ok:
         step_ms = []
-        trace_ms = [1e3 * dt / (steps * chunks)] * (steps * chunks)
+        n_rec = max(1, int(round(steps * chunks * launches_per_call_w)))
+        trace_ms = [1e3 * dt / n_rec] * n_rec
         chain_ms = w_chain
     else:
         trace_ms = _lib.profile_read(_lib.KERNEL_TRACE)

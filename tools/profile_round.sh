@@ -6,8 +6,8 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o r -
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_serial -o r -- python $R/bench.py $ARGS --no-pipeline > $O/kt_serial.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_w -o r -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --pmc-traffic off --no-pipeline > $O/pmc_w.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_r -o r -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --pmc-traffic off --no-pipeline > $O/pmc_r.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_step_w -o r -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --pmc-traffic off > $O/pmc_step_w.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_step_r -o r -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --pmc-traffic off > $O/pmc_step_r.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_step_w -o r -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --pmc-traffic off --pipeline-depth 2 --side-streams 1 > $O/pmc_step_w.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_step_r -o r -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --pmc-traffic off --pipeline-depth 2 --side-streams 1 > $O/pmc_step_r.log 2>&1
 # the device-side flatten and the advice image of a config-2 trace: kernel stats + PMC passes
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_emit -o r -- python $R/tools/emit_timing.py 1024 rsa2048 > $O/kt_emit.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_emit_w -o r -- python $R/tools/emit_timing.py 1024 rsa2048 0 noadvice > /dev/null 2>&1
