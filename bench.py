@@ -12,10 +12,16 @@ is already resident in HBM.
     configuration broadcast before and the result all-gather after the timed region (rank 0 checks
     samples of EVERY shard against pow()), plus the barrier / MAX-reduce that brackets the timing.
 
+The calls are pipelined (h2r_pipeline_*): RSA-2048's chain kernels on the caller's stream, its record kernels alternating between
+two side streams of the pipeline over three buffer sets (call k + 1's record kernel starts while call k's tail drains); the other
+shapes one launch per call (step_kernel: records of call k + chains of call k + 1).  --pipeline-depth / --side-streams select the form.
+  --advice: the prover-consumable witness as the product (h2r_pipeline_modpow_public_key_advice; roofline on cells_kernel).
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (trace_kernel, HBM-write bound): algorithmic bytes per launch
-                  / average launch duration measured with HIP events on the launch stream during
-                  the timed steps.
+  roofline     -- the dominant kernel (trace_kernel / step_kernel / cells_kernel, HBM-write bound): algorithmic bytes per launch /
+                  average launch time -- for launches that overlap on two side streams their PERIOD (timed wall time / launches;
+                  avg_launch_ms_in_flight carries a launch's own duration from HIP events stamped by the dispatch), for the one-launch
+                  steps the distance of two HIP events on the launch stream / launches, with --per-launch-timing per-launch HIP events.
   cpu_baseline -- the CPU oracle ("port" of the reference's path, oracle/h2r_oracle.c) timed on this
                   host's cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
