@@ -900,7 +900,9 @@ def main():
                          "kernel": dom_name,
                          "launches_timed": len(dom_ms), "signatures_per_launch": round(per_launch_batch, 1),
                          "timing": ("avg_launch_ms = the record launches' period (timed wall time / launches): the record kernels alternate between two side "
-                                    "streams and two are in flight at a time; avg_launch_ms_in_flight = a launch's own start-to-end time in the stamped warm-up steps") if overlap_ok else
+                                    "streams and two are in flight at a time; avg_launch_ms_in_flight = a launch's own start-to-end time in the stamped warm-up steps, while the "
+                                    "pipeline fills (at steady state two launches share the device throughout and a launch lasts about two periods: the kernel trace "
+                                    "under rocprofv3, profiles/r04_timeline_pipeline.txt, shows duration, overlap and period per launch)") if overlap_ok else
                                    ("two HIP events on the launch stream over the timed region (behind the first call and behind the last step launch): "
                                     "avg_launch_ms = the launches' period, an upper bound of the kernel's duration; per-launch dispatch stamps "
                                     "(which cost 6-7 us per step) only in the warm-up steps: avg_launch_ms_stamped_warmup") if span_ok else
