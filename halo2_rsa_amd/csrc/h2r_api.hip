@@ -1676,7 +1676,8 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
     // beats the one-launch step (same box, alternating: 5.41 / 5.41 M assigns/s against 5.18 / 5.32 M at 1,024 per call, 5.55-5.58 against
     // 5.50-5.51 M at 2,048).  Every other step shape is chain-bound enough to lose that way (RSA-1024 9.4 against 12.4 M, RSA-3072 2.1
     // against 2.5 M, RSA-4096 1.2 against 1.5 M; 128 x 32-bit limbs: the same): tools/two_queue_ab.sh, profiles/r04_two_queue.txt.
-    const bool overlap_records = ctx->layout.limb_width == 64 && ctx->L == 32 && p->aux[0] != p->aux[1] && p->depth >= 3 && knobs().pipe_step < 1;
+    // (calls of up to 2,048: at 4,096 per call one launch has little boundary left to hide and the step is ahead again, 5.37-5.42 against 5.27-5.33 M)
+    const bool overlap_records = ctx->layout.limb_width == 64 && ctx->L == 32 && batch <= 2048 && p->aux[0] != p->aux[1] && p->depth >= 3 && knobs().pipe_step < 1;
     const bool as_steps = step_eligible(ctx, batch, trace, T) && n_seg_single <= 1 && !overlap_records;
     if (p->pending && (!as_steps || p->pending_st != st)) {   // the records still owed go out alone, `st` behind them
         rc = pipeline_flush(p, st);
