@@ -19,6 +19,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <array>
 #include <variant>
 #include <vector>
 
@@ -338,6 +339,31 @@ class BigIntChip {
               "h2r_pow_trace_emit_advice");
         hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
         return out;
+    }
+    // ---- the placement of an op's cells in the five columns as DATA (h2r.h "LAYOUT": third-party maingate shapes, restated) ----
+    // a layout in which the given row kinds have their five documented cells in the given physical columns (identity elsewhere);
+    // throws H2R_E_SHAPE for a table that would change what a row means
+    h2r_advice_layout advice_layout(const std::vector<uint8_t> &kinds = {}, const std::vector<std::array<uint8_t, 5>> &column_of = {}) const {
+        h2r_advice_layout lay;
+        if (kinds.empty()) { check(h2r_advice_layout_default(&lay), "h2r_advice_layout_default"); return lay; }
+        if (kinds.size() != column_of.size()) throw Error(H2R_E_SHAPE, "advice_layout");
+        check(h2r_advice_layout_custom(ctx_, kinds.data(), reinterpret_cast<const uint8_t (*)[5]>(column_of.data()), (uint32_t)kinds.size(), &lay),
+              "h2r_advice_layout_custom");
+        return lay;
+    }
+    // permute an emitted image (batch elements of `rows` rows whose kinds are `kinds`, element stride `stride`) to the layout, in place
+    void apply_layout(const h2r_advice_layout &lay, const std::vector<uint8_t> &kinds, DeviceBuffer &image, uint64_t stride, size_t batch) const {
+        DeviceBuffer kd(kinds.size());
+        kd.upload(kinds.data(), kinds.size());
+        check(h2r_advice_apply_layout(ctx_, &lay, static_cast<const uint8_t *>(kd.get()), kinds.size(), image.get(), stride, batch, nullptr, nullptr),
+              "h2r_advice_apply_layout");
+        hip_check(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    }
+    // the fixed (selector) row of a kind under a layout
+    h2r_fixed_row advice_fixed_row(uint32_t kind, const h2r_advice_layout &lay) const {
+        h2r_fixed_row f;
+        check(h2r_advice_fixed_row_ex(ctx_, nullptr, &lay, kind, &f), "h2r_advice_fixed_row_ex");
+        return f;
     }
     // the equality (copy) constraints of one mul_mod record's rows: (row, col) <- (src_row, src_col) | limb src_col of operand a / b / n
     std::vector<h2r_copy> advice_copy_map() const {

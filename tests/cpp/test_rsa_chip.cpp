@@ -146,6 +146,24 @@ int main(int argc, char **argv) {
             }
         }
         REQUIRE(inside > 0 && outside == 3u * 32 * 32);   // x_j, y_{i-j} of both muls: 2 L^2 from a, b (here a = b) and L^2 from n
+        // the placement as data: mul_add's (a, b) <-> (c, d) through the descriptor -- the image's MUL_ADD rows trade their column pairs, every
+        // other row is untouched, the selectors follow; a table that splits the product over the gate's pairs is refused
+        const std::vector<uint8_t> kinds = bigint_chip.advice_row_kinds(r);
+        h2r_advice_layout lay = bigint_chip.advice_layout({(uint8_t)H2R_ROW_MUL_ADD}, {{2, 3, 0, 1, 4}});
+        bigint_chip.apply_layout(lay, kinds, img_d, rows * H2R_ADVICE_ROW_BYTES, 1);
+        img_d.download(ib.data(), ib.size());
+        size_t moved = 0;
+        for (uint64_t row = 0; row < rows; ++row) {
+            const uint8_t *x = ia.data() + row * 160, *y = ib.data() + row * 160;
+            if (kinds[row] == H2R_ROW_MUL_ADD) { REQUIRE(!std::memcmp(y + 64, x, 64) && !std::memcmp(y, x + 64, 64) && !std::memcmp(y + 128, x + 128, 32)); ++moved; }
+            else REQUIRE(!std::memcmp(x, y, 160));
+        }
+        REQUIRE(moved == 2u * 32 * 32);
+        const h2r_fixed_row f0 = bigint_chip.advice_fixed_row(H2R_ROW_MUL_ADD, bigint_chip.advice_layout()), f1 = bigint_chip.advice_fixed_row(H2R_ROW_MUL_ADD, lay);
+        REQUIRE(f0.s_mul_ab[0] == 1 && f0.s_mul_cd[0] == 0 && f1.s_mul_ab[0] == 0 && f1.s_mul_cd[0] == 1);
+        bool refused = false;
+        try { bigint_chip.advice_layout({(uint8_t)H2R_ROW_MUL_ADD}, {{0, 2, 1, 3, 4}}); } catch (const Error &e) { refused = e.code != H2R_OK; }
+        REQUIRE(refused);
     }
     // one verify_pkcs1v15_signature element and one modpow_public_key element as cells (src/chip.rs:128-199, :99-114)
     {
