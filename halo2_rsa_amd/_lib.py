@@ -24,6 +24,14 @@ class H2RParams(ctypes.Structure):
                 ("device", ctypes.c_int32)]
 
 
+class H2RAdviceRepr(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("flags", ctypes.c_uint32), ("col_stride", ctypes.c_uint64)]
+
+
+H2R_ADVICE_COLUMNS, H2R_ADVICE_MONTGOMERY = 0x400, 0x800
+H2R_VERSION = 4
+
+
 class H2RLayout(ctypes.Structure):
     _fields_ = [("limb_width", ctypes.c_uint32), ("num_limbs", ctypes.c_uint32), ("num_cols", ctypes.c_uint32),
                 ("limb_bytes", ctypes.c_uint32), ("wide_bytes", ctypes.c_uint32), ("carry_bytes", ctypes.c_uint32),
@@ -87,7 +95,7 @@ class H2RError(RuntimeError):
 
 
 _lib = None
-EXPORTS = ["h2r_ctx_create", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_rsa_compute_range_lens",
+EXPORTS = ["h2r_ctx_create", "h2r_ctx_create_ex", "h2r_ctx_advice_repr", "h2r_abi_version", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_rsa_compute_range_lens",
            "h2r_trace_layout", "h2r_pow_fixed_layout", "h2r_pow_var_layout", "h2r_workspace_bytes",
            "h2r_mul_mod_batch", "h2r_square_mod_batch", "h2r_pow_mod_fixed_exp_batch", "h2r_pow_mod_batch",
            "h2r_modpow_public_key_batch", "h2r_modpow_public_key_var_batch", "h2r_pipeline_create", "h2r_pipeline_create_ex", "h2r_pipeline_destroy",
@@ -145,6 +153,10 @@ def lib():
     L = ctypes.CDLL(path)
     vp, u64, u32, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int32
     L.h2r_ctx_create.argtypes = [ctypes.POINTER(H2RParams), ctypes.POINTER(vp)]
+    L.h2r_ctx_create_ex.argtypes = [ctypes.POINTER(H2RParams), ctypes.POINTER(H2RAdviceRepr), ctypes.POINTER(vp)]
+    L.h2r_ctx_advice_repr.argtypes = [vp, ctypes.POINTER(H2RAdviceRepr)]
+    L.h2r_abi_version.argtypes = []
+    L.h2r_abi_version.restype = u32
     L.h2r_ctx_destroy.argtypes = [vp]
     L.h2r_ctx_destroy.restype = None
     L.h2r_compute_range_lens.argtypes = [u32, u32, ctypes.POINTER(u32), ctypes.POINTER(u32)]

@@ -234,12 +234,13 @@ class BatchResult:
             nrows = int(lib().h2r_pow_advice_rows(chip._ctx, ctypes.byref(pl)))
         else:
             nrows = T * rows
+        ib = chip.image_bytes(nrows)
         if out is None:
-            out = torch.empty((batch, nrows * 160), dtype=torch.uint8, device=dev)
+            out = torch.empty((batch, ib), dtype=torch.uint8, device=dev)
         else:
-            if out.dtype != torch.uint8 or out.numel() < batch * nrows * 160 or not out.is_contiguous():
+            if out.dtype != torch.uint8 or out.numel() < batch * ib or not out.is_contiguous():
                 raise ValueError("emit_advice: out must be a contiguous uint8 buffer of at least batch * rows * 160 bytes")
-            out = out.view(-1)[:batch * nrows * 160].view(batch, nrows * 160)
+            out = out.view(-1)[:batch * ib].view(batch, ib)
         if kind == "mul_mod":
             check(lib().h2r_mul_mod_emit_advice(chip._ctx, a.data_ptr(), b.data_ptr(), n.data_ptr(), flags, self.trace.buf.data_ptr(), batch,
                                                 self.status.data_ptr(), out.data_ptr(), out.shape[1], chip._stream()), "h2r_mul_mod_emit_advice")
@@ -263,12 +264,13 @@ class BatchResult:
         if direct is None:
             direct = self.trace is None
         nrows = int(lib().h2r_modpow_public_key_advice_rows(chip._ctx, ctypes.byref(pl), None))
+        ib = chip.image_bytes(nrows)
         if out is None:
-            out = torch.empty((batch, nrows * 160), dtype=torch.uint8, device=x.limbs_dev.device)
+            out = torch.empty((batch, ib), dtype=torch.uint8, device=x.limbs_dev.device)
         else:
-            if out.dtype != torch.uint8 or out.numel() < batch * nrows * 160 or not out.is_contiguous():
+            if out.dtype != torch.uint8 or out.numel() < batch * ib or not out.is_contiguous():
                 raise ValueError("emit_modpow_advice: out must be a contiguous uint8 buffer of at least batch * rows * 160 bytes")
-            out = out.view(-1)[:batch * nrows * 160].view(batch, nrows * 160)
+            out = out.view(-1)[:batch * ib].view(batch, ib)
         flags = chip._flags(n, batch) | (_lib.H2R_ADVICE_DIRECT if direct else 0)
         check(lib().h2r_modpow_public_key_emit_advice(chip._ctx, ctypes.byref(pl), x.data_ptr(), n.data_ptr(), flags, self.in_field.buf.data_ptr(),
                                                       self.trace.buf.data_ptr() if (self.trace is not None and not direct) else None,
@@ -287,12 +289,18 @@ class BigIntChip:
 
     NUM_LOOKUP_LIMBS = 8  # big_integer/chip.rs:1163
 
-    def __init__(self, limb_width: int, bits_len: int, field: str = "bn254_fr", device: int = 0):
-        """BigIntChip::new (big_integer/chip.rs:1174-1185); raises where the reference asserts."""
+    def __init__(self, limb_width: int, bits_len: int, field: str = "bn254_fr", device: int = 0, columns: bool = False,
+                 montgomery: bool = False, col_stride: int = 0):
+        """BigIntChip::new (big_integer/chip.rs:1174-1185); raises where the reference asserts.
+        columns / montgomery / col_stride: the representation of the advice images and of every field element that crosses the
+        boundary (h2r_advice_repr): planar column vectors instead of 160-byte rows, x * R mod p instead of canonical integers."""
         self.limb_width, self.bits_len, self.device = limb_width, bits_len, device
+        self.columns, self.montgomery, self.col_stride = bool(columns), bool(montgomery), int(col_stride)
         self._ctx = ctypes.c_void_p()
         p = H2RParams(limb_width, bits_len, _lib.FIELDS[field], device)
-        check(lib().h2r_ctx_create(ctypes.byref(p), ctypes.byref(self._ctx)), "BigIntChip::new")
+        rp = _lib.H2RAdviceRepr(ctypes.sizeof(_lib.H2RAdviceRepr), (_lib.H2R_ADVICE_COLUMNS if columns else 0) |
+                                (_lib.H2R_ADVICE_MONTGOMERY if montgomery else 0), col_stride)
+        check(lib().h2r_ctx_create_ex(ctypes.byref(p), ctypes.byref(rp), ctypes.byref(self._ctx)), "BigIntChip::new")
         self.num_limbs = bits_len // limb_width
         self.layout = H2RLayout()
         check(lib().h2r_trace_layout(self._ctx, ctypes.byref(self.layout)), "h2r_trace_layout")
@@ -309,6 +317,15 @@ class BigIntChip:
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def image_bytes(self, rows: int) -> int:
+        """Bytes of one element's advice image of `rows` rows in the chip's representation: rows * 160 (row-major, or planar with
+        the five columns packed), 5 * col_stride for planar columns of a fixed stride."""
+        if self.columns and self.col_stride:
+            if rows * 32 > self.col_stride:
+                raise ValueError("image_bytes: %d rows do not fit a column of %d bytes" % (rows, self.col_stride))
+            return 5 * self.col_stride
+        return rows * 160
 
     @staticmethod
     def compute_range_lens(limb_width: int, num_limbs: int):
@@ -554,7 +571,7 @@ class BigIntChip:
         rows = int(lib().h2r_fresh_op_advice_rows(self._ctx, op, fl))
         if rows == 0:
             check(_lib.H2R_E_UNSUPPORTED, "h2r_fresh_op_advice_rows")
-        out = torch.empty((batch, rows * 160), dtype=torch.uint8, device=trace.device)
+        out = torch.empty((batch, self.image_bytes(rows)), dtype=torch.uint8, device=trace.device)
         check(lib().h2r_fresh_op_emit_advice(self._ctx, op, fl, a.data_ptr(), b.data_ptr() if b is not None else None,
                                              n.data_ptr() if n is not None else None, trace.data_ptr(), first_off, elem_stride, batch,
                                              status.data_ptr() if status is not None else None, out.data_ptr(), out.shape[1],

@@ -182,6 +182,9 @@ struct h2r_ctx {
     u8 refresh_inc[2 * 128 + 8]; u32 refresh_nf;
     u64 field_p[4];   // the field modulus (a_b encoding, chip.rs:859)
     FieldConsts fc;   // its Montgomery constants (lookup compression, is_zero's inverse witness)
+    h2r_advice_repr repr;      // representation of every field element that crosses the boundary (h2r_ctx_create_ex; default: row-major, canonical)
+    MontK mk;                  // the short Montgomery multipliers of the field (H2R_ADVICE_MONTGOMERY)
+    MontK *mk_dev = nullptr;
     u32 num_cus, lds_per_cu;   // of the ctx's device
     // the plain (stream-ordered) pow exports overlap chain and record kernels INSIDE a large call through this pipeline
     // (created on first use; calls on one ctx from several threads take turns queueing)
@@ -550,9 +553,24 @@ void in_field_sections(const AuxGeom &g, F &&emit) { fresh_sections(g, FRESH_IS_
 
 extern "C" {
 
-int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) try {
+uint32_t h2r_abi_version(void) { return H2R_VERSION; }
+
+int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) try { return h2r_ctx_create_ex(params, nullptr, out); } H2R_CATCH_STATUS
+
+int32_t h2r_ctx_advice_repr(const h2r_ctx *ctx, h2r_advice_repr *out) try {
+    if (!ctx || !out) return H2R_E_NULL;
+    *out = ctx->repr;
+    return H2R_OK;
+} H2R_CATCH_STATUS
+
+int32_t h2r_ctx_create_ex(const h2r_params *params, const h2r_advice_repr *repr, h2r_ctx **out) try {
     if (!params || !out) return H2R_E_NULL;
     *out = nullptr;
+    if (repr) {
+        if (repr->struct_size != sizeof(h2r_advice_repr)) return H2R_E_UNSUPPORTED;   // a caller built against another header
+        if ((repr->flags & ~(H2R_ADVICE_COLUMNS | H2R_ADVICE_MONTGOMERY)) || (repr->col_stride & 15)) return H2R_E_SHAPE;
+        if (repr->col_stride && !(repr->flags & H2R_ADVICE_COLUMNS)) return H2R_E_SHAPE;
+    }
     const u32 w = params->limb_width;
     if (w == 0 || params->bits_len == 0 || params->bits_len % w != 0) return H2R_E_SHAPE;  // chip.rs:1175
     const u32 L = params->bits_len / w;
@@ -573,6 +591,8 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) try {
     layout_compute(w, L, &c->layout);
     field_modulus(params->field, c->field_p);
     field_consts_init(c->field_p, &c->fc);
+    montk_init(c->field_p, &c->mk);
+    c->repr.struct_size = sizeof(h2r_advice_repr); c->repr.flags = repr ? repr->flags : 0u; c->repr.col_stride = repr ? repr->col_stride : 0;
     build_const_record(c);
     // histogram rows: composition table of the limb sub-limbs, then of the carry sub-limbs when its width
     // differs, then the carry overflow table
@@ -633,12 +653,17 @@ int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out) try {
         for (int k = 0; k < 4; ++k) kt[CELLS_KT_P + k] = c->fc.p[k];
         std::memcpy(&kt[CELLS_KT_FC], &c->fc, sizeof c->fc);
         {   // the column rows' fast-path sources, packed against this shape's LDS plan
-            const CellsLds lp = cells_lds_plan(w, L);
+            const bool mont = (c->repr.flags & H2R_ADVICE_MONTGOMERY) != 0;
+            const CellsLds lp = cells_lds_plan(w, L, mont);
             u32 *fs = reinterpret_cast<u32 *>(&kt[CELLS_KT_FSRC]);
             for (u32 k = 0; k < ADVICE_COL_ROWS * 3; ++k) {
-                fs[k] = cells_pack_fast_src(lp, w, cells_fast_src(k / 3, k % 3, false));
-                fs[CELLS_SRC_WORDS + k] = cells_pack_fast_src(lp, w, cells_fast_src(k / 3, k % 3, true));
+                fs[k] = cells_pack_fast_src(lp, w, cells_fast_src(k / 3, k % 3, false), mont);
+                fs[CELLS_SRC_WORDS + k] = cells_pack_fast_src(lp, w, cells_fast_src(k / 3, k % 3, true), mont);
             }
+        }
+        if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&c->mk_dev), sizeof(MontK)), "hipMalloc(Montgomery table)") ||
+            !hip_ok(hipMemcpy(c->mk_dev, &c->mk, sizeof(MontK), hipMemcpyHostToDevice), "hipMemcpy(Montgomery table)")) {
+            return H2R_E_HIP;
         }
         if (!hip_ok(hipMalloc(reinterpret_cast<void **>(&c->cells_ktab_dev), sizeof kt), "hipMalloc(cells table)") ||
             !hip_ok(hipMemcpy(c->cells_ktab_dev, kt, sizeof kt, hipMemcpyHostToDevice), "hipMemcpy(cells table)")) {
@@ -656,6 +681,7 @@ void h2r_ctx_destroy(h2r_ctx *ctx) try {
         if (ctx->const_rec_dev) (void)hipFree(ctx->const_rec_dev);
         if (ctx->advice_desc_dev) (void)hipFree(ctx->advice_desc_dev);
         if (ctx->cells_ktab_dev) (void)hipFree(ctx->cells_ktab_dev);
+        if (ctx->mk_dev) (void)hipFree(ctx->mk_dev);
         for (auto &kv : ctx->progs) { if (kv.second.dev) (void)hipFree(kv.second.dev); if (kv.second.inv_dev) (void)hipFree(kv.second.inv_dev); }
         if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
         if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
@@ -2220,11 +2246,14 @@ int32_t h2r_lookup_table_image(const h2r_ctx *ctx, const h2r_lookup_config *cfg,
     if (!ctx || !cfg || !tag_col || !value_col) return H2R_E_NULL;
     if (cfg->n_rows == 0 || cfg->n_rows > (u32)LOOKUP_MAX_ROWS) return H2R_E_SHAPE;
     std::memset(tag_col, 0, (size_t)cfg->n_rows * 32); std::memset(value_col, 0, (size_t)cfg->n_rows * 32);
-    for (u32 i = 0; i < cfg->n_lens; ++i)
+    const bool mont = (ctx->repr.flags & H2R_ADVICE_MONTGOMERY) != 0;
+    for (u32 i = 0; i < cfg->n_lens; ++i) {
+        const Fe tg = mont ? fe_to_mont(fe_small(cfg->tag[i]), ctx->fc) : fe_small(cfg->tag[i]);   // small integers: canonical as they are
         for (u32 v = 0; v < (1u << cfg->bit_len[i]); ++v) {
-            tag_col[(u64)(cfg->row_off[i] + v) * 4] = cfg->tag[i];   // small integers: canonical as they are
-            value_col[(u64)(cfg->row_off[i] + v) * 4] = v;
+            const Fe vv = mont ? fe_to_mont(fe_small(v), ctx->fc) : fe_small(v);
+            for (int k = 0; k < 4; ++k) { tag_col[(u64)(cfg->row_off[i] + v) * 4 + k] = tg.v[k]; value_col[(u64)(cfg->row_off[i] + v) * 4 + k] = vv.v[k]; }
         }
+    }
     return H2R_OK;
 } H2R_CATCH_STATUS
 
@@ -2458,6 +2487,25 @@ int32_t h2r_field_eval(const h2r_ctx *ctx, uint32_t op, const uint64_t a[4], con
         case 3: if (fe_is_zero(x)) return H2R_E_SHAPE; r = fe_inv(x, ctx->fc); break;
         case 4: if (fe_is_zero(x)) return H2R_E_SHAPE; r = fe_inv_fermat(x, ctx->fc); break;
         case 5: if (fe_is_zero(x)) return H2R_E_SHAPE; r = fe_inv_fast(x, ctx->fc); break;
+        case 6: {   // x * R mod p the way the kernels convert a cell: the SHORT Montgomery product over the digits x occupies
+            u32 d[8], t[8]; int K = 1;
+            for (int k = 0; k < 4; ++k) { d[2 * k] = (u32)x.v[k]; d[2 * k + 1] = (u32)(x.v[k] >> 32); }
+            for (int k = 0; k < 8; ++k) if (d[k]) K = k + 1;
+            switch (K) {
+                case 1: { const u32 q[1] = {d[0]}; mont_short<1>(q, ctx->mk.bk[1], ctx->mk.p, ctx->mk.n0inv, t); break; }
+                case 2: { const u32 q[2] = {d[0], d[1]}; mont_short<2>(q, ctx->mk.bk[2], ctx->mk.p, ctx->mk.n0inv, t); break; }
+                case 3: { const u32 q[3] = {d[0], d[1], d[2]}; mont_short<3>(q, ctx->mk.bk[3], ctx->mk.p, ctx->mk.n0inv, t); break; }
+                case 4: { const u32 q[4] = {d[0], d[1], d[2], d[3]}; mont_short<4>(q, ctx->mk.bk[4], ctx->mk.p, ctx->mk.n0inv, t); break; }
+                case 5: { const u32 q[5] = {d[0], d[1], d[2], d[3], d[4]}; mont_short<5>(q, ctx->mk.bk[5], ctx->mk.p, ctx->mk.n0inv, t); break; }
+                case 6: { const u32 q[6] = {d[0], d[1], d[2], d[3], d[4], d[5]}; mont_short<6>(q, ctx->mk.bk[6], ctx->mk.p, ctx->mk.n0inv, t); break; }
+                case 7: { const u32 q[7] = {d[0], d[1], d[2], d[3], d[4], d[5], d[6]}; mont_short<7>(q, ctx->mk.bk[7], ctx->mk.p, ctx->mk.n0inv, t); break; }
+                default: mont_short<8>(d, ctx->mk.bk[8], ctx->mk.p, ctx->mk.n0inv, t); break;
+            }
+            for (int k = 0; k < 4; ++k) r.v[k] = ((u64)t[2 * k + 1] << 32) | t[2 * k];
+            break;
+        }
+        case 7: r = fe_from_mont(x, ctx->fc); break;   // x * R^-1 mod p: a Montgomery-form element back to its canonical integer
+        case 8: r = fe_to_mont(x, ctx->fc); break;     // x * R mod p by the generic R^2 product (the cross-check of 6)
         default: return H2R_E_UNSUPPORTED;
     }
     for (int k = 0; k < 4; ++k) out[k] = r.v[k];
@@ -2668,6 +2716,23 @@ int32_t h2r_pow_trace_emit_stream(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
 uint32_t h2r_advice_rows(const h2r_ctx *ctx) try { return ctx ? advice_rows_per_record(ctx->L, ctx->layout.carry_nsub) : 0; } H2R_CATCH_ZERO
 
 namespace {
+// The caller's image buffer in the ctx's representation (h2r_advice_repr): `rows` rows per element, element e at + e * out_stride.
+int32_t advice_dst(const h2r_ctx *ctx, void *advice_out, u64 out_stride, u64 rows, u64 batch, AdviceDst *d) {
+    d->base = static_cast<u8 *>(advice_out); d->elem_stride = out_stride;
+    d->mont = (ctx->repr.flags & H2R_ADVICE_MONTGOMERY) ? 1u : 0u;
+    if (ctx->repr.flags & H2R_ADVICE_COLUMNS) {
+        const u64 cs = ctx->repr.col_stride ? ctx->repr.col_stride : rows * 32;   // 0: the element's five columns packed back to back
+        if (cs < rows * 32 || (cs & 15) || (out_stride & 15)) return H2R_E_SHAPE;
+        // [element][column][row] (out_stride covers five columns) or [column][element][row] (col_stride covers every element)
+        const bool elem_major = out_stride >= 4 * cs + rows * 32, col_major = batch == 0 || (out_stride >= rows * 32 && cs >= (batch - 1) * out_stride + rows * 32);
+        if (!elem_major && !col_major) return H2R_E_SHAPE;
+        d->row_pitch = 32; d->col_pitch = cs;
+    } else {
+        if (out_stride < rows * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
+        d->row_pitch = ADVICE_ROW_BYTES; d->col_pitch = 32;
+    }
+    return H2R_OK;
+}
 int32_t launch_advice(const h2r_ctx *ctx, AdviceArgs &aa, hipStream_t st) {
     const h2r_layout &lo = ctx->layout;
     if (lo.num_limbs > 128 || lo.limb_nsub != 8 || lo.carry_nsub > 16) return H2R_E_UNSUPPORTED;
@@ -2676,7 +2741,7 @@ int32_t launch_advice(const h2r_ctx *ctx, AdviceArgs &aa, hipStream_t st) {
     aa.carry_sub_stride = lo.carry_sub_stride; aa.record_stride = lo.record_stride;
     aa.rows = h2r_advice_rows(ctx);
     aa.f = ctx->fc; aa.desc = ctx->advice_desc_dev;
-    if (aa.out_stride < ((u64)aa.pre_rows + (u64)aa.T * aa.rows + (u64)(aa.T / 2) * aa.sel_rows) * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
+    aa.mk = ctx->mk_dev;
     if (aa.n_items == 0) return H2R_OK;
     if (aa.n_items >= (1ull << 31)) return H2R_E_UNSUPPORTED;
     ProfScope ps(H2R_KERNEL_EMIT, st, true);
@@ -2693,25 +2758,32 @@ int32_t launch_cells(const h2r_ctx *ctx, CellsArgs &ca, hipStream_t st) {
     ca.per_col_magic = (u32)(((1ull << 32) + (ADVICE_COL_ROWS + (lo.carry_nsub + 3) / 4) - 1) / (ADVICE_COL_ROWS + (lo.carry_nsub + 3) / 4));
     ca.L = lo.num_limbs; ca.carry_sub_bits = lo.carry_sub_bits; ca.carry_nsub = lo.carry_nsub;
     ca.rows = h2r_advice_rows(ctx);
-    if (ca.out_stride < ((u64)ca.pre_rows + (u64)ca.T * ca.rows + (u64)(ca.T / 2) * ca.sel_rows) * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
+    ca.mk = ctx->mk;
+    const bool mont = ca.dst.mont != 0;
     if (ca.n_items == 0) return H2R_OK;
     if (ca.n_items >= (1ull << 31)) return H2R_E_UNSUPPORTED;
     // Residency: FOUR waves per CU, one per SIMD (measured: 6.64-6.67 TB/s against 6.47 with the six the RSA-2048 shape's 26 KB would
     // allow, 4.2 with three -- profiles/r04_cells_kernel.txt).  Enforced the way occupancy is enforced on this hardware: by the LDS request.
-    u32 lds = cells_lds_bytes(lo.limb_width, lo.num_limbs);
+    u32 lds = cells_lds_bytes(lo.limb_width, lo.num_limbs, mont);
 #ifndef H2R_CELLS_WAVES
 #define H2R_CELLS_WAVES 4   // (developer variants: 0 = whatever fits)
 #endif
     const u32 quarter = H2R_CELLS_WAVES ? (ctx->lds_per_cu / H2R_CELLS_WAVES - 512) & ~15u : 0u;
     if (lds < quarter) lds = quarter;
+    const void *fn = lo.limb_width == 64 ? (mont ? reinterpret_cast<const void *>(&cells_kernel<64, 0, true>) : reinterpret_cast<const void *>(&cells_kernel<64>))
+                                         : (mont ? reinterpret_cast<const void *>(&cells_kernel<32, 0, true>) : reinterpret_cast<const void *>(&cells_kernel<32>));
     if (lds > 48 * 1024) {
-        if (lo.limb_width == 64) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cells_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        else (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&cells_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipGetLastError();
     }
     ProfScope ps(H2R_KERNEL_CELLS, st, true);
-    if (lo.limb_width == 64) hipExtLaunchKernelGGL((cells_kernel<64>), dim3((unsigned)ca.n_items), dim3(64), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ca);
-    else hipExtLaunchKernelGGL((cells_kernel<32>), dim3((unsigned)ca.n_items), dim3(64), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ca);
+    if (lo.limb_width == 64) {
+        if (mont) hipExtLaunchKernelGGL((cells_kernel<64, 0, true>), dim3((unsigned)ca.n_items), dim3(64), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ca);
+        else hipExtLaunchKernelGGL((cells_kernel<64>), dim3((unsigned)ca.n_items), dim3(64), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ca);
+    } else {
+        if (mont) hipExtLaunchKernelGGL((cells_kernel<32, 0, true>), dim3((unsigned)ca.n_items), dim3(64), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ca);
+        else hipExtLaunchKernelGGL((cells_kernel<32>), dim3((unsigned)ca.n_items), dim3(64), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ca);
+    }
     HIP_TRY(hipGetLastError());
     return H2R_OK;
 }
@@ -2721,6 +2793,8 @@ int32_t h2r_mul_mod_emit_advice(const h2r_ctx *ctx, const void *a, const void *b
                                 uint64_t batch, const uint8_t *status, void *advice_out, uint64_t out_stride, h2r_stream_t stream) try {
     if (!ctx || !a || !b || !n || !trace || !advice_out) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    AdviceDst dst;
+    if (const int32_t rc = advice_dst(ctx, advice_out, out_stride, h2r_advice_rows(ctx), batch, &dst)) return rc;
     H2R_ON_DEVICE(ctx->params.device);
     if (flags & H2R_ADVICE_DIRECT) {   // recomputed from (a, b, n) and the record's q, r limbs; nothing else of the record is read
         const h2r_layout &lo = ctx->layout;
@@ -2730,31 +2804,31 @@ int32_t h2r_mul_mod_emit_advice(const h2r_ctx *ctx, const void *a, const void *b
         ca.opQ = static_cast<const u8 *>(trace) + lo.plane_off[H2R_PL_Q]; ca.opR = static_cast<const u8 *>(trace) + lo.plane_off[H2R_PL_R];
         ca.qr_stride = lo.record_stride / lo.limb_bytes;
         ca.n = n; ca.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
-        ca.status = status; ca.T = 1; ca.n_items = batch; ca.out = static_cast<u8 *>(advice_out); ca.out_stride = out_stride;
+        ca.status = status; ca.T = 1; ca.n_items = batch; ca.dst = dst;
         return launch_cells(ctx, ca, static_cast<hipStream_t>(stream));
     }
     AdviceArgs aa;
     std::memset(&aa, 0, sizeof aa);
     aa.opA = a; aa.opB = b; aa.op_stride = ctx->L; aa.n = n; aa.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
     aa.status = status; aa.trace = static_cast<const u8 *>(trace); aa.elem_stride = ctx->layout.record_stride; aa.off_records = 0;
-    aa.T = 1; aa.n_items = batch; aa.out = static_cast<u8 *>(advice_out); aa.out_stride = out_stride;
+    aa.T = 1; aa.n_items = batch; aa.dst = dst;
     return launch_advice(ctx, aa, static_cast<hipStream_t>(stream));
 } H2R_CATCH_STATUS
 
-int32_t h2r_pow_trace_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *n, uint32_t flags, const void *trace,
-                                  uint64_t elem_stride, const void *workspace, uint64_t batch, const uint8_t *status,
-                                  void *advice_out, uint64_t out_stride, h2r_stream_t stream) try {
-    if (!ctx || !pl || !n || !workspace || !advice_out) return H2R_E_NULL;
+namespace {
+// the pow rows of an element image whose row 0 is dst's (the public export, and a section of the whole-element images)
+int32_t pow_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *n, uint32_t flags, const void *trace,
+                        uint64_t elem_stride, const void *workspace, uint64_t batch, const uint8_t *status,
+                        AdviceDst dst, h2r_stream_t stream) {
+    if (!ctx || !pl || !n || !workspace || !dst.base) return H2R_E_NULL;
     const bool var = pl->off_e_bits != UINT64_MAX;
     if (!trace && (var || !(flags & H2R_ADVICE_DIRECT))) return H2R_E_NULL;   // (a Var element's e_bits / selected planes live in the trace)
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (pl->num_mul_mods == 0 || batch == 0) return H2R_OK;
-    if (out_stride < h2r_pow_advice_rows(ctx, pl) * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
     H2R_ON_DEVICE(ctx->params.device);
     const u64 lb = ctx->layout.limb_bytes;
     const u8 *ws = reinterpret_cast<const u8 *>(round_up(reinterpret_cast<u64>(workspace), 256));   // as run_path carves it
     hipStream_t st = static_cast<hipStream_t>(stream);
-    u8 *out = static_cast<u8 *>(advice_out);
     u32 sel_rows = 0;
     if (var) {   // pow_mod: the to_bits rows of every exponent limb in front, the select rows of every bit behind its mul_mod (chip.rs:674-691)
         if (!pl->exp_limb_bits || !pl->e_num_limbs || pl->num_mul_mods != 2 * pl->num_exp_bits) return H2R_E_SHAPE;
@@ -2765,14 +2839,14 @@ int32_t h2r_pow_trace_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
         va.opA = ws; va.opR = ws + 3 * ctx->L * lb; va.op_stride = 4ull * ctx->L;
         va.status = status; va.batch = batch; va.L = ctx->L; va.T = pl->num_mul_mods; va.nbits = pl->num_exp_bits;
         va.exp_limb_bits = pl->exp_limb_bits; va.e_num_limbs = pl->e_num_limbs; va.rows = h2r_advice_rows(ctx);
-        va.out = out; va.out_stride = out_stride;
+        va.dst = dst; va.mk = ctx->mk_dev;
         const u64 per_elem = (u64)va.e_num_limbs * var_to_bits_rows(va.exp_limb_bits) + (u64)va.nbits * va.L;
         const u64 blocks = (batch * per_elem + 255) / 256;
         if (blocks >= (1ull << 31)) return H2R_E_UNSUPPORTED;
         if (ctx->layout.limb_width == 64) hipLaunchKernelGGL((var_rows_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, st, va);
         else hipLaunchKernelGGL((var_rows_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, va);
         HIP_TRY(hipGetLastError());
-        out += (u64)va.e_num_limbs * var_to_bits_rows(va.exp_limb_bits) * ADVICE_ROW_BYTES;
+        dst = dst.at_row((u64)va.e_num_limbs * var_to_bits_rows(va.exp_limb_bits));
         sel_rows = ctx->L;
     }
     if (flags & H2R_ADVICE_DIRECT) {   // from the call's operands alone (trace may be NULL: a fixed-exponent call that wrote no records)
@@ -2782,7 +2856,7 @@ int32_t h2r_pow_trace_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
         ca.op_stride = 4ull * ctx->L; ca.qr_stride = ca.op_stride;
         ca.n = n; ca.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
         ca.status = status; ca.T = pl->num_mul_mods; ca.n_items = batch * pl->num_mul_mods;
-        ca.out = out; ca.out_stride = out_stride;
+        ca.dst = dst;
         ca.pre_rows = 2u; ca.sel_rows = sel_rows;   // acc = assign_constant(1, L): [1], [0] (chip.rs:729 resp. :682)
         return launch_cells(ctx, ca, st);
     }
@@ -2792,9 +2866,19 @@ int32_t h2r_pow_trace_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
     aa.n = n; aa.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
     aa.status = status; aa.trace = static_cast<const u8 *>(trace); aa.elem_stride = elem_stride ? elem_stride : pl->elem_stride;
     aa.off_records = pl->off_records; aa.T = pl->num_mul_mods; aa.n_items = batch * pl->num_mul_mods;
-    aa.out = out; aa.out_stride = out_stride;
+    aa.dst = dst;
     aa.pre_rows = 2u; aa.sel_rows = sel_rows;
     return launch_advice(ctx, aa, st);
+}
+}  // namespace
+
+int32_t h2r_pow_trace_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *n, uint32_t flags, const void *trace,
+                                  uint64_t elem_stride, const void *workspace, uint64_t batch, const uint8_t *status,
+                                  void *advice_out, uint64_t out_stride, h2r_stream_t stream) try {
+    if (!ctx || !pl || !n || !workspace || !advice_out) return H2R_E_NULL;
+    AdviceDst dst;
+    if (const int32_t rc = advice_dst(ctx, advice_out, out_stride, h2r_pow_advice_rows(ctx, pl), batch, &dst)) return rc;
+    return pow_emit_advice(ctx, pl, n, flags, trace, elem_stride, workspace, batch, status, dst, stream);
 } H2R_CATCH_STATUS
 
 uint64_t h2r_pow_advice_rows(const h2r_ctx *ctx, const h2r_pow_layout *pl) try {
@@ -2832,7 +2916,12 @@ int32_t h2r_advice_fixed_row(const h2r_ctx *ctx, const h2r_lookup_config *cfg, u
     std::memset(out, 0, sizeof *out);
     const h2r_layout &lo = ctx->layout;
     const u64 (&p)[4] = ctx->fc.p;
-    auto put = [&](uint64_t (&dst)[4], const Fe &v, bool neg) { const Fe r = neg ? fe_sub(fe_zero(), v, p) : v; for (int k = 0; k < 4; ++k) dst[k] = r.v[k]; };
+    const bool mont = (ctx->repr.flags & H2R_ADVICE_MONTGOMERY) != 0;   // the selectors are field elements like the cells: the ctx's representation
+    auto put = [&](uint64_t (&dst)[4], const Fe &v, bool neg) {
+        Fe r = neg ? fe_sub(fe_zero(), v, p) : v;
+        if (mont) r = fe_to_mont(r, ctx->fc);
+        for (int k = 0; k < 4; ++k) dst[k] = r.v[k];
+    };
     const Fe one = fe_small(1);
     Fe Bv = fe_zero(); if (lo.limb_width == 64) Bv.v[1] = 1; else Bv.v[0] = 1ull << 32;
     Fe W; for (int k = 0; k < 4; ++k) W.v[k] = ctx->word_max.v[k];
@@ -2945,7 +3034,7 @@ int32_t fresh_row_prog(const h2r_ctx *ctx, uint32_t op, uint32_t flags, const h2
     return row_prog(ctx, op | (assert_one ? 256u : 0u), [&](RowProgBuilder &rb) { return rb.build(op, assert_one); }, out);
 }
 int32_t launch_row_prog(const h2r_ctx *ctx, const h2r_ctx::RowProg *rp, RowProgArgs &ra, hipStream_t st) {
-    ra.prog = rp->dev; ra.rows = (u32)rp->host.size(); ra.f = ctx->fc;
+    ra.prog = rp->dev; ra.rows = (u32)rp->host.size(); ra.f = ctx->fc; ra.mk = ctx->mk_dev;
     ra.inv_rows = rp->inv_dev; ra.n_inv = (u32)rp->inv_rows.size();
     const u64 blocks = ra.batch * ((ra.rows + 255) / 256);
     if (blocks == 0) return H2R_OK;
@@ -2980,10 +3069,11 @@ int32_t h2r_fresh_op_row_kinds(const h2r_ctx *ctx, uint32_t op, uint32_t flags, 
     return H2R_OK;
 } H2R_CATCH_STATUS
 
-int32_t h2r_fresh_op_emit_advice(const h2r_ctx *ctx, uint32_t op, uint32_t flags, const void *a, const void *b, const void *n,
-                                 const void *trace, uint64_t first_off, uint64_t elem_stride, uint64_t batch, const uint8_t *status,
-                                 void *advice_out, uint64_t out_stride, h2r_stream_t stream) try {
-    if (!ctx || !a || !trace || !advice_out) return H2R_E_NULL;
+namespace {
+int32_t fresh_emit_advice(const h2r_ctx *ctx, uint32_t op, uint32_t flags, const void *a, const void *b, const void *n,
+                          const void *trace, uint64_t first_off, uint64_t elem_stride, uint64_t batch, const uint8_t *status,
+                          const AdviceDst *dst_in, void *advice_out, uint64_t out_stride, h2r_stream_t stream) {
+    if (!ctx || !a || !trace || (!dst_in && !advice_out)) return H2R_E_NULL;
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     const h2r_ctx::RowProg *rp = nullptr;
     int32_t rc = fresh_row_prog(ctx, op, flags, &rp);
@@ -2995,7 +3085,10 @@ int32_t h2r_fresh_op_emit_advice(const h2r_ctx *ctx, uint32_t op, uint32_t flags
     if (rc) return rc;
     if (elem_stride == 0) elem_stride = es;
     const u64 rows = rp->host.size();
-    if (out_stride < rows * ADVICE_ROW_BYTES || (first_off & 15) || (elem_stride & 15)) return H2R_E_SHAPE;
+    if ((first_off & 15) || (elem_stride & 15)) return H2R_E_SHAPE;
+    AdviceDst dst;
+    if (dst_in) dst = *dst_in;
+    else if ((rc = advice_dst(ctx, advice_out, out_stride, rows, batch, &dst))) return rc;
     if (batch == 0) return H2R_OK;
     RowProgArgs ra;
     std::memset(&ra, 0, sizeof ra);
@@ -3004,9 +3097,16 @@ int32_t h2r_fresh_op_emit_advice(const h2r_ctx *ctx, uint32_t op, uint32_t flags
     ra.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
     ra.b_stride = (!needs_n && (flags & H2R_F_SHARED_MODULUS)) ? 0 : ctx->L;   // as h2r_fresh_op_batch
     ra.trace = static_cast<const u8 *>(trace); ra.elem_stride = elem_stride; ra.first_off = first_off;
-    ra.status = status; ra.batch = batch; ra.out = static_cast<u8 *>(advice_out); ra.out_stride = out_stride;
+    ra.status = status; ra.batch = batch; ra.dst = dst;
     H2R_ON_DEVICE(ctx->params.device);
     return launch_row_prog(ctx, rp, ra, static_cast<hipStream_t>(stream));
+}
+}  // namespace
+
+int32_t h2r_fresh_op_emit_advice(const h2r_ctx *ctx, uint32_t op, uint32_t flags, const void *a, const void *b, const void *n,
+                                 const void *trace, uint64_t first_off, uint64_t elem_stride, uint64_t batch, const uint8_t *status,
+                                 void *advice_out, uint64_t out_stride, h2r_stream_t stream) try {
+    return fresh_emit_advice(ctx, op, flags, a, b, n, trace, first_off, elem_stride, batch, status, nullptr, advice_out, out_stride, stream);
 } H2R_CATCH_STATUS
 
 // ---- the whole verify_pkcs1v15_signature element as advice rows ------------------------------------------------------------
@@ -3081,11 +3181,11 @@ int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, 
     if (rc) return rc;
     u64 sec[4];
     const u64 rows = h2r_verify_advice_rows(ctx, vl, sec);
-    if (out_stride < rows * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
+    AdviceDst dst;
+    if ((rc = advice_dst(ctx, advice_out, out_stride, rows, batch, &dst))) return rc;
     if (batch == 0) return H2R_OK;
     H2R_ON_DEVICE(ctx->params.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    u8 *out = static_cast<u8 *>(advice_out);
     // the three row programs (seed row, assert_in_field, encoded-message check: 2 % of the bytes, latency-bound inverse launches among them)
     // run on the ctx's side stream NEXT to the pow rows' kernel -- other rows of the same image -- and are joined before returning
     SideFork fork(ctx, st);
@@ -3094,16 +3194,16 @@ int32_t h2r_verify_emit_advice(const h2r_ctx *ctx, const h2r_verify_layout *vl, 
     std::memset(&ra, 0, sizeof ra);
     ra.a = sig; ra.b = n; ra.n = n; ra.a_stride = ctx->L; ra.b_stride = ra.n_stride = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
     ra.trace = static_cast<const u8 *>(trace); ra.elem_stride = vl->elem_stride; ra.first_off = vl->off_in_field;
-    ra.status = status; ra.batch = batch; ra.out_stride = out_stride;
-    ra.out = out;                                   // is_eq = assign_constant(1), src/chip.rs:137
+    ra.status = status; ra.batch = batch;
+    ra.dst = dst;                                   // is_eq = assign_constant(1), src/chip.rs:137
     if ((rc = launch_row_prog(ctx, pre, ra, ss))) return rc;
-    ra.out = out + sec[0] * ADVICE_ROW_BYTES;       // assert_in_field(sig, n), :106
+    ra.dst = dst.at_row(sec[0]);                    // assert_in_field(sig, n), :106
     if ((rc = launch_row_prog(ctx, inf, ra, ss))) return rc;
     ra.a = powed; ra.b = hashed; ra.b_stride = 4; ra.first_off = vl->off_em;
-    ra.out = out + (sec[0] + sec[1] + sec[2]) * ADVICE_ROW_BYTES;                                      // :138-198
+    ra.dst = dst.at_row(sec[0] + sec[1] + sec[2]);                                                     // :138-198
     if ((rc = launch_row_prog(ctx, em, ra, ss))) return rc;
-    rc = h2r_pow_trace_emit_advice(ctx, &vl->pow, n, flags, trace, vl->elem_stride, workspace, batch, status,
-                                   out + (sec[0] + sec[1]) * ADVICE_ROW_BYTES, out_stride, stream);   // pow_mod_fixed_exp / pow_mod, :108-111
+    rc = pow_emit_advice(ctx, &vl->pow, n, flags, trace, vl->elem_stride, workspace, batch, status,
+                         dst.at_row(sec[0] + sec[1]), stream);   // pow_mod_fixed_exp / pow_mod, :108-111
     if (rc) return rc;
     return fork.join();
 } H2R_CATCH_STATUS
@@ -3176,12 +3276,12 @@ int32_t h2r_advice_apply_layout(const h2r_ctx *ctx, const h2r_advice_layout *lay
                                 uint64_t out_stride, uint64_t batch, const uint8_t *status, h2r_stream_t stream) try {
     if (!ctx || !layout || !kinds_dev || !image) return H2R_E_NULL;
     if (ctx->params.device < 0 || layout->version != H2R_ADVICE_LAYOUT_VERSION) return H2R_E_UNSUPPORTED;
-    if (out_stride < rows * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
-    if (!rows || !batch) return H2R_OK;
-    H2R_ON_DEVICE(ctx->params.device);
     LayoutArgs la;
     std::memset(&la, 0, sizeof la);
-    la.kinds = kinds_dev; la.rows = rows; la.image = static_cast<u8 *>(image); la.out_stride = out_stride; la.batch = batch; la.status = status;
+    if (const int32_t rc = advice_dst(ctx, image, out_stride, rows, batch, &la.dst)) return rc;
+    if (!rows || !batch) return H2R_OK;
+    H2R_ON_DEVICE(ctx->params.device);
+    la.kinds = kinds_dev; la.rows = rows; la.batch = batch; la.status = status;
     std::memcpy(la.perm, layout->column_of, sizeof la.perm);
     const u64 blocks = (rows * batch + 255) / 256;
     if (blocks >= (1ull << 31)) return H2R_E_UNSUPPORTED;
@@ -3206,14 +3306,15 @@ int32_t h2r_modpow_public_key_emit_advice(const h2r_ctx *ctx, const h2r_pow_layo
     u64 sec[2];
     const u64 rows = h2r_modpow_public_key_advice_rows(ctx, pl, sec);
     if (!rows) return H2R_E_UNSUPPORTED;
-    if (out_stride < rows * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
+    AdviceDst dst;
+    int32_t rc = advice_dst(ctx, advice_out, out_stride, rows, batch, &dst);
+    if (rc) return rc;
     H2R_ON_DEVICE(ctx->params.device);
     SideFork fork(ctx, static_cast<hipStream_t>(stream));   // the in-field rows next to the pow rows (see h2r_verify_emit_advice)
-    int32_t rc = h2r_fresh_op_emit_advice(ctx, FRESH_IS_IN_FIELD, (flags & H2R_F_SHARED_MODULUS) | H2R_ADVICE_ASSERT_ONE, x, n, nullptr, in_field_trace, 0, 0,
-                                          batch, status, advice_out, out_stride, static_cast<h2r_stream_t>(fork.side()));
+    rc = fresh_emit_advice(ctx, FRESH_IS_IN_FIELD, (flags & H2R_F_SHARED_MODULUS) | H2R_ADVICE_ASSERT_ONE, x, n, nullptr, in_field_trace, 0, 0,
+                           batch, status, &dst, nullptr, 0, static_cast<h2r_stream_t>(fork.side()));
     if (rc) return rc;
-    rc = h2r_pow_trace_emit_advice(ctx, pl, n, flags | (trace ? 0u : H2R_ADVICE_DIRECT), trace, 0, workspace, batch, status,
-                                   static_cast<u8 *>(advice_out) + sec[0] * ADVICE_ROW_BYTES, out_stride, stream);
+    rc = pow_emit_advice(ctx, pl, n, flags | (trace ? 0u : H2R_ADVICE_DIRECT), trace, 0, workspace, batch, status, dst.at_row(sec[0]), stream);
     if (rc) return rc;
     return fork.join();
 } H2R_CATCH_STATUS
@@ -3233,7 +3334,8 @@ int32_t h2r_pipeline_modpow_public_key_advice(h2r_pipeline *p, const void *x, co
     u64 sec[2];
     const u64 rows = h2r_modpow_public_key_advice_rows(ctx, &pl, sec);
     if (!rows) return H2R_E_UNSUPPORTED;
-    if (out_stride < rows * ADVICE_ROW_BYTES) return H2R_E_SHAPE;
+    AdviceDst dst;
+    if ((rc = advice_dst(ctx, advice_out, out_stride, rows, batch, &dst))) return rc;
     if (batch == 0) return H2R_OK;
     H2R_ON_DEVICE(ctx->params.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -3252,13 +3354,13 @@ int32_t h2r_pipeline_modpow_public_key_advice(h2r_pipeline *p, const void *x, co
     const bool shared = (flags & H2R_F_SHARED_MODULUS) != 0;
     HIP_TRY(hipMemcpyAsync(ws + wp.off_n, n, (shared ? 1ull : batch) * ctx->L * lo.limb_bytes, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipEventRecord(p->chain_done[slot], st));
-    rc = h2r_fresh_op_emit_advice(ctx, FRESH_IS_IN_FIELD, (flags & H2R_F_SHARED_MODULUS) | H2R_ADVICE_ASSERT_ONE, x, n, nullptr, in_field_trace, 0, 0,
-                                  batch, status, advice_out, out_stride, stream);
+    rc = fresh_emit_advice(ctx, FRESH_IS_IN_FIELD, (flags & H2R_F_SHARED_MODULUS) | H2R_ADVICE_ASSERT_ONE, x, n, nullptr, in_field_trace, 0, 0,
+                           batch, status, &dst, nullptr, 0, stream);
     if (rc) return rc;
     hipStream_t side = p->aux[p->k & 1];
     HIP_TRY(hipStreamWaitEvent(side, p->chain_done[slot], 0));
-    rc = h2r_pow_trace_emit_advice(ctx, &pl, ws + wp.off_n, (flags & H2R_F_SHARED_MODULUS) | H2R_ADVICE_DIRECT, nullptr, 0, workspace, batch, status,
-                                   static_cast<u8 *>(advice_out) + sec[0] * ADVICE_ROW_BYTES, out_stride, static_cast<h2r_stream_t>(side));
+    rc = pow_emit_advice(ctx, &pl, ws + wp.off_n, (flags & H2R_F_SHARED_MODULUS) | H2R_ADVICE_DIRECT, nullptr, 0, workspace, batch, status,
+                         dst.at_row(sec[0]), static_cast<h2r_stream_t>(side));
     if (rc) return rc;
     HIP_TRY(hipEventRecord(p->trace_done[slot], side));
     p->done[slot] = DoneRef{p->trace_done[slot], 0, false};
@@ -3304,13 +3406,14 @@ int32_t h2r_hashed_msg_emit_advice(const h2r_ctx *ctx, const void *hm_trace, uin
     const int32_t rc = hashed_msg_prog(ctx, &rp);
     if (rc) return rc;
     if (hm_stride == 0) hm_stride = HM_REGION;
-    if (out_stride < rp->host.size() * ADVICE_ROW_BYTES || (hm_stride & 15) || hm_stride < HM_REGION) return H2R_E_SHAPE;
-    if (batch == 0) return H2R_OK;
+    if ((hm_stride & 15) || hm_stride < HM_REGION) return H2R_E_SHAPE;
     RowProgArgs ra;
     std::memset(&ra, 0, sizeof ra);
+    if (const int32_t rd = advice_dst(ctx, advice_out, out_stride, rp->host.size(), batch, &ra.dst)) return rd;
+    if (batch == 0) return H2R_OK;
     ra.a = ra.b = ra.n = hm_trace;   // no operand cells in this program
     ra.trace = static_cast<const u8 *>(hm_trace); ra.elem_stride = hm_stride; ra.first_off = 0;
-    ra.status = status; ra.batch = batch; ra.out = static_cast<u8 *>(advice_out); ra.out_stride = out_stride;
+    ra.status = status; ra.batch = batch;
     H2R_ON_DEVICE(ctx->params.device);
     return launch_row_prog(ctx, rp, ra, static_cast<hipStream_t>(stream));
 } H2R_CATCH_STATUS

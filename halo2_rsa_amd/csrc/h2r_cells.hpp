@@ -39,7 +39,8 @@ struct CellsArgs {
     const void *n; u64 n_stride;         // [elem][L] limbs (stride 0 = shared)
     const u8 *status;                    // [elem] nullable; nonzero => the element's items are skipped
     u32 T; u64 n_items;                  // item = elem * T + t
-    u8 *out; u64 out_stride;             // element e's image at out + e * out_stride: pre_rows rows, then record t at + (pre_rows + t * rows) * 160
+    AdviceDst dst;                       // element e's image: pre_rows rows, then record t from row pre_rows + t * rows (+ the select rows) on
+    MontK mk;                            // H2R_ADVICE_MONTGOMERY: the short Montgomery multipliers (kernel arguments: they reach the multiplies as SGPRs)
     u32 rows, pre_rows;
     u32 sel_rows;                        // pow_mod (Var): rows left free behind every EVEN record for the bit's select rows
     u32 L, carry_sub_bits, carry_nsub;
@@ -129,10 +130,13 @@ __host__ __device__ constexpr u32 cells_fast_src(u32 j, u32 k, bool last_col) {
 }
 
 // dynamic LDS of one wave (byte offsets): stage, operands, constants, column planes, flags, code tables
-struct CellsLds { u32 ops, kt, ce, ab, eqb, sum, amb, nq1, cout, cmod, fl, src, fsrc, total; };
-__host__ __device__ inline CellsLds cells_lds_plan(u32 limb_width, u32 L) {
+struct CellsLds { u32 ops, kt, ce, ab, eqb, sum, amb, nq1, cout, cmod, mab, meqb, msum, opsr, fl, src, fsrc, total; };
+__host__ __device__ inline CellsLds cells_lds_plan(u32 limb_width, u32 L, bool mont = false) {
     // 64-bit limbs: 32-byte entries AB, EQB, SUM, a_b, NQ1 and 16-byte entries carry, c.  32-bit limbs (every value but a_b's field
     // element is below 2^128): 16-byte entries AB, EQB, SUM, a 32-byte a_b; NQ1, the carry and c are cut from the SUM entry on the way.
+    // Montgomery cells are not the integers the column phase computes with: the integer planes AB, EQB, SUM stay what they are, and
+    // every ready-made cell (AB, EQB, a_b, SUM, NQ1, carry, c) has a 32-byte entry of its own; so have the limbs of a, b, q, n (the
+    // first two cells of every mul row), converted once per mul_mod.
     const bool w64 = limb_width == 64;
     const u32 es = w64 ? 32u : 16u, n = 2u * L + 1u;
     CellsLds p; u32 o = 64u * ADVICE_ROW_BYTES;
@@ -140,31 +144,36 @@ __host__ __device__ inline CellsLds cells_lds_plan(u32 limb_width, u32 L) {
     p.kt = o; o += CELLS_KT_WORDS * 8u;
     p.ce = o; o += CELLS_CONST_ENTRIES * 32u;
     p.ab = o; o += n * es; p.eqb = o; o += n * es; p.sum = o; o += n * es;
-    p.amb = o; o += n * 32u; p.nq1 = o; o += w64 ? n * 32u : 0u;
-    p.cout = o; o += w64 ? n * 16u : 0u; p.cmod = o; o += w64 ? n * 16u : 0u;
+    p.amb = o; o += n * 32u; p.nq1 = o; o += (w64 || mont) ? n * 32u : 0u;
+    p.cout = o; o += mont ? n * 32u : (w64 ? n * 16u : 0u); p.cmod = o; o += mont ? n * 32u : (w64 ? n * 16u : 0u);
+    p.mab = o; o += mont ? n * 32u : 0u; p.meqb = o; o += mont ? n * 32u : 0u; p.msum = o; o += mont ? n * 32u : 0u;
+    p.opsr = o; o += mont ? 4u * L * 32u : 0u;
     p.fl = o; o += 2u * L * 4u;
     p.src = o; o += CELLS_SRC_WORDS * 4u;
     p.fsrc = o; o += 2u * CELLS_SRC_WORDS * 4u;
     p.total = (o + 15u) & ~15u;
     return p;
 }
-__host__ __device__ inline u32 cells_lds_bytes(u32 limb_width, u32 L) { return cells_lds_plan(limb_width, L).total; }
-// A fast-path source as the kernel wants it: bits 0-11 LDS offset / 16 of the plane's (or constant's) first entry, bits 12-15 entry
-// stride / 16, bit 16 column c - 1, bit 17 indexed by min(column, 2) (the accumulated_extra constants), bit 18 the entry has a high
-// half, bits 19-22 (32-bit limbs) the cut of the SUM entry (CE_NQ1 / CE_COUT / CE_CMOD)
-__host__ __device__ inline u32 cells_pack_fast_src(const CellsLds &lp, u32 limb_width, u32 code) {
+__host__ __device__ inline u32 cells_lds_bytes(u32 limb_width, u32 L, bool mont = false) { return cells_lds_plan(limb_width, L, mont).total; }
+// A fast-path source as the kernel wants it: bits 0-12 LDS offset / 16 of the plane's (or constant's) first entry, bits 13-16 entry
+// stride / 16, bit 17 column c - 1, bit 18 indexed by min(column, 2) (the accumulated_extra constants), bit 19 the entry has a high
+// half, bits 20-23 (32-bit limbs, canonical cells) the cut of the SUM entry (CE_NQ1 / CE_COUT / CE_CMOD)
+__host__ __device__ inline u32 cells_pack_fast_src(const CellsLds &lp, u32 limb_width, u32 code, bool mont = false) {
     const u32 kind = code & 15u, m1 = (code & CE_M1) ? 1u : 0u;
     u32 base, stride = 0, byk = 0, hi = 1, xf = 0;
     if (kind < 3) base = lp.ce + kind * 32;
     else if (kind < CE_AB) { base = lp.ce + (3 + (kind - 3)) * 32; stride = 5 * 32; byk = 1; }
-    else if (limb_width == 64) {
+    else if (mont) {
+        base = kind == CE_AB ? lp.mab : kind == CE_EQB ? lp.meqb : kind == CE_AMB ? lp.amb : kind == CE_SUM ? lp.msum : kind == CE_NQ1 ? lp.nq1 : kind == CE_COUT ? lp.cout : lp.cmod;
+        stride = 32;
+    } else if (limb_width == 64) {
         if (kind < CE_COUT) { base = kind == CE_AB ? lp.ab : kind == CE_EQB ? lp.eqb : kind == CE_AMB ? lp.amb : kind == CE_SUM ? lp.sum : lp.nq1; stride = 32; }
         else { base = kind == CE_COUT ? lp.cout : lp.cmod; stride = 16; hi = 0; }
     } else {
         if (kind == CE_AMB) { base = lp.amb; stride = 32; }
         else { base = kind == CE_AB ? lp.ab : kind == CE_EQB ? lp.eqb : lp.sum; stride = 16; hi = 0; xf = kind >= CE_NQ1 ? kind : 0; }
     }
-    return (base / 16) | ((stride / 16) << 12) | (m1 << 16) | (byk << 17) | (hi << 18) | (xf << 19);
+    return (base / 16) | ((stride / 16) << 13) | (m1 << 17) | (byk << 18) | (hi << 19) | (xf << 20);
 }
 
 // Segmented inclusive scan of an NWD-dword unsigned value over the 64 lanes: lane l receives the sum of the values of lanes
@@ -221,7 +230,16 @@ __device__ __forceinline__ void cells_prefix_sum(u32 (&v)[NWD]) {
 // ABL (developer ablations, tools/cells_bench.hip; 0 in the library): 1 no row building, 2 no global stores, 4 plain instead of
 // non-temporal stores, 8 no is_equal_muled rows (zero rows) and no column phase, 16 no mul rows, 64 no fast paths, 128 chunks not
 // aligned to 128-byte lines, 512 workgroup = item (no XCD-contiguous mapping)
-template <int LW, int ABL = 0>
+// MONT (H2R_ADVICE_MONTGOMERY): every cell is x * R mod p.  What that costs is one SHORT Montgomery product per value (mont_short,
+// h2r_field.hpp: 17 multiply-adds per 32-bit digit of x) and the structure of the image keeps the number of values small:
+//   * the limbs of a, b, q, n -- the first two cells of the 2 L^2 mul rows -- are converted once per mul_mod into an LDS plane;
+//   * a mul row's accumulator is converted once (5 digits: 133 bits; 3 for 32-bit limbs) and the NEXT row's "previous accumulator"
+//     cell is the same value, taken from the lane above (the chunk's first lane: from the previous chunk's last);
+//   * the is_equal_muled planes hold ready-made cells, so their rows stay copies; constants are converted once per wave;
+//   * sub-limbs are one-digit products.
+// The planar form (dst.planar(): one contiguous vector per column) only changes how the staged chunk leaves: five 2 KB runs
+// instead of one 10 KB run, each store instruction still a whole number of 128-byte lines.
+template <int LW, int ABL = 0, bool MONT = false>
 __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
     using limb_t = typename LimbT<LW>::type;
     constexpr bool FAST = !(ABL & 64);
@@ -233,7 +251,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
     extern __shared__ uint4 cells_smem[];
     const u32 lane = threadIdx.x;
     const u32 L = a.L, L2 = 2 * L, C = 2 * L - 1;
-    const CellsLds lp = cells_lds_plan(LW, L);
+    const CellsLds lp = cells_lds_plan(LW, L, MONT);
     u8 *smem = reinterpret_cast<u8 *>(cells_smem);
     uint4 *stage = cells_smem;                                       // 64 rows x 160 bytes
     u64 *sa = reinterpret_cast<u64 *>(smem + lp.ops), *sb = sa + L, *sq = sb + L, *sn = sq + L, *sr = sn + L;
@@ -260,10 +278,14 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
         }
         if (lane < CELLS_KT_WORDS) kt[lane] = a.ktab[lane];
     }
-    u8 *out = a.out + (u64)elem * a.out_stride + ((u64)a.pre_rows + (u64)t * a.rows + (u64)((t + 1) >> 1) * a.sel_rows) * ADVICE_ROW_BYTES;
-    if (t == 0 && lane < a.pre_rows * NP) {   // pow_mod_fixed_exp's acc = assign_constant(1, L): [1, 0, 0, 0, 0] then [0, ...]
-        uint4 *pr = reinterpret_cast<uint4 *>(a.out + (u64)elem * a.out_stride);
-        pr[lane] = make_uint4(lane == 0 ? 1u : 0u, 0, 0, 0);
+    const bool planar = a.dst.planar();
+    u8 *img = a.dst.elem(elem);
+    // `out`: the record's first row (its column-a cell); the other columns of a row lie col_pitch apart, the next row row_pitch further
+    u8 *out = img + ((u64)a.pre_rows + (u64)t * a.rows + (u64)((t + 1) >> 1) * a.sel_rows) * a.dst.row_pitch;
+    if (t == 0 && lane < a.pre_rows * 5) {   // pow_mod_fixed_exp's acc = assign_constant(1, L): [1, 0, 0, 0, 0] then [0, ...]
+        uint4 *pr = reinterpret_cast<uint4 *>(img + (u64)(lane / 5) * a.dst.row_pitch + (u64)(lane % 5) * a.dst.col_pitch);
+        if (MONT && lane == 0) { pr[0] = make_uint4(a.mk.bk[0][0], a.mk.bk[0][1], a.mk.bk[0][2], a.mk.bk[0][3]); pr[1] = make_uint4(a.mk.bk[0][4], a.mk.bk[0][5], a.mk.bk[0][6], a.mk.bk[0][7]); }
+        else { pr[0] = make_uint4(lane == 0 ? 1u : 0u, 0, 0, 0); pr[1] = make_uint4(0, 0, 0, 0); }
     }
     const U192 Z = U192::make(0, 0, 0);
     const U192 Bw = LW == 64 ? U192::make(0, 1, 0) : U192::make(1ull << 32, 0, 0);   // 2^w
@@ -285,11 +307,42 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
             for (int k = 0; k < 4; ++k) { const u64 s1 = x[k] + kt[CELLS_KT_P + k]; const u64 c1 = s1 < x[k]; const u64 s2 = s1 + cy; cy = c1 | (u64)(s2 < s1); x[k] = s2; }
         }
     };
+    // Montgomery form of a (two's complement) value whose magnitude is below 2^(32 NWD): every value of this path
+    auto mont_wide = [&](const U192 &v, bool is_signed, u32 (&tt)[8]) {
+        const bool neg = is_signed && (v.w[2] >> 63) != 0;
+        const U192 m = neg ? Z - v : v;
+        u32 x[NWD];
+        x[0] = (u32)m.w[0]; x[1] = (u32)(m.w[0] >> 32); x[2] = (u32)m.w[1];
+        if constexpr (NWD == 5) { x[3] = (u32)(m.w[1] >> 32); x[4] = (u32)m.w[2]; }
+        mont_short<NWD>(x, a.mk.bk[NWD], a.mk.p, a.mk.n0inv, tt);
+        if (neg) mont_neg(tt, a.mk.p);
+    };
     auto cell = [&](uint4 *p, const U192 &v, bool is_signed) {   // 32 bytes little-endian
-        u64 x[4];
-        field4(v, is_signed, x);
-        p[0] = make_uint4((u32)x[0], (u32)(x[0] >> 32), (u32)x[1], (u32)(x[1] >> 32));
-        p[1] = make_uint4((u32)x[2], (u32)(x[2] >> 32), (u32)x[3], (u32)(x[3] >> 32));
+        if constexpr (MONT) {
+            u32 tt[8];
+            mont_wide(v, is_signed, tt);
+            p[0] = make_uint4(tt[0], tt[1], tt[2], tt[3]); p[1] = make_uint4(tt[4], tt[5], tt[6], tt[7]);
+        } else {
+            u64 x[4];
+            field4(v, is_signed, x);
+            p[0] = make_uint4((u32)x[0], (u32)(x[0] >> 32), (u32)x[1], (u32)(x[1] >> 32));
+            p[1] = make_uint4((u32)x[2], (u32)(x[2] >> 32), (u32)x[3], (u32)(x[3] >> 32));
+        }
+    };
+    // the cell of a K-digit unsigned value (lo, hi)
+    auto cell_k = [&](auto kc, u64 lo, u64 hi, uint4 &o0, uint4 &o1) {
+        constexpr int K = decltype(kc)::value;
+        if constexpr (MONT) {
+            u32 x[K], tt[8];
+            x[0] = (u32)lo;
+            if constexpr (K > 1) x[1] = (u32)(lo >> 32);
+            if constexpr (K > 2) x[2] = (u32)hi;
+            if constexpr (K > 3) x[3] = (u32)(hi >> 32);
+            mont_short<K>(x, a.mk.bk[K], a.mk.p, a.mk.n0inv, tt);
+            o0 = make_uint4(tt[0], tt[1], tt[2], tt[3]); o1 = make_uint4(tt[4], tt[5], tt[6], tt[7]);
+        } else {
+            o0 = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32)); o1 = make_uint4(0, 0, 0, 0);
+        }
     };
     // row rr of RangeChip::assign of the value v (nsub sub-limbs of sub_bits bits, the last one possibly shorter): four sub-limbs in
     // columns a..d -- the LAST row reversed, so that the last (overflow) term is in column a, and zero-padded -- and in column e what
@@ -322,6 +375,14 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
         for (u32 k = lane; k < 2 * CELLS_SRC_WORDS; k += 64) f_src[k] = packed[k];
     }
     wave_sync();
+    if constexpr (MONT) {   // the limbs of a, b, q, n as cells: what the mul rows' first two columns hold
+        uint4 *opsr = reinterpret_cast<uint4 *>(smem + lp.opsr);
+        for (u32 k = lane; k < 4 * L; k += 64) {
+            const u32 which = k / L, idx = k - which * L;
+            const u64 v = (which == 0 ? sa : which == 1 ? sb : which == 2 ? sq : sn)[idx];
+            cell_k(std::integral_constant<int, LW / 32>{}, v, 0, opsr[2 * k], opsr[2 * k + 1]);
+        }
+    }
     if constexpr (FAST) {   // the constant entries
         uint4 *ce = reinterpret_cast<uint4 *>(smem + lp.ce);
         if (lane < CELLS_CONST_ENTRIES) {
@@ -379,7 +440,14 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 f1 = (sum.w[0] & LMASK) == kt[kc * 10 + 5];                      // cs_acc_eq  :873
                 if (c == C - 1) f2 = cout.w[0] == kt[kc * 10 + 3] && cout.w[1] == kt[kc * 10 + 4];   // final_carry_eq  :890
                 if constexpr (FAST) cell(reinterpret_cast<uint4 *>(smem + lp.amb) + 2 * c, amb, true);   // the ready-made cells of the column
-                if constexpr (FAST && LW == 64) {
+                if constexpr (FAST && MONT) {
+                    cell(reinterpret_cast<uint4 *>(smem + lp.mab) + 2 * c, rdp(pAB, c), false);
+                    cell(reinterpret_cast<uint4 *>(smem + lp.meqb) + 2 * c, rdp(pEQB, c), false);
+                    cell(reinterpret_cast<uint4 *>(smem + lp.msum) + 2 * c, sum, false);
+                    cell(reinterpret_cast<uint4 *>(smem + lp.nq1) + 2 * c, U192::make(sum.w[0] & ~LMASK, sum.w[1], sum.w[2]), false);
+                    cell(reinterpret_cast<uint4 *>(smem + lp.cout) + 2 * c, cout, false);
+                    cell(reinterpret_cast<uint4 *>(smem + lp.cmod) + 2 * c, lim(sum.w[0] & LMASK), false);
+                } else if constexpr (FAST && LW == 64) {
                     cell(reinterpret_cast<uint4 *>(smem + lp.nq1) + 2 * c, U192::make(sum.w[0] & ~LMASK, sum.w[1], sum.w[2]), false);
                     reinterpret_cast<uint4 *>(smem + lp.cout)[c] = make_uint4((u32)cout.w[0], (u32)(cout.w[0] >> 32), (u32)cout.w[1], (u32)(cout.w[1] >> 32));
                     const u64 cm = sum.w[0] & LMASK;
@@ -403,6 +471,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
     u32 carry[NWD];
 #pragma unroll
     for (int k = 0; k < NWD; ++k) carry[k] = 0;
+    u32 carry_r[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // MONT: the cell of `carry` (the accumulator the previous chunk's last row left)
     bool columns_done = false;
     u32 dec_r0 = ~0u, dec_I = 0, dec_k = 0, dec_len = 1;   // the mul rows' fast path: row r0 + lane = position dec_k of column dec_I (both muls: 2C columns)
     // the first chunk ends where the image reaches a 128-byte line (160 = 128 + 32: at most three rows), every later chunk of 64
@@ -440,6 +509,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 dec_k = back ? ii + 1 - kk : kk;
                 dec_I = qn0 * C + i0;
                 dec_len = (i0 < L ? i0 : C - 1 - i0) + 2;
+                if constexpr (MONT) mont_short<NWD>(carry, a.mk.bk[NWD], a.mk.p, a.mk.n0inv, carry_r);   // (the general path left the integer)
             } else {
                 dec_k += 64;
                 while (__ballot(dec_k >= dec_len) != 0) {
@@ -494,6 +564,29 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 else wrp(pl, i, U192::make(((u64)p[1] << 32) | p[0], p[2], 0));
             }
             // [x_j, y_{i-j}, acc_prev, acc, 0]  :408 (a column's head row: all zero)
+            if constexpr (MONT) {
+                u32 acc_r[8];
+                mont_short<NWD>(p, a.mk.bk[NWD], a.mk.p, a.mk.n0inv, acc_r);
+                // acc_prev IS the row above's acc (position k - 1 of the same column; the first multiply-add starts from the constant 0)
+                uint4 pv[2];
+                {
+                    u32 up[8];
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) {
+                        const u32 sh = (u32)__builtin_amdgcn_ds_bpermute((int)((lane - 1) << 2), (int)acc_r[w]);
+                        up[w] = k >= 2 ? (lane == 0 ? carry_r[w] : sh) : 0u;
+                    }
+                    pv[0] = make_uint4(up[0], up[1], up[2], up[3]); pv[1] = make_uint4(up[4], up[5], up[6], up[7]);
+                }
+#pragma unroll
+                for (int w = 0; w < 8; ++w) carry_r[w] = (u32)__builtin_amdgcn_readlane((int)acc_r[w], 63);
+                const uint4 *opsr = reinterpret_cast<const uint4 *>(smem + lp.opsr);
+                const u32 xi = is_ma ? (qn ? 2 * L : 0) + j : 0, yi = is_ma ? (qn ? 3 * L : L) + (i - j) : 0;
+                const uint4 x0 = opsr[2 * xi], x1 = opsr[2 * xi + 1], y0 = opsr[2 * yi], y1 = opsr[2 * yi + 1];
+                srow[0] = is_ma ? x0 : Z4; srow[1] = is_ma ? x1 : Z4; srow[2] = is_ma ? y0 : Z4; srow[3] = is_ma ? y1 : Z4;
+                srow[4] = pv[0]; srow[5] = pv[1];
+                srow[6] = make_uint4(acc_r[0], acc_r[1], acc_r[2], acc_r[3]); srow[7] = make_uint4(acc_r[4], acc_r[5], acc_r[6], acc_r[7]);
+            } else {
             srow[0] = make_uint4((u32)x, (u32)(x >> 32), 0, 0); srow[1] = Z4;
             srow[2] = make_uint4((u32)y, (u32)(y >> 32), 0, 0); srow[3] = Z4;
             if constexpr (LW == 64) {
@@ -502,6 +595,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
             } else {
                 srow[4] = make_uint4(q[0], q[1], q[2], 0); srow[5] = Z4;
                 srow[6] = make_uint4(p[0], p[1], p[2], 0); srow[7] = Z4;
+            }
             }
             srow[8] = Z4; srow[9] = Z4;
             built = true; path = 1;
@@ -518,16 +612,16 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 const u32 *codes = f_src + (lastc ? CELLS_SRC_WORDS : 0u) + (is_range ? 0u : k * 3);
                 const u32 kc = c < 2 ? c : 2, kcp = c < 3 ? c - 1 : 2;   // (kcp is used for c >= 1 only)
                 auto entry = [&](u32 code, u32 &hi_off, u32 &xf) -> u32 {   // LDS byte address of the cell's entry; hi_off: of its high half
-                    const bool m1 = (code >> 16) & 1u, byk = (code >> 17) & 1u;
+                    const bool m1 = (code >> 17) & 1u, byk = (code >> 18) & 1u;
                     const u32 idx = byk ? (m1 ? kcp : kc) : (m1 ? c - 1 : c);
                     const bool zero = m1 && c == 0;
-                    const u32 addr = zero ? lp.ce : ((code & 0xfffu) + idx * ((code >> 12) & 15u)) << 4;
-                    hi_off = (!zero && ((code >> 18) & 1u)) ? addr + 16 : lp.ce;   // (no high half: the zero entry)
-                    xf = zero ? 0u : (code >> 19) & 15u;
+                    const u32 addr = zero ? lp.ce : ((code & 0x1fffu) + idx * ((code >> 13) & 15u)) << 4;
+                    hi_off = (!zero && ((code >> 19) & 1u)) ? addr + 16 : lp.ce;   // (no high half: the zero entry)
+                    xf = zero ? 0u : (code >> 20) & 15u;
                     return addr;
                 };
                 auto cut = [&](const uint4 &l, u32 xf) -> uint4 {   // 32-bit limbs: value >> 32, value mod 2^32, value with its low limb cleared
-                    if constexpr (LW == 64) return l;
+                    if constexpr (LW == 64 || MONT) return l;
                     else return xf == CE_COUT ? make_uint4(l.y, l.z, l.w, 0) : xf == CE_CMOD ? make_uint4(l.x, 0, 0, 0) : xf == CE_NQ1 ? make_uint4(0, l.y, l.z, l.w) : l;
                 };
                 u32 h0, h1, h2, x0, x1, x2;
@@ -538,13 +632,14 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 uint4 o[NP] = {l0, g0, l1, g1, l2, g2, Z4, Z4, Z4, Z4};
                 if (is_range) {   // RangeChip::assign(carry, ...)  :880-885
                     uint4 cv;
-                    if constexpr (LW == 64) cv = reinterpret_cast<const uint4 *>(smem + lp.cout)[c];
+                    if constexpr (MONT) { const U192 co = shr_limb(rdp(pSUM, c)); cv = make_uint4((u32)co.w[0], (u32)(co.w[0] >> 32), (u32)co.w[1], (u32)(co.w[1] >> 32)); }
+                    else if constexpr (LW == 64) cv = reinterpret_cast<const uint4 *>(smem + lp.cout)[c];
                     else cv = cut(reinterpret_cast<const uint4 *>(smem + lp.sum)[c], CE_COUT);
                     u64 c0, c1, c2, c3, rl, rh;
                     range_vals(((u64)cv.y << 32) | cv.x, ((u64)cv.w << 32) | cv.z, a.carry_nsub, a.carry_sub_bits, k - 18, c0, c1, c2, c3, rl, rh);
-                    o[0] = make_uint4((u32)c0, 0, 0, 0); o[1] = Z4; o[2] = make_uint4((u32)c1, 0, 0, 0); o[3] = Z4;
-                    o[4] = make_uint4((u32)c2, 0, 0, 0); o[5] = Z4; o[6] = make_uint4((u32)c3, 0, 0, 0); o[7] = Z4;
-                    o[8] = make_uint4((u32)rl, (u32)(rl >> 32), (u32)rh, (u32)(rh >> 32)); o[9] = Z4;
+                    using K1 = std::integral_constant<int, 1>;
+                    cell_k(K1{}, c0, 0, o[0], o[1]); cell_k(K1{}, c1, 0, o[2], o[3]); cell_k(K1{}, c2, 0, o[4], o[5]); cell_k(K1{}, c3, 0, o[6], o[7]);
+                    cell_k(std::integral_constant<int, LW == 64 ? 3 : 2>{}, rl, rh, o[8], o[9]);   // (a carry: 70 / 40 bits)
                 }
 #pragma unroll
                 for (u32 w = 0; w < NP; ++w) srow[w] = o[w];
@@ -668,7 +763,8 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 Fe xe;
                 field4(v0, true, xe.v);
                 const FieldConsts fc = *reinterpret_cast<const FieldConsts *>(a.ktab + CELLS_KT_FC);
-                const Fe iv = fe_inv_fast(xe, fc);
+                Fe iv = fe_inv_fast(xe, fc);
+                if constexpr (MONT) iv = fe_to_mont_k(iv, a.mk);
                 srow[2] = make_uint4((u32)iv.v[0], (u32)(iv.v[0] >> 32), (u32)iv.v[1], (u32)(iv.v[1] >> 32));
                 srow[3] = make_uint4((u32)iv.v[2], (u32)(iv.v[2] >> 32), (u32)iv.v[3], (u32)(iv.v[3] >> 32));
             }
@@ -678,20 +774,37 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
         wave_sync();
         u64 t_1 = 0;
         if constexpr (ABL & 256) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_1 = __builtin_amdgcn_s_memtime(); }
-        u8 *dst = out + (u64)r0 * ADVICE_ROW_BYTES;
-        auto put = [&](u32 u, const uint4 &v) {
-            if constexpr (ABL & 4) pst16(dst + (u64)u * 16, ((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z);
-            else if constexpr (!(ABL & 2)) st16(dst + (u64)u * 16, ((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z);
+        u8 *dst = out + (u64)r0 * a.dst.row_pitch;
+        auto put = [&](u8 *at, const uint4 &v) {
+            if constexpr (ABL & 4) pst16(at, ((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z);
+            else if constexpr (!(ABL & 2)) st16(at, ((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z);
             else if (v.x == 0x12345678u && v.w == 0x9abcdef0u) pst16(dst, 1, 2);   // (keeps the LDS reads alive)
         };
-        if (n_rows == 64) {   // ten LDS reads in flight, then ten 1 KB stores
-            uint4 v[NP];
+        if (!planar) {
+            if (n_rows == 64) {   // ten LDS reads in flight, then ten 1 KB stores
+                uint4 v[NP];
 #pragma unroll
-            for (u32 k = 0; k < NP; ++k) v[k] = stage[k * 64 + lane];
+                for (u32 k = 0; k < NP; ++k) v[k] = stage[k * 64 + lane];
 #pragma unroll
-            for (u32 k = 0; k < NP; ++k) put(k * 64 + lane, v[k]);
+                for (u32 k = 0; k < NP; ++k) put(dst + (u64)(k * 64 + lane) * 16, v[k]);
+            } else {
+                for (u32 u = lane; u < n_rows * NP; u += 64) put(dst + (u64)u * 16, stage[u]);
+            }
         } else {
-            for (u32 u = lane; u < n_rows * NP; u += 64) put(u, stage[u]);
+            // planar columns: the chunk is five runs of n_rows x 32 bytes, column c's at dst + c * col_pitch (row pitch 32: dst is the
+            // chunk's first row in column a).  Store k of the ten covers 16-byte pieces (k & 1) * 64 .. + 63 of column k / 2.
+            if (n_rows == 64) {
+                uint4 v[NP];
+#pragma unroll
+                for (u32 k = 0; k < NP; ++k) { const u32 piece = (k & 1) * 64 + lane; v[k] = stage[(piece >> 1) * NP + (k >> 1) * 2 + (piece & 1)]; }
+#pragma unroll
+                for (u32 k = 0; k < NP; ++k) put(dst + (u64)(k >> 1) * a.dst.col_pitch + (u64)((k & 1) * 64 + lane) * 16, v[k]);
+            } else {
+                for (u32 u = lane; u < n_rows * NP; u += 64) {
+                    const u32 col = u / (2 * n_rows), piece = u - col * 2 * n_rows;
+                    put(dst + (u64)col * a.dst.col_pitch + (u64)piece * 16, stage[(piece >> 1) * NP + col * 2 + (piece & 1)]);
+                }
+            }
         }
         wave_sync();
         if constexpr (ABL & 256) {

@@ -109,7 +109,7 @@ inline bool layout_perm_valid(const u8 (&col)[5], const h2r_fixed_row &f, bool i
     return true;
 }
 
-struct LayoutArgs { const u8 *kinds; u64 rows; u8 *image; u64 out_stride; u64 batch; const u8 *status; u8 perm[256][5]; };
+struct LayoutArgs { const u8 *kinds; u64 rows; AdviceDst dst; u64 batch; const u8 *status; u8 perm[256][5]; };
 
 // one thread per row: the row's five cells move to the columns the layout gives its kind (in place: a thread owns its row)
 __global__ __launch_bounds__(256) void advice_layout_kernel(LayoutArgs a) {
@@ -119,12 +119,12 @@ __global__ __launch_bounds__(256) void advice_layout_kernel(LayoutArgs a) {
     const u64 r = gid - elem * a.rows;
     const u8 *pm = a.perm[a.kinds[r]];
     if (pm[0] == 0 && pm[1] == 1 && pm[2] == 2 && pm[3] == 3 && pm[4] == 4) return;
-    uint4 *row = reinterpret_cast<uint4 *>(a.image + elem * a.out_stride + r * ADVICE_ROW_BYTES);
+    u8 *row = a.dst.elem(elem) + r * a.dst.row_pitch;   // (whole 32-byte cells move: the representation of their contents does not matter)
     uint4 v[10];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) v[k] = row[k];
+    for (int k = 0; k < 5; ++k) { const uint4 *c = reinterpret_cast<const uint4 *>(row + (u64)k * a.dst.col_pitch); v[2 * k] = c[0]; v[2 * k + 1] = c[1]; }
 #pragma unroll
-    for (int k = 0; k < 5; ++k) { row[2 * pm[k]] = v[2 * k]; row[2 * pm[k] + 1] = v[2 * k + 1]; }
+    for (int k = 0; k < 5; ++k) { uint4 *c = reinterpret_cast<uint4 *>(row + (u64)pm[k] * a.dst.col_pitch); c[0] = v[2 * k]; c[1] = v[2 * k + 1]; }
 }
 
 }  // namespace h2r

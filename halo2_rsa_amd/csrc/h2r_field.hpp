@@ -207,7 +207,82 @@ H2R_FD Fe fe_inv_fast(const Fe &a, const FieldConsts &f) {
     return fe_inv(a, f);
 }
 
+// ---- the prover's in-memory form: x * R mod p, R = 2^256 (halo2curves bn256 / pasta field elements are four 64-bit words in
+// Montgomery form) -------------------------------------------------------------------------------------------------------
+// Almost every cell of the witness is a SHORT integer (a sub-limb, a limb, a 70-bit carry, a 133-bit accumulator), and for a
+// K-dword x the product x * R is one Montgomery multiplication by 2^(32 K) * R mod p with only K reduction steps:
+//     x * (2^(32 K) R) * 2^(-32 K) = x R (mod p),   result < 2 p before the final conditional subtraction,
+// i.e. 17 K 32-bit multiply-adds instead of the 136 of the generic R^2 multiplication.  MontK holds those multipliers.
+struct MontK {
+    uint32_t p[8];         // modulus, 32-bit digits
+    uint32_t n0inv;        // -p^-1 mod 2^32
+    uint32_t pad_[3];
+    uint32_t bk[9][8];     // bk[K] = 2^(32 K) * R mod p (bk[0] = R mod p: the Montgomery form of 1; bk[8] = R^2 mod p)
+};
+
+template <int K>
+H2R_FD void mont_short(const uint32_t (&x)[K], const uint32_t *b, const uint32_t *p, uint32_t n0inv, uint32_t (&t)[8]) {
+    static_assert(K >= 1 && K <= 8, "digits of the short operand");
+    uint32_t t8 = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = 0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const uint64_t acc = (uint64_t)x[i] * b[j] + t[j] + c; t[j] = (uint32_t)acc; c = acc >> 32; }
+        t8 = (uint32_t)c;                                  // (t < 2 p < 2^255 after every step: nothing is pending in t8)
+        const uint32_t m = t[0] * n0inv;
+        c = ((uint64_t)m * p[0] + t[0]) >> 32;
+#pragma unroll
+        for (int j = 1; j < 8; ++j) { const uint64_t acc = (uint64_t)m * p[j] + t[j] + c; t[j - 1] = (uint32_t)acc; c = acc >> 32; }
+        t[7] = t8 + (uint32_t)c;                           // < 2^31
+    }
+    // t in [0, 2 p): one conditional subtraction
+    uint32_t d[8]; uint64_t br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const uint64_t s = (uint64_t)t[j] - p[j] - br; d[j] = (uint32_t)s; br = (s >> 32) & 1u; }
+    if (!br) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = d[j];
+    }
+}
+// p - t for t in [0, p) (0 stays 0): the Montgomery form of -x from that of x
+H2R_FD void mont_neg(uint32_t (&t)[8], const uint32_t *p) {
+    uint32_t nz = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) nz |= t[j];
+    if (!nz) return;
+    uint64_t br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const uint64_t s = (uint64_t)p[j] - t[j] - br; t[j] = (uint32_t)s; br = (s >> 32) & 1u; }
+}
+// canonical element (< p) -> Montgomery form, whatever its size: the generic K = 8 case
+H2R_FD Fe fe_to_mont_k(const Fe &a, const MontK &m) {
+    uint32_t x[8], t[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { x[2 * k] = (uint32_t)a.v[k]; x[2 * k + 1] = (uint32_t)(a.v[k] >> 32); }
+    mont_short<8>(x, m.bk[8], m.p, m.n0inv, t);
+    Fe r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r.v[k] = ((uint64_t)t[2 * k + 1] << 32) | t[2 * k];
+    return r;
+}
+
 // Host: derive the Montgomery constants of modulus p.
+inline void field_consts_init(const uint64_t p[4], FieldConsts *f);
+inline void montk_init(const uint64_t p[4], MontK *m) {
+    FieldConsts f;
+    field_consts_init(p, &f);
+    for (int k = 0; k < 4; ++k) { m->p[2 * k] = (uint32_t)p[k]; m->p[2 * k + 1] = (uint32_t)(p[k] >> 32); }
+    m->n0inv = (uint32_t)f.n0inv;
+    m->pad_[0] = m->pad_[1] = m->pad_[2] = 0;
+    Fe x; for (int k = 0; k < 4; ++k) x.v[k] = f.one[k];   // R mod p, then doubled 32 times per entry
+    for (int K = 0; K <= 8; ++K) {
+        for (int k = 0; k < 4; ++k) { m->bk[K][2 * k] = (uint32_t)x.v[k]; m->bk[K][2 * k + 1] = (uint32_t)(x.v[k] >> 32); }
+        for (int i = 0; i < 32; ++i) x = fe_add(x, x, f.p);
+    }
+}
 inline void field_consts_init(const uint64_t p[4], FieldConsts *f) {
     for (int k = 0; k < 4; ++k) f->p[k] = p[k];
     uint64_t inv = 1;                                   // Newton: inv = p^-1 mod 2^64

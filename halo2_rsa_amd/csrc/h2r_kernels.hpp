@@ -2688,6 +2688,54 @@ struct RecView {   // reads of one record through the documented plane layout (i
 #define H2R_ADVICE_INV 1
 #endif
 constexpr u32 ADVICE_ROW_BYTES = 160;
+// Where the cells of an advice image go, in either representation (h2r_advice_repr): cell (element e, row r, column c) lies at
+//     base + e * elem_stride + r * row_pitch + c * col_pitch.
+// Row-major image (the default): row_pitch = 160, col_pitch = 32.  Planar columns (H2R_ADVICE_COLUMNS, what a prover holds: one
+// contiguous vector per advice column): row_pitch = 32, col_pitch = the caller's column stride.  mont (H2R_ADVICE_MONTGOMERY):
+// the cells are x * R mod p (the in-memory form of halo2curves / pasta field elements) instead of canonical integers.
+struct AdviceDst {
+    u8 *base; u64 elem_stride, col_pitch; u32 row_pitch, mont;
+    __host__ __device__ bool planar() const { return row_pitch != ADVICE_ROW_BYTES; }
+    __host__ __device__ AdviceDst at_row(u64 r) const { AdviceDst d = *this; d.base += r * row_pitch; return d; }   // the image that starts r rows further down
+    __device__ __forceinline__ u8 *elem(u64 e) const { return base + e * elem_stride; }
+};
+// canonical cell -> the destination's form (zero and one-limb values, nearly every cell of the small kernels, take the short product)
+__device__ __forceinline__ void advice_cell_repr(uint4 &lo, uint4 &hi, const MontK *mk) {
+    if ((lo.x | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) == 0) return;
+    u32 t[8];
+    if ((lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) == 0) { const u32 x[2] = {lo.x, lo.y}; mont_short<2>(x, mk->bk[2], mk->p, mk->n0inv, t); }
+    else { const u32 x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}; mont_short<8>(x, mk->bk[8], mk->p, mk->n0inv, t); }
+    lo = make_uint4(t[0], t[1], t[2], t[3]); hi = make_uint4(t[4], t[5], t[6], t[7]);
+}
+// one cell of the element image at `img` (= dst.elem(e))
+__device__ __forceinline__ void advice_put_cell(const AdviceDst &d, const MontK *mk, u8 *img, u64 row, u32 col, uint4 lo, uint4 hi) {
+    if (d.mont) advice_cell_repr(lo, hi, mk);
+    u8 *p = img + row * d.row_pitch + (u64)col * d.col_pitch;
+    *reinterpret_cast<uint4 *>(p) = lo; *reinterpret_cast<uint4 *>(p + 16) = hi;
+}
+// The rows a workgroup of NT threads staged in LDS (row-major, canonical cells, 160 bytes each) leave for rows [r0, r0 + n_rows) of the
+// element image at `img`.  The default representation IS the stage: full 16-byte-per-lane lines.  Otherwise one thread per cell;
+// planar: consecutive threads take consecutive rows of one column (32 contiguous bytes each).
+template <u32 NT>
+__device__ __forceinline__ void advice_flush(const AdviceDst &d, const MontK *mk, u8 *img, u64 r0, u32 n_rows, const uint4 *stage, u32 tid) {
+    if (!d.mont && !d.planar()) {
+        u8 *dst = img + r0 * ADVICE_ROW_BYTES;
+        for (u32 k = tid; k < n_rows * (ADVICE_ROW_BYTES / 16); k += NT) {
+            const uint4 v = stage[k];
+            st16(dst + 16ull * k, ((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z);
+        }
+        return;
+    }
+    const bool planar = d.planar();
+    for (u32 k = tid; k < n_rows * 5; k += NT) {
+        const u32 row = planar ? k % n_rows : k / 5, col = planar ? k / n_rows : k - 5 * (k / 5);
+        uint4 lo = stage[row * 10 + 2 * col], hi = stage[row * 10 + 2 * col + 1];
+        if (d.mont) advice_cell_repr(lo, hi, mk);
+        u8 *p = img + (r0 + row) * d.row_pitch + (u64)col * d.col_pitch;
+        st16(p, ((u64)lo.y << 32) | lo.x, ((u64)lo.w << 32) | lo.z);
+        st16(p + 16, ((u64)hi.y << 32) | hi.x, ((u64)hi.w << 32) | hi.z);
+    }
+}
 constexpr u32 ADVICE_STAGE_ROWS = 256;   // rows built in LDS per stage (= the workgroup size)
 constexpr u32 ADVICE_COL_ROWS = 23;    // main-gate rows of one is_equal_muled column besides the carry's range assign
 __host__ __device__ inline u32 advice_rows_per_record(u32 L, u32 carry_nsub) {
@@ -2791,7 +2839,7 @@ struct AdviceArgs {
     const void *opA, *opB; u64 op_stride; const void *n; u64 n_stride;
     const u8 *status;
     const u8 *trace; u64 elem_stride, off_records, record_stride; u32 T; u64 n_items;
-    u8 *out; u64 out_stride;            // element e's image at out + e * out_stride: pre_rows rows, then record t at + (pre_rows + t * rows) * 160
+    AdviceDst dst; const MontK *mk;     // element e's image: pre_rows rows, then record t from row pre_rows + t * rows (+ the select rows) on
     u64 off[H2R_PL_COUNT];
     u32 L, carry_bits, carry_sub_bits, carry_nsub, carry_sub_stride;
     u32 rows;                           // rows of one record
@@ -2826,10 +2874,10 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
         sq[k] = rv.limb(H2R_PL_Q, k); sr[k] = rv.limb(H2R_PL_R, k);
     }
     __syncthreads();
-    u8 *out = a.out + (u64)elem * a.out_stride + ((u64)a.pre_rows + (u64)t * a.rows + (u64)((t + 1) >> 1) * a.sel_rows) * ADVICE_ROW_BYTES;
-    if (t == 0 && tid < a.pre_rows) {   // the constant limbs of pow_mod_fixed_exp's acc = 1: [1, 0, 0, 0, 0] then [0, ...]
-        uint4 *pr = reinterpret_cast<uint4 *>(a.out + (u64)elem * a.out_stride + (u64)tid * ADVICE_ROW_BYTES);
-        for (u32 k = 0; k < ADVICE_ROW_BYTES / 16; ++k) pr[k] = make_uint4((k == 0 && tid == 0) ? 1u : 0u, 0, 0, 0);
+    u8 *img = a.dst.elem(elem);
+    const u64 row_base = (u64)a.pre_rows + (u64)t * a.rows + (u64)((t + 1) >> 1) * a.sel_rows;   // the record's first row in the element image
+    if (t == 0 && tid < a.pre_rows * 5) {   // the constant limbs of pow_mod_fixed_exp's acc = 1: [1, 0, 0, 0, 0] then [0, ...]
+        advice_put_cell(a.dst, a.mk, img, tid / 5, tid % 5, make_uint4(tid == 0 ? 1u : 0u, 0, 0, 0), make_uint4(0, 0, 0, 0));
     }
     const U192 Z = U192::make(0, 0, 0);
     const U192 B = LW == 64 ? U192::make(0, 1, 0) : U192::make(1ull << 32, 0, 0);   // 2^w
@@ -3033,12 +3081,7 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
       __syncthreads();
       if (H2R_ADV_ABL != 2) if (r0 + SR < a.rows) plan_and_load(tid < SR ? r0 + SR + tid : a.rows);   // in flight while this stage leaves for HBM
       const u32 n_rows = a.rows - r0 < SR ? a.rows - r0 : SR;
-      uint4 *dst = reinterpret_cast<uint4 *>(out + (u64)r0 * ADVICE_ROW_BYTES);
-      if (H2R_ADV_ABL != 3)
-      for (u32 k = tid; k < n_rows * (ADVICE_ROW_BYTES / 16); k += 256) {
-          const uint4 v = stage[k];
-          st16(reinterpret_cast<u8 *>(dst + k), ((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z);
-      }
+      if (H2R_ADV_ABL != 3) advice_flush<256>(a.dst, a.mk, img, row_base + r0, n_rows, stage, tid);
       __syncthreads();
     }
 }

@@ -275,7 +275,7 @@ struct RowProgArgs {
     const void *a, *b, *n; u64 a_stride, b_stride, n_stride;   // limbs between the elements' operands (0: one shared integer)
     const u8 *trace; u64 elem_stride, first_off;               // element e's region at trace + e * elem_stride + first_off
     const u8 *status; u64 batch;
-    u8 *out; u64 out_stride;
+    AdviceDst dst; const MontK *mk;     // the program's first row = row 0 of dst
     FieldConsts f;
     const u32 *inv_rows; u32 n_inv;     // the rows with an RP_INV34 cell (rowprog_inv_kernel fills those cells)
 };
@@ -375,11 +375,7 @@ __global__ __launch_bounds__(256) void rowprog_kernel(RowProgArgs a) {
     }
     __syncthreads();
     const u32 n_rows = a.rows - r0 < SR ? a.rows - r0 : SR;
-    u8 *dst = a.out + (u64)elem * a.out_stride + (u64)r0 * ADVICE_ROW_BYTES;
-    for (u32 k = tid; k < n_rows * (ADVICE_ROW_BYTES / 16); k += 256) {
-        const uint4 v = stage[k];
-        st16(dst + 16ull * k, ((u64)v.y << 32) | v.x, ((u64)v.w << 32) | v.z);
-    }
+    advice_flush<256>(a.dst, a.mk, a.dst.elem(elem), r0, n_rows, stage, tid);
 }
 
 
@@ -409,8 +405,8 @@ __global__ __launch_bounds__(256) void rowprog_inv_kernel(RowProgArgs a) {
     __syncthreads();
     if (tid < cnt) {
         const Fe iv = fe_inv_fast(l_d[tid], a.f);
-        u8 *p = a.out + (u64)l_elem[tid] * a.out_stride + (u64)l_row[tid] * ADVICE_ROW_BYTES + 32;
-        st16(p, iv.v[0], iv.v[1]); st16(p + 16, iv.v[2], iv.v[3]);
+        advice_put_cell(a.dst, a.mk, a.dst.elem(l_elem[tid]), l_row[tid], 1, make_uint4((u32)iv.v[0], (u32)(iv.v[0] >> 32), (u32)iv.v[1], (u32)(iv.v[1] >> 32)),
+                        make_uint4((u32)iv.v[2], (u32)(iv.v[2] >> 32), (u32)iv.v[3], (u32)(iv.v[3] >> 32)));
     }
 }
 

@@ -26,7 +26,7 @@ struct VarRowsArgs {
     const u8 *status; u64 batch;
     u32 L, T, nbits, exp_limb_bits, e_num_limbs;
     u32 rows;                                      // rows of one mul_mod
-    u8 *out; u64 out_stride;
+    AdviceDst dst; const MontK *mk;                // row 0 of dst = the element's first to_bits row
 };
 
 __host__ __device__ inline u32 var_to_bits_rows(u32 exp_limb_bits) { return exp_limb_bits + (exp_limb_bits + 3) / 4 + 1; }
@@ -74,9 +74,9 @@ __global__ __launch_bounds__(256) void var_rows_kernel(VarRowsArgs a) {
         c[0] = bit; c[1] = muled; c[2] = bit; c[3] = acc; c[4] = sel;
         out_row = (u64)rows_a + 2 + (u64)t * (2ull * a.rows + a.L) + a.rows + j;
     }
-    uint4 *p = reinterpret_cast<uint4 *>(a.out + elem * a.out_stride + out_row * ADVICE_ROW_BYTES);
+    u8 *img = a.dst.elem(elem);
 #pragma unroll
-    for (int q = 0; q < 5; ++q) { p[2 * q] = make_uint4((u32)c[q], (u32)(c[q] >> 32), 0, 0); p[2 * q + 1] = make_uint4(0, 0, 0, 0); }
+    for (int q = 0; q < 5; ++q) advice_put_cell(a.dst, a.mk, img, out_row, q, make_uint4((u32)c[q], (u32)(c[q] >> 32), 0, 0), make_uint4(0, 0, 0, 0));
 }
 
 }  // namespace h2r

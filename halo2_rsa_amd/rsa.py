@@ -39,10 +39,10 @@ class RSASignature:
 class RSAChip:
     LIMB_WIDTH = 64  # src/chip.rs:203
 
-    def __init__(self, bits_len: int, exp_limb_bits: int, field: str = "bn254_fr", device: int = 0):
-        """RSAChip::new (src/chip.rs:214-221)."""
+    def __init__(self, bits_len: int, exp_limb_bits: int, field: str = "bn254_fr", device: int = 0, **advice_repr):
+        """RSAChip::new (src/chip.rs:214-221).  advice_repr: BigIntChip's columns / montgomery / col_stride."""
         self.bits_len, self.exp_limb_bits = bits_len, exp_limb_bits
-        self._bigint = BigIntChip(self.LIMB_WIDTH, bits_len, field, device)
+        self._bigint = BigIntChip(self.LIMB_WIDTH, bits_len, field, device, **advice_repr)
 
     def bigint_chip(self) -> BigIntChip:
         """src/chip.rs:224-230."""
@@ -287,13 +287,16 @@ class VerifyResult:
         batch = sig.batch
         total, _ = self.advice_sections()
         pre = int(lib().h2r_hashed_msg_advice_rows(self.chip._ctx)) if with_hashed_msg else 0
-        out = torch.empty((batch, (pre + total) * 160), dtype=torch.uint8, device=self.trace.device)
+        if pre and self.chip.columns and not self.chip.col_stride:
+            raise ValueError("emit_advice(with_hashed_msg): two calls write one image -- planar columns need a fixed col_stride")
+        out = torch.empty((batch, self.chip.image_bytes(pre + total)), dtype=torch.uint8, device=self.trace.device)
+        row_bytes = 32 if self.chip.columns else 160
         if with_hashed_msg:
             check(lib().h2r_hashed_msg_emit_advice(self.chip._ctx, self.hashed_msg_trace.data_ptr(), self.hashed_msg_trace.shape[1], batch,
                                                    None, out.data_ptr(), out.shape[1], self.chip._stream()), "h2r_hashed_msg_emit_advice")
         check(lib().h2r_verify_emit_advice(self.chip._ctx, ctypes.byref(self.layout), sig.data_ptr(), n.data_ptr(), hashed.data_ptr(),
                                            self.powed.data_ptr(), self.chip._flags(n, batch) | (H2R_ADVICE_DIRECT if direct else 0), self.trace.data_ptr(),
-                                           self.workspace.data_ptr(), batch, self.status.data_ptr(), out.data_ptr() + pre * 160, out.shape[1],
+                                           self.workspace.data_ptr(), batch, self.status.data_ptr(), out.data_ptr() + pre * row_bytes, out.shape[1],
                                            self.chip._stream()), "h2r_verify_emit_advice")
         return out
 

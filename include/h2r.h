@@ -46,7 +46,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define H2R_VERSION 3
+#define H2R_VERSION 4
 
 /* ---- status codes (function return values and per-element status bytes) ---------------------- */
 enum {
@@ -176,6 +176,40 @@ typedef struct h2r_pow_layout {
  * H2R_E_UNSUPPORTED when no kernel is compiled for the shape. */
 int32_t h2r_ctx_create(const h2r_params *params, h2r_ctx **out);
 void h2r_ctx_destroy(h2r_ctx *ctx);
+
+/* ---- representation of the field elements that cross the boundary (a property of the CONSUMER, fixed per ctx) -------------
+ * The reference hands every value to halo2 as `Value<F>` (big_integer/chip.rs:408, 590, 598; benches/bench.rs:35, 321-329:
+ * F = bn256::Fr).  [3P: halo2curves / pasta_curves, not in the reference tree] such an F lives in memory as four 64-bit words in
+ * MONTGOMERY form (x * R mod p, R = 2^256), and halo2 keeps ONE CONTIGUOUS VECTOR PER ADVICE COLUMN.  The default image of this
+ * library is row-major (five 32-byte cells per 160-byte row) with canonical little-endian integers: what a host-side shim that
+ * calls `F::from_repr` per cell wants.  A consumer that takes the witness as columns of F -- a device prover, or a Rust shim that
+ * memcpys into `Vec<F>` -- creates its ctx with
+ *   H2R_ADVICE_COLUMNS     every image is planar: cell (element e, row r, column c) at
+ *                            advice_out + e * out_stride + c * col_stride + r * 32
+ *                          col_stride = bytes between an element's column vectors (2^k * 32 for halo2's 2^k-row columns; multiple of
+ *                          16); 0 = packed: the five columns of a call's image back to back (col_stride = rows of that image * 32).
+ *                          Both [element][column][row] (out_stride >= 4 col_stride + rows * 32) and [column][element][row]
+ *                          (col_stride >= batch * out_stride) arrangements are accepted; a region that starts at row r0 of the
+ *                          caller's columns is addressed by passing advice_out + r0 * 32.
+ *   H2R_ADVICE_MONTGOMERY  every FIELD ELEMENT that crosses the boundary is x * R mod p: the cells of every image, the selectors of
+ *                          h2r_advice_fixed_row[_ex], the table of h2r_lookup_table_image, theta and the A' / S' columns of
+ *                          h2r_lookup_permuted_columns.  (Limbs, records, streams and statuses are integers, not field elements:
+ *                          unchanged.)
+ * Every *_emit_advice export, h2r_pipeline_modpow_public_key_advice and h2r_advice_apply_layout follow the ctx's representation;
+ * their `out_stride` stays the ELEMENT stride.  h2r_ctx_create == h2r_ctx_create_ex(params, NULL): row-major, canonical.
+ * struct_size must be sizeof(h2r_advice_repr) (H2R_E_UNSUPPORTED otherwise: a caller built against another header);
+ * h2r_abi_version() returns the H2R_VERSION the library was built from -- a binder checks it against its own header before it
+ * passes any struct (h2r_pow_layout, h2r_verify_layout, h2r_lookup_config, h2r_advice_layout carry no size field). */
+#define H2R_ADVICE_COLUMNS 0x400u
+#define H2R_ADVICE_MONTGOMERY 0x800u
+typedef struct h2r_advice_repr {
+    uint32_t struct_size; /* sizeof(h2r_advice_repr) */
+    uint32_t flags;       /* H2R_ADVICE_COLUMNS | H2R_ADVICE_MONTGOMERY */
+    uint64_t col_stride;  /* H2R_ADVICE_COLUMNS only; 0 = packed */
+} h2r_advice_repr;
+int32_t h2r_ctx_create_ex(const h2r_params *params, const h2r_advice_repr *repr, h2r_ctx **out);
+int32_t h2r_ctx_advice_repr(const h2r_ctx *ctx, h2r_advice_repr *out);
+uint32_t h2r_abi_version(void);
 
 /* BigIntChip::compute_range_lens (big_integer/chip.rs:1220-1249).  Host-only, no ctx needed. */
 int32_t h2r_compute_range_lens(uint32_t limb_width, uint32_t num_limbs,
@@ -645,8 +679,10 @@ int32_t h2r_lookup_permuted_columns(const h2r_ctx *ctx, const h2r_lookup_config 
                                     h2r_stream_t stream);
 /* Arithmetic of the ctx's field on canonical elements (host): op 0 = a + b, 1 = a - b, 2 = a * b, 3 = a^-1 (b ignored; a != 0;
  * binary extended Euclid), 4 = a^(p-2) (Fermat: the cross-check of 3), 5 = a^-1 as the kernels compute main_gate.is_zero's witness
- * (classical Euclid on (p, s) when a = +-s with s < 2^64 -- the only differences this path produces --, op 3 otherwise).
- * The same code the kernels run (lookup compression, main_gate.is_zero's inverse witness). */
+ * (classical Euclid on (p, s) when a = +-s with s < 2^64 -- the only differences this path produces --, op 3 otherwise),
+ * 6 = a * R mod p (R = 2^256: into the Montgomery form of H2R_ADVICE_MONTGOMERY, by the short product the kernels use for a cell),
+ * 7 = a * R^-1 mod p (a Montgomery-form element back to its canonical integer), 8 = a * R mod p by the generic R^2 product.
+ * The same code the kernels run (lookup compression, main_gate.is_zero's inverse witness, the cells' representation). */
 int32_t h2r_field_eval(const h2r_ctx *ctx, uint32_t op, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
 
 /* ---- host-side helpers (no device work) --------------------------------------------------------

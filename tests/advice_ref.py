@@ -709,3 +709,31 @@ def fixed_row_bits_compose(kind):
     f["se"] = -1
     f["se_next"] = 0 if last else 1
     return f
+
+
+# ---- the consumer's representation (include/h2r.h h2r_advice_repr) --------------------------------------------------------------
+R256 = 1 << 256
+
+
+def image_to_repr(rowmajor, rows, P, columns=False, montgomery=False, col_stride=0, fill=0):
+    """The default image of ONE element -- uint8 array of rows * 160 bytes, row-major, canonical little-endian cells -- as the
+    planar (one contiguous vector per column, `col_stride` bytes apart; 0 = packed) and / or Montgomery-form (x * R mod p,
+    R = 2^256: the in-memory form of halo2curves / pasta field elements [3P]) image the library writes for a ctx created with
+    H2R_ADVICE_COLUMNS / H2R_ADVICE_MONTGOMERY.  Bytes the image does not cover are `fill`."""
+    rm = np.ascontiguousarray(rowmajor, dtype=np.uint8).reshape(rows, 5, 32)
+    if montgomery:
+        words = rm.view("<u8").reshape(rows * 5, 4)
+        out = np.empty((rows * 5, 4), dtype=np.uint64)
+        for k in range(rows * 5):
+            v = int(words[k, 0]) | int(words[k, 1]) << 64 | int(words[k, 2]) << 128 | int(words[k, 3]) << 192
+            if v:
+                v = v * R256 % P
+            out[k] = (v & 0xFFFFFFFFFFFFFFFF, (v >> 64) & 0xFFFFFFFFFFFFFFFF, (v >> 128) & 0xFFFFFFFFFFFFFFFF, v >> 192)
+        rm = out.view(np.uint8).reshape(rows, 5, 32)
+    if not columns:
+        return rm.reshape(-1).copy()
+    cs = col_stride or rows * 32
+    buf = np.full(4 * cs + rows * 32, fill, dtype=np.uint8)
+    for c in range(5):
+        buf[c * cs:c * cs + rows * 32] = rm[:, c, :].reshape(-1)
+    return buf
