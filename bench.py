@@ -293,16 +293,21 @@ def advice_bench(args):
     e, chunk, steps, warmup = env.broadcast_ints([e, chunk, args.steps, args.warmup])
     global_batch = chunk * env.world
     lo, hi = shard_range(global_batch, env.rank, env.world)
-    chip = H.BigIntChip(w, bits, device=env.local_rank)
-    ns, xs, un, ux = synth_inputs(w, bits, lo, hi)
-    n_dev, x_dev = chip.assign_integer(un), chip.assign_integer(ux)
-    pl = chip.pow_fixed_layout(e)
-    dev = "cuda:%d" % env.local_rank
+    # --columns / --montgomery: the image in the PROVER'S representation (h2r_advice_repr): planar column vectors (here 4 KB-aligned
+    # columns just long enough for the element's rows; a prover's are 2^k rows) of x * R mod p cells
+    probe = H.BigIntChip(w, bits, device=env.local_rank)
+    pl = probe.pow_fixed_layout(e)
     L = _lib.lib()
     sec = (ctypes.c_uint64 * 2)()
-    rows = int(L.h2r_modpow_public_key_advice_rows(chip._ctx, ctypes.byref(pl), sec))
+    rows = int(L.h2r_modpow_public_key_advice_rows(probe._ctx, ctypes.byref(pl), sec))
     pow_rows = int(sec[1])
-    elem_bytes = rows * 160
+    col_stride = ((rows * 32 + 4095) // 4096) * 4096 if args.columns else 0
+    chip = H.BigIntChip(w, bits, device=env.local_rank, columns=args.columns, montgomery=args.montgomery, col_stride=col_stride) if (args.columns or args.montgomery) else probe
+    row_bytes = 32 if args.columns else 160
+    ns, xs, un, ux = synth_inputs(w, bits, lo, hi)
+    n_dev, x_dev = chip.assign_integer(un), chip.assign_integer(ux)
+    dev = "cuda:%d" % env.local_rank
+    elem_bytes = 5 * col_stride if args.columns else rows * 160
     nimg = int(os.environ.get("H2R_BENCH_ADV_DEPTH", "2"))   # image / workspace sets the calls rotate through (developer: 2..4)
     wss = [torch.zeros(chip.workspace_bytes(chunk, pl.num_mul_mods), dtype=torch.uint8, device=dev) for _ in range(nimg)]
     # Placement: like the record kernel's trace regions an image buffer has a store rate of its own, stable for
@@ -324,7 +329,7 @@ def advice_bench(args):
             ta.record()
             for _ in range(2):
                 _lib.check(L.h2r_pow_trace_emit_advice(chip._ctx, ctypes.byref(pl), n_dev.data_ptr(), _lib.H2R_ADVICE_DIRECT, None, 0, wss[0].data_ptr(),
-                                                       chunk, first.status.data_ptr(), buf.data_ptr() + int(sec[0]) * 160, elem_bytes, chip._stream()),
+                                                       chunk, first.status.data_ptr(), buf.data_ptr() + int(sec[0]) * row_bytes, elem_bytes, chip._stream()),
                            "h2r_pow_trace_emit_advice")
             tb.record()
             torch.cuda.synchronize()
@@ -381,7 +386,7 @@ def advice_bench(args):
             s_cells.wait_event(chain_done[k])
             # the pow rows, written directly from the call's operands (h2r_modpow_public_key_emit_advice = the two exports in a row)
             _lib.check(L.h2r_pow_trace_emit_advice(chip._ctx, ctypes.byref(pl), n_dev.data_ptr(), _lib.H2R_ADVICE_DIRECT, None, 0, wss[k].data_ptr(),
-                                                   chunk, sts[k].data_ptr(), images[k].data_ptr() + int(sec[0]) * 160, elem_bytes, chip._stream()),
+                                                   chunk, sts[k].data_ptr(), images[k].data_ptr() + int(sec[0]) * row_bytes, elem_bytes, chip._stream()),
                        "h2r_pow_trace_emit_advice")
             cells_done[k].record(s_cells)
         issued[0] += 1
@@ -425,6 +430,9 @@ def advice_bench(args):
     ref_img = ref.emit_modpow_advice(direct=False)
     torch.cuda.synchronize()
     timed = images[last].view(chunk, elem_bytes)[:sample]
+    if args.columns:   # (the columns are longer than the element's rows: compare what the image covers)
+        timed = timed.view(sample, 5, col_stride)[:, :, :rows * 32].reshape(sample, -1)
+        ref_img = ref_img.view(sample, 5, col_stride)[:, :, :rows * 32].reshape(sample, -1)
     ok = ref.status.cpu().numpy() == 0
     assert torch.equal(timed[torch.from_numpy(ok).to(timed.device)], ref_img[torch.from_numpy(ok).to(ref_img.device)]), \
         "the timed advice image differs from the image of the records"
@@ -443,8 +451,10 @@ def advice_bench(args):
             "ms_per_step": round(1e3 * dt / steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u%d" % w, "data": "synthetic",
             "config": {"workload": "%s batch=%d per GPU, %d-bit limbs, advice image (%d rows = %d B/assign: %d assert_in_field rows + %d pow rows)" %
-                                   (args.workload, chunk, w, rows, elem_bytes, int(sec[0]), pow_rows),
+                                   (args.workload, chunk, w, rows, rows * 160, int(sec[0]), pow_rows),
                        "path": "advice image",
+                       "representation": {"columns": bool(args.columns), "montgomery": bool(args.montgomery), "col_stride": col_stride,
+                                          "note": "planar: one contiguous vector per advice column; montgomery: cells = x * 2^256 mod p (the in-memory form of a halo2 field element)"},
                        "per_gpu_batch": chunk, "global_batch": global_batch, "calls_per_step": 1, "signatures_per_call": chunk,
                        "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world, "ranks": env.world,
                        "pipeline": ("h2r_pipeline_modpow_public_key_advice: chain kernels of call k+1 on the caller's stream next to cells_kernel of call k on the "
@@ -453,7 +463,7 @@ def advice_bench(args):
                        "untimed_clock_warmup_calls": ramp, "warmup_calls_total": 1 + ramp + warmup, "buffer_placement": placement},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
-                         "traffic_source": "not measured", "kernel": "cells_kernel<%d>" % w, "launches_timed": len(cells_ms),
+                         "traffic_source": "not measured", "kernel": "cells_kernel<%d%s>" % (w, ", Montgomery" if args.montgomery else ""), "launches_timed": len(cells_ms),
                          "signatures_per_launch": chunk, "avg_launch_ms": round(1e3 * avg_s, 4) if cells_ms else None,
                          "timing": ("avg_launch_ms = the launches' period (timed wall time / launches): two cells launches are in flight at a time; "
                                     "avg_launch_ms_in_flight = a launch's own start-to-end time (HIP events stamped by the dispatch)") if overlapped else
@@ -462,10 +472,11 @@ def advice_bench(args):
                          "algorithmic_bytes_per_launch": algo,
                          "chain_kernel_avg_ms": round(sum(chain_ms) / len(chain_ms), 4) if chain_ms else None,
                          "in_field_rows_kernel_avg_ms": round(sum(emit_ms) / len(emit_ms), 4) if emit_ms else None},
-            "whole_path_hbm_frac": round(global_batch * steps / dt * elem_bytes / (env.world * HBM_PEAK_GBS * 1e9), 4),
+            "whole_path_hbm_frac": round(global_batch * steps / dt * rows * 160 / (env.world * HBM_PEAK_GBS * 1e9), 4),
         }
         if env.world == 1 and args.pmc_traffic == "auto" and cells_ms:
-            hbm, how = measured_pmc_traffic(["--advice", "--workload", args.workload, "--batch", str(chunk)], "cells_kernel")   # (the passes run with --placement-candidates 0)
+            hbm, how = measured_pmc_traffic(["--advice", "--workload", args.workload, "--batch", str(chunk)] + (["--columns"] if args.columns else []) +
+                                            (["--montgomery"] if args.montgomery else []), "cells_kernel")   # (the passes run with --placement-candidates 0)
             if hbm is not None:
                 line["roofline"]["traffic"] = hbm
                 line["roofline"]["traffic_source"] = how
@@ -510,6 +521,8 @@ def main():
     ap.add_argument("--advice", action="store_true",
                     help="time the prover-consumable witness: every step's output is the 5-column advice image of its modpow_public_key "
                          "elements (assert_in_field rows + pow rows written directly from the operands by cells_kernel), no record planes")
+    ap.add_argument("--columns", action="store_true", help="--advice: planar column vectors instead of 160-byte rows (H2R_ADVICE_COLUMNS)")
+    ap.add_argument("--montgomery", action="store_true", help="--advice: cells in Montgomery form, x * 2^256 mod p (H2R_ADVICE_MONTGOMERY)")
     ap.add_argument("--shared-modulus", action="store_true",
                     help="one key, many signatures (H2R_F_SHARED_MODULUS): every element uses element 0's modulus")
     ap.add_argument("--per-launch-timing", action="store_true",
