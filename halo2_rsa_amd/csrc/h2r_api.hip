@@ -2506,6 +2506,24 @@ int32_t h2r_field_eval(const h2r_ctx *ctx, uint32_t op, const uint64_t a[4], con
         }
         case 7: r = fe_from_mont(x, ctx->fc); break;   // x * R^-1 mod p: a Montgomery-form element back to its canonical integer
         case 8: r = fe_to_mont(x, ctx->fc); break;     // x * R mod p by the generic R^2 product (the cross-check of 6)
+        case 9: {   // x * R mod p in radix 2^30 over the digits x occupies: what cells_kernel runs
+            u32 d[8], t[8]; int bits = 1;
+            for (int k = 0; k < 4; ++k) { d[2 * k] = (u32)x.v[k]; d[2 * k + 1] = (u32)(x.v[k] >> 32); }
+            for (int k = 0; k < 256; ++k) if ((d[k / 32] >> (k % 32)) & 1u) bits = k + 1;
+            switch ((bits + 29) / 30) {
+                case 1: mont_bits<30, 8>(d, ctx->mk, t); break;
+                case 2: mont_bits<60, 8>(d, ctx->mk, t); break;
+                case 3: mont_bits<90, 8>(d, ctx->mk, t); break;
+                case 4: mont_bits<120, 8>(d, ctx->mk, t); break;
+                case 5: mont_bits<150, 8>(d, ctx->mk, t); break;
+                case 6: mont_bits<180, 8>(d, ctx->mk, t); break;
+                case 7: mont_bits<210, 8>(d, ctx->mk, t); break;
+                case 8: mont_bits<240, 8>(d, ctx->mk, t); break;
+                default: mont_bits<256, 8>(d, ctx->mk, t); break;
+            }
+            for (int k = 0; k < 4; ++k) r.v[k] = ((u64)t[2 * k + 1] << 32) | t[2 * k];
+            break;
+        }
         default: return H2R_E_UNSUPPORTED;
     }
     for (int k = 0; k < 4; ++k) out[k] = r.v[k];
@@ -2758,7 +2776,7 @@ int32_t launch_cells(const h2r_ctx *ctx, CellsArgs &ca, hipStream_t st) {
     ca.per_col_magic = (u32)(((1ull << 32) + (ADVICE_COL_ROWS + (lo.carry_nsub + 3) / 4) - 1) / (ADVICE_COL_ROWS + (lo.carry_nsub + 3) / 4));
     ca.L = lo.num_limbs; ca.carry_sub_bits = lo.carry_sub_bits; ca.carry_nsub = lo.carry_nsub;
     ca.rows = h2r_advice_rows(ctx);
-    ca.mk = ctx->mk;
+    ca.mk = ctx->mk_dev;
     const bool mont = ca.dst.mont != 0;
     if (ca.n_items == 0) return H2R_OK;
     if (ca.n_items >= (1ull << 31)) return H2R_E_UNSUPPORTED;

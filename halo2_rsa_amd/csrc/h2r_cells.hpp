@@ -40,7 +40,7 @@ struct CellsArgs {
     const u8 *status;                    // [elem] nullable; nonzero => the element's items are skipped
     u32 T; u64 n_items;                  // item = elem * T + t
     AdviceDst dst;                       // element e's image: pre_rows rows, then record t from row pre_rows + t * rows (+ the select rows) on
-    MontK mk;                            // H2R_ADVICE_MONTGOMERY: the short Montgomery multipliers (kernel arguments: they reach the multiplies as SGPRs)
+    const MontK *mk;                     // H2R_ADVICE_MONTGOMERY: the short Montgomery multipliers (the kernel keeps the ones it needs in VGPRs: as SGPRs they spilled)
     u32 rows, pre_rows;
     u32 sel_rows;                        // pow_mod (Var): rows left free behind every EVEN record for the bit's select rows
     u32 L, carry_sub_bits, carry_nsub;
@@ -130,7 +130,7 @@ __host__ __device__ constexpr u32 cells_fast_src(u32 j, u32 k, bool last_col) {
 }
 
 // dynamic LDS of one wave (byte offsets): stage, operands, constants, column planes, flags, code tables
-struct CellsLds { u32 ops, kt, ce, ab, eqb, sum, amb, nq1, cout, cmod, mab, meqb, msum, opsr, fl, src, fsrc, total; };
+struct CellsLds { u32 ops, kt, ce, ab, eqb, sum, amb, nq1, cout, cmod, mab, meqb, msum, opsr, mk, fl, src, fsrc, total; };
 __host__ __device__ inline CellsLds cells_lds_plan(u32 limb_width, u32 L, bool mont = false) {
     // 64-bit limbs: 32-byte entries AB, EQB, SUM, a_b, NQ1 and 16-byte entries carry, c.  32-bit limbs (every value but a_b's field
     // element is below 2^128): 16-byte entries AB, EQB, SUM, a 32-byte a_b; NQ1, the carry and c are cut from the SUM entry on the way.
@@ -147,7 +147,8 @@ __host__ __device__ inline CellsLds cells_lds_plan(u32 limb_width, u32 L, bool m
     p.amb = o; o += n * 32u; p.nq1 = o; o += (w64 || mont) ? n * 32u : 0u;
     p.cout = o; o += mont ? n * 32u : (w64 ? n * 16u : 0u); p.cmod = o; o += mont ? n * 32u : (w64 ? n * 16u : 0u);
     p.mab = o; o += mont ? n * 32u : 0u; p.meqb = o; o += mont ? n * 32u : 0u; p.msum = o; o += mont ? n * 32u : 0u;
-    p.opsr = o; o += mont ? 4u * L * 32u : 0u;
+    p.opsr = o; o += mont ? (4u * L + 2u) * 32u : 0u;   // (+ a zero entry and the slot of the previous chunk's last accumulator cell)
+    p.mk = o; o += mont ? (u32)((sizeof(MontK) + 15) & ~15ull) : 0u;
     p.fl = o; o += 2u * L * 4u;
     p.src = o; o += CELLS_SRC_WORDS * 4u;
     p.fsrc = o; o += 2u * CELLS_SRC_WORDS * 4u;
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
     constexpr int WW = LW == 64 ? 3 : 2;     // 64-bit words of a wide value
     constexpr int ESW = LW == 64 ? 4 : 2;    // 64-bit words of a plane entry
     constexpr int NWD = LW == 64 ? 5 : 3;    // dwords of a running column sum (133 / 71 bits)
+    constexpr int WBITS = LW == 64 ? 150 : 90;   // MONT: bound of every wide value's magnitude (five / three 30-bit digits)
     constexpr u64 LMASK = LW == 64 ? ~0ull : 0xffffffffull;
     constexpr u32 NP = ADVICE_ROW_BYTES / 16;   // 16-byte pieces of a row
     extern __shared__ uint4 cells_smem[];
@@ -278,13 +280,29 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
         }
         if (lane < CELLS_KT_WORDS) kt[lane] = a.ktab[lane];
     }
+    // MONT: the multipliers this shape needs, in registers for the whole kernel (read back from an LDS copy so that they ARE vector
+    // registers: as kernel arguments they are SGPRs, the kernel has none to spare, and the spills sat in the middle of every product)
+    constexpr int DA = (WBITS + 29) / 30, DC = LW == 64 ? 3 : 2;   // 30-bit digits of a wide value / of a limb, a carry
+    struct { u32 p30[9], p32[8], n0, bA[9], bC[9], b1[9]; } mv;
+    if constexpr (MONT) {
+        u32 *lmk = reinterpret_cast<u32 *>(smem + lp.mk);
+        const u32 *gmk = reinterpret_cast<const u32 *>(a.mk);
+        for (u32 k = lane; k < sizeof(MontK) / 4; k += 64) lmk[k] = gmk[k];
+        wave_sync();
+        const MontK *m = reinterpret_cast<const MontK *>(lmk);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) { mv.p30[j] = m->p30[j]; mv.bA[j] = m->bk30[DA][j]; mv.bC[j] = m->bk30[DC][j]; mv.b1[j] = m->bk30[1][j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mv.p32[j] = m->p[j];
+        mv.n0 = m->n0inv30;
+    }
     const bool planar = a.dst.planar();
     u8 *img = a.dst.elem(elem);
     // `out`: the record's first row (its column-a cell); the other columns of a row lie col_pitch apart, the next row row_pitch further
     u8 *out = img + ((u64)a.pre_rows + (u64)t * a.rows + (u64)((t + 1) >> 1) * a.sel_rows) * a.dst.row_pitch;
     if (t == 0 && lane < a.pre_rows * 5) {   // pow_mod_fixed_exp's acc = assign_constant(1, L): [1, 0, 0, 0, 0] then [0, ...]
         uint4 *pr = reinterpret_cast<uint4 *>(img + (u64)(lane / 5) * a.dst.row_pitch + (u64)(lane % 5) * a.dst.col_pitch);
-        if (MONT && lane == 0) { pr[0] = make_uint4(a.mk.bk[0][0], a.mk.bk[0][1], a.mk.bk[0][2], a.mk.bk[0][3]); pr[1] = make_uint4(a.mk.bk[0][4], a.mk.bk[0][5], a.mk.bk[0][6], a.mk.bk[0][7]); }
+        if (MONT && lane == 0) { const u32 *one = reinterpret_cast<const MontK *>(smem + lp.mk)->bk[0]; pr[0] = make_uint4(one[0], one[1], one[2], one[3]); pr[1] = make_uint4(one[4], one[5], one[6], one[7]); }
         else { pr[0] = make_uint4(lane == 0 ? 1u : 0u, 0, 0, 0); pr[1] = make_uint4(0, 0, 0, 0); }
     }
     const U192 Z = U192::make(0, 0, 0);
@@ -314,8 +332,8 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
         u32 x[NWD];
         x[0] = (u32)m.w[0]; x[1] = (u32)(m.w[0] >> 32); x[2] = (u32)m.w[1];
         if constexpr (NWD == 5) { x[3] = (u32)(m.w[1] >> 32); x[4] = (u32)m.w[2]; }
-        mont_short<NWD>(x, a.mk.bk[NWD], a.mk.p, a.mk.n0inv, tt);
-        if (neg) mont_neg(tt, a.mk.p);
+        { u32 d[DA]; digits30<DA, NWD>(x, d); mont30<DA>(d, mv.bA, mv.p30, mv.n0, mv.p32, tt); }
+        if (neg) mont_neg(tt, mv.p32);
     };
     auto cell = [&](uint4 *p, const U192 &v, bool is_signed) {   // 32 bytes little-endian
         if constexpr (MONT) {
@@ -329,16 +347,20 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
             p[1] = make_uint4((u32)x[2], (u32)(x[2] >> 32), (u32)x[3], (u32)(x[3] >> 32));
         }
     };
-    // the cell of a K-digit unsigned value (lo, hi)
+    // the cell of an unsigned value (lo, hi) below 2^BITS
     auto cell_k = [&](auto kc, u64 lo, u64 hi, uint4 &o0, uint4 &o1) {
-        constexpr int K = decltype(kc)::value;
+        constexpr int BITS = decltype(kc)::value, K = (BITS + 31) / 32;
         if constexpr (MONT) {
             u32 x[K], tt[8];
             x[0] = (u32)lo;
             if constexpr (K > 1) x[1] = (u32)(lo >> 32);
             if constexpr (K > 2) x[2] = (u32)hi;
             if constexpr (K > 3) x[3] = (u32)(hi >> 32);
-            mont_short<K>(x, a.mk.bk[K], a.mk.p, a.mk.n0inv, tt);
+            constexpr int D = (BITS + 29) / 30;
+            static_assert(D == 1 || D == DC, "a sub-limb, or a limb / carry");
+            u32 d[D];
+            digits30<D, K>(x, d);
+            mont30<D>(d, D == 1 ? mv.b1 : mv.bC, mv.p30, mv.n0, mv.p32, tt);
             o0 = make_uint4(tt[0], tt[1], tt[2], tt[3]); o1 = make_uint4(tt[4], tt[5], tt[6], tt[7]);
         } else {
             o0 = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32)); o1 = make_uint4(0, 0, 0, 0);
@@ -380,8 +402,9 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
         for (u32 k = lane; k < 4 * L; k += 64) {
             const u32 which = k / L, idx = k - which * L;
             const u64 v = (which == 0 ? sa : which == 1 ? sb : which == 2 ? sq : sn)[idx];
-            cell_k(std::integral_constant<int, LW / 32>{}, v, 0, opsr[2 * k], opsr[2 * k + 1]);
+            cell_k(std::integral_constant<int, LW>{}, v, 0, opsr[2 * k], opsr[2 * k + 1]);
         }
+        if (lane < 4) opsr[2 * 4 * L + lane] = Z4;
     }
     if constexpr (FAST) {   // the constant entries
         uint4 *ce = reinterpret_cast<uint4 *>(smem + lp.ce);
@@ -471,7 +494,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
     u32 carry[NWD];
 #pragma unroll
     for (int k = 0; k < NWD; ++k) carry[k] = 0;
-    u32 carry_r[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // MONT: the cell of `carry` (the accumulator the previous chunk's last row left)
+
     bool columns_done = false;
     u32 dec_r0 = ~0u, dec_I = 0, dec_k = 0, dec_len = 1;   // the mul rows' fast path: row r0 + lane = position dec_k of column dec_I (both muls: 2C columns)
     // the first chunk ends where the image reaches a 128-byte line (160 = 128 + 32: at most three rows), every later chunk of 64
@@ -509,7 +532,12 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 dec_k = back ? ii + 1 - kk : kk;
                 dec_I = qn0 * C + i0;
                 dec_len = (i0 < L ? i0 : C - 1 - i0) + 2;
-                if constexpr (MONT) mont_short<NWD>(carry, a.mk.bk[NWD], a.mk.p, a.mk.n0inv, carry_r);   // (the general path left the integer)
+                if constexpr (MONT) {   // (the general path left the integer: its cell goes where a chunk's last row leaves its accumulator cell)
+                    u32 d[DA], cr[8];
+                    digits30<DA, NWD>(carry, d); mont30<DA>(d, mv.bA, mv.p30, mv.n0, mv.p32, cr);
+                    uint4 *slot = reinterpret_cast<uint4 *>(smem + lp.opsr) + 2 * (4 * L + 1);
+                    if (lane == 0) { slot[0] = make_uint4(cr[0], cr[1], cr[2], cr[3]); slot[1] = make_uint4(cr[4], cr[5], cr[6], cr[7]); }
+                }
             } else {
                 dec_k += 64;
                 while (__ballot(dec_k >= dec_len) != 0) {
@@ -566,26 +594,22 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
             // [x_j, y_{i-j}, acc_prev, acc, 0]  :408 (a column's head row: all zero)
             if constexpr (MONT) {
                 u32 acc_r[8];
-                mont_short<NWD>(p, a.mk.bk[NWD], a.mk.p, a.mk.n0inv, acc_r);
-                // acc_prev IS the row above's acc (position k - 1 of the same column; the first multiply-add starts from the constant 0)
-                uint4 pv[2];
-                {
-                    u32 up[8];
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) {
-                        const u32 sh = (u32)__builtin_amdgcn_ds_bpermute((int)((lane - 1) << 2), (int)acc_r[w]);
-                        up[w] = k >= 2 ? (lane == 0 ? carry_r[w] : sh) : 0u;
-                    }
-                    pv[0] = make_uint4(up[0], up[1], up[2], up[3]); pv[1] = make_uint4(up[4], up[5], up[6], up[7]);
-                }
-#pragma unroll
-                for (int w = 0; w < 8; ++w) carry_r[w] = (u32)__builtin_amdgcn_readlane((int)acc_r[w], 63);
-                const uint4 *opsr = reinterpret_cast<const uint4 *>(smem + lp.opsr);
-                const u32 xi = is_ma ? (qn ? 2 * L : 0) + j : 0, yi = is_ma ? (qn ? 3 * L : L) + (i - j) : 0;
+                if constexpr (ABL & 2048) { for (int w = 0; w < 8; ++w) acc_r[w] = p[w % NWD]; }   // (developer: no conversion)
+                else { u32 d[DA]; digits30<DA, NWD>(p, d); mont30<DA>(d, mv.bA, mv.p30, mv.n0, mv.p32, acc_r); }
+                // the limb cells are copies of the operand plane (a column's head row: of its zero entry)
+                uint4 *opsr = reinterpret_cast<uint4 *>(smem + lp.opsr);
+                const u32 zi = 4 * L, xi = is_ma ? (qn ? 2 * L : 0) + j : zi, yi = is_ma ? (qn ? 3 * L : L) + (i - j) : zi;
                 const uint4 x0 = opsr[2 * xi], x1 = opsr[2 * xi + 1], y0 = opsr[2 * yi], y1 = opsr[2 * yi + 1];
-                srow[0] = is_ma ? x0 : Z4; srow[1] = is_ma ? x1 : Z4; srow[2] = is_ma ? y0 : Z4; srow[3] = is_ma ? y1 : Z4;
-                srow[4] = pv[0]; srow[5] = pv[1];
+                srow[0] = x0; srow[1] = x1; srow[2] = y0; srow[3] = y1;
                 srow[6] = make_uint4(acc_r[0], acc_r[1], acc_r[2], acc_r[3]); srow[7] = make_uint4(acc_r[4], acc_r[5], acc_r[6], acc_r[7]);
+                // acc_prev IS the row above's acc (position k - 1 of the same column; the first multiply-add starts from the constant 0): a
+                // copy of the cell the lane above has just staged -- for lane 0 of the cell the previous chunk's lane 63 left in the slot
+                wave_sync();
+                const uint4 *pa = k < 2 ? opsr + 2 * zi : (lane == 0 ? opsr + 2 * (zi + 1) : srow - NP + 6);
+                const uint4 pv0 = pa[0], pv1 = pa[1];
+                wave_sync();
+                if (lane == 63) { opsr[2 * (zi + 1)] = srow[6]; opsr[2 * (zi + 1) + 1] = srow[7]; }
+                srow[4] = pv0; srow[5] = pv1;
             } else {
             srow[0] = make_uint4((u32)x, (u32)(x >> 32), 0, 0); srow[1] = Z4;
             srow[2] = make_uint4((u32)y, (u32)(y >> 32), 0, 0); srow[3] = Z4;
@@ -630,19 +654,42 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 const uint4 l1 = cut(*reinterpret_cast<const uint4 *>(smem + a1), x1), g1 = *reinterpret_cast<const uint4 *>(smem + h1);
                 const uint4 l2 = cut(*reinterpret_cast<const uint4 *>(smem + a2), x2), g2 = *reinterpret_cast<const uint4 *>(smem + h2);
                 uint4 o[NP] = {l0, g0, l1, g1, l2, g2, Z4, Z4, Z4, Z4};
+                if constexpr (!MONT) {
                 if (is_range) {   // RangeChip::assign(carry, ...)  :880-885
                     uint4 cv;
-                    if constexpr (MONT) { const U192 co = shr_limb(rdp(pSUM, c)); cv = make_uint4((u32)co.w[0], (u32)(co.w[0] >> 32), (u32)co.w[1], (u32)(co.w[1] >> 32)); }
-                    else if constexpr (LW == 64) cv = reinterpret_cast<const uint4 *>(smem + lp.cout)[c];
+                    if constexpr (LW == 64) cv = reinterpret_cast<const uint4 *>(smem + lp.cout)[c];
                     else cv = cut(reinterpret_cast<const uint4 *>(smem + lp.sum)[c], CE_COUT);
                     u64 c0, c1, c2, c3, rl, rh;
                     range_vals(((u64)cv.y << 32) | cv.x, ((u64)cv.w << 32) | cv.z, a.carry_nsub, a.carry_sub_bits, k - 18, c0, c1, c2, c3, rl, rh);
-                    using K1 = std::integral_constant<int, 1>;
-                    cell_k(K1{}, c0, 0, o[0], o[1]); cell_k(K1{}, c1, 0, o[2], o[3]); cell_k(K1{}, c2, 0, o[4], o[5]); cell_k(K1{}, c3, 0, o[6], o[7]);
-                    cell_k(std::integral_constant<int, LW == 64 ? 3 : 2>{}, rl, rh, o[8], o[9]);   // (a carry: 70 / 40 bits)
+                    o[0] = make_uint4((u32)c0, 0, 0, 0); o[1] = Z4; o[2] = make_uint4((u32)c1, 0, 0, 0); o[3] = Z4;
+                    o[4] = make_uint4((u32)c2, 0, 0, 0); o[5] = Z4; o[6] = make_uint4((u32)c3, 0, 0, 0); o[7] = Z4;
+                    o[8] = make_uint4((u32)rl, (u32)(rl >> 32), (u32)rh, (u32)(rh >> 32)); o[9] = Z4;
+                }
                 }
 #pragma unroll
                 for (u32 w = 0; w < NP; ++w) srow[w] = o[w];
+                if constexpr (MONT) {
+                    // The carries' range rows (:880-885) are the only cells of these rows that are not copies: at most nine rows of
+                    // a chunk (nrc of every 23 + nrc), five cells each.  One lane per CELL converts its value -- one conversion per lane
+                    // for the whole chunk instead of five in every lane -- and puts it where the row's copy pass left a placeholder.
+                    const u32 rr0 = r0 - r_T6;
+                    const u32 c0 = __umulhi(rr0, a.per_col_magic), k0 = rr0 - c0 * per_col;
+                    const u32 G0 = k0 <= 18 ? c0 * nrc : (k0 < 18 + nrc ? c0 * nrc + (k0 - 18) : (c0 + 1) * nrc);   // the first range row at or behind rr0
+                    wave_sync();
+                    for (u32 tb = 0; ; tb += 64) {
+                        const u32 t_ = tb + lane, G = G0 + t_ / 5, cellq = t_ % 5;
+                        const u32 gc = nrc == 3 ? (G * 0xAAABu) >> 17 : (nrc == 2 ? G >> 1 : G / nrc), gj = G - gc * nrc, grr = gc * per_col + 18 + gj;   // (G < 2^15)
+                        const bool task = grr < rr0 + 64 && gc < C - 1;
+                        if (__ballot(task) == 0) break;
+                        const U192 co = shr_limb(rdp(pSUM, task ? gc : 0u));
+                        u64 q0, q1, q2, q3, rl, rh;
+                        range_vals(co.w[0], co.w[1], a.carry_nsub, a.carry_sub_bits, gj, q0, q1, q2, q3, rl, rh);
+                        const u64 vlo = cellq == 0 ? q0 : cellq == 1 ? q1 : cellq == 2 ? q2 : cellq == 3 ? q3 : rl, vhi = cellq == 4 ? rh : 0;
+                        uint4 e0, e1;
+                        cell_k(std::integral_constant<int, LW == 64 ? 90 : 60>{}, vlo, vhi, e0, e1);   // (a carry: 70 / 40 bits)
+                        if (task) { uint4 *dst2 = stage + (u64)(grr - rr0) * NP + 2 * cellq; dst2[0] = e0; dst2[1] = e1; }
+                    }
+                }
                 built = true; path = 2;
             }
         }
@@ -756,15 +803,32 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 }
             }
         }
+        if constexpr (MONT) {
+            // (every lane converts whatever any lane needs: a cell that is zero in the whole chunk is not converted, and a chunk of
+            // nothing but range rows -- the q, r limbs' -- takes its sub-limbs as one-digit values)
+            const bool is_rng = id.sect == 0 || (id.sect == 4 && id.kind >= ROWK_RANGE_CARRY);
+            if (__ballot(valid && !is_rng) == 0) {
+                using K1 = std::integral_constant<int, 8>;
+                cell_k(K1{}, v0.w[0], 0, srow[0], srow[1]); cell_k(K1{}, v1.w[0], 0, srow[2], srow[3]);
+                cell_k(K1{}, v2.w[0], 0, srow[4], srow[5]); cell_k(K1{}, v3.w[0], 0, srow[6], srow[7]);
+                cell_k(std::integral_constant<int, LW == 64 ? 90 : 60>{}, v4.w[0], v4.w[1], srow[8], srow[9]);
+            } else {
+                auto put5 = [&](uint4 *p5, const U192 &v, bool sg) {
+                    if (__ballot(valid && !(v == Z)) == 0) { p5[0] = Z4; p5[1] = Z4; }
+                    else cell(p5, v, sg);
+                };
+                put5(srow, v0, sg0); put5(srow + 2, v1, sg1); put5(srow + 4, v2, sg2); put5(srow + 6, v3, false); put5(srow + 8, v4, false);
+            }
+        }
         if (valid) {
-            cell(srow, v0, sg0); cell(srow + 2, v1, sg1); cell(srow + 4, v2, sg2); cell(srow + 6, v3, false); cell(srow + 8, v4, false);
+            if constexpr (!MONT) { cell(srow, v0, sg0); cell(srow + 2, v1, sg1); cell(srow + 4, v2, sg2); cell(srow + 6, v3, false); cell(srow + 8, v4, false); }
             if (need_inv) {
                 // 1 / d, main_gate.is_zero's witness: never taken for a valid mul_mod (every comparison is between equal values)
                 Fe xe;
                 field4(v0, true, xe.v);
                 const FieldConsts fc = *reinterpret_cast<const FieldConsts *>(a.ktab + CELLS_KT_FC);
                 Fe iv = fe_inv_fast(xe, fc);
-                if constexpr (MONT) iv = fe_to_mont_k(iv, a.mk);
+                if constexpr (MONT) iv = fe_to_mont_k(iv, *reinterpret_cast<const MontK *>(smem + lp.mk));
                 srow[2] = make_uint4((u32)iv.v[0], (u32)(iv.v[0] >> 32), (u32)iv.v[1], (u32)(iv.v[1] >> 32));
                 srow[3] = make_uint4((u32)iv.v[2], (u32)(iv.v[2] >> 32), (u32)iv.v[3], (u32)(iv.v[3] >> 32));
             }

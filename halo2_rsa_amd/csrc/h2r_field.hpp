@@ -218,6 +218,10 @@ struct MontK {
     uint32_t n0inv;        // -p^-1 mod 2^32
     uint32_t pad_[3];
     uint32_t bk[9][8];     // bk[K] = 2^(32 K) * R mod p (bk[0] = R mod p: the Montgomery form of 1; bk[8] = R^2 mod p)
+    // the same in radix 2^30 (mont30 below: the form the GPU's 32 x 32 + 64 multiply-add runs without a single carry instruction)
+    uint32_t p30[9];       // modulus, 30-bit digits
+    uint32_t n0inv30;      // -p^-1 mod 2^30
+    uint32_t bk30[10][9];  // bk30[D] = 2^(30 D) * R mod p, 30-bit digits
 };
 
 template <int K>
@@ -246,6 +250,68 @@ H2R_FD void mont_short(const uint32_t (&x)[K], const uint32_t *b, const uint32_t
 #pragma unroll
         for (int j = 0; j < 8; ++j) t[j] = d[j];
     }
+}
+// The same product in radix 2^30.  v_mad_u64_u32 adds a 32 x 32-bit product to a 64-bit accumulator; with 30-bit digits a product is
+// below 2^60, so a column accumulator takes the two products of each of up to seven steps without overflowing and NO carry is
+// handled inside the loop: one instruction per digit product, all products of a step independent of each other (a wave that is
+// alone on its SIMD has nothing else to hide a carry chain's latency behind).  x: D digits of 30 bits (the value is below 2^(30 D));
+// b = 2^(30 D) R mod p and p as nine 30-bit digits; result x R mod p as eight 32-bit words.
+template <int D>
+H2R_FD void mont30(const uint32_t (&x)[D], const uint32_t *b, const uint32_t *p30, uint32_t n0inv30, const uint32_t *p32, uint32_t (&out)[8]) {
+    static_assert(D >= 1 && D <= 9, "30-bit digits of the short operand");
+    constexpr uint32_t M = (1u << 30) - 1;
+    uint64_t T[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) T[j] = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) T[j] += (uint64_t)x[i] * b[j];
+        const uint32_t m = ((uint32_t)T[0] * n0inv30) & M;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) T[j] += (uint64_t)m * p30[j];
+        const uint64_t cy = T[0] >> 30;                       // (T[0] is a multiple of 2^30 now)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) T[j] = T[j + 1];
+        T[0] += cy; T[8] = 0;
+        if (D >= 8 && i == 3) {                                // eight and nine steps: the accumulators are brought back below 2^31 once
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { T[j + 1] += T[j] >> 30; T[j] &= M; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { T[j + 1] += T[j] >> 30; T[j] &= M; }
+    // nine 30-bit digits (the value is below 2 p < 2^255) -> eight words
+    uint32_t t[8];
+    t[0] = (uint32_t)T[0] | ((uint32_t)T[1] << 30);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t[k] = ((uint32_t)T[k] >> (2 * k)) | ((uint32_t)T[k + 1] << (30 - 2 * k));
+    uint32_t d[8]; uint64_t br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const uint64_t s = (uint64_t)t[j] - p32[j] - br; d[j] = (uint32_t)s; br = (s >> 32) & 1u; }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = br ? t[j] : d[j];
+}
+// the 30-bit digits of a value given as W 32-bit words (D <= ceil(32 W / 30))
+template <int D, int W>
+H2R_FD void digits30(const uint32_t (&w)[W], uint32_t (&d)[D]) {
+    constexpr uint32_t M = (1u << 30) - 1;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const int bit = 30 * i, k = bit / 32, sh = bit % 32;
+        uint32_t v = k < W ? w[k] >> sh : 0u;
+        if (sh > 2 && k + 1 < W) v |= w[k + 1] << (32 - sh);
+        d[i] = v & M;
+    }
+}
+// x R mod p of a value below 2^BITS given as W 32-bit words
+template <int BITS, int W>
+H2R_FD void mont_bits(const uint32_t (&w)[W], const MontK &mk, uint32_t (&out)[8]) {
+    constexpr int D = (BITS + 29) / 30;
+    static_assert(D <= 9 && 32 * W + 29 >= 30 * D, "digits of the value");
+    uint32_t d[D];
+    digits30<D, W>(w, d);
+    mont30<D>(d, mk.bk30[D], mk.p30, mk.n0inv30, mk.p, out);
 }
 // p - t for t in [0, p) (0 stays 0): the Montgomery form of -x from that of x
 H2R_FD void mont_neg(uint32_t (&t)[8], const uint32_t *p) {
@@ -281,6 +347,20 @@ inline void montk_init(const uint64_t p[4], MontK *m) {
     for (int K = 0; K <= 8; ++K) {
         for (int k = 0; k < 4; ++k) { m->bk[K][2 * k] = (uint32_t)x.v[k]; m->bk[K][2 * k + 1] = (uint32_t)(x.v[k] >> 32); }
         for (int i = 0; i < 32; ++i) x = fe_add(x, x, f.p);
+    }
+    auto to30 = [](const uint64_t (&v)[4], uint32_t *d) {
+        uint32_t w[8];
+        for (int k = 0; k < 4; ++k) { w[2 * k] = (uint32_t)v[k]; w[2 * k + 1] = (uint32_t)(v[k] >> 32); }
+        uint32_t t[9];
+        digits30<9, 8>(w, t);
+        for (int k = 0; k < 9; ++k) d[k] = t[k];
+    };
+    to30(f.p, m->p30);
+    m->n0inv30 = m->n0inv & ((1u << 30) - 1);
+    for (int k = 0; k < 4; ++k) x.v[k] = f.one[k];
+    for (int D = 0; D <= 9; ++D) {
+        to30(x.v, m->bk30[D]);
+        for (int i = 0; i < 30; ++i) x = fe_add(x, x, f.p);
     }
 }
 inline void field_consts_init(const uint64_t p[4], FieldConsts *f) {

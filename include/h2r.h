@@ -681,7 +681,8 @@ int32_t h2r_lookup_permuted_columns(const h2r_ctx *ctx, const h2r_lookup_config 
  * binary extended Euclid), 4 = a^(p-2) (Fermat: the cross-check of 3), 5 = a^-1 as the kernels compute main_gate.is_zero's witness
  * (classical Euclid on (p, s) when a = +-s with s < 2^64 -- the only differences this path produces --, op 3 otherwise),
  * 6 = a * R mod p (R = 2^256: into the Montgomery form of H2R_ADVICE_MONTGOMERY, by the short product the kernels use for a cell),
- * 7 = a * R^-1 mod p (a Montgomery-form element back to its canonical integer), 8 = a * R mod p by the generic R^2 product.
+ * 7 = a * R^-1 mod p (a Montgomery-form element back to its canonical integer), 8 = a * R mod p by the generic R^2 product,
+ * 9 = a * R mod p in radix 2^30 (carry-free multiply-add columns: what the cells kernel runs).
  * The same code the kernels run (lookup compression, main_gate.is_zero's inverse witness, the cells' representation). */
 int32_t h2r_field_eval(const h2r_ctx *ctx, uint32_t op, const uint64_t a[4], const uint64_t b[4], uint64_t out[4]);
 

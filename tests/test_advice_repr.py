@@ -48,7 +48,7 @@ def test_short_montgomery_product_matches_big_integers(field):
     out = (ctypes.c_uint64 * 4)()
     for v in vals:
         v %= P
-        for op in (6, 8):
+        for op in (6, 8, 9):
             assert lib().h2r_field_eval(ctx, op, _words(v), None, out) == 0
             assert _int(out) == v * R256 % P, (op, hex(v))
         m = _words(v * R256 % P)
