@@ -318,6 +318,44 @@ class BigIntChip:
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def advice_check(self, kinds, image: torch.Tensor, batch: int, status: Optional[torch.Tensor] = None, copies=None, src_a=None,
+                     src_b=None, src_n=None, lookup: Optional["LookupArgument"] = None, layout=None):
+        """The device-side MockProver (h2r_advice_check): every row of every element image against the main-gate equation, the lookup
+        table and the copy pairs.  kinds: uint8 row kinds (numpy or device tensor); copies: H2RCopy array (ctypes) or a device tensor of
+        [n, 4] int32; returns (bad int32 [batch], first int64 [batch]); bad == 0 everywhere for a satisfying assignment."""
+        dev = image.device
+        kd = kinds if isinstance(kinds, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(kinds, dtype=np.uint8)).to(dev)
+        rows = kd.numel()
+        cd, n_copies = None, 0
+        if copies is not None:
+            if isinstance(copies, torch.Tensor):
+                cd = copies
+            else:
+                cd = torch.from_numpy(np.frombuffer(copies, dtype=np.uint32).view(np.int32).reshape(-1, 4).copy()).to(dev)
+            n_copies = cd.shape[0]
+        bad = torch.empty(batch, dtype=torch.int32, device=dev)
+        first = torch.empty(batch, dtype=torch.int64, device=dev)
+        flags = _lib.H2R_F_SHARED_MODULUS if (src_n is not None and src_n.batch == 1 and batch != 1) else 0
+        stride = image.shape[1] if image.dim() > 1 else image.numel() // batch
+        check(lib().h2r_advice_check(self._ctx, ctypes.byref(lookup.cfg) if lookup is not None else None,
+                                     ctypes.byref(layout) if layout is not None else None, kd.data_ptr(), rows, image.data_ptr(), stride, batch,
+                                     status.data_ptr() if status is not None else None, cd.data_ptr() if cd is not None else None, n_copies,
+                                     src_a.data_ptr() if src_a is not None else None, src_b.data_ptr() if src_b is not None else None,
+                                     src_n.data_ptr() if src_n is not None else None, flags, bad.data_ptr(), first.data_ptr(), self._stream()),
+              "h2r_advice_check")
+        self._keep = (kd, cd)
+        return bad, first
+
+    def pow_copy_map(self, pl: H2RPowLayout, e: int, row_offset: int = 0):
+        """h2r_pow_copy_map: the copy pairs of one fixed-exponent pow element as a ctypes array of H2RCopy."""
+        eb = _e_bytes(e)
+        n = int(lib().h2r_pow_copy_map(self._ctx, ctypes.byref(pl), eb, len(eb), row_offset, None, 0))
+        if n == 0:
+            check(_lib.H2R_E_UNSUPPORTED, "h2r_pow_copy_map")
+        arr = (_lib.H2RCopy * n)()
+        assert int(lib().h2r_pow_copy_map(self._ctx, ctypes.byref(pl), eb, len(eb), row_offset, arr, n)) == n
+        return arr
+
     def image_bytes(self, rows: int) -> int:
         """Bytes of one element's advice image of `rows` rows in the chip's representation: rows * 160 (row-major, or planar with
         the five columns packed), 5 * col_stride for planar columns of a fixed stride."""

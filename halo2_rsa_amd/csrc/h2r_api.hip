@@ -25,6 +25,7 @@
 #include "h2r_muled.hpp"
 #include "h2r_rowprog.hpp"
 #include "h2r_sha256.hpp"
+#include "h2r_check.hpp"
 
 using namespace h2r;
 
@@ -199,6 +200,9 @@ struct h2r_ctx {
     struct RowProg { std::vector<RpRow> host; RpRow *dev = nullptr; std::vector<u32> inv_rows; u32 *inv_dev = nullptr; };
     mutable std::mutex prog_mu;
     mutable std::map<u32, RowProg> progs;
+    // h2r_advice_check: the per-kind table (selectors, lookup bit lengths) of a (lookup configuration, layout) pair, on the device
+    mutable std::mutex check_mu;
+    mutable std::map<std::vector<u8>, CheckKind *> check_tabs;
 };
 
 namespace {
@@ -682,6 +686,7 @@ void h2r_ctx_destroy(h2r_ctx *ctx) try {
         if (ctx->advice_desc_dev) (void)hipFree(ctx->advice_desc_dev);
         if (ctx->cells_ktab_dev) (void)hipFree(ctx->cells_ktab_dev);
         if (ctx->mk_dev) (void)hipFree(ctx->mk_dev);
+        for (auto &kv : ctx->check_tabs) if (kv.second) (void)hipFree(kv.second);
         for (auto &kv : ctx->progs) { if (kv.second.dev) (void)hipFree(kv.second.dev); if (kv.second.inv_dev) (void)hipFree(kv.second.inv_dev); }
         if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
         if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
@@ -2929,12 +2934,16 @@ int32_t h2r_advice_row_kinds(const h2r_ctx *ctx, uint8_t *kinds_out) try {
     return H2R_OK;
 } H2R_CATCH_STATUS
 
+namespace { int32_t fixed_row_repr(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint32_t kind, bool mont, h2r_fixed_row *out); }
 int32_t h2r_advice_fixed_row(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint32_t kind, h2r_fixed_row *out) try {
     if (!ctx || !out) return H2R_E_NULL;
+    return fixed_row_repr(ctx, cfg, kind, (ctx->repr.flags & H2R_ADVICE_MONTGOMERY) != 0, out);   // the selectors are field elements like the cells: the ctx's representation
+} H2R_CATCH_STATUS
+namespace {
+int32_t fixed_row_repr(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint32_t kind, bool mont, h2r_fixed_row *out) {
     std::memset(out, 0, sizeof *out);
     const h2r_layout &lo = ctx->layout;
     const u64 (&p)[4] = ctx->fc.p;
-    const bool mont = (ctx->repr.flags & H2R_ADVICE_MONTGOMERY) != 0;   // the selectors are field elements like the cells: the ctx's representation
     auto put = [&](uint64_t (&dst)[4], const Fe &v, bool neg) {
         Fe r = neg ? fe_sub(fe_zero(), v, p) : v;
         if (mont) r = fe_to_mont(r, ctx->fc);
@@ -3013,7 +3022,8 @@ int32_t h2r_advice_fixed_row(const h2r_ctx *ctx, const h2r_lookup_config *cfg, u
         }
     }
     return H2R_OK;
-} H2R_CATCH_STATUS
+}
+}  // namespace
 
 // ---- advice rows of the Fresh-integer family (h2r_rowprog.hpp) ---------------------------------------------------------------
 namespace {
@@ -3253,6 +3263,17 @@ int32_t h2r_pow_operand_sources(const h2r_ctx *ctx, const h2r_pow_layout *pl, co
     return H2R_OK;
 } H2R_CATCH_STATUS
 
+namespace {
+int32_t layout_valid(const h2r_advice_layout *layout) {   // every entry a permutation of 0..4 (the table is public data: a hand-filled one must not index past a row)
+    if (layout->version != H2R_ADVICE_LAYOUT_VERSION) return H2R_E_UNSUPPORTED;
+    for (int k = 0; k < 256; ++k) {
+        u32 seen = 0;
+        for (int c = 0; c < 5; ++c) { const u32 v = layout->column_of[k][c]; if (v > 4 || (seen >> v) & 1u) return H2R_E_SHAPE; seen |= 1u << v; }
+    }
+    return H2R_OK;
+}
+}  // namespace
+
 int32_t h2r_advice_layout_default(h2r_advice_layout *out) try {
     if (!out) return H2R_E_NULL;
     out->version = H2R_ADVICE_LAYOUT_VERSION;
@@ -3279,8 +3300,9 @@ int32_t h2r_advice_layout_custom(const h2r_ctx *ctx, const uint8_t *kinds, const
 } H2R_CATCH_STATUS
 
 int32_t h2r_advice_fixed_row_ex(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const h2r_advice_layout *layout, uint32_t kind, h2r_fixed_row *out) try {
-    if (!layout || kind > 255) return layout ? H2R_E_SHAPE : H2R_E_NULL;
-    if (layout->version != H2R_ADVICE_LAYOUT_VERSION) return H2R_E_UNSUPPORTED;
+    if (!ctx || !layout || !out) return H2R_E_NULL;
+    if (kind > 255) return H2R_E_SHAPE;
+    if (const int32_t rv = layout_valid(layout)) return rv;
     h2r_fixed_row f;
     const int32_t rc = h2r_advice_fixed_row(ctx, cfg, kind, &f);
     if (rc) return rc;
@@ -3293,7 +3315,8 @@ int32_t h2r_advice_fixed_row_ex(const h2r_ctx *ctx, const h2r_lookup_config *cfg
 int32_t h2r_advice_apply_layout(const h2r_ctx *ctx, const h2r_advice_layout *layout, const uint8_t *kinds_dev, uint64_t rows, void *image,
                                 uint64_t out_stride, uint64_t batch, const uint8_t *status, h2r_stream_t stream) try {
     if (!ctx || !layout || !kinds_dev || !image) return H2R_E_NULL;
-    if (ctx->params.device < 0 || layout->version != H2R_ADVICE_LAYOUT_VERSION) return H2R_E_UNSUPPORTED;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    if (const int32_t rv = layout_valid(layout)) return rv;
     LayoutArgs la;
     std::memset(&la, 0, sizeof la);
     if (const int32_t rc = advice_dst(ctx, image, out_stride, rows, batch, &la.dst)) return rc;
@@ -3435,6 +3458,115 @@ int32_t h2r_hashed_msg_emit_advice(const h2r_ctx *ctx, const void *hm_trace, uin
     H2R_ON_DEVICE(ctx->params.device);
     return launch_row_prog(ctx, rp, ra, static_cast<hipStream_t>(stream));
 } H2R_CATCH_STATUS
+
+// ---- audit of an advice image: the device-side MockProver (h2r_check.hpp) ------------------------------------------------------
+namespace {
+int32_t check_table(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const h2r_advice_layout *layout, const CheckKind **out) {
+    std::vector<u8> key(sizeof(h2r_lookup_config) + sizeof layout->column_of, 0);
+    if (cfg) std::memcpy(key.data(), cfg, sizeof *cfg);
+    std::memcpy(key.data() + sizeof(h2r_lookup_config), layout->column_of, sizeof layout->column_of);
+    std::lock_guard<std::mutex> lk(ctx->check_mu);
+    auto it = ctx->check_tabs.find(key);
+    if (it != ctx->check_tabs.end()) { *out = it->second; return H2R_OK; }
+    std::vector<CheckKind> tab(256);
+    std::memset(static_cast<void *>(tab.data()), 0, tab.size() * sizeof(CheckKind));
+    for (u32 k = 0; k < 256; ++k) {
+        h2r_fixed_row f, g;
+        if (fixed_row_repr(ctx, cfg, k, true, &f)) continue;   // (an unknown kind, or one whose lookup the configuration has no table for: rows of it are flagged)
+        u8 col[5];
+        for (int c = 0; c < 5; ++c) col[c] = layout->column_of[k][c];
+        layout_permute_fixed(col, f, &g);
+        const uint64_t (*sel[9])[4] = {&g.sa, &g.sb, &g.sc, &g.sd, &g.se, &g.s_mul_ab, &g.s_mul_cd, &g.se_next, &g.s_const};
+        CheckKind &ck = tab[k];
+        for (int q = 0; q < 9; ++q) { for (int w = 0; w < 4; ++w) ck.s[q].v[w] = (*sel[q])[w]; if (!fe_is_zero(ck.s[q])) ck.nz |= 1u << q; }
+        auto bits_of = [&](u32 tag) -> u32 { if (!tag || !cfg) return 0; for (u32 i = 0; i < cfg->n_lens; ++i) if (cfg->tag[i] == tag) return cfg->bit_len[i]; return 0; };
+        ck.comp_bits = bits_of(g.tag_composition); ck.ov_bits = bits_of(g.tag_overflow);
+        ck.valid = 1;
+    }
+    CheckKind *dev = nullptr;
+    DeviceGuard dg(ctx->params.device);
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&dev), tab.size() * sizeof(CheckKind)));
+    if (hipMemcpy(dev, tab.data(), tab.size() * sizeof(CheckKind), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dev); return H2R_E_HIP; }
+    ctx->check_tabs.emplace(std::move(key), dev);
+    *out = dev;
+    return H2R_OK;
+}
+}  // namespace
+
+int32_t h2r_advice_check(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const h2r_advice_layout *layout, const uint8_t *kinds_dev, uint64_t rows,
+                         const void *image, uint64_t out_stride, uint64_t batch, const uint8_t *status, const h2r_copy *copies_dev, uint64_t n_copies,
+                         const void *src_a, const void *src_b, const void *src_n, uint32_t flags, uint32_t *bad_out, uint64_t *first_bad_out,
+                         h2r_stream_t stream) try {
+    if (!ctx || !kinds_dev || !image || !bad_out || !first_bad_out || (n_copies && !copies_dev)) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    if (flags & ~H2R_F_SHARED_MODULUS) return H2R_E_UNSUPPORTED;
+    h2r_advice_layout ident;
+    if (!layout) { h2r_advice_layout_default(&ident); layout = &ident; }
+    else if (const int32_t rc = layout_valid(layout)) return rc;
+    AdviceCheckArgs ca;
+    std::memset(static_cast<void *>(&ca), 0, sizeof ca);
+    if (const int32_t rc = advice_dst(ctx, const_cast<void *>(image), out_stride, rows, batch, &ca.img)) return rc;
+    H2R_ON_DEVICE(ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemsetAsync(bad_out, 0, batch * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(first_bad_out, 0, batch * sizeof(uint64_t), st));
+    if (!rows || !batch) return H2R_OK;
+    if (const int32_t rc = check_table(ctx, cfg, layout, &ca.tab)) return rc;
+    ca.kinds = kinds_dev; ca.rows = rows; ca.batch = batch; ca.status = status; ca.f = ctx->fc;
+    ca.bad = bad_out; ca.first = reinterpret_cast<unsigned long long *>(first_bad_out);
+    ca.copies = copies_dev; ca.n_copies = n_copies;
+    ca.ext[0] = src_a; ca.ext[1] = src_b; ca.ext[2] = src_n;
+    ca.ext_stride[0] = ca.ext_stride[1] = ctx->L; ca.ext_stride[2] = (flags & H2R_F_SHARED_MODULUS) ? 0 : ctx->L;
+    ca.limb_bytes = ctx->layout.limb_bytes;
+    std::memcpy(ca.perm, layout->column_of, sizeof ca.perm);
+    u64 blocks = (rows * batch + 255) / 256;
+    if (blocks >= (1ull << 31)) return H2R_E_UNSUPPORTED;
+    hipLaunchKernelGGL(advice_check_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ca);
+    HIP_TRY(hipGetLastError());
+    if (n_copies) {
+        blocks = (n_copies * batch + 255) / 256;
+        if (blocks >= (1ull << 31)) return H2R_E_UNSUPPORTED;
+        hipLaunchKernelGGL(advice_check_copies_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ca);
+        HIP_TRY(hipGetLastError());
+    }
+    return H2R_OK;
+} H2R_CATCH_STATUS
+
+// The copy constraints of one fixed-exponent pow element (h2r_pow_trace_emit_advice's image: CONST1, CONST0, then the records), rows
+// counted from `row_offset` (the pow section's first row inside a larger element image): every record's own pairs, and its operand
+// limbs tied to where pow_mod_fixed_exp takes them from (big_integer/chip.rs:729-740).
+uint64_t h2r_pow_copy_map(const h2r_ctx *ctx, const h2r_pow_layout *pl, const uint8_t *e_le_bytes, size_t e_len, uint64_t row_offset,
+                          h2r_copy *out, uint64_t cap) try {
+    if (!ctx || !pl || pl->off_e_bits != UINT64_MAX) return 0;
+    std::vector<int32_t> as(pl->num_mul_mods), bs(pl->num_mul_mods);
+    if (h2r_pow_operand_sources(ctx, pl, e_le_bytes, e_len, as.data(), bs.data())) return 0;
+    std::vector<h2r_copy> rec;
+    const u32 L = ctx->L, rows = h2r_advice_rows(ctx);
+    copy_map_record(L, (ctx->layout.carry_nsub + 3) / 4, rec);
+    u64 n = 0;
+    auto push = [&](u64 row, u32 col, u64 src_row, u32 src_col) {
+        if (out && n < cap) out[n] = h2r_copy{(uint32_t)row, col, (uint32_t)src_row, src_col};
+        ++n;
+    };
+    if (row_offset + 2 + (u64)pl->num_mul_mods * rows >= 0xFFFFFF00ull) return 0;
+    for (u32 t = 0; t < pl->num_mul_mods; ++t) {
+        const u64 base = row_offset + 2 + (u64)t * rows;
+        auto operand = [&](int32_t src, u32 limb, u64 *srow, u32 *scol) {   // where limb `limb` of an operand lives
+            if (src == H2R_SRC_X) { *srow = H2R_COPY_SRC_A; *scol = limb; }
+            else if (src == H2R_SRC_ONE) { *srow = row_offset + (limb ? 1 : 0); *scol = 0; }   // acc = assign_constant(1): CONST1, then the shared CONST0 cell
+            else { *srow = row_offset + 2 + (u64)src * rows + 2 * (L + limb); *scol = 4; }      // the r limbs of record `src`: column e of the assign's first row
+        };
+        for (const h2r_copy &c : rec) {
+            u64 srow; u32 scol;
+            if (c.src_row == H2R_COPY_SRC_A) operand(as[t], c.src_col, &srow, &scol);
+            else if (c.src_row == H2R_COPY_SRC_B) operand(bs[t], c.src_col, &srow, &scol);
+            else if (c.src_row == H2R_COPY_SRC_N) { srow = H2R_COPY_SRC_N; scol = c.src_col; }
+            else { srow = base + c.src_row; scol = c.src_col; }
+            push(base + c.row, c.col, srow, scol);
+        }
+    }
+    return n;
+} H2R_CATCH_ZERO
 
 // ---- in-place audit ----------------------------------------------------------------------------------------
 namespace {

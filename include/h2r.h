@@ -844,6 +844,27 @@ int32_t h2r_advice_fixed_row_ex(const h2r_ctx *ctx, const struct h2r_lookup_conf
 int32_t h2r_advice_apply_layout(const h2r_ctx *ctx, const h2r_advice_layout *layout, const uint8_t *kinds_dev, uint64_t rows, void *image,
                                 uint64_t out_stride, uint64_t batch, const uint8_t *status, h2r_stream_t stream);
 
+/* ---- audit of an advice image in HBM: the device-side MockProver --------------------------------------------------------------
+ * Every reference test ends in `MockProver::run(k, &circuit, ..).verify()` (src/chip.rs:338-345, 667; big_integer/chip.rs:1454-1458;
+ * examples/rsa_example.rs:207-212).  h2r_advice_check checks, where the image lies and independently of the kernels that wrote it,
+ * what MockProver checks of these rows: every row against the main-gate equation with the fixed row of its kind (under `layout`;
+ * NULL = the default), every cell of a lookup-enabled row against the (tag, value) table of `cfg` (composition: cells a..d below
+ * 2^bit_len(tag); overflow: cell a), every pair of `copies_dev` (n_copies h2r_copy entries ON THE DEVICE, rows counted from the
+ * element image's first row, logical columns; src_row = H2R_COPY_SRC_A / _B / _N: limb src_col of the element's src_a / src_b / src_n
+ * operand, num_limbs limbs per element, src_n shared with H2R_F_SHARED_MODULUS in flags) for equality, and that every cell is a
+ * canonical representative.  The image is read in the ctx's representation.  kinds_dev: the rows' kinds on the device (h2r_*_row_kinds
+ * uploaded once); bad_out[elem] (zeroed by the call) = violated checks, first_bad_out[elem] = (row << 8) | code of one of them
+ * (1 gate, 2 lookup, 3 copy, 4 a kind without a fixed row, 5 a cell >= p); elements with a nonzero status byte are skipped.
+ * h2r_pow_copy_map: the pairs of one fixed-exponent pow element (every record's h2r_advice_copy_map pairs + its operand limbs tied to
+ * the cells pow_mod_fixed_exp takes them from: h2r_pow_operand_sources; H2R_COPY_SRC_A = the assigned base x, _N = the modulus), rows
+ * counted from row_offset (the pow section's first row in a larger element image); returns the number of pairs (out NULL / cap 0 to ask). */
+int32_t h2r_advice_check(const h2r_ctx *ctx, const struct h2r_lookup_config *cfg, const h2r_advice_layout *layout, const uint8_t *kinds_dev,
+                         uint64_t rows, const void *image, uint64_t out_stride, uint64_t batch, const uint8_t *status,
+                         const h2r_copy *copies_dev, uint64_t n_copies, const void *src_a, const void *src_b, const void *src_n,
+                         uint32_t flags, uint32_t *bad_out, uint64_t *first_bad_out, h2r_stream_t stream);
+uint64_t h2r_pow_copy_map(const h2r_ctx *ctx, const h2r_pow_layout *pl, const uint8_t *e_le_bytes, size_t e_len, uint64_t row_offset,
+                          h2r_copy *out, uint64_t cap);
+
 /* One RSAChip::modpow_public_key element (src/chip.rs:99-114) as advice rows, in the reference's op order: [assert_in_field(x, n) :106:
  * the rows of h2r_fresh_op_emit_advice(H2R_OP_IS_IN_FIELD, H2R_ADVICE_ASSERT_ONE)] [pow_mod_fixed_exp / pow_mod :108-111: the rows of
  * h2r_pow_trace_emit_advice].  x, n, flags, in_field_trace, trace, workspace: what h2r_modpow_public_key_batch was given (a caller
