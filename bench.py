@@ -436,6 +436,19 @@ def advice_bench(args):
     ok = ref.status.cpu().numpy() == 0
     assert torch.equal(timed[torch.from_numpy(ok).to(timed.device)], ref_img[torch.from_numpy(ok).to(ref_img.device)]), \
         "the timed advice image differs from the image of the records"
+    # ... and the WHOLE last timed image through the device-side MockProver (h2r_advice_check): the main-gate equation of every row, the
+    # range-check table of every lookup-enabled cell, every copy pair of the pow rows -- 1,024 x 77,021 rows where they lie
+    import numpy as np
+    k_if = chip.fresh_op_row_kinds(_lib.FRESH_OPS.index("is_in_field"), assert_one=True)
+    k_pow = np.zeros(pow_rows, dtype=np.uint8)
+    _lib.check(L.h2r_pow_row_kinds(chip._ctx, ctypes.byref(pl), k_pow.ctypes.data), "h2r_pow_row_kinds")
+    t_chk = time.perf_counter()
+    bad, first = chip.advice_check(np.concatenate([k_if, k_pow]), images[last].view(chunk, elem_bytes), chunk, status=sts[last],
+                                   copies=chip.pow_copy_map(pl, e, row_offset=int(sec[0])), src_a=x_dev, src_n=n_dev,
+                                   lookup=H.LookupArgument(chip, rsa_chip=False))
+    n_bad = int((bad != 0).sum().item())
+    assert n_bad == 0, "h2r_advice_check: %d elements of the timed image violate a gate / lookup / copy (first: %#x)" % (n_bad, int(first[bad != 0][0].item()))
+    audit_s = time.perf_counter() - t_chk
     if env.rank == 0:
         algo = chunk * pow_rows * 160
         stamped_s = (sum(cells_ms) / len(cells_ms)) / 1e3 if cells_ms else float("nan")
@@ -460,7 +473,9 @@ def advice_bench(args):
                        "pipeline": ("h2r_pipeline_modpow_public_key_advice: chain kernels of call k+1 on the caller's stream next to cells_kernel of call k on the "
                                     "pipeline's side stream (2 workspaces, 2 images)") if pipe is not None else
                                    "chain kernels of call k+1 on a second stream next to cells_kernel of call k (2 workspaces, 2 images), stream-ordered exports + events (H2R_BENCH_ADV=%s)" % adv_mode,
-                       "untimed_clock_warmup_calls": ramp, "warmup_calls_total": 1 + ramp + warmup, "buffer_placement": placement},
+                       "untimed_clock_warmup_calls": ramp, "warmup_calls_total": 1 + ramp + warmup, "buffer_placement": placement,
+                       "post_run_audit": "h2r_advice_check on the last timed image: %d elements x %d rows, gate + lookup + %s copy pairs per element, 0 violations (%.2f s incl. the copy map)" %
+                                         (chunk, rows, "pow-row", audit_s)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
                          "traffic_source": "not measured", "kernel": "cells_kernel<%d%s>" % (w, ", Montgomery" if args.montgomery else ""), "launches_timed": len(cells_ms),

@@ -139,7 +139,8 @@ __host__ __device__ inline u64 lookup_slot_bytes(u32 n_rows) { return (u64)n_row
 
 struct LookupSetupArgs {
     const u32 *hist;         // [elem][5][n_rows]
-    const u64 *theta;        // [elem][4] canonical
+    const u64 *theta;        // [elem][4] canonical (mont: x * R mod p, like every field element of a Montgomery ctx)
+    u32 mont;                // H2R_ADVICE_MONTGOMERY: theta comes in, the columns' values go out, in Montgomery form
     u64 num_elems; u32 usable_rows, n_rows, n_lens, arg_mask;
     u32 tag[LOOKUP_MAX_LENS], row_off[LOOKUP_MAX_LENS], bit_len[LOOKUP_MAX_LENS];
     FieldConsts f;
@@ -181,6 +182,8 @@ __global__ __launch_bounds__(256) void lookup_setup_kernel(LookupSetupArgs a) {
     const u32 *h = a.hist + (elem * LOOKUP_ARGS + arg) * n;
     Fe theta;
     for (int k = 0; k < 4; ++k) theta.v[k] = a.theta[elem * 4 + k];
+    const bool theta_ok = !ge_p(theta.v, a.f.p);
+    if (a.mont && theta_ok) theta = fe_from_mont(theta, a.f);
     if (tid < a.n_lens) tagth[tid] = fe_mul_small(theta, a.tag[tid], a.f.p);
     if (tid == 0) total_in = 0;
     __syncthreads();
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void lookup_setup_kernel(LookupSetupArgs a) {
     atomicAdd(&total_in, my_in);
     __syncthreads();
     const u32 usable = a.usable_rows;
-    const bool fits = total_in <= usable && n <= usable && !ge_p(theta.v, a.f.p);   // (a challenge that is not a canonical element is refused too)
+    const bool fits = total_in <= usable && n <= usable && theta_ok;   // (a challenge that is not a canonical element is refused too)
     if (!fits) {   // more lookup inputs (or table rows) than usable rows: no such circuit.  G = 0 tells the fill kernel to leave the columns alone
         if (tid == 0) {
             if (a.status) a.status[elem] = (u8)H2R_E_SHAPE;
@@ -208,11 +211,27 @@ __global__ __launch_bounds__(256) void lookup_setup_kernel(LookupSetupArgs a) {
         }
         return;
     }
-    // 2. rank sort by the field's Ord (ties by row index), 3. scatter
+    // 2. rank by the field's Ord (ties by row index), 3. scatter.  The rows of a bit length are CONSECUTIVE field elements
+    //    tag theta + 0, + 1, ... (mod p), so the number of them below a value is a closed form -- n_lens field subtractions per row
+    //    instead of n comparisons: the set-up was a fifth of the whole call when it compared every pair of rows
     for (u32 r = tid; r < n; r += 256) {
         const Fe me = T[r];
-        u32 rank = 0;
-        for (u32 o = 0; o < n; ++o) { const Fe ot = T[o]; rank += (fe_lt(ot, me) || (o < r && fe_eq(ot, me))) ? 1u : 0u; }
+        u32 rank = r ? 1u : 0u;                               // row 0 = (0, 0): below every other row (or equal with the lower index)
+        for (u32 j = 0; j < a.n_lens; ++j) {
+            const Fe B = tagth[j];
+            const u32 S = 1u << a.bit_len[j];
+            auto small = [](const Fe &x, u32 cap) -> u32 { return ((x.v[1] | x.v[2] | x.v[3]) == 0 && x.v[0] < cap) ? (u32)x.v[0] : cap; };
+            const Fe d = fe_sub(me, B, a.f.p);               // the offset of `me` behind B on the circle of residues
+            const bool ge = !fe_lt(me, B);
+            Fe pm; for (int k = 0; k < 4; ++k) pm.v[k] = a.f.p[k];
+            const Fe wj = fe_is_zero(B) ? pm : fe_sub(fe_zero(), B, a.f.p);   // p - B: rows before the residues wrap
+            const u32 W = small(wj, S);                       // (W = S: the group does not wrap)
+            u32 less = ge ? small(d, W) : 0u;                 // rows B + u < me with u < W
+            if (W < S) less += small(me, S - W);              // the wrapped rows 0 .. S - W - 1
+            const u32 eq_u = small(d, S);                     // the group's row equal to `me`, if any: ties go to the lower row index
+            if (eq_u < S && a.row_off[j] + eq_u < r) ++less;
+            rank += less;
+        }
         order[rank] = r;
     }
     __syncthreads();
@@ -235,7 +254,7 @@ __global__ __launch_bounds__(256) void lookup_setup_kernel(LookupSetupArgs a) {
     Fe *val = reinterpret_cast<Fe *>(slot);
     u32 *a_start = reinterpret_cast<u32 *>(slot + (u64)n * 32), *a_rank = a_start + n + 1, *l_start = a_rank + n, *gcount = l_start + n + 1;
     // sorted distinct values: the head of every run
-    for (u32 i = tid; i < n; i += 256) if (i == 0 || gid[i] != gid[i - 1]) val[gid[i] - 1] = T[order[i]];
+    for (u32 i = tid; i < n; i += 256) if (i == 0 || gid[i] != gid[i - 1]) val[gid[i] - 1] = a.mont ? fe_to_mont(T[order[i]], a.f) : T[order[i]];
     // 6. prefix sums over the groups
     for (u32 g = tid; g < G; g += 256) { gr[g] = gm[g] ? 1u : 0u; gs[g] -= gr[g]; }   // leftover = table entries - [value occurs in A]
     __syncthreads();

@@ -625,8 +625,10 @@ int32_t h2r_trace_lookup_permutation_hist(const h2r_ctx *ctx, const void *trace,
  *    table compressed with the element's challenge (tag * theta + value), A' = the inputs sorted by the field's Ord (order of the
  *    canonical integers), S'[i] = A'[i] on the first row of every run of A', the leftover table values elsewhere (ascending,
  *    handed out from the LAST repeated row backwards, as the upstream Vec::pop does); the table column is the table's rows
- *    followed by its default row (0, 0).  The blinding tail (random) is the caller's.  Output: canonical 32-byte little-endian
- *    elements; element e, argument k at + e * out_elem_stride + k * usable_rows * 32 in a_perm_out and in s_perm_out.
+ *    followed by its default row (0, 0).  The blinding tail (random) is the caller's.  Output: 32-byte little-endian elements
+ *    (canonical; of a H2R_ADVICE_MONTGOMERY ctx: Montgomery form, and theta is then given in Montgomery form too -- the sort
+ *    order is that of the canonical integers either way); element e, argument k at + e * out_elem_stride + k * usable_rows * 32
+ *    in a_perm_out and in s_perm_out (planar already: one contiguous vector per argument).
  *    At most 65,535 circuits per call.  theta: [num_elems][4] uint64 on the device, canonical (< p) little-endian (every proof has its own challenge).  status
  *    (nullable, [num_elems]): H2R_E_SHAPE where the lookup inputs or the table do not fit usable_rows or theta is not canonical
  *    (that circuit's columns are left untouched).  arg_mask: bit k = produce argument k. */

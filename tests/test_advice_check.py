@@ -107,7 +107,7 @@ def test_every_single_cell_corruption_is_flagged(H, repr_kw):
     r_T6 = r_T5 + L + 4
     targets = [(0, 0), (1, 0),                                     # the constants of acc = 1
                (b1 + 0, 0), (b1 + 0, 4), (b1 + 1, 2), (b1 + 1, 4), (b1 + 127, 0),   # range rows of q / r limbs: sub-limbs, remainders
-               (b1 + r_T3 + 1, 0), (b1 + r_T3 + 1, 1), (b1 + r_T3 + 1, 3), (b1 + r_T3 + 700, 2), (b1 + r_T3 + mul_rows + 5, 3),   # mul rows
+               (b1 + r_T3 + 1, 0), (b1 + r_T3 + 1, 1), (b1 + r_T3 + 1, 3), (b1 + r_T3 + 559, 2), (b1 + r_T3 + mul_rows + 4, 3),   # mul rows (column 31's last, column 1's second)
                (b1 + r_T5 + 3, 0), (b1 + r_T5 + 3, 1), (b1 + r_T5 + 3, 2),          # eq_b
                (b1 + r_T5 + L, 0), (b1 + r_T5 + L + 3, 1),                          # is_equal_muled preamble: 2^w, the bit
                (b1 + r_T6 + 0, 2), (b1 + r_T6 + 1, 2), (b1 + r_T6 + 2, 0), (b1 + r_T6 + 3, 0), (b1 + r_T6 + 8, 0), (b1 + r_T6 + 9, 0),

@@ -314,3 +314,38 @@ def test_verify_element_and_layout_permutation(H, mode):
         exp = _expect(w_, rows, P, mode)
         assert _first_diff(g_, exp) is None, (mode, nm, _first_diff(g_, exp))
     assert not np.array_equal(w_img, w_perm)
+
+
+@pytest.mark.gpu
+def test_lookup_columns_in_montgomery_form(H):
+    """h2r_lookup_permuted_columns of a Montgomery ctx: theta comes in times R, A' / S' go out times R, the ORDER is that of the
+    canonical integers (the field's Ord) either way."""
+    import pyref as R
+    P = R.FIELD_MODULI["bn254_fr"]
+    w, L = 64, 8
+    rng = random.Random(77)
+    n = rng.getrandbits(w * L) | (1 << (w * L - 1)) | 1
+    x = rng.randrange(n)
+    usable = (1 << 12) - 6
+    thetas = [rng.randrange(P), P - 1]
+    outs = []
+    for mont in (False, True):
+        chip = H.BigIntChip(w, w * L, montgomery=mont)
+        la = H.LookupArgument(chip, rsa_chip=False)
+        x_dev, n_dev = chip.assign_integer([x, x]), chip.assign_integer([n, n])
+        res = chip.pow_mod_fixed_exp(x_dev, 3, n_dev)
+        hist = la.new_hist(2)
+        la.hist_values(x_dev.limbs_dev, w, 8, hist)
+        la.hist_records(res.trace, hist, res.status)
+        th = [t * R256 % P for t in thetas] if mont else thetas
+        a_perm, s_perm, status = la.permuted_columns(hist, th, usable)
+        torch.cuda.synchronize()
+        assert status.cpu().tolist() == [0, 0]
+        outs.append((a_perm.cpu().numpy(), s_perm.cpu().numpy()))
+    for col in range(2):
+        plain = outs[0][col].reshape(-1, 4).view("<u8") if False else outs[0][col].reshape(-1, 32)
+        mont = outs[1][col].reshape(-1, 32)
+        # distinct values are few (runs): convert each distinct 32-byte value once
+        uniq, inv = np.unique(plain, axis=0, return_inverse=True)
+        conv = np.stack([np.frombuffer((int.from_bytes(u.tobytes(), "little") * R256 % P).to_bytes(32, "little"), dtype=np.uint8) for u in uniq])
+        assert np.array_equal(conv[inv.reshape(-1)], mont), "A'" if col == 0 else "S'"
