@@ -503,6 +503,118 @@ def advice_bench(args):
     env.finalize()
 
 
+def lookup_bench(args):
+    """--lookup: the lookup ARGUMENT of the range-check batch (what `range_chip.load_table` + `create_proof` do with the sub-limb cells,
+    reference benches/bench.rs:141-142, 321-329): one step = h2r_lookup_permuted_columns for 256 circuits (RSA-2048 modpow_public_key
+    records, k = 17: 131,066 usable rows) x 5 arguments -- halo2's A' / S' columns, 10.7 GB written per call by lookup_fill_kernel
+    behind the set-up kernel that ranks the table.  The output pair lies in regions of the image arena (h2r_image_arena_create) unless
+    --placement-candidates 0.  roofline: lookup_fill_kernel, HBM-write bound, algorithmic bytes = the two columns."""
+    import ctypes
+    torch.cuda.set_device(0)
+    w, bits, e = WORKLOADS["rsa2048_e65537"]
+    B = args.batch if args.batch else 256
+    chip = H.BigIntChip(w, bits, device=0, montgomery=args.montgomery)
+    ns, xs, un, ux = synth_inputs(w, bits, 0, B)
+    res = chip.pow_mod_fixed_exp(chip.assign_integer(ux), e, chip.assign_integer(un))
+    la = H.LookupArgument(chip)
+    usable = (1 << 17) - 6
+    hist = la.new_hist(B)
+    la.hist_records(res.trace, hist)
+    torch.cuda.synchronize()
+    del res
+    torch.cuda.empty_cache()
+    P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    rng = random.Random(0x68327273 + 11)
+    thetas = [rng.randrange(P) for _ in range(B)]
+    col_bytes = B * 5 * usable * 32
+    cand = args.placement_candidates if args.placement_candidates >= 0 else 8
+    arena, placement = None, "as allocated"
+    if cand >= 2:
+        arena = H.TraceArena.for_images(chip, col_bytes, regions=2, candidates=cand)
+        out = tuple(r.view(B, 5, usable, 32) for r in arena.regions)
+        placement = {"candidates": len(arena.measurements_ms), "fill_ms_per_candidate": [round(t, 4) for t in arena.measurements_ms],
+                     "kept_ms": [round(t, 4) for t in arena.region_ms]}
+    else:
+        out = (torch.empty((B, 5, usable, 32), dtype=torch.uint8, device="cuda"), torch.empty((B, 5, usable, 32), dtype=torch.uint8, device="cuda"))
+    for _ in range(max(1, args.warmup)):
+        la.permuted_columns(hist, thetas, usable, out=out)
+    torch.cuda.synchronize()
+    steps = args.steps
+    _lib.profile_enable(steps + 4)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        a_perm, s_perm, status = la.permuted_columns(hist, thetas, usable, out=out)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    fill = _lib.profile_read(_lib.KERNEL_LOOKUP)
+    _lib.profile_enable(0)
+    assert not status.cpu().numpy().any()
+    # what was timed is the real thing: every column sorted, and a multiset-preserving permutation of (inputs, table) for sampled circuits
+    av = a_perm[0, 0].view(torch.int64).view(usable, 4)
+    assert bool((av[1:, 3] >= av[:-1, 3]).all().item()) or args.montgomery, "A' is not sorted"
+    algo = 2 * col_bytes
+    fill_s = (sum(fill) / len(fill)) / 1e3
+    line = {"metric": "lookup argument: permuted columns A', S' written", "value": round(algo * steps / dt / 1e9, 1), "unit": "GB/s", "n_gpus": 1,
+            "steps": steps, "warmup": max(1, args.warmup), "ms_per_step": round(1e3 * dt / steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "h2r_lookup_permuted_columns: %d RSA-2048 modpow_public_key circuits x 5 arguments x (A', S') x %d usable rows (k = 17), %d table rows"
+                                   % (B, usable, la.n_rows), "montgomery": bool(args.montgomery), "buffer_placement": placement},
+            "roofline": {"bound": "hbm", "achieved": round(algo / fill_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(algo / fill_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": "not measured",
+                         "kernel": "lookup_fill_kernel", "launches_timed": len(fill), "avg_launch_ms": round(1e3 * fill_s, 4),
+                         "algorithmic_bytes_per_launch": algo},
+            "whole_call_hbm_frac": round(algo * steps / dt / 1e9 / HBM_PEAK_GBS, 4)}
+    if args.pmc_traffic == "auto":
+        hbm, how = measured_pmc_traffic(["--lookup", "--batch", str(B)] + (["--montgomery"] if args.montgomery else []), "lookup_fill_kernel")
+        if hbm is not None:
+            line["roofline"]["traffic"] = hbm
+            line["roofline"]["traffic_source"] = how
+        else:
+            line["roofline"]["traffic_source"] = "live measurement skipped: " + how
+    print(json.dumps(line))
+
+
+def sub_run(extra, timeout=200):
+    """`bench.py <extra>` in a fresh process (same steps cap, no CPU baseline, no counters, no nested sub-runs): the parsed line."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-cpu-baseline", "--pmc-traffic", "off", "--scale-anchor", "off", "--sub-runs", "off"] + extra
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, check=True).stdout.strip().splitlines()[-1]
+        d = json.loads(out)
+        d["_wall_s"] = round(time.perf_counter() - t0, 1)
+        return d
+    except Exception as ex:
+        return {"error": str(ex)[:200]}
+
+
+def sub_run_lines(args):
+    """The numbers a driver that runs only the default line cannot see, each from a fresh process of this script: the headline as
+    allocated (no placement look), the advice image (default and prover representation), BASELINE configs 4 and 5, the lookup argument."""
+    st = ["--steps", str(args.steps), "--warmup", str(args.warmup)]
+    out = {}
+    d = sub_run(st + ["--placement-candidates", "0"])
+    out["plain_allocations"] = {"what": "this line's workload with every buffer as hipMalloc hands it out (no arena, no candidates)", "value": d.get("value"),
+                                "frac": d.get("roofline", {}).get("frac"), "whole_path_hbm_frac": d.get("whole_path_hbm_frac"), "wall_s": d.get("_wall_s"), "error": d.get("error")}
+    for key, extra in (("advice", []), ("advice_columns_montgomery", ["--columns", "--montgomery"])):
+        d = sub_run(st + ["--advice", "--placement-candidates", "8"] + extra)
+        out[key] = {"what": "bench.py --advice %s: elements/s of the %s advice image (12.3 MB each), cells_kernel" % (" ".join(extra), "planar Montgomery-form" if extra else "row-major canonical"),
+                    "value": d.get("value"), "frac": d.get("roofline", {}).get("frac"), "whole_path_hbm_frac": d.get("whole_path_hbm_frac"),
+                    "audit": d.get("config", {}).get("post_run_audit"), "wall_s": d.get("_wall_s"), "error": d.get("error")}
+    oc = {}
+    for key, extra in (("C4", ["--workload", "rsa4096_w32_e65537", "--batch", "4096", "--steps", "8", "--warmup", "2"]),
+                       ("C5", ["--workload", "rsa2048_e2048bit", "--batch", "256", "--steps", "8", "--warmup", "2"])):
+        d = sub_run(extra)
+        oc[key] = {"workload": " ".join(extra), "value": d.get("value"), "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step"),
+                   "frac": d.get("roofline", {}).get("frac"), "whole_path_hbm_frac": d.get("whole_path_hbm_frac"), "wall_s": d.get("_wall_s"), "error": d.get("error")}
+    out["other_configs"] = oc
+    d = sub_run(["--lookup", "--steps", "8", "--warmup", "2"])
+    out["lookup"] = {"what": "bench.py --lookup: h2r_lookup_permuted_columns, 256 circuits x 5 arguments (10.7 GB per call)", "whole_call_GBps": d.get("value"),
+                     "whole_call_frac": d.get("whole_call_hbm_frac"), "fill_kernel_frac": d.get("roofline", {}).get("frac"),
+                     "placement": d.get("config", {}).get("buffer_placement"), "wall_s": d.get("_wall_s"), "error": d.get("error")}
+    return out
+
+
 def main():
     # the image exports NCCL_DEBUG=VERSION, which makes RCCL print a banner on stdout; rank 0's stdout is ONE JSON line
     if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
@@ -536,6 +648,10 @@ def main():
     ap.add_argument("--advice", action="store_true",
                     help="time the prover-consumable witness: every step's output is the 5-column advice image of its modpow_public_key "
                          "elements (assert_in_field rows + pow rows written directly from the operands by cells_kernel), no record planes")
+    ap.add_argument("--lookup", action="store_true", help="the lookup argument's permuted columns (h2r_lookup_permuted_columns) as the product")
+    ap.add_argument("--sub-runs", choices=["auto", "off"], default="auto",
+                    help="auto: the default N = 1 line also carries plain_allocations, advice, advice_columns_montgomery, other_configs (C4, C5) and lookup, "
+                         "each measured in a fresh process of this script")
     ap.add_argument("--columns", action="store_true", help="--advice: planar column vectors instead of 160-byte rows (H2R_ADVICE_COLUMNS)")
     ap.add_argument("--montgomery", action="store_true", help="--advice: cells in Montgomery form, x * 2^256 mod p (H2R_ADVICE_MONTGOMERY)")
     ap.add_argument("--shared-modulus", action="store_true",
@@ -571,6 +687,8 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args.gpus)
+    if args.lookup:
+        return lookup_bench(args)
     if args.advice:
         return advice_bench(args)
 
@@ -962,6 +1080,8 @@ def main():
             # The driver's N = 1 point is BASELINE config 2 (1,024 signatures per step), its N > 1 points config 3 (8,192 per GPU as four
             # calls of 2,048): a like-for-like origin for the 1 -> 8 curve is the N > 1 per-GPU workload run on this one GPU.
             line["scale_anchor"] = scale_anchor_line(args)
+            if args.sub_runs == "auto" and args.placement_candidates < 0:
+                line.update(sub_run_lines(args))
         print(json.dumps(line))
     env.finalize()
 

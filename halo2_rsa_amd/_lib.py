@@ -99,7 +99,7 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_create_ex", "h2r_ctx_advice_repr", "h2r_ab
            "h2r_trace_layout", "h2r_pow_fixed_layout", "h2r_pow_var_layout", "h2r_workspace_bytes",
            "h2r_mul_mod_batch", "h2r_square_mod_batch", "h2r_pow_mod_fixed_exp_batch", "h2r_pow_mod_batch",
            "h2r_modpow_public_key_batch", "h2r_modpow_public_key_var_batch", "h2r_pipeline_create", "h2r_pipeline_create_ex", "h2r_pipeline_destroy",
-           "h2r_pipeline_modpow_public_key", "h2r_pipeline_modpow_public_key_advice", "h2r_pipeline_modpow_public_key_var", "h2r_pipeline_verify_pkcs1v15", "h2r_pipeline_join", "h2r_pipeline_call_plan", "h2r_exp_segment_plan", "h2r_arena_create", "h2r_arena_create_ex", "h2r_arena_region", "h2r_arena_region_bytes", "h2r_arena_region_ms", "h2r_arena_measurements", "h2r_arena_destroy", "h2r_verify_layout_fixed", "h2r_verify_pkcs1v15_batch",
+           "h2r_pipeline_modpow_public_key", "h2r_pipeline_modpow_public_key_advice", "h2r_pipeline_modpow_public_key_var", "h2r_pipeline_verify_pkcs1v15", "h2r_pipeline_join", "h2r_pipeline_call_plan", "h2r_exp_segment_plan", "h2r_arena_create", "h2r_arena_create_ex", "h2r_image_arena_create", "h2r_arena_region", "h2r_arena_region_bytes", "h2r_arena_region_ms", "h2r_arena_measurements", "h2r_arena_destroy", "h2r_verify_layout_fixed", "h2r_verify_pkcs1v15_batch",
            "h2r_verify_trace_flatten", "h2r_fresh_op_layout", "h2r_fresh_op_batch", "h2r_fresh_op_flatten",
            "h2r_mul_stream_bytes", "h2r_is_equal_muled_stream_bytes", "h2r_refresh_stream_bytes", "h2r_mul_batch",
            "h2r_mul_trace_flatten", "h2r_is_equal_muled_batch", "h2r_is_equal_muled_flatten", "h2r_refresh_batch",
@@ -182,6 +182,7 @@ def lib():
     L.h2r_pipeline_join.argtypes = [vp, vp]
     L.h2r_arena_create.argtypes = [vp, u64, u64, u32, u64, u32, u32, vp, ctypes.POINTER(vp)]
     L.h2r_arena_create_ex.argtypes = [vp, u64, u64, u32, u64, u32, u32, u64, vp, ctypes.POINTER(vp)]
+    L.h2r_image_arena_create.argtypes = [vp, u64, u32, u32, u64, vp, ctypes.POINTER(vp)]
     L.h2r_dist_version.argtypes = []
     L.h2r_dist_version.restype = ctypes.c_int32
     L.h2r_arena_region.argtypes = [vp, u32]

@@ -870,6 +870,23 @@ class TraceArena:
         self.measurements_ms = [float(buf[i]) for i in range(n)]
 
     @classmethod
+    def for_images(cls, chip: BigIntChip, region_bytes: int, regions: int = 2, candidates: int = 8, max_look_bytes: int = 0) -> "TraceArena":
+        """h2r_image_arena_create: the same look for any large output buffer (advice images, lookup columns), timed with a streaming fill."""
+        self = cls.__new__(cls)
+        self.chip = chip
+        self._a = ctypes.c_void_p()
+        check(lib().h2r_image_arena_create(chip._ctx, region_bytes, regions, candidates, max_look_bytes, chip._stream(), ctypes.byref(self._a)),
+              "h2r_image_arena_create")
+        nbytes = int(lib().h2r_arena_region_bytes(self._a))
+        dev = "cuda:%d" % chip.device
+        self.regions = [torch.as_tensor(TraceArena._Raw(int(lib().h2r_arena_region(self._a, i)), nbytes), device=dev) for i in range(regions)]
+        self.region_ms = [float(lib().h2r_arena_region_ms(self._a, i)) for i in range(regions)]
+        buf = (ctypes.c_double * (12 * candidates))()
+        n = int(lib().h2r_arena_measurements(self._a, buf, 12 * candidates))
+        self.measurements_ms = [float(buf[i]) for i in range(n)]
+        return self
+
+    @classmethod
     def for_pow(cls, chip: BigIntChip, e: int, batch: int, regions: int = 2, candidates: int = 16) -> "TraceArena":
         pl = chip.pow_fixed_layout(e)
         return cls(chip, pl.elem_stride, pl.off_records, pl.num_mul_mods, batch, regions, candidates)

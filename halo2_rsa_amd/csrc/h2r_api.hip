@@ -1176,6 +1176,21 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
 
 // max_look_bytes != 0: an upper bound on the device memory the look may hold at any time BESIDES the kept regions (rejected
 // candidates kept so that the next one lands elsewhere; the placeholder rounds are skipped) -- a service that shares the device
+namespace {
+// a streaming fill in the product kernels' store pattern (16 bytes per lane, non-temporal, whole 4 KB runs per workgroup step,
+// XCD-contiguous blocks): what h2r_image_arena_create times on a candidate region
+__global__ __launch_bounds__(256) void arena_fill_kernel(u8 *p, u64 bytes) {
+    const u64 per_block = 64ull << 10;
+    const u64 b = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    u8 *q = p + b * per_block;
+    const u64 n = bytes - b * per_block < per_block ? bytes - b * per_block : per_block;
+    for (u64 o = (u64)threadIdx.x * 16; o + 16 <= n; o += 4096) st16(q + o, 0x0123456789abcdefull ^ o, b);
+}
+using ArenaMeasure = std::function<int32_t(void *va, hipStream_t st, hipEvent_t ea, hipEvent_t eb, float *ms)>;
+int32_t arena_build(const h2r_ctx *ctx, u64 region_bytes, uint32_t regions, uint32_t candidates, uint64_t max_look_bytes, hipStream_t st,
+                    const ArenaMeasure &measure, h2r_arena **out);
+}  // namespace
+
 int32_t h2r_arena_create_ex(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t first_record_off, uint32_t records_per_elem,
                             uint64_t batch, uint32_t regions, uint32_t candidates, uint64_t max_look_bytes, h2r_stream_t stream,
                             h2r_arena **out) try {
@@ -1188,20 +1203,6 @@ int32_t h2r_arena_create_ex(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t f
     if (batch * (u64)records_per_elem >= (1ull << 32)) return H2R_E_UNSUPPORTED;
     H2R_ON_DEVICE(ctx->params.device);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipMemAllocationProp prop = {};
-    prop.type = hipMemAllocationTypePinned;
-    prop.location.type = hipMemLocationTypeDevice;
-    prop.location.id = ctx->params.device;
-    size_t gran = 0;
-    HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
-    if (!gran) gran = 2u << 20;
-    const u64 region_bytes = batch * elem_stride;
-    const u64 chunk_target = (knobs().arena_chunk_mb > 0 ? (u64)knobs().arena_chunk_mb : 256ull) << 20;
-    const u64 n_chunks = (region_bytes + chunk_target - 1) / chunk_target;
-    const u64 chunk = round_up((region_bytes + n_chunks - 1) / n_chunks, gran);
-    std::unique_ptr<h2r_arena> a(new (std::nothrow) h2r_arena());
-    if (!a) return H2R_E_HIP;
-    a->device = ctx->params.device; a->region_bytes = region_bytes;
     // operands of the measurement launches: any values do (the record kernel's store pattern does not depend on them)
     const u64 n_items = batch * records_per_elem;
     const u64 ops_bytes = n_items * 4ull * ctx->L * lo.limb_bytes;
@@ -1210,10 +1211,77 @@ int32_t h2r_arena_create_ex(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t f
     struct ScratchFree { u8 *p; ~ScratchFree() { if (p) (void)hipFree(p); } } scratch_free{scratch};
     HIP_TRY(hipMemsetAsync(scratch, 0x5a, ops_bytes, st));
     HIP_TRY(hipMemsetAsync(scratch + ops_bytes, 0, batch + 4096, st));
+    // three launches of the record kernel in the production geometry
+    const ArenaMeasure measure = [&](void *va, hipStream_t s2, hipEvent_t ea, hipEvent_t eb, float *ms_out) -> int32_t {
+        TraceArgs ta;
+        fill_trace_args(ctx, ta);
+        const u64 lb = lo.limb_width / 8;
+        ta.opA = scratch; ta.opB = scratch + ctx->L * lb; ta.opQ = scratch + 2 * ctx->L * lb; ta.opR = scratch + 3 * ctx->L * lb;
+        ta.op_stride = 4ull * ctx->L;
+        ta.n = scratch; ta.n_stride = 0;
+        ta.status = scratch + ops_bytes; ta.n_items = n_items; ta.T = records_per_elem;
+        ta.trace = static_cast<u8 *>(va); ta.elem_stride = elem_stride; ta.off_records = first_record_off;
+        if (knobs().trace_dyn_lds < 0 && lo.limb_width == 64 && ctx->L <= 32) ta.residency = 1;   // the kernel's stand-alone launch shape
+        float sum = 0.f;
+        for (int rep = 0; rep < 3; ++rep) {
+            if (!hip_ok(launch_trace(ctx, ta, s2, ea, eb), "launch_trace")) return H2R_E_HIP;
+            if (!hip_ok(hipStreamSynchronize(s2), "hipStreamSynchronize")) return H2R_E_HIP;
+            float ms = 0.f;
+            if (!hip_ok(hipEventElapsedTime(&ms, ea, eb), "hipEventElapsedTime")) return H2R_E_HIP;
+            if (rep) sum += ms;   // the first launch touches the pages
+        }
+        *ms_out = sum / 2.f;
+        return H2R_OK;
+    };
+    return arena_build(ctx, batch * elem_stride, regions, candidates, max_look_bytes, st, measure, out);
+} H2R_CATCH_STATUS
+
+// The same look for ANY large output the kernels stream into -- advice images, the lookup argument's A' / S' columns: where such a
+// buffer lies physically decides its store rate exactly as for the trace (cells_kernel 1.82-2.39 ms, lookup_fill_kernel 5.05-6.73 TB/s
+// by buffer).  The candidates are timed with a streaming fill in the product kernels' store pattern; h2r_arena_region etc. apply.
+int32_t h2r_image_arena_create(const h2r_ctx *ctx, uint64_t region_bytes, uint32_t regions, uint32_t candidates, uint64_t max_look_bytes,
+                               h2r_stream_t stream, h2r_arena **out) try {
+    if (!ctx || !out) return H2R_E_NULL;
+    *out = nullptr;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    if (!regions || candidates < regions || region_bytes < (1ull << 20) || (region_bytes >> 16) >= (1ull << 31)) return H2R_E_SHAPE;
+    H2R_ON_DEVICE(ctx->params.device);
+    const ArenaMeasure measure = [&](void *va, hipStream_t s2, hipEvent_t ea, hipEvent_t eb, float *ms_out) -> int32_t {
+        const unsigned blocks = (unsigned)((region_bytes + (64ull << 10) - 1) >> 16);
+        float sum = 0.f;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipExtLaunchKernelGGL(arena_fill_kernel, dim3(blocks), dim3(256), 0, s2, ea, eb, 0, static_cast<u8 *>(va), region_bytes);
+            if (!hip_ok(hipGetLastError(), "arena_fill_kernel") || !hip_ok(hipStreamSynchronize(s2), "hipStreamSynchronize")) return H2R_E_HIP;
+            float ms = 0.f;
+            if (!hip_ok(hipEventElapsedTime(&ms, ea, eb), "hipEventElapsedTime")) return H2R_E_HIP;
+            if (rep) sum += ms;
+        }
+        *ms_out = sum / 2.f;
+        return H2R_OK;
+    };
+    return arena_build(ctx, region_bytes, regions, candidates, max_look_bytes, static_cast<hipStream_t>(stream), measure, out);
+} H2R_CATCH_STATUS
+
+namespace {
+int32_t arena_build(const h2r_ctx *ctx, u64 region_bytes, uint32_t regions, uint32_t candidates, uint64_t max_look_bytes, hipStream_t st,
+                    const ArenaMeasure &measure, h2r_arena **out) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = ctx->params.device;
+    size_t gran = 0;
+    HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    if (!gran) gran = 2u << 20;
+    const u64 chunk_target = (knobs().arena_chunk_mb > 0 ? (u64)knobs().arena_chunk_mb : 256ull) << 20;
+    const u64 n_chunks = (region_bytes + chunk_target - 1) / chunk_target;
+    const u64 chunk = round_up((region_bytes + n_chunks - 1) / n_chunks, gran);
+    std::unique_ptr<h2r_arena> a(new (std::nothrow) h2r_arena());
+    if (!a) return H2R_E_HIP;
+    a->device = ctx->params.device; a->region_bytes = region_bytes;
     hipEvent_t ea = nullptr, eb = nullptr;
     HIP_TRY(hipEventCreate(&ea));
     if (!hip_ok(hipEventCreate(&eb), "hipEventCreate")) { (void)hipEventDestroy(ea); return H2R_E_HIP; }
-    // one candidate: reserve, create, map, touch, three launches of the record kernel in the production geometry
+    // one candidate: reserve, create, map, touch, measure
     auto make_candidate = [&](h2r_arena::Region &r) -> int32_t {
         r.mapped = n_chunks * chunk; r.chunk = chunk; r.n_mapped = 0;
         if (!hip_ok(hipMemAddressReserve(&r.va, r.mapped, 0, nullptr, 0), "hipMemAddressReserve")) { r.va = nullptr; return H2R_E_HIP; }
@@ -1228,25 +1296,7 @@ int32_t h2r_arena_create_ex(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t f
         acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
         if (!hip_ok(hipMemSetAccess(r.va, r.mapped, &acc, 1), "hipMemSetAccess")) return H2R_E_HIP;
         if (!hip_ok(hipMemsetAsync(r.va, 0, region_bytes, st), "hipMemsetAsync")) return H2R_E_HIP;
-        TraceArgs ta;
-        fill_trace_args(ctx, ta);
-        const u64 lb = lo.limb_width / 8;
-        ta.opA = scratch; ta.opB = scratch + ctx->L * lb; ta.opQ = scratch + 2 * ctx->L * lb; ta.opR = scratch + 3 * ctx->L * lb;
-        ta.op_stride = 4ull * ctx->L;
-        ta.n = scratch; ta.n_stride = 0;
-        ta.status = scratch + ops_bytes; ta.n_items = n_items; ta.T = records_per_elem;
-        ta.trace = static_cast<u8 *>(r.va); ta.elem_stride = elem_stride; ta.off_records = first_record_off;
-        if (knobs().trace_dyn_lds < 0 && lo.limb_width == 64 && ctx->L <= 32) ta.residency = 1;   // the kernel's stand-alone launch shape
-        float sum = 0.f;
-        for (int rep = 0; rep < 3; ++rep) {
-            if (!hip_ok(launch_trace(ctx, ta, st, ea, eb), "launch_trace")) return H2R_E_HIP;
-            if (!hip_ok(hipStreamSynchronize(st), "hipStreamSynchronize")) return H2R_E_HIP;
-            float ms = 0.f;
-            if (!hip_ok(hipEventElapsedTime(&ms, ea, eb), "hipEventElapsedTime")) return H2R_E_HIP;
-            if (rep) sum += ms;   // the first launch touches the pages
-        }
-        r.ms = sum / 2.f;
-        return H2R_OK;
+        return measure(r.va, st, ea, eb, &r.ms);
     };
     std::vector<h2r_arena::Region> cands;
     int32_t rc = H2R_OK;
@@ -1334,7 +1384,8 @@ int32_t h2r_arena_create_ex(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t f
     for (auto &r : cands) a->kept.push_back(std::move(r));
     *out = a.release();
     return H2R_OK;
-} H2R_CATCH_STATUS
+}
+}  // namespace
 
 void *h2r_arena_region(const h2r_arena *a, uint32_t i) try { return (a && i < a->kept.size()) ? a->kept[i].va : nullptr; } catch (...) { return nullptr; }
 uint64_t h2r_arena_region_bytes(const h2r_arena *a) try { return a ? a->region_bytes : 0; } H2R_CATCH_ZERO

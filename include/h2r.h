@@ -382,6 +382,12 @@ int32_t h2r_arena_create(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t firs
 int32_t h2r_arena_create_ex(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t first_record_off, uint32_t records_per_elem,
                             uint64_t batch, uint32_t regions, uint32_t candidates, uint64_t max_look_bytes, h2r_stream_t stream,
                             h2r_arena **out);
+/* The same look for ANY large buffer the kernels stream into -- advice images, the lookup argument's A' / S' columns: `regions`
+ * regions of region_bytes each, the fastest of `candidates` allocations timed with a streaming fill in the product kernels' store
+ * pattern (16 bytes per lane, non-temporal); max_look_bytes as for h2r_arena_create_ex.  A prover allocates such buffers once:
+ * this is "time a few, keep the fastest" as an export.  The accessors below apply. */
+int32_t h2r_image_arena_create(const h2r_ctx *ctx, uint64_t region_bytes, uint32_t regions, uint32_t candidates, uint64_t max_look_bytes,
+                               h2r_stream_t stream, h2r_arena **out);
 void *h2r_arena_region(const h2r_arena *a, uint32_t i);
 uint64_t h2r_arena_region_bytes(const h2r_arena *a);
 double h2r_arena_region_ms(const h2r_arena *a, uint32_t i);          /* measured record-kernel time of kept region i */
