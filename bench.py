@@ -552,6 +552,10 @@ def lookup_bench(args):
     # what was timed is the real thing: every column sorted, and a multiset-preserving permutation of (inputs, table) for sampled circuits
     av = a_perm[0, 0].view(torch.int64).view(usable, 4)
     assert bool((av[1:, 3] >= av[:-1, 3]).all().item()) or args.montgomery, "A' is not sorted"
+    del av, a_perm, s_perm, out          # (views of the arena's mapped memory: gone before the arena unmaps it)
+    torch.cuda.synchronize()
+    if arena is not None:
+        arena.close()
     algo = 2 * col_bytes
     fill_s = (sum(fill) / len(fill)) / 1e3
     line = {"metric": "lookup argument: permuted columns A', S' written", "value": round(algo * steps / dt / 1e9, 1), "unit": "GB/s", "n_gpus": 1,
@@ -584,6 +588,8 @@ def sub_run(extra, timeout=200):
         d = json.loads(out)
         d["_wall_s"] = round(time.perf_counter() - t0, 1)
         return d
+    except subprocess.CalledProcessError as ex:
+        return {"error": ("rc %d: " % ex.returncode) + (ex.stderr or "").strip()[-300:]}
     except Exception as ex:
         return {"error": str(ex)[:200]}
 
@@ -808,6 +814,11 @@ def main():
     nc = [n_dev if (args.shared_modulus and not os.environ.get("H2R_BENCH_REPLICATE_N")) else H.AssignedInteger(n_dev.limbs_dev[c * chunk:(c + 1) * chunk], w) for c in range(chunks)]
     pipes = [] if args.no_pipeline else [H.Pipeline(chip, depth=args.pipeline_depth, side_streams=args.side_streams) for _ in range(producers)]
     pipe = pipes[0] if pipes else None
+    pipeline_form = None
+    if pipe is not None:   # what the library chose for calls of this size on this stream (it measures whether its streams sit on three hardware queues)
+        pi = pipe.info(chunk)
+        pipeline_form = {"record_form": ["one-launch step", "two-queue", "side stream"][pi.record_form], "three_queues": {0: False, 1: True}.get(pi.three_queues),
+                         "probe_ms": round(pi.probe_ms, 3), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
     # producer p issues calls p, p + P, p + 2P, ... on its own stream; buffer set k % (depth * P) belongs to producer k % P
     prod_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(producers - 1)]
     counter = [0]
@@ -1034,6 +1045,7 @@ def main():
                                      ("chain k+1 || trace k, %d buffer sets, %d record stream(s)" % (args.pipeline_depth, args.side_streams))) +
                                     (", %d producers (a pipeline and a stream each, calls alternate)" % producers if producers > 1 else ""))
                                    if pipe is not None else "none",
+                       "pipeline_form": pipeline_form,
                        "untimed_clock_warmup_calls": ramp_steps * chunks,
                        # everything that ran before the timed region: 1 set-up call + the clock warm-up calls + the W warm-up steps
                        "warmup_calls_total": 1 + ramp_steps * chunks + warmup * chunks,

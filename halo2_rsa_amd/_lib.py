@@ -32,6 +32,14 @@ H2R_ADVICE_COLUMNS, H2R_ADVICE_MONTGOMERY = 0x400, 0x800
 H2R_VERSION = 4
 
 
+class H2RPipelineInfo(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("depth", ctypes.c_uint32), ("side_streams", ctypes.c_uint32), ("record_form", ctypes.c_uint32),
+                ("three_queues", ctypes.c_uint32), ("probe_ms", ctypes.c_float)]
+
+
+H2R_PIPE_ONE_LAUNCH_STEP, H2R_PIPE_TWO_QUEUE, H2R_PIPE_SIDE_STREAM = 0, 1, 2
+
+
 class H2RLayout(ctypes.Structure):
     _fields_ = [("limb_width", ctypes.c_uint32), ("num_limbs", ctypes.c_uint32), ("num_cols", ctypes.c_uint32),
                 ("limb_bytes", ctypes.c_uint32), ("wide_bytes", ctypes.c_uint32), ("carry_bytes", ctypes.c_uint32),
@@ -99,7 +107,7 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_create_ex", "h2r_ctx_advice_repr", "h2r_ab
            "h2r_trace_layout", "h2r_pow_fixed_layout", "h2r_pow_var_layout", "h2r_workspace_bytes",
            "h2r_mul_mod_batch", "h2r_square_mod_batch", "h2r_pow_mod_fixed_exp_batch", "h2r_pow_mod_batch",
            "h2r_modpow_public_key_batch", "h2r_modpow_public_key_var_batch", "h2r_pipeline_create", "h2r_pipeline_create_ex", "h2r_pipeline_destroy",
-           "h2r_pipeline_modpow_public_key", "h2r_pipeline_modpow_public_key_advice", "h2r_pipeline_modpow_public_key_var", "h2r_pipeline_verify_pkcs1v15", "h2r_pipeline_join", "h2r_pipeline_call_plan", "h2r_exp_segment_plan", "h2r_arena_create", "h2r_arena_create_ex", "h2r_image_arena_create", "h2r_arena_region", "h2r_arena_region_bytes", "h2r_arena_region_ms", "h2r_arena_measurements", "h2r_arena_destroy", "h2r_verify_layout_fixed", "h2r_verify_pkcs1v15_batch",
+           "h2r_pipeline_modpow_public_key", "h2r_pipeline_modpow_public_key_advice", "h2r_pipeline_modpow_public_key_var", "h2r_pipeline_verify_pkcs1v15", "h2r_pipeline_join", "h2r_pipeline_info", "h2r_pipeline_call_plan", "h2r_exp_segment_plan", "h2r_arena_create", "h2r_arena_create_ex", "h2r_image_arena_create", "h2r_arena_region", "h2r_arena_region_bytes", "h2r_arena_region_ms", "h2r_arena_measurements", "h2r_arena_destroy", "h2r_verify_layout_fixed", "h2r_verify_pkcs1v15_batch",
            "h2r_verify_trace_flatten", "h2r_fresh_op_layout", "h2r_fresh_op_batch", "h2r_fresh_op_flatten",
            "h2r_mul_stream_bytes", "h2r_is_equal_muled_stream_bytes", "h2r_refresh_stream_bytes", "h2r_mul_batch",
            "h2r_mul_trace_flatten", "h2r_is_equal_muled_batch", "h2r_is_equal_muled_flatten", "h2r_refresh_batch",
@@ -180,6 +188,7 @@ def lib():
     L.h2r_pipeline_modpow_public_key_advice.argtypes = [vp, vp, vp, ctypes.c_char_p, ctypes.c_size_t, u64, u32, vp, vp, vp, vp, vp, u64, vp]
     L.h2r_pipeline_modpow_public_key_var.argtypes = [vp, vp, vp, u32, u32, vp, u64, u32, vp, vp, vp, vp, vp, vp]
     L.h2r_pipeline_join.argtypes = [vp, vp]
+    L.h2r_pipeline_info.argtypes = [vp, vp, u64, ctypes.POINTER(H2RPipelineInfo)]
     L.h2r_arena_create.argtypes = [vp, u64, u64, u32, u64, u32, u32, vp, ctypes.POINTER(vp)]
     L.h2r_arena_create_ex.argtypes = [vp, u64, u64, u32, u64, u32, u32, u64, vp, ctypes.POINTER(vp)]
     L.h2r_image_arena_create.argtypes = [vp, u64, u32, u32, u64, vp, ctypes.POINTER(vp)]

@@ -830,6 +830,12 @@ class Pipeline:
                                                      powed.data_ptr(), is_valid.data_ptr(), status.data_ptr(), workspace.data_ptr(),
                                                      self.chip._stream()), "h2r_pipeline_verify_pkcs1v15_var")
 
+    def info(self, batch: int) -> "_lib.H2RPipelineInfo":
+        """h2r_pipeline_info: the form a call of `batch` elements on the current stream takes (runs the hardware-queue probe if needed)."""
+        out = _lib.H2RPipelineInfo(ctypes.sizeof(_lib.H2RPipelineInfo))
+        check(lib().h2r_pipeline_info(self._p, self.chip._stream(), batch, ctypes.byref(out)), "h2r_pipeline_info")
+        return out
+
     def join(self):
         check(lib().h2r_pipeline_join(self._p, self.chip._stream()), "h2r_pipeline_join")
 

@@ -5,6 +5,7 @@
 #include <rccl/rccl.h>   // types and enums only: the functions are resolved with dlsym (no link-time dependency on librccl)
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -996,6 +997,12 @@ struct h2r_pipeline {
     TraceArgs pending_ta;
     hipStream_t pending_st = nullptr;
     hipEvent_t flush_done = nullptr;   // orders another stream behind a flush
+    // Do the caller's stream and the two side streams sit on THREE hardware queues?  HIP multiplexes a process's streams onto
+    // GPU_MAX_HW_QUEUES queues (4 by default) in creation order; two streams of one queue never overlap, and the two-queue form then runs
+    // BEHIND the one-launch step it replaces (4.8 against 5.5 M assigns/s under torchrun with RCCL's streams in the process).  The library
+    // cannot read the assignment, so it measures it once per caller stream: three 150 us one-wave spinners (pipeline_three_queues).
+    std::map<hipStream_t, int> queue_probe;   // 1: three queues, 0: some pair shares one
+    float probe_ms = 0.f;                     // wall time of the last probe
 };
 
 // ---- multi-GPU: RCCL behind the C ABI --------------------------------------------------------------------------------------
@@ -1486,6 +1493,54 @@ int32_t pipeline_flush(h2r_pipeline *p, hipStream_t st) {
 
 int32_t h2r_pipeline_create(const h2r_ctx *ctx, h2r_pipeline **out) try { return h2r_pipeline_create_ex(ctx, 2, 1, out); } H2R_CATCH_STATUS
 
+namespace {
+__global__ void queue_probe_kernel(unsigned long long ticks) {   // one wave that holds its queue for `ticks` of the 100 MHz wall clock
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace
+namespace {
+bool pipeline_three_queues(h2r_pipeline *p, hipStream_t st) {
+    if (p->aux[0] == p->aux[1]) return false;
+    auto it = p->queue_probe.find(st);
+    if (it != p->queue_probe.end()) return it->second != 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (cs != hipStreamCaptureStatusNone) return false;           // (a capture cannot be timed: the form that needs no particular queues; not cached)
+    // everything queued so far out of the way, then the three spinners back to back: one spin of wall time when they overlap, three when they share
+    hipStream_t ss[3] = {st, p->aux[0], p->aux[1]};
+    for (hipStream_t s : ss) if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const unsigned long long spin_ticks = 15000;                  // 150 us
+    float best = 1e9f;
+    for (int rep = 0; rep < 2; ++rep) {                           // (the first round also loads the kernel)
+        const auto t0 = std::chrono::steady_clock::now();
+        for (hipStream_t s : ss) hipLaunchKernelGGL(queue_probe_kernel, dim3(1), dim3(64), 0, s, spin_ticks);
+        bool ok = hipGetLastError() == hipSuccess;
+        for (hipStream_t s : ss) ok = (hipStreamSynchronize(s) == hipSuccess) && ok;
+        if (!ok) { (void)hipGetLastError(); return false; }
+        const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (rep) best = ms;
+    }
+    p->probe_ms = best;
+    const int three = best < 0.150f * 1.6f ? 1 : 0;               // 0.15 ms overlapped, >= 0.30 with a shared queue
+    p->queue_probe[st] = three;
+    return three != 0;
+}
+}  // namespace
+
+int32_t h2r_pipeline_info(h2r_pipeline *p, h2r_stream_t stream, uint64_t batch, h2r_pipeline_info_t *out) try {
+    if (!p || !out) return H2R_E_NULL;
+    if (out->struct_size != sizeof(h2r_pipeline_info_t)) return H2R_E_UNSUPPORTED;
+    const h2r_ctx *ctx = p->ctx;
+    H2R_ON_DEVICE(ctx->params.device);
+    out->depth = p->depth; out->side_streams = p->aux[0] != p->aux[1] ? 2u : 1u;
+    const bool shape = ctx->layout.limb_width == 64 && ctx->L == 32 && batch && batch <= 2048 && p->aux[0] != p->aux[1] && p->depth >= 3;
+    out->three_queues = shape ? (pipeline_three_queues(p, static_cast<hipStream_t>(stream)) ? 1u : 0u) : 2u;   // 2: not asked (the shape has no two-queue form)
+    out->probe_ms = p->probe_ms;
+    out->record_form = (shape && out->three_queues == 1) ? H2R_PIPE_TWO_QUEUE : (step_eligible(ctx, batch, reinterpret_cast<void *>(1), 19) ? H2R_PIPE_ONE_LAUNCH_STEP : H2R_PIPE_SIDE_STREAM);
+    return H2R_OK;
+} H2R_CATCH_STATUS
+
 int32_t h2r_pipeline_create_ex(const h2r_ctx *ctx, uint32_t depth, uint32_t side_streams, h2r_pipeline **out) try {
     if (!ctx || !out) return H2R_E_NULL;
     *out = nullptr;
@@ -1759,7 +1814,10 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
     // 5.50-5.51 M at 2,048).  Every other step shape is chain-bound enough to lose that way (RSA-1024 9.4 against 12.4 M, RSA-3072 2.1
     // against 2.5 M, RSA-4096 1.2 against 1.5 M; 128 x 32-bit limbs: the same): tools/two_queue_ab.sh, profiles/r04_two_queue.txt.
     // (calls of up to 2,048: at 4,096 per call one launch has little boundary left to hide and the step is ahead again, 5.37-5.42 against 5.27-5.33 M)
-    const bool overlap_records = ctx->layout.limb_width == 64 && ctx->L == 32 && batch <= 2048 && p->aux[0] != p->aux[1] && p->depth >= 3 && knobs().pipe_step < 1;
+    // ... provided the three streams sit on three hardware queues, which the pipeline measures once per caller stream (pipeline_three_queues);
+    // with a shared queue the call falls back to the one-launch step
+    const bool overlap_records = ctx->layout.limb_width == 64 && ctx->L == 32 && batch <= 2048 && p->aux[0] != p->aux[1] && p->depth >= 3 && knobs().pipe_step < 1 &&
+                                 pipeline_three_queues(p, st);
     const bool as_steps = step_eligible(ctx, batch, trace, T) && n_seg_single <= 1 && !overlap_records;
     if (p->pending && (!as_steps || p->pending_st != st)) {   // the records still owed go out alone, `st` behind them
         rc = pipeline_flush(p, st);

@@ -331,6 +331,22 @@ int32_t h2r_pipeline_modpow_public_key_var(h2r_pipeline *p, const void *x, const
                                            uint32_t exp_limb_bits, const void *n, uint64_t batch, uint32_t flags, void *trace,
                                            void *in_field_trace, void *out, uint8_t *status, void *workspace, h2r_stream_t stream);
 int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream);
+/* Which form a pipelined modpow_public_key call of `batch` elements on `stream` takes.  The two-queue form (RSA-2048, calls of up to
+ * 2,048, depth >= 3, two side streams) needs the caller's stream and the two side streams on three different HARDWARE queues; the
+ * library cannot read HIP's stream -> queue assignment, so the pipeline MEASURES it the first time it meets a caller stream (three
+ * 150 us one-wave spinners, one per stream, after synchronising the three streams: ~0.5 ms once per (pipeline, stream); never inside a
+ * stream capture, which takes the step) and falls back to the one-launch step when two of them share a queue -- no environment
+ * variable is needed for correctness or for the 5.4-5.5 M assigns/s floor; GPU_MAX_HW_QUEUES=8 merely makes the faster form available
+ * to a process that has many streams.  h2r_pipeline_info runs the probe if it has not run for `stream` and reports the outcome. */
+enum { H2R_PIPE_ONE_LAUNCH_STEP = 0, H2R_PIPE_TWO_QUEUE = 1, H2R_PIPE_SIDE_STREAM = 2 };
+typedef struct h2r_pipeline_info_t {
+    uint32_t struct_size;   /* in: sizeof(h2r_pipeline_info_t) */
+    uint32_t depth, side_streams;
+    uint32_t record_form;   /* H2R_PIPE_* */
+    uint32_t three_queues;  /* 1: the three streams overlap; 0: two of them share a hardware queue; 2: not measured (the shape / size has no two-queue form) */
+    float probe_ms;         /* wall time of the three spinners (0.15: overlapped; 0.30-0.45: shared) */
+} h2r_pipeline_info_t;
+int32_t h2r_pipeline_info(h2r_pipeline *p, h2r_stream_t stream, uint64_t batch, h2r_pipeline_info_t *out);
 
 /* ---- multi-GPU: one process per GPU, signatures sharded, RCCL over xGMI behind the C ABI ---------------------------------
  * Signatures are independent: every rank owns a contiguous shard of the batch (h2r_dist_shard_range), runs the
