@@ -344,7 +344,7 @@ typedef struct h2r_pipeline_info_t {
     uint32_t depth, side_streams;
     uint32_t record_form;   /* H2R_PIPE_* */
     uint32_t three_queues;  /* 1: the three streams overlap; 0: two of them share a hardware queue; 2: not measured (the shape / size has no two-queue form) */
-    float probe_ms;         /* wall time of the three spinners (0.15: overlapped; 0.30-0.45: shared) */
+    float probe_ms;         /* wall time of the three 150 us spinners, best of three rounds (<= 0.186: three queues; 0.199-0.203 measured when two streams shared one; 0.3-0.45 with one queue) */
 } h2r_pipeline_info_t;
 int32_t h2r_pipeline_info(h2r_pipeline *p, h2r_stream_t stream, uint64_t batch, h2r_pipeline_info_t *out);
 

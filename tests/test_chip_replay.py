@@ -1,0 +1,56 @@
+"""The chip shim as code: integration/gpu_chip.rs (the reference-side binding; Rust cannot be compiled in this image) and its compiled
+twin tests/cpp/test_chip_replay.cpp -- the reference's control flow (big_integer/chip.rs:386-419, 542-629, 664-742, 822-895, 1323-1349)
+replayed over the GPU's flat stream against a mock RegionCtx that checks every gate relation, counts every call and requires the
+stream to be consumed to the last byte."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "test_chip_replay")
+
+
+def build_replay():
+    from halo2_rsa_amd import _build
+    _build.build_lib()
+    src = os.path.join(ROOT, "tests", "cpp", "test_chip_replay.cpp")
+    deps = [src, os.path.join(ROOT, "include", "h2r.h")]
+    if os.path.exists(EXE) and all(os.path.getmtime(EXE) >= os.path.getmtime(d) for d in deps):
+        return EXE
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), src, "-o", EXE,
+                           "-L" + os.path.join(ROOT, "halo2_rsa_amd", "lib"), "-lh2r", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath," + os.path.join(ROOT, "halo2_rsa_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib"])
+    return EXE
+
+
+def test_replay_twin_compiles():
+    assert os.path.exists(build_replay())
+
+
+def test_rust_shim_has_full_bodies_and_mirrors_the_twin():
+    """No `unimplemented!()` / `todo!()`; every method of the twin exists in the Rust file with the same statement anchors (the
+    reference line numbers the two files cite must agree)."""
+    rs = open(os.path.join(ROOT, "integration", "gpu_chip.rs")).read()
+    cpp = open(os.path.join(ROOT, "tests", "cpp", "test_chip_replay.cpp")).read()
+    assert "unimplemented!" not in rs and "todo!" not in rs
+    for fn in ("fn mul(", "fn mul_mod(", "fn square_mod(", "fn pow_mod_fixed_exp(", "fn pow_mod(", "fn is_equal_muled(", "fn div_mod_main_gate(",
+               "fn modpow_public_key("):
+        assert fn in rs, fn
+    anchors = lambda text: set(re.findall(r":(\d{3,4})(?:-\d{3,4})?\b", text))
+    for a in ("588", "596", "608", "617", "859", "860", "864", "869", "871", "873", "879", "890", "677", "686", "688", "693"):
+        assert a in anchors(cpp) and a in anchors(rs), a
+    # every export the shim binds is declared in include/h2r.h
+    hdr = open(os.path.join(ROOT, "include", "h2r.h")).read()
+    for name in set(re.findall(r"ffi::(h2r_[a-z0-9_]+)\(", rs)):          # (functions; ffi::h2r_layout etc. are the header's structs)
+        assert re.search(r"\b%s\(" % name, hdr), name
+    for name in set(re.findall(r"ffi::(h2r_[a-z0-9_]+)\b(?!\()", rs)):
+        assert re.search(r"\b%s\b" % name, hdr), name
+
+
+@pytest.mark.gpu
+def test_replay_consumes_the_stream_exactly_fix_and_var():
+    out = subprocess.run([build_replay()], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "CHIP_REPLAY_OK" in out.stdout and "Fix: 3 elements" in out.stdout and "Var: 3 elements" in out.stdout
