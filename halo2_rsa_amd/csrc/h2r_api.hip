@@ -3258,6 +3258,13 @@ namespace {
 struct SideFork {
     const h2r_ctx *ctx; hipStream_t main; std::unique_lock<std::mutex> lk; bool ok = false;
     SideFork(const h2r_ctx *c, hipStream_t st) : ctx(c), main(st), lk(c->side_mu) {
+        // A CAPTURING caller does not fork: the ctx has ONE side stream, and once a capture has forked into it the stream stays part of
+        // that capture until EndCapture -- a second emit on the same ctx before then (another thread, or this thread on a plain stream)
+        // would record / wait events across the capture's boundary and invalidate it.  Inside a capture the row programs run in order
+        // on the caller's stream (a graph has no use for the overlap of a 2 % tail anyway).
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(main, &cs) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (cs != hipStreamCaptureStatusNone) return;
         if (!ctx->side_stream) {
             if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
                 hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||

@@ -322,6 +322,43 @@ def test_verify_element_inside_a_stream_capture(H, golden):
     assert torch.equal(out, want)
 
 
+def test_capture_on_one_stream_and_a_plain_emit_on_another(H, golden):
+    """A capture in progress on stream A and a plain emit on stream B of the SAME ctx before EndCapture: the capturing call must not
+    have pulled the ctx's side stream into its capture (it runs its row programs in order on A), so the plain call forks and joins as
+    usual, the capture stays valid, and both images are right."""
+    import ctypes
+    from halo2_rsa_amd import _lib
+    rsa = H.RSAChip(2048, 5)
+    rng = random.Random(0x68327273 + 46)
+    B = 8
+    N = [rand_modulus(rng, 2048) for _ in range(B)]
+    pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(N, 32, 64), H.Fix(65537)))
+    sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints([rng.randrange(n) for n in N], 32, 64)))
+    res = rsa.verify_pkcs1v15_signature(pk, [rng.getrandbits(256) for _ in range(B)], sg)
+    want = res.emit_advice(direct=True)
+    out_graph, out_plain = torch.zeros_like(want), torch.zeros_like(want)
+    sig, n, hashed = res.inputs
+    chip = res.chip
+
+    def emit(dst, stream_ptr):
+        _lib.check(_lib.lib().h2r_verify_emit_advice(chip._ctx, ctypes.byref(res.layout), sig.data_ptr(), n.data_ptr(), hashed.data_ptr(), res.powed.data_ptr(),
+                                                     chip._flags(n, B) | _lib.H2R_ADVICE_DIRECT, res.trace.data_ptr(), res.workspace.data_ptr(), B,
+                                                     res.status.data_ptr(), dst.data_ptr(), dst.shape[1], stream_ptr), "h2r_verify_emit_advice")
+
+    torch.cuda.synchronize()
+    other = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="relaxed"):
+        emit(out_graph, chip._stream())
+        emit(out_plain, ctypes.c_void_p(other.cuda_stream))       # a plain stream, while the capture is still open
+        other.synchronize()                                        # ... and it RUNS while the capture is open
+    assert torch.equal(out_plain, want)
+    assert int(out_graph.max().item()) == 0
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_graph, want)
+
+
 def test_config2_full_size_direct_image(H):
     """BASELINE config 2 (1,024 RSA-2048 signatures, e = 65537): the 12.4 GB image written directly equals the image of the
     records, every byte, compared on the device."""
