@@ -1159,7 +1159,8 @@ int32_t h2r_dist_allreduce_max_f64(h2r_dist *d, double *values, uint64_t count, 
 // was not found, so the arena LOOKS: it maps `candidates` regions (HIP virtual-memory API, 256 MB physical chunks), runs the
 // record kernel in the production geometry on each, keeps the `regions` fastest and gives the others back.
 struct h2r_arena {
-    struct Region { void *va = nullptr; u64 mapped = 0, chunk = 0, n_mapped = 0; std::vector<hipMemGenericAllocationHandle_t> handles; float ms = 0.f; };
+    struct Region { void *va = nullptr; u64 mapped = 0, chunk = 0, n_mapped = 0; std::vector<hipMemGenericAllocationHandle_t> handles; float ms = 0.f;
+                    bool plain = false; /* a hipMalloc allocation (image arena) instead of stitched physical chunks */ };
     int device = 0;
     u64 region_bytes = 0;
     std::vector<Region> kept;          // fastest first
@@ -1168,6 +1169,7 @@ struct h2r_arena {
 
 namespace {
 void arena_free_region(h2r_arena::Region &r) {
+    if (r.plain) { if (r.va) (void)hipFree(r.va); r.va = nullptr; return; }
     // chunk k is mapped at va + k * chunk for k < n_mapped (a candidate that failed half-way has fewer than handles.size())
     for (u64 k = 0; r.va && k < r.n_mapped; ++k) (void)hipMemUnmap(static_cast<u8 *>(r.va) + k * r.chunk, r.chunk);
     for (auto h : r.handles) (void)hipMemRelease(h);
@@ -1195,7 +1197,7 @@ __global__ __launch_bounds__(256) void arena_fill_kernel(u8 *p, u64 bytes) {
 }
 using ArenaMeasure = std::function<int32_t(void *va, hipStream_t st, hipEvent_t ea, hipEvent_t eb, float *ms)>;
 int32_t arena_build(const h2r_ctx *ctx, u64 region_bytes, uint32_t regions, uint32_t candidates, uint64_t max_look_bytes, hipStream_t st,
-                    const ArenaMeasure &measure, h2r_arena **out);
+                    const ArenaMeasure &measure, bool plain, h2r_arena **out);
 }  // namespace
 
 int32_t h2r_arena_create_ex(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t first_record_off, uint32_t records_per_elem,
@@ -1240,7 +1242,7 @@ int32_t h2r_arena_create_ex(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t f
         *ms_out = sum / 2.f;
         return H2R_OK;
     };
-    return arena_build(ctx, batch * elem_stride, regions, candidates, max_look_bytes, st, measure, out);
+    return arena_build(ctx, batch * elem_stride, regions, candidates, max_look_bytes, st, measure, false, out);
 } H2R_CATCH_STATUS
 
 // The same look for ANY large output the kernels stream into -- advice images, the lookup argument's A' / S' columns: where such a
@@ -1266,12 +1268,14 @@ int32_t h2r_image_arena_create(const h2r_ctx *ctx, uint64_t region_bytes, uint32
         *ms_out = sum / 2.f;
         return H2R_OK;
     };
-    return arena_build(ctx, region_bytes, regions, candidates, max_look_bytes, static_cast<hipStream_t>(stream), measure, out);
+    // (plain hipMalloc candidates: regions stitched from physical chunks with the virtual-memory API aborted inside the runtime now and then
+    //  under this look -- "Memobj map does not have ptr", tools/image_arena_probe.py -- and a streaming buffer has no use for the stitching)
+    return arena_build(ctx, region_bytes, regions, candidates, max_look_bytes, static_cast<hipStream_t>(stream), measure, true, out);
 } H2R_CATCH_STATUS
 
 namespace {
 int32_t arena_build(const h2r_ctx *ctx, u64 region_bytes, uint32_t regions, uint32_t candidates, uint64_t max_look_bytes, hipStream_t st,
-                    const ArenaMeasure &measure, h2r_arena **out) {
+                    const ArenaMeasure &measure, bool plain, h2r_arena **out) {
     hipMemAllocationProp prop = {};
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
@@ -1291,6 +1295,11 @@ int32_t arena_build(const h2r_ctx *ctx, u64 region_bytes, uint32_t regions, uint
     // one candidate: reserve, create, map, touch, measure
     auto make_candidate = [&](h2r_arena::Region &r) -> int32_t {
         r.mapped = n_chunks * chunk; r.chunk = chunk; r.n_mapped = 0;
+        if (plain) {
+            r.plain = true; r.mapped = region_bytes;
+            if (!hip_ok(hipMalloc(&r.va, region_bytes), "hipMalloc")) { r.va = nullptr; return H2R_E_HIP; }
+            return measure(r.va, st, ea, eb, &r.ms);   // (its first launch touches the pages)
+        }
         if (!hip_ok(hipMemAddressReserve(&r.va, r.mapped, 0, nullptr, 0), "hipMemAddressReserve")) { r.va = nullptr; return H2R_E_HIP; }
         for (u64 k = 0; k < n_chunks; ++k) {
             hipMemGenericAllocationHandle_t h;
@@ -1352,7 +1361,7 @@ int32_t arena_build(const h2r_ctx *ctx, u64 region_bytes, uint32_t regions, uint
             keep_best(regions, false);
         }
     }
-    if (rc == H2R_OK && region_bytes <= (12ull << 30) && candidates >= 4 && !max_look_bytes) {
+    if (rc == H2R_OK && region_bytes <= (12ull << 30) && candidates >= 4 && !max_look_bytes && !plain) {
         // No fast class among the candidates?  On a box whose memory has not been churned yet (about one in five) the first
         // ~60 GB handed out are ALL of the slow class -- as physically contiguous memory always is -- while regions mapped after
         // some allocate / free traffic, or behind a large allocation, do contain fast ones (tools/no_fast_box_probe.py,
