@@ -5,13 +5,13 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r05; rm -rf $O; mkdir -p $O; cd /tmp; e
 A="--steps 20 --warmup 3 --no-cpu-baseline --pmc-traffic off"
 for mode in "" "--columns --montgomery"; do
   tag=$( [ -z "$mode" ] && echo advice || echo advice_cm )
-  timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$tag -o r -- python $R/bench.py --advice $mode $A > $O/kt_$tag.log 2>&1
-  timeout 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_${tag}_w -o r -- python $R/bench.py --advice $mode --steps 4 --warmup 1 --no-cpu-baseline --pmc-traffic off --placement-candidates 0 > /dev/null 2>&1
-  timeout 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_${tag}_r -o r -- python $R/bench.py --advice $mode --steps 4 --warmup 1 --no-cpu-baseline --pmc-traffic off --placement-candidates 0 > /dev/null 2>&1
+  timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_$tag -o r -- python $R/bench.py --advice $mode $A > $O/kt_$tag.log 2>&1
+  timeout -s KILL 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_${tag}_w -o r -- python $R/bench.py --advice $mode --steps 4 --warmup 1 --no-cpu-baseline --pmc-traffic off --placement-candidates 0 > /dev/null 2>&1
+  timeout -s KILL 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_${tag}_r -o r -- python $R/bench.py --advice $mode --steps 4 --warmup 1 --no-cpu-baseline --pmc-traffic off --placement-candidates 0 > /dev/null 2>&1
 done
-timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_lookup -o r -- python $R/bench.py --lookup --steps 8 --warmup 2 --no-cpu-baseline --pmc-traffic off > $O/kt_lookup.log 2>&1
-timeout 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_lookup_w -o r -- python $R/bench.py --lookup --steps 4 --warmup 1 --no-cpu-baseline --pmc-traffic off --placement-candidates 0 > /dev/null 2>&1
-timeout 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_lookup_r -o r -- python $R/bench.py --lookup --steps 4 --warmup 1 --no-cpu-baseline --pmc-traffic off --placement-candidates 0 > /dev/null 2>&1
+timeout -s KILL 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_lookup -o r -- python $R/bench.py --lookup --steps 8 --warmup 2 --no-cpu-baseline --pmc-traffic off > $O/kt_lookup.log 2>&1
+timeout -s KILL 150 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_lookup_w -o r -- python $R/bench.py --lookup --steps 4 --warmup 1 --no-cpu-baseline --pmc-traffic off --placement-candidates 0 > /dev/null 2>&1
+timeout -s KILL 150 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_lookup_r -o r -- python $R/bench.py --lookup --steps 4 --warmup 1 --no-cpu-baseline --pmc-traffic off --placement-candidates 0 > /dev/null 2>&1
 cd $R
 python - <<PY > $O/pmc_traffic_r05.json
 import csv, glob, json, os
@@ -36,12 +36,12 @@ out["_units"] = "rocprofv3 --pmc, separate passes; KB per dispatch (calibration 
 print(json.dumps(out, indent=1))
 PY
 for t in advice advice_cm lookup; do f=$(ls $O/kt_$t/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_$t.csv; done
-timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default_driver_args.json 2> $O/bench_default.err
-timeout 200 python bench.py --advice --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_advice.json 2>/dev/null
-timeout 200 python bench.py --advice --columns --steps 20 --warmup 5 --no-cpu-baseline --pmc-traffic off > $O/bench_advice_columns.json 2>/dev/null
-timeout 200 python bench.py --advice --montgomery --steps 20 --warmup 5 --no-cpu-baseline --pmc-traffic off > $O/bench_advice_montgomery.json 2>/dev/null
-timeout 200 python bench.py --advice --columns --montgomery --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_advice_columns_montgomery.json 2>/dev/null
-timeout 200 python bench.py --lookup --steps 8 --warmup 2 > $O/bench_lookup.json 2>/dev/null
-timeout 200 python bench.py --lookup --steps 8 --warmup 2 --placement-candidates 0 --pmc-traffic off > $O/bench_lookup_plain_allocations.json 2>/dev/null
+timeout -s KILL 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_default_driver_args.json 2> $O/bench_default.err
+timeout -s KILL 200 python bench.py --advice --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_advice.json 2>/dev/null
+timeout -s KILL 200 python bench.py --advice --columns --steps 20 --warmup 5 --no-cpu-baseline --pmc-traffic off > $O/bench_advice_columns.json 2>/dev/null
+timeout -s KILL 200 python bench.py --advice --montgomery --steps 20 --warmup 5 --no-cpu-baseline --pmc-traffic off > $O/bench_advice_montgomery.json 2>/dev/null
+timeout -s KILL 200 python bench.py --advice --columns --montgomery --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_advice_columns_montgomery.json 2>/dev/null
+timeout -s KILL 200 python bench.py --lookup --steps 8 --warmup 2 > $O/bench_lookup.json 2>/dev/null
+timeout -s KILL 200 python bench.py --lookup --steps 8 --warmup 2 --placement-candidates 0 --pmc-traffic off > $O/bench_lookup_plain_allocations.json 2>/dev/null
 rm -rf $O/kt_* $O/pmc_*_w $O/pmc_*_r
 ls -la $O
