@@ -181,7 +181,13 @@ __device__ __forceinline__ void block_mul(const u32 *A, const u32 *Bpad, ChainLd
     constexpr bool HALF = (MODE != MUL_FULL) && (K >= 64);
     constexpr int CGA = HALF ? G::CGH : G::CG;           // active 64-column groups
     constexpr int SSA = NW / CGA;                         // step slices
+#ifdef H2R_ABL_HALF_FULL_PRODUCT
+    // Developer ablation (WRONG results, timing only): the FULL product's loop at half its length -- the ceiling of what a squaring computed
+    // from half its limb products (a_j a_{c-j} for j < c - j, doubled, plus the diagonal) could save (profiles/r05_chain_accounting.txt).
+    constexpr int SLA = (MODE == MUL_FULL) ? K / SSA / 2 : K / SSA;
+#else
     constexpr int SLA = K / SSA;                          // steps per slice
+#endif
     constexpr int CB = (HALF && MODE == MUL_HIGH) ? K - 2 : 0;   // first column of the window
     static_assert(NW % CGA == 0 && K % SSA == 0 && SSA <= Geo<K, NW>::SSMAX, "bad half-product geometry");
     H2R_STAMP(s);
