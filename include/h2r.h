@@ -188,6 +188,9 @@ void h2r_ctx_destroy(h2r_ctx *ctx);
  *                            advice_out + e * out_stride + c * col_stride + r * 32
  *                          col_stride = bytes between an element's column vectors (2^k * 32 for halo2's 2^k-row columns; multiple of
  *                          16); 0 = packed: the five columns of a call's image back to back (col_stride = rows of that image * 32).
+ *                          A col_stride that is a multiple of 128 bytes (any 2^k-row column) keeps every column on the 128-byte line
+ *                          grid: cells_kernel then writes whole lines (0.80 of the HBM peak); packed columns of a row count that is
+ *                          not a multiple of 4 start mid-line and write partial lines (0.57, profiles/r05_cells_representations.txt).
  *                          Both [element][column][row] (out_stride >= 4 col_stride + rows * 32) and [column][element][row]
  *                          (col_stride >= batch * out_stride) arrangements are accepted; a region that starts at row r0 of the
  *                          caller's columns is addressed by passing advice_out + r0 * 32.
