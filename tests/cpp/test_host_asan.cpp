@@ -122,6 +122,37 @@ static int one_shape(uint32_t w, uint32_t L, uint32_t field) {
     auto kinds = heap<uint8_t>(rows);
     REQUIRE(h2r_advice_row_kinds(ctx, kinds.get()) == H2R_OK);
     for (uint32_t i = 0; i < rows; ++i) { h2r_fixed_row fr; REQUIRE(h2r_advice_fixed_row(ctx, &cfg, kinds[i], &fr) == H2R_OK); }
+    {   // the layout table is public data: NULL outputs and hand-filled non-permutations are refused, not dereferenced / indexed
+        auto lay = heap<h2r_advice_layout>(1);
+        REQUIRE(h2r_advice_layout_default(lay.get()) == H2R_OK);
+        h2r_fixed_row fr;
+        REQUIRE(h2r_advice_fixed_row_ex(ctx, &cfg, lay.get(), kinds[0], &fr) == H2R_OK);
+        REQUIRE(h2r_advice_fixed_row_ex(ctx, &cfg, lay.get(), kinds[0], nullptr) == H2R_E_NULL);
+        REQUIRE(h2r_advice_fixed_row_ex(nullptr, &cfg, lay.get(), kinds[0], &fr) == H2R_E_NULL);
+        lay.get()->column_of[kinds[0]][1] = 9;
+        REQUIRE(h2r_advice_fixed_row_ex(ctx, &cfg, lay.get(), kinds[0], &fr) == H2R_E_SHAPE);
+        lay.get()->column_of[kinds[0]][1] = 0;   // a repeated column: not a permutation
+        REQUIRE(h2r_advice_fixed_row_ex(ctx, &cfg, lay.get(), kinds[0], &fr) == H2R_E_SHAPE);
+        // the representation of a ctx: struct_size guards the ABI, unknown flags and a stride without the columns flag are refused
+        REQUIRE(h2r_abi_version() == H2R_VERSION);
+        h2r_params hp{lo.limb_width, lo.limb_width * lo.num_limbs, H2R_FIELD_BN254_FR, -1};
+        h2r_ctx *c2 = nullptr;
+        h2r_advice_repr rp{(uint32_t)sizeof(h2r_advice_repr) - 4, 0, 0};
+        REQUIRE(h2r_ctx_create_ex(&hp, &rp, &c2) == H2R_E_UNSUPPORTED && !c2);
+        rp = h2r_advice_repr{(uint32_t)sizeof(h2r_advice_repr), H2R_ADVICE_MONTGOMERY, 4096};
+        REQUIRE(h2r_ctx_create_ex(&hp, &rp, &c2) == H2R_E_SHAPE && !c2);
+        rp = h2r_advice_repr{(uint32_t)sizeof(h2r_advice_repr), H2R_ADVICE_COLUMNS | H2R_ADVICE_MONTGOMERY, 1u << 20};
+        REQUIRE(h2r_ctx_create_ex(&hp, &rp, &c2) == H2R_OK && c2);
+        h2r_advice_repr got{};
+        REQUIRE(h2r_ctx_advice_repr(c2, &got) == H2R_OK && got.flags == rp.flags && got.col_stride == rp.col_stride);
+        uint64_t a5[4] = {5, 0, 0, 0}, m5[4], back[4];
+        REQUIRE(h2r_field_eval(c2, 6, a5, nullptr, m5) == H2R_OK && h2r_field_eval(c2, 7, m5, nullptr, back) == H2R_OK && back[0] == 5 && !back[1]);
+        REQUIRE(h2r_field_eval(c2, 9, a5, nullptr, back) == H2R_OK && !std::memcmp(back, m5, 32));
+        REQUIRE(h2r_advice_fixed_row(c2, &cfg, kinds[0], &fr) == H2R_OK);
+        REQUIRE(h2r_advice_check(c2, &cfg, nullptr, kinds.get(), rows, tcol.get(), rows * 160, 1, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0,
+                                 nullptr, nullptr, nullptr) == H2R_E_NULL);
+        h2r_ctx_destroy(c2);
+    }
     uint64_t x[4] = {5, 0, 0, 0}, y[4] = {7, 0, 0, 0}, z[4], zi[4], one[4];
     REQUIRE(h2r_field_eval(ctx, 2, x, y, z) == H2R_OK && z[0] == 35);
     REQUIRE(h2r_field_eval(ctx, 3, z, nullptr, zi) == H2R_OK && h2r_field_eval(ctx, 2, z, zi, one) == H2R_OK && one[0] == 1 && !one[1] && !one[2] && !one[3]);

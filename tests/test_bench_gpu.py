@@ -77,3 +77,35 @@ def test_bench_advice_line():
     assert line["roofline"]["algorithmic_bytes_per_launch"] == 256 * (2 + 19 * 3973) * 160
     assert line["value"] > 0 and 0.2 < line["roofline"]["frac"] < 1.0
     assert line["config"]["buffer_placement"]["candidates"] == 3
+
+
+def test_bench_advice_in_the_provers_representation():
+    """--advice --columns --montgomery: planar Montgomery-form columns; the line says so, and bench.py's own post-run checks ran (the timed
+    image against the image of the records in the same representation, and h2r_advice_check over every row of the last timed image)."""
+    line = _run(["--advice", "--columns", "--montgomery", "--batch", "128", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--pmc-traffic", "off",
+                 "--placement-candidates", "0"])
+    rp = line["config"]["representation"]
+    assert rp["columns"] and rp["montgomery"] and rp["col_stride"] % 4096 == 0 and rp["col_stride"] >= (2 + 1532 + 19 * 3973) * 32
+    assert "Montgomery" in line["roofline"]["kernel"] and line["value"] > 0
+    assert "0 violations" in line["config"]["post_run_audit"]
+
+
+def test_bench_lookup_line():
+    line = _run(["--lookup", "--batch", "32", "--steps", "3", "--warmup", "1", "--pmc-traffic", "off", "--placement-candidates", "3"])
+    assert line["unit"] == "GB/s" and line["roofline"]["kernel"] == "lookup_fill_kernel" and 0.1 < line["roofline"]["frac"] < 1.0
+    assert line["roofline"]["algorithmic_bytes_per_launch"] == 2 * 32 * 5 * ((1 << 17) - 6) * 32
+    assert line["config"]["buffer_placement"]["candidates"] >= 3 and 0 < line["whole_call_hbm_frac"] <= line["roofline"]["frac"] + 1e-6
+
+
+def test_bench_default_line_carries_the_sub_runs():
+    """What the driver runs (`--gpus 1 --steps K --warmup W`, nothing else) also reports, from fresh processes: the headline as allocated,
+    the advice image in both representations (each audited by h2r_advice_check), BASELINE configs 4 and 5, the lookup argument."""
+    line = _run(["--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--pmc-traffic", "off"], timeout=900)
+    for key in ("plain_allocations", "advice", "advice_columns_montgomery", "other_configs", "lookup", "scale_anchor"):
+        assert key in line, key
+    assert line["plain_allocations"]["value"] > 0 and 0.2 < line["plain_allocations"]["frac"] < 1.0
+    for key in ("advice", "advice_columns_montgomery"):
+        assert line[key]["error"] is None and line[key]["value"] > 0 and "0 violations" in line[key]["audit"], line[key]
+    assert line["other_configs"]["C4"]["value"] > 0 and line["other_configs"]["C5"]["value"] > 0
+    assert line["lookup"]["error"] is None and line["lookup"]["whole_call_GBps"] > 0
+    assert line["config"]["pipeline_form"]["record_form"] in ("two-queue", "one-launch step")

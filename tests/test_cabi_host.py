@@ -42,6 +42,16 @@ def test_library_exports_every_declared_symbol():
     assert exported == declared, sorted(set(exported) ^ set(declared))
 
 
+def test_integration_md_binds_exactly_the_header():
+    """The Rust `extern "C"` block of INTEGRATION.md (what a maintainer pastes into the reference crate) lists exactly the header's
+    prototypes -- the same set the library exports."""
+    hdr = open(os.path.join(ROOT, "include", "h2r.h")).read()
+    declared = sorted(set(re.findall(r"\b(h2r_[a-z0-9_]+)\s*\(", hdr)))
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    bound = sorted(set(re.findall(r"pub fn (h2r_[a-z0-9_]+)\(", md)))
+    assert bound == declared, sorted(set(bound) ^ set(declared))
+
+
 def test_ctx_create_status_codes():
     ctx = ctypes.c_void_p()
     for (w, bits, field, want) in [(64, 2048 + 32, 0, _lib.H2R_E_SHAPE),      # bits_len % limb_width (chip.rs:1175)
