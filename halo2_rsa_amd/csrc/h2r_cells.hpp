@@ -681,10 +681,19 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                         const u32 gc = nrc == 3 ? (G * 0xAAABu) >> 17 : (nrc == 2 ? G >> 1 : G / nrc), gj = G - gc * nrc, grr = gc * per_col + 18 + gj;   // (G < 2^15)
                         const bool task = grr < rr0 + 64 && gc < C - 1;
                         if (__ballot(task) == 0) break;
+                        // the cell's value, straight from the carry (main_gate.decompose: four terms per row, the LAST row reversed and
+                        // zero-padded; column e = the carry with the terms of the rows above cleared)
                         const U192 co = shr_limb(rdp(pSUM, task ? gc : 0u));
-                        u64 q0, q1, q2, q3, rl, rh;
-                        range_vals(co.w[0], co.w[1], a.carry_nsub, a.carry_sub_bits, gj, q0, q1, q2, q3, rl, rh);
-                        const u64 vlo = cellq == 0 ? q0 : cellq == 1 ? q1 : cellq == 2 ? q2 : cellq == 3 ? q3 : rl, vhi = cellq == 4 ? rh : 0;
+                        const u32 nsub = a.carry_nsub, sb = a.carry_sub_bits, lastr = nrc - 1, n_last = nsub - 4 * lastr;
+                        const bool is_last = gj == lastr;
+                        const u32 term = is_last ? nsub - 1 - cellq : 4 * gj + cellq;          // (cellq < 4)
+                        const bool has_term = cellq < 4 && (!is_last || cellq < n_last);
+                        const u32 sh = term * sb;                                               // < 128
+                        const u64 shifted = sh >= 64 ? co.w[1] >> (sh - 64) : (sh ? (co.w[0] >> sh) | (co.w[1] << (64 - sh)) : co.w[0]);
+                        const u32 clr = 4 * gj * sb;                                            // bits composed by the rows above
+                        const u64 rl = clr >= 64 ? 0 : (clr ? (co.w[0] >> clr) << clr : co.w[0]);
+                        const u64 rh = clr >= 64 ? (clr >= 128 ? 0 : (co.w[1] >> (clr - 64)) << (clr - 64)) : co.w[1];
+                        const u64 vlo = cellq == 4 ? rl : (has_term ? shifted & ((1ull << sb) - 1) : 0), vhi = cellq == 4 ? rh : 0;
                         uint4 e0, e1;
                         cell_k(std::integral_constant<int, LW == 64 ? 90 : 60>{}, vlo, vhi, e0, e1);   // (a carry: 70 / 40 bits)
                         if (task) { uint4 *dst2 = stage + (u64)(grr - rr0) * NP + 2 * cellq; dst2[0] = e0; dst2[1] = e1; }
