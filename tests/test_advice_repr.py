@@ -349,3 +349,72 @@ def test_lookup_columns_in_montgomery_form(H):
         uniq, inv = np.unique(plain, axis=0, return_inverse=True)
         conv = np.stack([np.frombuffer((int.from_bytes(u.tobytes(), "little") * R256 % P).to_bytes(32, "little"), dtype=np.uint8) for u in uniq])
         assert np.array_equal(conv[inv.reshape(-1)], mont), "A'" if col == 0 else "S'"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", MODES)
+def test_fresh_ops_and_the_verifier_region_in_every_representation(H, mode):
+    """The stand-alone Fresh-integer ops (row programs with is_zero inverse witnesses: full-size field elements) and the whole
+    RSASignatureVerifier region -- hashed-message limb rows in front of the verify element, TWO calls writing ONE image, which needs
+    columns of a fixed stride -- in the consumer's representation."""
+    import pyref as R
+    P = R.FIELD_MODULI["bn254_fr"]
+    rng = random.Random(5150)
+    bits, batch = 1024, 4
+    N = [rand_modulus(rng, bits) for _ in range(batch)]
+    A = [rng.randrange(n) for n in N]
+    B = [rng.randrange(n) for n in N]
+    B[1] = A[1]                                  # an equal pair: is_equal's d = 0 branch next to the d != 0 ones
+    k_rows = 1 << 13
+
+    def fresh(kw):
+        chip = H.BigIntChip(64, bits, **kw)
+        a, b, n = chip.assign_integer(A), chip.assign_integer(B), chip.assign_integer(N)
+        out = {}
+        for name, res in (("add", chip.add(a, b)), ("sub_mod", chip.sub_mod(a, b, n)), ("is_equal_fresh", chip.is_equal_fresh(a, b)),
+                          ("is_less_than", chip.is_less_than(a, b)), ("is_zero", chip.is_zero(a))):
+            out[name] = res.emit_advice().cpu().numpy()
+        return out
+
+    want, got = fresh({}), fresh(mode)
+    for name in want:
+        rows = want[name].shape[1] // 160
+        exp = _expect(want[name], rows, P, mode)
+        assert _first_diff(got[name], exp) is None, (mode, name, _first_diff(got[name], exp))
+
+    # the verifier's region from message bytes
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "halo2_rsa_golden.json")) as f:
+        kats = json.load(f)["rsa_kats"]
+    ns, sigs = [int(k["n"]) for k in kats], [int(k["sig"]) for k in kats]
+
+    def region(kw):
+        rsa = H.RSAChip(2048, 5, **kw)
+        ver = H.RSASignatureVerifier(rsa)
+        pk = H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Fix(65537))
+        res = ver.verify_pkcs1v15_signature(pk, b"hello world", H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64)))
+        return res.emit_advice(with_hashed_msg=True).cpu().numpy(), res.is_valid.cpu().tolist()
+
+    w_img, w_valid = region({})
+    rows = w_img.shape[1] // 160
+    kw = dict(mode)
+    if kw.get("columns"):
+        kw["col_stride"] = ((rows * 32 + 4095) // 4096) * 4096
+    g_img, g_valid = region(kw)
+    assert w_valid == g_valid == [1, 1, 0]
+    exp = _expect(w_img, rows, P, mode, col_stride=kw.get("col_stride", 0))
+    if kw.get("columns"):           # (the columns are longer than the region: compare what the image covers)
+        cs = kw["col_stride"]
+        g5 = g_img.reshape(3, 5, cs)[:, :, :rows * 32]
+        e5 = exp.reshape(3, -1)
+        e5 = np.stack([np.stack([e5[e, c * cs:c * cs + rows * 32] for c in range(5)]) for e in range(3)])
+        assert np.array_equal(g5, e5)
+    else:
+        assert _first_diff(g_img, exp) is None, (mode, "verifier region", _first_diff(g_img, exp))
+    # without a fixed stride two calls cannot share packed columns: refused, not mis-written
+    if mode.get("columns"):
+        rsa = H.RSAChip(2048, 5, **mode)
+        res = H.RSASignatureVerifier(rsa).verify_pkcs1v15_signature(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Fix(65537)), b"hello world",
+                                                                    H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64)))
+        with pytest.raises(ValueError):
+            res.emit_advice(with_hashed_msg=True)
