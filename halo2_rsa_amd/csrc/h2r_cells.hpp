@@ -130,7 +130,7 @@ __host__ __device__ constexpr u32 cells_fast_src(u32 j, u32 k, bool last_col) {
 }
 
 // dynamic LDS of one wave (byte offsets): stage, operands, constants, column planes, flags, code tables
-struct CellsLds { u32 ops, kt, ce, ab, eqb, sum, amb, nq1, cout, cmod, mab, meqb, msum, opsr, mk, fl, src, fsrc, total; };
+struct CellsLds { u32 ops, kt, ce, ab, eqb, sum, amb, nq1, cout, cmod, mab, meqb, msum, opsr, icout, fl, src, fsrc, total; };
 __host__ __device__ inline CellsLds cells_lds_plan(u32 limb_width, u32 L, bool mont = false) {
     // 64-bit limbs: 32-byte entries AB, EQB, SUM, a_b, NQ1 and 16-byte entries carry, c.  32-bit limbs (every value but a_b's field
     // element is below 2^128): 16-byte entries AB, EQB, SUM, a 32-byte a_b; NQ1, the carry and c are cut from the SUM entry on the way.
@@ -143,12 +143,24 @@ __host__ __device__ inline CellsLds cells_lds_plan(u32 limb_width, u32 L, bool m
     p.ops = o; o += 5u * L * 8u;
     p.kt = o; o += CELLS_KT_WORDS * 8u;
     p.ce = o; o += CELLS_CONST_ENTRIES * 32u;
-    p.ab = o; o += n * es; p.eqb = o; o += n * es; p.sum = o; o += n * es;
-    p.amb = o; o += n * 32u; p.nq1 = o; o += (w64 || mont) ? n * 32u : 0u;
-    p.cout = o; o += mont ? n * 32u : (w64 ? n * 16u : 0u); p.cmod = o; o += mont ? n * 32u : (w64 ? n * 16u : 0u);
-    p.mab = o; o += mont ? n * 32u : 0u; p.meqb = o; o += mont ? n * 32u : 0u; p.msum = o; o += mont ? n * 32u : 0u;
-    p.opsr = o; o += mont ? (4u * L + 2u) * 32u : 0u;   // (+ a zero entry and the slot of the previous chunk's last accumulator cell)
-    p.mk = o; o += mont ? (u32)((sizeof(MontK) + 15) & ~15ull) : 0u;
+    if (mont) {
+        // Montgomery cells: what bounds the kernel is how many waves a CU holds (it is VALU-issue bound and a wave alone on its SIMD
+        // issues ~6 cycles per instruction: build-only 1.85 -> 1.57 -> 1.39 ms with 4 -> 5 -> 6 waves per CU), i.e. the LDS per wave:
+        // <= 32,000 bytes for five.  Seven planes of 32-byte cells; everything that is dead once the column phase starts LIVES IN THEM:
+        // the un-carried totals of mul(a, b) / mul(q, n) (integers, 32-byte entries) in the AB / EQB planes' own slots -- lane c reads
+        // column c's integers and then writes column c's cells --, the operand cells of the mul rows (4 L + 2 entries = two planes
+        // exactly) in the NQ1 + COUT planes.  The integer SUM plane shrinks to the carries (16 bytes), which the range rows need.
+        p.mab = o; o += n * 32u; p.meqb = o; o += n * 32u; p.amb = o; o += n * 32u; p.msum = o; o += n * 32u;
+        p.nq1 = o; o += n * 32u; p.cout = o; o += n * 32u; p.cmod = o; o += n * 32u;
+        p.ab = p.mab; p.eqb = p.meqb; p.sum = p.msum;   // (p.sum: no integer SUM plane -- unused)
+        p.opsr = p.nq1;
+        p.icout = o; o += n * 16u;
+    } else {
+        p.ab = o; o += n * es; p.eqb = o; o += n * es; p.sum = o; o += n * es;
+        p.amb = o; o += n * 32u; p.nq1 = o; o += w64 ? n * 32u : 0u;
+        p.cout = o; o += w64 ? n * 16u : 0u; p.cmod = o; o += w64 ? n * 16u : 0u;
+        p.mab = p.meqb = p.msum = p.opsr = p.icout = o;
+    }
     p.fl = o; o += 2u * L * 4u;
     p.src = o; o += CELLS_SRC_WORDS * 4u;
     p.fsrc = o; o += 2u * CELLS_SRC_WORDS * 4u;
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
     using limb_t = typename LimbT<LW>::type;
     constexpr bool FAST = !(ABL & 64);
     constexpr int WW = LW == 64 ? 3 : 2;     // 64-bit words of a wide value
-    constexpr int ESW = LW == 64 ? 4 : 2;    // 64-bit words of a plane entry
+    constexpr int ESW = (LW == 64 || MONT) ? 4 : 2;    // 64-bit words of a plane entry
     constexpr int NWD = LW == 64 ? 5 : 3;    // dwords of a running column sum (133 / 71 bits)
     constexpr int WBITS = LW == 64 ? 150 : 90;   // MONT: bound of every wide value's magnitude (five / three 30-bit digits)
     constexpr u64 LMASK = LW == 64 ? ~0ull : 0xffffffffull;
@@ -283,9 +295,9 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
     // MONT: the multipliers this shape needs, in registers for the whole kernel (read back from an LDS copy so that they ARE vector
     // registers: as kernel arguments they are SGPRs, the kernel has none to spare, and the spills sat in the middle of every product)
     constexpr int DA = (WBITS + 29) / 30, DC = LW == 64 ? 3 : 2;   // 30-bit digits of a wide value / of a limb, a carry
-    struct { u32 p30[9], p32[8], n0, bA[9], bC[9], b1[9]; } mv;
+    struct { u32 p30[9], p32[8], n0, n0_32, bA[9], bC[9], b1[9]; } mv;
     if constexpr (MONT) {
-        u32 *lmk = reinterpret_cast<u32 *>(smem + lp.mk);
+        u32 *lmk = reinterpret_cast<u32 *>(stage);   // (the stage is free until the first chunk)
         const u32 *gmk = reinterpret_cast<const u32 *>(a.mk);
         for (u32 k = lane; k < sizeof(MontK) / 4; k += 64) lmk[k] = gmk[k];
         wave_sync();
@@ -294,7 +306,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
         for (int j = 0; j < 9; ++j) { mv.p30[j] = m->p30[j]; mv.bA[j] = m->bk30[DA][j]; mv.bC[j] = m->bk30[DC][j]; mv.b1[j] = m->bk30[1][j]; }
 #pragma unroll
         for (int j = 0; j < 8; ++j) mv.p32[j] = m->p[j];
-        mv.n0 = m->n0inv30;
+        mv.n0 = m->n0inv30; mv.n0_32 = m->n0inv;
     }
     const bool planar = a.dst.planar();
     u8 *img = a.dst.elem(elem);
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
     u8 *out = img + ((u64)a.pre_rows + (u64)t * a.rows + (u64)((t + 1) >> 1) * a.sel_rows) * a.dst.row_pitch;
     if (t == 0 && lane < a.pre_rows * 5) {   // pow_mod_fixed_exp's acc = assign_constant(1, L): [1, 0, 0, 0, 0] then [0, ...]
         uint4 *pr = reinterpret_cast<uint4 *>(img + (u64)(lane / 5) * a.dst.row_pitch + (u64)(lane % 5) * a.dst.col_pitch);
-        if (MONT && lane == 0) { const u32 *one = reinterpret_cast<const MontK *>(smem + lp.mk)->bk[0]; pr[0] = make_uint4(one[0], one[1], one[2], one[3]); pr[1] = make_uint4(one[4], one[5], one[6], one[7]); }
+        if (MONT && lane == 0) { const u32 *one = reinterpret_cast<const MontK *>(stage)->bk[0]; pr[0] = make_uint4(one[0], one[1], one[2], one[3]); pr[1] = make_uint4(one[4], one[5], one[6], one[7]); }
         else { pr[0] = make_uint4(lane == 0 ? 1u : 0u, 0, 0, 0); pr[1] = make_uint4(0, 0, 0, 0); }
     }
     const U192 Z = U192::make(0, 0, 0);
@@ -364,6 +376,48 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
             o0 = make_uint4(tt[0], tt[1], tt[2], tt[3]); o1 = make_uint4(tt[4], tt[5], tt[6], tt[7]);
         } else {
             o0 = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32)); o1 = make_uint4(0, 0, 0, 0);
+        }
+    };
+    // ---- MONT: cells of the planes as operands (the integer planes are gone once the column phase has run) ----
+    // x - y mod p on cells
+    auto cell_sub = [&](const uint4 &x0, const uint4 &x1, const uint4 &y0, const uint4 &y1, uint4 &o0, uint4 &o1) {
+        const u32 x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w}, y[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+        u32 d[8], e[8]; u64 br = 0, cy = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const u64 t_ = (u64)x[j] - y[j] - br; d[j] = (u32)t_; br = (t_ >> 32) & 1u; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const u64 t_ = (u64)d[j] + mv.p32[j] + cy; e[j] = (u32)t_; cy = t_ >> 32; }
+        o0 = br ? make_uint4(e[0], e[1], e[2], e[3]) : make_uint4(d[0], d[1], d[2], d[3]);
+        o1 = br ? make_uint4(e[4], e[5], e[6], e[7]) : make_uint4(d[4], d[5], d[6], d[7]);
+    };
+    // the integer a cell stands for (x R -> x: one Montgomery product by 1).  Only a mul_mod whose q, r are NOT its quotient and remainder
+    // comes here (never produced by this library): its column rows are rebuilt from the integers, is_zero's inverses and all.
+    auto cell_int = [&](const uint4 *cp, bool is_signed) -> U192 {
+        const uint4 c0 = cp[0], c1 = cp[1];
+        const u32 x[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, one[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+        u32 tt[8];
+        mont_short<8>(x, one, mv.p32, mv.n0_32, tt);
+        if (is_signed && (tt[6] | tt[7])) {   // p - |x|: the negative difference
+            u64 br = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const u64 t_ = (u64)tt[j] - mv.p32[j] - br; tt[j] = (u32)t_; br = (t_ >> 32) & 1u; }
+        }
+        return U192::make(((u64)tt[1] << 32) | tt[0], ((u64)tt[3] << 32) | tt[2], ((u64)tt[5] << 32) | tt[4]);
+    };
+    // the three cells of row k (0..22, the carry's range rows taken out) of column c of a VALID mul_mod: copies of plane entries
+    auto col_row_copy = [&](u32 c, u32 k, uint4 (&o)[6]) {
+        const bool lastc = c == C - 1;
+        const u32 *codes = f_src + (lastc ? CELLS_SRC_WORDS : 0u) + k * 3;
+        const u32 kc = c < 2 ? c : 2, kcp = c < 3 ? c - 1 : 2;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const u32 code = codes[q];
+            const bool m1 = (code >> 17) & 1u, byk = (code >> 18) & 1u;
+            const u32 idx = byk ? (m1 ? kcp : kc) : (m1 ? c - 1 : c);
+            const bool zero = m1 && c == 0;
+            const u32 addr = zero ? lp.ce : ((code & 0x1fffu) + idx * ((code >> 13) & 15u)) << 4;
+            const u32 hi_off = (!zero && ((code >> 19) & 1u)) ? addr + 16 : lp.ce;
+            o[2 * q] = *reinterpret_cast<const uint4 *>(smem + addr); o[2 * q + 1] = *reinterpret_cast<const uint4 *>(smem + hi_off);
         }
     };
     // row rr of RangeChip::assign of the value v (nsub sub-limbs of sub_bits bits, the last one possibly shorter): four sub-limbs in
@@ -457,8 +511,9 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 const U192 carry_in = dhp + lim((u64)shp + (f ? 1u : 0u));
                 const U192 amb = rdp(pAB, c) - rdp(pEQB, c);
                 const U192 sum = amb + Wm + carry_in;                          // :860-861
-                wrp(pSUM, c, sum);
                 const U192 cout = shr_limb(sum);
+                if constexpr (MONT) reinterpret_cast<uint4 *>(smem + lp.icout)[c] = make_uint4((u32)cout.w[0], (u32)(cout.w[0] >> 32), (u32)cout.w[1], (u32)(cout.w[1] >> 32));
+                else wrp(pSUM, c, sum);
                 const u32 kc = c < 2 ? c : 2;
                 f1 = (sum.w[0] & LMASK) == kt[kc * 10 + 5];                      // cs_acc_eq  :873
                 if (c == C - 1) f2 = cout.w[0] == kt[kc * 10 + 3] && cout.w[1] == kt[kc * 10 + 4];   // final_carry_eq  :890
@@ -683,7 +738,8 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                         if (__ballot(task) == 0) break;
                         // the cell's value, straight from the carry (main_gate.decompose: four terms per row, the LAST row reversed and
                         // zero-padded; column e = the carry with the terms of the rows above cleared)
-                        const U192 co = shr_limb(rdp(pSUM, task ? gc : 0u));
+                        const uint4 ci = reinterpret_cast<const uint4 *>(smem + lp.icout)[task ? gc : 0u];
+                        const U192 co = U192::make(((u64)ci.y << 32) | ci.x, ((u64)ci.w << 32) | ci.z, 0);
                         const u32 nsub = a.carry_nsub, sb = a.carry_sub_bits, lastr = nrc - 1, n_last = nsub - 4 * lastr;
                         const bool is_last = gj == lastr;
                         const u32 term = is_last ? nsub - 1 - cellq : 4 * gj + cellq;          // (cellq < 4)
@@ -708,6 +764,8 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
         if (!valid) { id.kind = ROWK_NOP; id.sect = 9; }
         U192 v0 = Z, v1 = Z, v2 = Z, v3 = Z, v4 = Z;
         bool sg0 = false, sg1 = false, sg2 = false, need_inv = false;
+        uint4 cp[6] = {Z4, Z4, Z4, Z4, Z4, Z4};                        // MONT: cells taken from the planes as they are
+        bool row_copied = false, row_eqb = false;
         // ---- mul(a, b), mul(q, n): one limb product per lane, the column's running sums by a segmented scan ----
         if (!(ABL & 16) && __ballot(id.sect == 1) != 0) {
             const bool is_ma = id.sect == 1 && id.kind == ROWK_MUL_ADD;
@@ -763,32 +821,40 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
             range_vals(v, 0, 8, LW / 8, id.j, c0, c1, c2, c3, rl, rh);
             v0 = lim(c0); v1 = lim(c1); v2 = lim(c2); v3 = lim(c3); v4 = U192::make(rl, rh, 0);
         } else if (id.sect == 2) {                                   // eq_b[i] = qn[i] + r[i]  :617
-            const U192 e = rdp(pEQB, id.i);
-            v1 = lim(sr[id.i]); v0 = e - v1; v2 = e;
+            if constexpr (MONT) { v1 = lim(sr[id.i]); row_eqb = true; const uint4 *e = reinterpret_cast<const uint4 *>(smem + lp.meqb) + 2 * id.i; cp[4] = e[0]; cp[5] = e[1]; }
+            else { const U192 e = rdp(pEQB, id.i); v1 = lim(sr[id.i]); v0 = e - v1; v2 = e; }
         } else if (id.sect == 3) {                                   // :851-856
             if (id.i == 0) v0 = Bw; else if (id.i == 3) { v0 = lim(1); v1 = v0; v2 = v0; }
         } else if (!(ABL & 8) && id.sect == 4) {
             const u32 c = id.i;
             if (id.kind >= ROWK_RANGE_CARRY) {                       // RangeChip::assign(carry, ...)  :880-885
-                const U192 cout = shr_limb(rdp(pSUM, c));
+                U192 cout;
+                if constexpr (MONT) { const uint4 ci = reinterpret_cast<const uint4 *>(smem + lp.icout)[c]; cout = U192::make(((u64)ci.y << 32) | ci.x, ((u64)ci.w << 32) | ci.z, 0); }
+                else cout = shr_limb(rdp(pSUM, c));
                 u64 c0, c1, c2, c3, rl, rh;
                 range_vals(cout.w[0], cout.w[1], a.carry_nsub, a.carry_sub_bits, id.kind - ROWK_RANGE_CARRY, c0, c1, c2, c3, rl, rh);
                 v0 = lim(c0); v1 = lim(c1); v2 = lim(c2); v3 = lim(c3); v4 = U192::make(rl, rh, 0);
+            } else if (MONT && item_ok) {                            // a valid mul_mod: the row's cells are copies, as in the fast path
+                if constexpr (MONT) { col_row_copy(c, id.j, cp); row_copied = true; }
             } else {
                 const u32 j = id.j;
+                // (MONT: an inconsistent mul_mod -- the planes hold cells, the integers come back out of them)
+                auto gAB = [&](u32 ix) -> U192 { if constexpr (MONT) return cell_int(reinterpret_cast<const uint4 *>(smem + lp.mab) + 2 * ix, false); else return rdp(pAB, ix); };
+                auto gEQB = [&](u32 ix) -> U192 { if constexpr (MONT) return cell_int(reinterpret_cast<const uint4 *>(smem + lp.meqb) + 2 * ix, false); else return rdp(pEQB, ix); };
+                auto gSUM = [&](u32 ix) -> U192 { if constexpr (MONT) return cell_int(reinterpret_cast<const uint4 *>(smem + lp.msum) + 2 * ix, false); else return rdp(pSUM, ix); };
                 auto fetch = [&](u32 code, bool &sg) -> U192 {
                     if (c == C - 1 && (code & (1u << 13))) code = cells_src(CS_KT, 0, 0, 0, 3, 2);   // the last column: acc_extra
                     const u32 base = code & 7u, m1 = (code >> 9) & 1u, xf = (code >> 10) & 3u;
                     sg = ((code >> 12) & 1u) != 0;
                     if (base == 0 || (m1 && c == 0)) return Z;
                     const u32 idx = c - m1;
-                    if (base == CS_AMB) return rdp(pAB, idx) - rdp(pEQB, idx);   // a_b  :859 (two's complement)
+                    if (base == CS_AMB) return gAB(idx) - gEQB(idx);   // a_b  :859 (two's complement)
                     U192 val;
                     if (base == CS_KT) {
                         const u64 *ptr = kt + (idx < 2 ? idx : 2) * 10 + ((code >> 3) & 15u);
                         const u32 nw = ((code >> 7) & 3u) + 1;
                         val = U192::make(ptr[0], nw > 1 ? ptr[1] : 0, nw > 2 ? ptr[2] : 0);
-                    } else val = rdp(base == CS_AB ? pAB : base == CS_EQB ? pEQB : pSUM, idx);
+                    } else val = base == CS_AB ? gAB(idx) : base == CS_EQB ? gEQB(idx) : gSUM(idx);
                     if (xf == 0) return val;
                     if (xf == 1) return shr_limb(val);
                     if (xf == 2) return lim(val.w[0] & LMASK);
@@ -827,6 +893,16 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                     else cell(p5, v, sg);
                 };
                 put5(srow, v0, sg0); put5(srow + 2, v1, sg1); put5(srow + 4, v2, sg2); put5(srow + 6, v3, false); put5(srow + 8, v4, false);
+                if (row_copied) {
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) srow[q] = cp[q];
+                }
+                if (row_eqb) {   // [qn_i, r_i, eq_b_i]: eq_b_i is the plane's cell, r_i was converted above, qn_i = eq_b_i - r_i in the field
+                    const uint4 r0_ = srow[2], r1_ = srow[3];
+                    uint4 q0_, q1_;
+                    cell_sub(cp[4], cp[5], r0_, r1_, q0_, q1_);
+                    srow[0] = q0_; srow[1] = q1_; srow[4] = cp[4]; srow[5] = cp[5];
+                }
             }
         }
         if (valid) {
@@ -837,7 +913,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 field4(v0, true, xe.v);
                 const FieldConsts fc = *reinterpret_cast<const FieldConsts *>(a.ktab + CELLS_KT_FC);
                 Fe iv = fe_inv_fast(xe, fc);
-                if constexpr (MONT) iv = fe_to_mont_k(iv, *reinterpret_cast<const MontK *>(smem + lp.mk));
+                if constexpr (MONT) iv = fe_to_mont_k(iv, *a.mk);
                 srow[2] = make_uint4((u32)iv.v[0], (u32)(iv.v[0] >> 32), (u32)iv.v[1], (u32)(iv.v[1] >> 32));
                 srow[3] = make_uint4((u32)iv.v[2], (u32)(iv.v[2] >> 32), (u32)iv.v[3], (u32)(iv.v[3] >> 32));
             }

@@ -186,6 +186,44 @@ def test_mul_mod_and_pow_images_in_every_representation(H, w, L, field):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("w,L,field", [(64, 32, "bn254_fr"), (32, 16, "pasta_fq"), (64, 12, "bn254_fq")])
+def test_inconsistent_mul_mod_in_every_representation(H, w, L, field):
+    """Records whose q, r are NOT the quotient and remainder (R plane bumped by one; a second element with its Q plane bumped): the
+    direct kernel leaves its fast rows for the general path (d = x - y != 0, the inverse witness, eq_bit 0, the carries of a
+    non-zero difference); in a Montgomery ctx that path works on cells, so its image must still be the canonical ctx's image of the
+    SAME records, transposed and multiplied by R (the canonical one is checked against the gate in tests/test_cells_direct.py)."""
+    import pyref as R
+    from halo2_rsa_amd import _lib
+    from halo2_rsa_amd._lib import lib
+    P = R.FIELD_MODULI[field]
+    rng = random.Random(5 * w + L)
+    N = [rand_modulus(rng, w * L) for _ in range(4)]
+    A = [rng.randrange(n) for n in N]
+    B = [rng.randrange(n) for n in N]
+    P_IDX = {nm: k for k, nm in enumerate(_lib.PLANES)}
+
+    def run(kw):
+        chip = H.BigIntChip(w, w * L, field=field, **kw)
+        res = chip.mul_mod(chip.assign_integer(A), chip.assign_integer(B), chip.assign_integer(N))
+        torch.cuda.synchronize()
+        lo = chip.layout
+        for elem, plane, limb in ((1, "R", 0), (3, "Q", 1)):
+            off = elem * lo.record_stride + lo.plane_off[P_IDX[plane]] + limb * lo.limb_bytes
+            v = int.from_bytes(res.trace.buf[off:off + lo.limb_bytes].cpu().numpy().tobytes(), "little")
+            v = v + 1 if v + 1 < (1 << w) else v - 1
+            res.trace.buf[off:off + lo.limb_bytes] = torch.from_numpy(np.frombuffer(v.to_bytes(lo.limb_bytes, "little"), dtype=np.uint8).copy()).cuda()
+        rows = int(lib().h2r_advice_rows(chip._ctx))
+        return rows, res.emit_advice(direct=True).cpu().numpy()
+
+    rows, want = run({})
+    for mode in MODES:
+        r2, got = run(mode)
+        assert r2 == rows
+        exp = _expect(want, rows, P, mode)
+        assert _first_diff(got, exp) is None, (mode, _first_diff(got, exp))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("arrangement", ["element_major", "column_major"])
 def test_columns_of_a_fixed_stride_and_guard_bytes(H, arrangement):
     """halo2's columns have 2^k rows: col_stride = 2^k * 32, the region starts at some row r0 of the caller's columns.  Both

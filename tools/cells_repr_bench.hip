@@ -105,7 +105,8 @@ int main(int argc, char **argv) {
     auto line = [&](const char *nm, float ms) { std::printf("  %-34s %.3f ms  %.2f TB/s\n", nm, ms, gb / ms); std::fflush(stdout); };
     const int R = 5;
 
-    const u32 l4 = (160u * 1024 / 4 - 512) & ~15u, lds = l4 > base ? l4 : base;
+    const u32 wpc = argc > 6 ? (u32)std::atoi(argv[6]) : 4;   // waves per CU (by the LDS request)
+    const u32 l4 = argc > 7 ? (u32)std::atoi(argv[7]) : (mont && argc <= 6 ? 0u : (160u * 1024 / wpc - 512) & ~15u), lds = l4 > base ? l4 : base;   // argv[7]: the raw LDS request; Montgomery: whatever fits
     std::printf("representation: %s%s, lds request %u\n", mont ? "montgomery " : "canonical ", planar ? "planar" : "row-major", lds);
 #define RUN(ABL_) (w == 64 ? (mont ? run<64, ABL_, true>(ca, lds, R) : run<64, ABL_, false>(ca, lds, R)) : (mont ? run<32, ABL_, true>(ca, lds, R) : run<32, ABL_, false>(ca, lds, R)))
     {   // per-chunk cycle stamps of one wave (item in the middle of the grid), next to the full grid and alone
