@@ -141,28 +141,31 @@ __host__ __device__ inline CellsLds cells_lds_plan(u32 limb_width, u32 L, bool m
     const u32 es = w64 ? 32u : 16u, n = 2u * L + 1u;
     CellsLds p; u32 o = 64u * ADVICE_ROW_BYTES;
     p.ops = o; o += 5u * L * 8u;
-    p.kt = o; o += CELLS_KT_WORDS * 8u;
+    p.kt = o; o += mont ? 0u : CELLS_KT_WORDS * 8u;    // (Montgomery: the table is read from global memory where it is needed)
     p.ce = o; o += CELLS_CONST_ENTRIES * 32u;
     if (mont) {
         // Montgomery cells: what bounds the kernel is how many waves a CU holds (it is VALU-issue bound and a wave alone on its SIMD
         // issues ~6 cycles per instruction: build-only 1.85 -> 1.57 -> 1.39 ms with 4 -> 5 -> 6 waves per CU), i.e. the LDS per wave:
-        // <= 32,000 bytes for five.  Seven planes of 32-byte cells; everything that is dead once the column phase starts LIVES IN THEM:
-        // the un-carried totals of mul(a, b) / mul(q, n) (integers, 32-byte entries) in the AB / EQB planes' own slots -- lane c reads
-        // column c's integers and then writes column c's cells --, the operand cells of the mul rows (4 L + 2 entries = two planes
-        // exactly) in the NQ1 + COUT planes.  The integer SUM plane shrinks to the carries (16 bytes), which the range rows need.
-        p.mab = o; o += n * 32u; p.meqb = o; o += n * 32u; p.amb = o; o += n * 32u; p.msum = o; o += n * 32u;
-        p.nq1 = o; o += n * 32u; p.cout = o; o += n * 32u; p.cmod = o; o += n * 32u;
+        // <= 32,000 bytes for five, <= 26,880 for six (RSA-2048: 26,848).  Seven planes of 32-byte cells, one entry per column
+        // (2L - 1); everything that is dead once the column phase starts LIVES IN THEM: the un-carried totals of mul(a, b) / mul(q, n)
+        // (integers, 32-byte entries) in the AB / EQB planes' own slots -- lane c reads column c's integers and then writes column
+        // c's cells --, the operand cells of the mul rows (4 L + 2 entries) in the NQ1 + COUT + CMOD planes.  The integer SUM plane
+        // shrinks to the carries (16 bytes each, which the range rows need), and those lie over the limbs of a, b, q, n
+        // ((2L - 1) x 16 <= 4L x 8 bytes: no mul row is built after the column phase; r stays, the eq_b rows read it).
+        const u32 C = 2u * L - 1u, ne = C > (4u * L + 4u) / 3u ? C : (4u * L + 4u) / 3u;
+        p.mab = o; o += ne * 32u; p.meqb = o; o += ne * 32u; p.amb = o; o += ne * 32u; p.msum = o; o += ne * 32u;
+        p.nq1 = o; o += ne * 32u; p.cout = o; o += ne * 32u; p.cmod = o; o += ne * 32u;
         p.ab = p.mab; p.eqb = p.meqb; p.sum = p.msum;   // (p.sum: no integer SUM plane -- unused)
         p.opsr = p.nq1;
-        p.icout = o; o += n * 16u;
+        p.icout = p.ops;
     } else {
         p.ab = o; o += n * es; p.eqb = o; o += n * es; p.sum = o; o += n * es;
         p.amb = o; o += n * 32u; p.nq1 = o; o += w64 ? n * 32u : 0u;
         p.cout = o; o += w64 ? n * 16u : 0u; p.cmod = o; o += w64 ? n * 16u : 0u;
         p.mab = p.meqb = p.msum = p.opsr = p.icout = o;
     }
-    p.fl = o; o += 2u * L * 4u;
-    p.src = o; o += CELLS_SRC_WORDS * 4u;
+    p.fl = o; o += (2u * L + 3u) & ~3u;                 // one byte per column
+    p.src = o; o += mont ? 0u : CELLS_SRC_WORDS * 4u;   // (Montgomery: only an inconsistent mul_mod reads the codes -- computed there)
     p.fsrc = o; o += 2u * CELLS_SRC_WORDS * 4u;
     p.total = (o + 15u) & ~15u;
     return p;
@@ -269,9 +272,11 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
     u8 *smem = reinterpret_cast<u8 *>(cells_smem);
     uint4 *stage = cells_smem;                                       // 64 rows x 160 bytes
     u64 *sa = reinterpret_cast<u64 *>(smem + lp.ops), *sb = sa + L, *sq = sb + L, *sn = sq + L, *sr = sn + L;
-    u64 *kt = reinterpret_cast<u64 *>(smem + lp.kt);
+    u64 *kt_lds = reinterpret_cast<u64 *>(smem + lp.kt);
+    const u64 *kt = MONT ? a.ktab : kt_lds;                           // (Montgomery: no LDS copy -- a handful of global reads per column)
     u64 *pAB = reinterpret_cast<u64 *>(smem + lp.ab), *pEQB = reinterpret_cast<u64 *>(smem + lp.eqb), *pSUM = reinterpret_cast<u64 *>(smem + lp.sum);
-    u32 *pFL = reinterpret_cast<u32 *>(smem + lp.fl), *s_src = reinterpret_cast<u32 *>(smem + lp.src), *f_src = reinterpret_cast<u32 *>(smem + lp.fsrc);
+    u8 *pFL = smem + lp.fl;                                           // per column: bit 0 f1, 1 e1, 2 f2, 3 e2
+    u32 *s_src = reinterpret_cast<u32 *>(smem + lp.src), *f_src = reinterpret_cast<u32 *>(smem + lp.fsrc);
     // the column phase's scratch lives in the stage (free between two chunks)
     u64 *xDH0 = reinterpret_cast<u64 *>(stage), *xDH1 = xDH0 + L2, *xSLO = xDH1 + L2;
     u32 *xSHI = reinterpret_cast<u32 *>(xSLO + L2);
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
             sq[k] = reinterpret_cast<const limb_t *>(a.opQ)[iq + k]; sr[k] = reinterpret_cast<const limb_t *>(a.opR)[iq + k];
             sn[k] = reinterpret_cast<const limb_t *>(a.n)[(u64)elem * a.n_stride + k];
         }
-        if (lane < CELLS_KT_WORDS) kt[lane] = a.ktab[lane];
+        if constexpr (!MONT) { if (lane < CELLS_KT_WORDS) kt_lds[lane] = a.ktab[lane]; }
     }
     // MONT: the multipliers this shape needs, in registers for the whole kernel (read back from an LDS copy so that they ARE vector
     // registers: as kernel arguments they are SGPRs, the kernel has none to spare, and the spills sat in the middle of every product)
@@ -445,7 +450,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
             rem_hi = 0;
         }
     };
-    for (u32 k = lane; k < ADVICE_COL_ROWS * 3; k += 64) s_src[k] = cells_col_src(k / 3, k % 3);
+    if constexpr (!MONT) { for (u32 k = lane; k < ADVICE_COL_ROWS * 3; k += 64) s_src[k] = cells_col_src(k / 3, k % 3); }
     if constexpr (FAST) {
         const u32 *packed = reinterpret_cast<const u32 *>(a.ktab + CELLS_KT_FSRC);
         for (u32 k = lane; k < 2 * CELLS_SRC_WORDS; k += 64) f_src[k] = packed[k];
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
             const bool prev_ok = all_ok && (bad & ((1ull << lane) - 1)) == 0;
             if (col) {
                 const u32 e1 = (prev_ok && f1) ? 1u : 0u, e2 = (e1 && f2) ? 1u : 0u;
-                pFL[c] = (f1 ? 1u : 0u) | (e1 << 8) | ((f2 ? 1u : 0u) << 16) | (e2 << 24);
+                pFL[c] = (u8)((f1 ? 1u : 0u) | (e1 << 1) | ((f2 ? 1u : 0u) << 2) | (e2 << 3));
             }
             all_ok = all_ok && bad == 0;
         }
@@ -809,6 +814,9 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 if (id.j == (id.i < L ? id.i : L - 1)) wrp(id.qn ? pEQB : pAB, id.i, acc);   // the column's total
             }
         }
+        // (read before the column phase: in a short record the q, r range rows share the chunk with it, and a Montgomery ctx's carries
+        // then lie over the limbs of q)
+        const u64 v_range = id.sect == 0 ? (id.i < L ? sq[id.i] : sr[id.i - L]) : 0;
         if (!(ABL & 8) && !columns_done && r0 + n_rows >= r_T5) {   // every mul row is built: the columns' carries before any row that needs them
             wave_sync();
             column_phase();
@@ -816,9 +824,8 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
         }
         // ---- the other sections: range rows, eq_b, the is_equal_muled preamble and its column rows ----
         if (id.sect == 0) {                                          // RangeChip::assign(q[k] / r[k], w / 8, w)  :590, :598
-            const u64 v = id.i < L ? sq[id.i] : sr[id.i - L];
             u64 c0, c1, c2, c3, rl, rh;
-            range_vals(v, 0, 8, LW / 8, id.j, c0, c1, c2, c3, rl, rh);
+            range_vals(v_range, 0, 8, LW / 8, id.j, c0, c1, c2, c3, rl, rh);
             v0 = lim(c0); v1 = lim(c1); v2 = lim(c2); v3 = lim(c3); v4 = U192::make(rl, rh, 0);
         } else if (id.sect == 2) {                                   // eq_b[i] = qn[i] + r[i]  :617
             if constexpr (MONT) { v1 = lim(sr[id.i]); row_eqb = true; const uint4 *e = reinterpret_cast<const uint4 *>(smem + lp.meqb) + 2 * id.i; cp[4] = e[0]; cp[5] = e[1]; }
@@ -861,9 +868,10 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                     return U192::make(val.w[0] & ~LMASK, val.w[1], val.w[2]);
                 };
                 bool s0, s1, s2;
-                const U192 c0 = fetch(s_src[j * 3], s0), c1 = fetch(s_src[j * 3 + 1], s1), c2 = fetch(s_src[j * 3 + 2], s2);
-                const u32 fl = pFL[c], eprev = c ? pFL[c - 1] >> 24 : 1u;
-                const u32 f1 = fl & 0xff, e1 = (fl >> 8) & 0xff, f2 = (fl >> 16) & 0xff, e2 = fl >> 24;
+                auto src_code = [&](u32 q) -> u32 { if constexpr (MONT) return j < ADVICE_COL_ROWS ? cells_col_src(j, q) : 0u; else return s_src[j * 3 + q]; };
+                const U192 c0 = fetch(src_code(0), s0), c1 = fetch(src_code(1), s1), c2 = fetch(src_code(2), s2);
+                const u32 fl = pFL[c], eprev = c ? (pFL[c - 1] >> 3) & 1u : 1u;
+                const u32 f1 = fl & 1u, e1 = (fl >> 1) & 1u, f2 = (fl >> 2) & 1u, e2 = (fl >> 3) & 1u;
                 const U192 d = c0 - c1;
                 switch (j) {
                     case 4: case 10: v0 = Bw; v1 = c1; v2 = c2; break;
