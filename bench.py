@@ -298,9 +298,24 @@ def advice_bench(args):
     probe = H.BigIntChip(w, bits, device=env.local_rank)
     pl = probe.pow_fixed_layout(e)
     L = _lib.lib()
-    sec = (ctypes.c_uint64 * 2)()
-    rows = int(L.h2r_modpow_public_key_advice_rows(probe._ctx, ctypes.byref(pl), sec))
-    pow_rows = int(sec[1])
+    # --verify: the WHOLE RSAChip::verify_pkcs1v15_signature element (src/chip.rs:128-199: is_eq seed, assert_in_field, the pow rows, the
+    # encoded-message check) through h2r_pipeline_verify_pkcs1v15_advice -- no records, a 10 KB witness per element
+    whole = bool(args.verify)
+    vl = None
+    if whole:
+        assert w == 64, "--advice --verify: RSAChip::LIMB_WIDTH = 64 (src/chip.rs:203)"
+        eb = e.to_bytes((e.bit_length() + 7) // 8, "little")
+        full, vl = _lib.H2RVerifyLayout(), _lib.H2RVerifyLayout()
+        _lib.check(L.h2r_verify_layout_fixed(probe._ctx, eb, len(eb), ctypes.byref(full)), "h2r_verify_layout_fixed")
+        _lib.check(L.h2r_verify_layout_compact(probe._ctx, ctypes.byref(full), ctypes.byref(vl)), "h2r_verify_layout_compact")
+        sec4 = (ctypes.c_uint64 * 4)()
+        rows = int(L.h2r_verify_advice_rows(probe._ctx, ctypes.byref(vl), sec4))
+        pow_rows, pow_off = int(sec4[2]), int(sec4[0]) + int(sec4[1])
+        sec = [pow_off, pow_rows]
+    else:
+        sec = (ctypes.c_uint64 * 2)()
+        rows = int(L.h2r_modpow_public_key_advice_rows(probe._ctx, ctypes.byref(pl), sec))
+        pow_rows, pow_off = int(sec[1]), int(sec[0])
     col_stride = ((rows * 32 + 4095) // 4096) * 4096 if args.columns else 0
     chip = H.BigIntChip(w, bits, device=env.local_rank, columns=args.columns, montgomery=args.montgomery, col_stride=col_stride) if (args.columns or args.montgomery) else probe
     row_bytes = 32 if args.columns else 160
@@ -342,8 +357,12 @@ def advice_bench(args):
         torch.cuda.empty_cache()
     else:
         images = [torch.zeros(chunk * elem_bytes, dtype=torch.uint8, device=dev) for _ in range(nimg)]
-    ifs = chip.in_field_layout()[0]
-    ifb = [torch.zeros(chunk * ifs, dtype=torch.uint8, device=dev) for _ in range(nimg)]
+    ifs = vl.elem_stride if whole else chip.in_field_layout()[0]
+    ifb = [torch.zeros(chunk * ifs, dtype=torch.uint8, device=dev) for _ in range(nimg)]   # (--verify: the in-field + encoded-message witness)
+    if whole:
+        hrng = random.Random(0x68327273 + 23)
+        hashed_dev = torch.tensor([[hrng.getrandbits(63) for _ in range(4)] for _ in range(chunk)], dtype=torch.int64, device=dev)   # synthetic digests
+        valids = [torch.zeros(chunk, dtype=torch.uint8, device=dev) for _ in range(nimg)]
     outs = [torch.zeros((chunk, chip.num_limbs), dtype=chip.torch_dtype, device=dev) for _ in range(nimg)]
     sts = [torch.zeros(chunk, dtype=torch.uint8, device=dev) for _ in range(nimg)]
     # The chain stream has the higher priority: its short kernels get the CUs a retiring cells wave frees (same-box A/B,
@@ -352,6 +371,8 @@ def advice_bench(args):
     adv_mode = os.environ.get("H2R_BENCH_ADV", "")
     # default: ONE export per call, h2r_pipeline_modpow_public_key_advice (the pipeline owns the side streams and the events); the
     # developer modes streams | noprio | serial compose the same thing here from plain exports, two torch streams and events
+    if whole:
+        adv_mode = ""
     pipe = H.Pipeline(chip, nimg, 2) if adv_mode == "" else None
     s_chain = torch.cuda.Stream() if adv_mode == "noprio" else torch.cuda.Stream(priority=-1)
     s_cells = s_chain if adv_mode == "serial" else torch.cuda.Stream()
@@ -367,7 +388,10 @@ def advice_bench(args):
         k = issued[0] % nimg
         if pipe is not None:
             with torch.cuda.stream(s_chain):
-                pipe.modpow_public_key_advice(x_dev, e, n_dev, wss[k], outs[k], sts[k], ifb[k], images[k].view(chunk, elem_bytes))
+                if whole:
+                    pipe.verify_pkcs1v15_advice(x_dev, e, n_dev, hashed_dev, ifb[k], wss[k], outs[k], valids[k], sts[k], images[k].view(chunk, elem_bytes))
+                else:
+                    pipe.modpow_public_key_advice(x_dev, e, n_dev, wss[k], outs[k], sts[k], ifb[k], images[k].view(chunk, elem_bytes))
             r = _Res(); r.status = sts[k]; r.value = outs[k]
             results[k] = r
             issued[0] += 1
@@ -425,9 +449,17 @@ def advice_bench(args):
         if i < chunk and xs[i] < ns[i]:
             assert got[i] == pow(xs[i], e, ns[i]), "GPU result differs from pow(x, e, n)"
     sample = min(chunk, 8)
-    ref = chip.pow_mod_fixed_exp(H.AssignedInteger(x_dev.limbs_dev[:sample].contiguous(), w), e, H.AssignedInteger(n_dev.limbs_dev[:sample].contiguous(), w),
-                                 check_in_field=True)
-    ref_img = ref.emit_modpow_advice(direct=False)
+    if whole:   # the record-based whole element (h2r_verify_pkcs1v15_batch + h2r_verify_emit_advice) of the first signatures
+        rsa = H.RSAChip(bits, 5, device=env.local_rank, columns=args.columns, montgomery=args.montgomery, col_stride=col_stride) if (args.columns or args.montgomery) \
+            else H.RSAChip(bits, 5, device=env.local_rank)
+        pk = H.RSAPublicKey(H.AssignedInteger(n_dev.limbs_dev[:sample].contiguous(), w), H.Fix(e))
+        ref = rsa.verify_pkcs1v15_signature(pk, hashed_dev[:sample].contiguous(), H.RSASignature(H.AssignedInteger(x_dev.limbs_dev[:sample].contiguous(), w)))
+        ref_img = ref.emit_advice()
+        assert torch.equal(ref.is_valid, valids[last][:sample]), "is_valid of the timed call differs from the record-based call's"
+    else:
+        ref = chip.pow_mod_fixed_exp(H.AssignedInteger(x_dev.limbs_dev[:sample].contiguous(), w), e, H.AssignedInteger(n_dev.limbs_dev[:sample].contiguous(), w),
+                                     check_in_field=True)
+        ref_img = ref.emit_modpow_advice(direct=False)
     torch.cuda.synchronize()
     timed = images[last].view(chunk, elem_bytes)[:sample]
     if args.columns:   # (the columns are longer than the element's rows: compare what the image covers)
@@ -439,13 +471,18 @@ def advice_bench(args):
     # ... and the WHOLE last timed image through the device-side MockProver (h2r_advice_check): the main-gate equation of every row, the
     # range-check table of every lookup-enabled cell, every copy pair of the pow rows -- 1,024 x 77,021 rows where they lie
     import numpy as np
-    k_if = chip.fresh_op_row_kinds(_lib.FRESH_OPS.index("is_in_field"), assert_one=True)
-    k_pow = np.zeros(pow_rows, dtype=np.uint8)
-    _lib.check(L.h2r_pow_row_kinds(chip._ctx, ctypes.byref(pl), k_pow.ctypes.data), "h2r_pow_row_kinds")
+    if whole:
+        kinds_all = np.zeros(rows, dtype=np.uint8)
+        _lib.check(L.h2r_verify_row_kinds(chip._ctx, ctypes.byref(vl), kinds_all.ctypes.data), "h2r_verify_row_kinds")
+    else:
+        k_if = chip.fresh_op_row_kinds(_lib.FRESH_OPS.index("is_in_field"), assert_one=True)
+        k_pow = np.zeros(pow_rows, dtype=np.uint8)
+        _lib.check(L.h2r_pow_row_kinds(chip._ctx, ctypes.byref(pl), k_pow.ctypes.data), "h2r_pow_row_kinds")
+        kinds_all = np.concatenate([k_if, k_pow])
     t_chk = time.perf_counter()
-    bad, first = chip.advice_check(np.concatenate([k_if, k_pow]), images[last].view(chunk, elem_bytes), chunk, status=sts[last],
-                                   copies=chip.pow_copy_map(pl, e, row_offset=int(sec[0])), src_a=x_dev, src_n=n_dev,
-                                   lookup=H.LookupArgument(chip, rsa_chip=False))
+    bad, first = chip.advice_check(kinds_all, images[last].view(chunk, elem_bytes), chunk, status=sts[last],
+                                   copies=chip.pow_copy_map(pl, e, row_offset=pow_off), src_a=x_dev, src_n=n_dev,
+                                   lookup=H.LookupArgument(chip, rsa_chip=whole))
     n_bad = int((bad != 0).sum().item())
     assert n_bad == 0, "h2r_advice_check: %d elements of the timed image violate a gate / lookup / copy (first: %#x)" % (n_bad, int(first[bad != 0][0].item()))
     audit_s = time.perf_counter() - t_chk
@@ -463,14 +500,19 @@ def advice_bench(args):
             "value": round(global_batch * steps / dt, 1), "unit": "assigns/s", "n_gpus": env.world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(1e3 * dt / steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u%d" % w, "data": "synthetic",
-            "config": {"workload": "%s batch=%d per GPU, %d-bit limbs, advice image (%d rows = %d B/assign: %d assert_in_field rows + %d pow rows)" %
+            "config": {"workload": ("%s batch=%d per GPU, %d-bit limbs, advice image of the whole verify_pkcs1v15_signature element (%d rows = %d B/assign: 1 is_eq row + %d "
+                                    "assert_in_field rows + %d pow rows + %d encoded-message rows)" % (args.workload, chunk, w, rows, rows * 160, int(sec4[1]), pow_rows, int(sec4[3])))
+                                   if whole else
+                                   "%s batch=%d per GPU, %d-bit limbs, advice image (%d rows = %d B/assign: %d assert_in_field rows + %d pow rows)" %
                                    (args.workload, chunk, w, rows, rows * 160, int(sec[0]), pow_rows),
-                       "path": "advice image",
+                       "path": "advice image (verify element)" if whole else "advice image",
                        "representation": {"columns": bool(args.columns), "montgomery": bool(args.montgomery), "col_stride": col_stride,
                                           "note": "planar: one contiguous vector per advice column; montgomery: cells = x * 2^256 mod p (the in-memory form of a halo2 field element)"},
                        "per_gpu_batch": chunk, "global_batch": global_batch, "calls_per_step": 1, "signatures_per_call": chunk,
                        "mul_mods_per_assign": pl.num_mul_mods, "parallelism": "signature-sharded x%d" % env.world, "ranks": env.world,
-                       "pipeline": ("h2r_pipeline_modpow_public_key_advice: chain kernels of call k+1 on the caller's stream next to cells_kernel of call k on the "
+                       "pipeline": ("h2r_pipeline_verify_pkcs1v15_advice: chains, in-field / EM witness and the three short row programs of call k+1 on the caller's stream next to "
+                                    "cells_kernel of call k on the pipeline's side stream (2 workspaces, 2 images; no records)") if whole else
+                                   ("h2r_pipeline_modpow_public_key_advice: chain kernels of call k+1 on the caller's stream next to cells_kernel of call k on the "
                                     "pipeline's side stream (2 workspaces, 2 images)") if pipe is not None else
                                    "chain kernels of call k+1 on a second stream next to cells_kernel of call k (2 workspaces, 2 images), stream-ordered exports + events (H2R_BENCH_ADV=%s)" % adv_mode,
                        "untimed_clock_warmup_calls": ramp, "warmup_calls_total": 1 + ramp + warmup, "buffer_placement": placement,
@@ -491,7 +533,7 @@ def advice_bench(args):
         }
         if env.world == 1 and args.pmc_traffic == "auto" and cells_ms:
             hbm, how = measured_pmc_traffic(["--advice", "--workload", args.workload, "--batch", str(chunk)] + (["--columns"] if args.columns else []) +
-                                            (["--montgomery"] if args.montgomery else []), "cells_kernel")   # (the passes run with --placement-candidates 0)
+                                            (["--montgomery"] if args.montgomery else []) + (["--verify"] if whole else []), "cells_kernel")   # (the passes run with --placement-candidates 0)
             if hbm is not None:
                 line["roofline"]["traffic"] = hbm
                 line["roofline"]["traffic_source"] = how
@@ -602,9 +644,11 @@ def sub_run_lines(args):
     d = sub_run(st + ["--placement-candidates", "0"])
     out["plain_allocations"] = {"what": "this line's workload with every buffer as hipMalloc hands it out (no arena, no candidates)", "value": d.get("value"),
                                 "frac": d.get("roofline", {}).get("frac"), "whole_path_hbm_frac": d.get("whole_path_hbm_frac"), "wall_s": d.get("_wall_s"), "error": d.get("error")}
-    for key, extra in (("advice", []), ("advice_columns_montgomery", ["--columns", "--montgomery"])):
+    for key, extra in (("advice", []), ("advice_columns_montgomery", ["--columns", "--montgomery"]), ("advice_verify_element", ["--verify"])):
         d = sub_run(st + ["--advice", "--placement-candidates", "8"] + extra)
-        out[key] = {"what": "bench.py --advice %s: elements/s of the %s advice image (12.3 MB each), cells_kernel" % (" ".join(extra), "planar Montgomery-form" if extra else "row-major canonical"),
+        what = {"advice": "row-major canonical", "advice_columns_montgomery": "planar Montgomery-form",
+                "advice_verify_element": "whole verify_pkcs1v15_signature element's (is_eq + assert_in_field + pow + encoded-message rows) row-major canonical"}[key]
+        out[key] = {"what": "bench.py --advice %s: elements/s of the %s advice image (12.3 MB each), cells_kernel" % (" ".join(extra), what),
                     "value": d.get("value"), "frac": d.get("roofline", {}).get("frac"), "whole_path_hbm_frac": d.get("whole_path_hbm_frac"),
                     "audit": d.get("config", {}).get("post_run_audit"), "wall_s": d.get("_wall_s"), "error": d.get("error")}
     oc = {}
@@ -653,7 +697,8 @@ def main():
                          "SHA-256 + hashed-message limbs on the device in the timed region) instead of precomputed digests")
     ap.add_argument("--advice", action="store_true",
                     help="time the prover-consumable witness: every step's output is the 5-column advice image of its modpow_public_key "
-                         "elements (assert_in_field rows + pow rows written directly from the operands by cells_kernel), no record planes")
+                         "elements (assert_in_field rows + pow rows written directly from the operands by cells_kernel), no record planes; "
+                         "with --verify: of its whole verify_pkcs1v15_signature elements (h2r_pipeline_verify_pkcs1v15_advice)")
     ap.add_argument("--lookup", action="store_true", help="the lookup argument's permuted columns (h2r_lookup_permuted_columns) as the product")
     ap.add_argument("--sub-runs", choices=["auto", "off"], default="auto",
                     help="auto: the default N = 1 line also carries plain_allocations, advice, advice_columns_montgomery, other_configs (C4, C5) and lookup, "

@@ -808,6 +808,28 @@ class Pipeline:
                                                  is_valid.data_ptr(), status.data_ptr(), workspace.data_ptr(), self.chip._stream()),
               "h2r_pipeline_verify_pkcs1v15")
 
+    def verify_pkcs1v15_advice(self, sig: AssignedInteger, e: int, n: AssignedInteger, hashed, witness, workspace, powed, is_valid, status, advice_out):
+        """The whole verify_pkcs1v15_signature element as advice rows WITHOUT records (h2r_pipeline_verify_pkcs1v15_advice): chains, the
+        in-field / encoded-message witness, is_valid and the three short row programs on the current stream, the pow rows (cells_kernel) on
+        the pipeline's side stream next to the following call's chains.  `witness`: uint8 [batch, verify_witness_stride(e)];
+        advice_out: uint8 [batch, image bytes of h2r_verify_advice_rows], complete after depth - 1 further calls or join()."""
+        eb = _e_bytes(e)
+        check(lib().h2r_pipeline_verify_pkcs1v15_advice(self._p, sig.data_ptr(), n.data_ptr(), eb, len(eb), hashed.data_ptr(), sig.batch,
+                                                        self.chip._flags(n, sig.batch), witness.data_ptr(), powed.data_ptr(), is_valid.data_ptr(),
+                                                        status.data_ptr(), workspace.data_ptr(), advice_out.data_ptr(),
+                                                        advice_out.shape[-1] if advice_out.dim() > 1 else advice_out.numel() // sig.batch,
+                                                        self.chip._stream()), "h2r_pipeline_verify_pkcs1v15_advice")
+
+    def verify_compact_layout(self, e: int):
+        """h2r_verify_layout_compact of the fixed exponent's verify layout: elem_stride = bytes of witness per element; rows via
+        h2r_verify_advice_rows."""
+        from ._lib import H2RVerifyLayout
+        eb = _e_bytes(e)
+        full, vl = H2RVerifyLayout(), H2RVerifyLayout()
+        check(lib().h2r_verify_layout_fixed(self.chip._ctx, eb, len(eb), ctypes.byref(full)), "h2r_verify_layout_fixed")
+        check(lib().h2r_verify_layout_compact(self.chip._ctx, ctypes.byref(full), ctypes.byref(vl)), "h2r_verify_layout_compact")
+        return vl
+
     def signature_verifier(self, msgs, msg_off, fixed_len: int, sig: AssignedInteger, e: int, n: AssignedInteger, trace_buf, workspace, powed,
                            is_valid, status, hashed, digest=None, hm_trace=None):
         """Pipelined RSASignatureVerifier::verify_pkcs1v15_signature from message bytes (src/lib.rs:183-246): `msgs` uint8 on the device,

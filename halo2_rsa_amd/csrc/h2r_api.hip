@@ -3547,6 +3547,86 @@ int32_t h2r_pipeline_modpow_public_key_advice(h2r_pipeline *p, const void *x, co
     return H2R_OK;
 } H2R_CATCH_STATUS
 
+// ---- the whole RSAChip::verify_pkcs1v15_signature element as advice rows, no records, pipelined --------------------------------
+// The witness-only form of a verify layout: the element keeps its in-field and encoded-message witness (what the row programs read)
+// and nothing else -- no record planes.  `pow` is unchanged (row counts, the number of mul_mods); off_records marks the absence.
+int32_t h2r_verify_layout_compact(const h2r_ctx *ctx, const h2r_verify_layout *full, h2r_verify_layout *out) try {
+    if (!ctx || !full || !out) return H2R_E_NULL;
+    if (ctx->layout.limb_width != 64 || ctx->L < 9) return H2R_E_SHAPE;
+    const AuxGeom g(ctx->L, 64);
+    *out = *full;
+    out->off_in_field = 0;
+    out->off_em = round_up(g.in_field_sz(), 256);
+    out->elem_stride = round_up(out->off_em + g.em_sz(), 256);
+    return H2R_OK;
+} H2R_CATCH_STATUS
+
+// Pipelined like h2r_pipeline_modpow_public_key_advice: the chains, powed_out, the in-field / encoded-message witness, is_valid and the
+// three short row programs (is_eq seed, assert_in_field, the encoded-message check) of call k on the caller's stream; its pow rows
+// (cells_kernel, from the operands in the workspace) on a side stream of the pipeline, next to the chains of call k + 1.
+int32_t h2r_pipeline_verify_pkcs1v15_advice(h2r_pipeline *p, const void *sig, const void *n, const uint8_t *e_le, size_t e_len,
+                                            const uint64_t *hashed, uint64_t batch, uint32_t flags, void *witness, void *powed_out,
+                                            uint8_t *is_valid_out, uint8_t *status, void *workspace, void *advice_out, uint64_t out_stride,
+                                            h2r_stream_t stream) try {
+    if (!p || !sig || !n || !e_le || !hashed || !witness || !powed_out || !status || !workspace || !advice_out) return H2R_E_NULL;
+    const h2r_ctx *ctx = p->ctx;
+    h2r_verify_layout full, vl;
+    int32_t rc = h2r_verify_layout_fixed(ctx, e_le, e_len, &full);
+    if (rc) return rc;
+    if ((rc = h2r_verify_layout_compact(ctx, &full, &vl))) return rc;
+    const h2r_ctx::RowProg *pre, *inf, *em;
+    if ((rc = verify_progs(ctx, &pre, &inf, &em))) return rc;
+    u64 sec[4];
+    const u64 rows = h2r_verify_advice_rows(ctx, &vl, sec);
+    if (!rows) return H2R_E_UNSUPPORTED;
+    AdviceDst dst;
+    if ((rc = advice_dst(ctx, advice_out, out_stride, rows, batch, &dst))) return rc;
+    if (batch == 0) return H2R_OK;
+    H2R_ON_DEVICE(ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p->pending) {   // records still owed by a call of another form: they go out alone, `st` behind them
+        rc = pipeline_flush(p, st);
+        if (rc) return rc;
+    }
+    const u32 slot = p->k % p->depth;
+    p->done[slot] = DoneRef{};
+    rc = pow_fixed_impl(ctx, sig, n, e_le, e_len, batch, flags, nullptr, powed_out, status, workspace, stream, 1);
+    if (rc) return rc;
+    if ((rc = launch_verify_aux(ctx, sig, n, hashed, batch, flags, witness, vl, powed_out, is_valid_out, status, st))) return rc;
+    const h2r_layout &lo = ctx->layout;
+    const Workspace wp = workspace_plan(lo.limb_bytes, ctx->L, batch, vl.pow.num_mul_mods ? vl.pow.num_mul_mods : 1);
+    u8 *ws = reinterpret_cast<u8 *>(round_up(reinterpret_cast<u64>(workspace), 256));
+    const bool shared = (flags & H2R_F_SHARED_MODULUS) != 0;
+    HIP_TRY(hipMemcpyAsync(ws + wp.off_n, n, (shared ? 1ull : batch) * ctx->L * lo.limb_bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipEventRecord(p->chain_done[slot], st));
+    RowProgArgs ra;
+    std::memset(&ra, 0, sizeof ra);
+    ra.a = sig; ra.b = n; ra.n = n; ra.a_stride = ctx->L; ra.b_stride = ra.n_stride = shared ? 0 : ctx->L;
+    ra.trace = static_cast<const u8 *>(witness); ra.elem_stride = vl.elem_stride; ra.first_off = vl.off_in_field;
+    ra.status = status; ra.batch = batch;
+    ra.dst = dst;                                   // is_eq = assign_constant(1), src/chip.rs:137
+    if ((rc = launch_row_prog(ctx, pre, ra, st))) return rc;
+    ra.dst = dst.at_row(sec[0]);                    // assert_in_field(sig, n), :106
+    if ((rc = launch_row_prog(ctx, inf, ra, st))) return rc;
+    ra.a = powed_out; ra.b = hashed; ra.b_stride = 4; ra.first_off = vl.off_em;
+    ra.dst = dst.at_row(sec[0] + sec[1] + sec[2]);  // :138-198
+    if ((rc = launch_row_prog(ctx, em, ra, st))) return rc;
+    hipStream_t side = p->aux[p->k & 1];
+    HIP_TRY(hipStreamWaitEvent(side, p->chain_done[slot], 0));
+    rc = pow_emit_advice(ctx, &vl.pow, ws + wp.off_n, (flags & H2R_F_SHARED_MODULUS) | H2R_ADVICE_DIRECT, nullptr, 0, workspace, batch, status,
+                         dst.at_row(sec[0] + sec[1]), static_cast<h2r_stream_t>(side));   // pow_mod_fixed_exp, :111
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(p->trace_done[slot], side));
+    p->done[slot] = DoneRef{p->trace_done[slot], 0, false};
+    p->done_stream[slot] = side;
+    p->k += 1;
+    for (; p->joined + p->depth <= p->k; ++p->joined) {
+        rc = pipeline_wait_slot(p, p->joined % p->depth, st);
+        if (rc) return rc;
+    }
+    return H2R_OK;
+} H2R_CATCH_STATUS
+
 // ---- the hashed-message limbs of RSASignatureVerifier as advice rows (src/lib.rs:225-239) ---------------------------------
 namespace {
 constexpr u32 kProgHashedMsg = 0x1002;

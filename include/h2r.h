@@ -912,6 +912,22 @@ int32_t h2r_modpow_public_key_emit_advice(const h2r_ctx *ctx, const h2r_pow_layo
 int32_t h2r_pipeline_modpow_public_key_advice(h2r_pipeline *p, const void *x, const void *n, const uint8_t *e_le_bytes, size_t e_len,
                                               uint64_t batch, uint32_t flags, void *in_field_trace, void *out, uint8_t *status,
                                               void *workspace, void *advice_out, uint64_t out_stride, h2r_stream_t stream);
+/* The WHOLE RSAChip::verify_pkcs1v15_signature element (src/chip.rs:128-199) as advice rows without records, pipelined: the image of
+ * h2r_verify_emit_advice -- [is_eq seed][assert_in_field][pow rows][encoded-message check] -- for a fixed exponent, produced like
+ * h2r_pipeline_modpow_public_key_advice produces its two sections: the chains, powed_out, the in-field / encoded-message witness,
+ * is_valid_out, status and the three short row programs on `stream`; the pow rows (cells_kernel) on a side stream of the pipeline next
+ * to the chains of the following call.  The image follows the pipeline's join rule; everything else is stream-ordered.
+ * witness: batch * h2r_verify_layout_compact(...).elem_stride bytes -- the element's in-field and EM witness, the only part of a verify
+ * element's trace the rows need (9,984 B instead of 1.26 MB per RSA-2048 element).  h2r_verify_layout_compact turns a verify layout into
+ * that form (off_in_field = 0, off_em, elem_stride; `pow` unchanged); with it h2r_verify_emit_advice (flags | H2R_ADVICE_DIRECT,
+ * trace = the witness), h2r_verify_advice_rows and h2r_verify_row_kinds work as with the full layout.
+ * Consecutive calls rotate through `depth` sets of witness / powed_out / is_valid_out / status / workspace / advice_out.
+ * `bench.py --advice --verify` measures this form (77,200 rows = 12.35 MB per RSA-2048 element). */
+int32_t h2r_verify_layout_compact(const h2r_ctx *ctx, const h2r_verify_layout *full, h2r_verify_layout *out);
+int32_t h2r_pipeline_verify_pkcs1v15_advice(h2r_pipeline *p, const void *sig, const void *n, const uint8_t *e_le_bytes, size_t e_len,
+                                            const uint64_t *hashed, uint64_t batch, uint32_t flags, void *witness, void *powed_out,
+                                            uint8_t *is_valid_out, uint8_t *status, void *workspace, void *advice_out,
+                                            uint64_t out_stride, h2r_stream_t stream);
 uint32_t h2r_advice_rows(const h2r_ctx *ctx);
 int32_t h2r_mul_mod_emit_advice(const h2r_ctx *ctx, const void *a, const void *b, const void *n, uint32_t flags,
                                 const void *trace, uint64_t batch, const uint8_t *status, void *advice_out,

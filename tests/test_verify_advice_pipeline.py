@@ -1,0 +1,181 @@
+"""h2r_pipeline_verify_pkcs1v15_advice: the whole RSAChip::verify_pkcs1v15_signature element (src/chip.rs:128-199 -- is_eq seed :137,
+assert_in_field :106, pow_mod_fixed_exp :111, the encoded-message check :138-198) as advice rows WITHOUT records, pipelined.  The
+reference's own circuits for this method are TestRSASignatureCircuit1 / 2 and the BAD variant (src/chip.rs:694-838): the KAT1 / KAT2 /
+BAD vectors are elements here.  The record-based image (h2r_verify_pkcs1v15_batch + h2r_verify_emit_advice) is pinned against the Python
+restatement run on the oracle's stream (tests/test_gpu_parity.py); the records-free pipelined image must be that image, byte for byte,
+in every representation, and must pass the device-side MockProver (h2r_advice_check)."""
+import ctypes
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+
+
+def test_compact_layout_on_the_host():
+    """h2r_verify_layout_compact: the pow layout untouched, the witness regions packed from offset 0, a 256-byte stride; refused where
+    RSAChip is (limb width 64 only, src/chip.rs:203)."""
+    from halo2_rsa_amd import _lib
+    from halo2_rsa_amd._lib import lib
+    ctx = ctypes.c_void_p()
+    p = _lib.H2RParams(64, 2048, 0, -1)
+    assert lib().h2r_ctx_create(ctypes.byref(p), ctypes.byref(ctx)) == 0
+    e = (65537).to_bytes(3, "little")
+    full, vl = _lib.H2RVerifyLayout(), _lib.H2RVerifyLayout()
+    assert lib().h2r_verify_layout_fixed(ctx, e, len(e), ctypes.byref(full)) == 0
+    assert lib().h2r_verify_layout_compact(ctx, ctypes.byref(full), ctypes.byref(vl)) == 0
+    assert bytes(vl.pow) == bytes(full.pow)
+    assert vl.off_in_field == 0 and vl.off_em == full.off_em - full.off_in_field
+    assert vl.elem_stride % 256 == 0 and vl.elem_stride >= vl.off_em + full.em_stream_bytes and vl.off_em >= full.in_field_stream_bytes
+    assert vl.elem_stride < 16384 < full.elem_stride
+    assert (vl.in_field_stream_bytes, vl.em_stream_bytes, vl.stream_bytes) == (full.in_field_stream_bytes, full.em_stream_bytes, full.stream_bytes)
+    sa, sb = (ctypes.c_uint64 * 4)(), (ctypes.c_uint64 * 4)()
+    assert lib().h2r_verify_advice_rows(ctx, ctypes.byref(vl), sa) == lib().h2r_verify_advice_rows(ctx, ctypes.byref(full), sb) == 77200
+    assert list(sa) == list(sb) == [1, 1532, 75489, 178]
+    assert lib().h2r_verify_layout_compact(ctx, None, ctypes.byref(vl)) == _lib.H2R_E_NULL
+    lib().h2r_ctx_destroy(ctx)
+    p32 = _lib.H2RParams(32, 2048, 0, -1)
+    assert lib().h2r_ctx_create(ctypes.byref(p32), ctypes.byref(ctx)) == 0
+    assert lib().h2r_verify_layout_compact(ctx, ctypes.byref(full), ctypes.byref(vl)) == _lib.H2R_E_SHAPE
+    lib().h2r_ctx_destroy(ctx)
+
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def H():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import halo2_rsa_amd as H_
+    return H_
+
+
+def rand_modulus(rng, bits):
+    return rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+
+
+def _hashed_tensor(vals):
+    limbs = [[(h >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)] for h in vals]
+    return torch.tensor(np.array(limbs, dtype=np.uint64).view(np.int64), device="cuda")
+
+
+def _buffers(chip, vl, rows, B):
+    return dict(ws=torch.empty(chip.workspace_bytes(B, vl.pow.num_mul_mods), dtype=torch.uint8, device="cuda"),
+                wit=torch.zeros((B, vl.elem_stride), dtype=torch.uint8, device="cuda"),
+                powed=torch.zeros((B, chip.num_limbs), dtype=torch.int64, device="cuda"),
+                valid=torch.zeros(B, dtype=torch.uint8, device="cuda"), st=torch.zeros(B, dtype=torch.uint8, device="cuda"),
+                img=torch.empty((B, chip.image_bytes(rows)), dtype=torch.uint8, device="cuda"))
+
+
+def _inputs(golden, rng, B, bad_elem=None):
+    """KAT1, KAT2, BAD (src/chip.rs:703-798) + random moduli / signatures (their encoded message is wrong: is_valid = 0, every gate holds)."""
+    kats = golden["rsa_kats"]
+    ns = [int(k["n"]) for k in kats] + [rand_modulus(rng, 2048) for _ in range(B - 3)]
+    sigs = [int(k["sig"]) for k in kats] + [rng.randrange(n) for n in ns[3:]]
+    hashed = [int(k["hashed"]) for k in kats] + [rng.getrandbits(256) for _ in range(B - 3)]
+    if bad_elem is not None:
+        sigs[bad_elem] = ns[bad_elem] + 7          # not in the field: assert_in_field fails, the element has a status and no image
+    return ns, sigs, hashed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("repr_kw", [dict(), dict(columns=True), dict(montgomery=True), dict(columns=True, montgomery=True)])
+def test_pipelined_verify_image_is_the_record_based_image(H, golden, repr_kw):
+    """Four pipelined calls over two buffer sets (different inputs per call, one element not in the field): powed, is_valid, status and
+    every byte of every image equal what h2r_verify_pkcs1v15_batch + h2r_verify_emit_advice give for the same inputs; an element with a
+    status keeps its bytes; the plain emit reads the compact witness as its `trace` (H2R_ADVICE_DIRECT) and gives the same image."""
+    from halo2_rsa_amd._lib import lib
+    rsa = H.RSAChip(2048, 5, **repr_kw)
+    chip = rsa.bigint_chip()
+    rng = random.Random(0x68327273 + 61)
+    B, depth, calls_n = 7, 2, 4
+    pipe = H.Pipeline(chip, depth, 2)
+    vl = pipe.verify_compact_layout(65537)
+    sec = (ctypes.c_uint64 * 4)()
+    rows = int(lib().h2r_verify_advice_rows(chip._ctx, ctypes.byref(vl), sec))
+    assert rows == 77200
+    sets = [_buffers(chip, vl, rows, B) for _ in range(depth)]
+    calls, got = [], []
+    for k in range(calls_n):
+        ns, sigs, hashed = _inputs(golden, rng, B, bad_elem=5 if k == 1 else None)
+        calls.append((ns, sigs, hashed))
+        s = sets[k % depth]
+        if k >= depth:
+            got.append((k - depth, {key: v.clone() for key, v in s.items() if key != "ws"}))
+        s["img"].fill_(0x5A)
+        pipe.verify_pkcs1v15_advice(chip.assign_integer(sigs), 65537, chip.assign_integer(ns), _hashed_tensor(hashed), s["wit"], s["ws"],
+                                    s["powed"], s["valid"], s["st"], s["img"])
+    pipe.join()
+    for k in range(calls_n - depth, calls_n):
+        got.append((k, {key: v.clone() for key, v in sets[k % depth].items() if key != "ws"}))
+    pipe.close()
+    torch.cuda.synchronize()
+    assert sorted(g[0] for g in got) == list(range(calls_n))
+    for k, g in got:
+        ns, sigs, hashed = calls[k]
+        pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Fix(65537)))
+        sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64)))
+        res = rsa.verify_pkcs1v15_signature(pk, _hashed_tensor(hashed), sg)
+        want = res.emit_advice()
+        assert torch.equal(g["st"], res.status) and torch.equal(g["valid"], res.is_valid), k
+        assert g["valid"].cpu().tolist()[:3] == [1, 1, 0]
+        ok = (res.status == 0)
+        assert torch.equal(g["powed"][ok], res.powed.limbs_dev[ok]), k
+        assert torch.equal(g["img"][ok], want[ok]), k
+        if k == 1:
+            assert int(g["st"][5]) == H.H2R_E_NOT_IN_FIELD and int(g["valid"][5]) == 0 and bool((g["img"][5] == 0x5A).all())
+        # the same layout through the plain emit: the witness as `trace`, H2R_ADVICE_DIRECT
+        if k == calls_n - 1:
+            out = torch.full_like(g["img"], 0x5A)
+            s = sets[k % depth]
+            from halo2_rsa_amd import _lib
+            sig_d, n_d, h_d = chip.assign_integer(sigs), chip.assign_integer(ns), _hashed_tensor(hashed)
+            assert lib().h2r_verify_emit_advice(chip._ctx, ctypes.byref(vl), sig_d.data_ptr(), n_d.data_ptr(), h_d.data_ptr(), s["powed"].data_ptr(),
+                                                _lib.H2R_ADVICE_DIRECT, s["wit"].data_ptr(), s["ws"].data_ptr(), B, s["st"].data_ptr(), out.data_ptr(),
+                                                out.shape[1], chip._stream()) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(out, g["img"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("repr_kw", [dict(), dict(columns=True, montgomery=True)])
+def test_pipelined_verify_image_passes_the_device_mockprover(H, golden, repr_kw):
+    """h2r_advice_check on the records-free image: gate + lookup (RangeChip's 4-bit table included) + the pow rows' copy pairs, every
+    element; a flipped cell in the encoded-message section and one in the pow section are found."""
+    from halo2_rsa_amd._lib import lib
+    rsa = H.RSAChip(2048, 5, **repr_kw)
+    chip = rsa.bigint_chip()
+    look = H.LookupArgument(chip, rsa_chip=True)
+    rng = random.Random(17)
+    B = 6
+    pipe = H.Pipeline(chip, 2, 2)
+    vl = pipe.verify_compact_layout(65537)
+    sec = (ctypes.c_uint64 * 4)()
+    rows = int(lib().h2r_verify_advice_rows(chip._ctx, ctypes.byref(vl), sec))
+    s = _buffers(chip, vl, rows, B)
+    ns, sigs, hashed = _inputs(golden, rng, B)
+    sig_d, n_d = chip.assign_integer(sigs), chip.assign_integer(ns)
+    pipe.verify_pkcs1v15_advice(sig_d, 65537, n_d, _hashed_tensor(hashed), s["wit"], s["ws"], s["powed"], s["valid"], s["st"], s["img"])
+    pipe.join()
+    pipe.close()
+    kinds = np.zeros(rows, dtype=np.uint8)
+    assert lib().h2r_verify_row_kinds(chip._ctx, ctypes.byref(vl), kinds.ctypes.data) == 0
+    copies = chip.pow_copy_map(vl.pow, 65537, row_offset=sec[0] + sec[1])
+    bad, first = chip.advice_check(kinds, s["img"], B, copies=copies, src_a=sig_d, src_n=n_d, lookup=look)
+    assert bad.cpu().tolist() == [0] * B, (bad.cpu().tolist(), [hex(v) for v in first.cpu().tolist()])
+    assert s["valid"].cpu().tolist() == [1, 1, 0, 0, 0, 0]
+    if not repr_kw:
+        img = s["img"].clone()
+        em0 = sec[0] + sec[1] + sec[2]
+        r_em = next(r for r in range(em0, rows) if kinds[r] == 48)      # H2R_ROW_RANGE_U32: a sub-limb that leaves the table
+        img[2, r_em * 160 + 20] ^= 1
+        r_pow = sec[0] + sec[1] + 2 + 128 + 4                            # record 0, column 1's second multiply-add: its acc cell
+        img[4, r_pow * 160 + 96] ^= 1
+        bad, first = chip.advice_check(kinds, img, B, copies=copies, src_a=sig_d, src_n=n_d, lookup=look)
+        b = bad.cpu().tolist()
+        assert b[2] > 0 and b[4] > 0 and b[0] == b[1] == b[3] == b[5] == 0, b
