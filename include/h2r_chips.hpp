@@ -746,6 +746,28 @@ class Pipeline {
                                                     static_cast<uint8_t *>(b.status.get()), b.workspace.get(), advice.get(), advice_stride, stream),
               "h2r_pipeline_modpow_public_key_advice");
     }
+    // The WHOLE RSAInstructions::verify_pkcs1v15_signature element (src/chip.rs:128-199) as advice rows without records
+    // ([is_eq seed][assert_in_field][pow rows][encoded-message check]: h2r_verify_advice_rows rows per element): chains, witness, is_valid and
+    // the short row programs on `stream`, the pow rows on the pipeline's side streams.  witness: batch * compact_layout(pk).elem_stride bytes.
+    static h2r_verify_layout compact_layout(const RSAChip &chip, const AssignedRSAPublicKey &pk) {
+        auto *f = std::get_if<RSAPubE::Fix>(&pk.e);
+        if (!f) throw Error(H2R_E_UNSUPPORTED, "Pipeline::compact_layout (takes RSAPubE::Fix)");
+        h2r_verify_layout full, vl;
+        check(h2r_verify_layout_fixed(chip.bigint_chip().ctx(), f->e_le.data(), f->e_le.size(), &full), "h2r_verify_layout_fixed");
+        check(h2r_verify_layout_compact(chip.bigint_chip().ctx(), &full, &vl), "h2r_verify_layout_compact");
+        return vl;
+    }
+    void verify_pkcs1v15_signature_advice(const AssignedRSAPublicKey &pk, const AssignedInteger &hashed_msg, const AssignedRSASignature &sig, Buffers &b,
+                                DeviceBuffer &witness, DeviceBuffer &advice, uint64_t advice_stride, hipStream_t stream = nullptr) {
+        auto *f = std::get_if<RSAPubE::Fix>(&pk.e);
+        if (!f) throw Error(H2R_E_UNSUPPORTED, "Pipeline::verify_pkcs1v15_signature_advice (takes RSAPubE::Fix)");
+        const size_t batch = sig.c.batch();
+        check(h2r_pipeline_verify_pkcs1v15_advice(p_, sig.c.data(), pk.n.data(), f->e_le.data(), f->e_le.size(),
+                                                  static_cast<const uint64_t *>(hashed_msg.data()), batch,
+                                                  (pk.n.batch() == 1 && batch != 1) ? H2R_F_SHARED_MODULUS : 0u, witness.get(), b.powed.get(),
+                                                  static_cast<uint8_t *>(b.is_valid.get()), static_cast<uint8_t *>(b.status.get()), b.workspace.get(),
+                                                  advice.get(), advice_stride, stream), "h2r_pipeline_verify_pkcs1v15_advice");
+    }
     void join(hipStream_t stream = nullptr) { check(h2r_pipeline_join(p_, stream), "h2r_pipeline_join"); }
     // an element's whole verify witness in the reference's order (after join() + synchronisation)
     std::vector<uint8_t> flatten(const Buffers &b, size_t elem) const {

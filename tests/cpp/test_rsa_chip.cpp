@@ -205,6 +205,27 @@ int main(int argc, char **argv) {
             REQUIRE(hipDeviceSynchronize() == hipSuccess);
             for (int s2 = 0; s2 < 2; ++s2) { adv[s2].download(mb.data(), mb.size()); REQUIRE(ma == mb); }
         }
+        // ... and the WHOLE verify element without records, pipelined (h2r_pipeline_verify_pkcs1v15_advice): every image = the record-based one
+        {
+            Pipeline vpipe(rsa_chip, 2, 2);
+            const std::vector<uint8_t> e65537 = {0x01, 0x00, 0x01};
+            Pipeline::Buffers vb[2] = {vpipe.make_buffers(B, e65537), vpipe.make_buffers(B, e65537)};
+            const h2r_verify_layout cl = Pipeline::compact_layout(rsa_chip, pk);
+            REQUIRE(cl.off_in_field == 0 && cl.elem_stride < 16384);
+            const uint64_t vstride = rows * (uint64_t)H2R_ADVICE_ROW_BYTES;
+            DeviceBuffer wit[2] = {DeviceBuffer(B * cl.elem_stride), DeviceBuffer(B * cl.elem_stride)};
+            DeviceBuffer vadv[2] = {DeviceBuffer(B * vstride), DeviceBuffer(B * vstride)};
+            for (int k = 0; k < 3; ++k) vpipe.verify_pkcs1v15_signature_advice(pk, hashed_msg_assigned, sign, vb[k & 1], wit[k & 1], vadv[k & 1], vstride);
+            vpipe.join();
+            REQUIRE(hipDeviceSynchronize() == hipSuccess);
+            std::vector<uint8_t> va(ia.size()), valid(B);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                vadv[s2].download(va.data(), va.size());
+                REQUIRE(va == ia);
+                vb[s2].is_valid.download(valid.data(), B);
+                for (size_t i = 0; i < B; ++i) REQUIRE(valid[i] == kats[i].is_valid);
+            }
+        }
         BatchResult pw = bigint_chip.pow_mod_fixed_exp(sign.c, {0x01, 0x00, 0x01}, pk.n);
         REQUIRE(bigint_chip.advice_rows(pw) == 75489);
         DeviceBuffer p1 = bigint_chip.emit_advice(pw, pk.n), p2 = bigint_chip.emit_advice(pw, pk.n, true);
