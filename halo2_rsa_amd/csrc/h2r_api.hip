@@ -3189,12 +3189,20 @@ int32_t fresh_row_prog(const h2r_ctx *ctx, uint32_t op, uint32_t flags, const h2
 int32_t launch_row_prog(const h2r_ctx *ctx, const h2r_ctx::RowProg *rp, RowProgArgs &ra, hipStream_t st) {
     ra.prog = rp->dev; ra.rows = (u32)rp->host.size(); ra.f = ctx->fc; ra.mk = ctx->mk_dev;
     ra.inv_rows = rp->inv_dev; ra.n_inv = (u32)rp->inv_rows.size();
-    const u64 blocks = ra.batch * ((ra.rows + 255) / 256);
+    static const u32 sr = [] { const char *e = std::getenv("H2R_ROWPROG_STAGE_ROWS"); const int v = e ? std::atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? (u32)v : 256u; }();   // (developer A/B)
+    const u64 blocks = ra.batch * ((ra.rows + sr - 1) / sr);
     if (blocks == 0) return H2R_OK;
     if (blocks >= (1ull << 31)) return H2R_E_UNSUPPORTED;
     ProfScope ps(H2R_KERNEL_EMIT, st, true);
-    if (ctx->layout.limb_width == 64) hipExtLaunchKernelGGL((rowprog_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, st, ps.a, ps.on ? ps.b : nullptr, 0, ra);
-    else hipExtLaunchKernelGGL((rowprog_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, ps.a, ps.on ? ps.b : nullptr, 0, ra);
+    auto go = [&](auto lw_c, auto sr_c) {
+        constexpr int LW = decltype(lw_c)::value; constexpr u32 SR = decltype(sr_c)::value;
+        hipExtLaunchKernelGGL((rowprog_kernel<LW, SR>), dim3((unsigned)blocks), dim3(SR), 0, st, ps.a, ps.on ? ps.b : nullptr, 0, ra);
+    };
+    using I64 = std::integral_constant<int, 64>; using I32 = std::integral_constant<int, 32>;
+    const bool w64 = ctx->layout.limb_width == 64;
+    if (sr == 64) { if (w64) go(I64{}, std::integral_constant<u32, 64>{}); else go(I32{}, std::integral_constant<u32, 64>{}); }
+    else if (sr == 128) { if (w64) go(I64{}, std::integral_constant<u32, 128>{}); else go(I32{}, std::integral_constant<u32, 128>{}); }
+    else { if (w64) go(I64{}, std::integral_constant<u32, 256>{}); else go(I32{}, std::integral_constant<u32, 256>{}); }
     HIP_TRY(hipGetLastError());
     if (ra.n_inv) {   // is_zero's inverse witnesses, packed into full waves (rowprog_inv_kernel)
         const u64 ib = (ra.batch * ra.n_inv + 255) / 256;

@@ -310,10 +310,11 @@ __device__ __forceinline__ Fe rp_fetch(const RowProgArgs &a, const u8 *reg, u32 
     return v;
 }
 
-template <int LW>
-__global__ __launch_bounds__(256) void rowprog_kernel(RowProgArgs a) {
+// SR rows per workgroup (= its threads), staged in SR x 160 bytes of LDS.  Next to a cells kernel that fills every CU's LDS a workgroup
+// only starts where retiring cells workgroups have left SR x 160 bytes free: the smaller stage is the one that finds room.
+template <int LW, u32 SR = 256>
+__global__ __launch_bounds__(SR) void rowprog_kernel(RowProgArgs a) {
     using limb_t = typename LimbT<LW>::type;
-    constexpr u32 SR = 256;
     __shared__ uint4 stage[SR * (ADVICE_ROW_BYTES / 16)];
     const u32 tid = threadIdx.x;
     const u32 nchunks = (a.rows + SR - 1) / SR;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void rowprog_kernel(RowProgArgs a) {
     }
     __syncthreads();
     const u32 n_rows = a.rows - r0 < SR ? a.rows - r0 : SR;
-    advice_flush<256>(a.dst, a.mk, a.dst.elem(elem), r0, n_rows, stage, tid);
+    advice_flush<SR>(a.dst, a.mk, a.dst.elem(elem), r0, n_rows, stage, tid);
 }
 
 
