@@ -90,6 +90,17 @@ def test_bench_advice_in_the_provers_representation():
     assert "0 violations" in line["config"]["post_run_audit"]
 
 
+def test_bench_advice_whole_verify_element():
+    """--advice --verify: the whole verify_pkcs1v15_signature element through h2r_pipeline_verify_pkcs1v15_advice; bench.py's own checks ran
+    (is_valid and the timed image against the record-based call's, h2r_advice_check with RSAChip's table over every row)."""
+    line = _run(["--advice", "--verify", "--batch", "128", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--pmc-traffic", "off",
+                 "--placement-candidates", "0"])
+    assert line["config"]["path"] == "advice image (verify element)" and "77200 rows" in line["config"]["workload"]
+    assert "h2r_pipeline_verify_pkcs1v15_advice" in line["config"]["pipeline"]
+    assert line["roofline"]["algorithmic_bytes_per_launch"] == 128 * (2 + 19 * 3973) * 160
+    assert line["value"] > 0 and "0 violations" in line["config"]["post_run_audit"]
+
+
 def test_bench_lookup_line():
     line = _run(["--lookup", "--batch", "32", "--steps", "3", "--warmup", "1", "--pmc-traffic", "off", "--placement-candidates", "3"])
     assert line["unit"] == "GB/s" and line["roofline"]["kernel"] == "lookup_fill_kernel" and 0.1 < line["roofline"]["frac"] < 1.0
@@ -101,10 +112,10 @@ def test_bench_default_line_carries_the_sub_runs():
     """What the driver runs (`--gpus 1 --steps K --warmup W`, nothing else) also reports, from fresh processes: the headline as allocated,
     the advice image in both representations (each audited by h2r_advice_check), BASELINE configs 4 and 5, the lookup argument."""
     line = _run(["--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--pmc-traffic", "off"], timeout=900)
-    for key in ("plain_allocations", "advice", "advice_columns_montgomery", "other_configs", "lookup", "scale_anchor"):
+    for key in ("plain_allocations", "advice", "advice_columns_montgomery", "advice_verify_element", "other_configs", "lookup", "scale_anchor"):
         assert key in line, key
     assert line["plain_allocations"]["value"] > 0 and 0.2 < line["plain_allocations"]["frac"] < 1.0
-    for key in ("advice", "advice_columns_montgomery"):
+    for key in ("advice", "advice_columns_montgomery", "advice_verify_element"):
         assert line[key]["error"] is None and line[key]["value"] > 0 and "0 violations" in line[key]["audit"], line[key]
     assert line["other_configs"]["C4"]["value"] > 0 and line["other_configs"]["C5"]["value"] > 0
     assert line["lookup"]["error"] is None and line["lookup"]["whole_call_GBps"] > 0
