@@ -404,7 +404,10 @@ int32_t h2r_arena_create_ex(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t f
 /* The same look for ANY large buffer the kernels stream into -- advice images, the lookup argument's A' / S' columns: `regions`
  * regions of region_bytes each, the fastest of `candidates` allocations timed with a streaming fill in the product kernels' store
  * pattern (16 bytes per lane, non-temporal); max_look_bytes as for h2r_arena_create_ex.  A prover allocates such buffers once:
- * this is "time a few, keep the fastest" as an export.  The accessors below apply. */
+ * this is "time a few, keep the fastest" as an export.  The accessors below apply.
+ * [measured] The fill's ranking carries over to the cells kernel's images; it does NOT predict h2r_lookup_permuted_columns, whose rate
+ * belongs to the PAIR of column buffers it writes (0.65 of the HBM peak on the pair this look kept, 0.77 on the pair fastest under the
+ * call itself, same box): for that call time candidate pairs with the call (bench.py --lookup does). */
 int32_t h2r_image_arena_create(const h2r_ctx *ctx, uint64_t region_bytes, uint32_t regions, uint32_t candidates, uint64_t max_look_bytes,
                                h2r_stream_t stream, h2r_arena **out);
 void *h2r_arena_region(const h2r_arena *a, uint32_t i);
