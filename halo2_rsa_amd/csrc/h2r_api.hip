@@ -3189,7 +3189,13 @@ int32_t fresh_row_prog(const h2r_ctx *ctx, uint32_t op, uint32_t flags, const h2
 int32_t launch_row_prog(const h2r_ctx *ctx, const h2r_ctx::RowProg *rp, RowProgArgs &ra, hipStream_t st) {
     ra.prog = rp->dev; ra.rows = (u32)rp->host.size(); ra.f = ctx->fc; ra.mk = ctx->mk_dev;
     ra.inv_rows = rp->inv_dev; ra.n_inv = (u32)rp->inv_rows.size();
-    static const u32 sr = [] { const char *e = std::getenv("H2R_ROWPROG_STAGE_ROWS"); const int v = e ? std::atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? (u32)v : 256u; }();   // (developer A/B)
+    // Workgroup size.  A Montgomery ctx's cells kernel (256 VGPRs, six one-wave workgroups per CU, LDS full) lets a workgroup of several
+    // waves in only when its grid drains: 256-row row programs issued next to it sat there for its whole 2 ms with everything behind them
+    // on the stream (the next call's chains) -- one-wave workgroups (64 rows, 10 KB) are placed as cells workgroups retire: the pipelined
+    // calls 2.39 -> 2.26 ms (modpow_public_key element), 2.67 -> 2.26 ms (whole verify element); profiles/r05_advice_pipeline_montgomery.txt.
+    // Next to the canonical cells kernel both sizes run alike; 256 stays.  (H2R_ROWPROG_STAGE_ROWS = 64 | 128 | 256: developer A/B.)
+    static const u32 sr_env = [] { const char *e = std::getenv("H2R_ROWPROG_STAGE_ROWS"); const int v = e ? std::atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? (u32)v : 0u; }();
+    const u32 sr = sr_env ? sr_env : ((ctx->repr.flags & H2R_ADVICE_MONTGOMERY) ? 64u : 256u);
     const u64 blocks = ra.batch * ((ra.rows + sr - 1) / sr);
     if (blocks == 0) return H2R_OK;
     if (blocks >= (1ull << 31)) return H2R_E_UNSUPPORTED;
@@ -3205,10 +3211,16 @@ int32_t launch_row_prog(const h2r_ctx *ctx, const h2r_ctx::RowProg *rp, RowProgA
     else { if (w64) go(I64{}, std::integral_constant<u32, 256>{}); else go(I32{}, std::integral_constant<u32, 256>{}); }
     HIP_TRY(hipGetLastError());
     if (ra.n_inv) {   // is_zero's inverse witnesses, packed into full waves (rowprog_inv_kernel)
-        const u64 ib = (ra.batch * ra.n_inv + 255) / 256;
+        const u32 nt = sr == 64 ? 64u : 256u;   // (one-wave workgroups with the one-wave stage)
+        const u64 ib = (ra.batch * ra.n_inv + nt - 1) / nt;
         if (ib >= (1ull << 31)) return H2R_E_UNSUPPORTED;
-        if (ctx->layout.limb_width == 64) hipLaunchKernelGGL((rowprog_inv_kernel<64>), dim3((unsigned)ib), dim3(256), 0, st, ra);
-        else hipLaunchKernelGGL((rowprog_inv_kernel<32>), dim3((unsigned)ib), dim3(256), 0, st, ra);
+        if (nt == 64) {
+            if (w64) hipLaunchKernelGGL((rowprog_inv_kernel<64, 64>), dim3((unsigned)ib), dim3(64), 0, st, ra);
+            else hipLaunchKernelGGL((rowprog_inv_kernel<32, 64>), dim3((unsigned)ib), dim3(64), 0, st, ra);
+        } else {
+            if (w64) hipLaunchKernelGGL((rowprog_inv_kernel<64>), dim3((unsigned)ib), dim3(256), 0, st, ra);
+            else hipLaunchKernelGGL((rowprog_inv_kernel<32>), dim3((unsigned)ib), dim3(256), 0, st, ra);
+        }
         HIP_TRY(hipGetLastError());
     }
     return H2R_OK;

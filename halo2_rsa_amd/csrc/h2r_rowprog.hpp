@@ -385,15 +385,15 @@ __global__ __launch_bounds__(SR) void rowprog_kernel(RowProgArgs a) {
 // assert_in_field) are spread thinly over waves whose other lanes wait -- 5.1 ms for 1,024 RSA-2048 elements.  Here one thread
 // looks at one (element, is_zero row); the rows with d != 0 are packed into a dense list in LDS, so the waves that invert are
 // full, and every cell 1 = 1/d goes out as two 16-byte stores behind the image rowprog_kernel wrote.
-template <int LW>
-__global__ __launch_bounds__(256) void rowprog_inv_kernel(RowProgArgs a) {
+template <int LW, u32 NT = 256>
+__global__ __launch_bounds__(NT) void rowprog_inv_kernel(RowProgArgs a) {
     __shared__ u32 cnt;
-    __shared__ u32 l_elem[256], l_row[256];
-    __shared__ Fe l_d[256];
+    __shared__ u32 l_elem[NT], l_row[NT];
+    __shared__ Fe l_d[NT];
     const u32 tid = threadIdx.x;
     if (tid == 0) cnt = 0;
     __syncthreads();
-    const u64 g = (u64)blockIdx.x * 256 + tid;
+    const u64 g = (u64)blockIdx.x * NT + tid;
     if (g < a.batch * a.n_inv) {
         const u32 elem = (u32)(g / a.n_inv), r = a.inv_rows[g - (u64)elem * a.n_inv];
         if (!(a.status && a.status[elem])) {
