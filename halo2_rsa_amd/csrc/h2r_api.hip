@@ -176,6 +176,7 @@ struct h2r_ctx {
     U256 word_max;
     u8 *const_rec_dev;  // device copy of the constant record
     u32 *advice_desc_dev = nullptr;   // [h2r_advice_rows] packed row descriptors of the advice image (advice_pack)
+    u32 cells_nwv = 1;                // cells_kernel: waves per workgroup (Montgomery cells of the long shapes share one set of planes among several)
     u64 *cells_ktab_dev = nullptr;    // cells_kernel: columns 0, 1, >= 2 of the accumulated_extra constants (CELLS_KT_WORDS words)
     std::vector<u8> const_rec_host;
     // lookup-table row offsets for the multiplicity histogram
@@ -659,7 +660,12 @@ int32_t h2r_ctx_create_ex(const h2r_params *params, const h2r_advice_repr *repr,
         std::memcpy(&kt[CELLS_KT_FC], &c->fc, sizeof c->fc);
         {   // the column rows' fast-path sources, packed against this shape's LDS plan
             const bool mont = (c->repr.flags & H2R_ADVICE_MONTGOMERY) != 0;
-            const CellsLds lp = cells_lds_plan(w, L, mont);
+            // Montgomery cells of the long shapes (64 limbs and more): EIGHT waves share one set of planes (h2r_cells.hpp); measured per shape,
+            // TB/s with 1 / 4 / 8 waves: 128 x 32-bit 3.4 / 5.3 / 6.4, 96 x 32-bit 3.2 / 4.8 / 5.4, 64 x 32-bit 4.2 / 4.3 / 5.2, 64 x 64-bit 3.8 / 3.6 / 4.4,
+            // 48 x 64-bit 3.9 / 3.1 / 3.5, 32 x 64-bit 5.2 / 2.6 / 2.9 (tools/cells_nwv_probe.py, profiles/r05_cells_representations.txt)
+            static const u32 nwv_env = [] { const char *e = std::getenv("H2R_CELLS_NWV"); const int v = e ? std::atoi(e) : 0; return (v == 1 || v == 8) ? (u32)v : 0u; }();   // (developer A/B)
+            c->cells_nwv = !mont ? 1u : (nwv_env ? nwv_env : (L >= 64 ? 8u : 1u));
+            const CellsLds lp = cells_lds_plan(w, L, mont, c->cells_nwv);
             u32 *fs = reinterpret_cast<u32 *>(&kt[CELLS_KT_FSRC]);
             for (u32 k = 0; k < ADVICE_COL_ROWS * 3; ++k) {
                 fs[k] = cells_pack_fast_src(lp, w, cells_fast_src(k / 3, k % 3, false), mont);
@@ -2910,7 +2916,8 @@ int32_t launch_cells(const h2r_ctx *ctx, CellsArgs &ca, hipStream_t st) {
     if (ca.n_items >= (1ull << 31)) return H2R_E_UNSUPPORTED;
     // Residency: FOUR waves per CU, one per SIMD (measured: 6.64-6.67 TB/s against 6.47 with the six the RSA-2048 shape's 26 KB would
     // allow, 4.2 with three -- profiles/r04_cells_kernel.txt).  Enforced the way occupancy is enforced on this hardware: by the LDS request.
-    u32 lds = cells_lds_bytes(lo.limb_width, lo.num_limbs, mont);
+    const u32 nwv = mont ? ctx->cells_nwv : 1u;
+    u32 lds = cells_lds_bytes(lo.limb_width, lo.num_limbs, mont, nwv);
 #ifndef H2R_CELLS_WAVES
 #define H2R_CELLS_WAVES 4   // (developer variants: 0 = whatever fits)
 #endif
@@ -2918,20 +2925,19 @@ int32_t launch_cells(const h2r_ctx *ctx, CellsArgs &ca, hipStream_t st) {
     //  for RSA-2048, 2.9 -> 2.5 ms per 1,024 elements against four)
     const u32 quarter = (H2R_CELLS_WAVES && !mont) ? (ctx->lds_per_cu / H2R_CELLS_WAVES - 512) & ~15u : 0u;
     if (lds < quarter) lds = quarter;
-    const void *fn = lo.limb_width == 64 ? (mont ? reinterpret_cast<const void *>(&cells_kernel<64, 0, true>) : reinterpret_cast<const void *>(&cells_kernel<64>))
-                                         : (mont ? reinterpret_cast<const void *>(&cells_kernel<32, 0, true>) : reinterpret_cast<const void *>(&cells_kernel<32>));
-    if (lds > 48 * 1024) {
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipGetLastError();
-    }
+    if (lds > ctx->lds_per_cu) return H2R_E_UNSUPPORTED;
     ProfScope ps(H2R_KERNEL_CELLS, st, true);
-    if (lo.limb_width == 64) {
-        if (mont) hipExtLaunchKernelGGL((cells_kernel<64, 0, true>), dim3((unsigned)ca.n_items), dim3(64), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ca);
-        else hipExtLaunchKernelGGL((cells_kernel<64>), dim3((unsigned)ca.n_items), dim3(64), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ca);
-    } else {
-        if (mont) hipExtLaunchKernelGGL((cells_kernel<32, 0, true>), dim3((unsigned)ca.n_items), dim3(64), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ca);
-        else hipExtLaunchKernelGGL((cells_kernel<32>), dim3((unsigned)ca.n_items), dim3(64), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ca);
-    }
+    auto go = [&](auto kernel, u32 threads) {
+        if (lds > 48 * 1024) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipGetLastError();
+        }
+        hipExtLaunchKernelGGL(kernel, dim3((unsigned)ca.n_items), dim3(threads), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ca);
+    };
+    const bool w64 = lo.limb_width == 64;
+    if (!mont) { if (w64) go(&cells_kernel<64>, 64); else go(&cells_kernel<32>, 64); }
+    else if (nwv == 1) { if (w64) go(&cells_kernel<64, 0, true>, 64); else go(&cells_kernel<32, 0, true>, 64); }
+    else { if (w64) go(&cells_kernel<64, 0, true, 8>, 512); else go(&cells_kernel<32, 0, true, 8>, 512); }
     HIP_TRY(hipGetLastError());
     return H2R_OK;
 }

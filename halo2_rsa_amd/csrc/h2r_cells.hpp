@@ -130,8 +130,8 @@ __host__ __device__ constexpr u32 cells_fast_src(u32 j, u32 k, bool last_col) {
 }
 
 // dynamic LDS of one wave (byte offsets): stage, operands, constants, column planes, flags, code tables
-struct CellsLds { u32 ops, kt, ce, ab, eqb, sum, amb, nq1, cout, cmod, mab, meqb, msum, opsr, icout, fl, src, fsrc, total; };
-__host__ __device__ inline CellsLds cells_lds_plan(u32 limb_width, u32 L, bool mont = false) {
+struct CellsLds { u32 ops, kt, ce, ab, eqb, sum, amb, nq1, cout, cmod, mab, meqb, msum, opsr, icout, fl, src, fsrc, stage, total; };
+__host__ __device__ inline CellsLds cells_lds_plan(u32 limb_width, u32 L, bool mont = false, u32 nwv = 1) {
     // 64-bit limbs: 32-byte entries AB, EQB, SUM, a_b, NQ1 and 16-byte entries carry, c.  32-bit limbs (every value but a_b's field
     // element is below 2^128): 16-byte entries AB, EQB, SUM, a 32-byte a_b; NQ1, the carry and c are cut from the SUM entry on the way.
     // Montgomery cells are not the integers the column phase computes with: the integer planes AB, EQB, SUM stay what they are, and
@@ -139,7 +139,10 @@ __host__ __device__ inline CellsLds cells_lds_plan(u32 limb_width, u32 L, bool m
     // first two cells of every mul row), converted once per mul_mod.
     const bool w64 = limb_width == 64;
     const u32 es = w64 ? 32u : 16u, n = 2u * L + 1u;
-    CellsLds p; u32 o = 64u * ADVICE_ROW_BYTES;
+    // one wave per workgroup: its 64-row stage in front; several: their stages BEHIND everything else (the fast path's source codes hold
+    // LDS offsets / 16 in 13 bits: planes must stay below 128 KB)
+    CellsLds p; u32 o = nwv > 1 ? 0u : 64u * ADVICE_ROW_BYTES;
+    p.stage = 0;
     p.ops = o; o += 5u * L * 8u;
     p.kt = o; o += mont ? 0u : CELLS_KT_WORDS * 8u;    // (Montgomery: the table is read from global memory where it is needed)
     p.ce = o; o += CELLS_CONST_ENTRIES * 32u;
@@ -152,7 +155,7 @@ __host__ __device__ inline CellsLds cells_lds_plan(u32 limb_width, u32 L, bool m
         // c's cells --, the operand cells of the mul rows (4 L + 2 entries) in the NQ1 + COUT + CMOD planes.  The integer SUM plane
         // shrinks to the carries (16 bytes each, which the range rows need), and those lie over the limbs of a, b, q, n
         // ((2L - 1) x 16 <= 4L x 8 bytes: no mul row is built after the column phase; r stays, the eq_b rows read it).
-        const u32 C = 2u * L - 1u, ne = C > (4u * L + 4u) / 3u ? C : (4u * L + 4u) / 3u;
+        const u32 C = 2u * L - 1u, need = (4u * L + 2u + nwv + 2u) / 3u, ne = C > need ? C : need;   // (4L + 1 + nwv operand entries over three planes)
         p.mab = o; o += ne * 32u; p.meqb = o; o += ne * 32u; p.amb = o; o += ne * 32u; p.msum = o; o += ne * 32u;
         p.nq1 = o; o += ne * 32u; p.cout = o; o += ne * 32u; p.cmod = o; o += ne * 32u;
         p.ab = p.mab; p.eqb = p.meqb; p.sum = p.msum;   // (p.sum: no integer SUM plane -- unused)
@@ -168,9 +171,10 @@ __host__ __device__ inline CellsLds cells_lds_plan(u32 limb_width, u32 L, bool m
     p.src = o; o += mont ? 0u : CELLS_SRC_WORDS * 4u;   // (Montgomery: only an inconsistent mul_mod reads the codes -- computed there)
     p.fsrc = o; o += 2u * CELLS_SRC_WORDS * 4u;
     p.total = (o + 15u) & ~15u;
+    if (nwv > 1) { p.stage = p.total; p.total += nwv * 64u * ADVICE_ROW_BYTES; }
     return p;
 }
-__host__ __device__ inline u32 cells_lds_bytes(u32 limb_width, u32 L, bool mont = false) { return cells_lds_plan(limb_width, L, mont).total; }
+__host__ __device__ inline u32 cells_lds_bytes(u32 limb_width, u32 L, bool mont = false, u32 nwv = 1) { return cells_lds_plan(limb_width, L, mont, nwv).total; }
 // A fast-path source as the kernel wants it: bits 0-12 LDS offset / 16 of the plane's (or constant's) first entry, bits 13-16 entry
 // stride / 16, bit 17 column c - 1, bit 18 indexed by min(column, 2) (the accumulated_extra constants), bit 19 the entry has a high
 // half, bits 20-23 (32-bit limbs, canonical cells) the cut of the SUM entry (CE_NQ1 / CE_COUT / CE_CMOD)
@@ -255,8 +259,13 @@ __device__ __forceinline__ void cells_prefix_sum(u32 (&v)[NWD]) {
 //   * sub-limbs are one-digit products.
 // The planar form (dst.planar(): one contiguous vector per column) only changes how the staged chunk leaves: five 2 KB runs
 // instead of one 10 KB run, each store instruction still a whole number of 128-byte lines.
-template <int LW, int ABL = 0, bool MONT = false>
-__global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
+// NWV > 1: a workgroup of NWV waves per mul_mod SHARING one set of planes (each wave has a stage of its own).  The planes are what
+// limits the waves a CU holds for the long shapes in Montgomery form (7 x (2L - 1) x 32 bytes: 57 KB for 128 limbs -- two one-wave
+// workgroups per CU); eight waves around one set are 137 KB.  The chunks before the one that runs the column phase are split into NWV
+// contiguous runs (a wave entering the mul rows in the middle first recomputes the running sum of the column it enters: a silent pass over
+// the chunks that column can reach back into), that chunk is wave 0's, the chunks behind it are split again; workgroup barriers in between.
+template <int LW, int ABL = 0, bool MONT = false, int NWV = 1>
+__global__ __launch_bounds__(64 * NWV) void cells_kernel(CellsArgs a) {
     using limb_t = typename LimbT<LW>::type;
     constexpr bool FAST = !(ABL & 64);
     constexpr int WW = LW == 64 ? 3 : 2;     // 64-bit words of a wide value
@@ -266,11 +275,12 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
     constexpr u64 LMASK = LW == 64 ? ~0ull : 0xffffffffull;
     constexpr u32 NP = ADVICE_ROW_BYTES / 16;   // 16-byte pieces of a row
     extern __shared__ uint4 cells_smem[];
-    const u32 lane = threadIdx.x;
+    const u32 lane = threadIdx.x & 63u, wv = NWV > 1 ? threadIdx.x >> 6 : 0u;
     const u32 L = a.L, L2 = 2 * L, C = 2 * L - 1;
-    const CellsLds lp = cells_lds_plan(LW, L, MONT);
+    const CellsLds lp = cells_lds_plan(LW, L, MONT, NWV);
     u8 *smem = reinterpret_cast<u8 *>(cells_smem);
-    uint4 *stage = cells_smem;                                       // 64 rows x 160 bytes
+    uint4 *stage = reinterpret_cast<uint4 *>(smem + lp.stage) + (u64)wv * 64 * (ADVICE_ROW_BYTES / 16);   // this wave's 64 rows x 160 bytes
+    auto wg_sync = [&]() { if constexpr (NWV > 1) __syncthreads(); else wave_sync(); };
     u64 *sa = reinterpret_cast<u64 *>(smem + lp.ops), *sb = sa + L, *sq = sb + L, *sn = sq + L, *sr = sn + L;
     u64 *kt_lds = reinterpret_cast<u64 *>(smem + lp.kt);
     const u64 *kt = MONT ? a.ktab : kt_lds;                           // (Montgomery: no LDS copy -- a handful of global reads per column)
@@ -290,12 +300,12 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
     if (a.status && a.status[elem]) return;
     {
         const u64 ib = (u64)item * a.op_stride, iq = (u64)item * a.qr_stride;
-        for (u32 k = lane; k < L; k += 64) {
+        for (u32 k = threadIdx.x; k < L; k += 64 * NWV) {
             sa[k] = reinterpret_cast<const limb_t *>(a.opA)[ib + k]; sb[k] = reinterpret_cast<const limb_t *>(a.opB)[ib + k];
             sq[k] = reinterpret_cast<const limb_t *>(a.opQ)[iq + k]; sr[k] = reinterpret_cast<const limb_t *>(a.opR)[iq + k];
             sn[k] = reinterpret_cast<const limb_t *>(a.n)[(u64)elem * a.n_stride + k];
         }
-        if constexpr (!MONT) { if (lane < CELLS_KT_WORDS) kt_lds[lane] = a.ktab[lane]; }
+        if constexpr (!MONT) { if (threadIdx.x < CELLS_KT_WORDS) kt_lds[threadIdx.x] = a.ktab[threadIdx.x]; }
     }
     // MONT: the multipliers this shape needs, in registers for the whole kernel (read back from an LDS copy so that they ARE vector
     // registers: as kernel arguments they are SGPRs, the kernel has none to spare, and the spills sat in the middle of every product)
@@ -317,7 +327,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
     u8 *img = a.dst.elem(elem);
     // `out`: the record's first row (its column-a cell); the other columns of a row lie col_pitch apart, the next row row_pitch further
     u8 *out = img + ((u64)a.pre_rows + (u64)t * a.rows + (u64)((t + 1) >> 1) * a.sel_rows) * a.dst.row_pitch;
-    if (t == 0 && lane < a.pre_rows * 5) {   // pow_mod_fixed_exp's acc = assign_constant(1, L): [1, 0, 0, 0, 0] then [0, ...]
+    if (t == 0 && wv == 0 && lane < a.pre_rows * 5) {   // pow_mod_fixed_exp's acc = assign_constant(1, L): [1, 0, 0, 0, 0] then [0, ...]
         uint4 *pr = reinterpret_cast<uint4 *>(img + (u64)(lane / 5) * a.dst.row_pitch + (u64)(lane % 5) * a.dst.col_pitch);
         if (MONT && lane == 0) { const u32 *one = reinterpret_cast<const MontK *>(stage)->bk[0]; pr[0] = make_uint4(one[0], one[1], one[2], one[3]); pr[1] = make_uint4(one[4], one[5], one[6], one[7]); }
         else { pr[0] = make_uint4(lane == 0 ? 1u : 0u, 0, 0, 0); pr[1] = make_uint4(0, 0, 0, 0); }
@@ -450,24 +460,24 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
             rem_hi = 0;
         }
     };
-    if constexpr (!MONT) { for (u32 k = lane; k < ADVICE_COL_ROWS * 3; k += 64) s_src[k] = cells_col_src(k / 3, k % 3); }
+    if constexpr (!MONT) { for (u32 k = threadIdx.x; k < ADVICE_COL_ROWS * 3; k += 64 * NWV) s_src[k] = cells_col_src(k / 3, k % 3); }
     if constexpr (FAST) {
         const u32 *packed = reinterpret_cast<const u32 *>(a.ktab + CELLS_KT_FSRC);
-        for (u32 k = lane; k < 2 * CELLS_SRC_WORDS; k += 64) f_src[k] = packed[k];
+        for (u32 k = threadIdx.x; k < 2 * CELLS_SRC_WORDS; k += 64 * NWV) f_src[k] = packed[k];
     }
-    wave_sync();
+    wg_sync();
     if constexpr (MONT) {   // the limbs of a, b, q, n as cells: what the mul rows' first two columns hold
         uint4 *opsr = reinterpret_cast<uint4 *>(smem + lp.opsr);
-        for (u32 k = lane; k < 4 * L; k += 64) {
+        for (u32 k = threadIdx.x; k < 4 * L; k += 64 * NWV) {
             const u32 which = k / L, idx = k - which * L;
             const u64 v = (which == 0 ? sa : which == 1 ? sb : which == 2 ? sq : sn)[idx];
             cell_k(std::integral_constant<int, LW>{}, v, 0, opsr[2 * k], opsr[2 * k + 1]);
         }
-        if (lane < 4) opsr[2 * 4 * L + lane] = Z4;
+        if (threadIdx.x < 4) opsr[2 * 4 * L + threadIdx.x] = Z4;
     }
     if constexpr (FAST) {   // the constant entries
         uint4 *ce = reinterpret_cast<uint4 *>(smem + lp.ce);
-        if (lane < CELLS_CONST_ENTRIES) {
+        if (wv == 0 && lane < CELLS_CONST_ENTRIES) {
             U192 v = Z;
             if (lane == CE_ONE) v = lim(1);
             else if (lane == CE_BW) v = Bw;
@@ -546,6 +556,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
             all_ok = all_ok && bad == 0;
         }
         item_ok = all_ok;
+        if constexpr (NWV > 1) { if (lane == 0) pFL[2 * L - 1] = all_ok ? 1 : 0; }   // (for the other waves: the byte behind the last column's)
         wave_sync();
     };
 
@@ -559,13 +570,12 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
     u32 dec_r0 = ~0u, dec_I = 0, dec_k = 0, dec_len = 1;   // the mul rows' fast path: row r0 + lane = position dec_k of column dec_I (both muls: 2C columns)
     // the first chunk ends where the image reaches a 128-byte line (160 = 128 + 32: at most three rows), every later chunk of 64
     // rows (80 lines) then starts on one
-    u32 n_rows = 64;
+    u32 n_first = 64;
     if constexpr (!(ABL & 128)) {
         const u32 mis = (u32)(reinterpret_cast<u64>(out) & 127u);
-        if (mis && (mis & 31u) == 0) n_rows = (128u - mis) / 32u;
+        if (mis && (mis & 31u) == 0) n_first = (128u - mis) / 32u;
     }
-    for (u32 r0 = 0; r0 < a.rows; r0 += n_rows, n_rows = 64) {
-        if (a.rows - r0 < n_rows) n_rows = a.rows - r0;
+    auto chunk = [&](const u32 r0, const u32 n_rows) {
         const u32 r = r0 + lane;
         const bool valid = lane < n_rows;
         uint4 *srow = stage + (u64)lane * NP;
@@ -595,7 +605,7 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 if constexpr (MONT) {   // (the general path left the integer: its cell goes where a chunk's last row leaves its accumulator cell)
                     u32 d[DA], cr[8];
                     digits30<DA, NWD>(carry, d); mont30<DA>(d, mv.bA, mv.p30, mv.n0, mv.p32, cr);
-                    uint4 *slot = reinterpret_cast<uint4 *>(smem + lp.opsr) + 2 * (4 * L + 1);
+                    uint4 *slot = reinterpret_cast<uint4 *>(smem + lp.opsr) + 2 * (4 * L + 1 + wv);   // (a slot per wave)
                     if (lane == 0) { slot[0] = make_uint4(cr[0], cr[1], cr[2], cr[3]); slot[1] = make_uint4(cr[4], cr[5], cr[6], cr[7]); }
                 }
             } else {
@@ -665,10 +675,10 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 // acc_prev IS the row above's acc (position k - 1 of the same column; the first multiply-add starts from the constant 0): a
                 // copy of the cell the lane above has just staged -- for lane 0 of the cell the previous chunk's lane 63 left in the slot
                 wave_sync();
-                const uint4 *pa = k < 2 ? opsr + 2 * zi : (lane == 0 ? opsr + 2 * (zi + 1) : srow - NP + 6);
+                const uint4 *pa = k < 2 ? opsr + 2 * zi : (lane == 0 ? opsr + 2 * (zi + 1 + wv) : srow - NP + 6);
                 const uint4 pv0 = pa[0], pv1 = pa[1];
                 wave_sync();
-                if (lane == 63) { opsr[2 * (zi + 1)] = srow[6]; opsr[2 * (zi + 1) + 1] = srow[7]; }
+                if (lane == 63) { opsr[2 * (zi + 1 + wv)] = srow[6]; opsr[2 * (zi + 1 + wv) + 1] = srow[7]; }
                 srow[4] = pv0; srow[5] = pv1;
             } else {
             srow[0] = make_uint4((u32)x, (u32)(x >> 32), 0, 0); srow[1] = Z4;
@@ -970,6 +980,61 @@ __global__ __launch_bounds__(64) void cells_kernel(CellsArgs a) {
                 const u32 ci = r0 / 64 + (r0 % 64 ? 1 : 0);
                 if (ci < 1000) { a.dbg[3 * ci] = path; a.dbg[3 * ci + 1] = t_1 - t_0; a.dbg[3 * ci + 2] = t_2 - t_1; }
             }
+        }
+    };
+    if constexpr (NWV == 1) {
+        for (u32 r0 = 0, n = n_first; r0 < a.rows; r0 += n, n = 64) {
+            if (a.rows - r0 < n) n = a.rows - r0;
+            chunk(r0, n);
+        }
+    } else {
+        // chunk j: rows [cr0(j), cr0(j) + cn(j)); chunk 0 is the short one in front of the first 128-byte line
+        const u32 n0 = n_first < a.rows ? n_first : a.rows, NC = 1 + (a.rows - n0 + 63) / 64;
+        auto cr0 = [&](u32 j) -> u32 { return j ? n0 + 64 * (j - 1) : 0u; };
+        auto cn = [&](u32 j) -> u32 { const u32 s0 = cr0(j), m = j ? 64u : n0; return a.rows - s0 < m ? a.rows - s0 : m; };
+        const u32 cb = r_T5 <= n0 ? 0u : (r_T5 - n0 + 63) / 64;          // the chunk in which the last mul row is built: it runs the column phase
+        const u32 WU = (L + 63) / 64;                                             // chunks a column reaches back over
+        u32 last = ~0u;                                                           // the chunk whose running sum `carry` continues
+        __syncthreads();                                                          // (operand cells, constants: written by all waves)
+        for (u32 ph = 0; ph < 3; ++ph) {
+            u32 lo, hi;
+            if (ph == 0) { const u32 per = (cb + NWV - 1) / NWV; lo = wv * per; hi = lo + per < cb ? lo + per : cb; }
+            else if (ph == 1) { lo = cb; hi = wv == 0 ? cb + 1 : cb; }
+            else { const u32 m = NC - cb - 1, per = (m + NWV - 1) / NWV; lo = cb + 1 + wv * per; hi = lo + per < NC ? lo + per : NC; }
+            if (ph == 2) { columns_done = true; item_ok = pFL[2 * L - 1] != 0; }
+            for (u32 j = lo; j < hi; ++j) {
+                if (ph < 2 && j && last != j - 1) {
+                    // entering the mul rows in the middle: the running sum of the column that reaches into chunk j, from the chunks it can
+                    // begin in (sums restart at every column's head row, so the value assumed in front of them does not matter)
+#pragma unroll
+                    for (int k = 0; k < NWD; ++k) carry[k] = 0;
+                    for (u32 jj = j > WU ? j - WU : 0u; jj < j; ++jj) {
+                        const u32 rs = cr0(jj) + lane;
+                        const bool vs = lane < cn(jj);
+                        const AdviceRowId id = advice_decode(vs ? rs : 0u, L, nrc);
+                        const bool is_ma = vs && id.sect == 1 && id.kind == ROWK_MUL_ADD;
+                        u32 pp[NWD];
+#pragma unroll
+                        for (int k = 0; k < NWD; ++k) pp[k] = 0;
+                        if (is_ma) {
+                            const u64 x = (id.qn ? sq : sa)[id.j], y = (id.qn ? sn : sb)[id.i - id.j];
+                            if constexpr (LW == 64) { const u128 pr = (u128)x * y; pp[0] = (u32)pr; pp[1] = (u32)(pr >> 32); pp[2] = (u32)(pr >> 64); pp[3] = (u32)(pr >> 96); }
+                            else { const u64 pr = (u64)(u32)x * (u32)y; pp[0] = (u32)pr; pp[1] = (u32)(pr >> 32); }
+                        }
+                        if (lane == 0 && is_ma) {
+                            u32 c = 0;
+#pragma unroll
+                            for (int k = 0; k < NWD; ++k) pp[k] = __builtin_addc(pp[k], carry[k], c, &c);
+                        }
+                        cells_seg_scan<NWD>(pp, !is_ma);
+#pragma unroll
+                        for (int k = 0; k < NWD; ++k) carry[k] = (u32)__builtin_amdgcn_readlane((int)pp[k], 63);
+                    }
+                }
+                chunk(cr0(j), cn(j));
+                last = j;
+            }
+            __syncthreads();
         }
     }
 }
