@@ -492,72 +492,88 @@ __global__ __launch_bounds__(64 * NWV) void cells_kernel(CellsArgs a) {
 
     // ---- the 2L - 1 un-carried columns: eq_b, a_b, the carries and the running eq_bit (chip.rs:614-623, 857-893) -> planes ----
     bool item_ok = true;
-    auto column_phase = [&]() {
+    // (NWV > 1: every wave comes here -- the chunk's owner from inside the chunk, the others from the phase loop.  The owner prepares the
+    //  integers; then each wave walks ALL columns' integer arithmetic, which is cheap, and converts the cells of the planes that are its own:
+    //  seven planes over the waves instead of seven conversions per column in one wave)
+    auto column_phase = [&](const bool owner) {
         const U192 Wm = U192::make(kt[CELLS_KT_WM], kt[CELLS_KT_WM + 1], kt[CELLS_KT_WM + 2]);
+        if constexpr (NWV > 1) __syncthreads();       // the totals the other waves' mul rows left
+        u64 *const sDH0 = NWV > 1 ? reinterpret_cast<u64 *>(smem + lp.stage) : xDH0, *const sDH1 = sDH0 + L2, *const sSLO = sDH1 + L2;   // (the owner's stage)
+        u32 *const sSHI = reinterpret_cast<u32 *>(sSLO + L2);
+        if (owner) {
         for (u32 c = lane; c < C; c += 64) {
             const U192 A = rdp(pAB, c);
             U192 Q = rdp(pEQB, c);                 // (holds the q*n column until here)
             if (c < L) { Q = Q + lim(sr[c]); wrp(pEQB, c, Q); }                // eq_b[i] = qn[i] + r[i]  :617
             const U192 D = (A - Q) + Wm;          // a_b + word_max >= 0  :859-860
             const U192 dhi = shr_limb(D);
-            xSLO[c] = D.w[0] & LMASK; xDH0[c] = dhi.w[0]; xDH1[c] = dhi.w[1];
+            sSLO[c] = D.w[0] & LMASK; sDH0[c] = dhi.w[0]; sDH1[c] = dhi.w[1];
         }
         wave_sync();
         for (u32 c = lane; c < C; c += 64) {
-            const U192 S = lim(xSLO[c]) + (c ? U192::make(xDH0[c - 1], xDH1[c - 1], 0) : Z);
-            xSLO[c] = S.w[0] & LMASK;
-            xSHI[c] = (u32)shr_limb(S).w[0];
+            const U192 S = lim(sSLO[c]) + (c ? U192::make(sDH0[c - 1], sDH1[c - 1], 0) : Z);
+            sSLO[c] = S.w[0] & LMASK;
+            sSHI[c] = (u32)shr_limb(S).w[0];
         }
         wave_sync();
+        }
+        if constexpr (NWV > 1) __syncthreads();
+        auto mine = [&](u32 plane) -> bool { return NWV == 1 || plane % NWV == wv; };   // plane: 0 amb, 1 mab, 2 meqb, 3 msum, 4 nq1, 5 cout, 6 cmod
         bool cin = false, all_ok = true;
         for (u32 cb = 0; cb < C; cb += 64) {
             const u32 c = cb + lane;
             const bool col = c < C;
-            const u64 slo = col ? xSLO[c] : 0;
-            const u32 shp = (col && c) ? xSHI[c - 1] : 0;
+            const u64 slo = col ? sSLO[c] : 0;
+            const u32 shp = (col && c) ? sSHI[c - 1] : 0;
             const u128 U = (u128)slo + shp;
             const bool gen = col && (U >> LW) != 0, prop = col && ((u64)U & LMASK) == LMASK;
             const CarryGroup cg = carry_group(__ballot(gen), __ballot(prop), cin, 64);
             const bool f = ((cg.cin_mask >> lane) & 1) != 0;
             cin = cg.cout;
             bool f1 = true, f2 = true;
+            const U192 iA = col ? rdp(pAB, c) : Z, iQ = col ? rdp(pEQB, c) : Z;
+            if constexpr (NWV > 1 && MONT) __syncthreads();   // (the integers of this block are read by every wave before any wave's cells replace them)
             if (col) {
-                const U192 dhp = c ? U192::make(xDH0[c - 1], xDH1[c - 1], 0) : Z;
+                const U192 dhp = c ? U192::make(sDH0[c - 1], sDH1[c - 1], 0) : Z;
                 const U192 carry_in = dhp + lim((u64)shp + (f ? 1u : 0u));
-                const U192 amb = rdp(pAB, c) - rdp(pEQB, c);
+                const U192 amb = iA - iQ;
                 const U192 sum = amb + Wm + carry_in;                          // :860-861
                 const U192 cout = shr_limb(sum);
-                if constexpr (MONT) reinterpret_cast<uint4 *>(smem + lp.icout)[c] = make_uint4((u32)cout.w[0], (u32)(cout.w[0] >> 32), (u32)cout.w[1], (u32)(cout.w[1] >> 32));
-                else wrp(pSUM, c, sum);
+                if (owner) {
+                    if constexpr (MONT) reinterpret_cast<uint4 *>(smem + lp.icout)[c] = make_uint4((u32)cout.w[0], (u32)(cout.w[0] >> 32), (u32)cout.w[1], (u32)(cout.w[1] >> 32));
+                    else wrp(pSUM, c, sum);
+                }
                 const u32 kc = c < 2 ? c : 2;
                 f1 = (sum.w[0] & LMASK) == kt[kc * 10 + 5];                      // cs_acc_eq  :873
                 if (c == C - 1) f2 = cout.w[0] == kt[kc * 10 + 3] && cout.w[1] == kt[kc * 10 + 4];   // final_carry_eq  :890
-                if constexpr (FAST) cell(reinterpret_cast<uint4 *>(smem + lp.amb) + 2 * c, amb, true);   // the ready-made cells of the column
+                if constexpr (FAST) { if (mine(0)) cell(reinterpret_cast<uint4 *>(smem + lp.amb) + 2 * c, amb, true); }   // the ready-made cells of the column
                 if constexpr (FAST && MONT) {
-                    cell(reinterpret_cast<uint4 *>(smem + lp.mab) + 2 * c, rdp(pAB, c), false);
-                    cell(reinterpret_cast<uint4 *>(smem + lp.meqb) + 2 * c, rdp(pEQB, c), false);
-                    cell(reinterpret_cast<uint4 *>(smem + lp.msum) + 2 * c, sum, false);
-                    cell(reinterpret_cast<uint4 *>(smem + lp.nq1) + 2 * c, U192::make(sum.w[0] & ~LMASK, sum.w[1], sum.w[2]), false);
-                    cell(reinterpret_cast<uint4 *>(smem + lp.cout) + 2 * c, cout, false);
-                    cell(reinterpret_cast<uint4 *>(smem + lp.cmod) + 2 * c, lim(sum.w[0] & LMASK), false);
+                    if (mine(1)) cell(reinterpret_cast<uint4 *>(smem + lp.mab) + 2 * c, iA, false);
+                    if (mine(2)) cell(reinterpret_cast<uint4 *>(smem + lp.meqb) + 2 * c, iQ, false);
+                    if (mine(3)) cell(reinterpret_cast<uint4 *>(smem + lp.msum) + 2 * c, sum, false);
+                    if (mine(4)) cell(reinterpret_cast<uint4 *>(smem + lp.nq1) + 2 * c, U192::make(sum.w[0] & ~LMASK, sum.w[1], sum.w[2]), false);
+                    if (mine(5)) cell(reinterpret_cast<uint4 *>(smem + lp.cout) + 2 * c, cout, false);
+                    if (mine(6)) cell(reinterpret_cast<uint4 *>(smem + lp.cmod) + 2 * c, lim(sum.w[0] & LMASK), false);
                 } else if constexpr (FAST && LW == 64) {
+                    if (owner) {
                     cell(reinterpret_cast<uint4 *>(smem + lp.nq1) + 2 * c, U192::make(sum.w[0] & ~LMASK, sum.w[1], sum.w[2]), false);
                     reinterpret_cast<uint4 *>(smem + lp.cout)[c] = make_uint4((u32)cout.w[0], (u32)(cout.w[0] >> 32), (u32)cout.w[1], (u32)(cout.w[1] >> 32));
                     const u64 cm = sum.w[0] & LMASK;
                     reinterpret_cast<uint4 *>(smem + lp.cmod)[c] = make_uint4((u32)cm, (u32)(cm >> 32), 0, 0);
+                    }
                 }
             }
             const u64 bad = __ballot(col && !(f1 && f2));
             const bool prev_ok = all_ok && (bad & ((1ull << lane) - 1)) == 0;
-            if (col) {
+            if (col && owner) {
                 const u32 e1 = (prev_ok && f1) ? 1u : 0u, e2 = (e1 && f2) ? 1u : 0u;
                 pFL[c] = (u8)((f1 ? 1u : 0u) | (e1 << 1) | ((f2 ? 1u : 0u) << 2) | (e2 << 3));
             }
             all_ok = all_ok && bad == 0;
         }
         item_ok = all_ok;
-        if constexpr (NWV > 1) { if (lane == 0) pFL[2 * L - 1] = all_ok ? 1 : 0; }   // (for the other waves: the byte behind the last column's)
-        wave_sync();
+        if constexpr (NWV > 1) { if (owner && lane == 0) pFL[2 * L - 1] = all_ok ? 1 : 0; }   // (read again by the other waves behind the phase's barrier)
+        if constexpr (NWV > 1) __syncthreads(); else wave_sync();
     };
 
     const u32 mul_rows = C + L * L, r_T3 = 4 * L, r_T5 = r_T3 + 2 * mul_rows, r_T6 = r_T5 + L + 4;
@@ -829,7 +845,7 @@ __global__ __launch_bounds__(64 * NWV) void cells_kernel(CellsArgs a) {
         const u64 v_range = id.sect == 0 ? (id.i < L ? sq[id.i] : sr[id.i - L]) : 0;
         if (!(ABL & 8) && !columns_done && r0 + n_rows >= r_T5) {   // every mul row is built: the columns' carries before any row that needs them
             wave_sync();
-            column_phase();
+            column_phase(true);
             columns_done = true;
         }
         // ---- the other sections: range rows, eq_b, the is_equal_muled preamble and its column rows ----
@@ -999,7 +1015,7 @@ __global__ __launch_bounds__(64 * NWV) void cells_kernel(CellsArgs a) {
         for (u32 ph = 0; ph < 3; ++ph) {
             u32 lo, hi;
             if (ph == 0) { const u32 per = (cb + NWV - 1) / NWV; lo = wv * per; hi = lo + per < cb ? lo + per : cb; }
-            else if (ph == 1) { lo = cb; hi = wv == 0 ? cb + 1 : cb; }
+            else if (ph == 1) { lo = cb; hi = wv == 0 ? cb + 1 : cb; if (wv != 0) column_phase(false); }   // (the column phase is every wave's)
             else { const u32 m = NC - cb - 1, per = (m + NWV - 1) / NWV; lo = cb + 1 + wv * per; hi = lo + per < NC ? lo + per : NC; }
             if (ph == 2) { columns_done = true; item_ok = pFL[2 * L - 1] != 0; }
             for (u32 j = lo; j < hi; ++j) {
