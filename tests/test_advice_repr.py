@@ -186,7 +186,7 @@ def test_mul_mod_and_pow_images_in_every_representation(H, w, L, field):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,L,field", [(64, 32, "bn254_fr"), (32, 16, "pasta_fq"), (64, 12, "bn254_fq")])
+@pytest.mark.parametrize("w,L,field", [(64, 32, "bn254_fr"), (32, 16, "pasta_fq"), (64, 12, "bn254_fq"), (64, 64, "bn254_fr"), (32, 96, "pasta_fp")])
 def test_inconsistent_mul_mod_in_every_representation(H, w, L, field):
     """Records whose q, r are NOT the quotient and remainder (R plane bumped by one; a second element with its Q plane bumped): the
     direct kernel leaves its fast rows for the general path (d = x - y != 0, the inverse witness, eq_bit 0, the carries of a
