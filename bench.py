@@ -667,7 +667,7 @@ def sub_run_lines(args):
     out["plain_allocations"] = {"what": "this line's workload with every buffer as hipMalloc hands it out (no arena, no candidates)", "value": d.get("value"),
                                 "frac": d.get("roofline", {}).get("frac"), "whole_path_hbm_frac": d.get("whole_path_hbm_frac"), "wall_s": d.get("_wall_s"), "error": d.get("error")}
     for key, extra in (("advice", []), ("advice_columns_montgomery", ["--columns", "--montgomery"]), ("advice_verify_element", ["--verify"])):
-        d = sub_run(st + ["--advice", "--placement-candidates", "8"] + extra)
+        d = sub_run(st + ["--advice"] + extra)     # (the default look: 16 candidate images; with 8 the kept pair is 0.2 ms slower on most boxes)
         what = {"advice": "row-major canonical", "advice_columns_montgomery": "planar Montgomery-form",
                 "advice_verify_element": "whole verify_pkcs1v15_signature element's (is_eq + assert_in_field + pow + encoded-message rows) row-major canonical"}[key]
         out[key] = {"what": "bench.py --advice %s: elements/s of the %s advice image (12.3 MB each), cells_kernel" % (" ".join(extra), what),
