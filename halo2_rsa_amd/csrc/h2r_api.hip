@@ -3595,6 +3595,7 @@ int32_t h2r_pipeline_verify_pkcs1v15_advice(h2r_pipeline *p, const void *sig, co
                                             uint8_t *is_valid_out, uint8_t *status, void *workspace, void *advice_out, uint64_t out_stride,
                                             h2r_stream_t stream) try {
     if (!p || !sig || !n || !e_le || !hashed || !witness || !powed_out || !status || !workspace || !advice_out) return H2R_E_NULL;
+    if (reinterpret_cast<u64>(witness) & 15) return H2R_E_SHAPE;   // (16-byte stores into the witness sections)
     const h2r_ctx *ctx = p->ctx;
     h2r_verify_layout full, vl;
     int32_t rc = h2r_verify_layout_fixed(ctx, e_le, e_len, &full);

@@ -920,7 +920,7 @@ int32_t h2r_pipeline_modpow_public_key_advice(h2r_pipeline *p, const void *x, co
  * h2r_pipeline_modpow_public_key_advice produces its two sections: the chains, powed_out, the in-field / encoded-message witness,
  * is_valid_out, status and the three short row programs on `stream`; the pow rows (cells_kernel) on a side stream of the pipeline next
  * to the chains of the following call.  The image follows the pipeline's join rule; everything else is stream-ordered.
- * witness: batch * h2r_verify_layout_compact(...).elem_stride bytes -- the element's in-field and EM witness, the only part of a verify
+ * witness (16-byte aligned): batch * h2r_verify_layout_compact(...).elem_stride bytes -- the element's in-field and EM witness, the only part of a verify
  * element's trace the rows need (9,984 B instead of 1.26 MB per RSA-2048 element).  h2r_verify_layout_compact turns a verify layout into
  * that form (off_in_field = 0, off_em, elem_stride; `pow` unchanged); with it h2r_verify_emit_advice (flags | H2R_ADVICE_DIRECT,
  * trace = the witness), h2r_verify_advice_rows and h2r_verify_row_kinds work as with the full layout.
