@@ -808,6 +808,23 @@ class Pipeline:
                                                  is_valid.data_ptr(), status.data_ptr(), workspace.data_ptr(), self.chip._stream()),
               "h2r_pipeline_verify_pkcs1v15")
 
+    def modpow_public_key_var_advice(self, x: AssignedInteger, e: AssignedInteger, exp_limb_bits: int, n: AssignedInteger, workspace, out, status,
+                                     in_field_buf, witness, advice_out):
+        """RSAPubE::Var without records (h2r_pipeline_modpow_public_key_var_advice): `witness` uint8 [batch, pow_var_compact_layout().elem_stride]
+        keeps the exponent bits, the selected operands and the result; advice_out as for modpow_public_key_advice."""
+        check(lib().h2r_pipeline_modpow_public_key_var_advice(self._p, x.data_ptr(), e.data_ptr(), e.num_limbs(), exp_limb_bits, n.data_ptr(), x.batch,
+                                                              self.chip._flags(n, x.batch), in_field_buf.data_ptr(), witness.data_ptr(), out.data_ptr(),
+                                                              status.data_ptr(), workspace.data_ptr(), advice_out.data_ptr(),
+                                                              advice_out.shape[-1] if advice_out.dim() > 1 else advice_out.numel() // x.batch,
+                                                              self.chip._stream()), "h2r_pipeline_modpow_public_key_var_advice")
+
+    def pow_var_compact_layout(self, e_num_limbs: int, exp_limb_bits: int) -> H2RPowLayout:
+        """h2r_pow_layout_compact of the Var pow layout: elem_stride = witness bytes per element."""
+        full, pl = H2RPowLayout(), H2RPowLayout()
+        check(lib().h2r_pow_var_layout(self.chip._ctx, e_num_limbs, exp_limb_bits, ctypes.byref(full)), "h2r_pow_var_layout")
+        check(lib().h2r_pow_layout_compact(self.chip._ctx, ctypes.byref(full), ctypes.byref(pl)), "h2r_pow_layout_compact")
+        return pl
+
     def verify_pkcs1v15_advice(self, sig: AssignedInteger, e: int, n: AssignedInteger, hashed, witness, workspace, powed, is_valid, status, advice_out):
         """The whole verify_pkcs1v15_signature element as advice rows WITHOUT records (h2r_pipeline_verify_pkcs1v15_advice): chains, the
         in-field / encoded-message witness, is_valid and the three short row programs on the current stream, the pow rows (cells_kernel) on

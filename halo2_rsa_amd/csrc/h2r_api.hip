@@ -402,6 +402,9 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         sg.owned = true; ws = static_cast<u8 *>(sg.p);
     }
     ws = reinterpret_cast<u8 *>(round_up(reinterpret_cast<u64>(ws), 256));
+    // off_records = UINT64_MAX: a witness-only element (h2r_pow_layout_compact) -- the chain kernel leaves what it writes into a trace
+    // (a Var element's exponent bits and selected operands, the result), no record kernel follows
+    const bool records = trace && T && off_records != UINT64_MAX;
     ChainArgs ca;
     std::memset(&ca, 0, sizeof ca);
     ca.a = static_cast<const u32 *>(a); ca.b = static_cast<const u32 *>(b); ca.n = static_cast<const u32 *>(n);
@@ -420,7 +423,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
     }
     if (eb) ca.e = *eb;
     if (seg) { ca.state = reinterpret_cast<u32 *>(ws + wp.off_state); ca.bit_lo = seg->bit_lo; ca.bit_hi = seg->bit_hi; ca.t_base = seg->t_lo; }
-    u8 *n_copy = trace && T ? (n_copy_at ? static_cast<u8 *>(n_copy_at) : ws + wp.off_n) : nullptr;
+    u8 *n_copy = records ? (n_copy_at ? static_cast<u8 *>(n_copy_at) : ws + wp.off_n) : nullptr;
     ca.n_copy = reinterpret_cast<u32 *>(n_copy);
     // 128-digit chains (RSA-4096 at 64-bit limbs) are the longer leg next to their record kernel: their waves get issue
     // priority there (1.00 -> 1.05 M assigns/s; no effect measured for the shorter chains)
@@ -432,7 +435,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
     // recip_kernel in front of the chain kernel makes the chain kernel start 17 us AFTER the record kernel it shares the CUs
     // with instead of together with it, and the record kernel -- the longer leg -- then runs 0.195 -> 0.209 ms (same-box A/B,
     // bench.py --shared-modulus: 4.49 -> 4.8 M assigns/s without the precomputation).
-    const bool chain_hidden = trace_st && trace && T && (lo.limb_width == 32 || c->L <= 32);
+    const bool chain_hidden = trace_st && records && (lo.limb_width == 32 || c->L <= 32);
     if ((flags & H2R_F_SHARED_MODULUS) && batch > 1 && !chain_hidden)
         ca.pre = reinterpret_cast<const u32 *>(shared_pre ? static_cast<u8 *>(shared_pre) : ws + wp.off_pre);
     // Pipeline mode: the record stream must wait for this chain kernel.  The event it waits on is the dispatch's own
@@ -445,7 +448,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
     if (args_only) args_only->ca = ca;
     else {
         ProfScope ps(H2R_KERNEL_CHAIN, st, true);
-        const bool piped = trace_st && trace && T;
+        const bool piped = trace_st && records;
         chain_wait = ps.on ? ps.b : (piped ? chain_done : nullptr);
         if (c->K > 128) return H2R_E_UNSUPPORTED;
         HIP_TRY(launch_chain(c, ca, trace_st != nullptr, st, ps.a, chain_wait));
@@ -458,7 +461,7 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
         if (f) { for (int i = 0; i < 4000 && host[i]; ++i) std::fprintf(f, "%llu\n", (unsigned long long)host[i]); std::fclose(f); }
     }
 #endif
-    if (trace && T) {
+    if (records) {
         TraceArgs ta;
         fill_trace_args(c, ta);
         const u64 lb = lo.limb_width / 8;   // the four values of an item are L limbs apart
@@ -3642,6 +3645,78 @@ int32_t h2r_pipeline_verify_pkcs1v15_advice(h2r_pipeline *p, const void *sig, co
     HIP_TRY(hipStreamWaitEvent(side, p->chain_done[slot], 0));
     rc = pow_emit_advice(ctx, &vl.pow, ws + wp.off_n, (flags & H2R_F_SHARED_MODULUS) | H2R_ADVICE_DIRECT, nullptr, 0, workspace, batch, status,
                          dst.at_row(sec[0] + sec[1]), static_cast<h2r_stream_t>(side));   // pow_mod_fixed_exp, :111
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(p->trace_done[slot], side));
+    p->done[slot] = DoneRef{p->trace_done[slot], 0, false};
+    p->done_stream[slot] = side;
+    p->k += 1;
+    for (; p->joined + p->depth <= p->k; ++p->joined) {
+        rc = pipeline_wait_slot(p, p->joined % p->depth, st);
+        if (rc) return rc;
+    }
+    return H2R_OK;
+} H2R_CATCH_STATUS
+
+// ---- RSAPubE::Var (src/chip.rs:108-110) without records -------------------------------------------------------------------
+// The witness-only form of a pow layout: a Var element keeps its exponent bits, its selected operands and its result (what the to_bits /
+// select rows read) and no record planes; a Fix element keeps its result.  off_records = UINT64_MAX marks the absence.
+int32_t h2r_pow_layout_compact(const h2r_ctx *ctx, const h2r_pow_layout *full, h2r_pow_layout *out) try {
+    if (!ctx || !full || !out) return H2R_E_NULL;
+    const u64 limbs_bytes = (u64)ctx->L * ctx->layout.limb_bytes;
+    *out = *full;
+    out->off_records = UINT64_MAX;
+    const bool var = full->off_e_bits != UINT64_MAX;
+    u64 o = 0;
+    if (var) { out->off_selected = 0; out->selected_stride = limbs_bytes; o = (u64)full->num_exp_bits * limbs_bytes; }
+    out->off_result = o; o += limbs_bytes;
+    if (var) { out->off_e_bits = o; o += full->num_exp_bits; }
+    out->elem_stride = round_up(o, 256);
+    return H2R_OK;
+} H2R_CATCH_STATUS
+
+// h2r_pipeline_modpow_public_key_advice for the Var arm: per-element exponents (pow_mod, big_integer/chip.rs:664-696).  `witness`: batch *
+// h2r_pow_layout_compact(h2r_pow_var_layout(...)).elem_stride bytes.  The to_bits / select rows are written next to the cells kernel.
+int32_t h2r_pipeline_modpow_public_key_var_advice(h2r_pipeline *p, const void *x, const void *e_limbs, uint32_t e_num_limbs, uint32_t exp_limb_bits,
+                                                  const void *n, uint64_t batch, uint32_t flags, void *in_field_trace, void *witness, void *out,
+                                                  uint8_t *status, void *workspace, void *advice_out, uint64_t out_stride, h2r_stream_t stream) try {
+    if (!p || !x || !e_limbs || !n || !in_field_trace || !witness || !status || !workspace || !advice_out) return H2R_E_NULL;
+    if (reinterpret_cast<u64>(witness) & 15) return H2R_E_SHAPE;
+    const h2r_ctx *ctx = p->ctx;
+    h2r_pow_layout full, pl;
+    int32_t rc = h2r_pow_var_layout(ctx, e_num_limbs, exp_limb_bits, &full);
+    if (rc) return rc;
+    if ((rc = h2r_pow_layout_compact(ctx, &full, &pl))) return rc;
+    u64 sec[2];
+    const u64 rows = h2r_modpow_public_key_advice_rows(ctx, &pl, sec);
+    if (!rows) return H2R_E_UNSUPPORTED;
+    AdviceDst dst;
+    if ((rc = advice_dst(ctx, advice_out, out_stride, rows, batch, &dst))) return rc;
+    if (batch == 0) return H2R_OK;
+    H2R_ON_DEVICE(ctx->params.device);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (p->pending) {   // records still owed by a call of another form: they go out alone, `st` behind them
+        rc = pipeline_flush(p, st);
+        if (rc) return rc;
+    }
+    const u32 slot = p->k % p->depth;
+    p->done[slot] = DoneRef{};
+    rc = run_path(ctx, CHAIN_POW_VAR, x, nullptr, n, e_limbs, e_num_limbs, exp_limb_bits, nullptr, 1, batch, flags, pl.num_mul_mods, witness,
+                  pl.elem_stride, pl.off_records, &pl, out, status, workspace, st);
+    if (rc) return rc;
+    if ((rc = launch_in_field(ctx, x, n, batch, flags, in_field_trace, st))) return rc;
+    const h2r_layout &lo = ctx->layout;
+    const Workspace wp = workspace_plan(lo.limb_bytes, ctx->L, batch, pl.num_mul_mods ? pl.num_mul_mods : 1);
+    u8 *ws = reinterpret_cast<u8 *>(round_up(reinterpret_cast<u64>(workspace), 256));
+    const bool shared = (flags & H2R_F_SHARED_MODULUS) != 0;
+    HIP_TRY(hipMemcpyAsync(ws + wp.off_n, n, (shared ? 1ull : batch) * ctx->L * lo.limb_bytes, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipEventRecord(p->chain_done[slot], st));
+    rc = fresh_emit_advice(ctx, FRESH_IS_IN_FIELD, (flags & H2R_F_SHARED_MODULUS) | H2R_ADVICE_ASSERT_ONE, x, n, nullptr, in_field_trace, 0, 0,
+                           batch, status, &dst, nullptr, 0, stream);
+    if (rc) return rc;
+    hipStream_t side = p->aux[p->k & 1];
+    HIP_TRY(hipStreamWaitEvent(side, p->chain_done[slot], 0));
+    rc = pow_emit_advice(ctx, &pl, ws + wp.off_n, (flags & H2R_F_SHARED_MODULUS) | H2R_ADVICE_DIRECT, witness, pl.elem_stride, workspace, batch, status,
+                         dst.at_row(sec[0]), static_cast<h2r_stream_t>(side));
     if (rc) return rc;
     HIP_TRY(hipEventRecord(p->trace_done[slot], side));
     p->done[slot] = DoneRef{p->trace_done[slot], 0, false};

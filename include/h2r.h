@@ -931,6 +931,18 @@ int32_t h2r_pipeline_verify_pkcs1v15_advice(h2r_pipeline *p, const void *sig, co
                                             const uint64_t *hashed, uint64_t batch, uint32_t flags, void *witness, void *powed_out,
                                             uint8_t *is_valid_out, uint8_t *status, void *workspace, void *advice_out,
                                             uint64_t out_stride, h2r_stream_t stream);
+/* The RSAPubE::Var arm (src/chip.rs:108-110; pow_mod, big_integer/chip.rs:664-696) of h2r_pipeline_modpow_public_key_advice: per-element
+ * exponents, no records.  A Var element's to_bits / select rows read its exponent bits and selected operands: they are kept -- with the
+ * result -- in `witness`, batch * h2r_pow_layout_compact(h2r_pow_var_layout(...)).elem_stride bytes (16-byte aligned), the witness-only
+ * form of a pow layout (off_records = UINT64_MAX: no record planes; for a Fix layout just the result).  A compact layout is accepted by
+ * h2r_pow_advice_rows, h2r_pow_row_kinds, h2r_modpow_public_key_advice_rows and -- with H2R_ADVICE_DIRECT and the witness as `trace` --
+ * h2r_pow_trace_emit_advice / h2r_modpow_public_key_emit_advice; the record exports (flatten, check, hist, emit_stream) need the full one.
+ * Rows: [assert_in_field][to_bits rows of every exponent limb][CONST1, CONST0][per bit: two mul_mods' rows + the select rows]. */
+int32_t h2r_pow_layout_compact(const h2r_ctx *ctx, const h2r_pow_layout *full, h2r_pow_layout *out);
+int32_t h2r_pipeline_modpow_public_key_var_advice(h2r_pipeline *p, const void *x, const void *e_limbs, uint32_t e_num_limbs,
+                                                  uint32_t exp_limb_bits, const void *n, uint64_t batch, uint32_t flags,
+                                                  void *in_field_trace, void *witness, void *out, uint8_t *status, void *workspace,
+                                                  void *advice_out, uint64_t out_stride, h2r_stream_t stream);
 uint32_t h2r_advice_rows(const h2r_ctx *ctx);
 int32_t h2r_mul_mod_emit_advice(const h2r_ctx *ctx, const void *a, const void *b, const void *n, uint32_t flags,
                                 const void *trace, uint64_t batch, const uint8_t *status, void *advice_out,

@@ -497,6 +497,7 @@ class RSAChip {
     RSAChip(uint32_t bits_len, uint32_t exp_limb_bits, uint32_t field = H2R_FIELD_BN254_FR, int device = 0)
         : bits_len_(bits_len), exp_limb_bits_(exp_limb_bits), bigint_(LIMB_WIDTH, bits_len, field, device) {}
     const BigIntChip &bigint_chip() const { return bigint_; }  // src/chip.rs:224-230
+    uint32_t exp_limb_bits() const { return exp_limb_bits_; }
     // src/chip.rs:249-254
     static std::pair<std::vector<uint32_t>, std::vector<uint32_t>> compute_range_lens(uint32_t num_limbs) {
         std::vector<uint32_t> c(4), o(3);
@@ -745,6 +746,24 @@ class Pipeline {
                                                     (pk.n.batch() == 1 && batch != 1) ? H2R_F_SHARED_MODULUS : 0u, in_field.get(), b.powed.get(),
                                                     static_cast<uint8_t *>(b.status.get()), b.workspace.get(), advice.get(), advice_stride, stream),
               "h2r_pipeline_modpow_public_key_advice");
+    }
+    // The RSAPubE::Var arm of modpow_public_key_advice (src/chip.rs:108-110): per-element exponents, no records; `witness` keeps the exponent
+    // bits, the selected operands and the result: batch * compact_pow_layout(...).elem_stride bytes.
+    static h2r_pow_layout compact_pow_layout(const RSAChip &chip, uint32_t e_num_limbs) {
+        h2r_pow_layout full, pl;
+        check(h2r_pow_var_layout(chip.bigint_chip().ctx(), e_num_limbs, chip.exp_limb_bits(), &full), "h2r_pow_var_layout");
+        check(h2r_pow_layout_compact(chip.bigint_chip().ctx(), &full, &pl), "h2r_pow_layout_compact");
+        return pl;
+    }
+    void modpow_public_key_var_advice(const AssignedInteger &x, const AssignedRSAPublicKey &pk, Buffers &b, DeviceBuffer &in_field, DeviceBuffer &witness,
+                                      DeviceBuffer &advice, uint64_t advice_stride, hipStream_t stream = nullptr) {
+        auto *v = std::get_if<AssignedInteger>(&pk.e);
+        if (!v) throw Error(H2R_E_UNSUPPORTED, "Pipeline::modpow_public_key_var_advice (takes RSAPubE::Var)");
+        const size_t batch = x.batch();
+        check(h2r_pipeline_modpow_public_key_var_advice(p_, x.data(), v->data(), (uint32_t)v->num_limbs(), chip_.exp_limb_bits(), pk.n.data(), batch,
+                                                        (pk.n.batch() == 1 && batch != 1) ? H2R_F_SHARED_MODULUS : 0u, in_field.get(), witness.get(),
+                                                        b.powed.get(), static_cast<uint8_t *>(b.status.get()), b.workspace.get(), advice.get(),
+                                                        advice_stride, stream), "h2r_pipeline_modpow_public_key_var_advice");
     }
     // The WHOLE RSAInstructions::verify_pkcs1v15_signature element (src/chip.rs:128-199) as advice rows without records
     // ([is_eq seed][assert_in_field][pow rows][encoded-message check]: h2r_verify_advice_rows rows per element): chains, witness, is_valid and

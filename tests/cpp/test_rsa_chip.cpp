@@ -226,6 +226,32 @@ int main(int argc, char **argv) {
                 for (size_t i = 0; i < B; ++i) REQUIRE(valid[i] == kats[i].is_valid);
             }
         }
+        // ... and the RSAPubE::Var arm without records (h2r_pipeline_modpow_public_key_var_advice): = the image of the call with records
+        {
+            std::vector<uint64_t> ev(B);
+            for (size_t i = 0; i < B; ++i) ev[i] = 17 + 3 * i;
+            RSAPublicKey pkv_u{UnassignedInteger::from(n_limbs, B, 32), RSAPubE{RSAPubE::Var{UnassignedInteger::from(ev, B, 1)}}};
+            AssignedRSAPublicKey pkv = rsa_chip.assign_public_key(pkv_u);
+            ModpowResult mv = rsa_chip.modpow_public_key(sign.c, pkv);
+            uint64_t secv[2];
+            const uint64_t vrows = rsa_chip.advice_rows(mv, secv);
+            DeviceBuffer want = rsa_chip.emit_advice(mv, sign.c, pkv);
+            std::vector<uint8_t> wa(B * vrows * H2R_ADVICE_ROW_BYTES), ga(wa.size());
+            want.download(wa.data(), wa.size());
+            Pipeline vp(rsa_chip, 2, 2);
+            const h2r_pow_layout cl = Pipeline::compact_pow_layout(rsa_chip, 1);
+            REQUIRE(cl.off_records == UINT64_MAX && cl.num_mul_mods == mv.pow.pow_layout.num_mul_mods);
+            Pipeline::Buffers vb2[2] = {vp.make_buffers(B, {0x01, 0x00, 0x01}), vp.make_buffers(B, {0x01, 0x00, 0x01})};
+            uint64_t es2 = 0;
+            REQUIRE(h2r_fresh_op_layout(bigint_chip.ctx(), H2R_OP_IS_IN_FIELD, &es2, nullptr, nullptr) == H2R_OK);
+            const uint64_t vstride = vrows * (uint64_t)H2R_ADVICE_ROW_BYTES;
+            DeviceBuffer inf3[2] = {DeviceBuffer(B * es2), DeviceBuffer(B * es2)}, wit3[2] = {DeviceBuffer(B * cl.elem_stride), DeviceBuffer(B * cl.elem_stride)};
+            DeviceBuffer adv3[2] = {DeviceBuffer(B * vstride), DeviceBuffer(B * vstride)};
+            for (int k = 0; k < 3; ++k) vp.modpow_public_key_var_advice(sign.c, pkv, vb2[k & 1], inf3[k & 1], wit3[k & 1], adv3[k & 1], vstride);
+            vp.join();
+            REQUIRE(hipDeviceSynchronize() == hipSuccess);
+            for (int s2 = 0; s2 < 2; ++s2) { adv3[s2].download(ga.data(), ga.size()); REQUIRE(ga == wa); }
+        }
         BatchResult pw = bigint_chip.pow_mod_fixed_exp(sign.c, {0x01, 0x00, 0x01}, pk.n);
         REQUIRE(bigint_chip.advice_rows(pw) == 75489);
         DeviceBuffer p1 = bigint_chip.emit_advice(pw, pk.n), p2 = bigint_chip.emit_advice(pw, pk.n, true);

@@ -179,3 +179,95 @@ def test_pipelined_verify_image_passes_the_device_mockprover(H, golden, repr_kw)
         bad, first = chip.advice_check(kinds, img, B, copies=copies, src_a=sig_d, src_n=n_d, lookup=look)
         b = bad.cpu().tolist()
         assert b[2] > 0 and b[4] > 0 and b[0] == b[1] == b[3] == b[5] == 0, b
+
+
+# ---- RSAPubE::Var without records (h2r_pipeline_modpow_public_key_var_advice) ----------------------------------------------------------
+def test_pow_compact_layout_on_the_host():
+    """h2r_pow_layout_compact: the counts untouched, no record planes (off_records = UINT64_MAX), the Var element's selected operands /
+    result / exponent bits packed from offset 0; a Fix layout keeps its result only."""
+    from halo2_rsa_amd import _lib
+    from halo2_rsa_amd._lib import lib
+    ctx = ctypes.c_void_p()
+    p = _lib.H2RParams(64, 2048, 0, -1)
+    assert lib().h2r_ctx_create(ctypes.byref(p), ctypes.byref(ctx)) == 0
+    full, pl = _lib.H2RPowLayout(), _lib.H2RPowLayout()
+    assert lib().h2r_pow_var_layout(ctx, 1, 5, ctypes.byref(full)) == 0
+    assert lib().h2r_pow_layout_compact(ctx, ctypes.byref(full), ctypes.byref(pl)) == 0
+    assert (pl.num_mul_mods, pl.num_exp_bits, pl.exp_limb_bits, pl.e_num_limbs, pl.stream_bytes) == (10, 5, 5, 1, full.stream_bytes)
+    assert pl.off_records == 2 ** 64 - 1 and pl.off_selected == 0 and pl.selected_stride == 256
+    assert pl.off_result == 5 * 256 and pl.off_e_bits == 6 * 256 and pl.elem_stride == 7 * 256 < full.elem_stride
+    assert lib().h2r_pow_advice_rows(ctx, ctypes.byref(pl)) == lib().h2r_pow_advice_rows(ctx, ctypes.byref(full))
+    e = (65537).to_bytes(3, "little")
+    assert lib().h2r_pow_fixed_layout(ctx, e, len(e), ctypes.byref(full)) == 0
+    assert lib().h2r_pow_layout_compact(ctx, ctypes.byref(full), ctypes.byref(pl)) == 0
+    assert pl.off_e_bits == 2 ** 64 - 1 and pl.off_result == 0 and pl.elem_stride == 256 and pl.num_mul_mods == 19
+    assert lib().h2r_pow_layout_compact(ctx, None, ctypes.byref(pl)) == _lib.H2R_E_NULL
+    lib().h2r_ctx_destroy(ctx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("repr_kw", [dict(), dict(columns=True, montgomery=True)])
+def test_pipelined_var_arm_image_is_the_record_based_image(H, repr_kw):
+    """RSAChip::modpow_public_key with RSAPubE::Var (the arm the reference's TestRSASignatureCircuit2 takes: src/chip.rs:283, 327 use a 5-bit
+    e) as advice rows without records: three pipelined calls over two buffer sets, per-element exponents (all-zero among them), one element
+    not in the field -- result, status and every byte of every image equal h2r_modpow_public_key_var_batch + h2r_modpow_public_key_emit_advice
+    (pinned against the Python restatement on the oracle's Var stream in tests/test_cells_direct.py); h2r_advice_check passes on it."""
+    from halo2_rsa_amd import _lib
+    from halo2_rsa_amd._lib import lib
+    nb, n_el = 5, 2
+    rsa = H.RSAChip(2048, nb, **repr_kw)
+    chip = rsa.bigint_chip()
+    rng = random.Random(77)
+    B, depth, calls_n = 5, 2, 3
+    pipe = H.Pipeline(chip, depth, 2)
+    pl = pipe.pow_var_compact_layout(n_el, nb)
+    sec = (ctypes.c_uint64 * 2)()
+    rows = int(lib().h2r_modpow_public_key_advice_rows(chip._ctx, ctypes.byref(pl), sec))
+    ifs = chip.in_field_layout()[0]
+    sets = [dict(ws=torch.empty(chip.workspace_bytes(B, pl.num_mul_mods), dtype=torch.uint8, device="cuda"),
+                 wit=torch.zeros((B, pl.elem_stride), dtype=torch.uint8, device="cuda"), inf=torch.zeros(B * ifs, dtype=torch.uint8, device="cuda"),
+                 out=torch.zeros((B, chip.num_limbs), dtype=torch.int64, device="cuda"), st=torch.zeros(B, dtype=torch.uint8, device="cuda"),
+                 img=torch.empty((B, chip.image_bytes(rows)), dtype=torch.uint8, device="cuda")) for _ in range(depth)]
+    calls, got = [], []
+    for k in range(calls_n):
+        N = [rand_modulus(rng, 2048) for _ in range(B)]
+        X = [rng.randrange(n) for n in N]
+        E = [[rng.getrandbits(nb) for _ in range(n_el)] for _ in range(B)]
+        E[1] = [0] * n_el
+        E[2] = [0b10001, 0b00010]
+        if k == 1:
+            X[3] = N[3] + 2
+        calls.append((X, E, N))
+        s = sets[k % depth]
+        if k >= depth:
+            got.append((k - depth, {key: v.clone() for key, v in s.items() if key != "ws"}))
+        s["img"].fill_(0x5A)
+        e_dev = chip.assign_integer(H.UnassignedInteger(np.array(E, dtype=np.uint64)))
+        pipe.modpow_public_key_var_advice(chip.assign_integer(X), e_dev, nb, chip.assign_integer(N), s["ws"], s["out"], s["st"], s["inf"], s["wit"], s["img"])
+    pipe.join()
+    for k in range(calls_n - depth, calls_n):
+        got.append((k, {key: v.clone() for key, v in sets[k % depth].items() if key != "ws"}))
+    pipe.close()
+    torch.cuda.synchronize()
+    look = H.LookupArgument(chip, rsa_chip=True)
+    for k, g in got:
+        X, E, N = calls[k]
+        pkv = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(N, 32, 64), H.Var(H.UnassignedInteger(np.array(E, dtype=np.uint64)))))
+        rv = rsa.modpow_public_key(chip.assign_integer(X), pkv)
+        want = rv.emit_modpow_advice()
+        assert torch.equal(g["st"], rv.status), k
+        ok = (rv.status == 0)
+        assert want.shape == g["img"].shape and torch.equal(g["img"][ok], want[ok]), k
+        if k == 1:
+            assert int(g["st"][3]) == H.H2R_E_NOT_IN_FIELD and bool((g["img"][3] == 0x5A).all())
+        for i in range(B):
+            if int(g["st"][i]) == 0:
+                e_int = sum(v << (nb * j) for j, v in enumerate(E[i]))
+                got_int = int.from_bytes(g["out"][i].cpu().numpy().tobytes(), "little")
+                assert got_int == (pow(X[i], e_int, N[i]) if e_int else 1), (k, i)     # big_pow_mod returns 1 for e = 0 (utils.rs:2-17)
+        # the device MockProver on the records-free image
+        k_if = chip.fresh_op_row_kinds(_lib.FRESH_OPS.index("is_in_field"), assert_one=True)
+        k_pow = np.zeros(int(sec[1]), dtype=np.uint8)
+        assert lib().h2r_pow_row_kinds(chip._ctx, ctypes.byref(pl), k_pow.ctypes.data) == 0
+        bad, first = chip.advice_check(np.concatenate([k_if, k_pow]), g["img"], B, status=g["st"], lookup=look)
+        assert bad.cpu().tolist() == [0] * B, (k, bad.cpu().tolist(), [hex(v) for v in first.cpu().tolist()])
