@@ -837,6 +837,22 @@ class Pipeline:
                                                         advice_out.shape[-1] if advice_out.dim() > 1 else advice_out.numel() // sig.batch,
                                                         self.chip._stream()), "h2r_pipeline_verify_pkcs1v15_advice")
 
+    def verify_pkcs1v15_var_advice(self, sig: AssignedInteger, e: AssignedInteger, exp_limb_bits: int, n: AssignedInteger, hashed, witness, workspace, powed,
+                                   is_valid, status, advice_out):
+        """The RSAPubE::Var arm of verify_pkcs1v15_advice (h2r_pipeline_verify_pkcs1v15_var_advice); `witness` sized by verify_compact_layout_var."""
+        check(lib().h2r_pipeline_verify_pkcs1v15_var_advice(self._p, sig.data_ptr(), n.data_ptr(), e.data_ptr(), e.num_limbs(), exp_limb_bits, hashed.data_ptr(),
+                                                            sig.batch, self.chip._flags(n, sig.batch), witness.data_ptr(), powed.data_ptr(), is_valid.data_ptr(),
+                                                            status.data_ptr(), workspace.data_ptr(), advice_out.data_ptr(),
+                                                            advice_out.shape[-1] if advice_out.dim() > 1 else advice_out.numel() // sig.batch,
+                                                            self.chip._stream()), "h2r_pipeline_verify_pkcs1v15_var_advice")
+
+    def verify_compact_layout_var(self, e_num_limbs: int, exp_limb_bits: int):
+        from ._lib import H2RVerifyLayout
+        full, vl = H2RVerifyLayout(), H2RVerifyLayout()
+        check(lib().h2r_verify_layout_var(self.chip._ctx, e_num_limbs, exp_limb_bits, ctypes.byref(full)), "h2r_verify_layout_var")
+        check(lib().h2r_verify_layout_compact(self.chip._ctx, ctypes.byref(full), ctypes.byref(vl)), "h2r_verify_layout_compact")
+        return vl
+
     def verify_compact_layout(self, e: int):
         """h2r_verify_layout_compact of the fixed exponent's verify layout: elem_stride = bytes of witness per element; rows via
         h2r_verify_advice_rows."""

@@ -3587,21 +3587,33 @@ int32_t h2r_verify_layout_compact(const h2r_ctx *ctx, const h2r_verify_layout *f
     out->off_in_field = 0;
     out->off_em = round_up(g.in_field_sz(), 256);
     out->elem_stride = round_up(out->off_em + g.em_sz(), 256);
+    if (full->pow.off_e_bits != UINT64_MAX) {   // a Var element: its pow witness (selected operands, result, exponent bits) behind the EM region
+        h2r_pow_layout pc;
+        const int32_t rc = h2r_pow_layout_compact(ctx, &full->pow, &pc);
+        if (rc) return rc;
+        const u64 base = out->elem_stride;
+        pc.off_selected += base; pc.off_result += base; pc.off_e_bits += base;
+        out->elem_stride = base + pc.elem_stride;
+        pc.elem_stride = out->elem_stride;
+        out->pow = pc;
+    }
     return H2R_OK;
 } H2R_CATCH_STATUS
 
 // Pipelined like h2r_pipeline_modpow_public_key_advice: the chains, powed_out, the in-field / encoded-message witness, is_valid and the
 // three short row programs (is_eq seed, assert_in_field, the encoded-message check) of call k on the caller's stream; its pow rows
 // (cells_kernel, from the operands in the workspace) on a side stream of the pipeline, next to the chains of call k + 1.
-int32_t h2r_pipeline_verify_pkcs1v15_advice(h2r_pipeline *p, const void *sig, const void *n, const uint8_t *e_le, size_t e_len,
-                                            const uint64_t *hashed, uint64_t batch, uint32_t flags, void *witness, void *powed_out,
-                                            uint8_t *is_valid_out, uint8_t *status, void *workspace, void *advice_out, uint64_t out_stride,
-                                            h2r_stream_t stream) try {
-    if (!p || !sig || !n || !e_le || !hashed || !witness || !powed_out || !status || !workspace || !advice_out) return H2R_E_NULL;
+namespace {
+int32_t pipeline_verify_advice(h2r_pipeline *p, const void *sig, const void *n, const uint8_t *e_le, size_t e_len, const void *e_limbs,
+                               uint32_t e_num_limbs, uint32_t exp_limb_bits, const uint64_t *hashed, uint64_t batch, uint32_t flags, void *witness,
+                               void *powed_out, uint8_t *is_valid_out, uint8_t *status, void *workspace, void *advice_out, uint64_t out_stride,
+                               h2r_stream_t stream) {
+    if (!p || !sig || !n || (!e_le && !e_limbs) || !hashed || !witness || !powed_out || !status || !workspace || !advice_out) return H2R_E_NULL;
     if (reinterpret_cast<u64>(witness) & 15) return H2R_E_SHAPE;   // (16-byte stores into the witness sections)
     const h2r_ctx *ctx = p->ctx;
+    const bool var = e_limbs != nullptr;
     h2r_verify_layout full, vl;
-    int32_t rc = h2r_verify_layout_fixed(ctx, e_le, e_len, &full);
+    int32_t rc = var ? h2r_verify_layout_var(ctx, e_num_limbs, exp_limb_bits, &full) : h2r_verify_layout_fixed(ctx, e_le, e_len, &full);
     if (rc) return rc;
     if ((rc = h2r_verify_layout_compact(ctx, &full, &vl))) return rc;
     const h2r_ctx::RowProg *pre, *inf, *em;
@@ -3620,7 +3632,9 @@ int32_t h2r_pipeline_verify_pkcs1v15_advice(h2r_pipeline *p, const void *sig, co
     }
     const u32 slot = p->k % p->depth;
     p->done[slot] = DoneRef{};
-    rc = pow_fixed_impl(ctx, sig, n, e_le, e_len, batch, flags, nullptr, powed_out, status, workspace, stream, 1);
+    if (var) rc = run_path(ctx, CHAIN_POW_VAR, sig, nullptr, n, e_limbs, e_num_limbs, exp_limb_bits, nullptr, 1, batch, flags, vl.pow.num_mul_mods, witness,
+                           vl.elem_stride, UINT64_MAX, &vl.pow, powed_out, status, workspace, st);
+    else rc = pow_fixed_impl(ctx, sig, n, e_le, e_len, batch, flags, nullptr, powed_out, status, workspace, stream, 1);
     if (rc) return rc;
     if ((rc = launch_verify_aux(ctx, sig, n, hashed, batch, flags, witness, vl, powed_out, is_valid_out, status, st))) return rc;
     const h2r_layout &lo = ctx->layout;
@@ -3643,8 +3657,8 @@ int32_t h2r_pipeline_verify_pkcs1v15_advice(h2r_pipeline *p, const void *sig, co
     if ((rc = launch_row_prog(ctx, em, ra, st))) return rc;
     hipStream_t side = p->aux[p->k & 1];
     HIP_TRY(hipStreamWaitEvent(side, p->chain_done[slot], 0));
-    rc = pow_emit_advice(ctx, &vl.pow, ws + wp.off_n, (flags & H2R_F_SHARED_MODULUS) | H2R_ADVICE_DIRECT, nullptr, 0, workspace, batch, status,
-                         dst.at_row(sec[0] + sec[1]), static_cast<h2r_stream_t>(side));   // pow_mod_fixed_exp, :111
+    rc = pow_emit_advice(ctx, &vl.pow, ws + wp.off_n, (flags & H2R_F_SHARED_MODULUS) | H2R_ADVICE_DIRECT, var ? witness : nullptr, var ? vl.elem_stride : 0,
+                         workspace, batch, status, dst.at_row(sec[0] + sec[1]), static_cast<h2r_stream_t>(side));   // pow_mod_fixed_exp :111 / pow_mod :109
     if (rc) return rc;
     HIP_TRY(hipEventRecord(p->trace_done[slot], side));
     p->done[slot] = DoneRef{p->trace_done[slot], 0, false};
@@ -3655,6 +3669,26 @@ int32_t h2r_pipeline_verify_pkcs1v15_advice(h2r_pipeline *p, const void *sig, co
         if (rc) return rc;
     }
     return H2R_OK;
+}
+}  // namespace
+
+int32_t h2r_pipeline_verify_pkcs1v15_advice(h2r_pipeline *p, const void *sig, const void *n, const uint8_t *e_le, size_t e_len,
+                                            const uint64_t *hashed, uint64_t batch, uint32_t flags, void *witness, void *powed_out,
+                                            uint8_t *is_valid_out, uint8_t *status, void *workspace, void *advice_out, uint64_t out_stride,
+                                            h2r_stream_t stream) try {
+    if (!e_le) return H2R_E_NULL;
+    return pipeline_verify_advice(p, sig, n, e_le, e_len, nullptr, 0, 0, hashed, batch, flags, witness, powed_out, is_valid_out, status, workspace,
+                                  advice_out, out_stride, stream);
+} H2R_CATCH_STATUS
+
+// the RSAPubE::Var arm (src/chip.rs:108-110): the witness also keeps the pow_mod's exponent bits, selected operands and result
+int32_t h2r_pipeline_verify_pkcs1v15_var_advice(h2r_pipeline *p, const void *sig, const void *n, const void *e_limbs, uint32_t e_num_limbs,
+                                                uint32_t exp_limb_bits, const uint64_t *hashed, uint64_t batch, uint32_t flags, void *witness,
+                                                void *powed_out, uint8_t *is_valid_out, uint8_t *status, void *workspace, void *advice_out,
+                                                uint64_t out_stride, h2r_stream_t stream) try {
+    if (!e_limbs) return H2R_E_NULL;
+    return pipeline_verify_advice(p, sig, n, nullptr, 0, e_limbs, e_num_limbs, exp_limb_bits, hashed, batch, flags, witness, powed_out, is_valid_out, status,
+                                  workspace, advice_out, out_stride, stream);
 } H2R_CATCH_STATUS
 
 // ---- RSAPubE::Var (src/chip.rs:108-110) without records -------------------------------------------------------------------

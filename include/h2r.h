@@ -931,6 +931,12 @@ int32_t h2r_pipeline_verify_pkcs1v15_advice(h2r_pipeline *p, const void *sig, co
                                             const uint64_t *hashed, uint64_t batch, uint32_t flags, void *witness, void *powed_out,
                                             uint8_t *is_valid_out, uint8_t *status, void *workspace, void *advice_out,
                                             uint64_t out_stride, h2r_stream_t stream);
+/* the RSAPubE::Var arm: h2r_verify_layout_compact of a Var layout also keeps the pow_mod's exponent bits, selected operands and result
+ * (its `pow` is then the witness-only form, off_records = UINT64_MAX, offsets inside the element's witness) */
+int32_t h2r_pipeline_verify_pkcs1v15_var_advice(h2r_pipeline *p, const void *sig, const void *n, const void *e_limbs, uint32_t e_num_limbs,
+                                                uint32_t exp_limb_bits, const uint64_t *hashed, uint64_t batch, uint32_t flags,
+                                                void *witness, void *powed_out, uint8_t *is_valid_out, uint8_t *status, void *workspace,
+                                                void *advice_out, uint64_t out_stride, h2r_stream_t stream);
 /* The RSAPubE::Var arm (src/chip.rs:108-110; pow_mod, big_integer/chip.rs:664-696) of h2r_pipeline_modpow_public_key_advice: per-element
  * exponents, no records.  A Var element's to_bits / select rows read its exponent bits and selected operands: they are kept -- with the
  * result -- in `witness`, batch * h2r_pow_layout_compact(h2r_pow_var_layout(...)).elem_stride bytes (16-byte aligned), the witness-only

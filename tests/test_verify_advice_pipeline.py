@@ -271,3 +271,54 @@ def test_pipelined_var_arm_image_is_the_record_based_image(H, repr_kw):
         assert lib().h2r_pow_row_kinds(chip._ctx, ctypes.byref(pl), k_pow.ctypes.data) == 0
         bad, first = chip.advice_check(np.concatenate([k_if, k_pow]), g["img"], B, status=g["st"], lookup=look)
         assert bad.cpu().tolist() == [0] * B, (k, bad.cpu().tolist(), [hex(v) for v in first.cpu().tolist()])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("repr_kw", [dict(), dict(columns=True, montgomery=True)])
+def test_pipelined_verify_var_arm_image_is_the_record_based_image(H, golden, repr_kw):
+    """The whole verify_pkcs1v15_signature element with an RSAPubE::Var key (e = 65537 as 17-bit limbs for the KATs -- valid, valid, BAD --
+    and random exponents for random signatures), no records: is_valid, powed, status and every byte of the image equal
+    h2r_verify_pkcs1v15_var_batch + h2r_verify_emit_advice; the compact layout keeps the pow_mod witness behind the EM region."""
+    from halo2_rsa_amd import _lib
+    from halo2_rsa_amd._lib import lib
+    nb, n_el = 17, 1
+    rsa = H.RSAChip(2048, nb, **repr_kw)
+    chip = rsa.bigint_chip()
+    rng = random.Random(91)
+    B, depth, calls_n = 5, 2, 3
+    pipe = H.Pipeline(chip, depth, 2)
+    vl = pipe.verify_compact_layout_var(n_el, nb)
+    assert vl.pow.off_records == 2 ** 64 - 1 and vl.pow.off_selected >= vl.off_em and vl.pow.elem_stride == vl.elem_stride
+    sec = (ctypes.c_uint64 * 4)()
+    rows = int(lib().h2r_verify_advice_rows(chip._ctx, ctypes.byref(vl), sec))
+    sets = [_buffers(chip, vl, rows, B) for _ in range(depth)]
+    calls, got = [], []
+    for k in range(calls_n):
+        ns, sigs, hashed = _inputs(golden, rng, B, bad_elem=4 if k == 1 else None)
+        E = [[65537]] * 3 + [[rng.getrandbits(nb)] for _ in range(B - 3)]
+        calls.append((ns, sigs, hashed, E))
+        s = sets[k % depth]
+        if k >= depth:
+            got.append((k - depth, {key: v.clone() for key, v in s.items() if key != "ws"}))
+        s["img"].fill_(0x5A)
+        e_dev = chip.assign_integer(H.UnassignedInteger(np.array(E, dtype=np.uint64)))
+        pipe.verify_pkcs1v15_var_advice(chip.assign_integer(sigs), e_dev, nb, chip.assign_integer(ns), _hashed_tensor(hashed), s["wit"], s["ws"],
+                                        s["powed"], s["valid"], s["st"], s["img"])
+    pipe.join()
+    for k in range(calls_n - depth, calls_n):
+        got.append((k, {key: v.clone() for key, v in sets[k % depth].items() if key != "ws"}))
+    pipe.close()
+    torch.cuda.synchronize()
+    for k, g in got:
+        ns, sigs, hashed, E = calls[k]
+        pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Var(H.UnassignedInteger(np.array(E, dtype=np.uint64)))))
+        sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64)))
+        res = rsa.verify_pkcs1v15_signature(pk, _hashed_tensor(hashed), sg)
+        want = res.emit_advice()
+        assert torch.equal(g["st"], res.status) and torch.equal(g["valid"], res.is_valid), k
+        assert g["valid"].cpu().tolist()[:3] == [1, 1, 0]
+        ok = (res.status == 0)
+        assert torch.equal(g["powed"][ok], res.powed.limbs_dev[ok]), k
+        assert want.shape == g["img"].shape and torch.equal(g["img"][ok], want[ok]), k
+        if k == 1:
+            assert int(g["st"][4]) == H.H2R_E_NOT_IN_FIELD and bool((g["img"][4] == 0x5A).all())
