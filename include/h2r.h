@@ -922,7 +922,7 @@ int32_t h2r_pipeline_modpow_public_key_advice(h2r_pipeline *p, const void *x, co
  * to the chains of the following call.  The image follows the pipeline's join rule; everything else is stream-ordered.
  * witness (16-byte aligned): batch * h2r_verify_layout_compact(...).elem_stride bytes -- the element's in-field and EM witness, the only part of a verify
  * element's trace the rows need (9,984 B instead of 1.26 MB per RSA-2048 element).  h2r_verify_layout_compact turns a verify layout into
- * that form (off_in_field = 0, off_em, elem_stride; `pow` unchanged); with it h2r_verify_emit_advice (flags | H2R_ADVICE_DIRECT,
+ * that form (off_in_field = 0, off_em, elem_stride; `pow` unchanged for a Fix layout, the witness-only pow layout inside the element for a Var one); with it h2r_verify_emit_advice (flags | H2R_ADVICE_DIRECT,
  * trace = the witness), h2r_verify_advice_rows and h2r_verify_row_kinds work as with the full layout.
  * Consecutive calls rotate through `depth` sets of witness / powed_out / is_valid_out / status / workspace / advice_out.
  * `bench.py --advice --verify` measures this form (77,200 rows = 12.35 MB per RSA-2048 element). */
