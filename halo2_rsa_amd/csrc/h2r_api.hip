@@ -114,6 +114,8 @@ struct Knobs {
     long verify_fold = -1;                       // H2R_VERIFY_FOLD=0|1: the verifier's witness inside the step launch's chain role (-1 = the measured default per shape)
     long exp_segments = -1;                      // H2R_EXP_SEGMENTS=n: segments a long exponent is walked in (0 / 1 = never; -1 = the default rule, exp_segment_count)
     long single_call_segments = -1;              // H2R_SINGLE_CALL_SEGMENTS=n: segments of a SHORT exponent in a single stream-ordered call of 513..1,536 RSA-2048 elements
+    long rowprog_stage_rows = 0;                 // H2R_ROWPROG_STAGE_ROWS=64|128|256: rows (= threads) of a row-program workgroup (0 = the rule in launch_row_prog)
+    long cells_nwv = 0;                          // H2R_CELLS_NWV=1|8: waves per cells_kernel workgroup of a Montgomery ctx (0 = the rule at ctx creation)
     Knobs() {
 #ifdef H2R_DEV_KNOBS
         auto num = [](const char *name, long dflt) { const char *v = std::getenv(name); return v ? std::atol(v) : dflt; };
@@ -127,6 +129,7 @@ struct Knobs {
         { const char *m = std::getenv("H2R_PIPE_CU_MASK"); pipe_cu_mask = m ? std::strtoul(m, nullptr, 16) : 0; pipe_cu_mask_words = num("H2R_PIPE_CU_MASK_WORDS", 0); }
         verify_fold = num("H2R_VERIFY_FOLD", -1); exp_segments = num("H2R_EXP_SEGMENTS", -1); single_call_segments = num("H2R_SINGLE_CALL_SEGMENTS", -1);
         pipe_step = num("H2R_PIPE_STEP", -1); step_chain_x2_per_cu = num("H2R_STEP_CHAIN_X2_PER_CU", 0);
+        rowprog_stage_rows = num("H2R_ROWPROG_STAGE_ROWS", 0); cells_nwv = num("H2R_CELLS_NWV", 0);
         pipe_sub_batch = num("H2R_PIPE_SUB_BATCH", 0); arena_chunk_mb = num("H2R_ARENA_CHUNK_MB", 0); plain_overlap = num("H2R_PLAIN_OVERLAP", -1); pipe_pace = num("H2R_PIPE_PACE", -1);
 #endif
     }
@@ -666,7 +669,7 @@ int32_t h2r_ctx_create_ex(const h2r_params *params, const h2r_advice_repr *repr,
             // Montgomery cells of the long shapes (64 limbs and more): EIGHT waves share one set of planes (h2r_cells.hpp); measured per shape,
             // TB/s with 1 / 4 / 8 waves: 128 x 32-bit 3.4 / 5.3 / 6.4, 96 x 32-bit 3.2 / 4.8 / 5.4, 64 x 32-bit 4.2 / 4.3 / 5.2, 64 x 64-bit 3.8 / 3.6 / 4.4,
             // 48 x 64-bit 3.9 / 3.1 / 3.5, 32 x 64-bit 5.2 / 2.6 / 2.9 (tools/cells_nwv_probe.py, profiles/r05_cells_representations.txt)
-            static const u32 nwv_env = [] { const char *e = std::getenv("H2R_CELLS_NWV"); const int v = e ? std::atoi(e) : 0; return (v == 1 || v == 8) ? (u32)v : 0u; }();   // (developer A/B)
+            const u32 nwv_env = (knobs().cells_nwv == 1 || knobs().cells_nwv == 8) ? (u32)knobs().cells_nwv : 0u;   // (developer A/B)
             c->cells_nwv = !mont ? 1u : (nwv_env ? nwv_env : (L >= 64 ? 8u : 1u));
             const CellsLds lp = cells_lds_plan(w, L, mont, c->cells_nwv);
             u32 *fs = reinterpret_cast<u32 *>(&kt[CELLS_KT_FSRC]);
@@ -3202,8 +3205,9 @@ int32_t launch_row_prog(const h2r_ctx *ctx, const h2r_ctx::RowProg *rp, RowProgA
     // waves in only when its grid drains: 256-row row programs issued next to it sat there for its whole 2 ms with everything behind them
     // on the stream (the next call's chains) -- one-wave workgroups (64 rows, 10 KB) are placed as cells workgroups retire: the pipelined
     // calls 2.39 -> 2.26 ms (modpow_public_key element), 2.67 -> 2.26 ms (whole verify element); profiles/r05_advice_pipeline_montgomery.txt.
-    // Next to the canonical cells kernel both sizes run alike; 256 stays.  (H2R_ROWPROG_STAGE_ROWS = 64 | 128 | 256: developer A/B.)
-    static const u32 sr_env = [] { const char *e = std::getenv("H2R_ROWPROG_STAGE_ROWS"); const int v = e ? std::atoi(e) : 0; return (v == 64 || v == 128 || v == 256) ? (u32)v : 0u; }();
+    // Next to the canonical cells kernel both sizes run alike; 256 stays.  (H2R_ROWPROG_STAGE_ROWS = 64 | 128 | 256: developer A/B, -DH2R_DEV_KNOBS build.)
+    const long sr_k = knobs().rowprog_stage_rows;
+    const u32 sr_env = (sr_k == 64 || sr_k == 128 || sr_k == 256) ? (u32)sr_k : 0u;
     const u32 sr = sr_env ? sr_env : ((ctx->repr.flags & H2R_ADVICE_MONTGOMERY) ? 64u : 256u);
     const u64 blocks = ra.batch * ((ra.rows + sr - 1) / sr);
     if (blocks == 0) return H2R_OK;

@@ -1,4 +1,5 @@
-"""cells_kernel in Montgomery form, by waves per workgroup (H2R_CELLS_NWV = 1 | 2 | 4 | 8, read at ctx creation): ms per launch and TB/s
+"""(H2R_CELLS_NWV is read by the -DH2R_DEV_KNOBS build only: python -m halo2_rsa_amd._build devknobs -DH2R_DEV_KNOBS; H2R_LIB=halo2_rsa_amd/lib/variants/devknobs.so)
+cells_kernel in Montgomery form, by waves per workgroup (H2R_CELLS_NWV = 1 | 2 | 4 | 8, read at ctx creation): ms per launch and TB/s
 for a fixed-exponent pow image written directly from the operands.  argv: limb_width bits batch"""
 import ctypes, os, random, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
