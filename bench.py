@@ -569,7 +569,7 @@ def lookup_bench(args):
     rng = random.Random(0x68327273 + 11)
     thetas = [rng.randrange(P) for _ in range(B)]
     col_bytes = B * 5 * usable * 32
-    cand = args.placement_candidates if args.placement_candidates >= 0 else 8
+    cand = args.placement_candidates if args.placement_candidates >= 0 else 16   # (eight pairs: with four, a box now and then offers no fast one)
     arena, placement = None, "as allocated"
     look = os.environ.get("H2R_BENCH_LOOKUP_LOOK", "call")    # call: candidates timed with the call itself (default) | arena: h2r_image_arena_create's streaming fill
     if cand >= 4 and look == "call":
