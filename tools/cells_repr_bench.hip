@@ -152,5 +152,13 @@ int main(int argc, char **argv) {
     line("build only, no is_equal_muled rows", RUN(2 | 8));
     line("build only, no mul rows", RUN(2 | 16));
     line("full", RUN(0));
+    if (argc > 8) {   // the SAME image buffer under several LDS requests (= waves per CU): 6, 5, 4, 3 per CU and the shipped one again
+        for (u32 req : {26880u, 32000u, 40448u, 53760u, lds}) {
+            if (req < base) continue;
+            const u32 keep = lds;
+            const float ms = w == 64 ? (mont ? run<64, 0, true>(ca, req, R) : run<64, 0, false>(ca, req, R)) : (mont ? run<32, 0, true>(ca, req, R) : run<32, 0, false>(ca, req, R));
+            char nm[64]; std::snprintf(nm, sizeof nm, "full, lds request %u", req); line(nm, ms); (void)keep;
+        }
+    }
     return 0;
 }
