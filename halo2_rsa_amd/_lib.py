@@ -119,7 +119,7 @@ EXPORTS = ["h2r_ctx_create", "h2r_ctx_create_ex", "h2r_ctx_advice_repr", "h2r_ab
            "h2r_pow_trace_flatten_ex", "h2r_trace_emit_stream", "h2r_pow_trace_emit_stream", "h2r_mul_mod_trace_check", "h2r_pow_trace_check",
            "h2r_modpow_public_key_advice_rows", "h2r_modpow_public_key_emit_advice",
            "h2r_advice_copy_map", "h2r_pow_operand_sources", "h2r_advice_layout_default", "h2r_advice_layout_custom", "h2r_advice_fixed_row_ex",
-           "h2r_advice_apply_layout", "h2r_advice_check", "h2r_pow_copy_map",
+           "h2r_advice_apply_layout", "h2r_advice_check", "h2r_pow_copy_map", "h2r_lookup_hist_advice",
            "h2r_advice_rows", "h2r_mul_mod_emit_advice", "h2r_pow_trace_emit_advice", "h2r_pow_advice_rows", "h2r_pow_row_kinds", "h2r_advice_row_kinds",
            "h2r_advice_fixed_row", "h2r_fresh_op_advice_rows", "h2r_fresh_op_row_kinds", "h2r_fresh_op_emit_advice",
            "h2r_verify_advice_rows", "h2r_verify_row_kinds", "h2r_verify_emit_advice", "h2r_verify_layout_compact", "h2r_pipeline_verify_pkcs1v15_advice", "h2r_pow_layout_compact", "h2r_pipeline_modpow_public_key_var_advice", "h2r_pipeline_verify_pkcs1v15_var_advice", "h2r_verify_layout_var", "h2r_verify_pkcs1v15_var_batch", "h2r_pipeline_verify_pkcs1v15_var",
@@ -190,6 +190,7 @@ def lib():
     L.h2r_pow_layout_compact.argtypes = [vp, ctypes.POINTER(H2RPowLayout), ctypes.POINTER(H2RPowLayout)]
     L.h2r_pipeline_modpow_public_key_var_advice.argtypes = [vp, vp, vp, u32, u32, vp, u64, u32, vp, vp, vp, vp, vp, vp, u64, vp]
     L.h2r_pipeline_verify_pkcs1v15_var_advice.argtypes = [vp, vp, vp, vp, u32, u32, vp, u64, u32, vp, vp, vp, vp, vp, vp, u64, vp]
+    L.h2r_lookup_hist_advice.argtypes = [vp, vp, vp, vp, u64, vp, u64, u64, vp, vp, vp]
     L.h2r_verify_layout_compact.argtypes = [vp, ctypes.POINTER(H2RVerifyLayout), ctypes.POINTER(H2RVerifyLayout)]
     L.h2r_pipeline_verify_pkcs1v15_advice.argtypes = [vp, vp, vp, ctypes.c_char_p, ctypes.c_size_t, vp, u64, u32, vp, vp, vp, vp, vp, vp, u64, vp]
     L.h2r_pipeline_join.argtypes = [vp, vp]

@@ -1015,6 +1015,17 @@ class LookupArgument:
                                              elem_stride, batch, hist.data_ptr(), self.chip._stream()), "h2r_lookup_hist_fresh_op")
         return hist
 
+    def hist_advice(self, kinds, image: torch.Tensor, batch: int, hist: torch.Tensor, status: Optional[torch.Tensor] = None, layout=None) -> torch.Tensor:
+        """The multiplicities of an advice image (h2r_lookup_hist_advice): what hist_verify / hist_records / hist_fresh_op count from a trace,
+        for a witness without records.  kinds: uint8 row kinds (numpy or device tensor)."""
+        kd = kinds if isinstance(kinds, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(kinds, dtype=np.uint8)).to(image.device)
+        stride = image.shape[1] if image.dim() > 1 else image.numel() // batch
+        check(lib().h2r_lookup_hist_advice(self.chip._ctx, ctypes.byref(self.cfg), ctypes.byref(layout) if layout is not None else None, kd.data_ptr(),
+                                           kd.numel(), image.data_ptr(), stride, batch, status.data_ptr() if status is not None else None,
+                                           hist.data_ptr(), self.chip._stream()), "h2r_lookup_hist_advice")
+        self._keep = kd
+        return hist
+
     def hist_verify(self, res, hist: torch.Tensor) -> torch.Tensor:
         """Every lookup inside the witness of a verify_pkcs1v15_signature batch (rsa.VerifyResult): assert_in_field's range assigns,
         the records' limbs and carries, the encoded-message check's two 4-bit range assigns (h2r_lookup_hist_verify)."""

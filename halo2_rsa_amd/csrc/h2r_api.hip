@@ -3884,6 +3884,32 @@ int32_t h2r_advice_check(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const
     return H2R_OK;
 } H2R_CATCH_STATUS
 
+// The lookup multiplicities of an advice image (advice_hist_kernel): hist[elem][5][n_rows] uint32, ADDED to like every h2r_lookup_hist_*.
+int32_t h2r_lookup_hist_advice(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const h2r_advice_layout *layout, const uint8_t *kinds_dev,
+                               uint64_t rows, const void *image, uint64_t image_stride, uint64_t batch, const uint8_t *status, uint32_t *hist,
+                               h2r_stream_t stream) try {
+    if (!ctx || !cfg || !kinds_dev || !image || !hist) return H2R_E_NULL;
+    if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
+    if (cfg->n_rows == 0 || cfg->n_rows > (u32)LOOKUP_MAX_ROWS || cfg->n_lens == 0 || cfg->n_lens > H2R_LOOKUP_MAX_LENS) return H2R_E_SHAPE;
+    h2r_advice_layout ident;
+    if (!layout) { h2r_advice_layout_default(&ident); layout = &ident; }
+    else if (const int32_t rc = layout_valid(layout)) return rc;
+    AdviceHistArgs ha;
+    std::memset(static_cast<void *>(&ha), 0, sizeof ha);
+    if (const int32_t rc = advice_dst(ctx, const_cast<void *>(image), image_stride, rows, batch, &ha.img)) return rc;
+    if (!rows || !batch) return H2R_OK;
+    H2R_ON_DEVICE(ctx->params.device);
+    if (const int32_t rc = check_table(ctx, cfg, layout, &ha.tab)) return rc;
+    ha.kinds = kinds_dev; ha.rows = rows; ha.batch = batch; ha.status = status; ha.f = ctx->fc;
+    ha.hist = hist; ha.n_rows = cfg->n_rows; ha.n_lens = cfg->n_lens;
+    for (u32 i = 0; i < cfg->n_lens; ++i) { ha.bit_len[i] = cfg->bit_len[i]; ha.row_off[i] = cfg->row_off[i]; }
+    const u64 blocks = batch * ((rows + HIST_ROWS_PER_WG - 1) / HIST_ROWS_PER_WG);
+    if (blocks >= (1ull << 31)) return H2R_E_UNSUPPORTED;
+    hipLaunchKernelGGL(advice_hist_kernel, dim3((unsigned)blocks), dim3(256), 5u * cfg->n_rows * sizeof(u32), static_cast<hipStream_t>(stream), ha);
+    HIP_TRY(hipGetLastError());
+    return H2R_OK;
+} H2R_CATCH_STATUS
+
 // The copy constraints of one fixed-exponent pow element (h2r_pow_trace_emit_advice's image: CONST1, CONST0, then the records), rows
 // counted from `row_offset` (the pow section's first row inside a larger element image): every record's own pairs, and its operand
 // limbs tied to where pow_mod_fixed_exp takes them from (big_integer/chip.rs:729-740).

@@ -112,4 +112,67 @@ __global__ __launch_bounds__(256) void advice_check_copies_kernel(AdviceCheckArg
     if (!ok) achk_fail(a, elem, cp.row, ACHK_COPY);
 }
 
+// ---- the lookup multiplicities of an advice image: what h2r_lookup_permuted_columns needs of a witness that has no records ----
+// For every row whose kind enables the composition lookup, cells a..d each add one to their (tag, value) table row in arguments 0..3;
+// with the overflow lookup, cell a adds one in argument 4 (h2r.h: hist[elem][5][n_rows]).  A workgroup walks HIST_ROWS_PER_WG rows of
+// one element with a histogram of its own in LDS (the hot counters of a circuit are a few hundred) and adds what it gathered at the end.
+struct AdviceHistArgs {
+    AdviceDst img;
+    const u8 *kinds; u64 rows, batch; const u8 *status;
+    const CheckKind *tab;
+    FieldConsts f;
+    u32 *hist; u32 n_rows, n_lens;
+    u32 bit_len[8], row_off[8];
+};
+constexpr u32 HIST_ROWS_PER_WG = 16384;
+__global__ __launch_bounds__(256) void advice_hist_kernel(AdviceHistArgs a) {
+    extern __shared__ u32 hist_lds[];                        // [5][n_rows]
+    const u32 chunks = (u32)((a.rows + HIST_ROWS_PER_WG - 1) / HIST_ROWS_PER_WG);
+    const u64 elem = blockIdx.x / chunks;
+    const u64 r_lo = (u64)(blockIdx.x - elem * chunks) * HIST_ROWS_PER_WG, r_hi = r_lo + HIST_ROWS_PER_WG < a.rows ? r_lo + HIST_ROWS_PER_WG : a.rows;
+    if (a.status && a.status[elem]) return;
+    for (u32 k = threadIdx.x; k < 5 * a.n_rows; k += 256) hist_lds[k] = 0;
+    __shared__ unsigned short kbits[256];                               // per kind: composition bits | overflow bits << 8 (0: no lookup on the row) -- the scan reads nothing else per row
+    { const CheckKind &ck = a.tab[threadIdx.x]; kbits[threadIdx.x] = ck.valid ? (unsigned short)(ck.comp_bits | (ck.ov_bits << 8)) : (unsigned short)0; }
+    __syncthreads();
+    const u8 *img = a.img.base + elem * a.img.elem_stride;
+    auto table_row = [&](u32 bits, const Fe &cell, u32 &row) -> bool {
+        const Fe v = a.img.mont ? fe_from_mont(cell, a.f) : cell;
+        if ((v.v[1] | v.v[2] | v.v[3]) != 0 || (bits < 64 && (v.v[0] >> bits) != 0)) return false;   // not a table row: h2r_advice_check's finding, not counted
+        for (u32 i = 0; i < a.n_lens; ++i) if (a.bit_len[i] == bits) { row = a.row_off[i] + (u32)v.v[0]; return true; }
+        return false;
+    };
+    // Lookup rows are a few per cent of an image: each pass lists those of 1,024 rows densely, then one thread takes one (row, cell) of the
+    // list -- every lane of the waves that convert and count has a cell (a scan that did the work where it found a row ran 4x longer in
+    // Montgomery form: one active lane in a wave pays the whole conversion)
+    __shared__ u32 l_row[1024];
+    __shared__ u32 l_cnt;
+    for (u64 base = r_lo; base < r_hi; base += 1024) {
+        if (threadIdx.x == 0) l_cnt = 0;
+        __syncthreads();
+#pragma unroll
+        for (u32 q = 0; q < 4; ++q) {
+            const u64 r = base + q * 256 + threadIdx.x;
+            if (r < r_hi) {
+                const u32 kb = kbits[a.kinds[r]];
+                if (kb) l_row[atomicAdd(&l_cnt, 1u)] = (u32)(r - base) | (kb << 10);
+            }
+        }
+        __syncthreads();
+        const u32 n = l_cnt;
+        for (u32 t = threadIdx.x; t < 4 * n; t += 256) {
+            const u32 e = l_row[t >> 2], k = t & 3u, comp_bits = (e >> 10) & 0xffu, ov_bits = e >> 18;
+            if (!comp_bits && k) continue;
+            const Fe cell = achk_cell(a.img, img, base + (e & 1023u), k);
+            u32 row;
+            if (comp_bits && table_row(comp_bits, cell, row)) atomicAdd(&hist_lds[k * a.n_rows + row], 1u);
+            if (k == 0 && ov_bits && table_row(ov_bits, cell, row)) atomicAdd(&hist_lds[4 * a.n_rows + row], 1u);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    u32 *out = a.hist + elem * 5ull * a.n_rows;
+    for (u32 k = threadIdx.x; k < 5 * a.n_rows; k += 256) if (hist_lds[k]) atomicAdd(out + k, hist_lds[k]);
+}
+
 }  // namespace h2r

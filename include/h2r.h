@@ -702,6 +702,17 @@ int32_t h2r_lookup_hist_verify(const h2r_ctx *ctx, const h2r_lookup_config *cfg,
  * RangeChip::assign(limb, limb_width / 8, limb_width) */
 int32_t h2r_lookup_hist_fresh_op(const h2r_ctx *ctx, const h2r_lookup_config *cfg, uint32_t op, const void *trace, uint64_t first_off,
                                  uint64_t elem_stride, uint64_t num_elems, uint32_t *hist, h2r_stream_t stream);
+/* The multiplicities of an advice IMAGE (any *_emit_advice / pipelined advice export's output, in the ctx's representation, under `layout`;
+ * kinds_dev: the rows' kinds on the device as for h2r_advice_check): every row whose kind enables the composition lookup adds its cells
+ * a..d to arguments 0..3, every row with the overflow lookup its cell a to argument 4 -- what h2r_lookup_hist_verify / _records / _fresh_op
+ * count from a trace, for a witness that has no records (h2r_pipeline_*_advice).  A cell that is not a row of the table is not counted
+ * (h2r_advice_check reports it).  Elements with a nonzero status byte (nullable) are skipped.  What the caller still adds: the
+ * assign_integer range assigns of the circuit's inputs (h2r_lookup_hist_values), which are not rows of these images.
+ * 0.32 ms per 1,024 RSA-2048 modpow_public_key elements (12.6 GB image; 0.58 ms in planar Montgomery form). */
+struct h2r_advice_layout;
+int32_t h2r_lookup_hist_advice(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const struct h2r_advice_layout *layout, const uint8_t *kinds_dev,
+                               uint64_t rows, const void *image, uint64_t image_stride, uint64_t batch, const uint8_t *status, uint32_t *hist,
+                               h2r_stream_t stream);
 uint64_t h2r_lookup_workspace_bytes(const h2r_lookup_config *cfg, uint64_t num_elems);
 int32_t h2r_lookup_permuted_columns(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const uint32_t *hist, const uint64_t *theta,
                                     uint64_t num_elems, uint32_t usable_rows, uint32_t arg_mask, void *a_perm_out,
