@@ -486,6 +486,18 @@ def advice_bench(args):
     n_bad = int((bad != 0).sum().item())
     assert n_bad == 0, "h2r_advice_check: %d elements of the timed image violate a gate / lookup / copy (first: %#x)" % (n_bad, int(first[bad != 0][0].item()))
     audit_s = time.perf_counter() - t_chk
+    # ... and the lookup multiplicities counted from the timed image (h2r_lookup_hist_advice: what the lookup argument needs of a witness that has
+    # no records) against those of the first signatures' records
+    la = H.LookupArgument(chip, rsa_chip=whole)
+    if whole:
+        want_h = la.hist_verify(ref, la.new_hist(sample))
+    else:
+        want_h = la.hist_records(ref.trace, la.new_hist(sample), status=ref.status)
+        la.hist_fresh_op("is_in_field", ref.in_field.buf, ref.in_field.elem_stride, sample, want_h)
+    got_h = la.hist_advice(kinds_all, images[last].view(chunk, elem_bytes)[:sample], sample, la.new_hist(sample), status=sts[last][:sample].contiguous())
+    torch.cuda.synchronize()
+    okh = torch.from_numpy(ok).to(got_h.device)
+    assert torch.equal(got_h[okh], want_h[okh]), "the lookup multiplicities of the timed image differ from those of the records"
     if env.rank == 0:
         algo = chunk * pow_rows * 160
         stamped_s = (sum(cells_ms) / len(cells_ms)) / 1e3 if cells_ms else float("nan")
@@ -516,8 +528,8 @@ def advice_bench(args):
                                     "pipeline's side stream (2 workspaces, 2 images)") if pipe is not None else
                                    "chain kernels of call k+1 on a second stream next to cells_kernel of call k (2 workspaces, 2 images), stream-ordered exports + events (H2R_BENCH_ADV=%s)" % adv_mode,
                        "untimed_clock_warmup_calls": ramp, "warmup_calls_total": 1 + ramp + warmup, "buffer_placement": placement,
-                       "post_run_audit": "h2r_advice_check on the last timed image: %d elements x %d rows, gate + lookup + %s copy pairs per element, 0 violations (%.2f s incl. the copy map)" %
-                                         (chunk, rows, "pow-row", audit_s)},
+                       "post_run_audit": "h2r_advice_check on the last timed image: %d elements x %d rows, gate + lookup + %s copy pairs per element, 0 violations (%.2f s incl. the copy map); "
+                                         "h2r_lookup_hist_advice of its first %d elements = the multiplicities of their records" % (chunk, rows, "pow-row", audit_s, sample)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": None,
                          "traffic_source": "not measured", "kernel": "cells_kernel<%d%s>" % (w, ", Montgomery" if args.montgomery else ""), "launches_timed": len(cells_ms),
