@@ -230,8 +230,8 @@ def test_pipelined_var_arm_image_is_the_record_based_image(H, repr_kw):
                  img=torch.empty((B, chip.image_bytes(rows)), dtype=torch.uint8, device="cuda")) for _ in range(depth)]
     calls, got = [], []
     for k in range(calls_n):
-        N = [rand_modulus(rng, 2048) for _ in range(B)]
-        X = [rng.randrange(n) for n in N]
+        N = [rand_modulus(rng, 2048) for _ in range(1 if k == 2 else B)]          # (the last call: ONE modulus for the whole batch)
+        X = [rng.randrange(N[0] if k == 2 else N[i]) for i in range(B)]
         E = [[rng.getrandbits(nb) for _ in range(n_el)] for _ in range(B)]
         E[1] = [0] * n_el
         E[2] = [0b10001, 0b00010]
@@ -264,7 +264,7 @@ def test_pipelined_var_arm_image_is_the_record_based_image(H, repr_kw):
             if int(g["st"][i]) == 0:
                 e_int = sum(v << (nb * j) for j, v in enumerate(E[i]))
                 got_int = int.from_bytes(g["out"][i].cpu().numpy().tobytes(), "little")
-                assert got_int == (pow(X[i], e_int, N[i]) if e_int else 1), (k, i)     # big_pow_mod returns 1 for e = 0 (utils.rs:2-17)
+                assert got_int == (pow(X[i], e_int, N[i % len(N)] if len(N) > 1 else N[0]) if e_int else 1), (k, i)     # big_pow_mod returns 1 for e = 0 (utils.rs:2-17)
         # the device MockProver on the records-free image
         k_if = chip.fresh_op_row_kinds(_lib.FRESH_OPS.index("is_in_field"), assert_one=True)
         k_pow = np.zeros(int(sec[1]), dtype=np.uint8)
