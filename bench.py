@@ -654,6 +654,92 @@ def lookup_bench(args):
     print(json.dumps(line))
 
 
+def flow_bench(args):
+    """--records-free-flow: everything a column-taking prover needs of the witness of `batch` one-signature circuits (k = 17), no record written:
+    the whole verify_pkcs1v15_signature element image (h2r_pipeline_verify_pkcs1v15_advice), its lookup multiplicities from the image
+    (h2r_lookup_hist_advice + h2r_lookup_hist_values for assign_integer(sig), assign_integer(n)) and halo2's A', S' of the five lookup arguments
+    (h2r_lookup_permuted_columns).  The image call of batch k + 1 is issued in front of the multiplicities and columns of batch k."""
+    import ctypes
+    torch.cuda.set_device(0)
+    w, bits, e = WORKLOADS["rsa2048_e65537"]
+    B = args.batch if args.batch else 1024
+    usable = (1 << 17) - 6
+    rows0 = 77200
+    kw = dict(columns=True, montgomery=True, col_stride=((rows0 * 32 + 4095) // 4096) * 4096) if (args.columns or args.montgomery) else {}
+    rsa = H.RSAChip(bits, 5, **kw)
+    chip = rsa.bigint_chip()
+    la = H.LookupArgument(chip, rsa_chip=True)
+    ns, xs, un, ux = synth_inputs(w, bits, 0, B)
+    n, sig = chip.assign_integer(un), chip.assign_integer(ux)
+    rng = random.Random(0x68327273 + 31)
+    hashed = torch.tensor([[rng.getrandbits(63) for _ in range(4)] for _ in range(B)], dtype=torch.int64, device="cuda")
+    P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+    thetas = [rng.randrange(P) for _ in range(B)]
+    pipe = H.Pipeline(chip, 2, 2)
+    vl = pipe.verify_compact_layout(e)
+    L = _lib.lib()
+    sec = (ctypes.c_uint64 * 4)()
+    rows = int(L.h2r_verify_advice_rows(chip._ctx, ctypes.byref(vl), sec))
+    kinds = np.zeros(rows, dtype=np.uint8)
+    _lib.check(L.h2r_verify_row_kinds(chip._ctx, ctypes.byref(vl), kinds.ctypes.data), "h2r_verify_row_kinds")
+    kd = torch.from_numpy(kinds).cuda()
+    eb = chip.image_bytes(rows)
+    sets = [dict(img=torch.empty((B, eb), dtype=torch.uint8, device="cuda"), wit=torch.zeros((B, vl.elem_stride), dtype=torch.uint8, device="cuda"),
+                 ws=torch.empty(chip.workspace_bytes(B, vl.pow.num_mul_mods), dtype=torch.uint8, device="cuda"),
+                 powed=torch.zeros((B, chip.num_limbs), dtype=torch.int64, device="cuda"), valid=torch.zeros(B, dtype=torch.uint8, device="cuda"),
+                 st=torch.zeros(B, dtype=torch.uint8, device="cuda"), hist=la.new_hist(B)) for _ in range(2)]
+    cols = (torch.empty((B, 5, usable, 32), dtype=torch.uint8, device="cuda"), torch.empty((B, 5, usable, 32), dtype=torch.uint8, device="cuda"))
+    state = {}
+
+    def step(k):
+        s = sets[k & 1]
+        pipe.verify_pkcs1v15_advice(sig, e, n, hashed, s["wit"], s["ws"], s["powed"], s["valid"], s["st"], s["img"])
+        if k:
+            p = sets[(k - 1) & 1]
+            p["hist"].zero_()
+            la.hist_advice(kd, p["img"], B, p["hist"], status=p["st"])
+            la.hist_values(sig.limbs_dev, 64, 8, p["hist"])
+            la.hist_values(n.limbs_dev, 64, 8, p["hist"])
+            state["out"] = la.permuted_columns(p["hist"], thetas, usable, out=cols)
+
+    for k in range(max(2, args.warmup)):
+        step(k)
+    torch.cuda.synchronize()
+    k0, steps = max(2, args.warmup), args.steps
+    t0 = time.perf_counter()
+    for k in range(k0, k0 + steps):
+        step(k)
+    pipe.join()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    a_perm, s_perm, status = state["out"]
+    assert not status.cpu().numpy().any()
+    # what was timed is the real thing: results against pow(), the multiplicities of the first circuits against the record-based call's
+    last = sets[(k0 + steps - 2) & 1]
+    got = H.AssignedInteger(last["powed"].contiguous(), w).to_big_uint()
+    for i in (0, 1, B - 1):
+        if xs[i] < ns[i]:
+            assert got[i] == pow(xs[i], e, ns[i]), "GPU result differs from pow(x, e, n)"
+    sample = min(B, 4)
+    ref = rsa.verify_pkcs1v15_signature(H.RSAPublicKey(H.AssignedInteger(n.limbs_dev[:sample].contiguous(), w), H.Fix(e)), hashed[:sample].contiguous(),
+                                        H.RSASignature(H.AssignedInteger(sig.limbs_dev[:sample].contiguous(), w)))
+    want = la.hist_verify(ref, la.new_hist(sample))
+    la.hist_values(sig.limbs_dev[:sample].contiguous(), 64, 8, want)
+    la.hist_values(n.limbs_dev[:sample].contiguous(), 64, 8, want)
+    torch.cuda.synchronize()
+    assert torch.equal(last["hist"][:sample], want), "multiplicities counted from the image differ from the records'"
+    img_b, col_b = B * rows * 160, 2 * B * 5 * usable * 32
+    line = {"metric": "records-free prover inputs: circuits/sec (verify element image + lookup multiplicities + A', S')", "value": round(B / dt, 1), "unit": "circuits/s",
+            "n_gpus": 1, "steps": steps, "warmup": max(2, args.warmup), "ms_per_step": round(1e3 * dt, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "rsa2048_e65537, %d one-signature circuits per batch (k = 17): %d-row verify element image + 5 x (A', S') x %d usable rows" % (B, rows, usable),
+                       "representation": {"columns": bool(kw), "montgomery": bool(kw)}, "bytes_per_batch": {"advice_image": img_b, "lookup_columns": col_b},
+                       "placement": "as allocated (no look)"},
+            "roofline": {"bound": "hbm", "achieved": round((img_b + col_b) / dt / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round((img_b + col_b) / dt / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic": None, "kernel": "lookup_fill_kernel + cells_kernel (whole flow)", "algorithmic_bytes_per_launch": img_b + col_b}}
+    print(json.dumps(line))
+
+
 def sub_run(extra, timeout=200):
     """`bench.py <extra>` in a fresh process (same steps cap, no CPU baseline, no counters, no nested sub-runs): the parsed line."""
     import subprocess
@@ -692,6 +778,11 @@ def sub_run_lines(args):
         oc[key] = {"workload": " ".join(extra), "value": d.get("value"), "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step"),
                    "frac": d.get("roofline", {}).get("frac"), "whole_path_hbm_frac": d.get("whole_path_hbm_frac"), "wall_s": d.get("_wall_s"), "error": d.get("error")}
     out["other_configs"] = oc
+    d = sub_run(["--records-free-flow", "--steps", "6", "--warmup", "3"])
+    out["records_free_flow"] = {"what": "bench.py --records-free-flow: per batch of 1,024 one-signature circuits the verify element image (no records), its lookup multiplicities "
+                                        "counted from the image and A', S' of the five lookup arguments (55.6 GB per batch, plain allocations)", "value": d.get("value"), "unit": d.get("unit"),
+                                "ms_per_batch": d.get("ms_per_step"), "GBps": d.get("roofline", {}).get("achieved"), "frac": d.get("roofline", {}).get("frac"), "wall_s": d.get("_wall_s"),
+                                "error": d.get("error")}
     d = sub_run(["--lookup", "--steps", "8", "--warmup", "2"])
     out["lookup"] = {"what": "bench.py --lookup: h2r_lookup_permuted_columns, 256 circuits x 5 arguments (10.7 GB per call)", "whole_call_GBps": d.get("value"),
                      "whole_call_frac": d.get("whole_call_hbm_frac"), "fill_kernel_frac": d.get("roofline", {}).get("frac"),
@@ -734,6 +825,8 @@ def main():
                          "elements (assert_in_field rows + pow rows written directly from the operands by cells_kernel), no record planes; "
                          "with --verify: of its whole verify_pkcs1v15_signature elements (h2r_pipeline_verify_pkcs1v15_advice)")
     ap.add_argument("--lookup", action="store_true", help="the lookup argument's permuted columns (h2r_lookup_permuted_columns) as the product")
+    ap.add_argument("--records-free-flow", action="store_true",
+                    help="the whole records-free flow per batch of one-signature circuits: verify element image + multiplicities from the image + A', S'")
     ap.add_argument("--sub-runs", choices=["auto", "off"], default="auto",
                     help="auto: the default N = 1 line also carries plain_allocations, advice, advice_columns_montgomery, other_configs (C4, C5) and lookup, "
                          "each measured in a fresh process of this script")
@@ -772,6 +865,8 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args.gpus)
+    if args.records_free_flow:
+        return flow_bench(args)
     if args.lookup:
         return lookup_bench(args)
     if args.advice:

@@ -101,6 +101,14 @@ def test_bench_advice_whole_verify_element():
     assert line["value"] > 0 and "0 violations" in line["config"]["post_run_audit"]
 
 
+def test_bench_records_free_flow_line():
+    """--records-free-flow: image + multiplicities from the image + A', S' per batch; bench.py's own checks ran (pow(), multiplicities against the records')."""
+    line = _run(["--records-free-flow", "--batch", "64", "--steps", "3", "--warmup", "2"])
+    assert line["unit"] == "circuits/s" and line["value"] > 0 and 0.05 < line["roofline"]["frac"] < 1.0
+    bb = line["config"]["bytes_per_batch"]
+    assert bb["advice_image"] == 64 * 77200 * 160 and bb["lookup_columns"] == 2 * 64 * 5 * ((1 << 17) - 6) * 32
+
+
 def test_bench_lookup_line():
     line = _run(["--lookup", "--batch", "32", "--steps", "3", "--warmup", "1", "--pmc-traffic", "off", "--placement-candidates", "3"])
     assert line["unit"] == "GB/s" and line["roofline"]["kernel"] == "lookup_fill_kernel" and 0.1 < line["roofline"]["frac"] < 1.0
@@ -112,11 +120,12 @@ def test_bench_default_line_carries_the_sub_runs():
     """What the driver runs (`--gpus 1 --steps K --warmup W`, nothing else) also reports, from fresh processes: the headline as allocated,
     the advice image in both representations (each audited by h2r_advice_check), BASELINE configs 4 and 5, the lookup argument."""
     line = _run(["--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--pmc-traffic", "off"], timeout=900)
-    for key in ("plain_allocations", "advice", "advice_columns_montgomery", "advice_verify_element", "other_configs", "lookup", "scale_anchor"):
+    for key in ("plain_allocations", "advice", "advice_columns_montgomery", "advice_verify_element", "other_configs", "records_free_flow", "lookup", "scale_anchor"):
         assert key in line, key
     assert line["plain_allocations"]["value"] > 0 and 0.2 < line["plain_allocations"]["frac"] < 1.0
     for key in ("advice", "advice_columns_montgomery", "advice_verify_element"):
         assert line[key]["error"] is None and line[key]["value"] > 0 and "0 violations" in line[key]["audit"], line[key]
     assert line["other_configs"]["C4"]["value"] > 0 and line["other_configs"]["C5"]["value"] > 0
     assert line["lookup"]["error"] is None and line["lookup"]["whole_call_GBps"] > 0
+    assert line["records_free_flow"]["error"] is None and line["records_free_flow"]["value"] > 0
     assert line["config"]["pipeline_form"]["record_form"] in ("two-queue", "one-launch step")
