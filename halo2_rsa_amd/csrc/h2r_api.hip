@@ -2600,7 +2600,7 @@ int32_t h2r_lookup_permuted_columns(const h2r_ctx *ctx, const h2r_lookup_config 
     for (u32 i = 0; i < cfg->n_lens; ++i) { sa.tag[i] = cfg->tag[i]; sa.row_off[i] = cfg->row_off[i]; sa.bit_len[i] = cfg->bit_len[i]; }
     sa.f = ctx->fc; sa.ws = ws; sa.status = status;
     sa.mont = (ctx->repr.flags & H2R_ADVICE_MONTGOMERY) ? 1u : 0u;   // theta in, A' / S' out: the ctx's representation
-    hipLaunchKernelGGL(lookup_setup_kernel, dim3((unsigned)(num_elems * LOOKUP_ARGS)), dim3(256), 0, st, sa);
+    hipLaunchKernelGGL(lookup_setup_kernel, dim3((unsigned)(num_elems * LOOKUP_ARGS)), dim3(256), lookup_setup_lds_bytes(cfg->n_rows), st, sa);
     HIP_TRY(hipGetLastError());
     LookupFillArgs fa;
     std::memset(&fa, 0, sizeof fa);

@@ -167,15 +167,19 @@ __device__ __forceinline__ void block_scan_1024(u32 *x, u32 n, u32 *part /* 256 
     __syncthreads();
 }
 
+// LDS of the set-up kernel for a table of n rows (sized by the table, not by LOOKUP_MAX_ROWS: 19 KB instead of 54.5 KB for RSA-2048's 339 rows --
+// next to a cells kernel that holds most of a CU's LDS a 54.5 KB workgroup waited for room, 0.9 ms per 1,024 circuits in the records-free flow)
+__host__ __device__ inline u32 lookup_setup_lds_bytes(u32 n) { return n * 32u + LOOKUP_MAX_LENS * 32u + 5u * n * 4u + 256u * 4u + 16u; }
 __global__ __launch_bounds__(256) void lookup_setup_kernel(LookupSetupArgs a) {
-    __shared__ Fe T[LOOKUP_MAX_ROWS];            // compressed table rows, then the sorted distinct values
-    __shared__ Fe tagth[LOOKUP_MAX_LENS];
-    __shared__ u32 order[LOOKUP_MAX_ROWS];       // row at sorted position i
-    __shared__ u32 gid[LOOKUP_MAX_ROWS];         // group of sorted position i (inclusive scan of the run heads, minus one)
-    __shared__ u32 gm[LOOKUP_MAX_ROWS], gs[LOOKUP_MAX_ROWS], gr[LOOKUP_MAX_ROWS];   // per group: inputs, table entries, non-empty flag
-    __shared__ u32 part[256];
-    __shared__ u32 total_in;
+    extern __shared__ uint4 ls_dyn[];
     const u32 tid = threadIdx.x, n = a.n_rows;
+    Fe *T = reinterpret_cast<Fe *>(ls_dyn);                 // compressed table rows, then the sorted distinct values
+    Fe *tagth = T + n;
+    u32 *order = reinterpret_cast<u32 *>(tagth + LOOKUP_MAX_LENS);   // row at sorted position i
+    u32 *gid = order + n;                                    // group of sorted position i (inclusive scan of the run heads, minus one)
+    u32 *gm = gid + n, *gs = gm + n, *gr = gs + n;           // per group: inputs, table entries, non-empty flag
+    u32 *part = gr + n;                                      // [256]
+    u32 &total_in = part[256];
     const u32 arg = blockIdx.x % LOOKUP_ARGS;
     const u64 elem = blockIdx.x / LOOKUP_ARGS;
     if (!((a.arg_mask >> arg) & 1u)) return;
