@@ -583,7 +583,10 @@ def lookup_bench(args):
     col_bytes = B * 5 * usable * 32
     cand = args.placement_candidates if args.placement_candidates >= 0 else 16   # (eight pairs: with four, a box now and then offers no fast one)
     arena, placement = None, "as allocated"
-    look = os.environ.get("H2R_BENCH_LOOKUP_LOOK", "call")    # call: candidates timed with the call itself (default) | arena: h2r_image_arena_create's streaming fill
+    # roles (default): every candidate as S' next to one fixed A', then every other one as A' next to the best S' -- what the data say is that
+    # allocations fall into TWO classes and the call is fast exactly when its two columns lie in DIFFERENT classes (profiles/r05_lookup_placement.txt);
+    # call: adjacent pairs timed with the call; arena: h2r_image_arena_create's streaming fill (does not predict this call)
+    look = os.environ.get("H2R_BENCH_LOOKUP_LOOK", "roles")
     if cand >= 4 and look == "call":
         # The store rate of a buffer depends on the buffer AND on the kernel that writes it (profiles/r05_lookup_placement.txt: the image arena's
         # streaming fill ranks candidates 0.78-0.93 ms, and two boxes whose kept pair measured 0.78 ms ran this call at 0.69 and 0.84 of the
@@ -603,6 +606,27 @@ def lookup_bench(args):
         out = (pool[2 * best], pool[2 * best + 1])
         placement = {"candidates": len(pool), "look": "the call itself on pairs (A', S') of plain allocations, the fastest pair kept",
                      "call_ms_per_pair": [round(t, 4) for t in ms], "kept_ms": round(ms[best], 4)}
+        del pool
+        torch.cuda.empty_cache()
+    elif cand >= 4 and look == "roles":
+        pool = [torch.empty((B, 5, usable, 32), dtype=torch.uint8, device="cuda") for _ in range(cand)]
+
+        def t_pair(ia, is_):
+            la.permuted_columns(hist, thetas, usable, out=(pool[ia], pool[is_]))
+            ta, tb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ta.record()
+            for _ in range(2):
+                la.permuted_columns(hist, thetas, usable, out=(pool[ia], pool[is_]))
+            tb.record()
+            torch.cuda.synchronize()
+            return ta.elapsed_time(tb) / 2
+        ms_s = {i: t_pair(0, i) for i in range(1, cand)}
+        bs = min(ms_s, key=ms_s.get)
+        ms_a = {j: t_pair(j, bs) for j in range(cand) if j != bs}
+        ba = min(ms_a, key=ms_a.get)
+        out = (pool[ba], pool[bs])
+        placement = {"candidates": cand, "look": "roles: each candidate as S' next to one A', then each as A' next to the best S'",
+                     "ms_as_S": [round(ms_s[i], 4) for i in sorted(ms_s)], "ms_as_A": [round(ms_a[j], 4) for j in sorted(ms_a)], "kept_ms": round(ms_a[ba], 4)}
         del pool
         torch.cuda.empty_cache()
     elif cand >= 2:
