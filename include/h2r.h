@@ -407,7 +407,10 @@ int32_t h2r_arena_create_ex(const h2r_ctx *ctx, uint64_t elem_stride, uint64_t f
  * this is "time a few, keep the fastest" as an export.  The accessors below apply.
  * [measured] The fill's ranking carries over to the cells kernel's images; it does NOT predict h2r_lookup_permuted_columns, whose rate
  * belongs to the PAIR of column buffers it writes (0.65 of the HBM peak on the pair this look kept, 0.77 on the pair fastest under the
- * call itself, same box): for that call time candidate pairs with the call (bench.py --lookup does). */
+ * call itself, same box): for that call time candidate pairs with the call (bench.py --lookup does).  What the measurements show: allocations
+ * fall into two placement classes (runs of consecutive allocations), and TWO CONCURRENT store streams -- A' and S', the images of two cells
+ * kernels in flight -- are fast exactly when their buffers are of different classes (1.64-1.70 against 2.0-2.3 ms for the lookup call): rank
+ * the candidates of one output next to a fixed buffer for the other, under the call that will write them. */
 int32_t h2r_image_arena_create(const h2r_ctx *ctx, uint64_t region_bytes, uint32_t regions, uint32_t candidates, uint64_t max_look_bytes,
                                h2r_stream_t stream, h2r_arena **out);
 void *h2r_arena_region(const h2r_arena *a, uint32_t i);
