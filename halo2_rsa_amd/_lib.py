@@ -103,7 +103,7 @@ class H2RError(RuntimeError):
 
 
 _lib = None
-EXPORTS = ["h2r_ctx_create", "h2r_ctx_create_ex", "h2r_ctx_advice_repr", "h2r_abi_version", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_rsa_compute_range_lens",
+EXPORTS = ["h2r_ctx_create", "h2r_ctx_create_ex", "h2r_ctx_advice_repr", "h2r_abi_version", "h2r_build_id", "h2r_ctx_destroy", "h2r_compute_range_lens", "h2r_rsa_compute_range_lens",
            "h2r_trace_layout", "h2r_pow_fixed_layout", "h2r_pow_var_layout", "h2r_workspace_bytes",
            "h2r_mul_mod_batch", "h2r_square_mod_batch", "h2r_pow_mod_fixed_exp_batch", "h2r_pow_mod_batch",
            "h2r_modpow_public_key_batch", "h2r_modpow_public_key_var_batch", "h2r_pipeline_create", "h2r_pipeline_create_ex", "h2r_pipeline_destroy",
@@ -165,6 +165,8 @@ def lib():
     L.h2r_ctx_advice_repr.argtypes = [vp, ctypes.POINTER(H2RAdviceRepr)]
     L.h2r_abi_version.argtypes = []
     L.h2r_abi_version.restype = u32
+    L.h2r_build_id.argtypes = []
+    L.h2r_build_id.restype = ctypes.c_char_p
     L.h2r_ctx_destroy.argtypes = [vp]
     L.h2r_ctx_destroy.restype = None
     L.h2r_compute_range_lens.argtypes = [u32, u32, ctypes.POINTER(u32), ctypes.POINTER(u32)]

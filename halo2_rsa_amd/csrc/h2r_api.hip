@@ -16,9 +16,9 @@
 #include <new>
 #include <vector>
 
+#define H2R_TU_API 1   // this unit defines the plain kernels of the shared headers
 #include "h2r.h"
-#include "h2r_kernels.hpp"
-#include "h2r_cells.hpp"
+#include "h2r_internal.hpp"
 #include "h2r_varrows.hpp"
 #include "h2r_copymap.hpp"
 #include "h2r_layout.hpp"
@@ -93,48 +93,7 @@ struct ProfScope {  // start/stop events of one launch when profiling is armed
     }
 };
 
-// Developer knobs: compiled in ONLY by the -DH2R_DEV_KNOBS build (python -m halo2_rsa_amd._build <name> -DH2R_DEV_KNOBS,
-// selected with H2R_LIB by the sweeps under tools/).  The product library never reads the environment: every knob
-// keeps the measured default below.
-struct Knobs {
-    int chain_nw = 0, chain_deep = -1;          // H2R_CHAIN_NW, H2R_CHAIN_DEEP
-    long trace_dyn_lds = -1, trace_prio = -1;    // H2R_TRACE_DYN_LDS, H2R_TRACE_PRIO
-    long chain_prio = -1, ablate = 0;            // H2R_CHAIN_PRIO, H2R_ABLATE (needs the -DH2R_ABLATION build)
-    int pipe_stream_prio = -1;                   // H2R_PIPE_STREAM_PRIO = low (default) | normal | high  -> -1 | 0 | +1
-    bool chain_timing = false;                   // H2R_CHAIN_TIMING (needs the -DH2R_CHAIN_TIMING build)
-    bool pipe_serialize = false;                 // H2R_PIPE_SERIALIZE=1: with two record streams, a record kernel also waits for the previous one
-    long plain_overlap = -1;                     // H2R_PLAIN_OVERLAP=0: the plain pow exports never overlap their sub-batches internally
-    long arena_chunk_mb = 0;                     // H2R_ARENA_CHUNK_MB: physical chunk size of the arena's regions
-    long pipe_sub_batch = 0;                     // H2R_PIPE_SUB_BATCH: elements per chain + record kernel pair inside a pipelined call (multiple of 256)
-    long pipe_pace = -1;                         // H2R_PIPE_PACE=0|1: sub-batch i+1's chain kernel waits for sub-batch i-1's record kernel
-    long pipe_step = -1;                         // H2R_PIPE_STEP=0: never issue a pipeline step as one launch (the two-queue form for every shape)
-    long step_chain_x2_per_cu = 0;               // H2R_STEP_CHAIN_X2_PER_CU=n: n/2 chain workgroups per CU in a step launch (0 = the measured default)
-    unsigned long pipe_cu_mask = 0;              // H2R_PIPE_CU_MASK=<hex word>: the record stream is created with this 32-bit CU mask repeated over the device (experiment)
-    long pipe_cu_mask_words = 0;                 // H2R_PIPE_CU_MASK_WORDS=n: only the first n 32-bit words carry the mask, the rest are zero
-    long verify_fold = -1;                       // H2R_VERIFY_FOLD=0|1: the verifier's witness inside the step launch's chain role (-1 = the measured default per shape)
-    long exp_segments = -1;                      // H2R_EXP_SEGMENTS=n: segments a long exponent is walked in (0 / 1 = never; -1 = the default rule, exp_segment_count)
-    long single_call_segments = -1;              // H2R_SINGLE_CALL_SEGMENTS=n: segments of a SHORT exponent in a single stream-ordered call of 513..1,536 RSA-2048 elements
-    long rowprog_stage_rows = 0;                 // H2R_ROWPROG_STAGE_ROWS=64|128|256: rows (= threads) of a row-program workgroup (0 = the rule in launch_row_prog)
-    long cells_nwv = 0;                          // H2R_CELLS_NWV=1|8: waves per cells_kernel workgroup of a Montgomery ctx (0 = the rule at ctx creation)
-    Knobs() {
-#ifdef H2R_DEV_KNOBS
-        auto num = [](const char *name, long dflt) { const char *v = std::getenv(name); return v ? std::atol(v) : dflt; };
-        chain_nw = (int)num("H2R_CHAIN_NW", 0); chain_deep = (int)num("H2R_CHAIN_DEEP", -1);
-        trace_dyn_lds = num("H2R_TRACE_DYN_LDS", -1); trace_prio = num("H2R_TRACE_PRIO", -1);
-        chain_prio = num("H2R_CHAIN_PRIO", -1); ablate = num("H2R_ABLATE", 0);
-        const char *pe = std::getenv("H2R_PIPE_STREAM_PRIO");
-        pipe_stream_prio = !pe ? -1 : (!std::strcmp(pe, "high") ? 1 : (!std::strcmp(pe, "low") ? -1 : 0));
-        chain_timing = std::getenv("H2R_CHAIN_TIMING") != nullptr;
-        { const char *g = std::getenv("H2R_PIPE_SERIALIZE"); pipe_serialize = g && g[0] == '1'; }
-        { const char *m = std::getenv("H2R_PIPE_CU_MASK"); pipe_cu_mask = m ? std::strtoul(m, nullptr, 16) : 0; pipe_cu_mask_words = num("H2R_PIPE_CU_MASK_WORDS", 0); }
-        verify_fold = num("H2R_VERIFY_FOLD", -1); exp_segments = num("H2R_EXP_SEGMENTS", -1); single_call_segments = num("H2R_SINGLE_CALL_SEGMENTS", -1);
-        pipe_step = num("H2R_PIPE_STEP", -1); step_chain_x2_per_cu = num("H2R_STEP_CHAIN_X2_PER_CU", 0);
-        rowprog_stage_rows = num("H2R_ROWPROG_STAGE_ROWS", 0); cells_nwv = num("H2R_CELLS_NWV", 0);
-        pipe_sub_batch = num("H2R_PIPE_SUB_BATCH", 0); arena_chunk_mb = num("H2R_ARENA_CHUNK_MB", 0); plain_overlap = num("H2R_PLAIN_OVERLAP", -1); pipe_pace = num("H2R_PIPE_PACE", -1);
-#endif
-    }
-};
-const Knobs &knobs() { static const Knobs k; return k; }
+// (developer knobs: h2r_internal.hpp)
 
 // Element strides, in units of 256 bytes.  The record kernel's store rate depends on how consecutive elements' records
 // fall on the HBM channel interleave (sweep of the stride at batch 1024, profiles/r01_elem_stride_sweep.txt): the
@@ -212,16 +171,6 @@ struct h2r_ctx {
 
 namespace {
 
-// Shapes with a compiled record kernel.  BigIntChip::new only asserts bits_len % limb_width == 0 (chip.rs:1175); here
-// num_limbs must also be a multiple of 4 (64-bit limbs, up to 4096 bits: RSA-1024/1536/2048/3072/4096 ...) or of 8
-// (32-bit limbs, up to 4096 bits), so that every accumulator row is a whole number of 64-byte store segments.
-constexpr u32 kLStep64 = 4, kLMax64 = 64, kLStep32 = 8, kLMax32 = 128;
-bool shape_supported(u32 w, u32 L) {
-    if (w == 64) return L >= kLStep64 && L <= kLMax64 && L % kLStep64 == 0;
-    if (w == 32) return L >= kLStep32 && L <= kLMax32 && L % kLStep32 == 0;
-    return false;
-}
-
 void put_le(u8 *dst, const U256 &v, u32 nbytes) { std::memcpy(dst, v.v, nbytes); }
 
 // Fill the input-independent planes of is_equal_muled (accumulated_extra chain, chip.rs:869-875).
@@ -250,107 +199,13 @@ void build_const_record(h2r_ctx *c) {
     }
 }
 
-template <int LW, int L>
-hipError_t launch_trace_t(const TraceArgs &ta, u32 lds_per_cu, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
-    // the kernel hard-codes the accumulator row strides layout_compute derives for (LW, L)
-    if (ta.acc_lo_group != (LW == 64 ? 3ull * (2 * L * 16) : (u64)L * 16) || ta.acc_hi_group != ta.acc_lo_group ||
-        ta.acc_lo_row != (LW == 64 ? 2u * L * 16 : 0u) || ta.acc_spg != (LW == 64 ? 2u : 1u)) return hipErrorInvalidValue;
-    // (measured for the RSA-2048 shape: 128- and 64-thread workgroups are no better at any residency)
-    constexpr int BT = TraceGeo<L>::BT, IPB = TraceGeo<L>::IPB;
-    const u64 blocks = (ta.n_items + IPB - 1) / IPB;
-    if (blocks == 0) return hipSuccess;
-    // Residency cap: `residency` workgroups per CU (0 = whatever fits).  The cap is enforced the way occupancy is
-    // enforced on this hardware -- by the workgroup's LDS allocation: the launch requests as much (untouched) dynamic
-    // LDS as makes exactly `residency` workgroups fill a CU's LDS.  ea/eb (nullable): start/stop events stamped by
-    // the dispatch itself.
-    u32 dyn = ta.dyn_lds;
-    if (ta.residency) {
-        static const u32 static_lds = [] {   // the kernel's own (static) LDS, once per instantiation
-            hipFuncAttributes fa;
-            return hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&trace_kernel<LW, L, BT>)) == hipSuccess ? (u32)fa.sharedSizeBytes : 0u;
-        }();
-        const u32 per = lds_per_cu / ta.residency;
-        dyn = per > static_lds + 1024 ? ((per - static_lds - 512) & ~15u) : 0u;   // `residency` fit, `residency + 1` do not
-    }
-    if (dyn > 48 * 1024) {   // large requests must be announced (once per device; harmless to repeat)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&trace_kernel<LW, L, BT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        (void)hipGetLastError();
-    }
-    hipExtLaunchKernelGGL((trace_kernel<LW, L, BT>), dim3((unsigned)blocks), dim3(BT), dyn, st, ea, eb, 0, ta);
-    return hipGetLastError();
-}
-// one instantiation per supported num_limbs: L = STEP, 2 STEP, ..., MAXL
-template <int LW, int STEP, int I>
-hipError_t launch_trace_w(u32 L, const TraceArgs &ta, u32 lds_per_cu, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
-    if constexpr (I == 0) return hipErrorInvalidValue;
-    else {
-        if (L == (u32)(I * STEP)) return launch_trace_t<LW, I * STEP>(ta, lds_per_cu, st, ea, eb);
-        return launch_trace_w<LW, STEP, I - 1>(L, ta, lds_per_cu, st, ea, eb);
-    }
-}
+// The template kernel families are instantiated in their own translation units (h2r_internal.hpp): thin ctx-taking wrappers here.
 hipError_t launch_trace(const h2r_ctx *c, const TraceArgs &ta, hipStream_t st, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr) {
-    const u32 w = c->layout.limb_width, L = c->L;
-    if (!shape_supported(w, L)) return hipErrorInvalidValue;
-    if (w == 64) return launch_trace_w<64, kLStep64, kLMax64 / kLStep64>(L, ta, c->lds_per_cu, st, ea, eb);
-    return launch_trace_w<32, kLStep32, kLMax32 / kLStep32>(L, ta, c->lds_per_cu, st, ea, eb);
-}
-// grid_cap: upper bound on the chain kernel's workgroups (0 = one per element); a smaller grid walks the batch
-template <int K, int NW, bool DEEP>
-hipError_t launch_chain_t(const ChainArgs &ca, u64 grid_cap, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
-    if (ca.batch == 0) return hipSuccess;
-    if (ca.pre) {   // the shared modulus' Barrett constants, once, ahead of the elements' chains
-        hipLaunchKernelGGL((recip_kernel<K, NW>), dim3(1), dim3(64 * NW), 0, st, ca.n, ca.kreal, const_cast<u32 *>(ca.pre));
-        if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
-    }
-    const u64 grid = grid_cap && grid_cap < ca.batch ? grid_cap : ca.batch;
-    if (ca.state) hipExtLaunchKernelGGL((chain_kernel<K, NW, DEEP, true>), dim3((unsigned)grid), dim3(64 * NW), 0, st, ea, eb, 0, ca);   // a segment of a long exponent
-    else hipExtLaunchKernelGGL((chain_kernel<K, NW, DEEP, false>), dim3((unsigned)grid), dim3(64 * NW), 0, st, ea, eb, 0, ca);
-    return hipGetLastError();
+    return launch_trace_shape(c->layout.limb_width, c->L, c->lds_per_cu, ta, st, ea, eb);
 }
 // co_running: the call's record kernel of the PREVIOUS batch runs next to this chain kernel (pipeline mode)
 hipError_t launch_chain(const h2r_ctx *c, const ChainArgs &ca, bool co_running, hipStream_t st, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr) {
-    // Footprint next to a record kernel: at most four 4-wave (two 8-wave) workgroups per CU, the residency the
-    // batch-1024 RSA-2048 call has; a larger batch is walked by that grid instead of queueing more workgroups (a chain
-    // kernel with 8,192 workgroups kept every CU full of its waves and cost the record kernel 15 % of its store rate).
-    const u64 cap4 = co_running ? 4ull * c->num_cus : 0, cap2 = co_running ? 2ull * c->num_cus : 0;
-    // The chain kernel is compiled for K = 8, 16, 32, 64, 96, 128 digits; any other size runs as the next larger one with
-    // zero high digits (ca.kreal digits in memory).  NW = waves per element (a multiple of the 64-column groups).
-    // K = 96 (RSA-3072) is its own build: run as K = 128 it did 1.8x the multiply-accumulates and made the chain kernel
-    // the longer leg of the pipeline (0.57-0.65 ms against a 0.49 ms record kernel per 1,024 signatures).
-    const u32 K = ca.kreal <= 8 ? 8 : ca.kreal <= 16 ? 16 : ca.kreal <= 32 ? 32 : ca.kreal <= 64 ? 64 : ca.kreal <= 96 ? 96 : 128;
-    switch (K) {
-        case 8: return launch_chain_t<8, 1, false>(ca, 4 * cap4, st, ea, eb);
-        case 16: return launch_chain_t<16, 1, false>(ca, 4 * cap4, st, ea, eb);
-        case 32: return launch_chain_t<32, 4, false>(ca, cap4, st, ea, eb);
-        case 64: {
-            // Two chains per element side by side (chain_dual_kernel: squarings and multiplies of one exponent bit in lockstep, eight
-            // waves): for latency-bound batches -- at most two elements per CU -- of variable exponents (two independent mul_mods per
-            // bit) and of DENSE fixed exponents (a zero bit costs the multiply group a dropped mul_mod).  BASELINE config 5: 3,072
-            // dependent mul_mods become 2,048 steps.
-            if (knobs().chain_nw == 0 && knobs().chain_deep < 0 && ca.mode != CHAIN_MULMOD && !ca.pre && ca.batch <= 2ull * c->num_cus) {
-                u32 pop = 0;
-                for (u32 wi = 0; wi < (ca.e.nbits + 31) / 32; ++wi) pop += (u32)__builtin_popcount(ca.e.words[wi]);
-                const bool dense = ca.mode == CHAIN_POW_VAR || (ca.e.nbits >= 64 && 4 * pop >= ca.e.nbits);
-                if (dense) {
-                    const u64 grid = cap2 && cap2 < ca.batch ? cap2 : ca.batch;
-                    hipExtLaunchKernelGGL((chain_dual_kernel<64, true>), dim3((unsigned)grid), dim3(512), 0, st, ea, eb, 0, ca);
-                    return hipGetLastError();
-                }
-            }
-            // Throughput build (6 blocks per CU) when the batch fills the chip; latency build (deep operand prefetch,
-            // 139 VGPRs) when there are at most two elements per CU and each chain's own latency is what the call
-            // waits for (BASELINE config 5: 256 elements x 3,072 dependent mul_mods: 9.4 -> 7.8 ms, tools/c5_sweep.sh).
-            const int nw_env = knobs().chain_nw, deep_env = knobs().chain_deep;
-            const bool small = ca.batch <= 512;
-            const int nw = nw_env ? nw_env : 4;
-            const bool deep = deep_env >= 0 ? deep_env != 0 : small;
-            if (nw == 8) return deep ? launch_chain_t<64, 8, true>(ca, cap2, st, ea, eb) : launch_chain_t<64, 8, false>(ca, cap2, st, ea, eb);
-            if (nw == 2) return launch_chain_t<64, 2, false>(ca, 2 * cap4, st, ea, eb);
-            return deep ? launch_chain_t<64, 4, true>(ca, cap4, st, ea, eb) : launch_chain_t<64, 4, false>(ca, cap4, st, ea, eb);
-        }
-        case 96: return launch_chain_t<96, 6, false>(ca, cap4 * 2 / 3, st, ea, eb);
-        default: return launch_chain_t<128, 8, false>(ca, cap2, st, ea, eb);
-    }
+    return launch_chain_shape(c->num_cus, ca, co_running, st, ea, eb);
 }
 
 struct ScratchGuard {  // stream-ordered scratch when the caller passes workspace == NULL
@@ -671,6 +526,8 @@ int32_t h2r_ctx_create_ex(const h2r_params *params, const h2r_advice_repr *repr,
             // 48 x 64-bit 3.9 / 3.1 / 3.5, 32 x 64-bit 5.2 / 2.6 / 2.9 (tools/cells_nwv_probe.py, profiles/r05_cells_representations.txt)
             const u32 nwv_env = (knobs().cells_nwv == 1 || knobs().cells_nwv == 8) ? (u32)knobs().cells_nwv : 0u;   // (developer A/B)
             c->cells_nwv = !mont ? 1u : (nwv_env ? nwv_env : (L >= 64 ? 8u : 1u));
+            // (a device whose CU has less LDS than the eight-wave plan asks for runs the one-wave plan instead of failing at the first launch)
+            if (c->cells_nwv > 1 && cells_lds_plan(w, L, mont, c->cells_nwv).total > c->lds_per_cu) c->cells_nwv = 1;
             const CellsLds lp = cells_lds_plan(w, L, mont, c->cells_nwv);
             u32 *fs = reinterpret_cast<u32 *>(&kt[CELLS_KT_FSRC]);
             for (u32 k = 0; k < ADVICE_COL_ROWS * 3; ++k) {
@@ -940,6 +797,7 @@ int32_t h2r_verify_pkcs1v15_var_batch(const h2r_ctx *ctx, const void *sig, const
 
 int32_t h2r_verify_trace_flatten(const h2r_ctx *ctx, const h2r_verify_layout *vl, const void *elem_host, void *stream_out) try {
     if (!ctx || !vl || !elem_host || !stream_out) return H2R_E_NULL;
+    if (vl->pow.off_records == UINT64_MAX) return H2R_E_SHAPE;   // h2r_verify_layout_compact: no records to flatten
     const u8 *e = static_cast<const u8 *>(elem_host);
     u8 *o = static_cast<u8 *>(stream_out);
     const AuxGeom g(ctx->L, ctx->layout.limb_width);
@@ -1438,61 +1296,20 @@ namespace {
 // 32 limbs -- 64-digit chains on four waves, record workgroups of 256 threads), at batches the throughput chain build serves.
 // Measured against the two-queue form on the same boxes (bench.py, H2R_PIPE_STEP=0|1): 1,024 per call +1..5 %, 2,048 per call
 // +0..3 %, 8,192 as ONE step launch -4..+1 % -- so a call above 4,096 is walked as several launches of at most 4,096.
-// The shapes with a step build: (limb width, limbs) -> (chain digits K, waves NW).  A step's workgroup is the chain role's.
-struct StepShape { u32 w, L, K, NW; };
-constexpr StepShape kStepShapes[] = {{64, 32, 64, 4}, {64, 16, 32, 4}, {32, 128, 128, 8}, {64, 64, 128, 8}, {64, 48, 96, 6}};
-const StepShape *step_shape(const h2r_ctx *c) {
-    for (const StepShape &s : kStepShapes) if (c->layout.limb_width == s.w && c->L == s.L && c->K == s.K) return &s;
-    return nullptr;
-}
+const StepShape *step_shape(const h2r_ctx *c) { return step_shape_of(c->layout.limb_width, c->L, c->K); }
 bool step_eligible(const h2r_ctx *c, u64 batch, const void *trace, u32 T) {
     return knobs().pipe_step != 0 && knobs().chain_nw == 0 && step_shape(c) && batch > 512 && trace && T;
 }
 constexpr u64 kStepMax = 4096;   // elements per step launch: a larger call is walked as equal parts of at most this size
-// One step: the records described by `ta` (an earlier sub-batch) and the chains described by `ca`, one launch on `st`.
-extern "C++" {
-template <int K, int NW, int LW, int L>
-hipError_t launch_step_t(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, const AuxArgs *va, const Sha256Args *sha, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
-    constexpr int IPB = (64 * NW) / TraceGeo<L>::TPI;                   // record items per workgroup of this launch
-    const u64 rec_blocks = (ta.n_items + IPB - 1) / IPB;
-    // chain workgroups per CU: four 4-wave ones (what runs next to a record kernel on two queues), two 6- or 8-wave ones
-    // (measured, tools/step_shapes_ab.sh, profiles/r03_step_shapes.txt: RSA-3072 1.5 / 2 / 3 / 4 per CU -> 1.91 / 2.12 / 1.79 / 1.77 M
-    //  assigns/s; RSA-4096 1 / 1.5 / 2 / 3 -> 1.04 / 1.22 / 1.44 / 1.18 M; 128 x 32-bit limbs 1 / 1.5 / 2 / 3 -> 0.599 / 0.606 / 0.606 / 0.544 M)
-    u64 per_cu4 = NW == 4 ? 4ull * c->num_cus : 2ull * c->num_cus;
-    if (knobs().step_chain_x2_per_cu > 0) per_cu4 = (u64)knobs().step_chain_x2_per_cu * c->num_cus / 2;
-    u32 n_chain = (u32)std::min<u64>(ca.batch, per_cu4);
-    n_chain = (n_chain + 7) & ~7u;                                     // keeps blockIdx % 8 (the XCD) of the record role's workgroups
-    AuxArgs none;
-    std::memset(&none, 0, sizeof none);
-    const u64 n_aux = aa ? aa->batch : 0;
-    Sha256Args no_sha;
-    std::memset(&no_sha, 0, sizeof no_sha);
-    const u64 n_sha = sha ? ((sha->batch + 64 * NW - 1) / (64 * NW) + 7) & ~7ull : 0;   // one thread per message; a multiple of 8 (the XCD of what follows)
-    const dim3 grid((unsigned)(n_sha + n_chain + rec_blocks + n_aux));
-    if (va || sha) hipExtLaunchKernelGGL((step_kernel<K, NW, LW, L, true>), grid, dim3(64 * NW), 0, st, ea, eb, 0,
-                                         ca, ta, aa ? *aa : none, va ? *va : none, sha ? *sha : no_sha, (u32)n_sha, n_chain, (u32)rec_blocks);
-    else hipExtLaunchKernelGGL((step_kernel<K, NW, LW, L, false>), grid, dim3(64 * NW), 0, st, ea, eb, 0,
-                               ca, ta, aa ? *aa : none, none, sha ? *sha : no_sha, (u32)n_sha, n_chain, (u32)rec_blocks);
-    return hipGetLastError();
-}
-}  // extern "C++"
+// One step: the records described by `ta` (an earlier sub-batch) and the chains described by `ca`, one launch on `st` (h2r_tu_step.hip).
 hipError_t launch_step(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, const AuxArgs *va, const Sha256Args *sha, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
     const StepShape *s = step_shape(c);
     if (!s) return hipErrorInvalidValue;
-    if (s->L == 32) return launch_step_t<64, 4, 64, 32>(c, ca, ta, aa, va, sha, st, ea, eb);
-    if (s->L == 16) return launch_step_t<32, 4, 64, 16>(c, ca, ta, aa, va, sha, st, ea, eb);
-    if (s->L == 128) return launch_step_t<128, 8, 32, 128>(c, ca, ta, aa, va, sha, st, ea, eb);
-    if (s->L == 64) return launch_step_t<128, 8, 64, 64>(c, ca, ta, aa, va, sha, st, ea, eb);
-    return launch_step_t<96, 6, 64, 48>(c, ca, ta, aa, va, sha, st, ea, eb);
+    return launch_step_shape(*s, c->num_cus, ca, ta, aa, va, sha, st, ea, eb);
 }
 u32 step_shared_bytes(const h2r_ctx *c) {
     const StepShape *s = step_shape(c);
-    if (!s) return 0;
-    if (s->L == 32) return (u32)sizeof(StepShared<64, 4, 64, 32>);
-    if (s->L == 16) return (u32)sizeof(StepShared<32, 4, 64, 16>);
-    if (s->L == 128) return (u32)sizeof(StepShared<128, 8, 32, 128>);
-    if (s->L == 64) return (u32)sizeof(StepShared<128, 8, 64, 64>);
-    return (u32)sizeof(StepShared<96, 6, 64, 48>);
+    return s ? step_shared_bytes_shape(*s) : 0;
 }
 // The pending records alone (the end of a train of steps, or a call that cannot be issued as a step); `st` is ordered behind them.
 int32_t pipeline_flush(h2r_pipeline *p, hipStream_t st) {
@@ -2498,6 +2315,7 @@ int32_t lookup_hist_fresh_impl(const h2r_ctx *ctx, const h2r_lookup_config *cfg,
 int32_t h2r_lookup_hist_verify(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const h2r_verify_layout *vl, const void *trace,
                                uint64_t num_elems, const uint8_t *status, uint32_t *hist, h2r_stream_t stream) try {
     if (!ctx || !cfg || !vl || !trace || !hist) return H2R_E_NULL;
+    if (vl->pow.off_records == UINT64_MAX) return H2R_E_SHAPE;   // h2r_verify_layout_compact: the q / r limbs and carries are not in this witness (h2r_lookup_hist_advice counts them from the image)
     int32_t rc = lookup_hist_fresh_impl(ctx, cfg, H2R_OP_IS_IN_FIELD, trace, vl->off_in_field, vl->elem_stride, num_elems, status, hist, stream);   // (a failed element counts nothing, as in the two passes below)
     if (!rc) rc = h2r_lookup_hist_records(ctx, cfg, trace, vl->pow.off_records, vl->elem_stride, num_elems, vl->pow.num_mul_mods, status, hist, stream);
     if (!rc) rc = lookup_hist_values_impl(ctx, cfg, static_cast<const u8 *>(trace) + vl->off_em + 12, 4, 2, num_elems, vl->elem_stride, 12, 32, 4,
@@ -2854,6 +2672,7 @@ int32_t h2r_pow_trace_emit_stream(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
                                   uint64_t batch, uint32_t flags, void *stream_out, uint64_t out_stride, uint64_t out_off,
                                   h2r_stream_t stream) try {
     if (!ctx || !pl || !trace || !stream_out) return H2R_E_NULL;
+    if (pl->off_records == UINT64_MAX) return H2R_E_SHAPE;   // a witness-only layout (h2r_pow_layout_compact) holds no records
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (out_stride < out_off + h2r_pow_stream_bytes(ctx, pl, flags)) return H2R_E_SHAPE;
     const h2r_layout &lo = ctx->layout;
@@ -2933,18 +2752,7 @@ int32_t launch_cells(const h2r_ctx *ctx, CellsArgs &ca, hipStream_t st) {
     if (lds < quarter) lds = quarter;
     if (lds > ctx->lds_per_cu) return H2R_E_UNSUPPORTED;
     ProfScope ps(H2R_KERNEL_CELLS, st, true);
-    auto go = [&](auto kernel, u32 threads) {
-        if (lds > 48 * 1024) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            (void)hipGetLastError();
-        }
-        hipExtLaunchKernelGGL(kernel, dim3((unsigned)ca.n_items), dim3(threads), lds, st, ps.a, ps.on ? ps.b : nullptr, 0, ca);
-    };
-    const bool w64 = lo.limb_width == 64;
-    if (!mont) { if (w64) go(&cells_kernel<64>, 64); else go(&cells_kernel<32>, 64); }
-    else if (nwv == 1) { if (w64) go(&cells_kernel<64, 0, true>, 64); else go(&cells_kernel<32, 0, true>, 64); }
-    else { if (w64) go(&cells_kernel<64, 0, true, 8>, 512); else go(&cells_kernel<32, 0, true, 8>, 512); }
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(launch_cells_shape(lo.limb_width, mont, nwv, lds, ca, st, ps.a, ps.on ? ps.b : nullptr));
     return H2R_OK;
 }
 }  // namespace
@@ -2983,6 +2791,7 @@ int32_t pow_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void
     if (!ctx || !pl || !n || !workspace || !dst.base) return H2R_E_NULL;
     const bool var = pl->off_e_bits != UINT64_MAX;
     if (!trace && (var || !(flags & H2R_ADVICE_DIRECT))) return H2R_E_NULL;   // (a Var element's e_bits / selected planes live in the trace)
+    if (!(flags & H2R_ADVICE_DIRECT) && pl->off_records == UINT64_MAX) return H2R_E_SHAPE;   // the record-read image needs records: a witness-only layout serves H2R_ADVICE_DIRECT only
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     if (pl->num_mul_mods == 0 || batch == 0) return H2R_OK;
     H2R_ON_DEVICE(ctx->params.device);
@@ -3437,6 +3246,20 @@ int32_t layout_valid(const h2r_advice_layout *layout) {   // every entry a permu
     }
     return H2R_OK;
 }
+// the kinds whose rows are RangeChip::assign decomposition rows (lookup-enabled): e carries "what remains", the lookups read a..d, the overflow lookup reads a
+bool is_decompose_kind(u32 k) {
+    return (k >= ROWK_RANGE_LIMB && k < ROWK_RANGE_CARRY + 8) || (k >= ROWK_RANGE_U32 && k < ROWK_RANGE_U32 + 8) ||
+           (k >= ROWK_BITS_COMPOSE && k < ROWK_BITS_COMPOSE_LAST + 64);
+}
+// What h2r_advice_check / h2r_lookup_hist_advice also need of a (possibly hand-filled) layout: their lookup passes read the PHYSICAL columns
+// 0..3 (composition) and 0 (overflow) of a decomposition row, so such a row must keep a at column 0 and e at column 4 -- the rule
+// h2r_advice_layout_custom enforces (layout_perm_valid); any other table would give false violations or wrong multiplicities silently.
+int32_t layout_lookup_valid(const h2r_advice_layout *layout) {
+    if (const int32_t rc = layout_valid(layout)) return rc;
+    for (u32 k = 0; k < 256; ++k)
+        if (is_decompose_kind(k) && (layout->column_of[k][0] != 0 || layout->column_of[k][4] != 4)) return H2R_E_SHAPE;
+    return H2R_OK;
+}
 }  // namespace
 
 int32_t h2r_advice_layout_default(h2r_advice_layout *out) try {
@@ -3454,8 +3277,7 @@ int32_t h2r_advice_layout_custom(const h2r_ctx *ctx, const uint8_t *kinds, const
         const int32_t rc = h2r_advice_fixed_row(ctx, nullptr, kinds[i], &f);
         if (rc) return rc;
         const u32 k = kinds[i];
-        const bool decompose = (k >= ROWK_RANGE_LIMB && k < ROWK_RANGE_CARRY + 8) || (k >= ROWK_RANGE_U32 && k < ROWK_RANGE_U32 + 8) ||
-                               (k >= ROWK_BITS_COMPOSE && k < ROWK_BITS_COMPOSE_LAST + 64);
+        const bool decompose = is_decompose_kind(k);
         u8 col[5];
         for (int c = 0; c < 5; ++c) col[c] = column_of[i][c];
         if (!layout_perm_valid(col, f, decompose)) return H2R_E_SHAPE;
@@ -3582,7 +3404,7 @@ int32_t h2r_pipeline_modpow_public_key_advice(h2r_pipeline *p, const void *x, co
 
 // ---- the whole RSAChip::verify_pkcs1v15_signature element as advice rows, no records, pipelined --------------------------------
 // The witness-only form of a verify layout: the element keeps its in-field and encoded-message witness (what the row programs read)
-// and nothing else -- no record planes.  `pow` is unchanged (row counts, the number of mul_mods); off_records marks the absence.
+// and nothing else -- no record planes.  `pow` keeps its counts (rows, the number of mul_mods); pow.off_records = UINT64_MAX marks the absence.
 int32_t h2r_verify_layout_compact(const h2r_ctx *ctx, const h2r_verify_layout *full, h2r_verify_layout *out) try {
     if (!ctx || !full || !out) return H2R_E_NULL;
     if (ctx->layout.limb_width != 64 || ctx->L < 9) return H2R_E_SHAPE;
@@ -3591,6 +3413,7 @@ int32_t h2r_verify_layout_compact(const h2r_ctx *ctx, const h2r_verify_layout *f
     out->off_in_field = 0;
     out->off_em = round_up(g.in_field_sz(), 256);
     out->elem_stride = round_up(out->off_em + g.em_sz(), 256);
+    out->pow.off_records = UINT64_MAX;   // no record planes: the record exports refuse this layout (H2R_E_SHAPE)
     if (full->pow.off_e_bits != UINT64_MAX) {   // a Var element: its pow witness (selected operands, result, exponent bits) behind the EM region
         h2r_pow_layout pc;
         const int32_t rc = h2r_pow_layout_compact(ctx, &full->pow, &pc);
@@ -3854,7 +3677,7 @@ int32_t h2r_advice_check(const h2r_ctx *ctx, const h2r_lookup_config *cfg, const
     if (flags & ~H2R_F_SHARED_MODULUS) return H2R_E_UNSUPPORTED;
     h2r_advice_layout ident;
     if (!layout) { h2r_advice_layout_default(&ident); layout = &ident; }
-    else if (const int32_t rc = layout_valid(layout)) return rc;
+    else if (const int32_t rc = layout_lookup_valid(layout)) return rc;
     AdviceCheckArgs ca;
     std::memset(static_cast<void *>(&ca), 0, sizeof ca);
     if (const int32_t rc = advice_dst(ctx, const_cast<void *>(image), out_stride, rows, batch, &ca.img)) return rc;
@@ -3893,7 +3716,7 @@ int32_t h2r_lookup_hist_advice(const h2r_ctx *ctx, const h2r_lookup_config *cfg,
     if (cfg->n_rows == 0 || cfg->n_rows > (u32)LOOKUP_MAX_ROWS || cfg->n_lens == 0 || cfg->n_lens > H2R_LOOKUP_MAX_LENS) return H2R_E_SHAPE;
     h2r_advice_layout ident;
     if (!layout) { h2r_advice_layout_default(&ident); layout = &ident; }
-    else if (const int32_t rc = layout_valid(layout)) return rc;
+    else if (const int32_t rc = layout_lookup_valid(layout)) return rc;
     AdviceHistArgs ha;
     std::memset(static_cast<void *>(&ha), 0, sizeof ha);
     if (const int32_t rc = advice_dst(ctx, const_cast<void *>(image), image_stride, rows, batch, &ha.img)) return rc;
@@ -3985,6 +3808,7 @@ int32_t h2r_pow_trace_check(const h2r_ctx *ctx, const h2r_pow_layout *pl, const 
                             size_t e_len, uint32_t flags, const void *trace, uint64_t elem_stride, const void *workspace,
                             uint64_t batch, const uint8_t *status, uint32_t *bad_out, uint32_t *first_bad_out, h2r_stream_t stream) try {
     if (!ctx || !pl || !x || !n || !trace || !workspace || !bad_out) return H2R_E_NULL;
+    if (pl->off_records == UINT64_MAX) return H2R_E_SHAPE;   // a witness-only layout (h2r_pow_layout_compact) holds no records to audit
     if (ctx->params.device < 0) return H2R_E_UNSUPPORTED;
     const bool var = pl->off_e_bits != UINT64_MAX;
     if (!var && !e_le && e_len) return H2R_E_NULL;
@@ -4244,6 +4068,7 @@ int32_t h2r_pow_trace_flatten(const h2r_ctx *ctx, const h2r_pow_layout *pl, cons
 
 int32_t h2r_pow_trace_flatten_ex(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *elem_host, uint32_t flags, void *stream_out) try {
     if (!ctx || !pl || !elem_host || !stream_out) return H2R_E_NULL;
+    if (pl->off_records == UINT64_MAX) return H2R_E_SHAPE;   // a witness-only layout (h2r_pow_layout_compact) holds no records
     if (flags & ~H2R_STREAM_FIELD_AB) return H2R_E_UNSUPPORTED;
     const h2r_layout &lo = ctx->layout;
     const u64 rsb = h2r_stream_bytes(ctx, flags);
@@ -4324,70 +4149,3 @@ const char *h2r_last_hip_error(void) try { return g_hip_err; } H2R_CATCH_STR
 }  // extern "C"
 
 
-#ifdef H2R_EXP_FUSED
-// EXPERIMENT (developer build only; tools/fused_probe.py): the steady-state period of a pipeline step issued as ONE launch.
-// RSA-2048 shape only (64-bit limbs, 32 limbs).  The same call is repeated `iters` times: the chain role recomputes the
-// batch into workspace B while the record role rewrites the trace from workspace A (filled by a normal call first), so
-// every launch does a step's full work and the results stay valid.
-//   mode 0: fused launches back to back on `stream`;  mode 1: [chain kernel, record kernel] pairs on `stream` (serial);
-//   mode 2: record kernel alone;  mode 3: chain kernel alone.
-extern "C" int32_t h2r_exp_fused_period(const h2r_ctx *ctx, const void *x, const void *n, const uint8_t *e_le, size_t e_len, uint64_t batch,
-                                        void *trace, void *out, uint8_t *status, void *ws_a, void *ws_b, uint32_t iters, uint32_t mode,
-                                        uint32_t dyn_lds, h2r_stream_t stream, double *ms_per_iter) {
-    if (!ctx || !trace || !ws_a || !ws_b || !ms_per_iter) return H2R_E_NULL;
-    if (ctx->layout.limb_width != 64 || ctx->L != 32) return H2R_E_UNSUPPORTED;
-    H2R_ON_DEVICE(ctx->params.device);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    h2r_pow_layout pl;
-    int32_t rc = h2r_pow_fixed_layout(ctx, e_le, e_len, &pl);
-    if (rc) return rc;
-    ExpBits eb; u32 T;
-    rc = exp_to_bits(e_le, e_len, &eb, &T);
-    if (rc) return rc;
-    auto path = [&](void *ws) {
-        return run_path(ctx, CHAIN_POW_FIXED, x, nullptr, n, nullptr, 0, 0, &eb, 1, batch, 0, T, trace, pl.elem_stride, pl.off_records, &pl,
-                        out, status, ws, st);
-    };
-    rc = path(ws_a);   // a normal call: workspace A and the trace are valid from here on
-    if (rc) return rc;
-    PathArgs cap_a, cap_b;
-    auto args_of = [&](void *ws, PathArgs *pa) {
-        return run_path(ctx, CHAIN_POW_FIXED, x, nullptr, n, nullptr, 0, 0, &eb, 1, batch, 0, T, trace, pl.elem_stride, pl.off_records, &pl,
-                        out, status, ws, st, nullptr, nullptr, nullptr, nullptr, nullptr, pa);
-    };
-    rc = args_of(ws_a, &cap_a);
-    if (rc) return rc;
-    rc = args_of(ws_b, &cap_b);
-    if (rc) return rc;
-    const ChainArgs ca = cap_b.ca;
-    TraceArgs ta = cap_a.ta;
-    constexpr int IPB = TraceGeo<32>::IPB;
-    const u32 rec_blocks = (u32)((ta.n_items + IPB - 1) / IPB);
-    u32 n_chain = (u32)std::min<u64>(batch, 4ull * ctx->num_cus);
-    n_chain = (n_chain + 7) & ~7u;
-    if (dyn_lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&step_kernel<64, 4, 64, 32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds);
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    auto one = [&]() -> hipError_t {
-        if (mode == 0) {
-            AuxArgs none; std::memset(&none, 0, sizeof none);
-            Sha256Args no_sha; std::memset(&no_sha, 0, sizeof no_sha);
-            hipLaunchKernelGGL((step_kernel<64, 4, 64, 32, false>), dim3(n_chain + rec_blocks), dim3(256), dyn_lds, st, ca, ta, none, none, no_sha, 0u, n_chain, rec_blocks);
-            return hipGetLastError();
-        }
-        if (mode == 1 || mode == 3) { const hipError_t e = launch_chain(ctx, ca, false, st); if (e != hipSuccess) return e; }
-        if (mode == 1 || mode == 2) { TraceArgs t2 = ta; t2.residency = 1; const hipError_t e = launch_trace(ctx, t2, st); if (e != hipSuccess) return e; }
-        return hipSuccess;
-    };
-    for (int w = 0; w < 3; ++w) HIP_TRY(one());
-    HIP_TRY(hipEventRecord(e0, st));
-    for (u32 i = 0; i < iters; ++i) HIP_TRY(one());
-    HIP_TRY(hipEventRecord(e1, st));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    *ms_per_iter = (double)ms / (iters ? iters : 1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    return H2R_OK;
-}
-#endif

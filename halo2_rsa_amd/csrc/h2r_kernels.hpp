@@ -2004,6 +2004,7 @@ struct HistArgs {
     u32 *hist;  // [elem][hist_len]
 };
 
+#ifdef H2R_TU_API   // a plain (non-template) kernel: defined in the one translation unit that launches it
 __global__ __launch_bounds__(256) void hist_kernel(HistArgs a) {
     extern __shared__ u32 h[];
     const u64 elem = blockIdx.x;
@@ -2030,6 +2031,7 @@ __global__ __launch_bounds__(256) void hist_kernel(HistArgs a) {
     __syncthreads();
     for (u32 k = threadIdx.x; k < a.hist_len; k += blockDim.x) a.hist[elem * a.hist_len + k] = h[k];
 }
+#endif
 
 // Grouped ("sorted") arrangement of an element's lookup inputs: a stable counting sort of its sub-limb
 // cells by lookup-table row.  Cell ids follow the flat stream: record t contributes, in order, the q
@@ -3097,6 +3099,7 @@ struct DecompArgs {
     const u8 *values; u32 value_bytes; u64 count; u32 bit_len, sub_bits, nsub, has_ov;
     u8 *sub_out; u32 sub_stride; u32 *hist; u32 comp_len;
 };
+#ifdef H2R_TU_API   // a plain (non-template) kernel: defined in the one translation unit that launches it
 __global__ __launch_bounds__(256) void decompose_kernel(DecompArgs a) {
     extern __shared__ u32 h[];
     const u32 hl = a.hist ? a.comp_len + (a.has_ov ? (1u << (a.bit_len % a.sub_bits)) : 0) : 0;
@@ -3115,5 +3118,6 @@ __global__ __launch_bounds__(256) void decompose_kernel(DecompArgs a) {
     __syncthreads();
     for (u32 k = threadIdx.x; k < hl; k += blockDim.x) if (h[k]) atomicAdd(&a.hist[k], h[k]);
 }
+#endif
 
 }  // namespace h2r

@@ -92,6 +92,7 @@ __device__ __forceinline__ void sha256_outputs(const Sha256Args &a, u64 e, const
     }
 }
 
+#ifdef H2R_TU_API   // a plain (non-template) kernel: defined in the one translation unit that launches it
 __global__ __launch_bounds__(64) void sha256_kernel(Sha256Args a) {
     const u64 e = (u64)blockIdx.x * 64 + threadIdx.x;
     if (e >= a.batch) return;
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(64) void sha256_kernel(Sha256Args a) {
     }
     sha256_outputs(a, e, h);
 }
+#endif
 
 // ---- the same hash as a ROLE of the step launch (step_kernel, h2r_kernels.hpp) -------------------------------------------------------
 // The register budget there is the chain role's (80 VGPRs; the fully unrolled sha256_kernel takes 94), so the rounds run as four

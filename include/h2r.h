@@ -213,6 +213,10 @@ typedef struct h2r_advice_repr {
 int32_t h2r_ctx_create_ex(const h2r_params *params, const h2r_advice_repr *repr, h2r_ctx **out);
 int32_t h2r_ctx_advice_repr(const h2r_ctx *ctx, h2r_advice_repr *out);
 uint32_t h2r_abi_version(void);
+/* The build ID of the library: 64 hex digits, the SHA-256 of every source file it was compiled from (halo2_rsa_amd/csrc/ and
+ * include/, as halo2_rsa_amd/_build.py hashes them).  `python -m halo2_rsa_amd._build` reuses a shipped libh2r.so exactly when
+ * this equals the hash of the tree (file times play no part); a binder can log it next to h2r_abi_version(). */
+const char *h2r_build_id(void);
 
 /* BigIntChip::compute_range_lens (big_integer/chip.rs:1220-1249).  Host-only, no ctx needed. */
 int32_t h2r_compute_range_lens(uint32_t limb_width, uint32_t num_limbs,
@@ -936,7 +940,8 @@ int32_t h2r_pipeline_modpow_public_key_advice(h2r_pipeline *p, const void *x, co
  * to the chains of the following call.  The image follows the pipeline's join rule; everything else is stream-ordered.
  * witness (16-byte aligned): batch * h2r_verify_layout_compact(...).elem_stride bytes -- the element's in-field and EM witness, the only part of a verify
  * element's trace the rows need (9,984 B instead of 1.26 MB per RSA-2048 element).  h2r_verify_layout_compact turns a verify layout into
- * that form (off_in_field = 0, off_em, elem_stride; `pow` unchanged for a Fix layout, the witness-only pow layout inside the element for a Var one); with it h2r_verify_emit_advice (flags | H2R_ADVICE_DIRECT,
+ * that form (off_in_field = 0, off_em, elem_stride; pow.off_records = UINT64_MAX -- the record exports (flatten, check, hist, emit_stream and the record-read image) answer H2R_E_SHAPE; the rest of
+ * `pow` unchanged for a Fix layout, the witness-only pow layout inside the element for a Var one); with it h2r_verify_emit_advice (flags | H2R_ADVICE_DIRECT,
  * trace = the witness), h2r_verify_advice_rows and h2r_verify_row_kinds work as with the full layout.
  * Consecutive calls rotate through `depth` sets of witness / powed_out / is_valid_out / status / workspace / advice_out.
  * `bench.py --advice --verify` measures this form (77,200 rows = 12.35 MB per RSA-2048 element). */

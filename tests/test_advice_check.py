@@ -180,6 +180,19 @@ def test_verify_element_var_arm_and_layout(H, repr_kw):
     lay.column_of[6][0] = 7
     assert lib().h2r_advice_apply_layout(chip._ctx, ctypes.byref(lay), kd.data_ptr(), len(kinds), perm.data_ptr(), perm.shape[1], 3, None,
                                          chip._stream()) == _lib.H2R_E_SHAPE
+    # a hand-filled PERMUTATION that moves a off column 0 on a decomposition row (kind 32 = H2R_ROW_RANGE_LIMB): h2r_advice_layout_custom refuses
+    # it, and so do the two exports whose lookup passes read physical columns 0..3 / 0 of such rows (they would report false violations)
+    lay2 = _lib.H2RAdviceLayout()
+    assert lib().h2r_advice_layout_default(ctypes.byref(lay2)) == 0
+    lay2.column_of[32][0], lay2.column_of[32][1] = 1, 0
+    k32 = (ctypes.c_uint8 * 1)(32)
+    c32 = ((ctypes.c_uint8 * 5) * 1)((1, 0, 2, 3, 4))
+    assert lib().h2r_advice_layout_custom(chip._ctx, k32, c32, 1, ctypes.byref(_lib.H2RAdviceLayout())) == _lib.H2R_E_SHAPE
+    with pytest.raises(Exception):
+        chip.advice_check(kinds, img, 3, lookup=look, layout=lay2)
+    hist = torch.zeros(3 * 5 * look.cfg.n_rows, dtype=torch.int32, device="cuda")
+    assert lib().h2r_lookup_hist_advice(chip._ctx, ctypes.byref(look.cfg), ctypes.byref(lay2), kd.data_ptr(), len(kinds), img.data_ptr(), img.shape[1], 3,
+                                        None, hist.data_ptr(), chip._stream()) == _lib.H2R_E_SHAPE
     # the variable-exponent arm
     x = chip.assign_integer(sigs)
     pkv = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 32, 64), H.Var(H.UnassignedInteger.from_ints([19, 31, 1], 1, 64))))

@@ -9,20 +9,13 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXE = os.path.join(ROOT, "tests", "cpp", "test_chip_replay")
 
 
 def build_replay():
     from halo2_rsa_amd import _build
+    from cpp_build import build_cpp
     _build.build_lib()
-    src = os.path.join(ROOT, "tests", "cpp", "test_chip_replay.cpp")
-    deps = [src, os.path.join(ROOT, "include", "h2r.h")]
-    if os.path.exists(EXE) and all(os.path.getmtime(EXE) >= os.path.getmtime(d) for d in deps):
-        return EXE
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), src, "-o", EXE,
-                           "-L" + os.path.join(ROOT, "halo2_rsa_amd", "lib"), "-lh2r", "-L/opt/rocm/lib", "-lamdhip64",
-                           "-Wl,-rpath," + os.path.join(ROOT, "halo2_rsa_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib"])
-    return EXE
+    return build_cpp("test_chip_replay")
 
 
 def test_replay_twin_compiles():

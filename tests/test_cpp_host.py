@@ -6,24 +6,15 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXE = os.path.join(ROOT, "tests", "cpp", "test_rsa_chip")
 
 
 def build_cpp_test():
     from halo2_rsa_amd import _build
     from oracle_lib import build as build_oracle
+    from cpp_build import build_cpp
     _build.build_lib()
     build_oracle()
-    src = os.path.join(ROOT, "tests", "cpp", "test_rsa_chip.cpp")
-    deps = [src, os.path.join(ROOT, "include", "h2r_chips.hpp"), os.path.join(ROOT, "include", "h2r.h")]
-    if os.path.exists(EXE) and all(os.path.getmtime(EXE) >= os.path.getmtime(d) for d in deps):
-        return EXE
-    cmd = ["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
-           src, "-o", EXE, "-L" + os.path.join(ROOT, "halo2_rsa_amd", "lib"), "-lh2r", "-L" + os.path.join(ROOT, "oracle"), "-lh2r_oracle",
-           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + os.path.join(ROOT, "halo2_rsa_amd", "lib"),
-           "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-Wl,-rpath,/opt/rocm/lib"]
-    subprocess.check_call(cmd)
-    return EXE
+    return build_cpp("test_rsa_chip", extra_libs=[(os.path.join(ROOT, "oracle"), "h2r_oracle")])
 
 
 def test_cpp_host_mirror_compiles():

@@ -28,7 +28,10 @@ def test_compact_layout_on_the_host():
     full, vl = _lib.H2RVerifyLayout(), _lib.H2RVerifyLayout()
     assert lib().h2r_verify_layout_fixed(ctx, e, len(e), ctypes.byref(full)) == 0
     assert lib().h2r_verify_layout_compact(ctx, ctypes.byref(full), ctypes.byref(vl)) == 0
-    assert bytes(vl.pow) == bytes(full.pow)
+    assert vl.pow.off_records == 2 ** 64 - 1          # no record planes: what the record exports look at
+    vl.pow.off_records = full.pow.off_records
+    assert bytes(vl.pow) == bytes(full.pow)            # ... everything else of the pow layout untouched
+    vl.pow.off_records = 2 ** 64 - 1
     assert vl.off_in_field == 0 and vl.off_em == full.off_em - full.off_in_field
     assert vl.elem_stride % 256 == 0 and vl.elem_stride >= vl.off_em + full.em_stream_bytes and vl.off_em >= full.in_field_stream_bytes
     assert vl.elem_stride < 16384 < full.elem_stride
@@ -322,3 +325,36 @@ def test_pipelined_verify_var_arm_image_is_the_record_based_image(H, golden, rep
         assert want.shape == g["img"].shape and torch.equal(g["img"][ok], want[ok]), k
         if k == 1:
             assert int(g["st"][4]) == H.H2R_E_NOT_IN_FIELD and bool((g["img"][4] == 0x5A).all())
+
+
+def test_record_exports_refuse_a_compact_layout():
+    """A witness-only layout (h2r_pow_layout_compact / h2r_verify_layout_compact: off_records = UINT64_MAX) holds no records: every
+    export that reads records answers H2R_E_SHAPE instead of adding the sentinel to a pointer (host or device)."""
+    from halo2_rsa_amd import _lib
+    from halo2_rsa_amd._lib import lib
+    L = lib()
+    ctx = ctypes.c_void_p()
+    p = _lib.H2RParams(64, 2048, 0, -1)
+    assert L.h2r_ctx_create(ctypes.byref(p), ctypes.byref(ctx)) == 0
+    e = (65537).to_bytes(3, "little")
+    full, pl = _lib.H2RPowLayout(), _lib.H2RPowLayout()
+    assert L.h2r_pow_fixed_layout(ctx, e, len(e), ctypes.byref(full)) == 0
+    assert L.h2r_pow_layout_compact(ctx, ctypes.byref(full), ctypes.byref(pl)) == 0
+    vfull, vl = _lib.H2RVerifyLayout(), _lib.H2RVerifyLayout()
+    assert L.h2r_verify_layout_fixed(ctx, e, len(e), ctypes.byref(vfull)) == 0
+    assert L.h2r_verify_layout_compact(ctx, ctypes.byref(vfull), ctypes.byref(vl)) == 0
+    buf = ctypes.create_string_buffer(1 << 16)   # never touched: every call must refuse before it reads or writes
+    cfg = _lib.H2RLookupConfig()
+    assert L.h2r_lookup_config_default(ctx, 1, ctypes.byref(cfg)) == 0
+    S = _lib.H2R_E_SHAPE
+    assert L.h2r_pow_trace_flatten(ctx, ctypes.byref(pl), buf, buf) == S
+    assert L.h2r_pow_trace_flatten_ex(ctx, ctypes.byref(pl), buf, 0, buf) == S
+    assert L.h2r_verify_trace_flatten(ctx, ctypes.byref(vl), buf, buf) == S
+    assert L.h2r_pow_trace_emit_stream(ctx, ctypes.byref(pl), buf, 0, 1, 0, buf, 1 << 30, 0, None) == S
+    assert L.h2r_pow_trace_check(ctx, ctypes.byref(pl), buf, buf, e, len(e), 0, buf, 0, buf, 1, None, buf, None, None) == S
+    assert L.h2r_lookup_hist_verify(ctx, ctypes.byref(cfg), ctypes.byref(vl), buf, 1, None, buf, None) == S
+    # the record-read image (no H2R_ADVICE_DIRECT) of a witness-only layout
+    assert L.h2r_pow_trace_emit_advice(ctx, ctypes.byref(pl), buf, 0, buf, 0, buf, 1, None, buf, 1 << 30, None) == S
+    # the full layouts pass these guards (a host-only ctx then answers H2R_E_UNSUPPORTED where a device is needed)
+    assert L.h2r_pow_trace_emit_stream(ctx, ctypes.byref(full), buf, 0, 1, 0, buf, 1 << 30, 0, None) == _lib.H2R_E_UNSUPPORTED
+    L.h2r_ctx_destroy(ctx)
