@@ -279,7 +279,7 @@ def advice_bench(args):
     assert_in_field witness and its rows + cells_kernel, which writes the pow rows directly from the operands.  The chain kernels of
     call k + 1 run next to the cells kernel of call k (two workspaces, two images): ONE export per call,
     h2r_pipeline_modpow_public_key_advice (the pipeline owns the side streams and the events).  roofline: cells_kernel, HBM-write bound, algorithmic bytes = the pow rows it writes
-    (12,078,240 B per RSA-2048 e = 65537 element)."""
+    (12,081,280 B per RSA-2048 e = 65537 element)."""
     import ctypes
     env = DistEnv.from_environment(args.gpus, force=bool(os.environ.get("H2R_FORCE_DIST")))
     w, bits, e = WORKLOADS[args.workload]
@@ -720,7 +720,7 @@ def flow_bench(args):
     w, bits, e = WORKLOADS["rsa2048_e65537"]
     B = args.batch if args.batch else 1024
     usable = (1 << 17) - 6
-    rows0 = 77200
+    rows0 = 77219
     kw = dict(columns=True, montgomery=True, col_stride=((rows0 * 32 + 4095) // 4096) * 4096) if (args.columns or args.montgomery) else {}
     rsa = H.RSAChip(bits, 5, **kw)
     chip = rsa.bigint_chip()

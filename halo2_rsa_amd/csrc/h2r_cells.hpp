@@ -17,7 +17,7 @@
 //   * range rows (main_gate.decompose of a limb / carry) are cut from the value itself.
 // 64 rows = 10,240 bytes are staged in LDS and leave as ten 1 KB store instructions (16 bytes per lane) that cover whole
 // 128-byte lines (the first chunk of an item is cut so that every later one starts on a line), so the only HBM traffic is the
-// image itself: 635,680 bytes written per RSA-2048 mul_mod against 1.3 KB read.  No workgroup barrier anywhere (a workgroup IS a
+// image itself: 635,840 bytes written per RSA-2048 mul_mod against 1.3 KB read.  No workgroup barrier anywhere (a workgroup IS a
 // wave) and no global load inside the row loop (vmcnt counts loads and stores alike: waiting for a load would wait for the
 // previous chunk's stores).  Chunks that lie wholly inside the mul rows or the column rows of a VALID mul_mod take a branch-free
 // fast path; chunks that straddle sections, and a mul_mod whose q, r are not its quotient and remainder (never produced by this
@@ -712,7 +712,7 @@ __global__ __launch_bounds__(64 * NWV) void cells_kernel(CellsArgs a) {
         }
         // ================= fast path: a chunk of is_equal_muled column rows of a valid mul_mod =================
         if constexpr (FAST) {
-            if (!built && !(ABL & 8) && columns_done && item_ok && n_rows == 64 && r0 >= r_T6) {
+            if (!built && !(ABL & 8) && columns_done && item_ok && n_rows == 64 && r0 >= r_T6 && r0 + 64 < a.rows) {   // (not the chunk that holds the closing assert_one row)
                 const u32 rr = r - r_T6;
                 const u32 c = __umulhi(rr, a.per_col_magic);
                 u32 k = rr - c * per_col;
@@ -858,6 +858,8 @@ __global__ __launch_bounds__(64 * NWV) void cells_kernel(CellsArgs a) {
             else { const U192 e = rdp(pEQB, id.i); v1 = lim(sr[id.i]); v0 = e - v1; v2 = e; }
         } else if (id.sect == 3) {                                   // :851-856
             if (id.i == 0) v0 = Bw; else if (id.i == 3) { v0 = lim(1); v1 = v0; v2 = v0; }
+        } else if (id.sect == 5) {                                   // assert_equal_muled: main_gate.assert_one(eq_bit)  :1062
+            v0 = lim((pFL[C - 1] >> 3) & 1u);
         } else if (!(ABL & 8) && id.sect == 4) {
             const u32 c = id.i;
             if (id.kind >= ROWK_RANGE_CARRY) {                       // RangeChip::assign(carry, ...)  :880-885

@@ -79,6 +79,7 @@ inline void copy_map_record(u32 L, u32 nrc, std::vector<h2r_copy> &out) {
         cp(r(21), 0, r(19), 0); cp(r(21), 1, r(18), 2);
         cp(r(22), 0, r(17), 2); cp(r(22), 1, r(19), 0);
     }
+    cp(R.col_row(C - 1, 22) + 1, 0, R.col_row(C - 1, 22), 2);                            // assert_one [eq_bit]  :1062 -- the record's last row
 }
 
 // ---- layout as data ----

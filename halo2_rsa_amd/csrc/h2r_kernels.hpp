@@ -2676,11 +2676,13 @@ __global__ __launch_bounds__(64) void link_kernel(LinkArgs a) {
 //        13..16 is_equal(c, mod_acc): SUB [c, mod_acc, d], BIT [f,f,f], ISZERO_INV [d, 1/d or 1, f], ISZERO_RA [f, d]   17 MUL (and) [eq_bit, f, eq_bit']
 //        i < C-1: nrc RANGE_CARRY rows of carry_{i+1}; then is_equal(carry, dup) (4 rows) and MUL (and)
 //        i = C-1: is_equal(carry, acc_extra) (4 rows) and MUL (and)
+//   T7  assert_equal_muled's main_gate.assert_one(eq_bit) (:1062): ASSERT_ONE [eq_bit] -- the record's last row
 //   One workgroup per record, one thread per row (ten 16-byte stores of 160 contiguous bytes).  Bound: HBM writes
-//   (635,680 bytes per RSA-2048 mul_mod: 9.9 x the flat stream -- what materialising field-element cells costs).
+//   (635,840 bytes per RSA-2048 mul_mod: 9.9 x the flat stream -- what materialising field-element cells costs).
 // ================================================================================================
 enum : u32 { ROWK_NOP = 0, ROWK_CONST0, ROWK_CONST1, ROWK_CONST_B, ROWK_BIT, ROWK_VALUE, ROWK_MUL_ADD, ROWK_ADD, ROWK_SUB, ROWK_ADD_WM,
-             ROWK_ADDC_WM, ROWK_MUL, ROWK_ASSERT_EQ, ROWK_ISZERO_INV, ROWK_ISZERO_RA, ROWK_RANGE_LIMB = 32, ROWK_RANGE_CARRY = 40 };
+             ROWK_ADDC_WM, ROWK_MUL, ROWK_ASSERT_EQ, ROWK_ISZERO_INV, ROWK_ISZERO_RA, ROWK_ASSERT_ONE = 17 /* [a], a - 1 = 0 (15, 16: h2r_rowprog.hpp) */,
+             ROWK_RANGE_LIMB = 32, ROWK_RANGE_CARRY = 40 };
 
 template <int LW>
 struct RecView {   // reads of one record through the documented plane layout (include/h2r.h)
@@ -2748,13 +2750,13 @@ constexpr u32 ADVICE_STAGE_ROWS = 256;   // rows built in LDS per stage (= the w
 constexpr u32 ADVICE_COL_ROWS = 23;    // main-gate rows of one is_equal_muled column besides the carry's range assign
 __host__ __device__ inline u32 advice_rows_per_record(u32 L, u32 carry_nsub) {
     const u32 C = 2 * L - 1, nrc = (carry_nsub + 3) / 4;
-    return 2 * L * 2 + 2 * (C + L * L) + L + 4 + (C - 1) * (ADVICE_COL_ROWS + nrc) + ADVICE_COL_ROWS;
+    return 2 * L * 2 + 2 * (C + L * L) + L + 4 + (C - 1) * (ADVICE_COL_ROWS + nrc) + ADVICE_COL_ROWS + 1;   // + assert_equal_muled's assert_one(eq_bit), chip.rs:1062
 }
 
 // Row r of a mul_mod's image: which op it belongs to.  Shared by the kernel and the host export of the row kinds.
 struct AdviceRowId {
     u32 kind;      // ROWK_*
-    u32 sect;      // 0 q/r range rows, 1 mul rows, 2 eq_b, 3 is_equal_muled preamble, 4 is_equal_muled column rows
+    u32 sect;      // 0 q/r range rows, 1 mul rows, 2 eq_b, 3 is_equal_muled preamble, 4 is_equal_muled column rows, 5 the closing assert_one(eq_bit)
     u32 i, j;      // sect 0: i = limb (L.. = r limbs), j = row of the assign; sect 1: column i, step j (kind CONST0: the column's head);
                    // sect 2: i; sect 3: i = 0..3; sect 4: column i, j = row within the column (range rows: j = 18 + row of the assign)
     u32 qn;        // sect 1: 0 = mul(a, b), 1 = mul(q, n)
@@ -2788,6 +2790,9 @@ __host__ __device__ inline AdviceRowId advice_decode(u32 r, u32 L, u32 nrc) {
     if (r < r_T6p) { id.sect = 2; id.i = r - r_T5; id.kind = ROWK_ADD; return id; }
     if (r < r_T6) { id.sect = 3; id.i = r - r_T6p; id.kind = id.i == 0 ? ROWK_CONST_B : (id.i == 3 ? ROWK_BIT : ROWK_CONST0); return id; }
     const u32 rr = r - r_T6;
+    if (rr == (C - 1) * per_col + ADVICE_COL_ROWS) {   // assert_equal_muled: main_gate.assert_one(eq_bit)  :1062 -- the record's last row
+        id.sect = 5; id.i = C - 1; id.kind = ROWK_ASSERT_ONE; return id;
+    }
     const u32 c = rr / per_col < C - 1 ? rr / per_col : C - 1;
     u32 k = rr - c * per_col;
     id.sect = 4; id.i = c;
@@ -3037,6 +3042,7 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
                     fpp = c ? fp - 4 : fp; has_prev = c ? 1u : 0u;
                 }
             }
+            else if (id.sect == 5) fp = rv.rec + a.off[H2R_PL_FLAGS] + (u64)(C - 1) * 4;   // the final eq_bit: e2 of the last column
         }
         if (H2R_ADV_ABL == 5 && (id.sect == 4 || id.sect == 0)) { s0 = s_none(); s1 = s_none(); s2 = s_none(); fp = rv.rec; fpp = rv.rec; }
         fetch(s0, l0, h0, m0); fetch(s1, l1, h1, m1); fetch(s2, l2, h2, m2);
@@ -3063,6 +3069,7 @@ __global__ __launch_bounds__(256) void advice_kernel(AdviceArgs a) {
             if (id.sect == 1) { if (id.kind == ROWK_MUL_ADD) { v0 = lim(imm0); v1 = lim(imm1); v2 = c0; v3 = c1; } }
             else if (id.sect == 2) { v0 = c0; v1 = lim(imm0); v2 = c2; }
             else if (id.sect == 3) { if (id.i == 0) v0 = B; else if (id.i == 3) { v0 = lim(1); v1 = lim(1); v2 = lim(1); } }
+            else if (id.sect == 5) v0 = lim(fl >> 24);                                                 // assert_one [eq_bit]  :1062
             else {
                 const u32 f1 = fl & 0xff, e1 = (fl >> 8) & 0xff, f2 = (fl >> 16) & 0xff, e2 = fl >> 24;
                 const U192 d = c0 - c1;

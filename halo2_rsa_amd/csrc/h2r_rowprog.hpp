@@ -19,7 +19,7 @@
 namespace h2r {
 
 // row kinds beyond the mul_mod image's (h2r.h H2R_ROW_*)
-enum { ROWK_SELECT = 15, ROWK_NOT = 16, ROWK_ASSERT_ONE = 17, ROWK_CONST_BM1 = 18, ROWK_ASSERT_ZERO = 19,
+enum { ROWK_SELECT = 15, ROWK_NOT = 16, /* ROWK_ASSERT_ONE = 17: h2r_kernels.hpp (the mul_mod image ends with one) */ ROWK_CONST_BM1 = 18, ROWK_ASSERT_ZERO = 19,
        ROWK_CONST_EM = 20,    // + j: assign_constant of the j-th constant of the encoded-message check (em_const)
        ROWK_RANGE_U32 = 48,   // + row of RangeChip::assign(value, 4, 32): eight 4-bit sub-limbs (src/chip.rs:170-171)
        ROWK_CONST_COEFF8 = 56 }; // + j: assign_constant(2^(8j)), the byte coefficients of the hashed-message limbs (src/lib.rs:228-229)

@@ -774,7 +774,7 @@ int32_t h2r_pow_trace_emit_stream(const h2r_ctx *ctx, const h2r_pow_layout *pl, 
  * ceil(sub-limbs / 4) rows per RangeChip::assign, in the reference's op order.  Row shapes: DESIGN.md section 2b.  The
  * VALUES are the ones the flat stream pins; the third-party PLACEMENT (maingate / halo2wrong are not in the reference
  * tree) is restated from SURVEY Appendix A and is unpinned.
- *   h2r_advice_rows(ctx)            rows of one mul_mod (3,973 for RSA-2048 as 32 x 64-bit limbs): EVERY cell the ops assign --
+ *   h2r_advice_rows(ctx)            rows of one mul_mod (3,974 for RSA-2048 as 32 x 64-bit limbs): EVERY cell the ops assign --
  *                                   the flat stream's values, the assign_constant cells, the assign_bit(1) seeds, is_zero's inverses
  *   element e's image starts at advice_out + e * out_stride; record t of the element at + (pre + t * rows) * 160 bytes
  *   h2r_pow_trace_emit_advice: a pow element = [acc = assign_constant(1): CONST1 [1], CONST0 [0]] then its records back to back
@@ -841,7 +841,7 @@ int32_t h2r_fresh_op_row_kinds(const h2r_ctx *ctx, uint32_t op, uint32_t flags, 
  * reference's op order: [is_eq = assign_constant(1) :137] [assert_in_field(sig, n) :106] [pow_mod_fixed_exp :111 -- the rows of
  * h2r_pow_trace_emit_advice] [the encoded-message check :138-198: is_equal / and per limb, the constants (H2R_ROW_CONST_EM + j),
  * the two RangeChip::assign(half, 4, 32) of limb 6 (H2R_ROW_RANGE_U32 + row), their mul_add recomposition and assert_equal].
- * section_rows (nullable): the four sections' row counts (1, 1,532, 75,489, 178 for RSA-2048 with e = 65537).
+ * section_rows (nullable): the four sections' row counts (1, 1,532, 75,508, 178 for RSA-2048 with e = 65537).
  * sig, n, hashed, flags, trace, workspace: what h2r_verify_pkcs1v15_batch / h2r_pipeline_verify_pkcs1v15 were given (a caller
  * workspace is required: it holds every mul_mod's operands); powed: their powed_out.  Elements with a nonzero status are skipped.
  * Both exponent arms (src/chip.rs:108-111): a Var element (h2r_verify_layout_var) has the pow_mod rows of h2r_pow_trace_emit_advice
@@ -918,7 +918,7 @@ uint64_t h2r_pow_copy_map(const h2r_ctx *ctx, const h2r_pow_layout *pl, const ui
  * h2r_pow_trace_emit_advice].  x, n, flags, in_field_trace, trace, workspace: what h2r_modpow_public_key_batch was given (a caller
  * workspace is required).  trace = NULL: that call wrote no records -- the pow rows are written directly from the operands
  * (H2R_ADVICE_DIRECT, also selectable in flags with a trace): the prover-consumable witness without the record planes in between.
- * section_rows (nullable): {1,532, 75,489} for RSA-2048, e = 65537. */
+ * section_rows (nullable): {1,532, 75,508} for RSA-2048, e = 65537. */
 uint64_t h2r_modpow_public_key_advice_rows(const h2r_ctx *ctx, const h2r_pow_layout *pl, uint64_t section_rows[2]);
 int32_t h2r_modpow_public_key_emit_advice(const h2r_ctx *ctx, const h2r_pow_layout *pl, const void *x, const void *n, uint32_t flags,
                                           const void *in_field_trace, const void *trace, const void *workspace, uint64_t batch,
@@ -944,7 +944,7 @@ int32_t h2r_pipeline_modpow_public_key_advice(h2r_pipeline *p, const void *x, co
  * `pow` unchanged for a Fix layout, the witness-only pow layout inside the element for a Var one); with it h2r_verify_emit_advice (flags | H2R_ADVICE_DIRECT,
  * trace = the witness), h2r_verify_advice_rows and h2r_verify_row_kinds work as with the full layout.
  * Consecutive calls rotate through `depth` sets of witness / powed_out / is_valid_out / status / workspace / advice_out.
- * `bench.py --advice --verify` measures this form (77,200 rows = 12.35 MB per RSA-2048 element). */
+ * `bench.py --advice --verify` measures this form (77,219 rows = 12.35 MB per RSA-2048 element). */
 int32_t h2r_verify_layout_compact(const h2r_ctx *ctx, const h2r_verify_layout *full, h2r_verify_layout *out);
 int32_t h2r_pipeline_verify_pkcs1v15_advice(h2r_pipeline *p, const void *sig, const void *n, const uint8_t *e_le_bytes, size_t e_len,
                                             const uint64_t *hashed, uint64_t batch, uint32_t flags, void *witness, void *powed_out,

@@ -186,6 +186,7 @@ def mul_mod_image(p, a, b, n, stream, P):
             im.is_equal(cy, qacc, f2)                                      # :890
         im.row(ROW_MUL, e1, f2, e2)                                        # and, :887 / :891
         carry_prev, x_prev, eq_prev = cy, qacc, e2
+    im.row(17, eq_prev)                                      # T7: assert_equal_muled's main_gate.assert_one(eq_bit) :1062 (ROW_ASSERT_ONE)
     assert pos == len(st)
     return im
 

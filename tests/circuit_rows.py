@@ -33,7 +33,7 @@ class Rows:
         self.n = 0
         wm = pyref.compute_mul_word_max(self.w, self.L)
         self.carry_bits = bits_size(2 * wm) - self.w                        # :841-842
-        self.sub = pyref.sublimb_bit_len(self.w)                            # :1357-1365
+        self.sub_bits = pyref.sublimb_bit_len(self.w)                       # :1357-1365
 
     # ---- maingate / RangeChip calls [3P, restated costs] ----------------------------------------------------------
     def op(self, k=1):
@@ -50,7 +50,7 @@ class Rows:
         self.n += (nsub + 3) // 4
 
     def range_limb(self):
-        self.range_assign(self.sub, self.w)
+        self.range_assign(self.sub_bits, self.w)
 
     def to_bits(self, nb):
         self.n += nb + (nb + 3) // 4 + 1
@@ -95,6 +95,7 @@ class Rows:
             else:
                 self.is_equal()
             self.op(1)                                                      # and
+
     def assert_equal_fresh(self, n1, n2):                                   # instructions.rs:197-206: is_equal_fresh + assert_one
         self.is_equal_fresh(n1, n2)
         self.op(1)

@@ -129,7 +129,7 @@ int main(int argc, char **argv) {
         // the same mul_mod as cells (what main_gate.mul_add / range_chip.assign / the is_equal_muled ops assign, chip.rs:408, :590, :598, :851-893):
         // converted from the record and written directly from the operands -- the same bytes; the copy map holds value for value
         const uint64_t rows = bigint_chip.advice_rows(r);
-        REQUIRE(rows == 3973 && bigint_chip.advice_row_kinds(r).size() == rows);
+        REQUIRE(rows == 3974 && bigint_chip.advice_row_kinds(r).size() == rows);
         DeviceBuffer img = bigint_chip.emit_advice(r, aa, aa, an), img_d = bigint_chip.emit_advice(r, aa, aa, an, true);
         std::vector<uint8_t> ia(rows * H2R_ADVICE_ROW_BYTES), ib(ia.size());
         img.download(ia.data(), ia.size()); img_d.download(ib.data(), ib.size());
@@ -169,7 +169,7 @@ int main(int argc, char **argv) {
     {
         uint64_t sec[4], sec2[2];
         const uint64_t rows = rsa_chip.advice_rows(res, sec);
-        REQUIRE(sec[0] == 1 && sec[1] == 1532 && sec[2] == 75489 && sec[3] == 178 && rows == 77200);
+        REQUIRE(sec[0] == 1 && sec[1] == 1532 && sec[2] == 75508 && sec[3] == 178 && rows == 77219);
         DeviceBuffer img = rsa_chip.emit_advice(res, pk, hashed_msg_assigned, sign), img_d = rsa_chip.emit_advice(res, pk, hashed_msg_assigned, sign, true);
         std::vector<uint8_t> ia(B * rows * H2R_ADVICE_ROW_BYTES), ib(ia.size());
         img.download(ia.data(), ia.size()); img_d.download(ib.data(), ib.size());
@@ -183,14 +183,14 @@ int main(int argc, char **argv) {
         fimg.download(fa.data(), fa.size());
         for (size_t i = 0; i < B; ++i) REQUIRE(!std::memcmp(fa.data() + i * 1532 * 160, ia.data() + (i * rows + 1) * 160, 1532 * 160));
         ModpowResult mp = rsa_chip.modpow_public_key(sign.c, pk);
-        REQUIRE(rsa_chip.advice_rows(mp, sec2) == 1532 + 75489 && sec2[0] == 1532);
+        REQUIRE(rsa_chip.advice_rows(mp, sec2) == 1532 + 75508 && sec2[0] == 1532);
         DeviceBuffer m1 = rsa_chip.emit_advice(mp, sign.c, pk, true), m2 = rsa_chip.emit_advice(mp, sign.c, pk, false);
-        std::vector<uint8_t> ma(B * (1532 + 75489) * H2R_ADVICE_ROW_BYTES), mb(ma.size());
+        std::vector<uint8_t> ma(B * (1532 + 75508) * H2R_ADVICE_ROW_BYTES), mb(ma.size());
         m1.download(ma.data(), ma.size()); m2.download(mb.data(), mb.size());
         REQUIRE(ma == mb);
         // the pow rows of both elements are the same rows (same x = sig, same n, same e)
         for (size_t i = 0; i < B; ++i)
-            REQUIRE(!std::memcmp(ma.data() + (i * (1532 + 75489) + 1532) * 160, ia.data() + (i * rows + 1 + 1532) * 160, 75489ull * 160));
+            REQUIRE(!std::memcmp(ma.data() + (i * (1532 + 75508) + 1532) * 160, ia.data() + (i * rows + 1 + 1532) * 160, 75508ull * 160));
         // ... and the pipelined form of it: three calls over two buffer sets and two side streams, every image = the plain one
         {
             Pipeline apipe(rsa_chip, 2, 2);
@@ -198,7 +198,7 @@ int main(int argc, char **argv) {
             Pipeline::Buffers ab[2] = {apipe.make_buffers(B, e65537), apipe.make_buffers(B, e65537)};
             uint64_t es = 0;
             REQUIRE(h2r_fresh_op_layout(bigint_chip.ctx(), H2R_OP_IS_IN_FIELD, &es, nullptr, nullptr) == H2R_OK);
-            const uint64_t stride = (1532 + 75489) * (uint64_t)H2R_ADVICE_ROW_BYTES;
+            const uint64_t stride = (1532 + 75508) * (uint64_t)H2R_ADVICE_ROW_BYTES;
             DeviceBuffer inf2[2] = {DeviceBuffer(B * es), DeviceBuffer(B * es)}, adv[2] = {DeviceBuffer(B * stride), DeviceBuffer(B * stride)};
             for (int k = 0; k < 3; ++k) apipe.modpow_public_key_advice(sign.c, pk, ab[k & 1], inf2[k & 1], adv[k & 1], stride);
             apipe.join();
@@ -253,12 +253,12 @@ int main(int argc, char **argv) {
             for (int s2 = 0; s2 < 2; ++s2) { adv3[s2].download(ga.data(), ga.size()); REQUIRE(ga == wa); }
         }
         BatchResult pw = bigint_chip.pow_mod_fixed_exp(sign.c, {0x01, 0x00, 0x01}, pk.n);
-        REQUIRE(bigint_chip.advice_rows(pw) == 75489);
+        REQUIRE(bigint_chip.advice_rows(pw) == 75508);
         DeviceBuffer p1 = bigint_chip.emit_advice(pw, pk.n), p2 = bigint_chip.emit_advice(pw, pk.n, true);
-        std::vector<uint8_t> pa(B * 75489ull * 160), pb(pa.size());
+        std::vector<uint8_t> pa(B * 75508ull * 160), pb(pa.size());
         p1.download(pa.data(), pa.size()); p2.download(pb.data(), pb.size());
         REQUIRE(pa == pb);
-        for (size_t i = 0; i < B; ++i) REQUIRE(!std::memcmp(pa.data() + i * 75489ull * 160, ia.data() + (i * rows + 1 + 1532) * 160, 75489ull * 160));
+        for (size_t i = 0; i < B; ++i) REQUIRE(!std::memcmp(pa.data() + i * 75508ull * 160, ia.data() + (i * rows + 1 + 1532) * 160, 75508ull * 160));
     }
     // pipelined verifier: three back-to-back batches over two buffer sets give the same witnesses as the batch call
     {

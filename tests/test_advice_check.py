@@ -112,7 +112,8 @@ def test_every_single_cell_corruption_is_flagged(H, repr_kw):
                (b1 + r_T5 + L, 0), (b1 + r_T5 + L + 3, 1),                          # is_equal_muled preamble: 2^w, the bit
                (b1 + r_T6 + 0, 2), (b1 + r_T6 + 1, 2), (b1 + r_T6 + 2, 0), (b1 + r_T6 + 3, 0), (b1 + r_T6 + 8, 0), (b1 + r_T6 + 9, 0),
                (b1 + r_T6 + 14, 0), (b1 + r_T6 + 17, 2), (b1 + r_T6 + 18, 0), (b1 + r_T6 + 19, 1), (b1 + r_T6 + 20, 4),   # carry range rows
-               (b1 + r_T6 + 26 * 5 + 22, 2), (rows - 1, 2), (rows - 1, 0)]
+               (b1 + r_T6 + 26 * 5 + 22, 2), (rows - 2, 2), (rows - 2, 0),    # the last column's closing `and`
+               (rows - 1, 0)]                                                  # assert_equal_muled's assert_one(eq_bit), the record's last row (chip.rs:1062)
     assert len(targets) >= 20
     codes = set()
     for (row, col) in targets:

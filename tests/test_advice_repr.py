@@ -239,7 +239,7 @@ def test_columns_of_a_fixed_stride_and_guard_bytes(H, arrangement):
     base = H.BigIntChip(64, 2048)
     want = base.pow_mod_fixed_exp(base.assign_integer(X), e, base.assign_integer(N)).emit_advice().cpu().numpy()
     rows = want.shape[1] // 160
-    k_rows = 1 << 15                       # 2^15-row columns hold the 2 + 6 * 3,973 rows of e = 17
+    k_rows = 1 << 15                       # 2^15-row columns hold the 2 + 6 * 3,974 rows of e = 17
     assert rows + 5 <= k_rows
     for r0 in (0, 1, 2, 3, 5):             # every 128-byte phase of the first row
         if arrangement == "element_major":

@@ -74,7 +74,7 @@ def test_bench_advice_line():
     pow rows it writes, and bench.py's own check of the timed image against the image of a call with records."""
     line = _run(["--advice", "--batch", "256", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--pmc-traffic", "off", "--placement-candidates", "3"])
     assert line["config"]["path"] == "advice image" and line["roofline"]["kernel"].startswith("cells_kernel")
-    assert line["roofline"]["algorithmic_bytes_per_launch"] == 256 * (2 + 19 * 3973) * 160
+    assert line["roofline"]["algorithmic_bytes_per_launch"] == 256 * (2 + 19 * 3974) * 160
     assert line["value"] > 0 and 0.2 < line["roofline"]["frac"] < 1.0
     assert line["config"]["buffer_placement"]["candidates"] == 3
 
@@ -85,7 +85,7 @@ def test_bench_advice_in_the_provers_representation():
     line = _run(["--advice", "--columns", "--montgomery", "--batch", "128", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--pmc-traffic", "off",
                  "--placement-candidates", "0"])
     rp = line["config"]["representation"]
-    assert rp["columns"] and rp["montgomery"] and rp["col_stride"] % 4096 == 0 and rp["col_stride"] >= (2 + 1532 + 19 * 3973) * 32
+    assert rp["columns"] and rp["montgomery"] and rp["col_stride"] % 4096 == 0 and rp["col_stride"] >= (2 + 1532 + 19 * 3974) * 32
     assert "Montgomery" in line["roofline"]["kernel"] and line["value"] > 0
     assert "0 violations" in line["config"]["post_run_audit"]
 
@@ -95,9 +95,9 @@ def test_bench_advice_whole_verify_element():
     (is_valid and the timed image against the record-based call's, h2r_advice_check with RSAChip's table over every row)."""
     line = _run(["--advice", "--verify", "--batch", "128", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--pmc-traffic", "off",
                  "--placement-candidates", "0"])
-    assert line["config"]["path"] == "advice image (verify element)" and "77200 rows" in line["config"]["workload"]
+    assert line["config"]["path"] == "advice image (verify element)" and "77219 rows" in line["config"]["workload"]
     assert "h2r_pipeline_verify_pkcs1v15_advice" in line["config"]["pipeline"]
-    assert line["roofline"]["algorithmic_bytes_per_launch"] == 128 * (2 + 19 * 3973) * 160
+    assert line["roofline"]["algorithmic_bytes_per_launch"] == 128 * (2 + 19 * 3974) * 160
     assert line["value"] > 0 and "0 violations" in line["config"]["post_run_audit"]
 
 
@@ -106,7 +106,7 @@ def test_bench_records_free_flow_line():
     line = _run(["--records-free-flow", "--batch", "64", "--steps", "3", "--warmup", "2"])
     assert line["unit"] == "circuits/s" and line["value"] > 0 and 0.05 < line["roofline"]["frac"] < 1.0
     bb = line["config"]["bytes_per_batch"]
-    assert bb["advice_image"] == 64 * 77200 * 160 and bb["lookup_columns"] == 2 * 64 * 5 * ((1 << 17) - 6) * 32
+    assert bb["advice_image"] == 64 * 77219 * 160 and bb["lookup_columns"] == 2 * 64 * 5 * ((1 << 17) - 6) * 32
 
 
 def test_bench_lookup_line():

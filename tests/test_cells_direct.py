@@ -107,7 +107,8 @@ def test_direct_image_into_unaligned_rows(H):
 def test_direct_image_of_an_inconsistent_mul_mod_satisfies_the_gate(H, w, L, field):
     """q, r that are NOT the quotient and remainder of a * b (the record's R plane bumped by one): the kernel's general path --
     d = x - y != 0 in is_equal, its inverse witness, eq_bit falling to 0 -- must still give a satisfying assignment of every row
-    (the main-gate equation with the fixed row of the row's kind), and the final eq_bit must be 0."""
+    of is_equal_muled (the main-gate equation with the fixed row of the row's kind), the final eq_bit must be 0, and the closing assert_one row
+    must hold that 0."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import pyref as R
     import advice_ref as AR
@@ -140,14 +141,18 @@ def test_direct_image_of_an_inconsistent_mul_mod_satisfies_the_gate(H, w, L, fie
         fixed[k] = fr.as_dict()
     cells = [[int.from_bytes(img[1, r, 32 * c:32 * c + 32].tobytes(), "little") for c in range(5)] for r in range(rows)]
     n_inv = 0
-    for r in range(rows):
+    for r in range(rows - 1):                                      # every row but the record's last one ...
         f = fixed[int(kinds[r])]
         assert AR.gate_residual(cells[r], cells[r + 1][4] if r + 1 < rows else 0, f, P) == 0, (r, int(kinds[r]))
         if int(kinds[r]) == AR.ROW_ISZERO_INV and cells[r][0] != 0:
             assert cells[r][0] * cells[r][1] % P == 1 and cells[r][2] == 0
             n_inv += 1
     assert n_inv >= 1, "no is_zero inverse witness in the image of an inconsistent mul_mod"
-    assert cells[rows - 1][2] == 0, "final eq_bit of an inconsistent mul_mod"   # the last `and` row: [e1, f2, e2]
+    assert cells[rows - 2][2] == 0, "final eq_bit of an inconsistent mul_mod"   # the last `and` row: [e1, f2, e2]
+    # ... which is assert_equal_muled's main_gate.assert_one(eq_bit) (chip.rs:1062): the ONE row an inconsistent mul_mod cannot satisfy --
+    # it holds the eq_bit it was given (0), its gate reads a - 1 = -1.  (The reference's MockProver flags exactly this row.)
+    assert int(kinds[rows - 1]) == 17 and cells[rows - 1] == [0, 0, 0, 0, 0]
+    assert AR.gate_residual(cells[rows - 1], 0, fixed[17], P) == P - 1
 
 
 def test_modpow_public_key_element_without_records(H, golden):
@@ -169,7 +174,7 @@ def test_modpow_public_key_element_without_records(H, golden):
     sec = (ctypes.c_uint64 * 2)()
     total = int(lib().h2r_modpow_public_key_advice_rows(chip._ctx, ctypes.byref(pl), sec))
     assert list(sec) == [want_if.shape[1] // 160, want_pow.shape[1] // 160] and total == sum(sec)
-    assert list(sec) == [1532, 2 + 19 * 3973]
+    assert list(sec) == [1532, 2 + 19 * 3974]
     bare = chip.pow_mod_fixed_exp(chip.assign_integer(xs), 65537, chip.assign_integer(ns), want_trace=False, check_in_field=True,
                                   workspace=torch.empty(chip.workspace_bytes(6, pl.num_mul_mods), dtype=torch.uint8, device="cuda"))
     assert bare.trace is None and bare.in_field is not None
@@ -462,7 +467,7 @@ def test_verify_element_with_a_variable_exponent_as_advice_rows(H, golden):
     rf = rsa.verify_pkcs1v15_signature(pk_fix, hashed, sg)
     total, sec = rv.advice_sections()
     _, sec_f = rf.advice_sections()
-    rows = 3973
+    rows = 3974
     assert sec[0] == 1 and sec[1] == 1532 and sec[3] == sec_f[3]
     assert sec[2] == 4 * (5 + 2 + 1) + 2 + 20 * (2 * rows + 32)
     assert rv.is_valid.cpu().tolist() == [1, 1, 0]

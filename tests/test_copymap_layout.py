@@ -35,7 +35,7 @@ def test_copy_map_is_well_formed(w, L_):
     buf = (_lib.H2RCopy * n)()
     assert int(L.h2r_advice_copy_map(ctx, buf, n)) == n
     C = 2 * L_ - 1
-    assert n == 2 * 3 * L_ * L_ + 2 * L_ + C * 33     # three inputs per mul_add row, two per eq_b row, 33 per is_equal_muled column
+    assert n == 2 * 3 * L_ * L_ + 2 * L_ + C * 33 + 1   # three inputs per mul_add row, two per eq_b row, 33 per is_equal_muled column, the closing assert_one's one
     seen = set()
     kinds = np.zeros(rows, dtype=np.uint8)
     assert L.h2r_advice_row_kinds(ctx, kinds.ctypes.data) == 0

@@ -428,7 +428,7 @@ def test_advice_image(H, w, L, field):
     rows = int(lib().h2r_advice_rows(chip._ctx))
     assert img.shape == (batch, rows * 160)
     if (w, L) == (64, 32):
-        assert rows == 3973
+        assert rows == 3974
     # the fixed side, from the C ABI: row kinds and the selectors of every kind
     kinds = np.zeros(rows, dtype=np.uint8)
     assert lib().h2r_advice_row_kinds(chip._ctx, kinds.ctypes.data) == 0
@@ -2094,7 +2094,7 @@ def test_verify_element_advice_image(H, golden):
     sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs, 32, 64)))
     res = rsa.verify_pkcs1v15_signature(pk, hashed, sg)
     total, sec = res.advice_sections()
-    assert sec == [1, 1532, 2 + 19 * 3973, 178] and total == sum(sec)
+    assert sec == [1, 1532, 2 + 19 * 3974, 178] and total == sum(sec)
     img = res.emit_advice()
     torch.cuda.synchronize()
     assert res.status.cpu().tolist() == [0, 0, 0, 0, H.H2R_E_NOT_IN_FIELD]

@@ -35,7 +35,7 @@ def test_image_satisfies_the_main_gate_and_the_lookups(w, L, field):
     im = AR.mul_mod_image(o.p, a, b, n, st, P)
     C = 2 * L - 1
     nrc = (o.p.carry_nsub + 3) // 4
-    assert len(im.rows) == 4 * L + 2 * (C + L * L) + L + 4 + (C - 1) * (23 + nrc) + 23
+    assert len(im.rows) == 4 * L + 2 * (C + L * L) + L + 4 + (C - 1) * (23 + nrc) + 23 + 1   # ... + assert_one(eq_bit) :1062
     cfg = AR.LookupConfig(AR.range_lens(w, L, rsa=(w == 64)))
     fixed = [AR.fixed_row(k, w, L, o.p.carry_bits, o.p.carry_sub_bits, o.p.carry_nsub, cfg) for k in im.kinds]
     for ri, (cells, f) in enumerate(zip(im.rows, fixed)):
@@ -177,7 +177,7 @@ def test_pow_var_image_satisfies_the_main_gate(w, L, field, e_limbs, nb):
     per_limb = nb + (nb + 3) // 4 + 1
     C = 2 * L - 1
     nrc = (o.p.carry_nsub + 3) // 4
-    rows_mm = 4 * L + 2 * (C + L * L) + L + 4 + (C - 1) * (23 + nrc) + 23
+    rows_mm = 4 * L + 2 * (C + L * L) + L + 4 + (C - 1) * (23 + nrc) + 23 + 1   # ... + assert_one(eq_bit) :1062
     assert len(im.rows) == len(e_limbs) * per_limb + 2 + nbits * (2 * rows_mm + L)
     cfg = AR.LookupConfig(AR.range_lens(w, L, rsa=(w == 64)))
 

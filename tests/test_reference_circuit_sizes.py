@@ -94,7 +94,7 @@ def test_model_equals_library_rsa_element_rows(bits):
     assert L.h2r_verify_layout_fixed(ctx, e, len(e), ctypes.byref(vl)) == 0
     assert counted(m, m.verify_pkcs1v15_signature, 65537) == L.h2r_verify_advice_rows(ctx, ctypes.byref(vl), sec4)
     if bits == 2048:
-        assert list(sec4) == [1, 1532, 75489, 178]
+        assert list(sec4) == [1, 1532, 75508, 178]
     assert L.h2r_verify_layout_var(ctx, 1, 5, ctypes.byref(vl)) == 0
     assert counted(m, m.verify_pkcs1v15_signature, None, 1) == L.h2r_verify_advice_rows(ctx, ctypes.byref(vl), sec4)
     L.h2r_ctx_destroy(ctx)

@@ -316,7 +316,7 @@ def test_verify_with_a_variable_exponent(H, golden):
         for r in (res, res_m):
             assert r.status.cpu().tolist() == [0, 0, 0] and r.is_valid.cpu().tolist() == [1, 1, 0]
         nbits = exp_limb_bits * len(e_limbs)                              # [is_eq] [assert_in_field] [to_bits, acc = 1, per bit mul_mod / select / square_mod] [EM]
-        assert res.advice_sections()[1][2] == len(e_limbs) * (exp_limb_bits + (exp_limb_bits + 3) // 4 + 1) + 2 + nbits * (2 * 3973 + 32)
+        assert res.advice_sections()[1][2] == len(e_limbs) * (exp_limb_bits + (exp_limb_bits + 3) // 4 + 1) + 2 + nbits * (2 * 3974 + 32)
         for i in range(3):
             _, _, s_if = o.assert_in_field(o.limbs(sigs[i]), o.limbs(ns[i]))
             rc, out, s_pow = o.pow_mod(o.limbs(sigs[i]), np.array(e_limbs, dtype=np.uint64), exp_limb_bits, o.limbs(ns[i]))

@@ -37,8 +37,8 @@ def test_compact_layout_on_the_host():
     assert vl.elem_stride < 16384 < full.elem_stride
     assert (vl.in_field_stream_bytes, vl.em_stream_bytes, vl.stream_bytes) == (full.in_field_stream_bytes, full.em_stream_bytes, full.stream_bytes)
     sa, sb = (ctypes.c_uint64 * 4)(), (ctypes.c_uint64 * 4)()
-    assert lib().h2r_verify_advice_rows(ctx, ctypes.byref(vl), sa) == lib().h2r_verify_advice_rows(ctx, ctypes.byref(full), sb) == 77200
-    assert list(sa) == list(sb) == [1, 1532, 75489, 178]
+    assert lib().h2r_verify_advice_rows(ctx, ctypes.byref(vl), sa) == lib().h2r_verify_advice_rows(ctx, ctypes.byref(full), sb) == 77219
+    assert list(sa) == list(sb) == [1, 1532, 75508, 178]
     assert lib().h2r_verify_layout_compact(ctx, None, ctypes.byref(vl)) == _lib.H2R_E_NULL
     lib().h2r_ctx_destroy(ctx)
     p32 = _lib.H2RParams(32, 2048, 0, -1)
@@ -101,7 +101,7 @@ def test_pipelined_verify_image_is_the_record_based_image(H, golden, repr_kw):
     vl = pipe.verify_compact_layout(65537)
     sec = (ctypes.c_uint64 * 4)()
     rows = int(lib().h2r_verify_advice_rows(chip._ctx, ctypes.byref(vl), sec))
-    assert rows == 77200
+    assert rows == 77219
     sets = [_buffers(chip, vl, rows, B) for _ in range(depth)]
     calls, got = [], []
     for k in range(calls_n):

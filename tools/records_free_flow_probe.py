@@ -13,7 +13,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 mont = len(sys.argv) > 2 and sys.argv[2] == "montgomery"
 usable = (1 << 17) - 6
 rows_probe = H.RSAChip(2048, 5).bigint_chip()
-kw = dict(columns=True, montgomery=True, col_stride=((77200 * 32 + 4095) // 4096) * 4096) if mont else {}
+kw = dict(columns=True, montgomery=True, col_stride=((77219 * 32 + 4095) // 4096) * 4096) if mont else {}
 rsa = H.RSAChip(2048, 5, **kw)
 chip = rsa.bigint_chip()
 la = H.LookupArgument(chip, rsa_chip=True)
