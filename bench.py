@@ -254,6 +254,72 @@ def relaunch_under_torchrun(n):
     os.execv(sys.executable, cmd)
 
 
+def check_gathered(gathered, audit_all, world, shard, total, w, bits, e, sample=True, strict=True, expect=None):
+    """Rank 0's post-run check of the gathered results: sizes, audit verdict bytes, and samples from EVERY shard against pow() of the
+    regenerated inputs (expect = None), or against `expect(x, n)` (the dry run's stand-in for the GPU result).  Returns (ok, message)."""
+    try:
+        assert gathered.shape[0] == total and audit_all.shape[0] == total, "gathered %d results / %d verdict bytes for a batch of %d" % (gathered.shape[0], audit_all.shape[0], total)
+        n_flagged = int((audit_all != 0).sum().item())
+        assert n_flagged == 0 or not strict, "%d elements with a status or a violated witness relation" % n_flagged
+        if sample:
+            golden = load_golden(w, bits)
+            host = gathered.cpu().numpy().view(np.uint64 if w == 64 else np.uint32)   # [total, num_limbs] little-endian limbs
+            for r in range(world):
+                lo, hi = shard_range(total, r, world)
+                for off in sorted({0, (hi - lo) // 2 + 1 if hi - lo > 2 else 0, hi - lo - 1}):
+                    g = lo + off
+                    n_g, x_g = synth_element(w, bits, g, golden)
+                    v = sum(int(t) << (w * i) for i, t in enumerate(host[g]))
+                    if not (golden is not None and g < 3 and x_g >= n_g):
+                        want = pow(x_g, e, n_g) if expect is None else expect(x_g, n_g)
+                        assert v == want, "shard %d element %d differs from %s" % (r, off, "pow(x, e, n)" if expect is None else "the dry run's stand-in result")
+    except AssertionError as ex:
+        return False, str(ex)
+    return True, ""
+
+
+def dist_dry_run(args):
+    """--dry-run-dist: the N > 1 plumbing of this script WITHOUT the GPU -- argument handling, the relaunch under torch.distributed.run,
+    rendezvous, configuration broadcast, contiguous shards of the seeded global batch (a batch the ranks need not divide: --dry-total),
+    barrier + MAX timing, the gather of results + verdict bytes to rank 0, rank 0's samples from every shard, the agreed verdict and the
+    exit status.  Only the GPU call is replaced: the stand-in "result" of element (x, n) is x itself, its verdict byte 0.  gloo on CPU.
+    H2R_DRY_FAIL_RANK=r: rank r reports a failed audit of its shard;  H2R_DRY_LATE_RANK=r: rank r arrives 5 s late at the first collective."""
+    from halo2_rsa_amd.dist import finish_with_verdict
+    env = DistEnv.from_environment(args.gpus, force=bool(os.environ.get("H2R_FORCE_DIST")))
+    w, bits, e = WORKLOADS[args.workload]
+    if env.rank == int(os.environ.get("H2R_DRY_LATE_RANK", "-1")):
+        time.sleep(5.0)
+    env.init("gloo")
+    chunks = args.chunks if args.chunks else (1 if args.gpus == 1 else 4)
+    chunk = args.batch if args.batch else (1024 if args.gpus == 1 else 8192 // chunks)
+    e, chunk, chunks, steps, warmup, total = env.broadcast_ints([e, chunk, chunks, args.steps, args.warmup, args.dry_total or 0])
+    total = total or chunk * chunks * env.world
+    lo, hi = shard_range(total, env.rank, env.world)
+    ns, xs, un, ux = synth_inputs(w, bits, lo, hi)
+    env.barrier()
+    t0 = time.perf_counter()
+    result = torch.from_numpy(ux.limbs.view(np.int64).copy())          # <- where the hot path would run
+    audit = torch.zeros(hi - lo, dtype=torch.uint8)
+    if env.rank == int(os.environ.get("H2R_DRY_FAIL_RANK", "-1")) and hi > lo:
+        audit[(hi - lo) // 2] = 1
+    env.barrier()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
+    gathered, audit_all = env.gather_to_rank0(result, audit, total=total)
+    ok, msg = True, ""
+    n_mine = int((audit != 0).sum().item())
+    if n_mine:
+        ok, msg = False, "%d elements of this rank's shard with a status or a violated witness relation" % n_mine
+    elif env.rank == 0:
+        ok, msg = check_gathered(gathered, audit_all, env.world, None, total, w, bits, e, sample=True, strict=False, expect=lambda x, n: x)
+    finish_with_verdict(env, ok, msg)
+    if env.rank == 0:
+        sizes = [shard_range(total, r, env.world)[1] - shard_range(total, r, env.world)[0] for r in range(env.world)]
+        print(json.dumps({"dry_run": True, "n_gpus": env.world, "global_batch": total, "shard_sizes": sizes, "steps": steps, "warmup": warmup,
+                          "e": e, "max_over_ranks_s": round(dt, 6), "collective_backend": "torch.distributed gloo (CPU)",
+                          "post_run_check": "samples from every shard regenerated on rank 0; verdict agreed by every rank"}))
+    env.finalize()
+
+
 def ensure_built():
     """The bench needs libh2r.so (built in-tree by __graft_entry__.build(); git-ignored, but it travels with the
     working tree).  If it is missing, local rank 0 builds it with
@@ -948,9 +1014,14 @@ def main():
     ap.add_argument("--pmc-traffic", choices=["auto", "off"], default="auto",
                     help="roofline.traffic: auto = measure it now with two rocprofv3 --pmc passes of a short run of the same workload "
                          "(N = 1, rank 0; falls back to the committed profiles/pmc_traffic.json when rocprofv3 is unavailable); off = committed file only")
+    ap.add_argument("--dry-run-dist", action="store_true",
+                    help="the N > 1 plumbing without the GPU (gloo on CPU): see dist_dry_run; tests/test_dist_cpu.py runs it at N = 8")
+    ap.add_argument("--dry-total", type=int, default=0, help="--dry-run-dist: the global batch (need not be a multiple of N)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args.gpus)
+    if args.dry_run_dist:
+        return dist_dry_run(args)
     if args.records_free_flow:
         return flow_bench(args)
     if args.lookup:
@@ -1239,21 +1310,22 @@ def main():
         audit = aud_last
     shard_out = out[:shard].contiguous() if chunks > 1 else res.contiguous()
     gathered, audit_all = env.gather_to_rank0(shard_out, audit.contiguous())
-    if env.rank == 0:
-        assert gathered.shape[0] == env.world * shard_out.shape[0]
-        n_flagged = int((audit_all != 0).sum().item())
-        assert n_flagged == 0 or (w, bits) != (64, 2048) or args.shared_modulus, "%d elements with a status or a violated witness relation" % n_flagged
-        if (chunks > 1 or env.world > 1 or shard > 1024) and not args.shared_modulus:   # samples from EVERY shard against pow() of the regenerated inputs
-            golden = load_golden(w, bits)
-            vals = H.AssignedInteger(gathered, w)
-            host = vals.limbs_host()
-            for r in range(env.world):
-                for off in (0, shard // 2 + 1, shard - 1):
-                    g = r * shard + off
-                    n_g, x_g = synth_element(w, bits, g, golden)
-                    v = sum(int(t) << (w * i) for i, t in enumerate(host[g]))
-                    if not (golden is not None and g < 3 and x_g >= n_g):
-                        assert v == pow(x_g, e, n_g), "shard %d element %d differs from pow(x, e, n)" % (r, off)
+    # every rank judges its own shard, rank 0 also the gathered results; the verdict is then AGREED (halo2_rsa_amd.dist.finish_with_verdict):
+    # a failed audit anywhere makes every rank exit non-zero with one line, and no result line is printed
+    verdict_ok, verdict_msg = True, ""
+    try:
+        n_mine = int((audit != 0).sum().item())
+        assert n_mine == 0 or (w, bits) != (64, 2048) or args.shared_modulus, "%d elements of this rank's shard with a status or a violated witness relation" % n_mine
+        if env.rank == 0:
+            verdict_ok, verdict_msg = check_gathered(gathered, audit_all, env.world, shard, shard * env.world, w, bits, e,
+                                                     sample=(chunks > 1 or env.world > 1 or shard > 1024) and not args.shared_modulus,
+                                                     strict=(w, bits) == (64, 2048) and not args.shared_modulus)
+    except AssertionError as ex:
+        verdict_ok, verdict_msg = False, str(ex)
+    if env.world > 1:
+        from halo2_rsa_amd.dist import finish_with_verdict
+        finish_with_verdict(env, verdict_ok, verdict_msg)
+    assert verdict_ok, verdict_msg
 
     if env.rank == 0:
         # written (pow stream + the assert_in_field stream of modpow_public_key) + inputs read

@@ -1332,16 +1332,20 @@ int32_t pipeline_flush(h2r_pipeline *p, hipStream_t st) {
 int32_t h2r_pipeline_create(const h2r_ctx *ctx, h2r_pipeline **out) try { return h2r_pipeline_create_ex(ctx, 2, 1, out); } H2R_CATCH_STATUS
 
 namespace {
-__global__ void queue_probe_kernel(unsigned long long ticks) {   // one wave that holds its queue for `ticks` of the 100 MHz wall clock
+__global__ void queue_probe_kernel(unsigned long long ticks, unsigned long long *stamp) {   // one wave that holds its queue for `ticks` of the 100 MHz wall clock
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (stamp && threadIdx.x == 0) { stamp[0] = t0; stamp[1] = wall_clock64(); }   // when it ran, on the device's own clock
 }
 }  // namespace
 namespace {
-bool pipeline_three_queues(h2r_pipeline *p, hipStream_t st) {
+// force: measure again although `st` has a cached verdict (h2r_pipeline_info: the caller's way to refresh it after streams were created or
+// destroyed -- HIP may have re-assigned queues, and a destroyed stream's handle can come back for a new stream)
+bool pipeline_three_queues(h2r_pipeline *p, hipStream_t st, bool force = false) {
     if (p->aux[0] == p->aux[1]) return false;
+    if (knobs().pipe_form >= 0) return knobs().pipe_form == 1;    // (developer build: H2R_PIPE_FORM forces the form, e.g. under a profiler)
     auto it = p->queue_probe.find(st);
-    if (it != p->queue_probe.end()) return it->second != 0;
+    if (!force && it != p->queue_probe.end()) return it->second != 0;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (cs != hipStreamCaptureStatusNone) return false;           // (a capture cannot be timed: the form that needs no particular queues; not cached)
@@ -1350,21 +1354,31 @@ bool pipeline_three_queues(h2r_pipeline *p, hipStream_t st) {
     for (hipStream_t s : ss) if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return false; }
     const unsigned long long spin_ticks = 15000;                  // 150 us
     float best = 1e9f;
+    bool overlapped = false;
+    unsigned long long *stamps = nullptr;                         // [3][2]: every spinner's start and end on the DEVICE's wall clock
+    if (hipHostMalloc(reinterpret_cast<void **>(&stamps), 6 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); stamps = nullptr; }
     for (int rep = 0; rep < 4; ++rep) {                           // (the first round also loads the kernel; the best of the other three counts)
         const auto t0 = std::chrono::steady_clock::now();
-        for (hipStream_t s : ss) hipLaunchKernelGGL(queue_probe_kernel, dim3(1), dim3(64), 0, s, spin_ticks);
+        for (int k = 0; k < 3; ++k) hipLaunchKernelGGL(queue_probe_kernel, dim3(1), dim3(64), 0, ss[k], spin_ticks, stamps ? stamps + 2 * k : nullptr);
         bool ok = hipGetLastError() == hipSuccess;
         for (hipStream_t s : ss) ok = (hipStreamSynchronize(s) == hipSuccess) && ok;
-        if (!ok) { (void)hipGetLastError(); return false; }
+        if (!ok) { (void)hipGetLastError(); if (stamps) (void)hipHostFree(stamps); return false; }
         const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (rep && ms < best) best = ms;
+        if (rep && ms < best) {
+            best = ms;
+            // the device's own account of the round: all three ran at one instant iff the latest start precedes the earliest end
+            if (stamps) overlapped = std::max({stamps[0], stamps[2], stamps[4]}) < std::min({stamps[1], stamps[3], stamps[5]});
+        }
     }
+    if (stamps) (void)hipHostFree(stamps); else overlapped = true;   // (no stamp buffer: the host clock decides alone, as before)
     p->probe_ms = best;
     // Measured (profiles/r05_queue_probe.txt, 16 runs: plain / torchrun + RCCL, 4 / 8 hardware queues, low / normal side-stream priority):
     // 0.179-0.181 ms whenever the two-queue form then ran at 5.5-5.6 M assigns/s, 0.199-0.203 ms whenever it ran at 4.2-5.0 M -- two of the
     // streams share a queue and their packets overlap only partly.  A false "shared" costs 2 % (the step runs at 5.5 M), a false "three
     // queues" 10-25 %: the threshold sits close to the clean value.
-    const int three = best <= 0.186f ? 1 : 0;
+    // [r6] ... and, whatever the host clock says (launch latency is part of it), the spinners' own device-clock stamps must show the three
+    // running at one instant.
+    const int three = (best <= 0.186f && overlapped) ? 1 : 0;
     p->queue_probe[st] = three;
     return three != 0;
 }
@@ -1377,7 +1391,7 @@ int32_t h2r_pipeline_info(h2r_pipeline *p, h2r_stream_t stream, uint64_t batch, 
     H2R_ON_DEVICE(ctx->params.device);
     out->depth = p->depth; out->side_streams = p->aux[0] != p->aux[1] ? 2u : 1u;
     const bool shape = ctx->layout.limb_width == 64 && ctx->L == 32 && batch && batch <= 2048 && p->aux[0] != p->aux[1] && p->depth >= 3;
-    out->three_queues = shape ? (pipeline_three_queues(p, static_cast<hipStream_t>(stream)) ? 1u : 0u) : 2u;   // 2: not asked (the shape has no two-queue form)
+    out->three_queues = shape ? (pipeline_three_queues(p, static_cast<hipStream_t>(stream), true) ? 1u : 0u) : 2u;   // 2: not asked (the shape has no two-queue form)
     out->probe_ms = p->probe_ms;
     out->record_form = (shape && out->three_queues == 1) ? H2R_PIPE_TWO_QUEUE : (step_eligible(ctx, batch, reinterpret_cast<void *>(1), 19) ? H2R_PIPE_ONE_LAUNCH_STEP : H2R_PIPE_SIDE_STREAM);
     return H2R_OK;

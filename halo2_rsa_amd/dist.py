@@ -76,9 +76,13 @@ class DistEnv:
         dist.broadcast(t, src=0)
         return [int(v) for v in t.tolist()]
 
-    def gather_to_rank0(self, shard: torch.Tensor, status: torch.Tensor = None):
-        """Gather equally sized per-rank result tensors; rank 0 returns the concatenation, others None.  With `status` (uint8
-        [elems]) the pair (results, status) -- (None, None) on the other ranks."""
+    def gather_to_rank0(self, shard: torch.Tensor, status: torch.Tensor = None, total: int = None):
+        """Gather the per-rank result tensors; rank 0 returns the concatenation, others None.  With `status` (uint8 [elems]) the pair
+        (results, status) -- (None, None) on the other ranks.  Shards are equally sized unless `total` is given: then rank r holds the
+        shard_range(total, r, world) elements of a batch that the ranks do not divide (the shards travel padded to the largest one)."""
+        return gather_with_total(self, DistEnv._gather_equal, shard, status, total)
+
+    def _gather_equal(self, shard: torch.Tensor, status: torch.Tensor = None):
         if status is not None:
             return self._gather_one(shard), self._gather_one(status)
         return self._gather_one(shard)
@@ -104,6 +108,44 @@ class DistEnv:
             dist.barrier() if self.backend != "nccl" else dist.barrier(device_ids=[self.local_rank])
             dist.destroy_process_group()
             self.initialised = False
+
+
+def gather_with_total(env, gather_equal, shard: torch.Tensor, status, total):
+    """Uneven shards over an equal-size gather: pad to ceil(total / world) elements, gather, and let rank 0 cut every rank's padding off."""
+    if total is None or env.world == 1:
+        return gather_equal(env, shard, status)
+    lo, hi = shard_range(total, env.rank, env.world)
+    if shard.shape[0] != hi - lo or (status is not None and status.shape[0] != hi - lo):
+        raise ValueError("rank %d holds %d elements, shard_range(%d, %d, %d) is %d" % (env.rank, shard.shape[0], total, env.rank, env.world, hi - lo))
+    most = -(-total // env.world)
+    pad = most - (hi - lo)
+    if pad:
+        shard = torch.cat([shard, shard.new_zeros((pad,) + tuple(shard.shape[1:]))], 0)
+        if status is not None:
+            status = torch.cat([status, status.new_zeros(pad)], 0)
+    got = gather_equal(env, shard.contiguous(), status.contiguous() if status is not None else None)
+    if env.rank != 0:
+        return got
+    sizes = [shard_range(total, r, env.world)[1] - shard_range(total, r, env.world)[0] for r in range(env.world)]
+    cut = lambda t: torch.cat([t[r * most:r * most + sizes[r]] for r in range(env.world)], 0)
+    return (cut(got[0]), cut(got[1])) if status is not None else cut(got)
+
+
+def finish_with_verdict(env, ok: bool, message: str = "", key: str = "post_run_check"):
+    """The end of a multi-rank run: every rank leaves with the SAME verdict.  ok = this rank's own post-run check; if ANY rank failed, every
+    rank writes one line to stderr (the failing ones say what failed) and exits with status 3 -- no rank prints a result line next to a
+    failed audit elsewhere, and none is left waiting in a collective for a rank that raised."""
+    import sys
+    all_ok = agree_all(key, ok, env.rank, env.world)
+    if all_ok:
+        return
+    sys.stderr.write("rank %d: post-run check %s\n" % (env.rank, ("FAILED: " + message) if not ok else "passed here, FAILED on another rank: leaving without a result line"))
+    sys.stderr.flush()
+    try:
+        env.finalize()
+    except Exception:
+        pass
+    sys.exit(3)
 
 
 _key_uses = {}
@@ -208,9 +250,12 @@ class H2RDist:
         self._check(self._lib.h2r_dist_bcast(self._d, t.data_ptr(), t.numel() * 8, 0, self._stream()), "h2r_dist_bcast")
         return [int(v) for v in t.tolist()]
 
-    def gather_to_rank0(self, shard: torch.Tensor, status: torch.Tensor = None):
+    def gather_to_rank0(self, shard: torch.Tensor, status: torch.Tensor = None, total: int = None):
         """shard: [elems, num_limbs] limbs.  Every rank receives every shard (all-gather); rank 0 returns the concatenation.
-        status (uint8 [elems], optional) travels in the same group call: rank 0 then returns (results, status)."""
+        status (uint8 [elems], optional) travels in the same group call: rank 0 then returns (results, status).  `total`: as DistEnv's."""
+        return gather_with_total(self, H2RDist._gather_equal, shard, status, total)
+
+    def _gather_equal(self, shard: torch.Tensor, status: torch.Tensor = None):
         shard = shard.contiguous()
         out = torch.empty((self.world * shard.shape[0],) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
         st_all = torch.empty(self.world * shard.shape[0], dtype=torch.uint8, device=shard.device) if status is not None else None

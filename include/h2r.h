@@ -344,7 +344,11 @@ int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream);
  * 150 us one-wave spinners, one per stream, after synchronising the three streams: ~0.5 ms once per (pipeline, stream); never inside a
  * stream capture, which takes the step) and falls back to the one-launch step when two of them share a queue -- no environment
  * variable is needed for correctness or for the 5.4-5.5 M assigns/s floor; GPU_MAX_HW_QUEUES=8 merely makes the faster form available
- * to a process that has many streams.  h2r_pipeline_info runs the probe if it has not run for `stream` and reports the outcome. */
+ * to a process that has many streams.  The verdict is cached per (pipeline, stream handle); h2r_pipeline_info MEASURES AGAIN every time
+ * it is called (it synchronises the three streams: not for a hot path) and refreshes the cache -- call it after creating or destroying
+ * streams (HIP may re-assign queues; a destroyed stream's handle can come back for a new stream).  The first pipelined call on a new caller
+ * stream therefore synchronises that stream once (~0.5 ms).  Three queues = the host-side round took <= 0.186 ms AND the spinners' own
+ * device-clock stamps show all three running at one instant. */
 enum { H2R_PIPE_ONE_LAUNCH_STEP = 0, H2R_PIPE_TWO_QUEUE = 1, H2R_PIPE_SIDE_STREAM = 2 };
 typedef struct h2r_pipeline_info_t {
     uint32_t struct_size;   /* in: sizeof(h2r_pipeline_info_t) */

@@ -87,3 +87,53 @@ def test_gloo_world2_harness(tmp_path):
     assert "GLOO_OK" in out.stdout
     assert "ID_OK 0" in out.stdout and "ID_OK 1" in out.stdout
     assert "AGREE_OK 0" in out.stdout and "AGREE_OK 1" in out.stdout
+
+
+# ---- world 8 on CPU: bench.py's own N > 1 path (argument handling, relaunch under torch.distributed.run, shards, gather, verdict) with
+# only the GPU call replaced (bench.py --dry-run-dist).  The 1 -> 8 curve itself stays unmeasured on hardware. ----
+
+def _dry_run(extra_env, *extra_args, timeout=300):
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1", **extra_env)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run-dist", "--steps", "7", "--warmup", "2", *extra_args],
+                         capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    lines = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return out, lines
+
+
+def test_world8_batch_not_divisible_by_8():
+    """`python bench.py --gpus 8 ...` without a launcher re-executes itself under torch.distributed.run (relaunch_under_torchrun); 1,003 signatures over
+    8 ranks = three shards of 126 and five of 125, gathered (padded) to rank 0, samples of EVERY shard checked there, one JSON line."""
+    out, lines = _dry_run({}, "--dry-total", "1003")
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert len(lines) == 1
+    ln = lines[0]
+    assert ln["n_gpus"] == 8 and ln["global_batch"] == 1003 and ln["shard_sizes"] == [126, 126, 126, 125, 125, 125, 125, 125]
+    assert ln["steps"] == 7 and ln["warmup"] == 2 and ln["e"] == 65537          # rank 0's arguments reached every rank (broadcast)
+    assert "post-run check" not in out.stderr
+
+
+def test_world8_one_failed_audit_fails_every_rank():
+    """Rank 5 reports a violated witness relation in its shard: every rank exits non-zero with ONE line, rank 5's says what failed, nobody prints a
+    result line, nobody hangs in a collective."""
+    out, lines = _dry_run({"H2R_DRY_FAIL_RANK": "5"}, "--dry-total", "1003")
+    assert out.returncode != 0
+    assert lines == []
+    said = [ln for ln in out.stderr.splitlines() if "post-run check" in ln]
+    assert len(said) == 8 and sorted(int(ln.split()[1].rstrip(":")) for ln in said) == list(range(8))
+    failed = [ln for ln in said if "FAILED:" in ln]
+    assert len(failed) == 1 and failed[0].startswith("rank 5:") and "1 elements of this rank's shard" in failed[0]
+    assert sum("FAILED on another rank" in ln for ln in said) == 7
+
+
+def test_world8_a_rank_arrives_late():
+    """Rank 2 reaches the rendezvous 5 s after the others: the run completes with the same result line (the timing barrier brackets the step, so the
+    late start is not in max_over_ranks_s)."""
+    import time
+    t0 = time.time()
+    out, lines = _dry_run({"H2R_DRY_LATE_RANK": "2"})
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert time.time() - t0 >= 5.0
+    assert len(lines) == 1 and lines[0]["global_batch"] == 65536       # BASELINE config 3: 8,192 per GPU (the N > 1 default)
+    assert lines[0]["shard_sizes"] == [8192] * 8 and lines[0]["max_over_ranks_s"] < 4.0
