@@ -684,21 +684,30 @@ __device__ __forceinline__ int chain_modulus_setup(ChainLds<K, NW> &s, const u32
     return H2R_OK;
 }
 
+}  // namespace h2r
+#include "h2r_chain_wave.hpp"   // one wavefront per element (K <= 32): wave_mulmod, wave_modulus_setup
+namespace h2r {
+
 // One element's chain.  Returns through `status_out` semantics of the reference's panics (see h2r.h).
 // SEG = false (the step launches' chain role, whose register budget is tight): the code for segments of a long exponent is compiled out.
-template <int K, int NW, bool DEEP, bool SEG = true>
+// WAVE (K <= 32, NW = 1): the element belongs to ONE wavefront of a workgroup of independent waves -- `s` is that wave's own LDS, the
+// mul_mods run register-resident (h2r_chain_wave.hpp) and nothing below synchronises beyond the wave (a wave may leave early).
+template <int K, int NW, bool DEEP, bool SEG = true, bool WAVE = false>
 __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K, NW> &s, const u64 elem) {
     using G = Geo<K, NW>;
     constexpr int V = G::V;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    static_assert(!WAVE || (NW == 1 && K <= 32), "the one-wave chain holds 2K <= 64 product columns");
+    const int lane = threadIdx.x & 63, wave = WAVE ? 0 : (int)(threadIdx.x >> 6);
+    const int tid = WAVE ? lane : (int)threadIdx.x;   // this element's thread index among its NT threads
+    constexpr int NT = WAVE ? 64 : 64 * NW;
     const bool w0 = wave == 0;
     const u32 *n_g = args.n + elem * args.n_stride;
     const u32 KR = args.kreal;   // digits in memory; digits [KR, K) are zero
     u32 nraw[V];
 #pragma unroll
     for (int m = 0; m < V; ++m) nraw[m] = ((u32)(lane + 64 * m) < KR) ? n_g[lane + 64 * m] : 0;
-    for (int i = threadIdx.x; i < 3 * K; i += 64 * NW) { s.bpad[i] = 0; s.nnpad[i] = 0; s.mupad[i] = 0; }
-    if (threadIdx.x == 0) { s.dbg = (blockIdx.x == 0) ? args.dbg_time : nullptr; s.dbg_n = 0; }
+    if constexpr (!WAVE) { for (int i = tid; i < 3 * K; i += NT) { s.bpad[i] = 0; s.nnpad[i] = 0; s.mupad[i] = 0; } }
+    if (tid == 0) { s.dbg = (blockIdx.x == 0 && threadIdx.x == 0) ? args.dbg_time : nullptr; s.dbg_n = 0; }
     if (w0 && args.n_copy) glb_store<K>(args.n_copy + elem * KR, nraw, lane, KR);
     int status = H2R_OK;
     {   // n = 0: the reference divides by zero (chip.rs:566); block-uniform
@@ -733,30 +742,42 @@ __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K,
         // main_gate.to_bits(limb, exp_limb_bits) (chip.rs:677) cannot be satisfied by a limb with bits at or above
         // exp_limb_bits: the reference's circuit fails, so the element gets a status instead of a plausible trace
         bool wide = false;
-        for (u32 l = threadIdx.x; l < args.e_num_limbs; l += 64 * NW) {
+        for (u32 l = tid; l < args.e_num_limbs; l += NT) {
             const u32 *ed = args.e_limbs + (elem * args.e_num_limbs + l) * args.digits_per_limb;
             const u64 v = args.digits_per_limb == 2 ? (((u64)ed[1] << 32) | ed[0]) : (u64)ed[0];
             wide = wide || (v >> args.exp_limb_bits) != 0;
         }
-        if (__syncthreads_or(wide ? 1 : 0) && status == H2R_OK) status = H2R_E_SHAPE;
+        bool any_wide;
+        if constexpr (WAVE) any_wide = __ballot(wide) != 0; else any_wide = __syncthreads_or(wide ? 1 : 0) != 0;
+        if (any_wide && status == H2R_OK) status = H2R_E_SHAPE;
     }
     if (status != H2R_OK) {  // block-uniform early exit
-        if (threadIdx.x == 0) args.status[elem] = (u8)status;
+        if (tid == 0) args.status[elem] = (u8)status;
         return;
     }
     u32 shift;
     u32 nn[V];
+    u32 mu_w = 0;     // WAVE: mu' in registers (lanes 0..K-1)
     if (args.pre) {   // shared modulus: constants computed once by recip_kernel
         shift = args.pre[0];
 #pragma unroll
         for (int m = 0; m < V; ++m) nn[m] = (lane + 64 * m < K) ? args.pre[CHAIN_PRE_HDR + lane + 64 * m] : 0;
-        __syncthreads();   // the zero fill above is complete
-        for (int i = threadIdx.x; i < K; i += 64 * NW) { s.nnpad[K + i] = args.pre[CHAIN_PRE_HDR + i]; s.mupad[K + i] = args.pre[CHAIN_PRE_HDR + K + i]; }
-        __syncthreads();
+        if constexpr (WAVE) mu_w = lane < K ? args.pre[CHAIN_PRE_HDR + K + lane] : 0u;
+        else {
+            __syncthreads();   // the zero fill above is complete
+            for (int i = tid; i < K; i += NT) { s.nnpad[K + i] = args.pre[CHAIN_PRE_HDR + i]; s.mupad[K + i] = args.pre[CHAIN_PRE_HDR + K + i]; }
+            __syncthreads();
+        }
     } else {
-        (void)chain_modulus_setup<K, NW>(s, nraw, lane, wave, shift, nn);   // n != 0 was established above
+        if constexpr (WAVE) (void)wave_modulus_setup<K>(s, nraw[0], lane, shift, nn[0], mu_w);
+        else (void)chain_modulus_setup<K, NW>(s, nraw, lane, wave, shift, nn);   // n != 0 was established above
     }
     u32 q[V], r[V];
+    // one mul_mod, by the workgroup (four-wave form) or by this wave alone
+    auto mulmod = [&](const u32 (&oa)[V], const u32 (&ob)[V]) -> int {
+        if constexpr (WAVE) return wave_mulmod<K>(shift, lane, oa[0], ob[0], nn[0], mu_w, q[0], r[0]);
+        else return block_mulmod<K, NW, DEEP>(s, shift, lane, wave, oa, ob, nn, q, r);
+    };
     const u64 item0 = elem * args.T;
     auto emit = [&](u32 t, const u32 (&oa)[V], const u32 (&ob)[V]) {
         if (w0 && status == H2R_OK) {
@@ -782,7 +803,7 @@ __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K,
         if (st != H2R_OK && status == H2R_OK) status = st;
     };
     if (args.mode == CHAIN_MULMOD) {
-        fold(block_mulmod<K, NW, DEEP>(s, shift, lane, wave, cur, bop, nn, q, r));
+        fold(mulmod(cur, bop));
         emit(0, cur, bop);
         if (w0 && status == H2R_OK && args.out) glb_store<K>(args.out + elem * KR, r, lane, KR);
     } else {
@@ -802,14 +823,14 @@ __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K,
                 const u32 limb = bi / args.exp_limb_bits, pos = bi % args.exp_limb_bits;
                 if ((pos & 31) == 0 || (SEG && bi == b_lo)) eword = (args.e_limbs + (elem * args.e_num_limbs + limb) * args.digits_per_limb)[pos >> 5];
                 bit = (eword >> (pos & 31)) & 1u;
-                if (etrace && threadIdx.x == 0) etrace[args.off_e_bits + bi] = (u8)bit;
+                if (etrace && tid == 0) etrace[args.off_e_bits + bi] = (u8)bit;
             } else {
                 if ((bi & 31) == 0 || (SEG && bi == b_lo)) eword = args.e.words[bi >> 5];
                 bit = (eword >> (bi & 31)) & 1u;
             }
             if (var) {
                 // muled = mul_mod(acc, squared) ALWAYS (:686); acc[j] = select(muled[j], acc[j], bit) (:688-691)
-                fold(block_mulmod<K, NW, DEEP>(s, shift, lane, wave, acc, cur, nn, q, r));
+                fold(mulmod(acc, cur));
                 emit(t, acc, cur);
                 ++t;
 #pragma unroll
@@ -818,14 +839,14 @@ __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K,
                     glb_store<K>((u32 *)(etrace + args.off_selected + (u64)bi * args.selected_stride), acc, lane, KR);
             }
             // squared = square_mod(cur) (:734 resp. :693)
-            fold(block_mulmod<K, NW, DEEP>(s, shift, lane, wave, cur, cur, nn, q, r));
+            fold(mulmod(cur, cur));
             emit(t, cur, cur);
             ++t;
             u32 sq[V];
 #pragma unroll
             for (int m = 0; m < V; ++m) sq[m] = r[m];
             if (!var && bit) {  // acc = mul_mod(acc, cur_sq) with the value BEFORE this squaring (:732-739)
-                fold(block_mulmod<K, NW, DEEP>(s, shift, lane, wave, acc, cur, nn, q, r));
+                fold(mulmod(acc, cur));
                 emit(t, acc, cur);
                 ++t;
 #pragma unroll
@@ -844,7 +865,7 @@ __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K,
             }
         }
     }
-    if (threadIdx.x == 0) args.status[elem] = (u8)status;
+    if (tid == 0) args.status[elem] = (u8)status;
 }
 
 // DEEP: the latency build for small batches (about one block per CU, nothing else to hide LDS latency behind): the
@@ -864,6 +885,18 @@ __global__ __launch_bounds__(64 * NW, DEEP ? 2 : (K <= 64 ? H2R_CHAIN_MINB : H2R
         if (elem != blockIdx.x) __syncthreads();   // every wave is done with the previous element's LDS
         chain_element<K, NW, DEEP, SEG>(args, s, elem);
     }
+}
+
+// The one-wave form (K <= 32, h2r_chain_wave.hpp): a workgroup is CHAIN_WAVE_WPB independent waves, one element each; no workgroup barrier
+// anywhere.  Workgroup b walks the elements (b * WPB + wave) + k * gridDim.x * WPB.
+constexpr int CHAIN_WAVE_WPB = 4;
+template <int K, bool SEG = false>
+__global__ __launch_bounds__(64 * CHAIN_WAVE_WPB) void chain_wave_kernel(ChainArgs args) {
+    __shared__ ChainLds<K, 1> s[CHAIN_WAVE_WPB];
+    const int wv = threadIdx.x >> 6;
+    if (args.prio) __builtin_amdgcn_s_setprio(3);
+    for (u64 elem = (u64)blockIdx.x * CHAIN_WAVE_WPB + wv; elem < args.batch; elem += (u64)gridDim.x * CHAIN_WAVE_WPB)
+        chain_element<K, 1, false, SEG, true>(args, s[wv], elem);
 }
 
 // ---- two chains per element, side by side (round 3) -----------------------------------------------------------------
@@ -1831,18 +1864,21 @@ struct Sha256Args {
 };
 template <int NT> __device__ void sha256_role(const Sha256Args &a, u32 blk, u32 *w);   // h2r_sha256.hpp
 
-template <int K, int NW, int LW, int L>
+template <int K, int NW, int LW, int L, bool WAVE = false>
 union StepShared {
     ChainLds<K, NW> chain; TraceShared<LW, L, 64 * NW> trace; uint4 aux[sizeof(TraceShared<LW, L, 64 * NW>) / 16];
+    ChainLds<(WAVE ? K : 2), 1> chainw[WAVE ? NW : 1];   // the one-wave chain form (K <= 32): every wave of the chain role's workgroup owns one
     __device__ StepShared() {}
 };
 // FOLD: the verifier's build -- the chain role also writes the verifier's in-field + encoded-message witness (va), and the launch may
 // carry the SHA-256 role (sa).  A build of its own: with that code in it the kernel spills 41 registers instead of 2 (RSA-2048), so the
 // launches of modpow_public_key calls keep the build without it, whose registers and scratch are what they were.
-template <int K, int NW, int LW, int L, bool FOLD>
+// WAVE (K <= 32): the chain role's workgroup is NW independent one-wave chains (chain_element<.., WAVE>) -- workgroup b of the role walks the
+// elements (b * NW + wave) + k * n_chain * NW; the record role is unchanged.  The verifier's folded witness (va) is not built in this form.
+template <int K, int NW, int LW, int L, bool FOLD, bool WAVE = false>
 __global__ __launch_bounds__(64 * NW, H2R_CHAIN_MINB) void step_kernel(ChainArgs ca, TraceArgs ta, AuxArgs aa, AuxArgs va, Sha256Args sa, u32 n_sha, u32 n_chain, u32 n_rec) {
     static_assert((64 * NW) % TraceGeo<L>::TPI == 0, "the record role's items tile the chain role's workgroup");
-    __shared__ StepShared<K, NW, LW, L> sh;
+    __shared__ StepShared<K, NW, LW, L, WAVE> sh;
     if (FOLD && blockIdx.x < n_sha) {
         // FIRST in dispatch order (n_sha is a multiple of 8, like n_chain): the verifier's SHA-256 of THIS call's messages, one thread
         // per message -- a long, latency-bound role (three compressions of 64 dependent rounds), so it has to start with the launch;
@@ -1851,6 +1887,14 @@ __global__ __launch_bounds__(64 * NW, H2R_CHAIN_MINB) void step_kernel(ChainArgs
         return;
     }
     const u32 b = blockIdx.x - (FOLD ? n_sha : 0u);
+    if constexpr (WAVE) {
+        if (b < n_chain) {
+            const int wv = threadIdx.x >> 6;
+            for (u64 elem = (u64)b * NW + wv; elem < ca.batch; elem += (u64)n_chain * NW)
+                chain_element<(WAVE ? K : 2), 1, false, false, true>(ca, sh.chainw[wv], elem);
+            return;
+        }
+    }
     if (b < n_chain) {
         for (u64 elem = b; elem < ca.batch; elem += n_chain) {
             if (elem != b) __syncthreads();   // every wave is done with the previous element's LDS

@@ -34,7 +34,22 @@ hipError_t launch_chain_shape(u32 num_cus, const ChainArgs &ca, bool co_running,
     switch (K) {
         case 8: return launch_chain_t<8, 1, false>(ca, 4 * cap4, st, ea, eb);
         case 16: return launch_chain_t<16, 1, false>(ca, 4 * cap4, st, ea, eb);
-        case 32: return launch_chain_t<32, 4, false>(ca, cap4, st, ea, eb);
+        case 32: {
+            // one wavefront per element (h2r_chain_wave.hpp): workgroups of four independent chains
+            if (ca.batch == 0) return hipSuccess;
+            if (knobs().chain_wave != 0 && knobs().chain_nw == 0) {
+                if (ca.pre) {
+                    hipLaunchKernelGGL((recip_kernel<32, 4>), dim3(1), dim3(256), 0, st, ca.n, ca.kreal, const_cast<u32 *>(ca.pre));
+                    if (hipGetLastError() != hipSuccess) return hipErrorLaunchFailure;
+                }
+                const u64 wgs = (ca.batch + CHAIN_WAVE_WPB - 1) / CHAIN_WAVE_WPB;
+                const u64 grid = cap4 && cap4 < wgs ? cap4 : wgs;
+                if (ca.state) hipExtLaunchKernelGGL((chain_wave_kernel<32, true>), dim3((unsigned)grid), dim3(64 * CHAIN_WAVE_WPB), 0, st, ea, eb, 0, ca);
+                else hipExtLaunchKernelGGL((chain_wave_kernel<32, false>), dim3((unsigned)grid), dim3(64 * CHAIN_WAVE_WPB), 0, st, ea, eb, 0, ca);
+                return hipGetLastError();
+            }
+            return launch_chain_t<32, 4, false>(ca, cap4, st, ea, eb);
+        }
         case 64: {
             // Two chains per element side by side (chain_dual_kernel: squarings and multiplies of one exponent bit in lockstep, eight
             // waves): for latency-bound batches -- at most two elements per CU -- of variable exponents (two independent mul_mods per
