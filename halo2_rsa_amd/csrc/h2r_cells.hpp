@@ -359,7 +359,8 @@ __global__ __launch_bounds__(64 * NWV) void cells_kernel(CellsArgs a) {
         u32 x[NWD];
         x[0] = (u32)m.w[0]; x[1] = (u32)(m.w[0] >> 32); x[2] = (u32)m.w[1];
         if constexpr (NWD == 5) { x[3] = (u32)(m.w[1] >> 32); x[4] = (u32)m.w[2]; }
-        { u32 d[DA]; digits30<DA, NWD>(x, d); mont30<DA>(d, mv.bA, mv.p30, mv.n0, mv.p32, tt); }
+        if constexpr (ABL & 16384) { for (int w_ = 0; w_ < 8; ++w_) tt[w_] = x[w_ % NWD]; }   // (developer ablation: every conversion free -- wrong cells, timing only)
+        else { u32 d[DA]; digits30<DA, NWD>(x, d); mont30<DA>(d, mv.bA, mv.p30, mv.n0, mv.p32, tt); }
         if (neg) mont_neg(tt, mv.p32);
     };
     auto cell = [&](uint4 *p, const U192 &v, bool is_signed) {   // 32 bytes little-endian
@@ -387,7 +388,8 @@ __global__ __launch_bounds__(64 * NWV) void cells_kernel(CellsArgs a) {
             static_assert(D == 1 || D == DC, "a sub-limb, or a limb / carry");
             u32 d[D];
             digits30<D, K>(x, d);
-            mont30<D>(d, D == 1 ? mv.b1 : mv.bC, mv.p30, mv.n0, mv.p32, tt);
+            if constexpr (ABL & 16384) { for (int w_ = 0; w_ < 8; ++w_) tt[w_] = d[w_ % D]; }
+            else mont30<D>(d, D == 1 ? mv.b1 : mv.bC, mv.p30, mv.n0, mv.p32, tt);
             o0 = make_uint4(tt[0], tt[1], tt[2], tt[3]); o1 = make_uint4(tt[4], tt[5], tt[6], tt[7]);
         } else {
             o0 = make_uint4((u32)lo, (u32)(lo >> 32), (u32)hi, (u32)(hi >> 32)); o1 = make_uint4(0, 0, 0, 0);
@@ -620,7 +622,8 @@ __global__ __launch_bounds__(64 * NWV) void cells_kernel(CellsArgs a) {
                 dec_len = (i0 < L ? i0 : C - 1 - i0) + 2;
                 if constexpr (MONT) {   // (the general path left the integer: its cell goes where a chunk's last row leaves its accumulator cell)
                     u32 d[DA], cr[8];
-                    digits30<DA, NWD>(carry, d); mont30<DA>(d, mv.bA, mv.p30, mv.n0, mv.p32, cr);
+                    digits30<DA, NWD>(carry, d);
+                    if constexpr (ABL & 16384) { for (int w_ = 0; w_ < 8; ++w_) cr[w_] = d[w_ % DA]; } else mont30<DA>(d, mv.bA, mv.p30, mv.n0, mv.p32, cr);
                     uint4 *slot = reinterpret_cast<uint4 *>(smem + lp.opsr) + 2 * (4 * L + 1 + wv);   // (a slot per wave)
                     if (lane == 0) { slot[0] = make_uint4(cr[0], cr[1], cr[2], cr[3]); slot[1] = make_uint4(cr[4], cr[5], cr[6], cr[7]); }
                 }
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(64 * NWV) void cells_kernel(CellsArgs a) {
             // [x_j, y_{i-j}, acc_prev, acc, 0]  :408 (a column's head row: all zero)
             if constexpr (MONT) {
                 u32 acc_r[8];
-                if constexpr (ABL & 2048) { for (int w = 0; w < 8; ++w) acc_r[w] = p[w % NWD]; }   // (developer: no conversion)
+                if constexpr (ABL & (2048 | 16384)) { for (int w = 0; w < 8; ++w) acc_r[w] = p[w % NWD]; }   // (developer: no conversion)
                 else { u32 d[DA]; digits30<DA, NWD>(p, d); mont30<DA>(d, mv.bA, mv.p30, mv.n0, mv.p32, acc_r); }
                 // the limb cells are copies of the operand plane (a column's head row: of its zero entry)
                 uint4 *opsr = reinterpret_cast<uint4 *>(smem + lp.opsr);

@@ -141,9 +141,6 @@ int main(int argc, char **argv) {
         };
         stamp("as shipped", std::integral_constant<int, 0>{});
         stamp("no conversion", std::integral_constant<int, 2048>{});
-        stamp("no shuffle of the previous row", std::integral_constant<int, 4096>{});
-        stamp("no operand cells", std::integral_constant<int, 8192>{});
-        stamp("none of the three", std::integral_constant<int, 2048 | 4096 | 8192>{});
         CK(hipFree(ddbg));
     }
     line("full", RUN(0));
@@ -152,6 +149,13 @@ int main(int argc, char **argv) {
     line("build only, no is_equal_muled rows", RUN(2 | 8));
     line("build only, no mul rows", RUN(2 | 16));
     line("full", RUN(0));
+    if (mont) {   // [r6] ceilings of any faster conversion (wrong cells, timing only): the mul rows' conversions free / EVERY conversion free
+        line("mul-row conversions free", RUN(2048));
+        line("mul-row conversions free, build only", RUN(2 | 2048));
+        line("every conversion free", RUN(16384));
+        line("every conversion free, build only", RUN(2 | 16384));
+        line("full", RUN(0));
+    }
     if (argc > 8) {   // the SAME image buffer under several LDS requests (= waves per CU): 6, 5, 4, 3 per CU and the shipped one again
         for (u32 req : {26880u, 32000u, 40448u, 53760u, lds}) {
             if (req < base) continue;
