@@ -925,7 +925,9 @@ def sub_run_lines(args):
                     "audit": d.get("config", {}).get("post_run_audit"), "wall_s": d.get("_wall_s"), "error": d.get("error")}
     oc = {}
     for key, extra in (("C4", ["--workload", "rsa4096_w32_e65537", "--batch", "4096", "--steps", "8", "--warmup", "2"]),
-                       ("C5", ["--workload", "rsa2048_e2048bit", "--batch", "256", "--steps", "8", "--warmup", "2"])):
+                       ("C5", ["--workload", "rsa2048_e2048bit", "--batch", "256", "--steps", "8", "--warmup", "2"]),
+                       # [r6] RSA-1024: the key size of the reference's only enabled bench (benches/bench.rs:393-407); one-wave chains (h2r_chain_wave.hpp)
+                       ("rsa1024_2048_per_call", ["--workload", "rsa1024_e65537", "--batch", "2048", "--steps", "20", "--warmup", "5"])):
         d = sub_run(extra)
         oc[key] = {"workload": " ".join(extra), "value": d.get("value"), "unit": d.get("unit"), "ms_per_step": d.get("ms_per_step"),
                    "frac": d.get("roofline", {}).get("frac"), "whole_path_hbm_frac": d.get("whole_path_hbm_frac"), "wall_s": d.get("_wall_s"), "error": d.get("error")}
@@ -980,7 +982,7 @@ def main():
     ap.add_argument("--records-free-flow", action="store_true",
                     help="the whole records-free flow per batch of one-signature circuits: verify element image + multiplicities from the image + A', S'")
     ap.add_argument("--sub-runs", choices=["auto", "off"], default="auto",
-                    help="auto: the default N = 1 line also carries plain_allocations, advice, advice_columns_montgomery, other_configs (C4, C5) and lookup, "
+                    help="auto: the default N = 1 line also carries plain_allocations, advice, advice_columns_montgomery, other_configs (C4, C5, RSA-1024) and lookup, "
                          "each measured in a fresh process of this script")
     ap.add_argument("--columns", action="store_true", help="--advice: planar column vectors instead of 160-byte rows (H2R_ADVICE_COLUMNS)")
     ap.add_argument("--montgomery", action="store_true", help="--advice: cells in Montgomery form, x * 2^256 mod p (H2R_ADVICE_MONTGOMERY)")
