@@ -110,11 +110,14 @@ def build_lib(force=False, verbose=False, out=None, defines=()):
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)
-    # keep the object cache bounded: drop objects no longer named by the current tree (variants keep theirs while they are current)
-    if out == LIB:
-        for old in glob.glob(os.path.join(OBJ, "*.o")):
-            if old not in objs and time.time() - os.path.getmtime(old) > 7 * 86400:
-                os.remove(old)
+    # keep the object cache bounded: per unit the objects of this build and the six most recent others (developer variants, the previous tree)
+    by_unit = {}
+    for old in glob.glob(os.path.join(OBJ, "*.o")):
+        if old not in objs:
+            by_unit.setdefault(os.path.basename(old).split(".")[0], []).append(old)
+    for olds in by_unit.values():
+        for old in sorted(olds, key=os.path.getmtime, reverse=True)[6:]:
+            os.remove(old)
     assert lib_id(out) == sid, "the linked library does not carry the build ID"
     build_lib.last = "built in %.0f s (%s; %d unit(s) from the object cache), build id %s" % (
         time.time() - t0, ", ".join("%s %.0f s" % (u, t) for u, t in sorted(times.items())), len(UNITS) - len(jobs), sid[:16])

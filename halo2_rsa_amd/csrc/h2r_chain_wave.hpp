@@ -129,6 +129,60 @@ __device__ H2R_WAVE_MULMOD_INLINE int wave_mulmod(u32 shift, int lane, u32 a, u3
     return status;
 }
 
+// mu' = floor((B^(2K) - 1) / n') - B^K for the normalised modulus n' (lanes 0..K-1), by NEWTON'S ITERATION on the wave's own products instead of
+// Knuth's digit-by-digit division (wave_reciprocal: K steps of ~0.45 us each, every one a chain of VALU -> ballot -> SALU -> VALU round trips that a
+// lone wave cannot hide: 16 of the 56 us of an RSA-1024 e = 65537 chain).  y = B^K + m approximates R = floor(T / n'), T = B^(2K) - 1, FROM BELOW:
+//     e = T - n' y  (= the bitwise complement of n' y: T is all ones),   y <- y + floor(y e / B^(2K))   (the m e_lo / B^K term dropped: still from below)
+// never overshoots (y n' <= B^(2K)) and squares the relative error: from the 31 good bits of the top digit's reciprocal, 4 / 5 / 6 steps of two
+// products each reach K = 8 / 16 / 32 digits to within one unit (checked against big integers over adversarial and random moduli); the exact
+// floor then follows from one more residual: while e >= n': y += 1, e -= n'.
+template <int K>
+__device__ __forceinline__ u32 wave_reciprocal_newton(u32 nn, int lane) {
+    constexpr int ITERS = K <= 8 ? 4 : (K <= 16 ? 5 : 6);
+    const bool lo = lane < K, hi = lane >= K && lane < 2 * K;
+    const u32 ntop = (u32)__builtin_amdgcn_readlane((int)nn, K - 1);
+    const u64 c = ntop == 0xffffffffu ? 0xffffffffull : 0xffffffffffffffffull / ((u64)ntop + 1);   // < 2^33 (n' normalised: ntop >= 2^31)
+    u32 m = (lane == K - 1 && c > 0xffffffffull) ? (u32)(c - 0x100000000ull) : 0u;              // y0 = max(B^K, c B^(K-1)) <= R
+    const u32 nsh_ = (u32)__shfl((int)nn, (lane - K) & 63), nsh = hi ? nsh_ : 0u;                 // n' B^K
+    auto residual = [&](u32 mm) -> u32 {   // T - n' (B^K + mm), digit c in lane c (n' y <= T: the sum below has no carry out of digit 2K - 1)
+        const u32 p = wave_product<K, 0>(nn, mm, lane);
+        const u64 d = (u64)p + nsh;
+        const CarryGroup cg = carry_group(__ballot((d >> 32) != 0), __ballot((u32)d == 0xffffffffu), false, 64);
+        return lane < 2 * K ? ~((u32)d + (u32)((cg.cin_mask >> lane) & 1)) : 0u;
+    };
+#pragma unroll 1
+    for (int it = 0; it < ITERS; ++it) {
+        const u32 e = residual(m);
+        const u32 q = wave_product<K, K>(e, m, lane);                       // e_hi * m
+        const u64 d0 = lo ? (u64)q + e : 0;                                  // the carry of (q_lo + e_lo) into digit K
+        const CarryGroup c0 = carry_group(__ballot((d0 >> 32) != 0), __ballot(lo && (u32)d0 == 0xffffffffu), false, K);
+        const u64 d1 = hi ? (u64)q + e : 0;                                  // inc = e_hi + q_hi + that carry (lanes K..2K-1)
+        const CarryGroup c1 = carry_group(__ballot((d1 >> 32) != 0) >> K, __ballot(hi && (u32)d1 == 0xffffffffu) >> K, c0.cout, K);
+        const u32 inc = hi ? (u32)d1 + (u32)((c1.cin_mask >> (lane - K)) & 1) : 0u;
+        const u32 incl = (u32)__shfl((int)inc, (lane + K) & 63);
+        const u64 d2 = lo ? (u64)m + incl : 0;                               // m += inc  (y + inc <= R < 2 B^K: no carry out)
+        const CarryGroup c2 = carry_group(__ballot((d2 >> 32) != 0), __ballot(lo && (u32)d2 == 0xffffffffu), false, K);
+        m = lo ? (u32)d2 + (u32)((c2.cin_mask >> lane) & 1) : 0u;
+    }
+    u32 e = residual(m);
+#pragma unroll 1
+    for (int it = 0; it < 8; ++it) {                                         // the exact floor: at most one or two steps
+        bool ge = __ballot(hi && e != 0) != 0;
+        if (!ge) {
+            ge = true;
+            const u64 ne = __ballot(lo && e != nn);
+            if (ne) ge = ((__ballot(lo && e > nn) >> (63 - __builtin_clzll(ne))) & 1) != 0;
+        }
+        if (!ge) break;
+        const u32 sub = lo ? nn : 0u;
+        const CarryGroup cs = carry_group(__ballot(lane < 2 * K && e < sub), __ballot(lane < 2 * K && e == sub), false, 64);
+        e = lane < 2 * K ? e - sub - (u32)((cs.cin_mask >> lane) & 1) : 0u;
+        const CarryGroup ci = carry_group(0, __ballot(lo && m == 0xffffffffu), true, K);
+        if (lo) m += (u32)((ci.cin_mask >> lane) & 1);
+    }
+    return m;
+}
+
 // The per-modulus constants, wave-local: returns H2R_E_ZERO_MODULUS for n = 0 (reference divides by zero, chip.rs:566).
 template <int K>
 __device__ __forceinline__ int wave_modulus_setup(ChainLds<K, 1> &s, u32 nraw, int lane, u32 &shift, u32 &nn, u32 &mu) {
@@ -139,9 +193,24 @@ __device__ __forceinline__ int wave_modulus_setup(ChainLds<K, 1> &s, u32 nraw, i
     const u32 topv = (u32)__builtin_amdgcn_readlane((int)nraw, top_digit);
     shift = 32u * (u32)(K - 1 - top_digit) + (u32)__builtin_clz(topv);
     if (shift) (void)wave_shl2k<K>(nn, shift, lane);   // (n < B^K: nothing leaves, the lanes above K-1 stay zero)
+#ifndef H2R_WAVE_NEWTON   // shipped: the digit-by-digit reciprocal the four-wave form uses (wave-local, on registers)
     u32 nn1[1] = {nn}, mu1[1] = {0};
-    wave_reciprocal<K, 1>(s, nn1, lane, 0, mu1);   // wave-local Knuth D on registers
+    wave_reciprocal<K, 1>(s, nn1, lane, 0, mu1);
     mu = lane < K ? mu1[0] : 0u;
+#else
+    // (developer variant -DH2R_WAVE_NEWTON: exact -- digit for digit Knuth's on 157 parity tests and 15,000 adversarial moduli with -DH2R_WAVE_RECIP_CHECK --
+    //  and 4.4 us shorter per element alone (15.2 -> 10.8 us), but the step launch does not wait for it: 14.1 M either way at 1,024 per call, 15.6 against
+    //  15.8 M at 2,048, where its twelve extra products cost issue slots: profiles/r06_chain_wave.txt)
+    (void)s;
+    mu = wave_reciprocal_newton<K>(nn, lane);
+#ifdef H2R_WAVE_RECIP_CHECK
+    {
+        u32 nn1[1] = {nn}, mu1[1] = {0};
+        wave_reciprocal<K, 1>(s, nn1, lane, 0, mu1);
+        if (__ballot(lane < K && mu1[0] != mu) != 0) return H2R_E_INTERNAL;
+    }
+#endif
+#endif
     return H2R_OK;
 }
 

@@ -769,7 +769,10 @@ __device__ __forceinline__ void chain_element(const ChainArgs &args, ChainLds<K,
             __syncthreads();
         }
     } else {
-        if constexpr (WAVE) (void)wave_modulus_setup<K>(s, nraw[0], lane, shift, nn[0], mu_w);
+        if constexpr (WAVE) {
+            const int rs = wave_modulus_setup<K>(s, nraw[0], lane, shift, nn[0], mu_w);   // (n != 0 was established above: only the developer check can fail)
+            if (rs != H2R_OK) { if (tid == 0) args.status[elem] = (u8)rs; return; }
+        }
         else (void)chain_modulus_setup<K, NW>(s, nraw, lane, wave, shift, nn);   // n != 0 was established above
     }
     u32 q[V], r[V];
