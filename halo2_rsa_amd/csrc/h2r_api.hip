@@ -2437,7 +2437,15 @@ int32_t h2r_lookup_permuted_columns(const h2r_ctx *ctx, const h2r_lookup_config 
     LookupFillArgs fa;
     std::memset(&fa, 0, sizeof fa);
     fa.ws = ws; fa.num_elems = num_elems; fa.usable_rows = usable_rows; fa.n_rows = cfg->n_rows; fa.arg_mask = arg_mask & 31u;
-    fa.rows_per_block = 8192; fa.status = status;
+    // [r6] 256 rows (8 KB of A' and of S') per workgroup, was 8,192: what the workgroups in flight write is then a dense window of each column
+    // instead of a comb of 8 KB pieces 256 KB apart, which is what two buffers of one placement class punish most (same buffers, whole call:
+    // 1.63 -> 1.56 ms on a pair of different classes, 2.03-2.16 -> 1.76-1.90 ms on a pair of one class; the 15 KB slot every workgroup loads
+    // comes from the L2: tools/lookup_geometry_probe.py, profiles/r06_lookup_geometry.txt)
+    fa.rows_per_block = 256; fa.round_robin = 0; fa.status = status;
+#ifdef H2R_DEV_KNOBS   // developer build: bits 8-15 of arg_mask = rows per workgroup / 256, bit 16 = round-robin blocks (tools/lookup_geometry_probe.py)
+    if ((arg_mask >> 8) & 0xffu) fa.rows_per_block = 256u * ((arg_mask >> 8) & 0xffu);
+    fa.round_robin = (arg_mask >> 16) & 1u;
+#endif
     fa.a_perm = static_cast<u8 *>(a_perm_out); fa.s_perm = static_cast<u8 *>(s_perm_out); fa.out_elem_stride = out_elem_stride;
     const unsigned chunks = (usable_rows + fa.rows_per_block - 1) / fa.rows_per_block;
     const unsigned lds = (unsigned)lookup_slot_bytes(cfg->n_rows);

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void lookup_setup_kernel(LookupSetupArgs a) {
 }
 
 struct LookupFillArgs {
-    const u8 *ws; u64 num_elems; u32 usable_rows, n_rows, arg_mask, rows_per_block;
+    const u8 *ws; u64 num_elems; u32 usable_rows, n_rows, arg_mask, rows_per_block, round_robin;
     const u8 *status;
     u8 *a_perm, *s_perm; u64 out_elem_stride;   // element e, argument k at + e * out_elem_stride + k * usable_rows * 32
 };
@@ -299,10 +299,17 @@ __global__ __launch_bounds__(256) void lookup_fill_kernel(LookupFillArgs a) {
     const u32 usable = a.usable_rows, n_rep = usable - n_heads;   // repeated rows = leftover table entries
     u8 *ap = a.a_perm + elem * a.out_elem_stride + (u64)arg * usable * 32;
     u8 *sp = a.s_perm + elem * a.out_elem_stride + (u64)arg * usable * 32;
-    const u32 p0 = chunk * a.rows_per_block, p1 = p0 + a.rows_per_block < usable ? p0 + a.rows_per_block : usable;
+    // [r6] The workgroups of one column take its 256-row blocks ROUND-ROBIN (block b of the column goes to workgroup b mod gridDim.x), not one
+    // contiguous run of rows_per_block rows each: what the column's workgroups have in flight together is then ONE dense window of
+    // gridDim.x x 8 KB instead of a comb of 8 KB pieces 256 KB apart -- the comb is what the placement classes punish (a power-of-two stride
+    // between concurrent store streams: tools/store_pattern_probe.hip, profiles/r06_placement_counters.txt section 6).
+    const bool rr = a.round_robin != 0;
+    const u32 p0 = rr ? chunk * 256 : chunk * a.rows_per_block;
+    const u32 p1 = rr ? usable : (p0 + a.rows_per_block < usable ? p0 + a.rows_per_block : usable);
+    const u32 base_step = rr ? 256 * gridDim.x : 256;
     // a wave works on 64 consecutive rows: every lane computes one row, then the lanes exchange halves so that each of the
     // four store instructions writes 64 consecutive 16-byte units (rows base .. base+31, then base+32 .. base+63)
-    for (u32 base = p0 + (tid & ~63u); base < p1; base += 256) {
+    for (u32 base = p0 + (tid & ~63u); base < p1; base += base_step) {
         const u32 pos = base + lane;
         Fe av = fe_zero(), sv = fe_zero();
         if (pos < p1) {
