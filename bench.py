@@ -1151,7 +1151,7 @@ def main():
     if pipe is not None:   # what the library chose for calls of this size on this stream (it measures whether its streams sit on three hardware queues)
         pi = pipe.info(chunk)
         pipeline_form = {"record_form": ["one-launch step", "two-queue", "side stream"][pi.record_form], "three_queues": {0: False, 1: True}.get(pi.three_queues),
-                         "probe_ms": round(pi.probe_ms, 3), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
+                         "probe_ms": round(pi.probe_ms, 3), "probe_span_ms": round(pi.probe_span_ms, 4), "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")}
     # producer p issues calls p, p + P, p + 2P, ... on its own stream; buffer set k % (depth * P) belongs to producer k % P
     prod_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(producers - 1)]
     counter = [0]

@@ -34,7 +34,7 @@ H2R_VERSION = 4
 
 class H2RPipelineInfo(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32), ("depth", ctypes.c_uint32), ("side_streams", ctypes.c_uint32), ("record_form", ctypes.c_uint32),
-                ("three_queues", ctypes.c_uint32), ("probe_ms", ctypes.c_float)]
+                ("three_queues", ctypes.c_uint32), ("probe_ms", ctypes.c_float), ("probe_span_ms", ctypes.c_float)]
 
 
 H2R_PIPE_ONE_LAUNCH_STEP, H2R_PIPE_TWO_QUEUE, H2R_PIPE_SIDE_STREAM = 0, 1, 2

@@ -872,7 +872,7 @@ struct h2r_pipeline {
     // BEHIND the one-launch step it replaces (4.8 against 5.5 M assigns/s under torchrun with RCCL's streams in the process).  The library
     // cannot read the assignment, so it measures it once per caller stream: three 150 us one-wave spinners (pipeline_three_queues).
     std::map<hipStream_t, int> queue_probe;   // 1: three queues, 0: some pair shares one
-    float probe_ms = 0.f;                     // wall time of the last probe
+    float probe_ms = 0.f, probe_span_ms = 0.f; // the last probe: host wall time, device-clock span
 };
 
 // ---- multi-GPU: RCCL behind the C ABI --------------------------------------------------------------------------------------
@@ -1353,7 +1353,7 @@ bool pipeline_three_queues(h2r_pipeline *p, hipStream_t st, bool force = false) 
     hipStream_t ss[3] = {st, p->aux[0], p->aux[1]};
     for (hipStream_t s : ss) if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return false; }
     const unsigned long long spin_ticks = 15000;                  // 150 us
-    float best = 1e9f;
+    float best = 1e9f, span = 1e9f;                               // host wall time / device-clock span (first start to last end), best round of each
     bool overlapped = false;
     unsigned long long *stamps = nullptr;                         // [3][2]: every spinner's start and end on the DEVICE's wall clock
     if (hipHostMalloc(reinterpret_cast<void **>(&stamps), 6 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); stamps = nullptr; }
@@ -1364,21 +1364,30 @@ bool pipeline_three_queues(h2r_pipeline *p, hipStream_t st, bool force = false) 
         for (hipStream_t s : ss) ok = (hipStreamSynchronize(s) == hipSuccess) && ok;
         if (!ok) { (void)hipGetLastError(); if (stamps) (void)hipHostFree(stamps); return false; }
         const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (rep && ms < best) {
-            best = ms;
-            // the device's own account of the round: all three ran at one instant iff the latest start precedes the earliest end
-            if (stamps) overlapped = std::max({stamps[0], stamps[2], stamps[4]}) < std::min({stamps[1], stamps[3], stamps[5]});
+        if (!rep) continue;
+        best = std::min(best, ms);
+        if (stamps) {   // the device's own account of the round: all three ran at one instant iff the latest start precedes the earliest end
+            const bool ov = std::max({stamps[0], stamps[2], stamps[4]}) < std::min({stamps[1], stamps[3], stamps[5]});
+            const float sp = (float)(std::max({stamps[1], stamps[3], stamps[5]}) - std::min({stamps[0], stamps[2], stamps[4]})) * 1e-5f;   // 100 MHz ticks
+            if (ov && sp < span) { span = sp; overlapped = true; }
+            else if (!overlapped) span = std::min(span, sp);
         }
     }
-    if (stamps) (void)hipHostFree(stamps); else overlapped = true;   // (no stamp buffer: the host clock decides alone, as before)
-    p->probe_ms = best;
+    if (stamps) (void)hipHostFree(stamps);
+    p->probe_ms = best; p->probe_span_ms = stamps ? span : 0.f;
     // Measured (profiles/r05_queue_probe.txt, 16 runs: plain / torchrun + RCCL, 4 / 8 hardware queues, low / normal side-stream priority):
-    // 0.179-0.181 ms whenever the two-queue form then ran at 5.5-5.6 M assigns/s, 0.199-0.203 ms whenever it ran at 4.2-5.0 M -- two of the
-    // streams share a queue and their packets overlap only partly.  A false "shared" costs 2 % (the step runs at 5.5 M), a false "three
-    // queues" 10-25 %: the threshold sits close to the clean value.
-    // [r6] ... and, whatever the host clock says (launch latency is part of it), the spinners' own device-clock stamps must show the three
-    // running at one instant.
-    const int three = (best <= 0.186f && overlapped) ? 1 : 0;
+    // host wall time 0.179-0.181 ms whenever the two-queue form then ran at 5.5-5.6 M assigns/s, 0.199-0.203 ms whenever it ran at 4.2-5.0 M --
+    // two of the streams share a queue and their packets overlap only partly.  A false "shared" costs 2 % (the step runs at 5.5 M), a false
+    // "three queues" 10-25 %.
+    // [r6] The host clock carries launch latency and its jitter (clean rounds of 0.178-0.186 ms in this round's runs: one at 0.185 sat on the
+    // old 0.186 threshold).  The spinners' own device-clock stamps do not: first start to last end is 0.1539-0.1545 ms on three queues and
+    // 0.1595-0.1597 ms when two streams share one (profiles/r06_queue_probe.txt, 32 runs on two boxes, the same eight conditions), a gap of
+    // twenty times the spread.  The verdict is the device's: all three running at one instant AND span <= 0.157 ms; the host time only has
+    // to be sane (<= 0.195 ms).  Without a stamp buffer the host clock decides alone, at the old threshold.
+#ifdef H2R_DEV_KNOBS
+    if (std::getenv("H2R_PROBE_DEBUG")) std::fprintf(stderr, "h2r queue probe: host %.4f ms, device span %.4f ms, overlapped %d\n", best, span, (int)overlapped);
+#endif
+    const int three = stamps ? ((overlapped && span <= 0.157f && best <= 0.195f) ? 1 : 0) : (best <= 0.186f ? 1 : 0);
     p->queue_probe[st] = three;
     return three != 0;
 }
@@ -1386,13 +1395,15 @@ bool pipeline_three_queues(h2r_pipeline *p, hipStream_t st, bool force = false) 
 
 int32_t h2r_pipeline_info(h2r_pipeline *p, h2r_stream_t stream, uint64_t batch, h2r_pipeline_info_t *out) try {
     if (!p || !out) return H2R_E_NULL;
-    if (out->struct_size != sizeof(h2r_pipeline_info_t)) return H2R_E_UNSUPPORTED;
+    const bool v1 = out->struct_size == offsetof(h2r_pipeline_info_t, probe_span_ms);   // (callers built before probe_span_ms existed)
+    if (!v1 && out->struct_size != sizeof(h2r_pipeline_info_t)) return H2R_E_UNSUPPORTED;
     const h2r_ctx *ctx = p->ctx;
     H2R_ON_DEVICE(ctx->params.device);
     out->depth = p->depth; out->side_streams = p->aux[0] != p->aux[1] ? 2u : 1u;
     const bool shape = ctx->layout.limb_width == 64 && ctx->L == 32 && batch && batch <= 2048 && p->aux[0] != p->aux[1] && p->depth >= 3;
     out->three_queues = shape ? (pipeline_three_queues(p, static_cast<hipStream_t>(stream), true) ? 1u : 0u) : 2u;   // 2: not asked (the shape has no two-queue form)
     out->probe_ms = p->probe_ms;
+    if (!v1) out->probe_span_ms = p->probe_span_ms;
     out->record_form = (shape && out->three_queues == 1) ? H2R_PIPE_TWO_QUEUE : (step_eligible(ctx, batch, reinterpret_cast<void *>(1), 19) ? H2R_PIPE_ONE_LAUNCH_STEP : H2R_PIPE_SIDE_STREAM);
     return H2R_OK;
 } H2R_CATCH_STATUS

@@ -347,15 +347,18 @@ int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream);
  * to a process that has many streams.  The verdict is cached per (pipeline, stream handle); h2r_pipeline_info MEASURES AGAIN every time
  * it is called (it synchronises the three streams: not for a hot path) and refreshes the cache -- call it after creating or destroying
  * streams (HIP may re-assign queues; a destroyed stream's handle can come back for a new stream).  The first pipelined call on a new caller
- * stream therefore synchronises that stream once (~0.5 ms).  Three queues = the host-side round took <= 0.186 ms AND the spinners' own
- * device-clock stamps show all three running at one instant. */
+ * stream therefore synchronises that stream once (~0.5 ms).  Three queues = the spinners' own device-clock stamps show all three running
+ * at one instant AND first start to last end is <= 0.157 ms (0.154 measured on three queues, 0.160 when two streams share one; the host-side
+ * wall time, which carries launch jitter, only has to be <= 0.195 ms). */
 enum { H2R_PIPE_ONE_LAUNCH_STEP = 0, H2R_PIPE_TWO_QUEUE = 1, H2R_PIPE_SIDE_STREAM = 2 };
 typedef struct h2r_pipeline_info_t {
     uint32_t struct_size;   /* in: sizeof(h2r_pipeline_info_t) */
     uint32_t depth, side_streams;
     uint32_t record_form;   /* H2R_PIPE_* */
     uint32_t three_queues;  /* 1: the three streams overlap; 0: two of them share a hardware queue; 2: not measured (the shape / size has no two-queue form) */
-    float probe_ms;         /* wall time of the three 150 us spinners, best of three rounds (<= 0.186: three queues; 0.199-0.203 measured when two streams shared one; 0.3-0.45 with one queue) */
+    float probe_ms;         /* host wall time of the three 150 us spinners, best of three rounds (0.178-0.186 on three queues; 0.199-0.203 when two streams shared one; 0.3-0.45 with one queue) */
+    float probe_span_ms;    /* the same round on the device's clock, first start to last end (what decides).  A caller compiled against the struct without this field
+                               (struct_size 24) is still served */
 } h2r_pipeline_info_t;
 int32_t h2r_pipeline_info(h2r_pipeline *p, h2r_stream_t stream, uint64_t batch, h2r_pipeline_info_t *out);
 
