@@ -1,3 +1,5 @@
+# Recipe of profiles/r06_queue_probe.txt.  Needs the developer variant: python -m halo2_rsa_amd._build devknobs -DH2R_DEV_KNOBS (on the build host), then
+# gpurun -- "bash tools/queue_probe_conditions.sh > gpurun_out/probe.log 2>&1"
 cd $GRAFT_REPO_ROOT
 export H2R_LIB=$PWD/halo2_rsa_amd/lib/variants/devknobs.so H2R_PROBE_DEBUG=1
 ARGS="--gpus 1 --batch 2048 --chunks 4 --steps 20 --warmup 5 --no-cpu-baseline --pmc-traffic off --sub-runs off --scale-anchor off"
