@@ -959,9 +959,9 @@ def main():
     ap.add_argument("--workload", default="rsa2048_e65537", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline-depth", type=int, default=0, help="buffer sets the pipelined calls rotate through (2..4; default: 3 for the "
-                                                                    "RSA-2048 shape, 2 otherwise)")
+                                                                    "RSA-2048 and RSA-1024 shapes, 2 otherwise)")
     ap.add_argument("--side-streams", type=int, default=0,
-                    help="streams the record kernels alternate between (default: 2 for the RSA-2048 shape, whose pipelined calls then go out as "
+                    help="streams the record kernels alternate between (default: 2 for the RSA-2048 and RSA-1024 shapes, whose pipelined calls (RSA-1024: of 1,536 .. 4,096) then go out as "
                          "chain kernels on the caller's stream and record kernels alternating between two side streams -- call k + 1's record "
                          "kernel starts while call k's tail drains; 1 otherwise: one launch per call, or one side stream)")
     ap.add_argument("--producers", type=int, default=1,
@@ -1036,9 +1036,9 @@ def main():
     # RSA-2048 (32 x 64-bit limbs): three buffer sets and two record streams select the library's overlapped two-queue form (h2r.h,
     # h2r_pipeline_create_ex; same-box A/B against the one-launch step: tools/two_queue_ab.sh, profiles/r04_two_queue.txt)
     if args.pipeline_depth == 0:
-        args.pipeline_depth = 3 if (w, bits) == (64, 2048) else 2
+        args.pipeline_depth = 3 if (w, bits) in ((64, 2048), (64, 1024)) else 2
     if args.side_streams == 0:
-        args.side_streams = 2 if (w, bits) == (64, 2048) else 1
+        args.side_streams = 2 if (w, bits) in ((64, 2048), (64, 1024)) else 1
     # developer: H2R_BENCH_ONE_GPU=1 runs every rank on GPU 0 over gloo -- the N > 1 code path (shards, gather, checks) on a
     # one-GPU box; not a measurement of anything
     one_gpu = bool(os.environ.get("H2R_BENCH_ONE_GPU"))

@@ -1300,6 +1300,19 @@ const StepShape *step_shape(const h2r_ctx *c) { return step_shape_of(c->layout.l
 bool step_eligible(const h2r_ctx *c, u64 batch, const void *trace, u32 T) {
     return knobs().pipe_step != 0 && knobs().chain_nw == 0 && step_shape(c) && batch > 512 && trace && T;
 }
+// The shapes and call sizes with a two-queue form (chain kernels on the caller's stream, record kernels alternating between two side streams):
+// RSA-2048 up to 2,048 per call (profiles/r04_two_queue.txt), and [r6] RSA-1024 from 1,536 per call now that its chain is the one-wave kernel
+// (profiles/r06_two_queue_rsa1024.txt: 16.2-16.7 M assigns/s against the step's 14.5-15.9 M at 1,536-2,048 per call, 15.1-15.9 against 13.7-14.5 M at
+// 8,192; at 1,024 per call the step stays ahead).
+bool two_queue_shape(const h2r_ctx *c, u64 batch) {
+    if (c->layout.limb_width != 64) return false;
+    if (c->L == 32) return batch <= 2048;
+    if (c->L == 16 && c->K == 32 && knobs().chain_wave != 0 && knobs().chain_nw == 0) {
+        if (knobs().pipe_twoq_l16 > 0) return (long)batch <= knobs().pipe_twoq_l16;     // (developer build: the upper bound swept)
+        return knobs().pipe_twoq_l16 == 0 && batch >= 1536;                             // (H2R_PIPE_TWOQ_L16=-1: never)
+    }
+    return false;
+}
 constexpr u64 kStepMax = 4096;   // elements per step launch: a larger call is walked as equal parts of at most this size
 // One step: the records described by `ta` (an earlier sub-batch) and the chains described by `ca`, one launch on `st` (h2r_tu_step.hip).
 hipError_t launch_step(const h2r_ctx *c, const ChainArgs &ca, const TraceArgs &ta, const AuxArgs *aa, const AuxArgs *va, const Sha256Args *sha, hipStream_t st, hipEvent_t ea, hipEvent_t eb) {
@@ -1400,7 +1413,7 @@ int32_t h2r_pipeline_info(h2r_pipeline *p, h2r_stream_t stream, uint64_t batch, 
     const h2r_ctx *ctx = p->ctx;
     H2R_ON_DEVICE(ctx->params.device);
     out->depth = p->depth; out->side_streams = p->aux[0] != p->aux[1] ? 2u : 1u;
-    const bool shape = ctx->layout.limb_width == 64 && ctx->L == 32 && batch && batch <= 2048 && p->aux[0] != p->aux[1] && p->depth >= 3;
+    const bool shape = batch && two_queue_shape(ctx, batch) && p->aux[0] != p->aux[1] && p->depth >= 3;
     out->three_queues = shape ? (pipeline_three_queues(p, static_cast<hipStream_t>(stream), true) ? 1u : 0u) : 2u;   // 2: not asked (the shape has no two-queue form)
     out->probe_ms = p->probe_ms;
     if (!v1) out->probe_span_ms = p->probe_span_ms;
@@ -1678,12 +1691,13 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
     // RSA-2048 on a pipeline created with TWO side streams and three or more buffer sets: the two-queue form -- chain kernels on the caller's
     // stream, record kernels alternating between the side streams, so that call k + 1's record kernel starts while call k's tail drains --
     // beats the one-launch step (same box, alternating: 5.41 / 5.41 M assigns/s against 5.18 / 5.32 M at 1,024 per call, 5.55-5.58 against
-    // 5.50-5.51 M at 2,048).  Every other step shape is chain-bound enough to lose that way (RSA-1024 9.4 against 12.4 M, RSA-3072 2.1
-    // against 2.5 M, RSA-4096 1.2 against 1.5 M; 128 x 32-bit limbs: the same): tools/two_queue_ab.sh, profiles/r04_two_queue.txt.
+    // 5.50-5.51 M at 2,048).  The other step shapes were chain-bound enough to lose that way in round 4 (RSA-1024 with its four-wave chain 9.4
+    // against 12.4 M, RSA-3072 2.1 against 2.5 M, RSA-4096 1.2 against 1.5 M; 128 x 32-bit limbs: the same): tools/two_queue_ab.sh,
+    // profiles/r04_two_queue.txt.  [r6] RSA-1024 with the one-wave chain wins from 1,536 to 4,096 per call (two_queue_shape).
     // (calls of up to 2,048: at 4,096 per call one launch has little boundary left to hide and the step is ahead again, 5.37-5.42 against 5.27-5.33 M)
     // ... provided the three streams sit on three hardware queues, which the pipeline measures once per caller stream (pipeline_three_queues);
     // with a shared queue the call falls back to the one-launch step
-    const bool overlap_records = ctx->layout.limb_width == 64 && ctx->L == 32 && batch <= 2048 && p->aux[0] != p->aux[1] && p->depth >= 3 && knobs().pipe_step < 1 &&
+    const bool overlap_records = two_queue_shape(ctx, batch) && p->aux[0] != p->aux[1] && p->depth >= 3 && knobs().pipe_step < 1 &&
                                  pipeline_three_queues(p, st);
     const bool as_steps = step_eligible(ctx, batch, trace, T) && n_seg_single <= 1 && !overlap_records;
     if (p->pending && (!as_steps || p->pending_st != st)) {   // the records still owed go out alone, `st` behind them
@@ -1704,6 +1718,12 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
         sizes.swap(capped);
     } else {
         pipeline_plan(p, batch, assume_empty, sizes, pace);
+        if (overlap_records && ctx->L == 16 && batch > 4096 && knobs().pipe_sub_batch <= 0) {
+            // RSA-1024 in the two-queue form: a call above 4,096 as uniform sub-batches of 2,048, unpaced (8,192 per call 15.1 -> 15.6-15.9 M assigns/s,
+            // 16,384 13.9-14.1 -> 14.4-14.5 M; paced or as sub-batches of 4,096 it loses: profiles/r06_two_queue_rsa1024.txt)
+            sizes.clear(); pace = false;
+            for (u64 o2 = 0; o2 < batch; o2 += 2048) sizes.push_back(std::min<u64>(2048, batch - o2));
+        }
     }
     const bool split = sizes.size() > 1;
     const h2r_layout &lo = ctx->layout;

@@ -36,6 +36,7 @@ struct Knobs {
     long pipe_sub_batch = 0;                     // H2R_PIPE_SUB_BATCH: elements per chain + record kernel pair inside a pipelined call (multiple of 256)
     long pipe_pace = -1;                         // H2R_PIPE_PACE=0|1: sub-batch i+1's chain kernel waits for sub-batch i-1's record kernel
     long pipe_step = -1;                         // H2R_PIPE_STEP=0: never issue a pipeline step as one launch (the two-queue form for every shape)
+    long pipe_twoq_l16 = 0;                      // H2R_PIPE_TWOQ_L16=n: RSA-1024 takes the two-queue form for every call of up to n (-1: never; 0 = the measured rule)
     long pipe_form = -1;                         // H2R_PIPE_FORM=0|1: skip the queue probe; 1 = the two-queue form, 0 = the one-launch step
     long step_chain_x2_per_cu = 0;               // H2R_STEP_CHAIN_X2_PER_CU=n: n/2 chain workgroups per CU in a step launch (0 = the measured default)
     unsigned long pipe_cu_mask = 0;              // H2R_PIPE_CU_MASK=<hex word>: the record stream is created with this 32-bit CU mask repeated over the device (experiment)
@@ -57,7 +58,7 @@ struct Knobs {
         { const char *g = std::getenv("H2R_PIPE_SERIALIZE"); pipe_serialize = g && g[0] == '1'; }
         { const char *m = std::getenv("H2R_PIPE_CU_MASK"); pipe_cu_mask = m ? std::strtoul(m, nullptr, 16) : 0; pipe_cu_mask_words = num("H2R_PIPE_CU_MASK_WORDS", 0); }
         verify_fold = num("H2R_VERIFY_FOLD", -1); exp_segments = num("H2R_EXP_SEGMENTS", -1); single_call_segments = num("H2R_SINGLE_CALL_SEGMENTS", -1);
-        pipe_step = num("H2R_PIPE_STEP", -1); pipe_form = num("H2R_PIPE_FORM", -1); step_chain_x2_per_cu = num("H2R_STEP_CHAIN_X2_PER_CU", 0);
+        pipe_step = num("H2R_PIPE_STEP", -1); pipe_form = num("H2R_PIPE_FORM", -1); pipe_twoq_l16 = num("H2R_PIPE_TWOQ_L16", 0); step_chain_x2_per_cu = num("H2R_STEP_CHAIN_X2_PER_CU", 0);
         rowprog_stage_rows = num("H2R_ROWPROG_STAGE_ROWS", 0); cells_nwv = num("H2R_CELLS_NWV", 0);
         pipe_sub_batch = num("H2R_PIPE_SUB_BATCH", 0); arena_chunk_mb = num("H2R_ARENA_CHUNK_MB", 0); plain_overlap = num("H2R_PLAIN_OVERLAP", -1); pipe_pace = num("H2R_PIPE_PACE", -1);
 #endif

@@ -339,7 +339,7 @@ int32_t h2r_pipeline_modpow_public_key_var(h2r_pipeline *p, const void *x, const
                                            void *in_field_trace, void *out, uint8_t *status, void *workspace, h2r_stream_t stream);
 int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream);
 /* Which form a pipelined modpow_public_key call of `batch` elements on `stream` takes.  The two-queue form (RSA-2048, calls of up to
- * 2,048, depth >= 3, two side streams) needs the caller's stream and the two side streams on three different HARDWARE queues; the
+ * 2,048; RSA-1024, calls of 1,536 and more; depth >= 3, two side streams) needs the caller's stream and the two side streams on three different HARDWARE queues; the
  * library cannot read HIP's stream -> queue assignment, so the pipeline MEASURES it the first time it meets a caller stream (three
  * 150 us one-wave spinners, one per stream, after synchronising the three streams: ~0.5 ms once per (pipeline, stream); never inside a
  * stream capture, which takes the step) and falls back to the one-launch step when two of them share a queue -- no environment
@@ -434,7 +434,8 @@ void h2r_arena_destroy(h2r_arena *a);
  * sub-batches that get their own chain and record kernel (one entry = the call is one launch pair), and whether the
  * chain kernels are paced by the record kernels.  pipeline_busy: a record kernel of the previous call is still in
  * flight (the library asks the runtime; here the caller says).  Host-only, works on a context without a device.
- * sizes_out (nullable): up to `cap` entries; *n_out: the number of sub-batches. */
+ * sizes_out (nullable): up to `cap` entries; *n_out: the number of sub-batches.  (Not covered by this host-only query: an RSA-1024 call
+ * above 4,096 that takes the two-queue form -- h2r_pipeline_info says whether it does -- is walked as uniform sub-batches of 2,048, unpaced.) */
 int32_t h2r_pipeline_call_plan(const h2r_ctx *ctx, uint64_t batch, uint32_t pipeline_busy, uint64_t *sizes_out,
                                uint32_t cap, uint32_t *n_out, uint32_t *paced_out);
 

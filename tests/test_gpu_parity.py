@@ -1228,6 +1228,84 @@ def test_pipeline_full_size_rotation(H, depth, side_streams):
     pipe.close()
 
 
+@pytest.mark.parametrize("B", [1536, 4096, 6400])
+def test_pipeline_two_queue_rsa1024(H, B):
+    """[r6] RSA-1024 (the reference's enabled bench size, benches/bench.rs:393-407) calls of 1,536 signatures and more (above 4,096: walked as
+    sub-batches of 2,048 -- 6,400 ends with a ragged one) on a pipeline with two side
+    streams and three buffer sets take the two-queue form when the streams sit on three hardware queues (one-wave chain kernels on the caller's
+    stream, record kernels alternating between the side streams), else the one-launch step.  Either way five rotating calls leave, byte for byte,
+    what the plain export writes: every record of every call (audited in place before its set is reused), results, statuses."""
+    from halo2_rsa_amd import _lib
+    chip = H.BigIntChip(64, 1024)
+    depth = 3
+    pipe = H.Pipeline(chip, depth=depth, side_streams=2)
+    info = pipe.info(B)
+    assert info.three_queues in (0, 1) and (info.record_form == _lib.H2R_PIPE_TWO_QUEUE) == (info.three_queues == 1)
+    assert pipe.info(1024).three_queues == 2 and pipe.info(1024).record_form == _lib.H2R_PIPE_ONE_LAUNCH_STEP     # at 1,024 per call the step stays
+    pl = chip.pow_fixed_layout(65537)
+    rng = random.Random(1024 + B)
+    CALLS = 5
+    mk = lambda nbytes: torch.zeros(nbytes, dtype=torch.uint8, device="cuda")   # (zeros: the records' padding is never written)
+    sets = [dict(trace=mk(B * pl.elem_stride), ws=mk(chip.workspace_bytes(B, pl.num_mul_mods)),
+                 out=torch.empty((B, 16), dtype=torch.int64, device="cuda"), status=torch.zeros(B, dtype=torch.uint8, device="cuda")) for _ in range(depth)]
+    base_n = [rand_modulus(rng, 1024) for _ in range(256)]
+    inputs, outs, audits, digests = [], {}, {}, {}
+    for k in range(CALLS):
+        N = [base_n[(i * 7 + k) % 256] for i in range(B)]
+        X = [((n >> (k + 1)) ^ (0x9e3779b97f4a7c15 * (i + 1) * (k + 1))) % n for i, n in enumerate(N)]
+        if k == 3:
+            X[11] = N[11] + 1                                  # not in field: a status, no records for that element
+        inputs.append((N, X, chip.assign_integer(N), chip.assign_integer(X)))
+
+    def leave(k):   # call k's set right before it is reused: every record audited in place, results and a digest of the trace kept
+        s = sets[k % depth]
+        res = H.BatchResult(None, H.Trace(chip, s["trace"], B, pl), s["status"], None, s["ws"],
+                            ("pow_fixed", inputs[k][3], None, inputs[k][2], (65537).to_bytes(3, "little")))
+        audits[k] = res.audit()[0]
+        outs[k] = (s["out"].clone(), s["status"].clone())
+        digests[k] = s["trace"].view(torch.int64).sum()        # (stream-ordered; compared with the plain export's below)
+    _lib.profile_enable(64)
+    for k in range(CALLS):
+        if k >= depth:
+            leave(k - depth)
+        s = sets[k % depth]
+        pipe.modpow_public_key(inputs[k][3], 65537, inputs[k][2], s["trace"], s["ws"], s["out"], s["status"])
+    pipe.join()
+    torch.cuda.synchronize()
+    n_step, n_rec = len(_lib.profile_read(_lib.KERNEL_STEP)), len(_lib.profile_read(_lib.KERNEL_TRACE))
+    _lib.profile_enable(0)
+    if info.three_queues == 1:
+        assert n_step == 0 and n_rec >= CALLS, (n_step, n_rec)  # record kernels of their own, no step launch
+    else:
+        assert n_step >= CALLS - 1, (n_step, n_rec)
+    for k in range(CALLS - depth, CALLS):
+        leave(k)
+    ref_trace = mk(B * pl.elem_stride)
+    for k in range(CALLS):
+        N, X = inputs[k][0], inputs[k][1]
+        out, status = outs[k]
+        st = status.cpu().tolist()
+        assert all(v == (H.H2R_E_NOT_IN_FIELD if (k == 3 and i == 11) else 0) for i, v in enumerate(st)), k
+        bad = audits[k].cpu().numpy()
+        assert not np.delete(bad, 11 if k == 3 else []).any(), k
+        got = H.AssignedInteger(out, 64).to_big_uint()
+        assert all(got[i] == pow(X[i], 65537, N[i]) for i in range(B) if not (k == 3 and i == 11)), k
+        ref_trace.zero_()
+        ref = chip.pow_mod_fixed_exp(inputs[k][3], 65537, inputs[k][2], trace_buf=ref_trace, check_in_field=True)
+        assert torch.equal(ref.status, status), k
+        if k >= CALLS - depth:                                 # the sets still hold these calls: byte for byte
+            tr = sets[k % depth]["trace"]
+            if k == 3:                                         # (the failed element's trace is unspecified)
+                a, b = tr.view(B, -1), ref_trace.view(B, -1)
+                keep = torch.ones(B, dtype=torch.bool, device="cuda"); keep[11] = False
+                assert torch.equal(a[keep], b[keep]), k
+            else:
+                assert torch.equal(tr, ref_trace), k
+        elif k != 3:
+            assert int(digests[k].item()) == int(ref_trace.view(torch.int64).sum().item()), k
+    pipe.close()
+
+
 @pytest.mark.parametrize("B", [640, 96])
 def test_pipeline_inputs_may_be_refilled_between_calls(H, B):
     """include/h2r.h: the inputs of a pipelined call are read in stream order INSIDE the call.  A producer with ONE x and ONE n
