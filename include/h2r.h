@@ -308,10 +308,12 @@ int32_t h2r_modpow_public_key_var_batch(const h2r_ctx *ctx, const void *x, const
  *    walked as equal parts of at most 4,096, one launch each) whose
  *    workgroups run this call's chains and write this call's in-field witness and the PREVIOUS call's records; the
  *    last call's records go out alone at the join.  Everything is on the caller's stream, no side stream is involved.
- *    EXCEPT RSA-2048 (32 x 64-bit limbs) calls of up to 2,048 elements on a pipeline created with side_streams = 2 and depth >= 3: those take the two-queue
+ *    EXCEPT RSA-2048 (32 x 64-bit limbs) calls of up to 2,048 elements and RSA-1024 (16 x 64-bit limbs) calls of 1,536 and more on a pipeline
+ *    created with side_streams = 2 and depth >= 3: those take the two-queue
  *    form below with the record kernels alternating between the two side streams, so that call k + 1's record kernel starts while
- *    call k's tail workgroups drain -- 5.40-5.47 M assigns/s against 5.2-5.3 M as one-launch steps at 1,024 per call (the other
- *    step shapes are chain-bound enough to lose that way and keep the step whatever the pipeline's streams).  The overlap needs the
+ *    call k's tail workgroups drain -- RSA-2048 5.40-5.47 M assigns/s against 5.2-5.3 M as one-launch steps at 1,024 per call, RSA-1024
+ *    15.8-16.7 M against 14.5-15.9 M at 1,536-2,048 per call (the other step shapes are chain-bound enough to lose that way and keep
+ *    the step whatever the pipeline's streams).  The overlap needs the
  *    caller's stream and the two side streams on three different HARDWARE queues: HIP hands a process's streams GPU_MAX_HW_QUEUES
  *    queues (default 4) in creation order, so a host that also runs RCCL or many streams of its own should export
  *    GPU_MAX_HW_QUEUES=8 before the runtime initialises (4.8 M against 5.6 M assigns/s per GPU under torchrun without it:
