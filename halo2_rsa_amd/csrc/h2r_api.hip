@@ -286,6 +286,9 @@ int32_t run_path(const h2r_ctx *c, u32 mode, const void *a, const void *b, const
     // 128-digit chains (RSA-4096 at 64-bit limbs) are the longer leg next to their record kernel: their waves get issue
     // priority there (1.00 -> 1.05 M assigns/s; no effect measured for the shorter chains)
     if (trace_st && c->K > 96 && lo.limb_width == 64) ca.prio = 1;   // (the 32-bit-limb 4096-bit shape is record-bound)
+    // [r6] ... and so are RSA-1024's one-wave chains in the two-queue form's smallest calls (1,280 .. 1,535 per call: 14.4-14.5 -> 14.7-14.8 M assigns/s;
+    // neutral from 1,536: profiles/r06_two_queue_rsa1024.txt, 6.)
+    if (trace_st && c->L == 16 && c->K == 32 && lo.limb_width == 64 && batch >= 1280 && batch < 1536) ca.prio = 1;
     if (knobs().chain_prio >= 0) ca.prio = (u32)knobs().chain_prio;
     // one key, many elements: the Barrett constants of the shared modulus are computed once (recip_kernel) instead of by
     // every element's workgroup (big_integer/chip.rs:562-567 divides by the same n every time)
@@ -1301,15 +1304,15 @@ bool step_eligible(const h2r_ctx *c, u64 batch, const void *trace, u32 T) {
     return knobs().pipe_step != 0 && knobs().chain_nw == 0 && step_shape(c) && batch > 512 && trace && T;
 }
 // The shapes and call sizes with a two-queue form (chain kernels on the caller's stream, record kernels alternating between two side streams):
-// RSA-2048 up to 2,048 per call (profiles/r04_two_queue.txt), and [r6] RSA-1024 from 1,536 per call now that its chain is the one-wave kernel
+// RSA-2048 up to 2,048 per call (profiles/r04_two_queue.txt), and [r6] RSA-1024 from 1,280 per call now that its chain is the one-wave kernel
 // (profiles/r06_two_queue_rsa1024.txt: 16.2-16.7 M assigns/s against the step's 14.5-15.9 M at 1,536-2,048 per call, 15.1-15.9 against 13.7-14.5 M at
-// 8,192; at 1,024 per call the step stays ahead).
+// 8,192, 13.9-14.2 -> 14.7-14.8 M at 1,280 with chain priority; at 1,024 per call the step stays ahead or level in every variant).
 bool two_queue_shape(const h2r_ctx *c, u64 batch) {
     if (c->layout.limb_width != 64) return false;
     if (c->L == 32) return batch <= 2048;
     if (c->L == 16 && c->K == 32 && knobs().chain_wave != 0 && knobs().chain_nw == 0) {
         if (knobs().pipe_twoq_l16 > 0) return (long)batch <= knobs().pipe_twoq_l16;     // (developer build: the upper bound swept)
-        return knobs().pipe_twoq_l16 == 0 && batch >= 1536;                             // (H2R_PIPE_TWOQ_L16=-1: never)
+        return knobs().pipe_twoq_l16 == 0 && batch >= 1280;                             // (H2R_PIPE_TWOQ_L16=-1: never)
     }
     return false;
 }
@@ -1693,7 +1696,7 @@ int32_t pipeline_issue(h2r_pipeline *p, const void *x, const void *n, const uint
     // beats the one-launch step (same box, alternating: 5.41 / 5.41 M assigns/s against 5.18 / 5.32 M at 1,024 per call, 5.55-5.58 against
     // 5.50-5.51 M at 2,048).  The other step shapes were chain-bound enough to lose that way in round 4 (RSA-1024 with its four-wave chain 9.4
     // against 12.4 M, RSA-3072 2.1 against 2.5 M, RSA-4096 1.2 against 1.5 M; 128 x 32-bit limbs: the same): tools/two_queue_ab.sh,
-    // profiles/r04_two_queue.txt.  [r6] RSA-1024 with the one-wave chain wins from 1,536 to 4,096 per call (two_queue_shape).
+    // profiles/r04_two_queue.txt.  [r6] RSA-1024 with the one-wave chain wins from 1,280 per call (two_queue_shape).
     // (calls of up to 2,048: at 4,096 per call one launch has little boundary left to hide and the step is ahead again, 5.37-5.42 against 5.27-5.33 M)
     // ... provided the three streams sit on three hardware queues, which the pipeline measures once per caller stream (pipeline_three_queues);
     // with a shared queue the call falls back to the one-launch step

@@ -308,7 +308,7 @@ int32_t h2r_modpow_public_key_var_batch(const h2r_ctx *ctx, const void *x, const
  *    walked as equal parts of at most 4,096, one launch each) whose
  *    workgroups run this call's chains and write this call's in-field witness and the PREVIOUS call's records; the
  *    last call's records go out alone at the join.  Everything is on the caller's stream, no side stream is involved.
- *    EXCEPT RSA-2048 (32 x 64-bit limbs) calls of up to 2,048 elements and RSA-1024 (16 x 64-bit limbs) calls of 1,536 and more on a pipeline
+ *    EXCEPT RSA-2048 (32 x 64-bit limbs) calls of up to 2,048 elements and RSA-1024 (16 x 64-bit limbs) calls of 1,280 and more on a pipeline
  *    created with side_streams = 2 and depth >= 3: those take the two-queue
  *    form below with the record kernels alternating between the two side streams, so that call k + 1's record kernel starts while
  *    call k's tail workgroups drain -- RSA-2048 5.40-5.47 M assigns/s against 5.2-5.3 M as one-launch steps at 1,024 per call, RSA-1024
@@ -341,7 +341,7 @@ int32_t h2r_pipeline_modpow_public_key_var(h2r_pipeline *p, const void *x, const
                                            void *in_field_trace, void *out, uint8_t *status, void *workspace, h2r_stream_t stream);
 int32_t h2r_pipeline_join(h2r_pipeline *p, h2r_stream_t stream);
 /* Which form a pipelined modpow_public_key call of `batch` elements on `stream` takes.  The two-queue form (RSA-2048, calls of up to
- * 2,048; RSA-1024, calls of 1,536 and more; depth >= 3, two side streams) needs the caller's stream and the two side streams on three different HARDWARE queues; the
+ * 2,048; RSA-1024, calls of 1,280 and more; depth >= 3, two side streams) needs the caller's stream and the two side streams on three different HARDWARE queues; the
  * library cannot read HIP's stream -> queue assignment, so the pipeline MEASURES it the first time it meets a caller stream (three
  * 150 us one-wave spinners, one per stream, after synchronising the three streams: ~0.5 ms once per (pipeline, stream); never inside a
  * stream capture, which takes the step) and falls back to the one-launch step when two of them share a queue -- no environment

@@ -1228,9 +1228,9 @@ def test_pipeline_full_size_rotation(H, depth, side_streams):
     pipe.close()
 
 
-@pytest.mark.parametrize("B", [1536, 4096, 6400])
+@pytest.mark.parametrize("B", [1280, 4096, 6400])
 def test_pipeline_two_queue_rsa1024(H, B):
-    """[r6] RSA-1024 (the reference's enabled bench size, benches/bench.rs:393-407) calls of 1,536 signatures and more (above 4,096: walked as
+    """[r6] RSA-1024 (the reference's enabled bench size, benches/bench.rs:393-407) calls of 1,280 signatures and more (above 4,096: walked as
     sub-batches of 2,048 -- 6,400 ends with a ragged one) on a pipeline with two side
     streams and three buffer sets take the two-queue form when the streams sit on three hardware queues (one-wave chain kernels on the caller's
     stream, record kernels alternating between the side streams), else the one-launch step.  Either way five rotating calls leave, byte for byte,
