@@ -299,10 +299,12 @@ __global__ __launch_bounds__(256) void lookup_fill_kernel(LookupFillArgs a) {
     const u32 usable = a.usable_rows, n_rep = usable - n_heads;   // repeated rows = leftover table entries
     u8 *ap = a.a_perm + elem * a.out_elem_stride + (u64)arg * usable * 32;
     u8 *sp = a.s_perm + elem * a.out_elem_stride + (u64)arg * usable * 32;
-    // [r6] The workgroups of one column take its 256-row blocks ROUND-ROBIN (block b of the column goes to workgroup b mod gridDim.x), not one
-    // contiguous run of rows_per_block rows each: what the column's workgroups have in flight together is then ONE dense window of
-    // gridDim.x x 8 KB instead of a comb of 8 KB pieces 256 KB apart -- the comb is what the placement classes punish (a power-of-two stride
-    // between concurrent store streams: tools/store_pattern_probe.hip, profiles/r06_placement_counters.txt section 6).
+    // [r6] A workgroup takes ONE contiguous run of rows_per_block rows of the column (256 shipped: 8 KB of A' and of S', one 64-row pass per wave).
+    // With round 5's 8,192 rows per workgroup the resident workgroups wrote a comb of 8 KB pieces 256 KB apart, which is what the placement
+    // classes punish; with 256 they write one dense window and the same buffers give 2.02-2.16 -> 1.76-1.90 ms (one class) / 1.63 -> 1.56-1.59 ms
+    // (two classes) per 10.7 GB call (tools/store_pattern_probe.hip, tools/lookup_geometry_probe.py, profiles/r06_lookup_geometry.txt).  The slot
+    // every workgroup stages comes from the L2.  round_robin (developer sweeps only): the column's workgroups take its 256-row blocks in turn
+    // instead -- measured equal or worse at every size, off in the product.
     const bool rr = a.round_robin != 0;
     const u32 p0 = rr ? chunk * 256 : chunk * a.rows_per_block;
     const u32 p1 = rr ? usable : (p0 + a.rows_per_block < usable ? p0 + a.rows_per_block : usable);
