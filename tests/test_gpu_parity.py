@@ -1996,34 +1996,37 @@ def test_general_operand_shapes_mul_refresh_is_equal_muled(H, w, L, shapes):
         chip.refresh_ex(_u256_tensor(big, 3), L + 1, 1)          # operands longer than the chip's num_limbs
 
 
-@pytest.mark.parametrize("B,NL,EB", [(48, 5, 13), (640, 1, 5), (6, 10, 60)])   # (600-bit exponents: walked as two segments of bits)
-def test_pipelined_variable_exponent_calls(H, B, NL, EB):
+@pytest.mark.parametrize("B,NL,EB,bits,form", [(48, 5, 13, 2048, (2, 1)), (640, 1, 5, 2048, (2, 1)), (6, 10, 60, 2048, (2, 1)),   # (600-bit exponents: walked as two segments of bits)
+                                               (1408, 1, 5, 1024, (3, 2)),    # [r6] RSA-1024, two-queue form: one-wave chains walking per-element exponents
+                                               (1024, 1, 5, 2048, (3, 2))])   # RSA-2048, two-queue form
+def test_pipelined_variable_exponent_calls(H, B, NL, EB, bits, form):
     """h2r_pipeline_modpow_public_key_var (RSAPubE::Var, src/chip.rs:108-110): three pipelined calls with per-element 5-limb x 13-bit
-    exponents over two buffer sets leave byte for byte what the stream-ordered export writes (trace incl. e bits and selected
+    exponents over the pipeline's buffer sets leave byte for byte what the stream-ordered export writes (trace incl. e bits and selected
     limbs, in-field witness, results, status), and the results are pow(x, e, n)."""
     # (640 per call: issued as one-launch steps -- the chain role runs the variable-exponent walk inside step_kernel)
-    chip = H.BigIntChip(64, 2048)
+    chip = H.BigIntChip(64, bits)
     rng = random.Random(808 + B)
     pl = chip.pow_var_layout(NL, EB)
     ies = chip.in_field_layout()[0]
     mk = lambda nbytes: torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
     sets = [dict(trace=mk(B * pl.elem_stride), inf=mk(B * ies), ws=mk(chip.workspace_bytes(B, pl.num_mul_mods)),
-                 out=torch.zeros((B, 32), dtype=torch.int64, device="cuda"), status=mk(B)) for _ in range(2)]
-    pipe = chip.pipeline()
+                 out=torch.zeros((B, bits // 64), dtype=torch.int64, device="cuda"), status=mk(B)) for _ in range(form[0])]
+    pipe = H.Pipeline(chip, depth=form[0], side_streams=form[1])   # (as many buffer sets as the pipeline is deep)
     calls, snaps = [], []
     for k in range(3):
-        N = [rand_modulus(rng, 2048) for _ in range(B)]
+        N = [rand_modulus(rng, bits) for _ in range(min(B, 64))]
+        N = [N[i % len(N)] for i in range(B)]
         X = [rng.randrange(n) for n in N]
         E = [[rng.getrandbits(EB) for _ in range(NL)] for _ in range(B)]
         e_dev = H.AssignedInteger(torch.tensor(E, dtype=torch.int64, device="cuda"), 64)
         calls.append((N, X, E, chip.assign_integer(N), chip.assign_integer(X), e_dev))
-        s = sets[k % 2]
-        if k >= 2:
+        s = sets[k % form[0]]
+        if k >= form[0]:
             snaps.append((s["trace"].clone(), s["inf"].clone(), s["out"].clone(), s["status"].clone()))
         pipe.modpow_public_key_var(calls[k][4], e_dev, EB, calls[k][3], s["trace"], s["ws"], s["out"], s["status"], in_field_buf=s["inf"])
     pipe.join()
-    for k in (1, 2):
-        s = sets[k % 2]
+    for k in range(max(0, 3 - form[0]), 3):
+        s = sets[k % form[0]]
         snaps.append((s["trace"].clone(), s["inf"].clone(), s["out"].clone(), s["status"].clone()))
     torch.cuda.synchronize()
     for k in range(3):
