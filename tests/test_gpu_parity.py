@@ -842,6 +842,80 @@ def test_pipelined_verify_matches_batch_call(H, golden):
     pipe.close()
 
 
+def _probable_prime(rng, bits):
+    small = [3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 47, 53, 59, 61, 67, 71, 73, 79, 83, 89, 97]
+    while True:
+        c = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+        if all(c % q for q in small) and all(pow(b, c - 1, c) == 1 for b in (2, 3, 5, 7)) and (c - 1) % 65537:
+            return c
+
+
+def test_pipelined_verify_rsa1024_two_queue(H):
+    """[r6] The reference's bench shape (benches/bench.rs:369-407: RSA-1024 verification) through h2r_pipeline_verify_pkcs1v15 at 1,280 signatures per
+    call on a pipeline with two side streams and three buffer sets -- the two-queue form with one-wave chains when the streams sit on three hardware
+    queues.  Four rotating calls equal h2r_verify_pkcs1v15_batch element for element (verdicts, statuses, results, flat streams of sampled elements);
+    elements 0 and 1 carry VALID signatures (a prime modulus p stands in for n: sig = EM^(e^-1 mod p-1) mod p), element 2 the same with a wrong hash."""
+    rsa = H.RSAChip(1024, 5)
+    chip = rsa.bigint_chip()
+    rng = random.Random(1024)
+    B, CALLS, depth = 1280, 4, 3
+    pipe = H.Pipeline(chip, depth=depth, side_streams=2)
+    prime = _probable_prime(rng, 1024)
+    d = pow(65537, -1, prime - 1)
+    head = int.from_bytes(b"\x00\x01" + b"\xff" * (128 - 3 - 51) + b"\x00" + bytes.fromhex("3031300d060960864801650304020105000420"), "big")
+    base_n = [rand_modulus(rng, 1024) for _ in range(64)]
+    calls = []
+    for k in range(CALLS):
+        ns = [prime, prime, prime] + [base_n[(i + k) % 64] for i in range(B - 3)]
+        hashed = [rng.getrandbits(256) for _ in range(B)]
+        sigs = [pow((head << 256) | hashed[i], d, prime) for i in range(3)] + [rng.randrange(n) for n in ns[3:]]
+        hashed[2] ^= 1 << 77                                  # a signature over another digest
+        if k == 2:
+            sigs[9] = ns[9] + 3                               # not in field
+        pk = rsa.assign_public_key(H.RSAPublicKey(H.UnassignedInteger.from_ints(ns, 16, 64), H.Fix(65537)))
+        sg = rsa.assign_signature(H.RSASignature(H.UnassignedInteger.from_ints(sigs, 16, 64)))
+        ref = rsa.verify_pkcs1v15_signature(pk, hashed, sg)
+        hd = torch.from_numpy(H.UnassignedInteger.from_ints(hashed, 4, 64).limbs.view(np.int64)).cuda()
+        calls.append(dict(ref=ref, n=chip.assign_integer(pk.n), s=chip.assign_integer(sg.c), h=hd, ns=ns, sigs=sigs, hashed=hashed))
+    vl = calls[0]["ref"].layout
+    sets = [dict(trace=torch.zeros(B * vl.elem_stride, dtype=torch.uint8, device="cuda"),
+                 ws=torch.empty(chip.workspace_bytes(B, vl.pow.num_mul_mods), dtype=torch.uint8, device="cuda"),
+                 powed=torch.zeros((B, 16), dtype=torch.int64, device="cuda"), valid=torch.zeros(B, dtype=torch.uint8, device="cuda"),
+                 status=torch.zeros(B, dtype=torch.uint8, device="cuda")) for _ in range(depth)]
+    snaps = {}
+    for k, c in enumerate(calls):
+        s = sets[k % depth]
+        if k >= depth:
+            snaps[k - depth] = tuple(t.clone() for t in (s["trace"], s["powed"], s["valid"], s["status"]))
+        pipe.verify_pkcs1v15(c["s"], 65537, c["n"], c["h"], s["trace"], s["ws"], s["powed"], s["valid"], s["status"])
+    pipe.join()
+    for k in range(CALLS - depth, CALLS):
+        s = sets[k % depth]
+        snaps[k] = tuple(t.clone() for t in (s["trace"], s["powed"], s["valid"], s["status"]))
+    torch.cuda.synchronize()
+    for k, c in enumerate(calls):
+        trace, powed, valid, status = snaps[k]
+        ref = c["ref"]
+        assert torch.equal(valid, ref.is_valid) and torch.equal(status, ref.status), k
+        assert valid.cpu().tolist()[:3] == [1, 1, 0], k
+        st = status.cpu().tolist()
+        assert all(v == (H.H2R_E_NOT_IN_FIELD if (k == 2 and i == 9) else 0) for i, v in enumerate(st)), k
+        ok_rows = (status == 0).nonzero().flatten()
+        assert torch.equal(powed[ok_rows], ref.powed.limbs_dev[ok_rows]), k
+        got = H.rsa.VerifyResult(valid, H.AssignedInteger(powed, 64), status, trace, vl, chip)
+        for i in (0, 1, 2, 8, 640, B - 1):
+            assert np.array_equal(got.flatten(i), ref.flatten(i)), (k, i)
+        if k == 3:   # ... and the ORACLE's streams (assert_in_field + pow_mod_fixed_exp + the encoded-message check), a valid, a wrong-hash and a random element
+            o = Oracle(64, 16)
+            for i in (0, 2, 8):
+                rc_if, lt, s_if = o.assert_in_field(o.limbs(c["sigs"][i]), o.limbs(c["ns"][i]))
+                rc, out, s_pow = o.pow_mod_fixed_exp(o.limbs(c["sigs"][i]), o.limbs(c["ns"][i]), 65537)
+                rc, ok, s_em = o.pkcs1v15_em_check(out, o.limbs(c["hashed"][i], 4))
+                assert ok == (1 if i == 0 else 0)
+                assert np.array_equal(got.flatten(i), np.concatenate([s_if, s_pow, s_em])), i
+    pipe.close()
+
+
 def test_pipelined_verify_folded_into_the_step_launch(H, golden):
     """h2r_pipeline_verify_pkcs1v15 at 1,024 signatures per call (one-launch steps): from the second call on the chain role of the
     step launch writes the verifier's in-field + encoded-message witness itself (step_kernel<..., FOLD>), the first call of the
