@@ -11,7 +11,9 @@ rng = random.Random(99)
 E_DENSE = rng.getrandbits(640) | (1 << 639)
 E_SPARSE = (1 << 639) | (1 << 401) | (1 << 77) | 1
 for bits, B, depth, side, E in ((2048, 1024, 2, 1, 65537), (2048, 3072, 2, 1, 65537), (2048, 1024, 3, 2, 65537), (2048, 2048, 3, 2, 65537), (2048, 640, 4, 2, 65537), (2048, 8192, 2, 1, 65537), (2048, 384, 2, 1, 65537),
-                                (1024, 2048, 2, 1, 65537), (2048, 24, 2, 1, E_DENSE), (2048, 40, 3, 2, E_SPARSE)):
+                                (1024, 2048, 2, 1, 65537), (2048, 24, 2, 1, E_DENSE), (2048, 40, 3, 2, E_SPARSE),
+                                # [r6] RSA-1024 in the two-queue form (one-wave chain kernels; 1,280: chain waves at issue priority; 8,192: sub-batches of 2,048)
+                                (1024, 1280, 3, 2, 65537), (1024, 2048, 3, 2, 65537), (1024, 4096, 4, 2, 65537), (1024, 8192, 3, 2, 65537)):
     chip = H.BigIntChip(64, bits)
     pl = chip.pow_fixed_layout(E)
     base = [rng.getrandbits(bits) | (1 << (bits - 1)) | 1 for _ in range(64)]
